@@ -1,0 +1,19 @@
+"""boxinstseg_amd -- the BoxInst box-supervised mask-loss path of LiWentomng/BoxInstSeg, rebuilt
+MI355X-native (gfx950 HIP kernels behind a C ABI; see include/boxinst_hip.h and DESIGN.md).
+
+Public surface (mirrors the reference's for this path):
+    pairwise_nlog                      <-> mmdet.ops.pairwise.pairwise_nlog
+    pairwise_nlog_forward / _backward  <-> mmdet.ops.pairwise.pairwise_ext
+    CondInstMaskHead                   <-> mmdet.models.dense_heads.CondInstMaskHead (loss path)
+    boxinst_mask_loss, color_affinity, box_bitmasks : functional form of the same kernels
+"""
+from .pairwise import PairwiseNLog, pairwise_nlog, pairwise_nlog_backward, pairwise_nlog_forward
+from .functional import BoxInstMaskLoss, box_bitmasks, boxinst_mask_loss, color_affinity
+from .mask_head import CondInstMaskHead
+from .registry import HEADS, build_head
+from .config import load_config
+
+__all__ = ['pairwise_nlog', 'pairwise_nlog_forward', 'pairwise_nlog_backward', 'PairwiseNLog',
+           'boxinst_mask_loss', 'BoxInstMaskLoss', 'color_affinity', 'box_bitmasks',
+           'CondInstMaskHead', 'HEADS', 'build_head', 'load_config']
+__version__ = '0.1.0'

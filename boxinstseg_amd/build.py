@@ -1,0 +1,50 @@
+"""Build libboxinst_hip.so in-tree with plain hipcc for gfx950 (no torch cpp_extension, no hipify)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from typing import List
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB_DIR = os.path.join(HERE, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libboxinst_hip.so')
+SOURCES = ['abi.hip', 'pairwise_op.hip', 'color_affinity.hip', 'mask_loss.hip']
+HEADERS = ['common.hpp', 'srgb_lut.h', os.path.join('..', '..', 'include', 'boxinst_hip.h')]
+ARCH = 'gfx950'
+
+
+def hipcc() -> str:
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found: libboxinst_hip.so can only be built with the ROCm toolchain')
+    return exe
+
+
+def command(extra: List[str] | None = None) -> List[str]:
+    return [hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wall',
+            '-Wno-unused-function', *(extra or []), '-o', LIB_PATH, *[os.path.join(CSRC, s) for s in SOURCES]]
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source into boxinstseg_amd/lib/libboxinst_hip.so; returns its path."""
+    if force or is_stale():
+        os.makedirs(LIB_DIR, exist_ok=True)
+        cmd = command()
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build(force=True, verbose=True))

@@ -1,0 +1,87 @@
+// abi.hip -- library-level entry points of libboxinst_hip.so (see include/boxinst_hip.h).
+#include "common.hpp"
+
+namespace bxi {
+
+static thread_local int g_last_hip_error = 0;
+void set_last_hip_error(int e) { g_last_hip_error = e; }
+
+int launch_color_affinity(const bxi_image_batch* bt, int stride, int size, int dil, float thresh, uint8_t* rgb_small,
+                          float* sim, void* affinity, void* stream);
+int launch_loss(const bxi_instances* in, const uint8_t* affinity, int size, int dil, float warmup, float* losses,
+                float* g_logits, void* state, void* workspace, size_t workspace_bytes, void* stream);
+size_t loss_ws_bytes(int N, int h, int w);
+
+static inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace bxi
+
+extern "C" {
+
+int bxi_abi_version(void) { return BXI_ABI_VERSION; }
+
+const char* bxi_status_string(int status) {
+    switch (status) {
+        case BXI_OK: return "ok";
+        case BXI_ERR_NULL_POINTER: return "a required pointer is NULL";
+        case BXI_ERR_BAD_SHAPE: return "bad shape (negative, inconsistent or too large dimension)";
+        case BXI_ERR_BAD_ARGUMENT: return "bad argument (pairwise_size must be odd, dilation/stride >= 1)";
+        case BXI_ERR_UNSUPPORTED: return "configuration outside the fused fast path of this build";
+        case BXI_ERR_WORKSPACE: return "workspace missing, too small or not 256-byte aligned";
+        case BXI_ERR_LAUNCH: return "HIP kernel launch failed (see bxi_last_hip_error)";
+        case BXI_ERR_NO_DEVICE: return "no gfx950 HIP device";
+        default: return "unknown status";
+    }
+}
+
+int bxi_last_hip_error(void) { return bxi::g_last_hip_error; }
+
+int bxi_check_device(int ordinal) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || ordinal < 0 || ordinal >= count) {
+        (void)hipGetLastError();
+        return BXI_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ordinal) != hipSuccess) return BXI_ERR_NO_DEVICE;
+    const char* arch = prop.gcnArchName;
+    // "gfx950:sramecc+:xnack-"
+    if (arch[0] == 'g' && arch[1] == 'f' && arch[2] == 'x' && arch[3] == '9' && arch[4] == '5' && arch[5] == '0')
+        return BXI_OK;
+    return BXI_ERR_NO_DEVICE;
+}
+
+size_t bxi_boxinst_eval_workspace_bytes(int B, int Hc, int Wc, int stride, int N) {
+    if (B < 0 || Hc <= 0 || Wc <= 0 || stride < 1 || N < 0) return 0;
+    const int h = Hc / stride, w = Wc / stride;
+    if (h <= 0 || w <= 0) return 0;
+    const size_t P = (size_t)h * w;
+    return bxi::up256((size_t)B * 3 * P) + bxi::up256((size_t)B * P) + bxi::loss_ws_bytes(N, h, w);
+}
+
+int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host, int size, int dilation,
+                         float color_thresh, float warmup, float* losses, float* g_logits, void* state,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    if (!batch_host || !inst_host) return BXI_ERR_NULL_POINTER;
+    if (size != 3) return BXI_ERR_UNSUPPORTED;
+    const int stride = inst_host->stride;
+    if (stride < 1 || batch_host->Hc != inst_host->Hc || batch_host->Wc != inst_host->Wc ||
+        batch_host->B != inst_host->B)
+        return BXI_ERR_BAD_SHAPE;
+    const size_t need = bxi_boxinst_eval_workspace_bytes(batch_host->B, batch_host->Hc, batch_host->Wc, stride,
+                                                         inst_host->N);
+    if (!workspace || need == 0 || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255))
+        return BXI_ERR_WORKSPACE;
+    const size_t P = (size_t)inst_host->h * inst_host->w;
+    char* base = (char*)workspace;
+    uint8_t* rgb_small = (uint8_t*)base;
+    uint8_t* aff = (uint8_t*)(base + bxi::up256((size_t)batch_host->B * 3 * P));
+    char* lws = (char*)aff + bxi::up256((size_t)batch_host->B * P);
+    int rc = bxi::launch_color_affinity(batch_host, stride, size, dilation, color_thresh, rgb_small, nullptr, aff,
+                                        stream);
+    if (rc != BXI_OK) return rc;
+    return bxi::launch_loss(inst_host, aff, size, dilation, warmup, losses, g_logits, state, lws,
+                            workspace_bytes - (size_t)(lws - base), stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+// common.hpp -- shared host/device helpers for libboxinst_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/boxinst_hip.h"
+
+namespace bxi {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// ---- host side ------------------------------------------------------------------------------
+void set_last_hip_error(int e);
+
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_hip_error((int)e);
+        return BXI_ERR_LAUNCH;
+    }
+    return BXI_OK;
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline bool fits_i32(int64_t v) { return v >= 0 && v <= 0x7fffffffLL; }
+
+// ---- device side ----------------------------------------------------------------------------
+// log sigmoid, the reference's formula (pairwise.cu:27-37) in the overflow-free arrangement
+// min(x,0) - log(1 + exp(-|x|)).
+__device__ __forceinline__ float logsig(float x) { return fminf(x, 0.f) - logf(1.f + expf(-fabsf(x))); }
+__device__ __forceinline__ double logsig(double x) { return fmin(x, 0.0) - log(1.0 + exp(-fabs(x))); }
+
+template <typename T> __device__ __forceinline__ T t_exp(T x);
+template <> __device__ __forceinline__ float t_exp<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp(x); }
+template <typename T> __device__ __forceinline__ T t_log(T x);
+template <> __device__ __forceinline__ float t_log<float>(float x) { return logf(x); }
+template <> __device__ __forceinline__ double t_log<double>(double x) { return log(x); }
+template <typename T> __device__ __forceinline__ T t_abs(T x) { return x < T(0) ? -x : x; }
+
+// order-preserving map float -> uint32 (larger float <=> larger key); -inf maps above 0.
+__device__ __forceinline__ uint32_t float_key(float x) {
+    uint32_t u = __float_as_uint(x);
+    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k) {
+    uint32_t u = k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu);
+    return __uint_as_float(u);
+}
+// (value, index) -> one 64-bit key whose max is "largest value, then smallest index".
+__device__ __forceinline__ unsigned long long pack_max(float x, uint32_t idx) {
+    return ((unsigned long long)float_key(x) << 32) | (unsigned long long)(0xffffffffu - idx);
+}
+__device__ __forceinline__ float unpack_val(unsigned long long k) { return key_float((uint32_t)(k >> 32)); }
+__device__ __forceinline__ uint32_t unpack_idx(unsigned long long k) { return 0xffffffffu - (uint32_t)k; }
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(v, off, kWave);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// python slice [a:b] on an axis of length n -> [lo,hi)   (condinst_head.py:1429-1430)
+__device__ __forceinline__ void py_slice(int a, int b, int n, int& lo, int& hi) {
+    if (a < 0) a += n;
+    a = a < 0 ? 0 : (a > n ? n : a);
+    if (b < 0) b += n;
+    b = b < 0 ? 0 : (b > n ? n : b);
+    lo = a;
+    hi = b > a ? b : a;
+}
+
+// Box (x1,y1,x2,y2 in canvas pixels) -> half-open rectangle [r0,r1) x [c0,c1) on the sampled
+// grid y = start + r*stride: the cells whose sample lies inside the python slice.
+struct Rect { int r0, r1, c0, c1; };
+__device__ __forceinline__ void sampled_range(int lo, int hi, int start, int stride, int n, int& a, int& b) {
+    // smallest r with start + r*stride >= lo ; smallest r with start + r*stride >= hi
+    int ra = lo - start <= 0 ? 0 : (lo - start + stride - 1) / stride;
+    int rb = hi - start <= 0 ? 0 : (hi - start + stride - 1) / stride;
+    a = ra > n ? n : ra;
+    b = rb > n ? n : rb;
+    if (b < a) b = a;
+}
+__device__ __forceinline__ Rect box_rect(const float* box, int Hc, int Wc, int stride, int start, int h, int w) {
+    int y0, y1, x0, x1;
+    py_slice((int)box[1], (int)box[3] + 1, Hc, y0, y1);
+    py_slice((int)box[0], (int)box[2] + 1, Wc, x0, x1);
+    Rect rc;
+    sampled_range(y0, y1, start, stride, h, rc.r0, rc.r1);
+    sampled_range(x0, x1, start, stride, w, rc.c0, rc.c1);
+    if (rc.r1 <= rc.r0 || rc.c1 <= rc.c0) { rc.r0 = rc.r1 = rc.c0 = rc.c1 = 0; }
+    return rc;
+}
+
+// per-image metadata carried in kernel arguments (no device copy, no sync)
+struct GtTable {
+    const float* boxes[BXI_MAX_IMAGES];  // device pointers, [G_i,4]
+    int first[BXI_MAX_IMAGES + 1];       // first[b] = sum_{i<b} G_i
+    int B;
+};
+__device__ __forceinline__ const float* gt_box(const GtTable& t, int g, int& img) {
+    int b = 0;
+    while (b + 1 < t.B && g >= t.first[b + 1]) ++b;
+    img = b;
+    return t.boxes[b] + 4 * (g - t.first[b]);
+}
+
+}  // namespace bxi

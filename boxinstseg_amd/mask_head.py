@@ -1,0 +1,206 @@
+"""``CondInstMaskHead`` with the BoxInst loss path running on MI355X HIP kernels.
+
+Drop-in for the reference's ``CondInstMaskHead`` (``mmdet/models/dense_heads/condinst_head.py:1041-1448``)
+as far as the box-supervised loss path is concerned: same registry name, same constructor keywords
+(``configs/boxinst/*.py`` build it unchanged), same parameters/buffers in the state dict
+(``param_conv.{weight,bias}``, ``_iter``, ``sizes_of_interest``), same ``loss`` / ``get_targets`` /
+``get_bitmasks_from_boxes`` signatures and return values (keys ``loss_prj`` / ``loss_pairwise``).
+
+What is different on purpose:
+  * nothing on the path leaves the device: no ``tensor2imgs`` / ``rgb2lab`` round trip, no
+    per-image or per-box Python loop, no ``.item()`` for the warm-up factor (a host-side mirror of
+    ``_iter`` is kept, re-read from the buffer only after ``load_state_dict``);
+  * ``loss()`` produces the gradient w.r.t. ``mask_logits`` in the same pass (fused fwd+bwd);
+  * zero instances / an image without boxes give zero losses instead of NaN / an exception
+    (SURVEY 8a quirks 1 and 8);
+  * CPU tensors raise: there is no CPU implementation in this package (the CPU restatement lives
+    in ``oracle/`` and is test infrastructure only).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import functional as F_hip
+from .pairwise import pairwise_nlog
+from .registry import HEADS
+
+
+@HEADS.register_module()
+class CondInstMaskHead(nn.Module):
+
+    def __init__(self,
+                 in_channels: int = 8,
+                 in_stride: int = 8,
+                 out_stride: int = 4,
+                 dynamic_convs: int = 3,
+                 dynamic_channels: int = 8,
+                 disable_rel_coors: bool = False,
+                 bbox_head_channels: int = 256,
+                 sizes_of_interest: Sequence[int] = (64, 128, 256, 512, 1024),
+                 max_proposals: int = 500,
+                 topk_per_img: int = -1,
+                 boxinst_enabled: bool = False,
+                 bottom_pixels_removed: int = 10,
+                 pairwise_size: int = 3,
+                 pairwise_dilation: int = 2,
+                 pairwise_color_thresh: float = 0.3,
+                 pairwise_warmup: int = 10000,
+                 norm_cfg: Optional[dict] = None,
+                 init_cfg: Optional[dict] = None):
+        super().__init__()
+        if in_stride < out_stride or in_stride % out_stride:
+            raise AssertionError('in_stride must be a multiple of out_stride')
+        if dynamic_channels <= 1:
+            raise AssertionError('dynamic_channels must be > 1')
+        if not (max_proposals == -1 or topk_per_img == -1):
+            raise AssertionError('max_proposals and topk_per_img cannot be used at the same time')
+        self.in_channels = in_channels
+        self.in_stride = in_stride
+        self.out_stride = out_stride
+        self.dynamic_convs = dynamic_convs
+        self.dynamic_channels = dynamic_channels
+        self.disable_rel_coors = disable_rel_coors
+        self.bbox_head_channels = bbox_head_channels
+        self.max_proposals = max_proposals
+        self.topk_per_img = topk_per_img
+        self.boxinst_enabled = boxinst_enabled
+        self.bottom_pixels_removed = bottom_pixels_removed
+        self.pairwise_size = pairwise_size
+        self.pairwise_dilation = pairwise_dilation
+        self.pairwise_color_thresh = pairwise_color_thresh
+        self._warmup_iters = pairwise_warmup
+        self.norm_cfg = norm_cfg if norm_cfg is not None else dict(type='BN', requires_grad=True)
+        self.init_cfg = init_cfg if init_cfg is not None else dict(type='Normal', layer='Conv2d', std=0.01, bias=0)
+        self.fp16_enable = False   # sic: the reference sets this (mis-spelt) attribute, condinst_head.py:1108
+
+        # layout of the generated dynamic-conv parameters (condinst_head.py:1079-1089)
+        first_in = in_channels if disable_rel_coors else in_channels + 2
+        self.dy_weights: List[int] = []
+        self.dy_biases: List[int] = []
+        for i in range(dynamic_convs):
+            cin = first_in if i == 0 else dynamic_channels
+            cout = 1 if i == dynamic_convs - 1 else dynamic_channels
+            self.dy_weights.append(cin * cout)
+            self.dy_biases.append(cout)
+        self.num_gen_params = sum(self.dy_weights) + sum(self.dy_biases)
+
+        self.register_buffer('sizes_of_interest', torch.tensor(list(sizes_of_interest)))
+        self.register_buffer('_iter', torch.zeros([1]))
+        self._iter_host: Optional[float] = 0.0     # mirror of _iter; None = unknown (state dict loaded)
+        self.param_conv = nn.Conv2d(bbox_head_channels, self.num_gen_params, 3, stride=1, padding=1)
+        self.init_weights()
+
+    # ---- initialisation / checkpoint compatibility ------------------------------------------------
+    def init_weights(self) -> None:
+        """init_cfg=dict(type='Normal', layer='Conv2d', std=0.01, bias=0) (condinst_head.py:1064-1068)."""
+        cfg = self.init_cfg or {}
+        if cfg.get('type') == 'Normal':
+            nn.init.normal_(self.param_conv.weight, mean=cfg.get('mean', 0.0), std=cfg.get('std', 0.01))
+            if self.param_conv.bias is not None:
+                nn.init.constant_(self.param_conv.bias, cfg.get('bias', 0))
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._iter_host = None       # re-read from the buffer on the next loss() call (one sync)
+
+    def _tick(self) -> float:
+        """``self._iter += 1`` (condinst_head.py:1297) and the warm-up factor (:1330-1331), sync-free."""
+        if self._iter_host is None:
+            self._iter_host = float(self._iter.item())
+        self._iter += 1
+        self._iter_host += 1.0
+        return min(self._iter_host / float(self._warmup_iters), 1.0)
+
+    # ---- targets ----------------------------------------------------------------------------------
+    def get_targets(self, gt_bboxes, gt_masks, img, img_metas):
+        """condinst_head.py:1345-1393 -> (similarities, bitmasks, bitmasks_full).
+
+        BoxInst: ``similarities[i]`` is ``[G_i,K,h,w]`` (a zero-copy expand of the image's map; the
+        reference concatenates G_i copies), ``bitmasks[i]`` ``[G_i,h,w]``, ``bitmasks_full[i]``
+        ``[G_i,H,W]``.  Fully supervised: the strided ground-truth masks (:1384-1391)."""
+        if not self.boxinst_enabled:
+            start = int(self.out_stride // 2)
+            bitmasks = [m[:, start::self.out_stride, start::self.out_stride] for m in gt_masks]
+            return None, bitmasks, gt_masks
+        sim, _, _ = F_hip.color_affinity(
+            img, img_metas, out_stride=self.out_stride, bottom_pixels_removed=self.bottom_pixels_removed,
+            pairwise_size=self.pairwise_size, pairwise_dilation=self.pairwise_dilation,
+            pairwise_color_thresh=self.pairwise_color_thresh, want_similarity=True, want_bits=False)
+        return self._per_image_targets(gt_bboxes, sim, img.shape[2], img.shape[3])
+
+    def get_bitmasks_from_boxes(self, gt_bboxes, padded_images, padded_image_masks):
+        """condinst_head.py:1395-1448.  ``padded_images`` [B,3,H,W] RGB in 0..255 (integer valued),
+        ``padded_image_masks`` [B,H,W]."""
+        stride = self.out_stride
+        assert padded_images.size(2) % stride == 0
+        assert padded_images.size(3) % stride == 0
+        B, _, H, W = padded_images.shape
+        metas = [dict(img_shape=(H, W, 3), ori_shape=(H, W, 3)) for _ in range(B)]
+        sim, _, _ = F_hip.color_affinity(
+            padded_images.float(), metas, out_stride=stride, bottom_pixels_removed=0,
+            pairwise_size=self.pairwise_size, pairwise_dilation=self.pairwise_dilation,
+            pairwise_color_thresh=self.pairwise_color_thresh, want_similarity=True, want_bits=False,
+            image_masks=padded_image_masks, denormalize=False)
+        return self._per_image_targets(gt_bboxes, sim, H, W)
+
+    def _per_image_targets(self, gt_bboxes, sim: torch.Tensor, H: int, W: int):
+        stride, start = self.out_stride, int(self.out_stride // 2)
+        counts = [int(b.size(0)) for b in gt_bboxes]
+        small = F_hip.box_bitmasks(gt_bboxes, H, W, stride, start).split(counts, dim=0)
+        full = F_hip.box_bitmasks(gt_bboxes, H, W, 1, 0).split(counts, dim=0)
+        similarities = [sim[i:i + 1].expand(n, -1, -1, -1) for i, n in enumerate(counts)]
+        return similarities, list(small), list(full)
+
+    # ---- loss ---------------------------------------------------------------------------------------
+    def loss(self, imgs, img_metas, mask_logits, gt_inds, gt_bboxes, gt_masks, gt_labels) -> Dict[str, torch.Tensor]:
+        """condinst_head.py:1288-1343."""
+        if not mask_logits.is_cuda:
+            raise RuntimeError('CondInstMaskHead.loss: mask_logits must be a CUDA (HIP) tensor; '
+                               'boxinstseg_amd has no CPU loss path')
+        warmup = self._tick()
+        if not self.boxinst_enabled:
+            return {'loss_mask': self._supervised_loss(mask_logits, gt_inds, gt_masks)}
+        if self.pairwise_size == 3:
+            return F_hip.boxinst_mask_loss(
+                mask_logits, gt_inds, gt_bboxes, imgs=imgs, img_metas=img_metas, out_stride=self.out_stride,
+                bottom_pixels_removed=self.bottom_pixels_removed, pairwise_size=self.pairwise_size,
+                pairwise_dilation=self.pairwise_dilation, pairwise_color_thresh=self.pairwise_color_thresh,
+                warmup_factor=warmup)
+        return self._composed_loss(imgs, img_metas, mask_logits, gt_inds, gt_bboxes, warmup)
+
+    def _composed_loss(self, imgs, img_metas, mask_logits, gt_inds, gt_bboxes, warmup: float):
+        """Other window sizes: the reference's own composition (:1314-1332) over the HIP op and the HIP
+        target kernels (the fused kernel is specialised for the 3x3 window every config uses)."""
+        if mask_logits.size(0) == 0:
+            zero = 0 * mask_logits.sum()
+            return {'loss_prj': zero, 'loss_pairwise': zero}
+        similarities, bitmasks, _ = self.get_targets(gt_bboxes, None, imgs, img_metas)
+        scores = mask_logits.sigmoid()
+        bm = torch.cat(bitmasks, dim=0)[gt_inds].unsqueeze(1).to(scores.dtype)
+        sim = torch.cat(similarities, dim=0)[gt_inds].to(scores.dtype)
+        loss_prj = (_dice(scores.max(dim=2, keepdim=True)[0], bm.max(dim=2, keepdim=True)[0]) +
+                    _dice(scores.max(dim=3, keepdim=True)[0], bm.max(dim=3, keepdim=True)[0])).mean()
+        pw = pairwise_nlog(mask_logits, self.pairwise_size, self.pairwise_dilation)
+        weights = (sim >= self.pairwise_color_thresh).to(scores.dtype) * bm
+        loss_pw = (pw * weights).sum() / weights.sum().clamp(min=1.0) * warmup
+        return {'loss_prj': loss_prj, 'loss_pairwise': loss_pw}
+
+    def _supervised_loss(self, mask_logits, gt_inds, gt_masks):
+        """Fully supervised CondInst branch (:1338-1341); not part of the BoxInst hot path, plain torch."""
+        if mask_logits.size(0) == 0:
+            return 0 * mask_logits.sum()
+        start = int(self.out_stride // 2)
+        bm = torch.cat([m[:, start::self.out_stride, start::self.out_stride] for m in gt_masks], dim=0)
+        bm = bm[gt_inds].unsqueeze(1).to(mask_logits.dtype)
+        return _dice(mask_logits.sigmoid(), bm).mean()
+
+
+def _dice(x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    n = x.size(0)
+    x, target = x.reshape(n, -1), target.reshape(n, -1)
+    inter = (x * target).sum(dim=1)
+    union = (x ** 2.0).sum(dim=1) + (target ** 2.0).sum(dim=1) + 1e-5
+    return 1.0 - 2 * inter / union

@@ -1,0 +1,177 @@
+/*
+ * boxinst_hip.h -- C ABI of libboxinst_hip.so: the BoxInst box-supervised mask-loss path
+ * (projection term + colour-similarity pairwise term over CondInst mask logits) as hand-written
+ * HIP kernels for gfx950 (MI355X / CDNA4).
+ *
+ * This is the drop-in boundary.  Every entry point names the interface of the reference
+ * (LiWentomng/BoxInstSeg) it replaces; paths are relative to the upstream checkout:
+ *   bind.cpp          = mmdet/ops/pairwise/csrc/pairwise/bind.cpp
+ *   pairwise.cu       = mmdet/ops/pairwise/csrc/pairwise/pairwise.cu
+ *   condinst_head.py  = mmdet/models/dense_heads/condinst_head.py
+ *
+ * Conventions
+ *   - plain C types only; no torch / ATen types cross this boundary.
+ *   - every pointer is a DEVICE pointer owned by the caller unless its name ends in `_host`.
+ *   - allocation-free: outputs and workspace are supplied by the caller (size from *_workspace_bytes).
+ *   - asynchronous: work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     null stream); no host synchronisation, no hidden copies; safe under hipGraph capture.
+ *   - return value: BXI_OK (0) or a negative bxi_status; never throws.  The reference reports the
+ *     same conditions by TORCH_CHECK / AT_CUDA_CHECK (pairwise.cu:7-13,173,200); the Python
+ *     shim turns a non-zero status into RuntimeError.
+ *   - re-entrant, no global mutable state; one host thread per device is the expected use.
+ *   - tensors are dense, row-major (NCHW like the reference), fp32 unless the name says _f64.
+ */
+#ifndef BOXINST_HIP_H
+#define BOXINST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BXI_ABI_VERSION 1
+#define BXI_MAX_IMAGES 64   /* images per call (per-image metadata travels in kernel arguments) */
+
+typedef enum bxi_status {
+    BXI_OK = 0,
+    BXI_ERR_NULL_POINTER = -1,   /* a required pointer is NULL                                  */
+    BXI_ERR_BAD_SHAPE = -2,      /* negative/zero/inconsistent dimension, or > 2^31-1 elements  */
+    BXI_ERR_BAD_ARGUMENT = -3,   /* even pairwise_size, dilation < 1, stride < 1 ...            */
+    BXI_ERR_UNSUPPORTED = -4,    /* valid for the reference op, outside this build's fast path  */
+    BXI_ERR_WORKSPACE = -5,      /* workspace NULL / too small / misaligned                     */
+    BXI_ERR_LAUNCH = -6,         /* hipGetLastError() != hipSuccess after a launch             */
+    BXI_ERR_NO_DEVICE = -7       /* no HIP device / wrong architecture                          */
+} bxi_status;
+
+int bxi_abi_version(void);
+const char* bxi_status_string(int status);
+/* hipError_t of the most recent BXI_ERR_LAUNCH on this host thread (0 if none). */
+int bxi_last_hip_error(void);
+/* 0 if device `ordinal` exists and is gfx950, BXI_ERR_NO_DEVICE otherwise. */
+int bxi_check_device(int ordinal);
+
+/* ===========================================================================================
+ * 1. Op level -- replaces the pybind11 module `pairwise_ext` (bind.cpp:15-36)
+ * ===========================================================================================
+ *
+ * bxi_pairwise_nlog_forward_*  <->  pairwise_nlog_forward(int size, int dilation, Tensor& logits)
+ *     bind.cpp:15-20 -> pairwiseNLogForwardCUDALauncher pairwise.cu:154-175, kernel :68-104.
+ *     logits   [N,1,H,W]  (channel dim must be 1, pairwise.cu:93)
+ *     pairwise [N,size*size-1,H,W] = -log P(y_p == y_q), q = p + (dy,dx), dy outer / dx inner in
+ *     steps of `dilation`, centre skipped; an out-of-bounds neighbour gives 0.
+ *     Differences from the reference: runs on `stream` instead of the legacy default stream
+ *     (SURVEY 8a quirk 2); N == 0 is a no-op instead of an invalid launch.
+ */
+int bxi_pairwise_nlog_forward_f32(const float* logits, int N, int H, int W, int size, int dilation,
+                                  float* pairwise, void* stream);
+int bxi_pairwise_nlog_forward_f64(const double* logits, int N, int H, int W, int size, int dilation,
+                                  double* pairwise, void* stream);
+
+/* bxi_pairwise_nlog_backward_*  <->  pairwise_nlog_backward(size, dilation, logits, pairwise, g_pairwise)
+ *     bind.cpp:22-29 -> pairwiseNLogBackwardCUDALauncher pairwise.cu:177-202, kernel :106-149.
+ *     g_logits [N,1,H,W] is fully overwritten (the reference zero-fills then atomically adds,
+ *     pairwise.cu:186,62-65).  Here each pixel GATHERS its 2*(size*size-1) contributions using
+ *     f(x,y) = f(y,x) and channel K-1-k = the opposite offset, so the sum order is fixed and the
+ *     result is deterministic.  `pairwise` (the saved forward output) is accepted for signature
+ *     parity and may be NULL: the kernel recomputes the pair value.
+ */
+int bxi_pairwise_nlog_backward_f32(const float* logits, const float* pairwise, const float* g_pairwise,
+                                   int N, int H, int W, int size, int dilation, float* g_logits,
+                                   void* stream);
+int bxi_pairwise_nlog_backward_f64(const double* logits, const double* pairwise, const double* g_pairwise,
+                                   int N, int H, int W, int size, int dilation, double* g_logits,
+                                   void* stream);
+
+/* ===========================================================================================
+ * 2. Target side -- replaces get_original_image (condinst_head.py:170-186),
+ *    CondInstMaskHead.get_targets (:1345-1393), get_bitmasks_from_boxes (:1395-1448) and
+ *    get_image_color_similarity (:220-246); no host round trip, no per-image / per-box loop.
+ * ===========================================================================================
+ */
+typedef struct bxi_image_batch {
+    const float* imgs;        /* [B,3,Hc,Wc] network input (normalised), canvas-padded           */
+    int B, Hc, Wc;
+    const int* img_h_host;    /* [B] img_metas[i]['img_shape'][0]                                 */
+    const int* img_w_host;    /* [B] img_metas[i]['img_shape'][1]                                 */
+    const int* rows_removed_host; /* [B] int(bottom_pixels_removed*img_h/ori_h), :1358-1361       */
+    double mean[3], std[3];   /* img_norm_cfg, in the channel order of `imgs`                     */
+    int to_rgb;               /* img_norm_cfg['to_rgb']                                           */
+    const float* image_masks; /* optional [B,Hc,Wc] explicit validity masks (the padded_image_masks
+                                 argument of get_bitmasks_from_boxes); NULL = derive from the
+                                 img_h/img_w/rows_removed geometry as get_targets does            */
+} bxi_image_batch;
+
+/* Stage A: de-normalise + truncate to uint8 (:170-186) + stride x stride mean + .byte() (:1403,1413)
+ *   rgb_small [B,3,h,w] uint8, h = Hc/stride.
+ * Stage B: rgb2lab (skimage algorithm, fp64 -> f32, :1413-1416) + colour similarity (:220-246):
+ *   sim      [B,K,h,w] f32, K = size*size-1 (nullable: skip the 4*K bytes/pixel write)
+ *   affinity [B,h,w]  bit k of the low K bits = (sim[k] >= color_thresh) (:1324); uint8 per pixel
+ *            when K <= 8, uint32 when K <= 32 (nullable).
+ * size must be odd; K <= 32 for `affinity`; stride in {1,2,4,8}.
+ */
+int bxi_color_affinity_f32(const bxi_image_batch* batch_host, int stride, int size, int dilation,
+                           float color_thresh, uint8_t* rgb_small, float* sim, void* affinity,
+                           void* stream);
+
+/* Per-box bitmasks (:1426-1432): out [G, Hc/stride, Wc/stride] f32 in {0,1},
+ * out[g,r,c] = 1 iff (start+r*stride, start+c*stride) lies in the python slice
+ * [int(y1):int(y2)+1, int(x1):int(x2)+1] of an Hc x Wc array.  stride=1,start=0 gives the
+ * reference's `bitmasks_full`.  boxes_per_img_host: B device pointers to [G_i,4] xyxy f32. */
+int bxi_box_bitmasks_f32(const float* const* boxes_per_img_host, const int* gt_count_host, int B,
+                         int Hc, int Wc, int stride, int start, float* out, void* stream);
+
+/* ===========================================================================================
+ * 3. Loss -- replaces CondInstMaskHead.loss with boxinst_enabled (condinst_head.py:1288-1343):
+ *    compute_project_term (:134-143) + pairwise_nlog + weights / normalise / warm-up
+ *    (:1315-1332), forward AND backward to mask_logits in one pass over the logits.
+ * ===========================================================================================
+ */
+typedef struct bxi_instances {
+    const float* logits;      /* [N,1,h,w] mask logits                                            */
+    int N, h, w;
+    const int64_t* gt_inds;   /* [N] index into the batch-concatenated GT list (:1302,1316)       */
+    const float* const* boxes_per_img_host; /* [B] device pointers to [G_i,4] xyxy boxes          */
+    const int* gt_count_host; /* [B] G_i                                                          */
+    int B;
+    int Hc, Wc;               /* canvas size in pixels (h*stride, w*stride)                        */
+    int stride;               /* out_stride                                                       */
+} bxi_instances;
+
+size_t bxi_boxinst_loss_workspace_bytes(int N, int h, int w);
+size_t bxi_boxinst_loss_state_bytes(int N, int h, int w);
+
+/* losses[0] = loss_prj, losses[1] = loss_pairwise (device, f32).
+ * g_logits [N,1,h,w]: d(loss_prj + loss_pairwise)/d logits, i.e. the gradient for unit upstream
+ *   gradients, fully overwritten (nullable: forward only).
+ * affinity: output of bxi_color_affinity_f32 for the same size/dilation/threshold.
+ * warmup: min(_iter / pairwise_warmup, 1) (:1330-1331), evaluated on the host by the caller.
+ * state (bxi_boxinst_loss_state_bytes): what bxi_boxinst_loss_rescale_f32 needs later
+ *   (arg-max positions and unit projection gradients); nullable when g_logits is NULL.
+ * workspace (bxi_boxinst_loss_workspace_bytes, 256-B aligned): scratch, contents undefined after.
+ * Only size == 3 (K = 8) is built into this fused path; other sizes return BXI_ERR_UNSUPPORTED
+ * and the host composes section 1 + torch ops as the reference does.
+ * N == 0 writes two zeros (documented deviation; the reference yields NaN). */
+int bxi_boxinst_loss_fwd_bwd_f32(const bxi_instances* inst_host, const uint8_t* affinity,
+                                 int size, int dilation, float warmup, float* losses, float* g_logits,
+                                 void* state, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward with arbitrary upstream gradients, without a host sync: reads the two device scalars
+ * g_prj, g_pw and turns the unit gradient in place into g_prj*dprj + g_pw*dpairwise.
+ * All blocks exit immediately when both are exactly 1.0f (mmdet's `_parse_losses` sum). */
+int bxi_boxinst_loss_rescale_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw,
+                                 int dilation, const void* state, float* g_logits, void* stream);
+
+/* Whole evaluation in one host call = bxi_color_affinity_f32 (sim skipped) + bxi_boxinst_loss_fwd_bwd_f32.
+ * workspace must hold bxi_boxinst_eval_workspace_bytes(...). */
+size_t bxi_boxinst_eval_workspace_bytes(int B, int Hc, int Wc, int stride, int N);
+int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host,
+                         int size, int dilation, float color_thresh, float warmup,
+                         float* losses, float* g_logits, void* state,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOXINST_HIP_H */

@@ -1,0 +1,237 @@
+"""HIP path vs CPU oracle on the same seeded inputs (run on a real MI355X: -m gpu).
+
+Tolerances (north_star): losses within 1e-4 relative, gradient within 1e-4 * max|grad| of the fp32
+oracle; the op-level kernels are also checked in fp64 (1e-10)."""
+import numpy as np
+import pytest
+import torch
+
+from boxinstseg_amd import synthetic
+from tests.helpers import grad_report, hip_loss, oracle_path, rel, to_dev
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# op level: pairwise_nlog forward / backward  (mmdet.ops.pairwise)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype,tol', [(np.float32, 2e-6), (np.float64, 1e-12)])
+@pytest.mark.parametrize('shape,size,dil', [((3, 13, 17), 3, 2), ((2, 40, 24), 3, 1), ((2, 21, 33), 5, 2),
+                                            ((1, 5, 3), 3, 3), ((4, 64, 64), 3, 2)])
+def test_pairwise_op(dev, dtype, tol, shape, size, dil):
+    from boxinstseg_amd import pairwise_nlog
+    from oracle import c_oracle
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal(shape) * 4).astype(dtype)
+    want = c_oracle.pairwise_nlog_fwd(x, size, dil)
+    gp = rng.standard_normal(want.shape).astype(dtype)
+    want_g = c_oracle.pairwise_nlog_bwd(x, want, gp, size, dil)
+    xt = torch.from_numpy(x[:, None]).to(dev).requires_grad_(True)
+    out = pairwise_nlog(xt, size, dil)
+    out.backward(torch.from_numpy(gp).to(dev))
+    got = out.detach().cpu().numpy()
+    got_g = xt.grad.cpu().numpy()[:, 0]
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max())
+    assert np.abs(got_g - want_g).max() <= 10 * tol * max(1.0, np.abs(want_g).max())
+
+
+def test_pairwise_op_extreme_logits(dev):
+    """|x| up to 200: log-space evaluation must not overflow (pairwise.cu:27-50)."""
+    from boxinstseg_amd import pairwise_nlog
+    from oracle import c_oracle
+    vals = np.array([0, 1e-3, -1e-3, 3, -3, 30, -30, 100, -100, 200, -200], np.float32)
+    x = np.tile(vals, (1, 11, 1)).astype(np.float32)
+    x = x + x.transpose(0, 2, 1) * 0.5
+    want = c_oracle.pairwise_nlog_fwd(x, 3, 1)
+    got = pairwise_nlog(torch.from_numpy(x[:, None]).to(dev), 3, 1).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+
+
+def test_pairwise_op_errors(dev):
+    from boxinstseg_amd import pairwise_nlog, pairwise_nlog_forward
+    with pytest.raises(RuntimeError, match='CUDA'):
+        pairwise_nlog_forward(3, 2, torch.zeros(1, 1, 4, 4))
+    with pytest.raises(RuntimeError, match='contiguous'):
+        pairwise_nlog_forward(3, 2, torch.zeros(1, 1, 4, 8, device=dev)[..., ::2])
+    with pytest.raises(RuntimeError):
+        pairwise_nlog_forward(4, 2, torch.zeros(1, 1, 4, 4, device=dev))     # even window
+    assert pairwise_nlog(torch.zeros(0, 1, 4, 4, device=dev), 3, 2).shape == (0, 8, 4, 4)
+
+
+# ---------------------------------------------------------------------------------------------
+# target side
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('case', ['cfg1', 'ragged', 'bgr', 'stride8'])
+def test_color_affinity(dev, case):
+    from boxinstseg_amd import color_affinity
+    stride = 4
+    if case == 'cfg1':
+        d = synthetic.cfg1(0)
+    elif case == 'ragged':
+        d = synthetic.make_batch(B=2, H=96, W=160, boxes_per_img=2, seed=3, img_shapes=[(96, 131), (70, 160)],
+                                 ori_shapes=[(48, 66), (210, 480)], min_box=16, max_box=64)
+    elif case == 'bgr':
+        d = synthetic.make_batch(B=1, H=64, W=64, boxes_per_img=1, seed=4, min_box=16, max_box=32)
+        d['img_metas'][0]['img_norm_cfg'] = dict(mean=np.array([103.53, 116.28, 123.675], np.float32),
+                                                 std=np.array([1.0, 1.0, 1.0], np.float32), to_rgb=False)
+    else:
+        stride = 8
+        d = synthetic.make_batch(B=1, H=128, W=192, boxes_per_img=1, seed=5, stride=8, min_box=16, max_box=64)
+    ref = oracle_path(d)
+    sim, bits, _ = color_affinity(torch.from_numpy(d['imgs']).to(dev), d['img_metas'], out_stride=stride)
+    sim = sim.cpu().numpy()
+    bits = bits.cpu().numpy()
+    assert np.abs(sim - ref['sim']).max() <= 2e-6
+    want_bits = np.zeros(bits.shape, np.uint8)
+    for k in range(8):
+        want_bits |= ((ref['sim'][:, k] >= 0.3).astype(np.uint8) << k)
+    flips = int((np.unpackbits((bits ^ want_bits)[..., None], axis=-1)).sum())
+    assert flips <= 2, f'{flips} threshold flips'
+
+
+def test_box_bitmasks(dev):
+    from boxinstseg_amd import box_bitmasks
+    from oracle import c_oracle
+    boxes = [np.array([[10.7, 3.2, 50.9, 40.1], [-3.0, -2.0, 20.0, 10.0], [60.0, 60.0, 200.0, 200.0],
+                       [5.0, 5.0, 5.9, 5.9], [30.0, 2.0, 10.0, 60.0]], np.float32),
+             np.zeros((0, 4), np.float32),
+             np.array([[0.0, 0.0, 95.0, 63.0]], np.float32)]
+    H, W = 64, 96
+    for stride, start in ((4, 2), (1, 0)):
+        got = box_bitmasks([torch.from_numpy(b).to(dev) for b in boxes], H, W, stride, start).cpu().numpy()
+        allb = np.concatenate(boxes)
+        assert got.shape[0] == len(allb)
+        for g, box in enumerate(allb):
+            full = np.zeros((H, W), np.float32)
+            full[int(box[1]):int(box[3]) + 1, int(box[0]):int(box[2]) + 1] = 1.0     # condinst_head.py:1429-1430
+            assert np.array_equal(got[g], full[start::stride, start::stride]), (g, stride)
+            if stride == 4:
+                assert np.array_equal(got[g], c_oracle.box_bitmask(box, H, W, 4))
+
+
+# ---------------------------------------------------------------------------------------------
+# fused loss
+# ---------------------------------------------------------------------------------------------
+def _check(d, dev, warmup=1.0, up=None, tol=TOL):
+    g = (1.0, 1.0) if up is None else up
+    ref = oracle_path(d, warmup=warmup, g_prj=g[0], g_pw=g[1], want_targets=False)
+    lp, lw, grad = hip_loss(d, dev, warmup=warmup, up=up)
+    assert rel(lp, ref['loss_prj']) <= tol, (lp, ref['loss_prj'])
+    assert rel(lw, ref['loss_pairwise']) <= tol or abs(lw - ref['loss_pairwise']) < 1e-7, (lw, ref['loss_pairwise'])
+    err, ties = grad_report(grad, ref['grad'], d['mask_logits'][:, 0])
+    assert err <= tol, f'grad err {err:.3e} ({ties} ambiguous arg-max lines excluded)'
+    assert ties <= 3
+    return lp, lw
+
+
+def test_loss_cfg1(dev):
+    _check(synthetic.cfg1(0), dev)
+
+
+def test_loss_cfg1_warmup_and_upstream(dev):
+    _check(synthetic.cfg1(1), dev, warmup=0.37)
+    _check(synthetic.cfg1(2), dev, up=(0.5, 3.0))
+    _check(synthetic.cfg1(2), dev, up=(512.0, 512.0))      # Fp16OptimizerHook loss_scale
+
+
+def test_loss_ragged_two_per_box(dev):
+    d = synthetic.make_batch(B=2, H=96, W=160, boxes_per_img=3, inst_per_box=2, seed=7,
+                             img_shapes=[(96, 131), (70, 160)], ori_shapes=[(48, 66), (210, 480)],
+                             min_box=16, max_box=80)
+    _check(d, dev)
+
+
+def test_loss_wide_map(dev):
+    """w > 256 exercises the multi-chunk column loop; h not a multiple of the tile height."""
+    d = synthetic.make_batch(B=1, H=76, W=1344, boxes_per_img=3, seed=8, min_box=24, max_box=400)
+    _check(d, dev)
+
+
+def test_loss_extreme_logits(dev):
+    """saturated logits take the log-space branch of the fused kernel (methodology rule: force the branch)."""
+    d = synthetic.cfg1(3)
+    d['mask_logits'] = (d['mask_logits'] * 40.0).astype(np.float32)
+    ref = oracle_path(d, want_targets=False)
+    lp, lw, grad = hip_loss(d, dev)
+    assert np.isfinite([lp, lw]).all() and np.isfinite(grad).all()
+    assert rel(lw, ref['loss_pairwise']) <= TOL and rel(lp, ref['loss_prj']) <= TOL
+
+
+def test_loss_zero_instances_and_empty_image(dev):
+    from boxinstseg_amd import boxinst_mask_loss
+    d = synthetic.cfg1(0)
+    t = to_dev(d, dev)
+    empty = torch.zeros((0, 1, d['h'], d['w']), device=dev, requires_grad=True)
+    out = boxinst_mask_loss(empty, torch.zeros(0, dtype=torch.long, device=dev), t['gt_bboxes'], imgs=t['imgs'],
+                            img_metas=d['img_metas'])
+    assert float(out['loss_prj']) == 0.0 and float(out['loss_pairwise']) == 0.0
+    (out['loss_prj'] + out['loss_pairwise']).backward()
+    # an image with no GT boxes (the reference raises at condinst_head.py:1440)
+    d2 = synthetic.make_batch(B=2, H=64, W=64, boxes_per_img=2, seed=9, min_box=16, max_box=40)
+    d2['gt_bboxes'][0] = np.zeros((0, 4), np.float32)
+    d2['gt_inds'] = np.array([0, 1, 1], np.int64)
+    d2['mask_logits'] = d2['mask_logits'][:3]
+    _check(d2, dev)
+
+
+def test_deterministic(dev):
+    d = synthetic.cfg1(5)
+    a = hip_loss(d, dev)
+    b = hip_loss(d, dev)
+    assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
+
+
+def test_loss_cfg2_full_size(dev):
+    """The headline configuration against the C oracle (a few seconds of CPU)."""
+    lp, lw = _check(synthetic.cfg2(0), dev)
+    assert 0.1 < lp < 2.0 and 0.05 < lw < 2.0
+
+
+def test_loss_cfg2_two_per_box(dev):
+    _check(synthetic.cfg2(1, inst_per_box=2), dev)
+
+
+# ---------------------------------------------------------------------------------------------
+# module level
+# ---------------------------------------------------------------------------------------------
+def test_head_loss_and_targets(dev):
+    from boxinstseg_amd import CondInstMaskHead
+    d = synthetic.cfg1(0)
+    ref = oracle_path(d, warmup=0.0002)
+    t = to_dev(d, dev)
+    head = CondInstMaskHead(in_channels=16, boxinst_enabled=True, topk_per_img=64, max_proposals=-1).to(dev)
+    head._iter.fill_(1.0)
+    head._iter_host = None                                    # as after load_state_dict
+    logits = t['logits'].clone().requires_grad_(True)
+    out = head.loss(t['imgs'], d['img_metas'], logits, t['gt_inds'], t['gt_bboxes'], None, None)
+    assert set(out) == {'loss_prj', 'loss_pairwise'}
+    assert float(head._iter) == 2.0
+    assert rel(float(out['loss_prj']), ref['loss_prj']) <= TOL
+    assert rel(float(out['loss_pairwise']), ref['loss_pairwise']) <= TOL
+    sims, bms, full = head.get_targets(t['gt_bboxes'], None, t['imgs'], d['img_metas'])
+    assert sims[0].shape == (4, 8, 64, 64) and bms[0].shape == (4, 64, 64) and full[0].shape == (4, 256, 256)
+    assert np.abs(sims[0][0].cpu().numpy() - ref['sim'][0]).max() <= 2e-6
+    assert np.array_equal(bms[0].cpu().numpy(), ref['bitmask'])
+    with pytest.raises(RuntimeError, match='CUDA'):
+        head.loss(t['imgs'].cpu(), d['img_metas'], logits.detach().cpu(), t['gt_inds'].cpu(),
+                  [b.cpu() for b in t['gt_bboxes']], None, None)
+
+
+def test_head_composed_window5(dev):
+    """pairwise_size=5 goes through the op-level kernels + torch glue; compare with the oracle."""
+    from boxinstseg_amd import CondInstMaskHead
+    d = synthetic.make_batch(B=1, H=64, W=96, boxes_per_img=2, seed=11, min_box=16, max_box=48)
+    ref = oracle_path(d, size=5, dil=1)
+    t = to_dev(d, dev)
+    head = CondInstMaskHead(in_channels=16, boxinst_enabled=True, pairwise_size=5, pairwise_dilation=1,
+                            pairwise_warmup=1, max_proposals=-1).to(dev)
+    logits = t['logits'].clone().requires_grad_(True)
+    out = head.loss(t['imgs'], d['img_metas'], logits, t['gt_inds'], t['gt_bboxes'], None, None)
+    (out['loss_prj'] + out['loss_pairwise']).backward()
+    assert rel(float(out['loss_prj']), ref['loss_prj']) <= TOL
+    assert rel(float(out['loss_pairwise']), ref['loss_pairwise']) <= TOL
+    err, _ = grad_report(logits.grad.cpu().numpy()[:, 0], ref['grad'], d['mask_logits'][:, 0])
+    assert err <= TOL
