@@ -1,0 +1,317 @@
+#!/usr/bin/env python3
+"""bench.py -- BoxInst mask-loss path (projection + colour-similarity pairwise loss), fwd+bwd.
+
+Metric (BASELINE.json): pairwise+projection loss fwd+bwd images/sec @ 2x800x1024 x 32 instances.
+One *step* = one loss evaluation on a 2-image batch, through the C ABI of libboxinst_hip.so:
+  bxi_boxinst_eval_f32          stage1 (image pool+Lab || logit streaming) -> box -> loss_finalize
+  bxi_boxinst_loss_rescale_f32  the backward's upstream-gradient fold (a no-op launch for g = 1)
+i.e. everything CondInstMaskHead.loss + .backward() do for mask_logits, from the normalised images,
+boxes and logits already resident in HBM to loss_prj, loss_pairwise and d(loss)/d(mask_logits).
+Inputs rotate over `--sets` independent batches (default 8 x ~36 MB > the 256 MB Infinity Cache)
+so that every step reads cold data.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode graph|eager]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  The path has no exchange step (every unit is rank-local):
+ranks are weak-scaled replicas; RCCL is used for the barriers, the MAX of the elapsed times and one
+all-reduce of the summed loss scalars after the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=200)
+    ap.add_argument('--mode', choices=['graph', 'eager'], default='graph',
+                    help='graph: one hipGraph per input set, replayed; eager: direct C-ABI calls')
+    ap.add_argument('--sets', type=int, default=8, help='independent input sets rotated through')
+    ap.add_argument('--inst-per-box', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    return ap.parse_args()
+
+
+class EvalSet:
+    """One synthetic 2x800x1024 / 32-instance batch resident on the device + its output buffers."""
+
+    def __init__(self, lib, Fh, synthetic, dev, seed, inst_per_box):
+        d = synthetic.cfg2(seed=seed, inst_per_box=inst_per_box)
+        self.d = d
+        self.imgs = torch.from_numpy(d['imgs']).to(dev)
+        self.logits = torch.from_numpy(d['mask_logits']).to(dev)
+        self.gt_inds = torch.from_numpy(d['gt_inds']).to(dev)
+        self.boxes = [torch.from_numpy(b).to(dev) for b in d['gt_bboxes']]
+        self.batch = Fh._Batch(self.imgs, d['img_metas'], 10)
+        self.inst = Fh._Inst(self.logits, self.gt_inds, self.boxes, d['H'], d['W'], d['stride'])
+        N, h, w = self.inst.N, self.inst.h, self.inst.w
+        self.losses = torch.zeros(2, device=dev)
+        self.grad = torch.empty_like(self.inst.logits)
+        self.state = torch.empty(lib.bxi_boxinst_loss_state_bytes(N, h, w), dtype=torch.uint8, device=dev)
+        self.ws = torch.empty(lib.bxi_boxinst_eval_workspace_bytes(d['B'], d['H'], d['W'], d['stride'], N),
+                              dtype=torch.uint8, device=dev)
+        self.ones = torch.ones(2, device=dev)       # upstream gradients of loss_prj / loss_pairwise
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', local_rank if world > 1 else 0)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if dist is not None:
+        dist.barrier()
+    from boxinstseg_amd import _lib, functional as Fh, synthetic
+    lib = _lib.load()
+    assert lib.bxi_check_device(dev.index) == 0, 'not a gfx950 device'
+
+    sets = [EvalSet(lib, Fh, synthetic, dev, seed=1000 * rank + i, inst_per_box=args.inst_per_box)
+            for i in range(args.sets)]
+    stream = torch.cuda.Stream(device=dev)
+    SIZE, DIL, THRESH, WARM = 3, 2, 0.3, 1.0
+
+    def enqueue(s: EvalSet, st: int) -> None:
+        rc = lib.bxi_boxinst_eval_f32(C.byref(s.batch.struct), C.byref(s.inst.struct), SIZE, DIL, THRESH, WARM,
+                                      s.losses.data_ptr(), s.grad.data_ptr(), s.state.data_ptr(), s.ws.data_ptr(),
+                                      s.ws.numel(), st)
+        if rc == 0:
+            rc = lib.bxi_boxinst_loss_rescale_f32(C.byref(s.inst.struct), s.ones.data_ptr(),
+                                                  s.ones.data_ptr() + 4, DIL, s.state.data_ptr(),
+                                                  s.grad.data_ptr(), st)
+        if rc != 0:
+            raise RuntimeError(f'C ABI status {rc}: {_lib.status_string(rc)}')
+
+    # ---- parity gate (rank 0, set 0) before anything is timed -------------------------------------
+    with torch.cuda.stream(stream):
+        enqueue(sets[0], stream.cuda_stream)
+    stream.synchronize()
+    parity = None
+    if rank == 0:
+        from tests.helpers import oracle_path
+        ref = oracle_path(sets[0].d, want_targets=False)
+        got = sets[0].losses.cpu().numpy()
+        g = sets[0].grad.cpu().numpy()[:, 0]
+        parity = dict(loss_prj_rel=float(abs(got[0] - ref['loss_prj']) / abs(ref['loss_prj'])),
+                      loss_pairwise_rel=float(abs(got[1] - ref['loss_pairwise']) / abs(ref['loss_pairwise'])),
+                      grad_rel_max=float(np.abs(g - ref['grad']).max() / np.abs(ref['grad']).max()))
+        if max(parity.values()) > 1e-4:
+            raise SystemExit(f'parity gate failed, refusing to time: {parity}')
+
+    # ---- step function -------------------------------------------------------------------------------
+    graphs = None
+    if args.mode == 'graph':
+        graphs = []
+        with torch.cuda.stream(stream):
+            for s in sets:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    enqueue(s, torch.cuda.current_stream().cuda_stream)
+                graphs.append(g)
+        stream.synchronize()
+
+    def run(n_steps: int, first: int = 0) -> None:
+        with torch.cuda.stream(stream):
+            if graphs is not None:
+                for i in range(first, first + n_steps):
+                    graphs[i % len(graphs)].replay()
+            else:
+                st = stream.cuda_stream
+                for i in range(first, first + n_steps):
+                    enqueue(sets[i % len(sets)], st)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, first=args.warmup)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the two logged scalars, summed over ranks (what mmdet's _parse_losses all-reduces)
+        tot = torch.stack([s.losses for s in sets]).sum(0)
+        dist.all_reduce(tot)
+    images = 2 * args.steps * world
+    value = images / elapsed
+
+    result = {
+        'metric': 'pairwise+projection loss fwd+bwd images/sec @2x800x1024x32inst',
+        'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BoxInst R-50 FPN loss path, 2x800x1024 synthetic batch, '
+                               f'{sets[0].inst.N} instances, 1xMI355X per rank (BASELINE configs[1])',
+                   'images_per_step': 2, 'instances': sets[0].inst.N, 'map': [sets[0].inst.h, sets[0].inst.w],
+                   'launch': args.mode, 'input_sets': args.sets, 'parallelism': f'replicas x{world} (no exchange step)'},
+    }
+    if parity is not None:
+        result['parity'] = parity
+
+    # ---- per-kernel durations with HIP events on the launching stream (rank 0, N == 1) ------------
+    if rank == 0 and world == 1 and not args.no_kernel_timing:
+        result.update(kernel_timing(lib, _lib, sets, stream, enqueue, min(args.steps, 400)))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(sets[0].d, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+# algorithmic (compulsory) HBM bytes per launch -- DESIGN.md section 4.  Per unit: 12 B per input pixel
+# (3 x f32 read) + 12 B per pooled pixel (Lab written) for the image half of stage1; 4 B per
+# instance-pixel read (logits) + 4 B per instance-pixel written (gradient) for the loss, the write
+# split between stage1 (zero-fill outside the box tiles) and box_kernel (the box tiles).
+def box_tile_fraction(d, dil=2, br=8, bc=64):
+    """fraction of the N x h x w gradient written by box_kernel (tiles meeting the dilated box)."""
+    h, w, stride = d['h'], d['w'], d['stride']
+    boxes = np.concatenate(d['gt_bboxes'], axis=0)
+    hit = 0
+    for g in d['gt_inds']:
+        x1, y1, x2, y2 = [int(v) for v in boxes[g]]
+        rr = [r for r in range(h) if y1 <= r * stride + stride // 2 <= y2]
+        cc = [c for c in range(w) if x1 <= c * stride + stride // 2 <= x2]
+        if not rr or not cc:
+            continue
+        r0, r1 = max(rr[0] - dil, 0), min(rr[-1] + 1 + dil, h)
+        c0, c1 = max(cc[0] - dil, 0), min(cc[-1] + 1 + dil, w)
+        tr = range(r0 // br, (r1 - 1) // br + 1)
+        tc = range(c0 // bc, (c1 - 1) // bc + 1)
+        for a in tr:
+            for b in tc:
+                hit += (min(h, a * br + br) - a * br) * (min(w, b * bc + bc) - b * bc)
+    return hit / float(len(d['gt_inds']) * h * w)
+
+
+def algorithmic_bytes(d, N):
+    px_in = d['B'] * d['H'] * d['W']
+    px_small = d['B'] * d['h'] * d['w']
+    ipx = N * d['h'] * d['w']
+    f = box_tile_fraction(d)
+    return {
+        'stage1': 12 * px_in + 12 * px_small + 4 * ipx + int(4 * ipx * (1.0 - f)),
+        'box': int(4 * ipx * f) + int(4 * ipx * f),      # re-read of the box tiles' logits + their gradient
+        'loss_finalize': 0,                               # boxes' region + h+w maxima only (L2 resident)
+        'loss_rescale': 0,
+    }
+
+
+def kernel_timing(lib, _lib, sets, stream, enqueue, steps):
+    """Bracket every kernel launch with HIP events (bxi_set_launch_hook) over `steps` eager steps."""
+    events = {}
+
+    def hook(name, phase, st, user):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        events.setdefault(name.decode(), []).append(ev)
+
+    cb = _lib.LAUNCH_HOOK(hook)
+    run_stream = stream
+    with torch.cuda.stream(run_stream):
+        for i in range(20):
+            enqueue(sets[i % len(sets)], run_stream.cuda_stream)
+        run_stream.synchronize()
+        lib.bxi_set_launch_hook(C.cast(cb, C.c_void_p), None)
+        try:
+            for i in range(steps):
+                enqueue(sets[i % len(sets)], run_stream.cuda_stream)
+        finally:
+            lib.bxi_set_launch_hook(None, None)
+    run_stream.synchronize()
+    per_kernel = {}
+    for name, evs in events.items():
+        durs = [evs[j].elapsed_time(evs[j + 1]) * 1e3 for j in range(0, len(evs) - 1, 2)]   # us
+        per_kernel[name] = {'avg_us': float(np.mean(durs)), 'median_us': float(np.median(durs)),
+                            'min_us': float(np.min(durs)), 'launches': len(durs)}
+    alg = algorithmic_bytes(sets[0].d, sets[0].inst.N)
+    for name, v in per_kernel.items():
+        b = alg.get(name, 0)
+        v['algorithmic_bytes'] = b
+        v['achieved_GBps'] = b / (v['avg_us'] * 1e-6) / 1e9 if b else None
+    dom = max((k for k in per_kernel if alg.get(k, 0) > 0), key=lambda k: per_kernel[k]['avg_us'])
+    a = per_kernel[dom]['achieved_GBps']
+    return {
+        'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                     'frac': a / HBM_PEAK_GBPS, 'traffic': None,
+                     'avg_launch_us': per_kernel[dom]['avg_us'], 'algorithmic_bytes': alg[dom],
+                     'timing': 'hipEvent pairs around each launch on the launching stream (eager, cold input sets)'},
+        'kernels': per_kernel,
+    }
+
+
+def cpu_baseline(d, budget_s):
+    """The reference's CPU loss path (torch CPU ops, oracle/torch_oracle.py) on the host cores, fwd+bwd,
+    same workload; bounded to ~budget_s seconds.  Also the scalar C oracle on one core."""
+    from oracle import torch_oracle as to
+    from tests.helpers import oracle_path
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    imgs = torch.from_numpy(d['imgs'])
+    gi = torch.from_numpy(d['gt_inds'])
+    boxes = [torch.from_numpy(b) for b in d['gt_bboxes']]
+
+    def once():
+        x = torch.from_numpy(d['mask_logits']).requires_grad_(True)
+        out = to.mask_loss(imgs, d['img_metas'], x, gi, boxes)
+        (out['loss_prj'] + out['loss_pairwise']).backward()
+
+    once()                                              # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        once()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 20:
+            break
+    t_c0 = time.perf_counter()
+    oracle_path(d, want_targets=False)
+    t_c = time.perf_counter() - t_c0
+    return {'value': 2 * n / el, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} full evaluations (targets + loss fwd+bwd) of the same 2x800x1024x{len(d["gt_inds"])} '
+                      f'workload with the torch-CPU restatement of the reference path, {cores} threads',
+            'ms_per_eval': el / n * 1e3,
+            'c_oracle_openmp': {'value': 2 / t_c, 'unit': 'images/s', 'ms_per_eval': t_c * 1e3}}
+
+
+if __name__ == '__main__':
+    main()

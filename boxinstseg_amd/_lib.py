@@ -43,6 +43,7 @@ SIGNATURES = {
     'bxi_status_string': (C.c_char_p, [c_int]),
     'bxi_last_hip_error': (c_int, []),
     'bxi_check_device': (c_int, [c_int]),
+    'bxi_set_launch_hook': (None, [c_void_p, c_void_p]),
     'bxi_pairwise_nlog_forward_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'bxi_pairwise_nlog_forward_f64': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'bxi_pairwise_nlog_backward_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -50,7 +51,7 @@ SIGNATURES = {
     'bxi_pairwise_nlog_backward_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                                c_void_p, c_void_p]),
     'bxi_color_affinity_f32': (c_int, [C.POINTER(ImageBatch), c_int, c_int, c_int, c_float, c_void_p, c_void_p,
-                                       c_void_p, c_void_p]),
+                                       c_void_p, c_void_p, c_void_p]),
     'bxi_box_bitmasks_f32': (c_int, [C.POINTER(c_void_p), C.POINTER(c_int), c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_void_p]),
     'bxi_boxinst_loss_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
@@ -63,6 +64,8 @@ SIGNATURES = {
     'bxi_boxinst_eval_f32': (c_int, [C.POINTER(ImageBatch), C.POINTER(Instances), c_int, c_int, c_float, c_float,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
+
+LAUNCH_HOOK = C.CFUNCTYPE(None, C.c_char_p, c_int, c_void_p, c_void_p)
 
 _lib: Optional[C.CDLL] = None
 

@@ -5,11 +5,12 @@ namespace bxi {
 
 static thread_local int g_last_hip_error = 0;
 void set_last_hip_error(int e) { g_last_hip_error = e; }
+bxi_launch_hook g_hook = nullptr;
+void* g_hook_user = nullptr;
 
-int launch_color_affinity(const bxi_image_batch* bt, int stride, int size, int dil, float thresh, uint8_t* rgb_small,
-                          float* sim, void* affinity, void* stream);
-int launch_loss(const bxi_instances* in, const uint8_t* affinity, int size, int dil, float warmup, float* losses,
-                float* g_logits, void* state, void* workspace, size_t workspace_bytes, void* stream);
+int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, const bxi_instances* in,
+                const uint8_t* affinity, int size, int dil, float warmup, float* losses, float* g_logits, void* state,
+                void* workspace, size_t workspace_bytes, void* stream);
 size_t loss_ws_bytes(int N, int h, int w);
 
 static inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
@@ -36,6 +37,11 @@ const char* bxi_status_string(int status) {
 
 int bxi_last_hip_error(void) { return bxi::g_last_hip_error; }
 
+void bxi_set_launch_hook(bxi_launch_hook hook, void* user) {
+    bxi::g_hook_user = user;
+    bxi::g_hook = hook;
+}
+
 int bxi_check_device(int ordinal) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || ordinal < 0 || ordinal >= count) {
@@ -56,7 +62,7 @@ size_t bxi_boxinst_eval_workspace_bytes(int B, int Hc, int Wc, int stride, int N
     const int h = Hc / stride, w = Wc / stride;
     if (h <= 0 || w <= 0) return 0;
     const size_t P = (size_t)h * w;
-    return bxi::up256((size_t)B * 3 * P) + bxi::up256((size_t)B * P) + bxi::loss_ws_bytes(N, h, w);
+    return bxi::up256(sizeof(float) * (size_t)B * 3 * P) + bxi::loss_ws_bytes(N, h, w);
 }
 
 int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host, int size, int dilation,
@@ -74,14 +80,10 @@ int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances*
         return BXI_ERR_WORKSPACE;
     const size_t P = (size_t)inst_host->h * inst_host->w;
     char* base = (char*)workspace;
-    uint8_t* rgb_small = (uint8_t*)base;
-    uint8_t* aff = (uint8_t*)(base + bxi::up256((size_t)batch_host->B * 3 * P));
-    char* lws = (char*)aff + bxi::up256((size_t)batch_host->B * P);
-    int rc = bxi::launch_color_affinity(batch_host, stride, size, dilation, color_thresh, rgb_small, nullptr, aff,
-                                        stream);
-    if (rc != BXI_OK) return rc;
-    return bxi::launch_loss(inst_host, aff, size, dilation, warmup, losses, g_logits, state, lws,
-                            workspace_bytes - (size_t)(lws - base), stream);
+    float* lab = (float*)base;
+    char* lws = base + bxi::up256(sizeof(float) * (size_t)batch_host->B * 3 * P);
+    return bxi::launch_loss(batch_host, lab, color_thresh, inst_host, nullptr, size, dilation, warmup, losses,
+                            g_logits, state, lws, workspace_bytes - (size_t)(lws - base), stream);
 }
 
 }  // extern "C"

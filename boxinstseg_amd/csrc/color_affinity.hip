@@ -6,133 +6,74 @@
 //   get_bitmasks_from_boxes       condinst_head.py:1395-1448 (skimage rgb2lab on CPU, per-box loops)
 //   get_image_color_similarity    condinst_head.py:220-246  (two F.unfold materialisations)
 //
-// Kernel A  pool_rgb      : imgs [B,3,Hc,Wc] f32 -> rgb_small [B,3,h,w] u8
+// Kernel A  pool_rgb      : imgs [B,3,Hc,Wc] f32 -> lab [B,3,h,w] f32 (+ rgb_small [B,3,h,w] u8 on request)
 //     de-normalise (double mul, round to f32, double add, round to f32 = OpenCV's arithmetic on
 //     an f32 image with f64 scalars), truncate to u8, sum the stride x stride window, >> log2.
 //     Pure stream: 12 B read per input pixel (3 x f32), 3/stride^2 B written.  HBM roofline.
 //     One lane = one output pixel = `stride` rows x 16 B per channel, so a wave reads 1 KiB
 //     contiguous per load instruction; all 3*stride loads are issued before the first use.
-// Kernel B  affinity      : rgb_small -> Lab (fp64, LUT companding) in an LDS tile with halo ->
-//     8 (K) neighbour distances -> sim [B,K,h,w] f32 and/or K-bit threshold mask per pixel.
-//     Reads 3 B / pixel, writes 4K B / pixel (sim) + 1 B (mask): write-bound, tiny.
-#include "common.hpp"
-#include "srgb_lut.h"
+//     then rgb -> Lab per pooled pixel (skimage algorithm, fp64, LUT companding staged in LDS).
+//     In the fused evaluation this body runs inside stage1_kernel (mask_loss.hip), next to the
+//     logit-streaming workgroups; the stand-alone kernel here serves get_targets().
+// Kernel B  affinity      : Lab tile + halo in LDS -> K neighbour distances -> sim [B,K,h,w] f32
+//     and/or K-bit threshold mask per pixel.  Reads 12 B / pixel, writes 4K B / pixel (sim) +
+//     1 B (mask): write-bound, tiny.  Only get_targets() needs it: the fused loss derives the
+//     bits it needs from Lab inside box_kernel.
+#include "image_device.hpp"
 
 namespace bxi {
 
-struct ImageMeta {
-    int img_h[BXI_MAX_IMAGES];
-    int img_w[BXI_MAX_IMAGES];
-    int first_removed[BXI_MAX_IMAGES];  // rows >= this are zeroed in the validity mask
-};
-
-struct Denorm {
-    double mean[3], stdv[3];
-    int src_ch[3];  // output channel c (RGB) reads tensor channel src_ch[c]
-};
-
-__device__ __forceinline__ int denorm_u8(float x, double s, double m) {
-    // cv2.multiply(img_f32, std_f64) -> f32 ; cv2.add(img_f32, mean_f64) -> f32 ; astype(uint8)
-    float t = (float)((double)x * s);
-    float v = (float)((double)t + m);
-    return (int)v & 0xff;
-}
-
 // ---- Kernel A, stride 4, vector path ---------------------------------------------------------
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void pool_rgb_s4_kernel(const float* __restrict__ imgs, int B, int Hc, int Wc,
-                                                            ImageMeta meta, Denorm dn,
-                                                            uint8_t* __restrict__ out) {
-    const int h = Hc >> 2, w = Wc >> 2;
-    const int64_t total = (int64_t)B * h * w;
-    const int64_t o = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (o >= total) return;
-    const int c = (int)(o % w);
-    const int r = (int)((o / w) % h);
-    const int b = (int)(o / ((int64_t)w * h));
-    const int ih = meta.img_h[b], iw = meta.img_w[b];
-    const int64_t plane = (int64_t)Hc * Wc;
-    const float* base = imgs + (int64_t)b * 3 * plane + (int64_t)(4 * r) * Wc + 4 * c;
-
-    float4 v[3][4];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            v[ch][i] = *reinterpret_cast<const float4*>(base + dn.src_ch[ch] * plane + (int64_t)i * Wc);
-
-    const int x0 = 4 * c, y0 = 4 * r;
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const double s = dn.stdv[dn.src_ch[ch]], m = dn.mean[dn.src_ch[ch]];
-        int sum = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool yin = (y0 + i) < ih;
-            sum += (yin && x0 + 0 < iw) ? denorm_u8(v[ch][i].x, s, m) : 0;
-            sum += (yin && x0 + 1 < iw) ? denorm_u8(v[ch][i].y, s, m) : 0;
-            sum += (yin && x0 + 2 < iw) ? denorm_u8(v[ch][i].z, s, m) : 0;
-            sum += (yin && x0 + 3 < iw) ? denorm_u8(v[ch][i].w, s, m) : 0;
-        }
-        out[((int64_t)(b * 3 + ch) * h + r) * w + c] = (uint8_t)(sum >> 4);
-    }
+__global__ __launch_bounds__(256) void pool_rgb_s4_kernel(PoolArgs pa) {
+    __shared__ double lut[256];
+    lut[threadIdx.x] = kSrgbLut[threadIdx.x];
+    const int64_t total = (int64_t)pa.B * (pa.Hc >> 2) * (pa.Wc >> 2);
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    __syncthreads();
+    if (o < total) pool_pixel_s4(pa, o, lut);
 }
 
 // ---- Kernel A, any stride, scalar path (unaligned canvases, stride 1/2/8) ---------------------
-__global__ __launch_bounds__(256) void pool_rgb_generic_kernel(const float* __restrict__ imgs, int B, int Hc, int Wc,
-                                                               int stride, ImageMeta meta, Denorm dn,
-                                                               uint8_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void pool_rgb_generic_kernel(PoolArgs pa, int stride) {
+    const int Hc = pa.Hc, Wc = pa.Wc;
     const int h = Hc / stride, w = Wc / stride;
-    const int64_t total = (int64_t)B * h * w;
+    const int64_t total = (int64_t)pa.B * h * w;
     const int64_t plane = (int64_t)Hc * Wc;
+    const int64_t P = (int64_t)h * w;
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total;
          o += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(o % w);
         const int r = (int)((o / w) % h);
         const int b = (int)(o / ((int64_t)w * h));
-        const int ih = meta.img_h[b], iw = meta.img_w[b];
+        const int ih = pa.meta.img_h[b], iw = pa.meta.img_w[b];
+        int px[3];
         for (int ch = 0; ch < 3; ++ch) {
-            const int sc = dn.src_ch[ch];
-            const double s = dn.stdv[sc], m = dn.mean[sc];
-            const float* p = imgs + ((int64_t)b * 3 + sc) * plane;
+            const int sc = pa.dn.src_ch[ch];
+            const double s = pa.dn.stdv[sc], m = pa.dn.mean[sc];
+            const float* p = pa.imgs + ((int64_t)b * 3 + sc) * plane;
             float sum = 0.f;  // F.avg_pool2d accumulates in f32; exact for u8-valued inputs
             for (int i = 0; i < stride; ++i)
                 for (int j = 0; j < stride; ++j) {
                     const int y = r * stride + i, x = c * stride + j;
                     if (y < ih && x < iw) sum += (float)denorm_u8(p[(int64_t)y * Wc + x], s, m);
                 }
-            const float avg = sum / (float)(stride * stride);
-            out[((int64_t)(b * 3 + ch) * h + r) * w + c] = (uint8_t)(int)avg;
+            px[ch] = (int)(sum / (float)(stride * stride)) & 0xff;
+            if (pa.rgb_small) pa.rgb_small[((int64_t)b * 3 + ch) * P + (int64_t)r * w + c] = (uint8_t)px[ch];
+        }
+        if (pa.lab) {
+            float L, A, Bv;
+            rgb2lab_f32(kSrgbLut, px[0], px[1], px[2], L, A, Bv);
+            float* o3 = pa.lab + (int64_t)b * 3 * P + (int64_t)r * w + c;
+            o3[0] = L; o3[P] = A; o3[2 * P] = Bv;
         }
     }
 }
 
-// ---- Kernel B ---------------------------------------------------------------------------------
-__constant__ double kSrgbLut[256] = BXI_SRGB_LUT_INIT;
-
-// skimage.color.rgb2lab (rgb2xyz + xyz2lab, D65 / 2 deg) in fp64, no contraction, result to f32.
-__device__ __forceinline__ void rgb2lab_f32(int r8, int g8, int b8, float& L, float& A, float& Bv) {
-    const double r = kSrgbLut[r8], g = kSrgbLut[g8], b = kSrgbLut[b8];
-    double xyz[3];
-    const double M[3][3] = {{0.412453, 0.357580, 0.180423},
-                            {0.212671, 0.715160, 0.072169},
-                            {0.019334, 0.119193, 0.950227}};
-    const double white[3] = {0.95047, 1.0, 1.08883};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        double acc = __dadd_rn(__dadd_rn(__dmul_rn(M[i][0], r), __dmul_rn(M[i][1], g)), __dmul_rn(M[i][2], b));
-        double v = acc / white[i];
-        xyz[i] = v > 0.008856 ? cbrt(v) : __dadd_rn(__dmul_rn(7.787, v), 16.0 / 116.0);
-    }
-    L = (float)__dadd_rn(__dmul_rn(116.0, xyz[1]), -16.0);
-    A = (float)__dmul_rn(500.0, __dadd_rn(xyz[0], -xyz[1]));
-    Bv = (float)__dmul_rn(200.0, __dadd_rn(xyz[1], -xyz[2]));
-}
-
+// ---- Kernel B: Lab -> similarity / affinity bits ----------------------------------------------
 constexpr int kAffRows = 4, kAffCols = 64;  // output tile of the affinity kernel (256 threads)
 
 template <typename BitsT>
-__global__ __launch_bounds__(256) void affinity_kernel(const uint8_t* __restrict__ rgb_small, int B, int h, int w,
+__global__ __launch_bounds__(256) void affinity_kernel(const float* __restrict__ lab, int B, int h, int w,
                                                        int stride, int size, int dil, float thresh, ImageMeta meta,
                                                        const float* __restrict__ image_masks, int Hc, int Wc,
                                                        float* __restrict__ sim, BitsT* __restrict__ bits) {
@@ -152,21 +93,19 @@ __global__ __launch_bounds__(256) void affinity_kernel(const uint8_t* __restrict
     const int b = t / tiles_y;
     const int r0 = ty * kAffRows, c0 = tx * kAffCols;
     const int64_t P = (int64_t)h * w;
-    const uint8_t* src = rgb_small + (int64_t)b * 3 * P;
+    const float* src = lab + (int64_t)b * 3 * P;
     const int start = stride / 2;
-    const int ih = meta.img_h[b], iw = meta.img_w[b], fr = meta.first_removed[b];
 
     for (int i = threadIdx.x; i < TW * TH; i += blockDim.x) {
         const int rr = r0 - R + i / TW, cc = c0 - R + i % TW;
         float L = 0.f, A = 0.f, Bv = 0.f, m = 0.f;  // zero padding of F.unfold (condinst_head.py:203-207)
         if (rr >= 0 && rr < h && cc >= 0 && cc < w) {
             const int64_t p = (int64_t)rr * w + cc;
-            rgb2lab_f32(src[p], src[P + p], src[2 * P + p], L, A, Bv);
-            const int y = rr * stride + start, x = cc * stride + start;
+            L = src[p]; A = src[P + p]; Bv = src[2 * P + p];
             if (image_masks)
-                m = image_masks[((int64_t)b * Hc + y) * Wc + x];
+                m = image_masks[((int64_t)b * Hc + (rr * stride + start)) * Wc + (cc * stride + start)];
             else
-                m = (y < ih && x < iw && y < fr) ? 1.f : 0.f;  // condinst_head.py:1354-1369,1405
+                m = geom_mask(meta, b, rr, cc, stride);
         }
         labL[i] = L; labA[i] = A; labB[i] = Bv; msk[i] = m;
     }
@@ -184,9 +123,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(const uint8_t* __restrict
         for (int dx = -R; dx <= R; dx += dil) {
             if (dx == 0 && dy == 0) continue;
             const int qi = ci + dy * TW + dx;
-            const float dL = L0 - labL[qi], dA = A0 - labA[qi], dB = B0 - labB[qi];
-            const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(dL, dL), __fmul_rn(dA, dA)), __fmul_rn(dB, dB));
-            const float s = __fmul_rn(expf(__fmul_rn(-__fsqrt_rn(n2), 0.5f)), msk[qi]);  // :237,:246
+            const float s = color_sim(L0, A0, B0, labL[qi], labA[qi], labB[qi], msk[qi]);
             if (sim) sim[((int64_t)b * K + k) * P + (int64_t)r * w + c] = s;
             word |= (s >= thresh ? 1u : 0u) << k;                                            // :1324
             ++k;
@@ -230,48 +167,65 @@ int fill_image_meta(const bxi_image_batch* bt, ImageMeta& meta, Denorm& dn) {
     return BXI_OK;
 }
 
-int launch_color_affinity(const bxi_image_batch* bt, int stride, int size, int dil, float thresh, uint8_t* rgb_small,
-                          float* sim, void* affinity, void* stream) {
-    ImageMeta meta;
-    Denorm dn;
-    int st = fill_image_meta(bt, meta, dn);
+int fill_pool_args(const bxi_image_batch* bt, uint8_t* rgb_small, float* lab, PoolArgs& pa) {
+    int st = fill_image_meta(bt, pa.meta, pa.dn);
     if (st != BXI_OK) return st;
+    pa.imgs = bt->imgs; pa.B = bt->B; pa.Hc = bt->Hc; pa.Wc = bt->Wc;
+    pa.rgb_small = rgb_small; pa.lab = lab;
+    return BXI_OK;
+}
+
+bool pool_vec_ok(const bxi_image_batch* bt, int stride) {
+    return stride == 4 && (bt->Wc & 3) == 0 && (reinterpret_cast<uintptr_t>(bt->imgs) & 15) == 0;
+}
+
+int launch_pool(const bxi_image_batch* bt, int stride, uint8_t* rgb_small, float* lab, hipStream_t s) {
+    PoolArgs pa;
+    int st = fill_pool_args(bt, rgb_small, lab, pa);
+    if (st != BXI_OK) return st;
+    const int h = bt->Hc / stride, w = bt->Wc / stride;
+    const int64_t total = (int64_t)bt->B * h * w;
+    if (pool_vec_ok(bt, stride)) {
+        BXI_LAUNCH("pool_rgb", s, pool_rgb_s4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pa);
+    } else {
+        int64_t grid = (total + 255) / 256;
+        if (grid > 4096) grid = 4096;
+        BXI_LAUNCH("pool_rgb", s, pool_rgb_generic_kernel, dim3((unsigned)grid), dim3(256), 0, s, pa, stride);
+    }
+    return check_launch();
+}
+
+int launch_color_affinity(const bxi_image_batch* bt, int stride, int size, int dil, float thresh, float* lab,
+                          uint8_t* rgb_small, float* sim, void* affinity, void* stream) {
+    if (!bt) return BXI_ERR_NULL_POINTER;
     if (stride < 1 || size < 1 || (size & 1) == 0 || dil < 1) return BXI_ERR_BAD_ARGUMENT;
+    if (bt->B < 0 || bt->B > BXI_MAX_IMAGES || bt->Hc <= 0 || bt->Wc <= 0) return BXI_ERR_BAD_SHAPE;
     if (bt->Hc % stride || bt->Wc % stride) return BXI_ERR_BAD_SHAPE;  // asserts at condinst_head.py:1400-1401
     const int K = size * size - 1;
     if (affinity && K > 32) return BXI_ERR_UNSUPPORTED;
-    if (bt->B == 0) return BXI_OK;
-    if (!bt->imgs || !rgb_small) return BXI_ERR_NULL_POINTER;
+    if (bt->B == 0) { ImageMeta m; Denorm d; return fill_image_meta(bt, m, d); }
+    if (!bt->imgs || !lab) return BXI_ERR_NULL_POINTER;
     const int h = bt->Hc / stride, w = bt->Wc / stride;
     const int64_t total = (int64_t)bt->B * h * w;
     if (!fits_i32(total * (K > 3 ? K : 3))) return BXI_ERR_BAD_SHAPE;
     hipStream_t s = as_stream(stream);
-
-    const bool vec = stride == 4 && (reinterpret_cast<uintptr_t>(bt->imgs) & 15) == 0;
-    if (vec) {
-        constexpr int BLOCK = 64;  // one wave per workgroup: 1600 workgroups at 2x800x1024 -> even CU fill
-        hipLaunchKernelGGL((pool_rgb_s4_kernel<BLOCK>), dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
-                           s, bt->imgs, bt->B, bt->Hc, bt->Wc, meta, dn, rgb_small);
-    } else {
-        int64_t grid = (total + 255) / 256;
-        if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(pool_rgb_generic_kernel, dim3((unsigned)grid), dim3(256), 0, s, bt->imgs, bt->B, bt->Hc,
-                           bt->Wc, stride, meta, dn, rgb_small);
-    }
-    st = check_launch();
+    int st = launch_pool(bt, stride, rgb_small, lab, s);
     if (st != BXI_OK) return st;
     if (!sim && !affinity) return BXI_OK;
 
+    ImageMeta meta;
+    Denorm dn;
+    fill_image_meta(bt, meta, dn);
     const int R = size / 2 * dil;
     const size_t lds = sizeof(float) * 4 * (size_t)(kAffCols + 2 * R) * (size_t)(kAffRows + 2 * R);
     if (lds > 64 * 1024) return BXI_ERR_UNSUPPORTED;
     const int tiles = ((w + kAffCols - 1) / kAffCols) * ((h + kAffRows - 1) / kAffRows) * bt->B;
     if (K <= 8)
-        hipLaunchKernelGGL((affinity_kernel<uint8_t>), dim3(tiles), dim3(256), lds, s, rgb_small, bt->B, h, w, stride,
-                           size, dil, thresh, meta, bt->image_masks, bt->Hc, bt->Wc, sim, (uint8_t*)affinity);
+        BXI_LAUNCH("affinity", s, (affinity_kernel<uint8_t>), dim3(tiles), dim3(256), lds, s, lab, bt->B, h, w, stride,
+                   size, dil, thresh, meta, bt->image_masks, bt->Hc, bt->Wc, sim, (uint8_t*)affinity);
     else
-        hipLaunchKernelGGL((affinity_kernel<uint32_t>), dim3(tiles), dim3(256), lds, s, rgb_small, bt->B, h, w, stride,
-                           size, dil, thresh, meta, bt->image_masks, bt->Hc, bt->Wc, sim, (uint32_t*)affinity);
+        BXI_LAUNCH("affinity", s, (affinity_kernel<uint32_t>), dim3(tiles), dim3(256), lds, s, lab, bt->B, h, w, stride,
+                   size, dil, thresh, meta, bt->image_masks, bt->Hc, bt->Wc, sim, (uint32_t*)affinity);
     return check_launch();
 }
 
@@ -296,9 +250,9 @@ int fill_gt_table(const float* const* boxes_per_img_host, const int* gt_count_ho
 extern "C" {
 
 int bxi_color_affinity_f32(const bxi_image_batch* batch_host, int stride, int size, int dilation, float color_thresh,
-                           uint8_t* rgb_small, float* sim, void* affinity, void* stream) {
-    return bxi::launch_color_affinity(batch_host, stride, size, dilation, color_thresh, rgb_small, sim, affinity,
-                                      stream);
+                           float* lab, uint8_t* rgb_small, float* sim, void* affinity, void* stream) {
+    return bxi::launch_color_affinity(batch_host, stride, size, dilation, color_thresh, lab, rgb_small, sim,
+                                      affinity, stream);
 }
 
 int bxi_box_bitmasks_f32(const float* const* boxes_per_img_host, const int* gt_count_host, int B, int Hc, int Wc,
@@ -317,7 +271,7 @@ int bxi_box_bitmasks_f32(const float* const* boxes_per_img_host, const int* gt_c
     int gx = (int)((P + 255) / 256);
     if (gx > 1024) gx = 1024;
     if (G > 65535) return BXI_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(bxi::box_bitmask_kernel, dim3(gx, G), dim3(256), 0, bxi::as_stream(stream), gt, G, Hc, Wc,
+    BXI_LAUNCH("box_bitmask", bxi::as_stream(stream), bxi::box_bitmask_kernel, dim3(gx, G), dim3(256), 0, bxi::as_stream(stream), gt, G, Hc, Wc,
                        stride, start, h, w, out);
     return bxi::check_launch();
 }

@@ -24,6 +24,21 @@ inline int check_launch() {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// measurement hook (bxi_set_launch_hook): brackets one kernel launch
+extern bxi_launch_hook g_hook;
+extern void* g_hook_user;
+struct LaunchScope {
+    const char* name; hipStream_t s;
+    LaunchScope(const char* n, hipStream_t st) : name(n), s(st) { if (g_hook) g_hook(name, 0, (void*)s, g_hook_user); }
+    ~LaunchScope() { if (g_hook) g_hook(name, 1, (void*)s, g_hook_user); }
+};
+
+#define BXI_LAUNCH(label, stream, ...)                 \
+    do {                                               \
+        ::bxi::LaunchScope _scope(label, stream);      \
+        hipLaunchKernelGGL(__VA_ARGS__);               \
+    } while (0)
+
 inline bool fits_i32(int64_t v) { return v >= 0 && v <= 0x7fffffffLL; }
 
 // ---- device side ----------------------------------------------------------------------------

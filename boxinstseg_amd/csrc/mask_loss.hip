@@ -7,33 +7,25 @@
 //   weights = (sim >= thresh) * bitmask, normalise    :1324-1328
 //   warm-up                                           :1330-1332
 // and everything autograd does behind them (max backward, sigmoid backward, the op's atomicAdd
-// backward, ~1.3 GB of elementwise temporaries at 2x800x1024x32) with two launches:
-//
-// Kernel C  loss_main  (grid = N x ceil(h/TR) row tiles, 256 threads = 4 wave64)
-//   streams the logits once (float4 per lane, a wave = one 1 KiB row segment):
-//     - per-row max/arg-max of the logits by wave shuffles (complete inside the workgroup),
-//       per-column max/arg-max over the tile's rows -> one partial per tile (no atomics);
-//       max_p sigmoid(x_p) = sigmoid(max_p x_p), so sigmoid is applied to h+w maxima only;
-//     - only where the tile meets the instance's box dilated by `dilation` (~10 % of the map):
-//       sigmoid pairs (p, 1-p) staged in LDS with a `dilation` halo, 8-neighbour pairwise
-//       -log(p_i p_j + q_i q_j) and its gradient in gather form (symmetric pair, channel 7-k =
-//       opposite offset, so no atomics and a fixed summation order), weighted by the K-bit
-//       colour-affinity mask of the centre (bit k) and of the neighbour (bit 7-k);
-//     - writes the UN-normalised pairwise gradient (zeros outside the dilated box): every
-//       element of g_logits is written exactly once, as float4.
-//   HBM roofline: 4 B read + 4 B written per instance-pixel (+ <1 B of partials).
-// Kernel D  loss_finalize (grid = S x N)
-//   dice per instance from the h+w maxima, unit projection gradients at the arg-max positions,
-//   sum of the weight counts -> 1/max(sum W,1), rescale of the dilated-box region in place, the
-//   two loss scalars by the last-arriving workgroup (ticket), deterministic order.
-#include "common.hpp"
+// backward, ~1.3 GB of elementwise temporaries at 2x800x1024x32) with three launches, each
+// documented at its kernel below:
+//   stage1        { image pool + Lab } || { logit streaming: row/column maxima, zero-fill }   HBM stream
+//   box_kernel    colour-affinity bits + pairwise term and its gradient on the box tiles     latency bound
+//   loss_finalize dice, projection gradient at the arg-max positions, normalisation, scalars latency bound
+// Data layout in HBM: everything NCHW / row-major as the reference; per-pixel colour affinity is
+// never materialised as [N,8,h,w] -- box_kernel derives the 8-bit word it needs from Lab [B,3,h,w].
+#include "image_device.hpp"
 
 namespace bxi {
 
-constexpr int kTR = 8;          // rows per tile of loss_main
+constexpr int kSR = 16;         // rows per streaming tile (stage1): 4 rows per wave
+constexpr int kRW = kSR / 4;
 constexpr int kChunk = 256;     // columns per pass: 64 lanes x float4
+constexpr int kBR = 8;          // box tile rows    (box_kernel)
+constexpr int kBC = 64;         // box tile columns
 constexpr int kSlices = 4;      // row slices per instance in loss_finalize
 constexpr int kMaxDil = 8;
+constexpr int kMaxT = 32;       // per-instance column partials reduced per unrolled batch in loss_finalize
 
 struct InstArgs {
     const float* logits;
@@ -44,11 +36,11 @@ struct InstArgs {
 };
 
 struct LossWs {               // carved from the caller's workspace
-    float* colv;              // [N,T,w] per-tile column max (logit)
-    uint8_t* colr;            // [N,T,w] row offset of that max inside the tile
+    float* colv;              // [N,Ts,w] per-streaming-tile column max (logit)
+    uint8_t* colr;            // [N,Ts,w] row offset of that max inside the tile
     unsigned long long* rowkey;  // [N,h] packed (max logit, first column)
-    float* part_num;          // [N*T]
-    int* part_cnt;            // [N*T]
+    float* part_num;          // [N*Tr*Tc] per box tile: sum of W*pw
+    int* part_cnt;            // [N*Tr*Tc] per box tile: sum of W
     float* dice;              // [N]
     unsigned int* ticket;     // [1]
 };
@@ -62,18 +54,20 @@ struct LossState {            // kept for bxi_boxinst_loss_rescale_f32
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static inline int tiles_of(int h) { return (h + kTR - 1) / kTR; }
+static inline int stream_tiles(int h) { return (h + kSR - 1) / kSR; }
+static inline int box_tiles(int h, int w) { return ((h + kBR - 1) / kBR) * ((w + kBC - 1) / kBC); }
 
 static size_t carve_ws(void* base, int N, int h, int w, LossWs* ws) {
-    const size_t T = (size_t)tiles_of(h);
+    const size_t T = (size_t)stream_tiles(h);
+    const size_t TB = (size_t)box_tiles(h, w);
     size_t off = 0;
     char* p = (char*)base;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return p ? p + o : nullptr; };
     float* colv = (float*)take(sizeof(float) * N * T * w);
     uint8_t* colr = (uint8_t*)take((size_t)N * T * w);
     unsigned long long* rowkey = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)N * h);
-    float* part_num = (float*)take(sizeof(float) * N * T);
-    int* part_cnt = (int*)take(sizeof(int) * N * T);
+    float* part_num = (float*)take(sizeof(float) * N * TB);
+    int* part_cnt = (int*)take(sizeof(int) * N * TB);
     float* dice = (float*)take(sizeof(float) * (size_t)(N > 0 ? N : 1));
     unsigned int* ticket = (unsigned int*)take(sizeof(unsigned int));
     if (ws) { ws->colv = colv; ws->colr = colr; ws->rowkey = rowkey; ws->part_num = part_num;
@@ -144,74 +138,73 @@ __device__ __forceinline__ void store4(float* row, int c, int w, bool vec, float
     if (c + 3 < w) row[c + 3] = v.w;
 }
 
-// ---- Kernel C ----------------------------------------------------------------------------------
-// LDS: pq   [(kTR+2d)][w] float2   sigmoid pairs, tile rows + halo   (only when the tile meets the box)
-//      aff  [(kTR+2d)][w] uint8    affinity bits
-//      gt   [kTR][w]      float    gradient tile
-//      cbv  [4][kChunk]   float    per-wave column maxima, cbr [4][kChunk] int
-__global__ __launch_bounds__(256) void loss_main_kernel(InstArgs a, const uint8_t* __restrict__ affinity, int dil,
-                                                        LossWs ws, float* __restrict__ g_logits, int vec) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int T = (a.h + kTR - 1) / kTR;
-    const int n = blockIdx.x / T, t = blockIdx.x % T;
-    const int r0 = t * kTR, r1 = min(a.h, r0 + kTR);
-    const int w = a.w, h = a.h;
+// ================================================================================================
+// Kernel 1: stage1 = { pool_rgb + Lab workgroups }  ||  { logit streaming workgroups }
+// ================================================================================================
+// The two halves are independent (image side / logit side), so they share one launch: the grid is
+// n_pool workgroups of image work followed by N*Ts streaming workgroups, all resident at once.
+// Streaming workgroup (n, tile of kSR rows), 4 wave64, each wave owns kRW rows, a lane owns 4
+// consecutive columns (float4, a wave = 1 KiB contiguous):
+//   - issues all its row loads first, then (scalar path) looks the instance's box up;
+//   - row max / first arg-max: lane-local, then a 64-lane shuffle tree on a packed 64-bit key;
+//   - column max / first arg-max over the tile's rows: registers, then 4 waves through LDS,
+//     one partial per (tile, column) -- no atomics;
+//   - zero-fills d loss / d logits wherever no box tile of box_kernel will write.
+__device__ __forceinline__ bool seg_hit(const InstBox& ib, int r, int c) {
+    const int tr = r & ~(kBR - 1), tc = c & ~(kBC - 1);
+    return ib.any && tr < ib.dil.r1 && tr + kBR > ib.dil.r0 && tc < ib.dil.c1 && tc + kBC > ib.dil.c0;
+}
+
+__device__ __forceinline__ void stream_tile(const InstArgs& a, int dil, const LossWs& ws, float* __restrict__ g_logits,
+                                            int vec, int sb, float* cbv, int* cbr) {
+    const int h = a.h, w = a.w;
+    const int Ts = (h + kSR - 1) / kSR;
+    const int n = sb / Ts, t = sb % Ts;
+    const int r0 = t * kSR, r1 = min(h, r0 + kSR);
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int64_t P = (int64_t)h * w;
     const float* L = a.logits + (int64_t)n * P;
     float* G = g_logits ? g_logits + (int64_t)n * P : nullptr;
+    const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 
-    const InstBox ib = inst_box(a, n, dil);
-    const bool hit = ib.any && r0 < ib.dil.r1 && r1 > ib.dil.r0;   // wave-uniform (workgroup-uniform)
-
-    const int HR = kTR + 2 * dil;                                   // staged rows
-    float2* pq = reinterpret_cast<float2*>(smem);
-    float* gtile = reinterpret_cast<float*>(smem + sizeof(float2) * (size_t)HR * w);
-    float* cbv = gtile + (size_t)kTR * w;
-    int* cbr = reinterpret_cast<int*>(cbv + 4 * kChunk);
-    uint8_t* afl = reinterpret_cast<uint8_t*>(cbr + 4 * kChunk);
-
-    // ---- phase 1: stream the tile rows -----------------------------------------------------
-    unsigned long long rkey[kTR / 4];
+    float4 v[kRW];
+    {
+        const int c = lane * 4;
 #pragma unroll
-    for (int i = 0; i < kTR / 4; ++i) rkey[i] = 0ull;
+        for (int i = 0; i < kRW; ++i) {
+            const int r = r0 + wv + 4 * i;
+            v[i] = (r < r1 && c < w) ? load4(L + (int64_t)r * w, c, w, vec) : ninf;
+        }
+    }
+    const InstBox ib = inst_box(a, n, dil);   // two dependent scalar loads, overlapped with the row loads
 
-    for (int cb = 0; cb < w; cb += kChunk) {
+    unsigned long long rkey[kRW];
+#pragma unroll
+    for (int i = 0; i < kRW; ++i) rkey[i] = 0ull;
+
+    for (int cb = 0;;) {
         const int c = cb + lane * 4;
         float cmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int crow[4] = {r0, r0, r0, r0};
         if (c < w) {
 #pragma unroll
-            for (int i = 0; i < kTR / 4; ++i) {
+            for (int i = 0; i < kRW; ++i) {
                 const int r = r0 + wv + 4 * i;
                 if (r < r1) {
-                    const float4 v = load4(L + (int64_t)r * w, c, w, vec);
-                    // row arg-max, first column wins ties
-                    float m = v.x; int mc = c;
-                    if (v.y > m) { m = v.y; mc = c + 1; }
-                    if (v.z > m) { m = v.z; mc = c + 2; }
-                    if (v.w > m) { m = v.w; mc = c + 3; }
+                    float m = v[i].x; int mc = c;                       // first column wins ties
+                    if (v[i].y > m) { m = v[i].y; mc = c + 1; }
+                    if (v[i].z > m) { m = v[i].z; mc = c + 2; }
+                    if (v[i].w > m) { m = v[i].w; mc = c + 3; }
                     const unsigned long long key = pack_max(m, (uint32_t)mc);
                     rkey[i] = key > rkey[i] ? key : rkey[i];
-                    // column arg-max over this wave's rows (ascending r, strict > keeps the first)
-                    if (v.x > cmax[0]) { cmax[0] = v.x; crow[0] = r; }
-                    if (v.y > cmax[1]) { cmax[1] = v.y; crow[1] = r; }
-                    if (v.z > cmax[2]) { cmax[2] = v.z; crow[2] = r; }
-                    if (v.w > cmax[3]) { cmax[3] = v.w; crow[3] = r; }
-                    if (hit) {
-                        const int lr = r - r0 + dil;
-                        float2* dst = pq + (size_t)lr * w + c;
-                        if (c + 0 < w) dst[0] = sig_pair(v.x);
-                        if (c + 1 < w) dst[1] = sig_pair(v.y);
-                        if (c + 2 < w) dst[2] = sig_pair(v.z);
-                        if (c + 3 < w) dst[3] = sig_pair(v.w);
-                    } else if (G) {
-                        store4(G + (int64_t)r * w, c, w, vec, make_float4(0.f, 0.f, 0.f, 0.f));
-                    }
+                    if (v[i].x > cmax[0]) { cmax[0] = v[i].x; crow[0] = r; }   // ascending r, strict >
+                    if (v[i].y > cmax[1]) { cmax[1] = v[i].y; crow[1] = r; }
+                    if (v[i].z > cmax[2]) { cmax[2] = v[i].z; crow[2] = r; }
+                    if (v[i].w > cmax[3]) { cmax[3] = v[i].w; crow[3] = r; }
+                    if (G && !seg_hit(ib, r, c)) store4(G + (int64_t)r * w, c, w, vec, make_float4(0.f, 0.f, 0.f, 0.f));
                 }
             }
         }
-        // combine the 4 waves' column maxima through LDS
 #pragma unroll
         for (int j = 0; j < 4; ++j) { cbv[wv * kChunk + lane * 4 + j] = cmax[j]; cbr[wv * kChunk + lane * 4 + j] = crow[j]; }
         __syncthreads();
@@ -221,130 +214,264 @@ __global__ __launch_bounds__(256) void loss_main_kernel(InstArgs a, const uint8_
                 float m = cbv[tid]; int mr = cbr[tid];
 #pragma unroll
                 for (int q = 1; q < 4; ++q) {
-                    const float v = cbv[q * kChunk + tid]; const int vr = cbr[q * kChunk + tid];
-                    if (v > m || (v == m && vr < mr)) { m = v; mr = vr; }
+                    const float x = cbv[q * kChunk + tid]; const int xr = cbr[q * kChunk + tid];
+                    if (x > m || (x == m && xr < mr)) { m = x; mr = xr; }
                 }
-                const int64_t o = ((int64_t)n * T + t) * w + cc;
+                const int64_t o = ((int64_t)n * Ts + t) * w + cc;
                 ws.colv[o] = m;
                 ws.colr[o] = (uint8_t)(mr - r0);
             }
         }
+        cb += kChunk;
+        if (cb >= w) break;
         __syncthreads();
+        {
+            const int c2 = cb + lane * 4;
+#pragma unroll
+            for (int i = 0; i < kRW; ++i) {
+                const int r = r0 + wv + 4 * i;
+                v[i] = (r < r1 && c2 < w) ? load4(L + (int64_t)r * w, c2, w, vec) : ninf;
+            }
+        }
     }
 #pragma unroll
-    for (int i = 0; i < kTR / 4; ++i) {
+    for (int i = 0; i < kRW; ++i) {
         const int r = r0 + wv + 4 * i;
         const unsigned long long k = wave_max_u64(rkey[i]);
         if (lane == 0 && r < r1) ws.rowkey[(int64_t)n * h + r] = k;
     }
+    if (sb == 0 && tid == 0) *ws.ticket = 0u;   // consumed by loss_finalize two kernel boundaries later
+}
 
-    float num = 0.f;
-    int cnt = 0;
-    if (hit) {
-        // ---- phase 2a: halo rows + affinity bits + zero the gradient tile ---------------------
-        const uint8_t* AF = affinity + (int64_t)ib.img * P;
-        for (int i = tid; i < HR * (w / 4 + ((w & 3) ? 1 : 0)); i += 256) {
-            const int wq = (w + 3) / 4;
-            const int lr = i / wq, c = (i % wq) * 4;
-            const int r = r0 - dil + lr;
-            const bool own = lr >= dil && lr < dil + kTR;
-            if (r >= 0 && r < h) {
-                if (!own || r >= r1) {
-                    const float4 v = load4(L + (int64_t)r * w, c, w, vec);
-                    float2* dst = pq + (size_t)lr * w + c;
-                    if (c + 0 < w) dst[0] = sig_pair(v.x);
-                    if (c + 1 < w) dst[1] = sig_pair(v.y);
-                    if (c + 2 < w) dst[2] = sig_pair(v.z);
-                    if (c + 3 < w) dst[3] = sig_pair(v.w);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (c + j < w) afl[(size_t)lr * w + c + j] = AF[(int64_t)r * w + c + j];
-            }
-        }
-        for (int i = tid; i < kTR * w; i += 256) gtile[i] = 0.f;
+__global__ __launch_bounds__(256) void stage1_kernel(PoolArgs pa, int n_pool, InstArgs a, int dil, LossWs ws,
+                                                     float* __restrict__ g_logits, int vec) {
+    __shared__ __attribute__((aligned(16))) unsigned char sm[sizeof(float) * 4 * kChunk + sizeof(int) * 4 * kChunk];
+    if ((int)blockIdx.x < n_pool) {
+        double* lut = reinterpret_cast<double*>(sm);
+        lut[threadIdx.x] = kSrgbLut[threadIdx.x];
+        const int64_t total = (int64_t)pa.B * (pa.Hc >> 2) * (pa.Wc >> 2);
+        const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
         __syncthreads();
-
-        // ---- phase 2b: pairwise term on (tile rows) x (dilated box columns) -------------------
-        const int ra = max(r0, ib.dil.r0), rb = min(r1, ib.dil.r1);
-        const int cw = ib.dil.c1 - ib.dil.c0;
-        const int npx = (rb - ra) * cw;
-        for (int i = tid; i < npx; i += 256) {
-            const int r = ra + i / cw, c = ib.dil.c0 + i % cw;
-            const int lr = r - r0 + dil;
-            const float2 pp = pq[(size_t)lr * w + c];
-            const bool in_p = r >= ib.box.r0 && r < ib.box.r1 && c >= ib.box.c0 && c < ib.box.c1;
-            const uint32_t bits_p = in_p ? afl[(size_t)lr * w + c] : 0u;   // W[k,p] = bit k of p, p in box
-            float acc = 0.f;
-            int k = 0;
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    if (dx == 0 && dy == 0) continue;
-                    const int r2 = r + dy * dil, c2 = c + dx * dil;
-                    const uint32_t wp = (bits_p >> k) & 1u;
-                    cnt += (int)wp;                                          // weights.sum(), :1328
-                    if (r2 >= 0 && r2 < h && c2 >= 0 && c2 < w) {
-                        const int lr2 = lr + dy * dil;
-                        const bool in_q = r2 >= ib.box.r0 && r2 < ib.box.r1 && c2 >= ib.box.c0 && c2 < ib.box.c1;
-                        const uint32_t wq = in_q ? ((uint32_t)afl[(size_t)lr2 * w + c2] >> (7 - k)) & 1u : 0u;
-                        const uint32_t ws2 = wp + wq;
-                        if (ws2) {
-                            const float2 qq = pq[(size_t)lr2 * w + c2];
-                            const float S = pp.x * qq.x + pp.y * qq.y;      // P(y_p == y_q)
-                            float nl, coef;
-                            if (S > 1e-30f) {
-                                nl = -__logf(S);
-                                coef = -(qq.x - qq.y) * (pp.x * pp.y) * __frcp_rn(S);
-                            } else {   // |logit| beyond ~69: log-space evaluation as pairwise.cu:38-61
-                                const float xa = L[(int64_t)r * w + c], xb = L[(int64_t)r2 * w + c2];
-                                const float ax = logsig(xa), bx = logsig(-xa), ay = logsig(xb), by = logsig(-xb);
-                                const float e1 = ax + ay, e0 = bx + by;
-                                const float mx = fmaxf(e1, e0), df = fabsf(e1 - e0);
-                                nl = logsig(df) - mx;
-                                coef = -(expf(ay) - expf(by)) * expf(ax + bx + nl);
-                            }
-                            num += (float)wp * nl;
-                            acc += (float)ws2 * coef;
-                        }
-                    }
-                    ++k;
-                }
-            gtile[(size_t)(r - r0) * w + c] = acc;
-        }
-        __syncthreads();
-
-        // ---- phase 3: write the gradient tile ---------------------------------------------------
-        if (G) {
-            const int wq = (w + 3) / 4;
-            for (int i = tid; i < (r1 - r0) * wq; i += 256) {
-                const int lr = i / wq, c = (i % wq) * 4;
-                float4 v;
-                const float* src = gtile + (size_t)lr * w + c;
-                v.x = src[0];
-                v.y = c + 1 < w ? src[1] : 0.f;
-                v.z = c + 2 < w ? src[2] : 0.f;
-                v.w = c + 3 < w ? src[3] : 0.f;
-                store4(G + (int64_t)(r0 + lr) * w, c, w, vec, v);
-            }
-        }
-    }
-
-    // ---- block partials (fixed order: lanes by shuffle tree, waves 0..3) -------------------------
-    num = wave_sum_f32(num);
-    cnt = wave_sum_i32(cnt);
-    __syncthreads();
-    if (lane == 0) { cbv[wv] = num; cbr[wv] = cnt; }
-    __syncthreads();
-    if (tid == 0) {
-        ws.part_num[blockIdx.x] = (cbv[0] + cbv[1]) + (cbv[2] + cbv[3]);
-        ws.part_cnt[blockIdx.x] = cbr[0] + cbr[1] + cbr[2] + cbr[3];
-        if (blockIdx.x == 0) *ws.ticket = 0u;   // consumed by loss_finalize after the kernel boundary
+        if (o < total) pool_pixel_s4(pa, o, lut);
+    } else {
+        float* cbv = reinterpret_cast<float*>(sm);
+        int* cbr = reinterpret_cast<int*>(cbv + 4 * kChunk);
+        stream_tile(a, dil, ws, g_logits, vec, (int)blockIdx.x - n_pool, cbv, cbr);
     }
 }
 
-// ---- Kernel D ----------------------------------------------------------------------------------
+// ================================================================================================
+// Kernel 2: box_kernel -- pairwise term on the instance's (dilated) box, 8 x 64 pixel tiles
+// ================================================================================================
+// grid = N x ceil(h/8) x ceil(w/64); a workgroup whose tile misses the dilated box writes two
+// zero partials and exits (~85 % of them).  Otherwise:
+//   LDS  pq   [8+2d][64+2P]  (sigmoid(x), sigmoid(-x)) of the tile + halo            (P = d rounded up to 4)
+//        bits [8+2d][64+2P]  K-bit colour-affinity word of every in-box pixel of that region
+//        lab  [3][8+4d][64+2P2]  CIE-Lab of the tile + 2d halo (FROM_LAB)            (P2 = 2d rounded up to 4)
+//   1. all global loads are issued before the first LDS store (float4, aligned);
+//   2. affinity words from Lab (same arithmetic as affinity_kernel) or copied from `bits_in`;
+//   3. per pixel, 8 neighbours: S = p_i p_j + q_i q_j, -log S and its gradient, weighted by
+//      bit k of the pixel + bit 7-k of the neighbour (gather form: no atomics, fixed order);
+//   4. writes the UN-normalised pairwise gradient of the whole tile (zeros outside the dilated box).
+template <bool FROM_LAB>
+__global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __restrict__ lab, ImageMeta meta,
+                                                  const uint8_t* __restrict__ bits_in, float thresh, int dil, LossWs ws,
+                                                  float* __restrict__ g_logits, int vec) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float rnum[4];
+    __shared__ int rcnt[4];
+    const int h = a.h, w = a.w;
+    const int Tr = (h + kBR - 1) / kBR, Tc = (w + kBC - 1) / kBC;
+    int bi = blockIdx.x;
+    const int tcx = bi % Tc; bi /= Tc;
+    const int trx = bi % Tr;
+    const int n = bi / Tr;
+    const int r0 = trx * kBR, c0 = tcx * kBC;
+    const int tid = threadIdx.x;
+
+    const InstBox ib = inst_box(a, n, dil);
+    const bool hit = ib.any && r0 < ib.dil.r1 && r0 + kBR > ib.dil.r0 && c0 < ib.dil.c1 && c0 + kBC > ib.dil.c0;
+    if (!hit) {   // workgroup-uniform
+        if (tid == 0) { ws.part_num[blockIdx.x] = 0.f; ws.part_cnt[blockIdx.x] = 0; }
+        return;
+    }
+    const int64_t P = (int64_t)h * w;
+    const float* L = a.logits + (int64_t)n * P;
+    const int d = dil;
+    const int PAD = (d + 3) & ~3, PAD2 = (2 * d + 3) & ~3;
+    const int PR = kBR + 2 * d, PC = kBC + 2 * PAD;          // pq / bits region
+    const int LR = kBR + 4 * d, LC = kBC + 2 * PAD2;         // lab region
+    float2* pq = reinterpret_cast<float2*>(smem);
+    float* labs = reinterpret_cast<float*>(smem + sizeof(float2) * (size_t)PR * PC);
+    uint8_t* bits = smem + sizeof(float2) * (size_t)PR * PC + (FROM_LAB ? sizeof(float) * 3 * (size_t)LR * LC : 0);
+
+    // ---- 1. loads: logits region -> sigmoid pairs; Lab region (or bits) ---------------------------
+    {
+        const int q4 = PC / 4, items = PR * q4;
+        for (int base = tid; base < items; base += 256 * 2) {
+            float4 tmp[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = base + u * 256;
+                tmp[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < items) {
+                    const int lr = i / q4, r = r0 - d + lr, c = c0 - PAD + (i % q4) * 4;
+                    if (r >= 0 && r < h && c >= 0 && c < w) tmp[u] = load4(L + (int64_t)r * w, c, w, vec);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = base + u * 256;
+                if (i < items) {
+                    float2* dst = pq + (size_t)(i / q4) * PC + (i % q4) * 4;
+                    dst[0] = sig_pair(tmp[u].x); dst[1] = sig_pair(tmp[u].y);
+                    dst[2] = sig_pair(tmp[u].z); dst[3] = sig_pair(tmp[u].w);
+                }
+            }
+        }
+    }
+    if (FROM_LAB) {
+        const float* LB = lab + (int64_t)ib.img * 3 * P;
+        const int q4 = LC / 4, per = LR * q4, items = 3 * per;
+        for (int base = tid; base < items; base += 256 * 4) {
+            float4 tmp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * 256;
+                tmp[u] = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding of F.unfold
+                if (i < items) {
+                    const int ch = i / per, j = i % per;
+                    const int r = r0 - 2 * d + j / q4, c = c0 - PAD2 + (j % q4) * 4;
+                    if (r >= 0 && r < h && c >= 0 && c < w) {
+                        const float* row = LB + ch * P + (int64_t)r * w;
+                        if (vec) tmp[u] = *reinterpret_cast<const float4*>(row + c);
+                        else {
+                            tmp[u].x = row[c];
+                            tmp[u].y = c + 1 < w ? row[c + 1] : 0.f;
+                            tmp[u].z = c + 2 < w ? row[c + 2] : 0.f;
+                            tmp[u].w = c + 3 < w ? row[c + 3] : 0.f;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * 256;
+                if (i < items) *reinterpret_cast<float4*>(labs + (size_t)i * 4) = tmp[u];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. affinity words of the in-box pixels of the pq region -----------------------------------
+    {
+        const int bw = kBC + 2 * d, items = PR * bw;
+        const uint8_t* AF = FROM_LAB ? nullptr : bits_in + (int64_t)ib.img * P;
+        for (int i = tid; i < items; i += 256) {
+            const int lr = i / bw, lc = i % bw;
+            const int r = r0 - d + lr, c = c0 - d + lc;
+            uint32_t word = 0;
+            if (r >= ib.box.r0 && r < ib.box.r1 && c >= ib.box.c0 && c < ib.box.c1) {   // bitmask == 1, :1324-1325
+                if (FROM_LAB) {
+                    const int li = (lr + d) * LC + (lc - d + PAD2);     // same pixel in the lab region
+                    const float L0 = labs[li], A0 = labs[LR * LC + li], B0 = labs[2 * LR * LC + li];
+                    int k = 0;
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            if (dx == 0 && dy == 0) continue;
+                            const int r2 = r + dy * d, c2 = c + dx * d;
+                            float s = 0.f;                                // zero-padded mask => 0
+                            if (r2 >= 0 && r2 < h && c2 >= 0 && c2 < w) {
+                                const int qi = li + dy * d * LC + dx * d;
+                                s = color_sim(L0, A0, B0, labs[qi], labs[LR * LC + qi], labs[2 * LR * LC + qi],
+                                              geom_mask(meta, ib.img, r2, c2, a.stride));
+                            }
+                            word |= (s >= thresh ? 1u : 0u) << k;
+                            ++k;
+                        }
+                } else {
+                    word = AF[(int64_t)r * w + c];
+                }
+            }
+            bits[(size_t)lr * PC + (lc - d + PAD)] = (uint8_t)word;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. pairwise term, 2 pixels per thread -------------------------------------------------------
+    const int lr = tid >> 5, lc = (tid & 31) * 2;
+    const int r = r0 + lr;
+    float num = 0.f;
+    int cnt = 0;
+    float out[2] = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int c = c0 + lc + e;
+        if (r < ib.dil.r0 || r >= ib.dil.r1 || c < ib.dil.c0 || c >= ib.dil.c1) continue;
+        const int pi = (lr + d) * PC + (lc + e + PAD);
+        const float2 pp = pq[pi];
+        const uint32_t bits_p = bits[pi];
+        float acc = 0.f;
+        int k = 0;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                if (dx == 0 && dy == 0) continue;
+                const int r2 = r + dy * d, c2 = c + dx * d;
+                const uint32_t wp = (bits_p >> k) & 1u;
+                cnt += (int)wp;                                          // weights.sum(), :1328
+                if (r2 >= 0 && r2 < h && c2 >= 0 && c2 < w) {
+                    const int qi = pi + dy * d * PC + dx * d;
+                    const uint32_t wq = ((uint32_t)bits[qi] >> (7 - k)) & 1u;
+                    const uint32_t ws2 = wp + wq;
+                    if (ws2) {
+                        const float2 qq = pq[qi];
+                        const float S = pp.x * qq.x + pp.y * qq.y;      // P(y_p == y_q)
+                        float nl, coef;
+                        if (S > 1e-30f) {
+                            nl = -__logf(S);
+                            coef = -(qq.x - qq.y) * (pp.x * pp.y) * __frcp_rn(S);
+                        } else {   // |logit| beyond ~69: log-space evaluation as pairwise.cu:38-61
+                            const float xa = L[(int64_t)r * w + c], xb = L[(int64_t)r2 * w + c2];
+                            const float ax = logsig(xa), bx = logsig(-xa), ay = logsig(xb), by = logsig(-xb);
+                            const float e1 = ax + ay, e0 = bx + by;
+                            nl = logsig(fabsf(e1 - e0)) - fmaxf(e1, e0);
+                            coef = -(expf(ay) - expf(by)) * expf(ax + bx + nl);
+                        }
+                        num += (float)wp * nl;
+                        acc += (float)ws2 * coef;
+                    }
+                }
+                ++k;
+            }
+        out[e] = acc;
+    }
+    if (g_logits && r < h) {
+        float* G = g_logits + (int64_t)n * P + (int64_t)r * w + c0 + lc;
+        if (vec) {
+            if (c0 + lc < w) *reinterpret_cast<float2*>(G) = make_float2(out[0], out[1]);
+        } else {
+            if (c0 + lc < w) G[0] = out[0];
+            if (c0 + lc + 1 < w) G[1] = out[1];
+        }
+    }
+    // ---- block partials (fixed order) -------------------------------------------------------------------
+    num = wave_sum_f32(num);
+    cnt = wave_sum_i32(cnt);
+    if ((tid & 63) == 0) { rnum[tid >> 6] = num; rcnt[tid >> 6] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        ws.part_num[blockIdx.x] = (rnum[0] + rnum[1]) + (rnum[2] + rnum[3]);
+        ws.part_cnt[blockIdx.x] = rcnt[0] + rcnt[1] + rcnt[2] + rcnt[3];
+    }
+}
+
+// ================================================================================================
+// Kernel 3: loss_finalize (MODE 0) / loss_rescale (MODE 1), grid = kSlices x N
+// ================================================================================================
 __device__ __forceinline__ float block_sum_f32(float v, float* red) {
     v = wave_sum_f32(v);
     __syncthreads();
@@ -362,7 +489,13 @@ __device__ __forceinline__ double block_sum_f64(double v, double* red) {
 
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
 
-// MODE 0: finalize after loss_main.  MODE 1: rescale with device upstream gradients.
+// MODE 0: dice per instance from the h+w maxima, unit projection gradients at the arg-max
+//         positions, sum W -> normaliser, in-place rescale of the dilated-box region, loss scalars
+//         (ticket: the last-arriving instance sums the N dice values in index order).
+// MODE 1: fold arbitrary upstream gradients (device scalars) into the unit gradient; all
+//         workgroups exit at once when both are exactly 1.
+// Every global load of a phase is issued before its first use (the kernel is latency-, not
+// bandwidth-bound: it touches ~1 MB).
 template <int MODE>
 __global__ __launch_bounds__(256) void loss_finalize_kernel(InstArgs a, int dil, float warmup, LossWs ws, LossState st,
                                                             const float* __restrict__ up_prj,
@@ -381,19 +514,46 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(InstArgs a, int dil,
     int* carg = reinterpret_cast<int*>(grow + h);
     int* rarg = carg + w;
     float* G = g_logits ? g_logits + (int64_t)n * P : nullptr;
-    const InstBox ib = inst_box(a, n, dil);
 
     float dense_scale, sparse_scale;
+    InstBox ib;
+    unsigned int ticket_old = 0;
     if (MODE == 0) {
-        const int T = (h + kTR - 1) / kTR;
-        // column maxima: reduce the per-tile partials in tile order (first row wins ties)
+        const int Ts = (h + kSR - 1) / kSR;
+        const int NB = a.N * ((h + kBR - 1) / kBR) * ((w + kBC - 1) / kBC);
+        // ---- round 1: every load this phase needs, back to back ------------------------------------
+        double cnt = 0.0, numd = 0.0;
+        for (int base = tid; base < NB; base += 256 * 8) {
+            int pc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = base + u * 256; pc[u] = i < NB ? ws.part_cnt[i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cnt += (double)pc[u];            // exact (integers < 2^53)
+        }
+        if (s == 0 && n == 0)
+            for (int base = tid; base < NB; base += 256 * 8) {
+                float pn[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = base + u * 256; pn[u] = i < NB ? ws.part_num[i] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) numd += (double)pn[u];
+            }
+        ib = inst_box(a, n, dil);
         float ix = 0.f, ux = 0.f, iy = 0.f, uy = 0.f;
         for (int c = tid; c < w; c += 256) {
             float m = -INFINITY; int mr = 0;
-            for (int t = 0; t < T; ++t) {
-                const int64_t o = ((int64_t)n * T + t) * w + c;
-                const float v = ws.colv[o];
-                if (v > m) { m = v; mr = t * kTR + ws.colr[o]; }
+            for (int t0 = 0; t0 < Ts; t0 += kMaxT) {
+                float cv[kMaxT]; uint8_t cr[kMaxT];
+#pragma unroll
+                for (int u = 0; u < kMaxT; ++u) {
+                    const int t = t0 + u;
+                    const int64_t o = ((int64_t)n * Ts + (t < Ts ? t : 0)) * w + c;
+                    cv[u] = t < Ts ? ws.colv[o] : -INFINITY;
+                    cr[u] = t < Ts ? ws.colr[o] : (uint8_t)0;
+                }
+#pragma unroll
+                for (int u = 0; u < kMaxT; ++u)
+                    if (cv[u] > m) { m = cv[u]; mr = (t0 + u) * kSR + cr[u]; }   // tile order: first row wins ties
             }
             const float X = sigmoid_acc(m);
             const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
@@ -409,6 +569,18 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(InstArgs a, int dil,
         }
         const float Ix = block_sum_f32(ix, red32), Ux = block_sum_f32(ux, red32) + 1e-5f;
         const float Iy = block_sum_f32(iy, red32), Uy = block_sum_f32(uy, red32) + 1e-5f;
+        const float total = (float)block_sum_f64(cnt, red64);  // weights.sum() is an f32 in the reference
+        const float denom = fmaxf(total, 1.f);                 // .clamp(min=1.0), :1328
+        if (s == 0) {   // publish this instance's dice early: the ticket's round trip overlaps the passes below
+            const double numt = n == 0 ? block_sum_f64(numd, red64) : 0.0;
+            if (tid == 0) {
+                const float dice = (1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy);
+                __hip_atomic_store(&ws.dice[n], dice, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
+                if (n == 0) losses[1] = (float)(numt / (double)denom) * warmup;                      // :1327-1332
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ticket_old = __hip_atomic_fetch_add(ws.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         // dice = 1 - 2I/U ; d dice/d u_j = (-2 t_j U + 4 I u_j) / U^2 ; chain through sigmoid ; mean over N
         const float invN = 1.f / (float)a.N;
         for (int c = tid; c < w; c += 256) {
@@ -421,92 +593,87 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(InstArgs a, int dil,
             const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
             grow[r] = invN * ((-2.f * TY * Uy + 4.f * Iy * Y) / (Uy * Uy)) * Y * (1.f - Y);
         }
-        // sum of weights over the whole batch (integer, exact)
-        double cnt = 0.0;                                      // exact: integers well below 2^53
-        for (int i = tid; i < a.N * T; i += 256) cnt += (double)ws.part_cnt[i];
-        const float total = (float)block_sum_f64(cnt, red64);  // weights.sum() is an f32 in the reference
-        const float denom = fmaxf(total, 1.f);                 // .clamp(min=1.0), :1328
         dense_scale = warmup / denom;
         sparse_scale = 1.f;
         __syncthreads();
-        if (s == 0) {
-            if (st.colarg) {
-                for (int c = tid; c < w; c += 256) { st.colarg[(int64_t)n * w + c] = carg[c]; st.gcol[(int64_t)n * w + c] = gcol[c]; }
-                for (int r = tid; r < h; r += 256) { st.rowarg[(int64_t)n * h + r] = rarg[r]; st.grow[(int64_t)n * h + r] = grow[r]; }
-            }
-            // loss scalars: the last-arriving instance workgroup sums in index order (deterministic)
-            double numd = 0.0;
-            if (n == 0) for (int i = tid; i < a.N * T; i += 256) numd += (double)ws.part_num[i];
-            const double numt = block_sum_f64(numd, red64);
-            if (tid == 0) {
-                const float dice = (1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy);
-                __hip_atomic_store(&ws.dice[n], dice, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (n == 0) __hip_atomic_store(&losses[1], (float)(numt / (double)denom) * warmup, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned int old = __hip_atomic_fetch_add(ws.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last_flag = (old == (unsigned int)a.N - 1u);
-            }
-            __syncthreads();
-            if (last_flag) {
-                if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                __syncthreads();
-                float acc = 0.f;
-                for (int base = 0; base < a.N; base += 256) {
-                    if (base + tid < a.N)
-                        dbuf[tid] = __hip_atomic_load(&ws.dice[base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __syncthreads();
-                    if (tid == 0)
-                        for (int i = 0; i < min(256, a.N - base); ++i) acc += dbuf[i];
-                    __syncthreads();
-                }
-                if (tid == 0) losses[0] = acc / (float)a.N;   // .mean(), :143
-            }
+        if (s == 0 && st.colarg) {
+            for (int c = tid; c < w; c += 256) { st.colarg[(int64_t)n * w + c] = carg[c]; st.gcol[(int64_t)n * w + c] = gcol[c]; }
+            for (int r = tid; r < h; r += 256) { st.rowarg[(int64_t)n * h + r] = rarg[r]; st.grow[(int64_t)n * h + r] = grow[r]; }
         }
     } else {
         const float gp = *up_prj, gw = *up_pw;
         if (gp == 1.f && gw == 1.f) return;   // mmdet's _parse_losses sum: nothing to do
+        ib = inst_box(a, n, dil);
         for (int c = tid; c < w; c += 256) { carg[c] = st.colarg[(int64_t)n * w + c]; gcol[c] = st.gcol[(int64_t)n * w + c]; }
         for (int r = tid; r < h; r += 256) { rarg[r] = st.rowarg[(int64_t)n * h + r]; grow[r] = st.grow[(int64_t)n * h + r]; }
         dense_scale = gw;          // G <- gw*G + (gp-gw)*prj   (G currently = 1*pw + 1*prj)
         sparse_scale = gp - gw;
         __syncthreads();
     }
-    if (!G) return;
-    __syncthreads();
 
-    // ---- dense pass over this slice of the dilated box --------------------------------------------
-    const float sp_out = MODE == 0 ? 1.f : (sparse_scale + dense_scale);   // value outside the box: gp*prj
-    if (ib.any) {
-        const int rows = ib.dil.r1 - ib.dil.r0;
-        const int per = (rows + gridDim.x - 1) / gridDim.x;
-        const int ra = ib.dil.r0 + s * per, rb = min(ib.dil.r1, ra + per);
-        const int cw = ib.dil.c1 - ib.dil.c0;
-        const int npx = (rb - ra) * cw;
-        for (int i = tid; i < npx; i += 256) {
-            const int r = ra + i / cw, c = ib.dil.c0 + i % cw;
-            float v = G[(int64_t)r * w + c] * dense_scale;
-            float sp = 0.f;
-            if (carg[c] == r) sp += gcol[c];
-            if (rarg[r] == c) sp += grow[r];
-            G[(int64_t)r * w + c] = v + sp * sparse_scale;
-        }
-    }
-    // ---- sparse pass: arg-max positions outside the dilated box (the rest of the map is zero) ----
-    if (s == 0) {
-        for (int c = tid; c < w; c += 256) {
-            const int r = carg[c];
-            const bool in_d = ib.any && r >= ib.dil.r0 && r < ib.dil.r1 && c >= ib.dil.c0 && c < ib.dil.c1;
-            if (!in_d) {
-                float v = gcol[c];
-                if (rarg[r] == c) v += grow[r];
-                G[(int64_t)r * w + c] = v * sp_out;
+    if (G) {
+        // ---- dense pass over this slice of the dilated box (8 loads in flight per thread) -------------
+        const float sp_out = MODE == 0 ? 1.f : (sparse_scale + dense_scale);   // outside the box: gp * prj
+        if (ib.any) {
+            const int rows = ib.dil.r1 - ib.dil.r0;
+            const int per = (rows + gridDim.x - 1) / gridDim.x;
+            const int ra = ib.dil.r0 + s * per, rb = min(ib.dil.r1, ra + per);
+            const int cw = ib.dil.c1 - ib.dil.c0;
+            const int npx = (rb - ra) * cw;
+            for (int base = tid; base < npx; base += 256 * 8) {
+                float gv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = base + u * 256;
+                    gv[u] = i < npx ? G[(int64_t)(ra + i / cw) * w + ib.dil.c0 + i % cw] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = base + u * 256;
+                    if (i < npx) {
+                        const int r = ra + i / cw, c = ib.dil.c0 + i % cw;
+                        float sp = 0.f;
+                        if (carg[c] == r) sp += gcol[c];
+                        if (rarg[r] == c) sp += grow[r];
+                        G[(int64_t)r * w + c] = gv[u] * dense_scale + sp * sparse_scale;
+                    }
+                }
             }
         }
-        for (int r = tid; r < h; r += 256) {
-            const int c = rarg[r];
-            const bool in_d = ib.any && r >= ib.dil.r0 && r < ib.dil.r1 && c >= ib.dil.c0 && c < ib.dil.c1;
-            if (!in_d && carg[c] != r) G[(int64_t)r * w + c] = grow[r] * sp_out;
+        // ---- sparse pass: arg-max positions outside the dilated box (the rest of the map is zero) ------
+        if (s == 0) {
+            for (int c = tid; c < w; c += 256) {
+                const int r = carg[c];
+                const bool in_d = ib.any && r >= ib.dil.r0 && r < ib.dil.r1 && c >= ib.dil.c0 && c < ib.dil.c1;
+                if (!in_d) {
+                    float v = gcol[c];
+                    if (rarg[r] == c) v += grow[r];
+                    G[(int64_t)r * w + c] = v * sp_out;
+                }
+            }
+            for (int r = tid; r < h; r += 256) {
+                const int c = rarg[r];
+                const bool in_d = ib.any && r >= ib.dil.r0 && r < ib.dil.r1 && c >= ib.dil.c0 && c < ib.dil.c1;
+                if (!in_d && carg[c] != r) G[(int64_t)r * w + c] = grow[r] * sp_out;
+            }
+        }
+    }
+
+    if (MODE == 0 && s == 0) {
+        // ---- loss_prj: the last-arriving instance sums dice[0..N) in index order (deterministic) ---------
+        if (tid == 0) last_flag = (ticket_old == (unsigned int)a.N - 1u);
+        __syncthreads();
+        if (last_flag) {   // dice[] was stored write-through (sc1) and is read with agent-scope loads
+            float acc = 0.f;
+            for (int base = 0; base < a.N; base += 256) {
+                if (base + tid < a.N)
+                    dbuf[tid] = __hip_atomic_load(&ws.dice[base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                if (tid == 0)
+                    for (int i = 0; i < min(256, a.N - base); ++i) acc += dbuf[i];
+                __syncthreads();
+            }
+            if (tid == 0) losses[0] = acc / (float)a.N;   // .mean(), :143
         }
     }
 }
@@ -530,14 +697,22 @@ static int fill_inst(const bxi_instances* in, InstArgs& a) {
     return BXI_OK;
 }
 
-static size_t main_lds_bytes(int w, int dil) {
-    const size_t HR = kTR + 2 * dil;
-    return sizeof(float2) * HR * w + sizeof(float) * kTR * w + sizeof(float) * 4 * kChunk + sizeof(int) * 4 * kChunk +
-           HR * w;
+static size_t box_lds_bytes(int dil, bool from_lab) {
+    const size_t PAD = (dil + 3) & ~3, PAD2 = (2 * dil + 3) & ~3;
+    const size_t PR = kBR + 2 * dil, PC = kBC + 2 * PAD, LR = kBR + 4 * dil, LC = kBC + 2 * PAD2;
+    return sizeof(float2) * PR * PC + (from_lab ? sizeof(float) * 3 * LR * LC : 0) + PR * PC;
 }
 
-int launch_loss(const bxi_instances* in, const uint8_t* affinity, int size, int dil, float warmup, float* losses,
-                float* g_logits, void* state, void* workspace, size_t workspace_bytes, void* stream) {
+int fill_pool_args(const bxi_image_batch* bt, uint8_t* rgb_small, float* lab, PoolArgs& pa);
+int fill_image_meta(const bxi_image_batch* bt, ImageMeta& meta, Denorm& dn);
+bool pool_vec_ok(const bxi_image_batch* bt, int stride);
+int launch_pool(const bxi_image_batch* bt, int stride, uint8_t* rgb_small, float* lab, hipStream_t s);
+
+// One evaluation.  batch != NULL: image side included (lab is a [B,3,h,w] f32 scratch the pool
+// workgroups fill and box_kernel reads).  batch == NULL: `affinity` bits are given.
+int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, const bxi_instances* in,
+                const uint8_t* affinity, int size, int dil, float warmup, float* losses, float* g_logits, void* state,
+                void* workspace, size_t workspace_bytes, void* stream) {
     InstArgs a;
     int rc = fill_inst(in, a);
     if (rc != BXI_OK) return rc;
@@ -545,11 +720,22 @@ int launch_loss(const bxi_instances* in, const uint8_t* affinity, int size, int 
     if (size != 3 || dil > kMaxDil) return BXI_ERR_UNSUPPORTED;
     if (!losses) return BXI_ERR_NULL_POINTER;
     hipStream_t s = as_stream(stream);
+    PoolArgs pa = {};
+    ImageMeta meta = {};
+    const bool from_lab = batch != nullptr;
+    if (from_lab) {
+        if (batch->Hc != in->Hc || batch->Wc != in->Wc || batch->B != in->B) return BXI_ERR_BAD_SHAPE;
+        rc = fill_pool_args(batch, nullptr, lab, pa);
+        if (rc != BXI_OK) return rc;
+        meta = pa.meta;
+        if (batch->B > 0 && (!batch->imgs || !lab)) return BXI_ERR_NULL_POINTER;
+        if (batch->image_masks) return BXI_ERR_UNSUPPORTED;   // explicit masks: use bxi_color_affinity_f32 + bits
+    }
     if (a.N == 0) {
-        hipLaunchKernelGGL(zero_losses_kernel, dim3(1), dim3(1), 0, s, losses);
+        BXI_LAUNCH("zero_losses", s, zero_losses_kernel, dim3(1), dim3(1), 0, s, losses);
         return check_launch();
     }
-    if (!affinity) return BXI_ERR_NULL_POINTER;
+    if (!from_lab && !affinity) return BXI_ERR_NULL_POINTER;
     if (a.N > 65535) return BXI_ERR_BAD_SHAPE;
     const size_t need = carve_ws(nullptr, a.N, a.h, a.w, nullptr);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
@@ -560,22 +746,44 @@ int launch_loss(const bxi_instances* in, const uint8_t* affinity, int size, int 
         if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
         carve_state(state, a.N, a.h, a.w, &st);
     }
-    const size_t lds = main_lds_bytes(a.w, dil);
-    if (lds > 160 * 1024) return BXI_ERR_UNSUPPORTED;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(loss_main_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }
-    }
     const int vec = ((a.w & 3) == 0 && (reinterpret_cast<uintptr_t>(a.logits) & 15) == 0 &&
-                     (!g_logits || (reinterpret_cast<uintptr_t>(g_logits) & 15) == 0)) ? 1 : 0;
-    const int T = tiles_of(a.h);
-    hipLaunchKernelGGL(loss_main_kernel, dim3((unsigned)(a.N * T)), dim3(256), lds, s, a, affinity, dil, ws, g_logits, vec);
+                     (!g_logits || (reinterpret_cast<uintptr_t>(g_logits) & 15) == 0) &&
+                     (!lab || (reinterpret_cast<uintptr_t>(lab) & 15) == 0)) ? 1 : 0;
+
+    // ---- kernel 1: image pooling/Lab workgroups + logit streaming workgroups in one launch -----------
+    int n_pool = 0;
+    if (from_lab && batch->B > 0) {
+        if (pool_vec_ok(batch, a.stride)) {
+            const int64_t total = (int64_t)batch->B * a.h * a.w;
+            n_pool = (int)((total + 255) / 256);
+            n_pool = (n_pool + 7) & ~7;   // keep streaming tile i on XCD i % 8, like box tile i
+        } else {                           // unaligned canvas / other strides: separate scalar pooling launch
+            rc = launch_pool(batch, a.stride, nullptr, lab, s);
+            if (rc != BXI_OK) return rc;
+        }
+    }
+    const int n_stream = a.N * stream_tiles(a.h);
+    BXI_LAUNCH("stage1", s, stage1_kernel, dim3((unsigned)(n_pool + n_stream)), dim3(256), 0, s, pa, n_pool, a, dil, ws,
+               g_logits, vec);
     rc = check_launch();
     if (rc != BXI_OK) return rc;
+
+    // ---- kernel 2: pairwise term on the box tiles --------------------------------------------------------
+    const size_t lds = box_lds_bytes(dil, from_lab);
+    const int n_box = a.N * box_tiles(a.h, a.w);
+    if (from_lab)
+        BXI_LAUNCH("box", s, (box_kernel<true>), dim3((unsigned)n_box), dim3(256), lds, s, a, (const float*)lab, meta,
+                   (const uint8_t*)nullptr, color_thresh, dil, ws, g_logits, vec);
+    else
+        BXI_LAUNCH("box", s, (box_kernel<false>), dim3((unsigned)n_box), dim3(256), lds, s, a, (const float*)nullptr,
+                   meta, affinity, 0.f, dil, ws, g_logits, vec);
+    rc = check_launch();
+    if (rc != BXI_OK) return rc;
+
+    // ---- kernel 3: dice, normalisation, loss scalars -----------------------------------------------------
     const size_t lds_d = (sizeof(float) + sizeof(int)) * (size_t)(a.h + a.w);
-    hipLaunchKernelGGL((loss_finalize_kernel<0>), dim3(kSlices, a.N), dim3(256), lds_d, s, a, dil, warmup, ws, st,
-                       (const float*)nullptr, (const float*)nullptr, losses, g_logits);
+    BXI_LAUNCH("loss_finalize", s, (loss_finalize_kernel<0>), dim3(kSlices, a.N), dim3(256), lds_d, s, a, dil, warmup,
+               ws, st, (const float*)nullptr, (const float*)nullptr, losses, g_logits);
     return check_launch();
 }
 
@@ -592,8 +800,8 @@ int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_p
     carve_state(const_cast<void*>(state), a.N, a.h, a.w, &st);
     LossWs ws = {};
     const size_t lds_d = (sizeof(float) + sizeof(int)) * (size_t)(a.h + a.w);
-    hipLaunchKernelGGL((loss_finalize_kernel<1>), dim3(kSlices, a.N), dim3(256), lds_d, as_stream(stream), a, dil, 1.f,
-                       ws, st, g_prj, g_pw, (float*)nullptr, g_logits);
+    BXI_LAUNCH("loss_rescale", as_stream(stream), (loss_finalize_kernel<1>), dim3(kSlices, a.N), dim3(256), lds_d,
+               as_stream(stream), a, dil, 1.f, ws, st, g_prj, g_pw, (float*)nullptr, g_logits);
     return check_launch();
 }
 
@@ -616,8 +824,8 @@ size_t bxi_boxinst_loss_state_bytes(int N, int h, int w) {
 int bxi_boxinst_loss_fwd_bwd_f32(const bxi_instances* inst_host, const uint8_t* affinity, int size, int dilation,
                                  float warmup, float* losses, float* g_logits, void* state, void* workspace,
                                  size_t workspace_bytes, void* stream) {
-    return bxi::launch_loss(inst_host, affinity, size, dilation, warmup, losses, g_logits, state, workspace,
-                            workspace_bytes, stream);
+    return bxi::launch_loss(nullptr, nullptr, 0.f, inst_host, affinity, size, dilation, warmup, losses, g_logits, state,
+                            workspace, workspace_bytes, stream);
 }
 
 int bxi_boxinst_loss_rescale_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw, int dilation,

@@ -102,7 +102,7 @@ static int launch_fwd(const T* logits, int N, int H, int W, int size, int dil, T
     const int block = 256;
     int64_t grid = (total + block - 1) / block;
     if (grid > 256 * 64) grid = 256 * 64;  // 256 CUs x 8 waves/SIMD; grid-stride the rest
-    hipLaunchKernelGGL((pairwise_fwd_kernel<T>), dim3((unsigned)grid), dim3(block), 0, as_stream(stream), logits,
+    BXI_LAUNCH("pairwise_fwd", as_stream(stream), (pairwise_fwd_kernel<T>), dim3((unsigned)grid), dim3(block), 0, as_stream(stream), logits,
                        N, H, W, size, dil, out);
     return check_launch();
 }
@@ -119,7 +119,7 @@ static int launch_bwd(const T* logits, const T* g_pair, int N, int H, int W, int
     const int block = 256;
     int64_t grid = (total + block - 1) / block;
     if (grid > 256 * 64) grid = 256 * 64;
-    hipLaunchKernelGGL((pairwise_bwd_kernel<T>), dim3((unsigned)grid), dim3(block), 0, as_stream(stream), logits,
+    BXI_LAUNCH("pairwise_bwd", as_stream(stream), (pairwise_bwd_kernel<T>), dim3((unsigned)grid), dim3(block), 0, as_stream(stream), logits,
                        g_pair, N, H, W, size, dil, g_logits);
     return check_launch();
 }

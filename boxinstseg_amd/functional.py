@@ -121,7 +121,7 @@ def color_affinity(imgs: torch.Tensor, img_metas: Sequence[dict], *, out_stride:
                    pairwise_color_thresh: float = 0.3, want_similarity: bool = True, want_bits: bool = True,
                    image_masks: Optional[torch.Tensor] = None, denormalize: bool = True
                    ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], torch.Tensor]:
-    """-> (sim [B,K,h,w] f32 | None, bits [B,h,w] u8/int32 | None, rgb_small [B,3,h,w] u8)."""
+    """-> (sim [B,K,h,w] f32 | None, bits [B,h,w] u8/int32 | None, lab [B,3,h,w] f32)."""
     _require_cuda(imgs=imgs, image_masks=image_masks)
     batch = _Batch(imgs, img_metas, bottom_pixels_removed, image_masks, denormalize)
     B, Hc, Wc = batch.B, batch.Hc, batch.Wc
@@ -130,7 +130,7 @@ def color_affinity(imgs: torch.Tensor, img_metas: Sequence[dict], *, out_stride:
     h, w = Hc // out_stride, Wc // out_stride
     K = pairwise_size * pairwise_size - 1
     dev = imgs.device
-    rgb_small = torch.empty((B, 3, h, w), dtype=torch.uint8, device=dev)
+    lab = torch.empty((B, 3, h, w), dtype=torch.float32, device=dev)
     sim = torch.empty((B, K, h, w), dtype=torch.float32, device=dev) if want_similarity else None
     bits = None
     if want_bits:
@@ -138,9 +138,9 @@ def color_affinity(imgs: torch.Tensor, img_metas: Sequence[dict], *, out_stride:
     with torch.cuda.device(dev):
         _lib.check('bxi_color_affinity_f32', _lib.load().bxi_color_affinity_f32(
             C.byref(batch.struct), int(out_stride), int(pairwise_size), int(pairwise_dilation),
-            float(pairwise_color_thresh), rgb_small.data_ptr(), 0 if sim is None else sim.data_ptr(),
+            float(pairwise_color_thresh), lab.data_ptr(), 0, 0 if sim is None else sim.data_ptr(),
             0 if bits is None else bits.data_ptr(), _stream(dev)))
-    return sim, bits, rgb_small
+    return sim, bits, lab
 
 
 def box_bitmasks(gt_bboxes: Sequence[torch.Tensor], Hc: int, Wc: int, stride: int, start: int) -> torch.Tensor:

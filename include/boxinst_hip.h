@@ -52,6 +52,13 @@ int bxi_last_hip_error(void);
 /* 0 if device `ordinal` exists and is gfx950, BXI_ERR_NO_DEVICE otherwise. */
 int bxi_check_device(int ordinal);
 
+/* Measurement aid (bench.py): `hook(kernel_name, phase, stream, user)` is called on the host right
+ * before (phase 0) and right after (phase 1) each kernel launch this library enqueues, so the caller
+ * can bracket individual kernels with hipEvents on the launching stream.  NULL removes the hook.
+ * Process-wide; set it only while no other thread is inside the library. */
+typedef void (*bxi_launch_hook)(const char* kernel_name, int phase, void* stream, void* user);
+void bxi_set_launch_hook(bxi_launch_hook hook, void* user);
+
 /* ===========================================================================================
  * 1. Op level -- replaces the pybind11 module `pairwise_ext` (bind.cpp:15-36)
  * ===========================================================================================
@@ -103,16 +110,18 @@ typedef struct bxi_image_batch {
                                  img_h/img_w/rows_removed geometry as get_targets does            */
 } bxi_image_batch;
 
-/* Stage A: de-normalise + truncate to uint8 (:170-186) + stride x stride mean + .byte() (:1403,1413)
- *   rgb_small [B,3,h,w] uint8, h = Hc/stride.
- * Stage B: rgb2lab (skimage algorithm, fp64 -> f32, :1413-1416) + colour similarity (:220-246):
+/* Stage A (pool_rgb): de-normalise + truncate to uint8 (:170-186), stride x stride mean + .byte()
+ *   (:1403,1413), rgb2lab (skimage algorithm, fp64 -> f32, :1413-1416):
+ *   lab       [B,3,h,w] f32, h = Hc/stride   (required; also the scratch stage B reads)
+ *   rgb_small [B,3,h,w] uint8                (nullable)
+ * Stage B (affinity): colour similarity (:220-246):
  *   sim      [B,K,h,w] f32, K = size*size-1 (nullable: skip the 4*K bytes/pixel write)
  *   affinity [B,h,w]  bit k of the low K bits = (sim[k] >= color_thresh) (:1324); uint8 per pixel
  *            when K <= 8, uint32 when K <= 32 (nullable).
- * size must be odd; K <= 32 for `affinity`; stride in {1,2,4,8}.
+ * size must be odd; K <= 32 for `affinity`; any stride >= 1 dividing Hc and Wc.
  */
 int bxi_color_affinity_f32(const bxi_image_batch* batch_host, int stride, int size, int dilation,
-                           float color_thresh, uint8_t* rgb_small, float* sim, void* affinity,
+                           float color_thresh, float* lab, uint8_t* rgb_small, float* sim, void* affinity,
                            void* stream);
 
 /* Per-box bitmasks (:1426-1432): out [G, Hc/stride, Wc/stride] f32 in {0,1},
@@ -145,7 +154,7 @@ size_t bxi_boxinst_loss_state_bytes(int N, int h, int w);
 /* losses[0] = loss_prj, losses[1] = loss_pairwise (device, f32).
  * g_logits [N,1,h,w]: d(loss_prj + loss_pairwise)/d logits, i.e. the gradient for unit upstream
  *   gradients, fully overwritten (nullable: forward only).
- * affinity: output of bxi_color_affinity_f32 for the same size/dilation/threshold.
+ * affinity: the uint8 output of bxi_color_affinity_f32 for the same size/dilation/threshold.
  * warmup: min(_iter / pairwise_warmup, 1) (:1330-1331), evaluated on the host by the caller.
  * state (bxi_boxinst_loss_state_bytes): what bxi_boxinst_loss_rescale_f32 needs later
  *   (arg-max positions and unit projection gradients); nullable when g_logits is NULL.
@@ -163,8 +172,11 @@ int bxi_boxinst_loss_fwd_bwd_f32(const bxi_instances* inst_host, const uint8_t* 
 int bxi_boxinst_loss_rescale_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw,
                                  int dilation, const void* state, float* g_logits, void* stream);
 
-/* Whole evaluation in one host call = bxi_color_affinity_f32 (sim skipped) + bxi_boxinst_loss_fwd_bwd_f32.
- * workspace must hold bxi_boxinst_eval_workspace_bytes(...). */
+/* Whole evaluation in one host call, three launches: the image side (stage A above) runs inside the
+ * first loss kernel next to the logit streaming, and the affinity bits are derived from Lab where
+ * the loss needs them (nothing of stage B is materialised).  Same results as
+ * bxi_color_affinity_f32 + bxi_boxinst_loss_fwd_bwd_f32.  batch_host->image_masks must be NULL.
+ * workspace must hold bxi_boxinst_eval_workspace_bytes(...), 256-B aligned. */
 size_t bxi_boxinst_eval_workspace_bytes(int B, int Hc, int Wc, int stride, int N);
 int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host,
                          int size, int dilation, float color_thresh, float warmup,

@@ -123,7 +123,8 @@ def _check(d, dev, warmup=1.0, up=None, tol=TOL):
     assert rel(lw, ref['loss_pairwise']) <= tol or abs(lw - ref['loss_pairwise']) < 1e-7, (lw, ref['loss_pairwise'])
     err, ties = grad_report(grad, ref['grad'], d['mask_logits'][:, 0])
     assert err <= tol, f'grad err {err:.3e} ({ties} ambiguous arg-max lines excluded)'
-    assert ties <= 3
+    raw = float(np.abs(grad - ref['grad']).max() / np.abs(ref['grad']).max())
+    assert raw <= tol or ties > 0, f'raw grad err {raw:.3e} with no ambiguous arg-max line'
     return lp, lw
 
 
@@ -175,6 +176,23 @@ def test_loss_zero_instances_and_empty_image(dev):
     d2['gt_inds'] = np.array([0, 1, 1], np.int64)
     d2['mask_logits'] = d2['mask_logits'][:3]
     _check(d2, dev)
+
+
+def test_loss_from_precomputed_bits(dev):
+    """bxi_boxinst_loss_fwd_bwd_f32 (affinity bits given) == bxi_boxinst_eval_f32 (bits derived from Lab)."""
+    from boxinstseg_amd import boxinst_mask_loss, color_affinity
+    d = synthetic.make_batch(B=2, H=96, W=160, boxes_per_img=3, seed=12, img_shapes=[(96, 131), (70, 160)],
+                             ori_shapes=[(48, 66), (210, 480)], min_box=16, max_box=80)
+    t = to_dev(d, dev)
+    _, bits, _ = color_affinity(t['imgs'], d['img_metas'], want_similarity=False)
+    outs = []
+    for kw in (dict(affinity_bits=bits), dict(imgs=t['imgs'], img_metas=d['img_metas'])):
+        x = t['logits'].clone().requires_grad_(True)
+        o = boxinst_mask_loss(x, t['gt_inds'], t['gt_bboxes'], **kw)
+        (o['loss_prj'] + o['loss_pairwise']).backward()
+        outs.append((o['loss_prj'].item(), o['loss_pairwise'].item(), x.grad.clone()))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+    assert torch.equal(outs[0][2], outs[1][2])
 
 
 def test_deterministic(dev):

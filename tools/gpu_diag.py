@@ -43,7 +43,7 @@ inst = Fh._Inst(t['logits'], t['gt_inds'], t['gt_bboxes'], d['H'], d['W'], 4)
 losses = torch.empty(2, device=dev); grad = torch.empty_like(inst.logits)
 state = torch.empty(lib.bxi_boxinst_loss_state_bytes(inst.N, inst.h, inst.w), dtype=torch.uint8, device=dev)
 ws = torch.empty(lib.bxi_boxinst_eval_workspace_bytes(batch.B, d['H'], d['W'], 4, inst.N), dtype=torch.uint8, device=dev)
-rgb = torch.empty((2, 3, 200, 256), dtype=torch.uint8, device=dev); aff = torch.empty((2, 200, 256), dtype=torch.uint8, device=dev)
+rgb = torch.empty((2, 3, 200, 256), dtype=torch.float32, device=dev); aff = torch.empty((2, 200, 256), dtype=torch.uint8, device=dev)
 lws = torch.empty(lib.bxi_boxinst_loss_workspace_bytes(inst.N, inst.h, inst.w), dtype=torch.uint8, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 def ev_time(fn, n=200, warm=20):
@@ -55,7 +55,7 @@ def ev_time(fn, n=200, warm=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 f_eval = lambda: lib.bxi_boxinst_eval_f32(C.byref(batch.struct), C.byref(inst.struct), 3, 2, 0.3, 1.0, losses.data_ptr(), grad.data_ptr(), state.data_ptr(), ws.data_ptr(), ws.numel(), st)
-f_aff = lambda: lib.bxi_color_affinity_f32(C.byref(batch.struct), 4, 3, 2, 0.3, rgb.data_ptr(), 0, aff.data_ptr(), st)
+f_aff = lambda: lib.bxi_color_affinity_f32(C.byref(batch.struct), 4, 3, 2, 0.3, rgb.data_ptr(), 0, 0, aff.data_ptr(), st)
 f_loss = lambda: lib.bxi_boxinst_loss_fwd_bwd_f32(C.byref(inst.struct), aff.data_ptr(), 3, 2, 1.0, losses.data_ptr(), grad.data_ptr(), state.data_ptr(), lws.data_ptr(), lws.numel(), st)
 print('status', f_eval(), f_aff(), f_loss())
 t0 = time.perf_counter(); 
