@@ -26,11 +26,13 @@ namespace bxi {
 // ---- Kernel A, stride 4, vector path ---------------------------------------------------------
 __global__ __launch_bounds__(256) void pool_rgb_s4_kernel(PoolArgs pa) {
     __shared__ double lut[256];
-    lut[threadIdx.x] = kSrgbLut[threadIdx.x];
     const int64_t total = (int64_t)pa.B * (pa.Hc >> 2) * (pa.Wc >> 2);
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    PoolRegs pr;
+    if (o < total) pool_load_s4(pa, o, pr);
+    lut[threadIdx.x] = kSrgbLut[threadIdx.x];
     __syncthreads();
-    if (o < total) pool_pixel_s4(pa, o, lut);
+    if (o < total) pool_finish_s4(pa, o, pr, lut);
 }
 
 // ---- Kernel A, any stride, scalar path (unaligned canvases, stride 1/2/8) ---------------------

@@ -41,6 +41,20 @@ struct LaunchScope {
 
 inline bool fits_i32(int64_t v) { return v >= 0 && v <= 0x7fffffffLL; }
 
+// ---- developer tracing (-DBXI_TRACE builds only; never in the shipped library) ---------------
+// BXI_T(kernel_id, block, phase) stores the 100 MHz wall clock of lane 0 into a global buffer.
+#ifdef BXI_TRACE
+constexpr int kTraceBlocks = 8192, kTracePhases = 8;
+static __device__ long long* g_trace = nullptr;   // per translation unit
+#define BXI_T(kid, blk, ph)                                                                            \
+    do {                                                                                               \
+        if (threadIdx.x == 0 && g_trace && (blk) < ::bxi::kTraceBlocks)                                \
+            g_trace[((size_t)(kid) * ::bxi::kTraceBlocks + (blk)) * ::bxi::kTracePhases + (ph)] = wall_clock64(); \
+    } while (0)
+#else
+#define BXI_T(kid, blk, ph) do {} while (0)
+#endif
+
 // ---- device side ----------------------------------------------------------------------------
 // log sigmoid, the reference's formula (pairwise.cu:27-37) in the overflow-free arrangement
 // min(x,0) - log(1 + exp(-|x|)).

@@ -63,24 +63,32 @@ __device__ __forceinline__ void rgb2lab_f32(const double* lut, int r8, int g8, i
     Bv = (float)__dmul_rn(200.0, __dadd_rn(f[1], -f[2]));
 }
 
-// One pooled pixel of the stride-4 vector path: 3 channels x 4 rows x float4 (all 12 loads issued
-// before the first use), de-normalise, truncate, 4x4 sum >> 4, optional Lab.
-__device__ __forceinline__ void pool_pixel_s4(const PoolArgs& pa, int64_t o, const double* lut) {
+// One pooled pixel of the stride-4 vector path, in two halves so that the caller can put other
+// latency (staging the LUT in LDS) between issuing the 12 loads and consuming them:
+//   pool_load_s4  : 3 channels x 4 rows x float4, all issued back to back
+//   pool_finish_s4: de-normalise, truncate, 4x4 sum >> 4, optional Lab
+struct PoolRegs { float4 v[3][4]; };
+
+__device__ __forceinline__ void pool_load_s4(const PoolArgs& pa, int64_t o, PoolRegs& pr) {
+    const int h = pa.Hc >> 2, w = pa.Wc >> 2;
+    const int c = (int)(o % w);
+    const int r = (int)((o / w) % h);
+    const int b = (int)(o / ((int64_t)w * h));
+    const int64_t plane = (int64_t)pa.Hc * pa.Wc;
+    const float* base = pa.imgs + (int64_t)b * 3 * plane + (int64_t)(4 * r) * pa.Wc + 4 * c;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            pr.v[ch][i] = *reinterpret_cast<const float4*>(base + pa.dn.src_ch[ch] * plane + (int64_t)i * pa.Wc);
+}
+
+__device__ __forceinline__ void pool_finish_s4(const PoolArgs& pa, int64_t o, const PoolRegs& pr, const double* lut) {
     const int h = pa.Hc >> 2, w = pa.Wc >> 2;
     const int c = (int)(o % w);
     const int r = (int)((o / w) % h);
     const int b = (int)(o / ((int64_t)w * h));
     const int ih = pa.meta.img_h[b], iw = pa.meta.img_w[b];
-    const int64_t plane = (int64_t)pa.Hc * pa.Wc;
-    const float* base = pa.imgs + (int64_t)b * 3 * plane + (int64_t)(4 * r) * pa.Wc + 4 * c;
-
-    float4 v[3][4];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            v[ch][i] = *reinterpret_cast<const float4*>(base + pa.dn.src_ch[ch] * plane + (int64_t)i * pa.Wc);
-
     const int x0 = 4 * c, y0 = 4 * r;
     int px[3];
 #pragma unroll
@@ -90,10 +98,10 @@ __device__ __forceinline__ void pool_pixel_s4(const PoolArgs& pa, int64_t o, con
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool yin = (y0 + i) < ih;
-            sum += (yin && x0 + 0 < iw) ? denorm_u8(v[ch][i].x, s, m) : 0;
-            sum += (yin && x0 + 1 < iw) ? denorm_u8(v[ch][i].y, s, m) : 0;
-            sum += (yin && x0 + 2 < iw) ? denorm_u8(v[ch][i].z, s, m) : 0;
-            sum += (yin && x0 + 3 < iw) ? denorm_u8(v[ch][i].w, s, m) : 0;
+            sum += (yin && x0 + 0 < iw) ? denorm_u8(pr.v[ch][i].x, s, m) : 0;
+            sum += (yin && x0 + 1 < iw) ? denorm_u8(pr.v[ch][i].y, s, m) : 0;
+            sum += (yin && x0 + 2 < iw) ? denorm_u8(pr.v[ch][i].z, s, m) : 0;
+            sum += (yin && x0 + 3 < iw) ? denorm_u8(pr.v[ch][i].w, s, m) : 0;
         }
         px[ch] = sum >> 4;
     }

@@ -10,8 +10,11 @@
 // backward, ~1.3 GB of elementwise temporaries at 2x800x1024x32) with three launches, each
 // documented at its kernel below:
 //   stage1        { image pool + Lab } || { logit streaming: row/column maxima, zero-fill }   HBM stream
-//   box_kernel    colour-affinity bits + pairwise term and its gradient on the box tiles     latency bound
-//   loss_finalize dice, projection gradient at the arg-max positions, normalisation, scalars latency bound
+//   box_kernel    leaders: dice + projection gradient of each instance ; tiles: colour-affinity
+//                 bits + pairwise term and its un-normalised gradient on the box tiles       latency bound
+//   loss_scalars  the two loss values + the normaliser                                      one workgroup
+// and, in the backward, loss_apply (normalise the box tiles, add the projection gradient at the
+// h+w arg-max positions, fold the upstream gradients in from device memory).
 // Data layout in HBM: everything NCHW / row-major as the reference; per-pixel colour affinity is
 // never materialised as [N,8,h,w] -- box_kernel derives the 8-bit word it needs from Lab [B,3,h,w].
 #include "image_device.hpp"
@@ -23,7 +26,7 @@ constexpr int kRW = kSR / 4;
 constexpr int kChunk = 256;     // columns per pass: 64 lanes x float4
 constexpr int kBR = 8;          // box tile rows    (box_kernel)
 constexpr int kBC = 64;         // box tile columns
-constexpr int kSlices = 4;      // row slices per instance in loss_finalize
+constexpr int kSlices = 8;      // row slices per instance in loss_apply
 constexpr int kMaxDil = 8;
 constexpr int kMaxT = 32;       // per-instance column partials reduced per unrolled batch in loss_finalize
 
@@ -39,17 +42,32 @@ struct LossWs {               // carved from the caller's workspace
     float* colv;              // [N,Ts,w] per-streaming-tile column max (logit)
     uint8_t* colr;            // [N,Ts,w] row offset of that max inside the tile
     unsigned long long* rowkey;  // [N,h] packed (max logit, first column)
-    float* part_num;          // [N*Tr*Tc] per box tile: sum of W*pw
-    int* part_cnt;            // [N*Tr*Tc] per box tile: sum of W
+    unsigned long long* acc;  // [N,2] per instance: sum of W (integer) ; sum of W*pw in 2^-24 fixed point
+    struct InstRec* inst;     // [N]  box rectangle + image of every instance (written by stage1)
+    struct Pred* pred;        // [1]  colour-threshold predicate (written by stage1)
+    struct WorkRec* work;     // [N*Tr*Tc] compacted box tiles (written by stage1)
+    int* nwork;               // [1]
     float* dice;              // [N]
     unsigned int* ticket;     // [1]
 };
 
-struct LossState {            // kept for bxi_boxinst_loss_rescale_f32
+struct InstRec { int r0, r1, c0, c1, img, pad0, pad1, pad2; };   // 32 B: one load per workgroup
+struct WorkRec { int r0, r1, c0, c1, img, n, tile_r0, tile_c0; };  // box rectangle + the tile to process: 32 B
+
+// (sim >= thresh) for a valid neighbour, as a compare on the squared Lab distance:
+// exp(-0.5*sqrt(n2)) >= thresh  <=>  n2 <= n2max, with n2max found in stage1 by bisecting the exact
+// f32 expression of the reference over the float bit patterns (the expression is monotone in n2).
+struct Pred { float n2max; int fast; int zero_bit; int pad; };
+constexpr float kNumScale = 16777216.f;   // 2^24
+
+struct InstRec;
+struct LossState {            // what bxi_boxinst_loss_backward_f32 needs (forward -> backward)
     int* colarg;              // [N,w] arg-max row of column c
     int* rowarg;              // [N,h] arg-max column of row r
     float* gcol;              // [N,w] unit d loss_prj / d logit at (colarg[c], c)
     float* grow;              // [N,h] unit d loss_prj / d logit at (r, rowarg[r])
+    InstRec* inst;            // [N]   box rectangles
+    float* scale;             // [1]   warmup / max(sum W, 1)
 };
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -59,19 +77,21 @@ static inline int box_tiles(int h, int w) { return ((h + kBR - 1) / kBR) * ((w +
 
 static size_t carve_ws(void* base, int N, int h, int w, LossWs* ws) {
     const size_t T = (size_t)stream_tiles(h);
-    const size_t TB = (size_t)box_tiles(h, w);
     size_t off = 0;
     char* p = (char*)base;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return p ? p + o : nullptr; };
     float* colv = (float*)take(sizeof(float) * N * T * w);
     uint8_t* colr = (uint8_t*)take((size_t)N * T * w);
     unsigned long long* rowkey = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)N * h);
-    float* part_num = (float*)take(sizeof(float) * N * TB);
-    int* part_cnt = (int*)take(sizeof(int) * N * TB);
+    unsigned long long* acc = (unsigned long long*)take(sizeof(unsigned long long) * 2 * (size_t)(N > 0 ? N : 1));
+    InstRec* inst = (InstRec*)take(sizeof(InstRec) * (size_t)(N > 0 ? N : 1));
+    Pred* pred = (Pred*)take(sizeof(Pred));
+    WorkRec* work = (WorkRec*)take(sizeof(WorkRec) * (size_t)(N > 0 ? N : 1) * (size_t)box_tiles(h, w));
+    int* nwork = (int*)take(sizeof(int));
     float* dice = (float*)take(sizeof(float) * (size_t)(N > 0 ? N : 1));
     unsigned int* ticket = (unsigned int*)take(sizeof(unsigned int));
-    if (ws) { ws->colv = colv; ws->colr = colr; ws->rowkey = rowkey; ws->part_num = part_num;
-              ws->part_cnt = part_cnt; ws->dice = dice; ws->ticket = ticket; }
+    if (ws) { ws->colv = colv; ws->colr = colr; ws->rowkey = rowkey; ws->acc = acc; ws->inst = inst;
+              ws->pred = pred; ws->work = work; ws->nwork = nwork; ws->dice = dice; ws->ticket = ticket; }
     return off;
 }
 
@@ -83,7 +103,9 @@ static size_t carve_state(void* base, int N, int h, int w, LossState* st) {
     int* rowarg = (int*)take(sizeof(int) * (size_t)N * h);
     float* gcol = (float*)take(sizeof(float) * (size_t)N * w);
     float* grow = (float*)take(sizeof(float) * (size_t)N * h);
-    if (st) { st->colarg = colarg; st->rowarg = rowarg; st->gcol = gcol; st->grow = grow; }
+    InstRec* inst = (InstRec*)take(32 * (size_t)(N > 0 ? N : 1));
+    float* scale = (float*)take(sizeof(float));
+    if (st) { st->colarg = colarg; st->rowarg = rowarg; st->gcol = gcol; st->grow = grow; st->inst = inst; st->scale = scale; }
     return off;
 }
 
@@ -109,6 +131,19 @@ __device__ __forceinline__ InstBox inst_box(const InstArgs& a, int n, int dil) {
     if (ib.any) {
         ib.dil.r0 = max(ib.box.r0 - dil, 0); ib.dil.r1 = min(ib.box.r1 + dil, a.h);
         ib.dil.c0 = max(ib.box.c0 - dil, 0); ib.dil.c1 = min(ib.box.c1 + dil, a.w);
+    }
+    return ib;
+}
+
+__device__ __forceinline__ InstBox inst_from_rec(const InstRec& rc, int dil, int h, int w) {
+    InstBox ib;
+    ib.box.r0 = rc.r0; ib.box.r1 = rc.r1; ib.box.c0 = rc.c0; ib.box.c1 = rc.c1;
+    ib.img = rc.img;
+    ib.any = rc.r1 > rc.r0 && rc.c1 > rc.c0;
+    ib.dil = ib.box;
+    if (ib.any) {
+        ib.dil.r0 = max(rc.r0 - dil, 0); ib.dil.r1 = min(rc.r1 + dil, h);
+        ib.dil.c0 = max(rc.c0 - dil, 0); ib.dil.c1 = min(rc.c1 + dil, w);
     }
     return ib;
 }
@@ -155,8 +190,88 @@ __device__ __forceinline__ bool seg_hit(const InstBox& ib, int r, int c) {
     return ib.any && tr < ib.dil.r1 && tr + kBR > ib.dil.r0 && tc < ib.dil.c1 && tc + kBC > ib.dil.c0;
 }
 
-__device__ __forceinline__ void stream_tile(const InstArgs& a, int dil, const LossWs& ws, float* __restrict__ g_logits,
-                                            int vec, int sb, float* cbv, int* cbr) {
+// exact f32 predicate of the reference for a valid neighbour: exp(-||dLab|| * 0.5) >= thresh  (:237, :1324)
+__device__ __forceinline__ bool sim_pred(float n2, float thresh) {
+    return expf(__fmul_rn(-__fsqrt_rn(n2), 0.5f)) >= thresh;
+}
+
+__device__ __forceinline__ void make_pred(float thresh, Pred* out) {   // lane 0 of one wave
+    if ((threadIdx.x & 63) != 0) return;
+    Pred p; p.pad = 0; p.fast = 1;
+    p.zero_bit = (0.f >= thresh) ? 1 : 0;            // weight of a padded / masked-out neighbour (sim == 0)
+    // sim_pred(n2) is non-increasing in n2 >= 0 and positive floats order like their bit patterns:
+    // bisect the bit pattern for the largest n2 that still passes.
+    if (!sim_pred(0.f, thresh)) p.n2max = -1.f;                         // thresh > 1: never
+    else if (sim_pred(3.0e38f, thresh)) p.n2max = INFINITY;             // thresh <= 0 (exp underflows to 0): always
+    else {
+        uint32_t lo = 0u, hi = __float_as_uint(3.0e38f);                // pred(lo) true, pred(hi) false
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (sim_pred(__uint_as_float(mid), thresh)) lo = mid; else hi = mid;
+        }
+        p.n2max = __uint_as_float(lo);
+    }
+    *out = p;
+}
+
+// per-lane box lookup (lanes hold different instances): the image table is walked with a uniform
+// loop so that the by-value kernel argument is never indexed per lane.
+struct LaneBox { int r0, r1, c0, c1, img, tr0, ntr, tc0, ntc; };
+__device__ __forceinline__ LaneBox lane_box(const InstArgs& a, int dil, int m) {
+    LaneBox lb = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int64_t g = a.gt_inds[m];
+    const float* bp = nullptr;
+    for (int b = 0; b < a.gt.B; ++b)
+        if (g >= a.gt.first[b] && g < a.gt.first[b + 1]) { bp = a.gt.boxes[b] + 4 * (g - a.gt.first[b]); lb.img = b; }
+    if (!bp) return lb;
+    const Rect rc = box_rect(bp, a.Hc, a.Wc, a.stride, a.stride / 2, a.h, a.w);
+    if (rc.r1 <= rc.r0 || rc.c1 <= rc.c0) return lb;
+    lb.r0 = rc.r0; lb.r1 = rc.r1; lb.c0 = rc.c0; lb.c1 = rc.c1;
+    const int r0 = max(rc.r0 - dil, 0), r1 = min(rc.r1 + dil, a.h), c0 = max(rc.c0 - dil, 0), c1 = min(rc.c1 + dil, a.w);
+    lb.tr0 = r0 / kBR; lb.ntr = (r1 - 1) / kBR - r0 / kBR + 1;
+    lb.tc0 = c0 / kBC; lb.ntc = (c1 - 1) / kBC - c0 / kBC + 1;
+    return lb;
+}
+
+// One wave64 of instance n's first streaming workgroup: exclusive prefix of the box-tile counts of
+// instances 0..n-1 (deterministic order, no atomics, no pre-zeroed counter), then this instance's tiles.
+__device__ __forceinline__ void build_work_list(const InstArgs& a, int dil, const LossWs& ws, int n) {
+    const int lane = threadIdx.x & 63;
+    int base = 0, total = 0;
+    LaneBox mine = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m0 = 0; m0 < a.N; m0 += 64) {
+        const int m = m0 + lane;
+        LaneBox lb = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (m < a.N) lb = lane_box(a, dil, m);
+        const int cm = lb.ntr * lb.ntc;
+        int incl = cm;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (n >= m0 && n < m0 + 64) {
+            const int src = n - m0;
+            base = total + __shfl(incl - cm, src, 64);
+            mine.r0 = __shfl(lb.r0, src, 64); mine.r1 = __shfl(lb.r1, src, 64);
+            mine.c0 = __shfl(lb.c0, src, 64); mine.c1 = __shfl(lb.c1, src, 64); mine.img = __shfl(lb.img, src, 64);
+            mine.tr0 = __shfl(lb.tr0, src, 64); mine.ntr = __shfl(lb.ntr, src, 64);
+            mine.tc0 = __shfl(lb.tc0, src, 64); mine.ntc = __shfl(lb.ntc, src, 64);
+        }
+        total += __shfl(incl, 63, 64);
+    }
+    if (n == 0 && lane == 0) *ws.nwork = total;
+    const int cnt = mine.ntr * mine.ntc;
+    for (int i = lane; i < cnt; i += 64) {
+        WorkRec wr;
+        wr.r0 = mine.r0; wr.r1 = mine.r1; wr.c0 = mine.c0; wr.c1 = mine.c1; wr.img = mine.img; wr.n = n;
+        wr.tile_r0 = (mine.tr0 + i / mine.ntc) * kBR; wr.tile_c0 = (mine.tc0 + i % mine.ntc) * kBC;
+        ws.work[base + i] = wr;
+    }
+}
+
+__device__ __forceinline__ void stream_tile(const InstArgs& a, int dil, float thresh, const LossWs& ws,
+                                            float* __restrict__ g_logits, int vec, int sb, float* cbv, int* cbr) {
     const int h = a.h, w = a.w;
     const int Ts = (h + kSR - 1) / kSR;
     const int n = sb / Ts, t = sb % Ts;
@@ -176,7 +291,30 @@ __device__ __forceinline__ void stream_tile(const InstArgs& a, int dil, const Lo
             v[i] = (r < r1 && c < w) ? load4(L + (int64_t)r * w, c, w, vec) : ninf;
         }
     }
-    const InstBox ib = inst_box(a, n, dil);   // two dependent scalar loads, overlapped with the row loads
+    if (t == 0 && wv == 2) build_work_list(a, dil, ws, n);   // vector-load chain, overlaps the scalar one below
+    const InstBox ib = inst_box(a, n, dil);   // dependent scalar loads, overlapped with the row loads
+    if (t == 0 && tid == 0) {                 // publish for box_kernel / loss_apply (next launches)
+        InstRec rc; rc.r0 = ib.box.r0; rc.r1 = ib.box.r1; rc.c0 = ib.box.c0; rc.c1 = ib.box.c1; rc.img = ib.img;
+        rc.pad0 = rc.pad1 = rc.pad2 = 0;
+        ws.inst[n] = rc;
+        ws.acc[2 * n] = 0ull; ws.acc[2 * n + 1] = 0ull;
+    }
+    if (sb == 0) {
+        if (tid == 0) *ws.ticket = 0u;
+        if (wv == 1) make_pred(thresh, ws.pred);
+    }
+    // zero-fill first: it depends on the box only, so the stores overlap the row loads still in flight
+    if (G)
+        for (int cb = 0; cb < w; cb += kChunk) {
+            const int c = cb + lane * 4;
+            if (c < w) {
+#pragma unroll
+                for (int i = 0; i < kRW; ++i) {
+                    const int r = r0 + wv + 4 * i;
+                    if (r < r1 && !seg_hit(ib, r, c)) store4(G + (int64_t)r * w, c, w, vec, make_float4(0.f, 0.f, 0.f, 0.f));
+                }
+            }
+        }
 
     unsigned long long rkey[kRW];
 #pragma unroll
@@ -201,7 +339,6 @@ __device__ __forceinline__ void stream_tile(const InstArgs& a, int dil, const Lo
                     if (v[i].y > cmax[1]) { cmax[1] = v[i].y; crow[1] = r; }
                     if (v[i].z > cmax[2]) { cmax[2] = v[i].z; crow[2] = r; }
                     if (v[i].w > cmax[3]) { cmax[3] = v[i].w; crow[3] = r; }
-                    if (G && !seg_hit(ib, r, c)) store4(G + (int64_t)r * w, c, w, vec, make_float4(0.f, 0.f, 0.f, 0.f));
                 }
             }
         }
@@ -240,310 +377,87 @@ __device__ __forceinline__ void stream_tile(const InstArgs& a, int dil, const Lo
         const unsigned long long k = wave_max_u64(rkey[i]);
         if (lane == 0 && r < r1) ws.rowkey[(int64_t)n * h + r] = k;
     }
-    if (sb == 0 && tid == 0) *ws.ticket = 0u;   // consumed by loss_finalize two kernel boundaries later
 }
 
-__global__ __launch_bounds__(256) void stage1_kernel(PoolArgs pa, int n_pool, InstArgs a, int dil, LossWs ws,
-                                                     float* __restrict__ g_logits, int vec) {
+__global__ __launch_bounds__(256) void stage1_kernel(PoolArgs pa, int n_pool, InstArgs a, int dil, float thresh,
+                                                     LossWs ws, float* __restrict__ g_logits, int vec) {
     __shared__ __attribute__((aligned(16))) unsigned char sm[sizeof(float) * 4 * kChunk + sizeof(int) * 4 * kChunk];
+    BXI_T(0, blockIdx.x, 0);
     if ((int)blockIdx.x < n_pool) {
         double* lut = reinterpret_cast<double*>(sm);
-        lut[threadIdx.x] = kSrgbLut[threadIdx.x];
         const int64_t total = (int64_t)pa.B * (pa.Hc >> 2) * (pa.Wc >> 2);
         const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        PoolRegs pr;
+        if (o < total) pool_load_s4(pa, o, pr);          // 12 x 16 B per lane in flight ...
+        lut[threadIdx.x] = kSrgbLut[threadIdx.x];        // ... while the companding table is staged
         __syncthreads();
-        if (o < total) pool_pixel_s4(pa, o, lut);
+        if (o < total) pool_finish_s4(pa, o, pr, lut);
     } else {
         float* cbv = reinterpret_cast<float*>(sm);
         int* cbr = reinterpret_cast<int*>(cbv + 4 * kChunk);
-        stream_tile(a, dil, ws, g_logits, vec, (int)blockIdx.x - n_pool, cbv, cbr);
+        stream_tile(a, dil, thresh, ws, g_logits, vec, (int)blockIdx.x - n_pool, cbv, cbr);
     }
+    BXI_T(0, blockIdx.x, 1);
 }
 
 // ================================================================================================
-// Kernel 2: box_kernel -- pairwise term on the instance's (dilated) box, 8 x 64 pixel tiles
+// Kernel 2: box_kernel -- N leader workgroups (projection term) + pairwise term on 8 x 64 box tiles
 // ================================================================================================
-// grid = N x ceil(h/8) x ceil(w/64); a workgroup whose tile misses the dilated box writes two
-// zero partials and exits (~85 % of them).  Otherwise:
-//   LDS  pq   [8+2d][64+2P]  (sigmoid(x), sigmoid(-x)) of the tile + halo            (P = d rounded up to 4)
-//        bits [8+2d][64+2P]  K-bit colour-affinity word of every in-box pixel of that region
-//        lab  [3][8+4d][64+2P2]  CIE-Lab of the tile + 2d halo (FROM_LAB)            (P2 = 2d rounded up to 4)
-//   1. all global loads are issued before the first LDS store (float4, aligned);
-//   2. affinity words from Lab (same arithmetic as affinity_kernel) or copied from `bits_in`;
-//   3. per pixel, 8 neighbours: S = p_i p_j + q_i q_j, -log S and its gradient, weighted by
-//      bit k of the pixel + bit 7-k of the neighbour (gather form: no atomics, fixed order);
-//   4. writes the UN-normalised pairwise gradient of the whole tile (zeros outside the dilated box).
-template <bool FROM_LAB>
-__global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __restrict__ lab, ImageMeta meta,
-                                                  const uint8_t* __restrict__ bits_in, float thresh, int dil, LossWs ws,
-                                                  float* __restrict__ g_logits, int vec) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ float rnum[4];
-    __shared__ int rcnt[4];
-    const int h = a.h, w = a.w;
-    const int Tr = (h + kBR - 1) / kBR, Tc = (w + kBC - 1) / kBC;
-    int bi = blockIdx.x;
-    const int tcx = bi % Tc; bi /= Tc;
-    const int trx = bi % Tr;
-    const int n = bi / Tr;
-    const int r0 = trx * kBR, c0 = tcx * kBC;
-    const int tid = threadIdx.x;
-
-    const InstBox ib = inst_box(a, n, dil);
-    const bool hit = ib.any && r0 < ib.dil.r1 && r0 + kBR > ib.dil.r0 && c0 < ib.dil.c1 && c0 + kBC > ib.dil.c0;
-    if (!hit) {   // workgroup-uniform
-        if (tid == 0) { ws.part_num[blockIdx.x] = 0.f; ws.part_cnt[blockIdx.x] = 0; }
-        return;
-    }
-    const int64_t P = (int64_t)h * w;
-    const float* L = a.logits + (int64_t)n * P;
-    const int d = dil;
-    const int PAD = (d + 3) & ~3, PAD2 = (2 * d + 3) & ~3;
-    const int PR = kBR + 2 * d, PC = kBC + 2 * PAD;          // pq / bits region
-    const int LR = kBR + 4 * d, LC = kBC + 2 * PAD2;         // lab region
-    float2* pq = reinterpret_cast<float2*>(smem);
-    float* labs = reinterpret_cast<float*>(smem + sizeof(float2) * (size_t)PR * PC);
-    uint8_t* bits = smem + sizeof(float2) * (size_t)PR * PC + (FROM_LAB ? sizeof(float) * 3 * (size_t)LR * LC : 0);
-
-    // ---- 1. loads: logits region -> sigmoid pairs; Lab region (or bits) ---------------------------
-    {
-        const int q4 = PC / 4, items = PR * q4;
-        for (int base = tid; base < items; base += 256 * 2) {
-            float4 tmp[2];
+// grid = N + N x ceil(h/8) x ceil(w/64).
+// Leader workgroup n (blockIdx < N): reduces stage1's per-tile column partials and row keys of
+//   instance n to the h+w maxima, applies sigmoid to those only (max sigmoid = sigmoid max), forms
+//   the two dice terms (condinst_head.py:117-143) and the unit projection gradient at each arg-max
+//   position (kept in `state` for the backward).  Runs concurrently with the tile workgroups.
+// Tile workgroups take their (instance, tile) from the compacted work list stage1 built, so the
+// working ones are the first of the grid and start together; the rest exit after one scalar load.
+//   LDS  pq   [8+2d][64+2P]     (sigmoid(x), sigmoid(-x)) of the tile + halo         (P = d rounded up to 4)
+//        lab  [3][8+2d][64+2P]  CIE-Lab of the same region (FROM_LAB) | bits [8+2d][64+2P] (!FROM_LAB)
+//   1. all global loads (logits region, Lab region) are issued together, float4, aligned;
+//   2. per pixel, 8 neighbours (operands prefetched from LDS, branch-free): colour affinity of the
+//      pair from ||dLab||^2 (threshold predicate, see Pred; the two directions share the distance),
+//      S = p_i p_j + q_i q_j, -log S and its gradient, weighted by W[k,p] + W[7-k,q]
+//      (gather form: no atomics on the gradient, fixed summation order);
+//   3. writes the UN-normalised pairwise gradient of the whole tile (zeros outside the dilated box)
+//      and adds its integer partial sums to the instance's accumulators.
+__device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int i = base + u * 256;
-                tmp[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < items) {
-                    const int lr = i / q4, r = r0 - d + lr, c = c0 - PAD + (i % q4) * 4;
-                    if (r >= 0 && r < h && c >= 0 && c < w) tmp[u] = load4(L + (int64_t)r * w, c, w, vec);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int i = base + u * 256;
-                if (i < items) {
-                    float2* dst = pq + (size_t)(i / q4) * PC + (i % q4) * 4;
-                    dst[0] = sig_pair(tmp[u].x); dst[1] = sig_pair(tmp[u].y);
-                    dst[2] = sig_pair(tmp[u].z); dst[3] = sig_pair(tmp[u].w);
-                }
-            }
-        }
-    }
-    if (FROM_LAB) {
-        const float* LB = lab + (int64_t)ib.img * 3 * P;
-        const int q4 = LC / 4, per = LR * q4, items = 3 * per;
-        for (int base = tid; base < items; base += 256 * 4) {
-            float4 tmp[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * 256;
-                tmp[u] = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding of F.unfold
-                if (i < items) {
-                    const int ch = i / per, j = i % per;
-                    const int r = r0 - 2 * d + j / q4, c = c0 - PAD2 + (j % q4) * 4;
-                    if (r >= 0 && r < h && c >= 0 && c < w) {
-                        const float* row = LB + ch * P + (int64_t)r * w;
-                        if (vec) tmp[u] = *reinterpret_cast<const float4*>(row + c);
-                        else {
-                            tmp[u].x = row[c];
-                            tmp[u].y = c + 1 < w ? row[c + 1] : 0.f;
-                            tmp[u].z = c + 2 < w ? row[c + 2] : 0.f;
-                            tmp[u].w = c + 3 < w ? row[c + 3] : 0.f;
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * 256;
-                if (i < items) *reinterpret_cast<float4*>(labs + (size_t)i * 4) = tmp[u];
-            }
-        }
-    }
+    for (int k = 0; k < 4; ++k) v[k] = wave_sum_f32(v[k]);
     __syncthreads();
-
-    // ---- 2. affinity words of the in-box pixels of the pq region -----------------------------------
-    {
-        const int bw = kBC + 2 * d, items = PR * bw;
-        const uint8_t* AF = FROM_LAB ? nullptr : bits_in + (int64_t)ib.img * P;
-        for (int i = tid; i < items; i += 256) {
-            const int lr = i / bw, lc = i % bw;
-            const int r = r0 - d + lr, c = c0 - d + lc;
-            uint32_t word = 0;
-            if (r >= ib.box.r0 && r < ib.box.r1 && c >= ib.box.c0 && c < ib.box.c1) {   // bitmask == 1, :1324-1325
-                if (FROM_LAB) {
-                    const int li = (lr + d) * LC + (lc - d + PAD2);     // same pixel in the lab region
-                    const float L0 = labs[li], A0 = labs[LR * LC + li], B0 = labs[2 * LR * LC + li];
-                    int k = 0;
+    if ((threadIdx.x & 63) == 0)
 #pragma unroll
-                    for (int dy = -1; dy <= 1; ++dy)
+        for (int k = 0; k < 4; ++k) red[(threadIdx.x >> 6) * 4 + k] = v[k];
+    __syncthreads();
 #pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            if (dx == 0 && dy == 0) continue;
-                            const int r2 = r + dy * d, c2 = c + dx * d;
-                            float s = 0.f;                                // zero-padded mask => 0
-                            if (r2 >= 0 && r2 < h && c2 >= 0 && c2 < w) {
-                                const int qi = li + dy * d * LC + dx * d;
-                                s = color_sim(L0, A0, B0, labs[qi], labs[LR * LC + qi], labs[2 * LR * LC + qi],
-                                              geom_mask(meta, ib.img, r2, c2, a.stride));
-                            }
-                            word |= (s >= thresh ? 1u : 0u) << k;
-                            ++k;
-                        }
-                } else {
-                    word = AF[(int64_t)r * w + c];
-                }
-            }
-            bits[(size_t)lr * PC + (lc - d + PAD)] = (uint8_t)word;
-        }
-    }
-    __syncthreads();
-
-    // ---- 3. pairwise term, 2 pixels per thread -------------------------------------------------------
-    const int lr = tid >> 5, lc = (tid & 31) * 2;
-    const int r = r0 + lr;
-    float num = 0.f;
-    int cnt = 0;
-    float out[2] = {0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int c = c0 + lc + e;
-        if (r < ib.dil.r0 || r >= ib.dil.r1 || c < ib.dil.c0 || c >= ib.dil.c1) continue;
-        const int pi = (lr + d) * PC + (lc + e + PAD);
-        const float2 pp = pq[pi];
-        const uint32_t bits_p = bits[pi];
-        float acc = 0.f;
-        int k = 0;
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                if (dx == 0 && dy == 0) continue;
-                const int r2 = r + dy * d, c2 = c + dx * d;
-                const uint32_t wp = (bits_p >> k) & 1u;
-                cnt += (int)wp;                                          // weights.sum(), :1328
-                if (r2 >= 0 && r2 < h && c2 >= 0 && c2 < w) {
-                    const int qi = pi + dy * d * PC + dx * d;
-                    const uint32_t wq = ((uint32_t)bits[qi] >> (7 - k)) & 1u;
-                    const uint32_t ws2 = wp + wq;
-                    if (ws2) {
-                        const float2 qq = pq[qi];
-                        const float S = pp.x * qq.x + pp.y * qq.y;      // P(y_p == y_q)
-                        float nl, coef;
-                        if (S > 1e-30f) {
-                            nl = -__logf(S);
-                            coef = -(qq.x - qq.y) * (pp.x * pp.y) * __frcp_rn(S);
-                        } else {   // |logit| beyond ~69: log-space evaluation as pairwise.cu:38-61
-                            const float xa = L[(int64_t)r * w + c], xb = L[(int64_t)r2 * w + c2];
-                            const float ax = logsig(xa), bx = logsig(-xa), ay = logsig(xb), by = logsig(-xb);
-                            const float e1 = ax + ay, e0 = bx + by;
-                            nl = logsig(fabsf(e1 - e0)) - fmaxf(e1, e0);
-                            coef = -(expf(ay) - expf(by)) * expf(ax + bx + nl);
-                        }
-                        num += (float)wp * nl;
-                        acc += (float)ws2 * coef;
-                    }
-                }
-                ++k;
-            }
-        out[e] = acc;
-    }
-    if (g_logits && r < h) {
-        float* G = g_logits + (int64_t)n * P + (int64_t)r * w + c0 + lc;
-        if (vec) {
-            if (c0 + lc < w) *reinterpret_cast<float2*>(G) = make_float2(out[0], out[1]);
-        } else {
-            if (c0 + lc < w) G[0] = out[0];
-            if (c0 + lc + 1 < w) G[1] = out[1];
-        }
-    }
-    // ---- block partials (fixed order) -------------------------------------------------------------------
-    num = wave_sum_f32(num);
-    cnt = wave_sum_i32(cnt);
-    if ((tid & 63) == 0) { rnum[tid >> 6] = num; rcnt[tid >> 6] = cnt; }
-    __syncthreads();
-    if (tid == 0) {
-        ws.part_num[blockIdx.x] = (rnum[0] + rnum[1]) + (rnum[2] + rnum[3]);
-        ws.part_cnt[blockIdx.x] = rcnt[0] + rcnt[1] + rcnt[2] + rcnt[3];
-    }
-}
-
-// ================================================================================================
-// Kernel 3: loss_finalize (MODE 0) / loss_rescale (MODE 1), grid = kSlices x N
-// ================================================================================================
-__device__ __forceinline__ float block_sum_f32(float v, float* red) {
-    v = wave_sum_f32(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
-__device__ __forceinline__ double block_sum_f64(double v, double* red) {
-    v = wave_sum_f64(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
+    for (int k = 0; k < 4; ++k) v[k] = (red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]);
 }
 
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
 
-// MODE 0: dice per instance from the h+w maxima, unit projection gradients at the arg-max
-//         positions, sum W -> normaliser, in-place rescale of the dilated-box region, loss scalars
-//         (ticket: the last-arriving instance sums the N dice values in index order).
-// MODE 1: fold arbitrary upstream gradients (device scalars) into the unit gradient; all
-//         workgroups exit at once when both are exactly 1.
-// Every global load of a phase is issued before its first use (the kernel is latency-, not
-// bandwidth-bound: it touches ~1 MB).
-template <int MODE>
-__global__ __launch_bounds__(256) void loss_finalize_kernel(InstArgs a, int dil, float warmup, LossWs ws, LossState st,
-                                                            const float* __restrict__ up_prj,
-                                                            const float* __restrict__ up_pw,
-                                                            float* __restrict__ losses, float* __restrict__ g_logits) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ double red64[4];
-    __shared__ float red32[4];
-    __shared__ int last_flag;
-    __shared__ float dbuf[256];
-    const int n = blockIdx.y, s = blockIdx.x;
+__device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const LossWs& ws, const LossState& st, int n,
+                                             unsigned char* smem, float* red) {
     const int h = a.h, w = a.w, tid = threadIdx.x;
-    const int64_t P = (int64_t)h * w;
-    float* gcol = reinterpret_cast<float*>(smem);
-    float* grow = gcol + w;
-    int* carg = reinterpret_cast<int*>(grow + h);
-    int* rarg = carg + w;
-    float* G = g_logits ? g_logits + (int64_t)n * P : nullptr;
-
-    float dense_scale, sparse_scale;
-    InstBox ib;
-    unsigned int ticket_old = 0;
-    if (MODE == 0) {
-        const int Ts = (h + kSR - 1) / kSR;
-        const int NB = a.N * ((h + kBR - 1) / kBR) * ((w + kBC - 1) / kBC);
-        // ---- round 1: every load this phase needs, back to back ------------------------------------
-        double cnt = 0.0, numd = 0.0;
-        for (int base = tid; base < NB; base += 256 * 8) {
-            int pc[8];
+    const int Ts = (h + kSR - 1) / kSR;
+    float* xs = reinterpret_cast<float*>(smem);   // [w] column maxima (as sigmoid), then their gradients
+    float* ys = xs + w;                           // [h]
+    // ---- every global load of the first batch is issued before the first use -----------------------------
+    const InstRec rec = ws.inst[n];
+    float cv[kMaxT]; uint8_t cr[kMaxT];
+    {
+        const int c = tid < w ? tid : 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = base + u * 256; pc[u] = i < NB ? ws.part_cnt[i] : 0; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) cnt += (double)pc[u];            // exact (integers < 2^53)
+        for (int u = 0; u < kMaxT; ++u) {
+            const int64_t o = ((int64_t)n * Ts + (u < Ts ? u : 0)) * w + c;
+            cv[u] = u < Ts ? ws.colv[o] : -INFINITY;
+            cr[u] = u < Ts ? ws.colr[o] : (uint8_t)0;
         }
-        if (s == 0 && n == 0)
-            for (int base = tid; base < NB; base += 256 * 8) {
-                float pn[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { const int i = base + u * 256; pn[u] = i < NB ? ws.part_num[i] : 0.f; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) numd += (double)pn[u];
-            }
-        ib = inst_box(a, n, dil);
-        float ix = 0.f, ux = 0.f, iy = 0.f, uy = 0.f;
-        for (int c = tid; c < w; c += 256) {
-            float m = -INFINITY; int mr = 0;
-            for (int t0 = 0; t0 < Ts; t0 += kMaxT) {
-                float cv[kMaxT]; uint8_t cr[kMaxT];
+    }
+    const unsigned long long rk0 = ws.rowkey[(int64_t)n * h + (tid < h ? tid : 0)];
+    const InstBox ib = inst_from_rec(rec, dil, h, w);
+    float sums[4] = {0.f, 0.f, 0.f, 0.f};   // I_x, U_x, I_y, U_y
+    for (int c = tid; c < w; c += 256) {
+        float m = -INFINITY; int mr = 0;
+        for (int t0 = 0; t0 < Ts; t0 += kMaxT) {
+            if (c >= 256 || t0 > 0) {                 // beyond the prefetched batch (w > 256 or > kMaxT tiles)
 #pragma unroll
                 for (int u = 0; u < kMaxT; ++u) {
                     const int t = t0 + u;
@@ -551,129 +465,374 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(InstArgs a, int dil,
                     cv[u] = t < Ts ? ws.colv[o] : -INFINITY;
                     cr[u] = t < Ts ? ws.colr[o] : (uint8_t)0;
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < kMaxT; ++u)
-                    if (cv[u] > m) { m = cv[u]; mr = (t0 + u) * kSR + cr[u]; }   // tile order: first row wins ties
-            }
-            const float X = sigmoid_acc(m);
-            const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
-            gcol[c] = X; carg[c] = mr;
-            ix += X * TX; ux += X * X + TX * TX;
+            for (int u = 0; u < kMaxT; ++u)
+                if (cv[u] > m) { m = cv[u]; mr = (t0 + u) * kSR + cr[u]; }   // tile order: first row wins ties
         }
-        for (int r = tid; r < h; r += 256) {
-            const unsigned long long k = ws.rowkey[(int64_t)n * h + r];
-            const float Y = sigmoid_acc(unpack_val(k));
-            const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
-            grow[r] = Y; rarg[r] = (int)unpack_idx(k);
-            iy += Y * TY; uy += Y * Y + TY * TY;
-        }
-        const float Ix = block_sum_f32(ix, red32), Ux = block_sum_f32(ux, red32) + 1e-5f;
-        const float Iy = block_sum_f32(iy, red32), Uy = block_sum_f32(uy, red32) + 1e-5f;
-        const float total = (float)block_sum_f64(cnt, red64);  // weights.sum() is an f32 in the reference
-        const float denom = fmaxf(total, 1.f);                 // .clamp(min=1.0), :1328
-        if (s == 0) {   // publish this instance's dice early: the ticket's round trip overlaps the passes below
-            const double numt = n == 0 ? block_sum_f64(numd, red64) : 0.0;
-            if (tid == 0) {
-                const float dice = (1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy);
-                __hip_atomic_store(&ws.dice[n], dice, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
-                if (n == 0) losses[1] = (float)(numt / (double)denom) * warmup;                      // :1327-1332
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                ticket_old = __hip_atomic_fetch_add(ws.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+        const float X = sigmoid_acc(m);
+        const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
+        xs[c] = X;
+        if (st.colarg) st.colarg[(int64_t)n * w + c] = mr;
+        sums[0] += X * TX; sums[1] += X * X + TX * TX;
+    }
+    for (int r = tid; r < h; r += 256) {
+        const unsigned long long k = r < 256 ? rk0 : ws.rowkey[(int64_t)n * h + r];
+        const float Y = sigmoid_acc(unpack_val(k));
+        const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
+        ys[r] = Y;
+        if (st.rowarg) st.rowarg[(int64_t)n * h + r] = (int)unpack_idx(k);
+        sums[2] += Y * TY; sums[3] += Y * Y + TY * TY;
+    }
+    block_sum4(sums, red);
+    const float Ix = sums[0], Ux = sums[1] + 1e-5f, Iy = sums[2], Uy = sums[3] + 1e-5f;
+    if (tid == 0) ws.dice[n] = (1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy);   // :130, summed over both axes :143
+    if (st.gcol) {
         // dice = 1 - 2I/U ; d dice/d u_j = (-2 t_j U + 4 I u_j) / U^2 ; chain through sigmoid ; mean over N
         const float invN = 1.f / (float)a.N;
         for (int c = tid; c < w; c += 256) {
-            const float X = gcol[c];
+            const float X = xs[c];
             const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
-            gcol[c] = invN * ((-2.f * TX * Ux + 4.f * Ix * X) / (Ux * Ux)) * X * (1.f - X);
+            st.gcol[(int64_t)n * w + c] = invN * ((-2.f * TX * Ux + 4.f * Ix * X) / (Ux * Ux)) * X * (1.f - X);
         }
         for (int r = tid; r < h; r += 256) {
-            const float Y = grow[r];
+            const float Y = ys[r];
             const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
-            grow[r] = invN * ((-2.f * TY * Uy + 4.f * Iy * Y) / (Uy * Uy)) * Y * (1.f - Y);
+            st.grow[(int64_t)n * h + r] = invN * ((-2.f * TY * Uy + 4.f * Iy * Y) / (Uy * Uy)) * Y * (1.f - Y);
         }
-        dense_scale = warmup / denom;
-        sparse_scale = 1.f;
-        __syncthreads();
-        if (s == 0 && st.colarg) {
-            for (int c = tid; c < w; c += 256) { st.colarg[(int64_t)n * w + c] = carg[c]; st.gcol[(int64_t)n * w + c] = gcol[c]; }
-            for (int r = tid; r < h; r += 256) { st.rowarg[(int64_t)n * h + r] = rarg[r]; st.grow[(int64_t)n * h + r] = grow[r]; }
-        }
-    } else {
-        const float gp = *up_prj, gw = *up_pw;
-        if (gp == 1.f && gw == 1.f) return;   // mmdet's _parse_losses sum: nothing to do
-        ib = inst_box(a, n, dil);
-        for (int c = tid; c < w; c += 256) { carg[c] = st.colarg[(int64_t)n * w + c]; gcol[c] = st.gcol[(int64_t)n * w + c]; }
-        for (int r = tid; r < h; r += 256) { rarg[r] = st.rowarg[(int64_t)n * h + r]; grow[r] = st.grow[(int64_t)n * h + r]; }
-        dense_scale = gw;          // G <- gw*G + (gp-gw)*prj   (G currently = 1*pw + 1*prj)
-        sparse_scale = gp - gw;
-        __syncthreads();
+        if (tid == 0) st.inst[n] = rec;
     }
+}
 
-    if (G) {
-        // ---- dense pass over this slice of the dilated box (8 loads in flight per thread) -------------
-        const float sp_out = MODE == 0 ? 1.f : (sparse_scale + dense_scale);   // outside the box: gp * prj
-        if (ib.any) {
-            const int rows = ib.dil.r1 - ib.dil.r0;
-            const int per = (rows + gridDim.x - 1) / gridDim.x;
-            const int ra = ib.dil.r0 + s * per, rb = min(ib.dil.r1, ra + per);
-            const int cw = ib.dil.c1 - ib.dil.c0;
-            const int npx = (rb - ra) * cw;
-            for (int base = tid; base < npx; base += 256 * 8) {
-                float gv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = base + u * 256;
-                    gv[u] = i < npx ? G[(int64_t)(ra + i / cw) * w + ib.dil.c0 + i % cw] : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = base + u * 256;
-                    if (i < npx) {
-                        const int r = ra + i / cw, c = ib.dil.c0 + i % cw;
-                        float sp = 0.f;
-                        if (carg[c] == r) sp += gcol[c];
-                        if (rarg[r] == c) sp += grow[r];
-                        G[(int64_t)r * w + c] = gv[u] * dense_scale + sp * sparse_scale;
+// |logit| beyond ~69 makes S = p_i p_j + q_i q_j underflow: redo that pixel's 8 pairs in log space,
+// exactly as pairwise.cu:38-61 does.  Out of line and rolled: it runs for saturated logits only.
+__device__ __noinline__ float2 pair_logspace_redo(const float* __restrict__ L, const float2* pq, int h, int w, int d,
+                                                  int PC, int r, int c, int pi, float2 pp, uint32_t wps, uint32_t wqs) {
+    float acc2 = 0.f, dnum = 0.f;
+    const float xa = L[(int64_t)r * w + c];
+    const float ax = logsig(xa), bx = logsig(-xa);
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+        const int kk = k < 4 ? k : k + 1;                 // skip the centre of the 3x3 window
+        const int dy = kk / 3 - 1, dx = kk % 3 - 1;
+        const int r2 = r + dy * d, c2 = c + dx * d;
+        const uint32_t wp = (wps >> k) & 1u, wq = (wqs >> k) & 1u;
+        if (r2 >= 0 && r2 < h && c2 >= 0 && c2 < w && (wp + wq)) {
+            const float xb = L[(int64_t)r2 * w + c2];
+            const float ay = logsig(xb), by = logsig(-xb);
+            const float e1 = ax + ay, e0 = bx + by;
+            const float nl2 = logsig(fabsf(e1 - e0)) - fmaxf(e1, e0);
+            const float2 qq = pq[pi + dy * d * PC + dx * d];
+            const float S = pp.x * qq.x + pp.y * qq.y;
+            dnum += (float)wp * (nl2 + __logf(fmaxf(S, 1e-30f)));   // replaces the fast-path term
+            acc2 += (float)(wp + wq) * (-(expf(ay) - expf(by)) * expf(ax + bx + nl2));
+        }
+    }
+    return make_float2(dnum, acc2);   // (correction to the pixel's loss sum, its gradient)
+}
+
+template <bool FROM_LAB>
+__global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __restrict__ lab, ImageMeta meta,
+                                                  const uint8_t* __restrict__ bits_in, float thresh, int dil, LossWs ws,
+                                                  LossState st, float* __restrict__ g_logits, int vec) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float red[16];
+    __shared__ int rcnt[4];
+    const int h = a.h, w = a.w;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < a.N) {   // workgroup-uniform
+        leader_block(a, dil, ws, st, (int)blockIdx.x, smem, red);
+        return;
+    }
+    BXI_T(1, blockIdx.x, 0);
+    // work list built by stage1: the box tiles of all instances, compacted (hit tiles come first in the grid)
+    const int wi = (int)blockIdx.x - a.N;
+    const WorkRec wr = ws.work[wi];          // speculative (wi is always inside the list's capacity) ...
+    if (wi >= *ws.nwork) return;             // ... so both loads are in flight together; workgroup-uniform
+    const int n = wr.n, r0 = wr.tile_r0, c0 = wr.tile_c0;
+    InstRec rc; rc.r0 = wr.r0; rc.r1 = wr.r1; rc.c0 = wr.c0; rc.c1 = wr.c1; rc.img = wr.img;
+    const InstBox ib = inst_from_rec(rc, dil, h, w);
+    BXI_T(1, blockIdx.x, 1);
+    const int64_t P = (int64_t)h * w;
+    const float* L = a.logits + (int64_t)n * P;
+    const int d = dil;
+    const int PAD = (d + 3) & ~3;
+    const int PR = kBR + 2 * d, PC = kBC + 2 * PAD;          // staged region: tile + halo (columns padded to 4)
+    float2* pq = reinterpret_cast<float2*>(smem);
+    float* labs = reinterpret_cast<float*>(smem + sizeof(float2) * (size_t)PR * PC);   // [3][PR][PC]   (FROM_LAB)
+    uint8_t* bits = smem + sizeof(float2) * (size_t)PR * PC;                            // [PR][PC]      (!FROM_LAB)
+
+    // ---- 1. loads: logits region (-> sigmoid pairs) and Lab region, all in flight together -----------
+    {
+        const int q4 = PC / 4, items = PR * q4;                 // d = 2: 216 float4 per plane
+        const float* LB = FROM_LAB ? lab + (int64_t)ib.img * 3 * P : nullptr;
+        for (int i = tid; i < items; i += 256) {
+            const int lr = i / q4, r = r0 - d + lr, c = c0 - PAD + (i % q4) * 4;
+            const bool inb = r >= 0 && r < h && c >= 0 && c < w;
+            float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0, t3 = t0;   // zero padding of F.unfold
+            if (inb) {
+                t0 = load4(L + (int64_t)r * w, c, w, vec);
+                if (FROM_LAB) {
+                    const float* row = LB + (int64_t)r * w;
+                    if (vec) {
+                        t1 = *reinterpret_cast<const float4*>(row + c);
+                        t2 = *reinterpret_cast<const float4*>(row + P + c);
+                        t3 = *reinterpret_cast<const float4*>(row + 2 * P + c);
+                    } else {
+                        t1 = load4(row, c, w, false); t2 = load4(row + P, c, w, false); t3 = load4(row + 2 * P, c, w, false);
                     }
                 }
             }
-        }
-        // ---- sparse pass: arg-max positions outside the dilated box (the rest of the map is zero) ------
-        if (s == 0) {
-            for (int c = tid; c < w; c += 256) {
-                const int r = carg[c];
-                const bool in_d = ib.any && r >= ib.dil.r0 && r < ib.dil.r1 && c >= ib.dil.c0 && c < ib.dil.c1;
-                if (!in_d) {
-                    float v = gcol[c];
-                    if (rarg[r] == c) v += grow[r];
-                    G[(int64_t)r * w + c] = v * sp_out;
-                }
+            float2* dst = pq + (size_t)lr * PC + (i % q4) * 4;
+            dst[0] = sig_pair(t0.x); dst[1] = sig_pair(t0.y); dst[2] = sig_pair(t0.z); dst[3] = sig_pair(t0.w);
+            if (FROM_LAB) {
+                float* ld = labs + (size_t)lr * PC + (i % q4) * 4;
+                *reinterpret_cast<float4*>(ld) = t1;
+                *reinterpret_cast<float4*>(ld + PR * PC) = t2;
+                *reinterpret_cast<float4*>(ld + 2 * PR * PC) = t3;
             }
-            for (int r = tid; r < h; r += 256) {
-                const int c = rarg[r];
-                const bool in_d = ib.any && r >= ib.dil.r0 && r < ib.dil.r1 && c >= ib.dil.c0 && c < ib.dil.c1;
-                if (!in_d && carg[c] != r) G[(int64_t)r * w + c] = grow[r] * sp_out;
+        }
+        if (!FROM_LAB) {   // affinity words given: stage those of the in-box pixels (bitmask == 1, :1324-1325)
+            const uint8_t* AF = bits_in + (int64_t)ib.img * P;
+            for (int i = tid; i < PR * PC; i += 256) {
+                const int r = r0 - d + i / PC, c = c0 - PAD + i % PC;
+                const bool inbox = r >= ib.box.r0 && r < ib.box.r1 && c >= ib.box.c0 && c < ib.box.c1;
+                bits[i] = inbox ? AF[(int64_t)r * w + c] : (uint8_t)0;
             }
         }
     }
+    __syncthreads();
+    BXI_T(1, blockIdx.x, 2);
 
-    if (MODE == 0 && s == 0) {
-        // ---- loss_prj: the last-arriving instance sums dice[0..N) in index order (deterministic) ---------
-        if (tid == 0) last_flag = (ticket_old == (unsigned int)a.N - 1u);
-        __syncthreads();
-        if (last_flag) {   // dice[] was stored write-through (sc1) and is read with agent-scope loads
-            float acc = 0.f;
-            for (int base = 0; base < a.N; base += 256) {
-                if (base + tid < a.N)
-                    dbuf[tid] = __hip_atomic_load(&ws.dice[base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-                if (tid == 0)
-                    for (int i = 0; i < min(256, a.N - base); ++i) acc += dbuf[i];
-                __syncthreads();
+    // ---- 2. colour affinity + pairwise term, 2 pixels per thread ---------------------------------------
+    // weight of the pair (p, q = p + delta_k):  W[k,p] + W[7-k,q]
+    //   W[k,p]   = [p in box] * [sim(p->q) >= thresh],  sim(p->q) = exp(-||Lab_p-Lab_q||/2) * valid(q)
+    //   W[7-k,q] = [q in box] * [sim(q->p) >= thresh],  sim(q->p) = exp(-||Lab_q-Lab_p||/2) * valid(p)
+    // the two share the distance, so no per-pixel affinity word has to be staged (FROM_LAB).
+    const Pred pr = FROM_LAB ? *ws.pred : Pred{0.f, 1, 0, 0};
+    const int vr = FROM_LAB ? min(meta.img_h[ib.img], meta.first_removed[ib.img]) : 0;   // valid(q): :1354-1369,:1405
+    const int vc = FROM_LAB ? meta.img_w[ib.img] : 0;
+    const int half = a.stride / 2;
+    // thread -> row lr, columns lcx and lcx + 32: the 32 lanes of a row read consecutive LDS words
+    // (conflict-free ds_read_b32 / b64), unlike an adjacent-pixel pairing (2-way conflicts)
+    const int lr = tid >> 5, lcx = tid & 31;
+    const int r = r0 + lr;
+    float num = 0.f;
+    int cnt = 0;
+    float out[2] = {0.f, 0.f};
+    // per-row flags of the three neighbour rows: bit0 inside the map, bit1 inside the box, bit2 valid
+    uint32_t rfl[3];
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int r2 = r + dy * d;
+        const uint32_t in = (r2 >= 0 && r2 < h) ? 1u : 0u;
+        rfl[dy + 1] = in | ((r2 >= ib.box.r0 && r2 < ib.box.r1) ? 2u : 0u) | ((in && r2 * a.stride + half < vr) ? 4u : 0u);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int c = c0 + lcx + 32 * e;
+        if (r < ib.dil.r0 || r >= ib.dil.r1 || c < ib.dil.c0 || c >= ib.dil.c1) continue;
+        uint32_t cfl[3];
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int c2 = c + dx * d;
+            const uint32_t in = (c2 >= 0 && c2 < w) ? 1u : 0u;
+            cfl[dx + 1] = in | ((c2 >= ib.box.c0 && c2 < ib.box.c1) ? 2u : 0u) | ((in && c2 * a.stride + half < vc) ? 4u : 0u);
+        }
+        const int pi = (lr + d) * PC + (lcx + 32 * e + PAD);
+        const float2 pp = pq[pi];
+        const uint32_t fp_ = rfl[1] & cfl[1];                       // flags of p itself
+        const bool in_p = (fp_ & 2u) != 0u, val_p = (fp_ & 4u) != 0u;
+        const uint32_t bits_p = FROM_LAB ? 0u : bits[pi];
+        float L0 = 0.f, A0 = 0.f, B0 = 0.f;
+        if (FROM_LAB) { L0 = labs[pi]; A0 = labs[PR * PC + pi]; B0 = labs[2 * PR * PC + pi]; }
+        float2 nq[8]; float nL[8], nA[8], nB[8]; uint32_t nbw[8];
+        {
+            int k = 0;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (dx == 0 && dy == 0) continue;
+                    const int qi = pi + dy * d * PC + dx * d;
+                    nq[k] = pq[qi];
+                    if (FROM_LAB) { nL[k] = labs[qi]; nA[k] = labs[PR * PC + qi]; nB[k] = labs[2 * PR * PC + qi]; }
+                    else nbw[k] = bits[qi];
+                    ++k;
+                }
+        }
+        float acc = 0.f;
+        bool tiny = false;
+        uint32_t wps = 0, wqs = 0;     // bit k: W[k,p] / W[7-k,q] (kept for the rare log-space redo)
+        const float ppq = pp.x * pp.y;
+        int k = 0;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                if (dx == 0 && dy == 0) continue;
+                const uint32_t fq = rfl[dy + 1] & cfl[dx + 1];          // bit0 in map, bit1 in box, bit2 valid
+                const bool inb = (fq & 1u) != 0u;
+                uint32_t wp, wq;
+                if (FROM_LAB) {
+                    const float dL = L0 - nL[k], dA = A0 - nA[k], dB = B0 - nB[k];
+                    const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(dL, dL), __fmul_rn(dA, dA)), __fmul_rn(dB, dB));
+                    const uint32_t pn = n2 <= pr.n2max ? 1u : 0u;
+                    wp = in_p ? ((fq & 4u) ? pn : (uint32_t)pr.zero_bit) : 0u;           // padded / masked-out q: sim == 0
+                    wq = ((fq & 3u) == 3u) ? (val_p ? pn : (uint32_t)pr.zero_bit) : 0u;
+                } else {
+                    wp = (bits_p >> k) & 1u;
+                    wq = inb ? (nbw[k] >> (7 - k)) & 1u : 0u;
+                }
+                cnt += (int)wp;                                          // weights.sum(), :1328 (counts padded pairs too)
+                wps |= wp << k; wqs |= wq << k;
+                const float fw = inb ? (float)(wp + wq) : 0.f, fp = inb ? (float)wp : 0.f;
+                const float S = pp.x * nq[k].x + pp.y * nq[k].y;        // P(y_p == y_q)
+                tiny |= (fw != 0.f) && !(S > 1e-30f);
+                const float Sc = fmaxf(S, 1e-30f);
+                num += fp * -__logf(Sc);
+                acc += fw * (-(nq[k].x - nq[k].y) * ppq * __frcp_rn(Sc));
+                ++k;
             }
-            if (tid == 0) losses[0] = acc / (float)a.N;   // .mean(), :143
+        if (tiny) {   // rare
+            const float2 fix = pair_logspace_redo(L, pq, h, w, d, PC, r, c, pi, pp, wps, wqs);
+            num += fix.x; acc = fix.y;
+        }
+        out[e] = acc;
+    }
+    BXI_T(1, blockIdx.x, 4);
+    // ---- per-instance accumulators: integers, so the result does not depend on the arrival order --------
+    num = wave_sum_f32(num);
+    cnt = wave_sum_i32(cnt);
+    if ((tid & 63) == 0) { red[tid >> 6] = num; rcnt[tid >> 6] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        const float bn = (red[0] + red[1]) + (red[2] + red[3]);
+        const int bc = rcnt[0] + rcnt[1] + rcnt[2] + rcnt[3];
+        if (bc) atomicAdd(&ws.acc[2 * n], (unsigned long long)bc);
+        if (bn != 0.f) atomicAdd(&ws.acc[2 * n + 1], (unsigned long long)(long long)(bn * kNumScale));
+    }
+    // gradient tile last: nothing in this workgroup waits for these stores
+    if (g_logits && r < h) {
+        float* G = g_logits + (int64_t)n * P + (int64_t)r * w + c0 + lcx;   // 2 x 128 B contiguous per half-wave
+        if (c0 + lcx < w) G[0] = out[0];
+        if (c0 + lcx + 32 < w) G[32] = out[1];
+    }
+    BXI_T(1, blockIdx.x, 5);
+}
+
+// ================================================================================================
+// Kernel 3: loss_scalars -- one workgroup: the two loss values and the gradient normaliser
+// ================================================================================================
+__global__ __launch_bounds__(256) void loss_scalars_kernel(int N, float warmup, LossWs ws, LossState st,
+                                                           float* __restrict__ losses) {
+    __shared__ double red64[8];
+    __shared__ float dbuf[256];
+    const int tid = threadIdx.x;
+    unsigned long long acnt = 0ull; long long anum = 0;
+    float d0 = tid < N ? ws.dice[tid] : 0.f;
+    if (tid < N) { acnt = ws.acc[2 * tid]; anum = (long long)ws.acc[2 * tid + 1]; }
+    for (int i = tid + 256; i < N; i += 256) { acnt += ws.acc[2 * i]; anum += (long long)ws.acc[2 * i + 1]; }
+    double c = wave_sum_f64((double)acnt), s = wave_sum_f64((double)anum);   // exact: integers far below 2^53
+    if ((tid & 63) == 0) { red64[tid >> 6] = c; red64[4 + (tid >> 6)] = s; }
+    float acc = 0.f;                                   // dice summed in index order (deterministic)
+    for (int base = 0; base < N; base += 256) {
+        dbuf[tid] = base == 0 ? d0 : (base + tid < N ? ws.dice[base + tid] : 0.f);
+        __syncthreads();
+        if (tid == 0)
+            for (int i = 0; i < min(256, N - base); ++i) acc += dbuf[i];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double cnt = (red64[0] + red64[1]) + (red64[2] + red64[3]);
+        const double num = ((red64[4] + red64[5]) + (red64[6] + red64[7])) / (double)kNumScale;
+        const float denom = fmaxf((float)cnt, 1.f);                 // weights.sum().clamp(min=1.0), :1328
+        losses[0] = acc / (float)N;                                 // .mean(), :143
+        losses[1] = (float)(num / (double)denom) * warmup;          // :1327-1332
+        if (st.scale) *st.scale = warmup / denom;
+    }
+}
+
+// ================================================================================================
+// Kernel 4 (backward): loss_apply -- normalise the pairwise gradient, add the projection gradient
+// ================================================================================================
+// grid = kSlices x N.  g_logits holds zeros + the un-normalised pairwise gradient on the box tiles.
+//   dense pass over the box tiles:  G <- g_pw * (warmup / max(sum W,1)) * G + g_prj * prj(r,c)
+//   sparse pass elsewhere        :  G <- g_prj * prj(r,c) at the h+w arg-max positions
+// g_prj / g_pw are read from device memory (no host sync).
+__global__ __launch_bounds__(256) void loss_apply_kernel(InstArgs a, int dil, LossState st,
+                                                         const float* __restrict__ up_prj,
+                                                         const float* __restrict__ up_pw,
+                                                         float* __restrict__ g_logits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = blockIdx.y, s = blockIdx.x;
+    const int h = a.h, w = a.w, tid = threadIdx.x;
+    const int64_t P = (int64_t)h * w;
+    float* gcol = reinterpret_cast<float*>(smem);
+    float* grow = gcol + w;
+    int* carg = reinterpret_cast<int*>(grow + h);
+    int* rarg = carg + w;
+    float* G = g_logits + (int64_t)n * P;
+    // ---- every global load of the first batch is issued before the first use ---------------------------
+    const InstRec rec = st.inst[n];
+    const float gp = *up_prj, gw = *up_pw, scale = *st.scale;
+    const int ca0 = tid < w ? st.colarg[(int64_t)n * w + tid] : 0, ra0 = tid < h ? st.rowarg[(int64_t)n * h + tid] : 0;
+    const float gc0 = tid < w ? st.gcol[(int64_t)n * w + tid] : 0.f, gr0 = tid < h ? st.grow[(int64_t)n * h + tid] : 0.f;
+    const InstBox ib = inst_from_rec(rec, dil, h, w);
+    // the box tiles of box_kernel: tile-aligned hull of the dilated box
+    const int tr0 = ib.dil.r0 & ~(kBR - 1), tr1 = min(h, (ib.dil.r1 + kBR - 1) & ~(kBR - 1));
+    const int tc0 = ib.dil.c0 & ~(kBC - 1), tc1 = min(w, (ib.dil.c1 + kBC - 1) & ~(kBC - 1));
+    const int rows = ib.any ? tr1 - tr0 : 0;
+    const int per = (rows + gridDim.x - 1) / gridDim.x;
+    const int ra = tr0 + s * per, rb = min(tr1, ra + per);
+    const int cw = tc1 - tc0;
+    const int npx = ib.any && rb > ra ? (rb - ra) * cw : 0;
+    float gv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = tid + u * 256;
+        gv[u] = i < npx ? G[(int64_t)(ra + i / cw) * w + tc0 + i % cw] : 0.f;
+    }
+    if (tid < w) { carg[tid] = ca0; gcol[tid] = gc0; }
+    if (tid < h) { rarg[tid] = ra0; grow[tid] = gr0; }
+    for (int c = tid + 256; c < w; c += 256) { carg[c] = st.colarg[(int64_t)n * w + c]; gcol[c] = st.gcol[(int64_t)n * w + c]; }
+    for (int r = tid + 256; r < h; r += 256) { rarg[r] = st.rowarg[(int64_t)n * h + r]; grow[r] = st.grow[(int64_t)n * h + r]; }
+    const float dense_scale = gw * scale;
+    __syncthreads();
+    for (int base = tid; base < npx; base += 256 * 8) {
+        if (base != tid) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256;
+                gv[u] = i < npx ? G[(int64_t)(ra + i / cw) * w + tc0 + i % cw] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256;
+            if (i < npx) {
+                const int r = ra + i / cw, c = tc0 + i % cw;
+                float sp = 0.f;
+                if (carg[c] == r) sp += gcol[c];
+                if (rarg[r] == c) sp += grow[r];
+                G[(int64_t)r * w + c] = gv[u] * dense_scale + sp * gp;
+            }
+        }
+    }
+    if (s == 0) {   // arg-max positions outside the box tiles (the rest of the map stays zero)
+        for (int c = tid; c < w; c += 256) {
+            const int r = carg[c];
+            const bool in_t = ib.any && r >= tr0 && r < tr1 && c >= tc0 && c < tc1;
+            if (!in_t) {
+                float v = gcol[c];
+                if (rarg[r] == c) v += grow[r];
+                G[(int64_t)r * w + c] = v * gp;
+            }
+        }
+        for (int r = tid; r < h; r += 256) {
+            const int c = rarg[r];
+            const bool in_t = ib.any && r >= tr0 && r < tr1 && c >= tc0 && c < tc1;
+            if (!in_t && carg[c] != r) G[(int64_t)r * w + c] = grow[r] * gp;
         }
     }
 }
@@ -698,9 +857,9 @@ static int fill_inst(const bxi_instances* in, InstArgs& a) {
 }
 
 static size_t box_lds_bytes(int dil, bool from_lab) {
-    const size_t PAD = (dil + 3) & ~3, PAD2 = (2 * dil + 3) & ~3;
-    const size_t PR = kBR + 2 * dil, PC = kBC + 2 * PAD, LR = kBR + 4 * dil, LC = kBC + 2 * PAD2;
-    return sizeof(float2) * PR * PC + (from_lab ? sizeof(float) * 3 * LR * LC : 0) + PR * PC;
+    const size_t PAD = (dil + 3) & ~3;
+    const size_t PR = kBR + 2 * dil, PC = kBC + 2 * PAD;
+    return sizeof(float2) * PR * PC + (from_lab ? sizeof(float) * 3 * PR * PC : PR * PC);
 }
 
 int fill_pool_args(const bxi_image_batch* bt, uint8_t* rgb_small, float* lab, PoolArgs& pa);
@@ -741,7 +900,7 @@ int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, co
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
     LossWs ws;
     carve_ws(workspace, a.N, a.h, a.w, &ws);
-    LossState st = {nullptr, nullptr, nullptr, nullptr};
+    LossState st = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (state) {
         if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
         carve_state(state, a.N, a.h, a.w, &st);
@@ -763,32 +922,39 @@ int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, co
         }
     }
     const int n_stream = a.N * stream_tiles(a.h);
-    BXI_LAUNCH("stage1", s, stage1_kernel, dim3((unsigned)(n_pool + n_stream)), dim3(256), 0, s, pa, n_pool, a, dil, ws,
-               g_logits, vec);
+    BXI_LAUNCH("stage1", s, stage1_kernel, dim3((unsigned)(n_pool + n_stream)), dim3(256), 0, s, pa, n_pool, a, dil,
+               color_thresh, ws, g_logits, vec);
     rc = check_launch();
     if (rc != BXI_OK) return rc;
 
-    // ---- kernel 2: pairwise term on the box tiles --------------------------------------------------------
-    const size_t lds = box_lds_bytes(dil, from_lab);
-    const int n_box = a.N * box_tiles(a.h, a.w);
+    // ---- kernel 2: N leader workgroups (projection term) + the box tiles (pairwise term) ------------------
+    size_t lds = box_lds_bytes(dil, from_lab);
+    const size_t lds_leader = sizeof(float) * (size_t)(a.h + a.w);
+    if (lds < lds_leader) lds = lds_leader;
+    if (lds > 160 * 1024) return BXI_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        const void* fn = from_lab ? reinterpret_cast<const void*>(box_kernel<true>)
+                                  : reinterpret_cast<const void*>(box_kernel<false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }
+    }
+    const int n_box = a.N + a.N * box_tiles(a.h, a.w);
     if (from_lab)
         BXI_LAUNCH("box", s, (box_kernel<true>), dim3((unsigned)n_box), dim3(256), lds, s, a, (const float*)lab, meta,
-                   (const uint8_t*)nullptr, color_thresh, dil, ws, g_logits, vec);
+                   (const uint8_t*)nullptr, color_thresh, dil, ws, st, g_logits, vec);
     else
         BXI_LAUNCH("box", s, (box_kernel<false>), dim3((unsigned)n_box), dim3(256), lds, s, a, (const float*)nullptr,
-                   meta, affinity, 0.f, dil, ws, g_logits, vec);
+                   meta, affinity, 0.f, dil, ws, st, g_logits, vec);
     rc = check_launch();
     if (rc != BXI_OK) return rc;
 
-    // ---- kernel 3: dice, normalisation, loss scalars -----------------------------------------------------
-    const size_t lds_d = (sizeof(float) + sizeof(int)) * (size_t)(a.h + a.w);
-    BXI_LAUNCH("loss_finalize", s, (loss_finalize_kernel<0>), dim3(kSlices, a.N), dim3(256), lds_d, s, a, dil, warmup,
-               ws, st, (const float*)nullptr, (const float*)nullptr, losses, g_logits);
+    // ---- kernel 3: the two loss values + the normaliser the backward needs ---------------------------------
+    BXI_LAUNCH("loss_scalars", s, loss_scalars_kernel, dim3(1), dim3(256), 0, s, a.N, warmup, ws, st, losses);
     return check_launch();
 }
 
-int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state,
-                   float* g_logits, void* stream) {
+int launch_backward(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state,
+                    float* g_logits, void* stream) {
     InstArgs a;
     int rc = fill_inst(in, a);
     if (rc != BXI_OK) return rc;
@@ -796,12 +962,12 @@ int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_p
     if (a.N == 0) return BXI_OK;
     if (!g_prj || !g_pw || !state || !g_logits) return BXI_ERR_NULL_POINTER;
     if (a.N > 65535) return BXI_ERR_BAD_SHAPE;
+    if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
     LossState st;
     carve_state(const_cast<void*>(state), a.N, a.h, a.w, &st);
-    LossWs ws = {};
     const size_t lds_d = (sizeof(float) + sizeof(int)) * (size_t)(a.h + a.w);
-    BXI_LAUNCH("loss_rescale", as_stream(stream), (loss_finalize_kernel<1>), dim3(kSlices, a.N), dim3(256), lds_d,
-               as_stream(stream), a, dil, 1.f, ws, st, g_prj, g_pw, (float*)nullptr, g_logits);
+    BXI_LAUNCH("loss_apply", as_stream(stream), loss_apply_kernel, dim3(kSlices, a.N), dim3(256), lds_d,
+               as_stream(stream), a, dil, st, g_prj, g_pw, g_logits);
     return check_launch();
 }
 
@@ -809,6 +975,12 @@ size_t loss_ws_bytes(int N, int h, int w) { return carve_ws(nullptr, N, h, w, nu
 size_t loss_state_bytes(int N, int h, int w) { return carve_state(nullptr, N, h, w, nullptr); }
 
 }  // namespace bxi
+
+#ifdef BXI_TRACE
+extern "C" int bxi_debug_set_trace(void* buf) {   // developer builds only
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(bxi::g_trace), &buf, sizeof(buf));
+}
+#endif
 
 extern "C" {
 
@@ -828,9 +1000,9 @@ int bxi_boxinst_loss_fwd_bwd_f32(const bxi_instances* inst_host, const uint8_t* 
                             workspace, workspace_bytes, stream);
 }
 
-int bxi_boxinst_loss_rescale_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw, int dilation,
-                                 const void* state, float* g_logits, void* stream) {
-    return bxi::launch_rescale(inst_host, g_prj, g_pw, dilation, state, g_logits, stream);
+int bxi_boxinst_loss_backward_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw, int dilation,
+                                  const void* state, float* g_logits, void* stream) {
+    return bxi::launch_backward(inst_host, g_prj, g_pw, dilation, state, g_logits, stream);
 }
 
 }  // extern "C"

@@ -168,12 +168,11 @@ def box_bitmasks(gt_bboxes: Sequence[torch.Tensor], Hc: int, Wc: int, stride: in
 class BoxInstMaskLoss(torch.autograd.Function):
     """(loss_prj, loss_pairwise) = f(mask_logits); forward and backward in ONE pass over the logits.
 
-    forward  : bxi_boxinst_eval_f32 (colour affinity from the images + fused loss) -- or
-               bxi_boxinst_loss_fwd_bwd_f32 when precomputed affinity bits are given -- writes both
-               scalars and d(loss_prj + loss_pairwise)/d logits.
-    backward : bxi_boxinst_loss_rescale_f32 folds the two upstream scalars in on the device (no
-               host sync); it is a no-op launch when both are 1, which is what mmdet's
-               ``_parse_losses`` sum produces.
+    forward  : bxi_boxinst_eval_f32 (image side + fused loss) -- or bxi_boxinst_loss_fwd_bwd_f32 when
+               precomputed affinity bits are given -- writes both scalars and the un-finished
+               gradient (zeros + the un-normalised pairwise gradient on the box tiles).
+    backward : bxi_boxinst_loss_backward_f32 normalises, adds the projection gradient and folds the
+               two upstream scalars in, reading them from device memory (no host sync).
     """
 
     @staticmethod
@@ -226,15 +225,15 @@ class BoxInstMaskLoss(torch.autograd.Function):
     def backward(ctx, g_prj: torch.Tensor, g_pw: torch.Tensor):
         grad, inst = ctx.grad, ctx.inst
         if grad is None:
-            raise RuntimeError('BoxInstMaskLoss.backward called twice (the fused gradient buffer is consumed '
-                               'by the first call) or without a gradient request')
+            raise RuntimeError('BoxInstMaskLoss.backward called twice (the fused gradient buffer is finished in '
+                               'place by the first call) or without a gradient request')
         ctx.grad = None    # hand the buffer to autograd; a second backward must re-run the forward
         dev = grad.device
         if inst.N > 0:
             g_prj = g_prj.to(device=dev, dtype=torch.float32).contiguous()
             g_pw = g_pw.to(device=dev, dtype=torch.float32).contiguous()
             with torch.cuda.device(dev):
-                _lib.check('bxi_boxinst_loss_rescale_f32', _lib.load().bxi_boxinst_loss_rescale_f32(
+                _lib.check('bxi_boxinst_loss_backward_f32', _lib.load().bxi_boxinst_loss_backward_f32(
                     C.byref(inst.struct), g_prj.data_ptr(), g_pw.data_ptr(), ctx.dil, ctx.state.data_ptr(),
                     grad.data_ptr(), _stream(dev)))
         if grad.dtype != ctx.in_dtype:

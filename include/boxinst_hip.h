@@ -151,13 +151,15 @@ typedef struct bxi_instances {
 size_t bxi_boxinst_loss_workspace_bytes(int N, int h, int w);
 size_t bxi_boxinst_loss_state_bytes(int N, int h, int w);
 
-/* losses[0] = loss_prj, losses[1] = loss_pairwise (device, f32).
- * g_logits [N,1,h,w]: d(loss_prj + loss_pairwise)/d logits, i.e. the gradient for unit upstream
- *   gradients, fully overwritten (nullable: forward only).
+/* Forward (+ the bulk of the backward):
+ * losses[0] = loss_prj, losses[1] = loss_pairwise (device, f32), complete when the call's work is done.
+ * g_logits [N,1,h,w] (nullable: forward only): receives the UN-FINISHED gradient (zeros + the
+ *   un-normalised pairwise gradient on the box tiles); bxi_boxinst_loss_backward_f32 finishes it in
+ *   place.  Every element is written exactly once here.
  * affinity: the uint8 output of bxi_color_affinity_f32 for the same size/dilation/threshold.
  * warmup: min(_iter / pairwise_warmup, 1) (:1330-1331), evaluated on the host by the caller.
- * state (bxi_boxinst_loss_state_bytes): what bxi_boxinst_loss_rescale_f32 needs later
- *   (arg-max positions and unit projection gradients); nullable when g_logits is NULL.
+ * state (bxi_boxinst_loss_state_bytes, 256-B aligned): arg-max positions, unit projection gradients,
+ *   box rectangles and the normaliser, for the backward; nullable when g_logits is NULL.
  * workspace (bxi_boxinst_loss_workspace_bytes, 256-B aligned): scratch, contents undefined after.
  * Only size == 3 (K = 8) is built into this fused path; other sizes return BXI_ERR_UNSUPPORTED
  * and the host composes section 1 + torch ops as the reference does.
@@ -166,13 +168,13 @@ int bxi_boxinst_loss_fwd_bwd_f32(const bxi_instances* inst_host, const uint8_t* 
                                  int size, int dilation, float warmup, float* losses, float* g_logits,
                                  void* state, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Backward with arbitrary upstream gradients, without a host sync: reads the two device scalars
- * g_prj, g_pw and turns the unit gradient in place into g_prj*dprj + g_pw*dpairwise.
- * All blocks exit immediately when both are exactly 1.0f (mmdet's `_parse_losses` sum). */
-int bxi_boxinst_loss_rescale_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw,
-                                 int dilation, const void* state, float* g_logits, void* stream);
+/* Backward: g_logits <- g_prj * d loss_prj/d logits + g_pw * d loss_pairwise/d logits, in place on
+ * the buffer the forward filled (call exactly once per forward).  g_prj / g_pw are DEVICE scalars
+ * (the upstream gradients autograd hands over), so there is no host sync. */
+int bxi_boxinst_loss_backward_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw,
+                                  int dilation, const void* state, float* g_logits, void* stream);
 
-/* Whole evaluation in one host call, three launches: the image side (stage A above) runs inside the
+/* Whole forward in one host call, three launches: the image side (stage A above) runs inside the
  * first loss kernel next to the logit streaming, and the affinity bits are derived from Lab where
  * the loss needs them (nothing of stage B is materialised).  Same results as
  * bxi_color_affinity_f32 + bxi_boxinst_loss_fwd_bwd_f32.  batch_host->image_masks must be NULL.

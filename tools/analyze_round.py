@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Developer helper: summarise gpurun_out/ (rocprof kernel stats, block trace, bench lines)."""
+import csv, json, numpy as np, os
+g = 'gpurun_out'
+for r in csv.DictReader(open(f'{g}/prof_eager/r01_kernel_stats.csv')):
+    if 'bxi' in r['Name']: print('%-36s calls %s avg %.2f us min %.2f max %.2f' % (r['Name'].replace('void ','')[:36], r['Calls'], float(r['AverageNs'])/1e3, float(r['MinNs'])/1e3, float(r['MaxNs'])/1e3))
+for mode in ('eager', 'graph'):
+    try:
+        r = json.loads(open(f'{g}/bench_{mode}.json').read().strip().splitlines()[-1])
+        print(mode, 'value %.0f img/s  us/step %.2f' % (r['value'], r['ms_per_step']*1e3), {k: round(v['avg_us'], 2) for k, v in r.get('kernels', {}).items()})
+    except Exception as e: print(mode, 'n/a', e)
+t = np.load(f'{g}/trace.npz')['trace'].astype(np.float64)
+us = lambda x: x * 0.01
+t0 = t[t>0].min()
+s1 = t[0]; m = s1[:,0]>0; dur = us(s1[m,1]-s1[m,0]); npool=400
+print('stage1: blocks', m.sum(), 'last start %.2f last end %.2f' % (us(s1[m,0].max()-t0), us(s1[m,1].max()-t0)), 'pool dur mean %.2f max %.2f ; stream dur mean %.2f max %.2f' % (dur[:npool].mean(), dur[:npool].max(), dur[npool:].mean(), dur[npool:].max()))
+b = t[1]; m = b[:,0]>0
+if m.any():
+    bs = b[m,0].min()
+    print('box: tile blocks', m.sum(), 'first start %.2f (stage1 end +%.2f) last start +%.2f' % (us(bs-t0), us(bs-s1[s1[:,1]>0,1].max()), us(b[m,0].max()-bs)))
+    hit = m & (b[:,2]>0); nh = m & ~hit
+    print('  hit blocks', hit.sum())
+    for a_,b_,nm in [(0,1,'decide'),(1,2,'loads+stage'),(2,4,'affinity+pairwise'),(4,5,'partials+store')]:
+        d = us(b[hit,b_]-b[hit,a_]); print('  hit phase %-14s mean %.2f med %.2f max %.2f' % (nm, d.mean(), np.median(d), d.max()))
+    print('  hit last end +%.2f ; hit block total mean %.2f max %.2f' % (us(b[hit,5].max()-bs), us(b[hit,5]-b[hit,0]).mean(), us(b[hit,5]-b[hit,0]).max()), ' start quantiles', np.quantile(us(b[m,0]-bs),[0,.25,.5,.75,1]).round(2))
