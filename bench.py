@@ -3,7 +3,7 @@
 
 Metric (BASELINE.json): pairwise+projection loss fwd+bwd images/sec @ 2x800x1024 x 32 instances.
 One *step* = one loss evaluation on a 2-image batch, through the C ABI of libboxinst_hip.so:
-  bxi_boxinst_eval_f32           stage1 (image pool+Lab || logit streaming) -> box -> loss_scalars
+  bxi_boxinst_eval_f32           stage1 (image pool+Lab || logit streaming) -> box (pairwise tiles + projection leaders + loss scalars)
   bxi_boxinst_loss_backward_f32  loss_apply: normalise, add the projection gradient, fold upstream grads
 i.e. everything CondInstMaskHead.loss + .backward() do for mask_logits, from the normalised images,
 boxes and logits already resident in HBM to loss_prj, loss_pairwise and d(loss)/d(mask_logits).
@@ -231,7 +231,6 @@ def algorithmic_bytes(d, N):
     return {
         'stage1': 12 * px_in + 12 * px_small + 4 * ipx + int(4 * ipx * (1.0 - f)),
         'box': int(4 * ipx * f) + int(4 * ipx * f),      # re-read of the box tiles' logits + their gradient
-        'loss_scalars': 0,
         'loss_apply': int(8 * ipx * f),                   # read-modify-write of the box tiles
     }
 

@@ -109,6 +109,10 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for the
+// wave's outstanding global stores (vmcnt), so zero-fill / output stores stay in flight across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // python slice [a:b] on an axis of length n -> [lo,hi)   (condinst_head.py:1429-1430)
 __device__ __forceinline__ void py_slice(int a, int b, int n, int& lo, int& hi) {
     if (a < 0) a += n;

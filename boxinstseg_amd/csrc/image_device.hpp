@@ -91,19 +91,33 @@ __device__ __forceinline__ void pool_finish_s4(const PoolArgs& pa, int64_t o, co
     const int ih = pa.meta.img_h[b], iw = pa.meta.img_w[b];
     const int x0 = 4 * c, y0 = 4 * r;
     int px[3];
+    const bool inside = y0 + 3 < ih && x0 + 3 < iw;      // the whole 4x4 window is image, not canvas padding
+    if (__all(inside)) {                                  // wave-uniform: no per-element selects (the common case)
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const double s = pa.dn.stdv[pa.dn.src_ch[ch]], m = pa.dn.mean[pa.dn.src_ch[ch]];
-        int sum = 0;
+        for (int ch = 0; ch < 3; ++ch) {
+            const double s = pa.dn.stdv[pa.dn.src_ch[ch]], m = pa.dn.mean[pa.dn.src_ch[ch]];
+            int sum = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool yin = (y0 + i) < ih;
-            sum += (yin && x0 + 0 < iw) ? denorm_u8(pr.v[ch][i].x, s, m) : 0;
-            sum += (yin && x0 + 1 < iw) ? denorm_u8(pr.v[ch][i].y, s, m) : 0;
-            sum += (yin && x0 + 2 < iw) ? denorm_u8(pr.v[ch][i].z, s, m) : 0;
-            sum += (yin && x0 + 3 < iw) ? denorm_u8(pr.v[ch][i].w, s, m) : 0;
+            for (int i = 0; i < 4; ++i)
+                sum += denorm_u8(pr.v[ch][i].x, s, m) + denorm_u8(pr.v[ch][i].y, s, m) + denorm_u8(pr.v[ch][i].z, s, m) +
+                       denorm_u8(pr.v[ch][i].w, s, m);
+            px[ch] = sum >> 4;
         }
-        px[ch] = sum >> 4;
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const double s = pa.dn.stdv[pa.dn.src_ch[ch]], m = pa.dn.mean[pa.dn.src_ch[ch]];
+            int sum = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool yin = (y0 + i) < ih;
+                sum += (yin && x0 + 0 < iw) ? denorm_u8(pr.v[ch][i].x, s, m) : 0;
+                sum += (yin && x0 + 1 < iw) ? denorm_u8(pr.v[ch][i].y, s, m) : 0;
+                sum += (yin && x0 + 2 < iw) ? denorm_u8(pr.v[ch][i].z, s, m) : 0;
+                sum += (yin && x0 + 3 < iw) ? denorm_u8(pr.v[ch][i].w, s, m) : 0;
+            }
+            px[ch] = sum >> 4;
+        }
     }
     const int64_t P = (int64_t)h * w;
     const int64_t p = (int64_t)r * w + c;

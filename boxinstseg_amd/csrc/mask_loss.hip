@@ -7,12 +7,11 @@
 //   weights = (sim >= thresh) * bitmask, normalise    :1324-1328
 //   warm-up                                           :1330-1332
 // and everything autograd does behind them (max backward, sigmoid backward, the op's atomicAdd
-// backward, ~1.3 GB of elementwise temporaries at 2x800x1024x32) with three launches, each
+// backward, ~1.3 GB of elementwise temporaries at 2x800x1024x32) with two launches, each
 // documented at its kernel below:
 //   stage1        { image pool + Lab } || { logit streaming: row/column maxima, zero-fill }   HBM stream
 //   box_kernel    leaders: dice + projection gradient of each instance ; tiles: colour-affinity
 //                 bits + pairwise term and its un-normalised gradient on the box tiles       latency bound
-//   loss_scalars  the two loss values + the normaliser                                      one workgroup
 // and, in the backward, loss_apply (normalise the box tiles, add the projection gradient at the
 // h+w arg-max positions, fold the upstream gradients in from device memory).
 // Data layout in HBM: everything NCHW / row-major as the reference; per-pixel colour affinity is
@@ -21,8 +20,7 @@
 
 namespace bxi {
 
-constexpr int kSR = 16;         // rows per streaming tile (stage1): 4 rows per wave
-constexpr int kRW = kSR / 4;
+constexpr int kSR = 8;          // rows per streaming tile (stage1): one wave64 per tile
 constexpr int kChunk = 256;     // columns per pass: 64 lanes x float4
 constexpr int kBR = 8;          // box tile rows    (box_kernel)
 constexpr int kBC = 64;         // box tile columns
@@ -47,6 +45,8 @@ struct LossWs {               // carved from the caller's workspace
     struct Pred* pred;        // [1]  colour-threshold predicate (written by stage1)
     struct WorkRec* work;     // [N*Tr*Tc] compacted box tiles (written by stage1)
     int* nwork;               // [1]
+    unsigned int* arrive;     // [N+1] arrivals per instance (tiles + leader), [N] = instances complete (zeroed by stage1)
+    unsigned int* expect;     // [N]   box tiles of the instance + 1 (written by stage1)
     float* dice;              // [N]
     unsigned int* ticket;     // [1]
 };
@@ -88,10 +88,13 @@ static size_t carve_ws(void* base, int N, int h, int w, LossWs* ws) {
     Pred* pred = (Pred*)take(sizeof(Pred));
     WorkRec* work = (WorkRec*)take(sizeof(WorkRec) * (size_t)(N > 0 ? N : 1) * (size_t)box_tiles(h, w));
     int* nwork = (int*)take(sizeof(int));
+    unsigned int* arrive = (unsigned int*)take(sizeof(unsigned int) * (size_t)(N + 1));
+    unsigned int* expect = (unsigned int*)take(sizeof(unsigned int) * (size_t)(N > 0 ? N : 1));
     float* dice = (float*)take(sizeof(float) * (size_t)(N > 0 ? N : 1));
     unsigned int* ticket = (unsigned int*)take(sizeof(unsigned int));
     if (ws) { ws->colv = colv; ws->colr = colr; ws->rowkey = rowkey; ws->acc = acc; ws->inst = inst;
-              ws->pred = pred; ws->work = work; ws->nwork = nwork; ws->dice = dice; ws->ticket = ticket; }
+              ws->pred = pred; ws->work = work; ws->nwork = nwork; ws->arrive = arrive; ws->expect = expect;
+              ws->dice = dice; ws->ticket = ticket; }
     return off;
 }
 
@@ -176,15 +179,9 @@ __device__ __forceinline__ void store4(float* row, int c, int w, bool vec, float
 // ================================================================================================
 // Kernel 1: stage1 = { pool_rgb + Lab workgroups }  ||  { logit streaming workgroups }
 // ================================================================================================
-// The two halves are independent (image side / logit side), so they share one launch: the grid is
-// n_pool workgroups of image work followed by N*Ts streaming workgroups, all resident at once.
-// Streaming workgroup (n, tile of kSR rows), 4 wave64, each wave owns kRW rows, a lane owns 4
-// consecutive columns (float4, a wave = 1 KiB contiguous):
-//   - issues all its row loads first, then (scalar path) looks the instance's box up;
-//   - row max / first arg-max: lane-local, then a 64-lane shuffle tree on a packed 64-bit key;
-//   - column max / first arg-max over the tile's rows: registers, then 4 waves through LDS,
-//     one partial per (tile, column) -- no atomics;
-//   - zero-fills d loss / d logits wherever no box tile of box_kernel will write.
+// The two halves are independent (image side / logit side), so they share one launch of one-wave
+// workgroups: N*Ts streaming waves followed by B*h*w/64 pooling waves, all resident at once
+// (about 9 waves per CU at 2x800x1024x32), every wave issuing all of its loads before anything else.
 __device__ __forceinline__ bool seg_hit(const InstBox& ib, int r, int c) {
     const int tr = r & ~(kBR - 1), tc = c & ~(kBC - 1);
     return ib.any && tr < ib.dil.r1 && tr + kBR > ib.dil.r0 && tc < ib.dil.c1 && tc + kBC > ib.dil.c0;
@@ -205,6 +202,10 @@ __device__ __forceinline__ void make_pred(float thresh, Pred* out) {   // lane 0
     else if (sim_pred(3.0e38f, thresh)) p.n2max = INFINITY;             // thresh <= 0 (exp underflows to 0): always
     else {
         uint32_t lo = 0u, hi = __float_as_uint(3.0e38f);                // pred(lo) true, pred(hi) false
+        const float dstar = -2.f * logf(thresh);                        // analytic boundary: n2 = (2 ln thresh)^2
+        const uint32_t cb = __float_as_uint(dstar * dstar);
+        if (cb > 256u && cb < __float_as_uint(3.0e38f) - 256u && sim_pred(__uint_as_float(cb - 128u), thresh) &&
+            !sim_pred(__uint_as_float(cb + 128u), thresh)) { lo = cb - 128u; hi = cb + 128u; }   // 8 steps instead of 31
         while (hi - lo > 1u) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
             if (sim_pred(__uint_as_float(mid), thresh)) lo = mid; else hi = mid;
@@ -260,8 +261,15 @@ __device__ __forceinline__ void build_work_list(const InstArgs& a, int dil, cons
         }
         total += __shfl(incl, 63, 64);
     }
-    if (n == 0 && lane == 0) *ws.nwork = total;
+    if (n == 0 && lane == 0) { *ws.nwork = total; ws.arrive[a.N] = 0u; }
     const int cnt = mine.ntr * mine.ntc;
+    if (lane == 0) {   // per-instance records and zeroed accumulators for box_kernel / loss_apply (next launches)
+        InstRec rc; rc.r0 = mine.r0; rc.r1 = mine.r1; rc.c0 = mine.c0; rc.c1 = mine.c1; rc.img = mine.img;
+        rc.pad0 = rc.pad1 = rc.pad2 = 0;
+        ws.inst[n] = rc;
+        ws.acc[2 * n] = 0ull; ws.acc[2 * n + 1] = 0ull;
+        ws.expect[n] = (unsigned int)cnt + 1u; ws.arrive[n] = 0u;
+    }
     for (int i = lane; i < cnt; i += 64) {
         WorkRec wr;
         wr.r0 = mine.r0; wr.r1 = mine.r1; wr.c0 = mine.c0; wr.c1 = mine.c1; wr.img = mine.img; wr.n = n;
@@ -270,132 +278,135 @@ __device__ __forceinline__ void build_work_list(const InstArgs& a, int dil, cons
     }
 }
 
+// One wave64 = one streaming tile of kSR rows x all columns of one instance map.  A lane owns 4
+// consecutive columns (float4): a wave-level load/store instruction moves one 1 KiB row segment.
+//   - the zero-fill of d loss / d logits needs nothing, so it is issued first (box_kernel later
+//     overwrites the box tiles; ~15 % of the map is written twice, in exchange for no dependency);
+//   - all kSR row loads are issued back to back, then consumed: per-row max / first arg-max by a
+//     64-lane butterfly on a packed 64-bit key (the kSR butterflies are interleaved), per-column
+//     max / first arg-max over the tile's rows in registers -> one partial per (tile, column).
 __device__ __forceinline__ void stream_tile(const InstArgs& a, int dil, float thresh, const LossWs& ws,
-                                            float* __restrict__ g_logits, int vec, int sb, float* cbv, int* cbr) {
+                                            float* __restrict__ g_logits, int vec, int sb) {
     const int h = a.h, w = a.w;
     const int Ts = (h + kSR - 1) / kSR;
     const int n = sb / Ts, t = sb % Ts;
     const int r0 = t * kSR, r1 = min(h, r0 + kSR);
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int lane = threadIdx.x & 63;
     const int64_t P = (int64_t)h * w;
     const float* L = a.logits + (int64_t)n * P;
     float* G = g_logits ? g_logits + (int64_t)n * P : nullptr;
     const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    float4 v[kRW];
+    float4 v[kSR];
     {
         const int c = lane * 4;
 #pragma unroll
-        for (int i = 0; i < kRW; ++i) {
-            const int r = r0 + wv + 4 * i;
-            v[i] = (r < r1 && c < w) ? load4(L + (int64_t)r * w, c, w, vec) : ninf;
-        }
+        for (int i = 0; i < kSR; ++i) v[i] = (r0 + i < r1 && c < w) ? load4(L + (int64_t)(r0 + i) * w, c, w, vec) : ninf;
     }
-    if (t == 0 && wv == 2) build_work_list(a, dil, ws, n);   // vector-load chain, overlaps the scalar one below
-    const InstBox ib = inst_box(a, n, dil);   // dependent scalar loads, overlapped with the row loads
-    if (t == 0 && tid == 0) {                 // publish for box_kernel / loss_apply (next launches)
-        InstRec rc; rc.r0 = ib.box.r0; rc.r1 = ib.box.r1; rc.c0 = ib.box.c0; rc.c1 = ib.box.c1; rc.img = ib.img;
-        rc.pad0 = rc.pad1 = rc.pad2 = 0;
-        ws.inst[n] = rc;
-        ws.acc[2 * n] = 0ull; ws.acc[2 * n + 1] = 0ull;
-    }
-    if (sb == 0) {
-        if (tid == 0) *ws.ticket = 0u;
-        if (wv == 1) make_pred(thresh, ws.pred);
-    }
-    // zero-fill first: it depends on the box only, so the stores overlap the row loads still in flight
     if (G)
         for (int cb = 0; cb < w; cb += kChunk) {
             const int c = cb + lane * 4;
             if (c < w) {
 #pragma unroll
-                for (int i = 0; i < kRW; ++i) {
-                    const int r = r0 + wv + 4 * i;
-                    if (r < r1 && !seg_hit(ib, r, c)) store4(G + (int64_t)r * w, c, w, vec, make_float4(0.f, 0.f, 0.f, 0.f));
-                }
+                for (int i = 0; i < kSR; ++i)
+                    if (r0 + i < r1) store4(G + (int64_t)(r0 + i) * w, c, w, vec, zero);
             }
         }
+    BXI_T(0, blockIdx.x, 2);
+    __builtin_amdgcn_s_setprio(2);   // short tail: do not queue behind the pooling waves' long fp64 work
+    BXI_T(0, blockIdx.x, 3);
 
-    unsigned long long rkey[kRW];
+    float rmax[kSR]; int rcol[kSR];        // per-lane row maximum and its first column (across column chunks)
 #pragma unroll
-    for (int i = 0; i < kRW; ++i) rkey[i] = 0ull;
-
+    for (int i = 0; i < kSR; ++i) { rmax[i] = -INFINITY; rcol[i] = 0; }
+    const int Tsw = Ts;
     for (int cb = 0;;) {
         const int c = cb + lane * 4;
         float cmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        int crow[4] = {r0, r0, r0, r0};
+        int crow[4] = {0, 0, 0, 0};
         if (c < w) {
 #pragma unroll
-            for (int i = 0; i < kRW; ++i) {
-                const int r = r0 + wv + 4 * i;
-                if (r < r1) {
+            for (int i = 0; i < kSR; ++i) {
+                if (r0 + i < r1) {
                     float m = v[i].x; int mc = c;                       // first column wins ties
                     if (v[i].y > m) { m = v[i].y; mc = c + 1; }
                     if (v[i].z > m) { m = v[i].z; mc = c + 2; }
                     if (v[i].w > m) { m = v[i].w; mc = c + 3; }
-                    const unsigned long long key = pack_max(m, (uint32_t)mc);
-                    rkey[i] = key > rkey[i] ? key : rkey[i];
-                    if (v[i].x > cmax[0]) { cmax[0] = v[i].x; crow[0] = r; }   // ascending r, strict >
-                    if (v[i].y > cmax[1]) { cmax[1] = v[i].y; crow[1] = r; }
-                    if (v[i].z > cmax[2]) { cmax[2] = v[i].z; crow[2] = r; }
-                    if (v[i].w > cmax[3]) { cmax[3] = v[i].w; crow[3] = r; }
+                    if (m > rmax[i]) { rmax[i] = m; rcol[i] = mc; }     // chunks ascend: strict > keeps the first
+                    if (v[i].x > cmax[0]) { cmax[0] = v[i].x; crow[0] = i; }   // ascending row, strict >: first row wins
+                    if (v[i].y > cmax[1]) { cmax[1] = v[i].y; crow[1] = i; }
+                    if (v[i].z > cmax[2]) { cmax[2] = v[i].z; crow[2] = i; }
+                    if (v[i].w > cmax[3]) { cmax[3] = v[i].w; crow[3] = i; }
                 }
             }
-        }
+            const int64_t o = ((int64_t)n * Tsw + t) * w + c;
+            if (vec) {
+                *reinterpret_cast<float4*>(ws.colv + o) = make_float4(cmax[0], cmax[1], cmax[2], cmax[3]);
+                *reinterpret_cast<uchar4*>(ws.colr + o) = make_uchar4((unsigned char)crow[0], (unsigned char)crow[1],
+                                                                      (unsigned char)crow[2], (unsigned char)crow[3]);
+            } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { cbv[wv * kChunk + lane * 4 + j] = cmax[j]; cbr[wv * kChunk + lane * 4 + j] = crow[j]; }
-        __syncthreads();
-        {
-            const int cc = cb + tid;
-            if (cc < w) {
-                float m = cbv[tid]; int mr = cbr[tid];
-#pragma unroll
-                for (int q = 1; q < 4; ++q) {
-                    const float x = cbv[q * kChunk + tid]; const int xr = cbr[q * kChunk + tid];
-                    if (x > m || (x == m && xr < mr)) { m = x; mr = xr; }
-                }
-                const int64_t o = ((int64_t)n * Ts + t) * w + cc;
-                ws.colv[o] = m;
-                ws.colr[o] = (uint8_t)(mr - r0);
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < w) { ws.colv[o + j] = cmax[j]; ws.colr[o + j] = (uint8_t)crow[j]; }
             }
         }
         cb += kChunk;
         if (cb >= w) break;
-        __syncthreads();
-        {
-            const int c2 = cb + lane * 4;
+        const int c2 = cb + lane * 4;
 #pragma unroll
-            for (int i = 0; i < kRW; ++i) {
-                const int r = r0 + wv + 4 * i;
-                v[i] = (r < r1 && c2 < w) ? load4(L + (int64_t)r * w, c2, w, vec) : ninf;
-            }
-        }
+        for (int i = 0; i < kSR; ++i) v[i] = (r0 + i < r1 && c2 < w) ? load4(L + (int64_t)(r0 + i) * w, c2, w, vec) : ninf;
     }
+    BXI_T(0, blockIdx.x, 4);
+    // row maxima: kSR independent 32-bit butterflies advanced in lock step (their cross-lane moves
+    // pipeline); the arg-max is the lowest lane holding the maximum (lanes own ascending columns),
+    // found with one ballot + readlane per row.
+    float wmax[kSR];
 #pragma unroll
-    for (int i = 0; i < kRW; ++i) {
-        const int r = r0 + wv + 4 * i;
-        const unsigned long long k = wave_max_u64(rkey[i]);
-        if (lane == 0 && r < r1) ws.rowkey[(int64_t)n * h + r] = k;
+    for (int i = 0; i < kSR; ++i) wmax[i] = rmax[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float o[kSR];
+#pragma unroll
+        for (int i = 0; i < kSR; ++i) o[i] = __shfl_xor(wmax[i], off, kWave);
+#pragma unroll
+        for (int i = 0; i < kSR; ++i) wmax[i] = fmaxf(wmax[i], o[i]);
     }
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int i = 0; i < kSR; ++i) {
+        const unsigned long long who = __ballot(rmax[i] == wmax[i]);
+        const int first = who ? __ffsll((long long)who) - 1 : 0;
+        const int col = __builtin_amdgcn_readlane(rcol[i], first);
+        if (lane == i) mine = pack_max(wmax[i], (uint32_t)col);
+    }
+    if (lane < kSR && r0 + lane < r1) ws.rowkey[(int64_t)n * h + r0 + lane] = mine;
 }
 
-__global__ __launch_bounds__(256) void stage1_kernel(PoolArgs pa, int n_pool, InstArgs a, int dil, float thresh,
-                                                     LossWs ws, float* __restrict__ g_logits, int vec) {
-    __shared__ __attribute__((aligned(16))) unsigned char sm[sizeof(float) * 4 * kChunk + sizeof(int) * 4 * kChunk];
+// grid: [N + 1 table waves][pooling waves][N*Ts streaming waves].  The table waves (per-instance
+// records + work list of box_kernel, and the colour-threshold predicate) carry dependent load
+// chains, so they go first, before the memory system is saturated; nothing in this launch waits for them.
+__global__ __launch_bounds__(64) void stage1_kernel(PoolArgs pa, int n_pool, InstArgs a, int dil, float thresh,
+                                                    LossWs ws, float* __restrict__ g_logits, int vec) {
+    __shared__ double lut[256];
     BXI_T(0, blockIdx.x, 0);
-    if ((int)blockIdx.x < n_pool) {
-        double* lut = reinterpret_cast<double*>(sm);
+    const int n_tab = a.N + 1;
+    if ((int)blockIdx.x < n_tab) {
+        if ((int)blockIdx.x < a.N) build_work_list(a, dil, ws, (int)blockIdx.x);
+        else make_pred(thresh, ws.pred);
+    } else if ((int)blockIdx.x >= n_tab + n_pool) {
+        stream_tile(a, dil, thresh, ws, g_logits, vec, (int)blockIdx.x - n_tab - n_pool);
+    } else {
         const int64_t total = (int64_t)pa.B * (pa.Hc >> 2) * (pa.Wc >> 2);
-        const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        const int64_t o = (int64_t)((int)blockIdx.x - n_tab) * 64 + threadIdx.x;
         PoolRegs pr;
         if (o < total) pool_load_s4(pa, o, pr);          // 12 x 16 B per lane in flight ...
-        lut[threadIdx.x] = kSrgbLut[threadIdx.x];        // ... while the companding table is staged
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lut[threadIdx.x + 64 * k] = kSrgbLut[threadIdx.x + 64 * k];   // ... while the table is staged
+        BXI_T(0, blockIdx.x, 2);
+        lds_barrier();
+        BXI_T(0, blockIdx.x, 3);
         if (o < total) pool_finish_s4(pa, o, pr, lut);
-    } else {
-        float* cbv = reinterpret_cast<float*>(sm);
-        int* cbr = reinterpret_cast<int*>(cbv + 4 * kChunk);
-        stream_tile(a, dil, thresh, ws, g_logits, vec, (int)blockIdx.x - n_pool, cbv, cbr);
     }
     BXI_T(0, blockIdx.x, 1);
 }
@@ -432,6 +443,52 @@ __device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
 }
 
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
+
+// Arrival protocol (hierarchical ticket).  Every working workgroup of box_kernel -- the box tiles and
+// the leader of an instance -- calls this once, after thread 0 has issued its agent-scope
+// contributions (atomicAdd into acc / write-through store of dice).  The last arrival of an instance
+// arrives for the instance; the last instance computes the two loss values and the normaliser
+// (what a separate one-workgroup launch would otherwise do).  Counters are zeroed by stage1.
+__device__ __forceinline__ void arrive_and_finish(const LossWs& ws, const LossState& st, int n, int N, float warmup,
+                                                  float* __restrict__ losses, int* flag, double* red64, float* dbuf) {
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's contributions are performed
+        int last = 0;
+        const unsigned int o1 = __hip_atomic_fetch_add(&ws.arrive[n], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (o1 + 1u == __hip_atomic_load(&ws.expect[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            const unsigned int o2 = __hip_atomic_fetch_add(&ws.arrive[N], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (o2 + 1u == (unsigned int)N);
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;                                         // workgroup-uniform
+    // ---- the last workgroup of the launch: loss_prj, loss_pairwise, normaliser -----------------------------
+    unsigned long long acnt = 0ull; long long anum = 0;
+    for (int i = tid; i < N; i += 256) {
+        acnt += __hip_atomic_load(&ws.acc[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        anum += (long long)__hip_atomic_load(&ws.acc[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const double c = wave_sum_f64((double)acnt), s = wave_sum_f64((double)anum);   // exact: integers far below 2^53
+    if ((tid & 63) == 0) { red64[tid >> 6] = c; red64[4 + (tid >> 6)] = s; }
+    float acc = 0.f;                                            // dice summed in index order (deterministic)
+    for (int base = 0; base < N; base += 256) {
+        dbuf[tid] = base + tid < N ? __hip_atomic_load(&ws.dice[base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        __syncthreads();
+        if (tid == 0)
+            for (int i = 0; i < min(256, N - base); ++i) acc += dbuf[i];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double cnt = (red64[0] + red64[1]) + (red64[2] + red64[3]);
+        const double num = ((red64[4] + red64[5]) + (red64[6] + red64[7])) / (double)kNumScale;
+        const float denom = fmaxf((float)cnt, 1.f);                 // weights.sum().clamp(min=1.0), :1328
+        losses[0] = acc / (float)N;                                 // .mean(), :143
+        losses[1] = (float)(num / (double)denom) * warmup;          // :1327-1332
+        if (st.scale) *st.scale = warmup / denom;
+    }
+}
 
 __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const LossWs& ws, const LossState& st, int n,
                                              unsigned char* smem, float* red) {
@@ -486,7 +543,8 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const L
     }
     block_sum4(sums, red);
     const float Ix = sums[0], Ux = sums[1] + 1e-5f, Iy = sums[2], Uy = sums[3] + 1e-5f;
-    if (tid == 0) ws.dice[n] = (1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy);   // :130, summed over both axes :143
+    if (tid == 0)   // :130, summed over both axes :143 ; write-through, read by the last workgroup
+        __hip_atomic_store(&ws.dice[n], (1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (st.gcol) {
         // dice = 1 - 2I/U ; d dice/d u_j = (-2 t_j U + 4 I u_j) / U^2 ; chain through sigmoid ; mean over N
         const float invN = 1.f / (float)a.N;
@@ -533,15 +591,20 @@ __device__ __noinline__ float2 pair_logspace_redo(const float* __restrict__ L, c
 
 template <bool FROM_LAB>
 __global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __restrict__ lab, ImageMeta meta,
-                                                  const uint8_t* __restrict__ bits_in, float thresh, int dil, LossWs ws,
-                                                  LossState st, float* __restrict__ g_logits, int vec) {
+                                                  const uint8_t* __restrict__ bits_in, float thresh, int dil, float warmup,
+                                                  LossWs ws, LossState st, float* __restrict__ losses,
+                                                  float* __restrict__ g_logits, int vec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double red64[8];
+    __shared__ float dbuf[256];
     __shared__ float red[16];
     __shared__ int rcnt[4];
+    __shared__ int fin_flag;
     const int h = a.h, w = a.w;
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < a.N) {   // workgroup-uniform
         leader_block(a, dil, ws, st, (int)blockIdx.x, smem, red);
+        arrive_and_finish(ws, st, (int)blockIdx.x, a.N, warmup, losses, &fin_flag, red64, dbuf);
         return;
     }
     BXI_T(1, blockIdx.x, 0);
@@ -549,6 +612,7 @@ __global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __res
     const int wi = (int)blockIdx.x - a.N;
     const WorkRec wr = ws.work[wi];          // speculative (wi is always inside the list's capacity) ...
     if (wi >= *ws.nwork) return;             // ... so both loads are in flight together; workgroup-uniform
+    const Pred pr = FROM_LAB ? *ws.pred : Pred{0.f, 1, 0, 0};   // issued with the loads below, used after them
     const int n = wr.n, r0 = wr.tile_r0, c0 = wr.tile_c0;
     InstRec rc; rc.r0 = wr.r0; rc.r1 = wr.r1; rc.c0 = wr.c0; rc.c1 = wr.c1; rc.img = wr.img;
     const InstBox ib = inst_from_rec(rc, dil, h, w);
@@ -609,7 +673,6 @@ __global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __res
     //   W[k,p]   = [p in box] * [sim(p->q) >= thresh],  sim(p->q) = exp(-||Lab_p-Lab_q||/2) * valid(q)
     //   W[7-k,q] = [q in box] * [sim(q->p) >= thresh],  sim(q->p) = exp(-||Lab_q-Lab_p||/2) * valid(p)
     // the two share the distance, so no per-pixel affinity word has to be staged (FROM_LAB).
-    const Pred pr = FROM_LAB ? *ws.pred : Pred{0.f, 1, 0, 0};
     const int vr = FROM_LAB ? min(meta.img_h[ib.img], meta.first_removed[ib.img]) : 0;   // valid(q): :1354-1369,:1405
     const int vc = FROM_LAB ? meta.img_w[ib.img] : 0;
     const int half = a.stride / 2;
@@ -719,42 +782,11 @@ __global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __res
         if (c0 + lcx + 32 < w) G[32] = out[1];
     }
     BXI_T(1, blockIdx.x, 5);
+    arrive_and_finish(ws, st, n, a.N, warmup, losses, &fin_flag, red64, dbuf);
 }
 
 // ================================================================================================
-// Kernel 3: loss_scalars -- one workgroup: the two loss values and the gradient normaliser
-// ================================================================================================
-__global__ __launch_bounds__(256) void loss_scalars_kernel(int N, float warmup, LossWs ws, LossState st,
-                                                           float* __restrict__ losses) {
-    __shared__ double red64[8];
-    __shared__ float dbuf[256];
-    const int tid = threadIdx.x;
-    unsigned long long acnt = 0ull; long long anum = 0;
-    float d0 = tid < N ? ws.dice[tid] : 0.f;
-    if (tid < N) { acnt = ws.acc[2 * tid]; anum = (long long)ws.acc[2 * tid + 1]; }
-    for (int i = tid + 256; i < N; i += 256) { acnt += ws.acc[2 * i]; anum += (long long)ws.acc[2 * i + 1]; }
-    double c = wave_sum_f64((double)acnt), s = wave_sum_f64((double)anum);   // exact: integers far below 2^53
-    if ((tid & 63) == 0) { red64[tid >> 6] = c; red64[4 + (tid >> 6)] = s; }
-    float acc = 0.f;                                   // dice summed in index order (deterministic)
-    for (int base = 0; base < N; base += 256) {
-        dbuf[tid] = base == 0 ? d0 : (base + tid < N ? ws.dice[base + tid] : 0.f);
-        __syncthreads();
-        if (tid == 0)
-            for (int i = 0; i < min(256, N - base); ++i) acc += dbuf[i];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const double cnt = (red64[0] + red64[1]) + (red64[2] + red64[3]);
-        const double num = ((red64[4] + red64[5]) + (red64[6] + red64[7])) / (double)kNumScale;
-        const float denom = fmaxf((float)cnt, 1.f);                 // weights.sum().clamp(min=1.0), :1328
-        losses[0] = acc / (float)N;                                 // .mean(), :143
-        losses[1] = (float)(num / (double)denom) * warmup;          // :1327-1332
-        if (st.scale) *st.scale = warmup / denom;
-    }
-}
-
-// ================================================================================================
-// Kernel 4 (backward): loss_apply -- normalise the pairwise gradient, add the projection gradient
+// Kernel 3 (backward): loss_apply -- normalise the pairwise gradient, add the projection gradient
 // ================================================================================================
 // grid = kSlices x N.  g_logits holds zeros + the un-normalised pairwise gradient on the box tiles.
 //   dense pass over the box tiles:  G <- g_pw * (warmup / max(sum W,1)) * G + g_prj * prj(r,c)
@@ -914,16 +946,15 @@ int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, co
     if (from_lab && batch->B > 0) {
         if (pool_vec_ok(batch, a.stride)) {
             const int64_t total = (int64_t)batch->B * a.h * a.w;
-            n_pool = (int)((total + 255) / 256);
-            n_pool = (n_pool + 7) & ~7;   // keep streaming tile i on XCD i % 8, like box tile i
+            n_pool = (int)((total + 63) / 64);
         } else {                           // unaligned canvas / other strides: separate scalar pooling launch
             rc = launch_pool(batch, a.stride, nullptr, lab, s);
             if (rc != BXI_OK) return rc;
         }
     }
     const int n_stream = a.N * stream_tiles(a.h);
-    BXI_LAUNCH("stage1", s, stage1_kernel, dim3((unsigned)(n_pool + n_stream)), dim3(256), 0, s, pa, n_pool, a, dil,
-               color_thresh, ws, g_logits, vec);
+    BXI_LAUNCH("stage1", s, stage1_kernel, dim3((unsigned)(a.N + 1 + n_pool + n_stream)), dim3(64), 0, s, pa, n_pool, a,
+               dil, color_thresh, ws, g_logits, vec);
     rc = check_launch();
     if (rc != BXI_OK) return rc;
 
@@ -941,15 +972,10 @@ int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, co
     const int n_box = a.N + a.N * box_tiles(a.h, a.w);
     if (from_lab)
         BXI_LAUNCH("box", s, (box_kernel<true>), dim3((unsigned)n_box), dim3(256), lds, s, a, (const float*)lab, meta,
-                   (const uint8_t*)nullptr, color_thresh, dil, ws, st, g_logits, vec);
+                   (const uint8_t*)nullptr, color_thresh, dil, warmup, ws, st, losses, g_logits, vec);
     else
         BXI_LAUNCH("box", s, (box_kernel<false>), dim3((unsigned)n_box), dim3(256), lds, s, a, (const float*)nullptr,
-                   meta, affinity, 0.f, dil, ws, st, g_logits, vec);
-    rc = check_launch();
-    if (rc != BXI_OK) return rc;
-
-    // ---- kernel 3: the two loss values + the normaliser the backward needs ---------------------------------
-    BXI_LAUNCH("loss_scalars", s, loss_scalars_kernel, dim3(1), dim3(256), 0, s, a.N, warmup, ws, st, losses);
+                   meta, affinity, 0.f, dil, warmup, ws, st, losses, g_logits, vec);
     return check_launch();
 }
 

@@ -174,7 +174,7 @@ int bxi_boxinst_loss_fwd_bwd_f32(const bxi_instances* inst_host, const uint8_t* 
 int bxi_boxinst_loss_backward_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw,
                                   int dilation, const void* state, float* g_logits, void* stream);
 
-/* Whole forward in one host call, three launches: the image side (stage A above) runs inside the
+/* Whole forward in one host call, two launches: the image side (stage A above) runs inside the
  * first loss kernel next to the logit streaming, and the affinity bits are derived from Lab where
  * the loss needs them (nothing of stage B is materialised).  Same results as
  * bxi_color_affinity_f32 + bxi_boxinst_loss_fwd_bwd_f32.  batch_host->image_masks must be NULL.

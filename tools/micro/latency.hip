@@ -45,6 +45,44 @@ __global__ void k_write4(float4* p, size_t n4) {
     if (i < n4) p[i] = make_float4(0, 0, 0, 0);
 }
 
+// pool_rgb access pattern without the arithmetic: lane = one 4x4x3 window of a [B,3,H,W] f32 image
+template <int BLOCK>
+__global__ void k_poolpat(const float* __restrict__ img, int B, int H, int W, float* out) {
+    const int h = H / 4, w = W / 4;
+    const long long o = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (o >= (long long)B * h * w) return;
+    const int c = o % w, r = (o / w) % h, b = o / ((long long)w * h);
+    const long long plane = (long long)H * W;
+    const float* base = img + (long long)b * 3 * plane + (long long)(4 * r) * W + 4 * c;
+    float4 v[12];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[ch * 4 + i] = *reinterpret_cast<const float4*>(base + ch * plane + (long long)i * W);
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc += v[i].x + v[i].y + v[i].z + v[i].w;
+    if (acc == 123.456f) out[0] = acc;
+}
+// streaming-tile pattern: block = 4 waves, wave reads RW rows of 256 floats (1 KiB) of a [N,h,256] map, writes zeros
+template <int RW, bool WRITE>
+__global__ void k_streampat(const float* __restrict__ L, float* __restrict__ G, int N, int h, float* out) {
+    const int T = (h + 4 * RW - 1) / (4 * RW);
+    const int n = blockIdx.x / T, t = blockIdx.x % T, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = t * 4 * RW;
+    float4 v[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) { const int r = r0 + wv + 4 * i; v[i] = r < h ? *reinterpret_cast<const float4*>(L + ((long long)n * h + r) * 256 + lane * 4) : make_float4(0, 0, 0, 0); }
+    if (WRITE) {
+#pragma unroll
+        for (int i = 0; i < RW; ++i) { const int r = r0 + wv + 4 * i; if (r < h) *reinterpret_cast<float4*>(G + ((long long)n * h + r) * 256 + lane * 4) = make_float4(0, 0, 0, 0); }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) acc += v[i].x + v[i].y + v[i].z + v[i].w;
+    if (acc == 123.456f) out[0] = acc;
+}
+
 template <typename F> float time_us(F f, int reps, hipStream_t s) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 5; ++i) f(i);
@@ -112,6 +150,29 @@ int main() {
             printf("read 320MB grid-stride 4096 blocks: %.2f us -> %.0f GB/s\n", t, one * nbuf / t / 1e3);
         }
         hipFree(big);
+    }
+    // ---- access patterns of stage1 (2x3x800x1024 image, 32x200x256 logits), rotating over 8 cold sets ----
+    {
+        const int nset = 8; const size_t img_b = (size_t)2 * 3 * 800 * 1024 * 4, log_b = (size_t)32 * 200 * 256 * 4;
+        char *imgs, *logs, *grads; CK(hipMalloc(&imgs, img_b * nset)); CK(hipMalloc(&logs, log_b * nset)); CK(hipMalloc(&grads, log_b * nset));
+        CK(hipMemset(imgs, 1, img_b * nset)); CK(hipMemset(logs, 1, log_b * nset));
+        float t;
+        t = time_us([&](int i) { hipLaunchKernelGGL((k_poolpat<256>), 400, 256, 0, s, (const float*)(imgs + img_b * (i % nset)), 2, 800, 1024, o); }, 160, s);
+        printf("pool pattern 19.7MB, 400x256 threads : %.2f us -> %.0f GB/s\n", t, img_b / t / 1e3);
+        t = time_us([&](int i) { hipLaunchKernelGGL((k_poolpat<64>), 1600, 64, 0, s, (const float*)(imgs + img_b * (i % nset)), 2, 800, 1024, o); }, 160, s);
+        printf("pool pattern 19.7MB, 1600x64 threads : %.2f us -> %.0f GB/s\n", t, img_b / t / 1e3);
+        t = time_us([&](int i) { hipLaunchKernelGGL((k_poolpat<128>), 800, 128, 0, s, (const float*)(imgs + img_b * (i % nset)), 2, 800, 1024, o); }, 160, s);
+        printf("pool pattern 19.7MB, 800x128 threads : %.2f us -> %.0f GB/s\n", t, img_b / t / 1e3);
+        t = time_us([&](int i) { hipLaunchKernelGGL((k_streampat<4, false>), 32 * 13, 256, 0, s, (const float*)(logs + log_b * (i % nset)), (float*)(grads + log_b * (i % nset)), 32, 200, o); }, 160, s);
+        printf("stream pattern read 6.5MB (16-row tiles): %.2f us -> %.0f GB/s\n", t, log_b / t / 1e3);
+        t = time_us([&](int i) { hipLaunchKernelGGL((k_streampat<4, true>), 32 * 13, 256, 0, s, (const float*)(logs + log_b * (i % nset)), (float*)(grads + log_b * (i % nset)), 32, 200, o); }, 160, s);
+        printf("stream pattern read+write 13MB (16-row tiles): %.2f us -> %.0f GB/s\n", t, 2 * log_b / t / 1e3);
+        t = time_us([&](int i) { hipLaunchKernelGGL((k_streampat<2, true>), 32 * 25, 256, 0, s, (const float*)(logs + log_b * (i % nset)), (float*)(grads + log_b * (i % nset)), 32, 200, o); }, 160, s);
+        printf("stream pattern read+write 13MB (8-row tiles): %.2f us -> %.0f GB/s\n", t, 2 * log_b / t / 1e3);
+        // both back to back on two streams is what one fused launch does; emulate with sequential launches
+        t = time_us([&](int i) { hipLaunchKernelGGL((k_poolpat<256>), 400, 256, 0, s, (const float*)(imgs + img_b * (i % nset)), 2, 800, 1024, o);
+                                 hipLaunchKernelGGL((k_streampat<4, true>), 32 * 13, 256, 0, s, (const float*)(logs + log_b * (i % nset)), (float*)(grads + log_b * (i % nset)), 32, 200, o); }, 160, s);
+        printf("pool + stream as two launches: %.2f us\n", t);
     }
     return 0;
 }
