@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=200)
-    ap.add_argument('--mode', choices=['graph', 'eager'], default='graph',
+    ap.add_argument('--mode', choices=['graph', 'eager'], default="eager",
                     help='graph: one hipGraph per input set, replayed; eager: direct C-ABI calls')
     ap.add_argument('--sets', type=int, default=8, help='independent input sets rotated through')
     ap.add_argument('--inst-per-box', type=int, default=1)

@@ -419,8 +419,8 @@ __global__ __launch_bounds__(64) void stage1_kernel(PoolArgs pa, int n_pool, Ins
 //   instance n to the h+w maxima, applies sigmoid to those only (max sigmoid = sigmoid max), forms
 //   the two dice terms (condinst_head.py:117-143) and the unit projection gradient at each arg-max
 //   position (kept in `state` for the backward).  Runs concurrently with the tile workgroups.
-// Tile workgroups take their (instance, tile) from the compacted work list stage1 built, so the
-// working ones are the first of the grid and start together; the rest exit after one scalar load.
+// Tile workgroups take their (instance, tile) from the compacted work list stage1 built (at most 1024
+// tile workgroups are launched; each strides through the list), so the working ones start together.
 //   LDS  pq   [8+2d][64+2P]     (sigmoid(x), sigmoid(-x)) of the tile + halo         (P = d rounded up to 4)
 //        lab  [3][8+2d][64+2P]  CIE-Lab of the same region (FROM_LAB) | bits [8+2d][64+2P] (!FROM_LAB)
 //   1. all global loads (logits region, Lab region) are issued together, float4, aligned;
@@ -502,11 +502,13 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const L
     {
         const int c = tid < w ? tid : 0;
 #pragma unroll
-        for (int u = 0; u < kMaxT; ++u) {
-            const int64_t o = ((int64_t)n * Ts + (u < Ts ? u : 0)) * w + c;
-            cv[u] = u < Ts ? ws.colv[o] : -INFINITY;
-            cr[u] = u < Ts ? ws.colr[o] : (uint8_t)0;
+        for (int u = 0; u < kMaxT; ++u) {   // unconditional (index clamped): 2 x kMaxT loads in flight, no branches
+            const int64_t o = ((int64_t)n * Ts + min(u, Ts - 1)) * w + c;
+            cv[u] = ws.colv[o];
+            cr[u] = ws.colr[o];
         }
+#pragma unroll
+        for (int u = 0; u < kMaxT; ++u) cv[u] = u < Ts ? cv[u] : -INFINITY;
     }
     const unsigned long long rk0 = ws.rowkey[(int64_t)n * h + (tid < h ? tid : 0)];
     const InstBox ib = inst_from_rec(rec, dil, h, w);
@@ -541,7 +543,9 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const L
         if (st.rowarg) st.rowarg[(int64_t)n * h + r] = (int)unpack_idx(k);
         sums[2] += Y * TY; sums[3] += Y * Y + TY * TY;
     }
+    BXI_T(2, blockIdx.x, 1);
     block_sum4(sums, red);
+    BXI_T(2, blockIdx.x, 2);
     const float Ix = sums[0], Ux = sums[1] + 1e-5f, Iy = sums[2], Uy = sums[3] + 1e-5f;
     if (tid == 0)   // :130, summed over both axes :143 ; write-through, read by the last workgroup
         __hip_atomic_store(&ws.dice[n], (1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -603,186 +607,195 @@ __global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __res
     const int h = a.h, w = a.w;
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < a.N) {   // workgroup-uniform
+        BXI_T(2, blockIdx.x, 0);
         leader_block(a, dil, ws, st, (int)blockIdx.x, smem, red);
+        BXI_T(2, blockIdx.x, 3);
         arrive_and_finish(ws, st, (int)blockIdx.x, a.N, warmup, losses, &fin_flag, red64, dbuf);
+        BXI_T(2, blockIdx.x, 4);
         return;
     }
-    BXI_T(1, blockIdx.x, 0);
-    // work list built by stage1: the box tiles of all instances, compacted (hit tiles come first in the grid)
-    const int wi = (int)blockIdx.x - a.N;
-    const WorkRec wr = ws.work[wi];          // speculative (wi is always inside the list's capacity) ...
-    if (wi >= *ws.nwork) return;             // ... so both loads are in flight together; workgroup-uniform
-    const Pred pr = FROM_LAB ? *ws.pred : Pred{0.f, 1, 0, 0};   // issued with the loads below, used after them
-    const int n = wr.n, r0 = wr.tile_r0, c0 = wr.tile_c0;
-    InstRec rc; rc.r0 = wr.r0; rc.r1 = wr.r1; rc.c0 = wr.c0; rc.c1 = wr.c1; rc.img = wr.img;
-    const InstBox ib = inst_from_rec(rc, dil, h, w);
-    BXI_T(1, blockIdx.x, 1);
-    const int64_t P = (int64_t)h * w;
-    const float* L = a.logits + (int64_t)n * P;
-    const int d = dil;
-    const int PAD = (d + 3) & ~3;
-    const int PR = kBR + 2 * d, PC = kBC + 2 * PAD;          // staged region: tile + halo (columns padded to 4)
-    float2* pq = reinterpret_cast<float2*>(smem);
-    float* labs = reinterpret_cast<float*>(smem + sizeof(float2) * (size_t)PR * PC);   // [3][PR][PC]   (FROM_LAB)
-    uint8_t* bits = smem + sizeof(float2) * (size_t)PR * PC;                            // [PR][PC]      (!FROM_LAB)
+    const int nwork = *ws.nwork;
+    const int ntile_wg = (int)gridDim.x - a.N;
+    for (int wi = (int)blockIdx.x - a.N; wi < a.N * ((h + kBR - 1) / kBR) * ((w + kBC - 1) / kBC); wi += ntile_wg) {
+        BXI_T(1, blockIdx.x, 0);
+        // work list built by stage1: the box tiles of all instances, compacted.  The tile workgroups of this
+        // launch take item blockIdx - N (+ a multiple of the tile-workgroup count when there are more items)
+        const WorkRec wr = ws.work[wi];          // speculative (wi is always inside the list's capacity) ...
+        if (wi >= nwork) break;                  // workgroup-uniform
+        const Pred pr = FROM_LAB ? *ws.pred : Pred{0.f, 1, 0, 0};   // issued with the loads below, used after them
+        const int n = wr.n, r0 = wr.tile_r0, c0 = wr.tile_c0;
+        InstRec rc; rc.r0 = wr.r0; rc.r1 = wr.r1; rc.c0 = wr.c0; rc.c1 = wr.c1; rc.img = wr.img;
+        const InstBox ib = inst_from_rec(rc, dil, h, w);
+        BXI_T(1, blockIdx.x, 1);
+        const int64_t P = (int64_t)h * w;
+        const float* L = a.logits + (int64_t)n * P;
+        const int d = dil;
+        const int PAD = (d + 3) & ~3;
+        const int PR = kBR + 2 * d, PC = kBC + 2 * PAD;          // staged region: tile + halo (columns padded to 4)
+        float2* pq = reinterpret_cast<float2*>(smem);
+        float* labs = reinterpret_cast<float*>(smem + sizeof(float2) * (size_t)PR * PC);   // [3][PR][PC]   (FROM_LAB)
+        uint8_t* bits = smem + sizeof(float2) * (size_t)PR * PC;                            // [PR][PC]      (!FROM_LAB)
 
-    // ---- 1. loads: logits region (-> sigmoid pairs) and Lab region, all in flight together -----------
-    {
-        const int q4 = PC / 4, items = PR * q4;                 // d = 2: 216 float4 per plane
-        const float* LB = FROM_LAB ? lab + (int64_t)ib.img * 3 * P : nullptr;
-        for (int i = tid; i < items; i += 256) {
-            const int lr = i / q4, r = r0 - d + lr, c = c0 - PAD + (i % q4) * 4;
-            const bool inb = r >= 0 && r < h && c >= 0 && c < w;
-            float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0, t3 = t0;   // zero padding of F.unfold
-            if (inb) {
-                t0 = load4(L + (int64_t)r * w, c, w, vec);
-                if (FROM_LAB) {
-                    const float* row = LB + (int64_t)r * w;
-                    if (vec) {
-                        t1 = *reinterpret_cast<const float4*>(row + c);
-                        t2 = *reinterpret_cast<const float4*>(row + P + c);
-                        t3 = *reinterpret_cast<const float4*>(row + 2 * P + c);
-                    } else {
-                        t1 = load4(row, c, w, false); t2 = load4(row + P, c, w, false); t3 = load4(row + 2 * P, c, w, false);
+        // ---- 1. loads: logits region (-> sigmoid pairs) and Lab region, all in flight together -----------
+        {
+            const int q4 = PC / 4, items = PR * q4;                 // d = 2: 216 float4 per plane
+            const float* LB = FROM_LAB ? lab + (int64_t)ib.img * 3 * P : nullptr;
+            for (int i = tid; i < items; i += 256) {
+                const int lr = i / q4, r = r0 - d + lr, c = c0 - PAD + (i % q4) * 4;
+                const bool inb = r >= 0 && r < h && c >= 0 && c < w;
+                float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0, t3 = t0;   // zero padding of F.unfold
+                if (inb) {
+                    t0 = load4(L + (int64_t)r * w, c, w, vec);
+                    if (FROM_LAB) {
+                        const float* row = LB + (int64_t)r * w;
+                        if (vec) {
+                            t1 = *reinterpret_cast<const float4*>(row + c);
+                            t2 = *reinterpret_cast<const float4*>(row + P + c);
+                            t3 = *reinterpret_cast<const float4*>(row + 2 * P + c);
+                        } else {
+                            t1 = load4(row, c, w, false); t2 = load4(row + P, c, w, false); t3 = load4(row + 2 * P, c, w, false);
+                        }
                     }
                 }
+                float2* dst = pq + (size_t)lr * PC + (i % q4) * 4;
+                dst[0] = sig_pair(t0.x); dst[1] = sig_pair(t0.y); dst[2] = sig_pair(t0.z); dst[3] = sig_pair(t0.w);
+                if (FROM_LAB) {
+                    float* ld = labs + (size_t)lr * PC + (i % q4) * 4;
+                    *reinterpret_cast<float4*>(ld) = t1;
+                    *reinterpret_cast<float4*>(ld + PR * PC) = t2;
+                    *reinterpret_cast<float4*>(ld + 2 * PR * PC) = t3;
+                }
             }
-            float2* dst = pq + (size_t)lr * PC + (i % q4) * 4;
-            dst[0] = sig_pair(t0.x); dst[1] = sig_pair(t0.y); dst[2] = sig_pair(t0.z); dst[3] = sig_pair(t0.w);
-            if (FROM_LAB) {
-                float* ld = labs + (size_t)lr * PC + (i % q4) * 4;
-                *reinterpret_cast<float4*>(ld) = t1;
-                *reinterpret_cast<float4*>(ld + PR * PC) = t2;
-                *reinterpret_cast<float4*>(ld + 2 * PR * PC) = t3;
+            if (!FROM_LAB) {   // affinity words given: stage those of the in-box pixels (bitmask == 1, :1324-1325)
+                const uint8_t* AF = bits_in + (int64_t)ib.img * P;
+                for (int i = tid; i < PR * PC; i += 256) {
+                    const int r = r0 - d + i / PC, c = c0 - PAD + i % PC;
+                    const bool inbox = r >= ib.box.r0 && r < ib.box.r1 && c >= ib.box.c0 && c < ib.box.c1;
+                    bits[i] = inbox ? AF[(int64_t)r * w + c] : (uint8_t)0;
+                }
             }
         }
-        if (!FROM_LAB) {   // affinity words given: stage those of the in-box pixels (bitmask == 1, :1324-1325)
-            const uint8_t* AF = bits_in + (int64_t)ib.img * P;
-            for (int i = tid; i < PR * PC; i += 256) {
-                const int r = r0 - d + i / PC, c = c0 - PAD + i % PC;
-                const bool inbox = r >= ib.box.r0 && r < ib.box.r1 && c >= ib.box.c0 && c < ib.box.c1;
-                bits[i] = inbox ? AF[(int64_t)r * w + c] : (uint8_t)0;
-            }
-        }
-    }
-    __syncthreads();
-    BXI_T(1, blockIdx.x, 2);
+        __syncthreads();
+        BXI_T(1, blockIdx.x, 2);
 
-    // ---- 2. colour affinity + pairwise term, 2 pixels per thread ---------------------------------------
-    // weight of the pair (p, q = p + delta_k):  W[k,p] + W[7-k,q]
-    //   W[k,p]   = [p in box] * [sim(p->q) >= thresh],  sim(p->q) = exp(-||Lab_p-Lab_q||/2) * valid(q)
-    //   W[7-k,q] = [q in box] * [sim(q->p) >= thresh],  sim(q->p) = exp(-||Lab_q-Lab_p||/2) * valid(p)
-    // the two share the distance, so no per-pixel affinity word has to be staged (FROM_LAB).
-    const int vr = FROM_LAB ? min(meta.img_h[ib.img], meta.first_removed[ib.img]) : 0;   // valid(q): :1354-1369,:1405
-    const int vc = FROM_LAB ? meta.img_w[ib.img] : 0;
-    const int half = a.stride / 2;
-    // thread -> row lr, columns lcx and lcx + 32: the 32 lanes of a row read consecutive LDS words
-    // (conflict-free ds_read_b32 / b64), unlike an adjacent-pixel pairing (2-way conflicts)
-    const int lr = tid >> 5, lcx = tid & 31;
-    const int r = r0 + lr;
-    float num = 0.f;
-    int cnt = 0;
-    float out[2] = {0.f, 0.f};
-    // per-row flags of the three neighbour rows: bit0 inside the map, bit1 inside the box, bit2 valid
-    uint32_t rfl[3];
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-        const int r2 = r + dy * d;
-        const uint32_t in = (r2 >= 0 && r2 < h) ? 1u : 0u;
-        rfl[dy + 1] = in | ((r2 >= ib.box.r0 && r2 < ib.box.r1) ? 2u : 0u) | ((in && r2 * a.stride + half < vr) ? 4u : 0u);
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int c = c0 + lcx + 32 * e;
-        if (r < ib.dil.r0 || r >= ib.dil.r1 || c < ib.dil.c0 || c >= ib.dil.c1) continue;
-        uint32_t cfl[3];
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int c2 = c + dx * d;
-            const uint32_t in = (c2 >= 0 && c2 < w) ? 1u : 0u;
-            cfl[dx + 1] = in | ((c2 >= ib.box.c0 && c2 < ib.box.c1) ? 2u : 0u) | ((in && c2 * a.stride + half < vc) ? 4u : 0u);
+        // ---- 2. colour affinity + pairwise term, 2 pixels per thread ---------------------------------------
+        // weight of the pair (p, q = p + delta_k):  W[k,p] + W[7-k,q]
+        //   W[k,p]   = [p in box] * [sim(p->q) >= thresh],  sim(p->q) = exp(-||Lab_p-Lab_q||/2) * valid(q)
+        //   W[7-k,q] = [q in box] * [sim(q->p) >= thresh],  sim(q->p) = exp(-||Lab_q-Lab_p||/2) * valid(p)
+        // the two share the distance, so no per-pixel affinity word has to be staged (FROM_LAB).
+        const int vr = FROM_LAB ? min(meta.img_h[ib.img], meta.first_removed[ib.img]) : 0;   // valid(q): :1354-1369,:1405
+        const int vc = FROM_LAB ? meta.img_w[ib.img] : 0;
+        const int half = a.stride / 2;
+        // thread -> row lr, columns lcx and lcx + 32: the 32 lanes of a row read consecutive LDS words
+        // (conflict-free ds_read_b32 / b64), unlike an adjacent-pixel pairing (2-way conflicts)
+        const int lr = tid >> 5, lcx = tid & 31;
+        const int r = r0 + lr;
+        float num = 0.f;
+        int cnt = 0;
+        float out[2] = {0.f, 0.f};
+        // per-row flags of the three neighbour rows: bit0 inside the map, bit1 inside the box, bit2 valid
+        uint32_t rfl[3];
+    #pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int r2 = r + dy * d;
+            const uint32_t in = (r2 >= 0 && r2 < h) ? 1u : 0u;
+            rfl[dy + 1] = in | ((r2 >= ib.box.r0 && r2 < ib.box.r1) ? 2u : 0u) | ((in && r2 * a.stride + half < vr) ? 4u : 0u);
         }
-        const int pi = (lr + d) * PC + (lcx + 32 * e + PAD);
-        const float2 pp = pq[pi];
-        const uint32_t fp_ = rfl[1] & cfl[1];                       // flags of p itself
-        const bool in_p = (fp_ & 2u) != 0u, val_p = (fp_ & 4u) != 0u;
-        const uint32_t bits_p = FROM_LAB ? 0u : bits[pi];
-        float L0 = 0.f, A0 = 0.f, B0 = 0.f;
-        if (FROM_LAB) { L0 = labs[pi]; A0 = labs[PR * PC + pi]; B0 = labs[2 * PR * PC + pi]; }
-        float2 nq[8]; float nL[8], nA[8], nB[8]; uint32_t nbw[8];
-        {
+    #pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = c0 + lcx + 32 * e;
+            if (r < ib.dil.r0 || r >= ib.dil.r1 || c < ib.dil.c0 || c >= ib.dil.c1) continue;
+            uint32_t cfl[3];
+    #pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int c2 = c + dx * d;
+                const uint32_t in = (c2 >= 0 && c2 < w) ? 1u : 0u;
+                cfl[dx + 1] = in | ((c2 >= ib.box.c0 && c2 < ib.box.c1) ? 2u : 0u) | ((in && c2 * a.stride + half < vc) ? 4u : 0u);
+            }
+            const int pi = (lr + d) * PC + (lcx + 32 * e + PAD);
+            const float2 pp = pq[pi];
+            const uint32_t fp_ = rfl[1] & cfl[1];                       // flags of p itself
+            const bool in_p = (fp_ & 2u) != 0u, val_p = (fp_ & 4u) != 0u;
+            const uint32_t bits_p = FROM_LAB ? 0u : bits[pi];
+            float L0 = 0.f, A0 = 0.f, B0 = 0.f;
+            if (FROM_LAB) { L0 = labs[pi]; A0 = labs[PR * PC + pi]; B0 = labs[2 * PR * PC + pi]; }
+            float2 nq[8]; float nL[8], nA[8], nB[8]; uint32_t nbw[8];
+            {
+                int k = 0;
+    #pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+    #pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if (dx == 0 && dy == 0) continue;
+                        const int qi = pi + dy * d * PC + dx * d;
+                        nq[k] = pq[qi];
+                        if (FROM_LAB) { nL[k] = labs[qi]; nA[k] = labs[PR * PC + qi]; nB[k] = labs[2 * PR * PC + qi]; }
+                        else nbw[k] = bits[qi];
+                        ++k;
+                    }
+            }
+            float acc = 0.f;
+            bool tiny = false;
+            uint32_t wps = 0, wqs = 0;     // bit k: W[k,p] / W[7-k,q] (kept for the rare log-space redo)
+            const float ppq = pp.x * pp.y;
             int k = 0;
-#pragma unroll
+    #pragma unroll
             for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
+    #pragma unroll
                 for (int dx = -1; dx <= 1; ++dx) {
                     if (dx == 0 && dy == 0) continue;
-                    const int qi = pi + dy * d * PC + dx * d;
-                    nq[k] = pq[qi];
-                    if (FROM_LAB) { nL[k] = labs[qi]; nA[k] = labs[PR * PC + qi]; nB[k] = labs[2 * PR * PC + qi]; }
-                    else nbw[k] = bits[qi];
+                    const uint32_t fq = rfl[dy + 1] & cfl[dx + 1];          // bit0 in map, bit1 in box, bit2 valid
+                    const bool inb = (fq & 1u) != 0u;
+                    uint32_t wp, wq;
+                    if (FROM_LAB) {
+                        const float dL = L0 - nL[k], dA = A0 - nA[k], dB = B0 - nB[k];
+                        const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(dL, dL), __fmul_rn(dA, dA)), __fmul_rn(dB, dB));
+                        const uint32_t pn = n2 <= pr.n2max ? 1u : 0u;
+                        wp = in_p ? ((fq & 4u) ? pn : (uint32_t)pr.zero_bit) : 0u;           // padded / masked-out q: sim == 0
+                        wq = ((fq & 3u) == 3u) ? (val_p ? pn : (uint32_t)pr.zero_bit) : 0u;
+                    } else {
+                        wp = (bits_p >> k) & 1u;
+                        wq = inb ? (nbw[k] >> (7 - k)) & 1u : 0u;
+                    }
+                    cnt += (int)wp;                                          // weights.sum(), :1328 (counts padded pairs too)
+                    wps |= wp << k; wqs |= wq << k;
+                    const float fw = inb ? (float)(wp + wq) : 0.f, fp = inb ? (float)wp : 0.f;
+                    const float S = pp.x * nq[k].x + pp.y * nq[k].y;        // P(y_p == y_q)
+                    tiny |= (fw != 0.f) && !(S > 1e-30f);
+                    const float Sc = fmaxf(S, 1e-30f);
+                    num += fp * -__logf(Sc);
+                    acc += fw * (-(nq[k].x - nq[k].y) * ppq * __frcp_rn(Sc));
                     ++k;
                 }
-        }
-        float acc = 0.f;
-        bool tiny = false;
-        uint32_t wps = 0, wqs = 0;     // bit k: W[k,p] / W[7-k,q] (kept for the rare log-space redo)
-        const float ppq = pp.x * pp.y;
-        int k = 0;
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                if (dx == 0 && dy == 0) continue;
-                const uint32_t fq = rfl[dy + 1] & cfl[dx + 1];          // bit0 in map, bit1 in box, bit2 valid
-                const bool inb = (fq & 1u) != 0u;
-                uint32_t wp, wq;
-                if (FROM_LAB) {
-                    const float dL = L0 - nL[k], dA = A0 - nA[k], dB = B0 - nB[k];
-                    const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(dL, dL), __fmul_rn(dA, dA)), __fmul_rn(dB, dB));
-                    const uint32_t pn = n2 <= pr.n2max ? 1u : 0u;
-                    wp = in_p ? ((fq & 4u) ? pn : (uint32_t)pr.zero_bit) : 0u;           // padded / masked-out q: sim == 0
-                    wq = ((fq & 3u) == 3u) ? (val_p ? pn : (uint32_t)pr.zero_bit) : 0u;
-                } else {
-                    wp = (bits_p >> k) & 1u;
-                    wq = inb ? (nbw[k] >> (7 - k)) & 1u : 0u;
-                }
-                cnt += (int)wp;                                          // weights.sum(), :1328 (counts padded pairs too)
-                wps |= wp << k; wqs |= wq << k;
-                const float fw = inb ? (float)(wp + wq) : 0.f, fp = inb ? (float)wp : 0.f;
-                const float S = pp.x * nq[k].x + pp.y * nq[k].y;        // P(y_p == y_q)
-                tiny |= (fw != 0.f) && !(S > 1e-30f);
-                const float Sc = fmaxf(S, 1e-30f);
-                num += fp * -__logf(Sc);
-                acc += fw * (-(nq[k].x - nq[k].y) * ppq * __frcp_rn(Sc));
-                ++k;
+            if (tiny) {   // rare
+                const float2 fix = pair_logspace_redo(L, pq, h, w, d, PC, r, c, pi, pp, wps, wqs);
+                num += fix.x; acc = fix.y;
             }
-        if (tiny) {   // rare
-            const float2 fix = pair_logspace_redo(L, pq, h, w, d, PC, r, c, pi, pp, wps, wqs);
-            num += fix.x; acc = fix.y;
+            out[e] = acc;
         }
-        out[e] = acc;
+        BXI_T(1, blockIdx.x, 4);
+        // ---- per-instance accumulators: integers, so the result does not depend on the arrival order --------
+        num = wave_sum_f32(num);
+        cnt = wave_sum_i32(cnt);
+        if ((tid & 63) == 0) { red[tid >> 6] = num; rcnt[tid >> 6] = cnt; }
+        __syncthreads();
+        if (tid == 0) {
+            const float bn = (red[0] + red[1]) + (red[2] + red[3]);
+            const int bc = rcnt[0] + rcnt[1] + rcnt[2] + rcnt[3];
+            if (bc) atomicAdd(&ws.acc[2 * n], (unsigned long long)bc);
+            if (bn != 0.f) atomicAdd(&ws.acc[2 * n + 1], (unsigned long long)(long long)(bn * kNumScale));
+        }
+        // gradient tile last: nothing in this workgroup waits for these stores
+        if (g_logits && r < h) {
+            float* G = g_logits + (int64_t)n * P + (int64_t)r * w + c0 + lcx;   // 2 x 128 B contiguous per half-wave
+            if (c0 + lcx < w) G[0] = out[0];
+            if (c0 + lcx + 32 < w) G[32] = out[1];
+        }
+        BXI_T(1, blockIdx.x, 5);
+        arrive_and_finish(ws, st, n, a.N, warmup, losses, &fin_flag, red64, dbuf);
+        BXI_T(1, blockIdx.x, 6);
+        __syncthreads();                     // LDS is reused by the next work item
     }
-    BXI_T(1, blockIdx.x, 4);
-    // ---- per-instance accumulators: integers, so the result does not depend on the arrival order --------
-    num = wave_sum_f32(num);
-    cnt = wave_sum_i32(cnt);
-    if ((tid & 63) == 0) { red[tid >> 6] = num; rcnt[tid >> 6] = cnt; }
-    __syncthreads();
-    if (tid == 0) {
-        const float bn = (red[0] + red[1]) + (red[2] + red[3]);
-        const int bc = rcnt[0] + rcnt[1] + rcnt[2] + rcnt[3];
-        if (bc) atomicAdd(&ws.acc[2 * n], (unsigned long long)bc);
-        if (bn != 0.f) atomicAdd(&ws.acc[2 * n + 1], (unsigned long long)(long long)(bn * kNumScale));
-    }
-    // gradient tile last: nothing in this workgroup waits for these stores
-    if (g_logits && r < h) {
-        float* G = g_logits + (int64_t)n * P + (int64_t)r * w + c0 + lcx;   // 2 x 128 B contiguous per half-wave
-        if (c0 + lcx < w) G[0] = out[0];
-        if (c0 + lcx + 32 < w) G[32] = out[1];
-    }
-    BXI_T(1, blockIdx.x, 5);
-    arrive_and_finish(ws, st, n, a.N, warmup, losses, &fin_flag, red64, dbuf);
 }
 
 // ================================================================================================
@@ -969,7 +982,8 @@ int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, co
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }
     }
-    const int n_box = a.N + a.N * box_tiles(a.h, a.w);
+    const int n_tiles = a.N * box_tiles(a.h, a.w);
+    const int n_box = a.N + (n_tiles < 1024 ? n_tiles : 1024);   // list length is device data: stride through it
     if (from_lab)
         BXI_LAUNCH("box", s, (box_kernel<true>), dim3((unsigned)n_box), dim3(256), lds, s, a, (const float*)lab, meta,
                    (const uint8_t*)nullptr, color_thresh, dil, warmup, ws, st, losses, g_logits, vec);

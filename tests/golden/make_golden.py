@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the REFERENCE's own code.
+
+Run in the build container only (it reads /root/reference; the GPU box has no such path):
+
+    python tests/golden/make_golden.py
+
+What is executed is the upstream source itself: the module-level functions
+``compute_pairwise_term, dice_coefficient, compute_project_term, unfold_wo_center,
+get_image_color_similarity, get_original_image`` and the ``CondInstMaskHead`` methods ``loss``,
+``get_targets``, ``get_bitmasks_from_boxes`` are pulled out of
+``mmdet/models/dense_heads/condinst_head.py`` by AST (oracle/reference_extract.py) and run on CPU torch.
+Nothing of it is copied into this repository; only inputs/outputs are stored.
+
+Third-party hooks the reference calls but which are NOT in its tree and not installable here are
+supplied by the restatements in oracle/torch_oracle.py (so those two stay "parity unpinned"):
+  tensor2imgs (mmcv)  -> torch_oracle.denormalize_u8       color.rgb2lab (scikit-image) -> torch_oracle.rgb2lab
+``pairwise_nlog`` (the CUDA op; no CPU build exists) is bound to the reference's own pure-torch
+``compute_pairwise_term``, which the survey showed equal to a transcription of pairwise.cu to 1e-15.
+
+Fixtures (all small, float64 where the reference supports it):
+  pairwise_f64.npz   logits, size/dilation cases -> compute_pairwise_term and its autograd gradient
+  project_f64.npz    logits, bitmasks            -> compute_project_term and gradient
+  similarity.npz     lab, mask                   -> get_image_color_similarity
+  loss_cfg1.npz      BASELINE configs[0] (1x256x256, 4 boxes): full CondInstMaskHead.loss, f32
+  loss_ragged.npz    2 ragged images, 2 instances per box, warm-up 0.37
+  lab_kat.npz        textbook CIE-Lab known answers for the rgb2lab restatement
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from boxinstseg_amd import synthetic  # noqa: E402
+from oracle import reference_extract as rx  # noqa: E402
+from oracle import torch_oracle as to  # noqa: E402
+
+
+def reference_namespace():
+    holder = {}
+
+    def tensor2imgs(tensor, mean, std, to_rgb):
+        # returns BGR uint8 HxWx3 like mmcv (the caller flips back with [:, :, ::-1])
+        rgb = to.denormalize_u8(tensor[0], tensor.shape[2:], mean, std, to_rgb)      # RGB [3,h,w] float
+        return [np.ascontiguousarray(rgb.permute(1, 2, 0).numpy().astype(np.uint8)[:, :, ::-1])]
+
+    ns = rx.load(extra_globals=dict(
+        tensor2imgs=tensor2imgs,
+        color=type('color', (), {'rgb2lab': staticmethod(to.rgb2lab)}),
+        pairwise_nlog=lambda x, s, d: holder['ns'].compute_pairwise_term(x, s, d)))
+    holder['ns'] = ns
+    return ns
+
+
+class StubHead:
+    """The attributes CondInstMaskHead.loss / get_targets read (condinst_head.py:1100-1106)."""
+
+    def __init__(self, ns, it, warm=10000, size=3, dil=2, thresh=0.3, bottom=10, stride=4):
+        self.ns = ns
+        self.boxinst_enabled = True
+        self.bottom_pixels_removed = bottom
+        self.out_stride = stride
+        self.pairwise_size, self.pairwise_dilation, self.pairwise_color_thresh = size, dil, thresh
+        self._iter = torch.tensor([float(it)])
+        self._warmup_iters = warm
+
+    def get_targets(self, *a):
+        return self.ns.CondInstMaskHead_get_targets(self, *a)
+
+    def get_bitmasks_from_boxes(self, *a):
+        return self.ns.CondInstMaskHead_get_bitmasks_from_boxes(self, *a)
+
+
+def run_reference_loss(ns, d, it):
+    head = StubHead(ns, it)
+    imgs = torch.from_numpy(d['imgs'])
+    logits = torch.from_numpy(d['mask_logits']).requires_grad_(True)
+    boxes = [torch.from_numpy(b) for b in d['gt_bboxes']]
+    gi = torch.from_numpy(d['gt_inds'])
+    out = ns.CondInstMaskHead_loss(head, imgs, d['img_metas'], logits, gi, boxes, None, None)
+    (out['loss_prj'] + out['loss_pairwise']).backward()
+    head2 = StubHead(ns, it)
+    sims, bms, _ = head2.get_targets(boxes, None, imgs, d['img_metas'])
+    return dict(loss_prj=out['loss_prj'].item(), loss_pairwise=out['loss_pairwise'].item(),
+                grad=logits.grad.numpy()[:, 0], sim=np.stack([s[0].numpy() for s in sims]),
+                bitmask=torch.cat(bms).numpy(), warmup=min((it + 1) / 10000.0, 1.0))
+
+
+def pack_case(d):
+    return dict(imgs=d['imgs'], mask_logits=d['mask_logits'], gt_inds=d['gt_inds'],
+                boxes=np.concatenate(d['gt_bboxes']), gt_count=np.array([len(b) for b in d['gt_bboxes']]),
+                img_shapes=np.array([m['img_shape'][:2] for m in d['img_metas']]),
+                ori_shapes=np.array([m['ori_shape'][:2] for m in d['img_metas']]))
+
+
+def main():
+    assert rx.available(), 'needs /root/reference'
+    ns = reference_namespace()
+    rng = np.random.default_rng(20240925)
+
+    # ---- pairwise term (reference: compute_pairwise_term == the CUDA op) --------------------------------
+    out = {}
+    for name, shape, size, dil in [('a', (3, 13, 17), 3, 2), ('b', (2, 10, 12), 3, 1), ('c', (2, 9, 11), 5, 2)]:
+        x = torch.tensor(rng.standard_normal(shape) * 4.0, dtype=torch.float64)[:, None].requires_grad_(True)
+        y = ns.compute_pairwise_term(x, size, dil)
+        gp = torch.tensor(rng.standard_normal(tuple(y.shape)), dtype=torch.float64)
+        y.backward(gp)
+        out.update({f'{name}_logits': x.detach().numpy()[:, 0], f'{name}_size': size, f'{name}_dil': dil,
+                    f'{name}_pairwise': y.detach().numpy(), f'{name}_gp': gp.numpy(),
+                    f'{name}_grad': x.grad.numpy()[:, 0]})
+    ext = torch.tensor([0, 1e-3, -1e-3, 3, -3, 30, -30, 100, -100], dtype=torch.float64)
+    xe = (ext[None, :, None] + 0.5 * ext[None, None, :])[:, None].contiguous()
+    out['ext_logits'] = xe.numpy()[:, 0]
+    out['ext_pairwise'] = ns.compute_pairwise_term(xe, 3, 1).numpy()
+    np.savez_compressed(os.path.join(HERE, 'pairwise_f64.npz'), **out)
+
+    # ---- projection term ---------------------------------------------------------------------------------
+    x = torch.tensor(rng.standard_normal((3, 1, 12, 15)) * 2.0, dtype=torch.float64, requires_grad=True)
+    bm = torch.zeros((3, 1, 12, 15), dtype=torch.float64)
+    bm[0, 0, 2:9, 3:11] = 1
+    bm[1, 0, 0:4, 0:15] = 1
+    loss = ns.compute_project_term(x.sigmoid(), bm)      # instance 2: empty box
+    loss.backward()
+    np.savez_compressed(os.path.join(HERE, 'project_f64.npz'), logits=x.detach().numpy()[:, 0], bitmask=bm.numpy()[:, 0],
+                        loss=loss.item(), grad=x.grad.numpy()[:, 0])
+
+    # ---- colour similarity ------------------------------------------------------------------------------------
+    lab = torch.tensor(rng.uniform(-40, 90, size=(1, 3, 9, 13)), dtype=torch.float32)
+    lab[0, :, 4:, 6:] = lab[0, :, 4:5, 6:7]              # a flat region: similarities of exactly 1
+    mask = torch.ones((9, 13))
+    mask[-2:, :] = 0
+    sim = ns.get_image_color_similarity(lab, mask, 3, 2)
+    sim5 = ns.get_image_color_similarity(lab, mask, 5, 1)
+    np.savez_compressed(os.path.join(HERE, 'similarity.npz'), lab=lab.numpy()[0], mask=mask.numpy(), sim_3_2=sim.numpy()[0],
+                        sim_5_1=sim5.numpy()[0])
+
+    # ---- full loss: BASELINE configs[0] and a ragged two-image batch ---------------------------------------------
+    d = synthetic.cfg1(0)
+    r = run_reference_loss(ns, d, it=10000)
+    np.savez_compressed(os.path.join(HERE, 'loss_cfg1.npz'), **pack_case(d), **r)
+    d = synthetic.make_batch(B=2, H=96, W=160, boxes_per_img=3, inst_per_box=2, seed=7,
+                             img_shapes=[(96, 131), (70, 160)], ori_shapes=[(48, 66), (210, 480)],
+                             min_box=16, max_box=80)
+    r = run_reference_loss(ns, d, it=3699)
+    np.savez_compressed(os.path.join(HERE, 'loss_ragged.npz'), **pack_case(d), **r)
+
+    # ---- Lab known answers (published CIE values) -------------------------------------------------------
+    rgb = np.array([[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 77]], np.uint8)
+    want = np.array([[100.0, -0.0025, 0.0047], [0, 0, 0], [53.2406, 80.0923, 67.2028], [87.7351, -86.1830, 83.1797],
+                     [32.2957, 79.1856, -107.8573], [70.8063, -66.6255, 48.8599]])
+    np.savez_compressed(os.path.join(HERE, 'lab_kat.npz'), rgb=rgb, lab=want)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith('.npz'):
+            print(f'{f:20s} {os.path.getsize(os.path.join(HERE, f)) / 1024:8.1f} KiB')
+
+
+if __name__ == '__main__':
+    main()

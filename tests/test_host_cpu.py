@@ -1,0 +1,153 @@
+"""CPU: the host side of the drop-in (no kernel is launched here).
+
+* libboxinst_hip.so loads and exports every symbol include/boxinst_hip.h declares;
+* argument validation of the C ABI that needs no device (status codes, workspace sizing);
+* the Python mirror of the reference interface: constructor keywords, state-dict keys, registry,
+  config loading, and the loud failure on CPU tensors (there is no fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_CFG = '/root/reference/configs/boxinst/boxinst_r50_fpn_1x_coco.py'
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _built(built):
+    return built
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, 'include', 'boxinst_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(bxi_[a-z0-9_]+)\s*\(', src)) - {'bxi_launch_hook'})
+
+
+def test_library_exports_every_declared_symbol():
+    from boxinstseg_amd import _lib
+    lib = _lib.load()
+    names = header_symbols()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/boxinst_hip.h but not exported'
+        assert n in _lib.SIGNATURES, f'{n} has no ctypes signature'
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.bxi_abi_version() == 1
+    for code, name in _lib.STATUS.items():
+        assert _lib.status_string(code) and 'unknown' not in _lib.status_string(code)
+    assert 'unknown' in _lib.status_string(-99)
+
+
+def test_abi_argument_validation_without_device():
+    from boxinstseg_amd import _lib
+    lib = _lib.load()
+    # shapes / arguments are validated before anything touches a device
+    assert lib.bxi_pairwise_nlog_forward_f32(None, -1, 4, 4, 3, 2, None, None) == -2      # BAD_SHAPE
+    assert lib.bxi_pairwise_nlog_forward_f32(None, 1, 4, 4, 4, 2, None, None) == -3       # even window
+    assert lib.bxi_pairwise_nlog_forward_f32(None, 1, 4, 4, 3, 0, None, None) == -3       # dilation < 1
+    assert lib.bxi_pairwise_nlog_forward_f32(None, 1, 4, 4, 3, 2, None, None) == -1       # NULL pointers
+    assert lib.bxi_pairwise_nlog_forward_f32(None, 0, 4, 4, 3, 2, None, None) == 0        # N == 0: no-op
+    assert lib.bxi_boxinst_loss_workspace_bytes(32, 200, 256) > 32 * 25 * 256 * 5
+    assert lib.bxi_boxinst_loss_workspace_bytes(-1, 200, 256) == 0
+    assert lib.bxi_boxinst_loss_state_bytes(32, 200, 256) >= 32 * 456 * 8
+    assert lib.bxi_boxinst_eval_workspace_bytes(2, 800, 1024, 4, 32) > 2 * 3 * 200 * 256 * 4
+    assert lib.bxi_box_bitmasks_f32(None, None, 65, 64, 64, 4, 2, None, None) == -2       # > BXI_MAX_IMAGES
+    if not torch.cuda.is_available():
+        assert lib.bxi_check_device(0) == -7                                               # NO_DEVICE
+
+
+def test_head_constructor_and_state_dict_match_reference_contract():
+    import boxinstseg_amd as bx
+    kw = dict(in_channels=16, in_stride=8, out_stride=4, dynamic_convs=3, dynamic_channels=8, disable_rel_coors=False,
+              bbox_head_channels=256, sizes_of_interest=[64, 128, 256, 512, 1024], max_proposals=-1, topk_per_img=64,
+              boxinst_enabled=True, bottom_pixels_removed=10, pairwise_size=3, pairwise_dilation=2,
+              pairwise_color_thresh=0.3, pairwise_warmup=10000)           # configs/boxinst/boxinst_r50_fpn_1x_coco.py:54-71
+    head = bx.build_head(dict(type='CondInstMaskHead', **kw))
+    assert isinstance(head, bx.CondInstMaskHead)
+    sd = head.state_dict()
+    assert set(sd) == {'sizes_of_interest', '_iter', 'param_conv.weight', 'param_conv.bias'}
+    assert tuple(sd['param_conv.weight'].shape) == (233, 256, 3, 3) and tuple(sd['_iter'].shape) == (1,)
+    assert head.num_gen_params == 233 and head.dy_weights == [144, 64, 8] and head.dy_biases == [8, 8, 1]
+    # _iter survives a checkpoint round trip and drives the warm-up (condinst_head.py:1330-1331)
+    head._iter.fill_(2500.0)
+    other = bx.build_head(dict(type='CondInstMaskHead', **kw))
+    other.load_state_dict(head.state_dict())
+    assert other._iter_host is None and abs(other._tick() - 0.2501) < 1e-7 and float(other._iter) == 2501.0
+    with pytest.raises(AssertionError):
+        bx.CondInstMaskHead(max_proposals=500, topk_per_img=64)
+    with pytest.raises(KeyError):
+        bx.build_head(dict(type='NoSuchHead'))
+
+
+def test_cpu_tensors_fail_loudly():
+    import boxinstseg_amd as bx
+    from boxinstseg_amd import synthetic
+    d = synthetic.cfg1(0)
+    head = bx.CondInstMaskHead(in_channels=16, boxinst_enabled=True, max_proposals=-1)
+    args = (torch.from_numpy(d['imgs']), d['img_metas'], torch.from_numpy(d['mask_logits']),
+            torch.from_numpy(d['gt_inds']), [torch.from_numpy(b) for b in d['gt_bboxes']], None, None)
+    with pytest.raises(RuntimeError, match='CUDA'):
+        head.loss(*args)
+    with pytest.raises(RuntimeError, match='CUDA'):
+        bx.pairwise_nlog(torch.zeros(1, 1, 8, 8), 3, 2)
+    with pytest.raises(RuntimeError, match='CUDA'):
+        bx.color_affinity(args[0], d['img_metas'])
+    with pytest.raises(RuntimeError, match='CUDA'):
+        bx.boxinst_mask_loss(args[2], args[3], args[4], imgs=args[0], img_metas=d['img_metas'])
+
+
+def test_missing_library_is_an_error_not_a_fallback(monkeypatch):
+    from boxinstseg_amd import _lib, build
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(build, 'LIB_PATH', os.path.join(build.LIB_DIR, 'does_not_exist.so'))
+    with pytest.raises(RuntimeError, match='no CPU or PyTorch fallback'):
+        _lib.load()
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFG), reason='reference checkout not present (GPU box)')
+def test_reference_boxinst_configs_build_the_head_unchanged():
+    import glob
+    import boxinstseg_amd as bx
+    cfgs = sorted(glob.glob('/root/reference/configs/boxinst/*.py'))
+    assert len(cfgs) >= 5
+    for path in cfgs:
+        cfg = bx.load_config(path)
+        mh = cfg['model']['mask_head']
+        assert mh['type'] == 'CondInstMaskHead' and mh['boxinst_enabled'] is True
+        head = bx.build_head(mh)
+        assert head.pairwise_size == 3 and head.pairwise_dilation == 2 and head.out_stride == 4
+    cfg = bx.load_config(REF_CFG)
+    assert cfg['dist_params'] == dict(backend='nccl')             # RCCL under PyTorch-ROCm: unchanged
+    assert cfg['data']['samples_per_gpu'] == 2
+
+
+def test_config_loader_base_merge(tmp_path):
+    import boxinstseg_amd as bx
+    (tmp_path / 'base.py').write_text("model = dict(type='A', head=dict(x=1, y=2))\nlr = 0.1\n")
+    (tmp_path / 'child.py').write_text("_base_ = ['base.py']\nmodel = dict(head=dict(y=3, z=dict(_delete_=True, q=1)))\n")
+    cfg = bx.load_config(str(tmp_path / 'child.py'))
+    assert cfg == dict(model=dict(type='A', head=dict(x=1, y=3, z=dict(q=1))), lr=0.1)
+
+
+def test_synthetic_recipe_is_seeded_and_unambiguous():
+    from boxinstseg_amd import synthetic
+    a, b = synthetic.cfg1(3), synthetic.cfg1(3)
+    assert np.array_equal(a['imgs'], b['imgs']) and np.array_equal(a['mask_logits'], b['mask_logits'])
+    d = synthetic.cfg2(0)
+    assert d['imgs'].shape == (2, 3, 800, 1024) and d['mask_logits'].shape == (32, 1, 200, 256) and d['G'] == 32
+    mean = np.asarray(synthetic.MEAN, np.float64).reshape(1, 3, 1, 1)
+    std = np.asarray(synthetic.STD, np.float64).reshape(1, 3, 1, 1)
+    v = a['imgs'].astype(np.float64) * std + mean
+    frac = v - np.floor(v)
+    assert frac.min() > 0.2 and frac.max() < 0.3      # the +0.25 offset: uint8 truncation is unambiguous
+
+
+def test_rows_removed_matches_reference_arithmetic():
+    from boxinstseg_amd.functional import rows_removed
+    assert rows_removed(10, (800, 1024, 3), (800, 1024, 3)) == 10
+    assert rows_removed(10, (800, 1199, 3), (427, 640, 3)) == int(10 * float(800) / float(427)) == 18
+    assert rows_removed(0, (64, 64, 3), (64, 64, 3)) == 0

@@ -1,0 +1,131 @@
+"""CPU: both oracles against the golden fixtures generated from the reference's own functions
+(tests/golden/make_golden.py).  This is what pins the oracle (parity gate 1)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle, torch_oracle as to
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _built(built):
+    return built
+
+
+@pytest.mark.parametrize('case', ['a', 'b', 'c'])
+def test_pairwise_fwd_bwd_f64(case):
+    g = load('pairwise_f64.npz')
+    x, size, dil = g[f'{case}_logits'], int(g[f'{case}_size']), int(g[f'{case}_dil'])
+    pw = c_oracle.pairwise_nlog_fwd(x, size, dil)
+    assert np.abs(pw - g[f'{case}_pairwise']).max() < 1e-13
+    grad = c_oracle.pairwise_nlog_bwd(x, pw, g[f'{case}_gp'], size, dil)
+    assert np.abs(grad - g[f'{case}_grad']).max() < 1e-12
+    xt = torch.from_numpy(x[:, None]).requires_grad_(True)
+    y = to.pairwise_term(xt, size, dil)
+    y.backward(torch.from_numpy(g[f'{case}_gp']))
+    assert np.abs(y.detach().numpy() - g[f'{case}_pairwise']).max() < 1e-13
+    assert np.abs(xt.grad.numpy()[:, 0] - g[f'{case}_grad']).max() < 1e-12
+    # f32 flavour of the C oracle against the f64 truth
+    pw32 = c_oracle.pairwise_nlog_fwd(x.astype(np.float32), size, dil)
+    assert np.abs(pw32 - g[f'{case}_pairwise']).max() < 2e-6 * max(1.0, np.abs(g[f'{case}_pairwise']).max())
+
+
+def test_pairwise_extreme_logits_f64():
+    g = load('pairwise_f64.npz')
+    pw = c_oracle.pairwise_nlog_fwd(g['ext_logits'], 3, 1)
+    assert np.isfinite(pw).all()
+    assert np.abs(pw - g['ext_pairwise']).max() < 1e-12 * max(1.0, np.abs(g['ext_pairwise']).max())
+
+
+def test_pairwise_known_answers():
+    """pair = ln 2 at x=y=0; -> 0 for equal saturated logits; |x| - ln 2 for opposite ones; 0 at borders."""
+    x = np.zeros((1, 5, 5), np.float64)
+    pw = c_oracle.pairwise_nlog_fwd(x, 3, 1)
+    assert abs(pw[0, 4, 2, 2] - np.log(2.0)) < 1e-15
+    assert pw[0, 0, 0, 0] == 0.0 and pw[0, 7, 4, 4] == 0.0           # out-of-bounds neighbours
+    x[:] = 30.0
+    assert c_oracle.pairwise_nlog_fwd(x, 3, 1)[0, 4, 2, 2] < 1e-12
+    x[0, 2, 2] = -30.0
+    assert abs(c_oracle.pairwise_nlog_fwd(x, 3, 1)[0, 4, 2, 1] - (30.0 - np.log(2.0))) < 1e-9
+
+
+def test_project_term_f64():
+    g = load('project_f64.npz')
+    loss, grad = c_oracle.project_term(g['logits'], g['bitmask'])
+    assert abs(loss - float(g['loss'])) < 1e-13
+    assert np.abs(grad - g['grad']).max() < 1e-13
+    x = torch.from_numpy(g['logits'][:, None]).requires_grad_(True)
+    out = to.project_term(x.sigmoid(), torch.from_numpy(g['bitmask'][:, None]))
+    out.backward()
+    assert abs(out.item() - float(g['loss'])) < 1e-14
+    # dice known answers: zero prediction vs non-empty box -> 1 per axis
+    z = np.full((1, 6, 6), -60.0)
+    t = np.zeros((1, 6, 6)); t[0, 1:4, 2:5] = 1
+    assert abs(c_oracle.project_term(z, t, want_grad=False)[0] - 2.0) < 1e-9
+
+
+def test_color_similarity():
+    g = load('similarity.npz')
+    assert np.abs(c_oracle.color_similarity(g['lab'], g['mask'], 3, 2) - g['sim_3_2']).max() <= 6e-8
+    assert np.abs(c_oracle.color_similarity(g['lab'], g['mask'], 5, 1) - g['sim_5_1']).max() <= 6e-8
+    s = to.color_similarity(torch.from_numpy(g['lab'])[None], torch.from_numpy(g['mask']), 3, 2)[0].numpy()
+    assert np.array_equal(s, g['sim_3_2'])
+
+
+def test_lab_known_answers():
+    g = load('lab_kat.npz')
+    for rgb, want in zip(g['rgb'], g['lab']):
+        got = np.array(c_oracle.rgb2lab_one(*[int(v) for v in rgb]))
+        assert np.abs(got - want).max() < 6e-4, (rgb, got, want)
+    # C and numpy restatements agree to the last bit after the f32 cast, on every grey and a colour sweep
+    rng = np.random.default_rng(0)
+    rgb = np.concatenate([np.repeat(np.arange(256, dtype=np.uint8)[:, None], 3, 1),
+                          rng.integers(0, 256, size=(4096, 3)).astype(np.uint8)])
+    a = c_oracle.rgb2lab_u8(np.ascontiguousarray(rgb.T).reshape(3, -1, 1))[:, :, 0].T
+    b = to.rgb2lab(rgb).astype(np.float32)
+    assert np.abs(a - b).max() <= 4e-6
+
+
+@pytest.mark.parametrize('name', ['loss_cfg1.npz', 'loss_ragged.npz'])
+def test_full_path(name):
+    """CondInstMaskHead.loss of the reference (run on its own source) vs the C oracle."""
+    g = load(name)
+    hw = g['img_shapes']
+    rr = np.array([to.rows_removed(10, int(s[0]), int(o[0])) for s, o in zip(g['img_shapes'], g['ori_shapes'])])
+    out = c_oracle.boxinst_path(g['imgs'], hw, rr, (123.675, 116.28, 103.53), (58.395, 57.12, 57.375), True,
+                                g['boxes'], g['gt_count'], g['gt_inds'], g['mask_logits'][:, 0],
+                                warmup=float(g['warmup']), want_targets=True)
+    assert abs(out['loss_prj'] - float(g['loss_prj'])) <= 2e-6 * abs(float(g['loss_prj']))
+    assert abs(out['loss_pairwise'] - float(g['loss_pairwise'])) <= 2e-6 * abs(float(g['loss_pairwise']))
+    assert np.abs(out['grad'] - g['grad']).max() <= 2e-6 * np.abs(g['grad']).max()
+    assert np.abs(out['sim'] - g['sim']).max() <= 6e-8
+    assert np.array_equal(out['bitmask'], g['bitmask'])
+
+
+def test_box_bitmask_python_slices():
+    """condinst_head.py:1429-1430 with negative / inverted / out-of-canvas coordinates."""
+    H, W = 40, 56
+    for box in ([10.7, 3.2, 30.9, 20.1], [-3.0, -2.0, 20.0, 10.0], [30.0, 2.0, 10.0, 30.0], [50.0, 35.0, 90.0, 80.0],
+                [5.0, 5.0, 5.9, 5.9], [-60.0, -50.0, -1.0, -1.0]):
+        full = np.zeros((H, W), np.float32)
+        full[int(box[1]):int(box[3]) + 1, int(box[0]):int(box[2]) + 1] = 1.0
+        assert np.array_equal(c_oracle.box_bitmask(box, H, W, 4), full[2::4, 2::4]), box
+
+
+def test_image_mask_and_pool():
+    m = c_oracle.image_mask(32, 48, 30, 41, 7, 4)
+    full = np.ones((30, 41), np.float32); full[-7:, :] = 0
+    pad = np.zeros((32, 48), np.float32); pad[:30, :41] = full
+    assert np.array_equal(m, pad[2::4, 2::4])
+    rng = np.random.default_rng(1)
+    u = rng.integers(0, 256, size=(3, 8, 12)).astype(np.uint8)
+    want = torch.nn.functional.avg_pool2d(torch.from_numpy(u).float()[None], 4, 4)[0].byte().numpy()
+    assert np.array_equal(c_oracle.pool_u8(u, 4), want)

@@ -27,3 +27,8 @@ if m.any():
     for a_,b_,nm in [(0,1,'decide'),(1,2,'loads+stage'),(2,4,'affinity+pairwise'),(4,5,'partials+store')]:
         d = us(b[hit,b_]-b[hit,a_]); print('  hit phase %-14s mean %.2f med %.2f max %.2f' % (nm, d.mean(), np.median(d), d.max()))
     print('  hit last end +%.2f ; hit block total mean %.2f max %.2f' % (us(b[hit,5].max()-bs), us(b[hit,5]-b[hit,0]).mean(), us(b[hit,5]-b[hit,0]).max()), ' start quantiles', np.quantile(us(b[m,0]-bs),[0,.25,.5,.75,1]).round(2))
+
+    d = us(b[hit,6]-b[hit,5]); print('  hit phase arrive          mean %.2f med %.2f max %.2f ; last tile end +%.2f' % (d.mean(), np.median(d), d.max(), us(b[hit,6].max()-bs)))
+ld = t[2]; ml = ld[:,0]>0
+if ml.any():
+    print('leaders: n', ml.sum(), 'start +%.2f' % us(ld[ml,0].min()-bs), '| loads+maxima %.2f | sums %.2f | grads+state %.2f | arrive %.2f | last end +%.2f' % tuple([us(ld[ml,b_]-ld[ml,a_]).mean() for a_,b_ in [(0,1),(1,2),(2,3),(3,4)]] + [us(ld[ml,4].max()-bs)]))

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs merged into gpurun_out/ into the tracked summaries under profiles/.
+
+    python tools/summarize_profiles.py r01
+
+reads  gpurun_out/prof_eager/r01_kernel_stats.csv                    (rocprofv3 --kernel-trace --stats)
+       gpurun_out/pmc_FETCH_SIZE|pmc_WRITE_SIZE/r01_counter_collection.csv  (one --pmc pass per counter)
+writes profiles/<round>_kernel_stats_eager.csv, profiles/<round>_hbm_traffic.json, profiles/<round>_summary.md
+FETCH_SIZE is doubled for the streaming kernel, as MI355X_MICROARCH.md prescribes for 16 B/lane coalesced
+reads on gfx950 (the counter tallies 128-B requests at 64 B); WRITE_SIZE is used as reported (KB).
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+G, P = 'gpurun_out', 'profiles'
+os.makedirs(P, exist_ok=True)
+shutil.copy(f'{G}/prof_eager/r01_kernel_stats.csv', f'{P}/{rnd}_kernel_stats_eager.csv')
+stats = {}
+for r in csv.DictReader(open(f'{P}/{rnd}_kernel_stats_eager.csv')):
+    if 'bxi::' in r['Name']:
+        key = r['Name'].split('bxi::')[1].split('(')[0].split('<')[0]
+        stats[key] = dict(calls=int(r['Calls']), avg_us=float(r['AverageNs']) / 1e3, min_us=float(r['MinNs']) / 1e3,
+                          max_us=float(r['MaxNs']) / 1e3)
+traffic = collections.defaultdict(dict)
+for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+    path = f'{G}/pmc_{c}/r01_counter_collection.csv'
+    if not os.path.exists(path):
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if 'bxi::' in r['Kernel_Name']:
+            agg[r['Kernel_Name'].split('bxi::')[1].split('(')[0].split('<')[0]].append(float(r['Counter_Value']))
+    for k, v in agg.items():
+        v = v[len(v) // 4:]                       # drop warm-up launches
+        traffic[k][c + '_KB'] = sum(v) / len(v)
+out = {}
+for k, t in traffic.items():
+    fetch = t.get('FETCH_SIZE_KB', 0.0) * 1024 * 2      # gfx950: x2 for wide coalesced reads
+    write = t.get('WRITE_SIZE_KB', 0.0) * 1024
+    out[k] = dict(fetch_bytes_corrected=fetch, write_bytes=write, hbm_bytes=fetch + write, raw=t)
+json.dump(dict(round=rnd, command='python bench.py --mode eager --steps 100 --warmup 20', kernels=out,
+               note='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 correction, '
+                    'MI355X_MICROARCH.md section HBM); per launch, mean over the timed launches'),
+          open(f'{P}/{rnd}_hbm_traffic.json', 'w'), indent=1)
+with open(f'{P}/{rnd}_summary.md', 'w') as f:
+    f.write(f'# rocprofv3 summary, round {rnd[1:]} (MI355X, `python bench.py --mode eager --steps 400 --warmup 50`)\n\n')
+    f.write('| kernel | calls | avg us | min us | max us | HBM read (PMC, corrected) MB | HBM write (PMC) MB |\n|---|---:|---:|---:|---:|---:|---:|\n')
+    for k, s in sorted(stats.items(), key=lambda kv: -kv[1]['avg_us']):
+        t = out.get(k, {})
+        f.write(f"| {k} | {s['calls']} | {s['avg_us']:.2f} | {s['min_us']:.2f} | {s['max_us']:.2f} | "
+                f"{t.get('fetch_bytes_corrected', float('nan')) / 1e6:.2f} | {t.get('write_bytes', float('nan')) / 1e6:.2f} |\n")
+print(open(f'{P}/{rnd}_summary.md').read())
