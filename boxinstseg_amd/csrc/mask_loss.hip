@@ -26,7 +26,7 @@ constexpr int kBR = 8;          // box tile rows    (box_kernel)
 constexpr int kBC = 64;         // box tile columns
 constexpr int kSlices = 8;      // row slices per instance in loss_apply
 constexpr int kMaxDil = 8;
-constexpr int kMaxT = 32;       // per-instance column partials reduced per unrolled batch in loss_finalize
+constexpr int kMaxT = 32;       // per-instance column partials reduced per unrolled batch by the leader workgroups
 
 struct InstArgs {
     const float* logits;
@@ -37,8 +37,7 @@ struct InstArgs {
 };
 
 struct LossWs {               // carved from the caller's workspace
-    float* colv;              // [N,Ts,w] per-streaming-tile column max (logit)
-    uint8_t* colr;            // [N,Ts,w] row offset of that max inside the tile
+    unsigned long long* colkey;  // [N,Ts,w] per-streaming-tile column max: packed (logit, first row in tile)
     unsigned long long* rowkey;  // [N,h] packed (max logit, first column)
     unsigned long long* acc;  // [N,2] per instance: sum of W (integer) ; sum of W*pw in 2^-24 fixed point
     struct InstRec* inst;     // [N]  box rectangle + image of every instance (written by stage1)
@@ -80,8 +79,7 @@ static size_t carve_ws(void* base, int N, int h, int w, LossWs* ws) {
     size_t off = 0;
     char* p = (char*)base;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return p ? p + o : nullptr; };
-    float* colv = (float*)take(sizeof(float) * N * T * w);
-    uint8_t* colr = (uint8_t*)take((size_t)N * T * w);
+    unsigned long long* colkey = (unsigned long long*)take(sizeof(unsigned long long) * N * T * w);
     unsigned long long* rowkey = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)N * h);
     unsigned long long* acc = (unsigned long long*)take(sizeof(unsigned long long) * 2 * (size_t)(N > 0 ? N : 1));
     InstRec* inst = (InstRec*)take(sizeof(InstRec) * (size_t)(N > 0 ? N : 1));
@@ -92,7 +90,7 @@ static size_t carve_ws(void* base, int N, int h, int w, LossWs* ws) {
     unsigned int* expect = (unsigned int*)take(sizeof(unsigned int) * (size_t)(N > 0 ? N : 1));
     float* dice = (float*)take(sizeof(float) * (size_t)(N > 0 ? N : 1));
     unsigned int* ticket = (unsigned int*)take(sizeof(unsigned int));
-    if (ws) { ws->colv = colv; ws->colr = colr; ws->rowkey = rowkey; ws->acc = acc; ws->inst = inst;
+    if (ws) { ws->colkey = colkey; ws->rowkey = rowkey; ws->acc = acc; ws->inst = inst;
               ws->pred = pred; ws->work = work; ws->nwork = nwork; ws->arrive = arrive; ws->expect = expect;
               ws->dice = dice; ws->ticket = ticket; }
     return off;
@@ -341,14 +339,16 @@ __device__ __forceinline__ void stream_tile(const InstArgs& a, int dil, float th
                 }
             }
             const int64_t o = ((int64_t)n * Tsw + t) * w + c;
+            unsigned long long k4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) k4[j] = pack_max(cmax[j], (uint32_t)crow[j]);
             if (vec) {
-                *reinterpret_cast<float4*>(ws.colv + o) = make_float4(cmax[0], cmax[1], cmax[2], cmax[3]);
-                *reinterpret_cast<uchar4*>(ws.colr + o) = make_uchar4((unsigned char)crow[0], (unsigned char)crow[1],
-                                                                      (unsigned char)crow[2], (unsigned char)crow[3]);
+                *reinterpret_cast<ulonglong2*>(ws.colkey + o) = make_ulonglong2(k4[0], k4[1]);
+                *reinterpret_cast<ulonglong2*>(ws.colkey + o + 2) = make_ulonglong2(k4[2], k4[3]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (c + j < w) { ws.colv[o + j] = cmax[j]; ws.colr[o + j] = (uint8_t)crow[j]; }
+                    if (c + j < w) ws.colkey[o + j] = k4[j];
             }
         }
         cb += kChunk;
@@ -464,28 +464,27 @@ __device__ __forceinline__ void arrive_and_finish(const LossWs& ws, const LossSt
     }
     __syncthreads();
     if (!*flag) return;                                         // workgroup-uniform
-    // ---- the last workgroup of the launch: loss_prj, loss_pairwise, normaliser -----------------------------
-    unsigned long long acnt = 0ull; long long anum = 0;
-    for (int i = tid; i < N; i += 256) {
-        acnt += __hip_atomic_load(&ws.acc[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        anum += (long long)__hip_atomic_load(&ws.acc[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const double c = wave_sum_f64((double)acnt), s = wave_sum_f64((double)anum);   // exact: integers far below 2^53
-    if ((tid & 63) == 0) { red64[tid >> 6] = c; red64[4 + (tid >> 6)] = s; }
-    float acc = 0.f;                                            // dice summed in index order (deterministic)
-    for (int base = 0; base < N; base += 256) {
-        dbuf[tid] = base + tid < N ? __hip_atomic_load(&ws.dice[base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-        __syncthreads();
-        if (tid == 0)
-            for (int i = 0; i < min(256, N - base); ++i) acc += dbuf[i];
-        __syncthreads();
+    // ---- the last workgroup of the launch: loss_prj, loss_pairwise, normaliser (one wave, no barriers) ----
+    if (tid >= 64) return;
+    double cnt = 0.0, num = 0.0;
+    float dsum = 0.f;
+    for (int base = 0; base < N; base += 64) {
+        const int i = base + tid;
+        unsigned long long c = 0ull; long long s = 0; float dv = 0.f;
+        if (i < N) {   // three loads in flight per lane; written by agent-scope atomics / write-through stores
+            c = __hip_atomic_load(&ws.acc[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s = (long long)__hip_atomic_load(&ws.acc[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dv = __hip_atomic_load(&ws.dice[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        cnt += wave_sum_f64((double)c);                 // exact: integers far below 2^53
+        num += wave_sum_f64((double)s);
+        const int m = min(64, N - base);
+        for (int k = 0; k < m; ++k) dsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), k));   // index order
     }
     if (tid == 0) {
-        const double cnt = (red64[0] + red64[1]) + (red64[2] + red64[3]);
-        const double num = ((red64[4] + red64[5]) + (red64[6] + red64[7])) / (double)kNumScale;
-        const float denom = fmaxf((float)cnt, 1.f);                 // weights.sum().clamp(min=1.0), :1328
-        losses[0] = acc / (float)N;                                 // .mean(), :143
-        losses[1] = (float)(num / (double)denom) * warmup;          // :1327-1332
+        const float denom = fmaxf((float)cnt, 1.f);                         // weights.sum().clamp(min=1.0), :1328
+        losses[0] = dsum / (float)N;                                        // .mean(), :143
+        losses[1] = (float)((num / (double)kNumScale) / (double)denom) * warmup;   // :1327-1332
         if (st.scale) *st.scale = warmup / denom;
     }
 }
@@ -498,17 +497,12 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const L
     float* ys = xs + w;                           // [h]
     // ---- every global load of the first batch is issued before the first use -----------------------------
     const InstRec rec = ws.inst[n];
-    float cv[kMaxT]; uint8_t cr[kMaxT];
+    unsigned long long ck[kMaxT];
     {
         const int c = tid < w ? tid : 0;
 #pragma unroll
-        for (int u = 0; u < kMaxT; ++u) {   // unconditional (index clamped): 2 x kMaxT loads in flight, no branches
-            const int64_t o = ((int64_t)n * Ts + min(u, Ts - 1)) * w + c;
-            cv[u] = ws.colv[o];
-            cr[u] = ws.colr[o];
-        }
-#pragma unroll
-        for (int u = 0; u < kMaxT; ++u) cv[u] = u < Ts ? cv[u] : -INFINITY;
+        for (int u = 0; u < kMaxT; ++u)     // unconditional (index clamped): kMaxT 8-byte loads in flight, no branches
+            ck[u] = ws.colkey[((int64_t)n * Ts + min(u, Ts - 1)) * w + c];
     }
     const unsigned long long rk0 = ws.rowkey[(int64_t)n * h + (tid < h ? tid : 0)];
     const InstBox ib = inst_from_rec(rec, dil, h, w);
@@ -518,16 +512,14 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const L
         for (int t0 = 0; t0 < Ts; t0 += kMaxT) {
             if (c >= 256 || t0 > 0) {                 // beyond the prefetched batch (w > 256 or > kMaxT tiles)
 #pragma unroll
-                for (int u = 0; u < kMaxT; ++u) {
-                    const int t = t0 + u;
-                    const int64_t o = ((int64_t)n * Ts + (t < Ts ? t : 0)) * w + c;
-                    cv[u] = t < Ts ? ws.colv[o] : -INFINITY;
-                    cr[u] = t < Ts ? ws.colr[o] : (uint8_t)0;
-                }
+                for (int u = 0; u < kMaxT; ++u)
+                    ck[u] = ws.colkey[((int64_t)n * Ts + min(t0 + u, Ts - 1)) * w + c];
             }
 #pragma unroll
-            for (int u = 0; u < kMaxT; ++u)
-                if (cv[u] > m) { m = cv[u]; mr = (t0 + u) * kSR + cr[u]; }   // tile order: first row wins ties
+            for (int u = 0; u < kMaxT; ++u) {
+                const float v = unpack_val(ck[u]);
+                if (t0 + u < Ts && v > m) { m = v; mr = (t0 + u) * kSR + (int)unpack_idx(ck[u]); }   // tile order: first row wins ties
+            }
         }
         const float X = sigmoid_acc(m);
         const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
@@ -616,8 +608,8 @@ __global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __res
     }
     const int nwork = *ws.nwork;
     const int ntile_wg = (int)gridDim.x - a.N;
+    BXI_T(1, blockIdx.x, 0);
     for (int wi = (int)blockIdx.x - a.N; wi < a.N * ((h + kBR - 1) / kBR) * ((w + kBC - 1) / kBC); wi += ntile_wg) {
-        BXI_T(1, blockIdx.x, 0);
         // work list built by stage1: the box tiles of all instances, compacted.  The tile workgroups of this
         // launch take item blockIdx - N (+ a multiple of the tile-workgroup count when there are more items)
         const WorkRec wr = ws.work[wi];          // speculative (wi is always inside the list's capacity) ...
@@ -785,15 +777,16 @@ __global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __res
             if (bc) atomicAdd(&ws.acc[2 * n], (unsigned long long)bc);
             if (bn != 0.f) atomicAdd(&ws.acc[2 * n + 1], (unsigned long long)(long long)(bn * kNumScale));
         }
-        // gradient tile last: nothing in this workgroup waits for these stores
+        BXI_T(1, blockIdx.x, 5);
+        arrive_and_finish(ws, st, n, a.N, warmup, losses, &fin_flag, red64, dbuf);
+        BXI_T(1, blockIdx.x, 6);
+        // gradient tile last: nothing in this launch waits for these stores (the arrival above only
+        // covers the accumulators), they drain while the wave retires
         if (g_logits && r < h) {
             float* G = g_logits + (int64_t)n * P + (int64_t)r * w + c0 + lcx;   // 2 x 128 B contiguous per half-wave
             if (c0 + lcx < w) G[0] = out[0];
             if (c0 + lcx + 32 < w) G[32] = out[1];
         }
-        BXI_T(1, blockIdx.x, 5);
-        arrive_and_finish(ws, st, n, a.N, warmup, losses, &fin_flag, red64, dbuf);
-        BXI_T(1, blockIdx.x, 6);
         __syncthreads();                     // LDS is reused by the next work item
     }
 }
