@@ -51,7 +51,7 @@ struct LossWs {               // carved from the caller's workspace
 };
 
 struct InstRec { int r0, r1, c0, c1, img, pad0, pad1, pad2; };   // 32 B: one load per workgroup
-struct WorkRec { int r0, r1, c0, c1, img, n, tile_r0, tile_c0; };  // box rectangle + the tile to process: 32 B
+struct WorkRec { int r0, r1, c0, c1, img, n, tile_r0, tile_c0; float n2max; int zero_bit, pad0, pad1; };  // 48 B: all a tile needs
 
 // (sim >= thresh) for a valid neighbour, as a compare on the squared Lab distance:
 // exp(-0.5*sqrt(n2)) >= thresh  <=>  n2 <= n2max, with n2max found in stage1 by bisecting the exact
@@ -190,8 +190,7 @@ __device__ __forceinline__ bool sim_pred(float n2, float thresh) {
     return expf(__fmul_rn(-__fsqrt_rn(n2), 0.5f)) >= thresh;
 }
 
-__device__ __forceinline__ void make_pred(float thresh, Pred* out) {   // lane 0 of one wave
-    if ((threadIdx.x & 63) != 0) return;
+__device__ __forceinline__ Pred make_pred(float thresh) {   // uniform: every lane computes the same value
     Pred p; p.pad = 0; p.fast = 1;
     p.zero_bit = (0.f >= thresh) ? 1 : 0;            // weight of a padded / masked-out neighbour (sim == 0)
     // sim_pred(n2) is non-increasing in n2 >= 0 and positive floats order like their bit patterns:
@@ -210,7 +209,7 @@ __device__ __forceinline__ void make_pred(float thresh, Pred* out) {   // lane 0
         }
         p.n2max = __uint_as_float(lo);
     }
-    *out = p;
+    return p;
 }
 
 // per-lane box lookup (lanes hold different instances): the image table is walked with a uniform
@@ -234,7 +233,7 @@ __device__ __forceinline__ LaneBox lane_box(const InstArgs& a, int dil, int m) {
 
 // One wave64 of instance n's first streaming workgroup: exclusive prefix of the box-tile counts of
 // instances 0..n-1 (deterministic order, no atomics, no pre-zeroed counter), then this instance's tiles.
-__device__ __forceinline__ void build_work_list(const InstArgs& a, int dil, const LossWs& ws, int n) {
+__device__ __forceinline__ void build_work_list(const InstArgs& a, int dil, float thresh, const LossWs& ws, int n) {
     const int lane = threadIdx.x & 63;
     int base = 0, total = 0;
     LaneBox mine = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -261,6 +260,8 @@ __device__ __forceinline__ void build_work_list(const InstArgs& a, int dil, cons
     }
     if (n == 0 && lane == 0) { *ws.nwork = total; ws.arrive[a.N] = 0u; }
     const int cnt = mine.ntr * mine.ntc;
+    const Pred pr = make_pred(thresh);
+    if (n == 0 && lane == 0) *ws.pred = pr;
     if (lane == 0) {   // per-instance records and zeroed accumulators for box_kernel / loss_apply (next launches)
         InstRec rc; rc.r0 = mine.r0; rc.r1 = mine.r1; rc.c0 = mine.c0; rc.c1 = mine.c1; rc.img = mine.img;
         rc.pad0 = rc.pad1 = rc.pad2 = 0;
@@ -272,6 +273,7 @@ __device__ __forceinline__ void build_work_list(const InstArgs& a, int dil, cons
         WorkRec wr;
         wr.r0 = mine.r0; wr.r1 = mine.r1; wr.c0 = mine.c0; wr.c1 = mine.c1; wr.img = mine.img; wr.n = n;
         wr.tile_r0 = (mine.tr0 + i / mine.ntc) * kBR; wr.tile_c0 = (mine.tc0 + i % mine.ntc) * kBC;
+        wr.n2max = pr.n2max; wr.zero_bit = pr.zero_bit; wr.pad0 = wr.pad1 = 0;
         ws.work[base + i] = wr;
     }
 }
@@ -302,13 +304,16 @@ __device__ __forceinline__ void stream_tile(const InstArgs& a, int dil, float th
 #pragma unroll
         for (int i = 0; i < kSR; ++i) v[i] = (r0 + i < r1 && c < w) ? load4(L + (int64_t)(r0 + i) * w, c, w, vec) : ninf;
     }
-    if (G)
+    if (G)   // non-temporal: these lines are not read again in this launch and need not stay dirty in L2
         for (int cb = 0; cb < w; cb += kChunk) {
             const int c = cb + lane * 4;
             if (c < w) {
 #pragma unroll
                 for (int i = 0; i < kSR; ++i)
-                    if (r0 + i < r1) store4(G + (int64_t)(r0 + i) * w, c, w, vec, zero);
+                    if (r0 + i < r1) {
+                        if (vec) { typedef float f4v __attribute__((ext_vector_type(4))); __builtin_nontemporal_store((f4v){0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4v*>(G + (int64_t)(r0 + i) * w + c)); }
+                        else store4(G + (int64_t)(r0 + i) * w, c, w, false, zero);
+                    }
             }
         }
     BXI_T(0, blockIdx.x, 2);
@@ -383,17 +388,16 @@ __device__ __forceinline__ void stream_tile(const InstArgs& a, int dil, float th
     if (lane < kSR && r0 + lane < r1) ws.rowkey[(int64_t)n * h + r0 + lane] = mine;
 }
 
-// grid: [N + 1 table waves][pooling waves][N*Ts streaming waves].  The table waves (per-instance
-// records + work list of box_kernel, and the colour-threshold predicate) carry dependent load
+// grid: [N table waves][pooling waves][N*Ts streaming waves].  The table waves (per-instance
+// records + work list of box_kernel, incl. the colour-threshold predicate) carry dependent load
 // chains, so they go first, before the memory system is saturated; nothing in this launch waits for them.
 __global__ __launch_bounds__(64) void stage1_kernel(PoolArgs pa, int n_pool, InstArgs a, int dil, float thresh,
                                                     LossWs ws, float* __restrict__ g_logits, int vec) {
     __shared__ double lut[256];
     BXI_T(0, blockIdx.x, 0);
-    const int n_tab = a.N + 1;
+    const int n_tab = a.N;
     if ((int)blockIdx.x < n_tab) {
-        if ((int)blockIdx.x < a.N) build_work_list(a, dil, ws, (int)blockIdx.x);
-        else make_pred(thresh, ws.pred);
+        build_work_list(a, dil, thresh, ws, (int)blockIdx.x);
     } else if ((int)blockIdx.x >= n_tab + n_pool) {
         stream_tile(a, dil, thresh, ws, g_logits, vec, (int)blockIdx.x - n_tab - n_pool);
     } else {
@@ -614,10 +618,14 @@ __global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __res
         // launch take item blockIdx - N (+ a multiple of the tile-workgroup count when there are more items)
         const WorkRec wr = ws.work[wi];          // speculative (wi is always inside the list's capacity) ...
         if (wi >= nwork) break;                  // workgroup-uniform
-        const Pred pr = FROM_LAB ? *ws.pred : Pred{0.f, 1, 0, 0};   // issued with the loads below, used after them
+        Pred pr; pr.n2max = wr.n2max; pr.zero_bit = wr.zero_bit; pr.fast = 1; pr.pad = 0;
         const int n = wr.n, r0 = wr.tile_r0, c0 = wr.tile_c0;
         InstRec rc; rc.r0 = wr.r0; rc.r1 = wr.r1; rc.c0 = wr.c0; rc.c1 = wr.c1; rc.img = wr.img;
         const InstBox ib = inst_from_rec(rc, dil, h, w);
+        // scalar operands of the pair loop: requested now, so they arrive with the tile loads below
+        const int vr = FROM_LAB ? min(meta.img_h[ib.img], meta.first_removed[ib.img]) : 0;   // valid(q): :1354-1369,:1405
+        const int vc = FROM_LAB ? meta.img_w[ib.img] : 0;
+        const int half = a.stride / 2;
         BXI_T(1, blockIdx.x, 1);
         const int64_t P = (int64_t)h * w;
         const float* L = a.logits + (int64_t)n * P;
@@ -675,9 +683,6 @@ __global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __res
         //   W[k,p]   = [p in box] * [sim(p->q) >= thresh],  sim(p->q) = exp(-||Lab_p-Lab_q||/2) * valid(q)
         //   W[7-k,q] = [q in box] * [sim(q->p) >= thresh],  sim(q->p) = exp(-||Lab_q-Lab_p||/2) * valid(p)
         // the two share the distance, so no per-pixel affinity word has to be staged (FROM_LAB).
-        const int vr = FROM_LAB ? min(meta.img_h[ib.img], meta.first_removed[ib.img]) : 0;   // valid(q): :1354-1369,:1405
-        const int vc = FROM_LAB ? meta.img_w[ib.img] : 0;
-        const int half = a.stride / 2;
         // thread -> row lr, columns lcx and lcx + 32: the 32 lanes of a row read consecutive LDS words
         // (conflict-free ds_read_b32 / b64), unlike an adjacent-pixel pairing (2-way conflicts)
         const int lr = tid >> 5, lcx = tid & 31;
@@ -693,6 +698,57 @@ __global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __res
             const uint32_t in = (r2 >= 0 && r2 < h) ? 1u : 0u;
             rfl[dy + 1] = in | ((r2 >= ib.box.r0 && r2 < ib.box.r1) ? 2u : 0u) | ((in && r2 * a.stride + half < vr) ? 4u : 0u);
         }
+        // interior tile (workgroup-uniform): every pixel and every neighbour is inside the box, valid and in the
+        // map, so W[k,p] = W[7-k,q] = [n2 <= n2max] and none of the flag logic below is needed.  These are the
+        // tiles with the most work (all 512 pixels active), i.e. the tail of the launch.
+        const bool interior = FROM_LAB && r0 - d >= ib.box.r0 && r0 + kBR + d <= ib.box.r1 && c0 - d >= ib.box.c0 &&
+                              c0 + kBC + d <= ib.box.c1 && (r0 + kBR - 1 + d) * a.stride + half < vr &&
+                              (c0 + kBC - 1 + d) * a.stride + half < vc;
+        if (interior) {
+    #pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int c = c0 + lcx + 32 * e;
+                const int pi = (lr + d) * PC + (lcx + 32 * e + PAD);
+                const float2 pp = pq[pi];
+                const float L0 = labs[pi], A0 = labs[PR * PC + pi], B0 = labs[2 * PR * PC + pi];
+                float2 nq[8]; float nL[8], nA[8], nB[8];
+                {
+                    int k = 0;
+    #pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy)
+    #pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            if (dx == 0 && dy == 0) continue;
+                            const int qi = pi + dy * d * PC + dx * d;
+                            nq[k] = pq[qi]; nL[k] = labs[qi]; nA[k] = labs[PR * PC + qi]; nB[k] = labs[2 * PR * PC + qi];
+                            ++k;
+                        }
+                }
+                float acc = 0.f;
+                bool tiny = false;
+                uint32_t wps = 0;
+                const float ppq = pp.x * pp.y;
+    #pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float dL = L0 - nL[k], dA = A0 - nA[k], dB = B0 - nB[k];
+                    const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(dL, dL), __fmul_rn(dA, dA)), __fmul_rn(dB, dB));
+                    const bool on = n2 <= pr.n2max;
+                    const float fp = on ? 1.f : 0.f;
+                    wps |= (on ? 1u : 0u) << k;
+                    const float S = pp.x * nq[k].x + pp.y * nq[k].y;
+                    tiny |= on && !(S > 1e-30f);
+                    const float Sc = fmaxf(S, 1e-30f);
+                    num += fp * -__logf(Sc);
+                    acc += (fp + fp) * (-(nq[k].x - nq[k].y) * ppq * __frcp_rn(Sc));
+                }
+                cnt += __popc(wps);
+                if (tiny) {   // rare
+                    const float2 fix = pair_logspace_redo(L, pq, h, w, d, PC, r, c, pi, pp, wps, wps);
+                    num += fix.x; acc = fix.y;
+                }
+                out[e] = acc;
+            }
+        } else
     #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int c = c0 + lcx + 32 * e;
@@ -766,6 +822,12 @@ __global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __res
             out[e] = acc;
         }
         BXI_T(1, blockIdx.x, 4);
+#ifdef BXI_TRACE
+        if (tid == 0 && g_trace && blockIdx.x < kTraceBlocks)   // slot 7: active pixels of the tile, interior flag, XCC id
+            g_trace[((size_t)1 * kTraceBlocks + blockIdx.x) * kTracePhases + 7] =
+                (long long)(max(0, min(r0 + kBR, ib.dil.r1) - max(r0, ib.dil.r0)) * max(0, min(c0 + kBC, ib.dil.c1) - max(c0, ib.dil.c0))) |
+                ((long long)interior << 20) | ((long long)__smid() << 24);
+#endif
         // ---- per-instance accumulators: integers, so the result does not depend on the arrival order --------
         num = wave_sum_f32(num);
         cnt = wave_sum_i32(cnt);
@@ -959,7 +1021,7 @@ int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, co
         }
     }
     const int n_stream = a.N * stream_tiles(a.h);
-    BXI_LAUNCH("stage1", s, stage1_kernel, dim3((unsigned)(a.N + 1 + n_pool + n_stream)), dim3(64), 0, s, pa, n_pool, a,
+    BXI_LAUNCH("stage1", s, stage1_kernel, dim3((unsigned)(a.N + n_pool + n_stream)), dim3(64), 0, s, pa, n_pool, a,
                dil, color_thresh, ws, g_logits, vec);
     rc = check_launch();
     if (rc != BXI_OK) return rc;

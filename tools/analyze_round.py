@@ -13,7 +13,7 @@ t = np.load(f'{g}/trace.npz')['trace'].astype(np.float64)
 us = lambda x: x * 0.01
 t0 = t[t>0].min()
 s1 = t[0]; m = s1[:,0]>0; ns = 800; nb = int(m.sum())
-ntab = 33; pp = s1[ntab:nb-ns]; sp = s1[nb-ns:nb]; print('  table waves dur', np.round(us(s1[:ntab,1]-s1[:ntab,0]),2).tolist()[:6], 'max', us(s1[:ntab,1]-s1[:ntab,0]).max())
+ntab = 32; pp = s1[ntab:nb-ns]; sp = s1[nb-ns:nb]; print('  table waves dur', np.round(us(s1[:ntab,1]-s1[:ntab,0]),2).tolist()[:6], 'max', us(s1[:ntab,1]-s1[:ntab,0]).max())
 print('stage1: blocks', nb, 'last start %.2f last end %.2f' % (us(s1[m,0].max()-t0), us(s1[m,1].max()-t0)))
 print('  stream waves: dur mean %.2f max %.2f | issue loads+zero-fill %.2f | tables (t==0 only) %.2f | wait data+column max %.2f | row butterflies+store %.2f' % ((us(sp[:,1]-sp[:,0]).mean(), us(sp[:,1]-sp[:,0]).max()) + tuple(us(sp[:,b_]-sp[:,a_]).mean() for a_,b_ in [(0,2),(2,3),(3,4),(4,1)])))
 print('  pool waves  : dur mean %.2f max %.2f | loads issued+data arrived %.2f | barrier %.2f | de-normalise+Lab+store %.2f' % ((us(pp[:,1]-pp[:,0]).mean(), us(pp[:,1]-pp[:,0]).max()) + tuple(us(pp[:,b_]-pp[:,a_]).mean() for a_,b_ in [(0,2),(2,3),(3,1)])))
