@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument('--inst-per-box', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-pipelined', action='store_true', help='skip the multi-stream extra measurement')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     return ap.parse_args()
 
@@ -77,7 +78,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:      # launched by torch.distributed.run (also with one process)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -86,7 +87,7 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = torch.device('cuda', local_rank if world > 1 else 0)
+    dev = torch.device('cuda', local_rank if dist is not None else 0)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -186,6 +187,31 @@ def main():
     }
     if parity is not None:
         result['parity'] = parity
+
+    # ---- extra (not `value`): independent evaluations pipelined over several HIP streams ------------------------
+    # `value` above is one evaluation at a time (how a training iteration uses the path).  The kernels are
+    # latency-bound, so independent batches overlap well; reported for reference only.
+    if rank == 0 and world == 1 and args.mode == 'eager' and not args.no_pipelined:
+        extra = {}
+        for ns in (2, 4):
+            streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+            def run_multi(n_steps):
+                for i in range(n_steps):
+                    st = streams[i % ns]
+                    enqueue(sets[i % len(sets)], st.cuda_stream)
+            run_multi(64)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            run_multi(args.steps)
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t1
+            extra[f'{ns}_streams'] = {'images_per_s': 2 * args.steps / el, 'us_per_step': el / args.steps * 1e6}
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            enqueue(sets[i % len(sets)], stream.cuda_stream)
+        extra['host_enqueue_us_per_step'] = (time.perf_counter() - t1) / args.steps * 1e6
+        torch.cuda.synchronize(dev)
+        result['pipelined_throughput_extra'] = extra
 
     # ---- per-kernel durations with HIP events on the launching stream (rank 0, N == 1) ------------
     if rank == 0 and world == 1 and not args.no_kernel_timing:

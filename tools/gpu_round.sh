@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 timeout 600 python -m pytest tests -q -m gpu -x > gpurun_out/pytest.log 2>&1; tail -4 gpurun_out/pytest.log
 python tools/trace_eval.py > gpurun_out/trace.log 2>&1; tail -1 gpurun_out/trace.log
-timeout 300 python bench.py --mode eager --no-cpu-baseline > gpurun_out/bench_eager.json 2> gpurun_out/bench_eager.err; python - <<'PY'
+timeout 300 python bench.py --mode eager --no-cpu-baseline --no-pipelined > gpurun_out/bench_eager.json 2> gpurun_out/bench_eager.err; python - <<'PY'
 import json
 for m in ('eager',):
     try:
@@ -12,6 +12,6 @@ for m in ('eager',):
     except Exception as e:
         print(m, 'FAILED', e); print(open(f'gpurun_out/bench_{m}.err').read()[-1500:])
 PY
-timeout 300 python bench.py --mode graph --no-cpu-baseline --no-kernel-timing > gpurun_out/bench_graph.json 2> gpurun_out/bench_graph.err; tail -c 400 gpurun_out/bench_graph.json | head -c 400; echo
-cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_eager -o r01 -- python $GRAFT_REPO_ROOT/bench.py --mode eager --steps 400 --warmup 50 --no-cpu-baseline --no-kernel-timing > $GRAFT_REPO_ROOT/gpurun_out/prof_eager.log 2>&1
+timeout 300 python bench.py --mode graph --no-cpu-baseline --no-kernel-timing --no-pipelined > gpurun_out/bench_graph.json 2> gpurun_out/bench_graph.err; tail -c 400 gpurun_out/bench_graph.json | head -c 400; echo
+cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_eager -o r01 -- python $GRAFT_REPO_ROOT/bench.py --mode eager --steps 400 --warmup 50 --no-cpu-baseline --no-kernel-timing --no-pipelined > $GRAFT_REPO_ROOT/gpurun_out/prof_eager.log 2>&1
 cut -d, -f1-4 $GRAFT_REPO_ROOT/gpurun_out/prof_eager/r01_kernel_stats.csv | head -8
