@@ -41,13 +41,11 @@ struct LossWs {               // carved from the caller's workspace
     unsigned long long* rowkey;  // [N,h] packed (max logit, first column)
     unsigned long long* acc;  // [N,2] per instance: sum of W (integer) ; sum of W*pw in 2^-24 fixed point
     struct InstRec* inst;     // [N]  box rectangle + image of every instance (written by stage1)
-    struct Pred* pred;        // [1]  colour-threshold predicate (written by stage1)
     struct WorkRec* work;     // [N*Tr*Tc] compacted box tiles (written by stage1)
     int* nwork;               // [1]
     unsigned int* arrive;     // [N+1] arrivals per instance (tiles + leader), [N] = instances complete (zeroed by stage1)
     unsigned int* expect;     // [N]   box tiles of the instance + 1 (written by stage1)
     float* dice;              // [N]
-    unsigned int* ticket;     // [1]
 };
 
 struct InstRec { int r0, r1, c0, c1, img, pad0, pad1, pad2; };   // 32 B: one load per workgroup
@@ -83,16 +81,14 @@ static size_t carve_ws(void* base, int N, int h, int w, LossWs* ws) {
     unsigned long long* rowkey = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)N * h);
     unsigned long long* acc = (unsigned long long*)take(sizeof(unsigned long long) * 2 * (size_t)(N > 0 ? N : 1));
     InstRec* inst = (InstRec*)take(sizeof(InstRec) * (size_t)(N > 0 ? N : 1));
-    Pred* pred = (Pred*)take(sizeof(Pred));
     WorkRec* work = (WorkRec*)take(sizeof(WorkRec) * (size_t)(N > 0 ? N : 1) * (size_t)box_tiles(h, w));
     int* nwork = (int*)take(sizeof(int));
     unsigned int* arrive = (unsigned int*)take(sizeof(unsigned int) * (size_t)(N + 1));
     unsigned int* expect = (unsigned int*)take(sizeof(unsigned int) * (size_t)(N > 0 ? N : 1));
     float* dice = (float*)take(sizeof(float) * (size_t)(N > 0 ? N : 1));
-    unsigned int* ticket = (unsigned int*)take(sizeof(unsigned int));
     if (ws) { ws->colkey = colkey; ws->rowkey = rowkey; ws->acc = acc; ws->inst = inst;
-              ws->pred = pred; ws->work = work; ws->nwork = nwork; ws->arrive = arrive; ws->expect = expect;
-              ws->dice = dice; ws->ticket = ticket; }
+              ws->work = work; ws->nwork = nwork; ws->arrive = arrive; ws->expect = expect;
+              ws->dice = dice; }
     return off;
 }
 
@@ -152,7 +148,7 @@ __device__ __forceinline__ InstBox inst_from_rec(const InstRec& rc, int dil, int
 // (p, q) = (sigmoid(x), sigmoid(-x)), both accurate relatively (no 1-p cancellation)
 __device__ __forceinline__ float2 sig_pair(float x) {
     const float e = __expf(-fabsf(x));
-    const float r = __frcp_rn(1.f + e);
+    const float r = __builtin_amdgcn_rcpf(1.f + e);   // v_rcp_f32 (1 ulp); __frcp_rn would expand to a full IEEE division
     const float er = e * r;
     return x >= 0.f ? make_float2(r, er) : make_float2(er, r);
 }
@@ -180,10 +176,6 @@ __device__ __forceinline__ void store4(float* row, int c, int w, bool vec, float
 // The two halves are independent (image side / logit side), so they share one launch of one-wave
 // workgroups: N*Ts streaming waves followed by B*h*w/64 pooling waves, all resident at once
 // (about 9 waves per CU at 2x800x1024x32), every wave issuing all of its loads before anything else.
-__device__ __forceinline__ bool seg_hit(const InstBox& ib, int r, int c) {
-    const int tr = r & ~(kBR - 1), tc = c & ~(kBC - 1);
-    return ib.any && tr < ib.dil.r1 && tr + kBR > ib.dil.r0 && tc < ib.dil.c1 && tc + kBC > ib.dil.c0;
-}
 
 // exact f32 predicate of the reference for a valid neighbour: exp(-||dLab|| * 0.5) >= thresh  (:237, :1324)
 __device__ __forceinline__ bool sim_pred(float n2, float thresh) {
@@ -261,7 +253,6 @@ __device__ __forceinline__ void build_work_list(const InstArgs& a, int dil, floa
     if (n == 0 && lane == 0) { *ws.nwork = total; ws.arrive[a.N] = 0u; }
     const int cnt = mine.ntr * mine.ntc;
     const Pred pr = make_pred(thresh);
-    if (n == 0 && lane == 0) *ws.pred = pr;
     if (lane == 0) {   // per-instance records and zeroed accumulators for box_kernel / loss_apply (next launches)
         InstRec rc; rc.r0 = mine.r0; rc.r1 = mine.r1; rc.c0 = mine.c0; rc.c1 = mine.c1; rc.img = mine.img;
         rc.pad0 = rc.pad1 = rc.pad2 = 0;
@@ -739,7 +730,7 @@ __global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __res
                     tiny |= on && !(S > 1e-30f);
                     const float Sc = fmaxf(S, 1e-30f);
                     num += fp * -__logf(Sc);
-                    acc += (fp + fp) * (-(nq[k].x - nq[k].y) * ppq * __frcp_rn(Sc));
+                    acc += (fp + fp) * (-(nq[k].x - nq[k].y) * ppq * __builtin_amdgcn_rcpf(Sc));
                 }
                 cnt += __popc(wps);
                 if (tiny) {   // rare
@@ -812,7 +803,7 @@ __global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __res
                     tiny |= (fw != 0.f) && !(S > 1e-30f);
                     const float Sc = fmaxf(S, 1e-30f);
                     num += fp * -__logf(Sc);
-                    acc += fw * (-(nq[k].x - nq[k].y) * ppq * __frcp_rn(Sc));
+                    acc += fw * (-(nq[k].x - nq[k].y) * ppq * __builtin_amdgcn_rcpf(Sc));
                     ++k;
                 }
             if (tiny) {   // rare

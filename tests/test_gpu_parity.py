@@ -254,3 +254,71 @@ def test_head_composed_window5(dev):
     assert rel(float(out['loss_pairwise']), ref['loss_pairwise']) <= TOL
     err, _ = grad_report(logits.grad.cpu().numpy()[:, 0], ref['grad'], d['mask_logits'][:, 0])
     assert err <= TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# shape / parameter coverage of the fused path (loops that the headline shape never enters)
+# ---------------------------------------------------------------------------------------------
+def _check_cfg(d, dev, tol=TOL, **kw):
+    """oracle vs HIP with non-default loss parameters (dilation, threshold, stride...)."""
+    ref = oracle_path(d, want_targets=False, size=3, dil=kw.get('pairwise_dilation', 2),
+                      thresh=kw.get('pairwise_color_thresh', 0.3),
+                      bottom_pixels_removed=kw.get('bottom_pixels_removed', 10))
+    lp, lw, grad = hip_loss(d, dev, **kw)
+    assert rel(lp, ref['loss_prj']) <= tol, (lp, ref['loss_prj'])
+    assert rel(lw, ref['loss_pairwise']) <= tol or abs(lw - ref['loss_pairwise']) < 1e-7, (lw, ref['loss_pairwise'])
+    err, ties = grad_report(grad, ref['grad'], d['mask_logits'][:, 0])
+    assert err <= tol, f'grad err {err:.3e} ({ties} ambiguous arg-max lines excluded)'
+
+
+def test_loss_many_instances(dev):
+    """N = 300 > 256 (leader / final loops over instance chunks), 20 per box, three images."""
+    d = synthetic.make_batch(B=3, H=64, W=96, boxes_per_img=5, inst_per_box=20, seed=21, min_box=12, max_box=60)
+    assert d['N'] == 300
+    _check_cfg(d, dev)
+
+
+def test_loss_tall_and_wide_map(dev):
+    """h = 272 > 256 rows and w = 336 > 256 columns: second chunk of every row / column loop."""
+    d = synthetic.make_batch(B=1, H=1088, W=1344, boxes_per_img=3, seed=22, min_box=200, max_box=900)
+    _check_cfg(d, dev)
+
+
+@pytest.mark.parametrize('dil', [1, 3, 4])
+def test_loss_other_dilations(dev, dil):
+    d = synthetic.make_batch(B=2, H=96, W=160, boxes_per_img=3, seed=23 + dil, min_box=16, max_box=90)
+    _check_cfg(d, dev, pairwise_dilation=dil)
+
+
+def test_loss_unaligned_width_scalar_path(dev):
+    """w = 51 (not a multiple of 4): the non-vector load/store path of every kernel."""
+    d = synthetic.make_batch(B=2, H=72, W=204, boxes_per_img=2, seed=27, min_box=16, max_box=120)
+    assert d['w'] == 51
+    _check_cfg(d, dev)
+
+
+def test_loss_stride8_generic_pool(dev):
+    d = synthetic.make_batch(B=1, H=128, W=192, boxes_per_img=2, seed=28, stride=8, min_box=24, max_box=100)
+    _check_cfg(d, dev)
+
+
+@pytest.mark.parametrize('thresh', [0.0, -1.0, 0.999, 1.5, 0.05])
+def test_loss_threshold_extremes(dev, thresh):
+    """thresh <= 0: every pair (padded ones too) weighs 1; thresh > 1: none; the bisection's edge cases."""
+    d = synthetic.make_batch(B=1, H=64, W=64, boxes_per_img=2, seed=29, min_box=16, max_box=50)
+    _check_cfg(d, dev, pairwise_color_thresh=thresh)
+
+
+def test_loss_bottom_rows_removed_variants(dev):
+    d = synthetic.make_batch(B=2, H=96, W=128, boxes_per_img=2, seed=30, img_shapes=[(90, 128), (96, 100)],
+                             ori_shapes=[(30, 43), (960, 1000)], min_box=16, max_box=90)
+    _check_cfg(d, dev, bottom_pixels_removed=10)     # 30 rows removed in image 0, 1 in image 1
+    _check_cfg(d, dev, bottom_pixels_removed=0)
+
+
+def test_loss_box_edge_cases(dev):
+    """boxes touching / leaving the canvas, degenerate and inverted boxes, invalid gt index."""
+    d = synthetic.make_batch(B=1, H=64, W=96, boxes_per_img=6, seed=31, min_box=16, max_box=40)
+    d['gt_bboxes'][0] = np.array([[0.0, 0.0, 95.0, 63.0], [-5.0, -7.0, 20.0, 30.0], [80.0, 50.0, 200.0, 100.0],
+                                  [40.0, 40.0, 40.5, 40.5], [60.0, 30.0, 50.0, 20.0], [10.2, 5.9, 33.3, 41.7]], np.float32)
+    _check_cfg(d, dev)

@@ -11,7 +11,7 @@ for mode in ('eager', 'graph'):
     except Exception as e: print(mode, 'n/a', e)
 t = np.load(f'{g}/trace.npz')['trace'].astype(np.float64)
 us = lambda x: x * 0.01
-t0 = t[t>0].min()
+t0 = t[0][t[0]>0].min()
 s1 = t[0]; m = s1[:,0]>0; ns = 800; nb = int(m.sum())
 ntab = 32; pp = s1[ntab:nb-ns]; sp = s1[nb-ns:nb]; print('  table waves dur', np.round(us(s1[:ntab,1]-s1[:ntab,0]),2).tolist()[:6], 'max', us(s1[:ntab,1]-s1[:ntab,0]).max())
 print('stage1: blocks', nb, 'last start %.2f last end %.2f' % (us(s1[m,0].max()-t0), us(s1[m,1].max()-t0)))
