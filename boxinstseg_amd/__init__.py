@@ -9,11 +9,12 @@ Public surface (mirrors the reference's for this path):
 """
 from .pairwise import PairwiseNLog, pairwise_nlog, pairwise_nlog_backward, pairwise_nlog_forward
 from .functional import BoxInstMaskLoss, box_bitmasks, boxinst_mask_loss, color_affinity
+from .dynamic import DynamicMaskHead, dynamic_mask_forward
 from .mask_head import CondInstMaskHead
 from .registry import HEADS, build_head
 from .config import load_config
 
 __all__ = ['pairwise_nlog', 'pairwise_nlog_forward', 'pairwise_nlog_backward', 'PairwiseNLog',
-           'boxinst_mask_loss', 'BoxInstMaskLoss', 'color_affinity', 'box_bitmasks',
+           'boxinst_mask_loss', 'BoxInstMaskLoss', 'dynamic_mask_forward', 'DynamicMaskHead', 'color_affinity', 'box_bitmasks',
            'CondInstMaskHead', 'HEADS', 'build_head', 'load_config']
 __version__ = '0.1.0'

@@ -63,6 +63,12 @@ SIGNATURES = {
     'bxi_boxinst_eval_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'bxi_boxinst_eval_f32': (c_int, [C.POINTER(ImageBatch), C.POINTER(Instances), c_int, c_int, c_float, c_float,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'bxi_dynamic_mask_forward_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'bxi_dynamic_mask_backward_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    'bxi_dynamic_mask_backward_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_size_t, c_void_p]),
 }
 
 LAUNCH_HOOK = C.CFUNCTYPE(None, C.c_char_p, c_int, c_void_p, c_void_p)

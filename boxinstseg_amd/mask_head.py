@@ -24,6 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as F_hip
+from .dynamic import dynamic_mask_forward
 from .pairwise import pairwise_nlog
 from .registry import HEADS
 
@@ -113,6 +114,29 @@ class CondInstMaskHead(nn.Module):
         self._iter += 1
         self._iter_host += 1.0
         return min(self._iter_host / float(self._warmup_iters), 1.0)
+
+    # ---- the producer of mask_logits -------------------------------------------------------
+    def parse_dynamic_params(self, params):
+        """condinst_head.py:1120-1137: split [N,P] into the grouped-conv weights / biases of the three
+        dynamic layers (kept for callers that want the reference's view of the parameters)."""
+        n = params.size(0)
+        parts = list(torch.split_with_sizes(params, self.dy_weights + self.dy_biases, dim=1))
+        weights, biases = parts[:self.dynamic_convs], parts[self.dynamic_convs:]
+        for i in range(self.dynamic_convs):
+            cout = 1 if i == self.dynamic_convs - 1 else self.dynamic_channels
+            weights[i] = weights[i].reshape(n * cout, -1, 1, 1)
+            biases[i] = biases[i].reshape(n * cout)
+        return weights, biases
+
+    def forward(self, feat, params, coors, level_inds, img_inds):
+        """condinst_head.py:1139-1164 -> mask logits [N,1,H*f,W*f], f = in_stride // out_stride."""
+        if not feat.is_cuda:
+            raise RuntimeError('CondInstMaskHead.forward: feat must be a CUDA (HIP) tensor; no CPU path')
+        if self.dynamic_convs != 3 or self.dynamic_channels != 8 or feat.size(1) not in (8, 16):
+            raise RuntimeError('the HIP dynamic head is built for dynamic_convs=3, dynamic_channels=8, 8/16 feature channels')
+        return dynamic_mask_forward(feat, params, coors, level_inds, img_inds, self.sizes_of_interest,
+                                    in_stride=self.in_stride, out_stride=self.out_stride,
+                                    disable_rel_coors=self.disable_rel_coors)
 
     # ---- targets ----------------------------------------------------------------------------------
     def get_targets(self, gt_bboxes, gt_masks, img, img_metas):

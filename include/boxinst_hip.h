@@ -185,6 +185,33 @@ int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances*
                          float* losses, float* g_logits, void* state,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ===========================================================================================
+ * 4. The producer of mask_logits -- replaces CondInstMaskHead.forward (condinst_head.py:1139-1164):
+ *    relative coordinates (:1142-1154), parse_dynamic_params (:1120-1137), the three per-instance
+ *    grouped 1x1 convolutions + ReLU (:1156-1161) and aligned_bilinear (:146-167, :1163).
+ * ===========================================================================================
+ * feat   [B,C,H,W]  mask-branch features at `in_stride` (C = 8 or 16 built; others BXI_ERR_UNSUPPORTED)
+ * params [N,P]      per-instance dynamic parameters, P = (C+2)*8 + 64 + 8 + 8 + 8 + 1 (the
+ *                   split_with_sizes order of the reference: w0, w1, w2, b0, b1, b2); C*8+... when
+ *                   disable_rel_coors
+ * coors  [N,2] f32 (x,y) ; level_inds [N] i64 ; img_inds [N] i64 ; sizes_of_interest [n_levels] f32
+ * logits [N,1,H*factor,W*factor], factor = in_stride / out_stride.
+ */
+int bxi_dynamic_mask_forward_f32(const float* feat, int B, int C, int H, int W, const float* params, int N,
+                                 const float* coors, const int64_t* level_inds, const int64_t* img_inds,
+                                 const float* sizes_of_interest, int n_levels, int in_stride, int factor,
+                                 int disable_rel_coors, float* logits, void* stream);
+
+/* Backward of the above: g_feat [B,C,H,W] and g_params [N,P] (both fully overwritten) from g_logits.
+ * Deterministic (no atomics; the reference's feat[img_inds] backward is an atomic index_add).
+ * workspace: bxi_dynamic_mask_backward_workspace_bytes, 256-B aligned. */
+size_t bxi_dynamic_mask_backward_workspace_bytes(int B, int C, int H, int W, int N, int disable_rel_coors);
+int bxi_dynamic_mask_backward_f32(const float* feat, int B, int C, int H, int W, const float* params, int N,
+                                  const float* coors, const int64_t* level_inds, const int64_t* img_inds,
+                                  const float* sizes_of_interest, int n_levels, int in_stride, int factor,
+                                  int disable_rel_coors, const float* g_logits, float* g_feat, float* g_params,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

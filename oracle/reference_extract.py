@@ -18,8 +18,8 @@ HEAD_FILE = 'mmdet/models/dense_heads/condinst_head.py'
 PROJ_LOSS_FILE = 'mmdet/models/losses/box_projection_loss.py'
 
 FUNCTIONS = ('compute_pairwise_term', 'dice_coefficient', 'compute_project_term', 'unfold_wo_center',
-             'get_image_color_similarity', 'get_original_image')
-METHODS = ('loss', 'get_targets', 'get_bitmasks_from_boxes')
+             'get_image_color_similarity', 'get_original_image', 'aligned_bilinear')
+METHODS = ('loss', 'get_targets', 'get_bitmasks_from_boxes', 'forward', 'parse_dynamic_params')
 
 
 def available() -> bool:

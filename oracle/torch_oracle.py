@@ -210,6 +210,42 @@ def mask_loss(imgs: torch.Tensor, img_metas: List[dict], mask_logits: torch.Tens
                               pairwise_color_thresh=pairwise_color_thresh, warmup_factor=warmup_factor)
 
 
+# --------------------------------------------------------------------------------------------
+# producer of the logits -- condinst_head.py:146-167 (aligned_bilinear), :1139-1164 (forward)
+# --------------------------------------------------------------------------------------------
+def aligned_upsample(x: torch.Tensor, factor: int) -> torch.Tensor:
+    """[N,C,h,w] -> [N,C,factor*h,factor*w] with the sampling grid of the reference's aligned_bilinear."""
+    if factor == 1:
+        return x
+    h, w = x.shape[2:]
+    x = F.pad(x, (0, 1, 0, 1), mode='replicate')
+    x = F.interpolate(x, size=(factor * h + 1, factor * w + 1), mode='bilinear', align_corners=True)
+    x = F.pad(x, (factor // 2, 0, factor // 2, 0), mode='replicate')
+    return x[:, :, :factor * h, :factor * w]
+
+
+def dynamic_mask_forward(feat, params, coors, level_inds, img_inds, sizes_of_interest, *, in_stride=8, out_stride=4,
+                         dynamic_channels=8, disable_rel_coors=False):
+    """feat [B,C,H,W], params [N,P] -> logits [N,1,H*f,W*f] (three per-instance 1x1 convs as grouped convs)."""
+    x = feat[img_inds]
+    n, c, h, w = x.shape
+    if not disable_rel_coors:
+        xs = torch.arange(0, w * in_stride, in_stride, dtype=x.dtype, device=x.device) + in_stride // 2
+        ys = torch.arange(0, h * in_stride, in_stride, dtype=x.dtype, device=x.device) + in_stride // 2
+        loc = torch.stack([xs[None, :].expand(h, w), ys[:, None].expand(h, w)], dim=0)          # [2,h,w] (x,y)
+        rel = (coors[:, :, None, None] - loc[None]) / sizes_of_interest.float()[level_inds][:, None, None, None]
+        x = torch.cat([rel, x], dim=1)
+        c += 2
+    sizes = [c * dynamic_channels, dynamic_channels * dynamic_channels, dynamic_channels,
+             dynamic_channels, dynamic_channels, 1]
+    w0, w1, w2, b0, b1, b2 = torch.split_with_sizes(params, sizes, dim=1)
+    x = x.reshape(1, n * c, h, w)
+    x = F.relu(F.conv2d(x, w0.reshape(n * dynamic_channels, c, 1, 1), b0.reshape(-1), groups=n))
+    x = F.relu(F.conv2d(x, w1.reshape(n * dynamic_channels, dynamic_channels, 1, 1), b1.reshape(-1), groups=n))
+    x = F.conv2d(x, w2.reshape(n, dynamic_channels, 1, 1), b2.reshape(-1), groups=n)
+    return aligned_upsample(x.permute(1, 0, 2, 3), in_stride // out_stride)
+
+
 def warmup_factor(iteration: float, warmup_iters: int) -> float:
     """condinst_head.py:1330-1331."""
     return min(iteration / float(warmup_iters), 1.0)

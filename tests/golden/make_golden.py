@@ -25,6 +25,7 @@ Fixtures (all small, float64 where the reference supports it):
   loss_cfg1.npz      BASELINE configs[0] (1x256x256, 4 boxes): full CondInstMaskHead.loss, f32
   loss_ragged.npz    2 ragged images, 2 instances per box, warm-up 0.37
   lab_kat.npz        textbook CIE-Lab known answers for the rgb2lab restatement
+  dynamic_head_f64.npz  CondInstMaskHead.forward (+ parse_dynamic_params, aligned_bilinear) and autograd gradients
 """
 import os
 import sys
@@ -148,6 +149,32 @@ def main():
                              min_box=16, max_box=80)
     r = run_reference_loss(ns, d, it=3699)
     np.savez_compressed(os.path.join(HERE, 'loss_ragged.npz'), **pack_case(d), **r)
+
+    # ---- producer of the logits: CondInstMaskHead.forward (reference source) + autograd --------------------------------
+    out = {}
+    for name, C, no_rel, fac, (B, H, W, N) in [('a', 16, False, 2, (2, 9, 13, 5)), ('b', 8, True, 4, (1, 6, 7, 3)),
+                                                ('c', 16, False, 1, (2, 5, 34, 4))]:
+        class S:
+            pass
+        st = S()
+        st.in_stride, st.out_stride, st.disable_rel_coors, st.dynamic_convs, st.dynamic_channels = 8, 8 // fac, no_rel, 3, 8
+        cin = C if no_rel else C + 2
+        st.dy_weights, st.dy_biases = [cin * 8, 64, 8], [8, 8, 1]
+        st.sizes_of_interest = torch.tensor([64, 128, 256, 512, 1024])
+        st.parse_dynamic_params = lambda p, st=st: ns.CondInstMaskHead_parse_dynamic_params(st, p)
+        feat = torch.tensor(rng.standard_normal((B, C, H, W)), dtype=torch.float64, requires_grad=True)
+        params = torch.tensor(rng.standard_normal((N, sum(st.dy_weights) + 17)) * 0.4, dtype=torch.float64, requires_grad=True)
+        coors = torch.tensor(rng.uniform(0, 8 * W, size=(N, 2)), dtype=torch.float64)
+        lvl = torch.tensor(rng.integers(0, 5, size=N))
+        img = torch.tensor(rng.integers(0, B, size=N))
+        y = ns.CondInstMaskHead_forward(st, feat, params, coors, lvl, img)
+        g = torch.tensor(rng.standard_normal(tuple(y.shape)), dtype=torch.float64)
+        y.backward(g)
+        out.update({f'{name}_feat': feat.detach().numpy(), f'{name}_params': params.detach().numpy(), f'{name}_coors': coors.numpy(),
+                    f'{name}_level': lvl.numpy(), f'{name}_img': img.numpy(), f'{name}_cfg': np.array([C, int(no_rel), fac]),
+                    f'{name}_logits': y.detach().numpy(), f'{name}_g': g.numpy(), f'{name}_gfeat': feat.grad.numpy(),
+                    f'{name}_gparams': params.grad.numpy()})
+    np.savez_compressed(os.path.join(HERE, 'dynamic_head_f64.npz'), **out)
 
     # ---- Lab known answers (published CIE values) -------------------------------------------------------
     rgb = np.array([[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 77]], np.uint8)

@@ -1,0 +1,80 @@
+"""GPU: the dynamic mask head -- HIP forward/backward vs the golden fixture produced by the
+reference's own CondInstMaskHead.forward and vs the torch restatement at larger shapes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+SOI = [64, 128, 256, 512, 1024]
+
+
+def _run_hip(dev, feat, params, coors, lvl, img, fac, no_rel, g):
+    from boxinstseg_amd import dynamic_mask_forward
+    f = torch.from_numpy(feat.astype(np.float32)).to(dev).requires_grad_(True)
+    p = torch.from_numpy(params.astype(np.float32)).to(dev).requires_grad_(True)
+    y = dynamic_mask_forward(f, p, torch.from_numpy(coors.astype(np.float32)).to(dev), torch.from_numpy(lvl).to(dev),
+                             torch.from_numpy(img).to(dev), torch.tensor(SOI, device=dev), in_stride=8,
+                             out_stride=8 // fac, disable_rel_coors=bool(no_rel))
+    y.backward(torch.from_numpy(g.astype(np.float32)).to(dev))
+    return y.detach().cpu().numpy(), f.grad.cpu().numpy(), p.grad.cpu().numpy()
+
+
+def _close(got, want, tol):
+    return np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1e-30)
+
+
+@pytest.mark.parametrize('case', ['a', 'b', 'c'])
+def test_dynamic_head_vs_reference_fixture(dev, case):
+    g = np.load(os.path.join(G, 'dynamic_head_f64.npz'))
+    C, no_rel, fac = [int(v) for v in g[f'{case}_cfg']]
+    y, gf, gp = _run_hip(dev, g[f'{case}_feat'], g[f'{case}_params'], g[f'{case}_coors'], g[f'{case}_level'],
+                         g[f'{case}_img'], fac, no_rel, g[f'{case}_g'])
+    assert y.shape == g[f'{case}_logits'].shape
+    assert _close(y, g[f'{case}_logits'], 2e-5)
+    assert _close(gf, g[f'{case}_gfeat'], 2e-5)
+    assert _close(gp, g[f'{case}_gparams'], 2e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 100, 128, 32), (3, 8, 37, 50, 70), (1, 16, 8, 32, 1)])
+def test_dynamic_head_vs_oracle_large(dev, shape):
+    """BoxInst R-50 shape (2 x 16 x 100 x 128 features, 32 instances -> 200 x 256 logits) and ragged ones."""
+    from oracle import torch_oracle as to
+    B, C, H, W, N = shape
+    rng = np.random.default_rng(sum(shape))
+    feat = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    params = (rng.standard_normal((N, (C + 2) * 8 + 64 + 8 + 17)) * 0.3).astype(np.float32)
+    coors = rng.uniform(0, 8 * W, size=(N, 2)).astype(np.float32)
+    lvl = rng.integers(0, 5, size=N)
+    img = rng.integers(0, B, size=N)
+    g = rng.standard_normal((N, 1, 2 * H, 2 * W)).astype(np.float32)
+    f64 = lambda a: torch.from_numpy(a.astype(np.float64))
+    ft, pt = f64(feat).requires_grad_(True), f64(params).requires_grad_(True)
+    yo = to.dynamic_mask_forward(ft, pt, f64(coors), torch.from_numpy(lvl), torch.from_numpy(img), torch.tensor(SOI))
+    yo.backward(f64(g))
+    y, gf, gp = _run_hip(dev, feat, params, coors, lvl, img, 2, 0, g)
+    assert _close(y, yo.detach().numpy(), 2e-5)
+    assert _close(gf, ft.grad.numpy(), 5e-5)
+    assert _close(gp, pt.grad.numpy(), 5e-5)
+
+
+def test_dynamic_head_module_and_errors(dev):
+    from boxinstseg_amd import CondInstMaskHead
+    head = CondInstMaskHead(in_channels=16, boxinst_enabled=True, max_proposals=-1, topk_per_img=64).to(dev)
+    feat = torch.randn(2, 16, 12, 20, device=dev)
+    params = torch.randn(3, head.num_gen_params, device=dev)
+    out = head(feat, params, torch.rand(3, 2, device=dev) * 100, torch.tensor([0, 2, 4], device=dev),
+               torch.tensor([1, 0, 1], device=dev))
+    assert out.shape == (3, 1, 24, 40)
+    empty = head(feat, params[:0], torch.zeros(0, 2, device=dev), torch.zeros(0, dtype=torch.long, device=dev),
+                 torch.zeros(0, dtype=torch.long, device=dev))
+    assert empty.shape == (0, 1, 24, 40)
+    with pytest.raises(RuntimeError, match='CUDA'):
+        head(feat.cpu(), params.cpu(), torch.zeros(3, 2), torch.zeros(3, dtype=torch.long), torch.zeros(3, dtype=torch.long))
+    with pytest.raises(RuntimeError):
+        head(feat, params[:, :100], torch.zeros(3, 2, device=dev), torch.zeros(3, dtype=torch.long, device=dev),
+             torch.zeros(3, dtype=torch.long, device=dev))
+    w, b = head.parse_dynamic_params(params)
+    assert [tuple(t.shape) for t in w] == [(24, 18, 1, 1), (24, 8, 1, 1), (3, 8, 1, 1)] and [t.numel() for t in b] == [24, 24, 3]

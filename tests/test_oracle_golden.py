@@ -129,3 +129,19 @@ def test_image_mask_and_pool():
     u = rng.integers(0, 256, size=(3, 8, 12)).astype(np.uint8)
     want = torch.nn.functional.avg_pool2d(torch.from_numpy(u).float()[None], 4, 4)[0].byte().numpy()
     assert np.array_equal(c_oracle.pool_u8(u, 4), want)
+
+
+@pytest.mark.parametrize('case', ['a', 'b', 'c'])
+def test_dynamic_head_restatement_vs_reference(case):
+    """oracle.torch_oracle.dynamic_mask_forward vs CondInstMaskHead.forward run from the reference source."""
+    g = load('dynamic_head_f64.npz')
+    C, no_rel, fac = [int(v) for v in g[f'{case}_cfg']]
+    feat = torch.from_numpy(g[f'{case}_feat']).requires_grad_(True)
+    params = torch.from_numpy(g[f'{case}_params']).requires_grad_(True)
+    y = to.dynamic_mask_forward(feat, params, torch.from_numpy(g[f'{case}_coors']), torch.from_numpy(g[f'{case}_level']),
+                                torch.from_numpy(g[f'{case}_img']), torch.tensor([64, 128, 256, 512, 1024]),
+                                in_stride=8, out_stride=8 // fac, disable_rel_coors=bool(no_rel))
+    y.backward(torch.from_numpy(g[f'{case}_g']))
+    assert np.abs(y.detach().numpy() - g[f'{case}_logits']).max() < 1e-12
+    assert np.abs(feat.grad.numpy() - g[f'{case}_gfeat']).max() < 1e-12
+    assert np.abs(params.grad.numpy() - g[f'{case}_gparams']).max() < 1e-11
