@@ -29,7 +29,7 @@ namespace bxi {
 constexpr int kDC = 8;            // dynamic_channels (configs/boxinst: 8)
 constexpr int kYR = 8, kYC = 32;  // y tile (pixels at in_stride resolution) per workgroup
 constexpr int kSlots = 8;         // instance slots per (image, tile) in the backward
-constexpr int kRowPad = kYR * kYC + 4;   // LDS row stride of the staged operand rows (conflict-free b128)
+constexpr int kRowPad = kYR * kYC;       // LDS row stride of the staged operand rows
 
 struct DynArgs {
     const float* feat;        // [B,C,H,W]
@@ -41,128 +41,247 @@ struct DynArgs {
     int B, H, W, N, n_levels, in_stride, factor, rel;   // rel = !disable_rel_coors
 };
 
-template <int C> struct DynLayout {
-    static constexpr int CIN = C + 2;             // with relative coordinates (the first two channels)
-    static constexpr int W0 = 0;                  // [8][CIN]
-    static constexpr int W1 = CIN * kDC;          // [8][8]
-    static constexpr int W2 = W1 + kDC * kDC;     // [1][8]
-    static constexpr int B0 = W2 + kDC;
-    static constexpr int B1 = B0 + kDC;
-    static constexpr int B2 = B1 + kDC;
-    static constexpr int P = B2 + 1;
+
+// one pixel through the three dynamic layers.  `wts` = the instance's parameters in LDS (broadcast reads).
+// Every bound is a compile-time constant: a runtime bound would index the register arrays dynamically,
+// which the compiler can only serve with select chains (the first version of this file ran 10x slower).
+template <int C, bool REL> struct Dyn {
+    static constexpr int CIN = REL ? C + 2 : C;
+    static constexpr int W1 = CIN * kDC, W2 = W1 + kDC * kDC, B0 = W2 + kDC, B1 = B0 + kDC, B2 = B1 + kDC, P = B2 + 1;
 };
 
-// one pixel through the three dynamic layers.  `wts` = the instance's parameters in LDS.
-// With rel == 0 the first layer has C inputs ([8][C] weights) and in[0..1] are unused.
-template <int C>
-__device__ __forceinline__ float mlp_forward(const float* wts, const float (&in)[C + 2], int rel, float (&h1)[kDC],
-                                             float (&h2)[kDC]) {
-    const int cin = rel ? C + 2 : C, off = rel ? 0 : 2;
-    const int w1 = cin * kDC, w2 = w1 + kDC * kDC, b0 = w2 + kDC, b1 = b0 + kDC, b2 = b1 + kDC;
+// BXI_SEGMENT: the scheduler may not move instructions across it.  The weights arrive by scalar loads; without
+// the fences the scheduler hoists all 233 loads to the top, runs out of SGPRs and spills them to VGPR lanes.
+#define BXI_SEGMENT() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+// Packed math: a dot product runs over input PAIRS, acc2 += (w[2k], w[2k+1]) * (x[2k], x[2k+1]) as one
+// v_pk_fma_f32 with the weight pair as an SGPR operand, and ends with acc2.x + acc2.y: half the VALU
+// instructions of scalar FMAs (left to itself the compiler emits v_pk_mul + two v_add per pair).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f w2_at(const float* __restrict__ w, int i) { return v2f{w[i], w[i + 1]}; }
+
+// in2/h1/h2 hold consecutive channels as pairs
+template <int C, bool REL>
+__device__ __forceinline__ float mlp_forward(const float* __restrict__ wts, const v2f (&in2)[Dyn<C, REL>::CIN / 2],
+                                             v2f (&h1)[kDC / 2], v2f (&h2)[kDC / 2]) {
+    using D = Dyn<C, REL>;
+    static_assert(D::CIN % 2 == 0, "packed dot products need an even channel count");
+    float t[kDC];
 #pragma unroll
     for (int o = 0; o < kDC; ++o) {
-        float acc = wts[b0 + o];
-        for (int i = 0; i < cin; ++i) acc += wts[o * cin + i] * in[i + off];
-        h1[o] = fmaxf(acc, 0.f);
+        if (o % 4 == 0) BXI_SEGMENT();
+        v2f acc = {wts[D::B0 + o], 0.f};
+#pragma unroll
+        for (int i = 0; i < D::CIN / 2; ++i) acc = pk_fma(w2_at(wts, o * D::CIN + 2 * i), in2[i], acc);
+        t[o] = fmaxf(acc.x + acc.y, 0.f);
     }
+#pragma unroll
+    for (int o = 0; o < kDC / 2; ++o) h1[o] = v2f{t[2 * o], t[2 * o + 1]};
+    BXI_SEGMENT();
 #pragma unroll
     for (int o = 0; o < kDC; ++o) {
-        float acc = wts[b1 + o];
+        v2f acc = {wts[D::B1 + o], 0.f};
 #pragma unroll
-        for (int i = 0; i < kDC; ++i) acc += wts[w1 + o * kDC + i] * h1[i];
-        h2[o] = fmaxf(acc, 0.f);
+        for (int i = 0; i < kDC / 2; ++i) acc = pk_fma(w2_at(wts, D::W1 + o * kDC + 2 * i), h1[i], acc);
+        t[o] = fmaxf(acc.x + acc.y, 0.f);
     }
-    float y = wts[b2];
 #pragma unroll
-    for (int i = 0; i < kDC; ++i) y += wts[w2 + i] * h2[i];
-    return y;
+    for (int o = 0; o < kDC / 2; ++o) h2[o] = v2f{t[2 * o], t[2 * o + 1]};
+    v2f y = {wts[D::B2], 0.f};
+#pragma unroll
+    for (int i = 0; i < kDC / 2; ++i) y = pk_fma(w2_at(wts, D::W2 + 2 * i), h2[i], y);
+    BXI_SEGMENT();
+    return y.x + y.y;
 }
 
-template <int C>
-__device__ __forceinline__ void load_inputs(const DynArgs& a, int n, int b, int r, int c, float cx, float cy, float inv_soi,
-                                            float (&in)[C + 2]) {
-    const int64_t HW = (int64_t)a.H * a.W;
-    const float* f = a.feat + (int64_t)b * C * HW + (int64_t)r * a.W + c;
-    // locations = arange(0, W*stride, stride) + stride // 2   (:1143-1150)
-    in[0] = (cx - (float)(c * a.in_stride + a.in_stride / 2)) * inv_soi;
-    in[1] = (cy - (float)(r * a.in_stride + a.in_stride / 2)) * inv_soi;
+// two pixels at once: every weight is used the moment its scalar load lands, so none has to be kept
+// (evaluating the pixels one after the other makes the compiler keep all 233 SGPRs and spill them)
+template <int C, bool REL>
+__device__ __forceinline__ void mlp_forward2(const float* __restrict__ wts, const float (&inA)[Dyn<C, REL>::CIN],
+                                             const float (&inB)[Dyn<C, REL>::CIN], float& yA, float& yB) {
+    using D = Dyn<C, REL>;
+    float a1[kDC], b1[kDC], a2[kDC], b2[kDC];
 #pragma unroll
-    for (int k = 0; k < C; ++k) in[2 + k] = f[k * HW];
+    for (int o = 0; o < kDC; ++o) {
+        float accA = wts[D::B0 + o], accB = accA;
+#pragma unroll
+        for (int i = 0; i < D::CIN; ++i) { const float w = wts[o * D::CIN + i]; accA += w * inA[i]; accB += w * inB[i]; }
+        a1[o] = fmaxf(accA, 0.f); b1[o] = fmaxf(accB, 0.f);
+    }
+#pragma unroll
+    for (int o = 0; o < kDC; ++o) {
+        float accA = wts[D::B1 + o], accB = accA;
+#pragma unroll
+        for (int i = 0; i < kDC; ++i) { const float w = wts[D::W1 + o * kDC + i]; accA += w * a1[i]; accB += w * b1[i]; }
+        a2[o] = fmaxf(accA, 0.f); b2[o] = fmaxf(accB, 0.f);
+    }
+    yA = yB = wts[D::B2];
+#pragma unroll
+    for (int i = 0; i < kDC; ++i) { const float w = wts[D::W2 + i]; yA += w * a2[i]; yB += w * b2[i]; }
+}
+
+// in[] = (relative coordinates when REL,) C feature channels of pixel (r,c) of image b
+template <int C, bool REL>
+__device__ __forceinline__ void load_inputs(const DynArgs& a, int n, int b, int r, int c, float (&in)[Dyn<C, REL>::CIN]) {
+    const int64_t HW = (int64_t)a.H * a.W;
+    const float* fb = a.feat + (int64_t)b * C * HW;          // uniform base, 32-bit lane offset
+    const unsigned po = (unsigned)(r * a.W + c);
+    constexpr int off = REL ? 2 : 0;
+    if constexpr (REL) {
+        // locations = arange(0, W*stride, stride) + stride // 2 (:1143-1150); (coors - locations) / soi (:1151-1153)
+        const float soi = a.soi[a.level[n]];
+        in[0] = (a.coors[2 * n] - (float)(c * a.in_stride + a.in_stride / 2)) / soi;
+        in[1] = (a.coors[2 * n + 1] - (float)(r * a.in_stride + a.in_stride / 2)) / soi;
+    }
+#pragma unroll
+    for (int k = 0; k < C; ++k) in[off + k] = (fb + (int64_t)k * HW)[po];
 }
 
 // ---- forward ---------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(256) void dyn_fwd_kernel(DynArgs a, float* __restrict__ logits) {
-    __shared__ float wts[DynLayout<C>::P];
-    __shared__ float ytile[(kYR + 2) * (kYC + 2)];
+// F = the up-sampling factor as a compile-time constant (0: read a.factor; every index division is then a
+// real integer division, ~40 instructions each)
+template <int F> __device__ __forceinline__ int factor_of(const DynArgs& a) { return F ? F : a.factor; }
+
+// source row/column and fraction of output index R (aligned_bilinear :146-167):
+// z[R] = I[max(R - f/2, 0)], I[i] = sample of (y padded by one replicated row) at i/f
+__device__ __forceinline__ void upsample_src(int R, int f, int n_in, int& i0, int& i1, float& fr) {
+    const int ii = max(R - f / 2, 0);
+    i0 = ii / f;
+    fr = (float)(ii - i0 * f) / (float)f;
+    i1 = min(i0 + 1, n_in - 1);                             // replicate pad (:156)
+}
+
+template <int C, bool REL, int F>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void dyn_fwd_kernel(DynArgs a, const float* __restrict__ params, float* __restrict__ logits) {
+    using D = Dyn<C, REL>;
+    constexpr int kHalo = (kYR + 2) * (kYC + 2);
+    __shared__ float ytile[kHalo];
     const int tiles_x = (a.W + kYC - 1) / kYC, tiles_y = (a.H + kYR - 1) / kYR;
     int t = blockIdx.x;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int n = t / tiles_y;
     const int tid = threadIdx.x;
-    const int P = a.rel ? DynLayout<C>::P : DynLayout<C>::P - 2 * kDC;
-    for (int i = tid; i < P; i += 256) wts[i] = a.params[(int64_t)n * P + i];
+    BXI_T(3, blockIdx.x, 0);
+    // the instance's 233 parameters are wave-uniform: scalar loads, SGPR operands of the FMAs (no LDS, no VGPRs)
+    const float* __restrict__ wts = params + (int64_t)n * D::P;
     const int b = (int)a.img[n];
-    const float cx = a.coors[2 * n], cy = a.coors[2 * n + 1];
-    const float soi = a.soi[a.level[n]];
-    __syncthreads();
-    // y on the tile plus one pixel of halo on every side (rows r0-1 .. r0+kYR)
+    // y on the tile plus one pixel of halo on every side (rows r0-1 .. r0+kYR): 340 pixels on 256 threads.
+    // Both pixels of a thread are loaded (clamped coordinates, no branch) before either is evaluated.
     const int r0 = ty * kYR, c0 = tx * kYC;
-    for (int i = tid; i < (kYR + 2) * (kYC + 2); i += 256) {
-        const int r = r0 - 1 + i / (kYC + 2), c = c0 - 1 + i % (kYC + 2);
-        float y = 0.f;
-        if (r >= 0 && r < a.H && c >= 0 && c < a.W) {
-            float in[C + 2], h1[kDC], h2[kDC];
-            // the reference divides: rel_coors / soi (:1153)
-            load_inputs<C>(a, n, b, r, c, cx, cy, 1.f, in);
-            in[0] = in[0] / soi; in[1] = in[1] / soi;
-            y = mlp_forward<C>(wts, in, a.rel, h1, h2);
-        }
-        ytile[i] = y;
+    // thread t evaluates pixels 2t and 2t+1 of the halo tile (170 threads: waves 0-2), one code path
+    const int eA = 2 * tid, eB = 2 * tid + 1;
+    const int rA = r0 - 1 + eA / (kYC + 2), cA = c0 - 1 + eA % (kYC + 2);
+    const int rB = r0 - 1 + eB / (kYC + 2), cB = c0 - 1 + eB % (kYC + 2);
+    const bool vA = eA < kHalo && rA >= 0 && rA < a.H && cA >= 0 && cA < a.W;
+    const bool vB = eB < kHalo && rB >= 0 && rB < a.H && cB >= 0 && cB < a.W;
+    if (eA < kHalo) {
+        float inA[D::CIN], inB[D::CIN], yA, yB;
+        load_inputs<C, REL>(a, n, b, min(max(rA, 0), a.H - 1), min(max(cA, 0), a.W - 1), inA);
+        load_inputs<C, REL>(a, n, b, min(max(rB, 0), a.H - 1), min(max(cB, 0), a.W - 1), inB);
+        BXI_T(3, blockIdx.x, 1);
+        mlp_forward2<C, REL>(wts, inA, inB, yA, yB);
+        ytile[eA] = vA ? yA : 0.f;
+        if (eB < kHalo) ytile[eB] = vB ? yB : 0.f;
     }
     __syncthreads();
-    // aligned_bilinear (:146-167): z[R][Cc] = I[max(R - f/2, 0)][max(Cc - f/2, 0)],
-    // I[i][j] = bilinear sample of (y padded by one replicated row/column) at (i/f, j/f)
-    const int f = a.factor, OH = a.H * f, OW = a.W * f, half = f / 2;
+    BXI_T(3, blockIdx.x, 2);
+    const int f = factor_of<F>(a), OH = a.H * f, OW = a.W * f;
+    constexpr int VW = F == 0 ? 1 : (F % 4 == 0 ? 4 : (F % 2 == 0 ? 2 : 1));   // outputs per store
     const int R0 = r0 * f, C0 = c0 * f;
+    const int row_w = kYC * f / VW;                          // stores per output row of the tile
     float* out = logits + (int64_t)n * OH * OW;
-    for (int i = tid; i < kYR * f * kYC * f; i += 256) {
-        const int R = R0 + i / (kYC * f), Cc = C0 + i % (kYC * f);
+    auto Y = [&](int r, int c) { return ytile[(r - r0 + 1) * (kYC + 2) + (c - c0 + 1)]; };
+    for (int i = tid; i < kYR * f * row_w; i += 256) {
+        const int R = R0 + i / row_w, Cc = C0 + (i % row_w) * VW;
         if (R >= OH || Cc >= OW) continue;
-        const int ii = max(R - half, 0), jj = max(Cc - half, 0);
-        const int yi = ii / f, xj = jj / f;
-        const float fy = (float)(ii % f) / (float)f, fx = (float)(jj % f) / (float)f;
-        const int yi1 = min(yi + 1, a.H - 1), xj1 = min(xj + 1, a.W - 1);   // replicate pad (:156)
-        auto Y = [&](int r, int c) { return ytile[(r - r0 + 1) * (kYC + 2) + (c - c0 + 1)]; };
-        const float top = (1.f - fx) * Y(yi, xj) + fx * Y(yi, xj1);
-        const float bot = (1.f - fx) * Y(yi1, xj) + fx * Y(yi1, xj1);
-        out[(int64_t)R * OW + Cc] = (1.f - fy) * top + fy * bot;
+        int y0, y1; float fy;
+        upsample_src(R, f, a.H, y0, y1, fy);
+        float v[VW];
+#pragma unroll
+        for (int k = 0; k < VW; ++k) {
+            int x0, x1; float fx;
+            upsample_src(Cc + k, f, a.W, x0, x1, fx);
+            const float top = (1.f - fx) * Y(y0, x0) + fx * Y(y0, x1);
+            const float bot = (1.f - fx) * Y(y1, x0) + fx * Y(y1, x1);
+            v[k] = (1.f - fy) * top + fy * bot;
+        }
+        float* o = out + (int64_t)R * OW + Cc;
+        if constexpr (VW == 4) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        else if constexpr (VW == 2) *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
+        else o[0] = v[0];
     }
+    BXI_T(3, blockIdx.x, 3);
 }
 
 // ---- backward --------------------------------------------------------------------------------------
-// d y[r][c] = sum over the output pixels that sampled y[r][c], with their interpolation weights
-__device__ __forceinline__ float upsample_weight(int Rout, int r, int f, int Hin) {
-    const int ii = max(Rout - f / 2, 0);
-    const int yi = ii / f;
-    const float fy = (float)(ii % f) / (float)f;
-    float wgt = 0.f;
-    if (yi == r) wgt += 1.f - fy;
-    if (min(yi + 1, Hin - 1) == r) wgt += fy;
-    return wgt;
+// weight of output index R on source index r (transposed aligned_bilinear)
+__device__ __forceinline__ float upsample_weight(int R, int r, int f, int n_in) {
+    int i0, i1; float fr;
+    upsample_src(R, f, n_in, i0, i1, fr);
+    return (i0 == r ? 1.f - fr : 0.f) + (i1 == r ? fr : 0.f);
 }
 
-template <int C>
-__global__ __launch_bounds__(256) void dyn_bwd_kernel(DynArgs a, const float* __restrict__ g_logits,
-                                                      float* __restrict__ feat_part /*[kSlots,B,C,H,W]*/,
-                                                      float* __restrict__ param_part /*[N,T,P]*/) {
+// d y[r][c] = sum over the output pixels that sampled y[r][c].  The non-zero taps of source index r are
+// R in [f r - f + 1 + f/2, f r + f - 1 + f/2] (2f-1 of them), or [0, f - 1 + f/2] for r = 0 (the clamp
+// at :159-160 folds the first f/2 outputs onto source 0): a (2F-1)^2 window, loaded without branches.
+template <int F>
+__device__ __forceinline__ float gather_dy(const float* __restrict__ gz, int r, int c, int f, int H, int W) {
+    const int OH = H * f, OW = W * f, half = f / 2;
+    const int Rs = r == 0 ? 0 : f * r - f + 1 + half, Cs = c == 0 ? 0 : f * c - f + 1 + half;
+    float dout = 0.f;
+    if constexpr (F > 0) {
+        constexpr int NT = 2 * F - 1;
+        float wy[NT], wx[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            wy[k] = Rs + k < OH ? upsample_weight(Rs + k, r, F, H) : 0.f;
+            wx[k] = Cs + k < OW ? upsample_weight(Cs + k, c, F, W) : 0.f;
+        }
+        float g[NT][NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) g[i][j] = gz[(int64_t)min(Rs + i, OH - 1) * OW + min(Cs + j, OW - 1)];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) dout += wy[i] * wx[j] * g[i][j];
+    } else {
+        const int Rb = min(f * (r + 1) + half, OH), Cb = min(f * (c + 1) + half, OW);
+        for (int R = Rs; R < Rb; ++R) {
+            const float wy = upsample_weight(R, r, f, H);
+            for (int Cc = Cs; Cc < Cb; ++Cc) dout += wy * upsample_weight(Cc, c, f, W) * gz[(int64_t)R * OW + Cc];
+        }
+    }
+    return dout;
+}
+
+// sum over the 16 lanes of a DPP row; every lane gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));   // row_mirror
+    return v;
+}
+
+template <int C, bool REL, int F>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8)))
+void dyn_bwd_kernel(DynArgs a, const float* __restrict__ params, const float* __restrict__ params_again,
+                    const float* __restrict__ g_logits, float* __restrict__ feat_part /*[kSlots,B,C,H,W]*/,
+                    float* __restrict__ param_part /*[N,T,P]*/) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int CIN = C + 2;
-    constexpr int NROW = 1 + kDC + kDC + kDC + kDC + CIN;   // dout, dh2, dh1, h2, h1, in
-    float* rows = lds;                                      // [NROW][kRowPad]
-    float* wts = lds + NROW * kRowPad;                      // [P]
-    __shared__ int imgs[1024];
+    using D = Dyn<C, REL>;
+    constexpr int CIN = D::CIN;
+    constexpr int NROW = 1 + kDC + kDC + kDC + kDC + CIN;   // dout, dh2, dh1, h2, h1, in ; then a row of ones, a row of zeros
+    constexpr int kOnes = NROW, kZeros = NROW + 1;
+    constexpr int kChunkN = 1024;                           // instance ids scanned per pass
+    float* rows = lds;                                      // [NROW + 2][kRowPad]
+    __shared__ int mine[kChunkN / kSlots + 2];              // this workgroup's instances of the current chunk
+    __shared__ int n_mine;
     const int tiles_x = (a.W + kYC - 1) / kYC, tiles_y = (a.H + kYR - 1) / kYR, T = tiles_x * tiles_y;
     int t = blockIdx.x;
     const int slot = t % kSlots; t /= kSlots;
@@ -173,116 +292,252 @@ __global__ __launch_bounds__(256) void dyn_bwd_kernel(DynArgs a, const float* __
     const int lr = tid / kYC, lc = tid % kYC;
     const int r = ty * kYR + lr, c = tx * kYC + lc;
     const bool valid = r < a.H && c < a.W;
-    const int f = a.factor, OH = a.H * f, OW = a.W * f;
-    const int P = a.rel ? DynLayout<C>::P : DynLayout<C>::P - 2 * kDC;
-    const int cin = a.rel ? CIN : C, off = a.rel ? 0 : 2;
-    const int w1 = cin * kDC, w2 = w1 + kDC * kDC;
+    const int rr = min(r, a.H - 1), cc = min(c, a.W - 1);   // clamped: loads need no branch
+    const int f = factor_of<F>(a), OH = a.H * f, OW = a.W * f;
+    constexpr int P = D::P, cin = CIN, off = REL ? 2 : 0, w1 = D::W1, w2 = D::W2;
     const int64_t HW = (int64_t)a.H * a.W;
+    BXI_T(4, blockIdx.x, 0);
+    rows[kOnes * kRowPad + tid] = 1.f;                      // operands of the bias gradients / of the padded block rows
+    rows[kZeros * kRowPad + tid] = 0.f;
 
-    float dfeat[C];
+    // the features of this thread's pixel are the same for every instance: loaded once (uniform base + 32-bit
+    // lane offset, so that the addresses cost one VGPR, not two per channel)
+    float xf[C];
+    {
+        const float* fb = a.feat + (int64_t)b * C * HW;
+        const unsigned po = (unsigned)(rr * a.W + cc);
 #pragma unroll
-    for (int k = 0; k < C; ++k) dfeat[k] = 0.f;
-
-    int seen = 0;   // instances of image b met so far (uniform)
-    for (int nb = 0; nb < a.N; nb += 1024) {
-        __syncthreads();
-        for (int i = tid; i < min(1024, a.N - nb); i += 256) imgs[i] = (int)a.img[nb + i];
-        __syncthreads();
-        for (int k = 0; k < min(1024, a.N - nb); ++k) {
-            if (imgs[k] != b) continue;                      // uniform
-            const bool mine = (seen % kSlots) == slot;
-            ++seen;
-            if (!mine) continue;
-            const int n = nb + k;
-            // ---- phase 1: thread = pixel --------------------------------------------------------------
-            for (int i = tid; i < P; i += 256) wts[i] = a.params[(int64_t)n * P + i];
-            __syncthreads();
-            float in[CIN], h1[kDC], h2[kDC], dh2[kDC], dh1[kDC], dout = 0.f;
+        for (int k = 0; k < C; ++k) xf[k] = (fb + (int64_t)k * HW)[po];
+    }
+    // taps of the transposed up-sampling (gather_dy), fixed per thread when the window is small enough to keep
+    constexpr bool kKeepTaps = F == 1 || F == 2;
+    constexpr int NT = kKeepTaps ? 2 * F - 1 : 1;
+    unsigned goff[NT * NT];
+    float gw[NT * NT], g[NT * NT];
+    if constexpr (kKeepTaps) {
+        const int half = F / 2;
+        const int Rs = rr == 0 ? 0 : F * rr - F + 1 + half, Cs = cc == 0 ? 0 : F * cc - F + 1 + half;
 #pragma unroll
-            for (int i = 0; i < CIN; ++i) in[i] = 0.f;
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int i = 0; i < kDC; ++i) { h1[i] = h2[i] = dh1[i] = dh2[i] = 0.f; }
-            if (valid) {
-                const float soi = a.soi[a.level[n]];
-                load_inputs<C>(a, n, b, r, c, a.coors[2 * n], a.coors[2 * n + 1], 1.f, in);
-                in[0] = in[0] / soi; in[1] = in[1] / soi;
-                (void)mlp_forward<C>(wts, in, a.rel, h1, h2);
-                // transposed aligned_bilinear: candidates are the output rows/cols around f*r, f*c
-                const float* gz = g_logits + (int64_t)n * OH * OW;
-                const int Ra = max(f * (r - 1) + f / 2, 0), Rb = min(f * (r + 1) + f / 2, OH);
-                const int Ca = max(f * (c - 1) + f / 2, 0), Cb = min(f * (c + 1) + f / 2, OW);
-                const int Ra0 = r == 0 ? 0 : Ra, Ca0 = c == 0 ? 0 : Ca;   // rows/cols clamped to source index 0
-                for (int R = Ra0; R < Rb; ++R) {
-                    const float wy = upsample_weight(R, r, f, a.H);
-                    if (wy == 0.f) continue;
-                    for (int Cc = Ca0; Cc < Cb; ++Cc) {
-                        const float wx = upsample_weight(Cc, c, f, a.W);
-                        if (wx != 0.f) dout += wy * wx * gz[(int64_t)R * OW + Cc];
-                    }
-                }
-                // MLP backward
-#pragma unroll
-                for (int i = 0; i < kDC; ++i) dh2[i] = h2[i] > 0.f ? dout * wts[w2 + i] : 0.f;
-#pragma unroll
-                for (int i = 0; i < kDC; ++i) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int o = 0; o < kDC; ++o) acc += dh2[o] * wts[w1 + o * kDC + i];
-                    dh1[i] = h1[i] > 0.f ? acc : 0.f;
-                }
-#pragma unroll
-                for (int kk = 0; kk < C; ++kk) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int o = 0; o < kDC; ++o) acc += dh1[o] * wts[o * cin + (kk + 2 - off)];
-                    dfeat[kk] += acc;
-                }
+            for (int jx = 0; jx < NT; ++jx) {
+                const float wy = Rs + i < OH ? upsample_weight(Rs + i, rr, F, a.H) : 0.f;
+                const float wx = Cs + jx < OW ? upsample_weight(Cs + jx, cc, F, a.W) : 0.f;
+                gw[i * NT + jx] = wy * wx;
+                goff[i * NT + jx] = (unsigned)(min(Rs + i, OH - 1) * OW + min(Cs + jx, OW - 1));
             }
-            // stage the operand rows (zeros for pixels outside the map)
+    }
+    auto load_taps = [&](int n) {
+        const float* gz = g_logits + (int64_t)n * OH * OW;
+#pragma unroll
+        for (int q = 0; q < NT * NT; ++q) g[q] = gz[goff[q]];
+    };
+
+    v2f dfeat[C / 2];
+#pragma unroll
+    for (int k = 0; k < C / 2; ++k) dfeat[k] = v2f{0.f, 0.f};
+
+    // ---- phase-2 role of this thread (fixed for the whole kernel) ------------------------------------------
+    // rows: 0 dout | 1.. dh2 | 9.. dh1 | 17.. h2 | 25.. h1 | 33.. in.   Output families, each against (X, ones):
+    //   0: dh1[4 og ..] x (in, 1)  -> dW0, db0      NG0 column groups of 5
+    //   1: dh2[4 og ..] x (h1, 1)  -> dW1, db1      2 column groups
+    //   2: dout         x (h2, 1)  -> dW2, db2      2 column groups
+    constexpr int NG0 = (CIN + 1 + 4) / 5, NB = 2 * NG0 + 4 + 2;
+    static_assert(NB * 16 <= 256, "phase-2 blocks must fit the workgroup");
+    const int blk = tid >> 4, sl = tid & 15;
+    int aoff[4], boff[5];        // LDS offsets (floats) of this thread's operand rows at pixel 4*sl
+    int q_st[2];                 // this lane's two outputs: index into the instance's P gradients, -1 = none
+    {
+        int fam, og, ig, xrow, arow0, ncol, qbase, qsx, qbias;
+        if (blk < 2 * NG0) { fam = 0; og = blk / NG0; ig = blk % NG0; ncol = CIN; xrow = 1 + 4 * kDC; arow0 = 1 + kDC + 4 * og; }
+        else if (blk < 2 * NG0 + 4) { fam = 1; og = (blk - 2 * NG0) / 2; ig = (blk - 2 * NG0) % 2; ncol = kDC; xrow = 1 + 3 * kDC; arow0 = 1 + 4 * og; }
+        else { fam = 2; og = 0; ig = (blk - 2 * NG0 - 4) % 2; ncol = kDC; xrow = 1 + 2 * kDC; arow0 = 0; }
+        const int ycol0 = 5 * ig;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) aoff[x] = (fam == 2 ? (x == 0 ? 0 : kZeros) : arow0 + x) * kRowPad + 4 * sl;
+#pragma unroll
+        for (int y = 0; y < 5; ++y) {
+            const int i = ycol0 + y;
+            boff[y] = (i < ncol ? xrow + i : (i == ncol ? kOnes : kZeros)) * kRowPad + 4 * sl;
+        }
+        qbase = fam == 0 ? (4 * og) * cin : fam == 1 ? w1 + (4 * og) * kDC : w2;
+        qsx = fam == 0 ? cin : fam == 1 ? kDC : 0;
+        qbias = fam == 0 ? D::B0 + 4 * og : fam == 1 ? D::B1 + 4 * og : D::B2;
+        // after the row reduction every lane holds the 20 totals; lane sl stores elements sl and 16 + sl
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+            const int e = sl + 16 * e2, x = e / 5, y = e % 5, i = ycol0 + y;
+            const bool rowok = fam == 2 ? x == 0 : true;
+            int q = -1;
+            if (e < 20 && rowok && blk < NB) {
+                if (i < ncol) q = qbase + x * qsx + i;
+                else if (i == ncol) q = qbias + (fam == 2 ? 0 : x);
+            }
+            q_st[e2] = q;
+        }
+    }
+
+    int seen = 0;   // instances of image b in the chunks already scanned
+    bool first = true;
+    for (int nb = 0; nb < a.N; nb += kChunkN) {
+        // ---- the instances of image b in this chunk, every kSlots-th of them is this workgroup's (wave 0) ------
+        const int cnt = min(kChunkN, a.N - nb);
+        __syncthreads();
+        if (tid < kWave) {
+            int s0 = seen, mine0 = (seen + kSlots - 1 - slot) / kSlots, nm = 0;
+            for (int base = 0; base < cnt; base += kWave) {
+                const int k = base + tid;
+                const bool hit = k < cnt && (int)a.img[nb + k] == b;
+                const unsigned long long m = __ballot(hit);
+                const int ord = s0 + __popcll(m & ((1ull << tid) - 1ull));     // ordinal among image b's instances
+                if (hit && ord % kSlots == slot) mine[ord / kSlots - mine0] = k;
+                const int tot = __popcll(m);
+                nm = (s0 + tot + kSlots - 1 - slot) / kSlots - mine0;
+                s0 += tot;
+            }
+            if (tid == 0) n_mine = nm;
+            seen = s0;
+        }
+        __syncthreads();
+        seen = __shfl(seen, 0, kWave);   // only wave 0 counted; the other waves do not use `seen` (kept uniform anyway)
+        const int M = n_mine;
+        if (M > 0 && kKeepTaps) load_taps(nb + __builtin_amdgcn_readfirstlane(mine[0]));
+        for (int m = 0; m < M; ++m) {
+            const int n = nb + __builtin_amdgcn_readfirstlane(mine[m]);
+            // ---- phase 1: thread = pixel ------------------------------------------------------------------
+            const float* __restrict__ wts = params + (int64_t)n * P;     // uniform: scalar loads
+            v2f in2[CIN / 2], h1[kDC / 2], h2[kDC / 2], dh2[kDC / 2], dh1[kDC / 2];
+            float dout = 0.f;
+            if constexpr (REL) {
+                const float soi = a.soi[a.level[n]];
+                in2[0] = v2f{(a.coors[2 * n] - (float)(cc * a.in_stride + a.in_stride / 2)) / soi,
+                             (a.coors[2 * n + 1] - (float)(rr * a.in_stride + a.in_stride / 2)) / soi};
+            }
+#pragma unroll
+            for (int k = 0; k < C / 2; ++k) in2[off / 2 + k] = v2f{xf[2 * k], xf[2 * k + 1]};
+            if constexpr (kKeepTaps) {
+#pragma unroll
+                for (int q = 0; q < NT * NT; ++q) dout += gw[q] * g[q];
+            } else {
+                dout = gather_dy<F>(g_logits + (int64_t)n * OH * OW, rr, cc, f, a.H, a.W);
+            }
+            if (first) BXI_T(4, blockIdx.x, 1);
+            (void)mlp_forward<C, REL>(wts, in2, h1, h2);
+            if (!valid) {                                    // pixels outside the map stage zeros
+                dout = 0.f;
+#pragma unroll
+                for (int i = 0; i < CIN / 2; ++i) in2[i] = v2f{0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < kDC / 2; ++i) h1[i] = h2[i] = v2f{0.f, 0.f};
+            }
+            // MLP backward.  `params_again` is the same array under a second name, so that the weights are
+            // loaded again (scalar cache hits) rather than kept, and spilled, from the forward pass.
+            const float* __restrict__ wts_b = params_again + (int64_t)n * P;
+            const v2f dout2 = {dout, dout};
+#pragma unroll
+            for (int i = 0; i < kDC / 2; ++i) {
+                const v2f d = dout2 * w2_at(wts_b, w2 + 2 * i);
+                dh2[i] = v2f{h2[i].x > 0.f ? d.x : 0.f, h2[i].y > 0.f ? d.y : 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < kDC / 2; ++i) dh1[i] = v2f{0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < kDC; ++o) {                  // o outermost: the weights are consumed in address order
+                const float so = (o & 1) ? dh2[o / 2].y : dh2[o / 2].x;
+                const v2f bo = {so, so};
+#pragma unroll
+                for (int i = 0; i < kDC / 2; ++i) dh1[i] = pk_fma(bo, w2_at(wts_b, w1 + o * kDC + 2 * i), dh1[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < kDC / 2; ++i) dh1[i] = v2f{h1[i].x > 0.f ? dh1[i].x : 0.f, h1[i].y > 0.f ? dh1[i].y : 0.f};
+#pragma unroll
+            for (int o = 0; o < kDC; ++o) {
+                if (o % 4 == 0) {
+                    // pin the accumulators here: otherwise the FMAs are sunk below the fences, away from their loads
+#pragma unroll
+                    for (int kk = 0; kk < C / 2; ++kk) asm volatile("" : "+v"(dfeat[kk]));
+                    BXI_SEGMENT();
+                }
+                const float so = (o & 1) ? dh1[o / 2].y : dh1[o / 2].x;
+                const v2f bo = {so, so};
+#pragma unroll
+                for (int kk = 0; kk < C / 2; ++kk) dfeat[kk] = pk_fma(bo, w2_at(wts_b, o * cin + off + 2 * kk), dfeat[kk]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < C / 2; ++kk) asm volatile("" : "+v"(dfeat[kk]));
+            BXI_SEGMENT();
+            // stage the operand rows
             rows[0 * kRowPad + tid] = dout;
 #pragma unroll
             for (int i = 0; i < kDC; ++i) {
-                rows[(1 + i) * kRowPad + tid] = dh2[i];
-                rows[(1 + kDC + i) * kRowPad + tid] = dh1[i];
-                rows[(1 + 2 * kDC + i) * kRowPad + tid] = h2[i];
-                rows[(1 + 3 * kDC + i) * kRowPad + tid] = h1[i];
+                rows[(1 + i) * kRowPad + tid] = (i & 1) ? dh2[i / 2].y : dh2[i / 2].x;
+                rows[(1 + kDC + i) * kRowPad + tid] = (i & 1) ? dh1[i / 2].y : dh1[i / 2].x;
+                rows[(1 + 2 * kDC + i) * kRowPad + tid] = (i & 1) ? h2[i / 2].y : h2[i / 2].x;
+                rows[(1 + 3 * kDC + i) * kRowPad + tid] = (i & 1) ? h1[i / 2].y : h1[i / 2].x;
             }
 #pragma unroll
-            for (int i = 0; i < CIN; ++i) rows[(1 + 4 * kDC + i) * kRowPad + tid] = in[i];
-            __syncthreads();
-            // ---- phase 2: thread = parameter q: a dot product of two staged rows (or a row sum) -----------
-            if (tid < P) {
-                int ra, rb = -1;     // rb < 0: bias -> plain row sum
-                const int q = tid;
-                if (q < w1) { ra = 1 + kDC + q / cin; rb = 1 + 4 * kDC + (q % cin) + off; }                 // dW0[o][i] = dh1[o] . in[i]
-                else if (q < w2) { ra = 1 + (q - w1) / kDC; rb = 1 + 3 * kDC + (q - w1) % kDC; }         // dW1[o][i] = dh2[o] . h1[i]
-                else if (q < w2 + kDC) { ra = 0; rb = 1 + 2 * kDC + (q - w2); }                            // dW2[i]    = dout . h2[i]
-                else if (q < w2 + 2 * kDC) ra = 1 + kDC + (q - w2 - kDC);                                   // db0[o] = sum dh1[o]
-                else if (q < w2 + 3 * kDC) ra = 1 + (q - w2 - 2 * kDC);                                     // db1[o] = sum dh2[o]
-                else ra = 0;                                                                                // db2 = sum dout
-                const float4* A = reinterpret_cast<const float4*>(rows + ra * kRowPad);
-                float acc = 0.f;
-                if (rb >= 0) {
-                    const float4* Bv = reinterpret_cast<const float4*>(rows + rb * kRowPad);
-#pragma unroll 8
-                    for (int j = 0; j < kYR * kYC / 4; ++j) {
-                        const float4 x = A[j], y = Bv[j];
-                        acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-                    }
-                } else {
-#pragma unroll 8
-                    for (int j = 0; j < kYR * kYC / 4; ++j) { const float4 x = A[j]; acc += (x.x + x.y) + (x.z + x.w); }
+            for (int i = 0; i < CIN; ++i) rows[(1 + 4 * kDC + i) * kRowPad + tid] = (i & 1) ? in2[i / 2].y : in2[i / 2].x;
+            // the next instance's taps travel while phase 2 runs (lds_barrier does not wait for them)
+            if (kKeepTaps && m + 1 < M) load_taps(nb + __builtin_amdgcn_readfirstlane(mine[m + 1]));
+            lds_barrier();
+            if (first) BXI_T(4, blockIdx.x, 2);
+            // ---- phase 2: the parameter gradients, dW = dH^T X over the 256 staged pixels -------------------
+            // Thread (blk, s): a 4x5 block of outputs over the pixels {4 (16 j + s) .. +3, j < 4}: 9 operand
+            // float4 per 80 FMAs (a thread-per-parameter dot product needs 2 per 4, and the LDS pipe then
+            // costs 4x the FMAs).  The 16 slices of a block are the 16 lanes of a DPP row.
+            if (blk < NB) {
+                v2f acc2[4][5];
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 5; ++y) acc2[x][y] = v2f{0.f, 0.f};
+#pragma unroll 2
+                for (int jj = 0; jj < kYR * kYC / 64; ++jj) {
+                    float4 av[4], bv[5];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) av[x] = *reinterpret_cast<const float4*>(rows + aoff[x] + jj * 64);
+#pragma unroll
+                    for (int y = 0; y < 5; ++y) bv[y] = *reinterpret_cast<const float4*>(rows + boff[y] + jj * 64);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+#pragma unroll
+                        for (int y = 0; y < 5; ++y) {
+                            acc2[x][y] = pk_fma(v2f{av[x].x, av[x].y}, v2f{bv[y].x, bv[y].y}, acc2[x][y]);
+                            acc2[x][y] = pk_fma(v2f{av[x].z, av[x].w}, v2f{bv[y].z, bv[y].w}, acc2[x][y]);
+                        }
                 }
-                param_part[((int64_t)n * T + tile) * P + q] = acc;
+                float acc[4][5];
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 5; ++y) acc[x][y] = row16_sum(acc2[x][y].x + acc2[x][y].y);
+                // lane sl keeps totals sl and 16 + sl: two binary select trees instead of 20 branchy stores from lane 0
+                float* dst = param_part + ((int64_t)n * T + tile) * P;
+                const float* flat = &acc[0][0];
+                float lo8[8], lo4[4], lo2[2];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) lo8[i] = (sl & 1) ? flat[2 * i + 1] : flat[2 * i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lo4[i] = (sl & 2) ? lo8[2 * i + 1] : lo8[2 * i];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) lo2[i] = (sl & 4) ? lo4[2 * i + 1] : lo4[2 * i];
+                const float v0 = (sl & 8) ? lo2[1] : lo2[0];
+                const float h2a = (sl & 1) ? flat[17] : flat[16], h2b = (sl & 1) ? flat[19] : flat[18];
+                const float v1 = (sl & 2) ? h2b : h2a;
+                if (q_st[0] >= 0) dst[q_st[0]] = v0;
+                if (q_st[1] >= 0) dst[q_st[1]] = v1;
             }
-            __syncthreads();
+            lds_barrier();
+            if (first) BXI_T(4, blockIdx.x, 3);
+            first = false;
         }
     }
     if (valid) {
         float* o = feat_part + (((int64_t)slot * a.B + b) * C) * HW + (int64_t)r * a.W + c;
 #pragma unroll
-        for (int k = 0; k < C; ++k) o[k * HW] = dfeat[k];
+        for (int k = 0; k < C; ++k) o[k * HW] = (k & 1) ? dfeat[k / 2].y : dfeat[k / 2].x;
     }
+    BXI_T(4, blockIdx.x, 4);
 }
 
 __global__ __launch_bounds__(256) void dyn_reduce_kernel(const float* __restrict__ feat_part, int64_t feat_elems,
@@ -290,16 +545,28 @@ __global__ __launch_bounds__(256) void dyn_reduce_kernel(const float* __restrict
                                                          int N, int T, int P, float* __restrict__ g_params) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < feat_elems) {
+        float v[kSlots];
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) v[s] = feat_part[s * feat_elems + i];
         float acc = 0.f;
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) acc += feat_part[s * feat_elems + i];
+        for (int s = 0; s < kSlots; ++s) acc += v[s];
         g_feat[i] = acc;
     }
     const int64_t j = i - ((feat_elems + 255) / 256) * 256;
     if (j >= 0 && j < (int64_t)N * P) {
         const int n = (int)(j / P), q = (int)(j % P);
+        const float* src = param_part + (int64_t)n * T * P + q;
         float acc = 0.f;
-        for (int t = 0; t < T; ++t) acc += param_part[((int64_t)n * T + t) * P + q];
+        int t = 0;
+        for (; t + 8 <= T; t += 8) {                         // 8 loads in flight, summed in tile order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(t + u) * P];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; t < T; ++t) acc += src[(int64_t)t * P];
         g_params[j] = acc;
     }
 }
@@ -321,6 +588,23 @@ static int fill_dyn(const float* feat, int B, int C, int H, int W, const float* 
 static inline int dyn_tiles(int H, int W) { return ((H + kYR - 1) / kYR) * ((W + kYC - 1) / kYC); }
 static inline int dyn_params(int C, int rel) { return (C + (rel ? 2 : 0)) * kDC + kDC * kDC + kDC + 2 * kDC + 1; }
 
+// the kernels are instantiated for C in {8,16} x rel x factor in {1,2,4,other}
+#define BXI_DYN_DISPATCH_F(KC_, KR_, F_, ...)                                   \
+    do {                                                                       \
+        constexpr int KC = KC_; constexpr bool KR = KR_;                       \
+        if ((F_) == 2) { constexpr int KF = 2; __VA_ARGS__; }                         \
+        else if ((F_) == 1) { constexpr int KF = 1; __VA_ARGS__; }                    \
+        else if ((F_) == 4) { constexpr int KF = 4; __VA_ARGS__; }                    \
+        else { constexpr int KF = 0; __VA_ARGS__; }                                   \
+    } while (0)
+#define BXI_DYN_DISPATCH(C_, REL_, F_, ...)                                    \
+    do {                                                                       \
+        if ((C_) == 16 && (REL_)) BXI_DYN_DISPATCH_F(16, true, F_, __VA_ARGS__);      \
+        else if ((C_) == 16) BXI_DYN_DISPATCH_F(16, false, F_, __VA_ARGS__);          \
+        else if ((REL_)) BXI_DYN_DISPATCH_F(8, true, F_, __VA_ARGS__);                \
+        else BXI_DYN_DISPATCH_F(8, false, F_, __VA_ARGS__);                           \
+    } while (0)
+
 }  // namespace bxi
 
 extern "C" {
@@ -337,8 +621,7 @@ int bxi_dynamic_mask_forward_f32(const float* feat, int B, int C, int H, int W, 
     if (!logits) return BXI_ERR_NULL_POINTER;
     hipStream_t s = bxi::as_stream(stream);
     const unsigned grid = (unsigned)(N * bxi::dyn_tiles(H, W));
-    if (C == 16) BXI_LAUNCH("dyn_fwd", s, (bxi::dyn_fwd_kernel<16>), dim3(grid), dim3(256), 0, s, a, logits);
-    else BXI_LAUNCH("dyn_fwd", s, (bxi::dyn_fwd_kernel<8>), dim3(grid), dim3(256), 0, s, a, logits);
+    BXI_DYN_DISPATCH(C, a.rel, factor, BXI_LAUNCH("dyn_fwd", s, (bxi::dyn_fwd_kernel<KC, KR, KF>), dim3(grid), dim3(256), 0, s, a, params, logits));
     return bxi::check_launch();
 }
 
@@ -366,16 +649,11 @@ int bxi_dynamic_mask_backward_f32(const float* feat, int B, int C, int H, int W,
     const int64_t feat_elems = (int64_t)B * C * H * W;
     float* feat_part = (float*)workspace;
     float* param_part = (float*)((char*)workspace + (sizeof(float) * (size_t)bxi::kSlots * feat_elems + 255) / 256 * 256);
-    const int cin = C + 2;
-    const size_t lds = sizeof(float) * ((size_t)(1 + 4 * bxi::kDC + cin) * bxi::kRowPad + bxi::dyn_params(C, 1));
+    const int cin = C + (a.rel ? 2 : 0);
+    const size_t lds = sizeof(float) * ((size_t)(1 + 4 * bxi::kDC + cin + 2) * bxi::kRowPad);
     const unsigned grid = (unsigned)(B * T * bxi::kSlots);
-    if (C == 16) {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bxi::dyn_bwd_kernel<16>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        BXI_LAUNCH("dyn_bwd", s, (bxi::dyn_bwd_kernel<16>), dim3(grid), dim3(256), lds, s, a, g_logits, feat_part, param_part);
-    } else {
-        BXI_LAUNCH("dyn_bwd", s, (bxi::dyn_bwd_kernel<8>), dim3(grid), dim3(256), lds, s, a, g_logits, feat_part, param_part);
-    }
+    BXI_DYN_DISPATCH(C, a.rel, factor, BXI_LAUNCH("dyn_bwd", s, (bxi::dyn_bwd_kernel<KC, KR, KF>), dim3(grid), dim3(256), lds, s, a, params, params, g_logits,
+                                          feat_part, param_part));
     rc = bxi::check_launch();
     if (rc != BXI_OK) return rc;
     const int64_t nb = (feat_elems + 255) / 256 + ((int64_t)N * P + 255) / 256;
@@ -383,5 +661,9 @@ int bxi_dynamic_mask_backward_f32(const float* feat, int B, int C, int H, int W,
                param_part, N, T, P, g_params);
     return bxi::check_launch();
 }
+
+#ifdef BXI_TRACE
+int bxi_debug_set_trace_dyn(long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(bxi::g_trace), &buf, sizeof(buf)); }
+#endif
 
 }  // extern "C"
