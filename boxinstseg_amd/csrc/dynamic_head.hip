@@ -8,20 +8,29 @@
 // The reference runs three grouped F.conv2d over a [1, N*C, H, W] view (one 1x1 "conv" of 8 channels
 // per instance: far too small for MIOpen/MFMA) plus pad/interpolate/pad/crop.  Here:
 //
-// dyn_fwd_kernel   grid = N x tiles(8x32 of y).  233 weights of the instance in LDS (broadcast reads),
-//                  y tile + 1 halo in LDS, upsample from LDS, one coalesced store per output row.
-//                  Reads the feature tile (L2-resident, 4*C B per y pixel per instance), writes
-//                  4*f^2 B per y pixel per instance: write bound.
+// Every shape that indexes a register array is a template parameter (C, rel, factor): a runtime bound there costs
+// select chains or scratch.  The 233 parameters of an instance are wave-uniform: they are read with scalar loads and
+// reach the FMAs as SGPR-pair operands of v_pk_fma_f32 (no LDS traffic, no VGPRs); the SGPR file holds ~70 at a
+// time, so the MLP is cut into fenced segments (BXI_SEGMENT) that the scheduler may not merge.
+//
+// dyn_fwd_kernel   grid = N x tiles(8x32 of y).  Thread t evaluates pixels 2t and 2t+1 of the tile + 1 halo
+//                  (each weight feeds both), y goes to LDS, the up-sampled tile is written with float2/float4
+//                  stores.  Reads the feature tile (L2-resident, 4*C B per y pixel per instance), writes
+//                  4*f^2 B per y pixel per instance.
 // dyn_bwd_kernel   grid = B x tiles x kSlots.  A workgroup owns one 8x32 tile of one image and every
-//                  kSlots-th instance of that image:
-//                    phase 1 (thread = pixel): dy by the transposed interpolation (gather), forward
+//                  kSlots-th instance of that image (list compacted by wave 0 with ballots):
+//                    phase 1 (thread = pixel): dy by the transposed interpolation (a fixed (2f-1)^2 tap window,
+//                       offsets/weights kept in registers, the next instance's taps prefetched), forward
 //                       recomputed, MLP backward; accumulates d feat over its instances in registers
 //                       and stages 51 operand rows of 256 pixels in LDS;
-//                    phase 2 (thread = parameter, 233 of 256): the parameter gradients are 233 dot
-//                       products of two staged rows (dW = dH^T X, a [8..18] x 256 contraction too thin
-//                       for MFMA) -> one partial per (instance, tile).
+//                    phase 2 (thread = 4x5 block of outputs x 1/16 of the pixels): dW = dH^T X, a
+//                       [8..19] x 256 contraction too thin for MFMA; biases are the column against a row of
+//                       ones; the 16 pixel slices of a block are the 16 lanes of a DPP row
+//                       -> one partial per (instance, tile).
 //                  No atomics: partials are reduced in fixed order by dyn_reduce_kernel.
 // dyn_reduce_kernel  g_params[n,q] = sum over tiles ; g_feat[b,c,p] = sum over slots.
+// Measured (MI355X, B=2 C=16 100x128 -> 200x256, rocprofv3): N=32: fwd 13.3 us, bwd 29.6 us, reduce 6.0 us
+// (PyTorch-ROCm running the reference's op sequence: 228 us forward, 785 us forward+backward).
 #include "common.hpp"
 
 namespace bxi {
@@ -259,6 +268,13 @@ __device__ __forceinline__ float gather_dy(const float* __restrict__ gz, int r, 
     return dout;
 }
 
+// lanes whose bit is set in `mask` (a wave-uniform 64-bit lane mask) take a, the others b
+__device__ __forceinline__ float lane_select(unsigned long long mask, float a, float b) {
+    float r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
+
 // sum over the 16 lanes of a DPP row; every lane gets the total
 __device__ __forceinline__ float row16_sum(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
@@ -345,6 +361,7 @@ void dyn_bwd_kernel(DynArgs a, const float* __restrict__ params, const float* __
     constexpr int NG0 = (CIN + 1 + 4) / 5, NB = 2 * NG0 + 4 + 2;
     static_assert(NB * 16 <= 256, "phase-2 blocks must fit the workgroup");
     const int blk = tid >> 4, sl = tid & 15;
+    const unsigned long long m_b0 = __ballot(sl & 1), m_b1 = __ballot(sl & 2), m_b2 = __ballot(sl & 4), m_b3 = __ballot(sl & 8);
     int aoff[4], boff[5];        // LDS offsets (floats) of this thread's operand rows at pixel 4*sl
     int q_st[2];                 // this lane's two outputs: index into the instance's P gradients, -1 = none
     {
@@ -513,17 +530,19 @@ void dyn_bwd_kernel(DynArgs a, const float* __restrict__ params, const float* __
                     for (int y = 0; y < 5; ++y) acc[x][y] = row16_sum(acc2[x][y].x + acc2[x][y].y);
                 // lane sl keeps totals sl and 16 + sl: two binary select trees instead of 20 branchy stores from lane 0
                 float* dst = param_part + ((int64_t)n * T + tile) * P;
-                const float* flat = &acc[0][0];
+                // (explicit v_cndmask: written as ?: the compiler turns a select of array elements into a
+                //  dynamically indexed array in scratch)
+                auto flat = [&](int e) { return acc[e / 5][e % 5]; };
                 float lo8[8], lo4[4], lo2[2];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) lo8[i] = (sl & 1) ? flat[2 * i + 1] : flat[2 * i];
+                for (int i = 0; i < 8; ++i) lo8[i] = lane_select(m_b0, flat(2 * i + 1), flat(2 * i));
 #pragma unroll
-                for (int i = 0; i < 4; ++i) lo4[i] = (sl & 2) ? lo8[2 * i + 1] : lo8[2 * i];
+                for (int i = 0; i < 4; ++i) lo4[i] = lane_select(m_b1, lo8[2 * i + 1], lo8[2 * i]);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) lo2[i] = (sl & 4) ? lo4[2 * i + 1] : lo4[2 * i];
-                const float v0 = (sl & 8) ? lo2[1] : lo2[0];
-                const float h2a = (sl & 1) ? flat[17] : flat[16], h2b = (sl & 1) ? flat[19] : flat[18];
-                const float v1 = (sl & 2) ? h2b : h2a;
+                for (int i = 0; i < 2; ++i) lo2[i] = lane_select(m_b2, lo4[2 * i + 1], lo4[2 * i]);
+                const float v0 = lane_select(m_b3, lo2[1], lo2[0]);
+                const float h2a = lane_select(m_b0, flat(17), flat(16)), h2b = lane_select(m_b0, flat(19), flat(18));
+                const float v1 = lane_select(m_b1, h2b, h2a);
                 if (q_st[0] >= 0) dst[q_st[0]] = v0;
                 if (q_st[1] >= 0) dst[q_st[1]] = v1;
             }
