@@ -501,6 +501,9 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const L
     }
     const unsigned long long rk0 = ws.rowkey[(int64_t)n * h + (tid < h ? tid : 0)];
     const InstBox ib = inst_from_rec(rec, dil, h, w);
+    // field by field: a whole-struct copy moves the three padding words through scratch, and a kernel that owns
+    // scratch pays for it at every wave launch
+    if (st.gcol && tid == 0) st.inst[n] = InstRec{rec.r0, rec.r1, rec.c0, rec.c1, rec.img, 0, 0, 0};
     float sums[4] = {0.f, 0.f, 0.f, 0.f};   // I_x, U_x, I_y, U_y
     for (int c = tid; c < w; c += 256) {
         float m = -INFINITY; int mr = 0;
@@ -549,7 +552,6 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const L
             const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
             st.grow[(int64_t)n * h + r] = invN * ((-2.f * TY * Uy + 4.f * Iy * Y) / (Uy * Uy)) * Y * (1.f - Y);
         }
-        if (tid == 0) st.inst[n] = rec;
     }
 }
 
