@@ -6,15 +6,18 @@ Public surface (mirrors the reference's for this path):
     pairwise_nlog_forward / _backward  <-> mmdet.ops.pairwise.pairwise_ext
     CondInstMaskHead                   <-> mmdet.models.dense_heads.CondInstMaskHead (loss path)
     boxinst_mask_loss, color_affinity, box_bitmasks : functional form of the same kernels
+    MeanField, dice_loss, mil_loss     <-> mmdet.models.dense_heads.discobox_head
 """
 from .pairwise import PairwiseNLog, pairwise_nlog, pairwise_nlog_backward, pairwise_nlog_forward
 from .functional import BoxInstMaskLoss, box_bitmasks, boxinst_mask_loss, color_affinity
 from .dynamic import DynamicMaskHead, dynamic_mask_forward
 from .mask_head import CondInstMaskHead
+from .discobox import MeanField, dice_loss, meanfield_forward, meanfield_kernel, mil_loss
 from .registry import HEADS, build_head
 from .config import load_config
 
 __all__ = ['pairwise_nlog', 'pairwise_nlog_forward', 'pairwise_nlog_backward', 'PairwiseNLog',
            'boxinst_mask_loss', 'BoxInstMaskLoss', 'dynamic_mask_forward', 'DynamicMaskHead', 'color_affinity', 'box_bitmasks',
-           'CondInstMaskHead', 'HEADS', 'build_head', 'load_config']
+           'CondInstMaskHead', 'HEADS', 'build_head', 'load_config',
+           'MeanField', 'meanfield_kernel', 'meanfield_forward', 'dice_loss', 'mil_loss']
 __version__ = '0.1.0'

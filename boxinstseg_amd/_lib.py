@@ -69,6 +69,18 @@ SIGNATURES = {
     'bxi_dynamic_mask_backward_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_size_t, c_void_p]),
+    'bxi_meanfield_kernel_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, C.c_float, C.c_float, C.c_float,
+                                         c_void_p, c_void_p]),
+    'bxi_meanfield_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'bxi_meanfield_forward_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                          c_int, C.c_float, c_void_p, C.c_float, c_void_p, c_void_p, c_void_p, c_size_t,
+                                          c_void_p]),
+    'bxi_dice_loss_forward_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, C.c_int64, c_void_p, c_void_p, c_void_p]),
+    'bxi_dice_loss_backward_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, C.c_int64, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
+    'bxi_mil_loss_state_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'bxi_mil_loss_forward_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'bxi_mil_loss_backward_f32': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 LAUNCH_HOOK = C.CFUNCTYPE(None, C.c_char_p, c_int, c_void_p, c_void_p)

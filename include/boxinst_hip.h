@@ -212,6 +212,49 @@ int bxi_dynamic_mask_backward_f32(const float* feat, int B, int C, int H, int W,
                                   int disable_rel_coors, const float* g_logits, float* g_feat, float* g_params,
                                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ===========================================================================================
+ * 5. DiscoBox pseudo-label path -- mmdet/models/dense_heads/discobox_head.py:
+ *    MeanField.__init__ (:591-613), MeanField.forward / simple_forward (:617-655),
+ *    dice_loss (:542-550), mil_loss (:552-562).
+ * ===========================================================================================*/
+
+/* MeanField.__init__: the Gaussian-bilateral neighbourhood kernel of B images.
+ * feat [B,C,H,W] (the resized, normalised image; C = 3 in the reference), ksize odd (3 or 5),
+ * kernel [B,ksize*ksize,H,W]:
+ *   kernel[b,k,p] = alpha0 * exp( sum_c -(F[c,q]-F[c,p])^2 / (2 theta0^2) - |delta_k|^2 / (2 theta1^2) ),
+ *   F = feat + 10 inside the map, 0 outside (nn.Unfold's zero padding of the shifted map, :597-598). */
+int bxi_meanfield_kernel_f32(const float* feat, int B, int C, int H, int W, int ksize, float alpha0, float theta0,
+                             float theta1, float* kernel, void* stream);
+
+/* MeanField.forward for N instances at once: `iters` mean-field updates under no_grad (one launch per update over
+ * all instances, plus one before and one after; nothing is synchronised).
+ * kernel [B,ksize^2,H,W] (above); x [N,H,W] f32; targets [N,H,W], f32 (targets_u8 = 0) or u8 (1), values 0/1;
+ * img_inds [N] i64 (kernel plane of every instance) or NULL (all image 0: one MeanField object);
+ * inter_img_mask [N,2,H,W] f32 or NULL (added times gamma, :647-648);
+ * ret [N,H,W] f32 in {0,1} (the reference's [N,1,H,W]); valid [N] f32 (5 % <= foreground <= 95 %, :634-636).
+ * workspace: bxi_meanfield_workspace_bytes(N,H,W) (one bit per pixel, three planes), 8-byte aligned. */
+size_t bxi_meanfield_workspace_bytes(int N, int H, int W);
+int bxi_meanfield_forward_f32(const float* kernel, int B, int H, int W, int ksize, const float* x, const void* targets,
+                              int targets_u8, const int64_t* img_inds, int N, int iters, float base,
+                              const float* inter_img_mask, float gamma, float* ret, float* valid, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
+/* dice_loss (:542-550) of N rows of L elements: loss[n] = 1 - 2 a / (b + c), a = sum i t, b = sum i^2 + 0.001,
+ * c = sum t^2 + 0.001.  target f32 (target_u8 = 0) or u8 (1).  sums [N,2] f32 receives (a, b + c) for the backward. */
+int bxi_dice_loss_forward_f32(const float* input, const void* target, int target_u8, int N, int64_t L, float* loss,
+                              float* sums, void* stream);
+/* g_input[n,:] = g_loss[n] * ( -2 t / (b+c) + 4 a i / (b+c)^2 ) */
+int bxi_dice_loss_backward_f32(const float* input, const void* target, int target_u8, int N, int64_t L,
+                               const float* sums, const float* g_loss, float* g_input, void* stream);
+
+/* mil_loss(dice_loss, input, _, target) (:552-562): row/column maxima of input and target [N,H,W], one dice term
+ * per axis.  loss [N].  state (bxi_mil_loss_state_bytes) keeps the arg-max positions and the unit gradients of the
+ * H + W maxima; the backward writes g_input [N,H,W] densely (zeros elsewhere), no atomics. */
+size_t bxi_mil_loss_state_bytes(int N, int H, int W);
+int bxi_mil_loss_forward_f32(const float* input, const void* target, int target_u8, int N, int H, int W, float* loss,
+                             void* state, void* stream);
+int bxi_mil_loss_backward_f32(int N, int H, int W, const void* state, const float* g_loss, float* g_input, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,3 +61,31 @@ def load(extra_globals: Optional[Dict] = None, functions: Iterable[str] = FUNCTI
     exec(compile(mod, path, 'exec'), env)
     names = list(functions) + ['CondInstMaskHead_' + m for m in methods]
     return types.SimpleNamespace(**{n: env[n] for n in names if n in env}, _env=env)
+
+
+DISCOBOX_FILE = 'mmdet/models/dense_heads/discobox_head.py'
+DISCOBOX_FUNCTIONS = ('dice_loss', 'mil_loss')
+DISCOBOX_CLASSES = ('MeanField',)
+
+
+def load_discobox(extra_globals: Optional[Dict] = None) -> types.SimpleNamespace:
+    """the reference's ``MeanField`` module (discobox_head.py:585-651) and its
+    ``dice_loss`` / ``mil_loss`` (:542-562), compiled in memory from the reference tree."""
+    import numpy as np
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    path = os.path.join(REFERENCE_ROOT, DISCOBOX_FILE)
+    with open(path) as fh:
+        tree = ast.parse(fh.read(), filename=path)
+    body = [n for n in tree.body
+            if (isinstance(n, ast.FunctionDef) and n.name in DISCOBOX_FUNCTIONS)
+            or (isinstance(n, ast.ClassDef) and n.name in DISCOBOX_CLASSES)]
+    mod = ast.Module(body=body, type_ignores=[])
+    ast.fix_missing_locations(mod)
+    env = {'torch': torch, 'nn': nn, 'F': F, 'np': np}
+    if extra_globals:
+        env.update(extra_globals)
+    exec(compile(mod, path, 'exec'), env)
+    return types.SimpleNamespace(**{n: env[n] for n in DISCOBOX_FUNCTIONS + DISCOBOX_CLASSES}, _env=env)

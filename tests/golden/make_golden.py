@@ -176,6 +176,43 @@ def main():
                     f'{name}_gparams': params.grad.numpy()})
     np.savez_compressed(os.path.join(HERE, 'dynamic_head_f64.npz'), **out)
 
+    # ---- DiscoBox MeanField / dice_loss / mil_loss, the reference's own class and functions --------
+    dns = rx.load_discobox()
+    out = {}
+    for name, (H, W, n, ks, iters, base, use_inter) in {'a': (24, 40, 4, 3, 10, 0.10, False),
+                                                        'b': (33, 70, 5, 3, 6, 0.45, True),
+                                                        'c': (20, 131, 3, 5, 4, 0.10, False)}.items():
+        yy, xx = np.mgrid[0:H, 0:W]
+        feat = np.stack([np.sin(xx / 7.0) + 0.3 * np.cos(yy / 5.0), np.cos(xx / 9.0 + yy / 11.0), 0.5 * np.sin(yy / 4.0)])
+        feat = (feat + 0.05 * rng.standard_normal(feat.shape)).astype(np.float32)
+        mf = dns.MeanField(torch.from_numpy(feat)[None], alpha0=2.0, theta0=0.5, theta1=30.0, theta2=20.0, iter=iters,
+                           kernel_size=ks, base=base)
+        x = torch.tensor(rng.uniform(0, 1, size=(n, 1, H, W)), dtype=torch.float32)
+        t = torch.zeros(n, 1, H, W)
+        for i in range(n):
+            r0, c0 = int(rng.integers(0, H // 2)), int(rng.integers(0, W // 2))
+            t[i, 0, r0:r0 + int(rng.integers(4, H // 2 + 1)), c0:c0 + int(rng.integers(4, W // 2 + 1))] = 1
+        t[n - 1] = 0                                   # an instance without target
+        inter = torch.tensor(rng.uniform(0, 30, size=(n, 2, H, W)), dtype=torch.float32) if use_inter else None
+        ret, valid = mf(x, t, inter)
+        out.update({f'{name}_feat': feat, f'{name}_kernel': mf.kernel[0, 0].reshape(ks * ks, H, W).numpy(),
+                    f'{name}_x': x[:, 0].numpy(), f'{name}_t': t[:, 0].numpy().astype(np.uint8),
+                    f'{name}_cfg': np.array([ks, iters, base, 2.0, 0.5, 30.0, mf.gamma]), f'{name}_ret': ret[:, 0].numpy(),
+                    f'{name}_valid': valid.numpy()})
+        if inter is not None:
+            out[f'{name}_inter'] = inter.numpy()
+        inp = torch.tensor(rng.uniform(0, 1, size=(n, H, W)), dtype=torch.float32, requires_grad=True)
+        l = dns.mil_loss(dns.dice_loss, inp, inp, t[:, 0].byte())
+        gl = torch.tensor(rng.uniform(0.5, 1.5, size=n), dtype=torch.float32)
+        (l * gl).sum().backward()
+        inp2 = torch.tensor(rng.uniform(0, 1, size=(n, H, W)), dtype=torch.float32, requires_grad=True)
+        d = dns.dice_loss(inp2 * t[:, 0], ret[:, 0])
+        (d * gl).sum().backward()
+        out.update({f'{name}_mil_in': inp.detach().numpy(), f'{name}_mil_loss': l.detach().numpy(), f'{name}_gl': gl.numpy(),
+                    f'{name}_mil_grad': inp.grad.numpy(), f'{name}_dice_in': inp2.detach().numpy(),
+                    f'{name}_dice_loss': d.detach().numpy(), f'{name}_dice_grad': inp2.grad.numpy()})
+    np.savez_compressed(os.path.join(HERE, 'discobox.npz'), **out)
+
     # ---- Lab known answers (published CIE values) -------------------------------------------------------
     rgb = np.array([[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 77]], np.uint8)
     want = np.array([[100.0, -0.0025, 0.0047], [0, 0, 0], [53.2406, 80.0923, 67.2028], [87.7351, -86.1830, 83.1797],

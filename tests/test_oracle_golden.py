@@ -145,3 +145,30 @@ def test_dynamic_head_restatement_vs_reference(case):
     assert np.abs(y.detach().numpy() - g[f'{case}_logits']).max() < 1e-12
     assert np.abs(feat.grad.numpy() - g[f'{case}_gfeat']).max() < 1e-12
     assert np.abs(params.grad.numpy() - g[f'{case}_gparams']).max() < 1e-11
+
+
+# ---- DiscoBox MeanField / dice_loss / mil_loss ---------------------------------------------------------
+@pytest.mark.parametrize('case', ['a', 'b', 'c'])
+def test_discobox_restatement_vs_reference(case):
+    """oracle.discobox_oracle vs the reference's MeanField / mil_loss / dice_loss (fixtures made by running them)."""
+    from oracle import discobox_oracle as do
+    g = load('discobox.npz')
+    ks, iters, base, alpha0, theta0, theta1, gamma = [float(v) for v in g[f'{case}_cfg']]
+    ks, iters = int(ks), int(iters)
+    K = do.meanfield_kernel(g[f'{case}_feat'], ks, alpha0, theta0, theta1)
+    Kref = g[f'{case}_kernel']
+    assert np.abs(K - Kref).max() <= 2.4e-7 * alpha0 and (np.abs(K - Kref) <= 2e-7 * np.abs(Kref) + 1e-37).all()   # 1 ulp (exp)
+    inter = g[f'{case}_inter'] if f'{case}_inter' in g else None
+    ret, valid, states, margins = do.meanfield_forward(Kref, g[f'{case}_x'], g[f'{case}_t'], iters, base, inter, gamma,
+                                                       return_states=True)
+    # decisions are thresholds of fp32 expressions evaluated in the reference's op order: they must agree exactly
+    assert np.array_equal(ret, g[f'{case}_ret'])
+    assert np.array_equal(valid, g[f'{case}_valid'])
+    t = g[f'{case}_t']
+    l, gr = do.mil_loss(g[f'{case}_mil_in'], t)
+    assert np.abs(l - g[f'{case}_mil_loss']).max() < 2e-6
+    assert np.abs(gr * g[f'{case}_gl'][:, None, None] - g[f'{case}_mil_grad']).max() < 2e-6
+    x = g[f'{case}_dice_in'] * t
+    assert np.abs(do.dice_loss(x, g[f'{case}_ret']) - g[f'{case}_dice_loss']).max() < 2e-6
+    gd = do.dice_loss_grad(x, g[f'{case}_ret']) * t * g[f'{case}_gl'][:, None, None]
+    assert np.abs(gd - g[f'{case}_dice_grad']).max() < 2e-6
