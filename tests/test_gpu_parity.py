@@ -322,3 +322,33 @@ def test_loss_box_edge_cases(dev):
     d['gt_bboxes'][0] = np.array([[0.0, 0.0, 95.0, 63.0], [-5.0, -7.0, 20.0, 30.0], [80.0, 50.0, 200.0, 100.0],
                                   [40.0, 40.0, 40.5, 40.5], [60.0, 30.0, 50.0, 20.0], [10.2, 5.9, 33.3, 41.7]], np.float32)
     _check_cfg(d, dev)
+
+
+@pytest.mark.parametrize('seed', list(range(24)))
+def test_loss_fuzz(dev, seed):
+    """Seeded sweep over shapes and parameters nobody hand-picked: canvas sizes that are / are not multiples of the
+    tile sizes, ragged image shapes, 1-3 images, 0-6 boxes per image, 1-3 instances per box, strides 4 / 8,
+    dilations 1-3, random threshold / warm-up / rows removed / upstream gradients."""
+    rng = np.random.default_rng(9000 + seed)
+    stride = int(rng.choice([4, 4, 4, 8]))
+    B = int(rng.integers(1, 4))
+    H = int(rng.integers(3, 14)) * 16 + int(rng.choice([0, 0, stride, 2 * stride]))
+    W = int(rng.integers(3, 20)) * 16 + int(rng.choice([0, 0, stride, 3 * stride]))
+    shapes = [(int(rng.integers(H // 2, H + 1)), int(rng.integers(W // 2, W + 1))) for _ in range(B)]
+    d = synthetic.make_batch(B=B, H=H, W=W, boxes_per_img=int(rng.integers(0, 7)), inst_per_box=int(rng.integers(1, 4)),
+                             stride=stride, seed=100 + seed, img_shapes=shapes, min_box=8.0, max_box=float(max(H, W)),
+                             logit_scale=float(rng.choice([0.5, 2.0, 6.0])))
+    kw = dict(pairwise_dilation=int(rng.integers(1, 4)), pairwise_color_thresh=float(rng.choice([0.1, 0.3, 0.5, 0.8])),
+              bottom_pixels_removed=int(rng.integers(0, 40)))
+    warm = float(rng.choice([1.0, 0.37]))
+    up = (float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.5, 2.0)))
+    ref = oracle_path(d, warmup=warm, g_prj=up[0], g_pw=up[1], want_targets=False, size=3, dil=kw['pairwise_dilation'],
+                      thresh=kw['pairwise_color_thresh'], bottom_pixels_removed=kw['bottom_pixels_removed'])
+    lp, lw, grad = hip_loss(d, dev, warmup=warm, up=up, **kw)
+    if d['N'] == 0:
+        assert lp == 0.0 and lw == 0.0 and grad.size == 0
+        return
+    assert rel(lp, ref['loss_prj']) <= TOL, (lp, ref['loss_prj'])
+    assert rel(lw, ref['loss_pairwise']) <= TOL or abs(lw - ref['loss_pairwise']) < 1e-7, (lw, ref['loss_pairwise'])
+    err, ties = grad_report(grad, ref['grad'], d['mask_logits'][:, 0])
+    assert err <= TOL, f'grad err {err:.3e} ({ties} ambiguous arg-max lines excluded); cfg {B}x{H}x{W} s{stride} {kw}'
