@@ -81,6 +81,16 @@ SIGNATURES = {
     'bxi_mil_loss_state_bytes': (c_size_t, [c_int, c_int, c_int]),
     'bxi_mil_loss_forward_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'bxi_mil_loss_backward_f32': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'bxi_projection_loss_forward_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, C.c_float, c_void_p, c_void_p, c_void_p]),
+    'bxi_levelset_state_bytes': (c_size_t, [c_int, c_int]),
+    'bxi_levelset_loss_forward_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, C.c_float, c_void_p,
+                                              c_void_p, c_void_p]),
+    'bxi_levelset_loss_backward_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, C.c_float, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p]),
+    'bxi_lcm_affinity_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, C.c_float, c_void_p, c_void_p]),
+    'bxi_lcm_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'bxi_lcm_refine_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                   c_void_p]),
 }
 
 LAUNCH_HOOK = C.CFUNCTYPE(None, C.c_char_p, c_int, c_void_p, c_void_p)

@@ -1,0 +1,480 @@
+// levelset.hip -- SURVEY 8(f-4): Box2Mask / BoxLevelSet loss pieces on gfx950
+// (mmdet/models/losses/levelset_loss.py: LevelsetLoss :7-18, region_levelset :21-45,
+//  LocalConsistencyModule :63-126; BoxProjectionLoss lives with mil_loss in meanfield.hip).
+//
+// region_levelset: per instance and side (foreground / background score) the region mean of every target channel,
+//   a_c = sum(f T_c) / max(sum f, 1e-5), and the energy sum_c sum_p (T_c - a_c)^2 f_p.  One pass (8 workgroups per
+//   instance, partial sums combined in index order by a second small launch): the energy is
+//   Q_c - 2 a_c A_c + a_c^2 S with A = sum f T, Q = sum f T^2, accumulated in fp64 (the reference makes two passes and
+//   materialises [N,C,H,W] temporaries).  The backward is elementwise from the saved sums.
+// LocalConsistencyModule: an 8-neighbour (dilated, replicate-padded) affinity from the image and `iters` applications
+//   of the linear operator phi <- sum_k aff_k * phi(neighbour_k).  A map that fits LDS (96x96 in the reference) is
+//   refined by ONE workgroup in ONE launch, ping-ponging between two LDS planes; the backward is the adjoint operator,
+//   written as a gather (every (p,k) that lands on q after clamping is enumerated) so that it needs no atomics.
+#include "common.hpp"
+
+namespace bxi {
+
+constexpr int kLsMaxC = 8;
+
+__device__ __forceinline__ double block_sum_f64_ls(double v, double* red /*[16]*/) {
+    v = wave_sum_f64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];   // fixed order
+    return s;
+}
+
+// state per instance: S[2] | a[2][C] | R[2][C]   (doubles; R = A - a S, zero unless the clamp of :34-35 is active),
+// followed (after all instances) by the partial sums of the slices: [N][kLsSlices][2 + 4C]  = S[2] | A[2][C] | Q[2][C]
+__device__ __forceinline__ int ls_stride(int C) { return 2 + 4 * C; }
+constexpr int kLsSlices = 8;      // workgroups per instance in the forward (a single one per instance is latency bound)
+
+__global__ __launch_bounds__(1024) void levelset_partial_kernel(const float* __restrict__ ms, const float* __restrict__ tg, int N, int C,
+                                                                int H, int W, double* __restrict__ state) {
+    __shared__ double red[16];
+    const int n = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x;
+    const int64_t HW = (int64_t)H * W;
+    const int64_t chunk = ((HW + kLsSlices - 1) / kLsSlices + 3) & ~(int64_t)3;
+    const int64_t lo = sl * chunk, hi = lo + chunk < HW ? lo + chunk : HW;
+    const float* f0 = ms + (int64_t)n * 2 * HW;
+    const float* T = tg + (int64_t)n * C * HW;
+    double S[2] = {0.0, 0.0}, A[2][kLsMaxC], Q[2][kLsMaxC];
+#pragma unroll
+    for (int c = 0; c < kLsMaxC; ++c) { A[0][c] = A[1][c] = Q[0][c] = Q[1][c] = 0.0; }
+    for (int64_t p0 = lo + tid; p0 < hi; p0 += 4 * 1024) {        // 4 pixels per trip: their loads are independent
+        // unconditional loads at a clamped index (a guarded load becomes a branch, and branches serialise the loads);
+        // a pixel past the end gets zero scores, which add nothing to any sum
+        float fv[4], gv[4];
+        int64_t pc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int64_t p = p0 + u * 1024; pc[u] = p < hi ? p : hi - 1; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { fv[u] = f0[pc[u]]; gv[u] = f0[HW + pc[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (p0 + u * 1024 >= hi) { fv[u] = 0.f; gv[u] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { S[0] += (double)fv[u]; S[1] += (double)gv[u]; }
+#pragma unroll
+        for (int c = 0; c < kLsMaxC; ++c)
+            if (c < C) {
+                float tv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tv[u] = T[(int64_t)c * HW + pc[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double f = fv[u], g = gv[u], t = tv[u];
+                    A[0][c] += f * t; A[1][c] += g * t;
+                    Q[0][c] += f * t * t; Q[1][c] += g * t * t;
+                }
+            }
+    }
+    double* part = state + (int64_t)N * ls_stride(C) + ((int64_t)n * kLsSlices + sl) * ls_stride(C);
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const double s = block_sum_f64_ls(S[side], red);
+        if (tid == 0) part[side] = s;
+#pragma unroll
+        for (int c = 0; c < kLsMaxC; ++c)
+            if (c < C) {
+                const double a_sum = block_sum_f64_ls(A[side][c], red), q_sum = block_sum_f64_ls(Q[side][c], red);
+                if (tid == 0) { part[2 + side * C + c] = a_sum; part[2 + 2 * C + side * C + c] = q_sum; }
+            }
+    }
+}
+
+// slices summed in index order -> region means, energy, loss; one thread per instance
+__global__ __launch_bounds__(64) void levelset_finish_kernel(const float* __restrict__ pixel_num, int N, int C, double weight,
+                                                             float* __restrict__ loss, double* __restrict__ state) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    const double* part = state + (int64_t)N * ls_stride(C) + (int64_t)n * kLsSlices * ls_stride(C);
+    double* st = state + (int64_t)n * ls_stride(C);
+    double total = 0.0;
+    for (int side = 0; side < 2; ++side) {
+        double s = 0.0;
+        for (int k = 0; k < kLsSlices; ++k) s += part[k * ls_stride(C) + side];
+        const double sc = s > 1e-5 ? s : 1e-5;                   // .clamp(min=0.00001)
+        st[side] = s;
+        for (int c = 0; c < C; ++c) {
+            double a_sum = 0.0, q_sum = 0.0;
+            for (int k = 0; k < kLsSlices; ++k) { a_sum += part[k * ls_stride(C) + 2 + side * C + c]; q_sum += part[k * ls_stride(C) + 2 + 2 * C + side * C + c]; }
+            const double a = a_sum / sc;
+            total += q_sum - 2.0 * a * a_sum + a * a * s;
+            st[2 + side * C + c] = a; st[2 + 2 * C + side * C + c] = a_sum - a * s;
+        }
+    }
+    loss[n] = (float)(weight * total / ((double)C * (double)pixel_num[n]));
+}
+
+__global__ __launch_bounds__(256) void levelset_bwd_kernel(const float* __restrict__ ms, const float* __restrict__ tg,
+                                                           const float* __restrict__ pixel_num, int N, int C, int H, int W,
+                                                           double weight, const double* __restrict__ state,
+                                                           const float* __restrict__ g_loss, float* __restrict__ g_ms,
+                                                           float* __restrict__ g_tg) {
+    const int64_t HW = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)N * HW) return;
+    const int n = (int)(i / HW);
+    const int64_t p = i % HW;
+    const double* st = state + (int64_t)n * ls_stride(C);
+    const double w = (double)g_loss[n] * weight / ((double)C * (double)pixel_num[n]);
+    const float* f0 = ms + (int64_t)n * 2 * HW;
+    double gt[kLsMaxC];
+#pragma unroll
+    for (int c = 0; c < kLsMaxC; ++c) gt[c] = 0.0;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const double f = f0[side * HW + p];
+        const double s = st[side], sc = s > 1e-5 ? s : 1e-5;
+        double gm = 0.0;
+#pragma unroll
+        for (int c = 0; c < kLsMaxC; ++c)
+            if (c < C) {
+                const double t = tg[((int64_t)n * C + c) * HW + p];
+                const double a = st[2 + side * C + c], R = st[2 + 2 * C + side * C + c];
+                const double d = t - a;
+                const double da_df = (t - (s >= 1e-5 ? a : 0.0)) / sc;
+                gm += d * d - 2.0 * R * da_df;
+                gt[c] += 2.0 * d * f - 2.0 * R * f / sc;
+            }
+        g_ms[((int64_t)n * 2 + side) * HW + p] = (float)(w * gm);
+    }
+    if (g_tg) {
+#pragma unroll
+        for (int c = 0; c < kLsMaxC; ++c)
+            if (c < C) g_tg[((int64_t)n * C + c) * HW + p] = (float)(w * gt[c]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LocalConsistencyModule
+__device__ __forceinline__ void lcm_offset(int k, int& dy, int& dx) {     // get_kernel (:82-92): row-major 3x3 without the centre
+    const int kk = k < 4 ? k : k + 1;
+    dy = kk / 3 - 1; dx = kk % 3 - 1;
+}
+
+__global__ __launch_bounds__(256) void lcm_affinity_kernel(const float* __restrict__ imgs, int N, int C, int h, int w, int d,
+                                                           float alpha, float* __restrict__ aff) {
+    const int64_t hw = (int64_t)h * w;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)N * hw) return;
+    const int n = (int)(i / hw), p = (int)(i % hw), r = p / w, c = p % w;
+    float e[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = 0.f;
+    for (int ch = 0; ch < C; ++ch) {
+        const float* I = imgs + ((int64_t)n * C + ch) * hw;
+        const float ip = I[p];
+        float v[8], mean = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int dy, dx; lcm_offset(k, dy, dx);
+            const int r2 = min(max(r + dy * d, 0), h - 1), c2 = min(max(c + dx * d, 0), w - 1);   // replicate padding (:99)
+            v[k] = I[(int64_t)r2 * w + c2];
+            mean += v[k];
+        }
+        mean *= 0.125f;
+        float var = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) var += (v[k] - mean) * (v[k] - mean);
+        const float sd = sqrtf(var / 7.f) + 1e-8f;                 // torch.std: unbiased (:116)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float z = fabsf(v[k] - ip) / sd / alpha; e[k] -= z * z; }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { e[k] /= (float)C; m = fmaxf(m, e[k]); }      // .mean(dim=1)
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { e[k] = expf(e[k] - m); s += e[k]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) aff[((int64_t)n * 8 + k) * hw + p] = e[k] / s;
+}
+
+// one application of the operator (or of its adjoint) at pixel (r,c); src: a plane of h*w floats (LDS or global)
+__device__ __forceinline__ float lcm_apply(const float* __restrict__ A /*[8,h,w] of the instance*/, const float* src, int h, int w,
+                                           int d, int r, int c) {
+    const int64_t hw = (int64_t)h * w;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int dy, dx; lcm_offset(k, dy, dx);
+        const int r2 = min(max(r + dy * d, 0), h - 1), c2 = min(max(c + dx * d, 0), w - 1);
+        acc += A[k * hw + (int64_t)r * w + c] * src[r2 * w + c2];
+    }
+    return acc;
+}
+
+// positions p in [0,n) with clamp(p + delta, 0, n-1) == q
+__device__ __forceinline__ void lcm_sources(int q, int delta, int n, int& lo, int& hi) {
+    if (n == 1) { lo = 0; hi = 0; return; }
+    if (q == 0) { lo = 0; hi = min(-delta, n - 1); }
+    else if (q == n - 1) { lo = max(n - 1 - delta, 0); hi = n - 1; }
+    else { lo = hi = q - delta; if (lo < 0 || lo >= n) { lo = 1; hi = 0; } }
+}
+
+__device__ __forceinline__ float lcm_apply_adjoint(const float* __restrict__ A, const float* src, int h, int w, int d, int r, int c) {
+    const int64_t hw = (int64_t)h * w;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int dy, dx; lcm_offset(k, dy, dx);
+        int rlo, rhi, clo, chi;
+        lcm_sources(r, dy * d, h, rlo, rhi);
+        lcm_sources(c, dx * d, w, clo, chi);
+        for (int pr = rlo; pr <= rhi; ++pr)
+            for (int pc = clo; pc <= chi; ++pc) acc += A[k * hw + (int64_t)pr * w + pc] * src[pr * w + pc];
+    }
+    return acc;
+}
+
+// whole map in LDS: all iterations in one launch, one workgroup per instance
+template <bool ADJ>
+__global__ __launch_bounds__(1024) void lcm_refine_lds_kernel(const float* __restrict__ aff, const float* __restrict__ phi, int h, int w,
+                                                              int d, int iters, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lcm_planes[];   // [2][h*w]
+    const int n = blockIdx.x, tid = threadIdx.x, hw = h * w;
+    float* cur = lcm_planes;
+    float* nxt = lcm_planes + hw;
+    const float* A = aff + (int64_t)n * 8 * hw;
+    for (int p = tid; p < hw; p += 1024) cur[p] = phi[(int64_t)n * hw + p];
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        for (int p = tid; p < hw; p += 1024) {
+            const int r = p / w, c = p % w;
+            nxt[p] = ADJ ? lcm_apply_adjoint(A, cur, h, w, d, r, c) : lcm_apply(A, cur, h, w, d, r, c);
+        }
+        __syncthreads();
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    for (int p = tid; p < hw; p += 1024) out[(int64_t)n * hw + p] = cur[p];
+}
+
+// Maps of at most kLcmPPT * kLcmThreads pixels (96 x 96 in the reference): as above, and the 8 coefficients of a
+// thread's pixels stay in registers for all iterations (they do not change) -- forward: aff_k at the pixel itself;
+// adjoint: aff_k at the source pixel q - delta_k.  Pixels of the adjoint whose sources are folded by the replicate
+// padding (within `d` of a border) take the enumerating path in a second sweep.
+constexpr int kLcmThreads = 512;     // 8 waves: 256 VGPRs per lane for the coefficients
+constexpr int kLcmPPT = 18;          // pixels per thread: 18 x 512 = 96 x 96
+
+__global__ __launch_bounds__(kLcmThreads) void lcm_refine_cached_kernel(const float* __restrict__ aff, const float* __restrict__ phi,
+                                                                        int h, int w, int d, int iters, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lcm_planes[];   // [2][h*w]
+    const int n = blockIdx.x, tid = threadIdx.x, hw = h * w;
+    float* cur = lcm_planes;
+    float* nxt = lcm_planes + hw;
+    const float* A = aff + (int64_t)n * 8 * hw;
+    float coef[kLcmPPT][8];
+    int rc[kLcmPPT];            // r << 16 | c ; -1: no pixel
+#pragma unroll
+    for (int j = 0; j < kLcmPPT; ++j) {
+        const int p = tid + j * kLcmThreads;
+        rc[j] = -1;
+        if (p < hw) {
+            cur[p] = phi[(int64_t)n * hw + p];
+            rc[j] = ((p / w) << 16) | (p % w);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) coef[j][k] = A[(int64_t)k * hw + p];
+        }
+    }
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < kLcmPPT; ++j) {
+            if (rc[j] == -1) continue;
+            const int r = rc[j] >> 16, c = rc[j] & 0xffff;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int dy, dx; lcm_offset(k, dy, dx);
+                acc += coef[j][k] * cur[min(max(r + dy * d, 0), h - 1) * w + min(max(c + dx * d, 0), w - 1)];
+            }
+            nxt[tid + j * kLcmThreads] = acc;
+        }
+        __syncthreads();
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    for (int p = tid; p < hw; p += kLcmThreads) out[(int64_t)n * hw + p] = cur[p];
+}
+
+// The adjoint, all iterations in one launch.  The forward operator reads a replicate-padded plane:
+// out[p] = sum_k aff_k[p] * pad(phi)[p + delta_k + d].  Its adjoint is therefore (a) an 8-tap gather on the PADDED
+// domain with no clamping, gp[s] = sum_k aff_k[p_k] g[p_k], p_k = s - d - delta_k (skipped outside the map), followed by
+// (b) folding the padding back, g'[q] = sum of gp over the padded positions that replicate q.  Both steps are
+// branch-light, read only LDS (plus the 8 coefficient loads, issued together) and have a fixed summation order.
+__global__ __launch_bounds__(1024) void lcm_adjoint_lds_kernel(const float* __restrict__ aff, const float* __restrict__ gout, int h, int w,
+                                                               int d, int iters, float* __restrict__ gphi) {
+    extern __shared__ __attribute__((aligned(16))) float lcm_planes[];   // g [h*w] | gp [(h+2d)*(w+2d)]
+    const int n = blockIdx.x, tid = threadIdx.x, hw = h * w, hp = h + 2 * d, wp = w + 2 * d;
+    float* g = lcm_planes;
+    float* gp = lcm_planes + hw;
+    const float* A = aff + (int64_t)n * 8 * hw;
+    for (int p = tid; p < hw; p += 1024) g[p] = gout[(int64_t)n * hw + p];
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        for (int s = tid; s < hp * wp; s += 1024) {
+            const int sr = s / wp, sc = s % wp;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int dy, dx; lcm_offset(k, dy, dx);
+                const int pr = sr - d - dy * d, pc = sc - d - dx * d;
+                const bool in = pr >= 0 && pr < h && pc >= 0 && pc < w;
+                const int pi = in ? pr * w + pc : 0;                      // clamped: the loads carry no branch
+                acc += (in ? 1.f : 0.f) * (A[(int64_t)k * hw + pi] * g[pi]);
+            }
+            gp[s] = acc;
+        }
+        __syncthreads();
+        for (int q = tid; q < hw; q += 1024) {
+            const int r = q / w, c = q % w;
+            const int r_lo = r == 0 ? 0 : r + d, r_hi = r == h - 1 ? hp - 1 : r + d;      // padded rows that replicate row r
+            const int c_lo = c == 0 ? 0 : c + d, c_hi = c == w - 1 ? wp - 1 : c + d;
+            float acc = 0.f;
+            for (int sr = r_lo; sr <= r_hi; ++sr)
+                for (int sc = c_lo; sc <= c_hi; ++sc) acc += gp[sr * wp + sc];
+            g[q] = acc;
+        }
+        __syncthreads();
+    }
+    for (int p = tid; p < hw; p += 1024) gphi[(int64_t)n * hw + p] = g[p];
+}
+
+// any size: one launch per iteration, planes in global memory
+template <bool ADJ>
+__global__ __launch_bounds__(256) void lcm_refine_step_kernel(const float* __restrict__ aff, const float* __restrict__ src, int N, int h,
+                                                              int w, int d, float* __restrict__ dst) {
+    const int64_t hw = (int64_t)h * w;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)N * hw) return;
+    const int n = (int)(i / hw), p = (int)(i % hw), r = p / w, c = p % w;
+    const float* A = aff + (int64_t)n * 8 * hw;
+    const float* s = src + (int64_t)n * hw;
+    dst[i] = ADJ ? lcm_apply_adjoint(A, s, h, w, d, r, c) : lcm_apply(A, s, h, w, d, r, c);
+}
+
+}  // namespace bxi
+
+extern "C" {
+
+size_t bxi_levelset_state_bytes(int N, int C) {
+    if (N < 0 || C <= 0 || C > bxi::kLsMaxC) return 0;
+    return sizeof(double) * (size_t)(N > 0 ? N : 1) * (2 + 4 * C) * (1 + bxi::kLsSlices);
+}
+
+int bxi_levelset_loss_forward_f32(const float* mask_score, const float* target, const float* pixel_num, int N, int C, int H,
+                                  int W, float loss_weight, float* loss, void* state, void* stream) {
+    if (N < 0 || H <= 0 || W <= 0 || C <= 0) return BXI_ERR_BAD_SHAPE;
+    if (C > bxi::kLsMaxC) return BXI_ERR_UNSUPPORTED;
+    if (N == 0) return BXI_OK;
+    if (!mask_score || !target || !pixel_num || !loss || !state) return BXI_ERR_NULL_POINTER;
+    if (!bxi::fits_i32((int64_t)N * H * W * (C > 2 ? C : 2))) return BXI_ERR_BAD_SHAPE;
+    if (reinterpret_cast<uintptr_t>(state) & 7) return BXI_ERR_WORKSPACE;
+    hipStream_t s = bxi::as_stream(stream);
+    if (N > 65535) return BXI_ERR_UNSUPPORTED;
+    BXI_LAUNCH("levelset_partial", s, bxi::levelset_partial_kernel, dim3(bxi::kLsSlices, N), dim3(1024), 0, s, mask_score, target, N, C, H,
+               W, reinterpret_cast<double*>(state));
+    int rc = bxi::check_launch();
+    if (rc != BXI_OK) return rc;
+    BXI_LAUNCH("levelset_finish", s, bxi::levelset_finish_kernel, dim3((N + 63) / 64), dim3(64), 0, s, pixel_num, N, C, (double)loss_weight,
+               loss, reinterpret_cast<double*>(state));
+    return bxi::check_launch();
+}
+
+int bxi_levelset_loss_backward_f32(const float* mask_score, const float* target, const float* pixel_num, int N, int C, int H,
+                                   int W, float loss_weight, const void* state, const float* g_loss, float* g_mask_score,
+                                   float* g_target, void* stream) {
+    if (N < 0 || H <= 0 || W <= 0 || C <= 0) return BXI_ERR_BAD_SHAPE;
+    if (C > bxi::kLsMaxC) return BXI_ERR_UNSUPPORTED;
+    if (N == 0) return BXI_OK;
+    if (!mask_score || !target || !pixel_num || !state || !g_loss || !g_mask_score) return BXI_ERR_NULL_POINTER;
+    if (!bxi::fits_i32((int64_t)N * H * W * (C > 2 ? C : 2))) return BXI_ERR_BAD_SHAPE;
+    hipStream_t s = bxi::as_stream(stream);
+    const unsigned grid = (unsigned)(((int64_t)N * H * W + 255) / 256);
+    BXI_LAUNCH("levelset_bwd", s, bxi::levelset_bwd_kernel, dim3(grid), dim3(256), 0, s, mask_score, target, pixel_num, N, C, H, W,
+               (double)loss_weight, reinterpret_cast<const double*>(state), g_loss, g_mask_score, g_target);
+    return bxi::check_launch();
+}
+
+int bxi_lcm_affinity_f32(const float* imgs, int N, int C, int h, int w, int dilation, float alpha, float* aff, void* stream) {
+    if (N < 0 || C <= 0 || h <= 0 || w <= 0) return BXI_ERR_BAD_SHAPE;
+    if (dilation < 1 || !(alpha > 0.f)) return BXI_ERR_BAD_ARGUMENT;
+    if (N == 0) return BXI_OK;
+    if (!imgs || !aff) return BXI_ERR_NULL_POINTER;
+    if (!bxi::fits_i32((int64_t)N * h * w * (C > 8 ? C : 8))) return BXI_ERR_BAD_SHAPE;
+    hipStream_t s = bxi::as_stream(stream);
+    const unsigned grid = (unsigned)(((int64_t)N * h * w + 255) / 256);
+    BXI_LAUNCH("lcm_affinity", s, bxi::lcm_affinity_kernel, dim3(grid), dim3(256), 0, s, imgs, N, C, h, w, dilation, alpha, aff);
+    return bxi::check_launch();
+}
+
+size_t bxi_lcm_workspace_bytes(int N, int h, int w) {
+    if (N < 0 || h <= 0 || w <= 0) return 0;
+    return sizeof(float) * (size_t)(N > 0 ? N : 1) * h * w;
+}
+
+int bxi_lcm_refine_f32(const float* aff, const float* phi, int N, int h, int w, int dilation, int iters, int transpose,
+                       float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (N < 0 || h <= 0 || w <= 0 || iters < 0) return BXI_ERR_BAD_SHAPE;
+    if (dilation < 1) return BXI_ERR_BAD_ARGUMENT;
+    if (N == 0) return BXI_OK;
+    if (!aff || !phi || !out) return BXI_ERR_NULL_POINTER;
+    if (!bxi::fits_i32((int64_t)N * h * w * 8)) return BXI_ERR_BAD_SHAPE;
+    hipStream_t s = bxi::as_stream(stream);
+    const size_t lds = sizeof(float) * 2 * (size_t)h * w;
+    auto allow_lds = [&](const void* fn, size_t bytes) -> int {
+        if (bytes <= 64 * 1024) return BXI_OK;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { bxi::set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }
+        return BXI_OK;
+    };
+    if (!transpose) {
+        if ((int64_t)h * w <= bxi::kLcmPPT * bxi::kLcmThreads && h < 32768 && w < 65536) {
+            const int rc = allow_lds(reinterpret_cast<const void*>(bxi::lcm_refine_cached_kernel), lds);
+            if (rc != BXI_OK) return rc;
+            BXI_LAUNCH("lcm_refine", s, bxi::lcm_refine_cached_kernel, dim3(N), dim3(bxi::kLcmThreads), lds, s, aff, phi, h, w, dilation, iters, out);
+            return bxi::check_launch();
+        }
+        if (lds <= 128 * 1024) {
+            const int rc = allow_lds(reinterpret_cast<const void*>(bxi::lcm_refine_lds_kernel<false>), lds);
+            if (rc != BXI_OK) return rc;
+            BXI_LAUNCH("lcm_refine", s, bxi::lcm_refine_lds_kernel<false>, dim3(N), dim3(1024), lds, s, aff, phi, h, w, dilation, iters, out);
+            return bxi::check_launch();
+        }
+    } else {
+        const size_t lds_adj = sizeof(float) * ((size_t)h * w + (size_t)(h + 2 * dilation) * (w + 2 * dilation));
+        if (lds_adj <= 128 * 1024) {
+            const int rc = allow_lds(reinterpret_cast<const void*>(bxi::lcm_adjoint_lds_kernel), lds_adj);
+            if (rc != BXI_OK) return rc;
+            BXI_LAUNCH("lcm_adjoint", s, bxi::lcm_adjoint_lds_kernel, dim3(N), dim3(1024), lds_adj, s, aff, phi, h, w, dilation, iters, out);
+            return bxi::check_launch();
+        }
+    }
+    // large maps: ping-pong between `out` and the workspace plane, one launch per iteration
+    if (!workspace || workspace_bytes < bxi_lcm_workspace_bytes(N, h, w) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+        return BXI_ERR_WORKSPACE;
+    const int64_t total = (int64_t)N * h * w;
+    if (iters == 0) {
+        hipError_t e = hipMemcpyAsync(out, phi, sizeof(float) * total, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) { bxi::set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }
+        return BXI_OK;
+    }
+    float* ws = reinterpret_cast<float*>(workspace);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    const float* src = phi;
+    for (int it = 0; it < iters; ++it) {
+        float* dst = ((iters - 1 - it) % 2 == 0) ? out : ws;       // the last step writes `out`
+        if (transpose) BXI_LAUNCH("lcm_step", s, bxi::lcm_refine_step_kernel<true>, dim3(grid), dim3(256), 0, s, aff, src, N, h, w, dilation, dst);
+        else BXI_LAUNCH("lcm_step", s, bxi::lcm_refine_step_kernel<false>, dim3(grid), dim3(256), 0, s, aff, src, N, h, w, dilation, dst);
+        const int rc = bxi::check_launch();
+        if (rc != BXI_OK) return rc;
+        src = dst;
+    }
+    return BXI_OK;
+}
+
+}  // extern "C"

@@ -272,8 +272,11 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__
 // (all 4 x ceil(W/64) x 2 loads of a step are independent); row maxima by wave reductions of packed (value, first
 // column) keys, column maxima by 64-bit LDS atomic max of packed (value, first row) keys -- max is order-independent,
 // so the result is deterministic.
+// eps = what the two dice denominators carry in total (mil_loss/dice_loss: 0.001 + 0.001; BoxProjectionLoss: 1e-5),
+// weight = loss_weight (folded into the loss and the unit gradients)
 __global__ __launch_bounds__(1024) void mil_fwd_kernel(const float* __restrict__ in, const void* __restrict__ tg, int t_u8,
-                                                       int H, int W, float* __restrict__ loss, int* __restrict__ state) {
+                                                       int H, int W, double eps, double weight, float* __restrict__ loss,
+                                                       int* __restrict__ state) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mil_raw[];
     // colkey u64[W] | colt u32[W] (target maxima as ordered keys) | rowv f32[H] | rowt f32[H]
     u64* colkey = reinterpret_cast<u64*>(mil_raw);
@@ -331,15 +334,15 @@ __global__ __launch_bounds__(1024) void mil_fwd_kernel(const float* __restrict__
         ac += v * t; bcc += v * v + t * t;
     }
     for (int r = tid; r < H; r += 1024) { ar += (double)rowv[r] * rowt[r]; bcr += (double)rowv[r] * rowv[r] + (double)rowt[r] * rowt[r]; }
-    ac = block_sum_f64(ac, red); bcc = block_sum_f64(bcc, red) + 0.002;
-    ar = block_sum_f64(ar, red); bcr = block_sum_f64(bcr, red) + 0.002;
-    if (tid == 0) loss[n] = (float)((1.0 - 2.0 * ar / bcr) + (1.0 - 2.0 * ac / bcc));   // loss_func(column..) + loss_func(row..)
+    ac = block_sum_f64(ac, red); bcc = block_sum_f64(bcc, red) + eps;
+    ar = block_sum_f64(ar, red); bcr = block_sum_f64(bcr, red) + eps;
+    if (tid == 0) loss[n] = (float)(weight * ((1.0 - 2.0 * ar / bcr) + (1.0 - 2.0 * ac / bcc)));   // loss_func(column..) + loss_func(row..)
     for (int c = tid; c < W; c += 1024) {
         const double v = unpack_val(colkey[c]), t = key_float(coltk[c]);
-        gcol[c] = (float)(-2.0 * t / bcc + 4.0 * ac * v / (bcc * bcc));
+        gcol[c] = (float)(weight * (-2.0 * t / bcc + 4.0 * ac * v / (bcc * bcc)));
         argc[c] = (int)unpack_idx(colkey[c]);
     }
-    for (int r = tid; r < H; r += 1024) grow[r] = (float)(-2.0 * rowt[r] / bcr + 4.0 * ar * rowv[r] / (bcr * bcr));
+    for (int r = tid; r < H; r += 1024) grow[r] = (float)(weight * (-2.0 * rowt[r] / bcr + 4.0 * ar * rowv[r] / (bcr * bcr)));
 }
 
 __global__ __launch_bounds__(256) void mil_bwd_kernel(int N, int H, int W, const int* __restrict__ state,
@@ -462,8 +465,8 @@ size_t bxi_mil_loss_state_bytes(int N, int H, int W) {
     return (size_t)(N > 0 ? N : 1) * 2 * (size_t)(H + W) * 4;
 }
 
-int bxi_mil_loss_forward_f32(const float* input, const void* target, int target_u8, int N, int H, int W, float* loss,
-                             void* state, void* stream) {
+static int launch_mil_fwd(const float* input, const void* target, int target_u8, int N, int H, int W, double eps, double weight,
+                          float* loss, void* state, void* stream) {
     if (N < 0 || H <= 0 || W <= 0) return BXI_ERR_BAD_SHAPE;
     if (N == 0) return BXI_OK;
     if (!input || !target || !loss || !state) return BXI_ERR_NULL_POINTER;
@@ -471,9 +474,19 @@ int bxi_mil_loss_forward_f32(const float* input, const void* target, int target_
     const size_t lds = (size_t)W * 12 + (size_t)H * 8;
     if (lds > 64 * 1024) return BXI_ERR_UNSUPPORTED;
     hipStream_t s = bxi::as_stream(stream);
-    BXI_LAUNCH("mil_fwd", s, bxi::mil_fwd_kernel, dim3(N), dim3(1024), lds, s, input, target, target_u8 ? 1 : 0, H, W, loss,
-               reinterpret_cast<int*>(state));
+    BXI_LAUNCH("mil_fwd", s, bxi::mil_fwd_kernel, dim3(N), dim3(1024), lds, s, input, target, target_u8 ? 1 : 0, H, W, eps, weight,
+               loss, reinterpret_cast<int*>(state));
     return bxi::check_launch();
+}
+
+int bxi_mil_loss_forward_f32(const float* input, const void* target, int target_u8, int N, int H, int W, float* loss,
+                             void* state, void* stream) {
+    return launch_mil_fwd(input, target, target_u8, N, H, W, 0.002, 1.0, loss, state, stream);
+}
+
+int bxi_projection_loss_forward_f32(const float* mask_scores, const float* box_bitmask, int N, int H, int W, float loss_weight,
+                                    float* loss, void* state, void* stream) {
+    return launch_mil_fwd(mask_scores, box_bitmask, 0, N, H, W, 1e-5, (double)loss_weight, loss, state, stream);
 }
 
 int bxi_mil_loss_backward_f32(int N, int H, int W, const void* state, const float* g_loss, float* g_input, void* stream) {

@@ -75,6 +75,22 @@ def _make_heads():
 HEADS = _make_heads()
 
 
+def _make_losses():
+    try:  # pragma: no cover - mmdet is not installable in the build container
+        from mmdet.models.builder import LOSSES as mm_losses
+        return _MMDetHeads(mm_losses)
+    except Exception:
+        return Registry('loss')
+
+
+LOSSES = _make_losses()      # BoxProjectionLoss, LevelsetLoss (mmdet/models/builder.py: LOSSES)
+
+
 def build_head(cfg: dict, default_args: Optional[dict] = None):
     """``mmdet.models.builder.build_head`` for the heads this package provides."""
     return HEADS.build(cfg, default_args=default_args)
+
+
+def build_loss(cfg: dict, default_args: Optional[dict] = None):
+    """``mmdet.models.builder.build_loss`` for the losses this package provides."""
+    return LOSSES.build(cfg, default_args=default_args)

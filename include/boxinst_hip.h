@@ -255,6 +255,40 @@ int bxi_mil_loss_forward_f32(const float* input, const void* target, int target_
                              void* state, void* stream);
 int bxi_mil_loss_backward_f32(int N, int H, int W, const void* state, const float* g_loss, float* g_input, void* stream);
 
+/* ===========================================================================================
+ * 6. Box2Mask / BoxLevelSet loss pieces:
+ *    BoxProjectionLoss (mmdet/models/losses/box_projection_loss.py:5-43),
+ *    LevelsetLoss / region_levelset (mmdet/models/losses/levelset_loss.py:7-45),
+ *    LocalConsistencyModule (levelset_loss.py:63-126; LCM() :53-60 composes it with elementwise ops).
+ * ===========================================================================================*/
+
+/* BoxProjectionLoss.forward: loss[n] = loss_weight * (dice(max over rows) + dice(max over columns)), dice with
+ * eps = 1e-5 on the union (:34-43).  mask_scores, box_bitmask [N,H,W] f32 (the reference's [N,1,H,W]).
+ * state: bxi_mil_loss_state_bytes(N,H,W); backward: bxi_mil_loss_backward_f32 (loss_weight is in the state). */
+int bxi_projection_loss_forward_f32(const float* mask_scores, const float* box_bitmask, int N, int H, int W, float loss_weight,
+                                    float* loss, void* state, void* stream);
+
+/* LevelsetLoss.forward (:13-18) = loss_weight * region_levelset(mask_score, target) / pixel_num.
+ * mask_score [N,2,H,W] (foreground, background scores), target [N,C,H,W] (C <= 8), pixel_num [N]; loss [N].
+ * state (bxi_levelset_state_bytes) keeps the region sums / means for the backward. */
+size_t bxi_levelset_state_bytes(int N, int C);
+int bxi_levelset_loss_forward_f32(const float* mask_score, const float* target, const float* pixel_num, int N, int C, int H,
+                                  int W, float loss_weight, float* loss, void* state, void* stream);
+/* g_mask_score [N,2,H,W] and, if not NULL, g_target [N,C,H,W] (the deep-feature targets carry gradient, box2mask_head.py:319-328) */
+int bxi_levelset_loss_backward_f32(const float* mask_score, const float* target, const float* pixel_num, int N, int C, int H,
+                                   int W, float loss_weight, const void* state, const float* g_loss, float* g_mask_score,
+                                   float* g_target, void* stream);
+
+/* LocalConsistencyModule: affinity of the 8 dilated neighbours (replicate padding) from the image (:108-120),
+ * imgs [N,C,h,w] -> aff [N,8,h,w]; */
+int bxi_lcm_affinity_f32(const float* imgs, int N, int C, int h, int w, int dilation, float alpha, float* aff, void* stream);
+/* `iters` refinement steps phi <- sum_k aff_k * phi(neighbour_k) (:122-126): phi [N,h,w] -> out [N,h,w].
+ * transpose != 0 applies the adjoint operator instead (the backward: g_phi from g_out).
+ * workspace: bxi_lcm_workspace_bytes(N,h,w) (one ping-pong plane; unused when a map fits LDS), 16-byte aligned. */
+size_t bxi_lcm_workspace_bytes(int N, int h, int w);
+int bxi_lcm_refine_f32(const float* aff, const float* phi, int N, int h, int w, int dilation, int iters, int transpose,
+                       float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

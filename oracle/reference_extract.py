@@ -89,3 +89,32 @@ def load_discobox(extra_globals: Optional[Dict] = None) -> types.SimpleNamespace
         env.update(extra_globals)
     exec(compile(mod, path, 'exec'), env)
     return types.SimpleNamespace(**{n: env[n] for n in DISCOBOX_FUNCTIONS + DISCOBOX_CLASSES}, _env=env)
+
+
+LEVELSET_FILE = 'mmdet/models/losses/levelset_loss.py'
+LEVELSET_NAMES = ('LevelsetLoss', 'region_levelset', 'length_regularization', 'LCM', 'LocalConsistencyModule')
+
+
+def load_levelset(extra_globals: Optional[Dict] = None) -> types.SimpleNamespace:
+    """the reference's ``LevelsetLoss`` / ``region_levelset`` / ``LCM`` / ``LocalConsistencyModule``
+    (levelset_loss.py:7-126) and ``BoxProjectionLoss`` (box_projection_loss.py:5-43); registry decorators removed."""
+    import numpy as np
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    env = {'torch': torch, 'nn': nn, 'F': F, 'np': np}
+    if extra_globals:
+        env.update(extra_globals)
+    names = []
+    for rel, wanted in ((LEVELSET_FILE, LEVELSET_NAMES), (PROJ_LOSS_FILE, ('BoxProjectionLoss',))):
+        path = os.path.join(REFERENCE_ROOT, rel)
+        with open(path) as fh:
+            tree = ast.parse(fh.read(), filename=path)
+        body = [_strip_decorators(n) for n in tree.body
+                if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in wanted]
+        mod = ast.Module(body=body, type_ignores=[])
+        ast.fix_missing_locations(mod)
+        exec(compile(mod, path, 'exec'), env)
+        names += list(wanted)
+    return types.SimpleNamespace(**{n: env[n] for n in names}, _env=env)

@@ -213,6 +213,45 @@ def main():
                     f'{name}_dice_loss': d.detach().numpy(), f'{name}_dice_grad': inp2.grad.numpy()})
     np.savez_compressed(os.path.join(HERE, 'discobox.npz'), **out)
 
+    # ---- BoxProjectionLoss / LevelsetLoss / LCM, the reference's own classes under autograd -----------
+    lns = rx.load_levelset()
+    out = {}
+    for name, (N, H, W, C) in {'a': (3, 17, 23, 3), 'b': (4, 40, 72, 2), 'c': (1, 96, 96, 3)}.items():
+        s = torch.tensor(rng.uniform(0, 1, (N, 1, H, W)), dtype=torch.float64, requires_grad=True)
+        box = np.zeros((N, 1, H, W))
+        for i in range(N):
+            r0, c0 = int(rng.integers(0, H // 2)), int(rng.integers(0, W // 2))
+            box[i, 0, r0:r0 + int(rng.integers(3, H // 2 + 1)), c0:c0 + int(rng.integers(3, W // 2 + 1))] = 1
+        soft = torch.tensor(box * rng.uniform(0.3, 1.0, box.shape), dtype=torch.float64)      # interpolated masks are not binary
+        gl = torch.tensor(rng.uniform(0.5, 1.5, N), dtype=torch.float64)
+        l = lns.BoxProjectionLoss(loss_weight=1.3)(s, soft)
+        (l * gl).sum().backward()
+        out.update({f'{name}_scores': s.detach().numpy(), f'{name}_bitmask': soft.numpy(), f'{name}_gl': gl.numpy(),
+                    f'{name}_prj_loss': l.detach().numpy(), f'{name}_prj_grad': s.grad.numpy()})
+        ms = torch.tensor(rng.uniform(0, 1, (N, 2, H, W)) * box, dtype=torch.float64, requires_grad=True)
+        T = torch.tensor(rng.uniform(-1, 1, (N, C, H, W)), dtype=torch.float64, requires_grad=True)
+        if name == 'a':
+            with torch.no_grad():
+                ms[0, 1] = 0.0                      # a region without score: the clamp of :34-35 is active
+        pn = torch.tensor(np.maximum(box.sum((1, 2, 3)), 1.0))
+        l = lns.LevelsetLoss(loss_weight=0.7)(ms, T, pn)
+        (l * gl).sum().backward()
+        out.update({f'{name}_ms': ms.detach().numpy(), f'{name}_T': T.detach().numpy(), f'{name}_pn': pn.numpy(),
+                    f'{name}_lst_loss': l.detach().numpy(), f'{name}_lst_gms': ms.grad.numpy(), f'{name}_lst_gT': T.grad.numpy()})
+        yy, xx = np.mgrid[0:H, 0:W]
+        img = np.stack([np.sin(xx / 5.0 + i) + 0.2 * rng.standard_normal((3, H, W))[0] for i in range(N)])[:, None]
+        img = np.concatenate([img, np.cos(yy / 4.0)[None, None].repeat(N, 0) + 0.1 * rng.standard_normal((N, 1, H, W)),
+                              0.3 * rng.standard_normal((N, 1, H, W))], 1).astype(np.float32)
+        phi = torch.tensor(rng.uniform(0, 1, (N, 1, H, W)), dtype=torch.float32, requires_grad=True)
+        bx = torch.tensor(box, dtype=torch.float32)
+        lcm = lns.LocalConsistencyModule(num_iter=10, dilations=[2])
+        ref = lcm(torch.from_numpy(img), phi)
+        l = lns.LCM(torch.from_numpy(img), phi, bx)
+        l.backward()
+        out.update({f'{name}_img': img, f'{name}_phi': phi.detach().numpy(), f'{name}_refined': ref.detach().numpy(),
+                    f'{name}_lcm_loss': np.array(float(l.detach())), f'{name}_lcm_grad': phi.grad.numpy(), f'{name}_box': box.astype(np.float32)})
+    np.savez_compressed(os.path.join(HERE, 'levelset.npz'), **out)
+
     # ---- Lab known answers (published CIE values) -------------------------------------------------------
     rgb = np.array([[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 77]], np.uint8)
     want = np.array([[100.0, -0.0025, 0.0047], [0, 0, 0], [53.2406, 80.0923, 67.2028], [87.7351, -86.1830, 83.1797],

@@ -172,3 +172,25 @@ def test_discobox_restatement_vs_reference(case):
     assert np.abs(do.dice_loss(x, g[f'{case}_ret']) - g[f'{case}_dice_loss']).max() < 2e-6
     gd = do.dice_loss_grad(x, g[f'{case}_ret']) * t * g[f'{case}_gl'][:, None, None]
     assert np.abs(gd - g[f'{case}_dice_grad']).max() < 2e-6
+
+
+# ---- BoxProjectionLoss / LevelsetLoss / LCM ---------------------------------------------------------------
+@pytest.mark.parametrize('case', ['a', 'b', 'c'])
+def test_levelset_restatement_vs_reference(case):
+    """oracle.levelset_oracle (values and hand-derived gradients) vs the reference's classes run under autograd."""
+    from oracle import levelset_oracle as lo
+    g = load('levelset.npz')
+    gl = g[f'{case}_gl']
+    l, gr = lo.box_projection_loss(g[f'{case}_scores'][:, 0], g[f'{case}_bitmask'][:, 0], 1.3)
+    assert np.abs(l - g[f'{case}_prj_loss']).max() < 1e-12
+    assert np.abs(gr * gl[:, None, None] - g[f'{case}_prj_grad'][:, 0]).max() < 1e-12
+    l, gm, gT = lo.levelset_loss(g[f'{case}_ms'], g[f'{case}_T'], g[f'{case}_pn'], 0.7)
+    assert np.abs(l - g[f'{case}_lst_loss']).max() < 1e-12
+    assert np.abs(gm * gl[:, None, None, None] - g[f'{case}_lst_gms']).max() < 1e-12
+    assert np.abs(gT * gl[:, None, None, None] - g[f'{case}_lst_gT']).max() < 1e-12
+    aff = lo.lcm_affinity(g[f'{case}_img'])
+    ref = lo.lcm_refine(aff, g[f'{case}_phi'][:, 0])
+    assert np.abs(ref - g[f'{case}_refined'][:, 0]).max() < 5e-6          # the reference runs this one in fp32
+    l, gr = lo.lcm_loss(g[f'{case}_img'], g[f'{case}_phi'][:, 0], g[f'{case}_box'][:, 0])
+    assert abs(l - float(g[f'{case}_lcm_loss'])) < 2e-6
+    assert np.abs(gr - g[f'{case}_lcm_grad'][:, 0]).max() < 2e-6 * max(1.0, np.abs(gr).max() * 1e3)
