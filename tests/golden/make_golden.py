@@ -252,6 +252,21 @@ def main():
                     f'{name}_lcm_loss': np.array(float(l.detach())), f'{name}_lcm_grad': phi.grad.numpy(), f'{name}_box': box.astype(np.float32)})
     np.savez_compressed(os.path.join(HERE, 'levelset.npz'), **out)
 
+    # ---- tree_filter -- minimum spanning trees by the reference's own boruvka.cpp (oracle/_ref) ----------
+    from oracle import tree_filter_oracle as tfo
+    assert tfo.ref_available(), 'run `make -C oracle ref` first (compiles the reference boruvka.cpp where it lies)'
+    out = {}
+    for name, (H, W, quant) in {'a': (12, 17, 0.0), 'b': (31, 24, 0.5), 'c': (96, 96, 0.0), 'd': (5, 90, 0.25)}.items():
+        yy, xx = np.mgrid[0:H, 0:W]
+        fm = np.stack([np.sin(xx / 6.0) + 0.3 * np.cos(yy / 5.0), np.cos(xx / 9.0 + yy / 7.0), 0.4 * np.sin(yy / 3.0)])
+        fm = (fm + 0.15 * rng.standard_normal(fm.shape)).astype(np.float32)
+        if quant:
+            fm = (np.round(fm / quant) * quant).astype(np.float32)      # many equal weights: ties go to the smaller edge index
+        idx = tfo.grid_edges(H, W)
+        wt = tfo.grid_weights(fm)
+        out.update({f'{name}_fm': fm, f'{name}_tree': tfo.ref_boruvka_mst(idx, wt, H * W)})
+    np.savez_compressed(os.path.join(HERE, 'tree_filter.npz'), **out)
+
     # ---- Lab known answers (published CIE values) -------------------------------------------------------
     rgb = np.array([[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 77]], np.uint8)
     want = np.array([[100.0, -0.0025, 0.0047], [0, 0, 0], [53.2406, 80.0923, 67.2028], [87.7351, -86.1830, 83.1797],

@@ -194,3 +194,54 @@ def test_levelset_restatement_vs_reference(case):
     l, gr = lo.lcm_loss(g[f'{case}_img'], g[f'{case}_phi'][:, 0], g[f'{case}_box'][:, 0])
     assert abs(l - float(g[f'{case}_lcm_loss'])) < 2e-6
     assert np.abs(gr - g[f'{case}_lcm_grad'][:, 0]).max() < 2e-6 * max(1.0, np.abs(gr).max() * 1e3)
+
+
+# ---- tree_filter ----------------------------------------------------------------------------------------------
+def _edge_set(e):
+    return set((int(min(a, b)), int(max(a, b))) for a, b in np.asarray(e).reshape(-1, 2).tolist())
+
+
+@pytest.mark.parametrize('case', ['a', 'b', 'c', 'd'])
+def test_tree_filter_mst_vs_reference_boruvka(case):
+    """oracle mst (Kruskal under (weight, index)) == the edge set the reference's own boruvka.cpp produced (fixture), and,
+    where oracle/_ref is built, == a fresh run of it."""
+    from oracle import tree_filter_oracle as tfo
+    g = load('tree_filter.npz')
+    fm = g[f'{case}_fm']
+    H, W = fm.shape[1:]
+    idx, wt = tfo.grid_edges(H, W), tfo.grid_weights(fm)
+    mine = tfo.mst_edges(idx, wt, H * W)
+    assert len(mine) == H * W - 1
+    assert _edge_set(idx[mine]) == _edge_set(g[f'{case}_tree'])
+    if tfo.ref_available():
+        assert _edge_set(tfo.ref_boruvka_mst(idx, wt, H * W)) == _edge_set(g[f'{case}_tree'])
+
+
+def test_tree_filter_refine_restatement_closed_form_and_autograd():
+    """the recurrences of refine.cu restated (oracle) == the closed form they implement, and their gradients == autograd"""
+    from oracle import tree_filter_oracle as tfo
+    rng = np.random.default_rng(3)
+    H, W = 6, 8
+    V = H * W
+    fm = rng.standard_normal((3, H, W)).astype(np.float32)
+    idx = tfo.grid_edges(H, W)
+    si, sp, sc = tfo.bfs_order(idx[tfo.mst_edges(idx, tfo.grid_weights(fm), V)], V)
+    assert (sp[1:] < np.arange(1, V)).all() and sorted(si.tolist()) == list(range(V))
+    w = tfo.edge_weights(rng.standard_normal((3, V)) * 0.3, si, sp, False)
+    x = rng.standard_normal((2, V)); g = rng.standard_normal((2, V))
+    out, saved = tfo.refine_forward(x, w, si, sp, sc)
+    assert np.abs(out - tfo.refine_closed_form(x, w, si, sp)).max() < 1e-12
+    xt = torch.tensor(x, requires_grad=True); wt_ = torch.tensor(w, requires_grad=True)
+    S = [[None] * V for _ in range(V)]
+    one = torch.ones((), dtype=torch.float64)
+    for i in range(V):
+        S[i][i] = one
+        if i:
+            for j in range(i):
+                S[i][j] = S[int(sp[i])][j] * wt_[i]
+                S[j][i] = S[i][j]
+    Sf = torch.stack([torch.stack(r) for r in S])
+    o = (Sf[None] * xt[:, torch.from_numpy(si).long()][:, None, :]).sum(2) / Sf.sum(1)[None]
+    (o * torch.tensor(g[:, si])).sum().backward()
+    assert np.abs(tfo.refine_backward_feature(g, w, si, sp, sc, saved) - xt.grad.numpy()).max() < 1e-12
+    assert np.abs(tfo.refine_backward_weight(x, g, w, si, sp, sc, saved)[1:] - wt_.grad.numpy()[1:]).max() < 1e-12
