@@ -23,6 +23,11 @@ namespace bxi {
 typedef unsigned long long u64;
 typedef unsigned short u16;
 
+// One wave walks a tree level by level through LDS: its LDS operations execute in program order, so between two
+// levels only the compiler has to be held back and the outstanding LDS operations waited for -- not the global stores
+// of the level (a workgroup-scope fence waits for those too: ~1 us per level, hundreds of levels).
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 constexpr int kTfMaxV = 10240;     // LDS-resident vertex limit (96x96 = 9216 in the reference's _scale_target)
 
 // ---------------------------------------------------------------------------------------------------
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(256) void bfs_kernel(const int* __restrict__ tree, 
                 if (k < max_adj) s_child[i * max_adj + k] = pos;
             }
             n += total;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");     // LDS writes of this chunk before the next reads
+            wave_lds_fence();                                          // LDS writes of this chunk before the next reads
         }
         ++depth;
         if (lane == 0) lv[1 + depth] = hi;
@@ -211,7 +216,7 @@ __device__ __forceinline__ void tree_updown(const TreeLds& t, int lane, float* _
             t.val[i] = acc;
             if (u_out) u_out[i] = acc;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        wave_lds_fence();
     }
     for (int l = 0; l < t.D; ++l) {
         const int lo = t.lv[l], hi = t.lv[l + 1];
@@ -221,7 +226,7 @@ __device__ __forceinline__ void tree_updown(const TreeLds& t, int lane, float* _
             const float dp = t.val[i];
             for (int k = 0; k < nc; ++k) { const float wc = t.w[c0 + k]; t.val[c0 + k] = t.val[c0 + k] * (1.f - wc * wc) + dp * wc; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        wave_lds_fence();
     }
 }
 
