@@ -168,20 +168,32 @@ __global__ __launch_bounds__(256) void bfs_kernel(const int* __restrict__ tree, 
         for (int base = lo; base < hi; base += 64) {
             const int i = base + lane;
             int cur = 0, par = 0xffff, nch = 0;
-            u16 ch[4];
+            u16 ch[4] = {0, 0, 0, 0};
             if (i < hi) {
                 cur = si[i]; par = pv[i];
-                for (int k = 0; k < 4; ++k) { const u16 a = adj[cur * 4 + k]; if (a != 0xffff && a != par) ch[nch++] = a; }
-            }
-            int incl = nch;
+                const u64 a4 = *reinterpret_cast<const u64*>(adj + cur * 4);        // the 4 neighbour slots in one read
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, kWave); if (lane >= off) incl += o; }
-            const int total = __shfl(incl, 63, kWave);
-            int pos = n + incl - nch;
-            for (int k = 0; k < nch; ++k, ++pos) {
-                si[pos] = ch[k]; pv[pos] = (u16)cur;
-                s_index[pos] = ch[k]; s_parent[pos] = i;
-                if (k < max_adj) s_child[i * max_adj + k] = pos;
+                for (int k = 0; k < 4; ++k) {
+                    const u16 a = (u16)(a4 >> (16 * k));
+                    if (a != 0xffff && a != par) {                                   // slot k -> child number nch (static indexing)
+                        if (nch == 0) ch[0] = a; else if (nch == 1) ch[1] = a; else if (nch == 2) ch[2] = a; else ch[3] = a;
+                        ++nch;
+                    }
+                }
+            }
+            // exclusive prefix sum of nch (0..4) over the wave from three ballots: no LDS traffic
+            const u64 b0 = __ballot(nch & 1), b1 = __ballot(nch & 2), b2 = __ballot(nch & 4);
+            const u64 below = lane ? (~0ull >> (64 - lane)) : 0ull;
+            const int excl = __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
+            const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+            int pos = n + excl;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < nch) {
+                    si[pos + k] = ch[k]; pv[pos + k] = (u16)cur;
+                    s_index[pos + k] = ch[k]; s_parent[pos + k] = i;
+                    if (k < max_adj) s_child[i * max_adj + k] = pos + k;
+                }
             }
             n += total;
             wave_lds_fence();                                          // LDS writes of this chunk before the next reads
@@ -205,28 +217,44 @@ struct TreeLds {
 
 // U_i = x_i + sum_c w_c U_c (refine.cu:64-121), then D_0 = U_0, D_c = U_c (1 - w_c^2) + D_parent w_c (:17-62), in place.
 // Called by wave 0 only; `u_out` (sorted order, may be null) receives U before it is overwritten.
-__device__ __forceinline__ void tree_updown(const TreeLds& t, int lane, float* __restrict__ u_out) {
+__device__ __forceinline__ void tree_updown(const TreeLds& t, int V, int lane, float* __restrict__ u_out) {
+    // A level costs dependent LDS round trips, and there are ~1000 levels: the (up to 4, contiguous) children of a node
+    // are read unconditionally at clamped positions so that they travel together, and the bounds of the next level are
+    // read while this one is processed.
+    int lo = t.lv[t.D - 1], hi = t.lv[t.D];
     for (int l = t.D - 1; l >= 0; --l) {
-        const int lo = t.lv[l], hi = t.lv[l + 1];
+        const int nlo = l ? t.lv[l - 1] : 0;
         for (int i = lo + lane; i < hi; i += 64) {
             const uint32_t f = t.fc[i];
             const int c0 = f & 0xffffu, nc = f >> 16;
+            float v[4], w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int c = min(c0 + k, V - 1); v[k] = t.val[c]; w[k] = t.w[c]; }
             float acc = t.val[i];
-            for (int k = 0; k < nc; ++k) acc += t.val[c0 + k] * t.w[c0 + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc += k < nc ? v[k] * w[k] : 0.f;
             t.val[i] = acc;
             if (u_out) u_out[i] = acc;
         }
         wave_lds_fence();
+        hi = lo; lo = nlo;
     }
+    lo = 0; hi = t.lv[1];
     for (int l = 0; l < t.D; ++l) {
-        const int lo = t.lv[l], hi = t.lv[l + 1];
+        const int nhi = l + 2 <= t.D ? t.lv[l + 2] : hi;
         for (int i = lo + lane; i < hi; i += 64) {
             const uint32_t f = t.fc[i];
             const int c0 = f & 0xffffu, nc = f >> 16;
             const float dp = t.val[i];
-            for (int k = 0; k < nc; ++k) { const float wc = t.w[c0 + k]; t.val[c0 + k] = t.val[c0 + k] * (1.f - wc * wc) + dp * wc; }
+            float v[4], w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int c = min(c0 + k, V - 1); v[k] = t.val[c]; w[k] = t.w[c]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nc) t.val[c0 + k] = v[k] * (1.f - w[k] * w[k]) + dp * w[k];
         }
         wave_lds_fence();
+        lo = hi; hi = nhi;
     }
 }
 
@@ -282,7 +310,7 @@ __global__ __launch_bounds__(256) void tree_refine_kernel(RefineArgs a) {
         for (int i = tid; i < V; i += 256) t.val[i] = poison;
         __syncthreads();
         float* wu = (ch == 0 && a.wsum_up_sorted) ? a.wsum_up_sorted + (int64_t)b * V : nullptr;
-        if (tid < 64) tree_updown(t, tid, wu);
+        if (tid < 64) tree_updown(t, V, tid, wu);
         __syncthreads();
         if (ch == 0 && a.wsum_vertex)
             for (int i = tid; i < V; i += 256) a.wsum_vertex[(int64_t)b * V + si[i]] = t.val[i];
@@ -305,7 +333,7 @@ __global__ __launch_bounds__(256) void tree_refine_kernel(RefineArgs a) {
         t.val[i] = x * poison;
     }
     __syncthreads();
-    if (tid < 64) tree_updown(t, tid, a.up_sorted ? a.up_sorted + cb : nullptr);
+    if (tid < 64) tree_updown(t, V, tid, a.up_sorted ? a.up_sorted + cb : nullptr);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
