@@ -56,6 +56,18 @@ def test_abi_argument_validation_without_device():
     assert lib.bxi_boxinst_loss_state_bytes(32, 200, 256) >= 32 * 456 * 8
     assert lib.bxi_boxinst_eval_workspace_bytes(2, 800, 1024, 4, 32) > 2 * 3 * 200 * 256 * 4
     assert lib.bxi_box_bitmasks_f32(None, None, 65, 64, 64, 4, 2, None, None) == -2       # > BXI_MAX_IMAGES
+    # the "next" rows (dynamic head, DiscoBox, Box2Mask losses, tree_filter): same contract
+    assert lib.bxi_dynamic_mask_forward_f32(None, 1, 12, 4, 4, None, 1, None, None, None, None, 5, 8, 2, 0, None, None) == -4   # C not in {8,16}
+    assert lib.bxi_meanfield_kernel_f32(None, 1, 3, 4, 4, 4, 2.0, 0.5, 30.0, None, None) == -4       # even kernel
+    assert lib.bxi_meanfield_forward_f32(None, 1, 4, 4, 3, None, None, 0, None, 1, 10, 0.7, None, 0.01, None, None, None, 0, None) == -3   # base >= 0.5
+    assert lib.bxi_meanfield_workspace_bytes(2, 10, 130) == 3 * 8 * 2 * 10 * 3
+    assert lib.bxi_mil_loss_forward_f32(None, None, 0, 1, 4, 4, None, None, None) == -1
+    assert lib.bxi_levelset_loss_forward_f32(None, None, None, 1, 9, 4, 4, 1.0, None, None, None) == -4            # C > 8
+    assert lib.bxi_levelset_state_bytes(3, 2) == 8 * 3 * 10 * 9
+    assert lib.bxi_lcm_refine_f32(None, None, 1, 4, 4, 0, 10, 0, None, None, 0, None) == -3                         # dilation < 1
+    assert lib.bxi_mst_forward_i32(None, None, 1, 10, 20000, None, None, 0, None) == -4                             # above the LDS-resident limit
+    assert lib.bxi_bfs_forward_i32(None, 1, 1, 4, None, None, None, None, None) == -2
+    assert lib.bxi_tree_refine_backward_weight_workspace_bytes(2, 3, 100) == 4 * 4 * 2 * 3 * 100
     if not torch.cuda.is_available():
         assert lib.bxi_check_device(0) == -7                                               # NO_DEVICE
 
