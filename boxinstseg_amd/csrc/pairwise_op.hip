@@ -5,7 +5,8 @@
 //
 // Roofline: HBM.  Forward moves 4*(1+K) B per pixel (K = size^2-1 output planes, write-bound);
 // backward 4*(1+K+1) B per pixel (g_pairwise read once through L2: every element is used by the
-// pixel itself (channel k) and by one neighbour (channel K-1-k)).
+// pixel itself (channel k) and by one neighbour (channel K-1-k)).  size == 3 runs the tiled kernels
+// further down (20.5 us / 41 us at 32x200x256 f32); the two kernels below serve the other window sizes.
 #include "common.hpp"
 
 namespace bxi {
@@ -91,6 +92,157 @@ __global__ __launch_bounds__(256) void pairwise_bwd_kernel(const T* __restrict__
     }
 }
 
+// ---- size == 3 (every shipped config): tiled kernels ---------------------------------------------------------------------
+// The kernels above evaluate log-sigmoid of both endpoints for every pair: ~3 exp/log pairs per neighbour, 24 per
+// pixel -- ALU bound at 1.7 TB/s.  Here a workgroup stages (log s(x), log s(-x)) of its 16x64 tile + halo in LDS once
+// (2 per pixel), so a pair costs one exp/log (pair_nlog), and the 8 output planes are written as full 64-wide rows.
+constexpr int kPwTR = 16, kPwTC = 64, kPwMaxDil = 8;
+
+template <typename T> struct LogPair { T a, b; };
+
+template <typename T>
+__device__ __forceinline__ void pw_stage(const T* __restrict__ L, int H, int W, int r0, int c0, int d, LogPair<T>* tile) {
+    const int PR = kPwTR + 2 * d, PC = kPwTC + 2 * d;
+    for (int i = threadIdx.x; i < PR * PC; i += 256) {
+        const int r = r0 - d + i / PC, c = c0 - d + i % PC;
+        LogPair<T> v{T(0), T(0)};
+        if (r >= 0 && r < H && c >= 0 && c < W) { const T x = L[(int64_t)r * W + c]; v.a = logsig(x); v.b = logsig(-x); }
+        tile[i] = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pairwise3_fwd_kernel(const T* __restrict__ logits, int H, int W, int d, T* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_raw[];
+    LogPair<T>* tile = reinterpret_cast<LogPair<T>*>(pw_raw);
+    const int tiles_x = (W + kPwTC - 1) / kPwTC, tiles_y = (H + kPwTR - 1) / kPwTR;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int64_t n = t / tiles_y;
+    const int64_t P = (int64_t)H * W;
+    const int r0 = ty * kPwTR, c0 = tx * kPwTC, PC = kPwTC + 2 * d;
+    pw_stage(logits + n * P, H, W, r0, c0, d, tile);
+    __syncthreads();
+    const int lc = threadIdx.x & 63, lr0 = threadIdx.x >> 6;
+    const int c = c0 + lc;
+    if (c >= W) return;
+    T* o = out + n * 8 * P;
+#pragma unroll
+    for (int j = 0; j < kPwTR / 4; ++j) {
+        const int lr = lr0 + 4 * j, r = r0 + lr;
+        if (r >= H) break;
+        const LogPair<T> p = tile[(lr + d) * PC + lc + d];
+        // f(p,q) == f(q,p) bit for bit (both sums commute): a pair is evaluated once, by its earlier pixel, and written
+        // to channel k of p and channel 7-k of q; a pixel writes the zeros of its own padded (out-of-map) neighbours.
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                         // neighbours before p in raster order
+            const int dy = k == 3 ? 0 : -1, dx = k == 3 ? -1 : k - 1;
+            const int r2 = r + dy * d, c2 = c + dx * d;
+            if (!(r2 >= 0 && r2 < H && c2 >= 0 && c2 < W)) o[(int64_t)k * P + (int64_t)r * W + c] = T(0);   // pairwise.cu:43-44
+        }
+#pragma unroll
+        for (int k = 4; k < 8; ++k) {                         // neighbours after p
+            const int dy = k == 4 ? 0 : 1, dx = k == 4 ? 1 : k - 6;
+            const int r2 = r + dy * d, c2 = c + dx * d;
+            T v = T(0);
+            const bool in = r2 >= 0 && r2 < H && c2 >= 0 && c2 < W;
+            if (in) {
+                const LogPair<T> q = tile[(lr + d + dy * d) * PC + lc + d + dx * d];
+                v = pair_nlog(p.a, p.b, q.a, q.b);
+                o[(int64_t)(7 - k) * P + (int64_t)r2 * W + c2] = v;
+            }
+            o[(int64_t)k * P + (int64_t)r * W + c] = v;
+        }
+    }
+}
+
+// backward: per pixel also s(x) - s(-x) staged once; a pair (p,q) is evaluated once by its earlier pixel p, which keeps
+// its own share and deposits q's share -(s(p)-s(-p)) exp(a_q+b_q+f) G into slot [q][k-4] of an LDS plane (one writer per
+// slot: no atomics); pairs whose earlier pixel lies outside the tile are evaluated by the later pixel itself.
+template <typename T> struct LogTriple { T a, b, dd; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void pairwise3_bwd_kernel(const T* __restrict__ logits, const T* __restrict__ g_pair, int H, int W, int d,
+                                                            T* __restrict__ g_logits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_raw[];
+    const int PR = kPwTR + 2 * d, PC = kPwTC + 2 * d;
+    LogTriple<T>* tile = reinterpret_cast<LogTriple<T>*>(pw_raw);
+    T* slots = reinterpret_cast<T*>(tile + PR * PC);                     // [kPwTR*kPwTC][4]: shares deposited by earlier pixels
+    const int tiles_x = (W + kPwTC - 1) / kPwTC, tiles_y = (H + kPwTR - 1) / kPwTR;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int64_t n = t / tiles_y;
+    const int64_t P = (int64_t)H * W;
+    const int r0 = ty * kPwTR, c0 = tx * kPwTC;
+    const T* L = logits + n * P;
+    for (int i = threadIdx.x; i < PR * PC; i += 256) {
+        const int r = r0 - d + i / PC, c = c0 - d + i % PC;
+        LogTriple<T> v{T(0), T(0), T(0)};
+        if (r >= 0 && r < H && c >= 0 && c < W) { const T x = L[(int64_t)r * W + c]; v.a = logsig(x); v.b = logsig(-x); v.dd = t_exp(v.a) - t_exp(v.b); }
+        tile[i] = v;
+    }
+    for (int i = threadIdx.x; i < kPwTR * kPwTC * 4; i += 256) slots[i] = T(0);
+    __syncthreads();
+    const int lc = threadIdx.x & 63, lr0 = threadIdx.x >> 6;
+    const int c = c0 + lc;
+    const T* GP = g_pair + n * 8 * P;
+    T own[kPwTR / 4];
+    // the gradient sums G = g[k][p] + g[7-k][q] of all four pixels of the thread first: 64 loads in flight, clamped
+    // positions so that no branch stands in front of them
+    T G[kPwTR / 4][8];
+    const int cc = min(c, W - 1);
+#pragma unroll
+    for (int j = 0; j < kPwTR / 4; ++j) {
+        const int r = min(r0 + lr0 + 4 * j, H - 1);
+        const int64_t pp = (int64_t)r * W + cc;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;
+            const int r2 = min(max(r + dy * d, 0), H - 1), c2 = min(max(cc + dx * d, 0), W - 1);
+            G[j][k] = GP[(int64_t)k * P + pp] + GP[(int64_t)(7 - k) * P + (int64_t)r2 * W + c2];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kPwTR / 4; ++j) {
+        const int lr = lr0 + 4 * j, r = r0 + lr;
+        own[j] = T(0);
+        if (c >= W || r >= H) continue;
+        const LogTriple<T> p = tile[(lr + d) * PC + lc + d];
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;
+            const int r2 = r + dy * d, c2 = c + dx * d;
+            if (!(r2 >= 0 && r2 < H && c2 >= 0 && c2 < W)) continue;
+            const int lr2 = lr + dy * d, lc2 = lc + dx * d;
+            const bool q_in_tile = lr2 >= 0 && lr2 < kPwTR && lc2 >= 0 && lc2 < kPwTC;
+            if (k < 4 && q_in_tile) continue;                 // that pair is evaluated by q (the earlier pixel) and deposited
+            const LogTriple<T> q = tile[(lr2 + d) * PC + lc2 + d];
+            const T pair = pair_nlog(p.a, p.b, q.a, q.b);
+            const T Gk = G[j][k];                              // channel k at p is the pair (p,q); channel 7-k at q is the pair (q,p)
+            acc += -q.dd * t_exp(p.a + p.b + pair) * Gk;
+            if (k >= 4 && q_in_tile) slots[(lr2 * kPwTC + lc2) * 4 + (k - 4)] = -p.dd * t_exp(q.a + q.b + pair) * Gk;
+        }
+        own[j] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPwTR / 4; ++j) {
+        const int lr = lr0 + 4 * j, r = r0 + lr;
+        if (c >= W || r >= H) continue;
+        const T* sl = slots + (lr * kPwTC + lc) * 4;
+        // summation order: the four earlier neighbours (k = 3,2,1,0 deposit into slots 0..3), then the later ones
+        g_logits[n * P + (int64_t)r * W + c] = (((sl[3] + sl[2]) + sl[1]) + sl[0]) + own[j];
+    }
+}
+
+template <typename T>
+static size_t pw3_lds(int d) { return sizeof(LogPair<T>) * (size_t)(kPwTR + 2 * d) * (kPwTC + 2 * d); }
+template <typename T>
+static size_t pw3_bwd_lds(int d) { return sizeof(LogTriple<T>) * (size_t)(kPwTR + 2 * d) * (kPwTC + 2 * d) + sizeof(T) * kPwTR * kPwTC * 4; }
+
 template <typename T>
 static int launch_fwd(const T* logits, int N, int H, int W, int size, int dil, T* out, void* stream) {
     if (N < 0 || H <= 0 || W <= 0) return BXI_ERR_BAD_SHAPE;
@@ -100,6 +252,14 @@ static int launch_fwd(const T* logits, int N, int H, int W, int size, int dil, T
     const int64_t total = (int64_t)N * H * W;
     if (!fits_i32(total * (size * size - 1))) return BXI_ERR_BAD_SHAPE;
     const int block = 256;
+    if (size == 3 && dil <= kPwMaxDil) {
+        const int64_t tiles = (int64_t)N * ((H + kPwTR - 1) / kPwTR) * ((W + kPwTC - 1) / kPwTC);
+        if (fits_i32(tiles)) {
+            BXI_LAUNCH("pairwise_fwd", as_stream(stream), (pairwise3_fwd_kernel<T>), dim3((unsigned)tiles), dim3(block), pw3_lds<T>(dil),
+                       as_stream(stream), logits, H, W, dil, out);
+            return check_launch();
+        }
+    }
     int64_t grid = (total + block - 1) / block;
     if (grid > 256 * 64) grid = 256 * 64;  // 256 CUs x 8 waves/SIMD; grid-stride the rest
     BXI_LAUNCH("pairwise_fwd", as_stream(stream), (pairwise_fwd_kernel<T>), dim3((unsigned)grid), dim3(block), 0, as_stream(stream), logits,
@@ -117,6 +277,19 @@ static int launch_bwd(const T* logits, const T* g_pair, int N, int H, int W, int
     const int64_t total = (int64_t)N * H * W;
     if (!fits_i32(total * (size * size - 1 > 0 ? size * size - 1 : 1))) return BXI_ERR_BAD_SHAPE;
     const int block = 256;
+    if (size == 3 && dil <= kPwMaxDil) {
+        const int64_t tiles = (int64_t)N * ((H + kPwTR - 1) / kPwTR) * ((W + kPwTC - 1) / kPwTC);
+        if (fits_i32(tiles)) {
+            if (pw3_bwd_lds<T>(dil) > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pairwise3_bwd_kernel<T>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pw3_bwd_lds<T>(dil));
+                if (e != hipSuccess) { set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }
+            }
+            BXI_LAUNCH("pairwise_bwd", as_stream(stream), (pairwise3_bwd_kernel<T>), dim3((unsigned)tiles), dim3(block), pw3_bwd_lds<T>(dil),
+                       as_stream(stream), logits, g_pair, H, W, dil, g_logits);
+            return check_launch();
+        }
+    }
     int64_t grid = (total + block - 1) / block;
     if (grid > 256 * 64) grid = 256 * 64;
     BXI_LAUNCH("pairwise_bwd", as_stream(stream), (pairwise_bwd_kernel<T>), dim3((unsigned)grid), dim3(block), 0, as_stream(stream), logits,
