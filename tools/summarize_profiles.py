@@ -55,3 +55,22 @@ with open(f'{P}/{rnd}_summary.md', 'w') as f:
         f.write(f"| {k} | {s['calls']} | {s['avg_us']:.2f} | {s['min_us']:.2f} | {s['max_us']:.2f} | "
                 f"{t.get('fetch_bytes_corrected', float('nan')) / 1e6:.2f} | {t.get('write_bytes', float('nan')) / 1e6:.2f} |\n")
 print(open(f'{P}/{rnd}_summary.md').read())
+
+# ---- the "next" rows: one table per tracked rocprofv3 kernel-stats file under profiles/ ------------------
+EXTRA = [('dynamic_head', 'f-2 dynamic mask head', 'tools/bench_dynamic_head.py'),
+         ('discobox', 'f-3 DiscoBox MeanField / mil_loss / dice_loss', 'tools/bench_discobox.py'),
+         ('levelset', 'f-4 BoxProjectionLoss / LevelsetLoss / LCM', 'tools/bench_levelset.py'),
+         ('tree_filter', 'f-4 tree_filter (mst / bfs / refine)', 'tools/bench_tree_filter.py'),
+         ('pairwise_op', 'a-9..a-11 op-level pairwise_nlog (f32 / f64)', 'tools/bench_pairwise_op.py')]
+with open(f'{P}/{rnd}_summary.md', 'a') as f:
+    for key, title, cmd in EXTRA:
+        path = f'{P}/{rnd}_{key}_kernel_stats.csv'
+        if not os.path.exists(path):
+            continue
+        f.write(f'\n## {title} (`rocprofv3 --kernel-trace --stats -- python {cmd}`, `{os.path.basename(path)}`)\n\n')
+        f.write('| kernel | calls | avg us | min us | max us |\n|---|---:|---:|---:|---:|\n')
+        rows = [r for r in csv.DictReader(open(path)) if 'bxi::' in r['Name']]
+        for r in sorted(rows, key=lambda r: -float(r['AverageNs'])):
+            name = r['Name'].split('bxi::')[1].split('(')[0]
+            f.write(f"| {name} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['MinNs']) / 1e3:.2f} | {float(r['MaxNs']) / 1e3:.2f} |\n")
+print(open(f'{P}/{rnd}_summary.md').read()[-2500:])
