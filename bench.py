@@ -114,14 +114,16 @@ def main():
         if rc != 0:
             raise RuntimeError(f'C ABI status {rc}: {_lib.status_string(rc)}')
 
-    # ---- parity gate (rank 0, set 0) before anything is timed -------------------------------------
+    # ---- the CPU-baseline leg (rank 0, N == 1), run BEFORE anything is timed: it is the only place that touches oracle/.
+    # The oracle is timed as the reported CPU baseline and, as the checker, gates the run: a HIP result that disagrees
+    # with it is not timed.
     with torch.cuda.stream(stream):
         enqueue(sets[0], stream.cuda_stream)
     stream.synchronize()
     parity = None
-    if rank == 0:
-        from tests.helpers import oracle_path
-        ref = oracle_path(sets[0].d, want_targets=False)
+    cpu_leg = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_leg, ref = cpu_baseline(sets[0].d, args.cpu_seconds)
         got = sets[0].losses.cpu().numpy()
         g = sets[0].grad.cpu().numpy()[:, 0]
         parity = dict(loss_prj_rel=float(abs(got[0] - ref['loss_prj']) / abs(ref['loss_prj'])),
@@ -216,8 +218,8 @@ def main():
     # ---- per-kernel durations with HIP events on the launching stream (rank 0, N == 1) ------------
     if rank == 0 and world == 1 and not args.no_kernel_timing:
         result.update(kernel_timing(lib, _lib, sets, stream, enqueue, min(args.steps, 200), elapsed / args.steps * 1e6))
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline(sets[0].d, args.cpu_seconds)
+    if cpu_leg is not None:
+        result['cpu_baseline'] = cpu_leg
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
@@ -337,7 +339,8 @@ def kernel_timing(lib, _lib, sets, stream, enqueue, steps, step_us):
 
 def cpu_baseline(d, budget_s):
     """The reference's CPU loss path (torch CPU ops, oracle/torch_oracle.py) on the host cores, fwd+bwd,
-    same workload; bounded to ~budget_s seconds.  Also the scalar C oracle on one core."""
+    same workload; bounded to ~budget_s seconds.  Also the C oracle (OpenMP).  Returns (report, the C oracle's
+    result for the parity gate)."""
     from oracle import torch_oracle as to
     from tests.helpers import oracle_path
     host_cores = os.cpu_count() or 1
@@ -361,13 +364,13 @@ def cpu_baseline(d, budget_s):
         if el > budget_s or n >= 10:
             break
     t_c0 = time.perf_counter()
-    oracle_path(d, want_targets=False)
+    ref = oracle_path(d, want_targets=False)
     t_c = time.perf_counter() - t_c0
     return {'value': 2 * n / el, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n} full evaluations (targets + loss fwd+bwd) of the same 2x800x1024x{len(d["gt_inds"])} '
                       f'workload with the torch-CPU restatement of the reference path, {cores} threads',
             'ms_per_eval': el / n * 1e3, 'host_cores': host_cores,
-            'c_oracle_openmp': {'value': 2 / t_c, 'unit': 'images/s', 'ms_per_eval': t_c * 1e3}}
+            'c_oracle_openmp': {'value': 2 / t_c, 'unit': 'images/s', 'ms_per_eval': t_c * 1e3}}, ref
 
 
 if __name__ == '__main__':
