@@ -78,3 +78,41 @@ def test_dynamic_head_module_and_errors(dev):
              torch.zeros(3, dtype=torch.long, device=dev))
     w, b = head.parse_dynamic_params(params)
     assert [tuple(t.shape) for t in w] == [(24, 18, 1, 1), (24, 8, 1, 1), (3, 8, 1, 1)] and [t.numel() for t in b] == [24, 24, 3]
+
+
+@pytest.mark.parametrize('seed', list(range(12)))
+def test_dynamic_head_fuzz(dev, seed):
+    """Seeded sweep: feature maps that are / are not multiples of the 8x32 tile, C in {8,16}, relative coordinates on/off,
+    up-sampling factors 1/2/4 and the run-time path (3), 0..40 instances spread unevenly over 1..4 images (including
+    images with no instance and more than 8 instances per image: several per slot)."""
+    from oracle import torch_oracle as to
+    rng = np.random.default_rng(7000 + seed)
+    B = int(rng.integers(1, 5)); C = int(rng.choice([8, 16])); no_rel = bool(rng.integers(0, 2))
+    H = int(rng.integers(3, 40)); W = int(rng.integers(3, 70)); N = int(rng.integers(0, 41))
+    fac = int(rng.choice([1, 2, 2, 4, 3]))
+    stride = {1: 8, 2: 8, 4: 8, 3: 9}[fac]
+    feat = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    P = (C + (0 if no_rel else 2)) * 8 + 64 + 8 + 17
+    params = (rng.standard_normal((N, P)) * 0.3).astype(np.float32)
+    coors = rng.uniform(0, stride * W, size=(N, 2)).astype(np.float32)
+    lvl = rng.integers(0, 5, size=N)
+    img = rng.integers(0, max(1, B - int(rng.integers(0, 2))), size=N)       # sometimes the last image gets no instance
+    g = rng.standard_normal((N, 1, fac * H, fac * W)).astype(np.float32)
+    from boxinstseg_amd import dynamic_mask_forward
+    f = torch.from_numpy(feat).to(dev).requires_grad_(True)
+    p = torch.from_numpy(params).to(dev).requires_grad_(True)
+    y = dynamic_mask_forward(f, p, torch.from_numpy(coors).to(dev), torch.from_numpy(lvl).to(dev), torch.from_numpy(img).to(dev),
+                             torch.tensor(SOI, device=dev), in_stride=stride, out_stride=stride // fac, disable_rel_coors=no_rel)
+    assert y.shape == (N, 1, fac * H, fac * W)
+    if N == 0:
+        return
+    y.backward(torch.from_numpy(g).to(dev))
+    f64 = lambda a: torch.from_numpy(a.astype(np.float64))
+    ft, pt = f64(feat).requires_grad_(True), f64(params).requires_grad_(True)
+    yo = to.dynamic_mask_forward(ft, pt, f64(coors), torch.from_numpy(lvl), torch.from_numpy(img), torch.tensor(SOI),
+                                 in_stride=stride, out_stride=stride // fac, disable_rel_coors=no_rel)
+    yo.backward(f64(g))
+    cfg = f'B{B} C{C} {H}x{W} N{N} f{fac} rel{not no_rel}'
+    assert _close(y.detach().cpu().numpy(), yo.detach().numpy(), 3e-5), cfg
+    assert _close(f.grad.cpu().numpy(), ft.grad.numpy(), 1e-4), cfg
+    assert _close(p.grad.cpu().numpy(), pt.grad.numpy(), 1e-4), cfg
