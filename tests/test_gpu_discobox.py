@@ -134,3 +134,45 @@ def test_discobox_errors_and_empty(built, dev):
     ret, valid = mf(torch.zeros(0, 1, 8, 70, device=dev), torch.zeros(0, 1, 8, 70, device=dev))
     assert ret.shape == (0, 1, 8, 70) and valid.shape == (0,)
     assert dice_loss(torch.zeros(0, 5, device=dev), torch.zeros(0, 5, device=dev)).shape == (0,)
+
+
+@pytest.mark.parametrize('seed', list(range(10)))
+def test_meanfield_fuzz(built, dev, seed):
+    """Seeded sweep over map sizes (widths around the 64-pixel word boundary), kernel 3 / 5, iteration counts, bases, one or two
+    images, empty / full / thin targets, with and without inter_img_mask."""
+    from boxinstseg_amd import meanfield_forward
+    rng = np.random.default_rng(4000 + seed)
+    H = int(rng.integers(2, 60)); W = int(rng.choice([1, 5, 63, 64, 65, 127, 128, 129, int(rng.integers(2, 200))]))
+    ks = int(rng.choice([3, 3, 5])); iters = int(rng.integers(0, 12)); base = float(rng.choice([0.05, 0.1, 0.3, 0.45]))
+    n = int(rng.integers(1, 9)); B = int(rng.integers(1, 3))
+    yy, xx = np.mgrid[0:H, 0:W]
+    feats = np.stack([np.stack([np.sin(xx / (5.0 + b)), np.cos(yy / 6.0 + xx / 9.0), 0.3 * np.sin(yy / 3.0)]) for b in range(B)])
+    feats = (feats + 0.1 * rng.standard_normal(feats.shape)).astype(np.float32)
+    Ko = np.stack([do.meanfield_kernel(feats[b], ks, 2.0, 0.5, 30.0) for b in range(B)])
+    x = rng.uniform(0, 1, size=(n, H, W)).astype(np.float32)
+    t = np.zeros((n, H, W), np.uint8)
+    for i in range(n):
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            continue                                   # no target
+        if kind == 1:
+            t[i] = 1                                   # everything
+        elif kind == 2:
+            t[i, int(rng.integers(0, H)), :] = 1       # one row
+        else:
+            r0, c0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+            t[i, r0:r0 + int(rng.integers(1, H + 1)), c0:c0 + int(rng.integers(1, W + 1))] = 1
+    img = rng.integers(0, B, size=n)
+    inter = rng.uniform(0, 20, size=(n, 2, H, W)).astype(np.float32) if rng.integers(0, 2) else None
+    ret, valid = meanfield_forward(torch.from_numpy(Ko).to(dev), torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev), iters, base,
+                                   img_inds=torch.from_numpy(img).to(dev),
+                                   inter_img_mask=None if inter is None else torch.from_numpy(inter).to(dev), gamma=0.01)
+    want = np.zeros_like(x); wv = np.zeros(n, np.float32)
+    for b in range(B):
+        m = img == b
+        if m.any():
+            want[m], wv[m] = do.meanfield_forward(Ko[b], x[m], t[m], iters, base, None if inter is None else inter[m], 0.01)
+    bad = int((ret.cpu().numpy() != want).sum())
+    assert bad <= max(1, int(2e-4 * want.size)), f'{bad} of {want.size} labels differ ({H}x{W} ks{ks} it{iters} base{base})'
+    if bad == 0:
+        assert np.array_equal(valid.cpu().numpy(), wv)

@@ -160,3 +160,34 @@ def test_tree_filter_errors(built, dev):
         MinimumSpanningTree(TreeFilter2D.norm2_distance)(torch.zeros(1, 3, 4, 4))            # CPU tensor
     with pytest.raises(RuntimeError):                                                      # more vertices than the LDS-resident limit
         mst(torch.zeros(1, 10, 2, dtype=torch.int32, device=dev), torch.ones(1, 10, device=dev), 20000)
+
+
+@pytest.mark.parametrize('seed', list(range(8)))
+def test_tree_filter_fuzz(built, dev, seed):
+    """Seeded sweep: grids from 1xK strips to 100x100, weights with heavy ties, several graphs per call: the GPU tree is the
+    unique minimum spanning tree under (weight, index), its BFS order is valid, and refine matches the oracle on it."""
+    from boxinstseg_amd import bfs, mst, refine
+    rng = np.random.default_rng(6000 + seed)
+    H = int(rng.choice([1, 2, 3, 7, 20, 45, 100])); W = int(rng.choice([2, 3, 9, 33, 64, 100]))
+    B = int(rng.integers(1, 4)); C = int(rng.integers(1, 4)); V = H * W
+    idx = tfo.grid_edges(H, W)
+    wt = rng.uniform(1, 2, size=(B, len(idx))).astype(np.float32)
+    if seed % 2:
+        wt = (np.round(wt * 4) / 4).astype(np.float32)            # ties everywhere
+    tree = mst(torch.from_numpy(idx)[None].repeat(B, 1, 1).to(dev), torch.from_numpy(wt).to(dev), V)
+    si, sp, sc = bfs(tree, 4)
+    t, sin, spn, scn = tree.cpu().numpy(), si.cpu().numpy(), sp.cpu().numpy(), sc.cpu().numpy()
+    x = rng.standard_normal((B, C, V)).astype(np.float32); g = rng.standard_normal((B, C, V)).astype(np.float32)
+    w = rng.uniform(0.2, 1.0, size=(B, V)).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True); wd = torch.from_numpy(w).to(dev).requires_grad_(True)
+    out = refine(xd, wd, si, sp, sc, False)
+    out.backward(torch.from_numpy(g).to(dev))
+    for b in range(B):
+        assert _edge_set(t[b]) == _edge_set(idx[tfo.mst_edges(idx, wt[b], V)]), f'{H}x{W}'
+        assert sorted(sin[b].tolist()) == list(range(V)) and (spn[b, 1:] < np.arange(1, V)).all()
+        want, saved = tfo.refine_forward(x[b].astype(np.float64), w[b].astype(np.float64), sin[b], spn[b], scn[b])
+        assert np.abs(out[b].detach().cpu().numpy() - want).max() <= 3e-5 * max(np.abs(want).max(), 1.0)
+        gf = tfo.refine_backward_feature(g[b].astype(np.float64), w[b].astype(np.float64), sin[b], spn[b], scn[b], saved)
+        assert np.abs(xd.grad[b].cpu().numpy() - gf).max() <= 3e-5 * max(np.abs(gf).max(), 1.0)
+        gw = tfo.refine_backward_weight(x[b].astype(np.float64), g[b].astype(np.float64), w[b].astype(np.float64), sin[b], spn[b], scn[b], saved)
+        assert np.abs(wd.grad[b].cpu().numpy() - gw).max() <= 2e-4 * max(np.abs(gw).max(), 1.0)
