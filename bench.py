@@ -126,11 +126,17 @@ def main():
         cpu_leg, ref = cpu_baseline(sets[0].d, args.cpu_seconds)
         got = sets[0].losses.cpu().numpy()
         g = sets[0].grad.cpu().numpy()[:, 0]
+        from tests.helpers import grad_report
+        # rows / columns whose two largest sigmoids coincide in fp32 have no defined arg-max position (DESIGN section 1:
+        # the value of the gradient is the same, where it lands is not); they are excluded and counted
+        g_err, n_ties = grad_report(g, ref['grad'], sets[0].d['mask_logits'][:, 0])
         parity = dict(loss_prj_rel=float(abs(got[0] - ref['loss_prj']) / abs(ref['loss_prj'])),
                       loss_pairwise_rel=float(abs(got[1] - ref['loss_pairwise']) / abs(ref['loss_pairwise'])),
-                      grad_rel_max=float(np.abs(g - ref['grad']).max() / np.abs(ref['grad']).max()))
+                      grad_rel_max=float(g_err))
         if max(parity.values()) > 1e-4:
             raise SystemExit(f'parity gate failed, refusing to time: {parity}')
+        parity['ambiguous_argmax_lines_excluded'] = int(n_ties)
+        parity['grad_rel_max_raw'] = float(np.abs(g - ref['grad']).max() / np.abs(ref['grad']).max())
 
     # ---- step function -------------------------------------------------------------------------------
     graphs = None
