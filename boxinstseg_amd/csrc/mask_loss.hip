@@ -582,7 +582,7 @@ __device__ __noinline__ float2 pair_logspace_redo(const float* __restrict__ L, c
     return make_float2(dnum, acc2);   // (correction to the pixel's loss sum, its gradient)
 }
 
-template <bool FROM_LAB>
+template <bool FROM_LAB, bool PREFETCH>
 __device__ __forceinline__ void box_body(const InstArgs& a, const float* __restrict__ lab, const ImageMeta& meta,
                                          const uint8_t* __restrict__ bits_in, float thresh, int dil, float warmup,
                                          const LossWs& ws, const LossState& st, float* __restrict__ losses,
@@ -611,11 +611,38 @@ __device__ __forceinline__ void box_body(const InstArgs& a, const float* __restr
     // The record of the NEXT item is requested before the current tile is worked on, so that a looping workgroup does
     // not pay its ~1.5 us again per tile.
     const int cap = a.N * ((h + kBR - 1) / kBR) * ((w + kBC - 1) / kBC);
+    const int64_t P = (int64_t)h * w;
+    const int d = dil;
+    const int PAD = (d + 3) & ~3;
+    const int PR = kBR + 2 * d, PC = kBC + 2 * PAD;          // staged region: tile + halo (columns padded to 4)
+    const int q4 = PC / 4, items = PR * q4;                  // d = 2: 216 float4 per plane
+    const bool one_item = PREFETCH && items <= 256;          // d <= 3: a thread stages at most one float4 per plane
+    // the raw tile data (logits + 3 Lab planes) of a work item, one float4 per plane and thread (zero padding of F.unfold)
+    auto load_item = [&](const WorkRec& w_, int i, float4 (&t)[4]) {
+        t[0] = make_float4(0.f, 0.f, 0.f, 0.f); t[1] = t[0]; t[2] = t[0]; t[3] = t[0];
+        if (i >= items) return;
+        const int lr = i / q4, r = w_.tile_r0 - d + lr, c = w_.tile_c0 - PAD + (i % q4) * 4;
+        if (!(r >= 0 && r < h && c >= 0 && c < w)) return;
+        t[0] = load4(a.logits + (int64_t)w_.n * P + (int64_t)r * w, c, w, vec);
+        if (FROM_LAB) {
+            const float* row = lab + (int64_t)w_.img * 3 * P + (int64_t)r * w;
+            if (vec) {
+                t[1] = *reinterpret_cast<const float4*>(row + c);
+                t[2] = *reinterpret_cast<const float4*>(row + P + c);
+                t[3] = *reinterpret_cast<const float4*>(row + 2 * P + c);
+            } else {
+                t[1] = load4(row, c, w, false); t[2] = load4(row + P, c, w, false); t[3] = load4(row + 2 * P, c, w, false);
+            }
+        }
+    };
     WorkRec wr_next = ws.work[min((int)blockIdx.x - a.N, cap - 1)];   // speculative (inside the list's capacity) ...
+    float4 pre[4];                                           // the next tile's data, in flight while the current tile is worked on
+    if ((int)blockIdx.x - a.N < nwork && one_item) load_item(wr_next, tid, pre);
     for (int wi = (int)blockIdx.x - a.N; wi < cap; wi += ntile_wg) {
         if (wi >= nwork) break;                  // workgroup-uniform
         const WorkRec wr = wr_next;
-        if (wi + ntile_wg < nwork) wr_next = ws.work[wi + ntile_wg];
+        const bool more = wi + ntile_wg < nwork;
+        if (more) wr_next = ws.work[wi + ntile_wg];
         Pred pr; pr.n2max = wr.n2max; pr.zero_bit = wr.zero_bit; pr.fast = 1; pr.pad = 0;
         const int n = wr.n, r0 = wr.tile_r0, c0 = wr.tile_c0;
         InstRec rc; rc.r0 = wr.r0; rc.r1 = wr.r1; rc.c0 = wr.c0; rc.c1 = wr.c1; rc.img = wr.img;
@@ -625,45 +652,28 @@ __device__ __forceinline__ void box_body(const InstArgs& a, const float* __restr
         const int vc = FROM_LAB ? meta.img_w[ib.img] : 0;
         const int half = a.stride / 2;
         BXI_T(1, blockIdx.x, 1);
-        const int64_t P = (int64_t)h * w;
         const float* L = a.logits + (int64_t)n * P;
-        const int d = dil;
-        const int PAD = (d + 3) & ~3;
-        const int PR = kBR + 2 * d, PC = kBC + 2 * PAD;          // staged region: tile + halo (columns padded to 4)
         float2* pq = reinterpret_cast<float2*>(smem);
         float* labs = reinterpret_cast<float*>(smem + sizeof(float2) * (size_t)PR * PC);   // [3][PR][PC]   (FROM_LAB)
         uint8_t* bits = smem + sizeof(float2) * (size_t)PR * PC;                            // [PR][PC]      (!FROM_LAB)
 
-        // ---- 1. loads: logits region (-> sigmoid pairs) and Lab region, all in flight together -----------
+        // ---- 1. the logits region (-> sigmoid pairs) and the Lab region go to LDS ----------------------------
         {
-            const int q4 = PC / 4, items = PR * q4;                 // d = 2: 216 float4 per plane
-            const float* LB = FROM_LAB ? lab + (int64_t)ib.img * 3 * P : nullptr;
             for (int i = tid; i < items; i += 256) {
-                const int lr = i / q4, r = r0 - d + lr, c = c0 - PAD + (i % q4) * 4;
-                const bool inb = r >= 0 && r < h && c >= 0 && c < w;
-                float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0, t3 = t0;   // zero padding of F.unfold
-                if (inb) {
-                    t0 = load4(L + (int64_t)r * w, c, w, vec);
-                    if (FROM_LAB) {
-                        const float* row = LB + (int64_t)r * w;
-                        if (vec) {
-                            t1 = *reinterpret_cast<const float4*>(row + c);
-                            t2 = *reinterpret_cast<const float4*>(row + P + c);
-                            t3 = *reinterpret_cast<const float4*>(row + 2 * P + c);
-                        } else {
-                            t1 = load4(row, c, w, false); t2 = load4(row + P, c, w, false); t3 = load4(row + 2 * P, c, w, false);
-                        }
-                    }
-                }
+                float4 t[4];
+                if (one_item) { t[0] = pre[0]; t[1] = pre[1]; t[2] = pre[2]; t[3] = pre[3]; }   // requested during the previous tile
+                else load_item(wr, i, t);
+                const int lr = i / q4;
                 float2* dst = pq + (size_t)lr * PC + (i % q4) * 4;
-                dst[0] = sig_pair(t0.x); dst[1] = sig_pair(t0.y); dst[2] = sig_pair(t0.z); dst[3] = sig_pair(t0.w);
+                dst[0] = sig_pair(t[0].x); dst[1] = sig_pair(t[0].y); dst[2] = sig_pair(t[0].z); dst[3] = sig_pair(t[0].w);
                 if (FROM_LAB) {
                     float* ld = labs + (size_t)lr * PC + (i % q4) * 4;
-                    *reinterpret_cast<float4*>(ld) = t1;
-                    *reinterpret_cast<float4*>(ld + PR * PC) = t2;
-                    *reinterpret_cast<float4*>(ld + 2 * PR * PC) = t3;
+                    *reinterpret_cast<float4*>(ld) = t[1];
+                    *reinterpret_cast<float4*>(ld + PR * PC) = t[2];
+                    *reinterpret_cast<float4*>(ld + 2 * PR * PC) = t[3];
                 }
             }
+            if (one_item && more) load_item(wr_next, tid, pre);     // flies during the pair loop of this tile
             if (!FROM_LAB) {   // affinity words given: stage those of the in-box pixels (bitmask == 1, :1324-1325)
                 const uint8_t* AF = bits_in + (int64_t)ib.img * P;
                 for (int i = tid; i < PR * PC; i += 256) {
@@ -854,20 +864,22 @@ __device__ __forceinline__ void box_body(const InstArgs& a, const float* __restr
 // Two builds of the same body.  The default one (3 waves per SIMD, no spills) serves launches in which a tile workgroup
 // handles one tile (BASELINE: 32 instances): there the per-tile chain is the launch.  With hundreds of instances every
 // workgroup loops over many tiles and the launch is throughput bound: 4 waves per SIMD hide more of each chain and win
-// 8-11 % in spite of 12 spilled dwords (measured: 41.0 -> 37.6 us at 128 instances, 145 -> 128 us at 512).
+// in spite of 4 spilled dwords (measured: 41 -> 34 us at 128 instances, 145 -> 114 us at 512; 5 waves per SIMD need 32
+// spilled dwords and lose: 155 us).  The default build instead prefetches the next tile's raw data (16 VGPRs) during the
+// pair loop, worth 4-5 % when it loops; in the 4-wave build those registers would be spilled, so it does not.
 template <bool FROM_LAB>
 __global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __restrict__ lab, ImageMeta meta,
                                                   const uint8_t* __restrict__ bits_in, float thresh, int dil, float warmup,
                                                   LossWs ws, LossState st, float* __restrict__ losses,
                                                   float* __restrict__ g_logits, int vec) {
-    box_body<FROM_LAB>(a, lab, meta, bits_in, thresh, dil, warmup, ws, st, losses, g_logits, vec);
+    box_body<FROM_LAB, true>(a, lab, meta, bits_in, thresh, dil, warmup, ws, st, losses, g_logits, vec);
 }
 template <bool FROM_LAB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void box_kernel_dense(InstArgs a, const float* __restrict__ lab, ImageMeta meta, const uint8_t* __restrict__ bits_in, float thresh,
                       int dil, float warmup, LossWs ws, LossState st, float* __restrict__ losses, float* __restrict__ g_logits,
                       int vec) {
-    box_body<FROM_LAB>(a, lab, meta, bits_in, thresh, dil, warmup, ws, st, losses, g_logits, vec);
+    box_body<FROM_LAB, false>(a, lab, meta, bits_in, thresh, dil, warmup, ws, st, losses, g_logits, vec);
 }
 
 // ================================================================================================
@@ -1049,7 +1061,7 @@ int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, co
     if (lds < lds_leader) lds = lds_leader;
     if (lds > 160 * 1024) return BXI_ERR_UNSUPPORTED;
     const int n_tiles = a.N * box_tiles(a.h, a.w);
-    const bool dense = n_tiles > 6400;        // more than ~2 tiles per tile workgroup (see box_kernel_dense)
+    const bool dense = n_tiles > 6400;         // more than ~2 tiles per tile workgroup (see box_kernel_dense)
     if (lds > 64 * 1024) {
         const void* fn = from_lab ? (dense ? reinterpret_cast<const void*>(box_kernel_dense<true>) : reinterpret_cast<const void*>(box_kernel<true>))
                                   : (dense ? reinterpret_cast<const void*>(box_kernel_dense<false>) : reinterpret_cast<const void*>(box_kernel<false>));
