@@ -36,9 +36,11 @@ struct PoolArgs {
 static __device__ const double kSrgbLut[256] = BXI_SRGB_LUT_INIT;
 
 __device__ __forceinline__ int denorm_u8(float x, double s, double m) {
-    // cv2.multiply(img_f32, std_f64) -> f32 ; cv2.add(img_f32, mean_f64) -> f32 ; astype(uint8)
+    // OpenCV arithm_op: cv2.multiply against the float64 std row works in double (mul/div force the
+    // scalar depth to CV_64F) and rounds to the f32 image; cv2.add demotes a float64 scalar to CV_32F
+    // when the array is CV_32F, so the add is a plain f32 add of (float)mean.  astype(uint8) truncates.
     const float t = (float)((double)x * s);
-    const float v = (float)((double)t + m);
+    const float v = __fadd_rn(t, (float)m);
     return (int)v & 0xff;
 }
 

@@ -3,7 +3,11 @@
 No dataset or checkpoint is reachable, so tests, ``bench.py`` and ``smoke()`` all draw from here:
   image   uint8 RGB, 16x16-pixel blocks of uniform random colour + N(0,6) pixel noise, fed to the
           "network" as ((u + 0.25) - mean) / std in fp32 -- the +0.25 keeps the de-normalised value
-          away from an integer, so the uint8 truncation of condinst_head.py:180 is unambiguous;
+          away from an integer, so the uint8 truncation of condinst_head.py:180 is unambiguous.
+          ``pixel_offset=0`` instead feeds exactly what the reference pipeline's Normalize step
+          (mmcv imnormalize: f32 subtract of mean, double multiply by 1/std rounded to f32) makes of
+          a uint8 image, so the de-normalised value lands within an ulp of an integer -- the regime
+          real images are in, where every rounding step of the restatement shows;
   boxes   per image, x1,y1 uniform, width/height ~ U(64,512) px clipped to the image (xyxy fp32);
   logits  2*N(0,1) + (4*bitmask - 2): weakly correlated with the box, no sigmoid saturation.
 All arrays are numpy (CPU); callers move what they need to the device.
@@ -21,7 +25,8 @@ STD = (58.395, 57.12, 57.375)
 def make_batch(B: int = 2, H: int = 800, W: int = 1024, boxes_per_img: int = 16, inst_per_box: int = 1,
                stride: int = 4, seed: int = 0, img_shapes: Optional[Sequence[Sequence[int]]] = None,
                ori_shapes: Optional[Sequence[Sequence[int]]] = None, block: int = 16,
-               logit_scale: float = 2.0, min_box: float = 64.0, max_box: float = 512.0) -> Dict:
+               logit_scale: float = 2.0, min_box: float = 64.0, max_box: float = 512.0,
+               pixel_offset: float = 0.25) -> Dict:
     rng = np.random.default_rng(seed)
     h, w = H // stride, W // stride
     mean = np.asarray(MEAN, np.float32).reshape(1, 3, 1, 1)
@@ -30,7 +35,11 @@ def make_batch(B: int = 2, H: int = 800, W: int = 1024, boxes_per_img: int = 16,
     coarse = rng.integers(0, 256, size=(B, 3, gh, gw)).astype(np.float32)
     u = np.repeat(np.repeat(coarse, block, axis=2), block, axis=3)[:, :, :H, :W]
     u = np.clip(np.rint(u + rng.normal(0.0, 6.0, size=u.shape)), 0, 255).astype(np.float32)
-    imgs = ((u + np.float32(0.25)) - mean) / std
+    if pixel_offset:
+        imgs = ((u + np.float32(pixel_offset)) - mean) / std
+    else:
+        inv = 1.0 / np.asarray(STD, np.float64).reshape(1, 3, 1, 1)
+        imgs = ((u - mean).astype(np.float64) * inv).astype(np.float32)
     img_metas, gt_bboxes = [], []
     for b in range(B):
         ish = tuple(img_shapes[b]) if img_shapes is not None else (H, W)

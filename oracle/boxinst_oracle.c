@@ -37,8 +37,12 @@ void bxo_set_threads(int n) {
  * RGB->BGR flip; the caller then reverses the channel axis again (:182-183).  Net effect:
  *   to_rgb=True : out channel c = trunc(x[c]*std[c]+mean[c])
  *   to_rgb=False: out channel c = trunc(x[2-c]*std[2-c]+mean[2-c])
- * OpenCV evaluates both steps in double against the float64 scalars mmcv passes and rounds to
- * the float32 destination after each (UNPINNED: cv2 is not available to confirm). */
+ * mmcv passes mean/std as 1x3 float64 rows, which OpenCV's arithm_op treats as scalars:
+ *   - cv2.multiply: mul/div force the scalar depth to CV_64F, so the work type is double and the
+ *     product is rounded once to the float32 destination;
+ *   - cv2.add: a CV_64F scalar against a CV_32F array is demoted to CV_32F, so the sum is a plain
+ *     float32 add of (float)mean.
+ * (UNPINNED: restated from OpenCV's arithm.cpp; cv2 is not available here to confirm.) */
 void bxo_denormalize_u8(const float* img, int Hc, int Wc, int img_h, int img_w,
                         const double mean[3], const double std[3], int to_rgb, uint8_t* out) {
     const int64_t P = (int64_t)Hc * Wc;
@@ -50,7 +54,8 @@ void bxo_denormalize_u8(const float* img, int Hc, int Wc, int img_h, int img_w,
         for (int y = 0; y < img_h && y < Hc; ++y)
             for (int x = 0; x < img_w && x < Wc; ++x) {
                 float t = (float)((double)src[(int64_t)y * Wc + x] * std[sc]);
-                float v = (float)((double)t + mean[sc]);
+                const float mf = (float)mean[sc];
+                float v = t + mf; /* t is already rounded to f32: no contraction possible */
                 dst[(int64_t)y * Wc + x] = (uint8_t)(int32_t)v; /* numpy astype(uint8) on x86 */
             }
     }

@@ -18,9 +18,9 @@ _lib = None
 
 def build(force: bool = False) -> str:
     """Compile the C oracle with the committed Makefile (gcc).  Returns the .so path."""
-    if force or not os.path.exists(_SO):
-        subprocess.run(['make', '-C', _HERE] + (['-B'] if force else []), check=True,
-                       stdout=subprocess.DEVNULL)
+    # always go through make (dependency-driven, a no-op when up to date) so an edited source is never
+    # checked against a stale library
+    subprocess.run(['make', '-C', _HERE] + (['-B'] if force else []), check=True, stdout=subprocess.DEVNULL)
     return _SO
 
 

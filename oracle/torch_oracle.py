@@ -89,16 +89,18 @@ def color_similarity(lab: torch.Tensor, mask: torch.Tensor, size: int, dilation:
 def denormalize_u8(img: torch.Tensor, img_shape: Sequence[int], mean, std, to_rgb: bool) -> torch.Tensor:
     """condinst_head.py:170-186.  img [3,Hc,Wc] normalised -> [3,img_h,img_w] float RGB in 0..255.
 
-    mmcv ``imdenormalize``: ``cv2.multiply(img, std_f64)`` then ``cv2.add(img, mean_f64)`` -- each a
-    double op rounded to the f32 image -- then optional RGB->BGR; ``astype(uint8)`` truncates; the
-    caller reverses channels again (:182).  Net channel map: c -> (c if to_rgb else 2-c).
+    mmcv ``imdenormalize``: ``cv2.multiply(img, std_f64)`` (OpenCV works in double for mul/div by a
+    scalar row and rounds once to the f32 image) then ``cv2.add(img, mean_f64)`` (OpenCV demotes a
+    float64 scalar to float32 against a float32 array: a plain f32 add) -- then optional RGB->BGR;
+    ``astype(uint8)`` truncates; the caller reverses channels again (:182).  Net channel map:
+    c -> (c if to_rgb else 2-c).
     """
     ih, iw = int(img_shape[0]), int(img_shape[1])
     x = img[:, :ih, :iw].detach().cpu().to(torch.float32).numpy()
     mean = np.asarray(mean, dtype=np.float64).reshape(3, 1, 1)
     std = np.asarray(std, dtype=np.float64).reshape(3, 1, 1)
     t = (x.astype(np.float64) * std).astype(np.float32)
-    v = (t.astype(np.float64) + mean).astype(np.float32)
+    v = t + mean.astype(np.float32)
     u8 = v.astype(np.int32).astype(np.uint8)
     if not to_rgb:
         u8 = u8[::-1]

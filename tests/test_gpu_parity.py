@@ -64,7 +64,7 @@ def test_pairwise_op_errors(dev):
 # ---------------------------------------------------------------------------------------------
 # target side
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('case', ['cfg1', 'ragged', 'bgr', 'stride8'])
+@pytest.mark.parametrize('case', ['cfg1', 'ragged', 'bgr', 'stride8', 'exact_pixels'])
 def test_color_affinity(dev, case):
     from boxinstseg_amd import color_affinity
     stride = 4
@@ -77,6 +77,8 @@ def test_color_affinity(dev, case):
         d = synthetic.make_batch(B=1, H=64, W=64, boxes_per_img=1, seed=4, min_box=16, max_box=32)
         d['img_metas'][0]['img_norm_cfg'] = dict(mean=np.array([103.53, 116.28, 123.675], np.float32),
                                                  std=np.array([1.0, 1.0, 1.0], np.float32), to_rgb=False)
+    elif case == 'exact_pixels':              # de-normalised values within an ulp of an integer
+        d = synthetic.make_batch(B=2, H=96, W=160, boxes_per_img=1, seed=6, min_box=16, max_box=64, pixel_offset=0.0)
     else:
         stride = 8
         d = synthetic.make_batch(B=1, H=128, W=192, boxes_per_img=1, seed=5, stride=8, min_box=16, max_box=64)

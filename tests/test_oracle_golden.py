@@ -131,6 +131,28 @@ def test_image_mask_and_pool():
     assert np.array_equal(c_oracle.pool_u8(u, 4), want)
 
 
+def test_denormalize_on_exact_pixels():
+    """Real images de-normalise to within an ulp of an integer, so the uint8 truncation sees every
+    rounding step (double multiply -> f32, then f32 add of (float)mean).  The C and the numpy
+    restatements must agree bit for bit there, and a few values are worked by hand."""
+    from boxinstseg_amd import synthetic
+    d = synthetic.make_batch(B=1, H=64, W=96, boxes_per_img=1, seed=11, min_box=16, max_box=32, pixel_offset=0.0)
+    mean, std = np.asarray(synthetic.MEAN, np.float64), np.asarray(synthetic.STD, np.float64)
+    for to_rgb in (True, False):
+        a = c_oracle.denormalize_u8(d['imgs'][0], 64, 96, mean, std, to_rgb)
+        b = to.denormalize_u8(torch.from_numpy(d['imgs'][0]), (64, 96), mean, std, to_rgb).numpy()
+        assert np.array_equal(a.astype(np.float32), b)
+    # hand-worked: x = f32((f32(u) - f32(mean)) / std); t = f32(double(x) * std); v = t + f32(mean)
+    for u, c in [(0, 0), (255, 0), (17, 1), (200, 2), (124, 0), (116, 1)]:
+        mf = np.float32(mean[c])
+        x = np.float32(np.float64(np.float32(u) - mf) * (1.0 / std[c]))
+        t = np.float32(np.float64(x) * std[c])
+        v = np.float32(t + mf)
+        img = np.zeros((3, 1, 1), np.float32); img[c, 0, 0] = x
+        got = c_oracle.denormalize_u8(img, 1, 1, mean, std, True)[c, 0, 0]
+        assert int(got) == int(v) and abs(int(got) - u) <= 1
+
+
 @pytest.mark.parametrize('case', ['a', 'b', 'c'])
 def test_dynamic_head_restatement_vs_reference(case):
     """oracle.torch_oracle.dynamic_mask_forward vs CondInstMaskHead.forward run from the reference source."""
