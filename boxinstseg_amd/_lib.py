@@ -101,7 +101,7 @@ SIGNATURES = {
     'bxi_tree_refine_backward_weight_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'bxi_tree_refine_backward_weight_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                                                    c_size_t, c_void_p]),
+                                                    c_void_p, c_size_t, c_void_p]),
 }
 
 LAUNCH_HOOK = C.CFUNCTYPE(None, C.c_char_p, c_int, c_void_p, c_void_p)

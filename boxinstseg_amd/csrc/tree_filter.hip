@@ -23,12 +23,13 @@ namespace bxi {
 typedef unsigned long long u64;
 typedef unsigned short u16;
 
-// One wave walks a tree level by level through LDS: its LDS operations execute in program order, so between two
-// levels only the compiler has to be held back and the outstanding LDS operations waited for -- not the global stores
-// of the level (a workgroup-scope fence waits for those too: ~1 us per level, hundreds of levels).
-__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// One wave walks a tree level by level through LDS.  Its LDS operations execute in program order, so between two levels
+// nothing has to be waited for -- neither the LDS writes just issued nor the global stores of the level (a workgroup-scope
+// fence waits for those too: ~1 us per level, hundreds of levels); only the compiler has to be held back
+// (`asm volatile("" ::: "memory")`).
 
-constexpr int kTfMaxV = 10240;     // LDS-resident vertex limit (96x96 = 9216 in the reference's _scale_target)
+constexpr int kTfThreads = 1024;   // bfs / refine workgroups: one wave walks, all of them stage the inputs and write the outputs
+constexpr int kTfMaxV = 10200;     // LDS-resident vertex limit (96x96 = 9216 in the reference's _scale_target)
 
 // ---------------------------------------------------------------------------------------------------
 // mst
@@ -125,14 +126,19 @@ __global__ __launch_bounds__(1024) void mst_kernel(const int* __restrict__ edge_
 
 // ---------------------------------------------------------------------------------------------------
 // bfs: levels[b] = { D, off_0 = 0, off_1, ..., off_D = V }
-__global__ __launch_bounds__(256) void bfs_kernel(const int* __restrict__ tree, int V, int max_adj, int* __restrict__ sorted_index,
+// The walk (one wave, ~600 dependent levels at 96x96) touches LDS only: a position holds (vertex | parent vertex << 16),
+// a level reads its nodes and their 4 neighbour slots, ranks the non-parent neighbours with ballots and writes them
+// behind the nodes found so far (invalid slots go to a trash word: no divergent branches).  Level offsets collect in a
+// register (lane = level mod 64).  The outputs -- sorted_index, sorted_parent (positions), sorted_child -- are written
+// afterwards by the whole workgroup from the LDS arrays.
+__global__ __launch_bounds__(kTfThreads) void bfs_kernel(const int* __restrict__ tree, int V, int max_adj, int* __restrict__ sorted_index,
                                                   int* __restrict__ sorted_parent, int* __restrict__ sorted_child,
                                                   int* __restrict__ levels) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bfs_raw[];
-    u16* adj = reinterpret_cast<u16*>(bfs_raw);        // [V][4]
-    u16* si = adj + (size_t)V * 4;                     // [V] vertex at a position
-    u16* pv = si + V;                                  // [V] parent vertex of the vertex at a position
-    unsigned char* deg = reinterpret_cast<unsigned char*>(pv + V);   // [V]
+    u16* adj = reinterpret_cast<u16*>(bfs_raw);                          // [V][4]
+    uint32_t* node = reinterpret_cast<uint32_t*>(adj + (size_t)V * 4);   // [V+1] vertex | parent vertex << 16; [V] = trash
+    unsigned char* deg = reinterpret_cast<unsigned char*>(node + V + 1); // [V]
+    __shared__ int n_found;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int* ed = tree + (int64_t)b * (V - 1) * 2;
     int* s_index = sorted_index + (int64_t)b * V;
@@ -140,11 +146,11 @@ __global__ __launch_bounds__(256) void bfs_kernel(const int* __restrict__ tree, 
     int* s_child = sorted_child + (int64_t)b * V * max_adj;
     int* lv = levels + (int64_t)b * (V + 2);
     unsigned int* deg32 = reinterpret_cast<unsigned int*>(deg);
-    for (int i = tid; i < (V + 3) / 4; i += 256) deg32[i] = 0u;
-    for (int i = tid; i < V * max_adj; i += 256) s_child[i] = 0;
+    for (int i = tid; i < (V + 3) / 4; i += kTfThreads) deg32[i] = 0u;
+    for (int i = tid; i < V * max_adj; i += kTfThreads) s_child[i] = 0;
     __syncthreads();
     // adjacency (degree <= 4): slots by byte-wise LDS atomics on the packed degree words
-    for (int e = tid; e < V - 1; e += 256) {
+    for (int e = tid; e < V - 1; e += kTfThreads) {
         const int u = ed[2 * e], v = ed[2 * e + 1];
         const unsigned su = (atomicAdd(&deg32[u >> 2], 1u << (8 * (u & 3))) >> (8 * (u & 3))) & 0xffu;
         const unsigned sv = (atomicAdd(&deg32[v >> 2], 1u << (8 * (v & 3))) >> (8 * (v & 3))) & 0xffu;
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256) void bfs_kernel(const int* __restrict__ tree, 
         if (sv < 4) adj[v * 4 + sv] = (u16)u;
     }
     __syncthreads();
-    for (int v = tid; v < V; v += 256) {                // arrival order of the atomics -> ascending neighbour ids
+    for (int v = tid; v < V; v += kTfThreads) {                // arrival order of the atomics -> ascending neighbour ids
         const int d = min((int)deg[v], 4);
         u16 a[4];
         for (int k = 0; k < 4; ++k) a[k] = k < d ? adj[v * 4 + k] : (u16)0xffff;
@@ -160,190 +166,279 @@ __global__ __launch_bounds__(256) void bfs_kernel(const int* __restrict__ tree, 
         for (int k = 0; k < 4; ++k) adj[v * 4 + k] = a[k];
     }
     __syncthreads();
-    if (tid >= 64) return;                              // one wave walks the levels (no workgroup barrier inside)
-    const int lane = tid;
-    if (lane == 0) { si[0] = 0; pv[0] = 0xffff; s_index[0] = 0; s_parent[0] = 0; lv[1] = 0; }
-    int lo = 0, hi = 1, n = 1, depth = 0;
-    while (lo < hi) {
-        for (int base = lo; base < hi; base += 64) {
-            const int i = base + lane;
-            int cur = 0, par = 0xffff, nch = 0;
-            u16 ch[4] = {0, 0, 0, 0};
-            if (i < hi) {
-                cur = si[i]; par = pv[i];
+    if (tid < 64) {                                     // one wave walks the levels (no barrier, no wait between levels)
+        const int lane = tid;
+        if (lane == 0) node[0] = 0u | (0xffffu << 16);
+        int lo = 0, hi = 1, n = 1, depth = 0;
+        int offs = 0;                                   // lane k: off[64 c + k] of the chunk c being filled (off[0] = 0)
+        while (lo < hi) {
+            for (int base = lo; base < hi; base += 64) {
+                const int i = base + lane;
+                const bool act = i < hi;
+                const uint32_t nd = node[min(i, V)];
+                const uint32_t cur = act ? (nd & 0xffffu) : 0u, par = nd >> 16;
                 const u64 a4 = *reinterpret_cast<const u64*>(adj + cur * 4);        // the 4 neighbour slots in one read
+                uint32_t nb[4]; int rank[4]; bool ok[4];
+                int nch = 0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const u16 a = (u16)(a4 >> (16 * k));
-                    if (a != 0xffff && a != par) {                                   // slot k -> child number nch (static indexing)
-                        if (nch == 0) ch[0] = a; else if (nch == 1) ch[1] = a; else if (nch == 2) ch[2] = a; else ch[3] = a;
-                        ++nch;
-                    }
+                    nb[k] = (uint32_t)(a4 >> (16 * k)) & 0xffffu;
+                    ok[k] = act && nb[k] != 0xffffu && nb[k] != par;
+                    rank[k] = nch;
+                    nch += ok[k] ? 1 : 0;
                 }
-            }
-            // exclusive prefix sum of nch (0..4) over the wave from three ballots: no LDS traffic
-            const u64 b0 = __ballot(nch & 1), b1 = __ballot(nch & 2), b2 = __ballot(nch & 4);
-            const u64 below = lane ? (~0ull >> (64 - lane)) : 0ull;
-            const int excl = __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
-            const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-            int pos = n + excl;
+                // exclusive prefix sum of nch (0..4) over the wave from three ballots: no LDS traffic
+                const u64 b0 = __ballot(nch & 1), b1 = __ballot(nch & 2), b2 = __ballot(nch & 4);
+                const u64 below = lane ? (~0ull >> (64 - lane)) : 0ull;
+                const int excl = __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
+                const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+                const int pos = n + excl;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k < nch) {
-                    si[pos + k] = ch[k]; pv[pos + k] = (u16)cur;
-                    s_index[pos + k] = ch[k]; s_parent[pos + k] = i;
-                    if (k < max_adj) s_child[i * max_adj + k] = pos + k;
-                }
+                for (int k = 0; k < 4; ++k) node[ok[k] ? pos + rank[k] : V] = nb[k] | (cur << 16);
+                n += total;
+                asm volatile("" ::: "memory");          // a wave's LDS operations execute in order: compiler barrier only
             }
-            n += total;
-            wave_lds_fence();                                          // LDS writes of this chunk before the next reads
+            ++depth;
+            if ((depth & 63) == 0) lv[1 + depth - 64 + lane] = offs;                 // chunk complete
+            offs = lane == (depth & 63) ? hi : offs;                                 // off[depth] = hi
+            lo = hi; hi = n;
         }
-        ++depth;
-        if (lane == 0) lv[1 + depth] = hi;
-        lo = hi; hi = n;
+        if (lane <= (depth & 63)) lv[1 + (depth & ~63) + lane] = offs;
+        if (lane == 0) { lv[0] = depth; n_found = n; }
     }
-    if (lane == 0) lv[0] = depth;
+    __syncthreads();
+    // ---- outputs -------------------------------------------------------------------------------------------------------
+    const int nf = n_found;                             // < V only for a disconnected input
+    u16* pos_of = adj;                                  // the adjacency is no longer needed
+    for (int p = tid; p < V; p += kTfThreads) {
+        const uint32_t nd = p < nf ? node[p] : 0u;
+        s_index[p] = (int)(nd & 0xffffu);
+        if (p < nf) pos_of[nd & 0xffffu] = (u16)p;
+    }
+    __syncthreads();
+    for (int p = tid; p < V; p += kTfThreads) {
+        if (p == 0 || p >= nf) { s_parent[p] = 0; continue; }
+        const uint32_t pv = node[p] >> 16;
+        const int pp = pos_of[pv];
+        s_parent[p] = pp;
+        int k = 0;                                      // rank among the (contiguous) siblings
+        while (k < 3 && p - k - 1 >= 1 && (node[p - k - 1] >> 16) == pv) ++k;
+        if (k < max_adj) s_child[pp * max_adj + k] = p;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// refine: one workgroup per (tree, channel); a traversal = leaf->root aggregation then root->leaf propagation
-struct TreeLds {
-    float* val;        // [V] values in sorted order (x -> U -> D, in place)
-    float* w;          // [V] edge weight to the parent
-    uint32_t* fc;      // [V] first child position | child count << 16 ... packed: pos (low 16 bits), count (bits 16..18)
-    u16* lv;           // [D+1] level offsets
-    int D;
+// refine: one workgroup per (tree, channel); a traversal = leaf->root aggregation then root->leaf propagation.  The walk
+// is a chain of ~2 x 600 dependent steps at 96x96 executed by ONE wave, so what counts is the number of instructions and
+// LDS round trips per level.  A node is one 16-byte LDS record
+//     { value of plane 0, value of plane 1, edge weight to the parent, first child | count << 14 | parent << 17 }
+// and two value planes ride the same walk:
+//   forward            plane 0 = ones (weight_sum), plane 1 = the channel
+//   backward (weight)  plane 0 = g / weight_sum,    plane 1 = g / weight_sum * feature_out
+// Level offsets are read 64 at a time into a register (lane k = off[64 c + k]) and picked with readlane; the chunk
+// after the current one is already in flight.  DIR = -1 reads off[first], off[first-1], ...; DIR = +1 ascends.
+template <int DIR>
+struct LevelReader {
+    const int* off; int D, lane, idx, chunk, cur, nxt;
+    __device__ __forceinline__ int fetch(int c) const { return (c >= 0 && c * 64 <= D) ? off[min(c * 64 + lane, D)] : 0; }
+    __device__ __forceinline__ void init(const int* o, int d, int l, int first) {
+        off = o; D = d; lane = l; idx = first; chunk = first >> 6;
+        cur = fetch(chunk); nxt = fetch(chunk + DIR);
+    }
+    __device__ __forceinline__ int next() {              // the offset at idx, then idx += DIR (clamped reads past the ends)
+        const int j = min(max(idx, 0), D);
+        if ((j >> 6) != chunk) { chunk = j >> 6; cur = nxt; nxt = fetch(chunk + DIR); }
+        idx += DIR;
+        return __builtin_amdgcn_readlane(cur, __builtin_amdgcn_readfirstlane(j & 63));
+    }
 };
 
-// U_i = x_i + sum_c w_c U_c (refine.cu:64-121), then D_0 = U_0, D_c = U_c (1 - w_c^2) + D_parent w_c (:17-62), in place.
-// Called by wave 0 only; `u_out` (sorted order, may be null) receives U before it is overwritten.
-__device__ __forceinline__ void tree_updown(const TreeLds& t, int V, int lane, float* __restrict__ u_out) {
-    // A level costs dependent LDS round trips, and there are ~1000 levels: the (up to 4, contiguous) children of a node
-    // are read unconditionally at clamped positions so that they travel together, and the bounds of the next level are
-    // read while this one is processed.
-    int lo = t.lv[t.D - 1], hi = t.lv[t.D];
-    for (int l = t.D - 1; l >= 0; --l) {
-        const int nlo = l ? t.lv[l - 1] : 0;
-        for (int i = lo + lane; i < hi; i += 64) {
-            const uint32_t f = t.fc[i];
-            const int c0 = f & 0xffffu, nc = f >> 16;
-            float v[4], w[4];
+constexpr int kRecPad = 4;       // records past the last node: the 4 child reads of a node are unconditional
+
+// U_i = x_i + sum_c w_c U_c (refine.cu:64-121; thread = parent, children contiguous), then D_0 = U_0,
+// D_c = U_c (1 - w_c^2) + D_parent w_c (:17-62; thread = child).  Called by ONE wave: its LDS operations execute in order,
+// so nothing is waited for between levels (compiler barrier only), and what a level needs that does not depend on the
+// previous one (child ranges going up, the children's own records going down) is fetched one level ahead -- one LDS round
+// trip per level.  The walk issues no global memory operation except the level-offset chunks: going down, a node's D
+// values replace the two fields nobody needs any more (its weight and its links), so the records end as
+// { U0, U1, D0, D1 } and the workgroup writes all outputs afterwards, coalesced.
+__device__ __forceinline__ void tree_updown2(float4* __restrict__ rec, const int* __restrict__ off, int D, int V, int lane) {
+    float* recf = reinterpret_cast<float*>(rec);
+    {
+        LevelReader<-1> rd; rd.init(off, D, lane, D);
+        int hi = rd.next(), lo = rd.next();
+        uint32_t fpre = __float_as_uint(recf[4 * min(lo + lane, V - 1) + 3]);
+        for (int l = D - 1; l >= 0; --l) {
+            const int nlo = rd.next();
+            const uint32_t fnext = __float_as_uint(recf[4 * min(nlo + lane, V - 1) + 3]);
+            bool first = true;
+            for (int i = lo + lane; i < hi; i += 64) {
+                const uint32_t f = first ? fpre : __float_as_uint(recf[4 * i + 3]);
+                first = false;
+                const int c0 = f & 0x3fffu, nc = (f >> 14) & 7u;
+                const float2 own = *reinterpret_cast<const float2*>(recf + 4 * i);
+                float4 ch[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const int c = min(c0 + k, V - 1); v[k] = t.val[c]; w[k] = t.w[c]; }
-            float acc = t.val[i];
+                for (int k = 0; k < 4; ++k) ch[k] = rec[c0 + k];
+                // all four reads are issued together and unconditionally (left alone, the compiler sinks the first one into
+                // an `nc != 0` branch: a second dependent round trip per level)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc += k < nc ? v[k] * w[k] : 0.f;
-            t.val[i] = acc;
-            if (u_out) u_out[i] = acc;
+                for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(ch[k].x), "+v"(ch[k].y), "+v"(ch[k].z));
+                float a0 = own.x, a1 = own.y;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a0 = k < nc ? a0 + ch[k].x * ch[k].z : a0;
+                    a1 = k < nc ? a1 + ch[k].y * ch[k].z : a1;
+                }
+                *reinterpret_cast<float2*>(recf + 4 * i) = make_float2(a0, a1);
+            }
+            asm volatile("" ::: "memory");
+            fpre = fnext; hi = lo; lo = nlo;
         }
-        wave_lds_fence();
-        hi = lo; lo = nlo;
     }
-    lo = 0; hi = t.lv[1];
-    for (int l = 0; l < t.D; ++l) {
-        const int nhi = l + 2 <= t.D ? t.lv[l + 2] : hi;
-        for (int i = lo + lane; i < hi; i += 64) {
-            const uint32_t f = t.fc[i];
-            const int c0 = f & 0xffffu, nc = f >> 16;
-            const float dp = t.val[i];
-            float v[4], w[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const int c = min(c0 + k, V - 1); v[k] = t.val[c]; w[k] = t.w[c]; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < nc) t.val[c0 + k] = v[k] * (1.f - w[k] * w[k]) + dp * w[k];
+    if (lane == 0) *reinterpret_cast<float2*>(recf + 2) = *reinterpret_cast<const float2*>(recf);   // D_root = U_root
+    asm volatile("" ::: "memory");
+    {
+        LevelReader<1> rd; rd.init(off, D, lane, 1);
+        int lo = rd.next(), hi = rd.next();                 // level 1 = [off[1], off[2])
+        float4 rpre = rec[min(lo + lane, V - 1)];
+        for (int l = 1; l < D; ++l) {
+            const int nhi = rd.next();
+            const float4 rnext = rec[min(hi + lane, V - 1)];
+            bool first = true;
+            for (int c = lo + lane; c < hi; c += 64) {
+                const float4 r = first ? rpre : rec[c];
+                first = false;
+                const int pp = (int)(__float_as_uint(r.w) >> 17);
+                const float2 dp = *reinterpret_cast<const float2*>(recf + 4 * pp + 2);
+                const float w = r.z, a = 1.f - w * w;
+                *reinterpret_cast<float2*>(recf + 4 * c + 2) = make_float2(r.x * a + dp.x * w, r.y * a + dp.y * w);
+            }
+            asm volatile("" ::: "memory");
+            rpre = rnext; lo = hi; hi = nhi;
         }
-        wave_lds_fence();
-        lo = hi; hi = nhi;
     }
 }
 
-struct RefineArgs {
-    const float* in;            // [B,C,V] vertex order
+struct RefinePlane {
+    const float* in;            // [B,C,V] vertex order; null = ones (a per-tree plane: outputs are [B,V], written by channel 0)
     const float* pre_div;       // [B,V] vertex order or null: in / pre_div      (grad_out / weight_sum, refine.cu:251)
     const float* pre_mul;       // [B,C,V] vertex order or null: ... * pre_mul   (feature_grad = grad_out_norm * feature_out, :324)
+    float* up_sorted;           // or null : U
+    float* down_sorted;         // or null : D in sorted order
+    float* down_vertex;         // or null : D in vertex order
+};
+
+struct RefineArgs {
+    RefinePlane pl[2];
     const float* edge_weight;   // [B,V] sorted order
     const int* sorted_index;    // [B,V]
     const int* sorted_child;    // [B,V,max_adj]
     const int* levels;          // [B,V+2]
-    float* up_sorted;           // [B,C,V] or null : U
-    float* down_sorted;         // [B,C,V] or null : D in sorted order
-    float* down_vertex;         // [B,C,V] or null : D in vertex order (feature_aggr / grad_feature)
-    float* out_vertex;          // [B,C,V] or null : D / weight_sum in vertex order (feature_out)
-    float* wsum_up_sorted;      // [B,V] or null   : the same traversal of ones (weight_sum_up)
-    float* wsum_vertex;         // [B,V]           : weight_sum (written when wsum_up_sorted != null, read for out_vertex)
-    int B, C, V, max_adj, with_ones;
+    float* out_vertex;          // [B,C,V] or null : D(plane 1) / D(plane 0) in vertex order (feature_out)
+    int B, C, V, max_adj;
+    int n_planes;               // 1 or 2
 };
 
-__global__ __launch_bounds__(256) void tree_refine_kernel(RefineArgs a) {
+__global__ __launch_bounds__(kTfThreads) void tree_refine_kernel(RefineArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_raw[];
     const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, V = a.V;
-    TreeLds t;
-    t.val = reinterpret_cast<float*>(tf_raw);
-    t.w = t.val + V;
-    t.fc = reinterpret_cast<uint32_t*>(t.w + V);
-    t.lv = reinterpret_cast<u16*>(t.fc + V);
+    float4* rec = reinterpret_cast<float4*>(tf_raw);
+    float* recf = reinterpret_cast<float*>(tf_raw);
+    uint32_t* recu = reinterpret_cast<uint32_t*>(tf_raw);
     const int* lv = a.levels + (int64_t)b * (V + 2);
-    t.D = lv[0];
     const int* si = a.sorted_index + (int64_t)b * V;
     const int* sc = a.sorted_child + (int64_t)b * V * a.max_adj;
     const float* ew = a.edge_weight + (int64_t)b * V;
-    __shared__ int bad;
-    if (tid == 0) bad = 0;
-    __syncthreads();
-    for (int i = tid; i <= t.D; i += 256) t.lv[i] = (u16)lv[1 + i];
-    for (int i = tid; i < V; i += 256) {
-        t.w[i] = i ? ew[i] : 0.f;                                   // weight[0] = 0 (refine.cu:38)
-        int c0 = 0, nc = 0;
-        for (int k = 0; k < a.max_adj; ++k) {
-            const int c = sc[i * a.max_adj + k];
-            if (c <= 0) break;
-            if (nc == 0) c0 = c; else if (c != c0 + nc) bad = 1;     // children must be contiguous (bxi_bfs_forward_i32 order)
-            ++nc;
-        }
-        t.fc[i] = (uint32_t)c0 | ((uint32_t)nc << 16);
-    }
-    __syncthreads();
-    const float poison = bad ? __builtin_nanf("") : 1.f;              // a foreign ordering fails loudly in the values
-    // ---- the traversal of ones: weight_sum_up / weight_sum (refine.cu:223-228) --------------------------------------
-    if (a.with_ones) {
-        for (int i = tid; i < V; i += 256) t.val[i] = poison;
-        __syncthreads();
-        float* wu = (ch == 0 && a.wsum_up_sorted) ? a.wsum_up_sorted + (int64_t)b * V : nullptr;
-        if (tid < 64) tree_updown(t, V, tid, wu);
-        __syncthreads();
-        if (ch == 0 && a.wsum_vertex)
-            for (int i = tid; i < V; i += 256) a.wsum_vertex[(int64_t)b * V + si[i]] = t.val[i];
-        __syncthreads();
-    }
-    // ---- the channel ------------------------------------------------------------------------------------------------
     const int64_t cb = ((int64_t)b * a.C + ch) * V;
-    // weight_sum of this tree in sorted order is in t.val right now (if with_ones): the division needs it per node, so the
-    // channel values are staged in registers first
-    constexpr int kPer = (kTfMaxV + 255) / 256;
-    float ws[kPer];
+    // ---- topology + inputs -> records ----------------------------------------------------------------------------------
+    // kStage nodes per thread at a time, every independent load of the batch issued before the gathers that depend on them
+    // (node by node, each of a thread's ~36 nodes costs a chain of two or three global round trips: ~100 us per launch)
+    constexpr int kStage = 5;
+    int bad = 0;
+    const RefinePlane pl0 = a.pl[0], pl1 = a.pl[1];
+    const bool two = a.n_planes > 1;
+    for (int base = tid; base < V + kRecPad; base += kTfThreads * kStage) {
+        int p[kStage], ch4[kStage][4];
+        float w[kStage];
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) { const int i = tid + j * 256; ws[j] = (a.with_ones && i < V) ? t.val[i] : 1.f; }
-    __syncthreads();
-    for (int i = tid; i < V; i += 256) {
-        const int p = si[i];
-        float x = a.in[cb + p];
-        if (a.pre_div) x /= a.pre_div[(int64_t)b * V + p];
-        if (a.pre_mul) x *= a.pre_mul[cb + p];
-        t.val[i] = x * poison;
+        for (int j = 0; j < kStage; ++j) {
+            const int i = min(base + j * kTfThreads, V - 1);
+            p[j] = si[i];
+            w[j] = ew[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ch4[j][k] = sc[i * a.max_adj + min(k, a.max_adj - 1)];
+        }
+        float x0[kStage], x1[kStage], d0[kStage], d1[kStage], m0[kStage], m1[kStage];
+#pragma unroll
+        for (int j = 0; j < kStage; ++j) {
+            x0[j] = pl0.in ? pl0.in[cb + p[j]] : 1.f;
+            d0[j] = (pl0.in && pl0.pre_div) ? pl0.pre_div[(int64_t)b * V + p[j]] : 1.f;
+            m0[j] = (pl0.in && pl0.pre_mul) ? pl0.pre_mul[cb + p[j]] : 1.f;
+            x1[j] = (two && pl1.in) ? pl1.in[cb + p[j]] : (two ? 1.f : 0.f);
+            d1[j] = (two && pl1.in && pl1.pre_div) ? pl1.pre_div[(int64_t)b * V + p[j]] : 1.f;
+            m1[j] = (two && pl1.in && pl1.pre_mul) ? pl1.pre_mul[cb + p[j]] : 1.f;
+        }
+#pragma unroll
+        for (int j = 0; j < kStage; ++j) {
+            const int i = base + j * kTfThreads;
+            if (i >= V + kRecPad) break;
+            if (i >= V) { rec[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            float v0 = x0[j], v1 = x1[j];
+            if (pl0.in && pl0.pre_div) v0 /= d0[j];
+            if (pl0.in && pl0.pre_mul) v0 *= m0[j];
+            if (two && pl1.in && pl1.pre_div) v1 /= d1[j];
+            if (two && pl1.in && pl1.pre_mul) v1 *= m1[j];
+            int c0 = 0, nc = 0;
+            bool open = true;                                        // children = the leading positive slots
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = ch4[j][k];
+                open = open && k < a.max_adj && c > 0;
+                if (open) {
+                    if (nc == 0) c0 = c; else if (c != c0 + nc) bad = 1;   // children must be contiguous (bxi_bfs_forward_i32 order)
+                    ++nc;
+                }
+            }
+            if (a.max_adj > 4 && sc[i * a.max_adj + 4] > 0) bad = 1;  // more than 4 children: not a tree on a grid
+            if (c0 + nc > V) { bad = 1; nc = 0; }
+            rec[i] = make_float4(v0, v1, i ? w[j] : 0.f /* weight[0] = 0 (refine.cu:38) */, __uint_as_float((uint32_t)c0 | ((uint32_t)nc << 14)));
+        }
+    }
+    const float poison = __syncthreads_or(bad) ? __builtin_nanf("") : 1.f;   // a foreign ordering fails loudly in the values
+    for (int i = tid; i < V; i += kTfThreads) {                              // parent position into the children's records
+        const uint32_t f = recu[4 * i + 3];
+        const int c0 = f & 0x3fffu, nc = (f >> 14) & 7u;
+        for (int k = 0; k < nc; ++k) recu[4 * (c0 + k) + 3] |= (uint32_t)i << 17;   // one writer per child
+        if (i == 0) { recf[0] *= poison; recf[1] *= poison; }
     }
     __syncthreads();
-    if (tid < 64) tree_updown(t, V, tid, a.up_sorted ? a.up_sorted + cb : nullptr);
+    // ---- the walk (one wave) -------------------------------------------------------------------------------------------
+    if (tid < 64) tree_updown2(rec, lv + 1, lv[0], V, tid);
     __syncthreads();
+    // ---- results -------------------------------------------------------------------------------------------------------
+    for (int base = tid; base < V; base += kTfThreads * kStage) {
+        int p[kStage];
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const int i = tid + j * 256;
-        if (i < V) {
-            const float d = t.val[i];
-            const int p = si[i];
-            if (a.down_sorted) a.down_sorted[cb + i] = d;
-            if (a.down_vertex) a.down_vertex[cb + p] = d;
-            if (a.out_vertex) a.out_vertex[cb + p] = d / ws[j];
+        for (int j = 0; j < kStage; ++j) p[j] = si[min(base + j * kTfThreads, V - 1)];
+#pragma unroll
+        for (int j = 0; j < kStage; ++j) {
+            const int i = base + j * kTfThreads;
+            if (i >= V) break;
+            const float4 r = rec[i];                                  // { U0, U1, D0, D1 }
+            const float2 d = make_float2(r.z, r.w);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const RefinePlane& pl = q ? pl1 : pl0;
+                if (q >= a.n_planes) continue;
+                const bool per_tree = pl.in == nullptr;
+                if (per_tree && ch != 0) continue;
+                const int64_t ob = per_tree ? (int64_t)b * V : cb;
+                if (pl.up_sorted) pl.up_sorted[ob + i] = q ? r.y : r.x;
+                if (pl.down_sorted) pl.down_sorted[ob + i] = q ? d.y : d.x;
+                if (pl.down_vertex) pl.down_vertex[ob + p[j]] = q ? d.y : d.x;
+            }
+            if (a.out_vertex) a.out_vertex[cb + p[j]] = d.y / d.x;
         }
     }
 }
@@ -377,7 +472,7 @@ __global__ __launch_bounds__(256) void tree_grad_weight_kernel(const float* __re
     grad_w[i] = acc;
 }
 
-static size_t refine_lds_bytes(int V) { return (size_t)V * 12 + 2 * (size_t)(V + 2); }
+static size_t refine_lds_bytes(int V) { return 16 * (size_t)(V + kRecPad); }
 
 }  // namespace bxi
 
@@ -409,14 +504,14 @@ int bxi_bfs_forward_i32(const int* tree_edges, int B, int V, int max_adj, int* s
     if (V > bxi::kTfMaxV || max_adj > 8) return BXI_ERR_UNSUPPORTED;
     if (B == 0) return BXI_OK;
     if (!tree_edges || !sorted_index || !sorted_parent || !sorted_child || !levels) return BXI_ERR_NULL_POINTER;
-    const size_t lds = (size_t)V * 8 + (size_t)V * 4 + (size_t)((V + 3) / 4) * 4 + 16;
+    const size_t lds = (size_t)V * 8 + (size_t)(V + 1) * 4 + (size_t)((V + 3) / 4) * 4 + 16;
     if (lds > 150 * 1024) return BXI_ERR_UNSUPPORTED;
     hipStream_t s = bxi::as_stream(stream);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bxi::bfs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { bxi::set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }
     }
-    BXI_LAUNCH("bfs", s, bxi::bfs_kernel, dim3(B), dim3(256), lds, s, tree_edges, V, max_adj, sorted_index, sorted_parent, sorted_child, levels);
+    BXI_LAUNCH("bfs", s, bxi::bfs_kernel, dim3(B), dim3(bxi::kTfThreads), lds, s, tree_edges, V, max_adj, sorted_index, sorted_parent, sorted_child, levels);
     return bxi::check_launch();
 }
 
@@ -424,38 +519,41 @@ static int launch_refine(bxi::RefineArgs& a, void* stream) {
     if (a.B < 0 || a.C <= 0 || a.V <= 1 || a.max_adj < 1) return BXI_ERR_BAD_SHAPE;
     if (a.V > bxi::kTfMaxV || a.C > 65535) return BXI_ERR_UNSUPPORTED;
     if (a.B == 0) return BXI_OK;
-    if (!a.in || !a.edge_weight || !a.sorted_index || !a.sorted_child || !a.levels) return BXI_ERR_NULL_POINTER;
+    if (!a.edge_weight || !a.sorted_index || !a.sorted_child || !a.levels) return BXI_ERR_NULL_POINTER;
+    for (int q = 0; q < a.n_planes; ++q)
+        if (q + 1 == a.n_planes && !a.pl[q].in) return BXI_ERR_NULL_POINTER;
     const size_t lds = bxi::refine_lds_bytes(a.V);
-    if (lds > 150 * 1024) return BXI_ERR_UNSUPPORTED;
+    if (lds > 160 * 1024) return BXI_ERR_UNSUPPORTED;
     hipStream_t s = bxi::as_stream(stream);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bxi::tree_refine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { bxi::set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }
     }
-    BXI_LAUNCH("tree_refine", s, bxi::tree_refine_kernel, dim3(a.B, a.C), dim3(256), lds, s, a);
+    BXI_LAUNCH("tree_refine", s, bxi::tree_refine_kernel, dim3(a.B, a.C), dim3(bxi::kTfThreads), lds, s, a);
     return bxi::check_launch();
 }
 
 int bxi_tree_refine_forward_f32(const float* feature_in, const float* edge_weight, const int* sorted_index, const int* sorted_child,
                                 const int* levels, int B, int C, int V, int max_adj, float* feature_out, float* feature_aggr,
                                 float* feature_aggr_up, float* weight_sum, float* weight_sum_up, void* stream) {
-    if (B > 0 && (!feature_out || !feature_aggr || !feature_aggr_up || !weight_sum || !weight_sum_up)) return BXI_ERR_NULL_POINTER;
+    if (B > 0 && (!feature_in || !feature_out || !feature_aggr || !feature_aggr_up || !weight_sum || !weight_sum_up)) return BXI_ERR_NULL_POINTER;
     bxi::RefineArgs a{};
-    a.in = feature_in; a.edge_weight = edge_weight; a.sorted_index = sorted_index; a.sorted_child = sorted_child; a.levels = levels;
-    a.up_sorted = feature_aggr_up; a.down_vertex = feature_aggr; a.out_vertex = feature_out;
-    a.wsum_up_sorted = weight_sum_up; a.wsum_vertex = weight_sum;
-    a.B = B; a.C = C; a.V = V; a.max_adj = max_adj; a.with_ones = 1;
+    a.edge_weight = edge_weight; a.sorted_index = sorted_index; a.sorted_child = sorted_child; a.levels = levels;
+    a.pl[0].up_sorted = weight_sum_up; a.pl[0].down_vertex = weight_sum;                       // the traversal of ones (refine.cu:223-228)
+    a.pl[1].in = feature_in; a.pl[1].up_sorted = feature_aggr_up; a.pl[1].down_vertex = feature_aggr;
+    a.out_vertex = feature_out;
+    a.B = B; a.C = C; a.V = V; a.max_adj = max_adj; a.n_planes = 2;
     return launch_refine(a, stream);
 }
 
 int bxi_tree_refine_backward_feature_f32(const float* grad_out, const float* edge_weight, const int* sorted_index,
                                          const int* sorted_child, const int* levels, const float* weight_sum, int B, int C, int V,
                                          int max_adj, float* grad_feature, void* stream) {
-    if (B > 0 && (!weight_sum || !grad_feature)) return BXI_ERR_NULL_POINTER;
+    if (B > 0 && (!grad_out || !weight_sum || !grad_feature)) return BXI_ERR_NULL_POINTER;
     bxi::RefineArgs a{};
-    a.in = grad_out; a.pre_div = weight_sum; a.edge_weight = edge_weight; a.sorted_index = sorted_index; a.sorted_child = sorted_child;
-    a.levels = levels; a.down_vertex = grad_feature;
-    a.B = B; a.C = C; a.V = V; a.max_adj = max_adj; a.with_ones = 0;
+    a.edge_weight = edge_weight; a.sorted_index = sorted_index; a.sorted_child = sorted_child; a.levels = levels;
+    a.pl[0].in = grad_out; a.pl[0].pre_div = weight_sum; a.pl[0].down_vertex = grad_feature;
+    a.B = B; a.C = C; a.V = V; a.max_adj = max_adj; a.n_planes = 1;
     return launch_refine(a, stream);
 }
 
@@ -468,7 +566,7 @@ int bxi_tree_refine_backward_weight_f32(const float* grad_out, const float* edge
                                         const int* sorted_parent, const int* sorted_child, const int* levels, const float* feature_out,
                                         const float* feature_aggr, const float* feature_aggr_up, const float* weight_sum,
                                         const float* weight_sum_up, int B, int C, int V, int max_adj, float* grad_weight,
-                                        void* workspace, size_t workspace_bytes, void* stream) {
+                                        float* grad_feature, void* workspace, size_t workspace_bytes, void* stream) {
     if (B < 0 || C <= 0 || V <= 1) return BXI_ERR_BAD_SHAPE;
     if (B == 0) return BXI_OK;
     if (!grad_out || !sorted_parent || !feature_out || !feature_aggr || !feature_aggr_up || !weight_sum || !weight_sum_up || !grad_weight)
@@ -478,13 +576,12 @@ int bxi_tree_refine_backward_weight_f32(const float* grad_out, const float* edge
     const size_t plane = (size_t)B * C * V;
     float* GU = reinterpret_cast<float*>(workspace); float* OG = GU + plane; float* FGU = OG + plane; float* OG2 = FGU + plane;
     bxi::RefineArgs a{};
-    a.in = grad_out; a.pre_div = weight_sum; a.edge_weight = edge_weight; a.sorted_index = sorted_index; a.sorted_child = sorted_child;
-    a.levels = levels; a.up_sorted = GU; a.down_sorted = OG;
-    a.B = B; a.C = C; a.V = V; a.max_adj = max_adj; a.with_ones = 0;
+    a.edge_weight = edge_weight; a.sorted_index = sorted_index; a.sorted_child = sorted_child; a.levels = levels;
+    // plane 0: g~ = g / weight_sum -> GU, OG (and, in vertex order, refine_backward_feature's result); plane 1: g~ * feature_out
+    a.pl[0].in = grad_out; a.pl[0].pre_div = weight_sum; a.pl[0].up_sorted = GU; a.pl[0].down_sorted = OG; a.pl[0].down_vertex = grad_feature;
+    a.pl[1].in = grad_out; a.pl[1].pre_div = weight_sum; a.pl[1].pre_mul = feature_out; a.pl[1].up_sorted = FGU; a.pl[1].down_sorted = OG2;
+    a.B = B; a.C = C; a.V = V; a.max_adj = max_adj; a.n_planes = 2;
     int rc = launch_refine(a, stream);
-    if (rc != BXI_OK) return rc;
-    a.pre_mul = feature_out; a.up_sorted = FGU; a.down_sorted = OG2;
-    rc = launch_refine(a, stream);
     if (rc != BXI_OK) return rc;
     hipStream_t s = bxi::as_stream(stream);
     const unsigned grid = (unsigned)(((int64_t)B * V + 255) / 256);

@@ -2,7 +2,7 @@
 ``mst`` / ``bfs`` / ``refine`` (``mmdet/ops/tree_filter/functions/*.py`` over ``tree_filter_cuda``) and the modules
 ``MinimumSpanningTree`` / ``TreeFilter2D`` (``mmdet/ops/tree_filter/modules/tree_filter.py:10-150``).
 Same names, argument order and return values; the glue between the native calls is torch on the GPU, as in the
-reference.  No CPU path.  Graphs of at most 10240 vertices (the reference filters 96x96 maps).
+reference.  No CPU path.  Graphs of at most 10200 vertices (the reference filters 96x96 maps).
 """
 from __future__ import annotations
 
@@ -120,19 +120,20 @@ class _Refine(torch.autograd.Function):
         g = g.to(torch.float32).contiguous()
         lib = _lib.load()
         gf = torch.empty_like(out)
-        with torch.cuda.device(dev):
-            _lib.check('bxi_tree_refine_backward_feature_f32', lib.bxi_tree_refine_backward_feature_f32(
-                g.data_ptr(), w.data_ptr(), si.data_ptr(), sc.data_ptr(), levels.data_ptr(), wsum.data_ptr(), B, C, V, A, gf.data_ptr(),
-                _stream(dev)))
         gw = None
-        if not ctx.low_tree:            # functions/refine.py:33-41: the low-level tree passes no gradient to its weights
+        if ctx.low_tree:                # functions/refine.py:33-41: the low-level tree passes no gradient to its weights
+            with torch.cuda.device(dev):
+                _lib.check('bxi_tree_refine_backward_feature_f32', lib.bxi_tree_refine_backward_feature_f32(
+                    g.data_ptr(), w.data_ptr(), si.data_ptr(), sc.data_ptr(), levels.data_ptr(), wsum.data_ptr(), B, C, V, A, gf.data_ptr(),
+                    _stream(dev)))
+        else:                           # both gradients from one launch (the weight gradient's first traversal is the feature gradient)
             gw = torch.empty_like(w)
             ws = torch.empty(max(lib.bxi_tree_refine_backward_weight_workspace_bytes(B, C, V), 16), dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
                 _lib.check('bxi_tree_refine_backward_weight_f32', lib.bxi_tree_refine_backward_weight_f32(
                     g.data_ptr(), w.data_ptr(), si.data_ptr(), sp.data_ptr(), sc.data_ptr(), levels.data_ptr(), out.data_ptr(),
-                    aggr.data_ptr(), aggr_up.data_ptr(), wsum.data_ptr(), wsum_up.data_ptr(), B, C, V, A, gw.data_ptr(), ws.data_ptr(),
-                    ws.numel(), _stream(dev)))
+                    aggr.data_ptr(), aggr_up.data_ptr(), wsum.data_ptr(), wsum_up.data_ptr(), B, C, V, A, gw.data_ptr(), gf.data_ptr(),
+                    ws.data_ptr(), ws.numel(), _stream(dev)))
             gw = gw.to(ctx.dtypes[1])
         return gf.to(ctx.dtypes[0]), gw, None, None, None, None, None
 

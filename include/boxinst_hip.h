@@ -293,7 +293,7 @@ int bxi_lcm_refine_f32(const float* aff, const float* phi, int N, int h, int w, 
  * 7. The `tree_filter` extension -- mmdet/ops/tree_filter: mst_forward (src/mst/mst.cu:93-118 +
  *    boruvka.cpp), bfs_forward (src/bfs/bfs.cu:92-135), refine_forward / refine_backward_feature /
  *    refine_backward_weight (src/refine/refine.cu:186-370), as bound by src/tree_filter.cpp.
- *    V <= 10240 vertices (everything a traversal touches is LDS-resident); larger: BXI_ERR_UNSUPPORTED.
+ *    V <= 10200 vertices (everything a traversal touches is LDS-resident); larger: BXI_ERR_UNSUPPORTED.
  * ===========================================================================================*/
 
 /* Minimum spanning trees of B graphs: edge_index [B,E,2] i32, edge_weight [B,E] f32 >= 0 -> edge_out [B,V-1,2] i32.
@@ -318,6 +318,9 @@ int bxi_bfs_forward_i32(const int* tree_edges, int B, int V, int max_adj, int* s
 int bxi_tree_refine_forward_f32(const float* feature_in, const float* edge_weight, const int* sorted_index, const int* sorted_child,
                                 const int* levels, int B, int C, int V, int max_adj, float* feature_out, float* feature_aggr,
                                 float* feature_aggr_up, float* weight_sum, float* weight_sum_up, void* stream);
+/* refine_backward_feature / refine_backward_weight.  The weight gradient's first traversal IS the feature gradient, so
+ * bxi_tree_refine_backward_weight_f32 also returns it when `grad_feature` [B,C,V] is non-null (one launch for both,
+ * two concurrent traversals); workspace: bxi_tree_refine_backward_weight_workspace_bytes(B, C, V). */
 int bxi_tree_refine_backward_feature_f32(const float* grad_out, const float* edge_weight, const int* sorted_index,
                                          const int* sorted_child, const int* levels, const float* weight_sum, int B, int C, int V,
                                          int max_adj, float* grad_feature, void* stream);
@@ -326,7 +329,7 @@ int bxi_tree_refine_backward_weight_f32(const float* grad_out, const float* edge
                                         const int* sorted_parent, const int* sorted_child, const int* levels, const float* feature_out,
                                         const float* feature_aggr, const float* feature_aggr_up, const float* weight_sum,
                                         const float* weight_sum_up, int B, int C, int V, int max_adj, float* grad_weight,
-                                        void* workspace, size_t workspace_bytes, void* stream);
+                                        float* grad_feature, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }
