@@ -10,12 +10,19 @@ Pinning status:
     oracle/_ref/libboruvka_ref.so (oracle/Makefile, target ``ref``); ``mst_edges`` (Kruskal under the total order
     (weight, edge index), i.e. the unique tree Boruvka's strict ``>`` comparisons select) is checked against it, and
     the edge sets it produced are committed in tests/golden/tree_filter.npz.
-  * BFS order: the reference's order depends on the arrival order of CUDA atomics (bfs.cu:72); any breadth-first
-    order is equally valid, downstream results do not depend on it.  Restated with children in adjacency order.
-  * refine (forward, backward w.r.t. feature and edge weight): refine.cu is CUDA + THC and cannot be compiled or run
-    here -> parity to the reference's execution is UNPINNED.  The restatement follows refine.cu's recurrences and is
-    validated against (a) the closed form they implement, out_i = sum_j S(i,j) x_j / sum_j S(i,j) with S the product
-    of the edge weights on the tree path i..j (brute force), and (b) torch autograd through that closed form.
+  * BFS order and refine (forward, backward w.r.t. feature and edge weight): PINNED to the reference's own KERNELS.
+    bfs.cu / refine.cu are CUDA + ATen/THC and cannot run here as they are, but their `__global__` functions are plain
+    C++ apart from the CUDA execution model, so oracle/Makefile (target ``ref``) compiles exactly those functions, from
+    the reference tree, against oracle/ref_wrap/cuda_on_cpu.h (one OS thread per CUDA thread of a block, barrier =
+    __syncthreads, fetch-add = atomicAdd) into oracle/_ref/libtreekernels_ref.so; the host functions around them (launch
+    shapes, the divisions between launches) are restated in oracle/ref_wrap/tree_kernels_wrap.cpp with line citations.
+    ``ref_bfs`` / ``ref_refine_*`` below run them; their outputs on seeded trees are committed in
+    tests/golden/tree_filter.npz (``refk_*`` keys) and the restatement is checked against them.  What this does not pin
+    is nvcc's FMA contraction (the kernels are compiled with contraction off): agreement is at fp32 rounding level.
+    The reference's BFS order depends on the arrival order of atomics (bfs.cu:72) -- any breadth-first order is equally
+    valid and everything downstream is compared in vertex order.  The restatement is additionally validated against
+    (a) the closed form refine implements, out_i = sum_j S(i,j) x_j / sum_j S(i,j) with S the product of the edge
+    weights on the tree path i..j (brute force), and (b) torch autograd through that closed form.
 """
 from __future__ import annotations
 
@@ -39,6 +46,57 @@ def ref_boruvka_mst(index: np.ndarray, weight: np.ndarray, V: int) -> np.ndarray
     lib.ref_boruvka_mst(ctypes.c_int(V), ctypes.c_int(len(w)), idx.ctypes.data_as(ctypes.c_void_p),
                         w.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
     return out
+
+
+_REFK = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref', 'libtreekernels_ref.so')
+
+
+def ref_kernels_available() -> bool:
+    return os.path.exists(_REFK)
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def ref_bfs(edges: np.ndarray, V: int, max_adj: int = 4):
+    """the reference's adj_vec_kernel + breadth_first_sort_kernel (bfs.cu:19-90) run on the CPU: edges [V-1,2] ->
+    sorted_index [V], sorted_parent [V], sorted_child [V,max_adj] (one valid arrival order of its atomics)"""
+    lib = ctypes.CDLL(_REFK)
+    e = np.ascontiguousarray(edges, np.int32).reshape(1, V - 1, 2)
+    si = np.zeros((1, V), np.int32); sp = np.zeros((1, V), np.int32); sc = np.zeros((1, V, max_adj), np.int32)
+    lib.ref_bfs_forward(_vp(e), 1, V, max_adj, _vp(si), _vp(sp), _vp(sc))
+    return si[0], sp[0], sc[0]
+
+
+def ref_refine_forward(x: np.ndarray, w: np.ndarray, si, sp, sc):
+    """the reference's refine_forward kernels (refine.cu:19-134 under :201-249): x [C,V] f32 vertex order, w [V] f32 ->
+    dict(out, aggr [C,V] vertex order, aggr_up [C,V] sorted, wsum [V] vertex, wsum_up [V] sorted), all f32"""
+    lib = ctypes.CDLL(_REFK)
+    C, V = x.shape
+    A = sc.shape[1]
+    xs = np.ascontiguousarray(x, np.float32); ws = np.ascontiguousarray(w, np.float32)
+    si_, sp_, sc_ = (np.ascontiguousarray(t, np.int32) for t in (si, sp, sc))
+    r = dict(out=np.zeros((C, V), np.float32), aggr=np.zeros((C, V), np.float32), aggr_up=np.zeros((C, V), np.float32),
+             wsum=np.zeros(V, np.float32), wsum_up=np.zeros(V, np.float32))
+    lib.ref_refine_forward(_vp(xs), _vp(ws), _vp(si_), _vp(sp_), _vp(sc_), 1, C, V, A, _vp(r['out']), _vp(r['aggr']),
+                           _vp(r['aggr_up']), _vp(r['wsum']), _vp(r['wsum_up']))
+    return r
+
+
+def ref_refine_backward(g: np.ndarray, w: np.ndarray, si, sp, sc, fwd: dict):
+    """the reference's refine_backward_feature / refine_backward_weight (refine.cu:251-370) on the tensors its forward
+    saved: g [C,V] -> (grad_feature [C,V] vertex order, grad_weight [V] sorted order)"""
+    lib = ctypes.CDLL(_REFK)
+    C, V = g.shape
+    A = sc.shape[1]
+    gs = np.ascontiguousarray(g, np.float32); ws = np.ascontiguousarray(w, np.float32)
+    si_, sp_, sc_ = (np.ascontiguousarray(t, np.int32) for t in (si, sp, sc))
+    gf = np.zeros((C, V), np.float32); gw = np.zeros(V, np.float32)
+    lib.ref_refine_backward_feature(_vp(ws), _vp(si_), _vp(sp_), _vp(sc_), _vp(fwd['wsum']), _vp(gs), 1, C, V, A, _vp(gf))
+    lib.ref_refine_backward_weight(_vp(ws), _vp(si_), _vp(sp_), _vp(sc_), _vp(fwd['out']), _vp(fwd['aggr']), _vp(fwd['aggr_up']),
+                                   _vp(fwd['wsum']), _vp(fwd['wsum_up']), _vp(gs), 1, C, V, A, _vp(gw))
+    return gf, gw
 
 
 def grid_edges(H: int, W: int) -> np.ndarray:

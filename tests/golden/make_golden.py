@@ -265,6 +265,22 @@ def main():
         idx = tfo.grid_edges(H, W)
         wt = tfo.grid_weights(fm)
         out.update({f'{name}_fm': fm, f'{name}_tree': tfo.ref_boruvka_mst(idx, wt, H * W)})
+    # bfs + refine by the reference's own CUDA kernels run on the CPU (oracle/_ref/libtreekernels_ref.so): its BFS order,
+    # the five tensors of refine_forward and both gradients, on the trees above (own generator: the draws above are untouched)
+    assert tfo.ref_kernels_available(), 'run `make -C oracle ref` first'
+    rk = np.random.default_rng(20240925)
+    for name, C in (('a', 3), ('b', 2), ('d', 1)):
+        tree = out[f'{name}_tree']
+        V = tree.shape[0] + 1
+        si, sp, sc = tfo.ref_bfs(tree, V, 4)
+        x = rk.standard_normal((C, V)).astype(np.float32)
+        w = np.exp(-rk.random(V) * (3.0 if name == 'b' else 0.5)).astype(np.float32)
+        g = rk.standard_normal((C, V)).astype(np.float32)
+        fwd = tfo.ref_refine_forward(x, w, si, sp, sc)
+        gf, gw = tfo.ref_refine_backward(g, w, si, sp, sc, fwd)
+        out.update({f'refk_{name}_si': si, f'refk_{name}_sp': sp, f'refk_{name}_sc': sc, f'refk_{name}_x': x, f'refk_{name}_w': w,
+                    f'refk_{name}_g': g, f'refk_{name}_gf': gf, f'refk_{name}_gw': gw})
+        out.update({f'refk_{name}_{k}': v for k, v in fwd.items()})
     np.savez_compressed(os.path.join(HERE, 'tree_filter.npz'), **out)
 
     # ---- Lab known answers (published CIE values) -------------------------------------------------------

@@ -1,7 +1,7 @@
 """GPU parity of the tree_filter extension: HIP mst / bfs / refine and the MinimumSpanningTree /
 TreeFilter2D modules against (a) the edge sets the reference's own boruvka.cpp produced (tests/golden/tree_filter.npz)
-and (b) the oracle restatement of bfs / refine (validated on the CPU against the closed form and autograd).  Through the
-C ABI."""
+(b) the outputs of the reference's own bfs.cu / refine.cu kernels (fixture refk_* keys, and live at 96x96 where
+oracle/_ref is present) and (c) the oracle restatement of bfs / refine.  Through the C ABI."""
 import os
 
 import numpy as np
@@ -120,6 +120,61 @@ def test_refine_forward_backward_vs_oracle(built, dev, H, W, C, B, low):
             gw = tfo.refine_backward_weight(x[b].astype(np.float64), g[b].astype(np.float64), w[b].astype(np.float64), sin[b], spn[b],
                                             scn[b], saved)
             assert np.abs(wd.grad[b].cpu().numpy() - gw).max() <= 1e-4 * max(np.abs(gw).max(), 1.0)
+
+
+def _hip_refine_per_vertex(dev, tree_np, x, w_vertex, g):
+    """HIP bfs + refine (forward, both gradients) on one tree; the edge weight of vertex v's edge to its parent is
+    w_vertex[v]; everything returned in vertex order"""
+    from boxinstseg_amd import bfs, refine
+    tree = torch.from_numpy(np.ascontiguousarray(tree_np, np.int32))[None].to(dev)
+    si, sp, sc = bfs(tree, 4)
+    sin = si[0].cpu().numpy()
+    xd = torch.from_numpy(x)[None].to(dev).requires_grad_(True)
+    wd = torch.from_numpy(np.ascontiguousarray(w_vertex[sin]))[None].to(dev).requires_grad_(True)
+    out = refine(xd, wd, si, sp, sc, False)
+    out.backward(torch.from_numpy(g)[None].to(dev))
+    gw = np.zeros_like(w_vertex)
+    gw[sin] = wd.grad[0].cpu().numpy()
+    return out[0].detach().cpu().numpy(), xd.grad[0].cpu().numpy(), gw
+
+
+@pytest.mark.parametrize('case', ['a', 'b', 'd'])
+def test_refine_vs_reference_kernels_fixture(built, dev, case):
+    """HIP bfs + refine against what the reference's OWN bfs.cu / refine.cu kernels produced (run on the CPU through
+    oracle/ref_wrap/cuda_on_cpu.h, committed as the refk_* keys): the BFS orders differ, the results per vertex must not."""
+    g = np.load(os.path.join(GOLD, 'tree_filter.npz'))
+    si = g[f'refk_{case}_si']
+    w_vertex = np.zeros_like(g[f'refk_{case}_w']); w_vertex[si] = g[f'refk_{case}_w']
+    out, gf, gw = _hip_refine_per_vertex(dev, g[f'{case}_tree'], g[f'refk_{case}_x'], w_vertex, g[f'refk_{case}_g'])
+    want_gw = np.zeros_like(w_vertex); want_gw[si] = g[f'refk_{case}_gw']
+    assert np.abs(out - g[f'refk_{case}_out']).max() <= 5e-6 * max(1.0, np.abs(g[f'refk_{case}_out']).max())
+    assert np.abs(gf - g[f'refk_{case}_gf']).max() <= 5e-6 * max(1.0, np.abs(g[f'refk_{case}_gf']).max())
+    assert np.abs(gw - want_gw).max() <= 2e-5 * max(1.0, np.abs(want_gw).max())
+
+
+@pytest.mark.skipif(not tfo.ref_kernels_available(), reason='oracle/_ref/libtreekernels_ref.so not built (make -C oracle ref)')
+def test_refine_vs_reference_kernels_live_96x96(built, dev):
+    """the same comparison at Box2Mask's size, the reference kernels run on this host's CPU (the .so travels with the
+    snapshot; built from the reference tree in the build container only)"""
+    from boxinstseg_amd import mst
+    rng = np.random.default_rng(77)
+    H = W = 96
+    V = H * W
+    idx = tfo.grid_edges(H, W)
+    fm = rng.standard_normal((3, H, W)).astype(np.float32)
+    tree = mst(torch.from_numpy(idx)[None].to(dev), torch.from_numpy(tfo.grid_weights(fm))[None].to(dev), V)[0].cpu().numpy()
+    r_si, r_sp, r_sc = tfo.ref_bfs(tree, V)
+    C = 2
+    x = rng.standard_normal((C, V)).astype(np.float32)
+    g = rng.standard_normal((C, V)).astype(np.float32)
+    w_vertex = np.exp(-rng.random(V) * 0.8).astype(np.float32)
+    fwd = tfo.ref_refine_forward(x, w_vertex[r_si], r_si, r_sp, r_sc)
+    r_gf, r_gw = tfo.ref_refine_backward(g, w_vertex[r_si], r_si, r_sp, r_sc, fwd)
+    want_gw = np.zeros(V, np.float32); want_gw[r_si] = r_gw
+    out, gf, gw = _hip_refine_per_vertex(dev, tree, x, w_vertex, g)
+    assert np.abs(out - fwd['out']).max() <= 1e-5 * max(1.0, np.abs(fwd['out']).max())
+    assert np.abs(gf - r_gf).max() <= 1e-5 * max(1.0, np.abs(r_gf).max())
+    assert np.abs(gw - want_gw).max() <= 1e-4 * max(1.0, np.abs(want_gw).max())
 
 
 def test_tree_filter_module_end_to_end(built, dev):

@@ -239,6 +239,55 @@ def test_tree_filter_mst_vs_reference_boruvka(case):
         assert _edge_set(tfo.ref_boruvka_mst(idx, wt, H * W)) == _edge_set(g[f'{case}_tree'])
 
 
+def _per_vertex(gw_sorted, si):
+    out = np.zeros_like(gw_sorted)
+    out[si] = gw_sorted
+    return out
+
+
+@pytest.mark.parametrize('case', ['a', 'b', 'd'])
+def test_tree_filter_refine_restatement_vs_reference_kernels(case):
+    """oracle restatement of bfs.cu / refine.cu == what the reference's own kernels produced (run on the CPU through
+    oracle/ref_wrap/cuda_on_cpu.h; fixture keys refk_*), on the reference's BFS order AND on the oracle's own order
+    (results are order-independent in vertex order); where oracle/_ref is built, a fresh run reproduces the fixture."""
+    from oracle import tree_filter_oracle as tfo
+    g = load('tree_filter.npz')
+    tree = g[f'{case}_tree']
+    V = tree.shape[0] + 1
+    si, sp, sc = g[f'refk_{case}_si'], g[f'refk_{case}_sp'], g[f'refk_{case}_sc']
+    # the reference's order is a valid parent-before-child order of the same tree
+    assert sorted(si.tolist()) == list(range(V)) and si[0] == 0 and (sp[1:] < np.arange(1, V)).all()
+    assert _edge_set(np.stack([si[1:], si[sp[1:]]], 1)) == _edge_set(tree)
+    for i in range(V):
+        for c in sc[i]:
+            assert c == 0 or sp[c] == i
+    x, w, gr = (g[f'refk_{case}_{k}'].astype(np.float64) for k in ('x', 'w', 'g'))
+    for order in ('reference', 'oracle'):
+        o_si, o_sp, o_sc = (si, sp, sc) if order == 'reference' else tfo.bfs_order(tree, V)
+        w_o = w if order == 'reference' else _per_vertex(w, si)[o_si]      # the same weight on the same tree edge
+        out, saved = tfo.refine_forward(x, w_o, o_si, o_sp, o_sc)
+        assert np.abs(out - g[f'refk_{case}_out']).max() < 2e-6 * max(1.0, np.abs(out).max())
+        aggr = np.empty_like(saved['D']); aggr[:, o_si] = saved['D']
+        assert np.abs(aggr - g[f'refk_{case}_aggr']).max() < 2e-6 * np.abs(aggr).max()
+        wsum = np.empty(V); wsum[o_si] = saved['WD']
+        assert np.abs(wsum - g[f'refk_{case}_wsum']).max() < 2e-6 * wsum.max()
+        if order == 'reference':
+            assert np.abs(saved['U'] - g[f'refk_{case}_aggr_up']).max() < 2e-6 * np.abs(saved['U']).max()
+            assert np.abs(saved['WU'] - g[f'refk_{case}_wsum_up']).max() < 2e-6 * saved['WU'].max()
+        gf = tfo.refine_backward_feature(gr, w_o, o_si, o_sp, o_sc, saved)
+        assert np.abs(gf - g[f'refk_{case}_gf']).max() < 2e-6 * max(1.0, np.abs(gf).max())
+        gw = _per_vertex(tfo.refine_backward_weight(x, gr, w_o, o_si, o_sp, o_sc, saved), o_si)
+        want = _per_vertex(g[f'refk_{case}_gw'].astype(np.float64), si)
+        assert np.abs(gw - want).max() < 5e-6 * max(1.0, np.abs(want).max())
+    if tfo.ref_kernels_available():
+        fwd = tfo.ref_refine_forward(g[f'refk_{case}_x'], g[f'refk_{case}_w'], si, sp, sc)
+        assert np.array_equal(fwd['out'], g[f'refk_{case}_out'])
+        gf2, gw2 = tfo.ref_refine_backward(g[f'refk_{case}_g'], g[f'refk_{case}_w'], si, sp, sc, fwd)
+        assert np.array_equal(gf2, g[f'refk_{case}_gf']) and np.array_equal(gw2, g[f'refk_{case}_gw'])
+        r_si, r_sp, r_sc = tfo.ref_bfs(tree, V)                            # arrival order may differ; validity must not
+        assert sorted(r_si.tolist()) == list(range(V)) and (r_sp[1:] < np.arange(1, V)).all()
+
+
 def test_tree_filter_refine_restatement_closed_form_and_autograd():
     """the recurrences of refine.cu restated (oracle) == the closed form they implement, and their gradients == autograd"""
     from oracle import tree_filter_oracle as tfo
