@@ -14,6 +14,9 @@
  *             executed in the build container -- see tests/golden/make_golden.py):
  *             pairwise term fwd/bwd, projection term, unfold order, colour similarity from Lab,
  *             loss glue, get_targets / get_bitmasks_from_boxes control flow.
+ *            The pairwise op is additionally pinned BIT FOR BIT (f32 and f64, forward and backward)
+ *            to the reference's own pairwise.cu kernels, compiled from the reference tree and run
+ *            on the CPU (oracle/ref_wrap/pairwise_kernels_wrap.cpp, tests/golden/pairwise_refk.npz).
  *   UNPINNED (third-party code that is NOT in the reference tree and not installed here):
  *             mmcv.image.tensor2imgs / imdenormalize (OpenCV arithmetic) and
  *             skimage.color.rgb2lab.  Both are restated from their published algorithms;

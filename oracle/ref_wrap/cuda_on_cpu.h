@@ -66,11 +66,34 @@ void launch(dim3 grid, dim3 block, F&& body, G&& before_each_block) {
 }
 template <class F>
 void launch(dim3 grid, dim3 block, F&& body) { launch(grid, block, body, [] {}); }
+
+// For kernels without __syncthreads(): the CUDA threads run one after another on the calling thread (one particular, fixed
+// interleaving of their atomics).
+template <class F>
+void launch_serial(dim3 grid, dim3 block, F&& body) {
+    gridDim = grid; blockDim = block;
+    for (unsigned bx = 0; bx < grid.x; ++bx)
+        for (unsigned t = 0; t < block.x; ++t) {
+            threadIdx = dim3(t); blockIdx = dim3(bx);
+            body();
+        }
+}
 }  // namespace cpu_cuda
 
 #define __global__ static
+#define __device__
+#define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static volatile
 static inline void __syncthreads() { cpu_cuda::g_barrier->wait(); }
 static inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 static inline int atomicAdd(volatile int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+template <class T>
+static inline T atomic_add_fp(T* p, T v) {
+    std::atomic_ref<T> a(*p);
+    T old = a.load();
+    while (!a.compare_exchange_weak(old, old + v)) {}
+    return old;
+}
+static inline float atomicAdd(float* p, float v) { return atomic_add_fp(p, v); }
+static inline double atomicAdd(double* p, double v) { return atomic_add_fp(p, v); }

@@ -16,10 +16,13 @@ Third-party hooks the reference calls but which are NOT in its tree and not inst
 supplied by the restatements in oracle/torch_oracle.py (so those two stay "parity unpinned"):
   tensor2imgs (mmcv)  -> torch_oracle.denormalize_u8       color.rgb2lab (scikit-image) -> torch_oracle.rgb2lab
 ``pairwise_nlog`` (the CUDA op; no CPU build exists) is bound to the reference's own pure-torch
-``compute_pairwise_term``, which the survey showed equal to a transcription of pairwise.cu to 1e-15.
+``compute_pairwise_term``; the CUDA kernels themselves are run separately, on the CPU, through oracle/ref_wrap
+(pairwise_refk.npz; likewise bfs.cu / refine.cu for the refk_* keys of tree_filter.npz -- the BFS order stored there
+depends on thread arrival, so regenerating that file changes its refk_* arrays, consistently).
 
 Fixtures (all small, float64 where the reference supports it):
   pairwise_f64.npz   logits, size/dilation cases -> compute_pairwise_term and its autograd gradient
+  pairwise_refk.npz  the same op by the reference's own pairwise.cu kernels run on the CPU (oracle/ref_wrap), f32 + f64
   project_f64.npz    logits, bitmasks            -> compute_project_term and gradient
   similarity.npz     lab, mask                   -> get_image_color_similarity
   loss_cfg1.npz      BASELINE configs[0] (1x256x256, 4 boxes): full CondInstMaskHead.loss, f32
@@ -119,6 +122,22 @@ def main():
     out['ext_logits'] = xe.numpy()[:, 0]
     out['ext_pairwise'] = ns.compute_pairwise_term(xe, 3, 1).numpy()
     np.savez_compressed(os.path.join(HERE, 'pairwise_f64.npz'), **out)
+
+    # ---- the same op by the reference's OWN pairwise.cu kernels, run on the CPU (oracle/_ref/libpairwise_ref.so) -------
+    # (own generator: the draws of the fixtures around this block are untouched)
+    from oracle import pairwise_ref as pr
+    assert pr.available(), 'run `make -C oracle ref` first (compiles the reference pairwise.cu kernels where they lie)'
+    rk = np.random.default_rng(20240926)
+    out = {}
+    for name, (dt, size, dil, shape) in {'f32_3_2': (np.float32, 3, 2, (3, 1, 19, 27)), 'f64_3_2': (np.float64, 3, 2, (2, 1, 16, 21)),
+                                         'f32_5_1': (np.float32, 5, 1, (2, 1, 13, 11)), 'f64_3_1': (np.float64, 3, 1, (1, 1, 9, 70))}.items():
+        lg = (3.0 * rk.standard_normal(shape)).astype(dt)
+        lg[0, 0, 0, :6] = [-90.0, 90.0, -21.0, 21.0, -45.0, 0.0]              # both branches of _logsig, saturation
+        pw = pr.forward(lg, size, dil)
+        gp = rk.standard_normal(pw.shape).astype(dt)
+        out.update({f'{name}_logits': lg, f'{name}_size': size, f'{name}_dil': dil, f'{name}_pairwise': pw, f'{name}_gp': gp,
+                    f'{name}_grad': pr.backward(lg, pw, gp, size, dil)})
+    np.savez_compressed(os.path.join(HERE, 'pairwise_refk.npz'), **out)
 
     # ---- projection term ---------------------------------------------------------------------------------
     x = torch.tensor(rng.standard_normal((3, 1, 12, 15)) * 2.0, dtype=torch.float64, requires_grad=True)

@@ -37,6 +37,41 @@ def test_pairwise_op(dev, dtype, tol, shape, size, dil):
     assert np.abs(got_g - want_g).max() <= 10 * tol * max(1.0, np.abs(want_g).max())
 
 
+@pytest.mark.parametrize('case', ['f32_3_2', 'f64_3_2', 'f32_5_1', 'f64_3_1'])
+def test_pairwise_op_vs_reference_kernels_fixture(dev, case):
+    """HIP op against what the reference's OWN pairwise.cu kernels produced (run on the CPU, tests/golden/pairwise_refk.npz)."""
+    import os
+    from boxinstseg_amd import pairwise_nlog
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'pairwise_refk.npz'))
+    x, size, dil = g[f'{case}_logits'], int(g[f'{case}_size']), int(g[f'{case}_dil'])
+    tol = 2e-6 if x.dtype == np.float32 else 1e-12
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    out = pairwise_nlog(xt, size, dil)
+    out.backward(torch.from_numpy(g[f'{case}_gp']).to(dev))
+    want, want_g = g[f'{case}_pairwise'], g[f'{case}_grad']
+    assert np.abs(out.detach().cpu().numpy() - want).max() <= tol * max(1.0, np.abs(want).max())
+    assert np.abs(xt.grad.cpu().numpy() - want_g).max() <= 10 * tol * max(1.0, np.abs(want_g).max())
+
+
+def test_pairwise_op_vs_reference_kernels_live_full_size(dev):
+    """BASELINE configs[1] size (32 x 200 x 256, window 3, dilation 2): the reference kernels run on this host's CPU
+    (oracle/_ref travels with the snapshot; built from the reference tree in the build container only)."""
+    from boxinstseg_amd import pairwise_nlog
+    from oracle import pairwise_ref as pr
+    if not pr.available():
+        pytest.skip('oracle/_ref/libpairwise_ref.so not built (make -C oracle ref)')
+    rng = np.random.default_rng(5)
+    x = (2.5 * rng.standard_normal((32, 1, 200, 256))).astype(np.float32)
+    want = pr.forward(x, 3, 2)
+    gp = rng.random(want.shape).astype(np.float32)
+    want_g = pr.backward(x, want, gp, 3, 2)
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    out = pairwise_nlog(xt, 3, 2)
+    out.backward(torch.from_numpy(gp).to(dev))
+    assert np.abs(out.detach().cpu().numpy() - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+    assert np.abs(xt.grad.cpu().numpy() - want_g).max() <= 2e-5 * max(1.0, np.abs(want_g).max())
+
+
 def test_pairwise_op_extreme_logits(dev):
     """|x| up to 200: log-space evaluation must not overflow (pairwise.cu:27-50)."""
     from boxinstseg_amd import pairwise_nlog

@@ -38,6 +38,24 @@ def test_pairwise_fwd_bwd_f64(case):
     assert np.abs(pw32 - g[f'{case}_pairwise']).max() < 2e-6 * max(1.0, np.abs(g[f'{case}_pairwise']).max())
 
 
+@pytest.mark.parametrize('case', ['f32_3_2', 'f64_3_2', 'f32_5_1', 'f64_3_1'])
+def test_pairwise_oracle_is_bit_equal_to_reference_kernels(case):
+    """The C oracle against the outputs of the reference's OWN pairwise.cu kernels (compiled from the reference tree against
+    oracle/ref_wrap/cuda_on_cpu.h and run on the CPU; fixture pairwise_refk.npz): forward AND backward bit for bit, in f32
+    and f64, saturated logits included (the backward's atomicAdds in CUDA-thread order = the oracle's scatter order).
+    Where oracle/_ref is built, a fresh run of the reference kernels reproduces the fixture."""
+    g = load('pairwise_refk.npz')
+    x, size, dil = g[f'{case}_logits'], int(g[f'{case}_size']), int(g[f'{case}_dil'])
+    pw = c_oracle.pairwise_nlog_fwd(x[:, 0], size, dil)
+    assert pw.dtype == x.dtype and np.array_equal(pw, g[f'{case}_pairwise'])
+    grad = c_oracle.pairwise_nlog_bwd(x[:, 0], g[f'{case}_pairwise'], g[f'{case}_gp'], size, dil)
+    assert np.array_equal(grad, g[f'{case}_grad'][:, 0])
+    from oracle import pairwise_ref as pr
+    if pr.available():
+        assert np.array_equal(pr.forward(x, size, dil), g[f'{case}_pairwise'])
+        assert np.array_equal(pr.backward(x, g[f'{case}_pairwise'], g[f'{case}_gp'], size, dil), g[f'{case}_grad'])
+
+
 def test_pairwise_extreme_logits_f64():
     g = load('pairwise_f64.npz')
     pw = c_oracle.pairwise_nlog_fwd(g['ext_logits'], 3, 1)
