@@ -38,11 +38,15 @@ def is_stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source into boxinstseg_amd/lib/libboxinst_hip.so; returns its path."""
     if force or is_stale():
+        import fcntl
         os.makedirs(LIB_DIR, exist_ok=True)
-        cmd = command()
-        if verbose:
-            print(' '.join(cmd))
-        subprocess.run(cmd, check=True)
+        with open(os.path.join(LIB_DIR, '.build.lock'), 'w') as lk:      # one builder at a time (ranks of a multi-GPU run)
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if force or is_stale():
+                cmd = command()
+                if verbose:
+                    print(' '.join(cmd))
+                subprocess.run(cmd, check=True)
     return LIB_PATH
 
 

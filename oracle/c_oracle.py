@@ -19,8 +19,12 @@ _lib = None
 def build(force: bool = False) -> str:
     """Compile the C oracle with the committed Makefile (gcc).  Returns the .so path."""
     # always go through make (dependency-driven, a no-op when up to date) so an edited source is never
-    # checked against a stale library
-    subprocess.run(['make', '-C', _HERE] + (['-B'] if force else []), check=True, stdout=subprocess.DEVNULL)
+    # checked against a stale library; under a file lock, so that concurrent test processes do not rebuild it at once
+    import fcntl
+    os.makedirs(os.path.join(_HERE, '_build'), exist_ok=True)
+    with open(os.path.join(_HERE, '_build', '.lock'), 'w') as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.run(['make', '-C', _HERE] + (['-B'] if force else []), check=True, stdout=subprocess.DEVNULL)
     return _SO
 
 
