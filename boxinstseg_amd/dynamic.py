@@ -75,3 +75,19 @@ def dynamic_mask_forward(feat, params, coors, level_inds, img_inds, sizes_of_int
         raise RuntimeError('in_stride must be a multiple of out_stride')
     return DynamicMaskHead.apply(feat, params, coors, level_inds, img_inds, sizes_of_interest, in_stride,
                                  in_stride // out_stride, disable_rel_coors)
+
+
+def aligned_bilinear(tensor, factor):
+    """The module-level ``aligned_bilinear(tensor, factor)`` of condinst_head.py:146-167 for the test-time path
+    (``simple_test`` up-samples the mask probabilities to the input resolution): output sample ``(y, x)`` sits at source
+    coordinate ``((y - factor // 2) / factor, (x - factor // 2) / factor)``, clamped to the map.  Composed of torch ops on
+    whatever device the tensor lives on; the training-time ``x factor`` step is fused into ``dyn_fwd_kernel`` instead."""
+    import torch.nn.functional as F
+    assert tensor.dim() == 4 and factor >= 1 and int(factor) == factor
+    if factor == 1:
+        return tensor
+    h, w = tensor.shape[2:]
+    x = F.pad(tensor, (0, 1, 0, 1), mode='replicate')
+    x = F.interpolate(x, size=(factor * h + 1, factor * w + 1), mode='bilinear', align_corners=True)
+    x = F.pad(x, (factor // 2, 0, factor // 2, 0), mode='replicate')
+    return x[:, :, :factor * h, :factor * w]

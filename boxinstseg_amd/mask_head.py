@@ -4,7 +4,8 @@ Drop-in for the reference's ``CondInstMaskHead`` (``mmdet/models/dense_heads/con
 as far as the box-supervised loss path is concerned: same registry name, same constructor keywords
 (``configs/boxinst/*.py`` build it unchanged), same parameters/buffers in the state dict
 (``param_conv.{weight,bias}``, ``_iter``, ``sizes_of_interest``), same ``loss`` / ``get_targets`` /
-``get_bitmasks_from_boxes`` signatures and return values (keys ``loss_prj`` / ``loss_pairwise``).
+``get_bitmasks_from_boxes`` signatures and return values (keys ``loss_prj`` / ``loss_pairwise``), and the methods
+``CondInst.forward_train`` / ``simple_test`` call around them: ``training_sample``, ``forward``, ``simple_test``.
 
 What is different on purpose:
   * nothing on the path leaves the device: no ``tensor2imgs`` / ``rgb2lab`` round trip, no
@@ -138,6 +139,55 @@ class CondInstMaskHead(nn.Module):
                                     in_stride=self.in_stride, out_stride=self.out_stride,
                                     disable_rel_coors=self.disable_rel_coors)
 
+    # ---- the callers either side of the path: instance sampling (training) and mask post-processing (test) -----
+    def training_sample(self, cls_scores, centernesses, param_preds, coors, level_inds, img_inds, gt_inds):
+        """condinst_head.py:1166-1232: pick the positive locations whose dynamic parameters become instances.
+
+        ``max_proposals``: the first ``min(max_proposals, P)`` positives in a random order (the reference draws
+        ``randperm`` of that count, not a random subset).  ``topk_per_img``: per image, every ground-truth box keeps its
+        ``max(int(topk_per_img / boxes_in_image), 1)`` best locations by ``sigmoid(cls).max * sigmoid(centerness)``;
+        output order = image, then box index, then (boxes over the quota) descending score / (others) location order --
+        the reference's nested Python loops, here as sorts with no host synchronisation per box.
+        Returns ``(param_preds [N,P], coors, level_inds, img_inds, gt_inds)``."""
+        def flat(ts):
+            return torch.cat([t.permute(0, 2, 3, 1).flatten(end_dim=2) for t in ts], dim=0)
+
+        params = flat(param_preds)
+        pos = (gt_inds != -1).nonzero(as_tuple=True)[0]
+        params, coors, level_inds, img_inds, gt_inds = (t[pos] for t in (params, coors, level_inds, img_inds, gt_inds))
+        n = params.size(0)
+        if self.max_proposals != -1:
+            keep = torch.randperm(min(self.max_proposals, n), device=params.device)
+        elif self.topk_per_img != -1:
+            score = flat(cls_scores)[pos].sigmoid().max(dim=1)[0] * flat(centernesses).reshape(-1)[pos].sigmoid()
+            keep = _topk_per_box(img_inds, gt_inds, score, self.topk_per_img)
+        else:       # the reference leaves `sampled_inds` unbound here (an exception); keep every positive instead
+            keep = torch.arange(n, device=params.device)
+        return params[keep], coors[keep], level_inds[keep], img_inds[keep], gt_inds[keep]
+
+    def simple_test(self, mask_feat, det_labels, det_params, det_coors, det_level_inds, img_metas, num_classes,
+                    rescale=False):
+        """condinst_head.py:1234-1286: masks of the detections -> per image, per class lists of uint8 [h,w] arrays."""
+        import numpy as np
+        from .dynamic import aligned_bilinear
+        counts = [int(p.size(0)) for p in det_params]
+        if sum(counts) == 0:
+            return [[[] for _ in range(num_classes)] for _ in img_metas]
+        img_inds = torch.cat([torch.full((c,), i, dtype=torch.long, device=mask_feat.device) for i, c in enumerate(counts)])
+        logits = self.forward(mask_feat, torch.cat(det_params), torch.cat(det_coors), torch.cat(det_level_inds), img_inds)
+        probs = aligned_bilinear(logits.sigmoid(), self.out_stride)
+        results = []
+        for cur, labels, meta in zip(probs.split(counts, dim=0), det_labels, img_metas):
+            ih, iw = meta['img_shape'][:2]
+            cur = cur[:, :, :ih, :iw]
+            if rescale and cur.size(0):
+                oh, ow = meta['ori_shape'][:2]
+                cur = torch.nn.functional.interpolate(cur, (oh, ow), mode='bilinear', align_corners=False)
+            masks = (cur.squeeze(1) > 0.5).cpu().numpy().astype(np.uint8)
+            lab = labels.detach().cpu().numpy()
+            results.append([masks[lab == c] for c in range(num_classes)])
+        return results
+
     # ---- targets ----------------------------------------------------------------------------------
     def get_targets(self, gt_bboxes, gt_masks, img, img_metas):
         """condinst_head.py:1345-1393 -> (similarities, bitmasks, bitmasks_full).
@@ -220,6 +270,29 @@ class CondInstMaskHead(nn.Module):
         bm = torch.cat([m[:, start::self.out_stride, start::self.out_stride] for m in gt_masks], dim=0)
         bm = bm[gt_inds].unsqueeze(1).to(mask_logits.dtype)
         return _dice(mask_logits.sigmoid(), bm).mean()
+
+
+def _topk_per_box(img_inds: torch.Tensor, gt_inds: torch.Tensor, score: torch.Tensor, topk_per_img: int) -> torch.Tensor:
+    """Indices kept by the ``topk_per_img`` rule of ``training_sample`` (condinst_head.py:1201-1225), in its order."""
+    n = score.numel()
+    if n == 0:
+        return torch.zeros(0, dtype=torch.long, device=score.device)
+    key = img_inds.long() * (int(gt_inds.max()) + 1) + gt_inds.long()          # (image, box), ascending like the loops
+    groups, inv = torch.unique(key, return_inverse=True)
+    size = torch.bincount(inv, minlength=groups.numel())
+    g_img = groups // (int(gt_inds.max()) + 1)
+    boxes_in_img = torch.bincount(g_img)                                        # distinct boxes with a positive, per image
+    quota = torch.clamp(torch.div(topk_per_img, boxes_in_img[g_img], rounding_mode='floor'), min=1)
+    over = (size > quota)[inv]
+    # inside a group: descending score if it is over its quota, location order otherwise
+    by_score = torch.empty_like(inv)
+    by_score[torch.argsort(score, descending=True, stable=True)] = torch.arange(n, device=score.device)
+    second = torch.where(over, by_score, torch.arange(n, device=score.device))
+    order = torch.argsort(second, stable=True)
+    order = order[torch.argsort(inv[order], stable=True)]
+    start = torch.cumsum(size, 0) - size
+    rank = torch.arange(n, device=score.device) - start[inv[order]]
+    return order[rank < quota[inv[order]]]
 
 
 def _dice(x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:

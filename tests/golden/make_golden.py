@@ -29,6 +29,8 @@ Fixtures (all small, float64 where the reference supports it):
   loss_ragged.npz    2 ragged images, 2 instances per box, warm-up 0.37
   lab_kat.npz        textbook CIE-Lab known answers for the rgb2lab restatement
   dynamic_head_f64.npz  CondInstMaskHead.forward (+ parse_dynamic_params, aligned_bilinear) and autograd gradients
+  training_sample.npz   CondInstMaskHead.training_sample (topk_per_img / max_proposals branches), inputs and selections
+  simple_test.npz       CondInstMaskHead.simple_test (test-time masks per image and class)
 """
 import os
 import sys
@@ -194,6 +196,65 @@ def main():
                     f'{name}_logits': y.detach().numpy(), f'{name}_g': g.numpy(), f'{name}_gfeat': feat.grad.numpy(),
                     f'{name}_gparams': params.grad.numpy()})
     np.savez_compressed(os.path.join(HERE, 'dynamic_head_f64.npz'), **out)
+
+    # ---- the callers either side of the path: training_sample and simple_test, the reference's own methods -------------
+    # (own generator: the draws of the fixtures around this block are untouched)
+    cns = rx.load(methods=('training_sample', 'simple_test', 'forward', 'parse_dynamic_params'), functions=('aligned_bilinear',))
+    rk = np.random.default_rng(20240927)
+    out = {}
+    for name, (topk, maxp) in {'topk64': (64, -1), 'topk8': (8, -1), 'topk3': (3, -1), 'maxp': (-1, 20)}.items():
+        B, levels, Ccls, P = 2, [(8, 10), (4, 5), (2, 3)], 5, 7
+        cls = [rk.standard_normal((B, Ccls, h, w)).astype(np.float32) for h, w in levels]
+        ctr = [rk.standard_normal((B, 1, h, w)).astype(np.float32) for h, w in levels]
+        par = [rk.standard_normal((B, P, h, w)).astype(np.float32) for h, w in levels]
+        n = sum(B * h * w for h, w in levels)
+        coors = rk.standard_normal((n, 2)).astype(np.float32)
+        lvl = rk.integers(0, 3, size=n)
+        img = np.concatenate([np.repeat(np.arange(B), h * w) for h, w in levels])
+        gt = rk.integers(0, 6, size=n)
+        gt = np.where(rk.random(n) < 0.35, -1, gt + 6 * img)             # indices into the batch-concatenated box list
+        class S:
+            pass
+        st = S()
+        st.max_proposals, st.topk_per_img = maxp, topk
+        torch.manual_seed(7)                                             # the max_proposals branch draws a randperm
+        got = cns.CondInstMaskHead_training_sample(st, [torch.from_numpy(a) for a in cls], [torch.from_numpy(a) for a in ctr],
+                                                   [torch.from_numpy(a) for a in par], torch.from_numpy(coors), torch.from_numpy(lvl),
+                                                   torch.from_numpy(img), torch.from_numpy(gt))
+        out.update({f'{name}_cfg': np.array([topk, maxp]), f'{name}_coors': coors, f'{name}_lvl': lvl, f'{name}_img': img, f'{name}_gt': gt})
+        for i, (a, b, c) in enumerate(zip(cls, ctr, par)):
+            out.update({f'{name}_cls{i}': a, f'{name}_ctr{i}': b, f'{name}_par{i}': c})
+        for key, t in zip(('o_params', 'o_coors', 'o_lvl', 'o_img', 'o_gt'), got):
+            out[f'{name}_{key}'] = t.numpy()
+    np.savez_compressed(os.path.join(HERE, 'training_sample.npz'), **out)
+
+    out = {}
+    for name, C, rescale in (('a', 16, False), ('b', 8, True)):
+        class S:
+            pass
+        st = S()
+        st.in_stride, st.out_stride, st.disable_rel_coors, st.dynamic_convs, st.dynamic_channels = 8, 4, False, 3, 8
+        st.dy_weights, st.dy_biases = [(C + 2) * 8, 64, 8], [8, 8, 1]
+        st.sizes_of_interest = torch.tensor([64, 128, 256, 512, 1024])
+        st.parse_dynamic_params = lambda p, st=st: cns.CondInstMaskHead_parse_dynamic_params(st, p)
+        st.forward = lambda *a, st=st: cns.CondInstMaskHead_forward(st, *a)
+        B, H, W, counts, ncls = 2, 6, 9, [3, 2], 4
+        feat = rk.standard_normal((B, C, H, W)).astype(np.float32)
+        params = [(rk.standard_normal((c, sum(st.dy_weights) + 17)) * 0.6).astype(np.float32) for c in counts]
+        coors = [rk.uniform(0, 8 * W, size=(c, 2)).astype(np.float32) for c in counts]
+        lvls = [rk.integers(0, 5, size=c) for c in counts]
+        labels = [rk.integers(0, ncls, size=c) for c in counts]
+        metas = [dict(img_shape=(41, 70, 3), ori_shape=(60, 101, 3)), dict(img_shape=(48, 72, 3), ori_shape=(33, 50, 3))]
+        res = cns.CondInstMaskHead_simple_test(st, torch.from_numpy(feat), [torch.from_numpy(a) for a in labels],
+                                               [torch.from_numpy(a) for a in params], [torch.from_numpy(a) for a in coors],
+                                               [torch.from_numpy(a) for a in lvls], metas, ncls, rescale=rescale)
+        out.update({f'{name}_feat': feat, f'{name}_rescale': np.array(int(rescale)), f'{name}_ncls': np.array(ncls),
+                    f'{name}_shapes': np.array([[m['img_shape'][:2], m['ori_shape'][:2]] for m in metas])})
+        for i in range(B):
+            out.update({f'{name}_params{i}': params[i], f'{name}_coors{i}': coors[i], f'{name}_lvl{i}': lvls[i], f'{name}_labels{i}': labels[i]})
+            for c in range(ncls):
+                out[f'{name}_masks{i}_{c}'] = np.asarray(res[i][c], np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'simple_test.npz'), **out)
 
     # ---- DiscoBox MeanField / dice_loss / mil_loss, the reference's own class and functions --------
     dns = rx.load_discobox()

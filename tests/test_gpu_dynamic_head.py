@@ -60,6 +60,33 @@ def test_dynamic_head_vs_oracle_large(dev, shape):
     assert _close(gp, pt.grad.numpy(), 5e-5)
 
 
+@pytest.mark.parametrize('case', ['a', 'b'])
+def test_simple_test_masks_vs_reference(dev, case):
+    """CondInstMaskHead.simple_test (HIP dynamic head + torch up-sampling) against the masks the reference's own
+    simple_test / forward / aligned_bilinear produced on the CPU (tests/golden/simple_test.npz); a probability within
+    float noise of 0.5 may land on the other side, so a handful of pixels per instance is tolerated."""
+    import boxinstseg_amd as bx
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'simple_test.npz'))
+    feat = torch.from_numpy(g[f'{case}_feat']).to(dev)
+    ncls, rescale = int(g[f'{case}_ncls']), bool(int(g[f'{case}_rescale']))
+    head = bx.CondInstMaskHead(in_channels=feat.size(1), in_stride=8, out_stride=4).to(dev)
+    metas = [dict(img_shape=tuple(int(v) for v in sh[0]) + (3,), ori_shape=tuple(int(v) for v in sh[1]) + (3,)) for sh in g[f'{case}_shapes']]
+    t = lambda k: torch.from_numpy(g[f'{case}_{k}']).to(dev)
+    res = head.simple_test(feat, [t(f'labels{i}') for i in range(2)], [t(f'params{i}') for i in range(2)], [t(f'coors{i}') for i in range(2)],
+                           [t(f'lvl{i}') for i in range(2)], metas, ncls, rescale=rescale)
+    assert len(res) == 2 and all(len(r) == ncls for r in res)
+    for i in range(2):
+        for c in range(ncls):
+            want = g[f'{case}_masks{i}_{c}']
+            got = np.asarray(res[i][c], np.uint8)
+            assert got.shape == want.shape and got.dtype == np.uint8
+            if want.size:
+                assert int((got != want).sum()) <= 3 * want.shape[0], (i, c)
+    empty = head.simple_test(feat, [t('labels0')[:0], t('labels1')[:0]], [t('params0')[:0], t('params1')[:0]], [t('coors0')[:0], t('coors1')[:0]],
+                             [t('lvl0')[:0], t('lvl1')[:0]], metas, ncls)
+    assert empty == [[[] for _ in range(ncls)] for _ in range(2)]
+
+
 def test_dynamic_head_module_and_errors(dev):
     from boxinstseg_amd import CondInstMaskHead
     head = CondInstMaskHead(in_channels=16, boxinst_enabled=True, max_proposals=-1, topk_per_img=64).to(dev)

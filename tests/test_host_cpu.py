@@ -95,6 +95,26 @@ def test_head_constructor_and_state_dict_match_reference_contract():
         bx.build_head(dict(type='NoSuchHead'))
 
 
+@pytest.mark.parametrize('case', ['topk64', 'topk8', 'topk3', 'maxp'])
+def test_training_sample_selects_what_the_reference_selects(case):
+    """CondInstMaskHead.training_sample (sorts, no per-box Python loop) == the reference's own method (AST-extracted and
+    run on the same inputs by tests/golden/make_golden.py): same instances in the same order, both branches."""
+    import boxinstseg_amd as bx
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'training_sample.npz'))
+    topk, maxp = (int(v) for v in g[f'{case}_cfg'])
+    head = bx.CondInstMaskHead(in_channels=16, max_proposals=maxp, topk_per_img=topk)
+    t = lambda k: torch.from_numpy(g[f'{case}_{k}'])
+    torch.manual_seed(7)
+    got = head.training_sample([t(f'cls{i}') for i in range(3)], [t(f'ctr{i}') for i in range(3)], [t(f'par{i}') for i in range(3)],
+                               t('coors'), t('lvl'), t('img'), t('gt'))
+    for key, a in zip(('o_params', 'o_coors', 'o_lvl', 'o_img', 'o_gt'), got):
+        assert np.array_equal(a.numpy(), g[f'{case}_{key}']), key
+    # no positive location at all: empty selections, no exception
+    none = head.training_sample([t(f'cls{i}') for i in range(3)], [t(f'ctr{i}') for i in range(3)], [t(f'par{i}') for i in range(3)],
+                                t('coors'), t('lvl'), t('img'), torch.full_like(t('gt'), -1))
+    assert none[0].shape == (0, 7) and none[4].numel() == 0
+
+
 def test_cpu_tensors_fail_loudly():
     import boxinstseg_amd as bx
     from boxinstseg_amd import synthetic
