@@ -71,6 +71,14 @@ class EvalSet:
         self.ws = torch.empty(lib.bxi_boxinst_eval_workspace_bytes(d['B'], d['H'], d['W'], d['stride'], N),
                               dtype=torch.uint8, device=dev)
         self.ones = torch.ones(2, device=dev)       # upstream gradients of loss_prj / loss_pairwise
+        # the two C-ABI argument lists, marshalled once (what a training loop that keeps its buffers would do): only the
+        # stream is appended per call
+        vp = C.c_void_p
+        self.eval_args = (C.byref(self.batch.struct), C.byref(self.inst.struct), C.c_int(3), C.c_int(2), C.c_float(0.3),
+                          C.c_float(1.0), vp(self.losses.data_ptr()), vp(self.grad.data_ptr()), vp(self.state.data_ptr()),
+                          vp(self.ws.data_ptr()), C.c_size_t(self.ws.numel()))
+        self.bwd_args = (C.byref(self.inst.struct), vp(self.ones.data_ptr()), vp(self.ones.data_ptr() + 4), C.c_int(2),
+                         vp(self.state.data_ptr()), vp(self.grad.data_ptr()))
 
 
 def main():
@@ -103,14 +111,11 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     SIZE, DIL, THRESH, WARM = 3, 2, 0.3, 1.0
 
+    assert (SIZE, DIL, THRESH, WARM) == (3, 2, 0.3, 1.0)          # what EvalSet marshalled
+    f_eval, f_bwd = lib.bxi_boxinst_eval_f32, lib.bxi_boxinst_loss_backward_f32
+
     def enqueue(s: EvalSet, st: int) -> None:
-        rc = lib.bxi_boxinst_eval_f32(C.byref(s.batch.struct), C.byref(s.inst.struct), SIZE, DIL, THRESH, WARM,
-                                      s.losses.data_ptr(), s.grad.data_ptr(), s.state.data_ptr(), s.ws.data_ptr(),
-                                      s.ws.numel(), st)
-        if rc == 0:
-            rc = lib.bxi_boxinst_loss_backward_f32(C.byref(s.inst.struct), s.ones.data_ptr(),
-                                                  s.ones.data_ptr() + 4, DIL, s.state.data_ptr(),
-                                                  s.grad.data_ptr(), st)
+        rc = f_eval(*s.eval_args, st) or f_bwd(*s.bwd_args, st)
         if rc != 0:
             raise RuntimeError(f'C ABI status {rc}: {_lib.status_string(rc)}')
 

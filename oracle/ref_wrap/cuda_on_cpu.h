@@ -17,22 +17,28 @@ static thread_local dim3 threadIdx, blockIdx;
 static dim3 blockDim, gridDim;
 
 namespace cpu_cuda {
+// The threads of a block are OS threads, but only ONE of them runs kernel code at any time: a thread holds the block's
+// mutex from the moment it starts until it returns, and gives it up only while it waits in __syncthreads().  Every
+// barrier phase of a thread is therefore atomic with respect to the others -- one of the interleavings the CUDA model
+// allows, and free of data races by construction.  (The kernels do contain races that are benign under warp execution,
+// e.g. bfs.cu publishes sorted_index[pos] before parent_index[pos] and a reader tests only the former; with freely running
+// OS threads that window is wide enough to corrupt the traversal.)
 class BlockBarrier {
   public:
     explicit BlockBarrier(int n) : alive_(n) {}
-    void wait() {
-        std::unique_lock<std::mutex> l(m_);
+    void enter() { lock_.lock(); }                  // start of a thread's kernel body
+    void wait() {                                   // __syncthreads(); the caller holds the mutex
         const unsigned g = gen_;
         if (++waiting_ == alive_) { waiting_ = 0; ++gen_; cv_.notify_all(); }
-        else cv_.wait(l, [&] { return gen_ != g; });
+        else cv_.wait(lock_, [&] { return gen_ != g; });
     }
-    void drop() {                                   // the calling thread has returned from the kernel
-        std::unique_lock<std::mutex> l(m_);
+    void leave() {                                  // the calling thread has returned from the kernel
         --alive_;
         if (alive_ > 0 && waiting_ == alive_) { waiting_ = 0; ++gen_; cv_.notify_all(); }
+        lock_.unlock();
     }
   private:
-    std::mutex m_; std::condition_variable cv_; int alive_, waiting_ = 0; unsigned gen_ = 0;
+    std::mutex lock_; std::condition_variable_any cv_; int alive_, waiting_ = 0; unsigned gen_ = 0;
 };
 static BlockBarrier* g_barrier = nullptr;
 
@@ -43,9 +49,10 @@ void run_block(dim3 block, unsigned bx, unsigned by, F&& body) {
     std::vector<std::thread> th;
     for (unsigned t = 0; t < block.x; ++t)
         th.emplace_back([&, t] {
+            bar.enter();
             threadIdx = dim3(t); blockIdx = dim3(bx, by);
             body();
-            bar.drop();
+            bar.leave();
         });
     for (auto& x : th) x.join();
     g_barrier = nullptr;

@@ -59,9 +59,47 @@ def _vp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+_POOL = None
+
+
+def _isolated(fn_name: str, *args):
+    """Run one of the ``_ref_*`` functions below in a separate (spawned, re-used) process: the emulated CUDA blocks are
+    64 real threads running foreign kernels, and a fault in there must fail one test, not take the test session down."""
+    global _POOL
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    if _POOL is None:
+        _POOL = cf.ProcessPoolExecutor(max_workers=1, mp_context=mp.get_context('spawn'))
+    try:
+        return _POOL.submit(_dispatch, fn_name, args).result(timeout=600)
+    except cf.process.BrokenProcessPool as e:
+        _POOL = None
+        raise RuntimeError(f'reference kernel emulation ({fn_name}) crashed in its worker process') from e
+
+
+def _dispatch(fn_name, args):
+    return globals()[fn_name](*args)
+
+
 def ref_bfs(edges: np.ndarray, V: int, max_adj: int = 4):
     """the reference's adj_vec_kernel + breadth_first_sort_kernel (bfs.cu:19-90) run on the CPU: edges [V-1,2] ->
     sorted_index [V], sorted_parent [V], sorted_child [V,max_adj] (one valid arrival order of its atomics)"""
+    return _isolated('_ref_bfs', np.asarray(edges), int(V), int(max_adj))
+
+
+def ref_refine_forward(x: np.ndarray, w: np.ndarray, si, sp, sc):
+    """the reference's refine_forward kernels (refine.cu:19-134 under :201-249): x [C,V] f32 vertex order, w [V] f32 ->
+    dict(out, aggr [C,V] vertex order, aggr_up [C,V] sorted, wsum [V] vertex, wsum_up [V] sorted), all f32"""
+    return _isolated('_ref_refine_forward', *(np.asarray(a) for a in (x, w, si, sp, sc)))
+
+
+def ref_refine_backward(g: np.ndarray, w: np.ndarray, si, sp, sc, fwd: dict):
+    """the reference's refine_backward_feature / refine_backward_weight (refine.cu:251-370) on the tensors its forward
+    saved: g [C,V] -> (grad_feature [C,V] vertex order, grad_weight [V] sorted order)"""
+    return _isolated('_ref_refine_backward', *(np.asarray(a) for a in (g, w, si, sp, sc)), fwd)
+
+
+def _ref_bfs(edges: np.ndarray, V: int, max_adj: int = 4):
     lib = ctypes.CDLL(_REFK)
     e = np.ascontiguousarray(edges, np.int32).reshape(1, V - 1, 2)
     si = np.zeros((1, V), np.int32); sp = np.zeros((1, V), np.int32); sc = np.zeros((1, V, max_adj), np.int32)
@@ -69,9 +107,7 @@ def ref_bfs(edges: np.ndarray, V: int, max_adj: int = 4):
     return si[0], sp[0], sc[0]
 
 
-def ref_refine_forward(x: np.ndarray, w: np.ndarray, si, sp, sc):
-    """the reference's refine_forward kernels (refine.cu:19-134 under :201-249): x [C,V] f32 vertex order, w [V] f32 ->
-    dict(out, aggr [C,V] vertex order, aggr_up [C,V] sorted, wsum [V] vertex, wsum_up [V] sorted), all f32"""
+def _ref_refine_forward(x: np.ndarray, w: np.ndarray, si, sp, sc):
     lib = ctypes.CDLL(_REFK)
     C, V = x.shape
     A = sc.shape[1]
@@ -84,9 +120,7 @@ def ref_refine_forward(x: np.ndarray, w: np.ndarray, si, sp, sc):
     return r
 
 
-def ref_refine_backward(g: np.ndarray, w: np.ndarray, si, sp, sc, fwd: dict):
-    """the reference's refine_backward_feature / refine_backward_weight (refine.cu:251-370) on the tensors its forward
-    saved: g [C,V] -> (grad_feature [C,V] vertex order, grad_weight [V] sorted order)"""
+def _ref_refine_backward(g: np.ndarray, w: np.ndarray, si, sp, sc, fwd: dict):
     lib = ctypes.CDLL(_REFK)
     C, V = g.shape
     A = sc.shape[1]
