@@ -382,6 +382,8 @@ __device__ __forceinline__ void stream_tile(const InstArgs& a, int dil, float th
 // grid: [N table waves][pooling waves][N*Ts streaming waves].  The table waves (per-instance
 // records + work list of box_kernel, incl. the colour-threshold predicate) carry dependent load
 // chains, so they go first, before the memory system is saturated; nothing in this launch waits for them.
+constexpr int kPoolStaggerTicks = 300;     // x 10 ns
+
 __global__ __launch_bounds__(64) void stage1_kernel(PoolArgs pa, int n_pool, InstArgs a, int dil, float thresh,
                                                     LossWs ws, float* __restrict__ g_logits, int vec) {
     __shared__ double lut[256];
@@ -392,8 +394,19 @@ __global__ __launch_bounds__(64) void stage1_kernel(PoolArgs pa, int n_pool, Ins
     } else if ((int)blockIdx.x >= n_tab + n_pool) {
         stream_tile(a, dil, thresh, ws, g_logits, vec, (int)blockIdx.x - n_tab - n_pool);
     } else {
+        // Every wave of this launch gets its data at about the same time (the loads of all of them saturate HBM for ~5 us)
+        // and only then starts its arithmetic, so the SIMDs idle for 5 us and are oversubscribed afterwards.  There are 1.5
+        // pooling waves per SIMD (the heavy ones: fp64 Lab); the dispatcher hands out workgroups round-robin, so pooling
+        // waves r and r + 1024 share a SIMD.  The second of each pair holds its loads back by ~3 us: its data then arrives
+        // when its mate is finishing, and its arithmetic runs on a SIMD that is free again (stage1 10.5 -> 9.7 us; the
+        // optimum is flat between 2.3 and 3.5 us; no effect on the streaming waves, which the delay would only hurt).
+        const int r = (int)blockIdx.x - n_tab;
+        if ((r >> 10) & 1) {
+            const uint64_t t0 = wall_clock64();                       // 100 MHz
+            while ((int)(wall_clock64() - t0) < kPoolStaggerTicks) __builtin_amdgcn_s_sleep(2);
+        }
         const int64_t total = (int64_t)pa.B * (pa.Hc >> 2) * (pa.Wc >> 2);
-        const int64_t o = (int64_t)((int)blockIdx.x - n_tab) * 64 + threadIdx.x;
+        const int64_t o = (int64_t)r * 64 + threadIdx.x;
         PoolRegs pr;
         if (o < total) pool_load_s4(pa, o, pr);          // 12 x 16 B per lane in flight ...
 #pragma unroll
