@@ -26,6 +26,15 @@ def _close(got, want, tol):
     return np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1e-30)
 
 
+def _close_except_kinks(got, want, tol, groups, max_groups=2):
+    """Like _close, but a ReLU pre-activation that is zero to within fp32 rounding (seen once in ~10 000 random
+    instance-pixels: 6.8e-8 in fp64, <= 0 in fp32) gates one hidden unit differently and changes the gradient of that
+    one (instance, pixel): mismatches confined to at most `max_groups` groups (`groups` = the group id of every element:
+    the pixel for d feat, the instance for d params) are tolerated."""
+    bad = np.abs(got - want) > tol * max(np.abs(want).max(), 1e-30)
+    return len(np.unique(groups[bad])) <= max_groups
+
+
 @pytest.mark.parametrize('case', ['a', 'b', 'c'])
 def test_dynamic_head_vs_reference_fixture(dev, case):
     g = np.load(os.path.join(G, 'dynamic_head_f64.npz'))
@@ -141,5 +150,7 @@ def test_dynamic_head_fuzz(dev, seed):
     yo.backward(f64(g))
     cfg = f'B{B} C{C} {H}x{W} N{N} f{fac} rel{not no_rel}'
     assert _close(y.detach().cpu().numpy(), yo.detach().numpy(), 3e-5), cfg
-    assert _close(f.grad.cpu().numpy(), ft.grad.numpy(), 1e-4), cfg
-    assert _close(p.grad.cpu().numpy(), pt.grad.numpy(), 1e-4), cfg
+    pix = np.broadcast_to(np.arange(B * H * W).reshape(B, 1, H, W), feat.shape)
+    inst = np.broadcast_to(np.arange(N)[:, None], params.shape)
+    assert _close_except_kinks(f.grad.cpu().numpy(), ft.grad.numpy(), 1e-4, pix), cfg
+    assert _close_except_kinks(p.grad.cpu().numpy(), pt.grad.numpy(), 1e-4, inst), cfg
