@@ -344,6 +344,100 @@ __global__ __launch_bounds__(1024) void lcm_adjoint_lds_kernel(const float* __re
     for (int p = tid; p < hw; p += 1024) gphi[(int64_t)n * hw + p] = g[p];
 }
 
+// The adjoint for maps of at most kLcmPPT * kLcmThreads pixels, coefficients in registers: the SCATTER form.  The forward
+// reads pad(phi)[p + delta_k] with coefficient aff_k[p], so the adjoint adds aff_k[p] g[p] to padded position p + delta_k: for
+// a fixed tap k no two pixels hit the same position, so the eight taps are eight barrier-separated passes of plain LDS
+// read-modify-writes (no atomics; a position accumulates its terms in tap order, exactly like the gather above), with the
+// thread's own coefficients and g values in registers -- no global traffic inside the iterations (the gather re-reads the
+// eight coefficient planes from L2 every iteration: 144 us -> see DESIGN 3.7).
+constexpr int kLcmAdjThreads = 1024;  // 9 pixels per thread: 72 coefficient registers
+constexpr int kLcmAdjPPT = 9;
+constexpr int kLcmBorderPer = 1;       // border pixels per thread: 2h + 2w - 4 <= 1024 is checked on the host
+
+__global__ __launch_bounds__(kLcmAdjThreads) void lcm_adjoint_cached_kernel(const float* __restrict__ aff, const float* __restrict__ gout,
+                                                                         int h, int w, int d, int iters, float* __restrict__ gphi) {
+    extern __shared__ __attribute__((aligned(16))) float lcm_planes[];   // g [h*w] | gp [(h+2d)*(w+2d)]
+    const int n = blockIdx.x, tid = threadIdx.x, hw = h * w, hp = h + 2 * d, wp = w + 2 * d;
+    float* g = lcm_planes;
+    float* gp = lcm_planes + hw;
+    const float* A = aff + (int64_t)n * 8 * hw;
+    float coef[kLcmAdjPPT][8];
+    int sp[kLcmAdjPPT];            // position of the pixel in the padded plane; -1: no pixel
+    unsigned border = 0;           // bit j: pixel j lies on the first / last row or column (its padding folds back onto it)
+#pragma unroll
+    for (int j = 0; j < kLcmAdjPPT; ++j) {
+        const int p = tid + j * kLcmAdjThreads;
+        sp[j] = -1;
+        if (p < hw) {
+            const int r = p / w, c = p % w;
+            g[p] = gout[(int64_t)n * hw + p];
+            sp[j] = (r + d) * wp + c + d;
+            if (r == 0 || r == h - 1 || c == 0 || c == w - 1) border |= 1u << j;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) coef[j][k] = A[(int64_t)k * hw + p];
+        }
+    }
+    // tap 0 (dy = dx = -1) lands on padded rows [0, h) x columns [0, w) and STORES there; the rest of the padded plane (the
+    // last 2d rows and columns, fewer positions than threads at 96 x 96) is zeroed in the same phase: no clearing pass
+    const int n_clear = hp * wp - hw, rows_part = 2 * d * wp;
+    // border pixel number e * threads + tid of the perimeter walk: top row, bottom row, then the two side columns
+    int bq[kLcmBorderPer], b_r[kLcmBorderPer], b_c[kLcmBorderPer];
+#pragma unroll
+    for (int e = 0; e < kLcmBorderPer; ++e) {
+        const int t = tid + e * kLcmAdjThreads, n_border = 2 * w + 2 * max(h - 2, 0);
+        bq[e] = -1; b_r[e] = 0; b_c[e] = 0;
+        if (t < n_border && (h > 1 || t < w)) {
+            int r, c;
+            if (t < w) { r = 0; c = t; }
+            else if (t < 2 * w) { r = h - 1; c = t - w; }
+            else { const int u = t - 2 * w; r = 1 + (u >> 1); c = (u & 1) ? w - 1 : 0; }
+            if (!(w == 1 && t >= 2 * w && (t & 1))) {               // a one-column map: the two side columns coincide
+                bq[e] = r * w + c;
+                b_r[e] = (r == 0 ? 0 : r + d) | ((r == h - 1 ? hp - 1 : r + d) << 16);
+                b_c[e] = (c == 0 ? 0 : c + d) | ((c == w - 1 ? wp - 1 : c + d) << 16);
+            }
+        }
+    }
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        for (int s = tid; s < n_clear; s += kLcmAdjThreads)
+            gp[s < rows_part ? h * wp + s : ((s - rows_part) / (2 * d)) * wp + w + (s - rows_part) % (2 * d)] = 0.f;
+        float gv[kLcmAdjPPT];
+#pragma unroll
+        for (int j = 0; j < kLcmAdjPPT; ++j) gv[j] = sp[j] == -1 ? 0.f : g[tid + j * kLcmAdjThreads];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int dy, dx; lcm_offset(k, dy, dx);
+            int off = dy * d * wp + dx * d;
+            asm volatile("" : "+s"(off));      // keeps the (pixel, tap) addresses from being hoisted out of the iterations: spills
+            // within one tap the targets are distinct: all reads first, then all writes (written as `+=` per pixel the
+            // compiler must assume aliasing and waits for every LDS round trip in turn)
+            float old[kLcmAdjPPT];
+#pragma unroll
+            for (int j = 0; j < kLcmAdjPPT; ++j) old[j] = (k == 0 || sp[j] == -1) ? 0.f : gp[sp[j] + off];
+#pragma unroll
+            for (int j = 0; j < kLcmAdjPPT; ++j)
+                if (sp[j] != -1) gp[sp[j] + off] = old[j] + coef[j][k] * gv[j];
+            __syncthreads();
+        }
+        // fold the replicate padding back: an interior pixel reads its one padded position (its owner does that); the
+        // 2h + 2w - 4 border pixels sum the padded positions that replicate them (rows / columns ascending, as the gather
+        // kernel does), one border pixel per thread, ranges computed once before the iterations
+#pragma unroll
+        for (int j = 0; j < kLcmAdjPPT; ++j)
+            if (sp[j] != -1 && !((border >> j) & 1u)) g[tid + j * kLcmAdjThreads] = 0.f + gp[sp[j]];
+        for (int e = 0; e < kLcmBorderPer; ++e) {
+            if (bq[e] < 0) continue;
+            float acc = 0.f;
+            for (int sr = b_r[e] & 0xffff; sr <= (b_r[e] >> 16); ++sr)
+                for (int sc = b_c[e] & 0xffff; sc <= (b_c[e] >> 16); ++sc) acc += gp[sr * wp + sc];
+            g[bq[e]] = acc;
+        }
+        __syncthreads();
+    }
+    for (int p = tid; p < hw; p += kLcmAdjThreads) gphi[(int64_t)n * hw + p] = g[p];
+}
+
 // any size: one launch per iteration, planes in global memory
 template <bool ADJ>
 __global__ __launch_bounds__(256) void lcm_refine_step_kernel(const float* __restrict__ aff, const float* __restrict__ src, int N, int h,
@@ -447,6 +541,13 @@ int bxi_lcm_refine_f32(const float* aff, const float* phi, int N, int h, int w, 
         }
     } else {
         const size_t lds_adj = sizeof(float) * ((size_t)h * w + (size_t)(h + 2 * dilation) * (w + 2 * dilation));
+        if ((int64_t)h * w <= bxi::kLcmAdjPPT * bxi::kLcmAdjThreads && lds_adj <= 128 * 1024 && h >= 2 && w >= 2 &&
+            2 * h + 2 * w - 4 <= bxi::kLcmBorderPer * bxi::kLcmAdjThreads) {
+            const int rc = allow_lds(reinterpret_cast<const void*>(bxi::lcm_adjoint_cached_kernel), lds_adj);
+            if (rc != BXI_OK) return rc;
+            BXI_LAUNCH("lcm_adjoint", s, bxi::lcm_adjoint_cached_kernel, dim3(N), dim3(bxi::kLcmAdjThreads), lds_adj, s, aff, phi, h, w, dilation, iters, out);
+            return bxi::check_launch();
+        }
         if (lds_adj <= 128 * 1024) {
             const int rc = allow_lds(reinterpret_cast<const void*>(bxi::lcm_adjoint_lds_kernel), lds_adj);
             if (rc != BXI_OK) return rc;
