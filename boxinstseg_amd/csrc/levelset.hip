@@ -34,7 +34,7 @@ constexpr int kLsSlices = 8;      // workgroups per instance in the forward (a s
 
 __global__ __launch_bounds__(1024) void levelset_partial_kernel(const float* __restrict__ ms, const float* __restrict__ tg, int N, int C,
                                                                 int H, int W, double* __restrict__ state) {
-    __shared__ double red[16];
+    __shared__ double red[16 * (2 + 4 * kLsMaxC)];
     const int n = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x;
     const int64_t HW = (int64_t)H * W;
     const int64_t chunk = ((HW + kLsSlices - 1) / kLsSlices + 3) & ~(int64_t)3;
@@ -72,17 +72,33 @@ __global__ __launch_bounds__(1024) void levelset_partial_kernel(const float* __r
                 }
             }
     }
+    // All 2 + 4C sums are reduced TOGETHER: their wave butterflies are independent chains (one after another, each is six
+    // dependent cross-lane steps and two barriers: ~1 us per sum, 14 sums at C = 3), one LDS hand-over, one barrier, then
+    // thread q adds the 16 wave partials of sum q in wave order -- the same additions in the same order as before.
     double* part = state + (int64_t)N * ls_stride(C) + ((int64_t)n * kLsSlices + sl) * ls_stride(C);
+    const int n_sums = ls_stride(C);
+    S[0] = wave_sum_f64(S[0]); S[1] = wave_sum_f64(S[1]);
 #pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const double s = block_sum_f64_ls(S[side], red);
-        if (tid == 0) part[side] = s;
+    for (int c = 0; c < kLsMaxC; ++c)
+        if (c < C) {
+            A[0][c] = wave_sum_f64(A[0][c]); A[1][c] = wave_sum_f64(A[1][c]);
+            Q[0][c] = wave_sum_f64(Q[0][c]); Q[1][c] = wave_sum_f64(Q[1][c]);
+        }
+    if ((tid & 63) == 0) {
+        double* r = red + (tid >> 6) * (2 + 4 * kLsMaxC);
+        r[0] = S[0]; r[1] = S[1];
 #pragma unroll
         for (int c = 0; c < kLsMaxC; ++c)
             if (c < C) {
-                const double a_sum = block_sum_f64_ls(A[side][c], red), q_sum = block_sum_f64_ls(Q[side][c], red);
-                if (tid == 0) { part[2 + side * C + c] = a_sum; part[2 + 2 * C + side * C + c] = q_sum; }
+                r[2 + c] = A[0][c]; r[2 + C + c] = A[1][c];
+                r[2 + 2 * C + c] = Q[0][c]; r[2 + 3 * C + c] = Q[1][c];
             }
+    }
+    __syncthreads();
+    if (tid < n_sums) {
+        double s = 0.0;
+        for (int wv = 0; wv < 16; ++wv) s += red[wv * (2 + 4 * kLsMaxC) + tid];     // fixed order
+        part[tid] = s;
     }
 }
 
