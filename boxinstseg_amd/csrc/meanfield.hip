@@ -283,7 +283,7 @@ __global__ __launch_bounds__(1024) void mil_fwd_kernel(const float* __restrict__
     uint32_t* coltk = reinterpret_cast<uint32_t*>(colkey + W);
     float* rowv = reinterpret_cast<float*>(coltk + W);
     float* rowt = rowv + H;
-    __shared__ double red[16];
+    __shared__ double red[64];
     const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t HW = (int64_t)H * W;
     const float* x = in + (int64_t)n * HW;
@@ -298,25 +298,37 @@ __global__ __launch_bounds__(1024) void mil_fwd_kernel(const float* __restrict__
         u64 rkey[R]; float rt[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) { rkey[i] = 0ull; rt[i] = -INFINITY; }
-        for (int c = lane; c < W; c += 64) {
-            float v[R], t[R];
+        // kCT column trips (4 rows x 2 arrays each) are loaded before any of them is consumed: trip by trip, each one waits
+        // out a full memory latency behind the previous trip's LDS atomics (27 -> see DESIGN 3.6).  Columns past the end
+        // are clamped to the last one: a duplicate changes no maximum.
+        constexpr int kCT = 5;
+        for (int c0 = 0; c0 < W; c0 += 64 * kCT) {
+            float v[kCT][R], t[kCT][R];
 #pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const int r = min(rb + i, H - 1);               // clamped: the duplicate of the last row changes no maximum
-                v[i] = x[(int64_t)r * W + c];
-                t[i] = load_t(tg, t_u8, (int64_t)n * HW + (int64_t)r * W + c);
-            }
-            u64 ck = 0ull; float ct = -INFINITY;
+            for (int q = 0; q < kCT; ++q) {
+                const int c = min(c0 + q * 64 + lane, W - 1);
 #pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const int r = min(rb + i, H - 1);
-                const u64 kc_ = pack_max(v[i], (uint32_t)r); ck = kc_ > ck ? kc_ : ck;      // first row wins ties
-                ct = fmaxf(ct, t[i]);
-                const u64 kr = pack_max(v[i], (uint32_t)c); rkey[i] = kr > rkey[i] ? kr : rkey[i];
-                rt[i] = fmaxf(rt[i], t[i]);
+                for (int i = 0; i < R; ++i) {
+                    const int r = min(rb + i, H - 1);           // clamped: the duplicate of the last row changes no maximum
+                    v[q][i] = x[(int64_t)r * W + c];
+                    t[q][i] = load_t(tg, t_u8, (int64_t)n * HW + (int64_t)r * W + c);
+                }
             }
-            atomicMax(&colkey[c], ck);
-            atomicMax(&coltk[c], float_key(ct));
+#pragma unroll
+            for (int q = 0; q < kCT; ++q) {
+                const int c = min(c0 + q * 64 + lane, W - 1);
+                u64 ck = 0ull; float ct = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int r = min(rb + i, H - 1);
+                    const u64 kc_ = pack_max(v[q][i], (uint32_t)r); ck = kc_ > ck ? kc_ : ck;      // first row wins ties
+                    ct = fmaxf(ct, t[q][i]);
+                    const u64 kr = pack_max(v[q][i], (uint32_t)c); rkey[i] = kr > rkey[i] ? kr : rkey[i];
+                    rt[i] = fmaxf(rt[i], t[q][i]);
+                }
+                atomicMax(&colkey[c], ck);
+                atomicMax(&coltk[c], float_key(ct));
+            }
         }
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -334,8 +346,13 @@ __global__ __launch_bounds__(1024) void mil_fwd_kernel(const float* __restrict__
         ac += v * t; bcc += v * v + t * t;
     }
     for (int r = tid; r < H; r += 1024) { ar += (double)rowv[r] * rowt[r]; bcr += (double)rowv[r] * rowv[r] + (double)rowt[r] * rowt[r]; }
-    ac = block_sum_f64(ac, red); bcc = block_sum_f64(bcc, red) + eps;
-    ar = block_sum_f64(ar, red); bcr = block_sum_f64(bcr, red) + eps;
+    // the four sums together (one after another each costs six dependent cross-lane steps and two barriers)
+    ac = wave_sum_f64(ac); bcc = wave_sum_f64(bcc); ar = wave_sum_f64(ar); bcr = wave_sum_f64(bcr);
+    if (lane == 0) { red[wave * 4 + 0] = ac; red[wave * 4 + 1] = bcc; red[wave * 4 + 2] = ar; red[wave * 4 + 3] = bcr; }
+    __syncthreads();
+    ac = bcc = ar = bcr = 0.0;
+    for (int wv = 0; wv < 16; ++wv) { ac += red[wv * 4 + 0]; bcc += red[wv * 4 + 1]; ar += red[wv * 4 + 2]; bcr += red[wv * 4 + 3]; }   // fixed order
+    bcc += eps; bcr += eps;
     if (tid == 0) loss[n] = (float)(weight * ((1.0 - 2.0 * ar / bcr) + (1.0 - 2.0 * ac / bcc)));   // loss_func(column..) + loss_func(row..)
     for (int c = tid; c < W; c += 1024) {
         const double v = unpack_val(colkey[c]), t = key_float(coltk[c]);
