@@ -115,6 +115,33 @@ def test_training_sample_selects_what_the_reference_selects(case):
     assert none[0].shape == (0, 7) and none[4].numel() == 0
 
 
+@pytest.mark.parametrize('seed', list(range(40)))
+def test_topk_per_box_against_loops(seed):
+    """the sort-based selection of training_sample against a plain-loop statement of the rule (condinst_head.py:1201-1225):
+    per image, per box in ascending index, keep max(int(topk / boxes_in_image), 1) locations -- all of them in location
+    order if the box has no more than that, otherwise the best by score, best first."""
+    from boxinstseg_amd.mask_head import _topk_per_box
+    rng = np.random.default_rng(500 + seed)
+    n = int(rng.integers(0, 120)); B = int(rng.integers(1, 4)); G = int(rng.integers(1, 9)); topk = int(rng.choice([1, 2, 5, 16, 64]))
+    img = np.sort(rng.integers(0, B, size=n))
+    gt = rng.integers(0, G, size=n) + G * img
+    score = rng.permutation(n).astype(np.float32) / max(n, 1)           # distinct scores: no ties
+    want = []
+    for b in range(B):
+        idx_b = np.nonzero(img == b)[0]
+        boxes = np.unique(gt[idx_b])
+        if len(boxes) == 0:
+            continue
+        quota = max(int(topk / len(boxes)), 1)
+        for g_ in boxes:
+            idx = idx_b[gt[idx_b] == g_]
+            if len(idx) > quota:
+                idx = idx[np.argsort(-score[idx], kind='stable')[:quota]]
+            want.extend(idx.tolist())
+    got = _topk_per_box(torch.from_numpy(img), torch.from_numpy(gt), torch.from_numpy(score), topk).tolist()
+    assert got == want
+
+
 def test_cpu_tensors_fail_loudly():
     import boxinstseg_amd as bx
     from boxinstseg_amd import synthetic
