@@ -12,6 +12,13 @@ int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, co
                 const uint8_t* affinity, int size, int dil, float warmup, float* losses, float* g_logits, void* state,
                 void* workspace, size_t workspace_bytes, void* stream);
 size_t loss_ws_bytes(int N, int h, int w);
+size_t eval_ws_bytes(int N, int h, int w);
+bool fused_eval_supported(int dil);
+int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thresh, const bxi_instances* in, int dil, float warmup,
+                      const float* up_prj, const float* up_pw, float* losses, float* g_logits, void* state, void* workspace,
+                      size_t workspace_bytes, int force_rows, void* stream);
+int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits,
+                   void* stream);
 
 static inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -62,14 +69,15 @@ size_t bxi_boxinst_eval_workspace_bytes(int B, int Hc, int Wc, int stride, int N
     const int h = Hc / stride, w = Wc / stride;
     if (h <= 0 || w <= 0) return 0;
     const size_t P = (size_t)h * w;
-    return bxi::up256(sizeof(float) * (size_t)B * 3 * P) + bxi::loss_ws_bytes(N, h, w);
+    return bxi::up256(sizeof(float) * (size_t)B * 3 * P) + bxi::eval_ws_bytes(N, h, w);
 }
 
 int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host, int size, int dilation,
-                         float color_thresh, float warmup, float* losses, float* g_logits, void* state,
-                         void* workspace, size_t workspace_bytes, void* stream) {
+                         float color_thresh, float warmup, const float* up_prj, const float* up_pw, float* losses,
+                         float* g_logits, void* state, void* workspace, size_t workspace_bytes, void* stream) {
     if (!batch_host || !inst_host) return BXI_ERR_NULL_POINTER;
-    if (size != 3) return BXI_ERR_UNSUPPORTED;
+    if (size < 1 || (size & 1) == 0 || dilation < 1) return BXI_ERR_BAD_ARGUMENT;
+    if (size != 3 || !bxi::fused_eval_supported(dilation)) return BXI_ERR_UNSUPPORTED;
     const int stride = inst_host->stride;
     if (stride < 1 || batch_host->Hc != inst_host->Hc || batch_host->Wc != inst_host->Wc ||
         batch_host->B != inst_host->B)
@@ -82,8 +90,13 @@ int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances*
     char* base = (char*)workspace;
     float* lab = (float*)base;
     char* lws = base + bxi::up256(sizeof(float) * (size_t)batch_host->B * 3 * P);
-    return bxi::launch_loss(batch_host, lab, color_thresh, inst_host, nullptr, size, dilation, warmup, losses,
-                            g_logits, state, lws, workspace_bytes - (size_t)(lws - base), stream);
+    return bxi::launch_fused_eval(batch_host, lab, color_thresh, inst_host, dilation, warmup, up_prj, up_pw, losses, g_logits,
+                                  state, lws, workspace_bytes - (size_t)(lws - base), 0, stream);
+}
+
+int bxi_boxinst_grad_rescale_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw, int dilation,
+                                 const void* state, float* g_logits, void* stream) {
+    return bxi::launch_rescale(inst_host, g_prj, g_pw, dilation, state, g_logits, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,1031 @@
+// fused_eval.hip -- the BoxInst loss evaluation (forward AND finished backward) in TWO launches on gfx950.
+//
+// Replaces (reference, LiWentomng/BoxInstSeg) CondInstMaskHead.loss with boxinst_enabled,
+// condinst_head.py:1288-1343, together with everything it calls:
+//   get_targets / get_original_image / get_bitmasks_from_boxes   :170-186, :1345-1448   (image side)
+//   get_image_color_similarity + unfold_wo_center                :190-246
+//   compute_project_term + dice_coefficient                      :117-143
+//   pairwise_nlog (CUDA op, pairwise.cu:68-149) + weights / normalise / warm-up   :1315-1332
+// and what autograd does behind them, with the upstream factors folded in, so that g_logits leaves the
+// second launch FINISHED (no third launch; round 1 needed loss_apply for that).
+//
+//   prep_kernel   256-thread workgroups, three roles                                   HBM stream
+//     table waves   per-instance box rectangle, the compacted list of box tiles (+ colour predicate), zeroed counters
+//     stream blocks 4 waves x 8 rows of one instance map: zero-fill of g_logits, row maxima (complete), column
+//                   maxima of the block's 32 rows (combined through LDS) -> Sn = ceil(h/32) partials per column
+//     pool blocks   4 waves = the 4 input rows of 64 pooled pixels: a lane loads 3 x float4 (1 KiB contiguous per
+//                   wave-load), de-normalises 12 values; the 4x4 sums meet in LDS, then three waves take one CIE
+//                   channel each (fp64) -> Lab f32.  Four times more, four times lighter waves than one lane per
+//                   pooled pixel: their arithmetic overlaps the other waves' loads (tools/micro/dispatch.hip, D).
+//   pair_kernel   256-thread workgroups, three roles, dispatched in this order
+//     leaders       one per instance: column partials -> maxima -> sigmoid -> dice -> unit projection gradients
+//                   (published write-through + one flag), projection gradient at the arg-max positions outside the tiles
+//     count waves   one per box tile: sum of the pair weights W from Lab alone -> one packed atomic per tile
+//     math waves    one per box tile (wave64, no LDS, no barrier): the tile + halo lives in registers, a lane owns a
+//                   column; every unordered pair is evaluated ONCE and feeds both of its pixels (neighbour columns by
+//                   cross-lane moves); then reads sum W (complete: the count waves precede the math waves in the
+//                   grid, so nothing waits for a workgroup that may not have been dispatched), the leader's
+//                   coefficients, and stores  g = g_pw * warm/max(sum W,1) * d pw + g_prj * d prj.
+// Data layout in HBM: everything NCHW / row-major as the reference hands it over; Lab [B,3,h,w] f32 is the only
+// materialised intermediate (1.2 MB at 2x800x1024).
+#include "loss_common.hpp"
+#include <cstdlib>
+
+namespace bxi {
+
+constexpr int kWaves = 4;                       // waves per workgroup in both launches
+constexpr int kSRows = 8;                       // rows per stream wave
+constexpr int kSBlk = kWaves * kSRows;          // rows per stream workgroup
+constexpr int kChunkC = 256;                    // columns per pass of a stream wave: 64 lanes x float4
+constexpr int kMaxDilFused = 4;
+constexpr unsigned kSpinLimit = 200000;         // bounded waits (never reached: see the grid order above)
+
+#define BXI_RLX __ATOMIC_RELAXED
+#define BXI_AGENT __HIP_MEMORY_SCOPE_AGENT
+
+struct WorkRec2 {                               // 64 B: all a tile wave needs, written by the table waves
+    int r0, r1, c0, c1;                         // cells whose sample lies in the GT box (bitmask == 1)
+    int img, n, tile_r0, tile_c0;
+    float n2max; int zero_bit, vr, vc;          // colour predicate; valid(q) <=> y(q) < vr && x(q) < vc (:1354-1369,:1405)
+    int hc1, pad0, pad1, pad2;                  // end column of the instance's tile hull (= dilated box)
+};
+
+struct EvalWs {                                 // carved from the caller's workspace
+    unsigned long long* colpart;                // [N,Sn,w] packed (max logit, first row) of a 32-row block
+    unsigned long long* rowkey;                 // [N,h]    packed (max logit, first column)
+    InstRec* inst;                              // [N]
+    WorkRec2* work;                             // [cap]
+    int* nwork;                                 // [1]
+    unsigned int* expect;                       // [N]  tiles of the instance
+    // words polled inside pair_kernel; zeroed by prep_kernel's table waves (i.e. before a kernel boundary)
+    unsigned long long* acc1;                   // [N]  count waves : arrivals << 40 | sum W
+    unsigned long long* acc2;                   // [N]  math waves + leader : arrivals << 52 | sum (W pw + 1) in 2^-24 units
+    unsigned int* lflag;                        // [N]  leader's coefficients are published
+    unsigned int* fin;                          // [1]  instances complete
+    float* dice;                                // [N]
+};
+
+static inline int tile_width(int dil) { return 64 - 2 * dil; }
+static inline int eval_cap(int N, int h, int w, int dil, int R) {
+    const int tw = tile_width(dil);
+    return (N > 0 ? N : 1) * ((h + R - 1) / R) * ((w + tw - 1) / tw);
+}
+
+static size_t carve_eval(void* base, int N, int h, int w, EvalWs* ws) {
+    const int N1 = N > 0 ? N : 1;
+    const size_t Sn = (size_t)(h + kSBlk - 1) / kSBlk;
+    size_t off = 0;
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return p ? p + o : nullptr; };
+    EvalWs t;
+    t.colpart = (unsigned long long*)take(8 * (size_t)N1 * Sn * w);
+    t.rowkey = (unsigned long long*)take(8 * (size_t)N1 * h);
+    t.inst = (InstRec*)take(sizeof(InstRec) * (size_t)N1);
+    t.work = (WorkRec2*)take(sizeof(WorkRec2) * (size_t)eval_cap(N, h, w, 1, 4));   // the largest list any (dil, R) produces
+    t.nwork = (int*)take(sizeof(int));
+    t.expect = (unsigned int*)take(4 * (size_t)N1);
+    t.acc1 = (unsigned long long*)take(8 * (size_t)N1);
+    t.acc2 = (unsigned long long*)take(8 * (size_t)N1);
+    t.lflag = (unsigned int*)take(4 * (size_t)N1);
+    t.fin = (unsigned int*)take(4);
+    t.dice = (float*)take(4 * (size_t)N1);
+    if (ws) *ws = t;
+    return off;
+}
+
+// ================================================================================================
+// prep_kernel
+// ================================================================================================
+// ---- role 1: table waves (one wave per instance) -------------------------------------------------------------
+struct LaneBox2 { int r0, r1, c0, c1, img, tr0, ntr, hc0, hc1, ntc; };
+__device__ __forceinline__ LaneBox2 lane_box2(const InstArgs& a, int dil, int R, int m) {
+    LaneBox2 lb = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int64_t g = a.gt_inds[m];
+    const float* bp = nullptr;
+    for (int b = 0; b < a.gt.B; ++b)      // uniform loop: the by-value kernel argument is never indexed per lane
+        if (g >= a.gt.first[b] && g < a.gt.first[b + 1]) { bp = a.gt.boxes[b] + 4 * (g - a.gt.first[b]); lb.img = b; }
+    if (!bp) return lb;
+    const Rect rc = box_rect(bp, a.Hc, a.Wc, a.stride, a.stride / 2, a.h, a.w);
+    if (rc.r1 <= rc.r0 || rc.c1 <= rc.c0) return lb;
+    lb.r0 = rc.r0; lb.r1 = rc.r1; lb.c0 = rc.c0; lb.c1 = rc.c1;
+    const int r0 = max(rc.r0 - dil, 0), r1 = min(rc.r1 + dil, a.h);
+    lb.hc0 = max(rc.c0 - dil, 0); lb.hc1 = min(rc.c1 + dil, a.w);
+    lb.tr0 = r0 / R; lb.ntr = (r1 - 1) / R - r0 / R + 1;
+    const int tw = 64 - 2 * dil;
+    lb.ntc = (lb.hc1 - lb.hc0 + tw - 1) / tw;
+    return lb;
+}
+
+__device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& meta, int dil, int R, float thresh,
+                                           const EvalWs& ws, const LossState& st, int n) {
+    const int lane = threadIdx.x & 63;
+    int base = 0, total = 0;
+    LaneBox2 mine = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m0 = 0; m0 < a.N; m0 += 64) {           // exclusive scan of the tile counts: deterministic offsets, no atomics
+        const int m = m0 + lane;
+        LaneBox2 lb = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (m < a.N) lb = lane_box2(a, dil, R, m);
+        const int cm = lb.ntr * lb.ntc;
+        int incl = cm;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (n >= m0 && n < m0 + 64) {
+            const int src = n - m0;
+            base = total + __shfl(incl - cm, src, 64);
+            mine.r0 = __shfl(lb.r0, src, 64); mine.r1 = __shfl(lb.r1, src, 64);
+            mine.c0 = __shfl(lb.c0, src, 64); mine.c1 = __shfl(lb.c1, src, 64); mine.img = __shfl(lb.img, src, 64);
+            mine.tr0 = __shfl(lb.tr0, src, 64); mine.ntr = __shfl(lb.ntr, src, 64);
+            mine.hc0 = __shfl(lb.hc0, src, 64); mine.hc1 = __shfl(lb.hc1, src, 64); mine.ntc = __shfl(lb.ntc, src, 64);
+        }
+        total += __shfl(incl, 63, 64);
+    }
+    const int cnt = mine.ntr * mine.ntc;
+    const Pred pr = make_pred(thresh);
+    const int img = __builtin_amdgcn_readfirstlane(mine.img);
+    const int vr = min(meta.img_h[img], meta.first_removed[img]), vc = meta.img_w[img];
+    if (lane == 0) {
+        if (n == 0) { *ws.nwork = total; *ws.fin = 0u; if (st.status) { st.status[0] = 0; st.status[1] = R; } }
+        InstRec rc; rc.r0 = mine.r0; rc.r1 = mine.r1; rc.c0 = mine.c0; rc.c1 = mine.c1; rc.img = mine.img;
+        rc.pad0 = rc.pad1 = rc.pad2 = 0;
+        ws.inst[n] = rc;
+        if (st.inst) st.inst[n] = rc;
+        ws.expect[n] = (unsigned int)cnt;
+        ws.acc1[n] = 0ull; ws.acc2[n] = 0ull; ws.lflag[n] = 0u;
+    }
+    for (int i = lane; i < cnt; i += 64) {
+        WorkRec2 wr;
+        wr.r0 = mine.r0; wr.r1 = mine.r1; wr.c0 = mine.c0; wr.c1 = mine.c1; wr.img = mine.img; wr.n = n;
+        wr.tile_r0 = (mine.tr0 + i / mine.ntc) * R; wr.tile_c0 = mine.hc0 + (i % mine.ntc) * (64 - 2 * dil);
+        wr.n2max = pr.n2max; wr.zero_bit = pr.zero_bit; wr.vr = vr; wr.vc = vc;
+        wr.hc1 = mine.hc1; wr.pad0 = wr.pad1 = wr.pad2 = 0;
+        ws.work[base + i] = wr;
+    }
+}
+
+// ---- role 2: stream block = 4 waves x 8 rows of one instance map -----------------------------------------------
+//   - zero-fill of d loss / d logits first (depends on nothing; pair_kernel overwrites the box tiles);
+//   - all 8 row loads in flight together; per-row max / first arg-max by 8 interleaved butterflies;
+//   - per-column max / first arg-max over the wave's rows in registers, over the block's 4 waves through LDS.
+__device__ __forceinline__ void stream_block(const InstArgs& a, const EvalWs& ws, float* __restrict__ g_logits, int vec, int sb,
+                                             unsigned long long* colp /* LDS [kWaves][w] */) {
+    const int h = a.h, w = a.w;
+    const int Sn = (h + kSBlk - 1) / kSBlk;
+    const int n = sb / Sn, s = sb % Sn;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = s * kSBlk + wv * kSRows, r1 = min(h, r0 + kSRows);     // may be empty
+    const int64_t P = (int64_t)h * w;
+    const float* L = a.logits + (int64_t)n * P;
+    float* G = g_logits ? g_logits + (int64_t)n * P : nullptr;
+    const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    float4 v[kSRows];
+    {
+        const int c = lane * 4;
+#pragma unroll
+        for (int i = 0; i < kSRows; ++i) v[i] = (r0 + i < r1 && c < w) ? load4(L + (int64_t)(r0 + i) * w, c, w, vec) : ninf;
+    }
+    if (G)   // non-temporal: these lines are not read again in this launch
+        for (int cb = 0; cb < w; cb += kChunkC) {
+            const int c = cb + lane * 4;
+            if (c < w) {
+#pragma unroll
+                for (int i = 0; i < kSRows; ++i)
+                    if (r0 + i < r1) {
+                        if (vec) { typedef float f4v __attribute__((ext_vector_type(4))); __builtin_nontemporal_store((f4v){0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4v*>(G + (int64_t)(r0 + i) * w + c)); }
+                        else store4(G + (int64_t)(r0 + i) * w, c, w, false, zero);
+                    }
+            }
+        }
+    float rmax[kSRows]; int rcol[kSRows];
+#pragma unroll
+    for (int i = 0; i < kSRows; ++i) { rmax[i] = -INFINITY; rcol[i] = 0; }
+    for (int cb = 0;;) {
+        const int c = cb + lane * 4;
+        if (c < w) {
+            float cmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            int crow[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < kSRows; ++i) {
+                if (r0 + i < r1) {
+                    float m = v[i].x; int mc = c;                       // first column wins ties
+                    if (v[i].y > m) { m = v[i].y; mc = c + 1; }
+                    if (v[i].z > m) { m = v[i].z; mc = c + 2; }
+                    if (v[i].w > m) { m = v[i].w; mc = c + 3; }
+                    if (m > rmax[i]) { rmax[i] = m; rcol[i] = mc; }     // chunks ascend: strict > keeps the first
+                    if (v[i].x > cmax[0]) { cmax[0] = v[i].x; crow[0] = i; }   // ascending row, strict >: first row wins
+                    if (v[i].y > cmax[1]) { cmax[1] = v[i].y; crow[1] = i; }
+                    if (v[i].z > cmax[2]) { cmax[2] = v[i].z; crow[2] = i; }
+                    if (v[i].w > cmax[3]) { cmax[3] = v[i].w; crow[3] = i; }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c + j < w) colp[(size_t)wv * w + c + j] = pack_max(cmax[j], (uint32_t)(r0 + crow[j]));   // absolute row
+        }
+        cb += kChunkC;
+        if (cb >= w) break;
+        const int c2 = cb + lane * 4;
+#pragma unroll
+        for (int i = 0; i < kSRows; ++i) v[i] = (r0 + i < r1 && c2 < w) ? load4(L + (int64_t)(r0 + i) * w, c2, w, vec) : ninf;
+    }
+    float wmax[kSRows];
+#pragma unroll
+    for (int i = 0; i < kSRows; ++i) wmax[i] = rmax[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float o[kSRows];
+#pragma unroll
+        for (int i = 0; i < kSRows; ++i) o[i] = __shfl_xor(wmax[i], off, kWave);
+#pragma unroll
+        for (int i = 0; i < kSRows; ++i) wmax[i] = fmaxf(wmax[i], o[i]);
+    }
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int i = 0; i < kSRows; ++i) {
+        const unsigned long long who = __ballot(rmax[i] == wmax[i]);
+        const int first = who ? __ffsll((long long)who) - 1 : 0;
+        const int col = __builtin_amdgcn_readlane(rcol[i], first);
+        if (lane == i) mine = pack_max(wmax[i], (uint32_t)col);
+    }
+    if (lane < kSRows && r0 + lane < r1) ws.rowkey[(int64_t)n * h + r0 + lane] = mine;
+    lds_barrier();
+    for (int c = threadIdx.x; c < w; c += kWaves * 64) {
+        unsigned long long k = colp[c];
+#pragma unroll
+        for (int u = 1; u < kWaves; ++u) { const unsigned long long o = colp[(size_t)u * w + c]; k = o > k ? o : k; }
+        ws.colpart[((int64_t)n * Sn + s) * w + c] = k;       // larger value, then smaller row
+    }
+}
+
+// ---- role 3: pool block = the 4 input rows of 64 pooled pixels --------------------------------------------------
+// Arithmetic identical to pool_finish_s4 / rgb2lab_f32 (image_device.hpp), only distributed differently.
+__device__ __forceinline__ double lab_f(const double* lut, int i, int r8, int g8, int b8) {
+    const double r = lut[r8], g = lut[g8], b = lut[b8];
+    const double M[3][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}, {0.019334, 0.119193, 0.950227}};
+    const double white[3] = {0.95047, 1.0, 1.08883};
+    const double m0 = i == 0 ? M[0][0] : (i == 1 ? M[1][0] : M[2][0]);
+    const double m1 = i == 0 ? M[0][1] : (i == 1 ? M[1][1] : M[2][1]);
+    const double m2 = i == 0 ? M[0][2] : (i == 1 ? M[1][2] : M[2][2]);
+    const double wt = i == 0 ? white[0] : (i == 1 ? white[1] : white[2]);
+    const double acc = __dadd_rn(__dadd_rn(__dmul_rn(m0, r), __dmul_rn(m1, g)), __dmul_rn(m2, b));
+    const double v = acc / wt;
+    return v > 0.008856 ? cbrt(v) : __dadd_rn(__dmul_rn(7.787, v), 16.0 / 116.0);
+}
+
+__device__ __forceinline__ void pool_block(const PoolArgs& pa, int item, double* lut /*[256]*/, int* part /*[4][3][64]*/,
+                                           double* fch /*[3][64]*/) {
+    const int h = pa.Hc >> 2, w = pa.Wc >> 2;
+    const int segs = (w + 63) >> 6;
+    const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = seg * 64 + lane;
+    const int y = 4 * r + wv;
+    const bool act = c < w;
+    const int64_t plane = (int64_t)pa.Hc * pa.Wc;
+    float4 v[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) v[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) {
+        const float* base = pa.imgs + (int64_t)b * 3 * plane + (int64_t)y * pa.Wc + 4 * c;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) v[ch] = *reinterpret_cast<const float4*>(base + pa.dn.src_ch[ch] * plane);
+    }
+    lut[threadIdx.x] = kSrgbLut[threadIdx.x];            // staged while the image loads fly
+    const int ih = pa.meta.img_h[b], iw = pa.meta.img_w[b];
+    const int x0 = 4 * c;
+    const bool yin = y < ih;
+    int sum[3];
+    if (__all(!act || (yin && x0 + 3 < iw))) {           // wave-uniform: the whole row segment is image, not canvas padding
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const double s = pa.dn.stdv[pa.dn.src_ch[ch]], m = pa.dn.mean[pa.dn.src_ch[ch]];
+            sum[ch] = denorm_u8(v[ch].x, s, m) + denorm_u8(v[ch].y, s, m) + denorm_u8(v[ch].z, s, m) + denorm_u8(v[ch].w, s, m);
+        }
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const double s = pa.dn.stdv[pa.dn.src_ch[ch]], m = pa.dn.mean[pa.dn.src_ch[ch]];
+            int t = 0;
+            t += (yin && x0 + 0 < iw) ? denorm_u8(v[ch].x, s, m) : 0;
+            t += (yin && x0 + 1 < iw) ? denorm_u8(v[ch].y, s, m) : 0;
+            t += (yin && x0 + 2 < iw) ? denorm_u8(v[ch].z, s, m) : 0;
+            t += (yin && x0 + 3 < iw) ? denorm_u8(v[ch].w, s, m) : 0;
+            sum[ch] = t;
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) part[(wv * 3 + ch) * 64 + lane] = sum[ch];
+    lds_barrier();
+    if (wv < 3) {                                         // wave-uniform: wave i takes channel i of XYZ -> f_i
+        int px[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+            px[ch] = (part[(0 * 3 + ch) * 64 + lane] + part[(1 * 3 + ch) * 64 + lane] + part[(2 * 3 + ch) * 64 + lane] +
+                      part[(3 * 3 + ch) * 64 + lane]) >> 4;
+        fch[wv * 64 + lane] = lab_f(lut, wv, px[0], px[1], px[2]);
+    }
+    lds_barrier();
+    if (wv < 3 && act && pa.lab) {
+        const double f1 = fch[64 + lane];
+        float o;
+        if (wv == 0) o = (float)__dadd_rn(__dmul_rn(116.0, f1), -16.0);
+        else if (wv == 1) o = (float)__dmul_rn(500.0, __dadd_rn(fch[lane], -f1));
+        else o = (float)__dmul_rn(200.0, __dadd_rn(f1, -fch[128 + lane]));
+        const int64_t P = (int64_t)h * w;
+        pa.lab[((int64_t)b * 3 + wv) * P + (int64_t)r * w + c] = o;
+    }
+}
+
+// grid: [ceil(N/4) table blocks][N*Sn stream blocks][pool blocks].  The table waves carry dependent scalar chains, so
+// they go first; the stream blocks precede the pool blocks because their data feeds the next launch's first workgroups.
+__global__ __launch_bounds__(256) void prep_kernel(PoolArgs pa, int n_pool, InstArgs a, int dil, int R, float thresh, EvalWs ws,
+                                                   LossState st, float* __restrict__ g_logits, int vec) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n_tab = (a.N + kWaves - 1) / kWaves;
+    const int n_stream = a.N * ((a.h + kSBlk - 1) / kSBlk);
+    const int blk = (int)blockIdx.x;
+    if (blk < n_tab) {
+        const int n = blk * kWaves + (int)(threadIdx.x >> 6);
+        if (n < a.N) table_wave(a, pa.meta, dil, R, thresh, ws, st, n);
+    } else if (blk < n_tab + n_stream) {
+        stream_block(a, ws, g_logits, vec, blk - n_tab, reinterpret_cast<unsigned long long*>(smem));
+    } else {
+        double* lut = reinterpret_cast<double*>(smem);
+        double* fch = lut + 256;
+        int* part = reinterpret_cast<int*>(fch + 3 * 64);
+        pool_block(pa, blk - n_tab - n_stream, lut, part, fch);
+    }
+}
+
+// ================================================================================================
+// pair_kernel
+// ================================================================================================
+template <int D, int R> struct TG { static constexpr int RD = R + 2 * D, TW = 64 - 2 * D; };
+
+struct TileFlags {   // bit j = data row j (map row tile_r0 - D + j) of this lane's column; R / L = the lane D to the right / left
+    uint32_t ib, vd, ow, ibR, vdR, owR, ibL, vdL, owL;       // in GT box ; valid image pixel ; owned by this tile
+};
+
+__device__ __forceinline__ uint32_t row_bits(int lo, int hi, int base, int n) {   // bits j in [0,n) with lo <= base + j < hi
+    const int a = max(lo - base, 0), b = min(hi - base, n);
+    if (b <= a) return 0u;
+    return ((1u << b) - 1u) & ~((1u << a) - 1u);              // n <= 16
+}
+
+template <int D, int R>
+__device__ __forceinline__ TileFlags tile_flags(const WorkRec2& wr, int h, int w, int stride, int lane) {
+    constexpr int RD = TG<D, R>::RD;
+    const int base = wr.tile_r0 - D;
+    const int cl = wr.tile_c0 - D + lane;
+    const int half = stride / 2;
+    const int vrow = wr.vr - half <= 0 ? 0 : (wr.vr - half + stride - 1) / stride;      // r valid <=> r*stride + half < vr
+    const int vcol = wr.vc - half <= 0 ? 0 : (wr.vc - half + stride - 1) / stride;
+    const uint32_t rows_box = row_bits(wr.r0, wr.r1, base, RD);
+    const uint32_t rows_val = row_bits(0, min(h, vrow), base, RD);
+    const uint32_t rows_own = row_bits(wr.tile_r0, min(wr.tile_r0 + R, h), base, RD);
+    const int cv = min(w, vcol);
+    TileFlags f;
+    {
+        const int c = cl, ln = lane;
+        f.ib = (c >= wr.c0 && c < wr.c1) ? rows_box : 0u;
+        f.vd = (c >= 0 && c < cv) ? rows_val : 0u;
+        f.ow = (ln >= D && ln < 64 - D && c < wr.hc1) ? rows_own : 0u;
+    }
+    {
+        const int c = cl + D, ln = lane + D;
+        const bool in = ln < 64;
+        f.ibR = (in && c >= wr.c0 && c < wr.c1) ? rows_box : 0u;
+        f.vdR = (in && c >= 0 && c < cv) ? rows_val : 0u;
+        f.owR = (in && ln >= D && ln < 64 - D && c < wr.hc1) ? rows_own : 0u;
+    }
+    {
+        const int c = cl - D, ln = lane - D;
+        const bool in = ln >= 0;
+        f.ibL = (in && c >= wr.c0 && c < wr.c1) ? rows_box : 0u;
+        f.vdL = (in && c >= 0 && c < cv) ? rows_val : 0u;
+        f.owL = (in && ln >= D && ln < 64 - D && c < wr.hc1) ? rows_own : 0u;
+    }
+    return f;
+}
+
+// masks of one of the four forward directions; bit i = the pair (row i of this lane, partner):  W[k,p] = mA, W[7-k,q] = mB
+// (zero_bit == 0: the fast paths are not taken otherwise), and the same restricted to pixels this tile owns.
+struct DirMasks { uint32_t mA, mB, nA, nB; };
+template <int D>
+__device__ __forceinline__ void dir_masks(const TileFlags& f, DirMasks (&m)[4]) {
+    // 0: (0,+D) lane R same row | 1: (+D,-D) lane L | 2: (+D,0) same lane | 3: (+D,+D) lane R
+    m[0].mA = f.ib & f.vdR;          m[0].mB = f.ibR & f.vd;          m[0].nA = m[0].mA & f.ow; m[0].nB = m[0].mB & f.owR;
+    m[1].mA = f.ib & (f.vdL >> D);   m[1].mB = (f.ibL >> D) & f.vd;   m[1].nA = m[1].mA & f.ow; m[1].nB = m[1].mB & (f.owL >> D);
+    m[2].mA = f.ib & (f.vd >> D);    m[2].mB = (f.ib >> D) & f.vd;    m[2].nA = m[2].mA & f.ow; m[2].nB = m[2].mB & (f.ow >> D);
+    m[3].mA = f.ib & (f.vdR >> D);   m[3].mB = (f.ibR >> D) & f.vd;   m[3].nA = m[3].mA & f.ow; m[3].nB = m[3].mB & (f.owR >> D);
+}
+
+template <int D, int R>
+__device__ __forceinline__ void load_plane(const float* __restrict__ plane, const WorkRec2& wr, int h, int w, int lane,
+                                           float (&v)[R + 2 * D]) {
+    const int cc = min(max(wr.tile_c0 - D + lane, 0), w - 1);
+#pragma unroll
+    for (int j = 0; j < R + 2 * D; ++j) {
+        const int rr = min(max(wr.tile_r0 - D + j, 0), h - 1);       // clamped: pairs with a pixel outside the map weigh 0
+        v[j] = plane[(int64_t)rr * w + cc];
+    }
+}
+
+__device__ __forceinline__ float n2_of(float L0, float A0, float B0, float L1, float A1, float B1) {
+    const float dL = L0 - L1, dA = A0 - A1, dB = B0 - B1;     // un-fused: the decision must equal the affinity kernel's
+    return __fadd_rn(__fadd_rn(__fmul_rn(dL, dL), __fmul_rn(dA, dA)), __fmul_rn(dB, dB));
+}
+
+// Generic (slow) evaluation of one tile: ordered pairs per owned pixel straight from global memory, pair value and
+// gradient in log space exactly as pairwise.cu:38-61.  Taken for thresh <= 0 (zero_bit: padded / masked-out neighbours
+// weigh 1) and for tiles with saturated logits (S underflows).  Returns the lane's sum W (and sum W pw, gradients -> gout).
+template <int D, int R>
+__device__ __noinline__ int slow_tile(const float* __restrict__ Lg, const float* __restrict__ lab, int64_t P, int4 box, int img,
+                                      int tile_r0, int tile_c0, float n2max, int zero_bit, int vr, int vc, int hc1, int h,
+                                      int w, int stride, int lane, bool want_grad, float* gout /* LDS [R + 1][64]: gradients, then sum W pw */) {
+    struct { int r0, r1, c0, c1, img, tile_r0, tile_c0; float n2max; int zero_bit, vr, vc, hc1; } wr =
+        {box.x, box.y, box.z, box.w, img, tile_r0, tile_c0, n2max, zero_bit, vr, vc, hc1};
+    const int half = stride / 2;
+    const int c = wr.tile_c0 - D + lane;
+    const bool col_owned = lane >= D && lane < 64 - D && c < wr.hc1;
+    int cnt = 0;
+    float num = 0.f;
+    const float* L0p = lab + (int64_t)wr.img * 3 * P;
+#pragma unroll 1
+    for (int j = 0; j < R; ++j) {
+        const int r = wr.tile_r0 + j;
+        float gacc = 0.f;
+        if (col_owned && r < h) {
+            const bool in_p = r >= wr.r0 && r < wr.r1 && c >= wr.c0 && c < wr.c1;
+            const bool val_p = r * stride + half < wr.vr && c * stride + half < wr.vc;
+            const int64_t pi = (int64_t)r * w + c;
+            const float lp0 = L0p[pi], lp1 = L0p[P + pi], lp2 = L0p[2 * P + pi];
+            const float xa = want_grad ? Lg[pi] : 0.f;
+            const float ax = logsig(xa), bx = logsig(-xa);
+#pragma unroll 1
+            for (int k = 0; k < 8; ++k) {
+                const int kk = k < 4 ? k : k + 1;
+                const int r2 = r + (kk / 3 - 1) * D, c2 = c + (kk % 3 - 1) * D;
+                const bool inq = r2 >= 0 && r2 < h && c2 >= 0 && c2 < w;
+                uint32_t pn = 0u;
+                int64_t qi = 0;
+                if (inq) {
+                    qi = (int64_t)r2 * w + c2;
+                    pn = n2_of(lp0, lp1, lp2, L0p[qi], L0p[P + qi], L0p[2 * P + qi]) <= wr.n2max ? 1u : 0u;
+                }
+                const bool val_q = inq && r2 * stride + half < wr.vr && c2 * stride + half < wr.vc;
+                const bool in_q = inq && r2 >= wr.r0 && r2 < wr.r1 && c2 >= wr.c0 && c2 < wr.c1;
+                const uint32_t wp = in_p ? (val_q ? pn : (uint32_t)wr.zero_bit) : 0u;
+                const uint32_t wq = in_q ? (val_p ? pn : (uint32_t)wr.zero_bit) : 0u;
+                cnt += (int)wp;                                   // weights.sum() counts padded pairs too (:1328)
+                if (want_grad && inq && (wp + wq)) {
+                    const float xb = Lg[qi];
+                    const float ay = logsig(xb), by = logsig(-xb);
+                    const float e1 = ax + ay, e0 = bx + by;
+                    const float nl2 = logsig(fabsf(e1 - e0)) - fmaxf(e1, e0);
+                    num += (float)wp * nl2;
+                    gacc += (float)(wp + wq) * (-(expf(ay) - expf(by)) * expf(ax + bx + nl2));
+                }
+            }
+        }
+        if (want_grad) gout[j * 64 + lane] = gacc;
+    }
+    if (want_grad) gout[R * 64 + lane] = num;
+    return cnt;
+}
+
+// ---- count wave: sum over the tile's owned pixels of W[k,p] (Lab only) -------------------------------------------
+template <int D, int R>
+__device__ __forceinline__ void count_tile(const InstArgs& a, const float* __restrict__ lab, const EvalWs& ws, const WorkRec2& wr) {
+    constexpr int RD = TG<D, R>::RD;
+    const int lane = threadIdx.x & 63;
+    const int h = a.h, w = a.w;
+    const int64_t P = (int64_t)h * w;
+    int cnt = 0;
+    if (wr.zero_bit) {
+        cnt = slow_tile<D, R>(nullptr, lab, P, make_int4(wr.r0, wr.r1, wr.c0, wr.c1), wr.img, wr.tile_r0, wr.tile_c0, wr.n2max, wr.zero_bit,
+                                wr.vr, wr.vc, wr.hc1, h, w, a.stride, lane, false, nullptr);
+    } else {
+        float L[RD], A[RD], B[RD];
+        const float* lp = lab + (int64_t)wr.img * 3 * P;
+        load_plane<D, R>(lp, wr, h, w, lane, L);
+        load_plane<D, R>(lp + P, wr, h, w, lane, A);
+        load_plane<D, R>(lp + 2 * P, wr, h, w, lane, B);
+        const TileFlags f = tile_flags<D, R>(wr, h, w, a.stride, lane);
+        DirMasks m[4];
+        dir_masks<D>(f, m);
+        const int lr = min(lane + D, 63), ll = max(lane - D, 0);
+#pragma unroll
+        for (int i = 0; i < R + D; ++i) {
+            const int j = i + D;
+            const float LRj = __shfl(L[j], lr, 64), ARj = __shfl(A[j], lr, 64), BRj = __shfl(B[j], lr, 64);
+            const float LLj = __shfl(L[j], ll, 64), ALj = __shfl(A[j], ll, 64), BLj = __shfl(B[j], ll, 64);
+            if (i >= D) {
+                const float LRi = __shfl(L[i], lr, 64), ARi = __shfl(A[i], lr, 64), BRi = __shfl(B[i], lr, 64);
+                const bool pn = n2_of(L[i], A[i], B[i], LRi, ARi, BRi) <= wr.n2max;
+                cnt += pn ? (int)(((m[0].nA >> i) & 1u) + ((m[0].nB >> i) & 1u)) : 0;
+            }
+            { const bool pn = n2_of(L[i], A[i], B[i], LLj, ALj, BLj) <= wr.n2max;
+              cnt += pn ? (int)(((m[1].nA >> i) & 1u) + ((m[1].nB >> i) & 1u)) : 0; }
+            { const bool pn = n2_of(L[i], A[i], B[i], L[j], A[j], B[j]) <= wr.n2max;
+              cnt += pn ? (int)(((m[2].nA >> i) & 1u) + ((m[2].nB >> i) & 1u)) : 0; }
+            { const bool pn = n2_of(L[i], A[i], B[i], LRj, ARj, BRj) <= wr.n2max;
+              cnt += pn ? (int)(((m[3].nA >> i) & 1u) + ((m[3].nB >> i) & 1u)) : 0; }
+        }
+    }
+    cnt = wave_sum_i32(cnt);
+    if (lane == 0)   // one packed atomic per tile: (arrival, sum W); integer adds commute -> run-to-run identical
+        __hip_atomic_fetch_add(&ws.acc1[wr.n], (1ull << 40) | (unsigned long long)(unsigned int)cnt, BXI_RLX, BXI_AGENT);
+}
+
+// sum W over all instances, once every count wave has arrived.  Returns false on a time-out (never expected).
+__device__ __forceinline__ bool total_weight(const EvalWs& ws, int N, double* total) {
+    const int lane = threadIdx.x & 63;
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+        unsigned long long s = 0ull;
+        for (int b0 = 0; b0 < N; b0 += 64) {
+            const int i = b0 + lane;
+            if (i < N) {
+                const unsigned long long x = __hip_atomic_load(&ws.acc1[i], BXI_RLX, BXI_AGENT);
+                ok &= (unsigned int)(x >> 40) == ws.expect[i];
+                s += x & ((1ull << 40) - 1ull);
+            }
+        }
+        if (__all(ok)) {
+            *total = wave_sum_f64((double)s);        // exact: integers far below 2^53
+            return true;
+        }
+        if (spins > kSpinLimit) return false;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+// Last arrival of the launch (a math wave or a leader): loss_prj, loss_pairwise, the record of what was applied.
+__device__ __forceinline__ void finish_losses(const EvalWs& ws, const LossState& st, int N, float warmup, double total_w,
+                                              float upp, float upw, float* __restrict__ losses) {
+    const int lane = threadIdx.x & 63;
+    double num = 0.0;
+    float dsum = 0.f;
+    for (int b0 = 0; b0 < N; b0 += 64) {
+        const int i = b0 + lane;
+        double v = 0.0; float dv = 0.f;
+        if (i < N) {
+            const unsigned long long x = __hip_atomic_load(&ws.acc2[i], BXI_RLX, BXI_AGENT);
+            const long long fixed = (long long)(x & ((1ull << 52) - 1ull)) - ((long long)ws.expect[i] << 24);   // the +1 per tile
+            v = (double)fixed;
+            dv = __hip_atomic_load(&ws.dice[i], BXI_RLX, BXI_AGENT);
+        }
+        num += wave_sum_f64(v);
+        const int m = min(64, N - b0);
+        for (int k = 0; k < m; ++k) dsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), k));   // index order
+    }
+    if (lane == 0) {
+        const float denom = fmaxf((float)total_w, 1.f);                      // weights.sum().clamp(min=1.0), :1328
+        losses[0] = dsum / (float)N;                                         // .mean(), :143
+        losses[1] = (float)((num / (double)kNumScale) / (double)denom) * warmup;   // :1327-1332
+        if (st.scale) { *st.scale = warmup / denom; st.applied[0] = upp; st.applied[1] = upw; }
+    }
+}
+
+// arrival of a math wave / leader at instance n: returns true for the last arrival of the whole launch
+__device__ __forceinline__ bool arrive_final(const EvalWs& ws, int n, int N, unsigned long long add) {
+    bool last = false;
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long o = __hip_atomic_fetch_add(&ws.acc2[n], (1ull << 52) + add, BXI_RLX, BXI_AGENT);
+        if ((unsigned int)(o >> 52) == ws.expect[n]) {          // tiles + leader = expect + 1 arrivals: this was the last one
+            const unsigned int o2 = __hip_atomic_fetch_add(ws.fin, 1u, BXI_RLX, BXI_AGENT);
+            last = (o2 + 1u == (unsigned int)N);
+        }
+    }
+    return __builtin_amdgcn_readfirstlane((int)last) != 0;
+}
+
+// ---- math wave ---------------------------------------------------------------------------------------------------
+template <int D, int R>
+__device__ __forceinline__ void math_tile(const InstArgs& a, const float* __restrict__ lab, const EvalWs& ws, const LossState& st,
+                                          const WorkRec2& wr, float warmup, float upp, float upw, float* __restrict__ losses,
+                                          float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
+                                          double& total_w, bool& have_total) {
+    constexpr int RD = TG<D, R>::RD;
+    const int lane = threadIdx.x & 63;
+    const int h = a.h, w = a.w, n = wr.n;
+    const int64_t P = (int64_t)h * w;
+    const float* Lg = a.logits + (int64_t)n * P;
+    float g[R];
+    float num = 0.f;
+#pragma unroll
+    for (int j = 0; j < R; ++j) g[j] = 0.f;
+    bool slow = wr.zero_bit != 0;
+    if (!slow) {
+        float x[RD], L[RD], A[RD], B[RD];
+        const float* lp = lab + (int64_t)wr.img * 3 * P;
+        load_plane<D, R>(Lg, wr, h, w, lane, x);
+        load_plane<D, R>(lp, wr, h, w, lane, L);
+        load_plane<D, R>(lp + P, wr, h, w, lane, A);
+        load_plane<D, R>(lp + 2 * P, wr, h, w, lane, B);
+        const TileFlags f = tile_flags<D, R>(wr, h, w, a.stride, lane);
+        DirMasks m[4];
+        dir_masks<D>(f, m);
+        const int lr = min(lane + D, 63), ll = max(lane - D, 0);
+        // Rolling window over the rows: at step i the pairs (row i -> rows i, i + D) are evaluated; what the rows above
+        // contributed is final then, so row i's gradient is collected (and its registers die) inside the loop.
+        float pa_[RD], pb_[RD];                      // (sigmoid(x), sigmoid(-x)), rows [i, i + D] live
+        float aR[RD], bR[RD], LR[RD], AR[RD], BR[RD];   // the lane D to the right, rows [i, i + D] live
+        float gq[RD], gR[RD], gL[RD];                // gradient of this lane's pixels / of lane + D's / of lane - D's
+#pragma unroll
+        for (int j = 0; j < RD; ++j) { gq[j] = 0.f; gR[j] = 0.f; gL[j] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < D; ++j) { const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; }
+        float smin = 1.f;                            // smallest S among weighted pairs (saturation detector)
+        const int from_l = max(lane - D, 0), from_r = min(lane + D, 63);
+        // one unordered pair: p = (row i, this lane) ; q = (row j, lane given by the operands); dir = mask set
+#define BXI_PAIR(i, qa, qb, qL, qA, qB, dir, GP, GQ)                                                              \
+        {                                                                                                           \
+            const bool pn = n2_of(L[i], A[i], B[i], qL, qA, qB) <= wr.n2max;                                        \
+            const uint32_t c1 = ((m[dir].mA >> (i)) & 1u) + ((m[dir].mB >> (i)) & 1u);                              \
+            const uint32_t d1 = ((m[dir].nA >> (i)) & 1u) + ((m[dir].nB >> (i)) & 1u);                              \
+            const float gw = pn ? (float)c1 : 0.f, nw = pn ? (float)d1 : 0.f;                                      \
+            const float S = pa_[i] * (qa) + pb_[i] * (qb);                          /* P(y_p == y_q) */            \
+            smin = fminf(smin, gw != 0.f ? S : 1.f);                                                                \
+            const float Sc = fmaxf(S, 1e-30f);                                                                      \
+            num += nw * -__logf(Sc);                                                                                \
+            const float mm = gw * __builtin_amdgcn_rcpf(Sc);                                                        \
+            GP -= mm * ((qa) - (qb)) * (pa_[i] * pb_[i]);                                                           \
+            GQ -= mm * (pa_[i] - pb_[i]) * ((qa) * (qb));                                                           \
+        }
+#pragma unroll
+        for (int i = 0; i < R + D; ++i) {
+            const int j = i + D;
+            { const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; }
+            aR[j] = __shfl(pa_[j], lr, 64); bR[j] = __shfl(pb_[j], lr, 64);
+            LR[j] = __shfl(L[j], lr, 64); AR[j] = __shfl(A[j], lr, 64); BR[j] = __shfl(B[j], lr, 64);
+            const float aLj = __shfl(pa_[j], ll, 64), bLj = __shfl(pb_[j], ll, 64);
+            const float LLj = __shfl(L[j], ll, 64), ALj = __shfl(A[j], ll, 64), BLj = __shfl(B[j], ll, 64);
+            if (i >= D) BXI_PAIR(i, aR[i], bR[i], LR[i], AR[i], BR[i], 0, gq[i], gR[i])
+            BXI_PAIR(i, aLj, bLj, LLj, ALj, BLj, 1, gq[i], gL[j])
+            BXI_PAIR(i, pa_[j], pb_[j], L[j], A[j], B[j], 2, gq[i], gq[j])
+            BXI_PAIR(i, aR[j], bR[j], LR[j], AR[j], BR[j], 3, gq[i], gR[j])
+            if (i >= D) {     // row i is complete: collect what the neighbour lanes computed for it
+                const float fromL = __shfl(gR[i], from_l, 64);      // lane - D evaluated (.., +D) pairs into this lane
+                const float fromR = __shfl(gL[i], from_r, 64);      // lane + D evaluated (+D, -D) pairs into this lane
+                g[i - D] = gq[i] + (lane >= D ? fromL : 0.f) + (lane + D < 64 ? fromR : 0.f);
+            }
+        }
+#undef BXI_PAIR
+        slow = __any(!(smin > 1e-30f));
+    }
+    if (slow) {      // workgroup-divergent but wave-uniform; rare
+        const int cnt_unused = slow_tile<D, R>(Lg, lab, P, make_int4(wr.r0, wr.r1, wr.c0, wr.c1), wr.img, wr.tile_r0, wr.tile_c0, wr.n2max,
+                                               wr.zero_bit, wr.vr, wr.vc, wr.hc1, h, w, a.stride, lane, true, gbuf);
+        num = gbuf[R * 64 + lane];
+        (void)cnt_unused;
+#pragma unroll
+        for (int j = 0; j < R; ++j) g[j] = gbuf[j * 64 + lane];
+    }
+    // ---- sum W (count waves precede the math waves in the grid) and the instance's projection coefficients --------
+    bool ok = true;
+    if (!have_total) { ok = total_weight(ws, a.N, &total_w); have_total = ok; }
+    if (g_logits) {
+        if (lane == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(&ws.lflag[n], BXI_RLX, BXI_AGENT) == 0u) {
+                if (++spins > kSpinLimit) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+        const int c = wr.tile_c0 - D + lane;
+        const bool col_owned = lane >= D && lane < 64 - D && c < wr.hc1;
+        // published write-through by the leader: read past this XCD's caches
+        int carg = -1; float gc = 0.f;
+        if (col_owned) {
+            carg = __hip_atomic_load(&st.colarg[(int64_t)n * w + c], BXI_RLX, BXI_AGENT);
+            gc = __hip_atomic_load(&st.gcol[(int64_t)n * w + c], BXI_RLX, BXI_AGENT);
+        }
+        int rarg_l = -1; float gr_l = 0.f;
+        if (lane < R && wr.tile_r0 + lane < h) {
+            rarg_l = __hip_atomic_load(&st.rowarg[(int64_t)n * h + wr.tile_r0 + lane], BXI_RLX, BXI_AGENT);
+            gr_l = __hip_atomic_load(&st.grow[(int64_t)n * h + wr.tile_r0 + lane], BXI_RLX, BXI_AGENT);
+        }
+        const float scale = upw * (warmup / fmaxf((float)total_w, 1.f));
+        if (!ok && lane == 0 && st.status) atomicOr(st.status, 1);
+        float* G = g_logits + (int64_t)n * P;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int r = wr.tile_r0 + j;
+            const int ra = __builtin_amdgcn_readlane(rarg_l, j);
+            const float gr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gr_l), j));
+            if (col_owned && r < h) {
+                float sp = 0.f;
+                if (carg == r) sp += gc;
+                if (ra == c) sp += gr;
+                G[(int64_t)r * w + c] = g[j] * scale + sp * upp;
+            }
+        }
+    }
+    // ---- this tile's share of sum W pw, then the arrival --------------------------------------------------------------
+    num = wave_sum_f32(num);
+    const long long fx = (long long)(num * kNumScale) + (1ll << 24);     // + 1.0: keeps the packed field non-negative
+    if (arrive_final(ws, n, a.N, (unsigned long long)fx)) finish_losses(ws, st, a.N, warmup, total_w, upp, upw, losses);
+}
+
+// ---- leader workgroup --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = wave_sum_f32(v[k]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[(threadIdx.x >> 6) * 4 + k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]);
+}
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ void leader_block(const InstArgs& a, int dil, int R, const EvalWs& ws, const LossState& st, int n,
+                                             float upp, float* __restrict__ g_logits, unsigned char* smem, float* red) {
+    const int h = a.h, w = a.w, tid = threadIdx.x;
+    const int Sn = (h + kSBlk - 1) / kSBlk;
+    float* xs = reinterpret_cast<float*>(smem);   // [w] sigmoid of the column maxima, then their unit gradients
+    float* ys = xs + w;                           // [h]
+    int* carg = reinterpret_cast<int*>(ys + h);   // [w]
+    int* rarg = carg + w;                         // [h]
+    const InstRec rec = ws.inst[n];
+    const InstBox ib = inst_from_rec(rec, dil, h, w);
+    float sums[4] = {0.f, 0.f, 0.f, 0.f};   // I_x, U_x, I_y, U_y
+    for (int c = tid; c < w; c += 256) {
+        unsigned long long k = ws.colpart[(int64_t)n * Sn * w + c];
+        for (int s = 1; s < Sn; ++s) { const unsigned long long o = ws.colpart[((int64_t)n * Sn + s) * w + c]; k = o > k ? o : k; }
+        const float X = sigmoid_acc(unpack_val(k));
+        const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
+        xs[c] = X; carg[c] = (int)unpack_idx(k);
+        sums[0] += X * TX; sums[1] += X * X + TX * TX;
+    }
+    for (int r = tid; r < h; r += 256) {
+        const unsigned long long k = ws.rowkey[(int64_t)n * h + r];
+        const float Y = sigmoid_acc(unpack_val(k));
+        const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
+        ys[r] = Y; rarg[r] = (int)unpack_idx(k);
+        sums[2] += Y * TY; sums[3] += Y * Y + TY * TY;
+    }
+    block_sum4(sums, red);
+    const float Ix = sums[0], Ux = sums[1] + 1e-5f, Iy = sums[2], Uy = sums[3] + 1e-5f;
+    if (tid == 0)   // :130, summed over both axes :143
+        __hip_atomic_store(&ws.dice[n], (1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy), BXI_RLX, BXI_AGENT);
+    if (g_logits) {
+        // dice = 1 - 2I/U ; d dice/d u_j = (-2 t_j U + 4 I u_j) / U^2 ; chain through sigmoid ; mean over N
+        const float invN = 1.f / (float)a.N;
+        for (int c = tid; c < w; c += 256) {
+            const float X = xs[c];
+            const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
+            const float gv = invN * ((-2.f * TX * Ux + 4.f * Ix * X) / (Ux * Ux)) * X * (1.f - X);
+            xs[c] = gv;
+            __hip_atomic_store(&st.gcol[(int64_t)n * w + c], gv, BXI_RLX, BXI_AGENT);          // write-through
+            __hip_atomic_store(&st.colarg[(int64_t)n * w + c], carg[c], BXI_RLX, BXI_AGENT);
+        }
+        for (int r = tid; r < h; r += 256) {
+            const float Y = ys[r];
+            const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
+            const float gv = invN * ((-2.f * TY * Uy + 4.f * Iy * Y) / (Uy * Uy)) * Y * (1.f - Y);
+            ys[r] = gv;
+            __hip_atomic_store(&st.grow[(int64_t)n * h + r], gv, BXI_RLX, BXI_AGENT);
+            __hip_atomic_store(&st.rowarg[(int64_t)n * h + r], rarg[r], BXI_RLX, BXI_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains, then ONE lane raises the flag
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&ws.lflag[n], 1u, BXI_RLX, BXI_AGENT);
+        // projection gradient at the arg-max positions OUTSIDE the tiles (prep_kernel left zeros there; the math waves
+        // own every pixel of the tile hull: rows of the R-aligned tiles x columns of the dilated box)
+        const int hr0 = ib.any ? (ib.dil.r0 / R) * R : 0, hr1 = ib.any ? min(h, ((ib.dil.r1 + R - 1) / R) * R) : 0;
+        const int hc0 = ib.dil.c0, hc1 = ib.any ? ib.dil.c1 : 0;
+        float* G = g_logits + (int64_t)n * h * w;
+        for (int c = tid; c < w; c += 256) {
+            const int r = carg[c];
+            const bool in_t = r >= hr0 && r < hr1 && c >= hc0 && c < hc1;
+            if (!in_t) {
+                float v = xs[c];
+                if (rarg[r] == c) v += ys[r];
+                G[(int64_t)r * w + c] = v * upp;
+            }
+        }
+        for (int r = tid; r < h; r += 256) {
+            const int c = rarg[r];
+            const bool in_t = r >= hr0 && r < hr1 && c >= hc0 && c < hc1;
+            if (!in_t && carg[c] != r) G[(int64_t)r * w + c] = ys[r] * upp;
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+// grid: [N leader blocks][n_cb count blocks][n_cb math blocks]; a count / math block = 4 independent tile waves striding
+// through the work list.  Every wait in a math wave is for a workgroup EARLIER in the grid (leader, count waves), and
+// those never wait themselves, so the launch cannot stall on an un-dispatched workgroup whatever its size.
+template <int D, int R>
+__global__ __launch_bounds__(256, 2) void pair_kernel(InstArgs a, const float* __restrict__ lab, int dil, float warmup, EvalWs ws,
+                                                   LossState st, float* __restrict__ losses, float* __restrict__ g_logits,
+                                                   const float* __restrict__ up_prj, const float* __restrict__ up_pw, int n_cb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float red[16];
+    const int blk = (int)blockIdx.x;
+    const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
+    if (blk < a.N) {                                                   // ---- leader of instance blk
+        leader_block(a, dil, R, ws, st, blk, upp, g_logits, smem, red);
+        if (threadIdx.x < 64) {                                        // dice[n] is published (drained above)
+            if (arrive_final(ws, blk, a.N, 0ull)) {
+                double total_w = 0.0;
+                const bool ok = total_weight(ws, a.N, &total_w);
+                if (!ok && threadIdx.x == 0 && st.status) atomicOr(st.status, 2);
+                finish_losses(ws, st, a.N, warmup, total_w, upp, upw, losses);
+            }
+        }
+        return;
+    }
+    const int nwork = *ws.nwork;
+    const int wave = (int)(threadIdx.x >> 6);
+    const bool counting = blk < a.N + n_cb;
+    const int first = ((counting ? blk - a.N : blk - a.N - n_cb) * kWaves) + wave;
+    const int stride_w = n_cb * kWaves;
+    float* gbuf = reinterpret_cast<float*>(smem) + wave * ((R + 1) * 64);
+    double total_w = 0.0;
+    bool have_total = false;
+    for (int wi = first; wi < nwork; wi += stride_w) {
+        const WorkRec2 wr = ws.work[wi];
+        if (counting) count_tile<D, R>(a, lab, ws, wr);
+        else math_tile<D, R>(a, lab, ws, st, wr, warmup, upp, upw, losses, g_logits, gbuf, total_w, have_total);
+    }
+}
+
+// ---- rescale: g_logits finished for the factors recorded in `state` -> finished for (g_prj, g_pw) ----------------
+// grid (8, N).  No-op when the factors are the recorded ones (the usual case: loss.backward() seeds both terms with 1).
+// The record is not updated (every block reads it): at most one effective rescale per evaluation.
+__global__ __launch_bounds__(256) void rescale_kernel(InstArgs a, int dil, LossState st, const float* __restrict__ g_prj,
+                                                      const float* __restrict__ g_pw, float* __restrict__ g_logits) {
+    const float np = *g_prj, nw = *g_pw, op = st.applied[0], ow = st.applied[1];
+    if (np == op && nw == ow) return;
+    const int R = st.status[1];
+    const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int h = a.h, w = a.w;
+    const InstRec rec = st.inst[n];
+    const InstBox ib = inst_from_rec(rec, dil, h, w);
+    const int hr0 = ib.any ? (ib.dil.r0 / R) * R : 0, hr1 = ib.any ? min(h, ((ib.dil.r1 + R - 1) / R) * R) : 0;
+    const int hc0 = ib.dil.c0, hc1 = ib.any ? ib.dil.c1 : 0;
+    const float ratio = nw / ow;                      // recorded g_pw == 0 cannot be rescaled (documented)
+    float* G = g_logits + (int64_t)n * h * w;
+    const int* carg = st.colarg + (int64_t)n * w; const int* rarg = st.rowarg + (int64_t)n * h;
+    const float* gcol = st.gcol + (int64_t)n * w; const float* grow = st.grow + (int64_t)n * h;
+    const int cw = hc1 - hc0, rows = hr1 - hr0;
+    const int per = (rows + gridDim.x - 1) / gridDim.x;
+    const int ra = hr0 + s * per, rb = min(hr1, ra + per);
+    const int npx = cw > 0 && rb > ra ? (rb - ra) * cw : 0;
+    for (int i = tid; i < npx; i += 256) {            // G = ow*s*d + op*sp  ->  nw*s*d + np*sp
+        const int r = ra + i / cw, c = hc0 + i % cw;
+        float sp = 0.f;
+        if (carg[c] == r) sp += gcol[c];
+        if (rarg[r] == c) sp += grow[r];
+        const float v = G[(int64_t)r * w + c];
+        G[(int64_t)r * w + c] = (v - op * sp) * ratio + np * sp;
+    }
+    if (s == 0) {                                     // arg-max positions outside the hull hold op * sp
+        for (int c = tid; c < w; c += 256) {
+            const int r = carg[c];
+            const bool in_t = r >= hr0 && r < hr1 && c >= hc0 && c < hc1;
+            if (!in_t) {
+                float v = gcol[c];
+                if (rarg[r] == c) v += grow[r];
+                G[(int64_t)r * w + c] = v * np;
+            }
+        }
+        for (int r = tid; r < h; r += 256) {
+            const int c = rarg[r];
+            const bool in_t = r >= hr0 && r < hr1 && c >= hc0 && c < hc1;
+            if (!in_t && carg[c] != r) G[(int64_t)r * w + c] = grow[r] * np;
+        }
+    }
+}
+
+__global__ void zero_losses2_kernel(float* losses) { losses[0] = 0.f; losses[1] = 0.f; }
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+size_t eval_ws_bytes(int N, int h, int w) { return carve_eval(nullptr, N, h, w, nullptr); }
+
+static int tile_rows_for(int N, int h, int w, int dil) {
+    // 4-row tiles double the number of waves (more SIMDs busy) at 1.2x the pair evaluations; they pay while the work
+    // list is short enough that every tile wave still has a SIMD to itself.
+    return eval_cap(N, h, w, dil, 8) <= 6000 ? 4 : 8;
+}
+int eval_tile_rows(int N, int h, int w, int dil) { return tile_rows_for(N, h, w, dil); }
+
+template <int D, int R>
+static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, const float* lab, int dil, float warmup,
+                        const EvalWs& ws, const LossState& st, float* losses, float* g_logits, const float* up_prj,
+                        const float* up_pw, int n_cb) {
+    BXI_LAUNCH("pair", s, (pair_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, a, lab, dil, warmup, ws, st, losses, g_logits,
+               up_prj, up_pw, n_cb);
+}
+
+bool fused_eval_supported(int dil) { return dil >= 1 && dil <= kMaxDilFused; }
+
+// One evaluation, two launches.  lab: [B,3,h,w] f32 scratch (prep fills, pair reads).
+int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thresh, const bxi_instances* in, int dil, float warmup,
+                      const float* up_prj, const float* up_pw, float* losses, float* g_logits, void* state, void* workspace,
+                      size_t workspace_bytes, int force_rows, void* stream) {
+    InstArgs a;
+    int rc = fill_inst(in, a);
+    if (rc != BXI_OK) return rc;
+    if (!fused_eval_supported(dil)) return BXI_ERR_UNSUPPORTED;
+    if (!losses || !batch) return BXI_ERR_NULL_POINTER;
+    hipStream_t s = as_stream(stream);
+    PoolArgs pa = {};
+    if (batch->Hc != in->Hc || batch->Wc != in->Wc || batch->B != in->B) return BXI_ERR_BAD_SHAPE;
+    rc = fill_pool_args(batch, nullptr, lab, pa);
+    if (rc != BXI_OK) return rc;
+    if (batch->B > 0 && (!batch->imgs || !lab)) return BXI_ERR_NULL_POINTER;
+    if (batch->image_masks) return BXI_ERR_UNSUPPORTED;   // explicit masks: use bxi_color_affinity_f32 + bits
+    if (a.N == 0) {
+        BXI_LAUNCH("zero_losses", s, zero_losses2_kernel, dim3(1), dim3(1), 0, s, losses);
+        return check_launch();
+    }
+    if (a.N > 65535) return BXI_ERR_BAD_SHAPE;
+    if (g_logits && !state) return BXI_ERR_NULL_POINTER;
+    const size_t need = carve_eval(nullptr, a.N, a.h, a.w, nullptr);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
+    EvalWs ws;
+    carve_eval(workspace, a.N, a.h, a.w, &ws);
+    LossState st = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (state) {
+        if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
+        carve_state(state, a.N, a.h, a.w, &st);
+    }
+    const int vec = ((a.w & 3) == 0 && (reinterpret_cast<uintptr_t>(a.logits) & 15) == 0 &&
+                     (!g_logits || (reinterpret_cast<uintptr_t>(g_logits) & 15) == 0)) ? 1 : 0;
+    static const int env_rows = [] { const char* e = getenv("BXI_TILE_ROWS"); return e ? atoi(e) : 0; }();   // developer knob
+    if (!force_rows) force_rows = env_rows;
+    const int R = force_rows == 4 || force_rows == 8 ? force_rows : tile_rows_for(a.N, a.h, a.w, dil);
+
+    // ---- launch 1 --------------------------------------------------------------------------------------------------
+    int n_pool = 0;
+    if (batch->B > 0) {
+        if (pool_vec_ok(batch, a.stride)) n_pool = batch->B * a.h * ((a.w + 63) / 64);
+        else {                               // unaligned canvas / other strides: separate scalar pooling launch
+            rc = launch_pool(batch, a.stride, nullptr, lab, s);
+            if (rc != BXI_OK) return rc;
+        }
+    }
+    const int n_tab = (a.N + kWaves - 1) / kWaves;
+    const int n_stream = a.N * ((a.h + kSBlk - 1) / kSBlk);
+    size_t lds1 = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
+    if (lds1 < 8 * (size_t)kWaves * a.w) lds1 = 8 * (size_t)kWaves * a.w;
+    if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
+    BXI_LAUNCH("prep", s, prep_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, a, dil, R,
+               color_thresh, ws, st, g_logits, vec);
+    rc = check_launch();
+    if (rc != BXI_OK) return rc;
+
+    // ---- launch 2 --------------------------------------------------------------------------------------------------
+    const int cap = eval_cap(a.N, a.h, a.w, dil, R);
+    int n_cb = (cap + kWaves - 1) / kWaves;
+    if (n_cb > 512) n_cb = 512;                          // the list length is device data: the tile waves stride through it
+    size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
+    const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
+    if (lds2 < lds_leader) lds2 = lds_leader;
+    if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
+    const int grid = a.N + 2 * n_cb;
+#define BXI_PAIR_CASE(DD)                                                                                                    \
+    case DD:                                                                                                                 \
+        if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, lab, dil, warmup, ws, st, losses, g_logits, up_prj, up_pw, n_cb);   \
+        else launch_pair<DD, 8>(s, grid, lds2, a, lab, dil, warmup, ws, st, losses, g_logits, up_prj, up_pw, n_cb);          \
+        break;
+    switch (dil) {
+        BXI_PAIR_CASE(1) BXI_PAIR_CASE(2) BXI_PAIR_CASE(3) BXI_PAIR_CASE(4)
+        default: return BXI_ERR_UNSUPPORTED;
+    }
+#undef BXI_PAIR_CASE
+    return check_launch();
+}
+
+int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits,
+                   void* stream) {
+    InstArgs a;
+    int rc = fill_inst(in, a);
+    if (rc != BXI_OK) return rc;
+    if (!fused_eval_supported(dil)) return BXI_ERR_UNSUPPORTED;
+    if (a.N == 0) return BXI_OK;
+    if (!g_prj || !g_pw || !state || !g_logits) return BXI_ERR_NULL_POINTER;
+    if (a.N > 65535) return BXI_ERR_BAD_SHAPE;
+    if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
+    LossState st;
+    carve_state(const_cast<void*>(state), a.N, a.h, a.w, &st);
+    hipStream_t s = as_stream(stream);
+    BXI_LAUNCH("rescale", s, rescale_kernel, dim3(8, a.N), dim3(256), 0, s, a, dil, st, g_prj, g_pw, g_logits);
+    return check_launch();
+}
+
+}  // namespace bxi

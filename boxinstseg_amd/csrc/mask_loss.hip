@@ -16,7 +16,7 @@
 // h+w arg-max positions, fold the upstream gradients in from device memory).
 // Data layout in HBM: everything NCHW / row-major as the reference; per-pixel colour affinity is
 // never materialised as [N,8,h,w] -- box_kernel derives the 8-bit word it needs from Lab [B,3,h,w].
-#include "image_device.hpp"
+#include "loss_common.hpp"
 
 namespace bxi {
 
@@ -25,16 +25,7 @@ constexpr int kChunk = 256;     // columns per pass: 64 lanes x float4
 constexpr int kBR = 8;          // box tile rows    (box_kernel)
 constexpr int kBC = 64;         // box tile columns
 constexpr int kSlices = 8;      // row slices per instance in loss_apply
-constexpr int kMaxDil = 8;
-constexpr int kMaxT = 32;       // per-instance column partials reduced per unrolled batch by the leader workgroups
 
-struct InstArgs {
-    const float* logits;
-    const int64_t* gt_inds;
-    int N, h, w;
-    int Hc, Wc, stride;
-    GtTable gt;
-};
 
 struct LossWs {               // carved from the caller's workspace
     unsigned long long* colkey;  // [N,Ts,w] per-streaming-tile column max: packed (logit, first row in tile)
@@ -48,26 +39,10 @@ struct LossWs {               // carved from the caller's workspace
     float* dice;              // [N]
 };
 
-struct InstRec { int r0, r1, c0, c1, img, pad0, pad1, pad2; };   // 32 B: one load per workgroup
 struct WorkRec { int r0, r1, c0, c1, img, n, tile_r0, tile_c0; float n2max; int zero_bit, pad0, pad1; };  // 48 B: all a tile needs
 
-// (sim >= thresh) for a valid neighbour, as a compare on the squared Lab distance:
-// exp(-0.5*sqrt(n2)) >= thresh  <=>  n2 <= n2max, with n2max found in stage1 by bisecting the exact
-// f32 expression of the reference over the float bit patterns (the expression is monotone in n2).
-struct Pred { float n2max; int fast; int zero_bit; int pad; };
-constexpr float kNumScale = 16777216.f;   // 2^24
 
-struct InstRec;
-struct LossState {            // what bxi_boxinst_loss_backward_f32 needs (forward -> backward)
-    int* colarg;              // [N,w] arg-max row of column c
-    int* rowarg;              // [N,h] arg-max column of row r
-    float* gcol;              // [N,w] unit d loss_prj / d logit at (colarg[c], c)
-    float* grow;              // [N,h] unit d loss_prj / d logit at (r, rowarg[r])
-    InstRec* inst;            // [N]   box rectangles
-    float* scale;             // [1]   warmup / max(sum W, 1)
-};
 
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static inline int stream_tiles(int h) { return (h + kSR - 1) / kSR; }
 static inline int box_tiles(int h, int w) { return ((h + kBR - 1) / kBR) * ((w + kBC - 1) / kBC); }
@@ -92,83 +67,7 @@ static size_t carve_ws(void* base, int N, int h, int w, LossWs* ws) {
     return off;
 }
 
-static size_t carve_state(void* base, int N, int h, int w, LossState* st) {
-    size_t off = 0;
-    char* p = (char*)base;
-    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return p ? p + o : nullptr; };
-    int* colarg = (int*)take(sizeof(int) * (size_t)N * w);
-    int* rowarg = (int*)take(sizeof(int) * (size_t)N * h);
-    float* gcol = (float*)take(sizeof(float) * (size_t)N * w);
-    float* grow = (float*)take(sizeof(float) * (size_t)N * h);
-    InstRec* inst = (InstRec*)take(32 * (size_t)(N > 0 ? N : 1));
-    float* scale = (float*)take(sizeof(float));
-    if (st) { st->colarg = colarg; st->rowarg = rowarg; st->gcol = gcol; st->grow = grow; st->inst = inst; st->scale = scale; }
-    return off;
-}
 
-// ---- device helpers ----------------------------------------------------------------------------
-struct InstBox {
-    Rect box;   // cells whose sample lies in the GT box            (bitmask == 1)
-    Rect dil;   // box grown by `dilation`, clipped                  (pairwise gradient != 0)
-    int img;
-    bool any;
-};
-
-__device__ __forceinline__ InstBox inst_box(const InstArgs& a, int n, int dil) {
-    InstBox ib;
-    ib.img = 0;
-    ib.box.r0 = ib.box.r1 = ib.box.c0 = ib.box.c1 = 0;
-    const int64_t g = a.gt_inds[n];
-    if (g >= 0 && g < a.gt.first[a.gt.B]) {
-        const float* bx = gt_box(a.gt, (int)g, ib.img);
-        ib.box = box_rect(bx, a.Hc, a.Wc, a.stride, a.stride / 2, a.h, a.w);
-    }
-    ib.any = ib.box.r1 > ib.box.r0 && ib.box.c1 > ib.box.c0;
-    ib.dil = ib.box;
-    if (ib.any) {
-        ib.dil.r0 = max(ib.box.r0 - dil, 0); ib.dil.r1 = min(ib.box.r1 + dil, a.h);
-        ib.dil.c0 = max(ib.box.c0 - dil, 0); ib.dil.c1 = min(ib.box.c1 + dil, a.w);
-    }
-    return ib;
-}
-
-__device__ __forceinline__ InstBox inst_from_rec(const InstRec& rc, int dil, int h, int w) {
-    InstBox ib;
-    ib.box.r0 = rc.r0; ib.box.r1 = rc.r1; ib.box.c0 = rc.c0; ib.box.c1 = rc.c1;
-    ib.img = rc.img;
-    ib.any = rc.r1 > rc.r0 && rc.c1 > rc.c0;
-    ib.dil = ib.box;
-    if (ib.any) {
-        ib.dil.r0 = max(rc.r0 - dil, 0); ib.dil.r1 = min(rc.r1 + dil, h);
-        ib.dil.c0 = max(rc.c0 - dil, 0); ib.dil.c1 = min(rc.c1 + dil, w);
-    }
-    return ib;
-}
-
-// (p, q) = (sigmoid(x), sigmoid(-x)), both accurate relatively (no 1-p cancellation)
-__device__ __forceinline__ float2 sig_pair(float x) {
-    const float e = __expf(-fabsf(x));
-    const float r = __builtin_amdgcn_rcpf(1.f + e);   // v_rcp_f32 (1 ulp); __frcp_rn would expand to a full IEEE division
-    const float er = e * r;
-    return x >= 0.f ? make_float2(r, er) : make_float2(er, r);
-}
-
-__device__ __forceinline__ float4 load4(const float* row, int c, int w, bool vec) {
-    if (vec) return *reinterpret_cast<const float4*>(row + c);
-    float4 v;
-    v.x = c + 0 < w ? row[c + 0] : -INFINITY;
-    v.y = c + 1 < w ? row[c + 1] : -INFINITY;
-    v.z = c + 2 < w ? row[c + 2] : -INFINITY;
-    v.w = c + 3 < w ? row[c + 3] : -INFINITY;
-    return v;
-}
-__device__ __forceinline__ void store4(float* row, int c, int w, bool vec, float4 v) {
-    if (vec) { *reinterpret_cast<float4*>(row + c) = v; return; }
-    if (c + 0 < w) row[c + 0] = v.x;
-    if (c + 1 < w) row[c + 1] = v.y;
-    if (c + 2 < w) row[c + 2] = v.z;
-    if (c + 3 < w) row[c + 3] = v.w;
-}
 
 // ================================================================================================
 // Kernel 1: stage1 = { pool_rgb + Lab workgroups }  ||  { logit streaming workgroups }
@@ -177,32 +76,6 @@ __device__ __forceinline__ void store4(float* row, int c, int w, bool vec, float
 // workgroups: N*Ts streaming waves followed by B*h*w/64 pooling waves, all resident at once
 // (about 9 waves per CU at 2x800x1024x32), every wave issuing all of its loads before anything else.
 
-// exact f32 predicate of the reference for a valid neighbour: exp(-||dLab|| * 0.5) >= thresh  (:237, :1324)
-__device__ __forceinline__ bool sim_pred(float n2, float thresh) {
-    return expf(__fmul_rn(-__fsqrt_rn(n2), 0.5f)) >= thresh;
-}
-
-__device__ __forceinline__ Pred make_pred(float thresh) {   // uniform: every lane computes the same value
-    Pred p; p.pad = 0; p.fast = 1;
-    p.zero_bit = (0.f >= thresh) ? 1 : 0;            // weight of a padded / masked-out neighbour (sim == 0)
-    // sim_pred(n2) is non-increasing in n2 >= 0 and positive floats order like their bit patterns:
-    // bisect the bit pattern for the largest n2 that still passes.
-    if (!sim_pred(0.f, thresh)) p.n2max = -1.f;                         // thresh > 1: never
-    else if (sim_pred(3.0e38f, thresh)) p.n2max = INFINITY;             // thresh <= 0 (exp underflows to 0): always
-    else {
-        uint32_t lo = 0u, hi = __float_as_uint(3.0e38f);                // pred(lo) true, pred(hi) false
-        const float dstar = -2.f * logf(thresh);                        // analytic boundary: n2 = (2 ln thresh)^2
-        const uint32_t cb = __float_as_uint(dstar * dstar);
-        if (cb > 256u && cb < __float_as_uint(3.0e38f) - 256u && sim_pred(__uint_as_float(cb - 128u), thresh) &&
-            !sim_pred(__uint_as_float(cb + 128u), thresh)) { lo = cb - 128u; hi = cb + 128u; }   // 8 steps instead of 31
-        while (hi - lo > 1u) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (sim_pred(__uint_as_float(mid), thresh)) lo = mid; else hi = mid;
-        }
-        p.n2max = __uint_as_float(lo);
-    }
-    return p;
-}
 
 // per-lane box lookup (lanes hold different instances): the image table is walked with a uniform
 // loop so that the by-value kernel argument is never indexed per lane.
@@ -982,9 +855,7 @@ __global__ __launch_bounds__(256) void loss_apply_kernel(InstArgs a, int dil, Lo
 __global__ void zero_losses_kernel(float* losses) { losses[0] = 0.f; losses[1] = 0.f; }
 
 // ---- host side ---------------------------------------------------------------------------------
-int fill_gt_table(const float* const* boxes_per_img_host, const int* gt_count_host, int B, GtTable& gt, int& G);
-
-static int fill_inst(const bxi_instances* in, InstArgs& a) {
+int fill_inst(const bxi_instances* in, InstArgs& a) {
     if (!in) return BXI_ERR_NULL_POINTER;
     if (in->N < 0 || in->h <= 0 || in->w <= 0 || in->stride < 1) return BXI_ERR_BAD_SHAPE;
     if (in->Hc != in->h * in->stride || in->Wc != in->w * in->stride) return BXI_ERR_BAD_SHAPE;
@@ -1004,10 +875,6 @@ static size_t box_lds_bytes(int dil, bool from_lab) {
     return sizeof(float2) * PR * PC + (from_lab ? sizeof(float) * 3 * PR * PC : PR * PC);
 }
 
-int fill_pool_args(const bxi_image_batch* bt, uint8_t* rgb_small, float* lab, PoolArgs& pa);
-int fill_image_meta(const bxi_image_batch* bt, ImageMeta& meta, Denorm& dn);
-bool pool_vec_ok(const bxi_image_batch* bt, int stride);
-int launch_pool(const bxi_image_batch* bt, int stride, uint8_t* rgb_small, float* lab, hipStream_t s);
 
 // One evaluation.  batch != NULL: image side included (lab is a [B,3,h,w] f32 scratch the pool
 // workgroups fill and box_kernel reads).  batch == NULL: `affinity` bits are given.
@@ -1042,7 +909,7 @@ int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, co
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
     LossWs ws;
     carve_ws(workspace, a.N, a.h, a.w, &ws);
-    LossState st = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    LossState st = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (state) {
         if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
         carve_state(state, a.N, a.h, a.w, &st);
@@ -1134,6 +1001,13 @@ size_t bxi_boxinst_loss_workspace_bytes(int N, int h, int w) {
 size_t bxi_boxinst_loss_state_bytes(int N, int h, int w) {
     if (N < 0 || h <= 0 || w <= 0) return 0;
     return bxi::loss_state_bytes(N, h, w);
+}
+size_t bxi_boxinst_loss_state_status_offset(int N, int h, int w) {
+    if (N < 0 || h <= 0 || w <= 0) return 0;
+    bxi::LossState st;
+    char base[1];
+    bxi::carve_state(base, N, h, w, &st);
+    return (size_t)((char*)st.status - base);
 }
 
 int bxi_boxinst_loss_fwd_bwd_f32(const bxi_instances* inst_host, const uint8_t* affinity, int size, int dilation,

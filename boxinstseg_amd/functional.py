@@ -165,28 +165,172 @@ def box_bitmasks(gt_bboxes: Sequence[torch.Tensor], Hc: int, Wc: int, stride: in
 # ------------------------------------------------------------------------------------------------
 # loss
 # ------------------------------------------------------------------------------------------------
-class BoxInstMaskLoss(torch.autograd.Function):
-    """(loss_prj, loss_pairwise) = f(mask_logits); forward and backward in ONE pass over the logits.
+class _EvalPlan:
+    """Everything about one evaluation that depends on shapes / metadata only, marshalled once: the two C structs,
+    their host arrays, and the (per stream) workspace.  A call then only patches five device pointers."""
 
-    forward  : bxi_boxinst_eval_f32 (image side + fused loss) -- or bxi_boxinst_loss_fwd_bwd_f32 when
-               precomputed affinity bits are given -- writes both scalars and the un-finished
-               gradient (zeros + the un-normalised pairwise gradient on the box tiles).
-    backward : bxi_boxinst_loss_backward_f32 normalises, adds the projection gradient and folds the
-               two upstream scalars in, reading them from device memory (no host sync).
+    def __init__(self, dev, stream, B, Hc, Wc, stride, N, h, w, img_h, img_w, rows_rm, mean, std, to_rgb, counts):
+        lib = _lib.load()
+        self._h, self._w, self._rm = _lib.int_array(img_h), _lib.int_array(img_w), _lib.int_array(rows_rm)
+        self._cnt = _lib.int_array(counts)
+        self._ptrs = _lib.ptr_array([0] * max(len(counts), 1))
+        b = _lib.ImageBatch()
+        b.B, b.Hc, b.Wc = B, Hc, Wc
+        b.img_h_host = C.cast(self._h, C.POINTER(C.c_int))
+        b.img_w_host = C.cast(self._w, C.POINTER(C.c_int))
+        b.rows_removed_host = C.cast(self._rm, C.POINTER(C.c_int))
+        for i in range(3):
+            b.mean[i], b.std[i] = mean[i], std[i]
+        b.to_rgb = int(to_rgb)
+        b.image_masks = 0
+        s = _lib.Instances()
+        s.N, s.h, s.w = N, h, w
+        s.boxes_per_img_host = C.cast(self._ptrs, C.POINTER(C.c_void_p))
+        s.gt_count_host = C.cast(self._cnt, C.POINTER(C.c_int))
+        s.B = len(counts)
+        s.Hc, s.Wc, s.stride = Hc, Wc, stride
+        self.batch, self.inst = b, s
+        self.batch_ref, self.inst_ref = C.byref(b), C.byref(s)
+        self.ws = torch.empty(max(lib.bxi_boxinst_eval_workspace_bytes(B, Hc, Wc, stride, N), 256), dtype=torch.uint8,
+                              device=dev)
+        self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), self.ws.numel()
+        self.state_bytes = (max(lib.bxi_boxinst_loss_state_bytes(N, h, w), 256) + 255) // 256 * 256
+        self.grad_elems = N * h * w
+        self.eval = lib.bxi_boxinst_eval_f32
+        self.rescale = lib.bxi_boxinst_grad_rescale_f32
+
+
+_PLANS: Dict[tuple, _EvalPlan] = {}
+DEBUG_KEEP_LAST = False          # tests: keep the last evaluation's buffer so that its status word can be read
+_LAST: Dict[str, object] = {}
+
+
+def last_eval_status() -> Tuple[int, int]:
+    """(status, tile rows) of the last evaluation (needs DEBUG_KEEP_LAST; synchronises)."""
+    if not _LAST or not _LAST['need_grad']:
+        return 0, 0
+    plan, buf = _LAST['plan'], _LAST['buf']
+    off = 256 + _lib.load().bxi_boxinst_loss_state_status_offset(plan.inst.N, plan.inst.h, plan.inst.w)
+    v = buf[off:off + 8].view(torch.int32).cpu()
+    return int(v[0]), int(v[1])
+
+
+def _eval_plan(imgs, img_metas, mask_logits, gt_bboxes, stride: int, bottom_pixels_removed: int, stream: int) -> _EvalPlan:
+    if imgs.dim() != 4 or imgs.size(1) != 3:
+        raise RuntimeError(f'imgs must be [B,3,H,W], got {tuple(imgs.shape)}')
+    if mask_logits.dim() != 4 or mask_logits.size(1) != 1:
+        raise RuntimeError(f'mask_logits must be [N,1,h,w], got {tuple(mask_logits.shape)}')
+    B, _, Hc, Wc = imgs.shape
+    N, _, h, w = mask_logits.shape
+    cfg = img_metas[0]['img_norm_cfg'] if B else None
+    key = (imgs.device.index, stream, B, Hc, Wc, stride, N, h, w, bottom_pixels_removed,
+           tuple((m['img_shape'][0], m['img_shape'][1], m['ori_shape'][0]) for m in img_metas),
+           None if cfg is None else (tuple(float(v) for v in cfg['mean']), tuple(float(v) for v in cfg['std']), bool(cfg['to_rgb'])),
+           tuple(int(b.shape[0]) if b.dim() == 2 else b.numel() // 4 for b in gt_bboxes))
+    plan = _PLANS.get(key)
+    if plan is None:
+        if B > _lib.BXI_MAX_IMAGES or len(gt_bboxes) > _lib.BXI_MAX_IMAGES:
+            raise RuntimeError(f'at most {_lib.BXI_MAX_IMAGES} images per call, got {B}')
+        if len(img_metas) != B:
+            raise RuntimeError(f'{B} images but {len(img_metas)} img_metas')
+        if h * stride != Hc or w * stride != Wc:
+            raise RuntimeError(f'mask_logits {h}x{w} x stride {stride} != image canvas {Hc}x{Wc}')
+        for m in img_metas[1:]:
+            c2 = m['img_norm_cfg']
+            if list(c2['mean']) != list(cfg['mean']) or list(c2['std']) != list(cfg['std']) or \
+                    bool(c2['to_rgb']) != bool(cfg['to_rgb']):
+                raise RuntimeError('all images of a batch must share img_norm_cfg')
+        mean, std, to_rgb = key[11] if cfg is not None else ((0.0,) * 3, (1.0,) * 3, True)
+        if len(_PLANS) > 64:
+            _PLANS.clear()
+        plan = _PLANS[key] = _EvalPlan(
+            imgs.device, stream, B, Hc, Wc, stride, N, h, w, [m['img_shape'][0] for m in img_metas],
+            [m['img_shape'][1] for m in img_metas],
+            [rows_removed(bottom_pixels_removed, m['img_shape'], m['ori_shape']) for m in img_metas], mean, std, to_rgb,
+            key[12])
+    return plan
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class BoxInstMaskLoss(torch.autograd.Function):
+    """(loss_prj, loss_pairwise) = f(mask_logits); forward AND backward in ONE pass over the logits.
+
+    forward  : bxi_boxinst_eval_f32 (two launches) writes both scalars and the FINISHED gradient for unit upstream
+               factors -- what ``loss.backward()`` seeds the two terms with.
+               (Precomputed affinity bits: bxi_boxinst_loss_fwd_bwd_f32 + bxi_boxinst_loss_backward_f32.)
+    backward : bxi_boxinst_grad_rescale_f32 -- reads the two upstream scalars from device memory (no host sync) and returns
+               at once when both are 1; otherwise rewrites the gradient for them.
+    A second backward through the same node (``retain_graph=True``) re-evaluates into a fresh buffer, as the first
+    buffer then belongs to autograd (the reference's op supports re-entrant backward, pairwise.py:17-26).
     """
 
     @staticmethod
     def forward(ctx, mask_logits: torch.Tensor, imgs: Optional[torch.Tensor], img_metas, gt_inds: torch.Tensor,
                 gt_bboxes, cfg: Dict, affinity_bits: Optional[torch.Tensor]):
         _require_cuda(mask_logits=mask_logits, imgs=imgs, gt_inds=gt_inds, affinity_bits=affinity_bits)
+        ctx.in_dtype = mask_logits.dtype
+        ctx.cfg = cfg
+        ctx.fused = affinity_bits is None
+        need_grad = bool(ctx.needs_input_grad[0])
+        if affinity_bits is not None:
+            return BoxInstMaskLoss._forward_bits(ctx, mask_logits, gt_inds, gt_bboxes, cfg, affinity_bits, need_grad)
+        ctx.imgs, ctx.metas, ctx.gt_inds, ctx.boxes = imgs, img_metas, gt_inds, gt_bboxes
+        ctx.logits = mask_logits.detach()
+        ctx.calls = 0
+        losses, ctx.grad, ctx.state, ctx.plan, ctx.keep = BoxInstMaskLoss._evaluate(ctx, need_grad)
+        return losses[0], losses[1]
+
+    @staticmethod
+    def _evaluate(ctx, need_grad: bool):
+        cfg, logits = ctx.cfg, ctx.logits
+        dev = logits.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        imgs, x = _f32c(ctx.imgs), _f32c(logits)
+        gi = ctx.gt_inds
+        if gi.dtype != torch.int64 or gi.device != dev or not gi.is_contiguous():
+            gi = gi.to(device=dev, dtype=torch.int64).contiguous()
+        boxes = [b if (b.dtype == torch.float32 and b.device == dev and b.is_contiguous()) else
+                 b.detach().to(device=dev, dtype=torch.float32).contiguous() for b in ctx.boxes]
+        plan = _eval_plan(imgs, ctx.metas, x, boxes, int(cfg['out_stride']), int(cfg['bottom_pixels_removed']), stream)
+        if gi.numel() != plan.inst.N:
+            raise RuntimeError(f'{plan.inst.N} instances but {gi.numel()} gt_inds')
+        # ONE allocation: [losses 256 B][state][gradient]
+        nbytes = 256 + (plan.state_bytes + 4 * plan.grad_elems if need_grad else 0)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        base = buf.data_ptr()
+        if base & 255:
+            raise RuntimeError('allocator returned a buffer that is not 256-byte aligned')
+        plan.batch.imgs = imgs.data_ptr()
+        plan.inst.logits = x.data_ptr()
+        plan.inst.gt_inds = gi.data_ptr()
+        for i, b in enumerate(boxes):
+            plan._ptrs[i] = b.data_ptr() if b.numel() else 0
+        grad = None
+        if need_grad:
+            grad = buf[256 + plan.state_bytes:].view(torch.float32).view(x.shape)
+        with torch.cuda.device(dev):
+            _lib.check('bxi_boxinst_eval_f32', plan.eval(
+                plan.batch_ref, plan.inst_ref, int(cfg['pairwise_size']), int(cfg['pairwise_dilation']),
+                float(cfg['pairwise_color_thresh']), float(cfg['warmup_factor']), 0, 0, base,
+                base + 256 + plan.state_bytes if need_grad else 0, base + 256 if need_grad else 0,
+                plan.ws_ptr, plan.ws_bytes, stream))
+        losses = buf[:8].view(torch.float32)
+        if DEBUG_KEEP_LAST:
+            _LAST.clear()
+            _LAST.update(buf=buf, plan=plan, need_grad=need_grad)
+        return losses, grad, base + 256, plan, (imgs, x, gi, boxes, buf)
+
+    @staticmethod
+    def _forward_bits(ctx, mask_logits, gt_inds, gt_bboxes, cfg, affinity_bits, need_grad):
         dev = mask_logits.device
         stride, size, dil = int(cfg['out_stride']), int(cfg['pairwise_size']), int(cfg['pairwise_dilation'])
-        if imgs is not None:
-            Hc, Wc = imgs.shape[2], imgs.shape[3]
-        else:
-            Hc, Wc = mask_logits.shape[2] * stride, mask_logits.shape[3] * stride
+        Hc, Wc = mask_logits.shape[2] * stride, mask_logits.shape[3] * stride
         inst = _Inst(mask_logits, gt_inds, gt_bboxes, Hc, Wc, stride)
-        need_grad = bool(ctx.needs_input_grad[0])
         lib = _lib.load()
         losses = torch.empty(2, dtype=torch.float32, device=dev)
         grad = torch.empty_like(inst.logits) if need_grad else None
@@ -194,47 +338,59 @@ class BoxInstMaskLoss(torch.autograd.Function):
         if need_grad:
             state = torch.empty(max(lib.bxi_boxinst_loss_state_bytes(inst.N, inst.h, inst.w), 256),
                                 dtype=torch.uint8, device=dev)
+        bits = affinity_bits.contiguous()
+        if bits.dtype != torch.uint8 or tuple(bits.shape) != (len(gt_bboxes), inst.h, inst.w):
+            raise RuntimeError('affinity_bits must be uint8 [B,h,w]')
+        ws = torch.empty(max(lib.bxi_boxinst_loss_workspace_bytes(inst.N, inst.h, inst.w), 256), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            if affinity_bits is None:
-                batch = _Batch(imgs, img_metas, int(cfg['bottom_pixels_removed']))
-                nbytes = lib.bxi_boxinst_eval_workspace_bytes(batch.B, Hc, Wc, stride, inst.N)
-                ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
-                _lib.check('bxi_boxinst_eval_f32', lib.bxi_boxinst_eval_f32(
-                    C.byref(batch.struct), C.byref(inst.struct), size, dil, float(cfg['pairwise_color_thresh']),
-                    float(cfg['warmup_factor']), losses.data_ptr(), 0 if grad is None else grad.data_ptr(),
-                    0 if state is None else state.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
-            else:
-                bits = affinity_bits.contiguous()
-                if bits.dtype != torch.uint8 or tuple(bits.shape) != (len(gt_bboxes), inst.h, inst.w):
-                    raise RuntimeError('affinity_bits must be uint8 [B,h,w]')
-                nbytes = lib.bxi_boxinst_loss_workspace_bytes(inst.N, inst.h, inst.w)
-                ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
-                _lib.check('bxi_boxinst_loss_fwd_bwd_f32', lib.bxi_boxinst_loss_fwd_bwd_f32(
-                    C.byref(inst.struct), bits.data_ptr(), size, dil, float(cfg['warmup_factor']),
-                    losses.data_ptr(), 0 if grad is None else grad.data_ptr(),
-                    0 if state is None else state.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
-        ctx.inst = inst
-        ctx.dil = dil
-        ctx.grad = grad
-        ctx.state = state
-        ctx.in_dtype = mask_logits.dtype
+            _lib.check('bxi_boxinst_loss_fwd_bwd_f32', lib.bxi_boxinst_loss_fwd_bwd_f32(
+                C.byref(inst.struct), bits.data_ptr(), size, dil, float(cfg['warmup_factor']),
+                losses.data_ptr(), 0 if grad is None else grad.data_ptr(),
+                0 if state is None else state.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
+        ctx.inst, ctx.dil, ctx.grad, ctx.state_t = inst, dil, grad, state
         return losses[0], losses[1]
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_prj: torch.Tensor, g_pw: torch.Tensor):
+        if not ctx.fused:
+            return BoxInstMaskLoss._backward_bits(ctx, g_prj, g_pw)
+        if ctx.grad is None and ctx.calls == 0:
+            raise RuntimeError('BoxInstMaskLoss.backward without a gradient request')
+        if ctx.calls > 0:            # re-entrant backward: the first buffer now belongs to autograd
+            _, grad, state, plan, keep = BoxInstMaskLoss._evaluate(ctx, True)
+        else:
+            grad, state, plan, keep = ctx.grad, ctx.state, ctx.plan, ctx.keep
+            ctx.grad = None
+        ctx.calls += 1
+        dev = grad.device
+        if plan.inst.N > 0:
+            if g_prj.dtype != torch.float32 or g_prj.device != dev:
+                g_prj = g_prj.to(device=dev, dtype=torch.float32)
+            if g_pw.dtype != torch.float32 or g_pw.device != dev:
+                g_pw = g_pw.to(device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                _lib.check('bxi_boxinst_grad_rescale_f32', plan.rescale(
+                    plan.inst_ref, g_prj.data_ptr(), g_pw.data_ptr(), int(ctx.cfg['pairwise_dilation']), state,
+                    grad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        if grad.dtype != ctx.in_dtype:
+            grad = grad.to(ctx.in_dtype)
+        return grad, None, None, None, None, None, None
+
+    @staticmethod
+    def _backward_bits(ctx, g_prj, g_pw):
         grad, inst = ctx.grad, ctx.inst
         if grad is None:
-            raise RuntimeError('BoxInstMaskLoss.backward called twice (the fused gradient buffer is finished in '
-                               'place by the first call) or without a gradient request')
-        ctx.grad = None    # hand the buffer to autograd; a second backward must re-run the forward
+            raise RuntimeError('BoxInstMaskLoss.backward (precomputed-bits path) called twice: its gradient buffer is '
+                               'finished in place by the first call; evaluate again')
+        ctx.grad = None
         dev = grad.device
         if inst.N > 0:
             g_prj = g_prj.to(device=dev, dtype=torch.float32).contiguous()
             g_pw = g_pw.to(device=dev, dtype=torch.float32).contiguous()
             with torch.cuda.device(dev):
                 _lib.check('bxi_boxinst_loss_backward_f32', _lib.load().bxi_boxinst_loss_backward_f32(
-                    C.byref(inst.struct), g_prj.data_ptr(), g_pw.data_ptr(), ctx.dil, ctx.state.data_ptr(),
+                    C.byref(inst.struct), g_prj.data_ptr(), g_pw.data_ptr(), ctx.dil, ctx.state_t.data_ptr(),
                     grad.data_ptr(), _stream(dev)))
         if grad.dtype != ctx.in_dtype:
             grad = grad.to(ctx.in_dtype)
@@ -251,14 +407,21 @@ def boxinst_mask_loss(mask_logits: torch.Tensor, gt_inds: torch.Tensor, gt_bboxe
     Either ``imgs`` + ``img_metas`` (targets are computed on the device from the network input) or
     precomputed ``affinity_bits`` (from :func:`color_affinity`) must be given.
     Returns ``{'loss_prj', 'loss_pairwise'}`` attached to the autograd graph of ``mask_logits``.
+    Built for ``pairwise_size == 3`` and ``pairwise_dilation <= 4`` (``fused_supported``); other windows are
+    composed from the op-level kernels by ``CondInstMaskHead._composed_loss``.
     """
     if affinity_bits is None and (imgs is None or img_metas is None):
         raise RuntimeError('need imgs + img_metas or affinity_bits')
-    if pairwise_size != 3:
-        raise RuntimeError('the fused path is built for pairwise_size == 3; use boxinst_mask_loss_composed')
+    if not fused_supported(pairwise_size, pairwise_dilation, affinity_bits is not None):
+        raise RuntimeError('the fused path is built for pairwise_size == 3 (dilation <= 4 from images, <= 8 from bits); '
+                           'use CondInstMaskHead.loss, which composes the op-level kernels for other windows')
     cfg = dict(out_stride=out_stride, bottom_pixels_removed=bottom_pixels_removed, pairwise_size=pairwise_size,
                pairwise_dilation=pairwise_dilation, pairwise_color_thresh=pairwise_color_thresh,
                warmup_factor=warmup_factor)
     loss_prj, loss_pw = BoxInstMaskLoss.apply(mask_logits, imgs, img_metas, gt_inds, list(gt_bboxes), cfg,
                                               affinity_bits)
     return {'loss_prj': loss_prj, 'loss_pairwise': loss_pw}
+
+
+def fused_supported(pairwise_size: int, pairwise_dilation: int, from_bits: bool = False) -> bool:
+    return pairwise_size == 3 and 1 <= pairwise_dilation <= (8 if from_bits else 4)

@@ -237,7 +237,7 @@ class CondInstMaskHead(nn.Module):
         warmup = self._tick()
         if not self.boxinst_enabled:
             return {'loss_mask': self._supervised_loss(mask_logits, gt_inds, gt_masks)}
-        if self.pairwise_size == 3:
+        if F_hip.fused_supported(self.pairwise_size, self.pairwise_dilation):
             return F_hip.boxinst_mask_loss(
                 mask_logits, gt_inds, gt_bboxes, imgs=imgs, img_metas=img_metas, out_stride=self.out_stride,
                 bottom_pixels_removed=self.bottom_pixels_removed, pairwise_size=self.pairwise_size,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BXI_ABI_VERSION 1
+#define BXI_ABI_VERSION 2
 #define BXI_MAX_IMAGES 64   /* images per call (per-image metadata travels in kernel arguments) */
 
 typedef enum bxi_status {
@@ -150,6 +150,8 @@ typedef struct bxi_instances {
 
 size_t bxi_boxinst_loss_workspace_bytes(int N, int h, int w);
 size_t bxi_boxinst_loss_state_bytes(int N, int h, int w);
+/* byte offset, inside `state`, of two int32: {status (0 = fine; see bxi_boxinst_eval_f32), tile rows used}. */
+size_t bxi_boxinst_loss_state_status_offset(int N, int h, int w);
 
 /* Forward (+ the bulk of the backward):
  * losses[0] = loss_prj, losses[1] = loss_pairwise (device, f32), complete when the call's work is done.
@@ -161,8 +163,9 @@ size_t bxi_boxinst_loss_state_bytes(int N, int h, int w);
  * state (bxi_boxinst_loss_state_bytes, 256-B aligned): arg-max positions, unit projection gradients,
  *   box rectangles and the normaliser, for the backward; nullable when g_logits is NULL.
  * workspace (bxi_boxinst_loss_workspace_bytes, 256-B aligned): scratch, contents undefined after.
- * Only size == 3 (K = 8) is built into this fused path; other sizes return BXI_ERR_UNSUPPORTED
- * and the host composes section 1 + torch ops as the reference does.
+ * (The path for PRECOMPUTED affinity bits / explicit image masks; the evaluation from the network input is
+ * bxi_boxinst_eval_f32 below.)  Only size == 3 (K = 8) is built into this fused path; other sizes return
+ * BXI_ERR_UNSUPPORTED and the host composes section 1 + torch ops as the reference does.
  * N == 0 writes two zeros (documented deviation; the reference yields NaN). */
 int bxi_boxinst_loss_fwd_bwd_f32(const bxi_instances* inst_host, const uint8_t* affinity,
                                  int size, int dilation, float warmup, float* losses, float* g_logits,
@@ -174,16 +177,39 @@ int bxi_boxinst_loss_fwd_bwd_f32(const bxi_instances* inst_host, const uint8_t* 
 int bxi_boxinst_loss_backward_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw,
                                   int dilation, const void* state, float* g_logits, void* stream);
 
-/* Whole forward in one host call, two launches: the image side (stage A above) runs inside the
- * first loss kernel next to the logit streaming, and the affinity bits are derived from Lab where
- * the loss needs them (nothing of stage B is materialised).  Same results as
- * bxi_color_affinity_f32 + bxi_boxinst_loss_fwd_bwd_f32.  batch_host->image_masks must be NULL.
- * workspace must hold bxi_boxinst_eval_workspace_bytes(...), 256-B aligned. */
+/* The evaluation proper: forward AND finished backward in one host call, two launches (prep, pair).
+ *   launch 1: image side (stage A above: de-normalise, 4x4 pool, Lab) next to the logit streaming (row / column maxima,
+ *             zero-fill of g_logits) and the per-instance tables;
+ *   launch 2: projection term per instance, pair weights and pairwise term per box tile (colour affinity derived from
+ *             Lab where it is needed, nothing of stage B is materialised), normaliser, both loss scalars.
+ * losses[0] = loss_prj, losses[1] = loss_pairwise (device, f32), complete when the call's work is done.
+ * g_logits [N,1,h,w] (nullable: forward only) receives the FINISHED gradient
+ *       up_prj * d loss_prj / d logits  +  up_pw * d loss_pairwise / d logits,
+ *   every element written; up_prj / up_pw are DEVICE scalars read by the kernels (no host sync), NULL = 1 -- what
+ *   `loss.backward()` seeds the two terms with (mmdet/core/optimizers hooks; a loss scale is known before the forward).
+ *   Different factors later: bxi_boxinst_grad_rescale_f32.
+ * warmup: min(_iter / pairwise_warmup, 1) (:1330-1331), evaluated on the host by the caller.
+ * state (bxi_boxinst_loss_state_bytes, 256-B aligned; required with g_logits): arg-max positions, unit projection
+ *   gradients, box rectangles, normaliser, the factors applied, and a status word (0; non-zero = an in-kernel wait timed
+ *   out, which the grid order rules out -- checked by the tests).
+ * workspace (bxi_boxinst_eval_workspace_bytes, 256-B aligned): scratch incl. Lab; contents undefined after; every word
+ *   the second launch polls is zeroed by the first, so no initialisation is required.  One evaluation per workspace in flight.
+ * batch_host->image_masks must be NULL (explicit masks: bxi_color_affinity_f32 + bxi_boxinst_loss_fwd_bwd_f32).
+ * size == 3 and dilation <= 4 are built; others return BXI_ERR_UNSUPPORTED and the host composes section 1 + torch ops
+ * as the reference does.  N == 0 writes two zeros (documented deviation; the reference yields NaN). */
 size_t bxi_boxinst_eval_workspace_bytes(int B, int Hc, int Wc, int stride, int N);
 int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host,
                          int size, int dilation, float color_thresh, float warmup,
+                         const float* up_prj, const float* up_pw,
                          float* losses, float* g_logits, void* state,
                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* g_logits finished by bxi_boxinst_eval_f32 for the factors recorded in `state`  ->  finished for (g_prj, g_pw)
+ * (DEVICE scalars: the upstream gradients autograd hands over; no host sync).  The kernel returns at once when they
+ * equal the recorded ones (the usual case).  At most one effective rescale per evaluation (the record is not updated);
+ * a recorded up_pw of 0 cannot be rescaled. */
+int bxi_boxinst_grad_rescale_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw, int dilation,
+                                 const void* state, float* g_logits, void* stream);
 
 /* ===========================================================================================
  * 4. The producer of mask_logits -- replaces CondInstMaskHead.forward (condinst_head.py:1139-1164):

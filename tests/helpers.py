@@ -32,6 +32,7 @@ def to_dev(d, dev):
 
 def hip_loss(d, dev, warmup=1.0, up=None, **kw):
     """-> (loss_prj, loss_pairwise, grad[N,h,w] numpy)."""
+    F_hip.DEBUG_KEEP_LAST = True
     t = to_dev(d, dev)
     logits = t['logits'].clone().requires_grad_(True)
     out = F_hip.boxinst_mask_loss(logits, t['gt_inds'], t['gt_bboxes'], imgs=t['imgs'], img_metas=d['img_metas'],
@@ -41,6 +42,9 @@ def hip_loss(d, dev, warmup=1.0, up=None, **kw):
     else:
         (up[0] * out['loss_prj'] + up[1] * out['loss_pairwise']).backward()
     torch.cuda.synchronize()
+    if kw.get('pairwise_dilation', 2) <= 4 and logits.size(0) > 0:
+        status, rows = F_hip.last_eval_status()
+        assert status == 0 and rows in (4, 8), f'in-kernel wait timed out: status {status}'
     return float(out['loss_prj'].detach()), float(out['loss_pairwise'].detach()), logits.grad.cpu().numpy()[:, 0]
 
 
