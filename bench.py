@@ -3,19 +3,24 @@
 
 Metric (BASELINE.json): pairwise+projection loss fwd+bwd images/sec @ 2x800x1024 x 32 instances.
 One *step* = one loss evaluation on a 2-image batch, through the C ABI of libboxinst_hip.so:
-  bxi_boxinst_eval_f32           stage1 (image pool+Lab || logit streaming) -> box (pairwise tiles + projection leaders + loss scalars)
-  bxi_boxinst_loss_backward_f32  loss_apply: normalise, add the projection gradient, fold upstream grads
-i.e. everything CondInstMaskHead.loss + .backward() do for mask_logits, from the normalised images,
-boxes and logits already resident in HBM to loss_prj, loss_pairwise and d(loss)/d(mask_logits).
-Inputs rotate over `--sets` independent batches (default 8 x ~36 MB > the 256 MB Infinity Cache)
-so that every step reads cold data.
+  bxi_boxinst_eval_f32   prep (image pool + Lab || logit streaming || tables)  ->  pair (projection leaders, pair weights,
+                         pairwise term on the box tiles, normaliser, both loss scalars, FINISHED gradient)
+i.e. everything CondInstMaskHead.loss + .backward() do for mask_logits, from the normalised images, boxes and logits
+already resident in HBM to loss_prj, loss_pairwise and d(loss_prj + loss_pairwise)/d(mask_logits); the two upstream
+factors are read from device memory inside the kernels (ones here, as `loss.backward()` seeds them).
+Inputs rotate over `--sets` independent batches (default 8 x ~36 MB > the 256 MB Infinity Cache) so that every step
+reads cold data.  Before the timed region the GPU is kept busy for >= 0.15 s whatever --warmup says, so that a
+20-step run sees the same clocks as a 2000-step run.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode graph|eager]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode eager|graph]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  The path has no exchange step (every unit is rank-local):
-ranks are weak-scaled replicas; RCCL is used for the barriers, the MAX of the elapsed times and one
-all-reduce of the summed loss scalars after the timed region.
+`python bench.py --gpus N` without RANK in the environment spawns the N ranks itself (one process per GPU, backend nccl
+= RCCL).  The path has no exchange step (every unit is rank-local): ranks are weak-scaled replicas.  What a
+training job all-reduces AROUND the path is in the timed region for N > 1: per evaluation ONE RCCL all-reduce of a
+buffer the size of the mask head's `param_conv` parameters (537 065 f32 = 2.15 MB, mmdet/models/detectors/base.py:201-217
++ DDP) carrying the two loss scalars in its tail, issued asynchronously so that it overlaps the next evaluations.
+Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -34,28 +39,32 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PARAM_CONV_FLOATS = 233 * 256 * 9 + 233      # param_conv.weight [233,256,3,3] + bias [233]: 2.15 MB of f32
+PREROLL_S = 0.15
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=200)
-    ap.add_argument('--mode', choices=['graph', 'eager'], default="eager",
+    ap.add_argument('--mode', choices=['graph', 'eager'], default='eager',
                     help='graph: one hipGraph per input set, replayed; eager: direct C-ABI calls')
     ap.add_argument('--sets', type=int, default=8, help='independent input sets rotated through')
     ap.add_argument('--inst-per-box', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--no-pipelined', action='store_true', help='skip the multi-stream extra measurement')
+    ap.add_argument('--no-extras', '--no-pipelined', dest='no_extras', action='store_true',
+                    help='skip the extra measurements (multi-stream, warm cache, autograd / module API)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
-    return ap.parse_args()
+    ap.add_argument('--spawn', action='store_true', help='spawn the ranks even for --gpus 1 (exercises the launcher)')
+    return ap.parse_args(argv)
 
 
 class EvalSet:
     """One synthetic 2x800x1024 / 32-instance batch resident on the device + its output buffers."""
 
-    def __init__(self, lib, Fh, synthetic, dev, seed, inst_per_box):
+    def __init__(self, lib, Fh, synthetic, dev, seed, inst_per_box, ones):
         d = synthetic.cfg2(seed=seed, inst_per_box=inst_per_box)
         self.d = d
         self.imgs = torch.from_numpy(d['imgs']).to(dev)
@@ -70,31 +79,61 @@ class EvalSet:
         self.state = torch.empty(lib.bxi_boxinst_loss_state_bytes(N, h, w), dtype=torch.uint8, device=dev)
         self.ws = torch.empty(lib.bxi_boxinst_eval_workspace_bytes(d['B'], d['H'], d['W'], d['stride'], N),
                               dtype=torch.uint8, device=dev)
-        self.ones = torch.ones(2, device=dev)       # upstream gradients of loss_prj / loss_pairwise
-        # the two C-ABI argument lists, marshalled once (what a training loop that keeps its buffers would do): only the
+        # the C-ABI argument lists, marshalled once (what a training loop that keeps its buffers does): only the
         # stream is appended per call
         vp = C.c_void_p
         self.eval_args = (C.byref(self.batch.struct), C.byref(self.inst.struct), C.c_int(3), C.c_int(2), C.c_float(0.3),
-                          C.c_float(1.0), vp(self.losses.data_ptr()), vp(self.grad.data_ptr()), vp(self.state.data_ptr()),
-                          vp(self.ws.data_ptr()), C.c_size_t(self.ws.numel()))
-        self.bwd_args = (C.byref(self.inst.struct), vp(self.ones.data_ptr()), vp(self.ones.data_ptr() + 4), C.c_int(2),
-                         vp(self.state.data_ptr()), vp(self.grad.data_ptr()))
+                          C.c_float(1.0), vp(ones.data_ptr()), vp(ones.data_ptr() + 4), vp(self.losses.data_ptr()),
+                          vp(self.grad.data_ptr()), vp(self.state.data_ptr()), vp(self.ws.data_ptr()),
+                          C.c_size_t(self.ws.numel()))
+        self.rescale_args = (C.byref(self.inst.struct), vp(ones.data_ptr()), vp(ones.data_ptr() + 4), C.c_int(2),
+                             vp(self.state.data_ptr()), vp(self.grad.data_ptr()))
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _spawned(rank: int, argv, world: int, port: int):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    worker(parse_args(argv))
 
 
 def main():
     args = parse_args()
+    if 'RANK' not in os.environ and (args.gpus > 1 or args.spawn):
+        # the launcher of the reference is tools/dist_train.sh:10-20 (torch.distributed.launch, one process per GPU)
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f'--gpus {args.gpus} but only {torch.cuda.device_count()} visible device(s)')
+        import __graft_entry__ as entry
+        entry.build()                          # once, before the ranks start
+        import torch.multiprocessing as mp
+        mp.spawn(_spawned, args=(sys.argv[1:], args.gpus, free_port()), nprocs=args.gpus, join=True)
+        return
+    worker(args)
+
+
+def worker(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 or 'RANK' in os.environ:      # launched by torch.distributed.run (also with one process)
+    if 'RANK' in os.environ:                   # one process per GPU: torch.distributed.run, or spawned above
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f'--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks')
     else:
         dist = None
         torch.cuda.set_device(0)
+        if args.gpus != 1:
+            raise SystemExit('--gpus > 1 needs one process per GPU')
     dev = torch.device('cuda', local_rank if dist is not None else 0)
 
     import __graft_entry__ as entry
@@ -106,16 +145,14 @@ def main():
     lib = _lib.load()
     assert lib.bxi_check_device(dev.index) == 0, 'not a gfx950 device'
 
-    sets = [EvalSet(lib, Fh, synthetic, dev, seed=1000 * rank + i, inst_per_box=args.inst_per_box)
+    ones = torch.ones(2, device=dev)            # upstream gradients of loss_prj / loss_pairwise
+    sets = [EvalSet(lib, Fh, synthetic, dev, seed=1000 * rank + i, inst_per_box=args.inst_per_box, ones=ones)
             for i in range(args.sets)]
     stream = torch.cuda.Stream(device=dev)
-    SIZE, DIL, THRESH, WARM = 3, 2, 0.3, 1.0
-
-    assert (SIZE, DIL, THRESH, WARM) == (3, 2, 0.3, 1.0)          # what EvalSet marshalled
-    f_eval, f_bwd = lib.bxi_boxinst_eval_f32, lib.bxi_boxinst_loss_backward_f32
+    f_eval, f_rescale = lib.bxi_boxinst_eval_f32, lib.bxi_boxinst_grad_rescale_f32
 
     def enqueue(s: EvalSet, st: int) -> None:
-        rc = f_eval(*s.eval_args, st) or f_bwd(*s.bwd_args, st)
+        rc = f_eval(*s.eval_args, st)
         if rc != 0:
             raise RuntimeError(f'C ABI status {rc}: {_lib.status_string(rc)}')
 
@@ -125,6 +162,10 @@ def main():
     with torch.cuda.stream(stream):
         enqueue(sets[0], stream.cuda_stream)
     stream.synchronize()
+    off = lib.bxi_boxinst_loss_state_status_offset(sets[0].inst.N, sets[0].inst.h, sets[0].inst.w)
+    status = sets[0].state[off:off + 8].view(torch.int32).cpu().tolist()
+    if status[0] != 0:
+        raise SystemExit(f'in-kernel wait timed out (status {status[0]}): refusing to time')
     parity = None
     cpu_leg = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -145,11 +186,17 @@ def main():
         _, bits, _ = color_affinity(torch.from_numpy(sets[0].d['imgs']).to(dev), sets[0].d['img_metas'], out_stride=4)
         want_bits = np.zeros(bits.shape, np.uint8)
         for k in range(8):
-            want_bits |= ((ref['sim'][:, k] >= THRESH).astype(np.uint8) << k)
+            want_bits |= ((ref['sim'][:, k] >= 0.3).astype(np.uint8) << k)
         parity['weight_mask_hamming'] = int(np.unpackbits((bits.cpu().numpy() ^ want_bits)[..., None], axis=-1).sum())
         parity['weight_mask_bits'] = int(want_bits.size * 8)
         parity['ambiguous_argmax_lines_excluded'] = int(n_ties)
         parity['grad_rel_max_raw'] = float(np.abs(g - ref['grad']).max() / np.abs(ref['grad']).max())
+        parity['tile_rows'] = status[1]
+
+    # ---- what a training job all-reduces around the path (N > 1): one bucket per evaluation -------------------------
+    bucket = None
+    if dist is not None:
+        bucket = [torch.zeros(PARAM_CONV_FLOATS + 2, device=dev) for _ in range(args.sets)]
 
     # ---- step function -------------------------------------------------------------------------------
     graphs = None
@@ -163,15 +210,23 @@ def main():
                 graphs.append(g)
         stream.synchronize()
 
-    def run(n_steps: int, first: int = 0) -> None:
+    def run(n_steps: int, first: int = 0, comm: bool = True) -> None:
+        works = []
         with torch.cuda.stream(stream):
-            if graphs is not None:
-                for i in range(first, first + n_steps):
-                    graphs[i % len(graphs)].replay()
-            else:
-                st = stream.cuda_stream
-                for i in range(first, first + n_steps):
-                    enqueue(sets[i % len(sets)], st)
+            st = stream.cuda_stream
+            for i in range(first, first + n_steps):
+                k = i % len(sets)
+                if graphs is not None:
+                    graphs[k].replay()
+                else:
+                    enqueue(sets[k], st)
+                if dist is not None and comm:
+                    bucket[k][-2:].copy_(sets[k].losses, non_blocking=True)      # the two logged scalars ride in the bucket
+                    works.append(dist.all_reduce(bucket[k], async_op=True))
+                    if len(works) > 2 * len(sets):                                # bound the work queue, keep buffers safe
+                        works.pop(0).wait()
+            for wk in works:
+                wk.wait()
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -179,22 +234,45 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    def preroll():                       # >= PREROLL_S of back-to-back evaluations: clocks up, caches in steady state
+        t_end = time.perf_counter() + PREROLL_S
+        n = 0
+        while time.perf_counter() < t_end:
+            run(256, first=n, comm=False)
+            torch.cuda.synchronize(dev)
+            n += 256
+
     run(args.warmup)
+    preroll()
     barrier()
     t0 = time.perf_counter()
     run(args.steps, first=args.warmup)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
+    local_elapsed = elapsed
+    allreduce_us = None
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the two logged scalars, summed over ranks (what mmdet's _parse_losses all-reduces)
-        tot = torch.stack([s.losses for s in sets]).sum(0)
-        dist.all_reduce(tot)
+        # the same all-reduce alone, back to back (what one of them costs when nothing hides it)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            for i in range(100):
+                dist.all_reduce(bucket[i % len(bucket)])
+        torch.cuda.synchronize(dev)
+        allreduce_us = (time.perf_counter() - t1) / 100 * 1e6
+        # and the evaluations alone on this rank (no collective in the loop)
+        preroll()
+        t1 = time.perf_counter()
+        run(args.steps, comm=False)
+        torch.cuda.synchronize(dev)
+        eval_only = time.perf_counter() - t1
     images = 2 * args.steps * world
     value = images / elapsed
+    step_us = elapsed / args.steps * 1e6
 
     result = {
         'metric': 'pairwise+projection loss fwd+bwd images/sec @2x800x1024x32inst',
@@ -204,22 +282,29 @@ def main():
         'config': {'workload': 'BoxInst R-50 FPN loss path, 2x800x1024 synthetic batch, '
                                f'{sets[0].inst.N} instances, 1xMI355X per rank (BASELINE configs[1])',
                    'images_per_step': 2, 'instances': sets[0].inst.N, 'map': [sets[0].inst.h, sets[0].inst.w],
-                   'launch': args.mode, 'input_sets': args.sets, 'parallelism': f'replicas x{world} (no exchange step)'},
+                   'launch': args.mode, 'launches_per_step': 2, 'input_sets': args.sets, 'preroll_s': PREROLL_S,
+                   'parallelism': f'replicas x{world} (no exchange step inside the path)'},
     }
+    if dist is not None:
+        result['multi_gpu'] = {
+            'world_size': dist.get_world_size(), 'backend': 'nccl (RCCL)',
+            'per_rank_images_per_s': 2 * args.steps / local_elapsed,
+            'per_rank_images_per_s_without_collectives': 2 * args.steps / eval_only,
+            'allreduce_per_evaluation': f'{(PARAM_CONV_FLOATS + 2) * 4} B (param_conv-sized gradient bucket + the 2 loss scalars), '
+                                        'async, overlapping the following evaluations',
+            'allreduce_alone_us': allreduce_us}
     if parity is not None:
         result['parity'] = parity
 
+    extras = rank == 0 and world == 1 and not args.no_extras
     # ---- extra (not `value`): independent evaluations pipelined over several HIP streams ------------------------
-    # `value` above is one evaluation at a time (how a training iteration uses the path).  The kernels are
-    # latency-bound, so independent batches overlap well; reported for reference only.
-    if rank == 0 and world == 1 and args.mode == 'eager' and not args.no_pipelined:
+    if extras and args.mode == 'eager':
         extra = {}
         for ns in (2, 4):
             streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
             def run_multi(n_steps):
                 for i in range(n_steps):
-                    st = streams[i % ns]
-                    enqueue(sets[i % len(sets)], st.cuda_stream)
+                    enqueue(sets[i % len(sets)], streams[i % ns].cuda_stream)     # a set (and its workspace) stays on one stream
             run_multi(64)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
@@ -234,8 +319,8 @@ def main():
         torch.cuda.synchronize(dev)
         result['pipelined_throughput_extra'] = extra
 
-    # ---- extra (not `value`): the warm-cache figure SURVEY 8(d) asks to see beside the cold one -------------------
-    if rank == 0 and world == 1 and not args.no_pipelined:
+    # ---- extra: the warm-cache figure SURVEY 8(d) asks to see beside the cold one ---------------------------------
+    if extras:
         st = stream.cuda_stream
         with torch.cuda.stream(stream):
             for _ in range(64):
@@ -249,19 +334,25 @@ def main():
         result['warm_cache_extra'] = {'images_per_s': 2 * args.steps / el, 'us_per_step': el / args.steps * 1e6,
                                       'note': 'ONE input set re-used (inputs L2 / Infinity-Cache resident); `value` rotates over '
                                               f'{args.sets} sets so that every read is cold'}
+        # ---- extra: evaluation + the rescale launch autograd's backward() adds (returns at once for unit factors) ----
+        with torch.cuda.stream(stream):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                s = sets[i % len(sets)]
+                enqueue(s, st)
+                f_rescale(*s.rescale_args, st)
+            torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t1
+        result['autograd_backward_extra'] = {'images_per_s': 2 * args.steps / el, 'us_per_step': el / args.steps * 1e6,
+                                             'note': 'bxi_boxinst_eval_f32 + bxi_boxinst_grad_rescale_f32 (3 launches): the C-ABI '
+                                                     'sequence behind loss() + backward() when the upstream factors are only '
+                                                     'known at backward time'}
+        result['module_api'] = module_api(sets, dev, min(args.steps, 300))
 
     # ---- per-kernel durations with HIP events on the launching stream (rank 0, N == 1) ------------
     if rank == 0 and world == 1 and not args.no_kernel_timing:
-        result.update(kernel_timing(lib, _lib, sets, stream, enqueue, min(args.steps, 200), elapsed / args.steps * 1e6))
-        d0 = sets[0].d
-        # compulsory bytes of a whole evaluation given the API's inputs and outputs -- read imgs, write the
-        # similarity map, read it again, read the logits, write their gradient (the fused path never materialises the map)
-        whole = 12 * d0['B'] * d0['H'] * d0['W'] + 2 * 4 * 8 * d0['B'] * d0['h'] * d0['w'] + 8 * sets[0].inst.N * d0['h'] * d0['w'] + 640
-        result['whole_evaluation'] = {
-            'algorithmic_bytes_survey_8d': whole, 'achieved_GBps': whole / (elapsed / args.steps) / 1e9,
-            'frac_of_hbm_peak': whole / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
-            'wall_time_images_per_s': value,
-            'note': 'three dependent launches; the step is latency-bound (DESIGN section 5), the stream kernel is `roofline`'}
+        result.update(kernel_timing(lib, _lib, sets, stream, enqueue, min(max(args.steps, 50), 200), step_us, status[1]))
     if cpu_leg is not None:
         result['cpu_baseline'] = cpu_leg
     if rank == 0:
@@ -270,12 +361,51 @@ def main():
         dist.destroy_process_group()
 
 
-# algorithmic (compulsory) HBM bytes per launch -- DESIGN.md section 4.  Per unit: 12 B per input pixel
-# (3 x f32 read) + 12 B per pooled pixel (Lab written) for the image half of stage1; 4 B per
-# instance-pixel read (logits) + 4 B per instance-pixel written (gradient) for the loss, the write
-# split between stage1 (zero-fill outside the box tiles) and box_kernel (the box tiles).
-def box_tile_fraction(d, dil=2, br=8, bc=64):
-    """fraction of the N x h x w gradient written by box_kernel (tiles meeting the dilated box)."""
+def module_api(sets, dev, n):
+    """The same evaluation through the drop-in module: CondInstMaskHead.loss(...) + (loss_prj + loss_pairwise).backward()."""
+    import gc
+    from boxinstseg_amd import CondInstMaskHead
+    head = CondInstMaskHead(in_channels=16, boxinst_enabled=True, topk_per_img=64, max_proposals=-1).to(dev)
+    head._iter.fill_(20000.0)
+    head._iter_host = None
+    xs = [s.logits.clone().requires_grad_(True) for s in sets]
+
+    def once(i):
+        s, x = sets[i % len(sets)], xs[i % len(sets)]
+        out = head.loss(s.imgs, s.d['img_metas'], x, s.gt_inds, s.boxes, None, None)
+        (out['loss_prj'] + out['loss_pairwise']).backward()
+        x.grad = None
+
+    for i in range(30):
+        once(i)
+    torch.cuda.synchronize(dev)
+    gc.collect()
+    gc.freeze()                      # the collector otherwise walks the whole application heap every few hundred allocations
+    t0 = time.perf_counter()
+    for i in range(n):
+        once(i)
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    gc.unfreeze()
+    # the library's share of the host time: the same call with the autograd engine out of the picture
+    from boxinstseg_amd import functional as Fh
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for i in range(n):
+            s = sets[i % len(sets)]
+            head.loss(s.imgs, s.d['img_metas'], s.logits, s.gt_inds, s.boxes, None, None)
+    fwd_only = time.perf_counter() - t0
+    torch.cuda.synchronize(dev)
+    return {'images_per_s': 2 * n / el, 'us_per_call': el / n * 1e6, 'host_us_per_call': host / n * 1e6,
+            'loss_call_host_us_no_autograd': fwd_only / n * 1e6,
+            'note': 'CondInstMaskHead.loss + backward() of the two scalars, eager PyTorch (gc frozen); host-bound: '
+                    'the GPU work is `value`'}
+
+
+# algorithmic (compulsory) HBM bytes -- DESIGN.md section 4 / SURVEY 8(d).
+def hull_fraction(d, dil=2, rows=8):
+    """fraction of the N x h x w gradient the pair kernel's tiles own (R-aligned rows x the dilated box's columns)."""
     h, w, stride = d['h'], d['w'], d['stride']
     boxes = np.concatenate(d['gt_bboxes'], axis=0)
     hit = 0
@@ -287,43 +417,43 @@ def box_tile_fraction(d, dil=2, br=8, bc=64):
             continue
         r0, r1 = max(rr[0] - dil, 0), min(rr[-1] + 1 + dil, h)
         c0, c1 = max(cc[0] - dil, 0), min(cc[-1] + 1 + dil, w)
-        tr = range(r0 // br, (r1 - 1) // br + 1)
-        tc = range(c0 // bc, (c1 - 1) // bc + 1)
-        for a in tr:
-            for b in tc:
-                hit += (min(h, a * br + br) - a * br) * (min(w, b * bc + bc) - b * bc)
+        hit += (min(h, -(-r1 // rows) * rows) - r0 // rows * rows) * (c1 - c0)
     return hit / float(len(d['gt_inds']) * h * w)
 
 
-def algorithmic_bytes(d, N):
-    """Compulsory HBM bytes per launch (DESIGN.md section 4): per-unit figure x units of one launch."""
+def algorithmic_bytes(d, N, rows):
+    """Compulsory HBM bytes per launch: per-unit figure x units of one launch (DESIGN.md section 4)."""
     px_in = d['B'] * d['H'] * d['W']          # input pixels:     12 B read each (3 x f32)
     px_small = d['B'] * d['h'] * d['w']       # pooled pixels:    12 B written each (Lab, 3 x f32)
     ipx = N * d['h'] * d['w']                 # instance-pixels:  4 B read (logit) + 4 B written (gradient)
-    f = box_tile_fraction(d)
+    f = hull_fraction(d, rows=rows)
     return {
-        'stage1': 12 * px_in + 12 * px_small + 4 * ipx + 4 * ipx,
-        'box': int(4 * ipx * f) * 4 + int(4 * ipx * f),   # box tiles: logits + 3 Lab planes re-read, gradient rewritten
-        'loss_apply': int(8 * ipx * f),                   # read-modify-write of the box tiles
+        'prep': 12 * px_in + 12 * px_small + 4 * ipx + 4 * ipx,
+        'pair': int(4 * ipx * f) * 4 + int(4 * ipx * f),   # box tiles: logits + 3 Lab planes read, gradient written
     }
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch from the committed PMC summary (profiles/*_hbm_traffic.json, written by
-    tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)."""
+def survey_bytes(d, N):
+    """compulsory bytes of a whole evaluation given the API's inputs and outputs -- read imgs, write the
+    similarity map, read it again, read the logits, write their gradient (the fused path never materialises the map)."""
+    return 12 * d['B'] * d['H'] * d['W'] + 2 * 4 * 8 * d['B'] * d['h'] * d['w'] + 8 * N * d['h'] * d['w'] + 640
+
+
+def measured_traffic():
+    """HBM bytes per launch from the committed PMC summary of this command (profiles/*_hbm_traffic.json, written by
+    tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes) -> (dict, file) or (None, None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_traffic.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r02*_hbm_traffic.json')))
     if not files:
-        return None
+        return None, None
     try:
         k = json.load(open(files[-1]))['kernels']
-        key = {'stage1': 'stage1_kernel', 'box': 'box_kernel', 'loss_apply': 'loss_apply_kernel'}[kernel]
-        return float(k[key]['hbm_bytes'])
+        return {name: float(v['hbm_bytes']) for name, v in k.items()}, os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
+        return None, None
 
 
-def kernel_timing(lib, _lib, sets, stream, enqueue, steps, step_us):
+def kernel_timing(lib, _lib, sets, stream, enqueue, steps, step_us, rows):
     """Bracket every kernel launch with HIP events (bxi_set_launch_hook) over `steps` eager steps."""
     events = {}
 
@@ -333,11 +463,10 @@ def kernel_timing(lib, _lib, sets, stream, enqueue, steps, step_us):
         events.setdefault(name.decode(), []).append(ev)
 
     cb = _lib.LAUNCH_HOOK(hook)
-    run_stream = stream
-    with torch.cuda.stream(run_stream):
+    with torch.cuda.stream(stream):
         for i in range(20):
-            enqueue(sets[i % len(sets)], run_stream.cuda_stream)
-        run_stream.synchronize()
+            enqueue(sets[i % len(sets)], stream.cuda_stream)
+        stream.synchronize()
         # park the stream behind a ~0.1 s spin kernel so that every launch + event below is already queued
         # when the GPU gets to it: the event pairs then bracket kernels that run back to back, exactly as
         # in the timed region (otherwise they would also measure the host's enqueue latency)
@@ -345,37 +474,47 @@ def kernel_timing(lib, _lib, sets, stream, enqueue, steps, step_us):
         lib.bxi_set_launch_hook(C.cast(cb, C.c_void_p), None)
         try:
             for i in range(steps):
-                enqueue(sets[i % len(sets)], run_stream.cuda_stream)
+                enqueue(sets[i % len(sets)], stream.cuda_stream)
         finally:
             lib.bxi_set_launch_hook(None, None)
-    run_stream.synchronize()
+    stream.synchronize()
     raws = {name: np.array([evs[j].elapsed_time(evs[j + 1]) * 1e3 for j in range(0, len(evs) - 1, 2)])
             for name, evs in events.items()}                                                      # us
     # An event pair adds queue packets of its own.  Their cost is calibrated against the un-instrumented
     # timed region of this same run: (sum of bracketed durations per step - measured step time) / launches
-    # per step.  With it the per-kernel figures tile the step exactly as rocprofv3's durations do.
+    # per step.  With it the per-kernel figures tile the step as rocprofv3's durations do.
     bracket_us = max(0.0, (sum(float(np.mean(r)) for r in raws.values()) - step_us) / max(len(raws), 1))
+    d0, N = sets[0].d, sets[0].inst.N
+    alg = algorithmic_bytes(d0, N, rows)
+    traffic, traffic_file = measured_traffic()
+    key = {'prep': 'prep_kernel', 'pair': 'pair_kernel'}
     per_kernel = {}
     for name, raw in raws.items():
         durs = raw - bracket_us
-        per_kernel[name] = {'avg_us': float(np.mean(durs)), 'median_us': float(np.median(durs)),
-                            'min_us': float(np.min(durs)), 'launches': len(durs), 'raw_event_avg_us': float(np.mean(raw))}
-    alg = algorithmic_bytes(sets[0].d, sets[0].inst.N)
-    for name, v in per_kernel.items():
         b = alg.get(name, 0)
-        v['algorithmic_bytes'] = b
-        v['achieved_GBps'] = b / (v['avg_us'] * 1e-6) / 1e9 if b else None
-    # the roofline kernel = the one that carries the HBM stream (largest algorithmic byte count); the other
-    # kernels are latency-bound on ~1-10 MB and are listed with their own figures under "kernels"
-    dom = max((k for k in per_kernel if alg.get(k, 0) > 0), key=lambda k: alg[k])
-    a = per_kernel[dom]['achieved_GBps']
+        avg = float(np.mean(durs))
+        per_kernel[name] = {'avg_us': avg, 'median_us': float(np.median(durs)), 'min_us': float(np.min(durs)),
+                            'launches': len(durs), 'raw_event_avg_us': float(np.mean(raw)), 'algorithmic_bytes': b,
+                            'achieved_GBps': b / (avg * 1e-6) / 1e9 if b else None,
+                            'frac': b / (avg * 1e-6) / 1e9 / HBM_PEAK_GBPS if b else None,
+                            'traffic': traffic.get(key.get(name, name)) if traffic else None}
+    whole = survey_bytes(d0, N)
+    ksum = sum(v['avg_us'] for v in per_kernel.values())
+    a = whole / (ksum * 1e-6) / 1e9
     return {
-        'roofline': {'kernel': dom, 'selection': 'largest HBM byte count of the step', 'bound': 'hbm', 'achieved': a,
-                     'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': a / HBM_PEAK_GBPS, 'traffic': measured_traffic(dom),
-                     'avg_launch_us': per_kernel[dom]['avg_us'], 'algorithmic_bytes': alg[dom],
-                     'timing': 'hipEvent pairs around each launch on the launching stream, minus the per-bracket cost '
-                               'calibrated against the un-instrumented step time (event_bracket_us); launches queued '
-                               'behind a parked stream, cold input sets; rocprofv3 durations of the same command in profiles/'},
+        'roofline': {'kernel': 'prep + pair = the whole evaluation', 'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBPS,
+                     'unit': 'GB/s', 'frac': a / HBM_PEAK_GBPS,
+                     'traffic': sum(traffic.values()) if traffic else None,
+                     'traffic_source': traffic_file,
+                     'algorithmic_bytes': whole, 'algorithmic_bytes_source': 'SURVEY 8(d): 39 322 240 B at 2x800x1024x32',
+                     'kernel_time_us': ksum, 'wall_step_us': step_us,
+                     'frac_on_wall_time': whole / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                     'timing': 'hipEvent pairs around each launch on the launching stream (bxi_set_launch_hook), minus the '
+                               'per-bracket cost calibrated against the un-instrumented step time (event_bracket_us); launches '
+                               'queued behind a parked stream, cold input sets; rocprofv3 durations of the same command in '
+                               'profiles/',
+                     'per_kernel': {k: {'avg_us': v['avg_us'], 'algorithmic_bytes': v['algorithmic_bytes'], 'frac': v['frac']}
+                                    for k, v in per_kernel.items()}},
         'kernels': per_kernel,
         'event_bracket_us': bracket_us,
     }

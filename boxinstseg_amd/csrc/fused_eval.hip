@@ -38,7 +38,19 @@ constexpr int kSRows = 8;                       // rows per stream wave
 constexpr int kSBlk = kWaves * kSRows;          // rows per stream workgroup
 constexpr int kChunkC = 256;                    // columns per pass of a stream wave: 64 lanes x float4
 constexpr int kMaxDilFused = 4;
-constexpr unsigned kSpinLimit = 200000;         // bounded waits (never reached: see the grid order above)
+constexpr unsigned kSpinLimit = 200000;
+constexpr unsigned long long kGranuleInvalid = 0xffffffffull;         // bounded waits (never reached: see the grid order above)
+
+// developer tracing (-DBXI_TRACE builds only): per-WAVE phase stamps, see tools/trace_eval.py
+#ifdef BXI_TRACE
+#define BXI_TW(kid, idx, ph)                                                                                  \
+    do {                                                                                                      \
+        if ((threadIdx.x & 63) == 0 && g_trace && (idx) >= 0 && (idx) < ::bxi::kTraceBlocks)                  \
+            g_trace[((size_t)(kid) * ::bxi::kTraceBlocks + (idx)) * ::bxi::kTracePhases + (ph)] = wall_clock64(); \
+    } while (0)
+#else
+#define BXI_TW(kid, idx, ph) do {} while (0)
+#endif
 
 #define BXI_RLX __ATOMIC_RELAXED
 #define BXI_AGENT __HIP_MEMORY_SCOPE_AGENT
@@ -60,7 +72,6 @@ struct EvalWs {                                 // carved from the caller's work
     // words polled inside pair_kernel; zeroed by prep_kernel's table waves (i.e. before a kernel boundary)
     unsigned long long* acc1;                   // [N]  count waves : arrivals << 40 | sum W
     unsigned long long* acc2;                   // [N]  math waves + leader : arrivals << 52 | sum (W pw + 1) in 2^-24 units
-    unsigned int* lflag;                        // [N]  leader's coefficients are published
     unsigned int* fin;                          // [1]  instances complete
     float* dice;                                // [N]
 };
@@ -86,11 +97,19 @@ static size_t carve_eval(void* base, int N, int h, int w, EvalWs* ws) {
     t.expect = (unsigned int*)take(4 * (size_t)N1);
     t.acc1 = (unsigned long long*)take(8 * (size_t)N1);
     t.acc2 = (unsigned long long*)take(8 * (size_t)N1);
-    t.lflag = (unsigned int*)take(4 * (size_t)N1);
     t.fin = (unsigned int*)take(4);
     t.dice = (float*)take(4 * (size_t)N1);
     if (ws) *ws = t;
     return off;
+}
+
+// 16-byte store that is written through to memory as it is issued (sc1: agent scope) instead of staying dirty in this
+// XCD's L2 until the end-of-kernel write-back: the 6.5 MB zero-fill then drains while the launch is still reading, not in
+// a burst at the kernel boundary that the next launch's first loads queue behind.
+__device__ __forceinline__ void store4_through(float* p, float x, float y, float z, float w) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v v = {x, y, z, w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 // ================================================================================================
@@ -153,7 +172,11 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
         ws.inst[n] = rc;
         if (st.inst) st.inst[n] = rc;
         ws.expect[n] = (unsigned int)cnt;
-        ws.acc1[n] = 0ull; ws.acc2[n] = 0ull; ws.lflag[n] = 0u;
+        ws.acc1[n] = 0ull; ws.acc2[n] = 0ull;
+    }
+    if (st.colk) {      // "not published yet" (the leaders of the next launch publish; its math waves poll)
+        for (int i = lane; i < a.w; i += 64) st.colk[(int64_t)n * a.w + i] = kGranuleInvalid;
+        for (int i = lane; i < a.h; i += 64) st.rowk[(int64_t)n * a.h + i] = kGranuleInvalid;
     }
     for (int i = lane; i < cnt; i += 64) {
         WorkRec2 wr;
@@ -182,24 +205,25 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const EvalWs& ws
     const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    float4 v[kSRows];
-    {
-        const int c = lane * 4;
-#pragma unroll
-        for (int i = 0; i < kSRows; ++i) v[i] = (r0 + i < r1 && c < w) ? load4(L + (int64_t)(r0 + i) * w, c, w, vec) : ninf;
-    }
-    if (G)   // non-temporal: these lines are not read again in this launch
+    if (G)   // written through: see store4_through
         for (int cb = 0; cb < w; cb += kChunkC) {
             const int c = cb + lane * 4;
             if (c < w) {
 #pragma unroll
                 for (int i = 0; i < kSRows; ++i)
                     if (r0 + i < r1) {
-                        if (vec) { typedef float f4v __attribute__((ext_vector_type(4))); __builtin_nontemporal_store((f4v){0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4v*>(G + (int64_t)(r0 + i) * w + c)); }
+                        if (vec) store4_through(G + (int64_t)(r0 + i) * w + c, 0.f, 0.f, 0.f, 0.f);
                         else store4(G + (int64_t)(r0 + i) * w, c, w, false, zero);
                     }
             }
         }
+    float4 v[kSRows];
+    {
+        const int c = lane * 4;
+#pragma unroll
+        for (int i = 0; i < kSRows; ++i) v[i] = (r0 + i < r1 && c < w) ? load4(L + (int64_t)(r0 + i) * w, c, w, vec) : ninf;
+    }
+    BXI_TW(0, (int)blockIdx.x * kWaves + wv, 1);
     float rmax[kSRows]; int rcol[kSRows];
 #pragma unroll
     for (int i = 0; i < kSRows; ++i) { rmax[i] = -INFINITY; rcol[i] = 0; }
@@ -232,6 +256,7 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const EvalWs& ws
 #pragma unroll
         for (int i = 0; i < kSRows; ++i) v[i] = (r0 + i < r1 && c2 < w) ? load4(L + (int64_t)(r0 + i) * w, c2, w, vec) : ninf;
     }
+    BXI_TW(0, (int)blockIdx.x * kWaves + wv, 2);
     float wmax[kSRows];
 #pragma unroll
     for (int i = 0; i < kSRows; ++i) wmax[i] = rmax[i];
@@ -252,7 +277,9 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const EvalWs& ws
         if (lane == i) mine = pack_max(wmax[i], (uint32_t)col);
     }
     if (lane < kSRows && r0 + lane < r1) ws.rowkey[(int64_t)n * h + r0 + lane] = mine;
+    BXI_TW(0, (int)blockIdx.x * kWaves + wv, 3);
     lds_barrier();
+    BXI_TW(0, (int)blockIdx.x * kWaves + wv, 4);
     for (int c = threadIdx.x; c < w; c += kWaves * 64) {
         unsigned long long k = colp[c];
 #pragma unroll
@@ -276,78 +303,100 @@ __device__ __forceinline__ double lab_f(const double* lut, int i, int r8, int g8
     return v > 0.008856 ? cbrt(v) : __dadd_rn(__dmul_rn(7.787, v), 16.0 / 116.0);
 }
 
-__device__ __forceinline__ void pool_block(const PoolArgs& pa, int item, double* lut /*[256]*/, int* part /*[4][3][64]*/,
-                                           double* fch /*[3][64]*/) {
-    const int h = pa.Hc >> 2, w = pa.Wc >> 2;
-    const int segs = (w + 63) >> 6;
+__device__ __forceinline__ void pool_load(const PoolArgs& pa, int item, int segs, int h, int w, float4 (&v)[3]) {
     const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = seg * 64 + lane;
-    const int y = 4 * r + wv;
-    const bool act = c < w;
     const int64_t plane = (int64_t)pa.Hc * pa.Wc;
-    float4 v[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) v[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (act) {
-        const float* base = pa.imgs + (int64_t)b * 3 * plane + (int64_t)y * pa.Wc + 4 * c;
+    if (c < w) {
+        const float* base = pa.imgs + (int64_t)b * 3 * plane + (int64_t)(4 * r + wv) * pa.Wc + 4 * c;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) v[ch] = *reinterpret_cast<const float4*>(base + pa.dn.src_ch[ch] * plane);
     }
+}
+
+// items first, first + step, ... < n_items
+__device__ __forceinline__ void pool_block(const PoolArgs& pa, int first, int step, int n_items, double* lut /*[256]*/,
+                                           int* part /*[4][3][64]*/, double* fch /*[3][64]*/) {
+    const int h = pa.Hc >> 2, w = pa.Wc >> 2;
+    const int segs = (w + 63) >> 6;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float4 v[3], nx[3];
+    pool_load(pa, first, segs, h, w, v);
     lut[threadIdx.x] = kSrgbLut[threadIdx.x];            // staged while the image loads fly
-    const int ih = pa.meta.img_h[b], iw = pa.meta.img_w[b];
-    const int x0 = 4 * c;
-    const bool yin = y < ih;
-    int sum[3];
-    if (__all(!act || (yin && x0 + 3 < iw))) {           // wave-uniform: the whole row segment is image, not canvas padding
+    for (int item = first; item < n_items; item += step) {
+        const bool more = item + step < n_items;         // workgroup-uniform
+        if (more) pool_load(pa, item + step, segs, h, w, nx);
+        const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
+        const int c = seg * 64 + lane;
+        const int y = 4 * r + wv;
+        const bool act = c < w;
+        const int ih = pa.meta.img_h[b], iw = pa.meta.img_w[b];
+        const int x0 = 4 * c;
+        const bool yin = y < ih;
+        int sum[3];
+        if (__all(!act || (yin && x0 + 3 < iw))) {       // wave-uniform: the whole row segment is image, not canvas padding
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            const double s = pa.dn.stdv[pa.dn.src_ch[ch]], m = pa.dn.mean[pa.dn.src_ch[ch]];
-            sum[ch] = denorm_u8(v[ch].x, s, m) + denorm_u8(v[ch].y, s, m) + denorm_u8(v[ch].z, s, m) + denorm_u8(v[ch].w, s, m);
+            for (int ch = 0; ch < 3; ++ch) {
+                const double s = pa.dn.stdv[pa.dn.src_ch[ch]], m = pa.dn.mean[pa.dn.src_ch[ch]];
+                sum[ch] = denorm_u8(v[ch].x, s, m) + denorm_u8(v[ch].y, s, m) + denorm_u8(v[ch].z, s, m) + denorm_u8(v[ch].w, s, m);
+            }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const double s = pa.dn.stdv[pa.dn.src_ch[ch]], m = pa.dn.mean[pa.dn.src_ch[ch]];
+                int t = 0;
+                t += (yin && x0 + 0 < iw) ? denorm_u8(v[ch].x, s, m) : 0;
+                t += (yin && x0 + 1 < iw) ? denorm_u8(v[ch].y, s, m) : 0;
+                t += (yin && x0 + 2 < iw) ? denorm_u8(v[ch].z, s, m) : 0;
+                t += (yin && x0 + 3 < iw) ? denorm_u8(v[ch].w, s, m) : 0;
+                sum[ch] = t;
+            }
         }
-    } else {
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            const double s = pa.dn.stdv[pa.dn.src_ch[ch]], m = pa.dn.mean[pa.dn.src_ch[ch]];
-            int t = 0;
-            t += (yin && x0 + 0 < iw) ? denorm_u8(v[ch].x, s, m) : 0;
-            t += (yin && x0 + 1 < iw) ? denorm_u8(v[ch].y, s, m) : 0;
-            t += (yin && x0 + 2 < iw) ? denorm_u8(v[ch].z, s, m) : 0;
-            t += (yin && x0 + 3 < iw) ? denorm_u8(v[ch].w, s, m) : 0;
-            sum[ch] = t;
+        for (int ch = 0; ch < 3; ++ch) part[(wv * 3 + ch) * 64 + lane] = sum[ch];
+        BXI_TW(0, (int)blockIdx.x * kWaves + wv, 1);
+        lds_barrier();
+        BXI_TW(0, (int)blockIdx.x * kWaves + wv, 2);
+        if (wv < 3) {                                     // wave-uniform: wave i takes channel i of XYZ -> f_i
+            int px[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+                px[ch] = (part[(0 * 3 + ch) * 64 + lane] + part[(1 * 3 + ch) * 64 + lane] + part[(2 * 3 + ch) * 64 + lane] +
+                          part[(3 * 3 + ch) * 64 + lane]) >> 4;
+            fch[wv * 64 + lane] = lab_f(lut, wv, px[0], px[1], px[2]);
         }
-    }
+        BXI_TW(0, (int)blockIdx.x * kWaves + wv, 3);
+        lds_barrier();
+        BXI_TW(0, (int)blockIdx.x * kWaves + wv, 4);
+        if (wv < 3 && act && pa.lab) {
+            const double f1 = fch[64 + lane];
+            float o;
+            if (wv == 0) o = (float)__dadd_rn(__dmul_rn(116.0, f1), -16.0);
+            else if (wv == 1) o = (float)__dmul_rn(500.0, __dadd_rn(fch[lane], -f1));
+            else o = (float)__dmul_rn(200.0, __dadd_rn(f1, -fch[128 + lane]));
+            const int64_t P = (int64_t)h * w;
+            pa.lab[((int64_t)b * 3 + wv) * P + (int64_t)r * w + c] = o;
+        }
+        // the next trip's `part` / `fch` writes come after barriers every wave has to reach: no extra barrier needed
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) part[(wv * 3 + ch) * 64 + lane] = sum[ch];
-    lds_barrier();
-    if (wv < 3) {                                         // wave-uniform: wave i takes channel i of XYZ -> f_i
-        int px[3];
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch)
-            px[ch] = (part[(0 * 3 + ch) * 64 + lane] + part[(1 * 3 + ch) * 64 + lane] + part[(2 * 3 + ch) * 64 + lane] +
-                      part[(3 * 3 + ch) * 64 + lane]) >> 4;
-        fch[wv * 64 + lane] = lab_f(lut, wv, px[0], px[1], px[2]);
-    }
-    lds_barrier();
-    if (wv < 3 && act && pa.lab) {
-        const double f1 = fch[64 + lane];
-        float o;
-        if (wv == 0) o = (float)__dadd_rn(__dmul_rn(116.0, f1), -16.0);
-        else if (wv == 1) o = (float)__dmul_rn(500.0, __dadd_rn(fch[lane], -f1));
-        else o = (float)__dmul_rn(200.0, __dadd_rn(f1, -fch[128 + lane]));
-        const int64_t P = (int64_t)h * w;
-        pa.lab[((int64_t)b * 3 + wv) * P + (int64_t)r * w + c] = o;
+        for (int ch = 0; ch < 3; ++ch) v[ch] = nx[ch];
     }
 }
 
 // grid: [ceil(N/4) table blocks][N*Sn stream blocks][pool blocks].  The table waves carry dependent scalar chains, so
 // they go first; the stream blocks precede the pool blocks because their data feeds the next launch's first workgroups.
-__global__ __launch_bounds__(256) void prep_kernel(PoolArgs pa, int n_pool, InstArgs a, int dil, int R, float thresh, EvalWs ws,
+__global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, float thresh, EvalWs ws,
                                                    LossState st, float* __restrict__ g_logits, int vec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_tab = (a.N + kWaves - 1) / kWaves;
     const int n_stream = a.N * ((a.h + kSBlk - 1) / kSBlk);
     const int blk = (int)blockIdx.x;
+    const int tix = blk * kWaves + (int)(threadIdx.x >> 6);
+    (void)tix;
+    BXI_TW(0, tix, 0);
     if (blk < n_tab) {
         const int n = blk * kWaves + (int)(threadIdx.x >> 6);
         if (n < a.N) table_wave(a, pa.meta, dil, R, thresh, ws, st, n);
@@ -357,8 +406,9 @@ __global__ __launch_bounds__(256) void prep_kernel(PoolArgs pa, int n_pool, Inst
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
         int* part = reinterpret_cast<int*>(fch + 3 * 64);
-        pool_block(pa, blk - n_tab - n_stream, lut, part, fch);
+        pool_block(pa, blk - n_tab - n_stream, n_pool, n_items, lut, part, fch);
     }
+    BXI_TW(0, tix, 7);
 }
 
 // ================================================================================================
@@ -435,6 +485,8 @@ __device__ __forceinline__ void load_plane(const float* __restrict__ plane, cons
     }
 }
 
+__device__ __forceinline__ uint32_t spread4(uint32_t x4) { return (x4 * 0x00204081u) & 0x01010101u; }   // bits 0..3 -> bytes 0..3
+
 __device__ __forceinline__ float n2_of(float L0, float A0, float B0, float L1, float A1, float B1) {
     const float dL = L0 - L1, dA = A0 - A1, dB = B0 - B1;     // un-fused: the decision must equal the affinity kernel's
     return __fadd_rn(__fadd_rn(__fmul_rn(dL, dL), __fmul_rn(dA, dA)), __fmul_rn(dB, dB));
@@ -500,7 +552,7 @@ __device__ __noinline__ int slow_tile(const float* __restrict__ Lg, const float*
 
 // ---- count wave: sum over the tile's owned pixels of W[k,p] (Lab only) -------------------------------------------
 template <int D, int R>
-__device__ __forceinline__ void count_tile(const InstArgs& a, const float* __restrict__ lab, const EvalWs& ws, const WorkRec2& wr) {
+__device__ __forceinline__ void count_tile(const InstArgs& a, const float* __restrict__ lab, const EvalWs& ws, const WorkRec2& wr, int tix) {
     constexpr int RD = TG<D, R>::RD;
     const int lane = threadIdx.x & 63;
     const int h = a.h, w = a.w;
@@ -518,10 +570,12 @@ __device__ __forceinline__ void count_tile(const InstArgs& a, const float* __res
         const TileFlags f = tile_flags<D, R>(wr, h, w, a.stride, lane);
         DirMasks m[4];
         dir_masks<D>(f, m);
+        BXI_TW(2, tix, 1);
         const int lr = min(lane + D, 63), ll = max(lane - D, 0);
 #pragma unroll
         for (int i = 0; i < R + D; ++i) {
             const int j = i + D;
+            if (i == 1) BXI_TW(2, tix, 2);
             const float LRj = __shfl(L[j], lr, 64), ARj = __shfl(A[j], lr, 64), BRj = __shfl(B[j], lr, 64);
             const float LLj = __shfl(L[j], ll, 64), ALj = __shfl(A[j], ll, 64), BLj = __shfl(B[j], ll, 64);
             if (i >= D) {
@@ -538,6 +592,7 @@ __device__ __forceinline__ void count_tile(const InstArgs& a, const float* __res
         }
     }
     cnt = wave_sum_i32(cnt);
+    BXI_TW(2, tix, 3);
     if (lane == 0)   // one packed atomic per tile: (arrival, sum W); integer adds commute -> run-to-run identical
         __hip_atomic_fetch_add(&ws.acc1[wr.n], (1ull << 40) | (unsigned long long)(unsigned int)cnt, BXI_RLX, BXI_AGENT);
 }
@@ -610,7 +665,7 @@ template <int D, int R>
 __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __restrict__ lab, const EvalWs& ws, const LossState& st,
                                           const WorkRec2& wr, float warmup, float upp, float upw, float* __restrict__ losses,
                                           float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
-                                          double& total_w, bool& have_total) {
+                                          double& total_w, bool& have_total, int tix) {
     constexpr int RD = TG<D, R>::RD;
     const int lane = threadIdx.x & 63;
     const int h = a.h, w = a.w, n = wr.n;
@@ -634,42 +689,58 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
         const int lr = min(lane + D, 63), ll = max(lane - D, 0);
         // Rolling window over the rows: at step i the pairs (row i -> rows i, i + D) are evaluated; what the rows above
         // contributed is final then, so row i's gradient is collected (and its registers die) inside the loop.
-        float pa_[RD], pb_[RD];                      // (sigmoid(x), sigmoid(-x)), rows [i, i + D] live
-        float aR[RD], bR[RD], LR[RD], AR[RD], BR[RD];   // the lane D to the right, rows [i, i + D] live
+        // Per pixel: (a, b) = (sigmoid(x), sigmoid(-x)), t = a - b, u = a b.  Per pair (p, q):
+        //   S = a_p a_q + b_p b_q ; pw = -log S ; d pw / d x_p = -t_q u_p / S ; d pw / d x_q = -t_p u_q / S.
+        // S cannot underflow while every |x| <= 34 (then min(a, b) >= 1.7e-15 and S >= 3e-15); tiles with a larger logit
+        // take the log-space path below.
+        float pa_[RD], pb_[RD], pt_[RD], pu_[RD];    // this lane, rows [i, i + D] live
+        float aR[RD], bR[RD], tR[RD], uR[RD], LR[RD], AR[RD], BR[RD];   // the lane D to the right, rows [i, i + D] live
         float gq[RD], gR[RD], gL[RD];                // gradient of this lane's pixels / of lane + D's / of lane - D's
+        bool sat = false;
 #pragma unroll
-        for (int j = 0; j < RD; ++j) { gq[j] = 0.f; gR[j] = 0.f; gL[j] = 0.f; }
+        for (int j = 0; j < RD; ++j) { gq[j] = 0.f; gR[j] = 0.f; gL[j] = 0.f; sat |= !(fabsf(x[j]) <= 34.f); }
+        // pair weights as bytes, four rows per word: cw = W[k,p] + W[7-k,q] (gradient), dw = the same restricted to
+        // pixels this tile owns (loss sum)
+        uint32_t cw[4][(R + D + 3) / 4], dw[4][(R + D + 3) / 4];
 #pragma unroll
-        for (int j = 0; j < D; ++j) { const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; }
-        float smin = 1.f;                            // smallest S among weighted pairs (saturation detector)
+        for (int dir = 0; dir < 4; ++dir)
+#pragma unroll
+            for (int q4 = 0; q4 < (R + D + 3) / 4; ++q4) {
+                cw[dir][q4] = spread4((m[dir].mA >> (4 * q4)) & 15u) + spread4((m[dir].mB >> (4 * q4)) & 15u);
+                dw[dir][q4] = spread4((m[dir].nA >> (4 * q4)) & 15u) + spread4((m[dir].nB >> (4 * q4)) & 15u);
+            }
+        BXI_TW(1, tix, 1);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; pt_[j] = s.x - s.y; pu_[j] = s.x * s.y;
+        }
+        BXI_TW(1, tix, 2);
         const int from_l = max(lane - D, 0), from_r = min(lane + D, 63);
-        // one unordered pair: p = (row i, this lane) ; q = (row j, lane given by the operands); dir = mask set
-#define BXI_PAIR(i, qa, qb, qL, qA, qB, dir, GP, GQ)                                                              \
+        // one unordered pair: p = (row i, this lane) ; q = the operands ; dir = weight set
+#define BXI_PAIR(i, qa, qb, qt, qu, qL, qA, qB, dir, GP, GQ)                                                      \
         {                                                                                                           \
             const bool pn = n2_of(L[i], A[i], B[i], qL, qA, qB) <= wr.n2max;                                        \
-            const uint32_t c1 = ((m[dir].mA >> (i)) & 1u) + ((m[dir].mB >> (i)) & 1u);                              \
-            const uint32_t d1 = ((m[dir].nA >> (i)) & 1u) + ((m[dir].nB >> (i)) & 1u);                              \
-            const float gw = pn ? (float)c1 : 0.f, nw = pn ? (float)d1 : 0.f;                                      \
+            const float gw = pn ? (float)((cw[dir][(i) >> 2] >> (8 * ((i) & 3))) & 255u) : 0.f;                     \
+            const float nw = pn ? (float)((dw[dir][(i) >> 2] >> (8 * ((i) & 3))) & 255u) : 0.f;                     \
             const float S = pa_[i] * (qa) + pb_[i] * (qb);                          /* P(y_p == y_q) */            \
-            smin = fminf(smin, gw != 0.f ? S : 1.f);                                                                \
-            const float Sc = fmaxf(S, 1e-30f);                                                                      \
-            num += nw * -__logf(Sc);                                                                                \
-            const float mm = gw * __builtin_amdgcn_rcpf(Sc);                                                        \
-            GP -= mm * ((qa) - (qb)) * (pa_[i] * pb_[i]);                                                           \
-            GQ -= mm * (pa_[i] - pb_[i]) * ((qa) * (qb));                                                           \
+            num -= nw * __logf(S);                                                                                  \
+            const float mm = gw * __builtin_amdgcn_rcpf(S);                                                         \
+            GP -= mm * (qt) * pu_[i];                                                                               \
+            GQ -= mm * pt_[i] * (qu);                                                                               \
         }
 #pragma unroll
         for (int i = 0; i < R + D; ++i) {
             const int j = i + D;
-            { const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; }
-            aR[j] = __shfl(pa_[j], lr, 64); bR[j] = __shfl(pb_[j], lr, 64);
+            { const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; pt_[j] = s.x - s.y; pu_[j] = s.x * s.y; }
+            aR[j] = __shfl(pa_[j], lr, 64); bR[j] = __shfl(pb_[j], lr, 64); tR[j] = aR[j] - bR[j]; uR[j] = aR[j] * bR[j];
             LR[j] = __shfl(L[j], lr, 64); AR[j] = __shfl(A[j], lr, 64); BR[j] = __shfl(B[j], lr, 64);
             const float aLj = __shfl(pa_[j], ll, 64), bLj = __shfl(pb_[j], ll, 64);
+            const float tLj = aLj - bLj, uLj = aLj * bLj;
             const float LLj = __shfl(L[j], ll, 64), ALj = __shfl(A[j], ll, 64), BLj = __shfl(B[j], ll, 64);
-            if (i >= D) BXI_PAIR(i, aR[i], bR[i], LR[i], AR[i], BR[i], 0, gq[i], gR[i])
-            BXI_PAIR(i, aLj, bLj, LLj, ALj, BLj, 1, gq[i], gL[j])
-            BXI_PAIR(i, pa_[j], pb_[j], L[j], A[j], B[j], 2, gq[i], gq[j])
-            BXI_PAIR(i, aR[j], bR[j], LR[j], AR[j], BR[j], 3, gq[i], gR[j])
+            if (i >= D) BXI_PAIR(i, aR[i], bR[i], tR[i], uR[i], LR[i], AR[i], BR[i], 0, gq[i], gR[i])
+            BXI_PAIR(i, aLj, bLj, tLj, uLj, LLj, ALj, BLj, 1, gq[i], gL[j])
+            BXI_PAIR(i, pa_[j], pb_[j], pt_[j], pu_[j], L[j], A[j], B[j], 2, gq[i], gq[j])
+            BXI_PAIR(i, aR[j], bR[j], tR[j], uR[j], LR[j], AR[j], BR[j], 3, gq[i], gR[j])
             if (i >= D) {     // row i is complete: collect what the neighbour lanes computed for it
                 const float fromL = __shfl(gR[i], from_l, 64);      // lane - D evaluated (.., +D) pairs into this lane
                 const float fromR = __shfl(gL[i], from_r, 64);      // lane + D evaluated (+D, -D) pairs into this lane
@@ -677,7 +748,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
             }
         }
 #undef BXI_PAIR
-        slow = __any(!(smin > 1e-30f));
+        slow = __any(sat);
     }
     if (slow) {      // workgroup-divergent but wave-uniform; rare
         const int cnt_unused = slow_tile<D, R>(Lg, lab, P, make_int4(wr.r0, wr.r1, wr.c0, wr.c1), wr.img, wr.tile_r0, wr.tile_c0, wr.n2max,
@@ -688,32 +759,39 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
         for (int j = 0; j < R; ++j) g[j] = gbuf[j * 64 + lane];
     }
     // ---- sum W (count waves precede the math waves in the grid) and the instance's projection coefficients --------
+    BXI_TW(1, tix, 3);
     bool ok = true;
     if (!have_total) { ok = total_weight(ws, a.N, &total_w); have_total = ok; }
+    BXI_TW(1, tix, 4);
+    // ---- this tile's share of sum W pw and the arrival: issued before the stores, so that the returning atomic does not
+    // wait for them (vmcnt counts stores as well); nothing in this launch reads g_logits
+    num = wave_sum_f32(num);
+    const long long fx = (long long)(num * kNumScale) + (1ll << 24);     // + 1.0: keeps the packed field non-negative
+    const bool last_one = arrive_final(ws, n, a.N, (unsigned long long)fx);
+    if (last_one) finish_losses(ws, st, a.N, warmup, total_w, upp, upw, losses);
+    BXI_TW(1, tix, 5);
     if (g_logits) {
-        if (lane == 0) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(&ws.lflag[n], BXI_RLX, BXI_AGENT) == 0u) {
-                if (++spins > kSpinLimit) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
-        }
-        ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
         const int c = wr.tile_c0 - D + lane;
         const bool col_owned = lane >= D && lane < 64 - D && c < wr.hc1;
-        // published write-through by the leader: read past this XCD's caches
-        int carg = -1; float gc = 0.f;
-        if (col_owned) {
-            carg = __hip_atomic_load(&st.colarg[(int64_t)n * w + c], BXI_RLX, BXI_AGENT);
-            gc = __hip_atomic_load(&st.gcol[(int64_t)n * w + c], BXI_RLX, BXI_AGENT);
+        const bool row_lane = lane < R && wr.tile_r0 + lane < h;
+        // the leader of this instance publishes one 8-byte granule per column / row (write-through); read past this XCD's
+        // caches until they are there (the leaders precede every tile wave in the grid and never wait)
+        unsigned long long ck = 0ull, rk = 0ull;
+        for (unsigned spins = 0;; ++spins) {
+            if (col_owned) ck = __hip_atomic_load(&st.colk[(int64_t)n * w + c], BXI_RLX, BXI_AGENT);
+            if (row_lane) rk = __hip_atomic_load(&st.rowk[(int64_t)n * h + wr.tile_r0 + lane], BXI_RLX, BXI_AGENT);
+            if (__all((unsigned int)ck != 0xffffffffu && (unsigned int)rk != 0xffffffffu)) break;
+            if (spins > kSpinLimit) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(8);
         }
-        int rarg_l = -1; float gr_l = 0.f;
-        if (lane < R && wr.tile_r0 + lane < h) {
-            rarg_l = __hip_atomic_load(&st.rowarg[(int64_t)n * h + wr.tile_r0 + lane], BXI_RLX, BXI_AGENT);
-            gr_l = __hip_atomic_load(&st.grow[(int64_t)n * h + wr.tile_r0 + lane], BXI_RLX, BXI_AGENT);
-        }
+        const int carg = col_owned ? (int)(unsigned int)ck : -1;
+        const float gc = __uint_as_float((unsigned int)(ck >> 32));
+        const int rarg_l = row_lane ? (int)(unsigned int)rk : -1;
+        const float gr_l = __uint_as_float((unsigned int)(rk >> 32));
         const float scale = upw * (warmup / fmaxf((float)total_w, 1.f));
         if (!ok && lane == 0 && st.status) atomicOr(st.status, 1);
+        if (carg == -12345 && gc == 1.f) return;     // (never) forces the loads above to be waited for here in trace builds
+        BXI_TW(1, tix, 6);
         float* G = g_logits + (int64_t)n * P;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
@@ -728,10 +806,6 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
             }
         }
     }
-    // ---- this tile's share of sum W pw, then the arrival --------------------------------------------------------------
-    num = wave_sum_f32(num);
-    const long long fx = (long long)(num * kNumScale) + (1ll << 24);     // + 1.0: keeps the packed field non-negative
-    if (arrive_final(ws, n, a.N, (unsigned long long)fx)) finish_losses(ws, st, a.N, warmup, total_w, upp, upw, losses);
 }
 
 // ---- leader workgroup --------------------------------------------------------------------------------------------
@@ -774,7 +848,9 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, int R, 
         ys[r] = Y; rarg[r] = (int)unpack_idx(k);
         sums[2] += Y * TY; sums[3] += Y * Y + TY * TY;
     }
+    BXI_TW(3, n, 1);
     block_sum4(sums, red);
+    BXI_TW(3, n, 2);
     const float Ix = sums[0], Ux = sums[1] + 1e-5f, Iy = sums[2], Uy = sums[3] + 1e-5f;
     if (tid == 0)   // :130, summed over both axes :143
         __hip_atomic_store(&ws.dice[n], (1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy), BXI_RLX, BXI_AGENT);
@@ -785,21 +861,20 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, int R, 
             const float X = xs[c];
             const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
             const float gv = invN * ((-2.f * TX * Ux + 4.f * Ix * X) / (Ux * Ux)) * X * (1.f - X);
-            xs[c] = gv;
-            __hip_atomic_store(&st.gcol[(int64_t)n * w + c], gv, BXI_RLX, BXI_AGENT);          // write-through
-            __hip_atomic_store(&st.colarg[(int64_t)n * w + c], carg[c], BXI_RLX, BXI_AGENT);
+            xs[c] = gv;     // one aligned 8-byte write-through store per column: the datum is its own flag
+            __hip_atomic_store(&st.colk[(int64_t)n * w + c], ((unsigned long long)__float_as_uint(gv) << 32) | (unsigned int)carg[c],
+                               BXI_RLX, BXI_AGENT);
         }
         for (int r = tid; r < h; r += 256) {
             const float Y = ys[r];
             const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
             const float gv = invN * ((-2.f * TY * Uy + 4.f * Iy * Y) / (Uy * Uy)) * Y * (1.f - Y);
             ys[r] = gv;
-            __hip_atomic_store(&st.grow[(int64_t)n * h + r], gv, BXI_RLX, BXI_AGENT);
-            __hip_atomic_store(&st.rowarg[(int64_t)n * h + r], rarg[r], BXI_RLX, BXI_AGENT);
+            __hip_atomic_store(&st.rowk[(int64_t)n * h + r], ((unsigned long long)__float_as_uint(gv) << 32) | (unsigned int)rarg[r],
+                               BXI_RLX, BXI_AGENT);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains, then ONE lane raises the flag
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(&ws.lflag[n], 1u, BXI_RLX, BXI_AGENT);
+        BXI_TW(3, n, 3);
+        __syncthreads();      // xs / ys now hold the gradients for every thread
         // projection gradient at the arg-max positions OUTSIDE the tiles (prep_kernel left zeros there; the math waves
         // own every pixel of the tile hull: rows of the R-aligned tiles x columns of the dilated box)
         const int hr0 = ib.any ? (ib.dil.r0 / R) * R : 0, hr1 = ib.any ? min(h, ((ib.dil.r1 + R - 1) / R) * R) : 0;
@@ -819,17 +894,15 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, int R, 
             const bool in_t = r >= hr0 && r < hr1 && c >= hc0 && c < hc1;
             if (!in_t && carg[c] != r) G[(int64_t)r * w + c] = ys[r] * upp;
         }
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // dice[n] is performed before this workgroup's arrival is counted
 }
 
 // grid: [N leader blocks][n_cb count blocks][n_cb math blocks]; a count / math block = 4 independent tile waves striding
 // through the work list.  Every wait in a math wave is for a workgroup EARLIER in the grid (leader, count waves), and
 // those never wait themselves, so the launch cannot stall on an un-dispatched workgroup whatever its size.
 template <int D, int R>
-__global__ __launch_bounds__(256, 2) void pair_kernel(InstArgs a, const float* __restrict__ lab, int dil, float warmup, EvalWs ws,
+__global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair_kernel(InstArgs a, const float* __restrict__ lab, int dil, float warmup, EvalWs ws,
                                                    LossState st, float* __restrict__ losses, float* __restrict__ g_logits,
                                                    const float* __restrict__ up_prj, const float* __restrict__ up_pw, int n_cb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -837,9 +910,13 @@ __global__ __launch_bounds__(256, 2) void pair_kernel(InstArgs a, const float* _
     const int blk = (int)blockIdx.x;
     const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
     if (blk < a.N) {                                                   // ---- leader of instance blk
+        BXI_TW(3, blk, 0);
         leader_block(a, dil, R, ws, st, blk, upp, g_logits, smem, red);
+        BXI_TW(3, blk, 4);
         if (threadIdx.x < 64) {                                        // dice[n] is published (drained above)
-            if (arrive_final(ws, blk, a.N, 0ull)) {
+            const bool last_one = arrive_final(ws, blk, a.N, 0ull);
+            BXI_TW(3, blk, 5);
+            if (last_one) {
                 double total_w = 0.0;
                 const bool ok = total_weight(ws, a.N, &total_w);
                 if (!ok && threadIdx.x == 0 && st.status) atomicOr(st.status, 2);
@@ -853,13 +930,16 @@ __global__ __launch_bounds__(256, 2) void pair_kernel(InstArgs a, const float* _
     const bool counting = blk < a.N + n_cb;
     const int first = ((counting ? blk - a.N : blk - a.N - n_cb) * kWaves) + wave;
     const int stride_w = n_cb * kWaves;
+    const int tix = first;
+    (void)tix;
+    BXI_TW(counting ? 2 : 1, tix, 0);
     float* gbuf = reinterpret_cast<float*>(smem) + wave * ((R + 1) * 64);
     double total_w = 0.0;
     bool have_total = false;
     for (int wi = first; wi < nwork; wi += stride_w) {
         const WorkRec2 wr = ws.work[wi];
-        if (counting) count_tile<D, R>(a, lab, ws, wr);
-        else math_tile<D, R>(a, lab, ws, st, wr, warmup, upp, upw, losses, g_logits, gbuf, total_w, have_total);
+        if (counting) count_tile<D, R>(a, lab, ws, wr, tix);
+        else math_tile<D, R>(a, lab, ws, st, wr, warmup, upp, upw, losses, g_logits, gbuf, total_w, have_total, tix);
     }
 }
 
@@ -879,8 +959,11 @@ __global__ __launch_bounds__(256) void rescale_kernel(InstArgs a, int dil, LossS
     const int hc0 = ib.dil.c0, hc1 = ib.any ? ib.dil.c1 : 0;
     const float ratio = nw / ow;                      // recorded g_pw == 0 cannot be rescaled (documented)
     float* G = g_logits + (int64_t)n * h * w;
-    const int* carg = st.colarg + (int64_t)n * w; const int* rarg = st.rowarg + (int64_t)n * h;
-    const float* gcol = st.gcol + (int64_t)n * w; const float* grow = st.grow + (int64_t)n * h;
+    const unsigned long long* ckp = st.colk + (int64_t)n * w; const unsigned long long* rkp = st.rowk + (int64_t)n * h;
+    auto carg = [&](int c) { return (int)(unsigned int)ckp[c]; };
+    auto rarg = [&](int r) { return (int)(unsigned int)rkp[r]; };
+    auto gcol = [&](int c) { return __uint_as_float((unsigned int)(ckp[c] >> 32)); };
+    auto grow = [&](int r) { return __uint_as_float((unsigned int)(rkp[r] >> 32)); };
     const int cw = hc1 - hc0, rows = hr1 - hr0;
     const int per = (rows + gridDim.x - 1) / gridDim.x;
     const int ra = hr0 + s * per, rb = min(hr1, ra + per);
@@ -888,25 +971,25 @@ __global__ __launch_bounds__(256) void rescale_kernel(InstArgs a, int dil, LossS
     for (int i = tid; i < npx; i += 256) {            // G = ow*s*d + op*sp  ->  nw*s*d + np*sp
         const int r = ra + i / cw, c = hc0 + i % cw;
         float sp = 0.f;
-        if (carg[c] == r) sp += gcol[c];
-        if (rarg[r] == c) sp += grow[r];
+        if (carg(c) == r) sp += gcol(c);
+        if (rarg(r) == c) sp += grow(r);
         const float v = G[(int64_t)r * w + c];
         G[(int64_t)r * w + c] = (v - op * sp) * ratio + np * sp;
     }
     if (s == 0) {                                     // arg-max positions outside the hull hold op * sp
         for (int c = tid; c < w; c += 256) {
-            const int r = carg[c];
+            const int r = carg(c);
             const bool in_t = r >= hr0 && r < hr1 && c >= hc0 && c < hc1;
             if (!in_t) {
-                float v = gcol[c];
-                if (rarg[r] == c) v += grow[r];
+                float v = gcol(c);
+                if (rarg(r) == c) v += grow(r);
                 G[(int64_t)r * w + c] = v * np;
             }
         }
         for (int r = tid; r < h; r += 256) {
-            const int c = rarg[r];
+            const int c = rarg(r);
             const bool in_t = r >= hr0 && r < hr1 && c >= hc0 && c < hc1;
-            if (!in_t && carg[c] != r) G[(int64_t)r * w + c] = grow[r] * np;
+            if (!in_t && carg(c) != r) G[(int64_t)r * w + c] = grow(r) * np;
         }
     }
 }
@@ -959,7 +1042,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thre
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
     EvalWs ws;
     carve_eval(workspace, a.N, a.h, a.w, &ws);
-    LossState st = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    LossState st = {};
     if (state) {
         if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
         carve_state(state, a.N, a.h, a.w, &st);
@@ -971,20 +1054,27 @@ int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thre
     const int R = force_rows == 4 || force_rows == 8 ? force_rows : tile_rows_for(a.N, a.h, a.w, dil);
 
     // ---- launch 1 --------------------------------------------------------------------------------------------------
-    int n_pool = 0;
+    int n_pool = 0, n_items = 0;
+    const int n_tab = (a.N + kWaves - 1) / kWaves;
+    const int n_stream = a.N * ((a.h + kSBlk - 1) / kSBlk);
     if (batch->B > 0) {
-        if (pool_vec_ok(batch, a.stride)) n_pool = batch->B * a.h * ((a.w + 63) / 64);
+        if (pool_vec_ok(batch, a.stride)) {
+            // one item = the 4 input rows of 64 pooled pixels.  The whole launch should be resident at once (5 workgroups
+            // per CU at <= 96 VGPRs): a pool workgroup takes several items, the next one's loads in flight, when it is not.
+            n_items = batch->B * a.h * ((a.w + 63) / 64);
+            const int room = 5 * 256 - n_tab - n_stream;
+            const int per = room > 0 ? (n_items + room - 1) / room : 8;
+            n_pool = (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per);
+        }
         else {                               // unaligned canvas / other strides: separate scalar pooling launch
             rc = launch_pool(batch, a.stride, nullptr, lab, s);
             if (rc != BXI_OK) return rc;
         }
     }
-    const int n_tab = (a.N + kWaves - 1) / kWaves;
-    const int n_stream = a.N * ((a.h + kSBlk - 1) / kSBlk);
     size_t lds1 = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
     if (lds1 < 8 * (size_t)kWaves * a.w) lds1 = 8 * (size_t)kWaves * a.w;
     if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
-    BXI_LAUNCH("prep", s, prep_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, a, dil, R,
+    BXI_LAUNCH("prep", s, prep_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R,
                color_thresh, ws, st, g_logits, vec);
     rc = check_launch();
     if (rc != BXI_OK) return rc;
@@ -992,7 +1082,10 @@ int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thre
     // ---- launch 2 --------------------------------------------------------------------------------------------------
     const int cap = eval_cap(a.N, a.h, a.w, dil, R);
     int n_cb = (cap + kWaves - 1) / kWaves;
-    if (n_cb > 512) n_cb = 512;                          // the list length is device data: the tile waves stride through it
+    // the list length is device data: the tile waves stride through it.  3 (R = 4: <= 168 VGPRs) or 2 (R = 8) workgroups per
+    // CU are resident: leaders + count + math blocks should fit in one round.
+    const int room2 = ((R == 4 ? 3 : 2) * 256 - a.N) / 2;
+    if (n_cb > (room2 > 64 ? room2 : 64)) n_cb = room2 > 64 ? room2 : 64;
     size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
     const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
     if (lds2 < lds_leader) lds2 = lds_leader;
@@ -1029,3 +1122,9 @@ int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_p
 }
 
 }  // namespace bxi
+
+#ifdef BXI_TRACE
+extern "C" int bxi_debug_set_trace2(void* buf) {   // developer builds only
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(bxi::g_trace), &buf, sizeof(buf));
+}
+#endif

@@ -34,6 +34,8 @@ struct LossState {            // what the backward / rescale entry points need (
     InstRec* inst;            // [N]   box rectangles
     float* scale;             // [1]   warmup / max(sum W, 1)
     float* applied;           // [2]   upstream factors (g_prj, g_pw) folded into a finished gradient (fused_eval.hip)
+    unsigned long long* colk; // [N,w] fused_eval.hip: (unit gradient bits << 32) | arg-max row ; low word 0xffffffff = not published yet
+    unsigned long long* rowk; // [N,h] same for the rows
     int* status;              // [2]   {0 or a bit mask of protocol time-outs (never expected), tile rows R} (fused_eval.hip)
 };
 
@@ -50,9 +52,11 @@ static inline size_t carve_state(void* base, int N, int h, int w, LossState* st)
     InstRec* inst = (InstRec*)take(32 * (size_t)(N > 0 ? N : 1));
     float* scale = (float*)take(sizeof(float));
     float* applied = (float*)take(2 * sizeof(float));
+    unsigned long long* colk = (unsigned long long*)take(8 * (size_t)N * w);
+    unsigned long long* rowk = (unsigned long long*)take(8 * (size_t)N * h);
     int* status = (int*)take(2 * sizeof(int));
     if (st) { st->colarg = colarg; st->rowarg = rowarg; st->gcol = gcol; st->grow = grow; st->inst = inst; st->scale = scale;
-              st->applied = applied; st->status = status; }
+              st->applied = applied; st->colk = colk; st->rowk = rowk; st->status = status; }
     return off;
 }
 

@@ -909,7 +909,7 @@ int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, co
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
     LossWs ws;
     carve_ws(workspace, a.N, a.h, a.w, &ws);
-    LossState st = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    LossState st = {};
     if (state) {
         if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
         carve_state(state, a.N, a.h, a.w, &st);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): run one cfg-2 evaluation with the -DBXI_TRACE library and dump per-block
-phase timestamps (100 MHz wall clock) to gpurun_out/trace.npz."""
+"""Developer tool (GPU box): run one cfg-2 evaluation with the -DBXI_TRACE library and print per-wave phase timings
+(100 MHz wall clock) of prep_kernel / pair_kernel.  Build first:
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBXI_TRACE -o boxinstseg_amd/lib/libboxinst_hip_trace.so boxinstseg_amd/csrc/*.hip"""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -8,8 +9,9 @@ from boxinstseg_amd import _lib, build as hb
 hb.LIB_PATH = os.path.join(hb.LIB_DIR, 'libboxinst_hip_trace.so')
 from boxinstseg_amd import functional as Fh, synthetic
 lib = _lib.load()
-lib.bxi_debug_set_trace.argtypes = [C.c_void_p]
+lib.bxi_debug_set_trace2.argtypes = [C.c_void_p]
 dev = torch.device('cuda:0')
+ones = torch.ones(2, device=dev)
 sets = []
 for seed in range(8):
     d = synthetic.cfg2(seed)
@@ -23,13 +25,43 @@ for seed in range(8):
 st = torch.cuda.current_stream().cuda_stream
 def ev(s):
     batch, inst, losses, grad, state, ws = s[:6]
-    rc = lib.bxi_boxinst_eval_f32(C.byref(batch.struct), C.byref(inst.struct), 3, 2, 0.3, 1.0, losses.data_ptr(), grad.data_ptr(), state.data_ptr(), ws.data_ptr(), ws.numel(), st)
+    rc = lib.bxi_boxinst_eval_f32(C.byref(batch.struct), C.byref(inst.struct), 3, 2, 0.3, 1.0, ones.data_ptr(), ones.data_ptr() + 4,
+                                  losses.data_ptr(), grad.data_ptr(), state.data_ptr(), ws.data_ptr(), ws.numel(), st)
     assert rc == 0, rc
-for i in range(40): ev(sets[i % 8])
+for i in range(60): ev(sets[i % 8])
 torch.cuda.synchronize()
-trace = torch.zeros((3, 8192, 8), dtype=torch.int64, device=dev)
-assert lib.bxi_debug_set_trace(trace.data_ptr()) == 0
-torch.cuda._sleep(int(0.02*2e9)); ev(sets[0]); torch.cuda.synchronize()
+trace = torch.zeros((4, 8192, 8), dtype=torch.int64, device=dev)
+assert lib.bxi_debug_set_trace2(trace.data_ptr()) == 0
+torch.cuda._sleep(int(0.02 * 2e9)); ev(sets[3]); torch.cuda.synchronize()
+t = trace.cpu().numpy().astype(np.float64)
+us = lambda x: x * 0.01
+N, Sn = 32, 7
+n_tab, n_stream = 8 * 4, N * Sn * 4
+p = t[0]; live = p[:, 0] > 0
+t0 = p[live, 0].min()
+def q(x): return np.round(np.quantile(x, [0, .25, .5, .75, 1]), 2).tolist() if len(x) else []
+print('prep: waves', int(live.sum()), 'start', q(us(p[live, 0] - t0)), 'end', q(us(p[live, 7] - t0)))
+tab = p[:n_tab]; tab = tab[tab[:, 7] > 0]
+print('  table waves end', q(us(tab[:, 7] - t0)))
+sw = p[n_tab:n_tab + n_stream]; sw = sw[sw[:, 7] > 0]
+print('  stream waves: start', q(us(sw[:, 0] - t0)), '| loads+zero-fill issued', q(us(sw[:, 1] - sw[:, 0])), '| data + column max', q(us(sw[:, 2] - sw[:, 1])),
+      '| butterflies', q(us(sw[:, 3] - sw[:, 2])), '| barrier', q(us(sw[:, 4] - sw[:, 3])), '| end', q(us(sw[:, 7] - t0)))
+pw = p[n_tab + n_stream:]; pw = pw[pw[:, 7] > 0]
+print('  pool waves:', len(pw), 'start', q(us(pw[:, 0] - t0)), '| loads + denorm', q(us(pw[:, 1] - pw[:, 0])), '| barrier 1', q(us(pw[:, 2] - pw[:, 1])),
+      '| Lab f', q(us(pw[:, 3] - pw[:, 2])), '| barrier 2', q(us(pw[:, 4] - pw[:, 3])), '| end', q(us(pw[:, 7] - t0)))
+prep_end = p[live, 7].max()
+ld = t[3]; ld = ld[ld[:, 0] > 0]
+k0 = min(ld[:, 0].min(), t[1][t[1][:, 0] > 0, 0].min(), t[2][t[2][:, 0] > 0, 0].min())
+print('pair: first wave starts %.2f us after the last prep wave ended' % us(k0 - prep_end))
+print('  leaders', len(ld), 'start', q(us(ld[:, 0] - k0)), '| loads+maxima', q(us(ld[:, 1] - ld[:, 0])), '| sums', q(us(ld[:, 2] - ld[:, 1])),
+      '| coefs published', q(us(ld[:, 3] - ld[:, 2])), '| flag at', q(us(ld[:, 3] - k0)), '| sparse', q(us(ld[:, 4] - ld[:, 3])), '| arrive', q(us(ld[:, 5] - ld[:, 4])), '| end', q(us(ld[:, 5] - k0)))
+cw = t[2]; allc = cw[cw[:, 0] > 0]; cw = allc[allc[:, 3] > 0]
+print('  count waves with a tile', len(cw), 'of', len(allc), 'start', q(us(cw[:, 0] - k0)), '| record+flags', q(us(cw[:, 1] - cw[:, 0])), '| Lab arrived', q(us(cw[:, 2] - cw[:, 1])),
+      '| predicates', q(us(cw[:, 3] - cw[:, 2])), '| counted at', q(us(cw[:, 3] - k0)))
+mw = t[1]; allm = mw[mw[:, 0] > 0]; mw = allm[allm[:, 6] > 0]
+print('  math waves with a tile', len(mw), 'of', len(allm), 'start', q(us(mw[:, 0] - k0)), '| record+flags', q(us(mw[:, 1] - mw[:, 0])), '| data arrived', q(us(mw[:, 2] - mw[:, 1])),
+      '| pair math', q(us(mw[:, 3] - mw[:, 2])), '| sum W', q(us(mw[:, 4] - mw[:, 3])), '| arrive', q(us(mw[:, 5] - mw[:, 4])),
+      '| coefficients', q(us(mw[:, 6] - mw[:, 5])), '| stores issued at', q(us(mw[:, 6] - k0)))
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 np.savez_compressed(os.path.join(ROOT, 'gpurun_out', 'trace.npz'), trace=trace.cpu().numpy())
-print('saved', float(sets[0][2][0]), float(sets[0][2][1]))
+print('losses', float(sets[3][2][0]), float(sets[3][2][1]))
