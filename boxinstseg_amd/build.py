@@ -24,7 +24,7 @@ def hipcc() -> str:
 
 def command(extra: List[str] | None = None) -> List[str]:
     return [hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wall',
-            '-Wno-unused-function', *(extra or []), '-o', LIB_PATH, *[os.path.join(CSRC, s) for s in SOURCES]]
+            '-Wno-unused-function', '-mllvm', '-amdgpu-kernarg-preload-count=16', *(extra or []), '-o', LIB_PATH, *[os.path.join(CSRC, s) for s in SOURCES]]
 
 
 def is_stale() -> bool:

@@ -72,7 +72,6 @@ struct EvalWs {                                 // carved from the caller's work
     // words polled inside pair_kernel; zeroed by prep_kernel's table waves (i.e. before a kernel boundary)
     unsigned long long* acc1;                   // [N]  count waves : arrivals << 40 | sum W
     unsigned long long* acc2;                   // [N]  math waves + leader : arrivals << 52 | sum (W pw + 1) in 2^-24 units
-    unsigned int* fin;                          // [1]  instances complete
     float* dice;                                // [N]
 };
 
@@ -97,7 +96,6 @@ static size_t carve_eval(void* base, int N, int h, int w, EvalWs* ws) {
     t.expect = (unsigned int*)take(4 * (size_t)N1);
     t.acc1 = (unsigned long long*)take(8 * (size_t)N1);
     t.acc2 = (unsigned long long*)take(8 * (size_t)N1);
-    t.fin = (unsigned int*)take(4);
     t.dice = (float*)take(4 * (size_t)N1);
     if (ws) *ws = t;
     return off;
@@ -166,7 +164,7 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
     const int img = __builtin_amdgcn_readfirstlane(mine.img);
     const int vr = min(meta.img_h[img], meta.first_removed[img]), vc = meta.img_w[img];
     if (lane == 0) {
-        if (n == 0) { *ws.nwork = total; *ws.fin = 0u; if (st.status) { st.status[0] = 0; st.status[1] = R; } }
+        if (n == 0) { *ws.nwork = total; if (st.status) { st.status[0] = 0; st.status[1] = R; } }
         InstRec rc; rc.r0 = mine.r0; rc.r1 = mine.r1; rc.c0 = mine.c0; rc.c1 = mine.c1; rc.img = mine.img;
         rc.pad0 = rc.pad1 = rc.pad2 = 0;
         ws.inst[n] = rc;
@@ -477,11 +475,11 @@ __device__ __forceinline__ void dir_masks(const TileFlags& f, DirMasks (&m)[4]) 
 template <int D, int R>
 __device__ __forceinline__ void load_plane(const float* __restrict__ plane, const WorkRec2& wr, int h, int w, int lane,
                                            float (&v)[R + 2 * D]) {
-    const int cc = min(max(wr.tile_c0 - D + lane, 0), w - 1);
+    const uint32_t cc = (uint32_t)min(max(wr.tile_c0 - D + lane, 0), w - 1);
 #pragma unroll
     for (int j = 0; j < R + 2 * D; ++j) {
-        const int rr = min(max(wr.tile_r0 - D + j, 0), h - 1);       // clamped: pairs with a pixel outside the map weigh 0
-        v[j] = plane[(int64_t)rr * w + cc];
+        const uint32_t rr = (uint32_t)min(max(wr.tile_r0 - D + j, 0), h - 1);       // clamped: pairs with a pixel outside the map weigh 0
+        v[j] = plane[rr * (uint32_t)w + cc];       // uniform base + 32-bit offset (one plane < 2^31 elements)
     }
 }
 
@@ -496,7 +494,7 @@ __device__ __forceinline__ float n2_of(float L0, float A0, float B0, float L1, f
 // gradient in log space exactly as pairwise.cu:38-61.  Taken for thresh <= 0 (zero_bit: padded / masked-out neighbours
 // weigh 1) and for tiles with saturated logits (S underflows).  Returns the lane's sum W (and sum W pw, gradients -> gout).
 template <int D, int R>
-__device__ __noinline__ int slow_tile(const float* __restrict__ Lg, const float* __restrict__ lab, int64_t P, int4 box, int img,
+__device__ __forceinline__ int slow_tile(const float* __restrict__ Lg, const float* __restrict__ lab, int64_t P, int4 box, int img,
                                       int tile_r0, int tile_c0, float n2max, int zero_bit, int vr, int vc, int hc1, int h,
                                       int w, int stride, int lane, bool want_grad, float* gout /* LDS [R + 1][64]: gradients, then sum W pw */) {
     struct { int r0, r1, c0, c1, img, tile_r0, tile_c0; float n2max; int zero_bit, vr, vc, hc1; } wr =
@@ -647,19 +645,6 @@ __device__ __forceinline__ void finish_losses(const EvalWs& ws, const LossState&
     }
 }
 
-// arrival of a math wave / leader at instance n: returns true for the last arrival of the whole launch
-__device__ __forceinline__ bool arrive_final(const EvalWs& ws, int n, int N, unsigned long long add) {
-    bool last = false;
-    if ((threadIdx.x & 63) == 0) {
-        const unsigned long long o = __hip_atomic_fetch_add(&ws.acc2[n], (1ull << 52) + add, BXI_RLX, BXI_AGENT);
-        if ((unsigned int)(o >> 52) == ws.expect[n]) {          // tiles + leader = expect + 1 arrivals: this was the last one
-            const unsigned int o2 = __hip_atomic_fetch_add(ws.fin, 1u, BXI_RLX, BXI_AGENT);
-            last = (o2 + 1u == (unsigned int)N);
-        }
-    }
-    return __builtin_amdgcn_readfirstlane((int)last) != 0;
-}
-
 // ---- math wave ---------------------------------------------------------------------------------------------------
 template <int D, int R>
 __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __restrict__ lab, const EvalWs& ws, const LossState& st,
@@ -723,7 +708,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
             const float gw = pn ? (float)((cw[dir][(i) >> 2] >> (8 * ((i) & 3))) & 255u) : 0.f;                     \
             const float nw = pn ? (float)((dw[dir][(i) >> 2] >> (8 * ((i) & 3))) & 255u) : 0.f;                     \
             const float S = pa_[i] * (qa) + pb_[i] * (qb);                          /* P(y_p == y_q) */            \
-            num -= nw * __logf(S);                                                                                  \
+            num -= nw * (0.69314718055994531f * __builtin_amdgcn_logf(S));          /* v_log_f32 = log2 */         \
             const float mm = gw * __builtin_amdgcn_rcpf(S);                                                         \
             GP -= mm * (qt) * pu_[i];                                                                               \
             GQ -= mm * pt_[i] * (qu);                                                                               \
@@ -758,40 +743,47 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
 #pragma unroll
         for (int j = 0; j < R; ++j) g[j] = gbuf[j * 64 + lane];
     }
-    // ---- sum W (count waves precede the math waves in the grid) and the instance's projection coefficients --------
+    // ---- epilogue: one round of polls for everything the stores need, the arrival issued before and consumed after them ----
     BXI_TW(1, tix, 3);
-    bool ok = true;
-    if (!have_total) { ok = total_weight(ws, a.N, &total_w); have_total = ok; }
-    BXI_TW(1, tix, 4);
-    // ---- this tile's share of sum W pw and the arrival: issued before the stores, so that the returning atomic does not
-    // wait for them (vmcnt counts stores as well); nothing in this launch reads g_logits
     num = wave_sum_f32(num);
     const long long fx = (long long)(num * kNumScale) + (1ll << 24);     // + 1.0: keeps the packed field non-negative
-    const bool last_one = arrive_final(ws, n, a.N, (unsigned long long)fx);
-    if (last_one) finish_losses(ws, st, a.N, warmup, total_w, upp, upw, losses);
-    BXI_TW(1, tix, 5);
-    if (g_logits) {
-        const int c = wr.tile_c0 - D + lane;
-        const bool col_owned = lane >= D && lane < 64 - D && c < wr.hc1;
-        const bool row_lane = lane < R && wr.tile_r0 + lane < h;
-        // the leader of this instance publishes one 8-byte granule per column / row (write-through); read past this XCD's
-        // caches until they are there (the leaders precede every tile wave in the grid and never wait)
-        unsigned long long ck = 0ull, rk = 0ull;
-        for (unsigned spins = 0;; ++spins) {
-            if (col_owned) ck = __hip_atomic_load(&st.colk[(int64_t)n * w + c], BXI_RLX, BXI_AGENT);
-            if (row_lane) rk = __hip_atomic_load(&st.rowk[(int64_t)n * h + wr.tile_r0 + lane], BXI_RLX, BXI_AGENT);
-            if (__all((unsigned int)ck != 0xffffffffu && (unsigned int)rk != 0xffffffffu)) break;
-            if (spins > kSpinLimit) { ok = false; break; }
-            __builtin_amdgcn_s_sleep(8);
+    const int c = wr.tile_c0 - D + lane;
+    const bool col_owned = g_logits && lane >= D && lane < 64 - D && c < wr.hc1;
+    const bool row_lane = g_logits && lane < R && wr.tile_r0 + lane < h;
+    // sum W: every count wave has arrived (they precede the math waves in the grid); projection coefficients: the leader of
+    // this instance publishes one 8-byte granule per column / row (write-through; the leaders precede every tile wave and
+    // never wait).  Both are read past this XCD's caches, in the same round.
+    bool ok = true;
+    unsigned long long ck = 0ull, rk = 0ull;
+    for (unsigned spins = 0;; ++spins) {
+        bool have = true;
+        unsigned long long sw = 0ull;
+        if (!have_total)
+            for (int b0 = 0; b0 < a.N; b0 += 64) {
+                const int i = b0 + lane;
+                if (i < a.N) {
+                    const unsigned long long x = __hip_atomic_load(&ws.acc1[i], BXI_RLX, BXI_AGENT);
+                    have &= (unsigned int)(x >> 40) == ws.expect[i];
+                    sw += x & ((1ull << 40) - 1ull);
+                }
+            }
+        if (col_owned) { ck = __hip_atomic_load(&st.colk[(int64_t)n * w + c], BXI_RLX, BXI_AGENT); have &= (unsigned int)ck != 0xffffffffu; }
+        if (row_lane) { rk = __hip_atomic_load(&st.rowk[(int64_t)n * h + wr.tile_r0 + lane], BXI_RLX, BXI_AGENT); have &= (unsigned int)rk != 0xffffffffu; }
+        if (__all(have)) {
+            if (!have_total) { total_w = wave_sum_f64((double)sw); have_total = true; }     // exact: integers far below 2^53
+            break;
         }
+        if (spins > kSpinLimit) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (!ok && lane == 0 && st.status) atomicOr(st.status, 1);
+    BXI_TW(1, tix, 4);
+    if (g_logits) {
         const int carg = col_owned ? (int)(unsigned int)ck : -1;
         const float gc = __uint_as_float((unsigned int)(ck >> 32));
         const int rarg_l = row_lane ? (int)(unsigned int)rk : -1;
         const float gr_l = __uint_as_float((unsigned int)(rk >> 32));
         const float scale = upw * (warmup / fmaxf((float)total_w, 1.f));
-        if (!ok && lane == 0 && st.status) atomicOr(st.status, 1);
-        if (carg == -12345 && gc == 1.f) return;     // (never) forces the loads above to be waited for here in trace builds
-        BXI_TW(1, tix, 6);
         float* G = g_logits + (int64_t)n * P;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
@@ -806,6 +798,11 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
             }
         }
     }
+    BXI_TW(1, tix, 5);
+    // ---- this tile's share of sum W pw + its arrival: one atomic without return, the wave does not wait for it (a
+    // returning atomic on these 32 words costs ~3 us here); the finisher block at the end of the grid watches the counts
+    if (lane == 0) __hip_atomic_fetch_add(&ws.acc2[n], (1ull << 52) + (unsigned long long)fx, BXI_RLX, BXI_AGENT);
+    BXI_TW(1, tix, 6);
 }
 
 // ---- leader workgroup --------------------------------------------------------------------------------------------
@@ -898,13 +895,15 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, int R, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // dice[n] is performed before this workgroup's arrival is counted
 }
 
-// grid: [N leader blocks][n_cb count blocks][n_cb math blocks]; a count / math block = 4 independent tile waves striding
-// through the work list.  Every wait in a math wave is for a workgroup EARLIER in the grid (leader, count waves), and
+// grid: [N leader blocks][n_cb count blocks][n_cb math blocks][finisher]; a count / math block = 4 independent tile waves
+// striding through the work list; the finisher (one wave) writes the two loss values once everybody has arrived.  Every wait in a math wave is for a workgroup EARLIER in the grid (leader, count waves), and
 // those never wait themselves, so the launch cannot stall on an un-dispatched workgroup whatever its size.
 template <int D, int R>
-__global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair_kernel(InstArgs a, const float* __restrict__ lab, int dil, float warmup, EvalWs ws,
-                                                   LossState st, float* __restrict__ losses, float* __restrict__ g_logits,
-                                                   const float* __restrict__ up_prj, const float* __restrict__ up_pw, int n_cb) {
+__global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair_kernel(const WorkRec2* __restrict__ work, const int* __restrict__ nwork_p,
+                                                   const float* __restrict__ lab, const float* __restrict__ up_prj,
+                                                   const float* __restrict__ up_pw, int n_cb, int dil, float warmup,
+                                                   float* __restrict__ losses, float* __restrict__ g_logits, InstArgs a, EvalWs ws,
+                                                   LossState st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[16];
     const int blk = (int)blockIdx.x;
@@ -913,19 +912,32 @@ __global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair_kernel(InstArgs a,
         BXI_TW(3, blk, 0);
         leader_block(a, dil, R, ws, st, blk, upp, g_logits, smem, red);
         BXI_TW(3, blk, 4);
-        if (threadIdx.x < 64) {                                        // dice[n] is published (drained above)
-            const bool last_one = arrive_final(ws, blk, a.N, 0ull);
-            BXI_TW(3, blk, 5);
-            if (last_one) {
-                double total_w = 0.0;
-                const bool ok = total_weight(ws, a.N, &total_w);
-                if (!ok && threadIdx.x == 0 && st.status) atomicOr(st.status, 2);
-                finish_losses(ws, st, a.N, warmup, total_w, upp, upw, losses);
-            }
-        }
+        if (threadIdx.x == 0)                                          // dice[n] is performed (drained in leader_block)
+            __hip_atomic_fetch_add(&ws.acc2[blk], 1ull << 52, BXI_RLX, BXI_AGENT);
+        BXI_TW(3, blk, 5);
         return;
     }
-    const int nwork = *ws.nwork;
+    if (blk == (int)gridDim.x - 1) {                                   // ---- finisher: the last block of the grid, one wave
+        if (threadIdx.x >= 64) return;
+        // every leader and tile wave precedes this block in the grid and none of them waits for it
+        const int lane = threadIdx.x;
+        bool ok = false;
+        for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {
+            bool have = true;
+            for (int b0 = 0; b0 < a.N; b0 += 64) {
+                const int i = b0 + lane;
+                if (i < a.N) have &= (unsigned int)(__hip_atomic_load(&ws.acc2[i], BXI_RLX, BXI_AGENT) >> 52) == ws.expect[i] + 1u;
+            }
+            if (__all(have)) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        double total_w = 0.0;
+        ok = total_weight(ws, a.N, &total_w) && ok;
+        if (!ok && lane == 0 && st.status) atomicOr(st.status, 2);
+        finish_losses(ws, st, a.N, warmup, total_w, upp, upw, losses);
+        return;
+    }
+    const int nwork = *nwork_p;
     const int wave = (int)(threadIdx.x >> 6);
     const bool counting = blk < a.N + n_cb;
     const int first = ((counting ? blk - a.N : blk - a.N - n_cb) * kWaves) + wave;
@@ -937,7 +949,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair_kernel(InstArgs a,
     double total_w = 0.0;
     bool have_total = false;
     for (int wi = first; wi < nwork; wi += stride_w) {
-        const WorkRec2 wr = ws.work[wi];
+        const WorkRec2 wr = work[wi];
         if (counting) count_tile<D, R>(a, lab, ws, wr, tix);
         else math_tile<D, R>(a, lab, ws, st, wr, warmup, upp, upw, losses, g_logits, gbuf, total_w, have_total, tix);
     }
@@ -1010,8 +1022,8 @@ template <int D, int R>
 static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, const float* lab, int dil, float warmup,
                         const EvalWs& ws, const LossState& st, float* losses, float* g_logits, const float* up_prj,
                         const float* up_pw, int n_cb) {
-    BXI_LAUNCH("pair", s, (pair_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, a, lab, dil, warmup, ws, st, losses, g_logits,
-               up_prj, up_pw, n_cb);
+    BXI_LAUNCH("pair", s, (pair_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, (const WorkRec2*)ws.work, (const int*)ws.nwork, lab,
+               up_prj, up_pw, n_cb, dil, warmup, losses, g_logits, a, ws, st);
 }
 
 bool fused_eval_supported(int dil) { return dil >= 1 && dil <= kMaxDilFused; }
@@ -1090,7 +1102,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thre
     const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
     if (lds2 < lds_leader) lds2 = lds_leader;
     if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
-    const int grid = a.N + 2 * n_cb;
+    const int grid = a.N + 2 * n_cb + 1;                 // + the finisher
 #define BXI_PAIR_CASE(DD)                                                                                                    \
     case DD:                                                                                                                 \
         if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, lab, dil, warmup, ws, st, losses, g_logits, up_prj, up_pw, n_cb);   \

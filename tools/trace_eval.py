@@ -58,10 +58,10 @@ print('  leaders', len(ld), 'start', q(us(ld[:, 0] - k0)), '| loads+maxima', q(u
 cw = t[2]; allc = cw[cw[:, 0] > 0]; cw = allc[allc[:, 3] > 0]
 print('  count waves with a tile', len(cw), 'of', len(allc), 'start', q(us(cw[:, 0] - k0)), '| record+flags', q(us(cw[:, 1] - cw[:, 0])), '| Lab arrived', q(us(cw[:, 2] - cw[:, 1])),
       '| predicates', q(us(cw[:, 3] - cw[:, 2])), '| counted at', q(us(cw[:, 3] - k0)))
-mw = t[1]; allm = mw[mw[:, 0] > 0]; mw = allm[allm[:, 6] > 0]
+mw = t[1]; allm = mw[mw[:, 0] > 0]; mw = allm[allm[:, 5] > 0]
 print('  math waves with a tile', len(mw), 'of', len(allm), 'start', q(us(mw[:, 0] - k0)), '| record+flags', q(us(mw[:, 1] - mw[:, 0])), '| data arrived', q(us(mw[:, 2] - mw[:, 1])),
-      '| pair math', q(us(mw[:, 3] - mw[:, 2])), '| sum W', q(us(mw[:, 4] - mw[:, 3])), '| arrive', q(us(mw[:, 5] - mw[:, 4])),
-      '| coefficients', q(us(mw[:, 6] - mw[:, 5])), '| stores issued at', q(us(mw[:, 6] - k0)))
+      '| pair math', q(us(mw[:, 3] - mw[:, 2])), '| sum W + coefficients', q(us(mw[:, 4] - mw[:, 3])), '| stores issued', q(us(mw[:, 5] - mw[:, 4])),
+      '| arrival', q(us(mw[:, 6] - mw[:, 5])), '| stores issued at', q(us(mw[:, 5] - k0)), '| end', q(us(mw[:, 6] - k0)))
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 np.savez_compressed(os.path.join(ROOT, 'gpurun_out', 'trace.npz'), trace=trace.cpu().numpy())
 print('losses', float(sets[3][2][0]), float(sets[3][2][1]))
