@@ -22,9 +22,12 @@ def hipcc() -> str:
     return exe
 
 
-def command(extra: List[str] | None = None) -> List[str]:
+def command(extra: List[str] | None = None, out: str | None = None) -> List[str]:
+    # -amdgpu-kernarg-preload-count: the first kernel arguments arrive in SGPRs with the wave instead of through a
+    # scalar load from the kernarg segment (one dependent memory round trip less at the start of every wave)
     return [hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wall',
-            '-Wno-unused-function', '-mllvm', '-amdgpu-kernarg-preload-count=16', *(extra or []), '-o', LIB_PATH, *[os.path.join(CSRC, s) for s in SOURCES]]
+            '-Wno-unused-function', '-mllvm', '-amdgpu-kernarg-preload-count=16', *(extra or []), '-o', out or LIB_PATH,
+            *[os.path.join(CSRC, s) for s in SOURCES]]
 
 
 def is_stale() -> bool:
@@ -43,10 +46,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
         with open(os.path.join(LIB_DIR, '.build.lock'), 'w') as lk:      # one builder at a time (ranks of a multi-GPU run)
             fcntl.flock(lk, fcntl.LOCK_EX)
             if force or is_stale():
-                cmd = command()
+                # link into a temporary name and rename: a process that dlopens LIB_PATH meanwhile sees the old or the new
+                # library, never a partially written one, and a failed compile leaves no truncated file behind
+                tmp = os.path.join(LIB_DIR, f'.libboxinst_hip.{os.getpid()}.so.tmp')
+                cmd = command(out=tmp)
                 if verbose:
                     print(' '.join(cmd))
-                subprocess.run(cmd, check=True)
+                try:
+                    subprocess.run(cmd, check=True)
+                    os.replace(tmp, LIB_PATH)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
     return LIB_PATH
 
 

@@ -127,7 +127,9 @@ __device__ __forceinline__ void mf_eval_item(const MfArgs& a, const u64* sa, u64
     const int64_t wbase = (int64_t)n * H * segs;
     const int64_t HW = (int64_t)H * W;
     const int cc = c < W ? c : W - 1;                             // clamped: loads need no branch
-    const float* Kp = a.K + (a.img ? a.img[n] : 0) * (int64_t)KK * HW + (int64_t)r * W + cc;
+    // img_inds is device data: clamp it into [0, B) so that a bad index reads a wrong kernel plane, never foreign memory
+    const int64_t bi = a.img ? (a.img[n] < 0 ? 0 : (a.img[n] >= a.B ? a.B - 1 : a.img[n])) : 0;
+    const float* Kp = a.K + bi * (int64_t)KK * HW + (int64_t)r * W + cc;
     float kv[KK];
 #pragma unroll
     for (int k = 0; k < KK; ++k) kv[k] = Kp[(int64_t)k * HW];

@@ -91,8 +91,18 @@ class MeanField(torch.nn.Module):
             self.kernel = k.view(k.size(0), 1, k.size(1), -1)                           # the reference's layout (:611-612)
 
     def forward(self, x, targets, inter_img_mask=None):
+        """The reference broadcasts ``kernel [B,1,k*k,HW]`` against ``x [N,...]`` (discobox_head.py:617-655): B == 1 serves any
+        number of instances (every call site of the reference), B == N pairs instance i with image i; anything else fails
+        to broadcast there and raises here."""
+        B = self._kernel.size(0)
+        img_inds = None
+        if B != 1:
+            if x.size(0) != B:
+                raise RuntimeError(f'MeanField built from {B} feature maps cannot serve {x.size(0)} instances '
+                                   '(the reference broadcasts kernel [B,...] against x [N,...]: B must be 1 or N)')
+            img_inds = torch.arange(B, device=x.device)
         with torch.no_grad():
-            return meanfield_forward(self._kernel, x, targets, self.iter, self.base, None, inter_img_mask, self.gamma)
+            return meanfield_forward(self._kernel, x, targets, self.iter, self.base, img_inds, inter_img_mask, self.gamma)
 
 
 class _DiceLoss(torch.autograd.Function):

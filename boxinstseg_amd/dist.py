@@ -6,8 +6,8 @@ replicas and the path itself issues no collective.  What the reference does all-
 *logging* of the loss scalars in ``BaseDetector._parse_losses`` (mmdet/models/detectors/base.py:176-219):
 one ``all_reduce`` per logged key plus a key-count check, each followed by ``.item()``.  On xGMI a
 collective is latency-, not bandwidth-bound at this size, so :func:`parse_losses` stacks every logged
-scalar (and the key count) into ONE tensor and issues ONE all-reduce; values stay on the device until
-the caller asks for them.
+scalar into ONE tensor and issues ONE all-reduce for the values (after the reference's fixed-size key guard);
+values stay on the device until the caller asks for them.
 """
 from __future__ import annotations
 
@@ -38,14 +38,25 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local_rank
 
 
-def parse_losses(losses: Dict[str, torch.Tensor], sync: bool = True) -> Tuple[torch.Tensor, 'OrderedDict[str, torch.Tensor]']:
-    """``BaseDetector._parse_losses`` (base.py:176-219) with a single collective.
+def _key_digest(keys) -> int:
+    """order-sensitive 31-bit digest of the logged key names (same on every rank iff the key lists agree)."""
+    import zlib
+    return zlib.crc32('\x00'.join(keys).encode()) & 0x7fffffff
+
+
+def parse_losses(losses: Dict[str, torch.Tensor], sync: bool = True, check_keys: bool = True
+                 ) -> Tuple[torch.Tensor, 'OrderedDict[str, torch.Tensor]']:
+    """``BaseDetector._parse_losses`` (base.py:176-219) with one collective for the values.
 
     Returns ``(loss, log_vars)``: ``loss`` = sum of every entry whose key contains 'loss' (rank-local,
     attached to the autograd graph); ``log_vars`` = every entry (plus 'loss') averaged over ranks,
     as 0-dim device tensors (the reference calls ``.item()`` on each; do that only when logging).
-    Raises like the reference (base.py:201-210) when ranks disagree on the number of logged keys.
-    """
+
+    The key guard of the reference (base.py:201-210: ranks that disagree on the logged keys would otherwise issue
+    collectives of different sizes -- "GPUs will wait infinitely") is a FIXED-size all-reduce issued first, like the
+    reference's: [count, -count, digest, -digest] under MAX; a mismatch raises ``AssertionError`` on every rank before
+    the value collective is issued.  It costs one host read (the reference pays one per key); ``check_keys=False`` skips
+    it for callers whose key set cannot vary."""
     log_vars: 'OrderedDict[str, torch.Tensor]' = OrderedDict()
     for name, value in losses.items():
         if isinstance(value, torch.Tensor):
@@ -59,13 +70,17 @@ def parse_losses(losses: Dict[str, torch.Tensor], sync: bool = True) -> Tuple[to
     if sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         world = dist.get_world_size()
         keys = list(log_vars.keys())
-        packed = torch.stack([log_vars[k].detach().float() for k in keys] +
-                             [torch.tensor(float(len(keys)), device=loss.device)])
-        dist.all_reduce(packed)                                   # one RCCL all-reduce for everything
-        # the key-count guard: every rank contributed len(keys) -> the sum must be world * len(keys).
-        # Checked without a sync: the flag rides along and poisons the logged values with NaN on mismatch.
-        ok = packed[-1] == float(world * len(keys))
-        packed = torch.where(ok, packed / world, torch.full_like(packed, float('nan')))
+        if check_keys:
+            n, dg = float(len(keys)), float(_key_digest(keys))
+            guard = torch.tensor([n, -n, dg, -dg], device=loss.device, dtype=torch.float64)
+            dist.all_reduce(guard, op=dist.ReduceOp.MAX)
+            g = guard.tolist()
+            assert g[0] == -g[1] == n and g[2] == -g[3] == dg, (
+                f'loss log variables differ across ranks: this rank logs {len(keys)} keys {",".join(keys)}; '
+                f'count range [{-g[1]:.0f}, {g[0]:.0f}]')
+        packed = torch.stack([log_vars[k].detach().float() for k in keys])
+        dist.all_reduce(packed)                                   # one RCCL all-reduce for every logged value
+        packed = packed / world
         for i, k in enumerate(keys):
             log_vars[k] = packed[i]
     else:

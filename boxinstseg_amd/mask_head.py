@@ -108,12 +108,24 @@ class CondInstMaskHead(nn.Module):
         super()._load_from_state_dict(*args, **kwargs)
         self._iter_host = None       # re-read from the buffer on the next loss() call (one sync)
 
+    def set_iter(self, value: float) -> None:
+        """Set the iteration counter (buffer and host mirror together), e.g. when resuming by hand."""
+        self._iter.fill_(float(value))
+        self._iter_host = float(value)
+        self._iter_seen = (self._iter._version, self._iter.data_ptr())
+
     def _tick(self) -> float:
-        """``self._iter += 1`` (condinst_head.py:1297) and the warm-up factor (:1330-1331), sync-free."""
-        if self._iter_host is None:
+        """``self._iter += 1`` (condinst_head.py:1297) and the warm-up factor (:1330-1331), sync-free.
+
+        The host mirror is trusted only while nobody else wrote the buffer: any in-place write (``fill_``, ``copy_``, a DDP
+        buffer broadcast, ``load_state_dict``) bumps the tensor's version counter, a replaced buffer (``.to()``) changes its
+        storage -- either is noticed here without a synchronisation, and the value is re-read once."""
+        seen = (self._iter._version, self._iter.data_ptr())
+        if self._iter_host is None or getattr(self, '_iter_seen', None) != seen:
             self._iter_host = float(self._iter.item())
         self._iter += 1
         self._iter_host += 1.0
+        self._iter_seen = (self._iter._version, self._iter.data_ptr())
         return min(self._iter_host / float(self._warmup_iters), 1.0)
 
     # ---- the producer of mask_logits (SURVEY 8(f-2)) -------------------------------------------------------

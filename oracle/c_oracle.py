@@ -204,3 +204,22 @@ def boxinst_path(imgs: np.ndarray, img_hw: np.ndarray, rows_removed: np.ndarray,
                                C.c_float(g_pw), _p(losses), _p(g), _p(sim), _p(bm))
     return dict(loss_prj=float(losses[0]), loss_pairwise=float(losses[1]), grad=g, sim=sim,
                 bitmask=None if bm is None else bm[:G])
+
+
+def boxinst_path_f64(imgs, img_hw, rows_removed, mean, std, to_rgb, boxes, gt_count, gt_inds, logits, stride=4, size=3, dil=2,
+                     color_thresh=0.3, warmup=1.0, g_prj=1.0, g_pw=1.0):
+    """The fp64 oracle of the whole path (SURVEY 8(d) parity gate): the targets are what the reference computes them in
+    (uint8 / f32: de-normalise, pool, Lab, similarity -- condinst_head.py:1345-1448 -- those types are part of its
+    semantics), the loss and its gradient in float64 on the f32 logits (condinst_head.py:1297-1337 with
+    compute_pairwise_term substituted for the CUDA op, which the f64 kernels of pairwise.cu equal bit for bit).
+    -> dict(loss_prj, loss_pairwise, grad [N,h,w] f64, sim, bitmask)."""
+    t = boxinst_path(imgs, img_hw, rows_removed, mean, std, to_rgb, boxes, gt_count, gt_inds, logits, stride=stride, size=size,
+                     dil=dil, color_thresh=color_thresh, want_grad=False, want_targets=True)
+    gt_inds = np.asarray(gt_inds, np.int64).reshape(-1)
+    gt_count = np.asarray(gt_count, np.int64).reshape(-1)
+    img_of_gt = np.repeat(np.arange(len(gt_count)), gt_count)
+    sim = t['sim'][img_of_gt[gt_inds]].astype(np.float64)              # [N,K,h,w], :1316-1317
+    bm = t['bitmask'][gt_inds].astype(np.float64)
+    (lp, lw), g = boxinst_loss(np.asarray(logits, np.float64), sim, bm, size=size, dil=dil, color_thresh=color_thresh,
+                               warmup=warmup, g_prj=g_prj, g_pw=g_pw)
+    return dict(loss_prj=lp, loss_pairwise=lw, grad=g, sim=t['sim'], bitmask=t['bitmask'])

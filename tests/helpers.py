@@ -23,6 +23,17 @@ def oracle_path(d, warmup=1.0, g_prj=1.0, g_pw=1.0, bottom_pixels_removed=10, si
                                  want_targets=want_targets)
 
 
+def oracle_path_f64(d, warmup=1.0, g_prj=1.0, g_pw=1.0, bottom_pixels_removed=10, size=3, dil=2, thresh=0.3):
+    hw = np.array([[m['img_shape'][0], m['img_shape'][1]] for m in d['img_metas']], np.int32).reshape(-1, 2)
+    rr = np.array([rows_removed(bottom_pixels_removed, m['img_shape'], m['ori_shape']) for m in d['img_metas']], np.int32)
+    boxes = np.concatenate(d['gt_bboxes'], axis=0)
+    cfg = d['img_metas'][0]['img_norm_cfg']
+    return c_oracle.boxinst_path_f64(d['imgs'], hw, rr, cfg['mean'], cfg['std'], cfg['to_rgb'], boxes,
+                                     np.array([len(b) for b in d['gt_bboxes']], np.int32), d['gt_inds'], d['mask_logits'][:, 0],
+                                     stride=d['stride'], size=size, dil=dil, color_thresh=thresh, warmup=warmup, g_prj=g_prj,
+                                     g_pw=g_pw)
+
+
 def to_dev(d, dev):
     return dict(imgs=torch.from_numpy(d['imgs']).to(dev),
                 logits=torch.from_numpy(d['mask_logits']).to(dev),

@@ -69,18 +69,40 @@ def test_two_ranks_single_allreduce_logging():
     assert lv0 == lv1
 
 
+def _mismatch_worker(rank, world, port, same_count, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from boxinstseg_amd import dist as bdist
+    bdist.init_distributed('gloo')
+    losses = {'loss_prj': torch.tensor(1.0 + rank), 'loss_pairwise': torch.tensor(2.0)}
+    if rank == 1:
+        if same_count:
+            losses = {'loss_prj': losses['loss_prj'], 'loss_other': losses['loss_pairwise']}     # same count, other names
+        else:
+            losses['loss_extra'] = torch.tensor(0.0)
+    try:
+        bdist.parse_losses(losses)
+        q.put((rank, 'no error'))
+    except AssertionError as e:
+        q.put((rank, 'assert: ' + str(e)[:60]))
+    dist.barrier()                               # nobody hangs: the guard has a fixed size on every rank
+    dist.destroy_process_group()
+
+
 @pytest.mark.timeout(300)
-def test_two_ranks_key_count_mismatch_is_detected():
-    """base.py:201-210 asserts equal key counts to avoid a hang; here the count rides in the same all-reduce
-    and poisons the logged values instead of hanging (ranks stack different lengths -> detect by length)."""
+@pytest.mark.parametrize('same_count', [False, True])
+def test_two_ranks_key_mismatch_raises_on_every_rank(same_count):
+    """base.py:201-210: ranks that log different keys must fail loudly BEFORE a collective of differing size is issued
+    (NCCL / RCCL would hang or reduce garbage; only gloo rejects it by itself)."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, True, q)) for r in range(2)]
+    procs = [ctx.Process(target=_mismatch_worker, args=(r, 2, port, same_count, q)) for r in range(2)]
     for p in procs:
         p.start()
+    out = dict(q.get(timeout=120) for _ in procs)
     for p in procs:
-        p.join(120)
-    # gloo refuses an all_reduce of different lengths: both ranks must fail fast, not hang
-    assert all(p.exitcode is not None for p in procs)
-    assert any(p.exitcode != 0 for p in procs)
+        p.join(60)
+        assert p.exitcode == 0
+    assert out[0].startswith('assert') and out[1].startswith('assert'), out

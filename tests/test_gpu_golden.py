@@ -58,3 +58,34 @@ def test_loss_vs_reference(dev, name):
     sims, bms, _ = head.get_targets(boxes, None, imgs, metas)
     assert np.abs(np.stack([s[0].cpu().numpy() for s in sims]) - g['sim']).max() <= 2e-6
     assert np.array_equal(torch.cat(bms).cpu().numpy(), g['bitmask'])
+
+
+def test_lab_kernels_match_real_scikit_image(dev):
+    """Both Lab producers on the GPU -- pool_rgb (get_targets API) and the pool blocks of prep_kernel (the evaluation) -- against
+    skimage.color.rgb2lab itself (scikit-image 0.18.3; tests/golden/lab_skimage.npz, made by make_lab_golden.py in the build
+    container): 65 536 colours as a 1024x1024 image of constant 4x4 blocks, so that every pooled pixel is one fixture colour."""
+    import os
+    from boxinstseg_amd import boxinst_mask_loss, color_affinity, functional as Fh
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'lab_skimage.npz'))
+    rgb, want = g['rgb'][:65536], g['lab'][:65536]
+    small = rgb.reshape(256, 256, 3).transpose(2, 0, 1).astype(np.float32)                  # [3,256,256]
+    img = torch.from_numpy(np.repeat(np.repeat(small, 4, axis=1), 4, axis=2)[None]).to(dev)  # [1,3,1024,1024], integer valued
+    cfg = dict(mean=np.zeros(3, np.float32), std=np.ones(3, np.float32), to_rgb=True)
+    metas = [dict(img_shape=(1024, 1024, 3), ori_shape=(1024, 1024, 3), img_norm_cfg=cfg)]
+    want_planes = want.reshape(256, 256, 3).transpose(2, 0, 1)
+
+    def check(lab, what):
+        bad = lab != want_planes
+        assert bad.sum() <= 2, f'{what}: {int(bad.sum())} of {lab.size} Lab values differ from scikit-image'
+        if bad.any():
+            assert np.abs(lab.view(np.int32).astype(np.int64) - want_planes.view(np.int32).astype(np.int64)).max() <= 1
+
+    _, _, lab = color_affinity(img, metas, want_similarity=False, want_bits=False, bottom_pixels_removed=0)
+    check(lab.cpu().numpy()[0], 'pool_rgb kernel')
+    Fh.DEBUG_KEEP_LAST = True
+    x = torch.zeros((1, 1, 256, 256), device=dev, requires_grad=True)
+    boxinst_mask_loss(x, torch.zeros(1, dtype=torch.long, device=dev), [torch.tensor([[100., 100., 400., 300.]], device=dev)],
+                      imgs=img, img_metas=metas, bottom_pixels_removed=0)
+    torch.cuda.synchronize()
+    ws = Fh._LAST['plan'].ws
+    check(ws[:3 * 256 * 256 * 4].view(torch.float32).view(3, 256, 256).cpu().numpy(), 'prep_kernel pool blocks')

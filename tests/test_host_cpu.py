@@ -6,6 +6,7 @@
   config loading, and the loud failure on CPU tensors (there is no fallback)."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -210,3 +211,78 @@ def test_rows_removed_matches_reference_arithmetic():
     assert rows_removed(10, (800, 1024, 3), (800, 1024, 3)) == 10
     assert rows_removed(10, (800, 1199, 3), (427, 640, 3)) == int(10 * float(800) / float(427)) == 18
     assert rows_removed(0, (64, 64, 3), (64, 64, 3)) == 0
+
+
+def test_registers_into_mmdet_when_mmdet_is_importable():
+    """The real drop-in path: with mmdet importable, CondInstMaskHead / the Box2Mask losses are registered INTO
+    mmdet.models.builder.HEADS / LOSSES with force=True, replacing the stock classes of the same name
+    (mmdet/models/builder.py:7-15, mmcv Registry semantics).  mmdet / mmcv cannot be installed here, so a stand-in
+    `mmdet.models.builder` with an mmcv-style Registry is injected into sys.modules of a fresh interpreter."""
+    import subprocess
+    import textwrap
+    code = textwrap.dedent('''
+        import sys, types
+        class Registry:                                   # mmcv.utils.Registry: the surface mmdet's builder uses
+            def __init__(self, name): self.name, self._module_dict = name, {}
+            @property
+            def module_dict(self): return self._module_dict
+            def get(self, key): return self._module_dict.get(key)
+            def _register(self, cls, name=None, force=False):
+                key = name or cls.__name__
+                if not force and key in self._module_dict:
+                    raise KeyError(f"{key} is already registered in {self.name}")
+                self._module_dict[key] = cls
+            def register_module(self, name=None, force=False, module=None):
+                if module is not None:
+                    self._register(module, name, force); return module
+                def deco(cls):
+                    self._register(cls, name, force); return cls
+                return deco
+            def build(self, cfg, default_args=None):
+                args = dict(cfg); cls = self.get(args.pop("type"))
+                for k, v in (default_args or {}).items(): args.setdefault(k, v)
+                return cls(**args)
+        builder = types.ModuleType("mmdet.models.builder")
+        builder.HEADS, builder.LOSSES = Registry("models"), Registry("models")
+        class StockHead: pass
+        class StockLoss: pass
+        builder.HEADS.register_module(name="CondInstMaskHead", module=StockHead)          # the reference's own classes
+        builder.LOSSES.register_module(name="BoxProjectionLoss", module=StockLoss)
+        for name in ("mmdet", "mmdet.models"):
+            sys.modules[name] = types.ModuleType(name)
+        sys.modules["mmdet.models.builder"] = builder
+        sys.path.insert(0, %r)
+        import boxinstseg_amd
+        from boxinstseg_amd import registry
+        assert isinstance(registry.HEADS, registry._MMDetHeads) and isinstance(registry.LOSSES, registry._MMDetHeads)
+        assert builder.HEADS.get("CondInstMaskHead") is boxinstseg_amd.CondInstMaskHead, builder.HEADS.module_dict
+        from boxinstseg_amd import levelset
+        assert builder.LOSSES.get("BoxProjectionLoss") is levelset.BoxProjectionLoss
+        assert builder.LOSSES.get("LevelsetLoss") is levelset.LevelsetLoss
+        head = builder.HEADS.build(dict(type="CondInstMaskHead", in_channels=16, boxinst_enabled=True, topk_per_img=64,
+                                        max_proposals=-1))               # what CondInst.__init__ does via build_head
+        assert type(head) is boxinstseg_amd.CondInstMaskHead and head.param_conv.weight.shape == (233, 256, 3, 3)
+        assert type(registry.build_loss(dict(type="BoxProjectionLoss", loss_weight=2.0))) is levelset.BoxProjectionLoss
+        print("ok")
+    ''') % ROOT
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]
+
+
+def test_rgb2lab_oracle_matches_real_scikit_image():
+    """tests/golden/lab_skimage.npz holds skimage.color.rgb2lab (scikit-image 0.18.3, run in the build container by
+    tests/golden/make_lab_golden.py) of 65 536 random colours + the grey axis + primaries, cast to f32 as the reference does
+    (condinst_head.py:1413-1416).  The exhaustive tally over all 2^24 colours is in lab_skimage_exhaustive.json: 9 differ,
+    by one f32 ulp each (the last double bit of skimage's BLAS matrix product in rgb2xyz)."""
+    import json
+    from oracle import c_oracle
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'lab_skimage.npz'))
+    rgb, want = g['rgb'], g['lab']
+    got = c_oracle.rgb2lab_u8(np.ascontiguousarray(rgb.T).reshape(3, -1, 1))[:, :, 0].T
+    bad = (got != want).any(axis=1)
+    assert bad.sum() <= 2, f'{int(bad.sum())} of {len(rgb)} colours differ from scikit-image'
+    if bad.any():
+        ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1
+    tally = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'lab_skimage_exhaustive.json')))
+    assert tally['inputs'] == 1 << 24 and tally['f32_mismatches'] <= 16 and tally['max_ulp'] <= 1
