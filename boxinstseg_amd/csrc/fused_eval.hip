@@ -1012,9 +1012,10 @@ __global__ void zero_losses2_kernel(float* losses) { losses[0] = 0.f; losses[1] 
 size_t eval_ws_bytes(int N, int h, int w) { return carve_eval(nullptr, N, h, w, nullptr); }
 
 static int tile_rows_for(int N, int h, int w, int dil) {
-    // 4-row tiles double the number of waves (more SIMDs busy) at 1.2x the pair evaluations; they pay while the work
-    // list is short enough that every tile wave still has a SIMD to itself.
-    return eval_cap(N, h, w, dil, 8) <= 6000 ? 4 : 8;
+    (void)N; (void)h; (void)w; (void)dil;
+    // 8-row tiles: 38 pair evaluations per lane for 8 rows.  4-row tiles (BXI_TILE_ROWS=4) double the number of tile waves at
+    // 1.2x the pair evaluations; measured slower at 32 and at 64 instances (the leaders then queue behind the tile waves).
+    return 8;
 }
 int eval_tile_rows(int N, int h, int w, int dil) { return tile_rows_for(N, h, w, dil); }
 

@@ -159,7 +159,8 @@ class CondInstMaskHead(nn.Module):
         ``randperm`` of that count, not a random subset).  ``topk_per_img``: per image, every ground-truth box keeps its
         ``max(int(topk_per_img / boxes_in_image), 1)`` best locations by ``sigmoid(cls).max * sigmoid(centerness)``;
         output order = image, then box index, then (boxes over the quota) descending score / (others) location order --
-        the reference's nested Python loops, here as sorts with no host synchronisation per box.
+        the reference's nested Python loops, here as fixed-shape sorts / scatter-adds: two host synchronisations in all (the
+        positive mask and the final selection have data-dependent lengths, as in the reference), none per image or per box.
         Returns ``(param_preds [N,P], coors, level_inds, img_inds, gt_inds)``."""
         def flat(ts):
             return torch.cat([t.permute(0, 2, 3, 1).flatten(end_dim=2) for t in ts], dim=0)
@@ -172,7 +173,7 @@ class CondInstMaskHead(nn.Module):
             keep = torch.randperm(min(self.max_proposals, n), device=params.device)
         elif self.topk_per_img != -1:
             score = flat(cls_scores)[pos].sigmoid().max(dim=1)[0] * flat(centernesses).reshape(-1)[pos].sigmoid()
-            keep = _topk_per_box(img_inds, gt_inds, score, self.topk_per_img)
+            keep = _topk_per_box(img_inds, gt_inds, score, self.topk_per_img, int(cls_scores[0].size(0)))
         else:       # the reference leaves `sampled_inds` unbound here (an exception); keep every positive instead
             keep = torch.arange(n, device=params.device)
         return params[keep], coors[keep], level_inds[keep], img_inds[keep], gt_inds[keep]
@@ -284,27 +285,38 @@ class CondInstMaskHead(nn.Module):
         return _dice(mask_logits.sigmoid(), bm).mean()
 
 
-def _topk_per_box(img_inds: torch.Tensor, gt_inds: torch.Tensor, score: torch.Tensor, topk_per_img: int) -> torch.Tensor:
-    """Indices kept by the ``topk_per_img`` rule of ``training_sample`` (condinst_head.py:1201-1225), in its order."""
+def _topk_per_box(img_inds: torch.Tensor, gt_inds: torch.Tensor, score: torch.Tensor, topk_per_img: int,
+                  num_imgs: int) -> torch.Tensor:
+    """Indices kept by the ``topk_per_img`` rule of ``training_sample`` (condinst_head.py:1201-1225), in its order.
+
+    Fixed-shape tensor ops only (sorts, cumulative sums, scatter-adds over ``n`` or ``num_imgs`` slots): the one host
+    synchronisation is the final boolean selection, whose length is data dependent (as the reference's output is)."""
     n = score.numel()
+    dev = score.device
     if n == 0:
-        return torch.zeros(0, dtype=torch.long, device=score.device)
-    key = img_inds.long() * (int(gt_inds.max()) + 1) + gt_inds.long()          # (image, box), ascending like the loops
-    groups, inv = torch.unique(key, return_inverse=True)
-    size = torch.bincount(inv, minlength=groups.numel())
-    g_img = groups // (int(gt_inds.max()) + 1)
-    boxes_in_img = torch.bincount(g_img)                                        # distinct boxes with a positive, per image
-    quota = torch.clamp(torch.div(topk_per_img, boxes_in_img[g_img], rounding_mode='floor'), min=1)
-    over = (size > quota)[inv]
+        return torch.zeros(0, dtype=torch.long, device=dev)
+    ar = torch.arange(n, device=dev)
+    key = img_inds.long() * (1 << 32) + gt_inds.long()                        # (image, box), ascending like the loops
+    by_key = torch.argsort(key, stable=True)                                   # location order inside a group
+    skey = key[by_key]
+    first = torch.ones(n, dtype=torch.bool, device=dev)
+    first[1:] = skey[1:] != skey[:-1]
+    seg = torch.cumsum(first.long(), 0) - 1                                    # group id of every sorted element, 0..n-1
+    size = torch.zeros(n, dtype=torch.long, device=dev).scatter_add_(0, seg, torch.ones_like(seg))
+    # distinct boxes with a positive, per image -> quota of each group
+    boxes_in_img = torch.zeros(num_imgs, dtype=torch.long, device=dev).scatter_add_(
+        0, img_inds.long()[by_key], first.long())
+    quota = torch.clamp(torch.div(topk_per_img, boxes_in_img[img_inds.long()[by_key]], rounding_mode='floor'), min=1)
+    over = size[seg] > quota
     # inside a group: descending score if it is over its quota, location order otherwise
-    by_score = torch.empty_like(inv)
-    by_score[torch.argsort(score, descending=True, stable=True)] = torch.arange(n, device=score.device)
-    second = torch.where(over, by_score, torch.arange(n, device=score.device))
-    order = torch.argsort(second, stable=True)
-    order = order[torch.argsort(inv[order], stable=True)]
-    start = torch.cumsum(size, 0) - size
-    rank = torch.arange(n, device=score.device) - start[inv[order]]
-    return order[rank < quota[inv[order]]]
+    by_score = torch.empty(n, dtype=torch.long, device=dev)
+    by_score[torch.argsort(score, descending=True, stable=True)] = ar
+    second = torch.where(over, by_score[by_key], by_key)
+    inner = torch.argsort(second, stable=True)
+    order = inner[torch.argsort(seg[inner], stable=True)]                      # positions in the key-sorted list
+    start = torch.cumsum(size, 0) - size                                       # first position of group g (groups are contiguous)
+    rank = ar - start[seg[order]]
+    return by_key[order][rank < quota[order]]
 
 
 def _dice(x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:

@@ -139,7 +139,7 @@ def test_topk_per_box_against_loops(seed):
             if len(idx) > quota:
                 idx = idx[np.argsort(-score[idx], kind='stable')[:quota]]
             want.extend(idx.tolist())
-    got = _topk_per_box(torch.from_numpy(img), torch.from_numpy(gt), torch.from_numpy(score), topk).tolist()
+    got = _topk_per_box(torch.from_numpy(img), torch.from_numpy(gt), torch.from_numpy(score), topk, B).tolist()
     assert got == want
 
 
