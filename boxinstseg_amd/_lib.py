@@ -94,13 +94,15 @@ SIGNATURES = {
     'bxi_lcm_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'bxi_lcm_refine_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),
-    'bxi_mst_workspace_bytes': (c_size_t, [c_int]),
+    'bxi_mst_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'bxi_mst_forward_i32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
-    'bxi_bfs_forward_i32': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'bxi_bfs_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'bxi_bfs_forward_i32': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'bxi_tree_refine_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'bxi_tree_refine_forward_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
-                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'bxi_tree_refine_backward_feature_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                                     c_int, c_void_p, c_void_p]),
+                                                     c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'bxi_tree_refine_backward_weight_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'bxi_tree_refine_backward_weight_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

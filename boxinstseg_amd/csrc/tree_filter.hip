@@ -504,22 +504,41 @@ __global__ __launch_bounds__(256) void tree_grad_weight_kernel(const float* __re
 
 static size_t refine_lds_bytes(int V) { return 16 * (size_t)(V + kRecPad); }
 
+// tree_filter_large.hip: the same algorithms with their arrays in a global workspace (V > kTfMaxV)
+size_t mst_large_ws_bytes(int E, int V);
+size_t bfs_large_ws_bytes(int V);
+size_t refine_large_ws_bytes(int B, int C, int V);
+int launch_mst_large(const int* edge_index, const float* edge_weight, int B, int E, int V, int* edge_out, int* n_out, char* ws, hipStream_t s);
+int launch_bfs_large(const int* tree, int B, int V, int max_adj, int* si, int* sp, int* sc, int* levels, char* ws, hipStream_t s);
+int launch_refine_large(const void* planes2, const float* edge_weight, const int* sorted_index, const int* sorted_child, const int* levels,
+                        float* out_vertex, int B, int C, int V, int max_adj, int n_planes, char* ws, hipStream_t s);
+static bool tf_fits_lds(int V) { return V <= kTfMaxV; }
+constexpr int kTfMaxVLarge = 1 << 24;
+
 }  // namespace bxi
 
 extern "C" {
 
-size_t bxi_mst_workspace_bytes(int B) { return sizeof(int) * (size_t)(B > 0 ? B : 1); }
+size_t bxi_mst_workspace_bytes(int B, int E, int V) {
+    if (B < 0 || E <= 0 || V <= 1) return 0;
+    const size_t head = (sizeof(int) * (size_t)(B > 0 ? B : 1) + 15) / 16 * 16;
+    return head + (bxi::tf_fits_lds(V) && E <= 8 * bxi::kTfMaxV ? 0 : bxi::mst_large_ws_bytes(E, V) * (size_t)(B > 0 ? B : 1));
+}
 
 int bxi_mst_forward_i32(const int* edge_index, const float* edge_weight, int B, int E, int V, int* edge_out, void* workspace,
                         size_t workspace_bytes, void* stream) {
     if (B < 0 || E <= 0 || V <= 1) return BXI_ERR_BAD_SHAPE;
-    if (V > bxi::kTfMaxV || E > 8 * bxi::kTfMaxV) return BXI_ERR_UNSUPPORTED;
+    if (V > bxi::kTfMaxVLarge || E > 8 * bxi::kTfMaxVLarge) return BXI_ERR_UNSUPPORTED;
     if (B == 0) return BXI_OK;
     if (!edge_index || !edge_weight || !edge_out) return BXI_ERR_NULL_POINTER;
-    if (!workspace || workspace_bytes < bxi_mst_workspace_bytes(B) || (reinterpret_cast<uintptr_t>(workspace) & 3)) return BXI_ERR_WORKSPACE;
-    const size_t lds = (size_t)V * 12 + 4 * (size_t)((E + 31) / 32) + 16;
-    if (lds > 150 * 1024) return BXI_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < bxi_mst_workspace_bytes(B, E, V) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return BXI_ERR_WORKSPACE;
     hipStream_t s = bxi::as_stream(stream);
+    const size_t lds = (size_t)V * 12 + 4 * (size_t)((E + 31) / 32) + 16;
+    if (!bxi::tf_fits_lds(V) || E > 8 * bxi::kTfMaxV || lds > 150 * 1024) {        // arrays in the workspace instead of LDS
+        if (workspace_bytes < (sizeof(int) * (size_t)B + 15) / 16 * 16 + bxi::mst_large_ws_bytes(E, V) * (size_t)B) return BXI_ERR_WORKSPACE;
+        return bxi::launch_mst_large(edge_index, edge_weight, B, E, V, edge_out, reinterpret_cast<int*>(workspace),
+                                     reinterpret_cast<char*>(workspace) + (sizeof(int) * (size_t)B + 15) / 16 * 16, s);
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bxi::mst_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { bxi::set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }
@@ -528,15 +547,25 @@ int bxi_mst_forward_i32(const int* edge_index, const float* edge_weight, int B, 
     return bxi::check_launch();
 }
 
+size_t bxi_bfs_workspace_bytes(int B, int V) {
+    if (B < 0 || V <= 1) return 0;
+    return bxi::tf_fits_lds(V) ? 0 : bxi::bfs_large_ws_bytes(V) * (size_t)(B > 0 ? B : 1);
+}
+
 int bxi_bfs_forward_i32(const int* tree_edges, int B, int V, int max_adj, int* sorted_index, int* sorted_parent, int* sorted_child,
-                        int* levels, void* stream) {
+                        int* levels, void* workspace, size_t workspace_bytes, void* stream) {
     if (B < 0 || V <= 1 || max_adj < 1) return BXI_ERR_BAD_SHAPE;
-    if (V > bxi::kTfMaxV || max_adj > 8) return BXI_ERR_UNSUPPORTED;
+    if (V > bxi::kTfMaxVLarge || max_adj > 8) return BXI_ERR_UNSUPPORTED;
     if (B == 0) return BXI_OK;
     if (!tree_edges || !sorted_index || !sorted_parent || !sorted_child || !levels) return BXI_ERR_NULL_POINTER;
+    hipStream_t s = bxi::as_stream(stream);
+    if (!bxi::tf_fits_lds(V)) {
+        if (!workspace || workspace_bytes < bxi_bfs_workspace_bytes(B, V) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return BXI_ERR_WORKSPACE;
+        return bxi::launch_bfs_large(tree_edges, B, V, max_adj, sorted_index, sorted_parent, sorted_child, levels,
+                                     reinterpret_cast<char*>(workspace), s);
+    }
     const size_t lds = (size_t)V * 8 + (size_t)(V + 1) * 4 + (size_t)((V + 3) / 4) * 4 + 16;
     if (lds > 150 * 1024) return BXI_ERR_UNSUPPORTED;
-    hipStream_t s = bxi::as_stream(stream);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bxi::bfs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { bxi::set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }
@@ -545,13 +574,24 @@ int bxi_bfs_forward_i32(const int* tree_edges, int B, int V, int max_adj, int* s
     return bxi::check_launch();
 }
 
-static int launch_refine(bxi::RefineArgs& a, void* stream) {
+size_t bxi_tree_refine_workspace_bytes(int B, int C, int V) {
+    if (B < 0 || C <= 0 || V <= 1) return 0;
+    return bxi::tf_fits_lds(V) ? 0 : bxi::refine_large_ws_bytes(B, C, V);
+}
+
+static int launch_refine(bxi::RefineArgs& a, void* workspace, size_t workspace_bytes, void* stream) {
     if (a.B < 0 || a.C <= 0 || a.V <= 1 || a.max_adj < 1) return BXI_ERR_BAD_SHAPE;
-    if (a.V > bxi::kTfMaxV || a.C > 65535) return BXI_ERR_UNSUPPORTED;
+    if (a.V > bxi::kTfMaxVLarge || a.C > 65535) return BXI_ERR_UNSUPPORTED;
     if (a.B == 0) return BXI_OK;
     if (!a.edge_weight || !a.sorted_index || !a.sorted_child || !a.levels) return BXI_ERR_NULL_POINTER;
     for (int q = 0; q < a.n_planes; ++q)
         if (q + 1 == a.n_planes && !a.pl[q].in) return BXI_ERR_NULL_POINTER;
+    if (!bxi::tf_fits_lds(a.V)) {
+        if (!workspace || workspace_bytes < bxi_tree_refine_workspace_bytes(a.B, a.C, a.V) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+            return BXI_ERR_WORKSPACE;
+        return bxi::launch_refine_large(a.pl, a.edge_weight, a.sorted_index, a.sorted_child, a.levels, a.out_vertex, a.B, a.C, a.V, a.max_adj,
+                                        a.n_planes, reinterpret_cast<char*>(workspace), bxi::as_stream(stream));
+    }
     const size_t lds = bxi::refine_lds_bytes(a.V);
     if (lds > 160 * 1024) return BXI_ERR_UNSUPPORTED;
     hipStream_t s = bxi::as_stream(stream);
@@ -565,7 +605,8 @@ static int launch_refine(bxi::RefineArgs& a, void* stream) {
 
 int bxi_tree_refine_forward_f32(const float* feature_in, const float* edge_weight, const int* sorted_index, const int* sorted_child,
                                 const int* levels, int B, int C, int V, int max_adj, float* feature_out, float* feature_aggr,
-                                float* feature_aggr_up, float* weight_sum, float* weight_sum_up, void* stream) {
+                                float* feature_aggr_up, float* weight_sum, float* weight_sum_up, void* workspace, size_t workspace_bytes,
+                                void* stream) {
     if (B > 0 && (!feature_in || !feature_out || !feature_aggr || !feature_aggr_up || !weight_sum || !weight_sum_up)) return BXI_ERR_NULL_POINTER;
     bxi::RefineArgs a{};
     a.edge_weight = edge_weight; a.sorted_index = sorted_index; a.sorted_child = sorted_child; a.levels = levels;
@@ -573,23 +614,23 @@ int bxi_tree_refine_forward_f32(const float* feature_in, const float* edge_weigh
     a.pl[1].in = feature_in; a.pl[1].up_sorted = feature_aggr_up; a.pl[1].down_vertex = feature_aggr;
     a.out_vertex = feature_out;
     a.B = B; a.C = C; a.V = V; a.max_adj = max_adj; a.n_planes = 2;
-    return launch_refine(a, stream);
+    return launch_refine(a, workspace, workspace_bytes, stream);
 }
 
 int bxi_tree_refine_backward_feature_f32(const float* grad_out, const float* edge_weight, const int* sorted_index,
                                          const int* sorted_child, const int* levels, const float* weight_sum, int B, int C, int V,
-                                         int max_adj, float* grad_feature, void* stream) {
+                                         int max_adj, float* grad_feature, void* workspace, size_t workspace_bytes, void* stream) {
     if (B > 0 && (!grad_out || !weight_sum || !grad_feature)) return BXI_ERR_NULL_POINTER;
     bxi::RefineArgs a{};
     a.edge_weight = edge_weight; a.sorted_index = sorted_index; a.sorted_child = sorted_child; a.levels = levels;
     a.pl[0].in = grad_out; a.pl[0].pre_div = weight_sum; a.pl[0].down_vertex = grad_feature;
     a.B = B; a.C = C; a.V = V; a.max_adj = max_adj; a.n_planes = 1;
-    return launch_refine(a, stream);
+    return launch_refine(a, workspace, workspace_bytes, stream);
 }
 
 size_t bxi_tree_refine_backward_weight_workspace_bytes(int B, int C, int V) {
     if (B < 0 || C <= 0 || V <= 0) return 0;
-    return sizeof(float) * 4 * (size_t)(B > 0 ? B : 1) * C * V;
+    return (sizeof(float) * 4 * (size_t)(B > 0 ? B : 1) * C * V + 15) / 16 * 16 + bxi_tree_refine_workspace_bytes(B, C, V);
 }
 
 int bxi_tree_refine_backward_weight_f32(const float* grad_out, const float* edge_weight, const int* sorted_index,
@@ -601,8 +642,9 @@ int bxi_tree_refine_backward_weight_f32(const float* grad_out, const float* edge
     if (B == 0) return BXI_OK;
     if (!grad_out || !sorted_parent || !feature_out || !feature_aggr || !feature_aggr_up || !weight_sum || !weight_sum_up || !grad_weight)
         return BXI_ERR_NULL_POINTER;
-    if (!workspace || workspace_bytes < bxi_tree_refine_backward_weight_workspace_bytes(B, C, V) || (reinterpret_cast<uintptr_t>(workspace) & 3))
+    if (!workspace || workspace_bytes < bxi_tree_refine_backward_weight_workspace_bytes(B, C, V) || (reinterpret_cast<uintptr_t>(workspace) & 15))
         return BXI_ERR_WORKSPACE;
+    char* refine_ws = reinterpret_cast<char*>(workspace) + (sizeof(float) * 4 * (size_t)B * C * V + 15) / 16 * 16;
     const size_t plane = (size_t)B * C * V;
     float* GU = reinterpret_cast<float*>(workspace); float* OG = GU + plane; float* FGU = OG + plane; float* OG2 = FGU + plane;
     bxi::RefineArgs a{};
@@ -611,7 +653,7 @@ int bxi_tree_refine_backward_weight_f32(const float* grad_out, const float* edge
     a.pl[0].in = grad_out; a.pl[0].pre_div = weight_sum; a.pl[0].up_sorted = GU; a.pl[0].down_sorted = OG; a.pl[0].down_vertex = grad_feature;
     a.pl[1].in = grad_out; a.pl[1].pre_div = weight_sum; a.pl[1].pre_mul = feature_out; a.pl[1].up_sorted = FGU; a.pl[1].down_sorted = OG2;
     a.B = B; a.C = C; a.V = V; a.max_adj = max_adj; a.n_planes = 2;
-    int rc = launch_refine(a, stream);
+    int rc = launch_refine(a, refine_ws, bxi_tree_refine_workspace_bytes(B, C, V), stream);
     if (rc != BXI_OK) return rc;
     hipStream_t s = bxi::as_stream(stream);
     const unsigned grid = (unsigned)(((int64_t)B * V + 255) / 256);

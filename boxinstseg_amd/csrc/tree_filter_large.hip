@@ -1,0 +1,378 @@
+// tree_filter_large.hip -- the tree_filter extension for graphs that do not fit LDS (V > 10200 vertices).
+//
+// BoxLevelSet filters its mask-feature maps at full resolution (box_solov2_head.py:354-358: e.g. 200 x 304 = 60 800
+// vertices); the reference's kernels have no vertex limit (mmdet/ops/tree_filter/src/{mst/boruvka.cpp:20-112,
+// bfs/bfs.cu:46-98, refine/refine.cu:70-199}).  tree_filter.hip keeps everything a traversal touches in LDS and stops at
+// 10 200 vertices; the kernels here are the same algorithms with the per-graph arrays in a caller-supplied global
+// workspace and 32-bit indices, one 1024-thread workgroup per graph (mst, bfs) or per (graph, channel) (refine):
+//   mst     parallel Boruvka: per round every edge offers (weight bits, edge index) to both components (64-bit atomic min),
+//           roots hook to their cheapest neighbour (mutual pairs keep the smaller id), pointer jumping, relabel.  Same
+//           total order (weight, index) as the LDS kernel and as the reference's strict '>' -> the same edge set.
+//   bfs     level by level with the whole workgroup: a block-wide prefix sum of the children counts places the next
+//           frontier (deterministic, children of a node contiguous, neighbours in ascending vertex order).
+//   refine  leaf->root level by level (the workgroup takes a level's nodes; children are contiguous), root->leaf by pointer
+//           jumping over affine maps exactly as in tree_filter.hip.
+// Workgroup barriers order the global traffic: a workgroup runs on one CU, whose vector L1 is write-through, and every
+// array here is private to the workgroup.
+#include "common.hpp"
+
+namespace bxi {
+
+typedef unsigned long long u64;
+constexpr int kLT = 1024;
+
+__host__ __device__ static inline size_t up16(size_t v) { return (v + 15) / 16 * 16; }
+
+// ---------------------------------------------------------------------------------------------------
+struct MstLargeWs { u64* best; uint32_t* comp; uint32_t* link; uint32_t* chosen; };
+__host__ __device__ static size_t carve_mst_large(char* base, int E, int V, MstLargeWs* w) {
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off += up16(b); return base ? base + o : nullptr; };
+    MstLargeWs t;
+    t.best = (u64*)take(8 * (size_t)V); t.comp = (uint32_t*)take(4 * (size_t)V); t.link = (uint32_t*)take(4 * (size_t)V);
+    t.chosen = (uint32_t*)take(4 * (size_t)((E + 31) / 32));
+    if (w) *w = t;
+    return off;
+}
+size_t mst_large_ws_bytes(int E, int V) { return carve_mst_large(nullptr, E, V, nullptr); }
+
+__global__ __launch_bounds__(kLT) void mst_large_kernel(const int* __restrict__ edge_index, const float* __restrict__ edge_weight, int E,
+                                                        int V, int* __restrict__ edge_out, int* __restrict__ n_out, char* ws_base,
+                                                        size_t ws_stride) {
+    __shared__ int flag, scan[17];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    MstLargeWs w;
+    carve_mst_large(ws_base + (size_t)b * ws_stride, E, V, &w);
+    u64* best = w.best; uint32_t* comp = w.comp; uint32_t* link = w.link; uint32_t* chosen = w.chosen;
+    const int* idx = edge_index + (int64_t)b * E * 2;
+    const float* wt = edge_weight + (int64_t)b * E;
+    const int nwords = (E + 31) / 32;
+    for (int v = tid; v < V; v += kLT) comp[v] = (uint32_t)v;
+    for (int i = tid; i < nwords; i += kLT) chosen[i] = 0u;
+    __syncthreads();
+    for (int round = 0; round < 40; ++round) {
+        for (int v = tid; v < V; v += kLT) best[v] = ~0ull;
+        if (tid == 0) flag = 0;
+        __syncthreads();
+        for (int e = tid; e < E; e += kLT) {
+            const uint32_t cu = comp[idx[2 * e]], cv = comp[idx[2 * e + 1]];
+            if (cu != cv) {
+                const u64 key = ((u64)__float_as_uint(wt[e]) << 32) | (uint32_t)e;   // weights are >= 0: the bits order like the values
+                atomicMin(&best[cu], key);
+                atomicMin(&best[cv], key);
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < V; c += kLT) {
+            if (comp[c] != (uint32_t)c) continue;
+            const u64 k = best[c];
+            uint32_t to = (uint32_t)c;
+            if (k != ~0ull) {
+                const uint32_t e = (uint32_t)k;
+                atomicOr(&chosen[e >> 5], 1u << (e & 31));
+                const uint32_t cu = comp[idx[2 * e]], cv = comp[idx[2 * e + 1]];
+                to = cu == (uint32_t)c ? cv : cu;
+                flag = 1;
+            }
+            link[c] = to;
+        }
+        __syncthreads();
+        if (!flag) break;
+        for (int c = tid; c < V; c += kLT) {                             // two components that chose each other: the smaller id is the root
+            if (comp[c] != (uint32_t)c) continue;
+            const uint32_t o = link[c];
+            if (o != (uint32_t)c && link[o] == (uint32_t)c && (uint32_t)c < o) link[c] = (uint32_t)c;
+        }
+        __syncthreads();
+        for (int guard = 0; guard < 40; ++guard) {                       // pointer jumping (read phase / write phase)
+            if (tid == 0) flag = 0;
+            __syncthreads();
+            int changed = 0;
+            for (int c = tid; c < V; c += kLT) {
+                if (comp[c] != (uint32_t)c) continue;
+                const uint32_t p = link[c], gp = link[p];
+                if (gp != p) { link[c] = gp; changed = 1; }              // racing with p's own update only shortens the path further
+            }
+            if (changed) flag = 1;
+            __syncthreads();
+            if (!flag) break;
+            __syncthreads();
+        }
+        for (int v = tid; v < V; v += kLT) comp[v] = link[comp[v]];
+        __syncthreads();
+    }
+    // tree edges in ascending edge order: each thread owns a contiguous run of bitmap words
+    const int per = (nwords + kLT - 1) / kLT;
+    const int w0 = min(tid * per, nwords), w1 = min(w0 + per, nwords);
+    int cnt = 0;
+    for (int i = w0; i < w1; ++i) cnt += __popc(chosen[i]);
+    const int lane = tid & 63, wave = tid >> 6;
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, kWave); if (lane >= off) incl += o; }
+    if (lane == 63) scan[wave] = incl;
+    __syncthreads();
+    if (tid == 0) { int s = 0; for (int i = 0; i < 16; ++i) { const int t = scan[i]; scan[i] = s; s += t; } scan[16] = s; }
+    __syncthreads();
+    int pos = scan[wave] + incl - cnt;
+    int* out = edge_out + (int64_t)b * (V - 1) * 2;
+    for (int i = w0; i < w1; ++i) {
+        uint32_t m = chosen[i];
+        while (m) {
+            const int e = i * 32 + __ffs((int)m) - 1;
+            m &= m - 1;
+            if (pos < V - 1) { out[2 * pos] = idx[2 * e]; out[2 * pos + 1] = idx[2 * e + 1]; }
+            ++pos;
+        }
+    }
+    if (tid == 0) n_out[b] = scan[16];
+}
+
+int launch_mst_large(const int* edge_index, const float* edge_weight, int B, int E, int V, int* edge_out, int* n_out, char* ws,
+                     hipStream_t s) {
+    BXI_LAUNCH("mst_large", s, mst_large_kernel, dim3(B), dim3(kLT), 0, s, edge_index, edge_weight, E, V, edge_out, n_out, ws,
+               mst_large_ws_bytes(E, V));
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct BfsLargeWs { uint32_t* adj; uint32_t* deg; uint32_t* nodev; uint32_t* nodep; uint32_t* pos_of; };
+__host__ __device__ static size_t carve_bfs_large(char* base, int V, BfsLargeWs* w) {
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off += up16(b); return base ? base + o : nullptr; };
+    BfsLargeWs t;
+    t.adj = (uint32_t*)take(16 * (size_t)V); t.deg = (uint32_t*)take(4 * (size_t)V); t.nodev = (uint32_t*)take(4 * (size_t)(V + 1));
+    t.nodep = (uint32_t*)take(4 * (size_t)(V + 1)); t.pos_of = (uint32_t*)take(4 * (size_t)V);
+    if (w) *w = t;
+    return off;
+}
+size_t bfs_large_ws_bytes(int V) { return carve_bfs_large(nullptr, V, nullptr); }
+
+// block-wide exclusive prefix sum of a small per-thread count (0..4); returns the total through `total`
+__device__ __forceinline__ int block_excl_scan(int v, int* part /*[17]*/, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, kWave); if (lane >= off) incl += o; }
+    __syncthreads();                                   // `part` of the previous call has been read by everyone
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < kLT / 64; ++i) { const int p = part[i]; if (i < wave) base += p; tot += p; }
+    total = tot;
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(kLT) void bfs_large_kernel(const int* __restrict__ tree, int V, int max_adj, int* __restrict__ sorted_index,
+                                                        int* __restrict__ sorted_parent, int* __restrict__ sorted_child,
+                                                        int* __restrict__ levels, char* ws_base, size_t ws_stride) {
+    __shared__ int part[17];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    BfsLargeWs w;
+    carve_bfs_large(ws_base + (size_t)b * ws_stride, V, &w);
+    const int* ed = tree + (int64_t)b * (V - 1) * 2;
+    int* s_index = sorted_index + (int64_t)b * V;
+    int* s_parent = sorted_parent + (int64_t)b * V;
+    int* s_child = sorted_child + (int64_t)b * V * max_adj;
+    int* lv = levels + (int64_t)b * (V + 2);
+    for (int i = tid; i < V; i += kLT) w.deg[i] = 0u;
+    for (int i = tid; i < V * max_adj; i += kLT) s_child[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < V - 1; e += kLT) {            // adjacency (a vertex of a grid tree has at most 4 neighbours)
+        const int u = ed[2 * e], v = ed[2 * e + 1];
+        const unsigned su = atomicAdd(&w.deg[u], 1u), sv = atomicAdd(&w.deg[v], 1u);
+        if (su < 4) w.adj[4 * (size_t)u + su] = (uint32_t)v;
+        if (sv < 4) w.adj[4 * (size_t)v + sv] = (uint32_t)u;
+    }
+    __syncthreads();
+    for (int v = tid; v < V; v += kLT) {                // arrival order of the atomics -> ascending neighbour ids
+        const int d = min((int)w.deg[v], 4);
+        uint32_t a[4];
+        for (int k = 0; k < 4; ++k) a[k] = k < d ? w.adj[4 * (size_t)v + k] : 0xffffffffu;
+        for (int i = 1; i < 4; ++i) for (int j = i; j > 0 && a[j - 1] > a[j]; --j) { const uint32_t t = a[j]; a[j] = a[j - 1]; a[j - 1] = t; }
+        for (int k = 0; k < 4; ++k) w.adj[4 * (size_t)v + k] = a[k];
+    }
+    if (tid == 0) { w.nodev[0] = 0u; w.nodep[0] = 0xffffffffu; lv[1] = 0; }
+    __syncthreads();
+    int lo = 0, hi = 1, n = 1, depth = 0;
+    while (lo < hi) {                                   // workgroup-uniform
+        for (int base = lo; base < hi; base += kLT) {
+            const int i = base + tid;
+            const bool act = i < hi;
+            const uint32_t cur = act ? w.nodev[i] : 0u, par = act ? w.nodep[i] : 0u;
+            uint32_t nb[4]; int rank[4]; bool ok[4];
+            int nch = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                nb[k] = act ? w.adj[4 * (size_t)cur + k] : 0xffffffffu;
+                ok[k] = act && nb[k] != 0xffffffffu && nb[k] != par;
+                rank[k] = nch;
+                nch += ok[k] ? 1 : 0;
+            }
+            int total;
+            const int pos = n + block_excl_scan(nch, part, total);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ok[k]) { w.nodev[pos + rank[k]] = nb[k]; w.nodep[pos + rank[k]] = cur; }
+            n += total;
+        }
+        ++depth;
+        if (tid == 0) lv[1 + depth] = hi;               // off[depth] = end of this level
+        __syncthreads();                                // the next level's nodes are written
+        lo = hi; hi = n;
+    }
+    if (tid == 0) lv[0] = depth;
+    const int nf = n;                                   // < V only for a disconnected input
+    for (int p = tid; p < V; p += kLT) {
+        const uint32_t v = p < nf ? w.nodev[p] : 0u;
+        s_index[p] = (int)v;
+        if (p < nf) w.pos_of[v] = (uint32_t)p;
+    }
+    __syncthreads();
+    for (int p = tid; p < V; p += kLT) {
+        if (p == 0 || p >= nf) { s_parent[p] = 0; continue; }
+        const uint32_t pv = w.nodep[p];
+        const int pp = (int)w.pos_of[pv];
+        s_parent[p] = pp;
+        int k = 0;                                      // rank among the (contiguous) siblings
+        while (k < 3 && p - k - 1 >= 1 && w.nodep[p - k - 1] == pv) ++k;
+        if (k < max_adj) s_child[(size_t)pp * max_adj + k] = p;
+    }
+}
+
+int launch_bfs_large(const int* tree, int B, int V, int max_adj, int* si, int* sp, int* sc, int* levels, char* ws, hipStream_t s) {
+    BXI_LAUNCH("bfs_large", s, bfs_large_kernel, dim3(B), dim3(kLT), 0, s, tree, V, max_adj, si, sp, sc, levels, ws, bfs_large_ws_bytes(V));
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// refine: records {v0, v1, w, first child | count << 28} in global memory, parent in a second array
+struct RefinePlaneL { const float* in; const float* pre_div; const float* pre_mul; float* up_sorted; float* down_sorted; float* down_vertex; };
+struct RefineArgsL {
+    RefinePlaneL pl[2];
+    const float* edge_weight; const int* sorted_index; const int* sorted_child; const int* levels;
+    float* out_vertex;
+    int B, C, V, max_adj, n_planes;
+    char* ws; size_t ws_stride;
+};
+constexpr int kPadL = 4;
+static size_t refine_large_block_bytes(int V) { return up16(16 * (size_t)(V + kPadL)) + up16(4 * (size_t)V) + up16(16 * (size_t)(V + kPadL)); }
+size_t refine_large_ws_bytes(int B, int C, int V) { return refine_large_block_bytes(V) * (size_t)(B > 0 ? B : 1) * (size_t)C; }
+
+__global__ __launch_bounds__(kLT) void tree_refine_large_kernel(RefineArgsL a) {
+    const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, V = a.V;
+    char* wsb = a.ws + ((size_t)b * a.C + ch) * a.ws_stride;
+    float4* rec = reinterpret_cast<float4*>(wsb);
+    uint32_t* parent = reinterpret_cast<uint32_t*>(wsb + up16(16 * (size_t)(V + kPadL)));
+    float4* tmp = reinterpret_cast<float4*>(wsb + up16(16 * (size_t)(V + kPadL)) + up16(4 * (size_t)V));   // double buffer of the jump rounds
+    const int* lv = a.levels + (int64_t)b * (V + 2);
+    const int* si = a.sorted_index + (int64_t)b * V;
+    const int* sc = a.sorted_child + (int64_t)b * V * a.max_adj;
+    const float* ew = a.edge_weight + (int64_t)b * V;
+    const int64_t cb = ((int64_t)b * a.C + ch) * V;
+    const RefinePlaneL pl0 = a.pl[0], pl1 = a.pl[1];
+    const bool two = a.n_planes > 1;
+    int bad = 0;
+    for (int i = tid; i < V + kPadL; i += kLT) {
+        if (i >= V) { rec[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+        const int p = si[i];
+        float v0 = pl0.in ? pl0.in[cb + p] : 1.f;
+        if (pl0.in && pl0.pre_div) v0 /= pl0.pre_div[(int64_t)b * V + p];
+        if (pl0.in && pl0.pre_mul) v0 *= pl0.pre_mul[cb + p];
+        float v1 = (two && pl1.in) ? pl1.in[cb + p] : (two ? 1.f : 0.f);
+        if (two && pl1.in && pl1.pre_div) v1 /= pl1.pre_div[(int64_t)b * V + p];
+        if (two && pl1.in && pl1.pre_mul) v1 *= pl1.pre_mul[cb + p];
+        int c0 = 0, nc = 0;
+        bool open = true;                                            // children = the leading positive slots
+        for (int k = 0; k < 4; ++k) {
+            const int c = sc[(size_t)i * a.max_adj + min(k, a.max_adj - 1)];
+            open = open && k < a.max_adj && c > 0;
+            if (open) {
+                if (nc == 0) c0 = c; else if (c != c0 + nc) bad = 1;  // children must be contiguous (bxi_bfs_forward_i32 order)
+                ++nc;
+            }
+        }
+        if (a.max_adj > 4 && sc[(size_t)i * a.max_adj + 4] > 0) bad = 1;
+        if (c0 + nc > V) { bad = 1; nc = 0; }
+        rec[i] = make_float4(v0, v1, i ? ew[i] : 0.f /* weight[0] = 0 (refine.cu:38) */, __uint_as_float((uint32_t)c0 | ((uint32_t)nc << 28)));
+        if (i == 0) parent[0] = 0u;
+    }
+    const float poison = __syncthreads_or(bad) ? __builtin_nanf("") : 1.f;   // a foreign ordering fails loudly in the values
+    for (int i = tid; i < V; i += kLT) {
+        const uint32_t f = __float_as_uint(rec[i].w);
+        const int c0 = f & 0x0fffffffu, nc = f >> 28;
+        for (int k = 0; k < nc; ++k) parent[c0 + k] = (uint32_t)i;           // one writer per child
+    }
+    if (tid == 0) { float4 r = rec[0]; r.x *= poison; r.y *= poison; rec[0] = r; }
+    __syncthreads();
+    // ---- leaf->root, level by level: U_i = x_i + sum_c w_c U_c (refine.cu:64-121) ------------------------------------------
+    const int D = lv[0];
+    for (int l = D - 1; l >= 0; --l) {
+        const int lo = lv[1 + l], hi = lv[2 + l];
+        for (int i = lo + tid; i < hi; i += kLT) {
+            float4 r = rec[i];
+            const uint32_t f = __float_as_uint(r.w);
+            const int c0 = f & 0x0fffffffu, nc = f >> 28;
+            for (int k = 0; k < nc; ++k) { const float4 c = rec[c0 + k]; r.x += c.x * c.z; r.y += c.y * c.z; }
+            rec[i] = r;
+        }
+        __syncthreads();
+    }
+    for (int q = 0; q < 2; ++q) {                                     // U of both planes (sorted order)
+        const RefinePlaneL& pl = q ? pl1 : pl0;
+        const bool per_tree = pl.in == nullptr;
+        if (q >= a.n_planes || !pl.up_sorted || (per_tree && ch != 0)) continue;
+        float* uo = pl.up_sorted + (per_tree ? (int64_t)b * V : cb);
+        for (int i = tid; i < V; i += kLT) { const float4 r = rec[i]; uo[i] = q ? r.y : r.x; }
+    }
+    // ---- root->leaf by pointer jumping over affine maps: D_c = A_c + B_c D_anc(c), A = U (1 - w^2), B = w (refine.cu:17-62) ----
+    for (int i = tid; i < V; i += kLT) {
+        const float4 r = rec[i];
+        const float w = r.z, aa = 1.f - w * w;
+        rec[i] = i ? make_float4(r.x * aa, r.y * aa, w, __uint_as_float(parent[i])) : make_float4(r.x, r.y, 0.f, __uint_as_float(0xffffffffu));
+    }
+    __syncthreads();
+    const int rounds = D > 1 ? 32 - __clz(D - 1) : 0;
+    float4* src = rec; float4* dst = tmp;
+    for (int k = 0; k < rounds; ++k) {
+        for (int i = tid; i < V; i += kLT) {
+            const float4 r = src[i];
+            const uint32_t an = __float_as_uint(r.w);
+            if (an == 0xffffffffu) { dst[i] = r; continue; }
+            const float4 q = src[an];
+            dst[i] = make_float4(r.x + r.z * q.x, r.y + r.z * q.y, r.z * q.z, q.w);
+        }
+        __syncthreads();
+        float4* t = src; src = dst; dst = t;
+    }
+    for (int i = tid; i < V; i += kLT) {
+        const float4 d = src[i];
+        const int p = si[i];
+        for (int q = 0; q < 2; ++q) {
+            const RefinePlaneL& pl = q ? pl1 : pl0;
+            if (q >= a.n_planes) continue;
+            const bool per_tree = pl.in == nullptr;
+            if (per_tree && ch != 0) continue;
+            const int64_t ob = per_tree ? (int64_t)b * V : cb;
+            if (pl.down_sorted) pl.down_sorted[ob + i] = q ? d.y : d.x;
+            if (pl.down_vertex) pl.down_vertex[ob + p] = q ? d.y : d.x;
+        }
+        if (a.out_vertex) a.out_vertex[cb + p] = d.y / d.x;
+    }
+}
+
+int launch_refine_large(const void* planes2 /* RefinePlaneL[2] layout */, const float* edge_weight, const int* sorted_index,
+                        const int* sorted_child, const int* levels, float* out_vertex, int B, int C, int V, int max_adj, int n_planes,
+                        char* ws, hipStream_t s) {
+    RefineArgsL a;
+    const RefinePlaneL* p = reinterpret_cast<const RefinePlaneL*>(planes2);
+    a.pl[0] = p[0]; a.pl[1] = p[1];
+    a.edge_weight = edge_weight; a.sorted_index = sorted_index; a.sorted_child = sorted_child; a.levels = levels;
+    a.out_vertex = out_vertex; a.B = B; a.C = C; a.V = V; a.max_adj = max_adj; a.n_planes = n_planes;
+    a.ws = ws; a.ws_stride = refine_large_block_bytes(V);
+    BXI_LAUNCH("tree_refine_large", s, tree_refine_large_kernel, dim3(B, C), dim3(kLT), 0, s, a);
+    return check_launch();
+}
+
+}  // namespace bxi

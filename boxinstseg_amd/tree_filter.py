@@ -2,7 +2,8 @@
 ``mst`` / ``bfs`` / ``refine`` (``mmdet/ops/tree_filter/functions/*.py`` over ``tree_filter_cuda``) and the modules
 ``MinimumSpanningTree`` / ``TreeFilter2D`` (``mmdet/ops/tree_filter/modules/tree_filter.py:10-150``).
 Same names, argument order and return values; the glue between the native calls is torch on the GPU, as in the
-reference.  No CPU path.  Graphs of at most 10200 vertices (the reference filters 96x96 maps).
+reference.  No CPU path.  Graphs of up to 10200 vertices (Box2Mask's 96x96 maps) run LDS-resident kernels, larger ones
+(BoxLevelSet's full-resolution mask features) the global-workspace kernels of ``csrc/tree_filter_large.hip``.
 """
 from __future__ import annotations
 
@@ -33,7 +34,7 @@ def mst(edge_index, edge_weight, vertex_count):
     V = int(vertex_count)
     out = torch.empty((B, V - 1, 2), dtype=torch.int32, device=dev)
     lib = _lib.load()
-    ws = torch.empty(max(lib.bxi_mst_workspace_bytes(B), 4), dtype=torch.uint8, device=dev)
+    ws = torch.empty(max(lib.bxi_mst_workspace_bytes(B, E, V), 16), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         _lib.check('bxi_mst_forward_i32', lib.bxi_mst_forward_i32(idx.data_ptr(), w.data_ptr(), B, E, V, out.data_ptr(), ws.data_ptr(),
                                                                    ws.numel(), _stream(dev)))
@@ -49,9 +50,12 @@ def _bfs_levels(edge_index, max_adj_per_vertex):
     sp = torch.empty((B, V), dtype=torch.int32, device=dev)
     sc = torch.empty((B, V, max_adj_per_vertex), dtype=torch.int32, device=dev)
     lv = torch.empty((B, V + 2), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    ws = torch.empty(max(lib.bxi_bfs_workspace_bytes(B, V), 16), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        _lib.check('bxi_bfs_forward_i32', _lib.load().bxi_bfs_forward_i32(tree.data_ptr(), B, V, int(max_adj_per_vertex), si.data_ptr(),
-                                                                           sp.data_ptr(), sc.data_ptr(), lv.data_ptr(), _stream(dev)))
+        _lib.check('bxi_bfs_forward_i32', lib.bxi_bfs_forward_i32(tree.data_ptr(), B, V, int(max_adj_per_vertex), si.data_ptr(),
+                                                                   sp.data_ptr(), sc.data_ptr(), lv.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                                   _stream(dev)))
     return si, sp, sc, lv
 
 
@@ -101,10 +105,12 @@ class _Refine(torch.autograd.Function):
         out, aggr, aggr_up = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
         wsum = torch.empty((B, V), dtype=torch.float32, device=dev)
         wsum_up = torch.empty((B, V), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        ws = torch.empty(max(lib.bxi_tree_refine_workspace_bytes(B, C, V), 16), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            _lib.check('bxi_tree_refine_forward_f32', _lib.load().bxi_tree_refine_forward_f32(
+            _lib.check('bxi_tree_refine_forward_f32', lib.bxi_tree_refine_forward_f32(
                 x.data_ptr(), w.data_ptr(), si.data_ptr(), sc.data_ptr(), levels.data_ptr(), B, C, V, A, out.data_ptr(), aggr.data_ptr(),
-                aggr_up.data_ptr(), wsum.data_ptr(), wsum_up.data_ptr(), _stream(dev)))
+                aggr_up.data_ptr(), wsum.data_ptr(), wsum_up.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
         ctx.save_for_backward(w, si, sp, sc, levels, out, aggr, aggr_up, wsum, wsum_up)
         ctx.low_tree = low_tree
         ctx.dtypes = (feature_in.dtype, edge_weight.dtype)
@@ -122,10 +128,11 @@ class _Refine(torch.autograd.Function):
         gf = torch.empty_like(out)
         gw = None
         if ctx.low_tree:                # functions/refine.py:33-41: the low-level tree passes no gradient to its weights
+            ws = torch.empty(max(lib.bxi_tree_refine_workspace_bytes(B, C, V), 16), dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
                 _lib.check('bxi_tree_refine_backward_feature_f32', lib.bxi_tree_refine_backward_feature_f32(
                     g.data_ptr(), w.data_ptr(), si.data_ptr(), sc.data_ptr(), levels.data_ptr(), wsum.data_ptr(), B, C, V, A, gf.data_ptr(),
-                    _stream(dev)))
+                    ws.data_ptr(), ws.numel(), _stream(dev)))
         else:                           # both gradients from one launch (the weight gradient's first traversal is the feature gradient)
             gw = torch.empty_like(w)
             ws = torch.empty(max(lib.bxi_tree_refine_backward_weight_workspace_bytes(B, C, V), 16), dtype=torch.uint8, device=dev)

@@ -319,14 +319,17 @@ int bxi_lcm_refine_f32(const float* aff, const float* phi, int N, int h, int w, 
  * 7. The `tree_filter` extension -- mmdet/ops/tree_filter: mst_forward (src/mst/mst.cu:93-118 +
  *    boruvka.cpp), bfs_forward (src/bfs/bfs.cu:92-135), refine_forward / refine_backward_feature /
  *    refine_backward_weight (src/refine/refine.cu:186-370), as bound by src/tree_filter.cpp.
- *    V <= 10200 vertices (everything a traversal touches is LDS-resident); larger: BXI_ERR_UNSUPPORTED.
+ *    V <= 10200 vertices: everything a traversal touches is LDS-resident (Box2Mask's 96x96 maps).  Larger graphs (BoxLevelSet
+ *    filters its 200x304 mask features, box_solov2_head.py:354-358) run the same algorithms with their arrays in the
+ *    caller's workspace (the *_workspace_bytes functions return 0 extra when LDS suffices).
  * ===========================================================================================*/
 
 /* Minimum spanning trees of B graphs: edge_index [B,E,2] i32, edge_weight [B,E] f32 >= 0 -> edge_out [B,V-1,2] i32.
  * The tree is the unique MST under the order (weight, edge index) -- the edges the reference's Boruvka selects --
  * listed in ascending edge order (the reference lists them in Boruvka's emission order).  On the GPU, no host copy.
- * workspace: bxi_mst_workspace_bytes(B) (receives the number of tree edges per graph; V-1 for a connected graph). */
-size_t bxi_mst_workspace_bytes(int B);
+ * workspace: bxi_mst_workspace_bytes(B, E, V), 16-byte aligned; its first B ints receive the number of tree edges per graph
+ * (V-1 for a connected graph). */
+size_t bxi_mst_workspace_bytes(int B, int E, int V);
 int bxi_mst_forward_i32(const int* edge_index, const float* edge_weight, int B, int E, int V, int* edge_out, void* workspace,
                         size_t workspace_bytes, void* stream);
 
@@ -334,22 +337,26 @@ int bxi_mst_forward_i32(const int* edge_index, const float* edge_weight, int B, 
  * sorted_parent [B,V] (position of the parent), sorted_child [B,V,max_adj] (positions, 0 = none; zero-filled here).
  * Deterministic, children of a node contiguous.  levels [B,V+2] i32 = { D, off_0 = 0, ..., off_D = V }: the level
  * structure the refine kernels walk (an extra output; the reference keeps no such thing). */
+size_t bxi_bfs_workspace_bytes(int B, int V);          /* 0 when V fits LDS; then workspace may be NULL */
 int bxi_bfs_forward_i32(const int* tree_edges, int B, int V, int max_adj, int* sorted_index, int* sorted_parent, int* sorted_child,
-                        int* levels, void* stream);
+                        int* levels, void* workspace, size_t workspace_bytes, void* stream);
 
 /* refine_forward: feature_in [B,C,V] (vertex order), edge_weight [B,V] (sorted order, [0] unused) ->
  * feature_out, feature_aggr [B,C,V] (vertex order), feature_aggr_up [B,C,V] (sorted), weight_sum [B,V] (vertex),
  * weight_sum_up [B,V] (sorted) -- the five tensors of refine.cu:229-232.  sorted_* / levels from bxi_bfs_forward_i32
  * (a child order that is not contiguous yields NaN). */
+size_t bxi_tree_refine_workspace_bytes(int B, int C, int V);   /* 0 when V fits LDS; then workspace may be NULL; 16-byte aligned */
 int bxi_tree_refine_forward_f32(const float* feature_in, const float* edge_weight, const int* sorted_index, const int* sorted_child,
                                 const int* levels, int B, int C, int V, int max_adj, float* feature_out, float* feature_aggr,
-                                float* feature_aggr_up, float* weight_sum, float* weight_sum_up, void* stream);
+                                float* feature_aggr_up, float* weight_sum, float* weight_sum_up, void* workspace, size_t workspace_bytes,
+                                void* stream);
 /* refine_backward_feature / refine_backward_weight.  The weight gradient's first traversal IS the feature gradient, so
  * bxi_tree_refine_backward_weight_f32 also returns it when `grad_feature` [B,C,V] is non-null (one launch for both,
- * two concurrent traversals); workspace: bxi_tree_refine_backward_weight_workspace_bytes(B, C, V). */
+ * two concurrent traversals); workspace: bxi_tree_refine_backward_weight_workspace_bytes(B, C, V) (includes the refine
+ * workspace of large graphs), 16-byte aligned. */
 int bxi_tree_refine_backward_feature_f32(const float* grad_out, const float* edge_weight, const int* sorted_index,
                                          const int* sorted_child, const int* levels, const float* weight_sum, int B, int C, int V,
-                                         int max_adj, float* grad_feature, void* stream);
+                                         int max_adj, float* grad_feature, void* workspace, size_t workspace_bytes, void* stream);
 size_t bxi_tree_refine_backward_weight_workspace_bytes(int B, int C, int V);
 int bxi_tree_refine_backward_weight_f32(const float* grad_out, const float* edge_weight, const int* sorted_index,
                                         const int* sorted_parent, const int* sorted_child, const int* levels, const float* feature_out,

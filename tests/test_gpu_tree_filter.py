@@ -213,8 +213,8 @@ def test_tree_filter_errors(built, dev):
     from boxinstseg_amd import MinimumSpanningTree, TreeFilter2D, mst
     with pytest.raises(RuntimeError):
         MinimumSpanningTree(TreeFilter2D.norm2_distance)(torch.zeros(1, 3, 4, 4))            # CPU tensor
-    with pytest.raises(RuntimeError):                                                      # more vertices than the LDS-resident limit
-        mst(torch.zeros(1, 10, 2, dtype=torch.int32, device=dev), torch.ones(1, 10, device=dev), 20000)
+    with pytest.raises(RuntimeError):                                                      # beyond the 2^24-vertex limit of the workspace kernels
+        mst(torch.zeros(1, 10, 2, dtype=torch.int32, device=dev), torch.ones(1, 10, device=dev), (1 << 24) + 1)
 
 
 @pytest.mark.parametrize('seed', list(range(8)))
@@ -246,3 +246,149 @@ def test_tree_filter_fuzz(built, dev, seed):
         assert np.abs(xd.grad[b].cpu().numpy() - gf).max() <= 3e-5 * max(np.abs(gf).max(), 1.0)
         gw = tfo.refine_backward_weight(x[b].astype(np.float64), g[b].astype(np.float64), w[b].astype(np.float64), sin[b], spn[b], scn[b], saved)
         assert np.abs(wd.grad[b].cpu().numpy() - gw).max() <= 2e-4 * max(np.abs(gw).max(), 1.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# graphs beyond the LDS-resident limit (tree_filter_large.hip): BoxLevelSet filters 200x304 mask features
+# (box_solov2_head.py:354-358; the reference's kernels have no vertex limit)
+# ---------------------------------------------------------------------------------------------------------------------
+LARGE = [(200, 304), (120, 136)]
+
+
+@pytest.mark.parametrize('H,W', LARGE)
+def test_large_mst_selects_the_reference_tree(built, dev, H, W):
+    from boxinstseg_amd import mst
+    rng = np.random.default_rng(H + W)
+    V = H * W
+    assert V > 10200
+    idx = tfo.grid_edges(H, W)
+    fm = rng.standard_normal((3, H, W)).astype(np.float32)
+    fm2 = np.round(rng.standard_normal((1, H, W)) * 2).astype(np.float32)          # heavy ties
+    wts = np.stack([tfo.grid_weights(fm), tfo.grid_weights(fm2)])
+    tree = mst(torch.from_numpy(idx)[None].repeat(2, 1, 1).to(dev), torch.from_numpy(wts).to(dev), V).cpu().numpy()
+    order = {(int(a), int(b)): i for i, (a, b) in enumerate(idx.tolist())}
+    for b in range(2):
+        want = tfo.ref_boruvka_mst(idx, wts[b], V) if tfo.ref_available() else idx[tfo.mst_edges(idx, wts[b], V)]
+        assert _edge_set(tree[b]) == _edge_set(want), 'not the tree the reference Boruvka selects'
+        ids = [order[(int(a), int(c))] for a, c in tree[b].tolist()]
+        assert ids == sorted(ids) and len(ids) == V - 1
+
+
+def test_large_bfs_is_a_valid_deterministic_order(built, dev):
+    from boxinstseg_amd import bfs, mst
+    H, W = 200, 304
+    rng = np.random.default_rng(5)
+    V = H * W
+    idx = tfo.grid_edges(H, W)
+    wt = (rng.uniform(size=(2, len(idx))) + 1).astype(np.float32)
+    tree = mst(torch.from_numpy(idx)[None].repeat(2, 1, 1).to(dev), torch.from_numpy(wt).to(dev), V)
+    si, sp, sc = bfs(tree, 4)
+    si2, sp2, sc2 = bfs(tree, 4)
+    assert torch.equal(si, si2) and torch.equal(sp, sp2) and torch.equal(sc, sc2)
+    lv = si._bxi_levels.cpu().numpy()
+    si, sp, sc, t = si.cpu().numpy(), sp.cpu().numpy(), sc.cpu().numpy(), tree.cpu().numpy()
+    for b in range(2):
+        assert np.array_equal(np.sort(si[b]), np.arange(V)) and si[b, 0] == 0
+        assert (sp[b, 1:] < np.arange(1, V)).all() and sp[b, 0] == 0
+        a, c = si[b, 1:], si[b, sp[b, 1:]]
+        got = set(zip(np.minimum(a, c).tolist(), np.maximum(a, c).tolist()))
+        assert got == _edge_set(t[b])
+        depth = np.zeros(V, np.int64)
+        for i in range(1, V):
+            depth[i] = depth[sp[b, i]] + 1
+        assert (np.diff(depth) >= 0).all()
+        D = lv[b, 0]
+        assert D == depth.max() + 1 and lv[b, 1] == 0 and lv[b, 1 + D] == V
+        assert np.array_equal(np.searchsorted(depth, np.arange(D)), lv[b, 1:1 + D])
+        nch = (sc[b] > 0).sum(1)
+        assert nch.sum() == V - 1
+        first = sc[b, :, 0]
+        has = nch > 0
+        for k in range(1, 4):                       # children contiguous and pointing back to their parent
+            m = nch > k
+            assert (sc[b, m, k] == first[m] + k).all()
+        assert (sp[b, first[has]] == np.nonzero(has)[0]).all()
+
+
+@pytest.mark.parametrize('low', [True, False])
+def test_large_refine_forward_backward_vs_oracle(built, dev, low):
+    from boxinstseg_amd import bfs, mst, refine
+    H, W, C, B = 200, 304, 2, 2
+    rng = np.random.default_rng(11 + low)
+    V = H * W
+    idx = tfo.grid_edges(H, W)
+    fm = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    wt = np.stack([tfo.grid_weights(fm[b]) for b in range(B)])
+    tree = mst(torch.from_numpy(idx)[None].repeat(B, 1, 1).to(dev), torch.from_numpy(wt).to(dev), V)
+    si, sp, sc = bfs(tree, 4)
+    x = rng.standard_normal((B, C, V)).astype(np.float32)
+    g = rng.standard_normal((B, C, V)).astype(np.float32)
+    sin, spn, scn = si.cpu().numpy(), sp.cpu().numpy(), sc.cpu().numpy()
+    emb = rng.standard_normal((B, 3, V)) * (0.05 if low else 0.4)
+    w = np.stack([tfo.edge_weights(emb[b], sin[b], spn[b], low) for b in range(B)]).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    wd = torch.from_numpy(w).to(dev).requires_grad_(True)
+    out = refine(xd, wd, si, sp, sc, low)
+    out.backward(torch.from_numpy(g).to(dev))
+    for b in range(B):
+        want, saved = tfo.refine_forward(x[b].astype(np.float64), w[b].astype(np.float64), sin[b], spn[b], scn[b])
+        assert np.abs(out[b].detach().cpu().numpy() - want).max() <= 2e-5 * max(np.abs(want).max(), 1.0)
+        gf = tfo.refine_backward_feature(g[b].astype(np.float64), w[b].astype(np.float64), sin[b], spn[b], scn[b], saved)
+        assert np.abs(xd.grad[b].cpu().numpy() - gf).max() <= 2e-5 * max(np.abs(gf).max(), 1.0)
+        if low:
+            assert wd.grad is None
+        else:
+            gw = tfo.refine_backward_weight(x[b].astype(np.float64), g[b].astype(np.float64), w[b].astype(np.float64), sin[b], spn[b],
+                                            scn[b], saved)
+            assert np.abs(wd.grad[b].cpu().numpy() - gw).max() <= 1e-4 * max(np.abs(gw).max(), 1.0)
+
+
+@pytest.mark.skipif(not tfo.ref_kernels_available(), reason='oracle/_ref/libtreekernels_ref.so not built (make -C oracle ref)')
+def test_large_refine_vs_reference_kernels_live_200x304(built, dev):
+    """BoxLevelSet's size against the reference's OWN bfs.cu / refine.cu kernels run on this host's CPU
+    (oracle/_ref/libtreekernels_ref.so travels with the snapshot): the BFS orders differ, the results per vertex must not."""
+    from boxinstseg_amd import mst
+    rng = np.random.default_rng(78)
+    H, W = 200, 304
+    V = H * W
+    idx = tfo.grid_edges(H, W)
+    fm = rng.standard_normal((3, H, W)).astype(np.float32)
+    tree = mst(torch.from_numpy(idx)[None].to(dev), torch.from_numpy(tfo.grid_weights(fm))[None].to(dev), V)[0].cpu().numpy()
+    r_si, r_sp, r_sc = tfo.ref_bfs(tree, V)
+    C = 1
+    x = rng.standard_normal((C, V)).astype(np.float32)
+    g = rng.standard_normal((C, V)).astype(np.float32)
+    w_vertex = np.exp(-rng.random(V) * 0.8).astype(np.float32)
+    fwd = tfo.ref_refine_forward(x, w_vertex[r_si], r_si, r_sp, r_sc)
+    r_gf, r_gw = tfo.ref_refine_backward(g, w_vertex[r_si], r_si, r_sp, r_sc, fwd)
+    want_gw = np.zeros(V, np.float32); want_gw[r_si] = r_gw
+    out, gf, gw = _hip_refine_per_vertex(dev, tree, x, w_vertex, g)
+    assert np.abs(out - fwd['out']).max() <= 1e-5 * max(1.0, np.abs(fwd['out']).max())
+    assert np.abs(gf - r_gf).max() <= 1e-5 * max(1.0, np.abs(r_gf).max())
+    assert np.abs(gw - want_gw).max() <= 1e-4 * max(1.0, np.abs(want_gw).max())
+
+
+def test_large_tree_filter_module_end_to_end(built, dev):
+    """MinimumSpanningTree + TreeFilter2D on a 200x304 map with 2 groups, forward and backward, against the oracle."""
+    from boxinstseg_amd import MinimumSpanningTree, TreeFilter2D
+    rng = np.random.default_rng(3)
+    B, C, H, W = 1, 4, 200, 304
+    V = H * W
+    guide = torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32)).to(dev)
+    feat = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32)).to(dev).requires_grad_(True)
+    emb = torch.from_numpy((rng.standard_normal((B, 4, H, W)) * 0.3).astype(np.float32)).to(dev).requires_grad_(True)
+    tree = MinimumSpanningTree(TreeFilter2D.norm2_distance)(guide)
+    out = TreeFilter2D(groups=2)(feat, emb, tree, low_tree=False)
+    assert out.shape == feat.shape and torch.isfinite(out).all()
+    gout = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(torch.from_numpy(gout).to(dev))
+    si, sp, sc = tfo.bfs_order(tree[0].cpu().numpy(), V)
+    e = emb.detach().cpu().numpy()[0].reshape(4, V)
+    f = feat.detach().cpu().numpy()[0].reshape(C, V)
+    for gidx in range(2):
+        w = tfo.edge_weights(e[2 * gidx:2 * gidx + 2].astype(np.float64), si, sp, False)
+        want, saved = tfo.refine_forward(f[2 * gidx:2 * gidx + 2].astype(np.float64), w, si, sp, sc)
+        got = out[0, 2 * gidx:2 * gidx + 2].detach().cpu().numpy().reshape(2, V)
+        assert np.abs(got - want).max() <= 3e-5 * max(np.abs(want).max(), 1.0)
+    assert emb.grad is not None and torch.isfinite(emb.grad).all() and float(emb.grad.abs().sum()) > 0
+    assert torch.isfinite(feat.grad).all()

@@ -66,8 +66,12 @@ def test_abi_argument_validation_without_device():
     assert lib.bxi_levelset_loss_forward_f32(None, None, None, 1, 9, 4, 4, 1.0, None, None, None) == -4            # C > 8
     assert lib.bxi_levelset_state_bytes(3, 2) == 8 * 3 * 10 * 9
     assert lib.bxi_lcm_refine_f32(None, None, 1, 4, 4, 0, 10, 0, None, None, 0, None) == -3                         # dilation < 1
-    assert lib.bxi_mst_forward_i32(None, None, 1, 10, 20000, None, None, 0, None) == -4                             # above the LDS-resident limit
-    assert lib.bxi_bfs_forward_i32(None, 1, 1, 4, None, None, None, None, None) == -2
+    assert lib.bxi_mst_forward_i32(None, None, 1, 10, 20000, None, None, 0, None) == -1                             # large graphs are served (workspace arrays): NULL pointers
+    assert lib.bxi_mst_forward_i32(None, None, 1, 10, (1 << 24) + 1, None, None, 0, None) == -4
+    assert lib.bxi_mst_workspace_bytes(2, 18240, 9216) == 16 and lib.bxi_mst_workspace_bytes(1, 121096, 60800) > 16 * 60800
+    assert lib.bxi_bfs_workspace_bytes(2, 9216) == 0 and lib.bxi_bfs_workspace_bytes(1, 60800) >= 32 * 60800
+    assert lib.bxi_tree_refine_workspace_bytes(2, 8, 9216) == 0 and lib.bxi_tree_refine_workspace_bytes(1, 8, 60800) >= 8 * 36 * 60800
+    assert lib.bxi_bfs_forward_i32(None, 1, 1, 4, None, None, None, None, None, 0, None) == -2
     assert lib.bxi_tree_refine_backward_weight_workspace_bytes(2, 3, 100) == 4 * 4 * 2 * 3 * 100
     if not torch.cuda.is_available():
         assert lib.bxi_check_device(0) == -7                                               # NO_DEVICE
