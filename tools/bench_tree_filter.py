@@ -44,4 +44,18 @@ for B, N in ((2, 16), (2, 100)):
         t0 = time.perf_counter(); tfo.ref_boruvka_mst(idx, wt, H * W); cpu_ms = (time.perf_counter() - t0) * 1e3
     res[f'B{B}_N{N}'] = dict(hip_two_msts_us=ev(trees), hip_two_filters_fwd_bwd_us=ev(filt),
                              reference_boruvka_cpp_one_graph_ms_on_host=cpu_ms)
+# BoxLevelSet's size (box_solov2_head.py:354-358): one 200x304 mask-feature map, 5 channels -- the global-workspace kernels
+H2, W2 = 200, 304
+img2 = torch.rand(1, 3, H2, W2, generator=g).to(dev)
+feat2 = torch.rand(1, 5, H2, W2, generator=g).to(dev).requires_grad_(True)
+t2 = mstm(img2)
+def filt2():
+    o = tf(feature_in=feat2, embed_in=img2, tree=t2)
+    o.sum().backward(); feat2.grad = None
+cpu_ms = None
+if tfo.ref_available():
+    idx = tfo.grid_edges(H2, W2); wt = tfo.grid_weights(img2[0].cpu().numpy())
+    t0 = time.perf_counter(); tfo.ref_boruvka_mst(idx, wt, H2 * W2); cpu_ms = (time.perf_counter() - t0) * 1e3
+res['large_200x304_C5'] = dict(hip_mst_us=ev(lambda: mstm(img2), n=5, warm=1), hip_filter_fwd_bwd_us=ev(filt2, n=5, warm=1),
+                               reference_boruvka_cpp_one_graph_ms_on_host=cpu_ms)
 print(json.dumps(res, indent=1))

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Developer helper (GPU box): everything profiles/ is built from.  Usage: tools/gpu_profiles.sh r02
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-kernel-timing --no-extras"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_eager -o $TAG -- $CMD > $R/gpurun_out/prof_eager.log 2>&1
+cut -d, -f1-4 $R/gpurun_out/prof_eager/${TAG}_kernel_stats.csv | head -6
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -o $TAG -- \
+     python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-kernel-timing --no-extras > $R/gpurun_out/pmc_$c.log 2>&1
+  ls $R/gpurun_out/pmc_$c | head -3
+done
+for t in pairwise_op dynamic_head discobox levelset tree_filter; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$t -o $TAG -- python $R/tools/bench_$t.py > $R/gpurun_out/${t}_bench.json 2> $R/gpurun_out/${t}_bench.err
+  tail -c 300 $R/gpurun_out/${t}_bench.json | tr '\n' ' '; echo
+done
+cd $R && python tools/trace_eval.py 2>&1 | grep -v amdgpu.ids > gpurun_out/block_trace.txt; tail -3 gpurun_out/block_trace.txt | cut -c1-300
+python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 600 gpurun_out/bench_default.json

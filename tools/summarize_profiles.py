@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 outputs merged into gpurun_out/ into the tracked summaries under profiles/.
 
-    python tools/summarize_profiles.py r01
+    python tools/summarize_profiles.py r02        (after `gpurun -- tools/gpu_profiles.sh r02`)
 
-reads  gpurun_out/prof_eager/r01_kernel_stats.csv                    (rocprofv3 --kernel-trace --stats)
-       gpurun_out/pmc_FETCH_SIZE|pmc_WRITE_SIZE/r01_counter_collection.csv  (one --pmc pass per counter)
+reads  gpurun_out/prof_eager/<round>_kernel_stats.csv                    (rocprofv3 --kernel-trace --stats)
+       gpurun_out/pmc_FETCH_SIZE|pmc_WRITE_SIZE/<round>_counter_collection.csv  (one --pmc pass per counter)
+       gpurun_out/prof_<row>/<round>_kernel_stats.csv, gpurun_out/<row>_bench.json, gpurun_out/block_trace.txt, bench_default.json
 writes profiles/<round>_kernel_stats_eager.csv, profiles/<round>_hbm_traffic.json, profiles/<round>_summary.md
 FETCH_SIZE is doubled for the streaming kernel, as MI355X_MICROARCH.md prescribes for 16 B/lane coalesced
 reads on gfx950 (the counter tallies 128-B requests at 64 B); WRITE_SIZE is used as reported (KB).
@@ -16,10 +17,18 @@ import os
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+rnd = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 G, P = 'gpurun_out', 'profiles'
 os.makedirs(P, exist_ok=True)
-shutil.copy(f'{G}/prof_eager/r01_kernel_stats.csv', f'{P}/{rnd}_kernel_stats_eager.csv')
+shutil.copy(f'{G}/prof_eager/{rnd}_kernel_stats.csv', f'{P}/{rnd}_kernel_stats_eager.csv')
+for row in ('pairwise_op', 'dynamic_head', 'discobox', 'levelset', 'tree_filter'):
+    if os.path.exists(f'{G}/prof_{row}/{rnd}_kernel_stats.csv'):
+        shutil.copy(f'{G}/prof_{row}/{rnd}_kernel_stats.csv', f'{P}/{rnd}_{row}_kernel_stats.csv')
+    if os.path.exists(f'{G}/{row}_bench.json'):
+        shutil.copy(f'{G}/{row}_bench.json', f'{P}/{rnd}_{row}_bench.json')
+for src, dst in (('block_trace.txt', f'{rnd}_block_trace.txt'), ('bench_default.json', f'{rnd}_bench_default.json')):
+    if os.path.exists(f'{G}/{src}'):
+        shutil.copy(f'{G}/{src}', f'{P}/{dst}')
 stats = {}
 for r in csv.DictReader(open(f'{P}/{rnd}_kernel_stats_eager.csv')):
     if 'bxi::' in r['Name']:
@@ -28,7 +37,7 @@ for r in csv.DictReader(open(f'{P}/{rnd}_kernel_stats_eager.csv')):
                           max_us=float(r['MaxNs']) / 1e3)
 traffic = collections.defaultdict(dict)
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-    path = f'{G}/pmc_{c}/r01_counter_collection.csv'
+    path = f'{G}/pmc_{c}/{rnd}_counter_collection.csv'
     if not os.path.exists(path):
         continue
     agg = collections.defaultdict(list)
@@ -43,12 +52,12 @@ for k, t in traffic.items():
     fetch = t.get('FETCH_SIZE_KB', 0.0) * 1024 * 2      # gfx950: x2 for wide coalesced reads
     write = t.get('WRITE_SIZE_KB', 0.0) * 1024
     out[k] = dict(fetch_bytes_corrected=fetch, write_bytes=write, hbm_bytes=fetch + write, raw=t)
-json.dump(dict(round=rnd, command='python bench.py --mode eager --steps 100 --warmup 20 --no-cpu-baseline --no-kernel-timing --no-pipelined', kernels=out,
+json.dump(dict(round=rnd, command='python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-kernel-timing --no-extras', kernels=out,
                note='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 correction, '
                     'MI355X_MICROARCH.md section HBM); per launch, mean over the timed launches'),
           open(f'{P}/{rnd}_hbm_traffic.json', 'w'), indent=1)
 with open(f'{P}/{rnd}_summary.md', 'w') as f:
-    f.write(f'# rocprofv3 summary, round {rnd[1:]} (MI355X, `rocprofv3 --kernel-trace --stats -- python bench.py --mode eager --steps 400 --warmup 50 --no-cpu-baseline --no-kernel-timing --no-pipelined`)\n\n')
+    f.write(f'# rocprofv3 summary, round {rnd[1:]} (MI355X, `rocprofv3 --kernel-trace --stats -- python bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-kernel-timing --no-extras`)\n\n')
     f.write('| kernel | calls | avg us | min us | max us | HBM read (PMC, corrected) MB | HBM write (PMC) MB |\n|---|---:|---:|---:|---:|---:|---:|\n')
     for k, s in sorted(stats.items(), key=lambda kv: -kv[1]['avg_us']):
         t = out.get(k, {})
