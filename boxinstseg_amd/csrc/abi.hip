@@ -8,9 +8,6 @@ void set_last_hip_error(int e) { g_last_hip_error = e; }
 bxi_launch_hook g_hook = nullptr;
 void* g_hook_user = nullptr;
 
-int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, const bxi_instances* in,
-                const uint8_t* affinity, int size, int dil, float warmup, float* losses, float* g_logits, void* state,
-                void* workspace, size_t workspace_bytes, void* stream);
 size_t loss_ws_bytes(int N, int h, int w);
 size_t eval_ws_bytes(int N, int h, int w);
 bool fused_eval_supported(int dil);

@@ -1,21 +1,18 @@
-// mask_loss.hip -- BoxInst projection + pairwise loss, forward AND backward, on gfx950.
+// mask_loss.hip -- BoxInst projection + pairwise loss from PRECOMPUTED colour-affinity bits (bxi_boxinst_loss_fwd_bwd_f32
+// + bxi_boxinst_loss_backward_f32): the round-1 three-launch path, kept for callers that already hold the affinity words
+// of bxi_color_affinity_f32 (explicit image masks, get_targets()-style use) and as an independent cross-check of
+// fused_eval.hip (tests compare the two routes).  The evaluation from the network input is fused_eval.hip.
 //
-// Replaces (reference, LiWentomng/BoxInstSeg) CondInstMaskHead.loss with boxinst_enabled,
-// condinst_head.py:1288-1343:
+// Replaces (reference, LiWentomng/BoxInstSeg) CondInstMaskHead.loss with boxinst_enabled, condinst_head.py:1288-1343:
 //   mask_logits.sigmoid() / compute_project_term      :1300, :134-143 (+ dice_coefficient :117-131)
 //   pairwise_nlog (CUDA op, pairwise.cu:68-149)       :1321
 //   weights = (sim >= thresh) * bitmask, normalise    :1324-1328
 //   warm-up                                           :1330-1332
-// and everything autograd does behind them (max backward, sigmoid backward, the op's atomicAdd
-// backward, ~1.3 GB of elementwise temporaries at 2x800x1024x32) with two launches, each
-// documented at its kernel below:
-//   stage1        { image pool + Lab } || { logit streaming: row/column maxima, zero-fill }   HBM stream
-//   box_kernel    leaders: dice + projection gradient of each instance ; tiles: colour-affinity
-//                 bits + pairwise term and its un-normalised gradient on the box tiles       latency bound
-// and, in the backward, loss_apply (normalise the box tiles, add the projection gradient at the
-// h+w arg-max positions, fold the upstream gradients in from device memory).
-// Data layout in HBM: everything NCHW / row-major as the reference; per-pixel colour affinity is
-// never materialised as [N,8,h,w] -- box_kernel derives the 8-bit word it needs from Lab [B,3,h,w].
+//   stage1        tables + logit streaming: row/column maxima, zero-fill                                HBM stream
+//   box_kernel    leaders: dice + projection gradient of each instance ; tiles: pairwise term and its un-normalised
+//                 gradient on the box tiles (ordered pairs, tile staged in LDS)                          latency bound
+//   loss_apply    (backward) normalise the box tiles, add the projection gradient at the h+w arg-max positions, fold
+//                 the upstream gradients in from device memory.
 #include "loss_common.hpp"
 
 namespace bxi {
@@ -98,7 +95,7 @@ __device__ __forceinline__ LaneBox lane_box(const InstArgs& a, int dil, int m) {
 
 // One wave64 of instance n's first streaming workgroup: exclusive prefix of the box-tile counts of
 // instances 0..n-1 (deterministic order, no atomics, no pre-zeroed counter), then this instance's tiles.
-__device__ __forceinline__ void build_work_list(const InstArgs& a, int dil, float thresh, const LossWs& ws, int n) {
+__device__ __forceinline__ void build_work_list(const InstArgs& a, int dil, const LossWs& ws, int n) {
     const int lane = threadIdx.x & 63;
     int base = 0, total = 0;
     LaneBox mine = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -125,7 +122,6 @@ __device__ __forceinline__ void build_work_list(const InstArgs& a, int dil, floa
     }
     if (n == 0 && lane == 0) { *ws.nwork = total; ws.arrive[a.N] = 0u; }
     const int cnt = mine.ntr * mine.ntc;
-    const Pred pr = make_pred(thresh);
     if (lane == 0) {   // per-instance records and zeroed accumulators for box_kernel / loss_apply (next launches)
         InstRec rc; rc.r0 = mine.r0; rc.r1 = mine.r1; rc.c0 = mine.c0; rc.c1 = mine.c1; rc.img = mine.img;
         rc.pad0 = rc.pad1 = rc.pad2 = 0;
@@ -137,7 +133,7 @@ __device__ __forceinline__ void build_work_list(const InstArgs& a, int dil, floa
         WorkRec wr;
         wr.r0 = mine.r0; wr.r1 = mine.r1; wr.c0 = mine.c0; wr.c1 = mine.c1; wr.img = mine.img; wr.n = n;
         wr.tile_r0 = (mine.tr0 + i / mine.ntc) * kBR; wr.tile_c0 = (mine.tc0 + i % mine.ntc) * kBC;
-        wr.n2max = pr.n2max; wr.zero_bit = pr.zero_bit; wr.pad0 = wr.pad1 = 0;
+        wr.n2max = 0.f; wr.zero_bit = 0; wr.pad0 = wr.pad1 = 0;       // (colour predicate: only used when Lab is given)
         ws.work[base + i] = wr;
     }
 }
@@ -149,7 +145,7 @@ __device__ __forceinline__ void build_work_list(const InstArgs& a, int dil, floa
 //   - all kSR row loads are issued back to back, then consumed: per-row max / first arg-max by a
 //     64-lane butterfly on a packed 64-bit key (the kSR butterflies are interleaved), per-column
 //     max / first arg-max over the tile's rows in registers -> one partial per (tile, column).
-__device__ __forceinline__ void stream_tile(const InstArgs& a, int dil, float thresh, const LossWs& ws,
+__device__ __forceinline__ void stream_tile(const InstArgs& a, int dil, const LossWs& ws,
                                             float* __restrict__ g_logits, int vec, int sb) {
     const int h = a.h, w = a.w;
     const int Ts = (h + kSR - 1) / kSR;
@@ -252,43 +248,15 @@ __device__ __forceinline__ void stream_tile(const InstArgs& a, int dil, float th
     if (lane < kSR && r0 + lane < r1) ws.rowkey[(int64_t)n * h + r0 + lane] = mine;
 }
 
-// grid: [N table waves][pooling waves][N*Ts streaming waves].  The table waves (per-instance
-// records + work list of box_kernel, incl. the colour-threshold predicate) carry dependent load
-// chains, so they go first, before the memory system is saturated; nothing in this launch waits for them.
-constexpr int kPoolStaggerTicks = 300;     // x 10 ns
-
-__global__ __launch_bounds__(64) void stage1_kernel(PoolArgs pa, int n_pool, InstArgs a, int dil, float thresh,
-                                                    LossWs ws, float* __restrict__ g_logits, int vec) {
-    __shared__ double lut[256];
+// grid: [N table waves][N*Ts streaming waves].  The table waves (per-instance records + work list of box_kernel) carry
+// dependent load chains, so they go first; nothing in this launch waits for them.
+// (Round 1 also ran the image pooling here; the evaluation from the network input now lives in fused_eval.hip, and this file
+// serves the precomputed-affinity-bits entry point, bxi_boxinst_loss_fwd_bwd_f32.)
+__global__ __launch_bounds__(64) void stage1_kernel(InstArgs a, int dil, LossWs ws, float* __restrict__ g_logits, int vec) {
     BXI_T(0, blockIdx.x, 0);
     const int n_tab = a.N;
-    if ((int)blockIdx.x < n_tab) {
-        build_work_list(a, dil, thresh, ws, (int)blockIdx.x);
-    } else if ((int)blockIdx.x >= n_tab + n_pool) {
-        stream_tile(a, dil, thresh, ws, g_logits, vec, (int)blockIdx.x - n_tab - n_pool);
-    } else {
-        // Every wave of this launch gets its data at about the same time (the loads of all of them saturate HBM for ~5 us)
-        // and only then starts its arithmetic, so the SIMDs idle for 5 us and are oversubscribed afterwards.  There are 1.5
-        // pooling waves per SIMD (the heavy ones: fp64 Lab); the dispatcher hands out workgroups round-robin, so pooling
-        // waves r and r + 1024 share a SIMD.  The second of each pair holds its loads back by ~3 us: its data then arrives
-        // when its mate is finishing, and its arithmetic runs on a SIMD that is free again (stage1 10.5 -> 9.7 us; the
-        // optimum is flat between 2.3 and 3.5 us; no effect on the streaming waves, which the delay would only hurt).
-        const int r = (int)blockIdx.x - n_tab;
-        if ((r >> 10) & 1) {
-            const uint64_t t0 = wall_clock64();                       // 100 MHz
-            while ((int)(wall_clock64() - t0) < kPoolStaggerTicks) __builtin_amdgcn_s_sleep(2);
-        }
-        const int64_t total = (int64_t)pa.B * (pa.Hc >> 2) * (pa.Wc >> 2);
-        const int64_t o = (int64_t)r * 64 + threadIdx.x;
-        PoolRegs pr;
-        if (o < total) pool_load_s4(pa, o, pr);          // 12 x 16 B per lane in flight ...
-#pragma unroll
-        for (int k = 0; k < 4; ++k) lut[threadIdx.x + 64 * k] = kSrgbLut[threadIdx.x + 64 * k];   // ... while the table is staged
-        BXI_T(0, blockIdx.x, 2);
-        lds_barrier();
-        BXI_T(0, blockIdx.x, 3);
-        if (o < total) pool_finish_s4(pa, o, pr, lut);
-    }
+    if ((int)blockIdx.x < n_tab) build_work_list(a, dil, ws, (int)blockIdx.x);
+    else stream_tile(a, dil, ws, g_logits, vec, (int)blockIdx.x - n_tab);
     BXI_T(0, blockIdx.x, 1);
 }
 
@@ -303,10 +271,9 @@ __global__ __launch_bounds__(64) void stage1_kernel(PoolArgs pa, int n_pool, Ins
 // Tile workgroups take their (instance, tile) from the compacted work list stage1 built (at most 1024
 // tile workgroups are launched; each strides through the list), so the working ones start together.
 //   LDS  pq   [8+2d][64+2P]     (sigmoid(x), sigmoid(-x)) of the tile + halo         (P = d rounded up to 4)
-//        lab  [3][8+2d][64+2P]  CIE-Lab of the same region (FROM_LAB) | bits [8+2d][64+2P] (!FROM_LAB)
-//   1. all global loads (logits region, Lab region) are issued together, float4, aligned;
-//   2. per pixel, 8 neighbours (operands prefetched from LDS, branch-free): colour affinity of the
-//      pair from ||dLab||^2 (threshold predicate, see Pred; the two directions share the distance),
+//        bits [8+2d][64+2P]     affinity words of the in-box pixels
+//   1. the logits region is loaded float4, aligned;
+//   2. per pixel, 8 neighbours (operands prefetched from LDS, branch-free): colour weights from the staged affinity words,
 //      S = p_i p_j + q_i q_j, -log S and its gradient, weighted by W[k,p] + W[7-k,q]
 //      (gather form: no atomics on the gradient, fixed summation order);
 //   3. writes the UN-normalised pairwise gradient of the whole tile (zeros outside the dilated box)
@@ -468,9 +435,8 @@ __device__ __noinline__ float2 pair_logspace_redo(const float* __restrict__ L, c
     return make_float2(dnum, acc2);   // (correction to the pixel's loss sum, its gradient)
 }
 
-template <bool FROM_LAB, bool PREFETCH>
-__device__ __forceinline__ void box_body(const InstArgs& a, const float* __restrict__ lab, const ImageMeta& meta,
-                                         const uint8_t* __restrict__ bits_in, float thresh, int dil, float warmup,
+template <bool PREFETCH>
+__device__ __forceinline__ void box_body(const InstArgs& a, const uint8_t* __restrict__ bits_in, int dil, float warmup,
                                          const LossWs& ws, const LossState& st, float* __restrict__ losses,
                                          float* __restrict__ g_logits, int vec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -503,80 +469,53 @@ __device__ __forceinline__ void box_body(const InstArgs& a, const float* __restr
     const int PR = kBR + 2 * d, PC = kBC + 2 * PAD;          // staged region: tile + halo (columns padded to 4)
     const int q4 = PC / 4, items = PR * q4;                  // d = 2: 216 float4 per plane
     const bool one_item = PREFETCH && items <= 256;          // d <= 3: a thread stages at most one float4 per plane
-    // the raw tile data (logits + 3 Lab planes) of a work item, one float4 per plane and thread (zero padding of F.unfold)
-    auto load_item = [&](const WorkRec& w_, int i, float4 (&t)[4]) {
-        t[0] = make_float4(0.f, 0.f, 0.f, 0.f); t[1] = t[0]; t[2] = t[0]; t[3] = t[0];
+    // the raw logits of a work item's tile + halo, one float4 per thread (zero padding of F.unfold)
+    auto load_item = [&](const WorkRec& w_, int i, float4& t) {
+        t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i >= items) return;
         const int lr = i / q4, r = w_.tile_r0 - d + lr, c = w_.tile_c0 - PAD + (i % q4) * 4;
         if (!(r >= 0 && r < h && c >= 0 && c < w)) return;
-        t[0] = load4(a.logits + (int64_t)w_.n * P + (int64_t)r * w, c, w, vec);
-        if (FROM_LAB) {
-            const float* row = lab + (int64_t)w_.img * 3 * P + (int64_t)r * w;
-            if (vec) {
-                t[1] = *reinterpret_cast<const float4*>(row + c);
-                t[2] = *reinterpret_cast<const float4*>(row + P + c);
-                t[3] = *reinterpret_cast<const float4*>(row + 2 * P + c);
-            } else {
-                t[1] = load4(row, c, w, false); t[2] = load4(row + P, c, w, false); t[3] = load4(row + 2 * P, c, w, false);
-            }
-        }
+        t = load4(a.logits + (int64_t)w_.n * P + (int64_t)r * w, c, w, vec);
     };
     WorkRec wr_next = ws.work[min((int)blockIdx.x - a.N, cap - 1)];   // speculative (inside the list's capacity) ...
-    float4 pre[4];                                           // the next tile's data, in flight while the current tile is worked on
+    float4 pre;                                              // the next tile's data, in flight while the current tile is worked on
     if ((int)blockIdx.x - a.N < nwork && one_item) load_item(wr_next, tid, pre);
     for (int wi = (int)blockIdx.x - a.N; wi < cap; wi += ntile_wg) {
         if (wi >= nwork) break;                  // workgroup-uniform
         const WorkRec wr = wr_next;
         const bool more = wi + ntile_wg < nwork;
         if (more) wr_next = ws.work[wi + ntile_wg];
-        Pred pr; pr.n2max = wr.n2max; pr.zero_bit = wr.zero_bit; pr.fast = 1; pr.pad = 0;
         const int n = wr.n, r0 = wr.tile_r0, c0 = wr.tile_c0;
         InstRec rc; rc.r0 = wr.r0; rc.r1 = wr.r1; rc.c0 = wr.c0; rc.c1 = wr.c1; rc.img = wr.img;
         const InstBox ib = inst_from_rec(rc, dil, h, w);
-        // scalar operands of the pair loop: requested now, so they arrive with the tile loads below
-        const int vr = FROM_LAB ? min(meta.img_h[ib.img], meta.first_removed[ib.img]) : 0;   // valid(q): :1354-1369,:1405
-        const int vc = FROM_LAB ? meta.img_w[ib.img] : 0;
-        const int half = a.stride / 2;
         BXI_T(1, blockIdx.x, 1);
         const float* L = a.logits + (int64_t)n * P;
         float2* pq = reinterpret_cast<float2*>(smem);
-        float* labs = reinterpret_cast<float*>(smem + sizeof(float2) * (size_t)PR * PC);   // [3][PR][PC]   (FROM_LAB)
-        uint8_t* bits = smem + sizeof(float2) * (size_t)PR * PC;                            // [PR][PC]      (!FROM_LAB)
+        uint8_t* bits = smem + sizeof(float2) * (size_t)PR * PC;                            // [PR][PC] affinity words of the in-box pixels
 
-        // ---- 1. the logits region (-> sigmoid pairs) and the Lab region go to LDS ----------------------------
+        // ---- 1. the logits region (-> sigmoid pairs) and the affinity words go to LDS ------------------------------
         {
             for (int i = tid; i < items; i += 256) {
-                float4 t[4];
-                if (one_item) { t[0] = pre[0]; t[1] = pre[1]; t[2] = pre[2]; t[3] = pre[3]; }   // requested during the previous tile
+                float4 t;
+                if (one_item) t = pre;                               // requested during the previous tile
                 else load_item(wr, i, t);
                 const int lr = i / q4;
                 float2* dst = pq + (size_t)lr * PC + (i % q4) * 4;
-                dst[0] = sig_pair(t[0].x); dst[1] = sig_pair(t[0].y); dst[2] = sig_pair(t[0].z); dst[3] = sig_pair(t[0].w);
-                if (FROM_LAB) {
-                    float* ld = labs + (size_t)lr * PC + (i % q4) * 4;
-                    *reinterpret_cast<float4*>(ld) = t[1];
-                    *reinterpret_cast<float4*>(ld + PR * PC) = t[2];
-                    *reinterpret_cast<float4*>(ld + 2 * PR * PC) = t[3];
-                }
+                dst[0] = sig_pair(t.x); dst[1] = sig_pair(t.y); dst[2] = sig_pair(t.z); dst[3] = sig_pair(t.w);
             }
             if (one_item && more) load_item(wr_next, tid, pre);     // flies during the pair loop of this tile
-            if (!FROM_LAB) {   // affinity words given: stage those of the in-box pixels (bitmask == 1, :1324-1325)
-                const uint8_t* AF = bits_in + (int64_t)ib.img * P;
-                for (int i = tid; i < PR * PC; i += 256) {
-                    const int r = r0 - d + i / PC, c = c0 - PAD + i % PC;
-                    const bool inbox = r >= ib.box.r0 && r < ib.box.r1 && c >= ib.box.c0 && c < ib.box.c1;
-                    bits[i] = inbox ? AF[(int64_t)r * w + c] : (uint8_t)0;
-                }
+            const uint8_t* AF = bits_in + (int64_t)ib.img * P;       // those of the in-box pixels (bitmask == 1, :1324-1325)
+            for (int i = tid; i < PR * PC; i += 256) {
+                const int r = r0 - d + i / PC, c = c0 - PAD + i % PC;
+                const bool inbox = r >= ib.box.r0 && r < ib.box.r1 && c >= ib.box.c0 && c < ib.box.c1;
+                bits[i] = inbox ? AF[(int64_t)r * w + c] : (uint8_t)0;
             }
         }
         __syncthreads();
         BXI_T(1, blockIdx.x, 2);
 
-        // ---- 2. colour affinity + pairwise term, 2 pixels per thread ---------------------------------------
-        // weight of the pair (p, q = p + delta_k):  W[k,p] + W[7-k,q]
-        //   W[k,p]   = [p in box] * [sim(p->q) >= thresh],  sim(p->q) = exp(-||Lab_p-Lab_q||/2) * valid(q)
-        //   W[7-k,q] = [q in box] * [sim(q->p) >= thresh],  sim(q->p) = exp(-||Lab_q-Lab_p||/2) * valid(p)
-        // the two share the distance, so no per-pixel affinity word has to be staged (FROM_LAB).
+        // ---- 2. pairwise term, 2 pixels per thread ---------------------------------------------------------------------
+        // weight of the pair (p, q = p + delta_k):  W[k,p] + W[7-k,q], both from the staged affinity words
         // thread -> row lr, columns lcx and lcx + 32: the 32 lanes of a row read consecutive LDS words
         // (conflict-free ds_read_b32 / b64), unlike an adjacent-pixel pairing (2-way conflicts)
         const int lr = tid >> 5, lcx = tid & 31;
@@ -584,84 +523,20 @@ __device__ __forceinline__ void box_body(const InstArgs& a, const float* __restr
         float num = 0.f;
         int cnt = 0;
         float out[2] = {0.f, 0.f};
-        // per-row flags of the three neighbour rows: bit0 inside the map, bit1 inside the box, bit2 valid
-        uint32_t rfl[3];
+        uint32_t rin[3];                                      // the three neighbour rows: inside the map?
     #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int r2 = r + dy * d;
-            const uint32_t in = (r2 >= 0 && r2 < h) ? 1u : 0u;
-            rfl[dy + 1] = in | ((r2 >= ib.box.r0 && r2 < ib.box.r1) ? 2u : 0u) | ((in && r2 * a.stride + half < vr) ? 4u : 0u);
-        }
-        // interior tile (workgroup-uniform): every pixel and every neighbour is inside the box, valid and in the
-        // map, so W[k,p] = W[7-k,q] = [n2 <= n2max] and none of the flag logic below is needed.  These are the
-        // tiles with the most work (all 512 pixels active), i.e. the tail of the launch.
-        const bool interior = FROM_LAB && r0 - d >= ib.box.r0 && r0 + kBR + d <= ib.box.r1 && c0 - d >= ib.box.c0 &&
-                              c0 + kBC + d <= ib.box.c1 && (r0 + kBR - 1 + d) * a.stride + half < vr &&
-                              (c0 + kBC - 1 + d) * a.stride + half < vc;
-        if (interior) {
-    #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int c = c0 + lcx + 32 * e;
-                const int pi = (lr + d) * PC + (lcx + 32 * e + PAD);
-                const float2 pp = pq[pi];
-                const float L0 = labs[pi], A0 = labs[PR * PC + pi], B0 = labs[2 * PR * PC + pi];
-                float2 nq[8]; float nL[8], nA[8], nB[8];
-                {
-                    int k = 0;
-    #pragma unroll
-                    for (int dy = -1; dy <= 1; ++dy)
-    #pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            if (dx == 0 && dy == 0) continue;
-                            const int qi = pi + dy * d * PC + dx * d;
-                            nq[k] = pq[qi]; nL[k] = labs[qi]; nA[k] = labs[PR * PC + qi]; nB[k] = labs[2 * PR * PC + qi];
-                            ++k;
-                        }
-                }
-                float acc = 0.f;
-                bool tiny = false;
-                uint32_t wps = 0;
-                const float ppq = pp.x * pp.y;
-    #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float dL = L0 - nL[k], dA = A0 - nA[k], dB = B0 - nB[k];
-                    const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(dL, dL), __fmul_rn(dA, dA)), __fmul_rn(dB, dB));
-                    const bool on = n2 <= pr.n2max;
-                    const float fp = on ? 1.f : 0.f;
-                    wps |= (on ? 1u : 0u) << k;
-                    const float S = pp.x * nq[k].x + pp.y * nq[k].y;
-                    tiny |= on && !(S > 1e-30f);
-                    const float Sc = fmaxf(S, 1e-30f);
-                    num += fp * -__logf(Sc);
-                    acc += (fp + fp) * (-(nq[k].x - nq[k].y) * ppq * __builtin_amdgcn_rcpf(Sc));
-                }
-                cnt += __popc(wps);
-                if (tiny) {   // rare
-                    const float2 fix = pair_logspace_redo(L, pq, h, w, d, PC, r, c, pi, pp, wps, wps);
-                    num += fix.x; acc = fix.y;
-                }
-                out[e] = acc;
-            }
-        } else
+        for (int dy = -1; dy <= 1; ++dy) { const int r2 = r + dy * d; rin[dy + 1] = (r2 >= 0 && r2 < h) ? 1u : 0u; }
     #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int c = c0 + lcx + 32 * e;
             if (r < ib.dil.r0 || r >= ib.dil.r1 || c < ib.dil.c0 || c >= ib.dil.c1) continue;
-            uint32_t cfl[3];
+            uint32_t cin[3];
     #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int c2 = c + dx * d;
-                const uint32_t in = (c2 >= 0 && c2 < w) ? 1u : 0u;
-                cfl[dx + 1] = in | ((c2 >= ib.box.c0 && c2 < ib.box.c1) ? 2u : 0u) | ((in && c2 * a.stride + half < vc) ? 4u : 0u);
-            }
+            for (int dx = -1; dx <= 1; ++dx) { const int c2 = c + dx * d; cin[dx + 1] = (c2 >= 0 && c2 < w) ? 1u : 0u; }
             const int pi = (lr + d) * PC + (lcx + 32 * e + PAD);
             const float2 pp = pq[pi];
-            const uint32_t fp_ = rfl[1] & cfl[1];                       // flags of p itself
-            const bool in_p = (fp_ & 2u) != 0u, val_p = (fp_ & 4u) != 0u;
-            const uint32_t bits_p = FROM_LAB ? 0u : bits[pi];
-            float L0 = 0.f, A0 = 0.f, B0 = 0.f;
-            if (FROM_LAB) { L0 = labs[pi]; A0 = labs[PR * PC + pi]; B0 = labs[2 * PR * PC + pi]; }
-            float2 nq[8]; float nL[8], nA[8], nB[8]; uint32_t nbw[8];
+            const uint32_t bits_p = bits[pi];
+            float2 nq[8]; uint32_t nbw[8];
             {
                 int k = 0;
     #pragma unroll
@@ -671,8 +546,7 @@ __device__ __forceinline__ void box_body(const InstArgs& a, const float* __restr
                         if (dx == 0 && dy == 0) continue;
                         const int qi = pi + dy * d * PC + dx * d;
                         nq[k] = pq[qi];
-                        if (FROM_LAB) { nL[k] = labs[qi]; nA[k] = labs[PR * PC + qi]; nB[k] = labs[2 * PR * PC + qi]; }
-                        else nbw[k] = bits[qi];
+                        nbw[k] = bits[qi];
                         ++k;
                     }
             }
@@ -686,19 +560,9 @@ __device__ __forceinline__ void box_body(const InstArgs& a, const float* __restr
     #pragma unroll
                 for (int dx = -1; dx <= 1; ++dx) {
                     if (dx == 0 && dy == 0) continue;
-                    const uint32_t fq = rfl[dy + 1] & cfl[dx + 1];          // bit0 in map, bit1 in box, bit2 valid
-                    const bool inb = (fq & 1u) != 0u;
-                    uint32_t wp, wq;
-                    if (FROM_LAB) {
-                        const float dL = L0 - nL[k], dA = A0 - nA[k], dB = B0 - nB[k];
-                        const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(dL, dL), __fmul_rn(dA, dA)), __fmul_rn(dB, dB));
-                        const uint32_t pn = n2 <= pr.n2max ? 1u : 0u;
-                        wp = in_p ? ((fq & 4u) ? pn : (uint32_t)pr.zero_bit) : 0u;           // padded / masked-out q: sim == 0
-                        wq = ((fq & 3u) == 3u) ? (val_p ? pn : (uint32_t)pr.zero_bit) : 0u;
-                    } else {
-                        wp = (bits_p >> k) & 1u;
-                        wq = inb ? (nbw[k] >> (7 - k)) & 1u : 0u;
-                    }
+                    const bool inb = (rin[dy + 1] & cin[dx + 1]) != 0u;
+                    const uint32_t wp = (bits_p >> k) & 1u;
+                    const uint32_t wq = inb ? (nbw[k] >> (7 - k)) & 1u : 0u;
                     cnt += (int)wp;                                          // weights.sum(), :1328 (counts padded pairs too)
                     wps |= wp << k; wqs |= wq << k;
                     const float fw = inb ? (float)(wp + wq) : 0.f, fp = inb ? (float)wp : 0.f;
@@ -716,12 +580,6 @@ __device__ __forceinline__ void box_body(const InstArgs& a, const float* __restr
             out[e] = acc;
         }
         BXI_T(1, blockIdx.x, 4);
-#ifdef BXI_TRACE
-        if (tid == 0 && g_trace && blockIdx.x < kTraceBlocks)   // slot 7: active pixels of the tile, interior flag, XCC id
-            g_trace[((size_t)1 * kTraceBlocks + blockIdx.x) * kTracePhases + 7] =
-                (long long)(max(0, min(r0 + kBR, ib.dil.r1) - max(r0, ib.dil.r0)) * max(0, min(c0 + kBC, ib.dil.c1) - max(c0, ib.dil.c0))) |
-                ((long long)interior << 20) | ((long long)__smid() << 24);
-#endif
         // ---- per-instance accumulators: integers, so the result does not depend on the arrival order --------
         num = wave_sum_f32(num);
         cnt = wave_sum_i32(cnt);
@@ -748,24 +606,17 @@ __device__ __forceinline__ void box_body(const InstArgs& a, const float* __restr
 }
 
 // Two builds of the same body.  The default one (3 waves per SIMD, no spills) serves launches in which a tile workgroup
-// handles one tile (BASELINE: 32 instances): there the per-tile chain is the launch.  With hundreds of instances every
-// workgroup loops over many tiles and the launch is throughput bound: 4 waves per SIMD hide more of each chain and win
-// in spite of 4 spilled dwords (measured: 41 -> 34 us at 128 instances, 145 -> 114 us at 512; 5 waves per SIMD need 32
-// spilled dwords and lose: 155 us).  The default build instead prefetches the next tile's raw data (16 VGPRs) during the
-// pair loop, worth 4-5 % when it loops; in the 4-wave build those registers would be spilled, so it does not.
-template <bool FROM_LAB>
-__global__ __launch_bounds__(256) void box_kernel(InstArgs a, const float* __restrict__ lab, ImageMeta meta,
-                                                  const uint8_t* __restrict__ bits_in, float thresh, int dil, float warmup,
-                                                  LossWs ws, LossState st, float* __restrict__ losses,
-                                                  float* __restrict__ g_logits, int vec) {
-    box_body<FROM_LAB, true>(a, lab, meta, bits_in, thresh, dil, warmup, ws, st, losses, g_logits, vec);
+// handles one tile: there the per-tile chain is the launch.  With hundreds of instances every workgroup loops over many tiles
+// and the launch is throughput bound: 4 waves per SIMD hide more of each chain.  The default build instead prefetches the
+// next tile's raw data during the pair loop, worth 4-5 % when it loops.
+__global__ __launch_bounds__(256) void box_kernel(InstArgs a, const uint8_t* __restrict__ bits_in, int dil, float warmup, LossWs ws,
+                                                  LossState st, float* __restrict__ losses, float* __restrict__ g_logits, int vec) {
+    box_body<true>(a, bits_in, dil, warmup, ws, st, losses, g_logits, vec);
 }
-template <bool FROM_LAB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
-void box_kernel_dense(InstArgs a, const float* __restrict__ lab, ImageMeta meta, const uint8_t* __restrict__ bits_in, float thresh,
-                      int dil, float warmup, LossWs ws, LossState st, float* __restrict__ losses, float* __restrict__ g_logits,
-                      int vec) {
-    box_body<FROM_LAB, false>(a, lab, meta, bits_in, thresh, dil, warmup, ws, st, losses, g_logits, vec);
+void box_kernel_dense(InstArgs a, const uint8_t* __restrict__ bits_in, int dil, float warmup, LossWs ws, LossState st,
+                      float* __restrict__ losses, float* __restrict__ g_logits, int vec) {
+    box_body<false>(a, bits_in, dil, warmup, ws, st, losses, g_logits, vec);
 }
 
 // ================================================================================================
@@ -869,18 +720,16 @@ int fill_inst(const bxi_instances* in, InstArgs& a) {
     return BXI_OK;
 }
 
-static size_t box_lds_bytes(int dil, bool from_lab) {
+static size_t box_lds_bytes(int dil) {
     const size_t PAD = (dil + 3) & ~3;
     const size_t PR = kBR + 2 * dil, PC = kBC + 2 * PAD;
-    return sizeof(float2) * PR * PC + (from_lab ? sizeof(float) * 3 * PR * PC : PR * PC);
+    return sizeof(float2) * PR * PC + PR * PC;
 }
 
-
-// One evaluation.  batch != NULL: image side included (lab is a [B,3,h,w] f32 scratch the pool
-// workgroups fill and box_kernel reads).  batch == NULL: `affinity` bits are given.
-int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, const bxi_instances* in,
-                const uint8_t* affinity, int size, int dil, float warmup, float* losses, float* g_logits, void* state,
-                void* workspace, size_t workspace_bytes, void* stream) {
+// One evaluation from precomputed affinity bits: stage1 (tables + logit streaming) -> box (leaders + box tiles);
+// bxi_boxinst_loss_backward_f32 (loss_apply) finishes the gradient.
+int launch_loss(const bxi_instances* in, const uint8_t* affinity, int size, int dil, float warmup, float* losses, float* g_logits,
+                void* state, void* workspace, size_t workspace_bytes, void* stream) {
     InstArgs a;
     int rc = fill_inst(in, a);
     if (rc != BXI_OK) return rc;
@@ -888,22 +737,11 @@ int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, co
     if (size != 3 || dil > kMaxDil) return BXI_ERR_UNSUPPORTED;
     if (!losses) return BXI_ERR_NULL_POINTER;
     hipStream_t s = as_stream(stream);
-    PoolArgs pa = {};
-    ImageMeta meta = {};
-    const bool from_lab = batch != nullptr;
-    if (from_lab) {
-        if (batch->Hc != in->Hc || batch->Wc != in->Wc || batch->B != in->B) return BXI_ERR_BAD_SHAPE;
-        rc = fill_pool_args(batch, nullptr, lab, pa);
-        if (rc != BXI_OK) return rc;
-        meta = pa.meta;
-        if (batch->B > 0 && (!batch->imgs || !lab)) return BXI_ERR_NULL_POINTER;
-        if (batch->image_masks) return BXI_ERR_UNSUPPORTED;   // explicit masks: use bxi_color_affinity_f32 + bits
-    }
     if (a.N == 0) {
         BXI_LAUNCH("zero_losses", s, zero_losses_kernel, dim3(1), dim3(1), 0, s, losses);
         return check_launch();
     }
-    if (!from_lab && !affinity) return BXI_ERR_NULL_POINTER;
+    if (!affinity) return BXI_ERR_NULL_POINTER;
     if (a.N > 65535) return BXI_ERR_BAD_SHAPE;
     const size_t need = carve_ws(nullptr, a.N, a.h, a.w, nullptr);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
@@ -915,51 +753,29 @@ int launch_loss(const bxi_image_batch* batch, float* lab, float color_thresh, co
         carve_state(state, a.N, a.h, a.w, &st);
     }
     const int vec = ((a.w & 3) == 0 && (reinterpret_cast<uintptr_t>(a.logits) & 15) == 0 &&
-                     (!g_logits || (reinterpret_cast<uintptr_t>(g_logits) & 15) == 0) &&
-                     (!lab || (reinterpret_cast<uintptr_t>(lab) & 15) == 0)) ? 1 : 0;
+                     (!g_logits || (reinterpret_cast<uintptr_t>(g_logits) & 15) == 0)) ? 1 : 0;
 
-    // ---- kernel 1: image pooling/Lab workgroups + logit streaming workgroups in one launch -----------
-    int n_pool = 0;
-    if (from_lab && batch->B > 0) {
-        if (pool_vec_ok(batch, a.stride)) {
-            const int64_t total = (int64_t)batch->B * a.h * a.w;
-            n_pool = (int)((total + 63) / 64);
-        } else {                           // unaligned canvas / other strides: separate scalar pooling launch
-            rc = launch_pool(batch, a.stride, nullptr, lab, s);
-            if (rc != BXI_OK) return rc;
-        }
-    }
+    // ---- kernel 1: table waves + logit streaming waves ----------------------------------------------------
     const int n_stream = a.N * stream_tiles(a.h);
-    BXI_LAUNCH("stage1", s, stage1_kernel, dim3((unsigned)(a.N + n_pool + n_stream)), dim3(64), 0, s, pa, n_pool, a,
-               dil, color_thresh, ws, g_logits, vec);
+    BXI_LAUNCH("stage1", s, stage1_kernel, dim3((unsigned)(a.N + n_stream)), dim3(64), 0, s, a, dil, ws, g_logits, vec);
     rc = check_launch();
     if (rc != BXI_OK) return rc;
 
     // ---- kernel 2: N leader workgroups (projection term) + the box tiles (pairwise term) ------------------
-    size_t lds = box_lds_bytes(dil, from_lab);
+    size_t lds = box_lds_bytes(dil);
     const size_t lds_leader = sizeof(float) * (size_t)(a.h + a.w);
     if (lds < lds_leader) lds = lds_leader;
     if (lds > 160 * 1024) return BXI_ERR_UNSUPPORTED;
     const int n_tiles = a.N * box_tiles(a.h, a.w);
     const bool dense = n_tiles > 6400;         // more than ~2 tiles per tile workgroup (see box_kernel_dense)
     if (lds > 64 * 1024) {
-        const void* fn = from_lab ? (dense ? reinterpret_cast<const void*>(box_kernel_dense<true>) : reinterpret_cast<const void*>(box_kernel<true>))
-                                  : (dense ? reinterpret_cast<const void*>(box_kernel_dense<false>) : reinterpret_cast<const void*>(box_kernel<false>));
+        const void* fn = dense ? reinterpret_cast<const void*>(box_kernel_dense) : reinterpret_cast<const void*>(box_kernel);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }
     }
     const int n_box = a.N + (n_tiles < 1024 ? n_tiles : 1024);   // list length is device data: stride through it
-    if (from_lab) {
-        if (dense) BXI_LAUNCH("box", s, (box_kernel_dense<true>), dim3((unsigned)n_box), dim3(256), lds, s, a, (const float*)lab, meta,
-                              (const uint8_t*)nullptr, color_thresh, dil, warmup, ws, st, losses, g_logits, vec);
-        else BXI_LAUNCH("box", s, (box_kernel<true>), dim3((unsigned)n_box), dim3(256), lds, s, a, (const float*)lab, meta,
-                        (const uint8_t*)nullptr, color_thresh, dil, warmup, ws, st, losses, g_logits, vec);
-    } else {
-        if (dense) BXI_LAUNCH("box", s, (box_kernel_dense<false>), dim3((unsigned)n_box), dim3(256), lds, s, a, (const float*)nullptr,
-                              meta, affinity, 0.f, dil, warmup, ws, st, losses, g_logits, vec);
-        else BXI_LAUNCH("box", s, (box_kernel<false>), dim3((unsigned)n_box), dim3(256), lds, s, a, (const float*)nullptr,
-                        meta, affinity, 0.f, dil, warmup, ws, st, losses, g_logits, vec);
-    }
+    if (dense) BXI_LAUNCH("box", s, box_kernel_dense, dim3((unsigned)n_box), dim3(256), lds, s, a, affinity, dil, warmup, ws, st, losses, g_logits, vec);
+    else BXI_LAUNCH("box", s, box_kernel, dim3((unsigned)n_box), dim3(256), lds, s, a, affinity, dil, warmup, ws, st, losses, g_logits, vec);
     return check_launch();
 }
 
@@ -1013,8 +829,7 @@ size_t bxi_boxinst_loss_state_status_offset(int N, int h, int w) {
 int bxi_boxinst_loss_fwd_bwd_f32(const bxi_instances* inst_host, const uint8_t* affinity, int size, int dilation,
                                  float warmup, float* losses, float* g_logits, void* state, void* workspace,
                                  size_t workspace_bytes, void* stream) {
-    return bxi::launch_loss(nullptr, nullptr, 0.f, inst_host, affinity, size, dilation, warmup, losses, g_logits, state,
-                            workspace, workspace_bytes, stream);
+    return bxi::launch_loss(inst_host, affinity, size, dilation, warmup, losses, g_logits, state, workspace, workspace_bytes, stream);
 }
 
 int bxi_boxinst_loss_backward_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw, int dilation,
