@@ -296,53 +296,6 @@ __global__ __launch_bounds__(1024) void lcm_refine_lds_kernel(const float* __res
     for (int p = tid; p < hw; p += 1024) out[(int64_t)n * hw + p] = cur[p];
 }
 
-// Maps of at most kLcmPPT * kLcmThreads pixels (96 x 96 in the reference): as above, and the 8 coefficients of a
-// thread's pixels stay in registers for all iterations (they do not change) -- forward: aff_k at the pixel itself;
-// adjoint: aff_k at the source pixel q - delta_k.  Pixels of the adjoint whose sources are folded by the replicate
-// padding (within `d` of a border) take the enumerating path in a second sweep.
-constexpr int kLcmThreads = 512;     // 8 waves: 256 VGPRs per lane for the coefficients
-constexpr int kLcmPPT = 18;          // pixels per thread: 18 x 512 = 96 x 96
-
-__global__ __launch_bounds__(kLcmThreads) void lcm_refine_cached_kernel(const float* __restrict__ aff, const float* __restrict__ phi,
-                                                                        int h, int w, int d, int iters, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float lcm_planes[];   // [2][h*w]
-    const int n = blockIdx.x, tid = threadIdx.x, hw = h * w;
-    float* cur = lcm_planes;
-    float* nxt = lcm_planes + hw;
-    const float* A = aff + (int64_t)n * 8 * hw;
-    float coef[kLcmPPT][8];
-    int rc[kLcmPPT];            // r << 16 | c ; -1: no pixel
-#pragma unroll
-    for (int j = 0; j < kLcmPPT; ++j) {
-        const int p = tid + j * kLcmThreads;
-        rc[j] = -1;
-        if (p < hw) {
-            cur[p] = phi[(int64_t)n * hw + p];
-            rc[j] = ((p / w) << 16) | (p % w);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) coef[j][k] = A[(int64_t)k * hw + p];
-        }
-    }
-    __syncthreads();
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int j = 0; j < kLcmPPT; ++j) {
-            if (rc[j] == -1) continue;
-            const int r = rc[j] >> 16, c = rc[j] & 0xffff;
-            float acc = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                int dy, dx; lcm_offset(k, dy, dx);
-                acc += coef[j][k] * cur[min(max(r + dy * d, 0), h - 1) * w + min(max(c + dx * d, 0), w - 1)];
-            }
-            nxt[tid + j * kLcmThreads] = acc;
-        }
-        __syncthreads();
-        float* t = cur; cur = nxt; nxt = t;
-    }
-    for (int p = tid; p < hw; p += kLcmThreads) out[(int64_t)n * hw + p] = cur[p];
-}
-
 // The adjoint, all iterations in one launch.  The forward operator reads a replicate-padded plane:
 // out[p] = sum_k aff_k[p] * pad(phi)[p + delta_k + d].  Its adjoint is therefore (a) an 8-tap gather on the PADDED
 // domain with no clamping, gp[s] = sum_k aff_k[p_k] g[p_k], p_k = s - d - delta_k (skipped outside the map), followed by
@@ -386,98 +339,154 @@ __global__ __launch_bounds__(1024) void lcm_adjoint_lds_kernel(const float* __re
     for (int p = tid; p < hw; p += 1024) gphi[(int64_t)n * hw + p] = g[p];
 }
 
-// The adjoint for maps of at most kLcmPPT * kLcmThreads pixels, coefficients in registers: the SCATTER form.  The forward
-// reads pad(phi)[p + delta_k] with coefficient aff_k[p], so the adjoint adds aff_k[p] g[p] to padded position p + delta_k: for
-// a fixed tap k no two pixels hit the same position, so the eight taps are eight barrier-separated passes of plain LDS
-// read-modify-writes (no atomics; a position accumulates its terms in tap order, exactly like the gather above), with the
-// thread's own coefficients and g values in registers -- no global traffic inside the iterations (the gather re-reads the
-// eight coefficient planes from L2 every iteration: 144 us -> see DESIGN 3.7).
-constexpr int kLcmAdjThreads = 1024;  // 9 pixels per thread: 72 coefficient registers
-constexpr int kLcmAdjPPT = 9;
-constexpr int kLcmBorderPer = 1;       // border pixels per thread: 2h + 2w - 4 <= 1024 is checked on the host
+// ---- padded maps of at most kLcmPadSPT * 1024 positions (96 x 96, d = 2 in the reference), all iterations in one launch ----
+// Both directions work on REPLICATE-PADDED planes in LDS, so a tap is `plane[base + constant]`: no clamping arithmetic in
+// the iterations (the clamps were most of the instructions: 8 taps x 18 pixels x ~8 integer operations a thread and
+// iteration).  The 8 coefficients of a thread's positions stay in registers for all iterations.  H, W, D > 0 fix the shape
+// at compile time (the tap offsets become instruction immediates); 0 = run-time shape.
+constexpr int kLcmPadThreads = 1024;
+constexpr int kLcmPadSPT = 10;         // padded positions per thread: 10 x 1024 >= 100 x 100
 
-__global__ __launch_bounds__(kLcmAdjThreads) void lcm_adjoint_cached_kernel(const float* __restrict__ aff, const float* __restrict__ gout,
-                                                                         int h, int w, int d, int iters, float* __restrict__ gphi) {
-    extern __shared__ __attribute__((aligned(16))) float lcm_planes[];   // g [h*w] | gp [(h+2d)*(w+2d)]
-    const int n = blockIdx.x, tid = threadIdx.x, hw = h * w, hp = h + 2 * d, wp = w + 2 * d;
-    float* g = lcm_planes;
-    float* gp = lcm_planes + hw;
+// the padded positions that replicate pixel (r, c): rows [rlo, rhi] x columns [clo, chi] of the (h + 2d) x (w + 2d) plane
+__device__ __forceinline__ void lcm_replicas(int r, int c, int h, int w, int d, int& rlo, int& rhi, int& clo, int& chi) {
+    rlo = r == 0 ? 0 : r + d; rhi = r == h - 1 ? h + 2 * d - 1 : r + d;
+    clo = c == 0 ? 0 : c + d; chi = c == w - 1 ? w + 2 * d - 1 : c + d;
+}
+
+// Forward: EVERY position of the padded plane is computed (a padding cell repeats the arithmetic of the pixel it replicates:
+// 8.5 % more work at 96 x 96, d = 2), so the iterations carry no border case and one barrier each.
+template <int H, int W, int D>
+__global__ __launch_bounds__(kLcmPadThreads) void lcm_refine_pad_kernel(const float* __restrict__ aff, const float* __restrict__ phi,
+                                                                        int h_, int w_, int d_, int iters, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lcm_planes[];   // [2][(h + 2d) * (w + 2d)]
+    const int h = H ? H : h_, w = W ? W : w_, d = D ? D : d_;
+    const int n = blockIdx.x, tid = threadIdx.x, hw = h * w, hp = h + 2 * d, wp = w + 2 * d, hpwp = hp * wp;
+    float* cur = lcm_planes;
+    float* nxt = lcm_planes + hpwp;
     const float* A = aff + (int64_t)n * 8 * hw;
-    float coef[kLcmAdjPPT][8];
-    int sp[kLcmAdjPPT];            // position of the pixel in the padded plane; -1: no pixel
-    unsigned border = 0;           // bit j: pixel j lies on the first / last row or column (its padding folds back onto it)
+    float coef[kLcmPadSPT][8];
+    int base[kLcmPadSPT];           // padded index of the top-left tap of the pixel this position replicates; -1: no position
 #pragma unroll
-    for (int j = 0; j < kLcmAdjPPT; ++j) {
-        const int p = tid + j * kLcmAdjThreads;
-        sp[j] = -1;
-        if (p < hw) {
-            const int r = p / w, c = p % w;
-            g[p] = gout[(int64_t)n * hw + p];
-            sp[j] = (r + d) * wp + c + d;
-            if (r == 0 || r == h - 1 || c == 0 || c == w - 1) border |= 1u << j;
+    for (int j = 0; j < kLcmPadSPT; ++j) {
+        const int s = tid + j * kLcmPadThreads;
+        base[j] = -1;
+        if (s < hpwp) {
+            const int r = min(max(s / wp - d, 0), h - 1), c = min(max(s % wp - d, 0), w - 1);     // replicate padding (:99)
+            base[j] = r * wp + c;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) coef[j][k] = A[(int64_t)k * hw + p];
-        }
-    }
-    // tap 0 (dy = dx = -1) lands on padded rows [0, h) x columns [0, w) and STORES there; the rest of the padded plane (the
-    // last 2d rows and columns, fewer positions than threads at 96 x 96) is zeroed in the same phase: no clearing pass
-    const int n_clear = hp * wp - hw, rows_part = 2 * d * wp;
-    // border pixel number e * threads + tid of the perimeter walk: top row, bottom row, then the two side columns
-    int bq[kLcmBorderPer], b_r[kLcmBorderPer], b_c[kLcmBorderPer];
-#pragma unroll
-    for (int e = 0; e < kLcmBorderPer; ++e) {
-        const int t = tid + e * kLcmAdjThreads, n_border = 2 * w + 2 * max(h - 2, 0);
-        bq[e] = -1; b_r[e] = 0; b_c[e] = 0;
-        if (t < n_border && (h > 1 || t < w)) {
-            int r, c;
-            if (t < w) { r = 0; c = t; }
-            else if (t < 2 * w) { r = h - 1; c = t - w; }
-            else { const int u = t - 2 * w; r = 1 + (u >> 1); c = (u & 1) ? w - 1 : 0; }
-            if (!(w == 1 && t >= 2 * w && (t & 1))) {               // a one-column map: the two side columns coincide
-                bq[e] = r * w + c;
-                b_r[e] = (r == 0 ? 0 : r + d) | ((r == h - 1 ? hp - 1 : r + d) << 16);
-                b_c[e] = (c == 0 ? 0 : c + d) | ((c == w - 1 ? wp - 1 : c + d) << 16);
-            }
+            for (int k = 0; k < 8; ++k) coef[j][k] = A[(int64_t)k * hw + r * w + c];
+            cur[s] = phi[(int64_t)n * hw + r * w + c];
         }
     }
     __syncthreads();
     for (int it = 0; it < iters; ++it) {
-        for (int s = tid; s < n_clear; s += kLcmAdjThreads)
-            gp[s < rows_part ? h * wp + s : ((s - rows_part) / (2 * d)) * wp + w + (s - rows_part) % (2 * d)] = 0.f;
-        float gv[kLcmAdjPPT];
 #pragma unroll
-        for (int j = 0; j < kLcmAdjPPT; ++j) gv[j] = sp[j] == -1 ? 0.f : g[tid + j * kLcmAdjThreads];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            int dy, dx; lcm_offset(k, dy, dx);
-            int off = dy * d * wp + dx * d;
-            asm volatile("" : "+s"(off));      // keeps the (pixel, tap) addresses from being hoisted out of the iterations: spills
-            // within one tap the targets are distinct: all reads first, then all writes (written as `+=` per pixel the
-            // compiler must assume aliasing and waits for every LDS round trip in turn)
-            float old[kLcmAdjPPT];
-#pragma unroll
-            for (int j = 0; j < kLcmAdjPPT; ++j) old[j] = (k == 0 || sp[j] == -1) ? 0.f : gp[sp[j] + off];
-#pragma unroll
-            for (int j = 0; j < kLcmAdjPPT; ++j)
-                if (sp[j] != -1) gp[sp[j] + off] = old[j] + coef[j][k] * gv[j];
-            __syncthreads();
-        }
-        // fold the replicate padding back: an interior pixel reads its one padded position (its owner does that); the
-        // 2h + 2w - 4 border pixels sum the padded positions that replicate them (rows / columns ascending, as the gather
-        // kernel does), one border pixel per thread, ranges computed once before the iterations
-#pragma unroll
-        for (int j = 0; j < kLcmAdjPPT; ++j)
-            if (sp[j] != -1 && !((border >> j) & 1u)) g[tid + j * kLcmAdjThreads] = 0.f + gp[sp[j]];
-        for (int e = 0; e < kLcmBorderPer; ++e) {
-            if (bq[e] < 0) continue;
+        for (int j = 0; j < kLcmPadSPT; ++j) {
+            if (base[j] < 0) continue;
             float acc = 0.f;
-            for (int sr = b_r[e] & 0xffff; sr <= (b_r[e] >> 16); ++sr)
-                for (int sc = b_c[e] & 0xffff; sc <= (b_c[e] >> 16); ++sc) acc += gp[sr * wp + sc];
-            g[bq[e]] = acc;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int dy, dx; lcm_offset(k, dy, dx);
+                acc += coef[j][k] * cur[base[j] + (dy + 1) * d * wp + (dx + 1) * d];
+            }
+            nxt[tid + j * kLcmPadThreads] = acc;
+        }
+        __syncthreads();
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    for (int p = tid; p < hw; p += kLcmPadThreads) out[(int64_t)n * hw + p] = cur[(p / w + d) * wp + p % w + d];
+}
+
+// The adjoint.  The forward reads pad(phi)[p + delta_k] with coefficient aff_k[p]; its adjoint is (a) a gather on the PADDED
+// domain, gp[s] = sum_k aff_k[p_k] g[p_k] with p_k = s - d - delta_k (nothing where p_k falls outside the map), and (b)
+// folding the padding back, g'[q] = sum of gp over the padded positions that replicate q (rows, then columns, ascending).
+// The transposed coefficients aff_k[p_k(s)] of a thread's padded positions are fetched once; g lives in a ZERO-padded plane
+// (2d on every side), so (a) is again `plane[base + constant]` without a branch.  Summation orders = lcm_adjoint_lds_kernel's.
+template <int H, int W, int D>
+__global__ __launch_bounds__(kLcmPadThreads) void lcm_adjoint_pad_kernel(const float* __restrict__ aff, const float* __restrict__ gout,
+                                                                         int h_, int w_, int d_, int iters, float* __restrict__ gphi) {
+    extern __shared__ __attribute__((aligned(16))) float lcm_planes[];   // gz [(h + 4d) * (w + 4d)] | gp [(h + 2d) * (w + 2d)]
+    const int h = H ? H : h_, w = W ? W : w_, d = D ? D : d_;
+    const int n = blockIdx.x, tid = threadIdx.x, hw = h * w, hp = h + 2 * d, wp = w + 2 * d, wq = w + 4 * d, nq = (h + 4 * d) * wq;
+    float* gz = lcm_planes;
+    float* gp = lcm_planes + nq;
+    const float* A = aff + (int64_t)n * 8 * hw;
+    for (int i = tid; i < nq; i += kLcmPadThreads) gz[i] = 0.f;
+    float coef[kLcmPadSPT][8];
+    int sbase[kLcmPadSPT];          // index into gz of the top-left-most source of padded position s; -1: no position
+#pragma unroll
+    for (int j = 0; j < kLcmPadSPT; ++j) {
+        const int s = tid + j * kLcmPadThreads;
+        sbase[j] = -1;
+        if (s < hp * wp) {
+            const int sr = s / wp, sc = s % wp;
+            // source of tap k: pixel (sr - (dy + 1) d, sc - (dx + 1) d); in gz (shifted by 2d): (sr + (1 - dy) d, sc + (1 - dx) d)
+            sbase[j] = sr * wq + sc;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int dy, dx; lcm_offset(k, dy, dx);
+                const int pr = sr - (dy + 1) * d, pc = sc - (dx + 1) * d;
+                const bool in = pr >= 0 && pr < h && pc >= 0 && pc < w;
+                coef[j][k] = in ? A[(int64_t)k * hw + pr * w + pc] : 0.f;
+            }
+        }
+    }
+    // fold-back bookkeeping, once: an interior pixel copies its one padded position; perimeter pixel number tid of the walk
+    // (top row, bottom row, the two side columns) sums the padded positions that replicate it
+    constexpr int kPix = kLcmPadSPT - 1;                 // pixels per thread: hw <= hp * wp - ... <= 9 x 1024 when the padded plane fits
+    int gsrc[kPix], gdst[kPix];                          // gp / gz index of an interior pixel; -1: none or perimeter
+#pragma unroll
+    for (int j = 0; j < kPix; ++j) {
+        const int p = tid + j * kLcmPadThreads;
+        gsrc[j] = -1; gdst[j] = 0;
+        if (p < hw) {
+            const int r = p / w, c = p % w;
+            if (!(r == 0 || r == h - 1 || c == 0 || c == w - 1)) { gsrc[j] = (r + d) * wp + c + d; gdst[j] = (r + 2 * d) * wq + c + 2 * d; }
+        }
+    }
+    int bdst = -1, b_r = 0, b_c = 0;
+    {
+        const int n_border = 2 * w + 2 * max(h - 2, 0);
+        if (tid < n_border && (h > 1 || tid < w)) {
+            int r, c;
+            if (tid < w) { r = 0; c = tid; }
+            else if (tid < 2 * w) { r = h - 1; c = tid - w; }
+            else { const int u = tid - 2 * w; r = 1 + (u >> 1); c = (u & 1) ? w - 1 : 0; }
+            if (!(w == 1 && tid >= 2 * w && (tid & 1))) {               // a one-column map: the two side columns coincide
+                int rlo, rhi, clo, chi;
+                lcm_replicas(r, c, h, w, d, rlo, rhi, clo, chi);
+                bdst = (r + 2 * d) * wq + c + 2 * d; b_r = rlo | (rhi << 16); b_c = clo | (chi << 16);
+            }
+        }
+    }
+    __syncthreads();                 // the zero-fill is complete before the map goes in
+    for (int p = tid; p < hw; p += kLcmPadThreads) gz[(p / w + 2 * d) * wq + p % w + 2 * d] = gout[(int64_t)n * hw + p];
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < kLcmPadSPT; ++j) {
+            if (sbase[j] < 0) continue;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int dy, dx; lcm_offset(k, dy, dx);
+                acc += coef[j][k] * gz[sbase[j] + (1 - dy) * d * wq + (1 - dx) * d];
+            }
+            gp[tid + j * kLcmPadThreads] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kPix; ++j)
+            if (gsrc[j] >= 0) gz[gdst[j]] = 0.f + gp[gsrc[j]];
+        if (bdst >= 0) {
+            float acc = 0.f;
+            for (int sr = b_r & 0xffff; sr <= (b_r >> 16); ++sr)
+                for (int sc = b_c & 0xffff; sc <= (b_c >> 16); ++sc) acc += gp[sr * wp + sc];
+            gz[bdst] = acc;
         }
         __syncthreads();
     }
-    for (int p = tid; p < hw; p += kLcmAdjThreads) gphi[(int64_t)n * hw + p] = g[p];
+    for (int p = tid; p < hw; p += kLcmPadThreads) gphi[(int64_t)n * hw + p] = gz[(p / w + 2 * d) * wq + p % w + 2 * d];
 }
 
 // any size: one launch per iteration, planes in global memory
@@ -573,11 +582,20 @@ int bxi_lcm_refine_f32(const float* aff, const float* phi, int N, int h, int w, 
         if (e != hipSuccess) { bxi::set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }
         return BXI_OK;
     };
+    const int64_t hp = h + 2 * (int64_t)dilation, wpad = w + 2 * (int64_t)dilation;
+    const size_t lds_fwd = sizeof(float) * 2 * (size_t)(hp * wpad);
+    const size_t lds_adj2 = sizeof(float) * (size_t)((h + 4 * (int64_t)dilation) * (w + 4 * (int64_t)dilation) + hp * wpad);
+    const bool ref_shape = h == 96 && w == 96 && dilation == 2;           // Box2Mask's LCM (levelset_loss.py:64-66, 96 x 96 targets)
     if (!transpose) {
-        if ((int64_t)h * w <= bxi::kLcmPPT * bxi::kLcmThreads && h < 32768 && w < 65536) {
-            const int rc = allow_lds(reinterpret_cast<const void*>(bxi::lcm_refine_cached_kernel), lds);
+        if (hp * wpad <= bxi::kLcmPadSPT * bxi::kLcmPadThreads && lds_fwd <= 128 * 1024) {
+            const void* fn = ref_shape ? reinterpret_cast<const void*>(bxi::lcm_refine_pad_kernel<96, 96, 2>)
+                                       : reinterpret_cast<const void*>(bxi::lcm_refine_pad_kernel<0, 0, 0>);
+            const int rc = allow_lds(fn, lds_fwd);
             if (rc != BXI_OK) return rc;
-            BXI_LAUNCH("lcm_refine", s, bxi::lcm_refine_cached_kernel, dim3(N), dim3(bxi::kLcmThreads), lds, s, aff, phi, h, w, dilation, iters, out);
+            if (ref_shape)
+                BXI_LAUNCH("lcm_refine", s, (bxi::lcm_refine_pad_kernel<96, 96, 2>), dim3(N), dim3(bxi::kLcmPadThreads), lds_fwd, s, aff, phi, h, w, dilation, iters, out);
+            else
+                BXI_LAUNCH("lcm_refine", s, (bxi::lcm_refine_pad_kernel<0, 0, 0>), dim3(N), dim3(bxi::kLcmPadThreads), lds_fwd, s, aff, phi, h, w, dilation, iters, out);
             return bxi::check_launch();
         }
         if (lds <= 128 * 1024) {
@@ -588,11 +606,16 @@ int bxi_lcm_refine_f32(const float* aff, const float* phi, int N, int h, int w, 
         }
     } else {
         const size_t lds_adj = sizeof(float) * ((size_t)h * w + (size_t)(h + 2 * dilation) * (w + 2 * dilation));
-        if ((int64_t)h * w <= bxi::kLcmAdjPPT * bxi::kLcmAdjThreads && lds_adj <= 128 * 1024 && h >= 2 && w >= 2 &&
-            2 * h + 2 * w - 4 <= bxi::kLcmBorderPer * bxi::kLcmAdjThreads) {
-            const int rc = allow_lds(reinterpret_cast<const void*>(bxi::lcm_adjoint_cached_kernel), lds_adj);
+        if (hp * wpad <= bxi::kLcmPadSPT * bxi::kLcmPadThreads && (int64_t)h * w <= (bxi::kLcmPadSPT - 1) * bxi::kLcmPadThreads &&
+            2 * (int64_t)w + 2 * (h > 2 ? h - 2 : 0) <= bxi::kLcmPadThreads && lds_adj2 <= 128 * 1024) {
+            const void* fn = ref_shape ? reinterpret_cast<const void*>(bxi::lcm_adjoint_pad_kernel<96, 96, 2>)
+                                       : reinterpret_cast<const void*>(bxi::lcm_adjoint_pad_kernel<0, 0, 0>);
+            const int rc = allow_lds(fn, lds_adj2);
             if (rc != BXI_OK) return rc;
-            BXI_LAUNCH("lcm_adjoint", s, bxi::lcm_adjoint_cached_kernel, dim3(N), dim3(bxi::kLcmAdjThreads), lds_adj, s, aff, phi, h, w, dilation, iters, out);
+            if (ref_shape)
+                BXI_LAUNCH("lcm_adjoint", s, (bxi::lcm_adjoint_pad_kernel<96, 96, 2>), dim3(N), dim3(bxi::kLcmPadThreads), lds_adj2, s, aff, phi, h, w, dilation, iters, out);
+            else
+                BXI_LAUNCH("lcm_adjoint", s, (bxi::lcm_adjoint_pad_kernel<0, 0, 0>), dim3(N), dim3(bxi::kLcmPadThreads), lds_adj2, s, aff, phi, h, w, dilation, iters, out);
             return bxi::check_launch();
         }
         if (lds_adj <= 128 * 1024) {

@@ -269,39 +269,51 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------
-// mil_loss (:552-562): state = [N][ argc i32[W] | argr i32[H] | gcol f32[W] | grow f32[H] ]
-// One workgroup (16 waves) per instance, one pass over the map: a wave takes 4 rows at a time, lanes over the columns
-// (all 4 x ceil(W/64) x 2 loads of a step are independent); row maxima by wave reductions of packed (value, first
-// column) keys, column maxima by 64-bit LDS atomic max of packed (value, first row) keys -- max is order-independent,
-// so the result is deterministic.
+// mil_loss (:552-562): state = [N][ argc i32[W] | argr i32[H] | gcol f32[W] | grow f32[H] ] followed by scratch of the
+// forward.  Two launches so that the whole GPU reads the maps (one workgroup per instance kept 16 CUs busy: 28 us):
+//   mil_band_kernel   grid (bands of 16 rows, N): a wave takes 4 rows, lanes over the columns (all 4 x kCT x 2 loads of a step
+//                     are independent); row maxima (complete) by wave reductions of packed (value, first column) keys,
+//                     column maxima of the band by 64-bit LDS atomic max of packed (value, first row) keys -- max is
+//                     order-independent, so the result is deterministic -- written as per-band partials;
+//   mil_finish_kernel one workgroup per instance: combines the column partials, the four dice sums in fp64 (fixed order),
+//                     loss, unit gradients, arg-max positions.
 // eps = what the two dice denominators carry in total (mil_loss/dice_loss: 0.001 + 0.001; BoxProjectionLoss: 1e-5),
 // weight = loss_weight (folded into the loss and the unit gradients)
-__global__ __launch_bounds__(1024) void mil_fwd_kernel(const float* __restrict__ in, const void* __restrict__ tg, int t_u8,
-                                                       int H, int W, double eps, double weight, float* __restrict__ loss,
-                                                       int* __restrict__ state) {
+constexpr int kMilBandRows = 16;       // 4 waves x 4 rows
+
+struct MilScratch { u64* colkey; uint32_t* coltk; float* rowv; float* rowt; };   // [N][nb][W] x 2, [N][H] x 2
+__host__ __device__ inline size_t mil_state_words(int H, int W) { return 2 * (size_t)(H + W); }
+__host__ __device__ inline size_t mil_carve(void* state, int N, int H, int W, MilScratch* ms) {
+    const size_t N1 = N > 0 ? N : 1, nb = (size_t)(H + kMilBandRows - 1) / kMilBandRows;
+    size_t off = (N1 * mil_state_words(H, W) * 4 + 15) & ~(size_t)15;
+    char* p = static_cast<char*>(state);
+    MilScratch t;
+    t.colkey = reinterpret_cast<u64*>(p + off); off += 8 * N1 * nb * W;
+    t.coltk = reinterpret_cast<uint32_t*>(p + off); off += 4 * N1 * nb * W;
+    t.rowv = reinterpret_cast<float*>(p + off); off += 4 * N1 * H;
+    t.rowt = reinterpret_cast<float*>(p + off); off += 4 * N1 * H;
+    if (ms) *ms = t;
+    return off;
+}
+
+__global__ __launch_bounds__(256) void mil_band_kernel(const float* __restrict__ in, const void* __restrict__ tg, int t_u8, int H, int W,
+                                                       int* __restrict__ state, MilScratch ms) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mil_raw[];
-    // colkey u64[W] | colt u32[W] (target maxima as ordered keys) | rowv f32[H] | rowt f32[H]
-    u64* colkey = reinterpret_cast<u64*>(mil_raw);
-    uint32_t* coltk = reinterpret_cast<uint32_t*>(colkey + W);
-    float* rowv = reinterpret_cast<float*>(coltk + W);
-    float* rowt = rowv + H;
-    __shared__ double red[64];
-    const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    u64* colkey = reinterpret_cast<u64*>(mil_raw);                   // [W]
+    uint32_t* coltk = reinterpret_cast<uint32_t*>(colkey + W);       // [W] target maxima as ordered keys
+    const int band = blockIdx.x, n = blockIdx.y, nb = gridDim.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t HW = (int64_t)H * W;
     const float* x = in + (int64_t)n * HW;
-    int* argc = state + (int64_t)n * 2 * (H + W);
-    int* argr = argc + W;
-    float* gcol = reinterpret_cast<float*>(argr + H);
-    float* grow = gcol + W;
-    for (int c = tid; c < W; c += 1024) { colkey[c] = 0ull; coltk[c] = 0u; }
+    int* argr = state + (int64_t)n * mil_state_words(H, W) + W;
+    for (int c = tid; c < W; c += 256) { colkey[c] = 0ull; coltk[c] = 0u; }
     __syncthreads();
     constexpr int R = 4;
-    for (int rb = wave * R; rb < H; rb += 16 * R) {
+    const int rb = band * kMilBandRows + wave * R;
+    if (rb < H) {
         u64 rkey[R]; float rt[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) { rkey[i] = 0ull; rt[i] = -INFINITY; }
-        // kCT column trips (4 rows x 2 arrays each) are loaded before any of them is consumed: trip by trip, each one waits
-        // out a full memory latency behind the previous trip's LDS atomics (27 -> see DESIGN 3.6).  Columns past the end
+        // kCT column trips (4 rows x 2 arrays each) are loaded before any of them is consumed.  Columns / rows past the end
         // are clamped to the last one: a duplicate changes no maximum.
         constexpr int kCT = 5;
         for (int c0 = 0; c0 < W; c0 += 64 * kCT) {
@@ -311,7 +323,7 @@ __global__ __launch_bounds__(1024) void mil_fwd_kernel(const float* __restrict__
                 const int c = min(c0 + q * 64 + lane, W - 1);
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
-                    const int r = min(rb + i, H - 1);           // clamped: the duplicate of the last row changes no maximum
+                    const int r = min(rb + i, H - 1);
                     v[q][i] = x[(int64_t)r * W + c];
                     t[q][i] = load_t(tg, t_u8, (int64_t)n * HW + (int64_t)r * W + c);
                 }
@@ -338,30 +350,64 @@ __global__ __launch_bounds__(1024) void mil_fwd_kernel(const float* __restrict__
             float tm = rt[i];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) tm = fmaxf(tm, __shfl_xor(tm, off, kWave));
-            if (lane == 0 && rb + i < H) { rowv[rb + i] = unpack_val(k); rowt[rb + i] = tm; argr[rb + i] = (int)unpack_idx(k); }
+            if (lane == 0 && rb + i < H) {
+                ms.rowv[(int64_t)n * H + rb + i] = unpack_val(k); ms.rowt[(int64_t)n * H + rb + i] = tm; argr[rb + i] = (int)unpack_idx(k);
+            }
         }
     }
     __syncthreads();
+    for (int c = tid; c < W; c += 256) {
+        ms.colkey[((int64_t)n * nb + band) * W + c] = colkey[c];
+        ms.coltk[((int64_t)n * nb + band) * W + c] = coltk[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void mil_finish_kernel(int H, int W, int nb, double eps, double weight, float* __restrict__ loss,
+                                                         int* __restrict__ state, MilScratch ms) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mil_raw[];
+    u64* colkey = reinterpret_cast<u64*>(mil_raw);                   // [W]
+    uint32_t* coltk = reinterpret_cast<uint32_t*>(colkey + W);       // [W]
+    __shared__ double red[16];
+    const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int* argc = state + (int64_t)n * mil_state_words(H, W);
+    int* argr = argc + W;
+    float* gcol = reinterpret_cast<float*>(argr + H);
+    float* grow = gcol + W;
+    const float* rowv = ms.rowv + (int64_t)n * H;
+    const float* rowt = ms.rowt + (int64_t)n * H;
     double ac = 0.0, bcc = 0.0, ar = 0.0, bcr = 0.0;
-    for (int c = tid; c < W; c += 1024) {
-        const double v = unpack_val(colkey[c]), t = key_float(coltk[c]);
+    for (int c = tid; c < W; c += 256) {
+        u64 k = 0ull; uint32_t tk = 0u;
+        for (int b0 = 0; b0 < nb; b0 += 8) {    // 16 loads in flight; a larger key wins: larger value, then smaller row
+            u64 o[8]; uint32_t ot[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int b = min(b0 + i, nb - 1);                       // clamped: a duplicate changes no maximum
+                o[i] = ms.colkey[((int64_t)n * nb + b) * W + c];
+                ot[i] = ms.coltk[((int64_t)n * nb + b) * W + c];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { k = o[i] > k ? o[i] : k; tk = ot[i] > tk ? ot[i] : tk; }
+        }
+        colkey[c] = k; coltk[c] = tk;
+        const double v = unpack_val(k), t = key_float(tk);
         ac += v * t; bcc += v * v + t * t;
     }
-    for (int r = tid; r < H; r += 1024) { ar += (double)rowv[r] * rowt[r]; bcr += (double)rowv[r] * rowv[r] + (double)rowt[r] * rowt[r]; }
+    for (int r = tid; r < H; r += 256) { ar += (double)rowv[r] * rowt[r]; bcr += (double)rowv[r] * rowv[r] + (double)rowt[r] * rowt[r]; }
     // the four sums together (one after another each costs six dependent cross-lane steps and two barriers)
     ac = wave_sum_f64(ac); bcc = wave_sum_f64(bcc); ar = wave_sum_f64(ar); bcr = wave_sum_f64(bcr);
     if (lane == 0) { red[wave * 4 + 0] = ac; red[wave * 4 + 1] = bcc; red[wave * 4 + 2] = ar; red[wave * 4 + 3] = bcr; }
     __syncthreads();
     ac = bcc = ar = bcr = 0.0;
-    for (int wv = 0; wv < 16; ++wv) { ac += red[wv * 4 + 0]; bcc += red[wv * 4 + 1]; ar += red[wv * 4 + 2]; bcr += red[wv * 4 + 3]; }   // fixed order
+    for (int wv = 0; wv < 4; ++wv) { ac += red[wv * 4 + 0]; bcc += red[wv * 4 + 1]; ar += red[wv * 4 + 2]; bcr += red[wv * 4 + 3]; }   // fixed order
     bcc += eps; bcr += eps;
     if (tid == 0) loss[n] = (float)(weight * ((1.0 - 2.0 * ar / bcr) + (1.0 - 2.0 * ac / bcc)));   // loss_func(column..) + loss_func(row..)
-    for (int c = tid; c < W; c += 1024) {
+    for (int c = tid; c < W; c += 256) {        // each thread reads back what it wrote itself
         const double v = unpack_val(colkey[c]), t = key_float(coltk[c]);
         gcol[c] = (float)(weight * (-2.0 * t / bcc + 4.0 * ac * v / (bcc * bcc)));
         argc[c] = (int)unpack_idx(colkey[c]);
     }
-    for (int r = tid; r < H; r += 1024) grow[r] = (float)(weight * (-2.0 * rowt[r] / bcr + 4.0 * ar * rowv[r] / (bcr * bcr)));
+    for (int r = tid; r < H; r += 256) grow[r] = (float)(weight * (-2.0 * rowt[r] / bcr + 4.0 * ar * rowv[r] / (bcr * bcr)));
 }
 
 __global__ __launch_bounds__(256) void mil_bwd_kernel(int N, int H, int W, const int* __restrict__ state,
@@ -481,7 +527,7 @@ int bxi_dice_loss_backward_f32(const float* input, const void* target, int targe
 
 size_t bxi_mil_loss_state_bytes(int N, int H, int W) {
     if (N < 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)(N > 0 ? N : 1) * 2 * (size_t)(H + W) * 4;
+    return bxi::mil_carve(nullptr, N, H, W, nullptr);        // what the backward reads + the forward's per-band scratch
 }
 
 static int launch_mil_fwd(const float* input, const void* target, int target_u8, int N, int H, int W, double eps, double weight,
@@ -490,11 +536,19 @@ static int launch_mil_fwd(const float* input, const void* target, int target_u8,
     if (N == 0) return BXI_OK;
     if (!input || !target || !loss || !state) return BXI_ERR_NULL_POINTER;
     if (!bxi::fits_i32((int64_t)N * H * W)) return BXI_ERR_BAD_SHAPE;
-    const size_t lds = (size_t)W * 12 + (size_t)H * 8;
-    if (lds > 64 * 1024) return BXI_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(state) & 15) return BXI_ERR_WORKSPACE;
+    const size_t lds = (size_t)W * 12;
+    if (lds > 64 * 1024 || N > 65535) return BXI_ERR_UNSUPPORTED;
     hipStream_t s = bxi::as_stream(stream);
-    BXI_LAUNCH("mil_fwd", s, bxi::mil_fwd_kernel, dim3(N), dim3(1024), lds, s, input, target, target_u8 ? 1 : 0, H, W, eps, weight,
-               loss, reinterpret_cast<int*>(state));
+    bxi::MilScratch ms;
+    bxi::mil_carve(state, N, H, W, &ms);
+    const int nb = (H + bxi::kMilBandRows - 1) / bxi::kMilBandRows;
+    BXI_LAUNCH("mil_band", s, bxi::mil_band_kernel, dim3(nb, N), dim3(256), lds, s, input, target, target_u8 ? 1 : 0, H, W,
+               reinterpret_cast<int*>(state), ms);
+    int rc = bxi::check_launch();
+    if (rc != BXI_OK) return rc;
+    BXI_LAUNCH("mil_finish", s, bxi::mil_finish_kernel, dim3(N), dim3(256), lds, s, H, W, nb, eps, weight, loss,
+               reinterpret_cast<int*>(state), ms);
     return bxi::check_launch();
 }
 
