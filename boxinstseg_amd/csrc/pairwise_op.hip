@@ -157,18 +157,26 @@ __global__ __launch_bounds__(256) void pairwise3_fwd_kernel(const T* __restrict_
     }
 }
 
-// backward: per pixel also s(x) - s(-x) staged once; a pair (p,q) is evaluated once by its earlier pixel p, which keeps
-// its own share and deposits q's share -(s(p)-s(-p)) exp(a_q+b_q+f) G into slot [q][k-4] of an LDS plane (one writer per
-// slot: no atomics); pairs whose earlier pixel lies outside the tile are evaluated by the later pixel itself.
+// backward: a pair (p,q) is evaluated once by its earlier pixel p, which keeps its own share and deposits q's share into slot
+// [q][k-4] of an LDS plane (one writer per slot: no atomics); pairs whose earlier pixel lies outside the tile are evaluated
+// by the later pixel itself.  Two bodies:
+//   fast   every |logit| of the tile + halo <= 34: probabilities are staged, (s, s') = (sigmoid(x), sigmoid(-x)), one exp and one
+//          division per pixel; with t = s - s', u = s s' and S = s_p s_q + s'_p s'_q (= exp(-f), >= 3e-15, cannot underflow)
+//              d f / d x_p = -t_q u_p / S ,  d f / d x_q = -t_p u_q / S
+//          -- the same quantity as pairwise.cu:56-58's -(s(b) - s(-b)) exp(logs(a) + logs(-a) + f), a dozen instructions per pair
+//          instead of five exp / log evaluations (the kernel was bound by those: 43 us, 0.2 of the HBM peak);
+//   exact  otherwise (block-uniform choice): log space exactly as pairwise.cu:38-58, (log s, log s', s - s') staged.
 template <typename T> struct LogTriple { T a, b, dd; };
+template <typename T> struct ProbPair { T s, m; };      // sigmoid(x), sigmoid(-x)
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // 1 ulp
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+
 
 template <typename T>
 __global__ __launch_bounds__(256) void pairwise3_bwd_kernel(const T* __restrict__ logits, const T* __restrict__ g_pair, int H, int W, int d,
                                                             T* __restrict__ g_logits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pw_raw[];
     const int PR = kPwTR + 2 * d, PC = kPwTC + 2 * d;
-    LogTriple<T>* tile = reinterpret_cast<LogTriple<T>*>(pw_raw);
-    T* slots = reinterpret_cast<T*>(tile + PR * PC);                     // [kPwTR*kPwTC][4]: shares deposited by earlier pixels
     const int tiles_x = (W + kPwTC - 1) / kPwTC, tiles_y = (H + kPwTR - 1) / kPwTR;
     int t = blockIdx.x;
     const int tx = t % tiles_x; t /= tiles_x;
@@ -177,71 +185,153 @@ __global__ __launch_bounds__(256) void pairwise3_bwd_kernel(const T* __restrict_
     const int64_t P = (int64_t)H * W;
     const int r0 = ty * kPwTR, c0 = tx * kPwTC;
     const T* L = logits + n * P;
-    for (int i = threadIdx.x; i < PR * PC; i += 256) {
-        const int r = r0 - d + i / PC, c = c0 - d + i % PC;
-        LogTriple<T> v{T(0), T(0), T(0)};
-        if (r >= 0 && r < H && c >= 0 && c < W) { const T x = L[(int64_t)r * W + c]; v.a = logsig(x); v.b = logsig(-x); v.dd = t_exp(v.a) - t_exp(v.b); }
-        tile[i] = v;
+    // the tile + halo logits, all loads of a thread in flight together (out-of-map positions: 0, never used as a neighbour).
+    // A wave takes rows wave, wave + 4, ... of the staged tile, its lanes the columns in two passes (64 + 2d <= 128): no
+    // integer division in front of the loads (the address arithmetic, not the exp / log, was most of this kernel).
+    constexpr int kStageRows = (kPwTR + 2 * kPwMaxDil + 3) / 4;       // staged rows a wave may have to take
+    T xv[kStageRows][2];
+    bool sat = false;
+    const int swave = threadIdx.x >> 6, slane = threadIdx.x & 63;
+#pragma unroll
+    for (int e = 0; e < kStageRows; ++e) {
+        const int sr = swave + 4 * e, r = r0 - d + sr;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int sc = slane + 64 * hf, cq = c0 - d + sc;
+            xv[e][hf] = T(0);
+            if (sr < PR && sc < PC && r >= 0 && r < H && cq >= 0 && cq < W) { xv[e][hf] = L[(int64_t)r * W + cq]; sat |= !(t_abs(xv[e][hf]) <= T(34)); }
+        }
     }
-    for (int i = threadIdx.x; i < kPwTR * kPwTC * 4; i += 256) slots[i] = T(0);
-    __syncthreads();
     const int lc = threadIdx.x & 63, lr0 = threadIdx.x >> 6;
     const int c = c0 + lc;
     const T* GP = g_pair + n * 8 * P;
     T own[kPwTR / 4];
-    // the gradient sums G = g[k][p] + g[7-k][q] of all four pixels of the thread first: 64 loads in flight, clamped
-    // positions so that no branch stands in front of them
+    // the gradient sums G = g[k][p] + g[7-k][q] of all four pixels of the thread: 64 loads, requested before the
+    // block decides on its body and stages the tile, so that they fly meanwhile.  A neighbour's
+    // address is the pixel's plus a wave-uniform constant; where the neighbour lies outside the map the pixel's own address
+    // stands in (the value is not used), so no clamping arithmetic and no branch stands in front of the loads.
     T G[kPwTR / 4][8];
     const int cc = min(c, W - 1);
+    const bool c_lo = cc - d >= 0, c_hi = cc + d < W;
 #pragma unroll
     for (int j = 0; j < kPwTR / 4; ++j) {
         const int r = min(r0 + lr0 + 4 * j, H - 1);
-        const int64_t pp = (int64_t)r * W + cc;
+        const T* base = GP + ((int64_t)r * W + cc);
+        const bool r_lo = r - d >= 0, r_hi = r + d < H;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;
-            const int r2 = min(max(r + dy * d, 0), H - 1), c2 = min(max(cc + dx * d, 0), W - 1);
-            G[j][k] = GP[(int64_t)k * P + pp] + GP[(int64_t)(7 - k) * P + (int64_t)r2 * W + c2];
+            const bool ok = (dy < 0 ? r_lo : (dy > 0 ? r_hi : true)) && (dx < 0 ? c_lo : (dx > 0 ? c_hi : true));
+            const T* q = ok ? base + ((int64_t)(dy * d) * W + dx * d) : base;
+            G[j][k] = base[(int64_t)k * P] + q[(int64_t)(7 - k) * P];
         }
     }
+    // (sat is known once the logit loads -- issued first -- have returned; the G loads stay in flight across the barrier)
+    const bool exact = __syncthreads_or(sat ? 1 : 0) != 0;
+    if (!exact) {
+        ProbPair<T>* tile = reinterpret_cast<ProbPair<T>*>(pw_raw);
+        T* slots = reinterpret_cast<T*>(pw_raw + sizeof(LogTriple<T>) * (size_t)PR * PC);     // same place in both bodies
 #pragma unroll
-    for (int j = 0; j < kPwTR / 4; ++j) {
-        const int lr = lr0 + 4 * j, r = r0 + lr;
-        own[j] = T(0);
-        if (c >= W || r >= H) continue;
-        const LogTriple<T> p = tile[(lr + d) * PC + lc + d];
-        T acc = T(0);
+        for (int e = 0; e < kStageRows; ++e) {
+            const int sr = swave + 4 * e;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;
-            const int r2 = r + dy * d, c2 = c + dx * d;
-            if (!(r2 >= 0 && r2 < H && c2 >= 0 && c2 < W)) continue;
-            const int lr2 = lr + dy * d, lc2 = lc + dx * d;
-            const bool q_in_tile = lr2 >= 0 && lr2 < kPwTR && lc2 >= 0 && lc2 < kPwTC;
-            if (k < 4 && q_in_tile) continue;                 // that pair is evaluated by q (the earlier pixel) and deposited
-            const LogTriple<T> q = tile[(lr2 + d) * PC + lc2 + d];
-            const T pair = pair_nlog(p.a, p.b, q.a, q.b);
-            const T Gk = G[j][k];                              // channel k at p is the pair (p,q); channel 7-k at q is the pair (q,p)
-            acc += -q.dd * t_exp(p.a + p.b + pair) * Gk;
-            if (k >= 4 && q_in_tile) slots[(lr2 * kPwTC + lc2) * 4 + (k - 4)] = -p.dd * t_exp(q.a + q.b + pair) * Gk;
+            for (int hf = 0; hf < 2; ++hf) {
+                const int sc = slane + 64 * hf;
+                if (sr < PR && sc < PC) {
+                    const T x = xv[e][hf], en = t_exp(-t_abs(x)), big = T(1) / (T(1) + en), small = en * big;   // sigmoid(|x|), sigmoid(-|x|)
+                    tile[sr * PC + sc] = x >= T(0) ? ProbPair<T>{big, small} : ProbPair<T>{small, big};
+                }
+            }
         }
-        own[j] = acc;
+        for (int i = threadIdx.x; i < kPwTR * kPwTC * 4; i += 256) slots[i] = T(0);
+        __syncthreads();
+        // Branch-free: every tap of every pixel is evaluated (its staged neighbour always exists: the halo is d wide) and
+        // weighted by 0 where it does not count -- neighbour outside the map, or a pair that the earlier pixel evaluates
+        // (k < 4 with the neighbour inside the tile).  Per-pair branches cost more than the three wasted evaluations per
+        // pixel: they keep the independent division chains of a thread from overlapping.  A share for a neighbour outside
+        // the tile goes to a scratch cell.
+        T* trash = slots + 4 * kPwTR * kPwTC + (threadIdx.x & 63);
+#pragma unroll
+        for (int j = 0; j < kPwTR / 4; ++j) {
+            const int lr = lr0 + 4 * j, r = r0 + lr;
+            const ProbPair<T> p = tile[(lr + d) * PC + lc + d];
+            const T tp = p.s - p.m, up = p.s * p.m;
+            const bool r_lo = r - d >= 0, r_hi = r + d < H, c_lo2 = c - d >= 0, c_hi2 = c + d < W;
+            T acc = T(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;
+                const bool in_map = (dy < 0 ? r_lo : (dy > 0 ? r_hi : true)) && (dx < 0 ? c_lo2 : (dx > 0 ? c_hi2 : true));
+                const int lr2 = lr + dy * d, lc2 = lc + dx * d;
+                const bool q_in_tile = lr2 >= 0 && lr2 < kPwTR && lc2 >= 0 && lc2 < kPwTC;
+                const bool use = in_map && (k >= 4 || !q_in_tile);
+                const ProbPair<T> q = tile[(lr2 + d) * PC + lc2 + d];
+                const T S = p.s * q.s + p.m * q.m;                 // >= 3e-15: every |logit| <= 34
+                const T m = use ? G[j][k] * fast_rcp(S) : T(0);    // channel k at p is the pair (p,q); channel 7-k at q is the pair (q,p)
+                acc += -(q.s - q.m) * up * m;
+                if (k >= 4) *(q_in_tile ? &slots[(k - 4) * (kPwTR * kPwTC) + lr2 * kPwTC + lc2] : trash) = -tp * (q.s * q.m) * m;
+            }
+            own[j] = acc;
+        }
+    } else {
+        LogTriple<T>* tile = reinterpret_cast<LogTriple<T>*>(pw_raw);
+        T* slots = reinterpret_cast<T*>(tile + PR * PC);                     // [4][kPwTR*kPwTC]: shares deposited by earlier pixels
+#pragma unroll
+        for (int e = 0; e < kStageRows; ++e) {
+            const int sr = swave + 4 * e, r = r0 - d + sr;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int sc = slane + 64 * hf, cq = c0 - d + sc;
+                if (sr < PR && sc < PC) {
+                    LogTriple<T> v{T(0), T(0), T(0)};
+                    if (r >= 0 && r < H && cq >= 0 && cq < W) { const T x = xv[e][hf]; v.a = logsig(x); v.b = logsig(-x); v.dd = t_exp(v.a) - t_exp(v.b); }
+                    tile[sr * PC + sc] = v;
+                }
+            }
+        }
+        for (int i = threadIdx.x; i < kPwTR * kPwTC * 4; i += 256) slots[i] = T(0);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kPwTR / 4; ++j) {
+            const int lr = lr0 + 4 * j, r = r0 + lr;
+            own[j] = T(0);
+            if (c >= W || r >= H) continue;
+            const LogTriple<T> p = tile[(lr + d) * PC + lc + d];
+            T acc = T(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;
+                const int r2 = r + dy * d, c2 = c + dx * d;
+                if (!(r2 >= 0 && r2 < H && c2 >= 0 && c2 < W)) continue;
+                const int lr2 = lr + dy * d, lc2 = lc + dx * d;
+                const bool q_in_tile = lr2 >= 0 && lr2 < kPwTR && lc2 >= 0 && lc2 < kPwTC;
+                if (k < 4 && q_in_tile) continue;                 // that pair is evaluated by q (the earlier pixel) and deposited
+                const LogTriple<T> q = tile[(lr2 + d) * PC + lc2 + d];
+                const T pair = pair_nlog(p.a, p.b, q.a, q.b);
+                const T Gk = G[j][k];
+                acc += -q.dd * t_exp(p.a + p.b + pair) * Gk;
+                if (k >= 4 && q_in_tile) slots[(k - 4) * (kPwTR * kPwTC) + lr2 * kPwTC + lc2] = -p.dd * t_exp(q.a + q.b + pair) * Gk;
+            }
+            own[j] = acc;
+        }
     }
     __syncthreads();
+    const T* slots = reinterpret_cast<const T*>(pw_raw + sizeof(LogTriple<T>) * (size_t)PR * PC);
 #pragma unroll
     for (int j = 0; j < kPwTR / 4; ++j) {
         const int lr = lr0 + 4 * j, r = r0 + lr;
         if (c >= W || r >= H) continue;
-        const T* sl = slots + (lr * kPwTC + lc) * 4;
+        const T* sl = slots + lr * kPwTC + lc;             // four planes [k - 4][pixel]: a wave's accesses fall on distinct banks
+        constexpr int kPl = kPwTR * kPwTC;
         // summation order: the four earlier neighbours (k = 3,2,1,0 deposit into slots 0..3), then the later ones
-        g_logits[n * P + (int64_t)r * W + c] = (((sl[3] + sl[2]) + sl[1]) + sl[0]) + own[j];
+        g_logits[n * P + (int64_t)r * W + c] = (((sl[3 * kPl] + sl[2 * kPl]) + sl[kPl]) + sl[0]) + own[j];
     }
 }
 
 template <typename T>
 static size_t pw3_lds(int d) { return sizeof(LogPair<T>) * (size_t)(kPwTR + 2 * d) * (kPwTC + 2 * d); }
 template <typename T>
-static size_t pw3_bwd_lds(int d) { return sizeof(LogTriple<T>) * (size_t)(kPwTR + 2 * d) * (kPwTC + 2 * d) + sizeof(T) * kPwTR * kPwTC * 4; }
+static size_t pw3_bwd_lds(int d) { return sizeof(LogTriple<T>) * (size_t)(kPwTR + 2 * d) * (kPwTC + 2 * d) + sizeof(T) * (kPwTR * kPwTC * 4 + 64); }
 
 template <typename T>
 static int launch_fwd(const T* logits, int N, int H, int W, int size, int dil, T* out, void* stream) {
