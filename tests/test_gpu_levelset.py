@@ -72,10 +72,12 @@ def test_projection_and_levelset_vs_oracle(built, dev, N, H, W, C):
     assert _close(l2.cpu().numpy(), lo.levelset_loss(ms, T, np.ones(N), 1.0)[0])
 
 
-@pytest.mark.parametrize('N,h,w,iters,d', [(8, 96, 96, 10, 2), (2, 200, 304, 3, 2), (3, 5, 4, 4, 2), (2, 33, 70, 2, 1), (1, 1, 9, 2, 3)])
+@pytest.mark.parametrize('N,h,w,iters,d', [(8, 96, 96, 10, 2), (2, 200, 304, 3, 2), (3, 5, 4, 4, 2), (2, 33, 70, 2, 1), (1, 1, 9, 2, 3),
+                                           (4, 96, 96, 10, 1), (2, 90, 100, 3, 2), (1, 97, 97, 2, 2), (2, 64, 150, 2, 4), (2, 2, 2, 3, 1)])
 def test_lcm_vs_oracle(built, dev, N, h, w, iters, d):
-    """96x96 runs in one launch from LDS; 200x304 takes the per-iteration path; tiny maps exercise the clamped borders
-    of the adjoint (every source position enumerated)."""
+    """96x96 with d = 2 runs the compile-time-shaped padded-plane kernels, other shapes up to 10 x 1024 padded positions the
+    run-time-shaped ones (97x97: forward only, its adjoint and 64x150 with d = 4 take the two-plane LDS kernels); 200x304 takes
+    the per-iteration path; tiny maps exercise the replicate padding folding onto the same pixel from several sides."""
     from boxinstseg_amd import LocalConsistencyModule
     rng = np.random.default_rng(h * 31 + w)
     yy, xx = np.mgrid[0:h, 0:w]

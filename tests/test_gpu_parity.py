@@ -85,6 +85,25 @@ def test_pairwise_op_extreme_logits(dev):
     assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
 
 
+def test_pairwise_op_backward_mixed_saturation(dev):
+    """The size-3 backward picks its body per 16x64 tile: probabilities where every |logit| of the tile + halo <= 34, log space
+    (pairwise.cu:38-58 to the letter) otherwise.  A map with a few large logits makes both run in one launch, next to each other."""
+    from boxinstseg_amd import pairwise_nlog
+    from oracle import c_oracle
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal((2, 40, 150)) * 6).astype(np.float32)
+    x[0, 3, 5] = 60.0; x[0, 30, 140] = -200.0; x[1, 17, 70] = 34.5; x[1, 18, 70] = -33.9
+    want = c_oracle.pairwise_nlog_fwd(x, 3, 2)
+    gp = rng.standard_normal(want.shape).astype(np.float32)
+    want_g = c_oracle.pairwise_nlog_bwd(x, want, gp, 3, 2)
+    xt = torch.from_numpy(x[:, None]).to(dev).requires_grad_(True)
+    out = pairwise_nlog(xt, 3, 2)
+    out.backward(torch.from_numpy(gp).to(dev))
+    assert np.isfinite(xt.grad.cpu().numpy()).all()
+    assert np.abs(out.detach().cpu().numpy() - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+    assert np.abs(xt.grad.cpu().numpy()[:, 0] - want_g).max() <= 2e-5 * max(1.0, np.abs(want_g).max())
+
+
 def test_pairwise_op_errors(dev):
     from boxinstseg_amd import pairwise_nlog, pairwise_nlog_forward
     with pytest.raises(RuntimeError, match='CUDA'):
