@@ -146,10 +146,43 @@ class CondInstMaskHead(nn.Module):
         if not feat.is_cuda:
             raise RuntimeError('CondInstMaskHead.forward: feat must be a CUDA (HIP) tensor; no CPU path')
         if self.dynamic_convs != 3 or self.dynamic_channels != 8 or feat.size(1) not in (8, 16):
-            raise RuntimeError('the HIP dynamic head is built for dynamic_convs=3, dynamic_channels=8, 8/16 feature channels')
+            # every shipped config is 3 layers x 8 channels on 8 / 16 feature channels: that is what the HIP kernels are
+            # instantiated for.  The reference leaves the three numbers free (:1079-1089), so other heads run the same
+            # arithmetic composed of PyTorch-ROCm ops (still on the GPU; autograd supplies the backward).
+            return self._composed_forward(feat, params, coors, level_inds, img_inds)
         return dynamic_mask_forward(feat, params, coors, level_inds, img_inds, self.sizes_of_interest,
                                     in_stride=self.in_stride, out_stride=self.out_stride,
                                     disable_rel_coors=self.disable_rel_coors)
+
+    def _composed_forward(self, feat, params, coors, level_inds, img_inds):
+        """The dynamic head for layer counts / widths the HIP kernels are not built for: a per-instance 1x1 convolution is
+        a [cout, cin] x [cin, H*W] product, so the layers are batched matrix products over the instances."""
+        n = params.size(0)
+        expect = sum(self.dy_weights) + sum(self.dy_biases)
+        if params.dim() != 2 or (n > 0 and params.size(1) != expect):
+            raise RuntimeError(f'params must be [N,{expect}], got {tuple(params.shape)}')
+        x = feat[img_inds]                                                  # [N,C,H,W]
+        H, W = x.shape[2:]
+        if not self.disable_rel_coors:
+            half = self.in_stride // 2
+            xs = torch.arange(W, device=x.device, dtype=x.dtype) * self.in_stride + half
+            ys = torch.arange(H, device=x.device, dtype=x.dtype) * self.in_stride + half
+            scale = self.sizes_of_interest.to(device=x.device, dtype=x.dtype)[level_inds].view(n, 1, 1)
+            rel_x = ((coors[:, 0].view(n, 1, 1) - xs.view(1, 1, W)) / scale).expand(n, H, W)
+            rel_y = ((coors[:, 1].view(n, 1, 1) - ys.view(1, H, 1)) / scale).expand(n, H, W)
+            x = torch.cat([rel_x.unsqueeze(1), rel_y.unsqueeze(1), x], dim=1)
+        x = x.flatten(2)                                                    # [N,cin,H*W]
+        w_off, b_off = 0, sum(self.dy_weights)
+        for i, (nw, nb) in enumerate(zip(self.dy_weights, self.dy_biases)):
+            w = params[:, w_off:w_off + nw].reshape(n, nb, nw // nb)       # [N,cout,cin], rows = output channels
+            b = params[:, b_off:b_off + nb].reshape(n, nb, 1)
+            x = torch.baddbmm(b, w, x)
+            if i < self.dynamic_convs - 1:
+                x = torch.relu(x)
+            w_off += nw
+            b_off += nb
+        from .dynamic import aligned_bilinear
+        return aligned_bilinear(x.reshape(n, 1, H, W), self.in_stride // self.out_stride)
 
     # ---- the callers either side of the path: instance sampling (training) and mask post-processing (test) -----
     def training_sample(self, cls_scores, centernesses, param_preds, coors, level_inds, img_inds, gt_inds):

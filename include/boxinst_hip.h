@@ -216,7 +216,8 @@ int bxi_boxinst_grad_rescale_f32(const bxi_instances* inst_host, const float* g_
  *    relative coordinates (:1142-1154), parse_dynamic_params (:1120-1137), the three per-instance
  *    grouped 1x1 convolutions + ReLU (:1156-1161) and aligned_bilinear (:146-167, :1163).
  * ===========================================================================================
- * feat   [B,C,H,W]  mask-branch features at `in_stride` (C = 8 or 16 built; others BXI_ERR_UNSUPPORTED)
+ * feat   [B,C,H,W]  mask-branch features at `in_stride` (C = 8 or 16 built; others BXI_ERR_UNSUPPORTED: the host then
+ *                   composes the layers as batched matrix products, boxinstseg_amd/mask_head.py:_composed_forward)
  * params [N,P]      per-instance dynamic parameters, P = (C+2)*8 + 64 + 8 + 8 + 8 + 1 (the
  *                   split_with_sizes order of the reference: w0, w1, w2, b0, b1, b2); C*8+... when
  *                   disable_rel_coors

@@ -154,3 +154,27 @@ def test_dynamic_head_fuzz(dev, seed):
     inst = np.broadcast_to(np.arange(N)[:, None], params.shape)
     assert _close_except_kinks(f.grad.cpu().numpy(), ft.grad.numpy(), 1e-4, pix), cfg
     assert _close_except_kinks(p.grad.cpu().numpy(), pt.grad.numpy(), 1e-4, inst), cfg
+
+
+def test_dynamic_head_shapes_outside_the_hip_build_run_composed(dev):
+    """dynamic_convs / dynamic_channels other than 3 / 8 (free in the reference, condinst_head.py:1079-1089): same arithmetic
+    from PyTorch-ROCm ops on the GPU (checked against its own fp64 CPU evaluation; the composition itself is pinned on
+    the CPU, tests/test_host_cpu.py), differentiable, and the built shape gives the same logits through either path."""
+    from boxinstseg_amd import CondInstMaskHead
+    torch.manual_seed(3)
+    head = CondInstMaskHead(in_channels=6, dynamic_convs=2, dynamic_channels=4, boxinst_enabled=True).to(dev)
+    feat = torch.randn(2, 6, 12, 20, device=dev, requires_grad=True)
+    params = torch.randn(4, head.num_gen_params, device=dev, requires_grad=True)
+    coors = torch.rand(4, 2, device=dev) * 100
+    lvl = torch.tensor([0, 2, 4, 1], device=dev); img = torch.tensor([1, 0, 1, 1], device=dev)
+    out = head(feat, params, coors, lvl, img)
+    assert out.shape == (4, 1, 24, 40)
+    out.square().sum().backward()
+    assert torch.isfinite(feat.grad).all() and torch.isfinite(params.grad).all()
+    cpu = head.cpu().double()
+    want = cpu._composed_forward(feat.detach().cpu().double(), params.detach().cpu().double(), coors.cpu().double(), lvl.cpu(), img.cpu())
+    assert (out.detach().cpu().double() - want).abs().max() <= 1e-5 * max(1.0, float(want.abs().max()))
+    built = CondInstMaskHead(in_channels=8, boxinst_enabled=True).to(dev)
+    f8 = torch.randn(2, 8, 12, 20, device=dev); p8 = torch.randn(4, built.num_gen_params, device=dev)
+    a = built(f8, p8, coors, lvl, img); b = built._composed_forward(f8, p8, coors, lvl, img)
+    assert (a - b).abs().max() <= 2e-5 * max(1.0, float(b.abs().max()))

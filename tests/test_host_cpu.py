@@ -290,3 +290,43 @@ def test_rgb2lab_oracle_matches_real_scikit_image():
         assert ulp.max() <= 1
     tally = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'lab_skimage_exhaustive.json')))
     assert tally['inputs'] == 1 << 24 and tally['f32_mismatches'] <= 16 and tally['max_ulp'] <= 1
+
+
+@pytest.mark.parametrize('convs,ch,cin,no_rel', [(3, 8, 8, False), (2, 4, 6, False), (4, 16, 8, True), (1, 8, 5, False)])
+def test_composed_dynamic_head_for_shapes_outside_the_hip_build(convs, ch, cin, no_rel):
+    """CondInstMaskHead.forward for layer counts / widths the HIP kernels are not instantiated for (the reference leaves
+    dynamic_convs / dynamic_channels / in_channels free, condinst_head.py:1079-1089) is composed of torch ops; it is pure
+    torch, so it can be checked here: against the oracle of the shipped shape (pinned to the reference fixture), and
+    against the reference's formulation -- grouped 1x1 convolutions over a [1, N*C, H, W] view (:1139-1164) -- in general."""
+    import torch.nn.functional as F
+    from boxinstseg_amd import CondInstMaskHead
+    from oracle import torch_oracle as to
+    torch.manual_seed(convs * 100 + ch)
+    head = CondInstMaskHead(in_channels=cin, dynamic_convs=convs, dynamic_channels=ch, disable_rel_coors=no_rel,
+                            boxinst_enabled=True).double()
+    n, B, H, W = 5, 2, 6, 10
+    feat = torch.randn(B, cin, H, W, dtype=torch.float64)
+    params = torch.randn(n, head.num_gen_params, dtype=torch.float64, requires_grad=True)
+    coors = torch.rand(n, 2, dtype=torch.float64) * 60
+    lvl = torch.tensor([0, 1, 2, 3, 4]); img = torch.tensor([0, 1, 1, 0, 1])
+    got = head._composed_forward(feat, params, coors, lvl, img)
+    assert got.shape == (n, 1, 2 * H, 2 * W)
+    if (convs, ch) == (3, 8):
+        want = to.dynamic_mask_forward(feat, params, coors, lvl, img, head.sizes_of_interest, in_stride=8, out_stride=4,
+                                       dynamic_channels=8, disable_rel_coors=no_rel)
+        assert torch.allclose(got, want, rtol=0, atol=1e-12)
+    x = feat[img]
+    if not no_rel:
+        xs = torch.arange(0, W * 8, 8, dtype=torch.float64) + 4; ys = torch.arange(0, H * 8, 8, dtype=torch.float64) + 4
+        loc = torch.stack([xs[None, :].expand(H, W), ys[:, None].expand(H, W)], 0)
+        x = torch.cat([(coors[:, :, None, None] - loc[None]) / head.sizes_of_interest.double()[lvl][:, None, None, None], x], 1)
+    weights, biases = head.parse_dynamic_params(params)
+    x = x.reshape(1, -1, H, W)
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        x = F.conv2d(x, w, bias=b, groups=n)
+        if i < convs - 1:
+            x = F.relu(x)
+    want = to.aligned_upsample(x.permute(1, 0, 2, 3), 2)
+    assert torch.allclose(got, want, rtol=0, atol=1e-12)
+    got.sum().backward()
+    assert params.grad is not None and torch.isfinite(params.grad).all()
