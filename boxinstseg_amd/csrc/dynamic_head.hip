@@ -105,29 +105,37 @@ __device__ __forceinline__ float mlp_forward(const float* __restrict__ wts, cons
 }
 
 // two pixels at once: every weight is used the moment its scalar load lands, so none has to be kept
-// (evaluating the pixels one after the other makes the compiler keep all 233 SGPRs and spill them)
+// (evaluating the pixels one after the other makes the compiler keep all 233 SGPRs and spill them).  The two pixels ride
+// in the two halves of packed FMAs, acc(A,B) += (w,w) * (x_A, x_B), the weight broadcast from its SGPR: one instruction per
+// weight instead of two (the forward kernel is bound by instruction issue, not by its 6.5 MB of stores).
 template <int C, bool REL>
 __device__ __forceinline__ void mlp_forward2(const float* __restrict__ wts, const float (&inA)[Dyn<C, REL>::CIN],
                                              const float (&inB)[Dyn<C, REL>::CIN], float& yA, float& yB) {
     using D = Dyn<C, REL>;
-    float a1[kDC], b1[kDC], a2[kDC], b2[kDC];
+    v2f x0[D::CIN], x1[kDC], x2[kDC];
+#pragma unroll
+    for (int i = 0; i < D::CIN; ++i) x0[i] = v2f{inA[i], inB[i]};
 #pragma unroll
     for (int o = 0; o < kDC; ++o) {
-        float accA = wts[D::B0 + o], accB = accA;
+        const float b = wts[D::B0 + o];
+        v2f acc = {b, b};
 #pragma unroll
-        for (int i = 0; i < D::CIN; ++i) { const float w = wts[o * D::CIN + i]; accA += w * inA[i]; accB += w * inB[i]; }
-        a1[o] = fmaxf(accA, 0.f); b1[o] = fmaxf(accB, 0.f);
+        for (int i = 0; i < D::CIN; ++i) { const float w = wts[o * D::CIN + i]; acc = pk_fma(v2f{w, w}, x0[i], acc); }
+        x1[o] = v2f{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f)};
     }
 #pragma unroll
     for (int o = 0; o < kDC; ++o) {
-        float accA = wts[D::B1 + o], accB = accA;
+        const float b = wts[D::B1 + o];
+        v2f acc = {b, b};
 #pragma unroll
-        for (int i = 0; i < kDC; ++i) { const float w = wts[D::W1 + o * kDC + i]; accA += w * a1[i]; accB += w * b1[i]; }
-        a2[o] = fmaxf(accA, 0.f); b2[o] = fmaxf(accB, 0.f);
+        for (int i = 0; i < kDC; ++i) { const float w = wts[D::W1 + o * kDC + i]; acc = pk_fma(v2f{w, w}, x1[i], acc); }
+        x2[o] = v2f{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f)};
     }
-    yA = yB = wts[D::B2];
+    const float b2 = wts[D::B2];
+    v2f y = {b2, b2};
 #pragma unroll
-    for (int i = 0; i < kDC; ++i) { const float w = wts[D::W2 + i]; yA += w * a2[i]; yB += w * b2[i]; }
+    for (int i = 0; i < kDC; ++i) { const float w = wts[D::W2 + i]; y = pk_fma(v2f{w, w}, x2[i], y); }
+    yA = y.x; yB = y.y;
 }
 
 // in[] = (relative coordinates when REL,) C feature channels of pixel (r,c) of image b

@@ -9,5 +9,11 @@ for t in "$@"; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$t -o x -- python $R/tools/bench_$t.py > $R/gpurun_out/${t}_bench.json 2> $R/gpurun_out/${t}_bench.err
   f=$(ls $R/gpurun_out/prof_$t/*kernel_stats.csv $R/gpurun_out/prof_$t/*/*kernel_stats.csv 2>/dev/null | head -1)
   echo "== $t ($f)"
-  if [ -n "$f" ]; then grep "bxi::" "$f" | awk -F'","' '{printf "%-90.90s calls %s avg_ns %s\n", $1, $2, $4}'; fi
+  if [ -n "$f" ]; then python3 - "$f" <<'PY'
+import csv, sys
+for row in csv.reader(open(sys.argv[1])):
+    if 'bxi::' in row[0]:
+        print('%-70.70s calls %5s avg_us %8.2f min %8.2f max %8.2f' % (row[0], row[1], float(row[3]) / 1e3, float(row[5]) / 1e3, float(row[6]) / 1e3))
+PY
+  fi
 done
