@@ -548,6 +548,24 @@ __device__ __forceinline__ int slow_tile(const float* __restrict__ Lg, const flo
     return cnt;
 }
 
+// The value of lane + D / lane - D (its own where that lane does not exist: exactly __shfl(v, min(lane + D, 63)) and
+// __shfl(v, max(lane - D, 0))), by D wavefront shifts of one lane on the VALU's data-parallel path instead of a trip through
+// the LDS crossbar (ds_bpermute): the pair loop asks for twelve neighbour values per row and waited for each batch.
+template <int D>
+__device__ __forceinline__ float lane_plus(float v) {
+    int x = __float_as_int(v);
+#pragma unroll
+    for (int s = 0; s < D; ++s) x = __builtin_amdgcn_update_dpp(x, x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    return __int_as_float(x);
+}
+template <int D>
+__device__ __forceinline__ float lane_minus(float v) {
+    int x = __float_as_int(v);
+#pragma unroll
+    for (int s = 0; s < D; ++s) x = __builtin_amdgcn_update_dpp(x, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return __int_as_float(x);
+}
+
 // ---- count wave: sum over the tile's owned pixels of W[k,p] (Lab only) -------------------------------------------
 template <int D, int R>
 __device__ __forceinline__ void count_tile(const InstArgs& a, const float* __restrict__ lab, const EvalWs& ws, const WorkRec2& wr, int tix) {
@@ -569,15 +587,14 @@ __device__ __forceinline__ void count_tile(const InstArgs& a, const float* __res
         DirMasks m[4];
         dir_masks<D>(f, m);
         BXI_TW(2, tix, 1);
-        const int lr = min(lane + D, 63), ll = max(lane - D, 0);
 #pragma unroll
         for (int i = 0; i < R + D; ++i) {
             const int j = i + D;
             if (i == 1) BXI_TW(2, tix, 2);
-            const float LRj = __shfl(L[j], lr, 64), ARj = __shfl(A[j], lr, 64), BRj = __shfl(B[j], lr, 64);
-            const float LLj = __shfl(L[j], ll, 64), ALj = __shfl(A[j], ll, 64), BLj = __shfl(B[j], ll, 64);
+            const float LRj = lane_plus<D>(L[j]), ARj = lane_plus<D>(A[j]), BRj = lane_plus<D>(B[j]);
+            const float LLj = lane_minus<D>(L[j]), ALj = lane_minus<D>(A[j]), BLj = lane_minus<D>(B[j]);
             if (i >= D) {
-                const float LRi = __shfl(L[i], lr, 64), ARi = __shfl(A[i], lr, 64), BRi = __shfl(B[i], lr, 64);
+                const float LRi = lane_plus<D>(L[i]), ARi = lane_plus<D>(A[i]), BRi = lane_plus<D>(B[i]);
                 const bool pn = n2_of(L[i], A[i], B[i], LRi, ARi, BRi) <= wr.n2max;
                 cnt += pn ? (int)(((m[0].nA >> i) & 1u) + ((m[0].nB >> i) & 1u)) : 0;
             }
@@ -671,7 +688,6 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
         const TileFlags f = tile_flags<D, R>(wr, h, w, a.stride, lane);
         DirMasks m[4];
         dir_masks<D>(f, m);
-        const int lr = min(lane + D, 63), ll = max(lane - D, 0);
         // Rolling window over the rows: at step i the pairs (row i -> rows i, i + D) are evaluated; what the rows above
         // contributed is final then, so row i's gradient is collected (and its registers die) inside the loop.
         // Per pixel: (a, b) = (sigmoid(x), sigmoid(-x)), t = a - b, u = a b.  Per pair (p, q):
@@ -700,7 +716,6 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
             const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; pt_[j] = s.x - s.y; pu_[j] = s.x * s.y;
         }
         BXI_TW(1, tix, 2);
-        const int from_l = max(lane - D, 0), from_r = min(lane + D, 63);
         // one unordered pair: p = (row i, this lane) ; q = the operands ; dir = weight set
 #define BXI_PAIR(i, qa, qb, qt, qu, qL, qA, qB, dir, GP, GQ)                                                      \
         {                                                                                                           \
@@ -717,18 +732,18 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
         for (int i = 0; i < R + D; ++i) {
             const int j = i + D;
             { const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; pt_[j] = s.x - s.y; pu_[j] = s.x * s.y; }
-            aR[j] = __shfl(pa_[j], lr, 64); bR[j] = __shfl(pb_[j], lr, 64); tR[j] = aR[j] - bR[j]; uR[j] = aR[j] * bR[j];
-            LR[j] = __shfl(L[j], lr, 64); AR[j] = __shfl(A[j], lr, 64); BR[j] = __shfl(B[j], lr, 64);
-            const float aLj = __shfl(pa_[j], ll, 64), bLj = __shfl(pb_[j], ll, 64);
+            aR[j] = lane_plus<D>(pa_[j]); bR[j] = lane_plus<D>(pb_[j]); tR[j] = aR[j] - bR[j]; uR[j] = aR[j] * bR[j];
+            LR[j] = lane_plus<D>(L[j]); AR[j] = lane_plus<D>(A[j]); BR[j] = lane_plus<D>(B[j]);
+            const float aLj = lane_minus<D>(pa_[j]), bLj = lane_minus<D>(pb_[j]);
             const float tLj = aLj - bLj, uLj = aLj * bLj;
-            const float LLj = __shfl(L[j], ll, 64), ALj = __shfl(A[j], ll, 64), BLj = __shfl(B[j], ll, 64);
+            const float LLj = lane_minus<D>(L[j]), ALj = lane_minus<D>(A[j]), BLj = lane_minus<D>(B[j]);
             if (i >= D) BXI_PAIR(i, aR[i], bR[i], tR[i], uR[i], LR[i], AR[i], BR[i], 0, gq[i], gR[i])
             BXI_PAIR(i, aLj, bLj, tLj, uLj, LLj, ALj, BLj, 1, gq[i], gL[j])
             BXI_PAIR(i, pa_[j], pb_[j], pt_[j], pu_[j], L[j], A[j], B[j], 2, gq[i], gq[j])
             BXI_PAIR(i, aR[j], bR[j], tR[j], uR[j], LR[j], AR[j], BR[j], 3, gq[i], gR[j])
             if (i >= D) {     // row i is complete: collect what the neighbour lanes computed for it
-                const float fromL = __shfl(gR[i], from_l, 64);      // lane - D evaluated (.., +D) pairs into this lane
-                const float fromR = __shfl(gL[i], from_r, 64);      // lane + D evaluated (+D, -D) pairs into this lane
+                const float fromL = lane_minus<D>(gR[i]);            // lane - D evaluated (.., +D) pairs into this lane
+                const float fromR = lane_plus<D>(gL[i]);             // lane + D evaluated (+D, -D) pairs into this lane
                 g[i - D] = gq[i] + (lane >= D ? fromL : 0.f) + (lane + D < 64 ? fromR : 0.f);
             }
         }
