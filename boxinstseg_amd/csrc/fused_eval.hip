@@ -39,7 +39,14 @@ constexpr int kSBlk = kWaves * kSRows;          // rows per stream workgroup
 constexpr int kChunkC = 256;                    // columns per pass of a stream wave: 64 lanes x float4
 constexpr int kMaxDilFused = 4;
 constexpr unsigned kSpinLimit = 200000;
-constexpr unsigned long long kGranuleInvalid = 0xffffffffull;         // bounded waits (never reached: see the grid order above)
+constexpr unsigned long long kGranuleInvalid = 0xffffffffull;
+// A math wave's arrival + its share of the loss sum is one atomic on its instance's word.  ~20 tile waves per instance arrive
+// within a microsecond; atomics on one word are performed one after the other (~0.15 us each): the last arrival became
+// visible ~3 us after it was issued, and the launch ends on it.  Eight words per instance, each in its own 128 bytes.
+constexpr int kAcc2Split = 8, kAcc2Stride = 16;
+__device__ __forceinline__ unsigned long long* acc2_word(unsigned long long* acc2, int n, int sub) {
+    return acc2 + ((size_t)n * kAcc2Split + (sub & (kAcc2Split - 1))) * kAcc2Stride;
+}         // bounded waits (never reached: see the grid order above)
 
 // developer tracing (-DBXI_TRACE builds only): per-WAVE phase stamps, see tools/trace_eval.py
 #ifdef BXI_TRACE
@@ -71,7 +78,7 @@ struct EvalWs {                                 // carved from the caller's work
     unsigned int* expect;                       // [N]  tiles of the instance
     // words polled inside pair_kernel; zeroed by prep_kernel's table waves (i.e. before a kernel boundary)
     unsigned long long* acc1;                   // [N]  count waves : arrivals << 40 | sum W
-    unsigned long long* acc2;                   // [N]  math waves + leader : arrivals << 52 | sum (W pw + 1) in 2^-24 units
+    unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B)  math waves + leader : arrivals << 52 | sum (W pw + 1) in 2^-24 units
     float* dice;                                // [N]
 };
 
@@ -95,7 +102,7 @@ static size_t carve_eval(void* base, int N, int h, int w, EvalWs* ws) {
     t.nwork = (int*)take(sizeof(int));
     t.expect = (unsigned int*)take(4 * (size_t)N1);
     t.acc1 = (unsigned long long*)take(8 * (size_t)N1);
-    t.acc2 = (unsigned long long*)take(8 * (size_t)N1);
+    t.acc2 = (unsigned long long*)take(8 * (size_t)N1 * kAcc2Split * kAcc2Stride);
     t.dice = (float*)take(4 * (size_t)N1);
     if (ws) *ws = t;
     return off;
@@ -170,8 +177,9 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
         ws.inst[n] = rc;
         if (st.inst) st.inst[n] = rc;
         ws.expect[n] = (unsigned int)cnt;
-        ws.acc1[n] = 0ull; ws.acc2[n] = 0ull;
+        ws.acc1[n] = 0ull;
     }
+    if (lane < kAcc2Split) *acc2_word(ws.acc2, n, lane) = 0ull;
     if (st.colk) {      // "not published yet" (the leaders of the next launch publish; its math waves poll)
         for (int i = lane; i < a.w; i += 64) st.colk[(int64_t)n * a.w + i] = kGranuleInvalid;
         for (int i = lane; i < a.h; i += 64) st.rowk[(int64_t)n * a.h + i] = kGranuleInvalid;
@@ -645,7 +653,9 @@ __device__ __forceinline__ void finish_losses(const EvalWs& ws, const LossState&
         const int i = b0 + lane;
         double v = 0.0; float dv = 0.f;
         if (i < N) {
-            const unsigned long long x = __hip_atomic_load(&ws.acc2[i], BXI_RLX, BXI_AGENT);
+            unsigned long long x = 0ull;
+#pragma unroll
+            for (int sub = 0; sub < kAcc2Split; ++sub) x += __hip_atomic_load(acc2_word(ws.acc2, i, sub), BXI_RLX, BXI_AGENT);
             const long long fixed = (long long)(x & ((1ull << 52) - 1ull)) - ((long long)ws.expect[i] << 24);   // the +1 per tile
             v = (double)fixed;
             dv = __hip_atomic_load(&ws.dice[i], BXI_RLX, BXI_AGENT);
@@ -816,7 +826,8 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
     BXI_TW(1, tix, 5);
     // ---- this tile's share of sum W pw + its arrival: one atomic without return, the wave does not wait for it (a
     // returning atomic on these 32 words costs ~3 us here); the finisher block at the end of the grid watches the counts
-    if (lane == 0) __hip_atomic_fetch_add(&ws.acc2[n], (1ull << 52) + (unsigned long long)fx, BXI_RLX, BXI_AGENT);
+    if (lane == 0)
+        __hip_atomic_fetch_add(acc2_word(ws.acc2, n, wr.tile_r0 / R + wr.tile_c0 / TG<D, R>::TW), (1ull << 52) + (unsigned long long)fx, BXI_RLX, BXI_AGENT);
     BXI_TW(1, tix, 6);
 }
 
@@ -928,7 +939,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair_kernel(const WorkR
         leader_block(a, dil, R, ws, st, blk, upp, g_logits, smem, red);
         BXI_TW(3, blk, 4);
         if (threadIdx.x == 0)                                          // dice[n] is performed (drained in leader_block)
-            __hip_atomic_fetch_add(&ws.acc2[blk], 1ull << 52, BXI_RLX, BXI_AGENT);
+            __hip_atomic_fetch_add(acc2_word(ws.acc2, blk, 0), 1ull << 52, BXI_RLX, BXI_AGENT);
         BXI_TW(3, blk, 5);
         return;
     }
@@ -941,7 +952,13 @@ __global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair_kernel(const WorkR
             bool have = true;
             for (int b0 = 0; b0 < a.N; b0 += 64) {
                 const int i = b0 + lane;
-                if (i < a.N) have &= (unsigned int)(__hip_atomic_load(&ws.acc2[i], BXI_RLX, BXI_AGENT) >> 52) == ws.expect[i] + 1u;
+                if (i < a.N) {
+                    unsigned int arrived = 0u;
+#pragma unroll
+                    for (int sub = 0; sub < kAcc2Split; ++sub)
+                        arrived += (unsigned int)(__hip_atomic_load(acc2_word(ws.acc2, i, sub), BXI_RLX, BXI_AGENT) >> 52);
+                    have &= arrived == ws.expect[i] + 1u;
+                }
             }
             if (__all(have)) { ok = true; break; }
             __builtin_amdgcn_s_sleep(16);
