@@ -44,6 +44,9 @@ constexpr unsigned long long kGranuleInvalid = 0xffffffffull;
 // within a microsecond; atomics on one word are performed one after the other (~0.15 us each): the last arrival became
 // visible ~3 us after it was issued, and the launch ends on it.  Eight words per instance, each in its own 128 bytes.
 constexpr int kAcc2Split = 8, kAcc2Stride = 16;
+// The count waves' sums likewise: only their total over all instances is ever needed (the normaliser is global, :1327-1328),
+// so they go to 64 words, one per lane of whoever adds them up; "every tile counted" = the arrivals add up to the list length.
+constexpr int kAcc1Words = 64;
 __device__ __forceinline__ unsigned long long* acc2_word(unsigned long long* acc2, int n, int sub) {
     return acc2 + ((size_t)n * kAcc2Split + (sub & (kAcc2Split - 1))) * kAcc2Stride;
 }         // bounded waits (never reached: see the grid order above)
@@ -77,7 +80,7 @@ struct EvalWs {                                 // carved from the caller's work
     int* nwork;                                 // [1]
     unsigned int* expect;                       // [N]  tiles of the instance
     // words polled inside pair_kernel; zeroed by prep_kernel's table waves (i.e. before a kernel boundary)
-    unsigned long long* acc1;                   // [N]  count waves : arrivals << 40 | sum W
+    unsigned long long* acc1;                   // [kAcc1Words] (one per 128 B)  count waves : arrivals << 40 | sum W; all words together: every tile, the whole sum
     unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B)  math waves + leader : arrivals << 52 | sum (W pw + 1) in 2^-24 units
     float* dice;                                // [N]
 };
@@ -101,7 +104,7 @@ static size_t carve_eval(void* base, int N, int h, int w, EvalWs* ws) {
     t.work = (WorkRec2*)take(sizeof(WorkRec2) * (size_t)eval_cap(N, h, w, 1, 4));   // the largest list any (dil, R) produces
     t.nwork = (int*)take(sizeof(int));
     t.expect = (unsigned int*)take(4 * (size_t)N1);
-    t.acc1 = (unsigned long long*)take(8 * (size_t)N1);
+    t.acc1 = (unsigned long long*)take(8 * (size_t)kAcc1Words * kAcc2Stride);
     t.acc2 = (unsigned long long*)take(8 * (size_t)N1 * kAcc2Split * kAcc2Stride);
     t.dice = (float*)take(4 * (size_t)N1);
     if (ws) *ws = t;
@@ -177,8 +180,8 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
         ws.inst[n] = rc;
         if (st.inst) st.inst[n] = rc;
         ws.expect[n] = (unsigned int)cnt;
-        ws.acc1[n] = 0ull;
     }
+    if (n == 0) ws.acc1[lane * kAcc2Stride] = 0ull;
     if (lane < kAcc2Split) *acc2_word(ws.acc2, n, lane) = 0ull;
     if (st.colk) {      // "not published yet" (the leaders of the next launch publish; its math waves poll)
         for (int i = lane; i < a.w; i += 64) st.colk[(int64_t)n * a.w + i] = kGranuleInvalid;
@@ -617,27 +620,22 @@ __device__ __forceinline__ void count_tile(const InstArgs& a, const float* __res
     cnt = wave_sum_i32(cnt);
     BXI_TW(2, tix, 3);
     if (lane == 0)   // one packed atomic per tile: (arrival, sum W); integer adds commute -> run-to-run identical
-        __hip_atomic_fetch_add(&ws.acc1[wr.n], (1ull << 40) | (unsigned long long)(unsigned int)cnt, BXI_RLX, BXI_AGENT);
+        __hip_atomic_fetch_add(&ws.acc1[((wr.n * 7 + wr.tile_r0 / R + wr.tile_c0) & (kAcc1Words - 1)) * kAcc2Stride],
+                               (1ull << 40) | (unsigned long long)(unsigned int)cnt, BXI_RLX, BXI_AGENT);
+}
+
+// One round over the count words: true when every tile of the list has been counted; then *total = sum W over all instances.
+__device__ __forceinline__ bool counts_complete(const EvalWs& ws, int nwork, double* total) {
+    const unsigned long long x = __hip_atomic_load(&ws.acc1[(threadIdx.x & 63) * kAcc2Stride], BXI_RLX, BXI_AGENT);
+    const double arrived = wave_sum_f64((double)(x >> 40)), s = wave_sum_f64((double)(x & ((1ull << 40) - 1ull)));   // exact: integers far below 2^53
+    *total = s;
+    return arrived == (double)nwork;
 }
 
 // sum W over all instances, once every count wave has arrived.  Returns false on a time-out (never expected).
-__device__ __forceinline__ bool total_weight(const EvalWs& ws, int N, double* total) {
-    const int lane = threadIdx.x & 63;
+__device__ __forceinline__ bool total_weight(const EvalWs& ws, int nwork, double* total) {
     for (unsigned spins = 0;; ++spins) {
-        bool ok = true;
-        unsigned long long s = 0ull;
-        for (int b0 = 0; b0 < N; b0 += 64) {
-            const int i = b0 + lane;
-            if (i < N) {
-                const unsigned long long x = __hip_atomic_load(&ws.acc1[i], BXI_RLX, BXI_AGENT);
-                ok &= (unsigned int)(x >> 40) == ws.expect[i];
-                s += x & ((1ull << 40) - 1ull);
-            }
-        }
-        if (__all(ok)) {
-            *total = wave_sum_f64((double)s);        // exact: integers far below 2^53
-            return true;
-        }
+        if (counts_complete(ws, nwork, total)) return true;
         if (spins > kSpinLimit) return false;
         __builtin_amdgcn_s_sleep(8);
     }
@@ -677,7 +675,7 @@ template <int D, int R>
 __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __restrict__ lab, const EvalWs& ws, const LossState& st,
                                           const WorkRec2& wr, float warmup, float upp, float upw, float* __restrict__ losses,
                                           float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
-                                          double& total_w, bool& have_total, int tix) {
+                                          double& total_w, bool& have_total, int nwork, int tix) {
     constexpr int RD = TG<D, R>::RD;
     const int lane = threadIdx.x & 63;
     const int h = a.h, w = a.w, n = wr.n;
@@ -782,20 +780,13 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
     unsigned long long ck = 0ull, rk = 0ull;
     for (unsigned spins = 0;; ++spins) {
         bool have = true;
-        unsigned long long sw = 0ull;
-        if (!have_total)
-            for (int b0 = 0; b0 < a.N; b0 += 64) {
-                const int i = b0 + lane;
-                if (i < a.N) {
-                    const unsigned long long x = __hip_atomic_load(&ws.acc1[i], BXI_RLX, BXI_AGENT);
-                    have &= (unsigned int)(x >> 40) == ws.expect[i];
-                    sw += x & ((1ull << 40) - 1ull);
-                }
-            }
+        double sw = 0.0;
+        bool counted = true;
+        if (!have_total) counted = counts_complete(ws, nwork, &sw);       // wave-uniform
         if (col_owned) { ck = __hip_atomic_load(&st.colk[(int64_t)n * w + c], BXI_RLX, BXI_AGENT); have &= (unsigned int)ck != 0xffffffffu; }
         if (row_lane) { rk = __hip_atomic_load(&st.rowk[(int64_t)n * h + wr.tile_r0 + lane], BXI_RLX, BXI_AGENT); have &= (unsigned int)rk != 0xffffffffu; }
-        if (__all(have)) {
-            if (!have_total) { total_w = wave_sum_f64((double)sw); have_total = true; }     // exact: integers far below 2^53
+        if (counted && __all(have)) {
+            if (!have_total) { total_w = sw; have_total = true; }
             break;
         }
         if (spins > kSpinLimit) { ok = false; break; }
@@ -964,7 +955,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair_kernel(const WorkR
             __builtin_amdgcn_s_sleep(16);
         }
         double total_w = 0.0;
-        ok = total_weight(ws, a.N, &total_w) && ok;
+        ok = total_weight(ws, *nwork_p, &total_w) && ok;
         if (!ok && lane == 0 && st.status) atomicOr(st.status, 2);
         finish_losses(ws, st, a.N, warmup, total_w, upp, upw, losses);
         return;
@@ -983,7 +974,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair_kernel(const WorkR
     for (int wi = first; wi < nwork; wi += stride_w) {
         const WorkRec2 wr = work[wi];
         if (counting) count_tile<D, R>(a, lab, ws, wr, tix);
-        else math_tile<D, R>(a, lab, ws, st, wr, warmup, upp, upw, losses, g_logits, gbuf, total_w, have_total, tix);
+        else math_tile<D, R>(a, lab, ws, st, wr, warmup, upp, upw, losses, g_logits, gbuf, total_w, have_total, nwork, tix);
     }
 }
 
