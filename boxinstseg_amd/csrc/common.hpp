@@ -109,6 +109,48 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 
+// Wave totals on the VALU's data-parallel path (DPP) instead of six dependent trips through the LDS crossbar
+// (__shfl_xor = ds_bpermute, ~130 clk each): quad swaps, the two mirrors within a row of 16 lanes, then the four rows by
+// v_readlane.  Every lane gets the total; fixed order, so run-to-run identical.
+template <typename F>
+__device__ __forceinline__ void wave_total_steps(F&& step) {
+    step(0xB1);    // quad_perm:[1,0,3,2]
+    step(0x4E);    // quad_perm:[2,3,0,1]
+    step(0x141);   // row_half_mirror
+    step(0x140);   // row_mirror
+}
+__device__ __forceinline__ int dpp_i32(int v, int ctrl) {
+    switch (ctrl) {
+        case 0xB1: return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
+        case 0x4E: return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
+        case 0x141: return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
+        default: return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
+    }
+}
+__device__ __forceinline__ float wave_total_f32(float v) {
+    wave_total_steps([&](int c) { v += __int_as_float(dpp_i32(__float_as_int(v), c)); });
+    const int b = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+}
+__device__ __forceinline__ int wave_total_i32(int v) {
+    wave_total_steps([&](int c) { v += dpp_i32(v, c); });
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+__device__ __forceinline__ double wave_total_f64(double v) {
+    wave_total_steps([&](int c) {
+        const long long b = __double_as_longlong(v);
+        const int lo = dpp_i32((int)b, c), hi = dpp_i32((int)(b >> 32), c);
+        v += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    });
+    auto row = [&](int l) {
+        const long long b = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    };
+    return (row(0) + row(16)) + (row(32) + row(48));
+}
+
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for the
 // wave's outstanding global stores (vmcnt), so zero-fill / output stores stay in flight across it.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

@@ -617,7 +617,7 @@ __device__ __forceinline__ void count_tile(const InstArgs& a, const float* __res
               cnt += pn ? (int)(((m[3].nA >> i) & 1u) + ((m[3].nB >> i) & 1u)) : 0; }
         }
     }
-    cnt = wave_sum_i32(cnt);
+    cnt = wave_total_i32(cnt);
     BXI_TW(2, tix, 3);
     if (lane == 0)   // one packed atomic per tile: (arrival, sum W); integer adds commute -> run-to-run identical
         __hip_atomic_fetch_add(&ws.acc1[((wr.n * 7 + wr.tile_r0 / R + wr.tile_c0) & (kAcc1Words - 1)) * kAcc2Stride],
@@ -627,7 +627,7 @@ __device__ __forceinline__ void count_tile(const InstArgs& a, const float* __res
 // One round over the count words: true when every tile of the list has been counted; then *total = sum W over all instances.
 __device__ __forceinline__ bool counts_complete(const EvalWs& ws, int nwork, double* total) {
     const unsigned long long x = __hip_atomic_load(&ws.acc1[(threadIdx.x & 63) * kAcc2Stride], BXI_RLX, BXI_AGENT);
-    const double arrived = wave_sum_f64((double)(x >> 40)), s = wave_sum_f64((double)(x & ((1ull << 40) - 1ull)));   // exact: integers far below 2^53
+    const double arrived = (double)wave_total_i32((int)(x >> 40)), s = wave_total_f64((double)(x & ((1ull << 40) - 1ull)));   // exact: integers far below 2^31 / 2^53
     *total = s;
     return arrived == (double)nwork;
 }
@@ -768,7 +768,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
     }
     // ---- epilogue: one round of polls for everything the stores need, the arrival issued before and consumed after them ----
     BXI_TW(1, tix, 3);
-    num = wave_sum_f32(num);
+    num = wave_total_f32(num);
     const long long fx = (long long)(num * kNumScale) + (1ll << 24);     // + 1.0: keeps the packed field non-negative
     const int c = wr.tile_c0 - D + lane;
     const bool col_owned = g_logits && lane >= D && lane < 64 - D && c < wr.hc1;
