@@ -1,6 +1,7 @@
 #!/bin/bash
-# Developer helper (GPU box): everything profiles/ is built from.  Usage: tools/gpu_profiles.sh r02
+# Developer helper (GPU box): everything profiles/ is built from.  Usage: tools/gpu_profiles.sh r02 [eval-only]
 TAG=${1:-r02}
+ONLY=${2:-all}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
@@ -13,6 +14,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   ls $R/gpurun_out/pmc_$c | head -3
 done
 for t in pairwise_op dynamic_head discobox levelset tree_filter; do
+  [ "$ONLY" = eval-only ] && break
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$t -o $TAG -- python $R/tools/bench_$t.py > $R/gpurun_out/${t}_bench.json 2> $R/gpurun_out/${t}_bench.err
   tail -c 300 $R/gpurun_out/${t}_bench.json | tr '\n' ' '; echo
 done
