@@ -658,7 +658,7 @@ __device__ __forceinline__ void finish_losses(const EvalWs& ws, const LossState&
             v = (double)fixed;
             dv = __hip_atomic_load(&ws.dice[i], BXI_RLX, BXI_AGENT);
         }
-        num += wave_sum_f64(v);
+        num += wave_total_f64(v);
         const int m = min(64, N - b0);
         for (int k = 0; k < m; ++k) dsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), k));   // index order
     }
@@ -825,7 +825,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
 // ---- leader workgroup --------------------------------------------------------------------------------------------
 __device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = wave_sum_f32(v[k]);
+    for (int k = 0; k < 4; ++k) v[k] = wave_total_f32(v[k]);
     __syncthreads();
     if ((threadIdx.x & 63) == 0)
 #pragma unroll
