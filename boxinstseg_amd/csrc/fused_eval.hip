@@ -269,13 +269,19 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const EvalWs& ws
     float wmax[kSRows];
 #pragma unroll
     for (int i = 0; i < kSRows; ++i) wmax[i] = rmax[i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    // eight maxima over the wave side by side: within rows of 16 lanes by DPP, the four rows by v_readlane (no LDS crossbar)
+    wave_total_steps([&](int c) {
         float o[kSRows];
 #pragma unroll
-        for (int i = 0; i < kSRows; ++i) o[i] = __shfl_xor(wmax[i], off, kWave);
+        for (int i = 0; i < kSRows; ++i) o[i] = __int_as_float(dpp_i32(__float_as_int(wmax[i]), c));
 #pragma unroll
         for (int i = 0; i < kSRows; ++i) wmax[i] = fmaxf(wmax[i], o[i]);
+    });
+#pragma unroll
+    for (int i = 0; i < kSRows; ++i) {
+        const int b = __float_as_int(wmax[i]);
+        wmax[i] = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
+                        fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
     }
     unsigned long long mine = 0ull;
 #pragma unroll
