@@ -85,30 +85,6 @@ __device__ __forceinline__ unsigned long long pack_max(float x, uint32_t idx) {
 __device__ __forceinline__ float unpack_val(unsigned long long k) { return key_float((uint32_t)(k >> 32)); }
 __device__ __forceinline__ uint32_t unpack_idx(unsigned long long k) { return 0xffffffffu - (uint32_t)k; }
 
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        unsigned long long o = __shfl_xor(v, off, kWave);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-__device__ __forceinline__ float wave_sum_f32(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
-}
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
-}
-
 // Wave totals on the VALU's data-parallel path (DPP) instead of six dependent trips through the LDS crossbar
 // (__shfl_xor = ds_bpermute, ~130 clk each): quad swaps, the two mirrors within a row of 16 lanes, then the four rows by
 // v_readlane.  Every lane gets the total; fixed order, so run-to-run identical.
@@ -150,6 +126,29 @@ __device__ __forceinline__ double wave_total_f64(double v) {
     };
     return (row(0) + row(16)) + (row(32) + row(48));
 }
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    wave_total_steps([&](int c) {
+        const unsigned long long o = ((unsigned long long)(unsigned int)dpp_i32((int)(v >> 32), c) << 32) | (unsigned int)dpp_i32((int)v, c);
+        v = o > v ? o : v;
+    });
+    auto row = [&](int l) {
+        return ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)v, l);
+    };
+    const unsigned long long a = row(0), b = row(16), c2 = row(32), d = row(48);
+    const unsigned long long ab = a > b ? a : b, cd = c2 > d ? c2 : d;
+    return ab > cd ? ab : cd;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    wave_total_steps([&](int c) { v = fmaxf(v, __int_as_float(dpp_i32(__float_as_int(v), c))); });
+    const int b = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
+}
+// (the historical names: every kernel's wave reduction goes through the DPP forms above)
+__device__ __forceinline__ float wave_sum_f32(float v) { return wave_total_f32(v); }
+__device__ __forceinline__ double wave_sum_f64(double v) { return wave_total_f64(v); }
+__device__ __forceinline__ int wave_sum_i32(int v) { return wave_total_i32(v); }
 
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for the
 // wave's outstanding global stores (vmcnt), so zero-fill / output stores stay in flight across it.

@@ -347,9 +347,7 @@ __global__ __launch_bounds__(256) void mil_band_kernel(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const u64 k = wave_max_u64(rkey[i]);
-            float tm = rt[i];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) tm = fmaxf(tm, __shfl_xor(tm, off, kWave));
+            const float tm = wave_max_f32(rt[i]);
             if (lane == 0 && rb + i < H) {
                 ms.rowv[(int64_t)n * H + rb + i] = unpack_val(k); ms.rowt[(int64_t)n * H + rb + i] = tm; argr[rb + i] = (int)unpack_idx(k);
             }
