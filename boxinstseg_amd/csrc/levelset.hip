@@ -480,8 +480,25 @@ __global__ __launch_bounds__(kLcmPadThreads) void lcm_adjoint_pad_kernel(const f
             if (gsrc[j] >= 0) gz[gdst[j]] = 0.f + gp[gsrc[j]];
         if (bdst >= 0) {
             float acc = 0.f;
-            for (int sr = b_r & 0xffff; sr <= (b_r >> 16); ++sr)
-                for (int sc = b_c & 0xffff; sc <= (b_c >> 16); ++sc) acc += gp[sr * wp + sc];
+            if constexpr (D > 0) {
+                // at most (D + 1) x (D + 1) replicas: all loads issued together, added in row / column order (an absent one adds
+                // +0, which changes nothing); the run-time loops below made six waves walk dependent LDS reads while the
+                // other ten waited at the barrier
+                float v[(D + 1) * (D + 1)];
+#pragma unroll
+                for (int i = 0; i <= D; ++i)
+#pragma unroll
+                    for (int j = 0; j <= D; ++j) {
+                        const int sr = (b_r & 0xffff) + i, sc = (b_c & 0xffff) + j;
+                        const bool ok = sr <= (b_r >> 16) && sc <= (b_c >> 16);
+                        v[i * (D + 1) + j] = ok ? gp[sr * wp + sc] : 0.f;
+                    }
+#pragma unroll
+                for (int k = 0; k < (D + 1) * (D + 1); ++k) acc += v[k];
+            } else {
+                for (int sr = b_r & 0xffff; sr <= (b_r >> 16); ++sr)
+                    for (int sc = b_c & 0xffff; sc <= (b_c >> 16); ++sc) acc += gp[sr * wp + sc];
+            }
             gz[bdst] = acc;
         }
         __syncthreads();
