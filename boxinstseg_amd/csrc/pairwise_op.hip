@@ -170,6 +170,9 @@ template <typename T> struct LogTriple { T a, b, dd; };
 template <typename T> struct ProbPair { T s, m; };      // sigmoid(x), sigmoid(-x)
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // 1 ulp
 __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+// exp(-a), a >= 0: v_exp_f32 (2^x, ~1 ulp) on a * log2(e) -- the staged probabilities need 1e-6, not the last bit
+__device__ __forceinline__ float fast_exp_neg(float a) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * a); }
+__device__ __forceinline__ double fast_exp_neg(double a) { return exp(-a); }
 
 
 template <typename T>
@@ -206,24 +209,24 @@ __global__ __launch_bounds__(256) void pairwise3_bwd_kernel(const T* __restrict_
     const int c = c0 + lc;
     const T* GP = g_pair + n * 8 * P;
     T own[kPwTR / 4];
-    // the gradient sums G = g[k][p] + g[7-k][q] of all four pixels of the thread: 64 loads, requested before the
-    // block decides on its body and stages the tile, so that they fly meanwhile.  A neighbour's
-    // address is the pixel's plus a wave-uniform constant; where the neighbour lies outside the map the pixel's own address
-    // stands in (the value is not used), so no clamping arithmetic and no branch stands in front of the loads.
+    // the gradient sums G = g[k][p] + g[7-k][q] of all four pixels of the thread: 64 loads, requested before the block decides
+    // on its body and stages the tile, so that they fly meanwhile.  Addresses: a wave-uniform base (instance, plane, tap
+    // offset) + the pixel's 32-bit index; a neighbour outside the map gets weight 0 later, so its address only has to stay
+    // inside the instance's 8 planes -- one v_med3 on the index, no row / column clamps and no selects in front of the loads
+    // (that arithmetic, ~5 instructions per load, was a quarter of the kernel).
     T G[kPwTR / 4][8];
     const int cc = min(c, W - 1);
-    const bool c_lo = cc - d >= 0, c_hi = cc + d < W;
+    const int lim = (int)(8 * P) - 1;                    // fits: the launcher checks N * 8 * P against 2^31
 #pragma unroll
     for (int j = 0; j < kPwTR / 4; ++j) {
         const int r = min(r0 + lr0 + 4 * j, H - 1);
-        const T* base = GP + ((int64_t)r * W + cc);
-        const bool r_lo = r - d >= 0, r_hi = r + d < H;
+        const int pix = r * W + cc;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;
-            const bool ok = (dy < 0 ? r_lo : (dy > 0 ? r_hi : true)) && (dx < 0 ? c_lo : (dx > 0 ? c_hi : true));
-            const T* q = ok ? base + ((int64_t)(dy * d) * W + dx * d) : base;
-            G[j][k] = base[(int64_t)k * P] + q[(int64_t)(7 - k) * P];
+            const int own = k * (int)P + pix;
+            const int nb = min(max((7 - k) * (int)P + (dy * d) * W + dx * d + pix, 0), lim);
+            G[j][k] = GP[own] + GP[nb];
         }
     }
     // (sat is known once the logit loads -- issued first -- have returned; the G loads stay in flight across the barrier)
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256) void pairwise3_bwd_kernel(const T* __restrict_
             for (int hf = 0; hf < 2; ++hf) {
                 const int sc = slane + 64 * hf;
                 if (sr < PR && sc < PC) {
-                    const T x = xv[e][hf], en = t_exp(-t_abs(x)), big = T(1) / (T(1) + en), small = en * big;   // sigmoid(|x|), sigmoid(-|x|)
+                    const T x = xv[e][hf], en = fast_exp_neg(t_abs(x)), big = fast_rcp(T(1) + en), small = en * big;   // sigmoid(|x|), sigmoid(-|x|)
                     tile[sr * PC + sc] = x >= T(0) ? ProbPair<T>{big, small} : ProbPair<T>{small, big};
                 }
             }
