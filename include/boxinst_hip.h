@@ -275,8 +275,10 @@ int bxi_dice_loss_backward_f32(const float* input, const void* target, int targe
                                const float* sums, const float* g_loss, float* g_input, void* stream);
 
 /* mil_loss(dice_loss, input, _, target) (:552-562): row/column maxima of input and target [N,H,W], one dice term
- * per axis.  loss [N].  state (bxi_mil_loss_state_bytes) keeps the arg-max positions and the unit gradients of the
- * H + W maxima; the backward writes g_input [N,H,W] densely (zeros elsewhere), no atomics. */
+ * per axis.  loss [N].  state (bxi_mil_loss_state_bytes, 16-byte aligned) keeps the arg-max positions and the unit
+ * gradients of the H + W maxima, followed by the forward's scratch (per-band column maxima: the forward is two launches,
+ * row bands over the whole GPU + one workgroup per instance); the backward writes g_input [N,H,W] densely (zeros
+ * elsewhere), no atomics. */
 size_t bxi_mil_loss_state_bytes(int N, int H, int W);
 int bxi_mil_loss_forward_f32(const float* input, const void* target, int target_u8, int N, int H, int W, float* loss,
                              void* state, void* stream);
