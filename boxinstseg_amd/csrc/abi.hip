@@ -1,5 +1,6 @@
 // abi.hip -- library-level entry points of libboxinst_hip.so (see include/boxinst_hip.h).
 #include "common.hpp"
+#include "dynamic_head_device.hpp"
 
 namespace bxi {
 
@@ -13,7 +14,7 @@ size_t eval_ws_bytes(int N, int h, int w);
 bool fused_eval_supported(int dil);
 int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thresh, const bxi_instances* in, int dil, float warmup,
                       const float* up_prj, const float* up_pw, float* losses, float* g_logits, void* state, void* workspace,
-                      size_t workspace_bytes, int force_rows, void* stream);
+                      size_t workspace_bytes, int force_rows, void* stream, const DynArgs* head = nullptr, int head_C = 0);
 int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits,
                    void* stream);
 
@@ -89,6 +90,33 @@ int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances*
     char* lws = base + bxi::up256(sizeof(float) * (size_t)batch_host->B * 3 * P);
     return bxi::launch_fused_eval(batch_host, lab, color_thresh, inst_host, dilation, warmup, up_prj, up_pw, losses, g_logits,
                                   state, lws, workspace_bytes - (size_t)(lws - base), 0, stream);
+}
+
+int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host, const float* feat, int C, int Hs,
+                              int Ws, const float* params, const float* coors, const int64_t* level_inds, const int64_t* img_inds,
+                              const float* sizes_of_interest, int n_levels, int in_stride, int factor, int disable_rel_coors,
+                              int size, int dilation, float color_thresh, float warmup, const float* up_prj, const float* up_pw,
+                              float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!batch_host || !inst_host) return BXI_ERR_NULL_POINTER;
+    if (size < 1 || (size & 1) == 0 || dilation < 1) return BXI_ERR_BAD_ARGUMENT;
+    if (size != 3 || !bxi::fused_eval_supported(dilation)) return BXI_ERR_UNSUPPORTED;
+    const int stride = inst_host->stride;
+    if (stride < 1 || batch_host->Hc != inst_host->Hc || batch_host->Wc != inst_host->Wc || batch_host->B != inst_host->B)
+        return BXI_ERR_BAD_SHAPE;
+    if (inst_host->N == 0) return BXI_ERR_UNSUPPORTED;      // nothing to fuse: bxi_boxinst_eval_f32 writes the two zeros
+    if (!inst_host->logits) return BXI_ERR_NULL_POINTER;
+    bxi::DynArgs da;
+    int rc = bxi::fill_dyn(feat, inst_host->B, C, Hs, Ws, params, inst_host->N, coors, level_inds, img_inds, sizes_of_interest, n_levels,
+                           in_stride, factor, disable_rel_coors, da);
+    if (rc != BXI_OK) return rc;
+    const size_t need = bxi_boxinst_eval_workspace_bytes(batch_host->B, batch_host->Hc, batch_host->Wc, stride, inst_host->N);
+    if (!workspace || need == 0 || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
+    const size_t P = (size_t)inst_host->h * inst_host->w;
+    char* base = (char*)workspace;
+    float* lab = (float*)base;
+    char* lws = base + bxi::up256(sizeof(float) * (size_t)batch_host->B * 3 * P);
+    return bxi::launch_fused_eval(batch_host, lab, color_thresh, inst_host, dilation, warmup, up_prj, up_pw, losses, g_logits, state, lws,
+                                  workspace_bytes - (size_t)(lws - base), 0, stream, &da, C);
 }
 
 int bxi_boxinst_grad_rescale_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw, int dilation,

@@ -31,143 +31,14 @@
 // dyn_reduce_kernel  g_params[n,q] = sum over tiles ; g_feat[b,c,p] = sum over slots.
 // Measured (MI355X, B=2 C=16 100x128 -> 200x256, rocprofv3): N=32: fwd 13.3 us, bwd 29.6 us, reduce 6.0 us
 // (PyTorch-ROCm running the reference's op sequence: 228 us forward, 785 us forward+backward).
-#include "common.hpp"
+#include "dynamic_head_device.hpp"
 
 namespace bxi {
-
-constexpr int kDC = 8;            // dynamic_channels (configs/boxinst: 8)
-constexpr int kYR = 8, kYC = 32;  // y tile (pixels at in_stride resolution) per workgroup
-constexpr int kSlots = 8;         // instance slots per (image, tile) in the backward
-constexpr int kRowPad = kYR * kYC;       // LDS row stride of the staged operand rows
-
-struct DynArgs {
-    const float* feat;        // [B,C,H,W]
-    const float* params;      // [N,P]  P = (C+2)*8 + 64 + 8 + 8 + 8 + 1
-    const float* coors;       // [N,2]  (x,y) of the generating location, image pixels
-    const int64_t* level;     // [N]
-    const int64_t* img;       // [N]
-    const float* soi;         // [n_levels]
-    int B, H, W, N, n_levels, in_stride, factor, rel;   // rel = !disable_rel_coors
-};
-
-
-// one pixel through the three dynamic layers.  `wts` = the instance's parameters in LDS (broadcast reads).
-// Every bound is a compile-time constant: a runtime bound would index the register arrays dynamically,
-// which the compiler can only serve with select chains (the first version of this file ran 10x slower).
-template <int C, bool REL> struct Dyn {
-    static constexpr int CIN = REL ? C + 2 : C;
-    static constexpr int W1 = CIN * kDC, W2 = W1 + kDC * kDC, B0 = W2 + kDC, B1 = B0 + kDC, B2 = B1 + kDC, P = B2 + 1;
-};
-
-// BXI_SEGMENT: the scheduler may not move instructions across it.  The weights arrive by scalar loads; without
-// the fences the scheduler hoists all 233 loads to the top, runs out of SGPRs and spills them to VGPR lanes.
-#define BXI_SEGMENT() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-
-// Packed math: a dot product runs over input PAIRS, acc2 += (w[2k], w[2k+1]) * (x[2k], x[2k+1]) as one
-// v_pk_fma_f32 with the weight pair as an SGPR operand, and ends with acc2.x + acc2.y: half the VALU
-// instructions of scalar FMAs (left to itself the compiler emits v_pk_mul + two v_add per pair).
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f w2_at(const float* __restrict__ w, int i) { return v2f{w[i], w[i + 1]}; }
-
-// in2/h1/h2 hold consecutive channels as pairs
-template <int C, bool REL>
-__device__ __forceinline__ float mlp_forward(const float* __restrict__ wts, const v2f (&in2)[Dyn<C, REL>::CIN / 2],
-                                             v2f (&h1)[kDC / 2], v2f (&h2)[kDC / 2]) {
-    using D = Dyn<C, REL>;
-    static_assert(D::CIN % 2 == 0, "packed dot products need an even channel count");
-    float t[kDC];
-#pragma unroll
-    for (int o = 0; o < kDC; ++o) {
-        if (o % 4 == 0) BXI_SEGMENT();
-        v2f acc = {wts[D::B0 + o], 0.f};
-#pragma unroll
-        for (int i = 0; i < D::CIN / 2; ++i) acc = pk_fma(w2_at(wts, o * D::CIN + 2 * i), in2[i], acc);
-        t[o] = fmaxf(acc.x + acc.y, 0.f);
-    }
-#pragma unroll
-    for (int o = 0; o < kDC / 2; ++o) h1[o] = v2f{t[2 * o], t[2 * o + 1]};
-    BXI_SEGMENT();
-#pragma unroll
-    for (int o = 0; o < kDC; ++o) {
-        v2f acc = {wts[D::B1 + o], 0.f};
-#pragma unroll
-        for (int i = 0; i < kDC / 2; ++i) acc = pk_fma(w2_at(wts, D::W1 + o * kDC + 2 * i), h1[i], acc);
-        t[o] = fmaxf(acc.x + acc.y, 0.f);
-    }
-#pragma unroll
-    for (int o = 0; o < kDC / 2; ++o) h2[o] = v2f{t[2 * o], t[2 * o + 1]};
-    v2f y = {wts[D::B2], 0.f};
-#pragma unroll
-    for (int i = 0; i < kDC / 2; ++i) y = pk_fma(w2_at(wts, D::W2 + 2 * i), h2[i], y);
-    BXI_SEGMENT();
-    return y.x + y.y;
-}
-
-// two pixels at once: every weight is used the moment its scalar load lands, so none has to be kept
-// (evaluating the pixels one after the other makes the compiler keep all 233 SGPRs and spill them).  The two pixels ride
-// in the two halves of packed FMAs, acc(A,B) += (w,w) * (x_A, x_B), the weight broadcast from its SGPR: one instruction per
-// weight instead of two (the forward kernel is bound by instruction issue, not by its 6.5 MB of stores).
-template <int C, bool REL>
-__device__ __forceinline__ void mlp_forward2(const float* __restrict__ wts, const float (&inA)[Dyn<C, REL>::CIN],
-                                             const float (&inB)[Dyn<C, REL>::CIN], float& yA, float& yB) {
-    using D = Dyn<C, REL>;
-    v2f x0[D::CIN], x1[kDC], x2[kDC];
-#pragma unroll
-    for (int i = 0; i < D::CIN; ++i) x0[i] = v2f{inA[i], inB[i]};
-#pragma unroll
-    for (int o = 0; o < kDC; ++o) {
-        const float b = wts[D::B0 + o];
-        v2f acc = {b, b};
-#pragma unroll
-        for (int i = 0; i < D::CIN; ++i) { const float w = wts[o * D::CIN + i]; acc = pk_fma(v2f{w, w}, x0[i], acc); }
-        x1[o] = v2f{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f)};
-    }
-#pragma unroll
-    for (int o = 0; o < kDC; ++o) {
-        const float b = wts[D::B1 + o];
-        v2f acc = {b, b};
-#pragma unroll
-        for (int i = 0; i < kDC; ++i) { const float w = wts[D::W1 + o * kDC + i]; acc = pk_fma(v2f{w, w}, x1[i], acc); }
-        x2[o] = v2f{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f)};
-    }
-    const float b2 = wts[D::B2];
-    v2f y = {b2, b2};
-#pragma unroll
-    for (int i = 0; i < kDC; ++i) { const float w = wts[D::W2 + i]; y = pk_fma(v2f{w, w}, x2[i], y); }
-    yA = y.x; yB = y.y;
-}
-
-// in[] = (relative coordinates when REL,) C feature channels of pixel (r,c) of image b
-template <int C, bool REL>
-__device__ __forceinline__ void load_inputs(const DynArgs& a, int n, int b, int r, int c, float (&in)[Dyn<C, REL>::CIN]) {
-    const int64_t HW = (int64_t)a.H * a.W;
-    const float* fb = a.feat + (int64_t)b * C * HW;          // uniform base, 32-bit lane offset
-    const unsigned po = (unsigned)(r * a.W + c);
-    constexpr int off = REL ? 2 : 0;
-    if constexpr (REL) {
-        // locations = arange(0, W*stride, stride) + stride // 2 (:1143-1150); (coors - locations) / soi (:1151-1153)
-        const float soi = a.soi[a.level[n]];
-        in[0] = (a.coors[2 * n] - (float)(c * a.in_stride + a.in_stride / 2)) / soi;
-        in[1] = (a.coors[2 * n + 1] - (float)(r * a.in_stride + a.in_stride / 2)) / soi;
-    }
-#pragma unroll
-    for (int k = 0; k < C; ++k) in[off + k] = (fb + (int64_t)k * HW)[po];
-}
 
 // ---- forward ---------------------------------------------------------------------------------------
 // F = the up-sampling factor as a compile-time constant (0: read a.factor; every index division is then a
 // real integer division, ~40 instructions each)
 template <int F> __device__ __forceinline__ int factor_of(const DynArgs& a) { return F ? F : a.factor; }
-
-// source row/column and fraction of output index R (aligned_bilinear :146-167):
-// z[R] = I[max(R - f/2, 0)], I[i] = sample of (y padded by one replicated row) at i/f
-__device__ __forceinline__ void upsample_src(int R, int f, int n_in, int& i0, int& i1, float& fr) {
-    const int ii = max(R - f / 2, 0);
-    i0 = ii / f;
-    fr = (float)(ii - i0 * f) / (float)f;
-    i1 = min(i0 + 1, n_in - 1);                             // replicate pad (:156)
-}
 
 template <int C, bool REL, int F>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
@@ -598,7 +469,7 @@ __global__ __launch_bounds__(256) void dyn_reduce_kernel(const float* __restrict
     }
 }
 
-static int fill_dyn(const float* feat, int B, int C, int H, int W, const float* params, int N, const float* coors,
+int fill_dyn(const float* feat, int B, int C, int H, int W, const float* params, int N, const float* coors,
                     const int64_t* level, const int64_t* img, const float* soi, int n_levels, int in_stride, int factor,
                     int disable_rel, DynArgs& a) {
     if (B <= 0 || H <= 0 || W <= 0 || N < 0 || n_levels <= 0) return BXI_ERR_BAD_SHAPE;

@@ -29,6 +29,7 @@
 // Data layout in HBM: everything NCHW / row-major as the reference hands it over; Lab [B,3,h,w] f32 is the only
 // materialised intermediate (1.2 MB at 2x800x1024).
 #include "loss_common.hpp"
+#include "dynamic_head_device.hpp"
 #include <cstdlib>
 
 namespace bxi {
@@ -201,15 +202,22 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
 //   - zero-fill of d loss / d logits first (depends on nothing; pair_kernel overwrites the box tiles);
 //   - all 8 row loads in flight together; per-row max / first arg-max by 8 interleaved butterflies;
 //   - per-column max / first arg-max over the wave's rows in registers, over the block's 4 waves through LDS.
+// `src(r, c)` hands over logits (r, c .. c + 3) of instance n: loaded (LogitRows) or produced on the spot by the dynamic mask
+// head (HeadRows, head-fused variant); every (r, c) is asked for exactly once.
+struct LogitRows {
+    const float* L; int w, vec;
+    __device__ __forceinline__ float4 operator()(int r, int c) const { return load4(L + (int64_t)r * w, c, w, vec); }
+};
+
+template <typename Src>
 __device__ __forceinline__ void stream_block(const InstArgs& a, const EvalWs& ws, float* __restrict__ g_logits, int vec, int sb,
-                                             unsigned long long* colp /* LDS [kWaves][w] */) {
+                                             unsigned long long* colp /* LDS [kWaves][w] */, const Src& src) {
     const int h = a.h, w = a.w;
     const int Sn = (h + kSBlk - 1) / kSBlk;
     const int n = sb / Sn, s = sb % Sn;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r0 = s * kSBlk + wv * kSRows, r1 = min(h, r0 + kSRows);     // may be empty
     const int64_t P = (int64_t)h * w;
-    const float* L = a.logits + (int64_t)n * P;
     float* G = g_logits ? g_logits + (int64_t)n * P : nullptr;
     const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -230,7 +238,7 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const EvalWs& ws
     {
         const int c = lane * 4;
 #pragma unroll
-        for (int i = 0; i < kSRows; ++i) v[i] = (r0 + i < r1 && c < w) ? load4(L + (int64_t)(r0 + i) * w, c, w, vec) : ninf;
+        for (int i = 0; i < kSRows; ++i) v[i] = (r0 + i < r1 && c < w) ? src(r0 + i, c) : ninf;
     }
     BXI_TW(0, (int)blockIdx.x * kWaves + wv, 1);
     float rmax[kSRows]; int rcol[kSRows];
@@ -263,7 +271,7 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const EvalWs& ws
         if (cb >= w) break;
         const int c2 = cb + lane * 4;
 #pragma unroll
-        for (int i = 0; i < kSRows; ++i) v[i] = (r0 + i < r1 && c2 < w) ? load4(L + (int64_t)(r0 + i) * w, c2, w, vec) : ninf;
+        for (int i = 0; i < kSRows; ++i) v[i] = (r0 + i < r1 && c2 < w) ? src(r0 + i, c2) : ninf;
     }
     BXI_TW(0, (int)blockIdx.x * kWaves + wv, 2);
     float wmax[kSRows];
@@ -401,6 +409,84 @@ __device__ __forceinline__ void pool_block(const PoolArgs& pa, int first, int st
     }
 }
 
+// ---- head-fused variant: the stream role PRODUCES the logits ---------------------------------------------------------
+// The dynamic mask head (condinst_head.py:1139-1164: relative coordinates, three per-instance 1x1 convolutions with ReLU,
+// aligned_bilinear x2) evaluated where its output is first consumed: a stream block of instance n computes y on the 18 source
+// rows its 32 output rows sample (4 waves x rows, a lane two neighbouring pixels through mlp_forward2: one wave per SIMD issues
+// ~3000 instructions, under the image pooling's memory time), parks them in LDS, and then up-samples row by row straight into
+// the registers the maxima are taken from -- writing the logits (for pair_kernel and the head's backward) on the way.  The
+// separate 11.6 us dyn_fwd launch, its kernel boundary and one 6.5 MB read of the logits disappear.  Factor 2 only (every
+// shipped config: mask features at stride 8, logits at stride 4).
+template <int C, bool REL>
+__device__ __forceinline__ void head_stage_rows(const DynArgs& da, const float* __restrict__ params, int n, int ys0, int nrows,
+                                                float* __restrict__ ybuf /* LDS [nrows][W] */) {
+    using D = Dyn<C, REL>;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* __restrict__ wts = params + (int64_t)n * D::P;       // wave-uniform: scalar loads
+    const int b = (int)da.img[n];
+    for (int rr = wv; rr < nrows; rr += kWaves)
+        for (int c0 = 0; c0 < da.W; c0 += 128) {
+            const int cA = c0 + 2 * lane, cB = cA + 1;
+            float inA[D::CIN], inB[D::CIN], yA, yB;
+            load_inputs<C, REL>(da, n, b, ys0 + rr, min(cA, da.W - 1), inA);
+            load_inputs<C, REL>(da, n, b, ys0 + rr, min(cB, da.W - 1), inB);
+            mlp_forward2<C, REL>(wts, inA, inB, yA, yB);
+            if (cA < da.W) ybuf[rr * da.W + cA] = yA;
+            if (cB < da.W) ybuf[rr * da.W + cB] = yB;
+        }
+}
+
+struct HeadRows {       // aligned_bilinear x2 of the staged rows (the arithmetic of dyn_fwd_kernel's epilogue), logits stored as they appear
+    const float* ybuf; int ys0, Hs, Ws; float* out; int w;
+    // Output index R samples source max(R - 1, 0) / 2 with fraction 0 or 1/2 and its successor (clamped), :146-167.  For the four
+    // columns c .. c + 3 (c a multiple of 4) that is three source columns: c/2 - 1, c/2, c/2 + 1.
+    __device__ __forceinline__ float4 operator()(int r, int c) const {
+        const int iy = max(r - 1, 0), y0 = iy >> 1, y1 = min(y0 + 1, Hs - 1);
+        const float fy = (iy & 1) ? 0.5f : 0.f;
+        const int j1 = c >> 1, j0 = max(j1 - 1, 0), j2 = min(j1 + 1, Ws - 1);
+        const float f0 = c > 0 ? 0.5f : 0.f;
+        const float* row0 = ybuf + (y0 - ys0) * Ws;
+        const float* row1 = ybuf + (y1 - ys0) * Ws;
+        const float a0 = row0[j0], a1 = row0[j1], a2 = row0[j2], b0 = row1[j0], b1 = row1[j1], b2 = row1[j2];
+        auto mix = [](float fx, float u, float v) { return (1.f - fx) * u + fx * v; };
+        const float4 o = make_float4(mix(fy, mix(f0, a0, a1), mix(f0, b0, b1)), mix(fy, a1, b1),
+                                     mix(fy, mix(0.5f, a1, a2), mix(0.5f, b1, b2)), mix(fy, a2, b2));
+        *reinterpret_cast<float4*>(out + (unsigned)(r * w + c)) = o;
+        return o;
+    }
+};
+
+// grid as prep_kernel's; LDS: max(pool's, stream's column keys + 18 source rows)
+template <int C, bool REL>
+__global__ __launch_bounds__(256, 3) void prep_head_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, float thresh,
+                                                           EvalWs ws, LossState st, float* __restrict__ g_logits, DynArgs da,
+                                                           const float* __restrict__ params, float* __restrict__ logits_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n_tab = (a.N + kWaves - 1) / kWaves;
+    const int Sn = (a.h + kSBlk - 1) / kSBlk;
+    const int n_stream = a.N * Sn;
+    const int blk = (int)blockIdx.x;
+    if (blk < n_tab) {
+        const int n = blk * kWaves + (int)(threadIdx.x >> 6);
+        if (n < a.N) table_wave(a, pa.meta, dil, R, thresh, ws, st, n);
+    } else if (blk < n_tab + n_stream) {
+        const int sb = blk - n_tab, n = sb / Sn, s = sb % Sn;
+        unsigned long long* colp = reinterpret_cast<unsigned long long*>(smem);
+        float* ybuf = reinterpret_cast<float*>(colp + (size_t)kWaves * a.w);
+        // source rows sampled by output rows [32 s, 32 s + 32): (R - 1) / 2 and the one below, clamped (aligned_bilinear :156-160)
+        const int ys0 = max(kSBlk * s / 2 - 1, 0), ys1 = min(kSBlk * s / 2 + kSBlk / 2, da.H - 1);
+        head_stage_rows<C, REL>(da, params, n, ys0, ys1 - ys0 + 1, ybuf);
+        __syncthreads();
+        const HeadRows rows = {ybuf, ys0, da.H, da.W, logits_out + (int64_t)n * a.h * a.w, a.w};
+        stream_block(a, ws, g_logits, 1, sb, colp, rows);
+    } else {
+        double* lut = reinterpret_cast<double*>(smem);
+        double* fch = lut + 256;
+        int* part = reinterpret_cast<int*>(fch + 3 * 64);
+        pool_block(pa, blk - n_tab - n_stream, n_pool, n_items, lut, part, fch);
+    }
+}
+
 // grid: [ceil(N/4) table blocks][N*Sn stream blocks][pool blocks].  The table waves carry dependent scalar chains, so
 // they go first; the stream blocks precede the pool blocks because their data feeds the next launch's first workgroups.
 __global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, float thresh, EvalWs ws,
@@ -416,7 +502,9 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, i
         const int n = blk * kWaves + (int)(threadIdx.x >> 6);
         if (n < a.N) table_wave(a, pa.meta, dil, R, thresh, ws, st, n);
     } else if (blk < n_tab + n_stream) {
-        stream_block(a, ws, g_logits, vec, blk - n_tab, reinterpret_cast<unsigned long long*>(smem));
+        const int Sn = (a.h + kSBlk - 1) / kSBlk;
+        const LogitRows rows = {a.logits + (int64_t)((blk - n_tab) / Sn) * a.h * a.w, a.w, vec};
+        stream_block(a, ws, g_logits, vec, blk - n_tab, reinterpret_cast<unsigned long long*>(smem), rows);
     } else {
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
@@ -1061,7 +1149,7 @@ bool fused_eval_supported(int dil) { return dil >= 1 && dil <= kMaxDilFused; }
 // One evaluation, two launches.  lab: [B,3,h,w] f32 scratch (prep fills, pair reads).
 int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thresh, const bxi_instances* in, int dil, float warmup,
                       const float* up_prj, const float* up_pw, float* losses, float* g_logits, void* state, void* workspace,
-                      size_t workspace_bytes, int force_rows, void* stream) {
+                      size_t workspace_bytes, int force_rows, void* stream, const DynArgs* head, int head_C) {
     InstArgs a;
     int rc = fill_inst(in, a);
     if (rc != BXI_OK) return rc;
@@ -1104,7 +1192,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thre
             // one item = the 4 input rows of 64 pooled pixels.  The whole launch should be resident at once (5 workgroups
             // per CU at <= 96 VGPRs): a pool workgroup takes several items, the next one's loads in flight, when it is not.
             n_items = batch->B * a.h * ((a.w + 63) / 64);
-            const int room = 5 * 256 - n_tab - n_stream;
+            const int room = (head ? 3 : 5) * 256 - n_tab - n_stream;   // the head-fused launch needs ~170 VGPRs: three workgroups a CU
             const int per = room > 0 ? (n_items + room - 1) / room : 8;
             n_pool = (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per);
         }
@@ -1115,9 +1203,31 @@ int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thre
     }
     size_t lds1 = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
     if (lds1 < 8 * (size_t)kWaves * a.w) lds1 = 8 * (size_t)kWaves * a.w;
-    if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
-    BXI_LAUNCH("prep", s, prep_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R,
-               color_thresh, ws, st, g_logits, vec);
+    if (head) {
+        // the head-fused first launch: logits produced by the stream blocks (factor 2, vector rows, the pooled fast path)
+        if (head->factor != 2 || !vec || head->H * 2 != a.h || head->W * 2 != a.w || head->N != a.N || head->B != in->B ||
+            (batch->B > 0 && !pool_vec_ok(batch, a.stride)))
+            return BXI_ERR_UNSUPPORTED;
+        const size_t lds_head = 8 * (size_t)kWaves * a.w + sizeof(float) * (size_t)(kSBlk / 2 + 2) * head->W;
+        if (lds1 < lds_head) lds1 = lds_head;
+        if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
+        float* logits_out = const_cast<float*>(a.logits);
+        const unsigned grid1 = (unsigned)(n_tab + n_stream + n_pool);
+        if (head_C == 16 && head->rel)
+            BXI_LAUNCH("prep_head", s, (prep_head_kernel<16, true>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
+        else if (head_C == 16)
+            BXI_LAUNCH("prep_head", s, (prep_head_kernel<16, false>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
+        else if (head_C == 8 && head->rel)
+            BXI_LAUNCH("prep_head", s, (prep_head_kernel<8, true>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
+        else if (head_C == 8)
+            BXI_LAUNCH("prep_head", s, (prep_head_kernel<8, false>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
+        else
+            return BXI_ERR_UNSUPPORTED;
+    } else {
+        if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
+        BXI_LAUNCH("prep", s, prep_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R,
+                   color_thresh, ws, st, g_logits, vec);
+    }
     rc = check_launch();
     if (rc != BXI_OK) return rc;
 

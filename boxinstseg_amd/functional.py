@@ -397,6 +397,85 @@ class BoxInstMaskLoss(torch.autograd.Function):
         return grad, None, None, None, None, None, None
 
 
+class HeadBoxInstLoss(torch.autograd.Function):
+    """(mask_logits, loss_prj, loss_pairwise) = f(feat, params): ``CondInstMaskHead.forward`` + ``.loss`` with the dynamic
+    mask head evaluated inside the loss evaluation's first launch (``bxi_boxinst_head_eval_f32``).
+
+    backward: the finished gradient w.r.t. the logits (rescaled for the upstream factors, plus whatever arrives for the
+    logits output itself) goes through ``bxi_dynamic_mask_backward_f32`` to ``feat`` and ``params``."""
+
+    @staticmethod
+    def forward(ctx, feat, params, coors, level_inds, img_inds, sizes_of_interest, head_cfg, imgs, img_metas, gt_inds,
+                gt_bboxes, cfg):
+        _require_cuda(feat=feat, params=params, coors=coors, imgs=imgs, gt_inds=gt_inds)
+        dev = feat.device
+        in_stride, factor, no_rel = head_cfg
+        B, Cf, Hs, Ws = feat.shape
+        N = params.size(0)
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        i64 = lambda t: t.detach().to(device=dev, dtype=torch.int64).contiguous()
+        feat_c, params_c, coors_c = f32(feat), f32(params), f32(coors).view(-1, 2)
+        lvl, img, soi, gi = i64(level_inds), i64(img_inds), f32(sizes_of_interest), i64(gt_inds)
+        boxes = [b.detach().to(device=dev, dtype=torch.float32).contiguous() for b in gt_bboxes]
+        imgs_c = _f32c(imgs)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        logits = torch.empty((N, 1, Hs * factor, Ws * factor), dtype=torch.float32, device=dev)
+        plan = _eval_plan(imgs_c, img_metas, logits, boxes, int(cfg['out_stride']), int(cfg['bottom_pixels_removed']), stream)
+        need_grad = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        buf = torch.empty(256 + plan.state_bytes + 4 * plan.grad_elems, dtype=torch.uint8, device=dev)
+        base = buf.data_ptr()
+        plan.batch.imgs = imgs_c.data_ptr()
+        plan.inst.logits = logits.data_ptr()
+        plan.inst.gt_inds = gi.data_ptr()
+        for i, b in enumerate(boxes):
+            plan._ptrs[i] = b.data_ptr() if b.numel() else 0
+        with torch.cuda.device(dev):
+            _lib.check('bxi_boxinst_head_eval_f32', _lib.load().bxi_boxinst_head_eval_f32(
+                plan.batch_ref, plan.inst_ref, feat_c.data_ptr(), Cf, Hs, Ws, params_c.data_ptr(), coors_c.data_ptr(),
+                lvl.data_ptr(), img.data_ptr(), soi.data_ptr(), soi.numel(), int(in_stride), int(factor), int(bool(no_rel)),
+                int(cfg['pairwise_size']), int(cfg['pairwise_dilation']), float(cfg['pairwise_color_thresh']),
+                float(cfg['warmup_factor']), 0, 0, base, base + 256 + plan.state_bytes, base + 256, plan.ws_ptr,
+                plan.ws_bytes, stream))
+        losses = buf[:8].view(torch.float32)
+        ctx.save_for_backward(feat_c, params_c, coors_c, lvl, img, soi)
+        ctx.grad = buf[256 + plan.state_bytes:].view(torch.float32).view(logits.shape)
+        ctx.state, ctx.plan, ctx.keep = base + 256, plan, (imgs_c, gi, boxes, buf)
+        ctx.head_cfg, ctx.dil, ctx.need_grad = (int(in_stride), int(factor), int(bool(no_rel))), int(cfg['pairwise_dilation']), need_grad
+        ctx.dtypes = (feat.dtype, params.dtype)
+        ctx.mark_non_differentiable(logits) if not need_grad else None
+        return logits, losses[0], losses[1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_logits_in, g_prj, g_pw):
+        feat, params, coors, lvl, img, soi = ctx.saved_tensors
+        grad, plan = ctx.grad, ctx.plan
+        if grad is None:
+            raise RuntimeError('HeadBoxInstLoss.backward called twice: evaluate again (retain_graph is not supported here)')
+        ctx.grad = None
+        dev = grad.device
+        lib = _lib.load()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        g_prj = g_prj.to(device=dev, dtype=torch.float32)
+        g_pw = g_pw.to(device=dev, dtype=torch.float32)
+        in_stride, factor, no_rel = ctx.head_cfg
+        B, Cf, Hs, Ws = feat.shape
+        N = params.size(0)
+        g_feat, g_params = torch.empty_like(feat), torch.empty_like(params)
+        ws = torch.empty(max(lib.bxi_dynamic_mask_backward_workspace_bytes(B, Cf, Hs, Ws, N, no_rel), 256), dtype=torch.uint8,
+                         device=dev)
+        with torch.cuda.device(dev):
+            _lib.check('bxi_boxinst_grad_rescale_f32', plan.rescale(plan.inst_ref, g_prj.data_ptr(), g_pw.data_ptr(), ctx.dil,
+                                                                     ctx.state, grad.data_ptr(), stream))
+            if g_logits_in is not None:
+                grad = grad + g_logits_in.to(torch.float32)
+            _lib.check('bxi_dynamic_mask_backward_f32', lib.bxi_dynamic_mask_backward_f32(
+                feat.data_ptr(), B, Cf, Hs, Ws, params.data_ptr(), N, coors.data_ptr(), lvl.data_ptr(), img.data_ptr(),
+                soi.data_ptr(), soi.numel(), in_stride, factor, no_rel, grad.data_ptr(), g_feat.data_ptr(), g_params.data_ptr(),
+                ws.data_ptr(), ws.numel(), stream))
+        return (g_feat.to(ctx.dtypes[0]), g_params.to(ctx.dtypes[1])) + (None,) * 10
+
+
 def boxinst_mask_loss(mask_logits: torch.Tensor, gt_inds: torch.Tensor, gt_bboxes: Sequence[torch.Tensor], *,
                       imgs: Optional[torch.Tensor] = None, img_metas: Optional[Sequence[dict]] = None,
                       affinity_bits: Optional[torch.Tensor] = None, out_stride: int = 4,

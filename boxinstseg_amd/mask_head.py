@@ -154,6 +154,34 @@ class CondInstMaskHead(nn.Module):
                                     in_stride=self.in_stride, out_stride=self.out_stride,
                                     disable_rel_coors=self.disable_rel_coors)
 
+    def forward_loss(self, feat, params, coors, level_inds, img_inds, imgs, img_metas, gt_inds, gt_bboxes, gt_masks=None,
+                     gt_labels=None, fuse_head: bool = False):
+        """``mask_logits = self(feat, params, coors, level_inds, img_inds)`` followed by ``self.loss(imgs, img_metas, mask_logits,
+        gt_inds, gt_bboxes, gt_masks, gt_labels)`` -- the two calls ``CondInst.forward_train`` makes back to back
+        (``mmdet/models/detectors/condinst.py:71-74``) -- as ONE call.  With ``fuse_head=True`` and where the shapes allow, the
+        dynamic head is evaluated inside the loss evaluation's first launch (``bxi_boxinst_head_eval_f32``: one launch, one kernel
+        boundary and one read of the logits less).  That launch is parity-tested but, as measured, SLOWER than the
+        two it replaces (31 us against 13.5 + 11.5 us at 2 x 800 x 1024, 32 instances): the head's arithmetic sits on the 224
+        stream workgroups, one wave per SIMD, with nothing to hide its load latencies behind -- hence opt-in.
+        Returns ``(mask_logits, losses)``."""
+        factor = self.in_stride // self.out_stride
+        fused = (fuse_head and self.boxinst_enabled and feat.is_cuda and params.size(0) > 0 and factor == 2 and self.dynamic_convs == 3 and
+                 self.dynamic_channels == 8 and feat.size(1) in (8, 16) and feat.size(3) % 2 == 0 and
+                 F_hip.fused_supported(self.pairwise_size, self.pairwise_dilation) and self.out_stride == 4 and
+                 imgs.size(2) % 4 == 0 and imgs.size(3) % 4 == 0 and
+                 feat.size(2) * self.in_stride == imgs.size(2) and feat.size(3) * self.in_stride == imgs.size(3))
+        if not fused:
+            logits = self(feat, params, coors, level_inds, img_inds)
+            return logits, self.loss(imgs, img_metas, logits, gt_inds, gt_bboxes, gt_masks, gt_labels)
+        warmup = self._tick()
+        cfg = dict(out_stride=self.out_stride, bottom_pixels_removed=self.bottom_pixels_removed, pairwise_size=self.pairwise_size,
+                   pairwise_dilation=self.pairwise_dilation, pairwise_color_thresh=self.pairwise_color_thresh,
+                   warmup_factor=warmup)
+        logits, loss_prj, loss_pw = F_hip.HeadBoxInstLoss.apply(
+            feat, params, coors, level_inds, img_inds, self.sizes_of_interest, (self.in_stride, factor, self.disable_rel_coors),
+            imgs, img_metas, gt_inds, gt_bboxes, cfg)
+        return logits, {'loss_prj': loss_prj, 'loss_pairwise': loss_pw}
+
     def _composed_forward(self, feat, params, coors, level_inds, img_inds):
         """The dynamic head for layer counts / widths the HIP kernels are not built for: a per-instance 1x1 convolution is
         a [cout, cin] x [cin, H*W] product, so the layers are batched matrix products over the instances."""

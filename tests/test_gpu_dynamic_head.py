@@ -178,3 +178,46 @@ def test_dynamic_head_shapes_outside_the_hip_build_run_composed(dev):
     f8 = torch.randn(2, 8, 12, 20, device=dev); p8 = torch.randn(4, built.num_gen_params, device=dev)
     a = built(f8, p8, coors, lvl, img); b = built._composed_forward(f8, p8, coors, lvl, img)
     assert (a - b).abs().max() <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize('C,no_rel,N', [(16, False, 32), (8, False, 5), (8, True, 3)])
+def test_head_fused_into_the_loss_evaluation(dev, C, no_rel, N):
+    """CondInstMaskHead.forward_loss = forward() + loss() with the dynamic head evaluated inside the evaluation's first launch
+    (bxi_boxinst_head_eval_f32): same logits, same losses, same gradients w.r.t. the mask features and the dynamic parameters as
+    the two calls (different kernels, same arithmetic: fp32 rounding differences only)."""
+    import copy
+    from boxinstseg_amd import CondInstMaskHead, synthetic
+    d = synthetic.cfg2(3) if N == 32 else synthetic.cfg1(1)
+    imgs = torch.from_numpy(d['imgs']).to(dev)
+    B, H, W = imgs.shape[0], imgs.shape[2], imgs.shape[3]
+    boxes = [torch.from_numpy(b).to(dev) for b in d['gt_bboxes']]
+    gt_inds = torch.from_numpy(d['gt_inds']).to(dev)[:N]
+    n = gt_inds.numel()
+    counts = np.cumsum([0] + [b.shape[0] for b in boxes])
+    img_inds = torch.tensor([int(np.searchsorted(counts, int(g), side='right') - 1) for g in gt_inds.cpu()], device=dev)
+    torch.manual_seed(C + n)
+    head = CondInstMaskHead(in_channels=C, boxinst_enabled=True, disable_rel_coors=no_rel, max_proposals=-1, topk_per_img=64).to(dev)
+    head.set_iter(5000)
+    feat = torch.randn(B, C, H // 8, W // 8, device=dev)
+    params = 0.3 * torch.randn(n, head.num_gen_params, device=dev)
+    coors = torch.rand(n, 2, device=dev) * torch.tensor([W, H], device=dev)
+    lvl = torch.randint(0, 5, (n,), device=dev)
+
+    def run(fused):
+        h2 = copy.deepcopy(head)
+        f = feat.clone().requires_grad_(True); p = params.clone().requires_grad_(True)
+        if fused:
+            logits, losses = h2.forward_loss(f, p, coors, lvl, img_inds, imgs, d['img_metas'], gt_inds, boxes, fuse_head=True)
+        else:
+            logits = h2(f, p, coors, lvl, img_inds)
+            losses = h2.loss(imgs, d['img_metas'], logits, gt_inds, boxes, None, None)
+        (losses['loss_prj'] + 2.0 * losses['loss_pairwise']).backward()
+        return logits.detach(), losses['loss_prj'].detach(), losses['loss_pairwise'].detach(), f.grad, p.grad
+
+    a, b = run(True), run(False)
+    assert a[0].shape == b[0].shape
+    assert (a[0] - b[0]).abs().max() <= 2e-6 * max(1.0, float(b[0].abs().max()))
+    for i in (1, 2):
+        assert abs(float(a[i]) - float(b[i])) <= 1e-5 * max(abs(float(b[i])), 1e-6), (i, float(a[i]), float(b[i]))
+    for i in (3, 4):
+        assert (a[i] - b[i]).abs().max() <= 2e-4 * max(float(b[i].abs().max()), 1e-8), (i, float((a[i] - b[i]).abs().max()), float(b[i].abs().max()))
