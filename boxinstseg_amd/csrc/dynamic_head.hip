@@ -36,14 +36,9 @@
 namespace bxi {
 
 // ---- forward ---------------------------------------------------------------------------------------
-// F = the up-sampling factor as a compile-time constant (0: read a.factor; every index division is then a
-// real integer division, ~40 instructions each)
-template <int F> __device__ __forceinline__ int factor_of(const DynArgs& a) { return F ? F : a.factor; }
-
 template <int C, bool REL, int F>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void dyn_fwd_kernel(DynArgs a, const float* __restrict__ params, float* __restrict__ logits) {
-    using D = Dyn<C, REL>;
     constexpr int kHalo = (kYR + 2) * (kYC + 2);
     __shared__ float ytile[kHalo];
     const int tiles_x = (a.W + kYC - 1) / kYC, tiles_y = (a.H + kYR - 1) / kYR;
@@ -51,56 +46,8 @@ void dyn_fwd_kernel(DynArgs a, const float* __restrict__ params, float* __restri
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int n = t / tiles_y;
-    const int tid = threadIdx.x;
     BXI_T(3, blockIdx.x, 0);
-    // the instance's 233 parameters are wave-uniform: scalar loads, SGPR operands of the FMAs (no LDS, no VGPRs)
-    const float* __restrict__ wts = params + (int64_t)n * D::P;
-    const int b = (int)a.img[n];
-    // y on the tile plus one pixel of halo on every side (rows r0-1 .. r0+kYR): 340 pixels on 256 threads.
-    // Both pixels of a thread are loaded (clamped coordinates, no branch) before either is evaluated.
-    const int r0 = ty * kYR, c0 = tx * kYC;
-    // thread t evaluates pixels 2t and 2t+1 of the halo tile (170 threads: waves 0-2), one code path
-    const int eA = 2 * tid, eB = 2 * tid + 1;
-    const int rA = r0 - 1 + eA / (kYC + 2), cA = c0 - 1 + eA % (kYC + 2);
-    const int rB = r0 - 1 + eB / (kYC + 2), cB = c0 - 1 + eB % (kYC + 2);
-    const bool vA = eA < kHalo && rA >= 0 && rA < a.H && cA >= 0 && cA < a.W;
-    const bool vB = eB < kHalo && rB >= 0 && rB < a.H && cB >= 0 && cB < a.W;
-    if (eA < kHalo) {
-        float inA[D::CIN], inB[D::CIN], yA, yB;
-        load_inputs<C, REL>(a, n, b, min(max(rA, 0), a.H - 1), min(max(cA, 0), a.W - 1), inA);
-        load_inputs<C, REL>(a, n, b, min(max(rB, 0), a.H - 1), min(max(cB, 0), a.W - 1), inB);
-        BXI_T(3, blockIdx.x, 1);
-        mlp_forward2<C, REL>(wts, inA, inB, yA, yB);
-        ytile[eA] = vA ? yA : 0.f;
-        if (eB < kHalo) ytile[eB] = vB ? yB : 0.f;
-    }
-    __syncthreads();
-    BXI_T(3, blockIdx.x, 2);
-    const int f = factor_of<F>(a), OH = a.H * f, OW = a.W * f;
-    constexpr int VW = F == 0 ? 1 : (F % 4 == 0 ? 4 : (F % 2 == 0 ? 2 : 1));   // outputs per store
-    const int R0 = r0 * f, C0 = c0 * f;
-    const int row_w = kYC * f / VW;                          // stores per output row of the tile
-    float* out = logits + (int64_t)n * OH * OW;
-    auto Y = [&](int r, int c) { return ytile[(r - r0 + 1) * (kYC + 2) + (c - c0 + 1)]; };
-    for (int i = tid; i < kYR * f * row_w; i += 256) {
-        const int R = R0 + i / row_w, Cc = C0 + (i % row_w) * VW;
-        if (R >= OH || Cc >= OW) continue;
-        int y0, y1; float fy;
-        upsample_src(R, f, a.H, y0, y1, fy);
-        float v[VW];
-#pragma unroll
-        for (int k = 0; k < VW; ++k) {
-            int x0, x1; float fx;
-            upsample_src(Cc + k, f, a.W, x0, x1, fx);
-            const float top = (1.f - fx) * Y(y0, x0) + fx * Y(y0, x1);
-            const float bot = (1.f - fx) * Y(y1, x0) + fx * Y(y1, x1);
-            v[k] = (1.f - fy) * top + fy * bot;
-        }
-        float* o = out + (int64_t)R * OW + Cc;
-        if constexpr (VW == 4) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-        else if constexpr (VW == 2) *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
-        else o[0] = v[0];
-    }
+    dyn_tile_forward<C, REL, F, false>(a, params, logits, n, ty, tx, ytile, nullptr, nullptr, DynEpi{});
     BXI_T(3, blockIdx.x, 3);
 }
 

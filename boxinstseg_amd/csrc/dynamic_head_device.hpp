@@ -135,6 +135,110 @@ __device__ __forceinline__ void upsample_src(int R, int f, int n_in, int& i0, in
     i1 = min(i0 + 1, n_in - 1);                             // replicate pad (:156)
 }
 
+// F = the up-sampling factor as a compile-time constant (0: read a.factor; every index division is then a
+// real integer division, ~40 instructions each)
+template <int F> __device__ __forceinline__ int factor_of(const DynArgs& a) { return F ? F : a.factor; }
+
+// What the head-fused evaluation (fused_eval.hip) asks of a tile besides its logits: the zero-filled gradient tile and the
+// tile's share of the projection maxima -- per output row the (value, first column) key over the tile's 64 columns, per output
+// column the (value, first row) key over its 16 rows -- as partials the leaders of pair_kernel combine.
+struct DynEpi {
+    unsigned long long* colpart;    // [N][n_cb][OW]   n_cb = tiles in y
+    unsigned long long* rowpart;    // [N][n_rp][OH]   n_rp = tiles in x
+    float* g_zero;                  // [N][OH][OW] or nullptr
+    int n_cb, n_rp;
+};
+
+// One workgroup: y on an 8 x 32 tile (+ 1 halo) of instance n, up-sampled to the logits tile.  Thread t evaluates pixels 2t and
+// 2t+1 of the halo tile (each weight feeds both), y goes to LDS, the up-sampled tile is written with float2 / float4 stores.
+template <int C, bool REL, int F, bool EPI>
+__device__ __forceinline__ void dyn_tile_forward(const DynArgs& a, const float* __restrict__ params, float* __restrict__ logits, int n,
+                                                 int ty, int tx, float* ytile /* LDS [(kYR+2)*(kYC+2)] */,
+                                                 float* otile /* LDS [kYR*F][kYC*F], EPI */,
+                                                 unsigned long long* ckeys /* LDS [4][kYC*F], EPI */, const DynEpi& ep) {
+    using D = Dyn<C, REL>;
+    constexpr int kHalo = (kYR + 2) * (kYC + 2);
+    const int tid = threadIdx.x;
+    // the instance's 233 parameters are wave-uniform: scalar loads, SGPR operands of the FMAs (no LDS, no VGPRs)
+    const float* __restrict__ wts = params + (int64_t)n * D::P;
+    const int b = (int)a.img[n];
+    // y on the tile plus one pixel of halo on every side (rows r0-1 .. r0+kYR): 340 pixels on 256 threads.
+    // Both pixels of a thread are loaded (clamped coordinates, no branch) before either is evaluated.
+    const int r0 = ty * kYR, c0 = tx * kYC;
+    const int eA = 2 * tid, eB = 2 * tid + 1;
+    const int rA = r0 - 1 + eA / (kYC + 2), cA = c0 - 1 + eA % (kYC + 2);
+    const int rB = r0 - 1 + eB / (kYC + 2), cB = c0 - 1 + eB % (kYC + 2);
+    const bool vA = eA < kHalo && rA >= 0 && rA < a.H && cA >= 0 && cA < a.W;
+    const bool vB = eB < kHalo && rB >= 0 && rB < a.H && cB >= 0 && cB < a.W;
+    if (eA < kHalo) {
+        float inA[D::CIN], inB[D::CIN], yA, yB;
+        load_inputs<C, REL>(a, n, b, min(max(rA, 0), a.H - 1), min(max(cA, 0), a.W - 1), inA);
+        load_inputs<C, REL>(a, n, b, min(max(rB, 0), a.H - 1), min(max(cB, 0), a.W - 1), inB);
+        mlp_forward2<C, REL>(wts, inA, inB, yA, yB);
+        ytile[eA] = vA ? yA : 0.f;
+        if (eB < kHalo) ytile[eB] = vB ? yB : 0.f;
+    }
+    __syncthreads();
+    const int f = factor_of<F>(a), OH = a.H * f, OW = a.W * f;
+    constexpr int VW = F == 0 ? 1 : (F % 4 == 0 ? 4 : (F % 2 == 0 ? 2 : 1));   // outputs per store
+    const int R0 = r0 * f, C0 = c0 * f;
+    const int row_w = kYC * f / VW;                          // stores per output row of the tile
+    float* out = logits + (int64_t)n * OH * OW;
+    auto Y = [&](int r, int c) { return ytile[(r - r0 + 1) * (kYC + 2) + (c - c0 + 1)]; };
+    for (int i = tid; i < kYR * f * row_w; i += 256) {
+        const int R = R0 + i / row_w, Cc = C0 + (i % row_w) * VW;
+        if (R >= OH || Cc >= OW) continue;
+        int y0, y1; float fy;
+        upsample_src(R, f, a.H, y0, y1, fy);
+        float v[VW];
+#pragma unroll
+        for (int k = 0; k < VW; ++k) {
+            int x0, x1; float fx;
+            upsample_src(Cc + k, f, a.W, x0, x1, fx);
+            const float top = (1.f - fx) * Y(y0, x0) + fx * Y(y0, x1);
+            const float bot = (1.f - fx) * Y(y1, x0) + fx * Y(y1, x1);
+            v[k] = (1.f - fy) * top + fy * bot;
+        }
+        float* o = out + (int64_t)R * OW + Cc;
+        if constexpr (VW == 4) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        else if constexpr (VW == 2) *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
+        else o[0] = v[0];
+        if constexpr (EPI) {
+#pragma unroll
+            for (int k = 0; k < VW; ++k) otile[(R - R0) * (kYC * F) + (Cc - C0) + k] = v[k];
+        }
+    }
+    if constexpr (EPI) {
+        static_assert(!EPI || (F == 2 && kYC * F == 64 && kYR * F == 16), "the epilogue maps a lane to a column of a 16 x 64 tile");
+        constexpr int TW = kYC * F, TH = kYR * F;
+        __syncthreads();
+        const int wv = tid >> 6, lane = tid & 63, c = C0 + lane;
+        unsigned long long ck = 0ull;
+#pragma unroll
+        for (int i = 0; i < TH / 4; ++i) {
+            const int lr = wv * (TH / 4) + i, R = R0 + lr;
+            const bool ok = R < OH && c < OW;
+            const float v = ok ? otile[lr * TW + lane] : -INFINITY;
+            const unsigned long long rk = wave_max_u64(ok ? pack_max(v, (uint32_t)c) : 0ull);      // larger value, then smaller column
+            if (lane == 0 && R < OH) ep.rowpart[((int64_t)n * ep.n_rp + tx) * OH + R] = rk;
+            const unsigned long long k = ok ? pack_max(v, (uint32_t)R) : 0ull;                      // larger value, then smaller row
+            ck = k > ck ? k : ck;
+        }
+        ckeys[wv * TW + lane] = ck;
+        if (ep.g_zero) {                                                                            // the tile of d loss / d logits
+            const int zr = R0 + tid / (TW / 4), zc = C0 + (tid % (TW / 4)) * 4;
+            if (zr < OH && zc < OW) *reinterpret_cast<float4*>(ep.g_zero + ((int64_t)n * OH + zr) * OW + zc) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        if (wv == 0 && c < OW) {
+            unsigned long long k = ckeys[lane];
+#pragma unroll
+            for (int u = 1; u < 4; ++u) { const unsigned long long o = ckeys[u * TW + lane]; k = o > k ? o : k; }
+            ep.colpart[((int64_t)n * ep.n_cb + ty) * OW + c] = k;
+        }
+    }
+}
+
 // host side (dynamic_head.hip): argument checks shared with the head-fused evaluation
 int fill_dyn(const float* feat, int B, int C, int H, int W, const float* params, int N, const float* coors, const int64_t* level,
              const int64_t* img, const float* soi, int n_levels, int in_stride, int factor, int disable_rel, DynArgs& a);

@@ -74,8 +74,9 @@ struct WorkRec2 {                               // 64 B: all a tile wave needs, 
 };
 
 struct EvalWs {                                 // carved from the caller's workspace
-    unsigned long long* colpart;                // [N,Sn,w] packed (max logit, first row) of a 32-row block
-    unsigned long long* rowkey;                 // [N,h]    packed (max logit, first column)
+    unsigned long long* colpart;                // [N,n_cb,w] packed (max logit, first row) of a band of rows (32: stream blocks; 16: head tiles)
+    unsigned long long* rowkey;                 // [N,n_rp,h] packed (max logit, first column); n_rp = 1 (stream blocks: whole rows) or the head's tiles in x
+    int n_cb, n_rp;                             // set per launch
     InstRec* inst;                              // [N]
     WorkRec2* work;                             // [cap]
     int* nwork;                                 // [1]
@@ -95,12 +96,14 @@ static inline int eval_cap(int N, int h, int w, int dil, int R) {
 static size_t carve_eval(void* base, int N, int h, int w, EvalWs* ws) {
     const int N1 = N > 0 ? N : 1;
     const size_t Sn = (size_t)(h + kSBlk - 1) / kSBlk;
+    const size_t cb_max = (size_t)(h + kYR * 2 - 1) / (kYR * 2), rp_max = (size_t)(w + kYC * 2 - 1) / (kYC * 2);   // the head-fused launch's tiles
     size_t off = 0;
     char* p = (char*)base;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return p ? p + o : nullptr; };
     EvalWs t;
-    t.colpart = (unsigned long long*)take(8 * (size_t)N1 * Sn * w);
-    t.rowkey = (unsigned long long*)take(8 * (size_t)N1 * h);
+    t.colpart = (unsigned long long*)take(8 * (size_t)N1 * (cb_max > Sn ? cb_max : Sn) * w);
+    t.rowkey = (unsigned long long*)take(8 * (size_t)N1 * h * (rp_max > 1 ? rp_max : 1));
+    t.n_cb = (int)Sn; t.n_rp = 1;
     t.inst = (InstRec*)take(sizeof(InstRec) * (size_t)N1);
     t.work = (WorkRec2*)take(sizeof(WorkRec2) * (size_t)eval_cap(N, h, w, 1, 4));   // the largest list any (dil, R) produces
     t.nwork = (int*)take(sizeof(int));
@@ -409,81 +412,41 @@ __device__ __forceinline__ void pool_block(const PoolArgs& pa, int first, int st
     }
 }
 
-// ---- head-fused variant: the stream role PRODUCES the logits ---------------------------------------------------------
-// The dynamic mask head (condinst_head.py:1139-1164: relative coordinates, three per-instance 1x1 convolutions with ReLU,
-// aligned_bilinear x2) evaluated where its output is first consumed: a stream block of instance n computes y on the 18 source
-// rows its 32 output rows sample (4 waves x rows, a lane two neighbouring pixels through mlp_forward2: one wave per SIMD issues
-// ~3000 instructions, under the image pooling's memory time), parks them in LDS, and then up-samples row by row straight into
-// the registers the maxima are taken from -- writing the logits (for pair_kernel and the head's backward) on the way.  The
-// separate 11.6 us dyn_fwd launch, its kernel boundary and one 6.5 MB read of the logits disappear.  Factor 2 only (every
-// shipped config: mask features at stride 8, logits at stride 4).
+// ---- head-fused first launch ----------------------------------------------------------------------------------------
+// CondInstMaskHead.forward (condinst_head.py:1139-1164) and the evaluation's first launch as ONE grid of independent roles:
+//   [table blocks][pool blocks][head tiles: instance x 8 x 32 tiles of y -> 16 x 64 logits]
+// The head tiles are dyn_fwd_kernel's workgroups (dynamic_head_device.hpp) with an epilogue that does the stream role's job on
+// the tile they just produced: zero-fill of the gradient tile, per-row and per-column (value, first index) maxima as partials
+// for the leaders.  Nothing in the launch waits for anything else in it: the HBM-bound image pooling and the issue-bound MLP
+// simply run side by side, one launch, one boundary and one 6.5 MB read of the logits fewer than dyn_fwd + prep: 20.0 us against
+// 13.4 + 11.4 us (rocprofv3, tools/bench_head_fused.py).  (Pool blocks dealt evenly among the head tiles instead of first: 21.1 us.
+// The first attempt put the MLP into the stream blocks -- 224 workgroups, 4.5 dependent rounds a wave: 30.9 us.)
 template <int C, bool REL>
-__device__ __forceinline__ void head_stage_rows(const DynArgs& da, const float* __restrict__ params, int n, int ys0, int nrows,
-                                                float* __restrict__ ybuf /* LDS [nrows][W] */) {
-    using D = Dyn<C, REL>;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float* __restrict__ wts = params + (int64_t)n * D::P;       // wave-uniform: scalar loads
-    const int b = (int)da.img[n];
-    for (int rr = wv; rr < nrows; rr += kWaves)
-        for (int c0 = 0; c0 < da.W; c0 += 128) {
-            const int cA = c0 + 2 * lane, cB = cA + 1;
-            float inA[D::CIN], inB[D::CIN], yA, yB;
-            load_inputs<C, REL>(da, n, b, ys0 + rr, min(cA, da.W - 1), inA);
-            load_inputs<C, REL>(da, n, b, ys0 + rr, min(cB, da.W - 1), inB);
-            mlp_forward2<C, REL>(wts, inA, inB, yA, yB);
-            if (cA < da.W) ybuf[rr * da.W + cA] = yA;
-            if (cB < da.W) ybuf[rr * da.W + cB] = yB;
-        }
-}
-
-struct HeadRows {       // aligned_bilinear x2 of the staged rows (the arithmetic of dyn_fwd_kernel's epilogue), logits stored as they appear
-    const float* ybuf; int ys0, Hs, Ws; float* out; int w;
-    // Output index R samples source max(R - 1, 0) / 2 with fraction 0 or 1/2 and its successor (clamped), :146-167.  For the four
-    // columns c .. c + 3 (c a multiple of 4) that is three source columns: c/2 - 1, c/2, c/2 + 1.
-    __device__ __forceinline__ float4 operator()(int r, int c) const {
-        const int iy = max(r - 1, 0), y0 = iy >> 1, y1 = min(y0 + 1, Hs - 1);
-        const float fy = (iy & 1) ? 0.5f : 0.f;
-        const int j1 = c >> 1, j0 = max(j1 - 1, 0), j2 = min(j1 + 1, Ws - 1);
-        const float f0 = c > 0 ? 0.5f : 0.f;
-        const float* row0 = ybuf + (y0 - ys0) * Ws;
-        const float* row1 = ybuf + (y1 - ys0) * Ws;
-        const float a0 = row0[j0], a1 = row0[j1], a2 = row0[j2], b0 = row1[j0], b1 = row1[j1], b2 = row1[j2];
-        auto mix = [](float fx, float u, float v) { return (1.f - fx) * u + fx * v; };
-        const float4 o = make_float4(mix(fy, mix(f0, a0, a1), mix(f0, b0, b1)), mix(fy, a1, b1),
-                                     mix(fy, mix(0.5f, a1, a2), mix(0.5f, b1, b2)), mix(fy, a2, b2));
-        *reinterpret_cast<float4*>(out + (unsigned)(r * w + c)) = o;
-        return o;
-    }
-};
-
-// grid as prep_kernel's; LDS: max(pool's, stream's column keys + 18 source rows)
-template <int C, bool REL>
-__global__ __launch_bounds__(256, 3) void prep_head_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, float thresh,
+__global__ __launch_bounds__(256, 7) void head_prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, float thresh,
                                                            EvalWs ws, LossState st, float* __restrict__ g_logits, DynArgs da,
                                                            const float* __restrict__ params, float* __restrict__ logits_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_tab = (a.N + kWaves - 1) / kWaves;
-    const int Sn = (a.h + kSBlk - 1) / kSBlk;
-    const int n_stream = a.N * Sn;
     const int blk = (int)blockIdx.x;
     if (blk < n_tab) {
         const int n = blk * kWaves + (int)(threadIdx.x >> 6);
         if (n < a.N) table_wave(a, pa.meta, dil, R, thresh, ws, st, n);
-    } else if (blk < n_tab + n_stream) {
-        const int sb = blk - n_tab, n = sb / Sn, s = sb % Sn;
-        unsigned long long* colp = reinterpret_cast<unsigned long long*>(smem);
-        float* ybuf = reinterpret_cast<float*>(colp + (size_t)kWaves * a.w);
-        // source rows sampled by output rows [32 s, 32 s + 32): (R - 1) / 2 and the one below, clamped (aligned_bilinear :156-160)
-        const int ys0 = max(kSBlk * s / 2 - 1, 0), ys1 = min(kSBlk * s / 2 + kSBlk / 2, da.H - 1);
-        head_stage_rows<C, REL>(da, params, n, ys0, ys1 - ys0 + 1, ybuf);
-        __syncthreads();
-        const HeadRows rows = {ybuf, ys0, da.H, da.W, logits_out + (int64_t)n * a.h * a.w, a.w};
-        stream_block(a, ws, g_logits, 1, sb, colp, rows);
-    } else {
+    } else if (blk < n_tab + n_pool) {
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
         int* part = reinterpret_cast<int*>(fch + 3 * 64);
-        pool_block(pa, blk - n_tab - n_stream, n_pool, n_items, lut, part, fch);
+        pool_block(pa, blk - n_tab, n_pool, n_items, lut, part, fch);
+    } else {
+        const int tiles_x = (da.W + kYC - 1) / kYC, tiles_y = (da.H + kYR - 1) / kYR;
+        int t = blk - n_tab - n_pool;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int n = t / tiles_y;
+        unsigned long long* ckeys = reinterpret_cast<unsigned long long*>(smem);          // [4][64]
+        float* otile = reinterpret_cast<float*>(ckeys + 4 * 64);                          // [16][64]
+        float* ytile = otile + 16 * 64;                                                   // [(kYR+2)*(kYC+2)]
+        const DynEpi ep = {ws.colpart, ws.rowkey, g_logits, ws.n_cb, ws.n_rp};
+        dyn_tile_forward<C, REL, 2, true>(da, params, logits_out, n, ty, tx, ytile, otile, ckeys, ep);
     }
 }
 
@@ -933,7 +896,6 @@ __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf
 __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, int R, const EvalWs& ws, const LossState& st, int n,
                                              float upp, float* __restrict__ g_logits, unsigned char* smem, float* red) {
     const int h = a.h, w = a.w, tid = threadIdx.x;
-    const int Sn = (h + kSBlk - 1) / kSBlk;
     float* xs = reinterpret_cast<float*>(smem);   // [w] sigmoid of the column maxima, then their unit gradients
     float* ys = xs + w;                           // [h]
     int* carg = reinterpret_cast<int*>(ys + h);   // [w]
@@ -942,15 +904,16 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, int R, 
     const InstBox ib = inst_from_rec(rec, dil, h, w);
     float sums[4] = {0.f, 0.f, 0.f, 0.f};   // I_x, U_x, I_y, U_y
     for (int c = tid; c < w; c += 256) {
-        unsigned long long k = ws.colpart[(int64_t)n * Sn * w + c];
-        for (int s = 1; s < Sn; ++s) { const unsigned long long o = ws.colpart[((int64_t)n * Sn + s) * w + c]; k = o > k ? o : k; }
+        unsigned long long k = ws.colpart[(int64_t)n * ws.n_cb * w + c];
+        for (int s = 1; s < ws.n_cb; ++s) { const unsigned long long o = ws.colpart[((int64_t)n * ws.n_cb + s) * w + c]; k = o > k ? o : k; }
         const float X = sigmoid_acc(unpack_val(k));
         const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
         xs[c] = X; carg[c] = (int)unpack_idx(k);
         sums[0] += X * TX; sums[1] += X * X + TX * TX;
     }
     for (int r = tid; r < h; r += 256) {
-        const unsigned long long k = ws.rowkey[(int64_t)n * h + r];
+        unsigned long long k = ws.rowkey[(int64_t)n * ws.n_rp * h + r];
+        for (int s = 1; s < ws.n_rp; ++s) { const unsigned long long o = ws.rowkey[((int64_t)n * ws.n_rp + s) * h + r]; k = o > k ? o : k; }
         const float Y = sigmoid_acc(unpack_val(k));
         const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
         ys[r] = Y; rarg[r] = (int)unpack_idx(k);
@@ -1192,7 +1155,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thre
             // one item = the 4 input rows of 64 pooled pixels.  The whole launch should be resident at once (5 workgroups
             // per CU at <= 96 VGPRs): a pool workgroup takes several items, the next one's loads in flight, when it is not.
             n_items = batch->B * a.h * ((a.w + 63) / 64);
-            const int room = (head ? 3 : 5) * 256 - n_tab - n_stream;   // the head-fused launch needs ~170 VGPRs: three workgroups a CU
+            const int room = 5 * 256 - n_tab - (head ? 0 : n_stream);
             const int per = room > 0 ? (n_items + room - 1) / room : 8;
             n_pool = (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per);
         }
@@ -1204,23 +1167,26 @@ int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thre
     size_t lds1 = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
     if (lds1 < 8 * (size_t)kWaves * a.w) lds1 = 8 * (size_t)kWaves * a.w;
     if (head) {
-        // the head-fused first launch: logits produced by the stream blocks (factor 2, vector rows, the pooled fast path)
+        // the head-fused first launch (factor 2, vector rows, the pooled fast path): tables, pool blocks, head tiles
         if (head->factor != 2 || !vec || head->H * 2 != a.h || head->W * 2 != a.w || head->N != a.N || head->B != in->B ||
             (batch->B > 0 && !pool_vec_ok(batch, a.stride)))
             return BXI_ERR_UNSUPPORTED;
-        const size_t lds_head = 8 * (size_t)kWaves * a.w + sizeof(float) * (size_t)(kSBlk / 2 + 2) * head->W;
+        const int tiles = ((head->H + kYR - 1) / kYR) * ((head->W + kYC - 1) / kYC);
+        ws.n_cb = (head->H + kYR - 1) / kYR;
+        ws.n_rp = (head->W + kYC - 1) / kYC;
+        const size_t lds_head = 8 * 4 * 64 + sizeof(float) * (16 * 64 + (kYR + 2) * (kYC + 2));
         if (lds1 < lds_head) lds1 = lds_head;
         if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
         float* logits_out = const_cast<float*>(a.logits);
-        const unsigned grid1 = (unsigned)(n_tab + n_stream + n_pool);
+        const unsigned grid1 = (unsigned)(n_tab + n_pool + a.N * tiles);
         if (head_C == 16 && head->rel)
-            BXI_LAUNCH("prep_head", s, (prep_head_kernel<16, true>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
+            BXI_LAUNCH("head_prep", s, (head_prep_kernel<16, true>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
         else if (head_C == 16)
-            BXI_LAUNCH("prep_head", s, (prep_head_kernel<16, false>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
+            BXI_LAUNCH("head_prep", s, (head_prep_kernel<16, false>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
         else if (head_C == 8 && head->rel)
-            BXI_LAUNCH("prep_head", s, (prep_head_kernel<8, true>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
+            BXI_LAUNCH("head_prep", s, (head_prep_kernel<8, true>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
         else if (head_C == 8)
-            BXI_LAUNCH("prep_head", s, (prep_head_kernel<8, false>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
+            BXI_LAUNCH("head_prep", s, (head_prep_kernel<8, false>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
         else
             return BXI_ERR_UNSUPPORTED;
     } else {

@@ -155,15 +155,14 @@ class CondInstMaskHead(nn.Module):
                                     disable_rel_coors=self.disable_rel_coors)
 
     def forward_loss(self, feat, params, coors, level_inds, img_inds, imgs, img_metas, gt_inds, gt_bboxes, gt_masks=None,
-                     gt_labels=None, fuse_head: bool = False):
+                     gt_labels=None, fuse_head: bool = True):
         """``mask_logits = self(feat, params, coors, level_inds, img_inds)`` followed by ``self.loss(imgs, img_metas, mask_logits,
         gt_inds, gt_bboxes, gt_masks, gt_labels)`` -- the two calls ``CondInst.forward_train`` makes back to back
-        (``mmdet/models/detectors/condinst.py:71-74``) -- as ONE call.  With ``fuse_head=True`` and where the shapes allow, the
-        dynamic head is evaluated inside the loss evaluation's first launch (``bxi_boxinst_head_eval_f32``: one launch, one kernel
-        boundary and one read of the logits less).  That launch is parity-tested but, as measured, SLOWER than the
-        two it replaces (31 us against 13.5 + 11.5 us at 2 x 800 x 1024, 32 instances): the head's arithmetic sits on the 224
-        stream workgroups, one wave per SIMD, with nothing to hide its load latencies behind -- hence opt-in.
-        Returns ``(mask_logits, losses)``."""
+        (``mmdet/models/detectors/condinst.py:71-74``) -- as ONE call.  Where the shapes allow (and unless ``fuse_head=False``) the
+        dynamic head is evaluated inside the loss evaluation's first launch (``bxi_boxinst_head_eval_f32``): its tiles run side by
+        side with the image pooling and leave, besides the logits, the projection maxima and the zero-filled gradient -- one launch,
+        one kernel boundary and one read of the logits fewer (20 us against 13.4 + 11.4 us at 2 x 800 x 1024, 32 instances).
+        Returns ``(mask_logits, losses)``; every configuration the fused launch is not built for takes the two calls."""
         factor = self.in_stride // self.out_stride
         fused = (fuse_head and self.boxinst_enabled and feat.is_cuda and params.size(0) > 0 and factor == 2 and self.dynamic_convs == 3 and
                  self.dynamic_channels == 8 and feat.size(1) in (8, 16) and feat.size(3) % 2 == 0 and

@@ -205,14 +205,15 @@ int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances*
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same evaluation with the producer of the logits inside its first launch: replaces
- * CondInstMaskHead.forward (condinst_head.py:1139-1164) followed by CondInstMaskHead.loss (:1288-1343).  The stream blocks of the
- * first launch evaluate the dynamic mask head (arguments as bxi_dynamic_mask_forward_f32; B = inst_host->B, N = inst_host->N) on
- * the source rows their output rows sample and take the row / column maxima from the registers the up-sampled logits appear in;
- * inst_host->logits is the buffer the logits are WRITTEN to ([N,1,2*Hs,2*Ws]: pair_kernel and the head's backward,
- * bxi_dynamic_mask_backward_f32 with g_logits, read them).  One launch (dyn_fwd), its kernel boundary and one read of the logits
- * less than bxi_dynamic_mask_forward_f32 + bxi_boxinst_eval_f32 -- and, as measured on MI355X, slower than the two (31 us
- * against 13.5 + 11.5 us at 2 x 800 x 1024 x 32: the head's arithmetic lands on 224 workgroups): an option, not the default.  Built for factor == 2, C in {8, 16}, 16-byte aligned rows
- * (w % 4 == 0), the 4x-pooled image path; anything else (and N == 0) returns BXI_ERR_UNSUPPORTED: call the two entries instead. */
+ * CondInstMaskHead.forward (condinst_head.py:1139-1164) followed by CondInstMaskHead.loss (:1288-1343), the two calls
+ * mmdet/models/detectors/condinst.py:71-74 makes back to back.  The first launch runs the dynamic mask head's tiles (arguments as
+ * bxi_dynamic_mask_forward_f32; B = inst_host->B, N = inst_host->N) next to the image pooling; a tile leaves its logits, its
+ * zero-filled gradient tile and its share of the row / column maxima, so nothing reads the logits back before the pair launch.
+ * inst_host->logits is the buffer the logits are WRITTEN to ([N,1,2*Hs,2*Ws]; pair_kernel and the head's backward,
+ * bxi_dynamic_mask_backward_f32 with g_logits, read them).  One launch, its kernel boundary and one 6.5 MB read fewer than
+ * bxi_dynamic_mask_forward_f32 + bxi_boxinst_eval_f32 (20 us against 13.4 + 11.4 us at 2 x 800 x 1024 x 32).  Built for
+ * factor == 2, C in {8, 16}, 16-byte aligned rows (w % 4 == 0), the 4x-pooled image path; anything else (and N == 0) returns
+ * BXI_ERR_UNSUPPORTED: call the two entries instead.  Workspace / state / upstream factors as bxi_boxinst_eval_f32. */
 int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host,
                               const float* feat, int C, int Hs, int Ws, const float* params, const float* coors,
                               const int64_t* level_inds, const int64_t* img_inds, const float* sizes_of_interest, int n_levels,
