@@ -350,6 +350,7 @@ def worker(args):
                                              'note': 'bxi_boxinst_eval_f32 + bxi_boxinst_grad_rescale_f32 (3 launches): the C-ABI '
                                                      'sequence behind loss() + backward() when the upstream factors are only '
                                                      'known at backward time'}
+        result['head_fused_extra'] = head_fused(lib, Fh, sets, dev, stream, args.steps)
         result['module_api'] = module_api(sets, dev, min(args.steps, 300))
 
     # ---- per-kernel durations with HIP events on the launching stream (rank 0, N == 1) ------------
@@ -361,6 +362,64 @@ def worker(args):
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def head_fused(lib, Fh, sets, dev, stream, steps):
+    """Extra (not `value`): the step one level out -- CondInstMaskHead.forward + .loss at the C ABI, i.e. the
+    dynamic mask head (16 mask-feature channels at stride 8, random parameters) producing the logits the evaluation consumes:
+    bxi_dynamic_mask_forward_f32 + bxi_boxinst_eval_f32 (3 launches) against bxi_boxinst_head_eval_f32 (2 launches: the head's
+    tiles run inside the evaluation's first launch)."""
+    vp = C.c_void_p
+    g = torch.Generator(device='cpu').manual_seed(0)
+    packs = []
+    for s in sets:
+        d, N = s.d, s.inst.N
+        Hs, Ws = d['H'] // 8, d['W'] // 8
+        feat = torch.randn(d['B'], 16, Hs, Ws, generator=g).to(dev)
+        params = (0.3 * torch.randn(N, 18 * 8 + 64 + 8 + 8 + 8 + 1, generator=g)).to(dev)
+        coors = (torch.rand(N, 2, generator=g) * torch.tensor([float(d['W']), float(d['H'])])).to(dev)
+        lvl = torch.randint(0, 5, (N,), generator=g).to(dev)
+        counts = np.cumsum([0] + [b.shape[0] for b in d['gt_bboxes']])
+        img = torch.tensor([int(np.searchsorted(counts, int(x), side='right') - 1) for x in d['gt_inds']], dtype=torch.int64).to(dev)
+        soi = torch.tensor([64., 128., 256., 512., 1024.], device=dev)
+        head = (vp(feat.data_ptr()), C.c_int(16), C.c_int(Hs), C.c_int(Ws), vp(params.data_ptr()), vp(coors.data_ptr()),
+                vp(lvl.data_ptr()), vp(img.data_ptr()), vp(soi.data_ptr()), C.c_int(5), C.c_int(8), C.c_int(2), C.c_int(0))
+        logits2 = torch.empty_like(s.inst.logits)               # the head writes here: the timed sets keep their logits
+        inst2 = Fh._Inst(logits2, s.gt_inds, s.boxes, d['H'], d['W'], d['stride'])
+        ev = (s.eval_args[0], C.byref(inst2.struct)) + tuple(s.eval_args[2:])
+        fwd = (vp(feat.data_ptr()), C.c_int(d['B']), C.c_int(16), C.c_int(Hs), C.c_int(Ws), vp(params.data_ptr()), C.c_int(N),
+               vp(coors.data_ptr()), vp(lvl.data_ptr()), vp(img.data_ptr()), vp(soi.data_ptr()), C.c_int(5), C.c_int(8), C.c_int(2),
+               C.c_int(0), vp(logits2.data_ptr()))
+        packs.append((ev, head, fwd, (feat, params, coors, lvl, img, soi, logits2, inst2)))
+    st = stream.cuda_stream
+
+    def fused(pk):
+        ev, head, _, _ = pk
+        rc = lib.bxi_boxinst_head_eval_f32(ev[0], ev[1], *head, *ev[2:], st)
+        assert rc == 0, rc
+
+    def separate(pk):
+        ev, _, fwd, _ = pk
+        rc = lib.bxi_dynamic_mask_forward_f32(*fwd, st)
+        assert rc == 0, rc
+        rc = lib.bxi_boxinst_eval_f32(*ev, st)
+        assert rc == 0, rc
+
+    out = {}
+    with torch.cuda.stream(stream):
+        for name, fn in (('head_then_eval_3_launches', separate), ('head_eval_fused_2_launches', fused)):
+            for i in range(50):
+                fn(packs[i % len(packs)])
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for i in range(steps):
+                fn(packs[i % len(packs)])
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t1
+            out[name] = {'us_per_step': el / steps * 1e6, 'images_per_s': 2 * steps / el}
+    out['note'] = ('dynamic mask head forward + loss evaluation (forward and finished backward w.r.t. the logits) per step, C ABI, '
+                   'cold input sets, its own logits buffers')
+    return out
 
 
 def module_api(sets, dev, n):
