@@ -1092,10 +1092,13 @@ __global__ void zero_losses2_kernel(float* losses) { losses[0] = 0.f; losses[1] 
 size_t eval_ws_bytes(int N, int h, int w) { return carve_eval(nullptr, N, h, w, nullptr); }
 
 static int tile_rows_for(int N, int h, int w, int dil) {
-    (void)N; (void)h; (void)w; (void)dil;
-    // 8-row tiles: 38 pair evaluations per lane for 8 rows.  4-row tiles (BXI_TILE_ROWS=4) double the number of tile waves at
-    // 1.2x the pair evaluations; measured slower at 32 and at 64 instances (the leaders then queue behind the tile waves).
-    return 8;
+    (void)h; (void)w; (void)dil;
+    // A tile wave's time is the length of its dependent chain, so 4-row tiles (6 row steps instead of 10, 1.2x the pair
+    // evaluations in total, three waves a SIMD at <= 168 VGPRs) win while the tile waves are resident together: measured
+    // 11.4 vs 12.2 us at 32 instances, 19.8 vs 20.9 us at 64, 41.8 vs 40.6 us at 128 (2 x 800 x 1024).  (Before the arrival
+    // words were split they lost everywhere: twice the atomics per word.)  The number of tiles is device data; the instance
+    // count is what the host has.  Developer knob: BXI_TILE_ROWS.
+    return N <= 96 ? 4 : 8;
 }
 int eval_tile_rows(int N, int h, int w, int dil) { return tile_rows_for(N, h, w, dil); }
 
