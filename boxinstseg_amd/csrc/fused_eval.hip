@@ -482,8 +482,8 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, i
 // ================================================================================================
 template <int D, int R> struct TG { static constexpr int RD = R + 2 * D, TW = 64 - 2 * D; };
 
-struct TileFlags {   // bit j = data row j (map row tile_r0 - D + j) of this lane's column; R / L = the lane D to the right / left
-    uint32_t ib, vd, ow, ibR, vdR, owR, ibL, vdL, owL;       // in GT box ; valid image pixel ; owned by this tile
+struct TileFlags {   // bit j = data row j (map row tile_r0 - D + j) of this lane's column; R = the lane D to the right
+    uint32_t ib, vd, ow, ibR, vdR, owR;       // in GT box ; valid image pixel ; owned by this tile
 };
 
 __device__ __forceinline__ uint32_t row_bits(int lo, int hi, int base, int n) {   // bits j in [0,n) with lo <= base + j < hi
@@ -513,31 +513,26 @@ __device__ __forceinline__ TileFlags tile_flags(const WorkRec2& wr, int h, int w
     }
     {
         const int c = cl + D, ln = lane + D;
-        const bool in = ln < 64;
+        const bool in = ln < 64;      // lanes without a right neighbour: every pair weight 0 (they receive some other lane's data)
         f.ibR = (in && c >= wr.c0 && c < wr.c1) ? rows_box : 0u;
         f.vdR = (in && c >= 0 && c < cv) ? rows_val : 0u;
         f.owR = (in && ln >= D && ln < 64 - D && c < wr.hc1) ? rows_own : 0u;
     }
-    {
-        const int c = cl - D, ln = lane - D;
-        const bool in = ln >= 0;
-        f.ibL = (in && c >= wr.c0 && c < wr.c1) ? rows_box : 0u;
-        f.vdL = (in && c >= 0 && c < cv) ? rows_val : 0u;
-        f.owL = (in && ln >= D && ln < 64 - D && c < wr.hc1) ? rows_own : 0u;
-    }
     return f;
 }
 
-// masks of one of the four forward directions; bit i = the pair (row i of this lane, partner):  W[k,p] = mA, W[7-k,q] = mB
-// (zero_bit == 0: the fast paths are not taken otherwise), and the same restricted to pixels this tile owns.
+// The four pair directions of a step i (j = i + D), every one between this lane and the lane D to its right or itself, so
+// that only right-neighbour values are ever fetched:
+//   0: A = (i, l)  B = (i, l + D)   |   1: A = (j, l)  B = (i, l + D)   |   2: A = (i, l)  B = (j, l)   |   3: A = (i, l)  B = (j, l + D)
+// masks, bit i = the pair of step i:  W[k, A] = mA, W[7 - k, B] = mB (zero_bit == 0: the fast paths are not taken otherwise),
+// and the same restricted to pixels this tile owns.
 struct DirMasks { uint32_t mA, mB, nA, nB; };
 template <int D>
 __device__ __forceinline__ void dir_masks(const TileFlags& f, DirMasks (&m)[4]) {
-    // 0: (0,+D) lane R same row | 1: (+D,-D) lane L | 2: (+D,0) same lane | 3: (+D,+D) lane R
-    m[0].mA = f.ib & f.vdR;          m[0].mB = f.ibR & f.vd;          m[0].nA = m[0].mA & f.ow; m[0].nB = m[0].mB & f.owR;
-    m[1].mA = f.ib & (f.vdL >> D);   m[1].mB = (f.ibL >> D) & f.vd;   m[1].nA = m[1].mA & f.ow; m[1].nB = m[1].mB & (f.owL >> D);
-    m[2].mA = f.ib & (f.vd >> D);    m[2].mB = (f.ib >> D) & f.vd;    m[2].nA = m[2].mA & f.ow; m[2].nB = m[2].mB & (f.ow >> D);
-    m[3].mA = f.ib & (f.vdR >> D);   m[3].mB = (f.ibR >> D) & f.vd;   m[3].nA = m[3].mA & f.ow; m[3].nB = m[3].mB & (f.owR >> D);
+    m[0].mA = f.ib & f.vdR;          m[0].mB = f.ibR & f.vd;          m[0].nA = m[0].mA & f.ow;        m[0].nB = m[0].mB & f.owR;
+    m[1].mA = (f.ib >> D) & f.vdR;   m[1].mB = f.ibR & (f.vd >> D);   m[1].nA = m[1].mA & (f.ow >> D); m[1].nB = m[1].mB & f.owR;
+    m[2].mA = f.ib & (f.vd >> D);    m[2].mB = (f.ib >> D) & f.vd;    m[2].nA = m[2].mA & f.ow;        m[2].nB = m[2].mB & (f.ow >> D);
+    m[3].mA = f.ib & (f.vdR >> D);   m[3].mB = (f.ibR >> D) & f.vd;   m[3].nA = m[3].mA & f.ow;        m[3].nB = m[3].mB & (f.owR >> D);
 }
 
 template <int D, int R>
@@ -616,21 +611,22 @@ __device__ __forceinline__ int slow_tile(const float* __restrict__ Lg, const flo
     return cnt;
 }
 
-// The value of lane + D / lane - D (its own where that lane does not exist: exactly __shfl(v, min(lane + D, 63)) and
-// __shfl(v, max(lane - D, 0))), by D wavefront shifts of one lane on the VALU's data-parallel path instead of a trip through
-// the LDS crossbar (ds_bpermute): the pair loop asks for twelve neighbour values per row and waited for each batch.
+// The value of lane + D / lane - D, by D wavefront rotations of one lane on the VALU's data-parallel path instead of a trip
+// through the LDS crossbar (ds_bpermute).  A rotation, not a shift: every lane receives something (the last D lanes receive
+// lanes 0..D-1: finite data of the same tile), so the instruction needs no "old" operand and no copy in front of it; whatever
+// those lanes compute from it is weighted 0 (TileFlags) or discarded by the caller.
 template <int D>
 __device__ __forceinline__ float lane_plus(float v) {
     int x = __float_as_int(v);
 #pragma unroll
-    for (int s = 0; s < D; ++s) x = __builtin_amdgcn_update_dpp(x, x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    for (int s = 0; s < D; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
     return __int_as_float(x);
 }
 template <int D>
 __device__ __forceinline__ float lane_minus(float v) {
     int x = __float_as_int(v);
 #pragma unroll
-    for (int s = 0; s < D; ++s) x = __builtin_amdgcn_update_dpp(x, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    for (int s = 0; s < D; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
     return __int_as_float(x);
 }
 
@@ -655,24 +651,21 @@ __device__ __forceinline__ void count_tile(const InstArgs& a, const float* __res
         DirMasks m[4];
         dir_masks<D>(f, m);
         BXI_TW(2, tix, 1);
+        float LR[RD], AR[RD], BR[RD];
+#pragma unroll
+        for (int i = 0; i < RD; ++i) { LR[i] = lane_plus<D>(L[i]); AR[i] = lane_plus<D>(A[i]); BR[i] = lane_plus<D>(B[i]); }
+        uint32_t pb[4] = {0u, 0u, 0u, 0u};        // bit i = the colour predicate of the pair of step i
 #pragma unroll
         for (int i = 0; i < R + D; ++i) {
             const int j = i + D;
             if (i == 1) BXI_TW(2, tix, 2);
-            const float LRj = lane_plus<D>(L[j]), ARj = lane_plus<D>(A[j]), BRj = lane_plus<D>(B[j]);
-            const float LLj = lane_minus<D>(L[j]), ALj = lane_minus<D>(A[j]), BLj = lane_minus<D>(B[j]);
-            if (i >= D) {
-                const float LRi = lane_plus<D>(L[i]), ARi = lane_plus<D>(A[i]), BRi = lane_plus<D>(B[i]);
-                const bool pn = n2_of(L[i], A[i], B[i], LRi, ARi, BRi) <= wr.n2max;
-                cnt += pn ? (int)(((m[0].nA >> i) & 1u) + ((m[0].nB >> i) & 1u)) : 0;
-            }
-            { const bool pn = n2_of(L[i], A[i], B[i], LLj, ALj, BLj) <= wr.n2max;
-              cnt += pn ? (int)(((m[1].nA >> i) & 1u) + ((m[1].nB >> i) & 1u)) : 0; }
-            { const bool pn = n2_of(L[i], A[i], B[i], L[j], A[j], B[j]) <= wr.n2max;
-              cnt += pn ? (int)(((m[2].nA >> i) & 1u) + ((m[2].nB >> i) & 1u)) : 0; }
-            { const bool pn = n2_of(L[i], A[i], B[i], LRj, ARj, BRj) <= wr.n2max;
-              cnt += pn ? (int)(((m[3].nA >> i) & 1u) + ((m[3].nB >> i) & 1u)) : 0; }
+            if (i >= D) pb[0] |= n2_of(L[i], A[i], B[i], LR[i], AR[i], BR[i]) <= wr.n2max ? 1u << i : 0u;
+            pb[1] |= n2_of(L[j], A[j], B[j], LR[i], AR[i], BR[i]) <= wr.n2max ? 1u << i : 0u;
+            pb[2] |= n2_of(L[i], A[i], B[i], L[j], A[j], B[j]) <= wr.n2max ? 1u << i : 0u;
+            pb[3] |= n2_of(L[i], A[i], B[i], LR[j], AR[j], BR[j]) <= wr.n2max ? 1u << i : 0u;
         }
+#pragma unroll
+        for (int dir = 0; dir < 4; ++dir) cnt += __popc(pb[dir] & m[dir].nA) + __popc(pb[dir] & m[dir].nB);
     }
     cnt = wave_total_i32(cnt);
     BXI_TW(2, tix, 3);
@@ -761,11 +754,11 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
         // take the log-space path below.
         float pa_[RD], pb_[RD], pt_[RD], pu_[RD];    // this lane, rows [i, i + D] live
         float aR[RD], bR[RD], tR[RD], uR[RD], LR[RD], AR[RD], BR[RD];   // the lane D to the right, rows [i, i + D] live
-        float gq[RD], gR[RD], gL[RD];                // gradient of this lane's pixels / of lane + D's / of lane - D's
+        float gq[RD], gR[RD];                        // gradient of this lane's pixels / of lane + D's
         bool sat = false;
 #pragma unroll
-        for (int j = 0; j < RD; ++j) { gq[j] = 0.f; gR[j] = 0.f; gL[j] = 0.f; sat |= !(fabsf(x[j]) <= 34.f); }
-        // pair weights as bytes, four rows per word: cw = W[k,p] + W[7-k,q] (gradient), dw = the same restricted to
+        for (int j = 0; j < RD; ++j) { gq[j] = 0.f; gR[j] = 0.f; sat |= !(fabsf(x[j]) <= 34.f); }
+        // pair weights as bytes, four rows per word: cw = W[k,A] + W[7-k,B] (gradient), dw = the same restricted to
         // pixels this tile owns (loss sum)
         uint32_t cw[4][(R + D + 3) / 4], dw[4][(R + D + 3) / 4];
 #pragma unroll
@@ -776,42 +769,42 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
                 dw[dir][q4] = spread4((m[dir].nA >> (4 * q4)) & 15u) + spread4((m[dir].nB >> (4 * q4)) & 15u);
             }
         BXI_TW(1, tix, 1);
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; pt_[j] = s.x - s.y; pu_[j] = s.x * s.y;
-        }
-        BXI_TW(1, tix, 2);
-        // one unordered pair: p = (row i, this lane) ; q = the operands ; dir = weight set
-#define BXI_PAIR(i, qa, qb, qt, qu, qL, qA, qB, dir, GP, GQ)                                                      \
+#define BXI_ROW(j)                                                                                                  \
         {                                                                                                           \
-            const bool pn = n2_of(L[i], A[i], B[i], qL, qA, qB) <= wr.n2max;                                        \
+            const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; pt_[j] = s.x - s.y; pu_[j] = s.x * s.y;    \
+            aR[j] = lane_plus<D>(pa_[j]); bR[j] = lane_plus<D>(pb_[j]); tR[j] = aR[j] - bR[j]; uR[j] = aR[j] * bR[j]; \
+            LR[j] = lane_plus<D>(L[j]); AR[j] = lane_plus<D>(A[j]); BR[j] = lane_plus<D>(B[j]);                     \
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) BXI_ROW(j)
+        BXI_TW(1, tix, 2);
+        // one unordered pair: A = (row ra, this lane) ; B = (row rb of the lane `q` names) ; num collects -log2 S
+#define BXI_PAIR(i, ra, rb, qa, qb, qt, qu, qL, qA, qB, dir, GA, GB)                                              \
+        {                                                                                                           \
+            const bool pn = n2_of(L[ra], A[ra], B[ra], qL[rb], qA[rb], qB[rb]) <= wr.n2max;                         \
             const float gw = pn ? (float)((cw[dir][(i) >> 2] >> (8 * ((i) & 3))) & 255u) : 0.f;                     \
             const float nw = pn ? (float)((dw[dir][(i) >> 2] >> (8 * ((i) & 3))) & 255u) : 0.f;                     \
-            const float S = pa_[i] * (qa) + pb_[i] * (qb);                          /* P(y_p == y_q) */            \
-            num -= nw * (0.69314718055994531f * __builtin_amdgcn_logf(S));          /* v_log_f32 = log2 */         \
+            const float S = pa_[ra] * qa[rb] + pb_[ra] * qb[rb];                    /* P(y_A == y_B) */            \
+            num -= nw * __builtin_amdgcn_logf(S);                                   /* v_log_f32 = log2 */         \
             const float mm = gw * __builtin_amdgcn_rcpf(S);                                                         \
-            GP -= mm * (qt) * pu_[i];                                                                               \
-            GQ -= mm * pt_[i] * (qu);                                                                               \
+            GA -= mm * qt[rb] * pu_[ra];                                                                            \
+            GB -= mm * pt_[ra] * qu[rb];                                                                            \
         }
 #pragma unroll
         for (int i = 0; i < R + D; ++i) {
             const int j = i + D;
-            { const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; pt_[j] = s.x - s.y; pu_[j] = s.x * s.y; }
-            aR[j] = lane_plus<D>(pa_[j]); bR[j] = lane_plus<D>(pb_[j]); tR[j] = aR[j] - bR[j]; uR[j] = aR[j] * bR[j];
-            LR[j] = lane_plus<D>(L[j]); AR[j] = lane_plus<D>(A[j]); BR[j] = lane_plus<D>(B[j]);
-            const float aLj = lane_minus<D>(pa_[j]), bLj = lane_minus<D>(pb_[j]);
-            const float tLj = aLj - bLj, uLj = aLj * bLj;
-            const float LLj = lane_minus<D>(L[j]), ALj = lane_minus<D>(A[j]), BLj = lane_minus<D>(B[j]);
-            if (i >= D) BXI_PAIR(i, aR[i], bR[i], tR[i], uR[i], LR[i], AR[i], BR[i], 0, gq[i], gR[i])
-            BXI_PAIR(i, aLj, bLj, tLj, uLj, LLj, ALj, BLj, 1, gq[i], gL[j])
-            BXI_PAIR(i, pa_[j], pb_[j], pt_[j], pu_[j], L[j], A[j], B[j], 2, gq[i], gq[j])
-            BXI_PAIR(i, aR[j], bR[j], tR[j], uR[j], LR[j], AR[j], BR[j], 3, gq[i], gR[j])
-            if (i >= D) {     // row i is complete: collect what the neighbour lanes computed for it
-                const float fromL = lane_minus<D>(gR[i]);            // lane - D evaluated (.., +D) pairs into this lane
-                const float fromR = lane_plus<D>(gL[i]);             // lane + D evaluated (+D, -D) pairs into this lane
-                g[i - D] = gq[i] + (lane >= D ? fromL : 0.f) + (lane + D < 64 ? fromR : 0.f);
+            BXI_ROW(j)
+            if (i >= D) BXI_PAIR(i, i, i, aR, bR, tR, uR, LR, AR, BR, 0, gq[i], gR[i])
+            BXI_PAIR(i, j, i, aR, bR, tR, uR, LR, AR, BR, 1, gq[j], gR[i])
+            BXI_PAIR(i, i, j, pa_, pb_, pt_, pu_, L, A, B, 2, gq[i], gq[j])
+            BXI_PAIR(i, i, j, aR, bR, tR, uR, LR, AR, BR, 3, gq[i], gR[j])
+            if (i >= D) {     // row i is complete: collect what the lane D to the left computed for it
+                const float fromL = lane_minus<D>(gR[i]);
+                g[i - D] = gq[i] + (lane >= D ? fromL : 0.f);
             }
         }
+        num *= 0.69314718055994531f;
+#undef BXI_ROW
 #undef BXI_PAIR
         slow = __any(sat);
     }
