@@ -896,21 +896,38 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, int R, 
     const InstRec rec = ws.inst[n];
     const InstBox ib = inst_from_rec(rec, dil, h, w);
     float sums[4] = {0.f, 0.f, 0.f, 0.f};   // I_x, U_x, I_y, U_y
-    for (int c = tid; c < w; c += 256) {
-        unsigned long long k = ws.colpart[(int64_t)n * ws.n_cb * w + c];
-        for (int s = 1; s < ws.n_cb; ++s) { const unsigned long long o = ws.colpart[((int64_t)n * ws.n_cb + s) * w + c]; k = o > k ? o : k; }
-        const float X = sigmoid_acc(unpack_val(k));
-        const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
-        xs[c] = X; carg[c] = (int)unpack_idx(k);
-        sums[0] += X * TX; sums[1] += X * X + TX * TX;
-    }
-    for (int r = tid; r < h; r += 256) {
-        unsigned long long k = ws.rowkey[(int64_t)n * ws.n_rp * h + r];
-        for (int s = 1; s < ws.n_rp; ++s) { const unsigned long long o = ws.rowkey[((int64_t)n * ws.n_rp + s) * h + r]; k = o > k ? o : k; }
-        const float Y = sigmoid_acc(unpack_val(k));
-        const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
-        ys[r] = Y; rarg[r] = (int)unpack_idx(k);
-        sums[2] += Y * TY; sums[3] += Y * Y + TY * TY;
+    // the partial maxima of a column / row: up to eight loads in flight at once (the band count is launch data, and a loop
+    // of load -> compare would walk through L2 once per band: 7 x 0.5 us at 200 rows)
+    auto best_key = [](const unsigned long long* __restrict__ part, int n_part, int64_t stride) {
+        unsigned long long k = part[0];
+        for (int s0 = 0; s0 < n_part; s0 += 8) {
+            unsigned long long o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = part[(int64_t)min(s0 + u, n_part - 1) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) k = o[u] > k ? o[u] : k;
+        }
+        return k;
+    };
+    for (int i = tid; i < max(w, h); i += 256) {
+        const bool is_c = i < w, is_r = i < h;
+        // both keys requested before either is used
+        const unsigned long long kc = best_key(ws.colpart + (int64_t)n * ws.n_cb * w + (is_c ? i : 0), ws.n_cb, w);
+        const unsigned long long kr = best_key(ws.rowkey + (int64_t)n * ws.n_rp * h + (is_r ? i : 0), ws.n_rp, h);
+        if (is_c) {
+            const int c = i;
+            const float X = sigmoid_acc(unpack_val(kc));
+            const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
+            xs[c] = X; carg[c] = (int)unpack_idx(kc);
+            sums[0] += X * TX; sums[1] += X * X + TX * TX;
+        }
+        if (is_r) {
+            const int r = i;
+            const float Y = sigmoid_acc(unpack_val(kr));
+            const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
+            ys[r] = Y; rarg[r] = (int)unpack_idx(kr);
+            sums[2] += Y * TY; sums[3] += Y * Y + TY * TY;
+        }
     }
     BXI_TW(3, n, 1);
     block_sum4(sums, red);
