@@ -30,6 +30,7 @@
 // materialised intermediate (1.2 MB at 2x800x1024).
 #include "loss_common.hpp"
 #include "dynamic_head_device.hpp"
+#include <atomic>
 #include <cstdlib>
 
 namespace bxi {
@@ -1101,6 +1102,20 @@ __global__ void zero_losses2_kernel(float* losses) { losses[0] = 0.f; losses[1] 
 // ---- host side ---------------------------------------------------------------------------------------------------
 size_t eval_ws_bytes(int N, int h, int w) { return carve_eval(nullptr, N, h, w, nullptr); }
 
+// compute units of the current device (256 on an MI355X in SPX mode, 32 per partition in CPX): the grids are sized so that a
+// launch is resident in one round.  Cached per device ordinal; a wrong value costs time, never correctness.
+static int device_cus() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cached[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 static int tile_rows_for(int N, int h, int w, int dil) {
     (void)h; (void)w; (void)dil;
     // A tile wave's time is the length of its dependent chain, so 4-row tiles (6 row steps instead of 10, 1.2x the pair
@@ -1168,7 +1183,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thre
             // one item = the 4 input rows of 64 pooled pixels.  The whole launch should be resident at once (5 workgroups
             // per CU at <= 96 VGPRs): a pool workgroup takes several items, the next one's loads in flight, when it is not.
             n_items = batch->B * a.h * ((a.w + 63) / 64);
-            const int room = 5 * 256 - n_tab - (head ? 0 : n_stream);
+            const int room = 5 * device_cus() - n_tab - (head ? 0 : n_stream);
             const int per = room > 0 ? (n_items + room - 1) / room : 8;
             n_pool = (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per);
         }
@@ -1215,7 +1230,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thre
     int n_cb = (cap + kWaves - 1) / kWaves;
     // the list length is device data: the tile waves stride through it.  3 (R = 4: <= 168 VGPRs) or 2 (R = 8) workgroups per
     // CU are resident: leaders + count + math blocks should fit in one round.
-    const int room2 = ((R == 4 ? 3 : 2) * 256 - a.N) / 2;
+    const int room2 = ((R == 4 ? 3 : 2) * device_cus() - a.N) / 2;
     if (n_cb > (room2 > 64 ? room2 : 64)) n_cb = room2 > 64 ? room2 : 64;
     size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
     const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;

@@ -111,9 +111,9 @@ __device__ __forceinline__ void pw_stage(const T* __restrict__ L, int H, int W, 
     }
 }
 
+// the exact body: log space as pairwise.cu:38-50 (every dtype; for f32 only when a logit of the tile is beyond +-34)
 template <typename T>
-__global__ __launch_bounds__(256) void pairwise3_fwd_kernel(const T* __restrict__ logits, int H, int W, int d, T* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char pw_raw[];
+__device__ __forceinline__ void pairwise3_fwd_exact(const T* __restrict__ logits, int H, int W, int d, T* __restrict__ out, unsigned char* pw_raw) {
     LogPair<T>* tile = reinterpret_cast<LogPair<T>*>(pw_raw);
     const int tiles_x = (W + kPwTC - 1) / kPwTC, tiles_y = (H + kPwTR - 1) / kPwTR;
     int t = blockIdx.x;
@@ -157,6 +157,102 @@ __global__ __launch_bounds__(256) void pairwise3_fwd_kernel(const T* __restrict_
     }
 }
 
+template <typename T> struct ProbPair { T s, m; };      // sigmoid(x), sigmoid(-x)
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // 1 ulp
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+// exp(-a), a >= 0: v_exp_f32 (2^x, ~1 ulp) on a * log2(e) -- the staged probabilities need 1e-6, not the last bit
+__device__ __forceinline__ float fast_exp_neg(float a) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * a); }
+__device__ __forceinline__ double fast_exp_neg(double a) { return exp(-a); }
+constexpr int kPwStageRows = (kPwTR + 2 * kPwMaxDil + 3) / 4;       // staged rows a wave may have to take
+
+template <typename T>
+__global__ __launch_bounds__(256) void pairwise3_fwd_kernel(const T* __restrict__ logits, int H, int W, int d, T* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_raw[];
+    pairwise3_fwd_exact<T>(logits, H, W, d, out, pw_raw);
+}
+
+// f32: the log-space body spends ~270 instructions per pixel (two accurate exp/log pairs per staged pixel and one per pair, a
+// 64-bit address and a branch per store) and ran with the VALU 92 % busy -- 20.6 us for 59 MB.  While every |logit| of the tile
+// + halo is <= 34 (block-uniform; otherwise the exact body above) probabilities are staged, (s, s') = (sigmoid(x), sigmoid(-x))
+// with one v_exp_f32 and one v_rcp_f32 per pixel, and a pair is S = s_p s_q + s'_p s'_q (>= 3e-15), f = -ln2 log2 S: two
+// multiply-adds and one v_log_f32.  Stores: a wave-uniform plane base + the pixel's 32-bit byte offset; a pair whose later pixel
+// lies outside the map is 0 and its second store lands on the first one's address (same value) instead of behind a branch.
+template <int D>      // dilation (compile time: the staged tile's row length divides by a constant); 0 = run time
+__global__ __launch_bounds__(256) void pairwise3_fwd_fast_kernel(const float* __restrict__ logits, int H, int W, int d_, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_raw[];
+    const int d = D ? D : d_;
+    const int PR = kPwTR + 2 * d, PC = kPwTC + 2 * d;
+    const int tiles_x = (W + kPwTC - 1) / kPwTC, tiles_y = (H + kPwTR - 1) / kPwTR;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int64_t n = t / tiles_y;
+    const int64_t P = (int64_t)H * W;
+    const int r0 = ty * kPwTR, c0 = tx * kPwTC;
+    const float* L = logits + n * P;
+    // tile + halo logits, element i = threadIdx + 256 e of the staged tile (row-major): every lane of every load is used (rows
+    // taken by waves with the columns in two passes issued half of their instructions for the 2d columns beyond 64), all
+    // loads of a thread in flight together
+    constexpr int kMaxE = ((kPwTR + 2 * (D ? D : kPwMaxDil)) * (kPwTC + 2 * (D ? D : kPwMaxDil)) + 255) / 256;
+    float xv[kMaxE];
+    bool sat = false;
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) {
+        const int i = threadIdx.x + 256 * e;
+        const int r = r0 - d + i / PC, cq = c0 - d + i % PC;
+        xv[e] = 0.f;          // outside the map: never used as a neighbour (those pairs are 0)
+        if (i < PR * PC && (unsigned)r < (unsigned)H && (unsigned)cq < (unsigned)W) { xv[e] = L[(uint32_t)(r * W + cq)]; sat |= !(fabsf(xv[e]) <= 34.f); }
+    }
+    if (__syncthreads_or(sat ? 1 : 0)) {       // rare
+        pairwise3_fwd_exact<float>(logits, H, W, d, out, pw_raw);
+        return;
+    }
+    ProbPair<float>* tile = reinterpret_cast<ProbPair<float>*>(pw_raw);
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) {
+        const int i = threadIdx.x + 256 * e;
+        if (i < PR * PC) {
+            const float x = xv[e], en = fast_exp_neg(fabsf(x)), big = fast_rcp(1.f + en), small = en * big;   // sigmoid(|x|), sigmoid(-|x|)
+            tile[i] = x >= 0.f ? ProbPair<float>{big, small} : ProbPair<float>{small, big};
+        }
+    }
+    __syncthreads();
+    const int lc = threadIdx.x & 63, lr0 = threadIdx.x >> 6;
+    const int c = c0 + lc;
+    if (c >= W) return;
+    char* ob = reinterpret_cast<char*>(out + n * 8 * P);                 // wave-uniform; 8 planes of one instance < 2^31 bytes (launcher)
+    const uint32_t plane = (uint32_t)P * 4u;
+    const bool c_lo = c - d >= 0, c_hi = c + d < W;
+    const bool edge_tile = r0 < d || c0 < d || c0 + kPwTC + d > W;       // block-uniform: some pixel has an earlier neighbour outside the map
+#pragma unroll
+    for (int j = 0; j < kPwTR / 4; ++j) {
+        const int lr = lr0 + 4 * j, r = r0 + lr;
+        if (r >= H) break;
+        const uint32_t pix = (uint32_t)(r * W + c) * 4u;
+        const bool r_lo = r - d >= 0, r_hi = r + d < H;
+        if (edge_tile) {
+            // earlier neighbours outside the map: this pixel writes their zeros (pairwise.cu:43-44); inside, the neighbour writes
+            if (!(r_lo && c_lo)) *reinterpret_cast<float*>(ob + pix) = 0.f;
+            if (!r_lo) *reinterpret_cast<float*>(ob + plane + pix) = 0.f;
+            if (!(r_lo && c_hi)) *reinterpret_cast<float*>(ob + 2u * plane + pix) = 0.f;
+            if (!c_lo) *reinterpret_cast<float*>(ob + 3u * plane + pix) = 0.f;
+        }
+        const ProbPair<float> p = tile[(lr + d) * PC + lc + d];
+#pragma unroll
+        for (int k = 4; k < 8; ++k) {                         // later neighbours: (0,+d) (+d,-d) (+d,0) (+d,+d)
+            const int dy = k == 4 ? 0 : 1, dx = k == 4 ? 1 : k - 6;
+            const bool in = (dy ? r_hi : true) && (dx < 0 ? c_lo : (dx > 0 ? c_hi : true));
+            const ProbPair<float> q = tile[(lr + d + dy * d) * PC + lc + d + dx * d];      // staged whether in the map or not
+            const float S = p.s * q.s + p.m * q.m;
+            const float v = in ? -0.69314718055994531f * __builtin_amdgcn_logf(S) : 0.f;
+            const uint32_t own = (uint32_t)k * plane + pix;
+            const uint32_t other = (uint32_t)(7 - k) * plane + pix + (uint32_t)((dy * d * W + dx * d) * 4);   // channel 7-k of q
+            *reinterpret_cast<float*>(ob + own) = v;
+            *reinterpret_cast<float*>(ob + (in ? other : own)) = v;
+        }
+    }
+}
+
 // backward: a pair (p,q) is evaluated once by its earlier pixel p, which keeps its own share and deposits q's share into slot
 // [q][k-4] of an LDS plane (one writer per slot: no atomics); pairs whose earlier pixel lies outside the tile are evaluated
 // by the later pixel itself.  Two bodies:
@@ -167,12 +263,6 @@ __global__ __launch_bounds__(256) void pairwise3_fwd_kernel(const T* __restrict_
 //          instead of five exp / log evaluations (the kernel was bound by those: 43 us, 0.2 of the HBM peak);
 //   exact  otherwise (block-uniform choice): log space exactly as pairwise.cu:38-58, (log s, log s', s - s') staged.
 template <typename T> struct LogTriple { T a, b, dd; };
-template <typename T> struct ProbPair { T s, m; };      // sigmoid(x), sigmoid(-x)
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // 1 ulp
-__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
-// exp(-a), a >= 0: v_exp_f32 (2^x, ~1 ulp) on a * log2(e) -- the staged probabilities need 1e-6, not the last bit
-__device__ __forceinline__ float fast_exp_neg(float a) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * a); }
-__device__ __forceinline__ double fast_exp_neg(double a) { return exp(-a); }
 
 
 template <typename T>
@@ -348,8 +438,20 @@ static int launch_fwd(const T* logits, int N, int H, int W, int size, int dil, T
     if (size == 3 && dil <= kPwMaxDil) {
         const int64_t tiles = (int64_t)N * ((H + kPwTR - 1) / kPwTR) * ((W + kPwTC - 1) / kPwTC);
         if (fits_i32(tiles)) {
-            BXI_LAUNCH("pairwise_fwd", as_stream(stream), (pairwise3_fwd_kernel<T>), dim3((unsigned)tiles), dim3(block), pw3_lds<T>(dil),
-                       as_stream(stream), logits, H, W, dil, out);
+            if constexpr (sizeof(T) == 4) {
+                const dim3 g((unsigned)tiles), b(block);
+                const size_t lds = pw3_lds<T>(dil);
+                hipStream_t st = as_stream(stream);
+                switch (dil) {
+                    case 1: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<1>, g, b, lds, st, logits, H, W, dil, out); break;
+                    case 2: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<2>, g, b, lds, st, logits, H, W, dil, out); break;
+                    case 3: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<3>, g, b, lds, st, logits, H, W, dil, out); break;
+                    case 4: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<4>, g, b, lds, st, logits, H, W, dil, out); break;
+                    default: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<0>, g, b, lds, st, logits, H, W, dil, out); break;
+                }
+            } else
+                BXI_LAUNCH("pairwise_fwd", as_stream(stream), (pairwise3_fwd_kernel<T>), dim3((unsigned)tiles), dim3(block), pw3_lds<T>(dil),
+                           as_stream(stream), logits, H, W, dil, out);
             return check_launch();
         }
     }
