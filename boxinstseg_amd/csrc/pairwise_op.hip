@@ -265,10 +265,11 @@ __global__ __launch_bounds__(256) void pairwise3_fwd_fast_kernel(const float* __
 template <typename T> struct LogTriple { T a, b, dd; };
 
 
-template <typename T>
-__global__ __launch_bounds__(256) void pairwise3_bwd_kernel(const T* __restrict__ logits, const T* __restrict__ g_pair, int H, int W, int d,
+template <typename T, int D>      // D: dilation at compile time (the staged tile's row length divides by a constant); 0 = run time
+__global__ __launch_bounds__(256) void pairwise3_bwd_kernel(const T* __restrict__ logits, const T* __restrict__ g_pair, int H, int W, int d_,
                                                             T* __restrict__ g_logits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pw_raw[];
+    const int d = D ? D : d_;
     const int PR = kPwTR + 2 * d, PC = kPwTC + 2 * d;
     const int tiles_x = (W + kPwTC - 1) / kPwTC, tiles_y = (H + kPwTR - 1) / kPwTR;
     int t = blockIdx.x;
@@ -278,22 +279,18 @@ __global__ __launch_bounds__(256) void pairwise3_bwd_kernel(const T* __restrict_
     const int64_t P = (int64_t)H * W;
     const int r0 = ty * kPwTR, c0 = tx * kPwTC;
     const T* L = logits + n * P;
-    // the tile + halo logits, all loads of a thread in flight together (out-of-map positions: 0, never used as a neighbour).
-    // A wave takes rows wave, wave + 4, ... of the staged tile, its lanes the columns in two passes (64 + 2d <= 128): no
-    // integer division in front of the loads (the address arithmetic, not the exp / log, was most of this kernel).
-    constexpr int kStageRows = (kPwTR + 2 * kPwMaxDil + 3) / 4;       // staged rows a wave may have to take
-    T xv[kStageRows][2];
+    // the tile + halo logits, element i = threadIdx + 256 e of the staged tile (row-major), all loads of a thread in flight
+    // together (out-of-map positions: 0, never used as a neighbour).  Every lane of every load is used: rows taken by waves
+    // with the columns in two passes issued half of their instructions for the 2d columns beyond 64.
+    constexpr int kMaxE = ((kPwTR + 2 * (D ? D : kPwMaxDil)) * (kPwTC + 2 * (D ? D : kPwMaxDil)) + 255) / 256;
+    T xv[kMaxE];
     bool sat = false;
-    const int swave = threadIdx.x >> 6, slane = threadIdx.x & 63;
 #pragma unroll
-    for (int e = 0; e < kStageRows; ++e) {
-        const int sr = swave + 4 * e, r = r0 - d + sr;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int sc = slane + 64 * hf, cq = c0 - d + sc;
-            xv[e][hf] = T(0);
-            if (sr < PR && sc < PC && r >= 0 && r < H && cq >= 0 && cq < W) { xv[e][hf] = L[(int64_t)r * W + cq]; sat |= !(t_abs(xv[e][hf]) <= T(34)); }
-        }
+    for (int e = 0; e < kMaxE; ++e) {
+        const int i = threadIdx.x + 256 * e;
+        const int r = r0 - d + i / PC, cq = c0 - d + i % PC;
+        xv[e] = T(0);
+        if (i < PR * PC && (unsigned)r < (unsigned)H && (unsigned)cq < (unsigned)W) { xv[e] = L[(uint32_t)(r * W + cq)]; sat |= !(t_abs(xv[e]) <= T(34)); }
     }
     const int lc = threadIdx.x & 63, lr0 = threadIdx.x >> 6;
     const int c = c0 + lc;
@@ -306,17 +303,19 @@ __global__ __launch_bounds__(256) void pairwise3_bwd_kernel(const T* __restrict_
     // (that arithmetic, ~5 instructions per load, was a quarter of the kernel).
     T G[kPwTR / 4][8];
     const int cc = min(c, W - 1);
-    const int lim = (int)(8 * P) - 1;                    // fits: the launcher checks N * 8 * P against 2^31
+    const int lim = (int)(8 * P - 1) * (int)sizeof(T);            // bytes; fits: the launcher takes this kernel only while 8 P sizeof(T) < 2^31
+    const char* gb = reinterpret_cast<const char*>(GP);             // wave-uniform base + 32-bit byte offset: no 64-bit address arithmetic per load
+    const int plane = (int)P * (int)sizeof(T);
 #pragma unroll
     for (int j = 0; j < kPwTR / 4; ++j) {
         const int r = min(r0 + lr0 + 4 * j, H - 1);
-        const int pix = r * W + cc;
+        const int pix = (r * W + cc) * (int)sizeof(T);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;
-            const int own = k * (int)P + pix;
-            const int nb = min(max((7 - k) * (int)P + (dy * d) * W + dx * d + pix, 0), lim);
-            G[j][k] = GP[own] + GP[nb];
+            const int tap = (7 - k) * plane + ((dy * d) * W + dx * d) * (int)sizeof(T);     // wave-uniform
+            const int nb = min(max(tap + pix, 0), lim);
+            G[j][k] = *reinterpret_cast<const T*>(gb + (uint32_t)(k * plane + pix)) + *reinterpret_cast<const T*>(gb + (uint32_t)nb);
         }
     }
     // (sat is known once the logit loads -- issued first -- have returned; the G loads stay in flight across the barrier)
@@ -325,15 +324,11 @@ __global__ __launch_bounds__(256) void pairwise3_bwd_kernel(const T* __restrict_
         ProbPair<T>* tile = reinterpret_cast<ProbPair<T>*>(pw_raw);
         T* slots = reinterpret_cast<T*>(pw_raw + sizeof(LogTriple<T>) * (size_t)PR * PC);     // same place in both bodies
 #pragma unroll
-        for (int e = 0; e < kStageRows; ++e) {
-            const int sr = swave + 4 * e;
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int sc = slane + 64 * hf;
-                if (sr < PR && sc < PC) {
-                    const T x = xv[e][hf], en = fast_exp_neg(t_abs(x)), big = fast_rcp(T(1) + en), small = en * big;   // sigmoid(|x|), sigmoid(-|x|)
-                    tile[sr * PC + sc] = x >= T(0) ? ProbPair<T>{big, small} : ProbPair<T>{small, big};
-                }
+        for (int e = 0; e < kMaxE; ++e) {
+            const int i = threadIdx.x + 256 * e;
+            if (i < PR * PC) {
+                const T x = xv[e], en = fast_exp_neg(t_abs(x)), big = fast_rcp(T(1) + en), small = en * big;   // sigmoid(|x|), sigmoid(-|x|)
+                tile[i] = x >= T(0) ? ProbPair<T>{big, small} : ProbPair<T>{small, big};
             }
         }
         for (int i = threadIdx.x; i < kPwTR * kPwTC * 4; i += 256) slots[i] = T(0);
@@ -370,16 +365,13 @@ __global__ __launch_bounds__(256) void pairwise3_bwd_kernel(const T* __restrict_
         LogTriple<T>* tile = reinterpret_cast<LogTriple<T>*>(pw_raw);
         T* slots = reinterpret_cast<T*>(tile + PR * PC);                     // [4][kPwTR*kPwTC]: shares deposited by earlier pixels
 #pragma unroll
-        for (int e = 0; e < kStageRows; ++e) {
-            const int sr = swave + 4 * e, r = r0 - d + sr;
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int sc = slane + 64 * hf, cq = c0 - d + sc;
-                if (sr < PR && sc < PC) {
-                    LogTriple<T> v{T(0), T(0), T(0)};
-                    if (r >= 0 && r < H && cq >= 0 && cq < W) { const T x = xv[e][hf]; v.a = logsig(x); v.b = logsig(-x); v.dd = t_exp(v.a) - t_exp(v.b); }
-                    tile[sr * PC + sc] = v;
-                }
+        for (int e = 0; e < kMaxE; ++e) {
+            const int i = threadIdx.x + 256 * e;
+            const int r = r0 - d + i / PC, cq = c0 - d + i % PC;
+            if (i < PR * PC) {
+                LogTriple<T> v{T(0), T(0), T(0)};
+                if ((unsigned)r < (unsigned)H && (unsigned)cq < (unsigned)W) { const T x = xv[e]; v.a = logsig(x); v.b = logsig(-x); v.dd = t_exp(v.a) - t_exp(v.b); }
+                tile[i] = v;
             }
         }
         for (int i = threadIdx.x; i < kPwTR * kPwTC * 4; i += 256) slots[i] = T(0);
@@ -438,16 +430,16 @@ static int launch_fwd(const T* logits, int N, int H, int W, int size, int dil, T
     if (size == 3 && dil <= kPwMaxDil) {
         const int64_t tiles = (int64_t)N * ((H + kPwTR - 1) / kPwTR) * ((W + kPwTC - 1) / kPwTC);
         if (fits_i32(tiles)) {
-            if constexpr (sizeof(T) == 4) {
+            if (sizeof(T) == 4 && (int64_t)8 * H * W * 4 < ((int64_t)1 << 31)) {      // the fast kernel addresses an instance's planes by 32-bit byte offsets
                 const dim3 g((unsigned)tiles), b(block);
                 const size_t lds = pw3_lds<T>(dil);
                 hipStream_t st = as_stream(stream);
                 switch (dil) {
-                    case 1: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<1>, g, b, lds, st, logits, H, W, dil, out); break;
-                    case 2: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<2>, g, b, lds, st, logits, H, W, dil, out); break;
-                    case 3: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<3>, g, b, lds, st, logits, H, W, dil, out); break;
-                    case 4: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<4>, g, b, lds, st, logits, H, W, dil, out); break;
-                    default: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<0>, g, b, lds, st, logits, H, W, dil, out); break;
+                    case 1: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<1>, g, b, lds, st, (const float*)logits, H, W, dil, (float*)out); break;
+                    case 2: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<2>, g, b, lds, st, (const float*)logits, H, W, dil, (float*)out); break;
+                    case 3: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<3>, g, b, lds, st, (const float*)logits, H, W, dil, (float*)out); break;
+                    case 4: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<4>, g, b, lds, st, (const float*)logits, H, W, dil, (float*)out); break;
+                    default: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<0>, g, b, lds, st, (const float*)logits, H, W, dil, (float*)out); break;
                 }
             } else
                 BXI_LAUNCH("pairwise_fwd", as_stream(stream), (pairwise3_fwd_kernel<T>), dim3((unsigned)tiles), dim3(block), pw3_lds<T>(dil),
@@ -472,16 +464,29 @@ static int launch_bwd(const T* logits, const T* g_pair, int N, int H, int W, int
     const int64_t total = (int64_t)N * H * W;
     if (!fits_i32(total * (size * size - 1 > 0 ? size * size - 1 : 1))) return BXI_ERR_BAD_SHAPE;
     const int block = 256;
-    if (size == 3 && dil <= kPwMaxDil) {
+    if (size == 3 && dil <= kPwMaxDil && (int64_t)8 * H * W * (int64_t)sizeof(T) < ((int64_t)1 << 31)) {      // the tiled kernel addresses an instance's planes by 32-bit byte offsets
         const int64_t tiles = (int64_t)N * ((H + kPwTR - 1) / kPwTR) * ((W + kPwTC - 1) / kPwTC);
         if (fits_i32(tiles)) {
-            if (pw3_bwd_lds<T>(dil) > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pairwise3_bwd_kernel<T>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pw3_bwd_lds<T>(dil));
-                if (e != hipSuccess) { set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }
+            hipStream_t st = as_stream(stream);
+            const size_t lds = pw3_bwd_lds<T>(dil);
+            const dim3 g((unsigned)tiles), b(block);
+#define BXI_PW3_BWD(DD)                                                                                                                        \
+            {                                                                                                                                  \
+                if (lds > 64 * 1024) {                                                                                                         \
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pairwise3_bwd_kernel<T, DD>),                             \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+                    if (e != hipSuccess) { set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }                                                \
+                }                                                                                                                              \
+                BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_kernel<T, DD>), g, b, lds, st, logits, g_pair, H, W, dil, g_logits);             \
             }
-            BXI_LAUNCH("pairwise_bwd", as_stream(stream), (pairwise3_bwd_kernel<T>), dim3((unsigned)tiles), dim3(block), pw3_bwd_lds<T>(dil),
-                       as_stream(stream), logits, g_pair, H, W, dil, g_logits);
+            if constexpr (sizeof(T) == 4) {
+                if (dil == 1) BXI_PW3_BWD(1)
+                else if (dil == 2) BXI_PW3_BWD(2)
+                else if (dil == 3) BXI_PW3_BWD(3)
+                else if (dil == 4) BXI_PW3_BWD(4)
+                else BXI_PW3_BWD(0)
+            } else BXI_PW3_BWD(0)
+#undef BXI_PW3_BWD
             return check_launch();
         }
     }
