@@ -18,7 +18,8 @@ TOL = 1e-4
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('dtype,tol', [(np.float32, 2e-6), (np.float64, 1e-12)])
 @pytest.mark.parametrize('shape,size,dil', [((3, 13, 17), 3, 2), ((2, 40, 24), 3, 1), ((2, 21, 33), 5, 2),
-                                            ((1, 5, 3), 3, 3), ((4, 64, 64), 3, 2)])
+                                            ((1, 5, 3), 3, 3), ((4, 64, 64), 3, 2), ((2, 30, 70), 3, 4), ((1, 37, 150), 3, 6),
+                                            ((1, 19, 130), 3, 2), ((2, 16, 64), 3, 8)])
 def test_pairwise_op(dev, dtype, tol, shape, size, dil):
     from boxinstseg_amd import pairwise_nlog
     from oracle import c_oracle
