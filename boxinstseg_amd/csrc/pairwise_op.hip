@@ -6,7 +6,7 @@
 // Roofline: HBM.  Forward moves 4*(1+K) B per pixel (K = size^2-1 output planes, write-bound);
 // backward 4*(1+K+1) B per pixel (g_pairwise read once through L2: every element is used by the
 // pixel itself (channel k) and by one neighbour (channel K-1-k)).  size == 3 runs the tiled kernels
-// further down (20.6 us / 26.5 us at 32x200x256 f32); the two kernels below serve the other window sizes.
+// further down (13.1 us / 20.7 us at 32x200x256 f32); the two kernels below serve the other window sizes.
 #include "common.hpp"
 
 namespace bxi {
