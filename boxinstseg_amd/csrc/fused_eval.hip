@@ -84,8 +84,8 @@ struct EvalWs {                                 // carved from the caller's work
     unsigned int* expect;                       // [N]  tiles of the instance
     // words polled inside pair_kernel; zeroed by prep_kernel's table waves (i.e. before a kernel boundary)
     unsigned long long* acc1;                   // [kAcc1Words] (one per 128 B)  count waves : arrivals << 40 | sum W; all words together: every tile, the whole sum
-    unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B)  math waves + leader : arrivals << 52 | sum (W pw + 1) in 2^-24 units
-    float* dice;                                // [N]
+    unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B)  math waves : arrivals << 52 | sum (W pw + 1) in 2^-24 units
+    unsigned long long* dice;                   // [N] leader : 1 << 32 | bits of the instance's dice loss (0 = not published; zeroed by the table waves)
 };
 
 static inline int tile_width(int dil) { return 64 - 2 * dil; }
@@ -111,7 +111,7 @@ static size_t carve_eval(void* base, int N, int h, int w, EvalWs* ws) {
     t.expect = (unsigned int*)take(4 * (size_t)N1);
     t.acc1 = (unsigned long long*)take(8 * (size_t)kAcc1Words * kAcc2Stride);
     t.acc2 = (unsigned long long*)take(8 * (size_t)N1 * kAcc2Split * kAcc2Stride);
-    t.dice = (float*)take(4 * (size_t)N1);
+    t.dice = (unsigned long long*)take(8 * (size_t)N1);
     if (ws) *ws = t;
     return off;
 }
@@ -188,6 +188,7 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
     }
     if (n == 0) ws.acc1[lane * kAcc2Stride] = 0ull;
     if (lane < kAcc2Split) *acc2_word(ws.acc2, n, lane) = 0ull;
+    if (lane == 0) ws.dice[n] = 0ull;
     if (st.colk) {      // "not published yet" (the leaders of the next launch publish; its math waves poll)
         for (int i = lane; i < a.w; i += 64) st.colk[(int64_t)n * a.w + i] = kGranuleInvalid;
         for (int i = lane; i < a.h; i += 64) st.rowk[(int64_t)n * a.h + i] = kGranuleInvalid;
@@ -683,37 +684,35 @@ __device__ __forceinline__ bool counts_complete(const EvalWs& ws, int nwork, dou
     return arrived == (double)nwork;
 }
 
-// sum W over all instances, once every count wave has arrived.  Returns false on a time-out (never expected).
-__device__ __forceinline__ bool total_weight(const EvalWs& ws, int nwork, double* total) {
-    for (unsigned spins = 0;; ++spins) {
-        if (counts_complete(ws, nwork, total)) return true;
-        if (spins > kSpinLimit) return false;
-        __builtin_amdgcn_s_sleep(8);
+// The finisher's round: everything the two loss values are made of, requested together -- the tile arrivals and sums W pw
+// (8 words per instance, arrival count and sum in one word), the dice granules, the count words -- so that the round in
+// which everything turns out to be complete is also the round that delivers the data (three dependent rounds past the
+// caches, ~1 us each, used to follow the last tile's arrival: check, sum W, then the sums again; the launch ends on them).
+// Instances [b0, b0 + 64).  Returns whether all of them are complete; adds their sums.
+__device__ __forceinline__ bool finisher_round(const EvalWs& ws, int N, int b0, unsigned int expect, double* num, float* dsum) {
+    const int lane = threadIdx.x & 63, i = b0 + lane;
+    unsigned long long x = 0ull, dg = 1ull << 32;
+    if (i < N) {
+        unsigned long long w[kAcc2Split];
+#pragma unroll
+        for (int sub = 0; sub < kAcc2Split; ++sub) w[sub] = __hip_atomic_load(acc2_word(ws.acc2, i, sub), BXI_RLX, BXI_AGENT);
+        dg = __hip_atomic_load(&ws.dice[i], BXI_RLX, BXI_AGENT);
+#pragma unroll
+        for (int sub = 0; sub < kAcc2Split; ++sub) x += w[sub];
     }
+    const bool have = i >= N || ((unsigned int)(x >> 52) == expect && (dg >> 32) != 0ull);
+    if (!__all(have)) return false;
+    const long long fixed = (long long)(x & ((1ull << 52) - 1ull)) - ((long long)expect << 24);   // the +1 per tile
+    *num += wave_total_f64(i < N ? (double)fixed : 0.0);
+    const float dv = i < N ? __uint_as_float((unsigned int)dg) : 0.f;
+    const int m = min(64, N - b0);
+    for (int k = 0; k < m; ++k) *dsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), k));   // index order
+    return true;
 }
 
-// Last arrival of the launch (a math wave or a leader): loss_prj, loss_pairwise, the record of what was applied.
-__device__ __forceinline__ void finish_losses(const EvalWs& ws, const LossState& st, int N, float warmup, double total_w,
-                                              float upp, float upw, float* __restrict__ losses) {
-    const int lane = threadIdx.x & 63;
-    double num = 0.0;
-    float dsum = 0.f;
-    for (int b0 = 0; b0 < N; b0 += 64) {
-        const int i = b0 + lane;
-        double v = 0.0; float dv = 0.f;
-        if (i < N) {
-            unsigned long long x = 0ull;
-#pragma unroll
-            for (int sub = 0; sub < kAcc2Split; ++sub) x += __hip_atomic_load(acc2_word(ws.acc2, i, sub), BXI_RLX, BXI_AGENT);
-            const long long fixed = (long long)(x & ((1ull << 52) - 1ull)) - ((long long)ws.expect[i] << 24);   // the +1 per tile
-            v = (double)fixed;
-            dv = __hip_atomic_load(&ws.dice[i], BXI_RLX, BXI_AGENT);
-        }
-        num += wave_total_f64(v);
-        const int m = min(64, N - b0);
-        for (int k = 0; k < m; ++k) dsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), k));   // index order
-    }
-    if (lane == 0) {
+__device__ __forceinline__ void write_losses(const LossState& st, int N, float warmup, double total_w, double num, float dsum,
+                                             float upp, float upw, float* __restrict__ losses) {
+    if ((threadIdx.x & 63) == 0) {
         const float denom = fmaxf((float)total_w, 1.f);                      // weights.sum().clamp(min=1.0), :1328
         losses[0] = dsum / (float)N;                                         // .mean(), :143
         losses[1] = (float)((num / (double)kNumScale) / (double)denom) * warmup;   // :1327-1332
@@ -935,7 +934,8 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, int R, 
     BXI_TW(3, n, 2);
     const float Ix = sums[0], Ux = sums[1] + 1e-5f, Iy = sums[2], Uy = sums[3] + 1e-5f;
     if (tid == 0)   // :130, summed over both axes :143
-        __hip_atomic_store(&ws.dice[n], (1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy), BXI_RLX, BXI_AGENT);
+        __hip_atomic_store(&ws.dice[n], (1ull << 32) | (unsigned long long)__float_as_uint((1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy)),
+                           BXI_RLX, BXI_AGENT);       // the datum is its own flag
     if (g_logits) {
         // dice = 1 - 2I/U ; d dice/d u_j = (-2 t_j U + 4 I u_j) / U^2 ; chain through sigmoid ; mean over N
         const float invN = 1.f / (float)a.N;
@@ -977,7 +977,6 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, int R, 
             if (!in_t && carg[c] != r) G[(int64_t)r * w + c] = ys[r] * upp;
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // dice[n] is performed before this workgroup's arrival is counted
 }
 
 // grid: [N leader blocks][n_cb count blocks][n_cb math blocks][finisher]; a count / math block = 4 independent tile waves
@@ -997,8 +996,6 @@ __global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair_kernel(const WorkR
         BXI_TW(3, blk, 0);
         leader_block(a, dil, R, ws, st, blk, upp, g_logits, smem, red);
         BXI_TW(3, blk, 4);
-        if (threadIdx.x == 0)                                          // dice[n] is performed (drained in leader_block)
-            __hip_atomic_fetch_add(acc2_word(ws.acc2, blk, 0), 1ull << 52, BXI_RLX, BXI_AGENT);
         BXI_TW(3, blk, 5);
         return;
     }
@@ -1006,26 +1003,20 @@ __global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair_kernel(const WorkR
         if (threadIdx.x >= 64) return;
         // every leader and tile wave precedes this block in the grid and none of them waits for it
         const int lane = threadIdx.x;
+        const int nwork = *nwork_p;
         bool ok = false;
+        double total_w = 0.0, num = 0.0;
+        float dsum = 0.f;
         for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {
-            bool have = true;
-            for (int b0 = 0; b0 < a.N; b0 += 64) {
-                const int i = b0 + lane;
-                if (i < a.N) {
-                    unsigned int arrived = 0u;
-#pragma unroll
-                    for (int sub = 0; sub < kAcc2Split; ++sub)
-                        arrived += (unsigned int)(__hip_atomic_load(acc2_word(ws.acc2, i, sub), BXI_RLX, BXI_AGENT) >> 52);
-                    have &= arrived == ws.expect[i] + 1u;
-                }
-            }
-            if (__all(have)) { ok = true; break; }
-            __builtin_amdgcn_s_sleep(16);
+            num = 0.0; dsum = 0.f;
+            bool all = counts_complete(ws, nwork, &total_w);            // issued with the first pass's loads, used after them
+            for (int b0 = 0; b0 < a.N && all; b0 += 64)                    // (> 64 instances: the passes follow one another)
+                all = finisher_round(ws, a.N, b0, b0 + lane < a.N ? ws.expect[b0 + lane] : 0u, &num, &dsum) && all;
+            if (all) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(2);
         }
-        double total_w = 0.0;
-        ok = total_weight(ws, *nwork_p, &total_w) && ok;
         if (!ok && lane == 0 && st.status) atomicOr(st.status, 2);
-        finish_losses(ws, st, a.N, warmup, total_w, upp, upw, losses);
+        write_losses(st, a.N, warmup, total_w, num, dsum, upp, upw, losses);
         return;
     }
     const int nwork = *nwork_p;

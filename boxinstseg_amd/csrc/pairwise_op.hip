@@ -163,7 +163,6 @@ __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
 // exp(-a), a >= 0: v_exp_f32 (2^x, ~1 ulp) on a * log2(e) -- the staged probabilities need 1e-6, not the last bit
 __device__ __forceinline__ float fast_exp_neg(float a) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * a); }
 __device__ __forceinline__ double fast_exp_neg(double a) { return exp(-a); }
-constexpr int kPwStageRows = (kPwTR + 2 * kPwMaxDil + 3) / 4;       // staged rows a wave may have to take
 
 template <typename T>
 __global__ __launch_bounds__(256) void pairwise3_fwd_kernel(const T* __restrict__ logits, int H, int W, int d, T* __restrict__ out) {
