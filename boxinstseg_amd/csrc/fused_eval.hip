@@ -540,11 +540,12 @@ __device__ __forceinline__ void dir_masks(const TileFlags& f, DirMasks (&m)[4]) 
 template <int D, int R>
 __device__ __forceinline__ void load_plane(const float* __restrict__ plane, const WorkRec2& wr, int h, int w, int lane,
                                            float (&v)[R + 2 * D]) {
-    const uint32_t cc = (uint32_t)min(max(wr.tile_c0 - D + lane, 0), w - 1);
-#pragma unroll
+    const uint32_t cc4 = (uint32_t)min(max(wr.tile_c0 - D + lane, 0), w - 1) * 4u;
+    const char* pb = reinterpret_cast<const char*>(plane);                       // scalar (the record is): base + 32-bit byte offset,
+#pragma unroll                                                                   // no 64-bit address arithmetic per load (one plane < 2^31 bytes)
     for (int j = 0; j < R + 2 * D; ++j) {
         const uint32_t rr = (uint32_t)min(max(wr.tile_r0 - D + j, 0), h - 1);       // clamped: pairs with a pixel outside the map weigh 0
-        v[j] = plane[rr * (uint32_t)w + cc];       // uniform base + 32-bit offset (one plane < 2^31 elements)
+        v[j] = *reinterpret_cast<const float*>(pb + (rr * (uint32_t)w * 4u + cc4));
     }
 }
 
@@ -819,7 +820,12 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
     // ---- epilogue: one round of polls for everything the stores need, the arrival issued before and consumed after them ----
     BXI_TW(1, tix, 3);
     num = wave_total_f32(num);
-    const long long fx = (long long)(num * kNumScale) + (1ll << 24);     // + 1.0: keeps the packed field non-negative
+    long long fx = (long long)(num * kNumScale) + (1ll << 24);           // + 1.0: keeps the packed field non-negative
+    {   // converted here, under the polls' latency, not between the stores and the arrival (the compiler sinks it there: lane 0 only)
+        int lo = (int)(fx & 0xffffffffll), hi = (int)(fx >> 32);
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        fx = ((long long)hi << 32) | (long long)(unsigned int)lo;
+    }
     const int c = wr.tile_c0 - D + lane;
     const bool col_owned = g_logits && lane >= D && lane < 64 - D && c < wr.hc1;
     const bool row_lane = g_logits && lane < R && wr.tile_r0 + lane < h;
@@ -850,7 +856,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
         const int rarg_l = row_lane ? (int)(unsigned int)rk : -1;
         const float gr_l = __uint_as_float((unsigned int)(rk >> 32));
         const float scale = upw * (warmup / fmaxf((float)total_w, 1.f));
-        float* G = g_logits + (int64_t)n * P;
+        char* G = reinterpret_cast<char*>(g_logits + (int64_t)n * P);      // scalar base + 32-bit byte offset
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int r = wr.tile_r0 + j;
@@ -860,7 +866,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
                 float sp = 0.f;
                 if (carg == r) sp += gc;
                 if (ra == c) sp += gr;
-                G[(int64_t)r * w + c] = g[j] * scale + sp * upp;
+                *reinterpret_cast<float*>(G + (uint32_t)(r * w + c) * 4u) = g[j] * scale + sp * upp;
             }
         }
     }
@@ -1031,7 +1037,14 @@ __global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair_kernel(const WorkR
     double total_w = 0.0;
     bool have_total = false;
     for (int wi = first; wi < nwork; wi += stride_w) {
-        const WorkRec2 wr = work[wi];
+        WorkRec2 wr = work[wi];
+        // the record is the same in every lane: as scalars, the instance's planes become scalar bases and the tile's 32 loads take
+        // (scalar base + one shared 32-bit lane offset per row) instead of a 64-bit address computed per load
+#define BXI_SC(f) wr.f = __builtin_amdgcn_readfirstlane(wr.f)
+        BXI_SC(r0); BXI_SC(r1); BXI_SC(c0); BXI_SC(c1); BXI_SC(img); BXI_SC(n); BXI_SC(tile_r0); BXI_SC(tile_c0);
+        BXI_SC(zero_bit); BXI_SC(vr); BXI_SC(vc); BXI_SC(hc1);
+#undef BXI_SC
+        wr.n2max = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wr.n2max)));
         if (counting) count_tile<D, R>(a, lab, ws, wr, tix);
         else math_tile<D, R>(a, lab, ws, st, wr, warmup, upp, upw, losses, g_logits, gbuf, total_w, have_total, nwork, tix);
     }
