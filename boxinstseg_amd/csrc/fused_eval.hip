@@ -17,15 +17,17 @@
 //                   wave-load), de-normalises 12 values; the 4x4 sums meet in LDS, then three waves take one CIE
 //                   channel each (fp64) -> Lab f32.  Four times more, four times lighter waves than one lane per
 //                   pooled pixel: their arithmetic overlaps the other waves' loads (tools/micro/dispatch.hip, D).
-//   pair_kernel   256-thread workgroups, three roles, dispatched in this order
+//   pair_kernel   256-thread workgroups, three roles + a one-wave finisher, dispatched in this order
 //     leaders       one per instance: column partials -> maxima -> sigmoid -> dice -> unit projection gradients
-//                   (published write-through + one flag), projection gradient at the arg-max positions outside the tiles
+//                   (published as self-flagging 8-byte granules, like its dice loss), projection gradient at the arg-max
+//                   positions outside the tiles
 //     count waves   one per box tile: sum of the pair weights W from Lab alone -> one packed atomic per tile
 //     math waves    one per box tile (wave64, no LDS, no barrier): the tile + halo lives in registers, a lane owns a
 //                   column; every unordered pair is evaluated ONCE and feeds both of its pixels (neighbour columns by
 //                   cross-lane moves); then reads sum W (complete: the count waves precede the math waves in the
 //                   grid, so nothing waits for a workgroup that may not have been dispatched), the leader's
 //                   coefficients, and stores  g = g_pw * warm/max(sum W,1) * d pw + g_prj * d prj.
+//     finisher      last block: one round of polls delivers both the completion check and the data of the two loss values
 // Data layout in HBM: everything NCHW / row-major as the reference hands it over; Lab [B,3,h,w] f32 is the only
 // materialised intermediate (1.2 MB at 2x800x1024).
 #include "loss_common.hpp"
