@@ -5,7 +5,7 @@
 //   sol_pair : read the box tiles' logits + 3 Lab planes with their halo (611 tiles x 12 rows x 64 columns x 4 planes = 7.5 MB),
 //              write the gradient tiles (611 x 8 x 60 x 4 B = 1.2 MB)
 // 8 input sets are rotated (312 MB > the 256 MB Infinity Cache), as bench.py does.  Printed: us per launch pair, each launch
-// alone, and two empty launches -- the floor the real kernels (9.3 + 14.4 us) are to be read against.
+// alone, and two empty launches -- the floor the real kernels (9.3 + 9.9 us at the end of round 2) are to be read against.
 // Build: hipcc --offload-arch=gfx950 -O3 -o sol_eval sol_eval.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
