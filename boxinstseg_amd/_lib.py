@@ -13,7 +13,7 @@ from . import build as _build
 c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
 BXI_MAX_IMAGES = 64
-BXI_ABI_VERSION = 2
+BXI_ABI_VERSION = 3
 
 STATUS = {0: 'BXI_OK', -1: 'BXI_ERR_NULL_POINTER', -2: 'BXI_ERR_BAD_SHAPE', -3: 'BXI_ERR_BAD_ARGUMENT',
           -4: 'BXI_ERR_UNSUPPORTED', -5: 'BXI_ERR_WORKSPACE', -6: 'BXI_ERR_LAUNCH', -7: 'BXI_ERR_NO_DEVICE'}
@@ -62,6 +62,7 @@ SIGNATURES = {
     'bxi_boxinst_loss_backward_f32': (c_int, [C.POINTER(Instances), c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                              c_void_p]),
     'bxi_boxinst_eval_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    'bxi_boxinst_eval_workspace_init': (c_int, [c_void_p, c_size_t, c_void_p]),
     'bxi_boxinst_eval_f32': (c_int, [C.POINTER(ImageBatch), C.POINTER(Instances), c_int, c_int, c_float, c_float,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'bxi_boxinst_head_eval_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -1,6 +1,7 @@
 // abi.hip -- library-level entry points of libboxinst_hip.so (see include/boxinst_hip.h).
 #include "common.hpp"
 #include "dynamic_head_device.hpp"
+#include <cstdlib>
 
 namespace bxi {
 
@@ -18,7 +19,18 @@ int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thre
 int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits,
                    void* stream);
 
+size_t eval3_ws_bytes(int B, int N, int h, int w);
+size_t eval3_sync_bytes();
+bool eval3_supported(int dil);
+int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_instances* in, int dil, float warmup, const float* up_prj,
+                 const float* up_pw, float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, int force_rows,
+                 void* stream, const DynArgs* head = nullptr, int head_C = 0);
+int launch_rescale3(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits, void* stream);
+int eval3_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
+
 static inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+// developer switch for A/B runs on one box: BXI_EVAL_V2=1 takes the round-2 kernels (fused_eval.hip)
+static bool use_v2() { static const bool v = [] { const char* e = getenv("BXI_EVAL_V2"); return e && e[0] == '1'; }(); return v; }
 
 }  // namespace bxi
 
@@ -67,7 +79,12 @@ size_t bxi_boxinst_eval_workspace_bytes(int B, int Hc, int Wc, int stride, int N
     const int h = Hc / stride, w = Wc / stride;
     if (h <= 0 || w <= 0) return 0;
     const size_t P = (size_t)h * w;
-    return bxi::up256(sizeof(float) * (size_t)B * 3 * P) + bxi::eval_ws_bytes(N, h, w);
+    const size_t v2 = bxi::up256(sizeof(float) * (size_t)B * 3 * P) + bxi::eval_ws_bytes(N, h, w), v3 = bxi::eval3_ws_bytes(B, N, h, w);
+    return v2 > v3 ? v2 : v3;
+}
+
+int bxi_boxinst_eval_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    return bxi::eval3_workspace_init(workspace, workspace_bytes, stream);
 }
 
 int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host, int size, int dilation,
@@ -84,6 +101,9 @@ int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances*
                                                          inst_host->N);
     if (!workspace || need == 0 || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255))
         return BXI_ERR_WORKSPACE;
+    if (!bxi::use_v2())
+        return bxi::launch_eval3(batch_host, color_thresh, inst_host, dilation, warmup, up_prj, up_pw, losses, g_logits, state, workspace,
+                                 workspace_bytes, 0, stream);
     const size_t P = (size_t)inst_host->h * inst_host->w;
     char* base = (char*)workspace;
     float* lab = (float*)base;
@@ -111,6 +131,9 @@ int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_insta
     if (rc != BXI_OK) return rc;
     const size_t need = bxi_boxinst_eval_workspace_bytes(batch_host->B, batch_host->Hc, batch_host->Wc, stride, inst_host->N);
     if (!workspace || need == 0 || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
+    if (!bxi::use_v2())
+        return bxi::launch_eval3(batch_host, color_thresh, inst_host, dilation, warmup, up_prj, up_pw, losses, g_logits, state, workspace,
+                                 workspace_bytes, 0, stream, &da, C);
     const size_t P = (size_t)inst_host->h * inst_host->w;
     char* base = (char*)workspace;
     float* lab = (float*)base;
@@ -121,6 +144,7 @@ int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_insta
 
 int bxi_boxinst_grad_rescale_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw, int dilation,
                                  const void* state, float* g_logits, void* stream) {
+    if (!bxi::use_v2()) return bxi::launch_rescale3(inst_host, g_prj, g_pw, dilation, state, g_logits, stream);
     return bxi::launch_rescale(inst_host, g_prj, g_pw, dilation, state, g_logits, stream);
 }
 

@@ -154,6 +154,24 @@ __device__ __forceinline__ int wave_sum_i32(int v) { return wave_total_i32(v); }
 // wave's outstanding global stores (vmcnt), so zero-fill / output stores stay in flight across it.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- stores that are written through to memory as they are issued (sc1 = agent scope) --------------------------------
+// Used (a) for bulk output that should drain while the launch is still reading instead of in a burst at the kernel
+// boundary, and (b) for data another workgroup of the SAME launch reads after an arrival counter (MI355X_MICROARCH.md,
+// "inter-workgroup visibility", form R1: sc1 payload -> s_waitcnt vmcnt(0) -> agent-scope atomic).  16-byte forms: a narrower
+// sc1 store is one fabric write per lane.  The asm forms are invisible to the compiler's vmcnt bookkeeping: callers drain
+// with drain_vmem() before they publish.
+__device__ __forceinline__ void store4_through(float* p, float x, float y, float z, float w) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v v = {x, y, z, w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_u64x2_through(unsigned long long* p, unsigned long long a, unsigned long long b) {
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const u4v v = {(unsigned int)a, (unsigned int)(a >> 32), (unsigned int)b, (unsigned int)(b >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // python slice [a:b] on an axis of length n -> [lo,hi)   (condinst_head.py:1429-1430)
 __device__ __forceinline__ void py_slice(int a, int b, int n, int& lo, int& hi) {
     if (a < 0) a += n;

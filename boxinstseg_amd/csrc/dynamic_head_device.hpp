@@ -147,6 +147,8 @@ struct DynEpi {
     unsigned long long* rowpart;    // [N][n_rp][OH]   n_rp = tiles in x
     float* g_zero;                  // [N][OH][OW] or nullptr
     int n_cb, n_rp;
+    int through;                    // 1: partials and the zero tile are written through (sc1): a workgroup of the SAME launch reads
+                                    //    them after an arrival counter (eval3.hip: the instance's last tile is its leader)
 };
 
 // One workgroup: y on an 8 x 32 tile (+ 1 halo) of instance n, up-sampled to the logits tile.  Thread t evaluates pixels 2t and
@@ -220,21 +222,28 @@ __device__ __forceinline__ void dyn_tile_forward(const DynArgs& a, const float* 
             const bool ok = R < OH && c < OW;
             const float v = ok ? otile[lr * TW + lane] : -INFINITY;
             const unsigned long long rk = wave_max_u64(ok ? pack_max(v, (uint32_t)c) : 0ull);      // larger value, then smaller column
-            if (lane == 0 && R < OH) ep.rowpart[((int64_t)n * ep.n_rp + tx) * OH + R] = rk;
+            if (lane == 0 && R < OH) {
+                unsigned long long* dst = ep.rowpart + ((int64_t)n * ep.n_rp + tx) * OH + R;
+                if (ep.through) __hip_atomic_store(dst, rk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = rk;
+            }
             const unsigned long long k = ok ? pack_max(v, (uint32_t)R) : 0ull;                      // larger value, then smaller row
             ck = k > ck ? k : ck;
         }
         ckeys[wv * TW + lane] = ck;
         if (ep.g_zero) {                                                                            // the tile of d loss / d logits
             const int zr = R0 + tid / (TW / 4), zc = C0 + (tid % (TW / 4)) * 4;
-            if (zr < OH && zc < OW) *reinterpret_cast<float4*>(ep.g_zero + ((int64_t)n * OH + zr) * OW + zc) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (zr < OH && zc < OW) {
+                float* dst = ep.g_zero + ((int64_t)n * OH + zr) * OW + zc;
+                if (ep.through) store4_through(dst, 0.f, 0.f, 0.f, 0.f); else *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         __syncthreads();
         if (wv == 0 && c < OW) {
             unsigned long long k = ckeys[lane];
 #pragma unroll
             for (int u = 1; u < 4; ++u) { const unsigned long long o = ckeys[u * TW + lane]; k = o > k ? o : k; }
-            ep.colpart[((int64_t)n * ep.n_cb + ty) * OW + c] = k;
+            unsigned long long* dst = ep.colpart + ((int64_t)n * ep.n_cb + ty) * OW + c;
+            if (ep.through) __hip_atomic_store(dst, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = k;
         }
     }
 }

@@ -1,0 +1,1387 @@
+// eval3.hip -- the BoxInst loss evaluation (forward AND finished backward) in TWO launches on gfx950, with NO workgroup ever
+// waiting for another one.
+//
+// Replaces (reference, LiWentomng/BoxInstSeg) CondInstMaskHead.loss with boxinst_enabled,
+// condinst_head.py:1288-1343, together with everything it calls:
+//   get_targets / get_original_image / get_bitmasks_from_boxes   :170-186, :1345-1448   (image side)
+//   get_image_color_similarity + unfold_wo_center                :190-246
+//   compute_project_term + dice_coefficient                      :117-143
+//   pairwise_nlog (CUDA op, pairwise.cu:68-149) + weights / normalise / warm-up   :1315-1332
+// and what autograd does behind them, with the upstream factors folded in.
+//
+// Everything the second launch needs is FINISHED by the first one, so its tile waves read plain post-boundary data:
+//   launch 1  prep3_kernel   256-thread workgroups, three roles                                          HBM stream
+//     table waves   per-instance table (tile prefix, box cells, image, valid-cell limits): 16 bytes per instance
+//     pool blocks   the 4 input rows of 64 pooled pixels -> de-normalise, truncate, 4x4 mean, Lab (fp64) -> one 16-byte
+//                   write-through store per pooled pixel; then each of the block's 4 waves ARRIVES on one of the (up to) four
+//                   row segments whose colour pairs this segment completes; the wave whose arrival is the last one evaluates
+//                   that segment: the four colour predicates per pixel (one byte) and the segment's share of the pair-weight
+//                   normaliser  sum W  (a function of the image and the boxes only, :1324-1328) -> integer atomics.
+//     stream blocks 4 waves x 8 rows of one instance map: zero-fill of g_logits, row maxima, column maxima of the block's
+//                   32 rows -> partials (write-through); the block whose arrival is the instance's last one is its LEADER:
+//                   maxima -> sigmoid -> dice -> unit projection gradients, the arg-max positions outside the box tiles.
+//   launch 2  pair3_kernel   one wave64 per box tile (no LDS, no barrier, no wait): logits tile + halo in registers, every
+//                   unordered pair evaluated once, gradient stored finished:  g = g_pw warm/max(sum W,1) d pw + g_prj d prj;
+//                   its share of sum W pw goes to an integer accumulator by an atomic without return.
+//     finisher      the last workgroup: polls the accumulators (bounded), writes the two loss values -- NaN and a status word
+//                   when anything in either launch was inconsistent -- and leaves every counter zero for the next evaluation.
+// "Last arrival continues" needs no forward-progress assumption: nobody spins on anybody (the finisher waits for workgroups
+// that never wait, whatever the dispatch order).  The counters live in a fixed region at the start of the workspace that
+// is zero between evaluations (bxi_boxinst_eval_workspace_init once, then every evaluation cleans up after itself).
+// Data layout in HBM: everything NCHW / row-major as the reference hands it over; intermediates: Lab [B,h,w] float4 (1.6 MB at
+// 2x800x1024), predicate bytes [B,h,w], column / row partial maxima, 16-byte table entries.
+#include "loss_common.hpp"
+#include "dynamic_head_device.hpp"
+#include <atomic>
+#include <cstdlib>
+
+namespace bxi {
+namespace v3 {
+
+constexpr int kWaves = 4;                       // waves per workgroup in both launches
+constexpr int kSRows = 8;                       // rows per stream wave
+constexpr int kSBlk = kWaves * kSRows;          // rows per stream workgroup
+constexpr int kChunkC = 256;                    // columns per pass of a stream wave: 64 lanes x float4
+constexpr int kMaxDilFused = 4;
+constexpr unsigned kSpinLimit = 400000;         // finisher polls (~0.5 us each): far beyond any launch
+constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
+constexpr int kSumWords = 64;                   // sum W: 64 words, each in its own 128 bytes
+constexpr int kMaxItems = 1 << 18;              // pooled row segments per batch the fixed counter region covers
+constexpr int kMaxInst = 65536;
+constexpr int kRectCap = 256;                   // instance rectangles staged in LDS by a pool block
+constexpr unsigned kFaultFinisher = 2u, kFaultItemCount = 4u, kFaultInstCount = 8u;
+
+#ifdef BXI_TRACE
+#define BXI_TW(kid, idx, ph)                                                                                  \
+    do {                                                                                                      \
+        if ((threadIdx.x & 63) == 0 && g_trace && (idx) >= 0 && (idx) < ::bxi::kTraceBlocks)                  \
+            g_trace[((size_t)(kid) * ::bxi::kTraceBlocks + (idx)) * ::bxi::kTracePhases + (ph)] = wall_clock64(); \
+    } while (0)
+#else
+#define BXI_TW(kid, idx, ph) do {} while (0)
+#endif
+
+#define BXI_RLX __ATOMIC_RELAXED
+#define BXI_AGENT __HIP_MEMORY_SCOPE_AGENT
+
+// ---- workspace ---------------------------------------------------------------------------------------------------------
+// [sync region: zero between evaluations][Lab][predicate bytes][partials][table][accumulators]
+constexpr size_t kSyncFault = 0, kSyncSumw = 256, kSyncInst = kSyncSumw + (size_t)kSumWords * 128,
+                 kSyncItem = kSyncInst + 4 * (size_t)kMaxInst, kSyncBytes = kSyncItem + 4 * (size_t)kMaxItems;
+
+struct Ws {
+    unsigned int* fault;                        // [1]   bit mask of protocol inconsistencies seen by launch 1 (never expected)
+    unsigned long long* sumw;                   // [kSumWords] (one per 128 B) sum W, added by the pool blocks' segment tasks
+    unsigned int* inst_cnt;                     // [N]   stream-block arrivals of the instance
+    unsigned int* item_cnt;                     // [B*h*segs] arrivals on a pooled row segment
+    float4* lab4;                               // [B,h,w] (L, a, b, 0)
+    unsigned char* pred;                        // [B,h,w] bit d = colour predicate of pair direction d with this pixel as (i, l)
+    float* lab_planar;                          // [B,3,h,w] only the generic pooling path (other strides, unaligned canvases) fills it
+    unsigned long long* colpart;                // [N,n_cb,w] packed (max logit, first row) of a band of rows
+    unsigned long long* rowkey;                 // [N,n_rp,h] packed (max logit, first column)
+    int n_cb, n_rp;
+    int4* tab;                                  // [N+1] {tile prefix | img << 24, r0 | r1 << 16, c0 | c1 << 16, vrow | vcol << 16}; [N].x = tiles
+    int4* hdr;                                  // [1]   {bits of n2max, zero_bit, R, 0}
+    unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B) arrivals << 52 | sum (W pw + 1) in 2^-24 units
+    float* dice;                                // [N]   dice loss of the instance (both axes)
+};
+
+__device__ __forceinline__ unsigned long long* acc2_word(unsigned long long* acc2, int n, int sub) {
+    return acc2 + ((size_t)n * kAcc2Split + (sub & (kAcc2Split - 1))) * kAcc2Stride;
+}
+
+static inline int tile_width(int dil) { return 64 - 2 * dil; }
+static inline int64_t eval_cap(int N, int h, int w, int dil, int R) {
+    const int tw = tile_width(dil);
+    return (int64_t)(N > 0 ? N : 1) * ((h + R - 1) / R) * ((w + tw - 1) / tw);
+}
+
+// LDS of the leader: [w] + [h] floats, [w] + [h] ints, then 16 floats + a flag word of scratch
+__host__ __device__ inline size_t leader_bytes(int h, int w) { return ((2 * sizeof(float) * (size_t)(h + w)) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t stream_red_off(int h, int w) {      // a stream block's scratch: behind its column buffer AND the leader's arrays
+    const size_t a = 8 * (size_t)kWaves * w, b = leader_bytes(h, w);
+    return a > b ? a : b;
+}
+
+static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
+    const int N1 = N > 0 ? N : 1;
+    const size_t Sn = (size_t)(h + kSBlk - 1) / kSBlk;
+    const size_t cb_max = (size_t)(h + kYR * 2 - 1) / (kYR * 2), rp_max = (size_t)(w + kYC * 2 - 1) / (kYC * 2);   // the head-fused launch's tiles
+    size_t off = 0;
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return p ? p + o : nullptr; };
+    Ws t;
+    char* sync = (char*)take(kSyncBytes);
+    t.fault = (unsigned int*)(sync ? sync + kSyncFault : nullptr);
+    t.sumw = (unsigned long long*)(sync ? sync + kSyncSumw : nullptr);
+    t.inst_cnt = (unsigned int*)(sync ? sync + kSyncInst : nullptr);
+    t.item_cnt = (unsigned int*)(sync ? sync + kSyncItem : nullptr);
+    const size_t P = (size_t)h * w, B1 = B > 0 ? B : 1;
+    t.lab4 = (float4*)take(16 * B1 * P);
+    t.pred = (unsigned char*)take(B1 * P);
+    t.lab_planar = (float*)take(12 * B1 * P);
+    t.colpart = (unsigned long long*)take(8 * (size_t)N1 * (cb_max > Sn ? cb_max : Sn) * w);
+    t.rowkey = (unsigned long long*)take(8 * (size_t)N1 * h * (rp_max > 1 ? rp_max : 1));
+    t.n_cb = (int)Sn; t.n_rp = 1;
+    t.tab = (int4*)take(16 * (size_t)(N1 + 1));
+    t.hdr = (int4*)take(16);
+    t.acc2 = (unsigned long long*)take(8 * (size_t)N1 * kAcc2Split * kAcc2Stride);
+    t.dice = (float*)take(4 * (size_t)N1);
+    if (ws) *ws = t;
+    return off;
+}
+
+// ================================================================================================
+// launch 1
+// ================================================================================================
+// ---- role 1: table waves (one wave per 64 table entries) --------------------------------------------------------------
+struct LaneBox { int r0, r1, c0, c1, img, cnt, vrow, vcol; };
+__device__ __forceinline__ int valid_cells(int limit_px, int stride, int n) {     // cells r with r*stride + stride/2 < limit_px
+    const int half = stride / 2;
+    const int v = limit_px - half <= 0 ? 0 : (limit_px - half + stride - 1) / stride;
+    return min(v, n);
+}
+__device__ __forceinline__ LaneBox lane_box(const InstArgs& a, const ImageMeta& meta, int dil, int R, int m) {
+    LaneBox lb = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int64_t g = a.gt_inds[m];
+    const float* bp = nullptr;
+    int ih = 0, iw = 0, fr = 0;
+    for (int b = 0; b < a.gt.B; ++b)      // uniform loop: the by-value kernel arguments are never indexed per lane
+        if (g >= a.gt.first[b] && g < a.gt.first[b + 1]) {
+            bp = a.gt.boxes[b] + 4 * (g - a.gt.first[b]); lb.img = b;
+            ih = meta.img_h[b]; iw = meta.img_w[b]; fr = meta.first_removed[b];
+        }
+    if (!bp) return lb;
+    lb.vrow = valid_cells(min(ih, fr), a.stride, a.h);      // valid(q) <=> y(q) < img_h && y(q) < first_removed && x(q) < img_w (:1354-1369,:1405)
+    lb.vcol = valid_cells(iw, a.stride, a.w);
+    const Rect rc = box_rect(bp, a.Hc, a.Wc, a.stride, a.stride / 2, a.h, a.w);
+    if (rc.r1 <= rc.r0 || rc.c1 <= rc.c0) return lb;
+    lb.r0 = rc.r0; lb.r1 = rc.r1; lb.c0 = rc.c0; lb.c1 = rc.c1;
+    const int r0 = max(rc.r0 - dil, 0), r1 = min(rc.r1 + dil, a.h);
+    const int hc0 = max(rc.c0 - dil, 0), hc1 = min(rc.c1 + dil, a.w);
+    const int tw = 64 - 2 * dil;
+    lb.cnt = ((r1 - 1) / R - r0 / R + 1) * ((hc1 - hc0 + tw - 1) / tw);
+    return lb;
+}
+
+__device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& meta, int dil, int R, float thresh, const Ws& ws,
+                                           const LossState& st, int k) {
+    const int lane = threadIdx.x & 63;
+    int base = 0, prefix = 0;
+    LaneBox mine = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m0 = 0; m0 <= 64 * k; m0 += 64) {       // exclusive scan of the tile counts: deterministic offsets, no atomics
+        const int m = m0 + lane;
+        LaneBox lb = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (m < a.N) lb = lane_box(a, meta, dil, R, m);
+        int incl = lb.cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (m0 == 64 * k) { prefix = base + incl - lb.cnt; mine = lb; }
+        base += __shfl(incl, 63, 64);
+    }
+    const int m = 64 * k + lane;
+    if (m < a.N) {
+        ws.tab[m] = make_int4(prefix | (mine.img << 24), mine.r0 | (mine.r1 << 16), mine.c0 | (mine.c1 << 16), mine.vrow | (mine.vcol << 16));
+        if (st.inst) { InstRec rc; rc.r0 = mine.r0; rc.r1 = mine.r1; rc.c0 = mine.c0; rc.c1 = mine.c1; rc.img = mine.img; rc.pad0 = rc.pad1 = rc.pad2 = 0; st.inst[m] = rc; }
+#pragma unroll
+        for (int sub = 0; sub < kAcc2Split; ++sub) *acc2_word(ws.acc2, m, sub) = 0ull;     // polled after a kernel boundary
+    } else if (m == a.N) {
+        ws.tab[m] = make_int4(prefix, 0, 0, 0);
+    }
+    if (k == 0 && lane == 0) {
+        const Pred pr = make_pred(thresh);
+        *ws.hdr = make_int4(__float_as_int(pr.n2max), pr.zero_bit, R, 0);
+        if (st.status) st.status[1] = R;
+    }
+}
+
+// ---- role 2: stream block = 4 waves x 8 rows of one instance map; the instance's last block to arrive is its leader ----
+struct LogitRows {
+    const float* L; int w, vec;
+    __device__ __forceinline__ float4 operator()(int r, int c) const { return load4(L + (int64_t)r * w, c, w, vec); }
+};
+
+__device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = wave_total_f32(v[k]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[(threadIdx.x >> 6) * 4 + k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]);
+}
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
+
+// The leader of instance n (a whole workgroup): every band's partials are in memory (the arrival counter said so).
+//   partial maxima -> maxima -> sigmoid on those only -> both dice terms (:117-143) -> unit projection gradients, published as
+//   one 8-byte word per column / row (gradient bits << 32 | arg-max index) for the tile waves of the next launch and for
+//   bxi_boxinst_grad_rescale_f32; the projection gradient at the arg-max positions OUTSIDE the tile hull is written here
+//   (every zero-fill of this instance was written through and drained before its block arrived).
+__device__ __forceinline__ void leader_block(const InstArgs& a, int dil, int R, const Ws& ws, const LossState& st, int n, float upp,
+                                             float* __restrict__ g_logits, unsigned char* smem, float* red) {
+    const int h = a.h, w = a.w, tid = threadIdx.x;
+    float* xs = reinterpret_cast<float*>(smem);   // [w] sigmoid of the column maxima, then their unit gradients
+    float* ys = xs + w;                           // [h]
+    int* carg = reinterpret_cast<int*>(ys + h);   // [w]
+    int* rarg = carg + w;                         // [h]
+    const InstBox ib = inst_box(a, n, dil);
+    float sums[4] = {0.f, 0.f, 0.f, 0.f};   // I_x, U_x, I_y, U_y
+    // written by other workgroups of this launch: read past this CU's L1 (relaxed agent-scope loads = sc1)
+    auto best_key = [](const unsigned long long* part, int n_part, int64_t stride) {
+        unsigned long long k = 0ull;
+        for (int s0 = 0; s0 < n_part; s0 += 8) {
+            unsigned long long o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = __hip_atomic_load(part + (int64_t)min(s0 + u, n_part - 1) * stride, BXI_RLX, BXI_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) k = o[u] > k ? o[u] : k;
+        }
+        return k;
+    };
+    for (int i = tid; i < max(w, h); i += 256) {
+        const bool is_c = i < w, is_r = i < h;
+        const unsigned long long kc = best_key(ws.colpart + (int64_t)n * ws.n_cb * w + (is_c ? i : 0), ws.n_cb, w);
+        const unsigned long long kr = best_key(ws.rowkey + (int64_t)n * ws.n_rp * h + (is_r ? i : 0), ws.n_rp, h);
+        if (is_c) {
+            const int c = i;
+            const float X = sigmoid_acc(unpack_val(kc));
+            const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
+            xs[c] = X; carg[c] = (int)unpack_idx(kc);
+            sums[0] += X * TX; sums[1] += X * X + TX * TX;
+        }
+        if (is_r) {
+            const int r = i;
+            const float Y = sigmoid_acc(unpack_val(kr));
+            const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
+            ys[r] = Y; rarg[r] = (int)unpack_idx(kr);
+            sums[2] += Y * TY; sums[3] += Y * Y + TY * TY;
+        }
+    }
+    block_sum4(sums, red);
+    const float Ix = sums[0], Ux = sums[1] + 1e-5f, Iy = sums[2], Uy = sums[3] + 1e-5f;
+    if (tid == 0) ws.dice[n] = (1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy);      // :130, summed over both axes :143
+    if (g_logits) {
+        // dice = 1 - 2I/U ; d dice/d u_j = (-2 t_j U + 4 I u_j) / U^2 ; chain through sigmoid ; mean over N
+        const float invN = 1.f / (float)a.N;
+        for (int c = tid; c < w; c += 256) {
+            const float X = xs[c];
+            const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
+            const float gv = invN * ((-2.f * TX * Ux + 4.f * Ix * X) / (Ux * Ux)) * X * (1.f - X);
+            xs[c] = gv;
+            st.colk[(int64_t)n * w + c] = ((unsigned long long)__float_as_uint(gv) << 32) | (unsigned int)carg[c];
+        }
+        for (int r = tid; r < h; r += 256) {
+            const float Y = ys[r];
+            const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
+            const float gv = invN * ((-2.f * TY * Uy + 4.f * Iy * Y) / (Uy * Uy)) * Y * (1.f - Y);
+            ys[r] = gv;
+            st.rowk[(int64_t)n * h + r] = ((unsigned long long)__float_as_uint(gv) << 32) | (unsigned int)rarg[r];
+        }
+        __syncthreads();      // xs / ys now hold the gradients for every thread
+        // the tile waves own every pixel of the tile hull: rows of the R-aligned tiles x columns of the dilated box
+        const int hr0 = ib.any ? (ib.dil.r0 / R) * R : 0, hr1 = ib.any ? min(h, ((ib.dil.r1 + R - 1) / R) * R) : 0;
+        const int hc0 = ib.dil.c0, hc1 = ib.any ? ib.dil.c1 : 0;
+        float* G = g_logits + (int64_t)n * h * w;
+        for (int c = tid; c < w; c += 256) {
+            const int r = carg[c];
+            const bool in_t = r >= hr0 && r < hr1 && c >= hc0 && c < hc1;
+            if (!in_t) {
+                float v = xs[c];
+                if (rarg[r] == c) v += ys[r];
+                G[(int64_t)r * w + c] = v * upp;
+            }
+        }
+        for (int r = tid; r < h; r += 256) {
+            const int c = rarg[r];
+            const bool in_t = r >= hr0 && r < hr1 && c >= hc0 && c < hc1;
+            if (!in_t && carg[c] != r) G[(int64_t)r * w + c] = ys[r] * upp;
+        }
+    }
+}
+
+// Arrival of one workgroup on its instance; true (workgroup-uniform) for the last of `expected`.  Every store of the
+// workgroup that the leader depends on has been written through; this drains them first.
+__device__ __forceinline__ bool arrive_on_instance(const Ws& ws, int n, unsigned int expected, unsigned int* flag /* LDS */) {
+    drain_vmem();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int old = __hip_atomic_fetch_add(ws.inst_cnt + n, 1u, BXI_RLX, BXI_AGENT);
+        if (old + 1u > expected) atomicOr(ws.fault, kFaultInstCount);
+        *flag = old + 1u;
+    }
+    __syncthreads();
+    return *flag == expected;
+}
+
+template <typename Src>
+__device__ __forceinline__ void stream_block(const InstArgs& a, const Ws& ws, float* __restrict__ g_logits, int vec, int sb,
+                                             unsigned long long* colp /* LDS [kWaves][w] */, const Src& src, int tix) {
+    const int h = a.h, w = a.w;
+    const int Sn = (h + kSBlk - 1) / kSBlk;
+    const int n = sb / Sn, s = sb % Sn;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = s * kSBlk + wv * kSRows, r1 = min(h, r0 + kSRows);     // may be empty
+    const int64_t P = (int64_t)h * w;
+    float* G = g_logits ? g_logits + (int64_t)n * P : nullptr;
+    const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+
+    if (G)   // zero-fill of d loss / d logits (depends on nothing); written through: drains while the launch is still reading
+        for (int cb = 0; cb < w; cb += kChunkC) {
+            const int c = cb + lane * 4;
+            if (c < w) {
+#pragma unroll
+                for (int i = 0; i < kSRows; ++i)
+                    if (r0 + i < r1) {
+                        if (vec) store4_through(G + (int64_t)(r0 + i) * w + c, 0.f, 0.f, 0.f, 0.f);
+                        else
+                            for (int j = 0; j < 4; ++j)
+                                if (c + j < w) __hip_atomic_store(G + (int64_t)(r0 + i) * w + c + j, 0.f, BXI_RLX, BXI_AGENT);
+                    }
+            }
+        }
+    float4 v[kSRows];
+    {
+        const int c = lane * 4;
+#pragma unroll
+        for (int i = 0; i < kSRows; ++i) v[i] = (r0 + i < r1 && c < w) ? src(r0 + i, c) : ninf;
+    }
+    BXI_TW(0, tix, 1);
+    float rmax[kSRows]; int rcol[kSRows];
+#pragma unroll
+    for (int i = 0; i < kSRows; ++i) { rmax[i] = -INFINITY; rcol[i] = 0; }
+    for (int cb = 0;;) {
+        const int c = cb + lane * 4;
+        if (c < w) {
+            float cmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            int crow[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < kSRows; ++i) {
+                if (r0 + i < r1) {
+                    float m = v[i].x; int mc = c;                       // first column wins ties
+                    if (v[i].y > m) { m = v[i].y; mc = c + 1; }
+                    if (v[i].z > m) { m = v[i].z; mc = c + 2; }
+                    if (v[i].w > m) { m = v[i].w; mc = c + 3; }
+                    if (m > rmax[i]) { rmax[i] = m; rcol[i] = mc; }     // chunks ascend: strict > keeps the first
+                    if (v[i].x > cmax[0]) { cmax[0] = v[i].x; crow[0] = i; }   // ascending row, strict >: first row wins
+                    if (v[i].y > cmax[1]) { cmax[1] = v[i].y; crow[1] = i; }
+                    if (v[i].z > cmax[2]) { cmax[2] = v[i].z; crow[2] = i; }
+                    if (v[i].w > cmax[3]) { cmax[3] = v[i].w; crow[3] = i; }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c + j < w) colp[(size_t)wv * w + c + j] = pack_max(cmax[j], (uint32_t)(r0 + crow[j]));   // absolute row
+        }
+        cb += kChunkC;
+        if (cb >= w) break;
+        const int c2 = cb + lane * 4;
+#pragma unroll
+        for (int i = 0; i < kSRows; ++i) v[i] = (r0 + i < r1 && c2 < w) ? src(r0 + i, c2) : ninf;
+    }
+    BXI_TW(0, tix, 2);
+    float wmax[kSRows];
+#pragma unroll
+    for (int i = 0; i < kSRows; ++i) wmax[i] = rmax[i];
+    // eight maxima over the wave side by side: within rows of 16 lanes by DPP, the four rows by v_readlane (no LDS crossbar)
+    wave_total_steps([&](int c) {
+        float o[kSRows];
+#pragma unroll
+        for (int i = 0; i < kSRows; ++i) o[i] = __int_as_float(dpp_i32(__float_as_int(wmax[i]), c));
+#pragma unroll
+        for (int i = 0; i < kSRows; ++i) wmax[i] = fmaxf(wmax[i], o[i]);
+    });
+#pragma unroll
+    for (int i = 0; i < kSRows; ++i) {
+        const int b = __float_as_int(wmax[i]);
+        wmax[i] = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
+                        fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
+    }
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int i = 0; i < kSRows; ++i) {
+        const unsigned long long who = __ballot(rmax[i] == wmax[i]);
+        const int first = who ? __ffsll((long long)who) - 1 : 0;
+        const int col = __builtin_amdgcn_readlane(rcol[i], first);
+        if (lane == i) mine = pack_max(wmax[i], (uint32_t)col);
+    }
+    if (lane < kSRows && r0 + lane < r1) __hip_atomic_store(&ws.rowkey[(int64_t)n * h + r0 + lane], mine, BXI_RLX, BXI_AGENT);   // sc1: written through
+    BXI_TW(0, tix, 3);
+    lds_barrier();
+    BXI_TW(0, tix, 4);
+    unsigned long long* dstrow = ws.colpart + ((int64_t)n * Sn + s) * w;
+    const bool pairs = (w & 1) == 0;                          // then every (band, column pair) is 16-byte aligned
+    for (int c = 2 * (int)threadIdx.x; c < w; c += 2 * kWaves * 64) {
+        unsigned long long k0 = colp[c], k1 = c + 1 < w ? colp[c + 1] : 0ull;      // larger value, then smaller row
+#pragma unroll
+        for (int u = 1; u < kWaves; ++u) {
+            const unsigned long long o0 = colp[(size_t)u * w + c], o1 = c + 1 < w ? colp[(size_t)u * w + c + 1] : 0ull;
+            k0 = o0 > k0 ? o0 : k0; k1 = o1 > k1 ? o1 : k1;
+        }
+        if (pairs) store_u64x2_through(dstrow + c, k0, k1);
+        else {
+            __hip_atomic_store(dstrow + c, k0, BXI_RLX, BXI_AGENT);
+            if (c + 1 < w) __hip_atomic_store(dstrow + c + 1, k1, BXI_RLX, BXI_AGENT);
+        }
+    }
+}
+
+// ---- role 3: pool block = the 4 input rows of 64 pooled pixels, then the colour pairs its row segment completes --------
+__device__ __forceinline__ double lab_f(const double* lut, int i, int r8, int g8, int b8) {
+    const double r = lut[r8], g = lut[g8], b = lut[b8];
+    const double M[3][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}, {0.019334, 0.119193, 0.950227}};
+    const double white[3] = {0.95047, 1.0, 1.08883};
+    const double m0 = i == 0 ? M[0][0] : (i == 1 ? M[1][0] : M[2][0]);
+    const double m1 = i == 0 ? M[0][1] : (i == 1 ? M[1][1] : M[2][1]);
+    const double m2 = i == 0 ? M[0][2] : (i == 1 ? M[1][2] : M[2][2]);
+    const double wt = i == 0 ? white[0] : (i == 1 ? white[1] : white[2]);
+    const double acc = __dadd_rn(__dadd_rn(__dmul_rn(m0, r), __dmul_rn(m1, g)), __dmul_rn(m2, b));
+    const double v = acc / wt;
+    return v > 0.008856 ? cbrt(v) : __dadd_rn(__dmul_rn(7.787, v), 16.0 / 116.0);
+}
+
+__device__ __forceinline__ void pool_load(const PoolArgs& pa, int item, int segs, int h, int w, float4 (&v)[3]) {
+    const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = seg * 64 + lane;
+    const int64_t plane = (int64_t)pa.Hc * pa.Wc;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) v[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < w) {
+        const float* base = pa.imgs + (int64_t)b * 3 * plane + (int64_t)(4 * r + wv) * pa.Wc + 4 * c;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) v[ch] = *reinterpret_cast<const float4*>(base + pa.dn.src_ch[ch] * plane);
+    }
+}
+
+__device__ __forceinline__ float n2_of(float L0, float A0, float B0, float L1, float A1, float B1) {
+    const float dL = L0 - L1, dA = A0 - A1, dB = B0 - B1;     // un-fused: the decision must equal get_image_color_similarity's (:237)
+    return __fadd_rn(__fadd_rn(__fmul_rn(dL, dL), __fmul_rn(dA, dA)), __fmul_rn(dB, dB));
+}
+
+// the value of lane + d (a wavefront rotation per step: every lane receives something; the last d lanes receive lanes 0..d-1)
+__device__ __forceinline__ float lane_plus_n(float v, int d) {
+    int x = __float_as_int(v);
+    for (int s = 0; s < d; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+    return __int_as_float(x);
+}
+
+struct Lab3 { float L, A, B; };
+__device__ __forceinline__ Lab3 lab_read(const float4* p) {   // written by another workgroup of this launch: past this CU's L1
+    const unsigned long long la = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), BXI_RLX, BXI_AGENT);
+    const unsigned int b = __hip_atomic_load(reinterpret_cast<const unsigned int*>(p) + 2, BXI_RLX, BXI_AGENT);
+    Lab3 o; o.L = __uint_as_float((unsigned int)la); o.A = __uint_as_float((unsigned int)(la >> 32)); o.B = __uint_as_float(b);
+    return o;
+}
+
+__device__ __forceinline__ int4 rect_entry(const InstArgs& a, int n) {
+    const InstBox ib = inst_box(a, n, 0);
+    return make_int4(ib.box.r0 | (ib.box.r1 << 16), ib.box.c0 | (ib.box.c1 << 16), ib.img, 0);
+}
+
+// One wave: the colour pairs whose step row is pooled row r of segment `seg` of image b -- directions (get_image_color_similarity
+// :220-246 through unfold_wo_center's offsets :190-217, each unordered pair once):
+//   0: (r, c) - (r, c+D)    1: (r+D, c) - (r, c+D)    2: (r, c) - (r+D, c)    3: (r, c) - (r+D, c+D)
+// -> one predicate byte per pixel (bit d: squared Lab distance <= n2max, i.e. sim >= thresh for a valid neighbour), and the
+// segment's share of  sum W = sum_n sum_{p in box n} sum_k [sim_k(p) >= thresh]  (:1324-1328): a pair (p, q) weighs
+// [p in box n][q valid] + [q in box n][p valid] for every instance n of the image.
+__device__ __forceinline__ void affinity_item(const InstArgs& a, const ImageMeta& meta, const Ws& ws, int D, const int4* rects, int nrect,
+                                              float n2max, int zero_bit, int item, int segs) {
+    const int h = a.h, w = a.w, lane = threadIdx.x & 63;
+    const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
+    const int c = seg * 64 + lane, cn = c + D;
+    const bool rowD = r + D < h;                                  // wave-uniform
+    const float4* L4 = ws.lab4 + (int64_t)b * h * w;
+    const int cc = min(c, w - 1), ccn = min(cn, w - 1);
+    const Lab3 o0 = lab_read(L4 + (int64_t)r * w + cc);
+    const Lab3 oD = rowD ? lab_read(L4 + (int64_t)(r + D) * w + cc) : o0;
+    Lab3 n0, nD;
+    n0.L = lane_plus_n(o0.L, D); n0.A = lane_plus_n(o0.A, D); n0.B = lane_plus_n(o0.B, D);
+    nD.L = lane_plus_n(oD.L, D); nD.A = lane_plus_n(oD.A, D); nD.B = lane_plus_n(oD.B, D);
+    if (lane >= 64 - D) {                                         // the right neighbour lives in the next segment
+        n0 = lab_read(L4 + (int64_t)r * w + ccn);
+        nD = rowD ? lab_read(L4 + (int64_t)(r + D) * w + ccn) : n0;
+    }
+    const bool cin = c < w, nin = cn < w;
+    const bool p0 = cin && nin && n2_of(o0.L, o0.A, o0.B, n0.L, n0.A, n0.B) <= n2max;
+    const bool p1 = cin && nin && rowD && n2_of(oD.L, oD.A, oD.B, n0.L, n0.A, n0.B) <= n2max;
+    const bool p2 = cin && rowD && n2_of(o0.L, o0.A, o0.B, oD.L, oD.A, oD.B) <= n2max;
+    const bool p3 = cin && nin && rowD && n2_of(o0.L, o0.A, o0.B, nD.L, nD.A, nD.B) <= n2max;
+    if (cin) ws.pred[((int64_t)b * h + r) * w + c] = (unsigned char)((p0 ? 1 : 0) | (p1 ? 2 : 0) | (p2 ? 4 : 0) | (p3 ? 8 : 0));
+    if (zero_bit) return;        // thresh <= 0: every pair weighs 1, sum W has a closed form (pair3_kernel)
+    const int vrow = valid_cells(min(meta.img_h[b], meta.first_removed[b]), a.stride, h), vcol = valid_cells(meta.img_w[b], a.stride, w);
+    const bool v00 = r < vrow && c < vcol, v0n = r < vrow && cn < vcol, vD0 = r + D < vrow && c < vcol, vDn = r + D < vrow && cn < vcol;
+    // what a box containing the site adds:  (r, c)  (r, c+D)  (r+D, c)  (r+D, c+D)
+    const int s00 = (p0 && v0n) + (p2 && vD0) + (p3 && vDn), s0n = (p0 && v00) + (p1 && vD0), sD0 = (p1 && v0n) + (p2 && v00), sDn = (p3 && v00) ? 1 : 0;
+    int cnt = 0;
+    for (int n = 0; n < a.N; ++n) {                               // wave-uniform loop; rectangles from LDS (broadcast reads)
+        const int4 rc = n < nrect ? rects[n] : rect_entry(a, n);
+        if (rc.z != b) continue;
+        const int r0 = rc.x & 0xffff, r1 = (int)((unsigned int)rc.x >> 16), c0 = rc.y & 0xffff, c1 = (int)((unsigned int)rc.y >> 16);
+        const bool rr = r >= r0 && r < r1, rD = r + D >= r0 && r + D < r1;
+        if (!(rr || rD)) continue;
+        const bool c_in = c >= c0 && c < c1, n_in = cn >= c0 && cn < c1;
+        cnt += (rr && c_in ? s00 : 0) + (rr && n_in ? s0n : 0) + (rD && c_in ? sD0 : 0) + (rD && n_in ? sDn : 0);
+    }
+    cnt = wave_total_i32(cnt);
+    if (lane == 0 && cnt)       // integer adds commute: run-to-run identical
+        __hip_atomic_fetch_add(ws.sumw + (size_t)(item & (kSumWords - 1)) * kAcc2Stride, (unsigned long long)(unsigned int)cnt, BXI_RLX, BXI_AGENT);
+}
+
+// items first, first + step, ... < n_items
+__device__ __forceinline__ void pool_block(const PoolArgs& pa, const InstArgs& a, const Ws& ws, int dil, float thresh, int first, int step,
+                                           int n_items, double* lut /*[256]*/, int* part /*[4][3][64]*/, double* fch /*[3][64]*/,
+                                           int4* rects /*[kRectCap]*/, int* predp /*[2]*/, int tix) {
+    const int h = pa.Hc >> 2, w = pa.Wc >> 2;
+    const int segs = (w + 63) >> 6;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float4 v[3], nx[3];
+    pool_load(pa, first, segs, h, w, v);
+    // staged while the image loads fly: the companding table, the instances' box rectangles, the colour predicate
+    lut[threadIdx.x] = kSrgbLut[threadIdx.x];
+    const int nrect = min(a.N, kRectCap);
+    for (int n = threadIdx.x; n < nrect; n += 256) rects[n] = rect_entry(a, n);
+    if (wv == 3) {
+        const Pred pr = make_pred(thresh);
+        if (lane == 0) { predp[0] = __float_as_int(pr.n2max); predp[1] = pr.zero_bit; }
+    }
+    for (int item = first; item < n_items; item += step) {
+        const bool more = item + step < n_items;         // workgroup-uniform
+        if (more) pool_load(pa, item + step, segs, h, w, nx);
+        const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
+        const int c = seg * 64 + lane;
+        const int y = 4 * r + wv;
+        const bool act = c < w;
+        const int ih = pa.meta.img_h[b], iw = pa.meta.img_w[b];
+        const int x0 = 4 * c;
+        const bool yin = y < ih;
+        int sum[3];
+        if (__all(!act || (yin && x0 + 3 < iw))) {       // wave-uniform: the whole row segment is image, not canvas padding
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const double s = pa.dn.stdv[pa.dn.src_ch[ch]], m = pa.dn.mean[pa.dn.src_ch[ch]];
+                sum[ch] = denorm_u8(v[ch].x, s, m) + denorm_u8(v[ch].y, s, m) + denorm_u8(v[ch].z, s, m) + denorm_u8(v[ch].w, s, m);
+            }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const double s = pa.dn.stdv[pa.dn.src_ch[ch]], m = pa.dn.mean[pa.dn.src_ch[ch]];
+                int t = 0;
+                t += (yin && x0 + 0 < iw) ? denorm_u8(v[ch].x, s, m) : 0;
+                t += (yin && x0 + 1 < iw) ? denorm_u8(v[ch].y, s, m) : 0;
+                t += (yin && x0 + 2 < iw) ? denorm_u8(v[ch].z, s, m) : 0;
+                t += (yin && x0 + 3 < iw) ? denorm_u8(v[ch].w, s, m) : 0;
+                sum[ch] = t;
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) part[(wv * 3 + ch) * 64 + lane] = sum[ch];
+        BXI_TW(0, tix, 1);
+        lds_barrier();
+        BXI_TW(0, tix, 2);
+        if (wv < 3) {                                     // wave-uniform: wave i takes channel i of XYZ -> f_i
+            int px[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+                px[ch] = (part[(0 * 3 + ch) * 64 + lane] + part[(1 * 3 + ch) * 64 + lane] + part[(2 * 3 + ch) * 64 + lane] +
+                          part[(3 * 3 + ch) * 64 + lane]) >> 4;
+            fch[wv * 64 + lane] = lab_f(lut, wv, px[0], px[1], px[2]);
+        }
+        BXI_TW(0, tix, 3);
+        lds_barrier();
+        if (wv == 0) {       // one 16-byte write-through store per pooled pixel, drained before anybody is told
+            if (act) {
+                const double f0 = fch[lane], f1 = fch[64 + lane], f2 = fch[128 + lane];
+                store4_through(reinterpret_cast<float*>(ws.lab4 + ((int64_t)b * h + r) * w + c), (float)__dadd_rn(__dmul_rn(116.0, f1), -16.0),
+                               (float)__dmul_rn(500.0, __dadd_rn(f0, -f1)), (float)__dmul_rn(200.0, __dadd_rn(f1, -f2)), 0.f);
+            }
+            drain_vmem();
+        }
+        lds_barrier();       // the segment's Lab is in memory; `part` / `fch` are free again
+        BXI_TW(0, tix, 4);
+        {   // wave wv arrives on one of the four segments whose pairs this one takes part in; the last arrival evaluates it
+            const int rt = r - ((wv & 1) ? dil : 0), sg = seg - (wv >> 1);
+            if (rt >= 0 && sg >= 0) {
+                const int target = (b * h + rt) * segs + sg;
+                const unsigned int expected = (1u + (rt + dil < h ? 1u : 0u)) * (1u + (sg + 1 < segs ? 1u : 0u));
+                unsigned int old = 0u;
+                if (lane == 0) old = __hip_atomic_fetch_add(ws.item_cnt + target, 1u, BXI_RLX, BXI_AGENT);
+                old = (unsigned int)__builtin_amdgcn_readfirstlane((int)old);
+                BXI_TW(0, tix, 5);
+                if (old + 1u == expected) affinity_item(a, pa.meta, ws, dil, rects, nrect, __int_as_float(predp[0]), predp[1], target, segs);
+                else if (old + 1u > expected && lane == 0) atomicOr(ws.fault, kFaultItemCount);
+                BXI_TW(0, tix, 6);
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) v[ch] = nx[ch];
+    }
+}
+
+// grid: [table blocks][pool blocks][stream blocks] (pool_first) or [table][stream][pool]
+__global__ __launch_bounds__(256, 5) void prep3_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, float thresh, Ws ws,
+                                                       LossState st, const float* __restrict__ up_prj, float* __restrict__ g_logits, int vec,
+                                                       int pool_first) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
+    const int Sn = (a.h + kSBlk - 1) / kSBlk;
+    const int n_stream = a.N * Sn;
+    const int blk = (int)blockIdx.x;
+    const int tix = blk * kWaves + (int)(threadIdx.x >> 6);
+    (void)tix;
+    BXI_TW(0, tix, 0);
+    int role = 0, idx = blk;                              // 0 table, 1 pool, 2 stream
+    if (blk >= n_tab) {
+        idx = blk - n_tab;
+        const int n_a = pool_first ? n_pool : n_stream;
+        if (idx < n_a) role = pool_first ? 1 : 2;
+        else { idx -= n_a; role = pool_first ? 2 : 1; }
+    }
+    if (role == 0) {
+        const int k = blk * kWaves + (int)(threadIdx.x >> 6);
+        if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, thresh, ws, st, k);
+    } else if (role == 2) {
+        const float upp = up_prj ? *up_prj : 1.f;         // for the leader; requested before anything else
+        const int n = idx / Sn;
+        const LogitRows rows = {a.logits + (int64_t)n * a.h * a.w, a.w, vec};
+        unsigned long long* colp = reinterpret_cast<unsigned long long*>(smem);
+        stream_block(a, ws, g_logits, vec, idx, colp, rows, tix);
+        float* red = reinterpret_cast<float*>(smem + stream_red_off(a.h, a.w));
+        if (arrive_on_instance(ws, n, (unsigned int)Sn, reinterpret_cast<unsigned int*>(red + 16))) {
+            BXI_TW(0, tix, 5);
+            leader_block(a, dil, R, ws, st, n, upp, g_logits, smem, red);
+            BXI_TW(0, tix, 6);
+        }
+    } else {
+        double* lut = reinterpret_cast<double*>(smem);
+        double* fch = lut + 256;
+        int* part = reinterpret_cast<int*>(fch + 3 * 64);
+        int4* rects = reinterpret_cast<int4*>(part + 4 * 3 * 64);
+        int* predp = reinterpret_cast<int*>(rects + kRectCap);
+        pool_block(pa, a, ws, dil, thresh, idx, n_pool, n_items, lut, part, fch, rects, predp, tix);
+    }
+    BXI_TW(0, tix, 7);
+}
+
+// ---- head-fused first launch ----------------------------------------------------------------------------
+// CondInstMaskHead.forward (condinst_head.py:1139-1164) and the evaluation's first launch as ONE grid of independent roles:
+//   [table blocks][pool blocks][head tiles: instance x 8 x 32 tiles of y -> 16 x 64 logits]
+// A head tile does the stream role's job on the tile it just produced (zero-filled gradient tile, row / column partial maxima,
+// all written through), then arrives on its instance like a stream block: the last tile of an instance is its leader.
+template <int C, bool REL>
+__global__ __launch_bounds__(256, 5) void head_prep3_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, float thresh,
+                                                            Ws ws, LossState st, const float* __restrict__ up_prj, float* __restrict__ g_logits,
+                                                            DynArgs da, const float* __restrict__ params, float* __restrict__ logits_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
+    const int blk = (int)blockIdx.x;
+    const int tix = blk * kWaves + (int)(threadIdx.x >> 6);
+    (void)tix;
+    if (blk < n_tab) {
+        const int k = blk * kWaves + (int)(threadIdx.x >> 6);
+        if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, thresh, ws, st, k);
+    } else if (blk < n_tab + n_pool) {
+        double* lut = reinterpret_cast<double*>(smem);
+        double* fch = lut + 256;
+        int* part = reinterpret_cast<int*>(fch + 3 * 64);
+        int4* rects = reinterpret_cast<int4*>(part + 4 * 3 * 64);
+        int* predp = reinterpret_cast<int*>(rects + kRectCap);
+        pool_block(pa, a, ws, dil, thresh, blk - n_tab, n_pool, n_items, lut, part, fch, rects, predp, tix);
+    } else {
+        const float upp = up_prj ? *up_prj : 1.f;
+        const int tiles_x = (da.W + kYC - 1) / kYC, tiles_y = (da.H + kYR - 1) / kYR;
+        int t = blk - n_tab - n_pool;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int n = t / tiles_y;
+        unsigned long long* ckeys = reinterpret_cast<unsigned long long*>(smem);          // [4][64]
+        float* otile = reinterpret_cast<float*>(ckeys + 4 * 64);                          // [16][64]
+        float* ytile = otile + 16 * 64;                                                   // [(kYR+2)*(kYC+2)]
+        const DynEpi ep = {ws.colpart, ws.rowkey, g_logits, ws.n_cb, ws.n_rp, 1};
+        dyn_tile_forward<C, REL, 2, true>(da, params, logits_out, n, ty, tx, ytile, otile, ckeys, ep);
+        // the leader's LDS (2 (h + w) words + 17) starts at smem as well: every thread is past the tile's last LDS read
+        float* red = reinterpret_cast<float*>(smem + leader_bytes(a.h, a.w));
+        if (arrive_on_instance(ws, n, (unsigned int)(tiles_x * tiles_y), reinterpret_cast<unsigned int*>(red + 16)))
+            leader_block(a, dil, R, ws, st, n, upp, g_logits, smem, red);
+    }
+}
+
+// ---- the image side for strides other than 4 / unaligned canvases: separate launches (pool_rgb_generic of color_affinity.hip
+// -> Lab planes, then these two), no arrival counters needed: each runs after a kernel boundary -----------------------------
+__global__ __launch_bounds__(256) void pack_lab4_kernel(const float* __restrict__ lab, float4* __restrict__ lab4, int B, int64_t P) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * P; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / P, p = i - b * P;
+        const float* src = lab + b * 3 * P + p;
+        lab4[i] = make_float4(src[0], src[P], src[2 * P], 0.f);
+    }
+}
+__global__ __launch_bounds__(256) void affinity_all_kernel(InstArgs a, ImageMeta meta, Ws ws, int dil, float thresh, int n_items) {
+    const Pred pr = make_pred(thresh);
+    const int segs = (a.w + 63) >> 6;
+    for (int item = (int)blockIdx.x * kWaves + (int)(threadIdx.x >> 6); item < n_items; item += (int)gridDim.x * kWaves)
+        affinity_item(a, meta, ws, dil, nullptr, 0, pr.n2max, pr.zero_bit, item, segs);
+}
+
+// ================================================================================================
+// launch 2
+// ================================================================================================
+template <int D, int R> struct TG { static constexpr int RD = R + 2 * D, TW = 64 - 2 * D; };
+
+struct Tile {                                   // wave-uniform (SGPRs)
+    int r0, r1, c0, c1;                         // cells whose sample lies in the GT box (bitmask == 1)
+    int img, n, tile_r0, tile_c0;
+    int vrow, vcol;                             // valid(q) <=> row(q) < vrow && col(q) < vcol
+    int hc1;                                    // end column of the instance's tile hull (= dilated box)
+};
+
+struct TileFlags {   // bit j = data row j (map row tile_r0 - D + j) of this lane's column; R = the lane D to the right
+    uint32_t ib, vd, ow, ibR, vdR, owR;       // in GT box ; valid image pixel ; owned by this tile
+};
+
+__device__ __forceinline__ uint32_t row_bits(int lo, int hi, int base, int n) {   // bits j in [0,n) with lo <= base + j < hi
+    const int a = max(lo - base, 0), b = min(hi - base, n);
+    if (b <= a) return 0u;
+    return ((1u << b) - 1u) & ~((1u << a) - 1u);              // n <= 16
+}
+
+template <int D, int R>
+__device__ __forceinline__ TileFlags tile_flags(const Tile& t, int h, int w, int lane) {
+    constexpr int RD = TG<D, R>::RD;
+    const int base = t.tile_r0 - D;
+    const int cl = t.tile_c0 - D + lane;
+    const uint32_t rows_box = row_bits(t.r0, t.r1, base, RD);
+    const uint32_t rows_val = row_bits(0, min(h, t.vrow), base, RD);
+    const uint32_t rows_own = row_bits(t.tile_r0, min(t.tile_r0 + R, h), base, RD);
+    const int cv = min(w, t.vcol);
+    TileFlags f;
+    {
+        const int c = cl, ln = lane;
+        f.ib = (c >= t.c0 && c < t.c1) ? rows_box : 0u;
+        f.vd = (c >= 0 && c < cv) ? rows_val : 0u;
+        f.ow = (ln >= D && ln < 64 - D && c < t.hc1) ? rows_own : 0u;
+    }
+    {
+        const int c = cl + D, ln = lane + D;
+        const bool in = ln < 64;      // lanes without a right neighbour: every pair weight 0 (they receive some other lane's data)
+        f.ibR = (in && c >= t.c0 && c < t.c1) ? rows_box : 0u;
+        f.vdR = (in && c >= 0 && c < cv) ? rows_val : 0u;
+        f.owR = (in && ln >= D && ln < 64 - D && c < t.hc1) ? rows_own : 0u;
+    }
+    return f;
+}
+
+// The four pair directions of a step i (j = i + D), every one between this lane and the lane D to its right or itself, so
+// that only right-neighbour values are ever fetched:
+//   0: A = (i, l)  B = (i, l + D)   |   1: A = (j, l)  B = (i, l + D)   |   2: A = (i, l)  B = (j, l)   |   3: A = (i, l)  B = (j, l + D)
+// masks, bit i = the pair of step i:  W[k, A] = mA, W[7 - k, B] = mB, and the same restricted to pixels this tile owns;
+// `pb` = the colour predicates of the steps (launch 1's bytes, transposed).
+struct DirMasks { uint32_t mA, mB, nA, nB; };
+template <int D>
+__device__ __forceinline__ void dir_masks(const TileFlags& f, const uint32_t (&pb)[4], DirMasks (&m)[4]) {
+    m[0].mA = f.ib & f.vdR;          m[0].mB = f.ibR & f.vd;          m[0].nA = m[0].mA & f.ow;        m[0].nB = m[0].mB & f.owR;
+    m[1].mA = (f.ib >> D) & f.vdR;   m[1].mB = f.ibR & (f.vd >> D);   m[1].nA = m[1].mA & (f.ow >> D); m[1].nB = m[1].mB & f.owR;
+    m[2].mA = f.ib & (f.vd >> D);    m[2].mB = (f.ib >> D) & f.vd;    m[2].nA = m[2].mA & f.ow;        m[2].nB = m[2].mB & (f.ow >> D);
+    m[3].mA = f.ib & (f.vdR >> D);   m[3].mB = (f.ibR >> D) & f.vd;   m[3].nA = m[3].mA & f.ow;        m[3].nB = m[3].mB & (f.owR >> D);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { m[d].mA &= pb[d]; m[d].mB &= pb[d]; m[d].nA &= pb[d]; m[d].nB &= pb[d]; }
+}
+
+__device__ __forceinline__ uint32_t spread4(uint32_t x4) { return (x4 * 0x00204081u) & 0x01010101u; }   // bits 0..3 -> bytes 0..3
+
+template <int D>
+__device__ __forceinline__ float lane_plus(float v) {
+    int x = __float_as_int(v);
+#pragma unroll
+    for (int s = 0; s < D; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+    return __int_as_float(x);
+}
+template <int D>
+__device__ __forceinline__ float lane_minus(float v) {
+    int x = __float_as_int(v);
+#pragma unroll
+    for (int s = 0; s < D; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
+    return __int_as_float(x);
+}
+
+// Generic (slow) evaluation of one tile: ordered pairs per owned pixel straight from global memory, pair value and
+// gradient in log space exactly as pairwise.cu:38-61.  Taken for thresh <= 0 (zero_bit: padded / masked-out neighbours
+// weigh 1) and for tiles with saturated logits (S underflows).  Gradients -> gout, the lane's sum W pw -> gout[R].
+template <int D, int R>
+__device__ __forceinline__ void slow_tile(const float* __restrict__ Lg, const float4* __restrict__ lab4, const Tile& t, float n2max, int zero_bit,
+                                          int h, int w, int lane, float* gout /* LDS [R + 1][64] */) {
+    const int c = t.tile_c0 - D + lane;
+    const bool col_owned = lane >= D && lane < 64 - D && c < t.hc1;
+    float num = 0.f;
+    const float4* L0p = lab4 + (int64_t)t.img * h * w;
+#pragma unroll 1
+    for (int j = 0; j < R; ++j) {
+        const int r = t.tile_r0 + j;
+        float gacc = 0.f;
+        if (col_owned && r < h) {
+            const bool in_p = r >= t.r0 && r < t.r1 && c >= t.c0 && c < t.c1;
+            const bool val_p = r < t.vrow && c < t.vcol;
+            const int64_t pi = (int64_t)r * w + c;
+            const float4 lp = L0p[pi];
+            const float xa = Lg[pi];
+            const float ax = logsig(xa), bx = logsig(-xa);
+#pragma unroll 1
+            for (int k = 0; k < 8; ++k) {
+                const int kk = k < 4 ? k : k + 1;
+                const int r2 = r + (kk / 3 - 1) * D, c2 = c + (kk % 3 - 1) * D;
+                const bool inq = r2 >= 0 && r2 < h && c2 >= 0 && c2 < w;
+                uint32_t pn = 0u;
+                int64_t qi = 0;
+                if (inq) {
+                    qi = (int64_t)r2 * w + c2;
+                    const float4 lq = L0p[qi];
+                    pn = n2_of(lp.x, lp.y, lp.z, lq.x, lq.y, lq.z) <= n2max ? 1u : 0u;
+                }
+                const bool val_q = inq && r2 < t.vrow && c2 < t.vcol;
+                const bool in_q = inq && r2 >= t.r0 && r2 < t.r1 && c2 >= t.c0 && c2 < t.c1;
+                const uint32_t wp = in_p ? (val_q ? pn : (uint32_t)zero_bit) : 0u;
+                const uint32_t wq = in_q ? (val_p ? pn : (uint32_t)zero_bit) : 0u;
+                if (inq && (wp + wq)) {
+                    const float xb = Lg[qi];
+                    const float ay = logsig(xb), by = logsig(-xb);
+                    const float e1 = ax + ay, e0 = bx + by;
+                    const float nl2 = logsig(fabsf(e1 - e0)) - fmaxf(e1, e0);
+                    num += (float)wp * nl2;
+                    gacc += (float)(wp + wq) * (-(expf(ay) - expf(by)) * expf(ax + bx + nl2));
+                }
+            }
+        }
+        gout[j * 64 + lane] = gacc;
+    }
+    gout[R * 64 + lane] = num;
+}
+
+template <int D, int R>
+__device__ __forceinline__ void load_plane(const float* __restrict__ plane, const Tile& t, int h, int w, int lane, float (&v)[R + 2 * D]) {
+    const uint32_t cc4 = (uint32_t)min(max(t.tile_c0 - D + lane, 0), w - 1) * 4u;
+    const char* pb = reinterpret_cast<const char*>(plane);                       // scalar base + 32-bit byte offset (one plane < 2^31 bytes)
+#pragma unroll
+    for (int j = 0; j < R + 2 * D; ++j) {
+        const uint32_t rr = (uint32_t)min(max(t.tile_r0 - D + j, 0), h - 1);       // clamped: pairs with a pixel outside the map weigh 0
+        v[j] = *reinterpret_cast<const float*>(pb + (rr * (uint32_t)w * 4u + cc4));
+    }
+}
+
+// ---- tile wave (wave64, no LDS, no barrier, no wait) ---------------------------------------------------------------------
+// Every UNORDERED pair is evaluated once and feeds both of its pixels: f(p,q) = f(q,p), the two weights W[k,p] + W[7-k,q]
+// share the colour predicate.  Per pixel (a, b) = (sigmoid(x), sigmoid(-x)), t = a - b, u = a b.  Per pair (p, q):
+//   S = a_p a_q + b_p b_q ; pw = -log S ; d pw / d x_p = -t_q u_p / S ; d pw / d x_q = -t_p u_q / S      (pairwise.cu:38-61)
+// S cannot underflow while every |x| <= 34; tiles with a larger logit take the log-space path.
+template <int D, int R>
+__device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const LossState& st, const Tile& t, float scale, float upp,
+                                          float n2max, int zero_bit, float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
+                                          int tix) {
+    constexpr int RD = TG<D, R>::RD;
+    const int lane = threadIdx.x & 63;
+    const int h = a.h, w = a.w, n = t.n;
+    const int64_t P = (int64_t)h * w;
+    const float* Lg = a.logits + (int64_t)n * P;
+    const int c = t.tile_c0 - D + lane;
+    const bool col_owned = g_logits && lane >= D && lane < 64 - D && c < t.hc1;
+    const bool row_lane = g_logits && lane < R && t.tile_r0 + lane < h;
+    // everything the tile needs is plain data of the previous launch, requested together
+    float x[RD];
+    load_plane<D, R>(Lg, t, h, w, lane, x);
+    uint32_t pbyte[R + D];
+    {
+        const unsigned char* pp = ws.pred + (int64_t)t.img * P;
+        const uint32_t cc = (uint32_t)min(max(c, 0), w - 1);
+#pragma unroll
+        for (int i = 0; i < R + D; ++i) pbyte[i] = pp[(uint32_t)min(max(t.tile_r0 - D + i, 0), h - 1) * (uint32_t)w + cc];
+    }
+    unsigned long long ck = 0ull, rk = 0ull;
+    if (col_owned) ck = st.colk[(int64_t)n * w + c];
+    if (row_lane) rk = st.rowk[(int64_t)n * h + t.tile_r0 + lane];
+    float g[R];
+    float num = 0.f;
+#pragma unroll
+    for (int j = 0; j < R; ++j) g[j] = 0.f;
+    bool slow = zero_bit != 0;
+    if (!slow) {
+        const TileFlags f = tile_flags<D, R>(t, h, w, lane);
+        uint32_t pb[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < R + D; ++i)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) pb[d] |= ((pbyte[i] >> d) & 1u) << i;
+        DirMasks m[4];
+        dir_masks<D>(f, pb, m);
+        float pa_[RD], pb_[RD], pt_[RD], pu_[RD];    // this lane, rows [i, i + D] live
+        float aR[RD], bR[RD], tR[RD], uR[RD];        // the lane D to the right
+        float gq[RD], gR[RD];                        // gradient of this lane's pixels / of lane + D's
+        bool sat = false;
+#pragma unroll
+        for (int j = 0; j < RD; ++j) { gq[j] = 0.f; gR[j] = 0.f; sat |= !(fabsf(x[j]) <= 34.f); }
+        // pair weights as bytes, four rows per word: cw = W[k,A] + W[7-k,B] (gradient), dw = the same restricted to
+        // pixels this tile owns (loss sum)
+        uint32_t cw[4][(R + D + 3) / 4], dw[4][(R + D + 3) / 4];
+#pragma unroll
+        for (int dir = 0; dir < 4; ++dir)
+#pragma unroll
+            for (int q4 = 0; q4 < (R + D + 3) / 4; ++q4) {
+                cw[dir][q4] = spread4((m[dir].mA >> (4 * q4)) & 15u) + spread4((m[dir].mB >> (4 * q4)) & 15u);
+                dw[dir][q4] = spread4((m[dir].nA >> (4 * q4)) & 15u) + spread4((m[dir].nB >> (4 * q4)) & 15u);
+            }
+        BXI_TW(1, tix, 2);
+#define BXI_ROW(j)                                                                                                  \
+        {                                                                                                           \
+            const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; pt_[j] = s.x - s.y; pu_[j] = s.x * s.y;    \
+            aR[j] = lane_plus<D>(pa_[j]); bR[j] = lane_plus<D>(pb_[j]); tR[j] = aR[j] - bR[j]; uR[j] = aR[j] * bR[j]; \
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) BXI_ROW(j)
+        // one unordered pair: A = (row ra, this lane) ; B = (row rb of the lane `q` names) ; num collects -log2 S
+#define BXI_PAIR(i, ra, rb, qa, qb, qt, qu, dir, GA, GB)                                                            \
+        {                                                                                                           \
+            const float gw = (float)((cw[dir][(i) >> 2] >> (8 * ((i) & 3))) & 255u);                                \
+            const float nw = (float)((dw[dir][(i) >> 2] >> (8 * ((i) & 3))) & 255u);                                \
+            const float S = pa_[ra] * qa[rb] + pb_[ra] * qb[rb];                    /* P(y_A == y_B) */            \
+            num -= nw * __builtin_amdgcn_logf(S);                                   /* v_log_f32 = log2 */         \
+            const float mm = gw * __builtin_amdgcn_rcpf(S);                                                         \
+            GA -= mm * qt[rb] * pu_[ra];                                                                            \
+            GB -= mm * pt_[ra] * qu[rb];                                                                            \
+        }
+#pragma unroll
+        for (int i = 0; i < R + D; ++i) {
+            const int j = i + D;
+            BXI_ROW(j)
+            if (i >= D) BXI_PAIR(i, i, i, aR, bR, tR, uR, 0, gq[i], gR[i])
+            BXI_PAIR(i, j, i, aR, bR, tR, uR, 1, gq[j], gR[i])
+            BXI_PAIR(i, i, j, pa_, pb_, pt_, pu_, 2, gq[i], gq[j])
+            BXI_PAIR(i, i, j, aR, bR, tR, uR, 3, gq[i], gR[j])
+            if (i >= D) {     // row i is complete: collect what the lane D to the left computed for it
+                const float fromL = lane_minus<D>(gR[i]);
+                g[i - D] = gq[i] + (lane >= D ? fromL : 0.f);
+            }
+        }
+        num *= 0.69314718055994531f;
+#undef BXI_ROW
+#undef BXI_PAIR
+        slow = __any(sat);
+    }
+    if (slow) {      // wave-uniform; rare
+        slow_tile<D, R>(Lg, ws.lab4, t, n2max, zero_bit, h, w, lane, gbuf);
+        num = gbuf[R * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < R; ++j) g[j] = gbuf[j * 64 + lane];
+    }
+    BXI_TW(1, tix, 3);
+    num = wave_total_f32(num);
+    const long long fx = (long long)(num * kNumScale) + (1ll << 24);           // + 1.0: keeps the packed field non-negative
+    if (g_logits) {
+        const int carg = col_owned ? (int)(unsigned int)ck : -1;
+        const float gc = __uint_as_float((unsigned int)(ck >> 32));
+        const int rarg_l = row_lane ? (int)(unsigned int)rk : -1;
+        const float gr_l = __uint_as_float((unsigned int)(rk >> 32));
+        char* G = reinterpret_cast<char*>(g_logits + (int64_t)n * P);      // scalar base + 32-bit byte offset
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int r = t.tile_r0 + j;
+            const int ra = __builtin_amdgcn_readlane(rarg_l, j);
+            const float gr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gr_l), j));
+            if (col_owned && r < h) {
+                float sp = 0.f;
+                if (carg == r) sp += gc;
+                if (ra == c) sp += gr;
+                *reinterpret_cast<float*>(G + (uint32_t)(r * w + c) * 4u) = g[j] * scale + sp * upp;
+            }
+        }
+    }
+    BXI_TW(1, tix, 4);
+    // this tile's share of sum W pw + its arrival: one atomic without return; the wave does not wait for it
+    if (lane == 0)
+        __hip_atomic_fetch_add(acc2_word(ws.acc2, n, t.tile_r0 / R + t.tile_c0 / TG<D, R>::TW), (1ull << 52) + (unsigned long long)fx, BXI_RLX, BXI_AGENT);
+    BXI_TW(1, tix, 5);
+}
+
+// sum W of the evaluation: the pool blocks' count words, or (thresh <= 0: every pair weighs 1, :1324) 8 x the box areas
+__device__ __forceinline__ double total_weight(const InstArgs& a, const Ws& ws, int zero_bit) {
+    const int lane = threadIdx.x & 63;
+    if (!zero_bit) return wave_total_f64((double)ws.sumw[(size_t)lane * kAcc2Stride]);      // exact: integers far below 2^53
+    double s = 0.0;
+    for (int m0 = 0; m0 < a.N; m0 += 64) {
+        const int m = m0 + lane;
+        if (m < a.N) {
+            const int4 e = ws.tab[m];
+            const int r0 = e.y & 0xffff, r1 = (int)((unsigned int)e.y >> 16), c0 = e.z & 0xffff, c1 = (int)((unsigned int)e.z >> 16);
+            s += 8.0 * (double)((r1 - r0) * (int64_t)(c1 - c0));
+        }
+    }
+    return wave_total_f64(s);
+}
+
+__device__ __forceinline__ Tile tile_of(const int4& e, int D, int R, int TW, int n, int idx, int h, int w) {   // e: the instance's table entry (uniform)
+    Tile t;
+    t.r0 = e.y & 0xffff; t.r1 = (int)((unsigned int)e.y >> 16); t.c0 = e.z & 0xffff; t.c1 = (int)((unsigned int)e.z >> 16);
+    t.img = (int)((unsigned int)e.x >> 24); t.n = n;
+    t.vrow = e.w & 0xffff; t.vcol = (int)((unsigned int)e.w >> 16);
+    const int dr0 = max(t.r0 - D, 0), hc0 = max(t.c0 - D, 0);
+    t.hc1 = min(t.c1 + D, w);
+    const int ntc = (t.hc1 - hc0 + TW - 1) / TW;
+    const int ti = idx / ntc, tj = idx - ti * ntc;
+    t.tile_r0 = (dr0 / R + ti) * R;
+    t.tile_c0 = hc0 + tj * TW;
+    (void)h;
+    return t;
+}
+
+// The finisher's round over instances [b0, b0 + 64): arrivals and sums of every tile (8 words per instance, arrival count and
+// sum in one word), requested together.  Returns whether all of them are complete; adds their sums.
+__device__ __forceinline__ bool finisher_round(const Ws& ws, int N, int b0, double* num) {
+    const int lane = threadIdx.x & 63, i = b0 + lane;
+    unsigned long long x = 0ull;
+    unsigned int expect = 0u;
+    if (i < N) {
+        unsigned long long wd[kAcc2Split];
+#pragma unroll
+        for (int sub = 0; sub < kAcc2Split; ++sub) wd[sub] = __hip_atomic_load(acc2_word(ws.acc2, i, sub), BXI_RLX, BXI_AGENT);
+        expect = (unsigned int)((ws.tab[i + 1].x & 0xffffff) - (ws.tab[i].x & 0xffffff));
+#pragma unroll
+        for (int sub = 0; sub < kAcc2Split; ++sub) x += wd[sub];
+    }
+    const bool have = (unsigned int)(x >> 52) == expect;
+    if (!__all(have)) return false;
+    const long long fixed = (long long)(x & ((1ull << 52) - 1ull)) - ((long long)expect << 24);   // the +1 per tile
+    *num += wave_total_f64(i < N ? (double)fixed : 0.0);
+    return true;
+}
+
+// grid: [tile blocks (4 independent tile waves each, striding through the tile list)][finisher]
+template <int D, int R>
+__global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
+                                                       float* __restrict__ losses, float* __restrict__ g_logits, InstArgs a, Ws ws, LossState st,
+                                                       int n_items) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int blk = (int)blockIdx.x, lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const int N = a.N;
+    const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
+    const int4 hdr = *ws.hdr;
+    const float n2max = __int_as_float(__builtin_amdgcn_readfirstlane(hdr.x));
+    const int zero_bit = __builtin_amdgcn_readfirstlane(hdr.y);
+    if (blk == (int)gridDim.x - 1) {                                   // ---- finisher
+        // launch 1 is complete: its arrival counters go back to zero for the next evaluation
+        for (int i = threadIdx.x; i < n_items; i += 256) ws.item_cnt[i] = 0u;
+        for (int i = threadIdx.x; i < N; i += 256) ws.inst_cnt[i] = 0u;
+        if (threadIdx.x >= 64) return;
+        BXI_TW(3, 0, 0);
+        bool ok = false;
+        double num = 0.0;
+        for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {        // waits only for workgroups that never wait themselves
+            num = 0.0;
+            bool all = true;
+            for (int b0 = 0; b0 < N && all; b0 += 64) all = finisher_round(ws, N, b0, &num);
+            if (all) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const double total_w = total_weight(a, ws, zero_bit);
+        float dsum = 0.f;
+        for (int b0 = 0; b0 < N; b0 += 64) {                             // index order: run-to-run identical
+            const float dv = b0 + lane < N ? ws.dice[b0 + lane] : 0.f;
+            const int m = min(64, N - b0);
+            for (int k = 0; k < m; ++k) dsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), k));
+        }
+        unsigned int status = __hip_atomic_load(ws.fault, BXI_RLX, BXI_AGENT) | (ok ? 0u : kFaultFinisher);
+        status = (unsigned int)__builtin_amdgcn_readfirstlane((int)status);
+        if (lane == 0) {
+            const float denom = fmaxf((float)total_w, 1.f);                      // weights.sum().clamp(min=1.0), :1328
+            float l0 = dsum / (float)N;                                          // .mean(), :143
+            float l1 = (float)((num / (double)kNumScale) / (double)denom) * warmup;   // :1327-1332
+            if (status) { l0 = __int_as_float(0x7fc00000); l1 = l0; }            // loud: mmdet's CheckInvalidLossHook fires
+            losses[0] = l0; losses[1] = l1;
+            if (st.scale) { *st.scale = warmup / denom; st.applied[0] = upp; st.applied[1] = upw; }
+            if (st.status) st.status[0] = (int)status;
+            *ws.fault = 0u;
+        }
+        ws.sumw[(size_t)lane * kAcc2Stride] = 0ull;                              // every tile wave has read it (or the evaluation is void)
+        BXI_TW(3, 0, 1);
+        return;
+    }
+    const int wid = blk * kWaves + wave, nwaves = ((int)gridDim.x - 1) * kWaves;
+    BXI_TW(1, wid, 0);
+    // the table (16 bytes per instance, the same lines for every wave) and the count words, requested together
+    int4 e0 = make_int4(0, 0, 0, 0);
+    if (lane <= N) e0 = ws.tab[lane];
+    const int total = N < 64 ? __builtin_amdgcn_readlane(e0.x, N < 64 ? N : 0) : __builtin_amdgcn_readfirstlane(ws.tab[N].x);
+    if (wid >= total) return;
+    const double total_w = total_weight(a, ws, zero_bit);
+    const float scale = upw * (warmup / fmaxf((float)total_w, 1.f));
+    float* gbuf = reinterpret_cast<float*>(smem) + wave * ((R + 1) * 64);
+    for (int ti = wid; ti < total; ti += nwaves) {
+        int n = 0;
+        int4 e = make_int4(0, 0, 0, 0);
+        if (N < 64) {
+            const unsigned long long mask = __ballot(lane < N && (e0.x & 0xffffff) <= ti);
+            n = __popcll(mask) - 1;
+            e.x = __builtin_amdgcn_readlane(e0.x, n); e.y = __builtin_amdgcn_readlane(e0.y, n);
+            e.z = __builtin_amdgcn_readlane(e0.z, n); e.w = __builtin_amdgcn_readlane(e0.w, n);
+        } else {
+            for (int m0 = 0; m0 < N; m0 += 64) {
+                int4 em = make_int4(0, 0, 0, 0);
+                if (m0 + lane < N) em = ws.tab[m0 + lane];
+                const unsigned long long mask = __ballot(m0 + lane < N && (em.x & 0xffffff) <= ti);
+                const int cntm = __popcll(mask);
+                if (cntm == 0) break;
+                n = m0 + cntm - 1;
+                e.x = __builtin_amdgcn_readlane(em.x, cntm - 1); e.y = __builtin_amdgcn_readlane(em.y, cntm - 1);
+                e.z = __builtin_amdgcn_readlane(em.z, cntm - 1); e.w = __builtin_amdgcn_readlane(em.w, cntm - 1);
+                if (cntm < 64) break;
+            }
+        }
+        const Tile t = tile_of(e, D, R, TG<D, R>::TW, n, ti - (e.x & 0xffffff), a.h, a.w);
+        BXI_TW(1, wid, 1);
+        math_tile<D, R>(a, ws, st, t, scale, upp, n2max, zero_bit, g_logits, gbuf, wid);
+    }
+}
+
+// ---- rescale: g_logits finished for the factors recorded in `state` -> finished for (g_prj, g_pw) ----------------
+// grid (8, N).  No-op when the factors are the recorded ones (the usual case: loss.backward() seeds both terms with 1).
+// An evaluation whose status word is set has no gradient: it is poisoned here, next to the NaN losses.
+__global__ __launch_bounds__(256) void rescale3_kernel(InstArgs a, int dil, LossState st, const float* __restrict__ g_prj,
+                                                       const float* __restrict__ g_pw, float* __restrict__ g_logits) {
+    const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int h = a.h, w = a.w;
+    float* G = g_logits + (int64_t)n * h * w;
+    if (st.status[0] != 0) {
+        const int per = (h + gridDim.x - 1) / gridDim.x;
+        const int ra = s * per, rb = min(h, ra + per);
+        for (int i = tid; i < (rb - ra) * w; i += 256) G[(int64_t)ra * w + i] = __int_as_float(0x7fc00000);
+        return;
+    }
+    const float np = *g_prj, nw = *g_pw, op = st.applied[0], ow = st.applied[1];
+    if (np == op && nw == ow) return;
+    const int R = st.status[1];
+    const InstRec rec = st.inst[n];
+    const InstBox ib = inst_from_rec(rec, dil, h, w);
+    const int hr0 = ib.any ? (ib.dil.r0 / R) * R : 0, hr1 = ib.any ? min(h, ((ib.dil.r1 + R - 1) / R) * R) : 0;
+    const int hc0 = ib.dil.c0, hc1 = ib.any ? ib.dil.c1 : 0;
+    const float ratio = nw / ow;                      // recorded g_pw == 0 cannot be rescaled (documented)
+    const unsigned long long* ckp = st.colk + (int64_t)n * w; const unsigned long long* rkp = st.rowk + (int64_t)n * h;
+    auto carg = [&](int c) { return (int)(unsigned int)ckp[c]; };
+    auto rarg = [&](int r) { return (int)(unsigned int)rkp[r]; };
+    auto gcol = [&](int c) { return __uint_as_float((unsigned int)(ckp[c] >> 32)); };
+    auto grow = [&](int r) { return __uint_as_float((unsigned int)(rkp[r] >> 32)); };
+    const int cw = hc1 - hc0, rows = hr1 - hr0;
+    const int per = (rows + gridDim.x - 1) / gridDim.x;
+    const int ra = hr0 + s * per, rb = min(hr1, ra + per);
+    const int npx = cw > 0 && rb > ra ? (rb - ra) * cw : 0;
+    for (int i = tid; i < npx; i += 256) {            // G = ow*s*d + op*sp  ->  nw*s*d + np*sp
+        const int r = ra + i / cw, c = hc0 + i % cw;
+        float sp = 0.f;
+        if (carg(c) == r) sp += gcol(c);
+        if (rarg(r) == c) sp += grow(r);
+        const float v = G[(int64_t)r * w + c];
+        G[(int64_t)r * w + c] = (v - op * sp) * ratio + np * sp;
+    }
+    if (s == 0) {                                     // arg-max positions outside the hull hold op * sp
+        for (int c = tid; c < w; c += 256) {
+            const int r = carg(c);
+            const bool in_t = r >= hr0 && r < hr1 && c >= hc0 && c < hc1;
+            if (!in_t) {
+                float v = gcol(c);
+                if (rarg(r) == c) v += grow(r);
+                G[(int64_t)r * w + c] = v * np;
+            }
+        }
+        for (int r = tid; r < h; r += 256) {
+            const int c = rarg(r);
+            const bool in_t = r >= hr0 && r < hr1 && c >= hc0 && c < hc1;
+            if (!in_t && carg(c) != r) G[(int64_t)r * w + c] = grow(r) * np;
+        }
+    }
+}
+
+__global__ void zero_losses2_kernel(float* losses) { losses[0] = 0.f; losses[1] = 0.f; }
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+// compute units of the current device (256 on an MI355X in SPX mode, 32 per partition in CPX): the grids are sized so that a
+// launch is resident in one round.  Cached per device ordinal; a wrong value costs time, never correctness.
+static int device_cus() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cached[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+static int tile_rows_for(int N) { return N <= 96 ? 4 : 8; }
+
+template <int D, int R>
+static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, float warmup, const Ws& ws, const LossState& st, float* losses,
+                        float* g_logits, const float* up_prj, const float* up_pw, int n_items) {
+    BXI_LAUNCH("pair", s, (pair3_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, up_prj, up_pw, warmup, losses, g_logits, a, ws, st, n_items);
+}
+
+}  // namespace v3
+
+size_t eval3_ws_bytes(int B, int N, int h, int w) { return v3::carve(nullptr, B, N, h, w, nullptr); }
+size_t eval3_sync_bytes() { return v3::kSyncBytes; }
+bool eval3_supported(int dil) { return dil >= 1 && dil <= v3::kMaxDilFused; }
+
+// One evaluation, two launches.  `workspace` starts with the sync region (zero between evaluations).
+int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_instances* in, int dil, float warmup, const float* up_prj,
+                 const float* up_pw, float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, int force_rows,
+                 void* stream, const DynArgs* head, int head_C) {
+    using namespace v3;
+    InstArgs a;
+    int rc = fill_inst(in, a);
+    if (rc != BXI_OK) return rc;
+    if (!eval3_supported(dil)) return BXI_ERR_UNSUPPORTED;
+    if (!losses || !batch) return BXI_ERR_NULL_POINTER;
+    hipStream_t s = as_stream(stream);
+    PoolArgs pa = {};
+    if (batch->Hc != in->Hc || batch->Wc != in->Wc || batch->B != in->B) return BXI_ERR_BAD_SHAPE;
+    rc = fill_pool_args(batch, nullptr, nullptr, pa);
+    if (rc != BXI_OK) return rc;
+    if (batch->B > 0 && !batch->imgs) return BXI_ERR_NULL_POINTER;
+    if (batch->image_masks) return BXI_ERR_UNSUPPORTED;   // explicit masks: use bxi_color_affinity_f32 + bits
+    if (a.N == 0) {
+        BXI_LAUNCH("zero_losses", s, zero_losses2_kernel, dim3(1), dim3(1), 0, s, losses);
+        return check_launch();
+    }
+    if (a.N >= kMaxInst || a.h > 65535 || a.w > 65535) return BXI_ERR_BAD_SHAPE;
+    if (batch->B <= 0) return BXI_ERR_BAD_SHAPE;
+    if (g_logits && !state) return BXI_ERR_NULL_POINTER;
+    const bool pooled_in_launch = pool_vec_ok(batch, a.stride);     // else: the generic pooling kernels in launches of their own
+    const size_t need = carve(nullptr, batch->B, a.N, a.h, a.w, nullptr);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
+    Ws ws;
+    carve(workspace, batch->B, a.N, a.h, a.w, &ws);
+    LossState st = {};
+    if (state) {
+        if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
+        carve_state(state, a.N, a.h, a.w, &st);
+    }
+    const int vec = ((a.w & 3) == 0 && (reinterpret_cast<uintptr_t>(a.logits) & 15) == 0 &&
+                     (!g_logits || (reinterpret_cast<uintptr_t>(g_logits) & 15) == 0)) ? 1 : 0;
+    static const int env_rows = env_int("BXI_TILE_ROWS", 0);            // developer knobs
+    static const int env_pool_first = env_int("BXI_POOL_FIRST", 1);
+    static const int env_pool_wgs = env_int("BXI_POOL_WGS_PER_CU", 5);
+    if (!force_rows) force_rows = env_rows;
+    const int R = force_rows == 4 || force_rows == 8 ? force_rows : tile_rows_for(a.N);
+    if (eval_cap(a.N, a.h, a.w, dil, R) >= (1 << 24)) return BXI_ERR_BAD_SHAPE;     // the table packs a tile prefix into 24 bits
+
+    // ---- launch 1 --------------------------------------------------------------------------------------------------
+    const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
+    const int Sn = (a.h + kSBlk - 1) / kSBlk;
+    const int n_stream = a.N * Sn;
+    // one item = the 4 input rows of 64 pooled pixels.  The whole launch should be resident at once (5 workgroups per CU at
+    // <= 96 VGPRs): a pool workgroup takes several items, the next one's loads in flight, when it is not.
+    const int64_t n_items64 = (int64_t)batch->B * a.h * ((a.w + 63) / 64);
+    if (n_items64 > kMaxItems) return BXI_ERR_UNSUPPORTED;
+    const int n_items = (int)n_items64;
+    const int room = env_pool_wgs * device_cus() - n_tab - (head ? 0 : n_stream);
+    const int per = room > 0 ? (n_items + room - 1) / room : 8;
+    const int n_pool = pooled_in_launch ? (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per) : 0;
+    const size_t lds_pool = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64 + 16 * (size_t)kRectCap + 16;
+    const size_t lds_leader = leader_bytes(a.h, a.w) + 4 * 20;
+    size_t lds1 = lds_pool;
+    if (head) {
+        // the head-fused first launch (factor 2, vector rows): tables, pool blocks, head tiles
+        if (head->factor != 2 || !vec || head->H * 2 != a.h || head->W * 2 != a.w || head->N != a.N || head->B != in->B || !pooled_in_launch)
+            return BXI_ERR_UNSUPPORTED;
+        const int tiles = ((head->H + kYR - 1) / kYR) * ((head->W + kYC - 1) / kYC);
+        ws.n_cb = (head->H + kYR - 1) / kYR;
+        ws.n_rp = (head->W + kYC - 1) / kYC;
+        const size_t lds_head = 8 * 4 * 64 + sizeof(float) * (16 * 64 + (kYR + 2) * (kYC + 2));
+        if (lds1 < lds_head) lds1 = lds_head;
+        if (lds1 < lds_leader) lds1 = lds_leader;
+        if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
+        float* logits_out = const_cast<float*>(a.logits);
+        const unsigned grid1 = (unsigned)(n_tab + n_pool + a.N * tiles);
+        if (head_C == 16 && head->rel)
+            BXI_LAUNCH("head_prep", s, (head_prep3_kernel<16, true>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, up_prj, g_logits, *head, head->params, logits_out);
+        else if (head_C == 16)
+            BXI_LAUNCH("head_prep", s, (head_prep3_kernel<16, false>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, up_prj, g_logits, *head, head->params, logits_out);
+        else if (head_C == 8 && head->rel)
+            BXI_LAUNCH("head_prep", s, (head_prep3_kernel<8, true>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, up_prj, g_logits, *head, head->params, logits_out);
+        else if (head_C == 8)
+            BXI_LAUNCH("head_prep", s, (head_prep3_kernel<8, false>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, up_prj, g_logits, *head, head->params, logits_out);
+        else
+            return BXI_ERR_UNSUPPORTED;
+    } else {
+        const size_t lds_stream = stream_red_off(a.h, a.w) + 4 * 20;
+        if (lds1 < lds_stream) lds1 = lds_stream;
+        if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
+        BXI_LAUNCH("prep", s, prep3_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R,
+                   color_thresh, ws, st, up_prj, g_logits, vec, env_pool_first);
+    }
+    rc = check_launch();
+    if (rc != BXI_OK) return rc;
+    if (!pooled_in_launch) {
+        rc = launch_pool(batch, a.stride, nullptr, ws.lab_planar, s);
+        if (rc != BXI_OK) return rc;
+        const int64_t BP = (int64_t)batch->B * a.h * a.w;
+        BXI_LAUNCH("pack_lab4", s, pack_lab4_kernel, dim3((unsigned)((BP + 255) / 256 > 2048 ? 2048 : (BP + 255) / 256)), dim3(256), 0, s,
+                   (const float*)ws.lab_planar, ws.lab4, batch->B, (int64_t)a.h * a.w);
+        BXI_LAUNCH("affinity_all", s, affinity_all_kernel, dim3((unsigned)((n_items + kWaves - 1) / kWaves > 2048 ? 2048 : (n_items + kWaves - 1) / kWaves)),
+                   dim3(256), 0, s, a, pa.meta, ws, dil, color_thresh, n_items);
+        rc = check_launch();
+        if (rc != BXI_OK) return rc;
+    }
+
+    // ---- launch 2 --------------------------------------------------------------------------------------------------
+    const int64_t cap = eval_cap(a.N, a.h, a.w, dil, R);
+    int64_t n_mb = (cap + kWaves - 1) / kWaves;
+    // the list length is device data: the tile waves stride through it; the launch should be resident in one round
+    static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 3);
+    const int room2 = env_pair_wgs * device_cus() - 1;
+    if (n_mb > (room2 > 64 ? room2 : 64)) n_mb = room2 > 64 ? room2 : 64;
+    const size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
+    const int grid = (int)n_mb + 1;                 // + the finisher
+#define BXI_PAIR_CASE(DD)                                                                                            \
+    case DD:                                                                                                         \
+        if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, ws, st, losses, g_logits, up_prj, up_pw, n_items);   \
+        else launch_pair<DD, 8>(s, grid, lds2, a, warmup, ws, st, losses, g_logits, up_prj, up_pw, n_items);          \
+        break;
+    switch (dil) {
+        BXI_PAIR_CASE(1) BXI_PAIR_CASE(2) BXI_PAIR_CASE(3) BXI_PAIR_CASE(4)
+        default: return BXI_ERR_UNSUPPORTED;
+    }
+#undef BXI_PAIR_CASE
+    return check_launch();
+}
+
+int launch_rescale3(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits, void* stream) {
+    using namespace v3;
+    InstArgs a;
+    int rc = fill_inst(in, a);
+    if (rc != BXI_OK) return rc;
+    if (!eval3_supported(dil)) return BXI_ERR_UNSUPPORTED;
+    if (a.N == 0) return BXI_OK;
+    if (!g_prj || !g_pw || !state || !g_logits) return BXI_ERR_NULL_POINTER;
+    if (a.N > 65535) return BXI_ERR_BAD_SHAPE;
+    if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
+    LossState st;
+    carve_state(const_cast<void*>(state), a.N, a.h, a.w, &st);
+    hipStream_t s = as_stream(stream);
+    BXI_LAUNCH("rescale", s, rescale3_kernel, dim3(8, a.N), dim3(256), 0, s, a, dil, st, g_prj, g_pw, g_logits);
+    return check_launch();
+}
+
+int eval3_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    if (!workspace || workspace_bytes < v3::kSyncBytes || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
+    if (hipMemsetAsync(workspace, 0, v3::kSyncBytes, as_stream(stream)) != hipSuccess) { set_last_hip_error((int)hipGetLastError()); return BXI_ERR_LAUNCH; }
+    return BXI_OK;
+}
+
+}  // namespace bxi
+
+#ifdef BXI_TRACE
+extern "C" int bxi_debug_set_trace3(void* buf) {   // developer builds only
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(bxi::g_trace), &buf, sizeof(buf));
+}
+#endif

@@ -118,15 +118,6 @@ static size_t carve_eval(void* base, int N, int h, int w, EvalWs* ws) {
     return off;
 }
 
-// 16-byte store that is written through to memory as it is issued (sc1: agent scope) instead of staying dirty in this
-// XCD's L2 until the end-of-kernel write-back: the 6.5 MB zero-fill then drains while the launch is still reading, not in
-// a burst at the kernel boundary that the next launch's first loads queue behind.
-__device__ __forceinline__ void store4_through(float* p, float x, float y, float z, float w) {
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    const f4v v = {x, y, z, w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-
 // ================================================================================================
 // prep_kernel
 // ================================================================================================
@@ -449,7 +440,7 @@ __global__ __launch_bounds__(256, 7) void head_prep_kernel(PoolArgs pa, int n_po
         unsigned long long* ckeys = reinterpret_cast<unsigned long long*>(smem);          // [4][64]
         float* otile = reinterpret_cast<float*>(ckeys + 4 * 64);                          // [16][64]
         float* ytile = otile + 16 * 64;                                                   // [(kYR+2)*(kYC+2)]
-        const DynEpi ep = {ws.colpart, ws.rowkey, g_logits, ws.n_cb, ws.n_rp};
+        const DynEpi ep = {ws.colpart, ws.rowkey, g_logits, ws.n_cb, ws.n_rp, 0};
         dyn_tile_forward<C, REL, 2, true>(da, params, logits_out, n, ty, tx, ytile, otile, ckeys, ep);
     }
 }

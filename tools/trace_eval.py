@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): run one cfg-2 evaluation with the -DBXI_TRACE library and print per-wave phase timings
-(100 MHz wall clock) of prep_kernel / pair_kernel.  Build first:
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBXI_TRACE -o boxinstseg_amd/lib/libboxinst_hip_trace.so boxinstseg_amd/csrc/*.hip"""
+(100 MHz wall clock) of prep3_kernel / pair3_kernel (csrc/eval3.hip).  Build first:
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBXI_TRACE -mllvm -amdgpu-kernarg-preload-count=16 \
+        -o boxinstseg_amd/lib/libboxinst_hip_trace.so boxinstseg_amd/csrc/*.hip"""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -9,7 +10,7 @@ from boxinstseg_amd import _lib, build as hb
 hb.LIB_PATH = os.path.join(hb.LIB_DIR, 'libboxinst_hip_trace.so')
 from boxinstseg_amd import functional as Fh, synthetic
 lib = _lib.load()
-lib.bxi_debug_set_trace2.argtypes = [C.c_void_p]
+lib.bxi_debug_set_trace3.argtypes = [C.c_void_p]
 dev = torch.device('cuda:0')
 ones = torch.ones(2, device=dev)
 sets = []
@@ -21,6 +22,7 @@ for seed in range(8):
     losses = torch.zeros(2, device=dev); grad = torch.empty_like(inst.logits)
     state = torch.empty(lib.bxi_boxinst_loss_state_bytes(inst.N, inst.h, inst.w), dtype=torch.uint8, device=dev)
     ws = torch.empty(lib.bxi_boxinst_eval_workspace_bytes(2, 800, 1024, 4, inst.N), dtype=torch.uint8, device=dev)
+    assert lib.bxi_boxinst_eval_workspace_init(ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream) == 0
     sets.append((batch, inst, losses, grad, state, ws, imgs, logits, gi, boxes))
 st = torch.cuda.current_stream().cuda_stream
 def ev(s):
@@ -31,37 +33,48 @@ def ev(s):
 for i in range(60): ev(sets[i % 8])
 torch.cuda.synchronize()
 trace = torch.zeros((4, 8192, 8), dtype=torch.int64, device=dev)
-assert lib.bxi_debug_set_trace2(trace.data_ptr()) == 0
+assert lib.bxi_debug_set_trace3(trace.data_ptr()) == 0
 torch.cuda._sleep(int(0.02 * 2e9)); ev(sets[3]); torch.cuda.synchronize()
 t = trace.cpu().numpy().astype(np.float64)
 us = lambda x: x * 0.01
 N, Sn = 32, 7
-n_tab, n_stream = 8 * 4, N * Sn * 4
+pool_first = int(os.environ.get('BXI_POOL_FIRST', '1'))
+n_tab = 1 * 4
+n_stream = N * Sn * 4
 p = t[0]; live = p[:, 0] > 0
+n_live = int(np.nonzero(live)[0].max()) + 1
+n_pool = n_live - n_tab - n_stream
 t0 = p[live, 0].min()
 def q(x): return np.round(np.quantile(x, [0, .25, .5, .75, 1]), 2).tolist() if len(x) else []
+def d(a, b): return np.where((a > 0) & (b > 0), a - b, np.nan)
+def qd(a, b):
+    x = d(a, b); x = x[~np.isnan(x)]
+    return q(us(x))
 print('prep: waves', int(live.sum()), 'start', q(us(p[live, 0] - t0)), 'end', q(us(p[live, 7] - t0)))
 tab = p[:n_tab]; tab = tab[tab[:, 7] > 0]
 print('  table waves end', q(us(tab[:, 7] - t0)))
-sw = p[n_tab:n_tab + n_stream]; sw = sw[sw[:, 7] > 0]
-print('  stream waves: start', q(us(sw[:, 0] - t0)), '| loads+zero-fill issued', q(us(sw[:, 1] - sw[:, 0])), '| data + column max', q(us(sw[:, 2] - sw[:, 1])),
-      '| butterflies', q(us(sw[:, 3] - sw[:, 2])), '| barrier', q(us(sw[:, 4] - sw[:, 3])), '| end', q(us(sw[:, 7] - t0)))
-pw = p[n_tab + n_stream:]; pw = pw[pw[:, 7] > 0]
-print('  pool waves:', len(pw), 'start', q(us(pw[:, 0] - t0)), '| loads + denorm', q(us(pw[:, 1] - pw[:, 0])), '| barrier 1', q(us(pw[:, 2] - pw[:, 1])),
-      '| Lab f', q(us(pw[:, 3] - pw[:, 2])), '| barrier 2', q(us(pw[:, 4] - pw[:, 3])), '| end', q(us(pw[:, 7] - t0)))
+if pool_first:
+    pw = p[n_tab:n_tab + n_pool]; sw = p[n_tab + n_pool:n_tab + n_pool + n_stream]
+else:
+    sw = p[n_tab:n_tab + n_stream]; pw = p[n_tab + n_stream:n_live]
+sw = sw[sw[:, 7] > 0]; pw = pw[pw[:, 7] > 0]
+print('  stream waves:', len(sw), 'start', q(us(sw[:, 0] - t0)), '| loads+zero-fill issued', qd(sw[:, 1], sw[:, 0]), '| data + column max', qd(sw[:, 2], sw[:, 1]),
+      '| butterflies', qd(sw[:, 3], sw[:, 2]), '| barrier', qd(sw[:, 4], sw[:, 3]), '| end', q(us(sw[:, 7] - t0)))
+ld = sw[sw[:, 5] > 0]
+print('    leaders:', len(ld), 'partials + arrival', qd(ld[:, 5], ld[:, 4]), '| leader work', qd(ld[:, 6], ld[:, 5]), '| arrived at', q(us(ld[:, 5] - t0)), '| end', q(us(ld[:, 7] - t0)))
+nl = sw[sw[:, 5] == 0]
+print('    others: partials + arrival', qd(nl[:, 7], nl[:, 4]))
+print('  pool waves (last item of each):', len(pw), 'start', q(us(pw[:, 0] - t0)), '| loads + denorm at', q(us(pw[:, 1] - t0)), '| barrier 1', qd(pw[:, 2], pw[:, 1]),
+      '| Lab f', qd(pw[:, 3], pw[:, 2]), '| Lab stored + barriers', qd(pw[:, 4], pw[:, 3]), '| arrival returned', qd(pw[:, 5], pw[:, 4]),
+      '| segment task (or none)', qd(pw[:, 6], pw[:, 5]), '| end', q(us(pw[:, 7] - t0)))
 prep_end = p[live, 7].max()
-ld = t[3]; ld = ld[ld[:, 0] > 0]
-k0 = min(ld[:, 0].min(), t[1][t[1][:, 0] > 0, 0].min(), t[2][t[2][:, 0] > 0, 0].min())
-print('pair: first wave starts %.2f us after the last prep wave ended' % us(k0 - prep_end))
-print('  leaders', len(ld), 'start', q(us(ld[:, 0] - k0)), '| loads+maxima', q(us(ld[:, 1] - ld[:, 0])), '| sums', q(us(ld[:, 2] - ld[:, 1])),
-      '| coefs published', q(us(ld[:, 3] - ld[:, 2])), '| flag at', q(us(ld[:, 3] - k0)), '| sparse', q(us(ld[:, 4] - ld[:, 3])), '| arrive', q(us(ld[:, 5] - ld[:, 4])), '| end', q(us(ld[:, 5] - k0)))
-cw = t[2]; allc = cw[cw[:, 0] > 0]; cw = allc[allc[:, 3] > 0]
-print('  count waves with a tile', len(cw), 'of', len(allc), 'start', q(us(cw[:, 0] - k0)), '| record+flags', q(us(cw[:, 1] - cw[:, 0])), '| Lab arrived', q(us(cw[:, 2] - cw[:, 1])),
-      '| predicates', q(us(cw[:, 3] - cw[:, 2])), '| counted at', q(us(cw[:, 3] - k0)))
 mw = t[1]; allm = mw[mw[:, 0] > 0]; mw = allm[allm[:, 5] > 0]
-print('  math waves with a tile', len(mw), 'of', len(allm), 'start', q(us(mw[:, 0] - k0)), '| record+flags', q(us(mw[:, 1] - mw[:, 0])), '| data arrived', q(us(mw[:, 2] - mw[:, 1])),
-      '| pair math', q(us(mw[:, 3] - mw[:, 2])), '| sum W + coefficients', q(us(mw[:, 4] - mw[:, 3])), '| stores issued', q(us(mw[:, 5] - mw[:, 4])),
-      '| arrival', q(us(mw[:, 6] - mw[:, 5])), '| stores issued at', q(us(mw[:, 5] - k0)), '| end', q(us(mw[:, 6] - k0)))
+k0 = allm[:, 0].min()
+print('pair: first wave starts %.2f us after the last prep wave ended' % us(k0 - prep_end))
+print('  tile waves with a tile', len(mw), 'of', len(allm), 'start', q(us(mw[:, 0] - k0)), '| table -> tile', qd(mw[:, 1], mw[:, 0]), '| data arrived + masks', qd(mw[:, 2], mw[:, 1]),
+      '| pair math', qd(mw[:, 3], mw[:, 2]), '| stores issued', qd(mw[:, 4], mw[:, 3]), '| arrival issued', qd(mw[:, 5], mw[:, 4]), '| end', q(us(mw[:, 5] - k0)))
+fw = t[3][0]
+print('  finisher: start %.2f end %.2f' % (us(fw[0] - k0), us(fw[1] - k0)))
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 np.savez_compressed(os.path.join(ROOT, 'gpurun_out', 'trace.npz'), trace=trace.cpu().numpy())
 print('losses', float(sets[3][2][0]), float(sets[3][2][1]))
