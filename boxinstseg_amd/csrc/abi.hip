@@ -87,6 +87,8 @@ int bxi_boxinst_eval_workspace_init(void* workspace, size_t workspace_bytes, voi
     return bxi::eval3_workspace_init(workspace, workspace_bytes, stream);
 }
 
+size_t bxi_boxinst_eval_workspace_lab_offset(void) { return bxi::up256(bxi::eval3_sync_bytes()); }
+
 int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host, int size, int dilation,
                          float color_thresh, float warmup, const float* up_prj, const float* up_pw, float* losses,
                          float* g_logits, void* state, void* workspace, size_t workspace_bytes, void* stream) {

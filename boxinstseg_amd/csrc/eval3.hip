@@ -1,5 +1,5 @@
-// eval3.hip -- the BoxInst loss evaluation (forward AND finished backward) in TWO launches on gfx950, with NO workgroup ever
-// waiting for another one.
+// eval3.hip -- the BoxInst loss evaluation (forward AND finished backward) in TWO launches on gfx950, in which no workgroup
+// ever waits for the RESULT OF ANOTHER WORKGROUP'S COMPUTATION inside a launch.
 //
 // Replaces (reference, LiWentomng/BoxInstSeg) CondInstMaskHead.loss with boxinst_enabled,
 // condinst_head.py:1288-1343, together with everything it calls:
@@ -9,31 +9,38 @@
 //   pairwise_nlog (CUDA op, pairwise.cu:68-149) + weights / normalise / warm-up   :1315-1332
 // and what autograd does behind them, with the upstream factors folded in.
 //
-// Everything the second launch needs is FINISHED by the first one, so its tile waves read plain post-boundary data:
 //   launch 1  prep3_kernel   256-thread workgroups, three roles                                          HBM stream
 //     table waves   per-instance table (tile prefix, box cells, image, valid-cell limits): 16 bytes per instance
-//     pool blocks   the 4 input rows of 64 pooled pixels -> de-normalise, truncate, 4x4 mean, Lab (fp64) -> one 16-byte
-//                   write-through store per pooled pixel; then each of the block's 4 waves ARRIVES on one of the (up to) four
-//                   row segments whose colour pairs this segment completes; the wave whose arrival is the last one evaluates
-//                   that segment: the four colour predicates per pixel (one byte) and the segment's share of the pair-weight
+//     stream blocks 4 waves x 8 rows of one instance map: zero-fill of g_logits (written through), row maxima, column maxima
+//                   of the block's 32 rows -> partials for the leaders of the next launch
+//     pool blocks   the 4 input rows of 64 pooled pixels -> de-normalise, truncate, 4x4 mean, Lab (fp64) -> ONE 16-byte
+//                   write-through store per pooled pixel (L, a, b, tag of this evaluation).  When its last image load has
+//                   returned, each of the block's 4 waves ARRIVES (one integer atomic) on one of the (up to) four row segments
+//                   whose colour pairs the block's segment takes part in; the wave whose arrival is the last one evaluates that
+//                   segment: the four colour predicates per pixel (one byte) and the segment's share of the pair-weight
 //                   normaliser  sum W  (a function of the image and the boxes only, :1324-1328) -> integer atomics.
-//     stream blocks 4 waves x 8 rows of one instance map: zero-fill of g_logits, row maxima, column maxima of the block's
-//                   32 rows -> partials (write-through); the block whose arrival is the instance's last one is its LEADER:
-//                   maxima -> sigmoid -> dice -> unit projection gradients, the arg-max positions outside the box tiles.
-//   launch 2  pair3_kernel   one wave64 per box tile (no LDS, no barrier, no wait): logits tile + halo in registers, every
-//                   unordered pair evaluated once, gradient stored finished:  g = g_pw warm/max(sum W,1) d pw + g_prj d prj;
-//                   its share of sum W pw goes to an integer accumulator by an atomic without return.
+//                   So sum W and the predicates are FINISHED when the launch ends.
+//   launch 2  pair3_kernel   [leaders][tile blocks][finisher]; nothing in it waits except the finisher
+//     leaders       one block per instance: partial maxima -> maxima -> sigmoid -> dice -> unit projection gradients, ADDED
+//                   (float atomic) at the arg-max positions of the zero-filled gradient
+//     tile waves    one wave64 per box tile (no LDS, no barrier): logits tile + halo in registers, every unordered pair
+//                   evaluated once; g_pw warm/max(sum W,1) d pw is ADDED (float atomic) to the gradient -- an element receives
+//                   at most two additions onto 0 (its tile's and its leader's), so the sum does not depend on their order;
+//                   the tile's share of sum W pw goes to an integer accumulator by an atomic without return.
 //     finisher      the last workgroup: polls the accumulators (bounded), writes the two loss values -- NaN and a status word
 //                   when anything in either launch was inconsistent -- and leaves every counter zero for the next evaluation.
-// "Last arrival continues" needs no forward-progress assumption: nobody spins on anybody (the finisher waits for workgroups
-// that never wait, whatever the dispatch order).  The counters live in a fixed region at the start of the workspace that
-// is zero between evaluations (bxi_boxinst_eval_workspace_init once, then every evaluation cleans up after itself).
+// "Last arrival continues" needs no forward-progress assumption: nobody spins on a workgroup that may not have been dispatched
+// (the finisher waits for workgroups that never wait; a segment task re-reads a pixel only while a store that HAS been issued
+// is still on its way).  The counters live in a fixed region at the start of the workspace that is zero between evaluations
+// (bxi_boxinst_eval_workspace_init once, then every evaluation cleans up after itself).
 // Data layout in HBM: everything NCHW / row-major as the reference hands it over; intermediates: Lab [B,h,w] float4 (1.6 MB at
 // 2x800x1024), predicate bytes [B,h,w], column / row partial maxima, 16-byte table entries.
 #include "loss_common.hpp"
 #include "dynamic_head_device.hpp"
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
+#include <cmath>
 
 namespace bxi {
 namespace v3 {
@@ -44,12 +51,12 @@ constexpr int kSBlk = kWaves * kSRows;          // rows per stream workgroup
 constexpr int kChunkC = 256;                    // columns per pass of a stream wave: 64 lanes x float4
 constexpr int kMaxDilFused = 4;
 constexpr unsigned kSpinLimit = 400000;         // finisher polls (~0.5 us each): far beyond any launch
+constexpr int kTagRetries = 4096;               // re-reads of a pixel whose store has been issued but has not landed yet
 constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
 constexpr int kSumWords = 64;                   // sum W: 64 words, each in its own 128 bytes
 constexpr int kMaxItems = 1 << 18;              // pooled row segments per batch the fixed counter region covers
 constexpr int kMaxInst = 65536;
-constexpr int kRectCap = 256;                   // instance rectangles staged in LDS by a pool block
-constexpr unsigned kFaultFinisher = 2u, kFaultItemCount = 4u, kFaultInstCount = 8u;
+constexpr unsigned kFaultFinisher = 2u, kFaultItemCount = 4u, kFaultTag = 8u;
 
 #ifdef BXI_TRACE
 #define BXI_TW(kid, idx, ph)                                                                                  \
@@ -64,26 +71,30 @@ constexpr unsigned kFaultFinisher = 2u, kFaultItemCount = 4u, kFaultInstCount = 
 #define BXI_RLX __ATOMIC_RELAXED
 #define BXI_AGENT __HIP_MEMORY_SCOPE_AGENT
 
+// float add at the L2 without return (global_atomic_add_f32): the gradient is zero-filled by launch 1 and every element
+// receives at most two additions, so the result does not depend on their order
+__device__ __forceinline__ void add_f32(float* p, float v) {
+    (void)__builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)p, v);
+}
+
 // ---- workspace ---------------------------------------------------------------------------------------------------------
 // [sync region: zero between evaluations][Lab][predicate bytes][partials][table][accumulators]
-constexpr size_t kSyncFault = 0, kSyncSumw = 256, kSyncInst = kSyncSumw + (size_t)kSumWords * 128,
-                 kSyncItem = kSyncInst + 4 * (size_t)kMaxInst, kSyncBytes = kSyncItem + 4 * (size_t)kMaxItems;
+constexpr size_t kSyncFault = 0, kSyncSumw = 256, kSyncItem = kSyncSumw + (size_t)kSumWords * 128,
+                 kSyncBytes = kSyncItem + 4 * (size_t)kMaxItems;
 
 struct Ws {
     unsigned int* fault;                        // [1]   bit mask of protocol inconsistencies seen by launch 1 (never expected)
     unsigned long long* sumw;                   // [kSumWords] (one per 128 B) sum W, added by the pool blocks' segment tasks
-    unsigned int* inst_cnt;                     // [N]   stream-block arrivals of the instance
     unsigned int* item_cnt;                     // [B*h*segs] arrivals on a pooled row segment
-    float4* lab4;                               // [B,h,w] (L, a, b, 0)
+    float4* lab4;                               // [B,h,w] (L, a, b, tag)
     unsigned char* pred;                        // [B,h,w] bit d = colour predicate of pair direction d with this pixel as (i, l)
     float* lab_planar;                          // [B,3,h,w] only the generic pooling path (other strides, unaligned canvases) fills it
     unsigned long long* colpart;                // [N,n_cb,w] packed (max logit, first row) of a band of rows
     unsigned long long* rowkey;                 // [N,n_rp,h] packed (max logit, first column)
     int n_cb, n_rp;
     int4* tab;                                  // [N+1] {tile prefix | img << 24, r0 | r1 << 16, c0 | c1 << 16, vrow | vcol << 16}; [N].x = tiles
-    int4* hdr;                                  // [1]   {bits of n2max, zero_bit, R, 0}
     unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B) arrivals << 52 | sum (W pw + 1) in 2^-24 units
-    float* dice;                                // [N]   dice loss of the instance (both axes)
+    unsigned long long* dice;                   // [N]   leader: 1 << 32 | bits of the instance's dice loss (0 = not published)
 };
 
 __device__ __forceinline__ unsigned long long* acc2_word(unsigned long long* acc2, int n, int sub) {
@@ -94,13 +105,6 @@ static inline int tile_width(int dil) { return 64 - 2 * dil; }
 static inline int64_t eval_cap(int N, int h, int w, int dil, int R) {
     const int tw = tile_width(dil);
     return (int64_t)(N > 0 ? N : 1) * ((h + R - 1) / R) * ((w + tw - 1) / tw);
-}
-
-// LDS of the leader: [w] + [h] floats, [w] + [h] ints, then 16 floats + a flag word of scratch
-__host__ __device__ inline size_t leader_bytes(int h, int w) { return ((2 * sizeof(float) * (size_t)(h + w)) + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t stream_red_off(int h, int w) {      // a stream block's scratch: behind its column buffer AND the leader's arrays
-    const size_t a = 8 * (size_t)kWaves * w, b = leader_bytes(h, w);
-    return a > b ? a : b;
 }
 
 static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
@@ -114,7 +118,6 @@ static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
     char* sync = (char*)take(kSyncBytes);
     t.fault = (unsigned int*)(sync ? sync + kSyncFault : nullptr);
     t.sumw = (unsigned long long*)(sync ? sync + kSyncSumw : nullptr);
-    t.inst_cnt = (unsigned int*)(sync ? sync + kSyncInst : nullptr);
     t.item_cnt = (unsigned int*)(sync ? sync + kSyncItem : nullptr);
     const size_t P = (size_t)h * w, B1 = B > 0 ? B : 1;
     t.lab4 = (float4*)take(16 * B1 * P);
@@ -124,9 +127,8 @@ static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
     t.rowkey = (unsigned long long*)take(8 * (size_t)N1 * h * (rp_max > 1 ? rp_max : 1));
     t.n_cb = (int)Sn; t.n_rp = 1;
     t.tab = (int4*)take(16 * (size_t)(N1 + 1));
-    t.hdr = (int4*)take(16);
     t.acc2 = (unsigned long long*)take(8 * (size_t)N1 * kAcc2Split * kAcc2Stride);
-    t.dice = (float*)take(4 * (size_t)N1);
+    t.dice = (unsigned long long*)take(8 * (size_t)N1);
     if (ws) *ws = t;
     return off;
 }
@@ -164,8 +166,7 @@ __device__ __forceinline__ LaneBox lane_box(const InstArgs& a, const ImageMeta& 
     return lb;
 }
 
-__device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& meta, int dil, int R, float thresh, const Ws& ws,
-                                           const LossState& st, int k) {
+__device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& meta, int dil, int R, const Ws& ws, const LossState& st, int k) {
     const int lane = threadIdx.x & 63;
     int base = 0, prefix = 0;
     LaneBox mine = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -186,137 +187,21 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
     if (m < a.N) {
         ws.tab[m] = make_int4(prefix | (mine.img << 24), mine.r0 | (mine.r1 << 16), mine.c0 | (mine.c1 << 16), mine.vrow | (mine.vcol << 16));
         if (st.inst) { InstRec rc; rc.r0 = mine.r0; rc.r1 = mine.r1; rc.c0 = mine.c0; rc.c1 = mine.c1; rc.img = mine.img; rc.pad0 = rc.pad1 = rc.pad2 = 0; st.inst[m] = rc; }
+        // the words the next launch's finisher polls: zeroed here, i.e. before a kernel boundary
 #pragma unroll
-        for (int sub = 0; sub < kAcc2Split; ++sub) *acc2_word(ws.acc2, m, sub) = 0ull;     // polled after a kernel boundary
+        for (int sub = 0; sub < kAcc2Split; ++sub) *acc2_word(ws.acc2, m, sub) = 0ull;
+        ws.dice[m] = 0ull;
     } else if (m == a.N) {
         ws.tab[m] = make_int4(prefix, 0, 0, 0);
     }
-    if (k == 0 && lane == 0) {
-        const Pred pr = make_pred(thresh);
-        *ws.hdr = make_int4(__float_as_int(pr.n2max), pr.zero_bit, R, 0);
-        if (st.status) st.status[1] = R;
-    }
+    if (k == 0 && lane == 0 && st.status) st.status[1] = R;
 }
 
-// ---- role 2: stream block = 4 waves x 8 rows of one instance map; the instance's last block to arrive is its leader ----
+// ---- role 2: stream block = 4 waves x 8 rows of one instance map ---------------------------------------------------------
 struct LogitRows {
     const float* L; int w, vec;
     __device__ __forceinline__ float4 operator()(int r, int c) const { return load4(L + (int64_t)r * w, c, w, vec); }
 };
-
-__device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = wave_total_f32(v[k]);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) red[(threadIdx.x >> 6) * 4 + k] = v[k];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]);
-}
-__device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
-
-// The leader of instance n (a whole workgroup): every band's partials are in memory (the arrival counter said so).
-//   partial maxima -> maxima -> sigmoid on those only -> both dice terms (:117-143) -> unit projection gradients, published as
-//   one 8-byte word per column / row (gradient bits << 32 | arg-max index) for the tile waves of the next launch and for
-//   bxi_boxinst_grad_rescale_f32; the projection gradient at the arg-max positions OUTSIDE the tile hull is written here
-//   (every zero-fill of this instance was written through and drained before its block arrived).
-__device__ __forceinline__ void leader_block(const InstArgs& a, int dil, int R, const Ws& ws, const LossState& st, int n, float upp,
-                                             float* __restrict__ g_logits, unsigned char* smem, float* red) {
-    const int h = a.h, w = a.w, tid = threadIdx.x;
-    float* xs = reinterpret_cast<float*>(smem);   // [w] sigmoid of the column maxima, then their unit gradients
-    float* ys = xs + w;                           // [h]
-    int* carg = reinterpret_cast<int*>(ys + h);   // [w]
-    int* rarg = carg + w;                         // [h]
-    const InstBox ib = inst_box(a, n, dil);
-    float sums[4] = {0.f, 0.f, 0.f, 0.f};   // I_x, U_x, I_y, U_y
-    // written by other workgroups of this launch: read past this CU's L1 (relaxed agent-scope loads = sc1)
-    auto best_key = [](const unsigned long long* part, int n_part, int64_t stride) {
-        unsigned long long k = 0ull;
-        for (int s0 = 0; s0 < n_part; s0 += 8) {
-            unsigned long long o[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) o[u] = __hip_atomic_load(part + (int64_t)min(s0 + u, n_part - 1) * stride, BXI_RLX, BXI_AGENT);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) k = o[u] > k ? o[u] : k;
-        }
-        return k;
-    };
-    for (int i = tid; i < max(w, h); i += 256) {
-        const bool is_c = i < w, is_r = i < h;
-        const unsigned long long kc = best_key(ws.colpart + (int64_t)n * ws.n_cb * w + (is_c ? i : 0), ws.n_cb, w);
-        const unsigned long long kr = best_key(ws.rowkey + (int64_t)n * ws.n_rp * h + (is_r ? i : 0), ws.n_rp, h);
-        if (is_c) {
-            const int c = i;
-            const float X = sigmoid_acc(unpack_val(kc));
-            const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
-            xs[c] = X; carg[c] = (int)unpack_idx(kc);
-            sums[0] += X * TX; sums[1] += X * X + TX * TX;
-        }
-        if (is_r) {
-            const int r = i;
-            const float Y = sigmoid_acc(unpack_val(kr));
-            const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
-            ys[r] = Y; rarg[r] = (int)unpack_idx(kr);
-            sums[2] += Y * TY; sums[3] += Y * Y + TY * TY;
-        }
-    }
-    block_sum4(sums, red);
-    const float Ix = sums[0], Ux = sums[1] + 1e-5f, Iy = sums[2], Uy = sums[3] + 1e-5f;
-    if (tid == 0) ws.dice[n] = (1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy);      // :130, summed over both axes :143
-    if (g_logits) {
-        // dice = 1 - 2I/U ; d dice/d u_j = (-2 t_j U + 4 I u_j) / U^2 ; chain through sigmoid ; mean over N
-        const float invN = 1.f / (float)a.N;
-        for (int c = tid; c < w; c += 256) {
-            const float X = xs[c];
-            const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
-            const float gv = invN * ((-2.f * TX * Ux + 4.f * Ix * X) / (Ux * Ux)) * X * (1.f - X);
-            xs[c] = gv;
-            st.colk[(int64_t)n * w + c] = ((unsigned long long)__float_as_uint(gv) << 32) | (unsigned int)carg[c];
-        }
-        for (int r = tid; r < h; r += 256) {
-            const float Y = ys[r];
-            const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
-            const float gv = invN * ((-2.f * TY * Uy + 4.f * Iy * Y) / (Uy * Uy)) * Y * (1.f - Y);
-            ys[r] = gv;
-            st.rowk[(int64_t)n * h + r] = ((unsigned long long)__float_as_uint(gv) << 32) | (unsigned int)rarg[r];
-        }
-        __syncthreads();      // xs / ys now hold the gradients for every thread
-        // the tile waves own every pixel of the tile hull: rows of the R-aligned tiles x columns of the dilated box
-        const int hr0 = ib.any ? (ib.dil.r0 / R) * R : 0, hr1 = ib.any ? min(h, ((ib.dil.r1 + R - 1) / R) * R) : 0;
-        const int hc0 = ib.dil.c0, hc1 = ib.any ? ib.dil.c1 : 0;
-        float* G = g_logits + (int64_t)n * h * w;
-        for (int c = tid; c < w; c += 256) {
-            const int r = carg[c];
-            const bool in_t = r >= hr0 && r < hr1 && c >= hc0 && c < hc1;
-            if (!in_t) {
-                float v = xs[c];
-                if (rarg[r] == c) v += ys[r];
-                G[(int64_t)r * w + c] = v * upp;
-            }
-        }
-        for (int r = tid; r < h; r += 256) {
-            const int c = rarg[r];
-            const bool in_t = r >= hr0 && r < hr1 && c >= hc0 && c < hc1;
-            if (!in_t && carg[c] != r) G[(int64_t)r * w + c] = ys[r] * upp;
-        }
-    }
-}
-
-// Arrival of one workgroup on its instance; true (workgroup-uniform) for the last of `expected`.  Every store of the
-// workgroup that the leader depends on has been written through; this drains them first.
-__device__ __forceinline__ bool arrive_on_instance(const Ws& ws, int n, unsigned int expected, unsigned int* flag /* LDS */) {
-    drain_vmem();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int old = __hip_atomic_fetch_add(ws.inst_cnt + n, 1u, BXI_RLX, BXI_AGENT);
-        if (old + 1u > expected) atomicOr(ws.fault, kFaultInstCount);
-        *flag = old + 1u;
-    }
-    __syncthreads();
-    return *flag == expected;
-}
 
 template <typename Src>
 __device__ __forceinline__ void stream_block(const InstArgs& a, const Ws& ws, float* __restrict__ g_logits, int vec, int sb,
@@ -409,28 +294,19 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const Ws& ws, fl
         const int col = __builtin_amdgcn_readlane(rcol[i], first);
         if (lane == i) mine = pack_max(wmax[i], (uint32_t)col);
     }
-    if (lane < kSRows && r0 + lane < r1) __hip_atomic_store(&ws.rowkey[(int64_t)n * h + r0 + lane], mine, BXI_RLX, BXI_AGENT);   // sc1: written through
+    if (lane < kSRows && r0 + lane < r1) ws.rowkey[(int64_t)n * h + r0 + lane] = mine;
     BXI_TW(0, tix, 3);
     lds_barrier();
     BXI_TW(0, tix, 4);
-    unsigned long long* dstrow = ws.colpart + ((int64_t)n * Sn + s) * w;
-    const bool pairs = (w & 1) == 0;                          // then every (band, column pair) is 16-byte aligned
-    for (int c = 2 * (int)threadIdx.x; c < w; c += 2 * kWaves * 64) {
-        unsigned long long k0 = colp[c], k1 = c + 1 < w ? colp[c + 1] : 0ull;      // larger value, then smaller row
+    for (int c = threadIdx.x; c < w; c += kWaves * 64) {
+        unsigned long long k = colp[c];
 #pragma unroll
-        for (int u = 1; u < kWaves; ++u) {
-            const unsigned long long o0 = colp[(size_t)u * w + c], o1 = c + 1 < w ? colp[(size_t)u * w + c + 1] : 0ull;
-            k0 = o0 > k0 ? o0 : k0; k1 = o1 > k1 ? o1 : k1;
-        }
-        if (pairs) store_u64x2_through(dstrow + c, k0, k1);
-        else {
-            __hip_atomic_store(dstrow + c, k0, BXI_RLX, BXI_AGENT);
-            if (c + 1 < w) __hip_atomic_store(dstrow + c + 1, k1, BXI_RLX, BXI_AGENT);
-        }
+        for (int u = 1; u < kWaves; ++u) { const unsigned long long o = colp[(size_t)u * w + c]; k = o > k ? o : k; }
+        ws.colpart[((int64_t)n * Sn + s) * w + c] = k;       // larger value, then smaller row
     }
 }
 
-// ---- role 3: pool block = the 4 input rows of 64 pooled pixels, then the colour pairs its row segment completes --------
+// ---- role 3: pool block = the 4 input rows of 64 pooled pixels, then the colour pairs its row segments complete ---------
 __device__ __forceinline__ double lab_f(const double* lut, int i, int r8, int g8, int b8) {
     const double r = lut[r8], g = lut[g8], b = lut[b8];
     const double M[3][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}, {0.019334, 0.119193, 0.950227}};
@@ -470,17 +346,60 @@ __device__ __forceinline__ float lane_plus_n(float v, int d) {
     return __int_as_float(x);
 }
 
-struct Lab3 { float L, A, B; };
-__device__ __forceinline__ Lab3 lab_read(const float4* p) {   // written by another workgroup of this launch: past this CU's L1
-    const unsigned long long la = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), BXI_RLX, BXI_AGENT);
-    const unsigned int b = __hip_atomic_load(reinterpret_cast<const unsigned int*>(p) + 2, BXI_RLX, BXI_AGENT);
-    Lab3 o; o.L = __uint_as_float((unsigned int)la); o.A = __uint_as_float((unsigned int)(la >> 32)); o.B = __uint_as_float(b);
-    return o;
-}
-
 __device__ __forceinline__ int4 rect_entry(const InstArgs& a, int n) {
     const InstBox ib = inst_box(a, n, 0);
     return make_int4(ib.box.r0 | (ib.box.r1 << 16), ib.box.c0 | (ib.box.c1 << 16), ib.img, 0);
+}
+
+// Four 16-byte loads past this CU's L1 (sc1), waited for together.  The asm is invisible to the compiler's vmcnt bookkeeping,
+// which is harmless here: memory operations complete in order, so its own waits can only become longer.  Called only when no
+// image load of the wave is in flight any more (a wave consumes its loads in order: a load behind a prefetch would wait for it).
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load4_sc1(const float4* p0, const float4* p1, const float4* p2, const float4* p3, f4v& a, f4v& b, f4v& c, f4v& d) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
+
+// A pooled row segment (r, seg) of image b takes part in the colour pairs whose STEP segment is one of (r, seg), (r - D, seg),
+// (r, seg - 1), (r - D, seg - 1): a step segment T = (rt, sg) needs the Lab of (rt, sg), (rt + D, sg) and the first D pixels of
+// (rt, sg + 1), (rt + D, sg + 1).  Wave wv of the block that produced (r, seg) arrives on target wv (bit 0: row offset, bit 1:
+// segment offset); the target is complete when all its `expected` contributors have arrived.
+struct SegTask { int target; unsigned int expected; bool have, spec; };
+__device__ __forceinline__ SegTask seg_task(int item, int segs, int h, int dil, int wv) {
+    const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
+    const int rt = r - ((wv & 1) ? dil : 0), sg = seg - (wv >> 1);
+    SegTask t;
+    t.have = rt >= 0 && sg >= 0;
+    const bool hasD = rt + dil < h, hasS = sg + 1 < segs;
+    t.target = (b * h + rt) * segs + sg;
+    t.expected = (1u + (hasD ? 1u : 0u)) * (1u + (hasS ? 1u : 0u));
+    // the contributor with the highest item index arrives last when segments complete in dispatch order: it requests the
+    // target's Lab together with its arrival instead of after it (one round trip instead of two at the end of the launch);
+    // any other order is as correct, the last arrival then reads after it knows
+    t.spec = t.have && wv == ((hasD ? 1 : 0) | (hasS ? 2 : 0));
+    return t;
+}
+
+struct SegData { f4v o0, oD, x0, xD; };     // (rt, c) (rt + D, c) and the same D columns to the right, for the lanes that need them from memory
+__device__ __forceinline__ void seg_read(const Ws& ws, int D, int item, int segs, int h, int w, SegData& d) {
+    const int lane = threadIdx.x & 63;
+    const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
+    const int c = seg * 64 + lane;
+    const int cc = min(c, w - 1), cx = min(lane >= 64 - D ? c + D : c, w - 1), rD = min(r + D, h - 1);
+    const float4* L4 = ws.lab4 + (int64_t)b * h * w;
+    load4_sc1(L4 + (int64_t)r * w + cc, L4 + (int64_t)rD * w + cc, L4 + (int64_t)r * w + cx, L4 + (int64_t)rD * w + cx, d.o0, d.oD, d.x0, d.xD);
+}
+// every pixel the segment's pairs use carries this evaluation's tag, i.e. its (single, 16-byte) store has landed
+__device__ __forceinline__ bool seg_valid(const SegData& d, int D, int item, int segs, int h, int w, unsigned int tag) {
+    const int lane = threadIdx.x & 63;
+    const int seg = item % segs, r = (item / segs) % h;
+    const int c = seg * 64 + lane;
+    const bool rowD = r + D < h, fix = lane >= 64 - D && c + D < w;
+    bool ok = true;
+    if (c < w) { ok &= __float_as_uint(d.o0.w) == tag; if (rowD) ok &= __float_as_uint(d.oD.w) == tag; }
+    if (fix) { ok &= __float_as_uint(d.x0.w) == tag; if (rowD) ok &= __float_as_uint(d.xD.w) == tag; }
+    return __all(ok);
 }
 
 // One wave: the colour pairs whose step row is pooled row r of segment `seg` of image b -- directions (get_image_color_similarity
@@ -488,29 +407,21 @@ __device__ __forceinline__ int4 rect_entry(const InstArgs& a, int n) {
 //   0: (r, c) - (r, c+D)    1: (r+D, c) - (r, c+D)    2: (r, c) - (r+D, c)    3: (r, c) - (r+D, c+D)
 // -> one predicate byte per pixel (bit d: squared Lab distance <= n2max, i.e. sim >= thresh for a valid neighbour), and the
 // segment's share of  sum W = sum_n sum_{p in box n} sum_k [sim_k(p) >= thresh]  (:1324-1328): a pair (p, q) weighs
-// [p in box n][q valid] + [q in box n][p valid] for every instance n of the image.
-__device__ __forceinline__ void affinity_item(const InstArgs& a, const ImageMeta& meta, const Ws& ws, int D, const int4* rects, int nrect,
-                                              float n2max, int zero_bit, int item, int segs) {
+// [p in box n][q valid] + [q in box n][p valid] for every instance n of the image.  `rect`: lane n holds instance n's box cells.
+__device__ __forceinline__ void affinity_item(const InstArgs& a, const ImageMeta& meta, const Ws& ws, int D, float n2max, int zero_bit,
+                                              const SegData& d, int4 rect, int item, int segs) {
     const int h = a.h, w = a.w, lane = threadIdx.x & 63;
     const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
     const int c = seg * 64 + lane, cn = c + D;
     const bool rowD = r + D < h;                                  // wave-uniform
-    const float4* L4 = ws.lab4 + (int64_t)b * h * w;
-    const int cc = min(c, w - 1), ccn = min(cn, w - 1);
-    const Lab3 o0 = lab_read(L4 + (int64_t)r * w + cc);
-    const Lab3 oD = rowD ? lab_read(L4 + (int64_t)(r + D) * w + cc) : o0;
-    Lab3 n0, nD;
-    n0.L = lane_plus_n(o0.L, D); n0.A = lane_plus_n(o0.A, D); n0.B = lane_plus_n(o0.B, D);
-    nD.L = lane_plus_n(oD.L, D); nD.A = lane_plus_n(oD.A, D); nD.B = lane_plus_n(oD.B, D);
-    if (lane >= 64 - D) {                                         // the right neighbour lives in the next segment
-        n0 = lab_read(L4 + (int64_t)r * w + ccn);
-        nD = rowD ? lab_read(L4 + (int64_t)(r + D) * w + ccn) : n0;
-    }
+    float nL = lane_plus_n(d.o0.x, D), nA = lane_plus_n(d.o0.y, D), nB = lane_plus_n(d.o0.z, D);
+    float mL = lane_plus_n(d.oD.x, D), mA = lane_plus_n(d.oD.y, D), mB = lane_plus_n(d.oD.z, D);
+    if (lane >= 64 - D) { nL = d.x0.x; nA = d.x0.y; nB = d.x0.z; mL = d.xD.x; mA = d.xD.y; mB = d.xD.z; }   // the right neighbour lives in the next segment
     const bool cin = c < w, nin = cn < w;
-    const bool p0 = cin && nin && n2_of(o0.L, o0.A, o0.B, n0.L, n0.A, n0.B) <= n2max;
-    const bool p1 = cin && nin && rowD && n2_of(oD.L, oD.A, oD.B, n0.L, n0.A, n0.B) <= n2max;
-    const bool p2 = cin && rowD && n2_of(o0.L, o0.A, o0.B, oD.L, oD.A, oD.B) <= n2max;
-    const bool p3 = cin && nin && rowD && n2_of(o0.L, o0.A, o0.B, nD.L, nD.A, nD.B) <= n2max;
+    const bool p0 = cin && nin && n2_of(d.o0.x, d.o0.y, d.o0.z, nL, nA, nB) <= n2max;
+    const bool p1 = cin && nin && rowD && n2_of(d.oD.x, d.oD.y, d.oD.z, nL, nA, nB) <= n2max;
+    const bool p2 = cin && rowD && n2_of(d.o0.x, d.o0.y, d.o0.z, d.oD.x, d.oD.y, d.oD.z) <= n2max;
+    const bool p3 = cin && nin && rowD && n2_of(d.o0.x, d.o0.y, d.o0.z, mL, mA, mB) <= n2max;
     if (cin) ws.pred[((int64_t)b * h + r) * w + c] = (unsigned char)((p0 ? 1 : 0) | (p1 ? 2 : 0) | (p2 ? 4 : 0) | (p3 ? 8 : 0));
     if (zero_bit) return;        // thresh <= 0: every pair weighs 1, sum W has a closed form (pair3_kernel)
     const int vrow = valid_cells(min(meta.img_h[b], meta.first_removed[b]), a.stride, h), vcol = valid_cells(meta.img_w[b], a.stride, w);
@@ -518,37 +429,75 @@ __device__ __forceinline__ void affinity_item(const InstArgs& a, const ImageMeta
     // what a box containing the site adds:  (r, c)  (r, c+D)  (r+D, c)  (r+D, c+D)
     const int s00 = (p0 && v0n) + (p2 && vD0) + (p3 && vDn), s0n = (p0 && v00) + (p1 && vD0), sD0 = (p1 && v0n) + (p2 && v00), sDn = (p3 && v00) ? 1 : 0;
     int cnt = 0;
-    for (int n = 0; n < a.N; ++n) {                               // wave-uniform loop; rectangles from LDS (broadcast reads)
-        const int4 rc = n < nrect ? rects[n] : rect_entry(a, n);
-        if (rc.z != b) continue;
-        const int r0 = rc.x & 0xffff, r1 = (int)((unsigned int)rc.x >> 16), c0 = rc.y & 0xffff, c1 = (int)((unsigned int)rc.y >> 16);
-        const bool rr = r >= r0 && r < r1, rD = r + D >= r0 && r + D < r1;
-        if (!(rr || rD)) continue;
-        const bool c_in = c >= c0 && c < c1, n_in = cn >= c0 && cn < c1;
-        cnt += (rr && c_in ? s00 : 0) + (rr && n_in ? s0n : 0) + (rD && c_in ? sD0 : 0) + (rD && n_in ? sDn : 0);
+    for (int m0 = 0; m0 < a.N; m0 += 64) {
+        if (m0) rect = m0 + lane < a.N ? rect_entry(a, m0 + lane) : make_int4(0, 0, -1, 0);
+        // the instances of this image whose rows reach r or r + D: usually a handful
+        const int q0 = rect.x & 0xffff, q1 = (int)((unsigned int)rect.x >> 16);
+        unsigned long long mask = __ballot(m0 + lane < a.N && rect.z == b && ((r >= q0 && r < q1) || (r + D >= q0 && r + D < q1)));
+        while (mask) {
+            const int n = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            const int rx = __builtin_amdgcn_readlane(rect.x, n), ry = __builtin_amdgcn_readlane(rect.y, n);
+            const int r0 = rx & 0xffff, r1 = (int)((unsigned int)rx >> 16), c0 = ry & 0xffff, c1 = (int)((unsigned int)ry >> 16);
+            const bool rr = r >= r0 && r < r1, rD = r + D >= r0 && r + D < r1;
+            const bool c_in = c >= c0 && c < c1, n_in = cn >= c0 && cn < c1;
+            cnt += (rr && c_in ? s00 : 0) + (rr && n_in ? s0n : 0) + (rD && c_in ? sD0 : 0) + (rD && n_in ? sDn : 0);
+        }
     }
     cnt = wave_total_i32(cnt);
     if (lane == 0 && cnt)       // integer adds commute: run-to-run identical
         __hip_atomic_fetch_add(ws.sumw + (size_t)(item & (kSumWords - 1)) * kAcc2Stride, (unsigned long long)(unsigned int)cnt, BXI_RLX, BXI_AGENT);
 }
 
+// The block's waves, once no image load of theirs is in flight: arrivals for two of the block's segments at a time (both
+// atomics and the speculative reads in one round trip), then the tasks of the targets these arrivals completed.
+__device__ __forceinline__ void seg_arrive2(const InstArgs& a, const ImageMeta& meta, const Ws& ws, int dil, float n2max, int zero_bit, unsigned int tag,
+                                            int4 rect, int item0, int item1 /* -1: none */, int segs) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = a.h, w = a.w;
+    SegTask t[2];
+    t[0] = seg_task(item0, segs, h, dil, wv);
+    t[1] = seg_task(item1 >= 0 ? item1 : item0, segs, h, dil, wv);
+    if (item1 < 0) { t[1].have = false; t[1].spec = false; }
+    unsigned int old[2] = {0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (t[k].have && lane == 0) old[k] = __hip_atomic_fetch_add(ws.item_cnt + t[k].target, 1u, BXI_RLX, BXI_AGENT);
+    SegData d[2];
+    bool fresh[2] = {false, false};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (t[k].spec) { seg_read(ws, dil, t[k].target, segs, h, w, d[k]); fresh[k] = true; }      // in flight together with the atomics
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!t[k].have) continue;                                  // wave-uniform
+        const unsigned int now = (unsigned int)__builtin_amdgcn_readfirstlane((int)old[k]) + 1u;
+        if (now > t[k].expected) { if (lane == 0) atomicOr(ws.fault, kFaultItemCount); continue; }
+        if (now != t[k].expected) continue;
+        // the last arrival: every contributor has ISSUED its stores; one that has not landed yet is re-read
+        bool ok = fresh[k] && seg_valid(d[k], dil, t[k].target, segs, h, w, tag);
+        for (int tries = 0; !ok && tries < kTagRetries; ++tries) {
+            if (tries) __builtin_amdgcn_s_sleep(4);
+            seg_read(ws, dil, t[k].target, segs, h, w, d[k]);
+            ok = seg_valid(d[k], dil, t[k].target, segs, h, w, tag);
+        }
+        if (!ok) { if (lane == 0) atomicOr(ws.fault, kFaultTag); continue; }
+        affinity_item(a, meta, ws, dil, n2max, zero_bit, d[k], rect, t[k].target, segs);
+    }
+}
+
 // items first, first + step, ... < n_items
-__device__ __forceinline__ void pool_block(const PoolArgs& pa, const InstArgs& a, const Ws& ws, int dil, float thresh, int first, int step,
-                                           int n_items, double* lut /*[256]*/, int* part /*[4][3][64]*/, double* fch /*[3][64]*/,
-                                           int4* rects /*[kRectCap]*/, int* predp /*[2]*/, int tix) {
+__device__ __forceinline__ void pool_block(const PoolArgs& pa, const InstArgs& a, const Ws& ws, int dil, float n2max, int zero_bit, unsigned int tag,
+                                           int first, int step, int n_items, double* lut /*[256]*/, int* part /*[4][3][64]*/,
+                                           double* fch /*[3][64]*/, int tix) {
     const int h = pa.Hc >> 2, w = pa.Wc >> 2;
     const int segs = (w + 63) >> 6;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float4 v[3], nx[3];
     pool_load(pa, first, segs, h, w, v);
-    // staged while the image loads fly: the companding table, the instances' box rectangles, the colour predicate
-    lut[threadIdx.x] = kSrgbLut[threadIdx.x];
-    const int nrect = min(a.N, kRectCap);
-    for (int n = threadIdx.x; n < nrect; n += 256) rects[n] = rect_entry(a, n);
-    if (wv == 3) {
-        const Pred pr = make_pred(thresh);
-        if (lane == 0) { predp[0] = __float_as_int(pr.n2max); predp[1] = pr.zero_bit; }
-    }
+    lut[threadIdx.x] = kSrgbLut[threadIdx.x];            // staged while the image loads fly
+    // lane n of every wave: instance n's box cells (requested now, used by the segment tasks at the end)
+    const int4 rect = lane < a.N ? rect_entry(a, lane) : make_int4(0, 0, -1, 0);
     for (int item = first; item < n_items; item += step) {
         const bool more = item + step < n_items;         // workgroup-uniform
         if (more) pool_load(pa, item + step, segs, h, w, nx);
@@ -593,39 +542,26 @@ __device__ __forceinline__ void pool_block(const PoolArgs& pa, const InstArgs& a
         }
         BXI_TW(0, tix, 3);
         lds_barrier();
-        if (wv == 0) {       // one 16-byte write-through store per pooled pixel, drained before anybody is told
-            if (act) {
-                const double f0 = fch[lane], f1 = fch[64 + lane], f2 = fch[128 + lane];
-                store4_through(reinterpret_cast<float*>(ws.lab4 + ((int64_t)b * h + r) * w + c), (float)__dadd_rn(__dmul_rn(116.0, f1), -16.0),
-                               (float)__dmul_rn(500.0, __dadd_rn(f0, -f1)), (float)__dmul_rn(200.0, __dadd_rn(f1, -f2)), 0.f);
-            }
-            drain_vmem();
+        if (wv == 0 && act) {       // one 16-byte write-through store per pooled pixel: (L, a, b, tag); a reader that finds the tag has the pixel
+            const double f0 = fch[lane], f1 = fch[64 + lane], f2 = fch[128 + lane];
+            store4_through(reinterpret_cast<float*>(ws.lab4 + ((int64_t)b * h + r) * w + c), (float)__dadd_rn(__dmul_rn(116.0, f1), -16.0),
+                           (float)__dmul_rn(500.0, __dadd_rn(f0, -f1)), (float)__dmul_rn(200.0, __dadd_rn(f1, -f2)), __uint_as_float(tag));
         }
-        lds_barrier();       // the segment's Lab is in memory; `part` / `fch` are free again
-        BXI_TW(0, tix, 4);
-        {   // wave wv arrives on one of the four segments whose pairs this one takes part in; the last arrival evaluates it
-            const int rt = r - ((wv & 1) ? dil : 0), sg = seg - (wv >> 1);
-            if (rt >= 0 && sg >= 0) {
-                const int target = (b * h + rt) * segs + sg;
-                const unsigned int expected = (1u + (rt + dil < h ? 1u : 0u)) * (1u + (sg + 1 < segs ? 1u : 0u));
-                unsigned int old = 0u;
-                if (lane == 0) old = __hip_atomic_fetch_add(ws.item_cnt + target, 1u, BXI_RLX, BXI_AGENT);
-                old = (unsigned int)__builtin_amdgcn_readfirstlane((int)old);
-                BXI_TW(0, tix, 5);
-                if (old + 1u == expected) affinity_item(a, pa.meta, ws, dil, rects, nrect, __int_as_float(predp[0]), predp[1], target, segs);
-                else if (old + 1u > expected && lane == 0) atomicOr(ws.fault, kFaultItemCount);
-                BXI_TW(0, tix, 6);
-            }
-        }
+        // the next trip's `part` / `fch` writes come after barriers every wave has to reach: no extra barrier needed
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) v[ch] = nx[ch];
     }
+    // ---- every image load of this wave has returned: arrivals, and the segment tasks they complete ----
+    lds_barrier();           // wave 0 has ISSUED the block's last Lab store
+    BXI_TW(0, tix, 4);
+    for (int item = first; item < n_items; item += 2 * step)
+        seg_arrive2(a, pa.meta, ws, dil, n2max, zero_bit, tag, rect, item, item + step < n_items ? item + step : -1, segs);
+    BXI_TW(0, tix, 5);
 }
 
 // grid: [table blocks][pool blocks][stream blocks] (pool_first) or [table][stream][pool]
-__global__ __launch_bounds__(256, 5) void prep3_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, float thresh, Ws ws,
-                                                       LossState st, const float* __restrict__ up_prj, float* __restrict__ g_logits, int vec,
-                                                       int pool_first) {
+__global__ __launch_bounds__(256, 5) void prep3_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, float n2max, int zero_bit,
+                                                       unsigned int tag, Ws ws, LossState st, float* __restrict__ g_logits, int vec, int pool_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
     const int Sn = (a.h + kSBlk - 1) / kSBlk;
@@ -643,26 +579,15 @@ __global__ __launch_bounds__(256, 5) void prep3_kernel(PoolArgs pa, int n_pool, 
     }
     if (role == 0) {
         const int k = blk * kWaves + (int)(threadIdx.x >> 6);
-        if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, thresh, ws, st, k);
+        if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, ws, st, k);
     } else if (role == 2) {
-        const float upp = up_prj ? *up_prj : 1.f;         // for the leader; requested before anything else
-        const int n = idx / Sn;
-        const LogitRows rows = {a.logits + (int64_t)n * a.h * a.w, a.w, vec};
-        unsigned long long* colp = reinterpret_cast<unsigned long long*>(smem);
-        stream_block(a, ws, g_logits, vec, idx, colp, rows, tix);
-        float* red = reinterpret_cast<float*>(smem + stream_red_off(a.h, a.w));
-        if (arrive_on_instance(ws, n, (unsigned int)Sn, reinterpret_cast<unsigned int*>(red + 16))) {
-            BXI_TW(0, tix, 5);
-            leader_block(a, dil, R, ws, st, n, upp, g_logits, smem, red);
-            BXI_TW(0, tix, 6);
-        }
+        const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
+        stream_block(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);
     } else {
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
         int* part = reinterpret_cast<int*>(fch + 3 * 64);
-        int4* rects = reinterpret_cast<int4*>(part + 4 * 3 * 64);
-        int* predp = reinterpret_cast<int*>(rects + kRectCap);
-        pool_block(pa, a, ws, dil, thresh, idx, n_pool, n_items, lut, part, fch, rects, predp, tix);
+        pool_block(pa, a, ws, dil, n2max, zero_bit, tag, idx, n_pool, n_items, lut, part, fch, tix);
     }
     BXI_TW(0, tix, 7);
 }
@@ -670,11 +595,11 @@ __global__ __launch_bounds__(256, 5) void prep3_kernel(PoolArgs pa, int n_pool, 
 // ---- head-fused first launch ----------------------------------------------------------------------------
 // CondInstMaskHead.forward (condinst_head.py:1139-1164) and the evaluation's first launch as ONE grid of independent roles:
 //   [table blocks][pool blocks][head tiles: instance x 8 x 32 tiles of y -> 16 x 64 logits]
-// A head tile does the stream role's job on the tile it just produced (zero-filled gradient tile, row / column partial maxima,
-// all written through), then arrives on its instance like a stream block: the last tile of an instance is its leader.
+// A head tile does the stream role's job on the tile it just produced: zero-filled gradient tile (written through), per-row and
+// per-column (value, first index) maxima as partials for the leaders.
 template <int C, bool REL>
-__global__ __launch_bounds__(256, 5) void head_prep3_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, float thresh,
-                                                            Ws ws, LossState st, const float* __restrict__ up_prj, float* __restrict__ g_logits,
+__global__ __launch_bounds__(256, 5) void head_prep3_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, float n2max,
+                                                            int zero_bit, unsigned int tag, Ws ws, LossState st, float* __restrict__ g_logits,
                                                             DynArgs da, const float* __restrict__ params, float* __restrict__ logits_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
@@ -683,16 +608,13 @@ __global__ __launch_bounds__(256, 5) void head_prep3_kernel(PoolArgs pa, int n_p
     (void)tix;
     if (blk < n_tab) {
         const int k = blk * kWaves + (int)(threadIdx.x >> 6);
-        if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, thresh, ws, st, k);
+        if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, ws, st, k);
     } else if (blk < n_tab + n_pool) {
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
         int* part = reinterpret_cast<int*>(fch + 3 * 64);
-        int4* rects = reinterpret_cast<int4*>(part + 4 * 3 * 64);
-        int* predp = reinterpret_cast<int*>(rects + kRectCap);
-        pool_block(pa, a, ws, dil, thresh, blk - n_tab, n_pool, n_items, lut, part, fch, rects, predp, tix);
+        pool_block(pa, a, ws, dil, n2max, zero_bit, tag, blk - n_tab, n_pool, n_items, lut, part, fch, tix);
     } else {
-        const float upp = up_prj ? *up_prj : 1.f;
         const int tiles_x = (da.W + kYC - 1) / kYC, tiles_y = (da.H + kYR - 1) / kYR;
         int t = blk - n_tab - n_pool;
         const int tx = t % tiles_x; t /= tiles_x;
@@ -703,27 +625,26 @@ __global__ __launch_bounds__(256, 5) void head_prep3_kernel(PoolArgs pa, int n_p
         float* ytile = otile + 16 * 64;                                                   // [(kYR+2)*(kYC+2)]
         const DynEpi ep = {ws.colpart, ws.rowkey, g_logits, ws.n_cb, ws.n_rp, 1};
         dyn_tile_forward<C, REL, 2, true>(da, params, logits_out, n, ty, tx, ytile, otile, ckeys, ep);
-        // the leader's LDS (2 (h + w) words + 17) starts at smem as well: every thread is past the tile's last LDS read
-        float* red = reinterpret_cast<float*>(smem + leader_bytes(a.h, a.w));
-        if (arrive_on_instance(ws, n, (unsigned int)(tiles_x * tiles_y), reinterpret_cast<unsigned int*>(red + 16)))
-            leader_block(a, dil, R, ws, st, n, upp, g_logits, smem, red);
     }
 }
 
 // ---- the image side for strides other than 4 / unaligned canvases: separate launches (pool_rgb_generic of color_affinity.hip
 // -> Lab planes, then these two), no arrival counters needed: each runs after a kernel boundary -----------------------------
-__global__ __launch_bounds__(256) void pack_lab4_kernel(const float* __restrict__ lab, float4* __restrict__ lab4, int B, int64_t P) {
+__global__ __launch_bounds__(256) void pack_lab4_kernel(const float* __restrict__ lab, float4* __restrict__ lab4, int B, int64_t P, unsigned int tag) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * P; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / P, p = i - b * P;
         const float* src = lab + b * 3 * P + p;
-        lab4[i] = make_float4(src[0], src[P], src[2 * P], 0.f);
+        lab4[i] = make_float4(src[0], src[P], src[2 * P], __uint_as_float(tag));
     }
 }
-__global__ __launch_bounds__(256) void affinity_all_kernel(InstArgs a, ImageMeta meta, Ws ws, int dil, float thresh, int n_items) {
-    const Pred pr = make_pred(thresh);
-    const int segs = (a.w + 63) >> 6;
-    for (int item = (int)blockIdx.x * kWaves + (int)(threadIdx.x >> 6); item < n_items; item += (int)gridDim.x * kWaves)
-        affinity_item(a, meta, ws, dil, nullptr, 0, pr.n2max, pr.zero_bit, item, segs);
+__global__ __launch_bounds__(256) void affinity_all_kernel(InstArgs a, ImageMeta meta, Ws ws, int dil, float n2max, int zero_bit, int n_items) {
+    const int segs = (a.w + 63) >> 6, lane = threadIdx.x & 63;
+    const int4 rect = lane < a.N ? rect_entry(a, lane) : make_int4(0, 0, -1, 0);
+    for (int item = (int)blockIdx.x * kWaves + (int)(threadIdx.x >> 6); item < n_items; item += (int)gridDim.x * kWaves) {
+        SegData d;
+        seg_read(ws, dil, item, segs, a.h, a.w, d);
+        affinity_item(a, meta, ws, dil, n2max, zero_bit, d, rect, item, segs);
+    }
 }
 
 // ================================================================================================
@@ -870,15 +791,27 @@ __device__ __forceinline__ void load_plane(const float* __restrict__ plane, cons
     }
 }
 
+__device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = wave_total_f32(v[k]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[(threadIdx.x >> 6) * 4 + k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]);
+}
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
+
 // ---- tile wave (wave64, no LDS, no barrier, no wait) ---------------------------------------------------------------------
 // Every UNORDERED pair is evaluated once and feeds both of its pixels: f(p,q) = f(q,p), the two weights W[k,p] + W[7-k,q]
 // share the colour predicate.  Per pixel (a, b) = (sigmoid(x), sigmoid(-x)), t = a - b, u = a b.  Per pair (p, q):
 //   S = a_p a_q + b_p b_q ; pw = -log S ; d pw / d x_p = -t_q u_p / S ; d pw / d x_q = -t_p u_q / S      (pairwise.cu:38-61)
 // S cannot underflow while every |x| <= 34; tiles with a larger logit take the log-space path.
 template <int D, int R>
-__device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const LossState& st, const Tile& t, float scale, float upp,
-                                          float n2max, int zero_bit, float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
-                                          int tix) {
+__device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float scale, float n2max, int zero_bit,
+                                          float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */, int tix) {
     constexpr int RD = TG<D, R>::RD;
     const int lane = threadIdx.x & 63;
     const int h = a.h, w = a.w, n = t.n;
@@ -886,7 +819,6 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     const float* Lg = a.logits + (int64_t)n * P;
     const int c = t.tile_c0 - D + lane;
     const bool col_owned = g_logits && lane >= D && lane < 64 - D && c < t.hc1;
-    const bool row_lane = g_logits && lane < R && t.tile_r0 + lane < h;
     // everything the tile needs is plain data of the previous launch, requested together
     float x[RD];
     load_plane<D, R>(Lg, t, h, w, lane, x);
@@ -897,9 +829,6 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
 #pragma unroll
         for (int i = 0; i < R + D; ++i) pbyte[i] = pp[(uint32_t)min(max(t.tile_r0 - D + i, 0), h - 1) * (uint32_t)w + cc];
     }
-    unsigned long long ck = 0ull, rk = 0ull;
-    if (col_owned) ck = st.colk[(int64_t)n * w + c];
-    if (row_lane) rk = st.rowk[(int64_t)n * h + t.tile_r0 + lane];
     float g[R];
     float num = 0.f;
 #pragma unroll
@@ -977,22 +906,11 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     num = wave_total_f32(num);
     const long long fx = (long long)(num * kNumScale) + (1ll << 24);           // + 1.0: keeps the packed field non-negative
     if (g_logits) {
-        const int carg = col_owned ? (int)(unsigned int)ck : -1;
-        const float gc = __uint_as_float((unsigned int)(ck >> 32));
-        const int rarg_l = row_lane ? (int)(unsigned int)rk : -1;
-        const float gr_l = __uint_as_float((unsigned int)(rk >> 32));
         char* G = reinterpret_cast<char*>(g_logits + (int64_t)n * P);      // scalar base + 32-bit byte offset
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int r = t.tile_r0 + j;
-            const int ra = __builtin_amdgcn_readlane(rarg_l, j);
-            const float gr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gr_l), j));
-            if (col_owned && r < h) {
-                float sp = 0.f;
-                if (carg == r) sp += gc;
-                if (ra == c) sp += gr;
-                *reinterpret_cast<float*>(G + (uint32_t)(r * w + c) * 4u) = g[j] * scale + sp * upp;
-            }
+            if (col_owned && r < h) add_f32(reinterpret_cast<float*>(G + (uint32_t)(r * w + c) * 4u), g[j] * scale);
         }
     }
     BXI_TW(1, tix, 4);
@@ -1000,6 +918,95 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     if (lane == 0)
         __hip_atomic_fetch_add(acc2_word(ws.acc2, n, t.tile_r0 / R + t.tile_c0 / TG<D, R>::TW), (1ull << 52) + (unsigned long long)fx, BXI_RLX, BXI_AGENT);
     BXI_TW(1, tix, 5);
+}
+
+// ---- leader workgroup (one per instance) -------------------------------------------------------------------------------
+//   partial maxima -> maxima -> sigmoid on those only -> both dice terms (:117-143) -> unit projection gradients, recorded as
+//   one 8-byte word per column / row (gradient bits << 32 | arg-max index) for bxi_boxinst_grad_rescale_f32 and ADDED to the
+//   gradient at the arg-max positions.  Nobody in this launch reads what a leader writes except the finisher (its dice loss).
+__device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const Ws& ws, const LossState& st, int n, float upp,
+                                             float* __restrict__ g_logits, unsigned char* smem, float* red) {
+    const int h = a.h, w = a.w, tid = threadIdx.x;
+    float* xs = reinterpret_cast<float*>(smem);   // [w] sigmoid of the column maxima, then their unit gradients
+    float* ys = xs + w;                           // [h]
+    int* carg = reinterpret_cast<int*>(ys + h);   // [w]
+    int* rarg = carg + w;                         // [h]
+    const int4 e = ws.tab[n];
+    const int br0 = e.y & 0xffff, br1 = (int)((unsigned int)e.y >> 16), bc0 = e.z & 0xffff, bc1 = (int)((unsigned int)e.z >> 16);
+    const bool any = br1 > br0 && bc1 > bc0;
+    (void)dil;
+    float sums[4] = {0.f, 0.f, 0.f, 0.f};   // I_x, U_x, I_y, U_y
+    // the partial maxima of a column / row: up to eight loads in flight at once
+    auto best_key = [](const unsigned long long* __restrict__ part, int n_part, int64_t stride) {
+        unsigned long long k = 0ull;
+        for (int s0 = 0; s0 < n_part; s0 += 8) {
+            unsigned long long o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = part[(int64_t)min(s0 + u, n_part - 1) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) k = o[u] > k ? o[u] : k;
+        }
+        return k;
+    };
+    for (int i = tid; i < max(w, h); i += 256) {
+        const bool is_c = i < w, is_r = i < h;
+        // both keys requested before either is used
+        const unsigned long long kc = best_key(ws.colpart + (int64_t)n * ws.n_cb * w + (is_c ? i : 0), ws.n_cb, w);
+        const unsigned long long kr = best_key(ws.rowkey + (int64_t)n * ws.n_rp * h + (is_r ? i : 0), ws.n_rp, h);
+        if (is_c) {
+            const int c = i;
+            const float X = sigmoid_acc(unpack_val(kc));
+            const float TX = (any && c >= bc0 && c < bc1) ? 1.f : 0.f;
+            xs[c] = X; carg[c] = (int)unpack_idx(kc);
+            sums[0] += X * TX; sums[1] += X * X + TX * TX;
+        }
+        if (is_r) {
+            const int r = i;
+            const float Y = sigmoid_acc(unpack_val(kr));
+            const float TY = (any && r >= br0 && r < br1) ? 1.f : 0.f;
+            ys[r] = Y; rarg[r] = (int)unpack_idx(kr);
+            sums[2] += Y * TY; sums[3] += Y * Y + TY * TY;
+        }
+    }
+    BXI_TW(2, n, 1);
+    block_sum4(sums, red);
+    const float Ix = sums[0], Ux = sums[1] + 1e-5f, Iy = sums[2], Uy = sums[3] + 1e-5f;
+    if (tid == 0)   // :130, summed over both axes :143; the datum is its own flag
+        __hip_atomic_store(&ws.dice[n], (1ull << 32) | (unsigned long long)__float_as_uint((1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy)),
+                           BXI_RLX, BXI_AGENT);
+    BXI_TW(2, n, 2);
+    if (g_logits) {
+        // dice = 1 - 2I/U ; d dice/d u_j = (-2 t_j U + 4 I u_j) / U^2 ; chain through sigmoid ; mean over N
+        const float invN = 1.f / (float)a.N;
+        for (int c = tid; c < w; c += 256) {
+            const float X = xs[c];
+            const float TX = (any && c >= bc0 && c < bc1) ? 1.f : 0.f;
+            const float gv = invN * ((-2.f * TX * Ux + 4.f * Ix * X) / (Ux * Ux)) * X * (1.f - X);
+            xs[c] = gv;
+            st.colk[(int64_t)n * w + c] = ((unsigned long long)__float_as_uint(gv) << 32) | (unsigned int)carg[c];
+        }
+        for (int r = tid; r < h; r += 256) {
+            const float Y = ys[r];
+            const float TY = (any && r >= br0 && r < br1) ? 1.f : 0.f;
+            const float gv = invN * ((-2.f * TY * Uy + 4.f * Iy * Y) / (Uy * Uy)) * Y * (1.f - Y);
+            ys[r] = gv;
+            st.rowk[(int64_t)n * h + r] = ((unsigned long long)__float_as_uint(gv) << 32) | (unsigned int)rarg[r];
+        }
+        __syncthreads();      // xs / ys now hold the gradients for every thread
+        // one addition per arg-max position (a pixel that is its column's AND its row's arg-max gets their sum in one)
+        float* G = g_logits + (int64_t)n * h * w;
+        for (int c = tid; c < w; c += 256) {
+            const int r = carg[c];
+            float v = xs[c];
+            if (rarg[r] == c) v += ys[r];
+            add_f32(G + (int64_t)r * w + c, v * upp);
+        }
+        for (int r = tid; r < h; r += 256) {
+            const int c = rarg[r];
+            if (carg[c] != r) add_f32(G + (int64_t)r * w + c, ys[r] * upp);
+        }
+    }
+    BXI_TW(2, n, 3);
 }
 
 // sum W of the evaluation: the pool blocks' count words, or (thresh <= 0: every pair weighs 1, :1324) 8 x the box areas
@@ -1034,62 +1041,64 @@ __device__ __forceinline__ Tile tile_of(const int4& e, int D, int R, int TW, int
 }
 
 // The finisher's round over instances [b0, b0 + 64): arrivals and sums of every tile (8 words per instance, arrival count and
-// sum in one word), requested together.  Returns whether all of them are complete; adds their sums.
-__device__ __forceinline__ bool finisher_round(const Ws& ws, int N, int b0, double* num) {
+// sum in one word) and the leaders' dice losses, requested together.  Returns whether all are complete; adds their sums.
+__device__ __forceinline__ bool finisher_round(const Ws& ws, int N, int b0, double* num, float* dsum) {
     const int lane = threadIdx.x & 63, i = b0 + lane;
-    unsigned long long x = 0ull;
+    unsigned long long x = 0ull, dg = 1ull << 32;
     unsigned int expect = 0u;
     if (i < N) {
         unsigned long long wd[kAcc2Split];
 #pragma unroll
         for (int sub = 0; sub < kAcc2Split; ++sub) wd[sub] = __hip_atomic_load(acc2_word(ws.acc2, i, sub), BXI_RLX, BXI_AGENT);
+        dg = __hip_atomic_load(&ws.dice[i], BXI_RLX, BXI_AGENT);
         expect = (unsigned int)((ws.tab[i + 1].x & 0xffffff) - (ws.tab[i].x & 0xffffff));
 #pragma unroll
         for (int sub = 0; sub < kAcc2Split; ++sub) x += wd[sub];
     }
-    const bool have = (unsigned int)(x >> 52) == expect;
+    const bool have = (unsigned int)(x >> 52) == expect && (dg >> 32) != 0ull;
     if (!__all(have)) return false;
     const long long fixed = (long long)(x & ((1ull << 52) - 1ull)) - ((long long)expect << 24);   // the +1 per tile
     *num += wave_total_f64(i < N ? (double)fixed : 0.0);
+    const float dv = i < N ? __uint_as_float((unsigned int)dg) : 0.f;
+    const int m = min(64, N - b0);
+    for (int k = 0; k < m; ++k) *dsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), k));   // index order: run-to-run identical
     return true;
 }
 
-// grid: [tile blocks (4 independent tile waves each, striding through the tile list)][finisher]
+// grid: [N leaders][tile blocks (4 independent tile waves each, striding through the tile list)][finisher]
 template <int D, int R>
 __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
-                                                       float* __restrict__ losses, float* __restrict__ g_logits, InstArgs a, Ws ws, LossState st,
-                                                       int n_items) {
+                                                       float n2max, int zero_bit, float* __restrict__ losses, float* __restrict__ g_logits,
+                                                       InstArgs a, Ws ws, LossState st, int n_items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float red[16];
     const int blk = (int)blockIdx.x, lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int N = a.N;
     const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
-    const int4 hdr = *ws.hdr;
-    const float n2max = __int_as_float(__builtin_amdgcn_readfirstlane(hdr.x));
-    const int zero_bit = __builtin_amdgcn_readfirstlane(hdr.y);
+    if (blk < N) {                                                     // ---- leader of instance blk
+        BXI_TW(2, blk, 0);
+        leader_block(a, D, ws, st, blk, upp, g_logits, smem, red);
+        return;
+    }
     if (blk == (int)gridDim.x - 1) {                                   // ---- finisher
         // launch 1 is complete: its arrival counters go back to zero for the next evaluation
         for (int i = threadIdx.x; i < n_items; i += 256) ws.item_cnt[i] = 0u;
-        for (int i = threadIdx.x; i < N; i += 256) ws.inst_cnt[i] = 0u;
         if (threadIdx.x >= 64) return;
         BXI_TW(3, 0, 0);
+        // final since the kernel boundary: requested before the polls, used after them
+        const double total_w = total_weight(a, ws, zero_bit);
+        const unsigned int fault = __hip_atomic_load(ws.fault, BXI_RLX, BXI_AGENT);
         bool ok = false;
         double num = 0.0;
+        float dsum = 0.f;
         for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {        // waits only for workgroups that never wait themselves
-            num = 0.0;
+            num = 0.0; dsum = 0.f;
             bool all = true;
-            for (int b0 = 0; b0 < N && all; b0 += 64) all = finisher_round(ws, N, b0, &num);
+            for (int b0 = 0; b0 < N && all; b0 += 64) all = finisher_round(ws, N, b0, &num, &dsum);
             if (all) { ok = true; break; }
             __builtin_amdgcn_s_sleep(2);
         }
-        const double total_w = total_weight(a, ws, zero_bit);
-        float dsum = 0.f;
-        for (int b0 = 0; b0 < N; b0 += 64) {                             // index order: run-to-run identical
-            const float dv = b0 + lane < N ? ws.dice[b0 + lane] : 0.f;
-            const int m = min(64, N - b0);
-            for (int k = 0; k < m; ++k) dsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), k));
-        }
-        unsigned int status = __hip_atomic_load(ws.fault, BXI_RLX, BXI_AGENT) | (ok ? 0u : kFaultFinisher);
-        status = (unsigned int)__builtin_amdgcn_readfirstlane((int)status);
+        const unsigned int status = (unsigned int)__builtin_amdgcn_readfirstlane((int)(fault | (ok ? 0u : kFaultFinisher)));
         if (lane == 0) {
             const float denom = fmaxf((float)total_w, 1.f);                      // weights.sum().clamp(min=1.0), :1328
             float l0 = dsum / (float)N;                                          // .mean(), :143
@@ -1104,14 +1113,14 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_ke
         BXI_TW(3, 0, 1);
         return;
     }
-    const int wid = blk * kWaves + wave, nwaves = ((int)gridDim.x - 1) * kWaves;
+    const int wid = (blk - N) * kWaves + wave, nwaves = ((int)gridDim.x - 1 - N) * kWaves;
     BXI_TW(1, wid, 0);
     // the table (16 bytes per instance, the same lines for every wave) and the count words, requested together
     int4 e0 = make_int4(0, 0, 0, 0);
     if (lane <= N) e0 = ws.tab[lane];
+    const double total_w = total_weight(a, ws, zero_bit);
     const int total = N < 64 ? __builtin_amdgcn_readlane(e0.x, N < 64 ? N : 0) : __builtin_amdgcn_readfirstlane(ws.tab[N].x);
     if (wid >= total) return;
-    const double total_w = total_weight(a, ws, zero_bit);
     const float scale = upw * (warmup / fmaxf((float)total_w, 1.f));
     float* gbuf = reinterpret_cast<float*>(smem) + wave * ((R + 1) * 64);
     for (int ti = wid; ti < total; ti += nwaves) {
@@ -1137,7 +1146,7 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_ke
         }
         const Tile t = tile_of(e, D, R, TG<D, R>::TW, n, ti - (e.x & 0xffffff), a.h, a.w);
         BXI_TW(1, wid, 1);
-        math_tile<D, R>(a, ws, st, t, scale, upp, n2max, zero_bit, g_logits, gbuf, wid);
+        math_tile<D, R>(a, ws, t, scale, n2max, zero_bit, g_logits, gbuf, wid);
     }
 }
 
@@ -1219,10 +1228,50 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 
 static int tile_rows_for(int N) { return N <= 96 ? 4 : 8; }
 
+// (sim >= thresh) for a valid neighbour as a compare on the squared Lab distance: exp(-0.5 * sqrt(n2)) >= thresh  <=>  n2 <= n2max
+// (get_image_color_similarity :237 + the threshold of loss() :1324), n2max found by bisecting the f32 expression over the float
+// bit patterns (it is non-increasing in n2 >= 0, and positive floats order like their bit patterns).  Host arithmetic: sqrtf is
+// correctly rounded everywhere; expf is the C library's, as in the CPU reference path.
+struct HostPred { float n2max; int zero_bit; };
+static bool host_sim_pred(float n2, float thresh) { return expf(-sqrtf(n2) * 0.5f) >= thresh; }
+static HostPred host_pred(float thresh) {
+    static std::atomic<uint64_t> cache{~0ull};                          // (thresh bits << 32 | n2max bits) of the last call
+    uint32_t tb, nb;
+    memcpy(&tb, &thresh, 4);
+    const uint64_t c = cache.load(std::memory_order_relaxed);
+    HostPred p;
+    p.zero_bit = (0.f >= thresh) ? 1 : 0;                               // weight of a padded / masked-out neighbour (sim == 0)
+    if ((uint32_t)(c >> 32) == tb && c != ~0ull) { nb = (uint32_t)c; memcpy(&p.n2max, &nb, 4); return p; }
+    if (!host_sim_pred(0.f, thresh)) p.n2max = -1.f;                    // thresh > 1: never
+    else if (host_sim_pred(3.0e38f, thresh)) p.n2max = INFINITY;        // thresh <= 0 (exp underflows to 0): always
+    else {
+        uint32_t lo = 0u, hi;
+        const float big = 3.0e38f;
+        memcpy(&hi, &big, 4);                                           // pred(lo) true, pred(hi) false
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            float fm;
+            memcpy(&fm, &mid, 4);
+            if (host_sim_pred(fm, thresh)) lo = mid; else hi = mid;
+        }
+        memcpy(&p.n2max, &lo, 4);
+    }
+    memcpy(&nb, &p.n2max, 4);
+    cache.store(((uint64_t)tb << 32) | nb, std::memory_order_relaxed);
+    return p;
+}
+
+static unsigned int next_tag() {        // marks the Lab pixels of one evaluation; never the same for two consecutive evaluations
+    static std::atomic<unsigned int> counter{0x5a5a0000u};
+    unsigned int t = counter.fetch_add(1u, std::memory_order_relaxed) + 1u;
+    return t;
+}
+
 template <int D, int R>
-static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, float warmup, const Ws& ws, const LossState& st, float* losses,
-                        float* g_logits, const float* up_prj, const float* up_pw, int n_items) {
-    BXI_LAUNCH("pair", s, (pair3_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, up_prj, up_pw, warmup, losses, g_logits, a, ws, st, n_items);
+static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, float warmup, float n2max, int zero_bit, const Ws& ws,
+                        const LossState& st, float* losses, float* g_logits, const float* up_prj, const float* up_pw, int n_items) {
+    BXI_LAUNCH("pair", s, (pair3_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, up_prj, up_pw, warmup, n2max, zero_bit, losses, g_logits,
+               a, ws, st, n_items);
 }
 
 }  // namespace v3
@@ -1273,6 +1322,8 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     if (!force_rows) force_rows = env_rows;
     const int R = force_rows == 4 || force_rows == 8 ? force_rows : tile_rows_for(a.N);
     if (eval_cap(a.N, a.h, a.w, dil, R) >= (1 << 24)) return BXI_ERR_BAD_SHAPE;     // the table packs a tile prefix into 24 bits
+    const HostPred pr = host_pred(color_thresh);
+    const unsigned int tag = next_tag();
 
     // ---- launch 1 --------------------------------------------------------------------------------------------------
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
@@ -1286,9 +1337,7 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     const int room = env_pool_wgs * device_cus() - n_tab - (head ? 0 : n_stream);
     const int per = room > 0 ? (n_items + room - 1) / room : 8;
     const int n_pool = pooled_in_launch ? (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per) : 0;
-    const size_t lds_pool = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64 + 16 * (size_t)kRectCap + 16;
-    const size_t lds_leader = leader_bytes(a.h, a.w) + 4 * 20;
-    size_t lds1 = lds_pool;
+    size_t lds1 = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
     if (head) {
         // the head-fused first launch (factor 2, vector rows): tables, pool blocks, head tiles
         if (head->factor != 2 || !vec || head->H * 2 != a.h || head->W * 2 != a.w || head->N != a.N || head->B != in->B || !pooled_in_launch)
@@ -1298,26 +1347,23 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
         ws.n_rp = (head->W + kYC - 1) / kYC;
         const size_t lds_head = 8 * 4 * 64 + sizeof(float) * (16 * 64 + (kYR + 2) * (kYC + 2));
         if (lds1 < lds_head) lds1 = lds_head;
-        if (lds1 < lds_leader) lds1 = lds_leader;
         if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
         float* logits_out = const_cast<float*>(a.logits);
         const unsigned grid1 = (unsigned)(n_tab + n_pool + a.N * tiles);
-        if (head_C == 16 && head->rel)
-            BXI_LAUNCH("head_prep", s, (head_prep3_kernel<16, true>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, up_prj, g_logits, *head, head->params, logits_out);
-        else if (head_C == 16)
-            BXI_LAUNCH("head_prep", s, (head_prep3_kernel<16, false>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, up_prj, g_logits, *head, head->params, logits_out);
-        else if (head_C == 8 && head->rel)
-            BXI_LAUNCH("head_prep", s, (head_prep3_kernel<8, true>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, up_prj, g_logits, *head, head->params, logits_out);
-        else if (head_C == 8)
-            BXI_LAUNCH("head_prep", s, (head_prep3_kernel<8, false>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, up_prj, g_logits, *head, head->params, logits_out);
-        else
-            return BXI_ERR_UNSUPPORTED;
+#define BXI_HEAD_LAUNCH(CC, RR)                                                                                                          \
+        BXI_LAUNCH("head_prep", s, (head_prep3_kernel<CC, RR>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, pr.n2max,  \
+                   pr.zero_bit, tag, ws, st, g_logits, *head, head->params, logits_out)
+        if (head_C == 16 && head->rel) BXI_HEAD_LAUNCH(16, true);
+        else if (head_C == 16) BXI_HEAD_LAUNCH(16, false);
+        else if (head_C == 8 && head->rel) BXI_HEAD_LAUNCH(8, true);
+        else if (head_C == 8) BXI_HEAD_LAUNCH(8, false);
+        else return BXI_ERR_UNSUPPORTED;
+#undef BXI_HEAD_LAUNCH
     } else {
-        const size_t lds_stream = stream_red_off(a.h, a.w) + 4 * 20;
-        if (lds1 < lds_stream) lds1 = lds_stream;
+        if (lds1 < 8 * (size_t)kWaves * a.w) lds1 = 8 * (size_t)kWaves * a.w;
         if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
         BXI_LAUNCH("prep", s, prep3_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R,
-                   color_thresh, ws, st, up_prj, g_logits, vec, env_pool_first);
+                   pr.n2max, pr.zero_bit, tag, ws, st, g_logits, vec, env_pool_first);
     }
     rc = check_launch();
     if (rc != BXI_OK) return rc;
@@ -1326,9 +1372,9 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
         if (rc != BXI_OK) return rc;
         const int64_t BP = (int64_t)batch->B * a.h * a.w;
         BXI_LAUNCH("pack_lab4", s, pack_lab4_kernel, dim3((unsigned)((BP + 255) / 256 > 2048 ? 2048 : (BP + 255) / 256)), dim3(256), 0, s,
-                   (const float*)ws.lab_planar, ws.lab4, batch->B, (int64_t)a.h * a.w);
+                   (const float*)ws.lab_planar, ws.lab4, batch->B, (int64_t)a.h * a.w, tag);
         BXI_LAUNCH("affinity_all", s, affinity_all_kernel, dim3((unsigned)((n_items + kWaves - 1) / kWaves > 2048 ? 2048 : (n_items + kWaves - 1) / kWaves)),
-                   dim3(256), 0, s, a, pa.meta, ws, dil, color_thresh, n_items);
+                   dim3(256), 0, s, a, pa.meta, ws, dil, pr.n2max, pr.zero_bit, n_items);
         rc = check_launch();
         if (rc != BXI_OK) return rc;
     }
@@ -1337,15 +1383,19 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     const int64_t cap = eval_cap(a.N, a.h, a.w, dil, R);
     int64_t n_mb = (cap + kWaves - 1) / kWaves;
     // the list length is device data: the tile waves stride through it; the launch should be resident in one round
-    static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 3);
-    const int room2 = env_pair_wgs * device_cus() - 1;
+    static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 0);
+    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? 3 : 2);
+    const int room2 = occ * device_cus() - 1 - a.N;
     if (n_mb > (room2 > 64 ? room2 : 64)) n_mb = room2 > 64 ? room2 : 64;
-    const size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
-    const int grid = (int)n_mb + 1;                 // + the finisher
-#define BXI_PAIR_CASE(DD)                                                                                            \
-    case DD:                                                                                                         \
-        if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, ws, st, losses, g_logits, up_prj, up_pw, n_items);   \
-        else launch_pair<DD, 8>(s, grid, lds2, a, warmup, ws, st, losses, g_logits, up_prj, up_pw, n_items);          \
+    size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
+    const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
+    if (lds2 < lds_leader) lds2 = lds_leader;
+    if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
+    const int grid = a.N + (int)n_mb + 1;                 // leaders + tile blocks + the finisher
+#define BXI_PAIR_CASE(DD)                                                                                                                  \
+    case DD:                                                                                                                               \
+        if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, ws, st, losses, g_logits, up_prj, up_pw, n_items);  \
+        else launch_pair<DD, 8>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, ws, st, losses, g_logits, up_prj, up_pw, n_items);         \
         break;
     switch (dil) {
         BXI_PAIR_CASE(1) BXI_PAIR_CASE(2) BXI_PAIR_CASE(3) BXI_PAIR_CASE(4)

@@ -207,6 +207,9 @@ int bxi_boxinst_loss_backward_f32(const bxi_instances* inst_host, const float* g
  * Strides other than 4 / unaligned canvases pool the image in launches of their own (same results, not the fast path). */
 size_t bxi_boxinst_eval_workspace_bytes(int B, int Hc, int Wc, int stride, int N);
 int bxi_boxinst_eval_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
+/* byte offset, inside `workspace`, of the Lab image the evaluation leaves behind: [B, Hc/stride, Wc/stride] x float4 (L, a, b, tag)
+ * -- what skimage.color.rgb2lab gives at condinst_head.py:1413-1416; exposed so that tests can compare it with scikit-image. */
+size_t bxi_boxinst_eval_workspace_lab_offset(void);
 int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host,
                          int size, int dilation, float color_thresh, float warmup,
                          const float* up_prj, const float* up_pw,

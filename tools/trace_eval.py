@@ -60,19 +60,18 @@ else:
 sw = sw[sw[:, 7] > 0]; pw = pw[pw[:, 7] > 0]
 print('  stream waves:', len(sw), 'start', q(us(sw[:, 0] - t0)), '| loads+zero-fill issued', qd(sw[:, 1], sw[:, 0]), '| data + column max', qd(sw[:, 2], sw[:, 1]),
       '| butterflies', qd(sw[:, 3], sw[:, 2]), '| barrier', qd(sw[:, 4], sw[:, 3]), '| end', q(us(sw[:, 7] - t0)))
-ld = sw[sw[:, 5] > 0]
-print('    leaders:', len(ld), 'partials + arrival', qd(ld[:, 5], ld[:, 4]), '| leader work', qd(ld[:, 6], ld[:, 5]), '| arrived at', q(us(ld[:, 5] - t0)), '| end', q(us(ld[:, 7] - t0)))
-nl = sw[sw[:, 5] == 0]
-print('    others: partials + arrival', qd(nl[:, 7], nl[:, 4]))
 print('  pool waves (last item of each):', len(pw), 'start', q(us(pw[:, 0] - t0)), '| loads + denorm at', q(us(pw[:, 1] - t0)), '| barrier 1', qd(pw[:, 2], pw[:, 1]),
-      '| Lab f', qd(pw[:, 3], pw[:, 2]), '| Lab stored + barriers', qd(pw[:, 4], pw[:, 3]), '| arrival returned', qd(pw[:, 5], pw[:, 4]),
-      '| segment task (or none)', qd(pw[:, 6], pw[:, 5]), '| end', q(us(pw[:, 7] - t0)))
+      '| Lab f', qd(pw[:, 3], pw[:, 2]), '| Lab stored + barrier', qd(pw[:, 4], pw[:, 3]), '| arrivals + segment tasks', qd(pw[:, 5], pw[:, 4]),
+      '| items done at', q(us(pw[:, 4] - t0)), '| end', q(us(pw[:, 7] - t0)))
 prep_end = p[live, 7].max()
 mw = t[1]; allm = mw[mw[:, 0] > 0]; mw = allm[allm[:, 5] > 0]
-k0 = allm[:, 0].min()
+ld = t[2]; ld = ld[ld[:, 0] > 0]
+k0 = min(allm[:, 0].min(), ld[:, 0].min())
 print('pair: first wave starts %.2f us after the last prep wave ended' % us(k0 - prep_end))
+print('  leaders', len(ld), 'start', q(us(ld[:, 0] - k0)), '| loads+maxima', qd(ld[:, 1], ld[:, 0]), '| sums + dice', qd(ld[:, 2], ld[:, 1]),
+      '| coefficients + adds', qd(ld[:, 3], ld[:, 2]), '| dice at', q(us(ld[:, 2] - k0)), '| end', q(us(ld[:, 3] - k0)))
 print('  tile waves with a tile', len(mw), 'of', len(allm), 'start', q(us(mw[:, 0] - k0)), '| table -> tile', qd(mw[:, 1], mw[:, 0]), '| data arrived + masks', qd(mw[:, 2], mw[:, 1]),
-      '| pair math', qd(mw[:, 3], mw[:, 2]), '| stores issued', qd(mw[:, 4], mw[:, 3]), '| arrival issued', qd(mw[:, 5], mw[:, 4]), '| end', q(us(mw[:, 5] - k0)))
+      '| pair math', qd(mw[:, 3], mw[:, 2]), '| adds issued', qd(mw[:, 4], mw[:, 3]), '| arrival issued', qd(mw[:, 5], mw[:, 4]), '| end', q(us(mw[:, 5] - k0)))
 fw = t[3][0]
 print('  finisher: start %.2f end %.2f' % (us(fw[0] - k0), us(fw[1] - k0)))
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
