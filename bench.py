@@ -79,9 +79,6 @@ class EvalSet:
         self.state = torch.empty(lib.bxi_boxinst_loss_state_bytes(N, h, w), dtype=torch.uint8, device=dev)
         self.ws = torch.empty(lib.bxi_boxinst_eval_workspace_bytes(d['B'], d['H'], d['W'], d['stride'], N),
                               dtype=torch.uint8, device=dev)
-        rc = lib.bxi_boxinst_eval_workspace_init(self.ws.data_ptr(), self.ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
-        if rc != 0:
-            raise RuntimeError(f'bxi_boxinst_eval_workspace_init: status {rc}')
         # the C-ABI argument lists, marshalled once (what a training loop that keeps its buffers does): only the
         # stream is appended per call
         vp = C.c_void_p

@@ -62,7 +62,6 @@ SIGNATURES = {
     'bxi_boxinst_loss_backward_f32': (c_int, [C.POINTER(Instances), c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                              c_void_p]),
     'bxi_boxinst_eval_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    'bxi_boxinst_eval_workspace_init': (c_int, [c_void_p, c_size_t, c_void_p]),
     'bxi_boxinst_eval_workspace_lab_offset': (c_size_t, []),
     'bxi_boxinst_eval_f32': (c_int, [C.POINTER(ImageBatch), C.POINTER(Instances), c_int, c_int, c_float, c_float,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -20,13 +20,11 @@ int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_p
                    void* stream);
 
 size_t eval3_ws_bytes(int B, int N, int h, int w);
-size_t eval3_sync_bytes();
 bool eval3_supported(int dil);
 int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_instances* in, int dil, float warmup, const float* up_prj,
                  const float* up_pw, float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, int force_rows,
                  void* stream, const DynArgs* head = nullptr, int head_C = 0);
 int launch_rescale3(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits, void* stream);
-int eval3_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 
 static inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 // developer switch for A/B runs on one box: BXI_EVAL_V2=1 takes the round-2 kernels (fused_eval.hip)
@@ -83,11 +81,7 @@ size_t bxi_boxinst_eval_workspace_bytes(int B, int Hc, int Wc, int stride, int N
     return v2 > v3 ? v2 : v3;
 }
 
-int bxi_boxinst_eval_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
-    return bxi::eval3_workspace_init(workspace, workspace_bytes, stream);
-}
-
-size_t bxi_boxinst_eval_workspace_lab_offset(void) { return bxi::up256(bxi::eval3_sync_bytes()); }
+size_t bxi_boxinst_eval_workspace_lab_offset(void) { return 0; }
 
 int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host, int size, int dilation,
                          float color_thresh, float warmup, const float* up_prj, const float* up_pw, float* losses,

@@ -1,5 +1,4 @@
-// eval3.hip -- the BoxInst loss evaluation (forward AND finished backward) in TWO launches on gfx950, in which no workgroup
-// ever waits for the RESULT OF ANOTHER WORKGROUP'S COMPUTATION inside a launch.
+// eval3.hip -- the BoxInst loss evaluation (forward AND finished backward) in TWO launches on gfx950.
 //
 // Replaces (reference, LiWentomng/BoxInstSeg) CondInstMaskHead.loss with boxinst_enabled,
 // condinst_head.py:1288-1343, together with everything it calls:
@@ -9,32 +8,28 @@
 //   pairwise_nlog (CUDA op, pairwise.cu:68-149) + weights / normalise / warm-up   :1315-1332
 // and what autograd does behind them, with the upstream factors folded in.
 //
-//   launch 1  prep3_kernel   256-thread workgroups, three roles                                          HBM stream
-//     table waves   per-instance table (tile prefix, box cells, image, valid-cell limits): 16 bytes per instance
+//   launch 1  prep3_kernel   256-thread workgroups, three roles, nothing waits                              HBM stream
+//     table waves   per-instance table (tile prefix, box cells, image, valid-cell limits): 16 bytes per instance; zeroes the
+//                   words the next launch polls
 //     stream blocks 4 waves x 8 rows of one instance map: zero-fill of g_logits (written through), row maxima, column maxima
 //                   of the block's 32 rows -> partials for the leaders of the next launch
 //     pool blocks   the 4 input rows of 64 pooled pixels -> de-normalise, truncate, 4x4 mean, Lab (fp64) -> ONE 16-byte
-//                   write-through store per pooled pixel (L, a, b, tag of this evaluation).  When its last image load has
-//                   returned, each of the block's 4 waves ARRIVES (one integer atomic) on one of the (up to) four row segments
-//                   whose colour pairs the block's segment takes part in; the wave whose arrival is the last one evaluates that
-//                   segment: the four colour predicates per pixel (one byte) and the segment's share of the pair-weight
-//                   normaliser  sum W  (a function of the image and the boxes only, :1324-1328) -> integer atomics.
-//                   So sum W and the predicates are FINISHED when the launch ends.
-//   launch 2  pair3_kernel   [leaders][tile blocks][finisher]; nothing in it waits except the finisher
+//                   store per pooled pixel
+//   launch 2  pair3_kernel   [leaders][count blocks][tile blocks][finisher]
 //     leaders       one block per instance: partial maxima -> maxima -> sigmoid -> dice -> unit projection gradients, ADDED
-//                   (float atomic) at the arg-max positions of the zero-filled gradient
+//                   (float atomic) at the arg-max positions of the zero-filled gradient.  Nobody waits for a leader but the finisher.
+//     count waves   one wave64 per box tile: the pair weights' sum from Lab alone -> one packed integer atomic per tile
 //     tile waves    one wave64 per box tile (no LDS, no barrier): logits tile + halo in registers, every unordered pair
 //                   evaluated once; g_pw warm/max(sum W,1) d pw is ADDED (float atomic) to the gradient -- an element receives
 //                   at most two additions onto 0 (its tile's and its leader's), so the sum does not depend on their order;
-//                   the tile's share of sum W pw goes to an integer accumulator by an atomic without return.
-//     finisher      the last workgroup: polls the accumulators (bounded), writes the two loss values -- NaN and a status word
-//                   when anything in either launch was inconsistent -- and leaves every counter zero for the next evaluation.
-// "Last arrival continues" needs no forward-progress assumption: nobody spins on a workgroup that may not have been dispatched
-// (the finisher waits for workgroups that never wait; a segment task re-reads a pixel only while a store that HAS been issued
-// is still on its way).  The counters live in a fixed region at the start of the workspace that is zero between evaluations
-// (bxi_boxinst_eval_workspace_init once, then every evaluation cleans up after itself).
+//                   the tile's share of sum W pw goes to an integer accumulator by an atomic without return.  Its one wait:
+//                   sum W (the normaliser is global) from the count waves, which precede it in the grid and never wait.
+//     finisher      the last workgroup: polls the accumulators, writes the two loss values.
+// Every wait is bounded and running out of it is loud: NaN losses, a status word, a poisoned gradient (rescale3_kernel).
+// Table entries instead of a work list: a tile wave finds its tile from 16 bytes per instance that every wave reads (the same
+// few cache lines), not from a record of its own behind a list length (two dependent misses right after the kernel boundary).
 // Data layout in HBM: everything NCHW / row-major as the reference hands it over; intermediates: Lab [B,h,w] float4 (1.6 MB at
-// 2x800x1024), predicate bytes [B,h,w], column / row partial maxima, 16-byte table entries.
+// 2x800x1024), column / row partial maxima, 16-byte table entries.
 #include "loss_common.hpp"
 #include "dynamic_head_device.hpp"
 #include <atomic>
@@ -50,13 +45,11 @@ constexpr int kSRows = 8;                       // rows per stream wave
 constexpr int kSBlk = kWaves * kSRows;          // rows per stream workgroup
 constexpr int kChunkC = 256;                    // columns per pass of a stream wave: 64 lanes x float4
 constexpr int kMaxDilFused = 4;
-constexpr unsigned kSpinLimit = 400000;         // finisher polls (~0.5 us each): far beyond any launch
-constexpr int kTagRetries = 4096;               // re-reads of a pixel whose store has been issued but has not landed yet
+constexpr unsigned kSpinLimit = 400000;         // bounded waits (~0.3 us per poll): far beyond any launch; running out is loud (NaN losses)
 constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
-constexpr int kSumWords = 64;                   // sum W: 64 words, each in its own 128 bytes
-constexpr int kMaxItems = 1 << 18;              // pooled row segments per batch the fixed counter region covers
+constexpr int kAcc1Words = 64;                  // count-wave arrivals + sum W: 64 words, each in its own 128 bytes
 constexpr int kMaxInst = 65536;
-constexpr unsigned kFaultFinisher = 2u, kFaultItemCount = 4u, kFaultTag = 8u;
+constexpr unsigned kFaultCounts = 1u, kFaultFinisher = 2u;
 
 #ifdef BXI_TRACE
 #define BXI_TW(kid, idx, ph)                                                                                  \
@@ -78,23 +71,18 @@ __device__ __forceinline__ void add_f32(float* p, float v) {
 }
 
 // ---- workspace ---------------------------------------------------------------------------------------------------------
-// [sync region: zero between evaluations][Lab][predicate bytes][partials][table][accumulators]
-constexpr size_t kSyncFault = 0, kSyncSumw = 256, kSyncItem = kSyncSumw + (size_t)kSumWords * 128,
-                 kSyncBytes = kSyncItem + 4 * (size_t)kMaxItems;
-
 struct Ws {
-    unsigned int* fault;                        // [1]   bit mask of protocol inconsistencies seen by launch 1 (never expected)
-    unsigned long long* sumw;                   // [kSumWords] (one per 128 B) sum W, added by the pool blocks' segment tasks
-    unsigned int* item_cnt;                     // [B*h*segs] arrivals on a pooled row segment
-    float4* lab4;                               // [B,h,w] (L, a, b, tag)
-    unsigned char* pred;                        // [B,h,w] bit d = colour predicate of pair direction d with this pixel as (i, l)
+    float4* lab4;                               // [B,h,w] (L, a, b, 0)
     float* lab_planar;                          // [B,3,h,w] only the generic pooling path (other strides, unaligned canvases) fills it
     unsigned long long* colpart;                // [N,n_cb,w] packed (max logit, first row) of a band of rows
     unsigned long long* rowkey;                 // [N,n_rp,h] packed (max logit, first column)
     int n_cb, n_rp;
     int4* tab;                                  // [N+1] {tile prefix | img << 24, r0 | r1 << 16, c0 | c1 << 16, vrow | vcol << 16}; [N].x = tiles
-    unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B) arrivals << 52 | sum (W pw + 1) in 2^-24 units
+    // words polled inside pair3_kernel; zeroed by prep3_kernel's table waves, i.e. before a kernel boundary
+    unsigned long long* acc1;                   // [kAcc1Words] (one per 128 B) count waves: arrivals << 40 | sum W
+    unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B) tile waves: arrivals << 52 | sum (W pw + 1) in 2^-24 units
     unsigned long long* dice;                   // [N]   leader: 1 << 32 | bits of the instance's dice loss (0 = not published)
+    unsigned int* fault;                        // [1]   bit mask of waits that ran out (never expected)
 };
 
 __device__ __forceinline__ unsigned long long* acc2_word(unsigned long long* acc2, int n, int sub) {
@@ -115,20 +103,17 @@ static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
     char* p = (char*)base;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return p ? p + o : nullptr; };
     Ws t;
-    char* sync = (char*)take(kSyncBytes);
-    t.fault = (unsigned int*)(sync ? sync + kSyncFault : nullptr);
-    t.sumw = (unsigned long long*)(sync ? sync + kSyncSumw : nullptr);
-    t.item_cnt = (unsigned int*)(sync ? sync + kSyncItem : nullptr);
     const size_t P = (size_t)h * w, B1 = B > 0 ? B : 1;
     t.lab4 = (float4*)take(16 * B1 * P);
-    t.pred = (unsigned char*)take(B1 * P);
     t.lab_planar = (float*)take(12 * B1 * P);
     t.colpart = (unsigned long long*)take(8 * (size_t)N1 * (cb_max > Sn ? cb_max : Sn) * w);
     t.rowkey = (unsigned long long*)take(8 * (size_t)N1 * h * (rp_max > 1 ? rp_max : 1));
     t.n_cb = (int)Sn; t.n_rp = 1;
     t.tab = (int4*)take(16 * (size_t)(N1 + 1));
+    t.acc1 = (unsigned long long*)take(8 * (size_t)kAcc1Words * kAcc2Stride);
     t.acc2 = (unsigned long long*)take(8 * (size_t)N1 * kAcc2Split * kAcc2Stride);
     t.dice = (unsigned long long*)take(8 * (size_t)N1);
+    t.fault = (unsigned int*)take(4);
     if (ws) *ws = t;
     return off;
 }
@@ -187,14 +172,17 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
     if (m < a.N) {
         ws.tab[m] = make_int4(prefix | (mine.img << 24), mine.r0 | (mine.r1 << 16), mine.c0 | (mine.c1 << 16), mine.vrow | (mine.vcol << 16));
         if (st.inst) { InstRec rc; rc.r0 = mine.r0; rc.r1 = mine.r1; rc.c0 = mine.c0; rc.c1 = mine.c1; rc.img = mine.img; rc.pad0 = rc.pad1 = rc.pad2 = 0; st.inst[m] = rc; }
-        // the words the next launch's finisher polls: zeroed here, i.e. before a kernel boundary
+        // the words the next launch polls: zeroed here, i.e. before a kernel boundary (no hipMemsetAsync, no initialisation contract)
 #pragma unroll
         for (int sub = 0; sub < kAcc2Split; ++sub) *acc2_word(ws.acc2, m, sub) = 0ull;
         ws.dice[m] = 0ull;
     } else if (m == a.N) {
         ws.tab[m] = make_int4(prefix, 0, 0, 0);
     }
-    if (k == 0 && lane == 0 && st.status) st.status[1] = R;
+    if (k == 0) {
+        ws.acc1[(size_t)lane * kAcc2Stride] = 0ull;
+        if (lane == 0) { *ws.fault = 0u; if (st.status) { st.status[0] = 0; st.status[1] = R; } }
+    }
 }
 
 // ---- role 2: stream block = 4 waves x 8 rows of one instance map ---------------------------------------------------------
@@ -306,7 +294,7 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const Ws& ws, fl
     }
 }
 
-// ---- role 3: pool block = the 4 input rows of 64 pooled pixels, then the colour pairs its row segments complete ---------
+// ---- role 3: pool block = the 4 input rows of 64 pooled pixels ---------
 __device__ __forceinline__ double lab_f(const double* lut, int i, int r8, int g8, int b8) {
     const double r = lut[r8], g = lut[g8], b = lut[b8];
     const double M[3][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}, {0.019334, 0.119193, 0.950227}};
@@ -339,165 +327,15 @@ __device__ __forceinline__ float n2_of(float L0, float A0, float B0, float L1, f
     return __fadd_rn(__fadd_rn(__fmul_rn(dL, dL), __fmul_rn(dA, dA)), __fmul_rn(dB, dB));
 }
 
-// the value of lane + d (a wavefront rotation per step: every lane receives something; the last d lanes receive lanes 0..d-1)
-__device__ __forceinline__ float lane_plus_n(float v, int d) {
-    int x = __float_as_int(v);
-    for (int s = 0; s < d; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
-    return __int_as_float(x);
-}
-
-__device__ __forceinline__ int4 rect_entry(const InstArgs& a, int n) {
-    const InstBox ib = inst_box(a, n, 0);
-    return make_int4(ib.box.r0 | (ib.box.r1 << 16), ib.box.c0 | (ib.box.c1 << 16), ib.img, 0);
-}
-
-// Four 16-byte loads past this CU's L1 (sc1), waited for together.  The asm is invisible to the compiler's vmcnt bookkeeping,
-// which is harmless here: memory operations complete in order, so its own waits can only become longer.  Called only when no
-// image load of the wave is in flight any more (a wave consumes its loads in order: a load behind a prefetch would wait for it).
-typedef float f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void load4_sc1(const float4* p0, const float4* p1, const float4* p2, const float4* p3, f4v& a, f4v& b, f4v& c, f4v& d) {
-    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
-                 "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
-}
-
-// A pooled row segment (r, seg) of image b takes part in the colour pairs whose STEP segment is one of (r, seg), (r - D, seg),
-// (r, seg - 1), (r - D, seg - 1): a step segment T = (rt, sg) needs the Lab of (rt, sg), (rt + D, sg) and the first D pixels of
-// (rt, sg + 1), (rt + D, sg + 1).  Wave wv of the block that produced (r, seg) arrives on target wv (bit 0: row offset, bit 1:
-// segment offset); the target is complete when all its `expected` contributors have arrived.
-struct SegTask { int target; unsigned int expected; bool have, spec; };
-__device__ __forceinline__ SegTask seg_task(int item, int segs, int h, int dil, int wv) {
-    const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
-    const int rt = r - ((wv & 1) ? dil : 0), sg = seg - (wv >> 1);
-    SegTask t;
-    t.have = rt >= 0 && sg >= 0;
-    const bool hasD = rt + dil < h, hasS = sg + 1 < segs;
-    t.target = (b * h + rt) * segs + sg;
-    t.expected = (1u + (hasD ? 1u : 0u)) * (1u + (hasS ? 1u : 0u));
-    // the contributor with the highest item index arrives last when segments complete in dispatch order: it requests the
-    // target's Lab together with its arrival instead of after it (one round trip instead of two at the end of the launch);
-    // any other order is as correct, the last arrival then reads after it knows
-    t.spec = t.have && wv == ((hasD ? 1 : 0) | (hasS ? 2 : 0));
-    return t;
-}
-
-struct SegData { f4v o0, oD, x0, xD; };     // (rt, c) (rt + D, c) and the same D columns to the right, for the lanes that need them from memory
-__device__ __forceinline__ void seg_read(const Ws& ws, int D, int item, int segs, int h, int w, SegData& d) {
-    const int lane = threadIdx.x & 63;
-    const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
-    const int c = seg * 64 + lane;
-    const int cc = min(c, w - 1), cx = min(lane >= 64 - D ? c + D : c, w - 1), rD = min(r + D, h - 1);
-    const float4* L4 = ws.lab4 + (int64_t)b * h * w;
-    load4_sc1(L4 + (int64_t)r * w + cc, L4 + (int64_t)rD * w + cc, L4 + (int64_t)r * w + cx, L4 + (int64_t)rD * w + cx, d.o0, d.oD, d.x0, d.xD);
-}
-// every pixel the segment's pairs use carries this evaluation's tag, i.e. its (single, 16-byte) store has landed
-__device__ __forceinline__ bool seg_valid(const SegData& d, int D, int item, int segs, int h, int w, unsigned int tag) {
-    const int lane = threadIdx.x & 63;
-    const int seg = item % segs, r = (item / segs) % h;
-    const int c = seg * 64 + lane;
-    const bool rowD = r + D < h, fix = lane >= 64 - D && c + D < w;
-    bool ok = true;
-    if (c < w) { ok &= __float_as_uint(d.o0.w) == tag; if (rowD) ok &= __float_as_uint(d.oD.w) == tag; }
-    if (fix) { ok &= __float_as_uint(d.x0.w) == tag; if (rowD) ok &= __float_as_uint(d.xD.w) == tag; }
-    return __all(ok);
-}
-
-// One wave: the colour pairs whose step row is pooled row r of segment `seg` of image b -- directions (get_image_color_similarity
-// :220-246 through unfold_wo_center's offsets :190-217, each unordered pair once):
-//   0: (r, c) - (r, c+D)    1: (r+D, c) - (r, c+D)    2: (r, c) - (r+D, c)    3: (r, c) - (r+D, c+D)
-// -> one predicate byte per pixel (bit d: squared Lab distance <= n2max, i.e. sim >= thresh for a valid neighbour), and the
-// segment's share of  sum W = sum_n sum_{p in box n} sum_k [sim_k(p) >= thresh]  (:1324-1328): a pair (p, q) weighs
-// [p in box n][q valid] + [q in box n][p valid] for every instance n of the image.  `rect`: lane n holds instance n's box cells.
-__device__ __forceinline__ void affinity_item(const InstArgs& a, const ImageMeta& meta, const Ws& ws, int D, float n2max, int zero_bit,
-                                              const SegData& d, int4 rect, int item, int segs) {
-    const int h = a.h, w = a.w, lane = threadIdx.x & 63;
-    const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
-    const int c = seg * 64 + lane, cn = c + D;
-    const bool rowD = r + D < h;                                  // wave-uniform
-    float nL = lane_plus_n(d.o0.x, D), nA = lane_plus_n(d.o0.y, D), nB = lane_plus_n(d.o0.z, D);
-    float mL = lane_plus_n(d.oD.x, D), mA = lane_plus_n(d.oD.y, D), mB = lane_plus_n(d.oD.z, D);
-    if (lane >= 64 - D) { nL = d.x0.x; nA = d.x0.y; nB = d.x0.z; mL = d.xD.x; mA = d.xD.y; mB = d.xD.z; }   // the right neighbour lives in the next segment
-    const bool cin = c < w, nin = cn < w;
-    const bool p0 = cin && nin && n2_of(d.o0.x, d.o0.y, d.o0.z, nL, nA, nB) <= n2max;
-    const bool p1 = cin && nin && rowD && n2_of(d.oD.x, d.oD.y, d.oD.z, nL, nA, nB) <= n2max;
-    const bool p2 = cin && rowD && n2_of(d.o0.x, d.o0.y, d.o0.z, d.oD.x, d.oD.y, d.oD.z) <= n2max;
-    const bool p3 = cin && nin && rowD && n2_of(d.o0.x, d.o0.y, d.o0.z, mL, mA, mB) <= n2max;
-    if (cin) ws.pred[((int64_t)b * h + r) * w + c] = (unsigned char)((p0 ? 1 : 0) | (p1 ? 2 : 0) | (p2 ? 4 : 0) | (p3 ? 8 : 0));
-    if (zero_bit) return;        // thresh <= 0: every pair weighs 1, sum W has a closed form (pair3_kernel)
-    const int vrow = valid_cells(min(meta.img_h[b], meta.first_removed[b]), a.stride, h), vcol = valid_cells(meta.img_w[b], a.stride, w);
-    const bool v00 = r < vrow && c < vcol, v0n = r < vrow && cn < vcol, vD0 = r + D < vrow && c < vcol, vDn = r + D < vrow && cn < vcol;
-    // what a box containing the site adds:  (r, c)  (r, c+D)  (r+D, c)  (r+D, c+D)
-    const int s00 = (p0 && v0n) + (p2 && vD0) + (p3 && vDn), s0n = (p0 && v00) + (p1 && vD0), sD0 = (p1 && v0n) + (p2 && v00), sDn = (p3 && v00) ? 1 : 0;
-    int cnt = 0;
-    for (int m0 = 0; m0 < a.N; m0 += 64) {
-        if (m0) rect = m0 + lane < a.N ? rect_entry(a, m0 + lane) : make_int4(0, 0, -1, 0);
-        // the instances of this image whose rows reach r or r + D: usually a handful
-        const int q0 = rect.x & 0xffff, q1 = (int)((unsigned int)rect.x >> 16);
-        unsigned long long mask = __ballot(m0 + lane < a.N && rect.z == b && ((r >= q0 && r < q1) || (r + D >= q0 && r + D < q1)));
-        while (mask) {
-            const int n = __ffsll((long long)mask) - 1;
-            mask &= mask - 1ull;
-            const int rx = __builtin_amdgcn_readlane(rect.x, n), ry = __builtin_amdgcn_readlane(rect.y, n);
-            const int r0 = rx & 0xffff, r1 = (int)((unsigned int)rx >> 16), c0 = ry & 0xffff, c1 = (int)((unsigned int)ry >> 16);
-            const bool rr = r >= r0 && r < r1, rD = r + D >= r0 && r + D < r1;
-            const bool c_in = c >= c0 && c < c1, n_in = cn >= c0 && cn < c1;
-            cnt += (rr && c_in ? s00 : 0) + (rr && n_in ? s0n : 0) + (rD && c_in ? sD0 : 0) + (rD && n_in ? sDn : 0);
-        }
-    }
-    cnt = wave_total_i32(cnt);
-    if (lane == 0 && cnt)       // integer adds commute: run-to-run identical
-        __hip_atomic_fetch_add(ws.sumw + (size_t)(item & (kSumWords - 1)) * kAcc2Stride, (unsigned long long)(unsigned int)cnt, BXI_RLX, BXI_AGENT);
-}
-
-// The block's waves, once no image load of theirs is in flight: arrivals for two of the block's segments at a time (both
-// atomics and the speculative reads in one round trip), then the tasks of the targets these arrivals completed.
-__device__ __forceinline__ void seg_arrive2(const InstArgs& a, const ImageMeta& meta, const Ws& ws, int dil, float n2max, int zero_bit, unsigned int tag,
-                                            int4 rect, int item0, int item1 /* -1: none */, int segs) {
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int h = a.h, w = a.w;
-    SegTask t[2];
-    t[0] = seg_task(item0, segs, h, dil, wv);
-    t[1] = seg_task(item1 >= 0 ? item1 : item0, segs, h, dil, wv);
-    if (item1 < 0) { t[1].have = false; t[1].spec = false; }
-    unsigned int old[2] = {0u, 0u};
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-        if (t[k].have && lane == 0) old[k] = __hip_atomic_fetch_add(ws.item_cnt + t[k].target, 1u, BXI_RLX, BXI_AGENT);
-    SegData d[2];
-    bool fresh[2] = {false, false};
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-        if (t[k].spec) { seg_read(ws, dil, t[k].target, segs, h, w, d[k]); fresh[k] = true; }      // in flight together with the atomics
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (!t[k].have) continue;                                  // wave-uniform
-        const unsigned int now = (unsigned int)__builtin_amdgcn_readfirstlane((int)old[k]) + 1u;
-        if (now > t[k].expected) { if (lane == 0) atomicOr(ws.fault, kFaultItemCount); continue; }
-        if (now != t[k].expected) continue;
-        // the last arrival: every contributor has ISSUED its stores; one that has not landed yet is re-read
-        bool ok = fresh[k] && seg_valid(d[k], dil, t[k].target, segs, h, w, tag);
-        for (int tries = 0; !ok && tries < kTagRetries; ++tries) {
-            if (tries) __builtin_amdgcn_s_sleep(4);
-            seg_read(ws, dil, t[k].target, segs, h, w, d[k]);
-            ok = seg_valid(d[k], dil, t[k].target, segs, h, w, tag);
-        }
-        if (!ok) { if (lane == 0) atomicOr(ws.fault, kFaultTag); continue; }
-        affinity_item(a, meta, ws, dil, n2max, zero_bit, d[k], rect, t[k].target, segs);
-    }
-}
-
 // items first, first + step, ... < n_items
-__device__ __forceinline__ void pool_block(const PoolArgs& pa, const InstArgs& a, const Ws& ws, int dil, float n2max, int zero_bit, unsigned int tag,
-                                           int first, int step, int n_items, double* lut /*[256]*/, int* part /*[4][3][64]*/,
-                                           double* fch /*[3][64]*/, int tix) {
+__device__ __forceinline__ void pool_block(const PoolArgs& pa, const Ws& ws, int first, int step, int n_items, double* lut /*[256]*/,
+                                           int* part /*[4][3][64]*/, double* fch /*[3][64]*/, int tix) {
     const int h = pa.Hc >> 2, w = pa.Wc >> 2;
     const int segs = (w + 63) >> 6;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float4 v[3], nx[3];
     pool_load(pa, first, segs, h, w, v);
     lut[threadIdx.x] = kSrgbLut[threadIdx.x];            // staged while the image loads fly
-    // lane n of every wave: instance n's box cells (requested now, used by the segment tasks at the end)
-    const int4 rect = lane < a.N ? rect_entry(a, lane) : make_int4(0, 0, -1, 0);
     for (int item = first; item < n_items; item += step) {
         const bool more = item + step < n_items;         // workgroup-uniform
         if (more) pool_load(pa, item + step, segs, h, w, nx);
@@ -542,26 +380,22 @@ __device__ __forceinline__ void pool_block(const PoolArgs& pa, const InstArgs& a
         }
         BXI_TW(0, tix, 3);
         lds_barrier();
-        if (wv == 0 && act) {       // one 16-byte write-through store per pooled pixel: (L, a, b, tag); a reader that finds the tag has the pixel
+        BXI_TW(0, tix, 4);
+        if (wv == 3 && act) {       // one 16-byte store per pooled pixel (the wave that had no channel to compute)
             const double f0 = fch[lane], f1 = fch[64 + lane], f2 = fch[128 + lane];
-            store4_through(reinterpret_cast<float*>(ws.lab4 + ((int64_t)b * h + r) * w + c), (float)__dadd_rn(__dmul_rn(116.0, f1), -16.0),
-                           (float)__dmul_rn(500.0, __dadd_rn(f0, -f1)), (float)__dmul_rn(200.0, __dadd_rn(f1, -f2)), __uint_as_float(tag));
+            ws.lab4[((int64_t)b * h + r) * w + c] = make_float4((float)__dadd_rn(__dmul_rn(116.0, f1), -16.0), (float)__dmul_rn(500.0, __dadd_rn(f0, -f1)),
+                                                                (float)__dmul_rn(200.0, __dadd_rn(f1, -f2)), 0.f);
         }
-        // the next trip's `part` / `fch` writes come after barriers every wave has to reach: no extra barrier needed
+        // the next trip's `part` writes come after this barrier; its `fch` writes after the next one, which wave 3 reaches only
+        // after it has read `fch` here: no extra barrier needed
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) v[ch] = nx[ch];
     }
-    // ---- every image load of this wave has returned: arrivals, and the segment tasks they complete ----
-    lds_barrier();           // wave 0 has ISSUED the block's last Lab store
-    BXI_TW(0, tix, 4);
-    for (int item = first; item < n_items; item += 2 * step)
-        seg_arrive2(a, pa.meta, ws, dil, n2max, zero_bit, tag, rect, item, item + step < n_items ? item + step : -1, segs);
-    BXI_TW(0, tix, 5);
 }
 
 // grid: [table blocks][pool blocks][stream blocks] (pool_first) or [table][stream][pool]
-__global__ __launch_bounds__(256, 5) void prep3_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, float n2max, int zero_bit,
-                                                       unsigned int tag, Ws ws, LossState st, float* __restrict__ g_logits, int vec, int pool_first) {
+__global__ __launch_bounds__(256, 5) void prep3_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, Ws ws, LossState st,
+                                                       float* __restrict__ g_logits, int vec, int pool_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
     const int Sn = (a.h + kSBlk - 1) / kSBlk;
@@ -587,7 +421,7 @@ __global__ __launch_bounds__(256, 5) void prep3_kernel(PoolArgs pa, int n_pool, 
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
         int* part = reinterpret_cast<int*>(fch + 3 * 64);
-        pool_block(pa, a, ws, dil, n2max, zero_bit, tag, idx, n_pool, n_items, lut, part, fch, tix);
+        pool_block(pa, ws, idx, n_pool, n_items, lut, part, fch, tix);
     }
     BXI_TW(0, tix, 7);
 }
@@ -596,11 +430,11 @@ __global__ __launch_bounds__(256, 5) void prep3_kernel(PoolArgs pa, int n_pool, 
 // CondInstMaskHead.forward (condinst_head.py:1139-1164) and the evaluation's first launch as ONE grid of independent roles:
 //   [table blocks][pool blocks][head tiles: instance x 8 x 32 tiles of y -> 16 x 64 logits]
 // A head tile does the stream role's job on the tile it just produced: zero-filled gradient tile (written through), per-row and
-// per-column (value, first index) maxima as partials for the leaders.
+// per-column (value, first index) maxima as partials for the leaders.  Nothing in the launch waits for anything else in it.
 template <int C, bool REL>
-__global__ __launch_bounds__(256, 5) void head_prep3_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, float n2max,
-                                                            int zero_bit, unsigned int tag, Ws ws, LossState st, float* __restrict__ g_logits,
-                                                            DynArgs da, const float* __restrict__ params, float* __restrict__ logits_out) {
+__global__ __launch_bounds__(256, 7) void head_prep3_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, Ws ws, LossState st,
+                                                            float* __restrict__ g_logits, DynArgs da, const float* __restrict__ params,
+                                                            float* __restrict__ logits_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
     const int blk = (int)blockIdx.x;
@@ -613,7 +447,7 @@ __global__ __launch_bounds__(256, 5) void head_prep3_kernel(PoolArgs pa, int n_p
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
         int* part = reinterpret_cast<int*>(fch + 3 * 64);
-        pool_block(pa, a, ws, dil, n2max, zero_bit, tag, blk - n_tab, n_pool, n_items, lut, part, fch, tix);
+        pool_block(pa, ws, blk - n_tab, n_pool, n_items, lut, part, fch, tix);
     } else {
         const int tiles_x = (da.W + kYC - 1) / kYC, tiles_y = (da.H + kYR - 1) / kYR;
         int t = blk - n_tab - n_pool;
@@ -623,27 +457,18 @@ __global__ __launch_bounds__(256, 5) void head_prep3_kernel(PoolArgs pa, int n_p
         unsigned long long* ckeys = reinterpret_cast<unsigned long long*>(smem);          // [4][64]
         float* otile = reinterpret_cast<float*>(ckeys + 4 * 64);                          // [16][64]
         float* ytile = otile + 16 * 64;                                                   // [(kYR+2)*(kYC+2)]
-        const DynEpi ep = {ws.colpart, ws.rowkey, g_logits, ws.n_cb, ws.n_rp, 1};
+        const DynEpi ep = {ws.colpart, ws.rowkey, g_logits, ws.n_cb, ws.n_rp, 0};
         dyn_tile_forward<C, REL, 2, true>(da, params, logits_out, n, ty, tx, ytile, otile, ckeys, ep);
     }
 }
 
-// ---- the image side for strides other than 4 / unaligned canvases: separate launches (pool_rgb_generic of color_affinity.hip
-// -> Lab planes, then these two), no arrival counters needed: each runs after a kernel boundary -----------------------------
-__global__ __launch_bounds__(256) void pack_lab4_kernel(const float* __restrict__ lab, float4* __restrict__ lab4, int B, int64_t P, unsigned int tag) {
+// ---- the image side for strides other than 4 / unaligned canvases: launches of their own (pool_rgb_generic of
+// color_affinity.hip -> Lab planes, then this repacking) -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_lab4_kernel(const float* __restrict__ lab, float4* __restrict__ lab4, int B, int64_t P) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * P; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / P, p = i - b * P;
         const float* src = lab + b * 3 * P + p;
-        lab4[i] = make_float4(src[0], src[P], src[2 * P], __uint_as_float(tag));
-    }
-}
-__global__ __launch_bounds__(256) void affinity_all_kernel(InstArgs a, ImageMeta meta, Ws ws, int dil, float n2max, int zero_bit, int n_items) {
-    const int segs = (a.w + 63) >> 6, lane = threadIdx.x & 63;
-    const int4 rect = lane < a.N ? rect_entry(a, lane) : make_int4(0, 0, -1, 0);
-    for (int item = (int)blockIdx.x * kWaves + (int)(threadIdx.x >> 6); item < n_items; item += (int)gridDim.x * kWaves) {
-        SegData d;
-        seg_read(ws, dil, item, segs, a.h, a.w, d);
-        affinity_item(a, meta, ws, dil, n2max, zero_bit, d, rect, item, segs);
+        lab4[i] = make_float4(src[0], src[P], src[2 * P], 0.f);
     }
 }
 
@@ -791,27 +616,85 @@ __device__ __forceinline__ void load_plane(const float* __restrict__ plane, cons
     }
 }
 
-__device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
+// The colour predicates of a tile's steps from the Lab image (get_image_color_similarity :220-246 through unfold_wo_center's
+// offsets :190-217, thresholded as loss() does :1324): bit i of pb[d] = squared Lab distance of the pair of direction d at step i
+// <= n2max, i.e. sim >= thresh for a valid neighbour.  Right-neighbour values by wavefront rotations, as in the tile wave.
+template <int D, int R>
+__device__ __forceinline__ void pred_bits(const float4* __restrict__ lab4, const Tile& t, int h, int w, int lane, float n2max, uint32_t (&pb)[4]) {
+    constexpr int RD = TG<D, R>::RD;
+    float L[RD], A[RD], B[RD], LR[RD], AR[RD], BR[RD];
+    const float4* img = lab4 + (int64_t)t.img * h * w;
+    const uint32_t cc = (uint32_t)min(max(t.tile_c0 - D + lane, 0), w - 1);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = wave_total_f32(v[k]);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0)
+    for (int j = 0; j < RD; ++j) {
+        const float4 v = img[(uint32_t)min(max(t.tile_r0 - D + j, 0), h - 1) * (uint32_t)w + cc];      // one 16-byte load per pixel
+        L[j] = v.x; A[j] = v.y; B[j] = v.z;
+    }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) red[(threadIdx.x >> 6) * 4 + k] = v[k];
-    __syncthreads();
+    for (int j = 0; j < RD; ++j) { LR[j] = lane_plus<D>(L[j]); AR[j] = lane_plus<D>(A[j]); BR[j] = lane_plus<D>(B[j]); }
+    pb[0] = pb[1] = pb[2] = pb[3] = 0u;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]);
+    for (int i = 0; i < R + D; ++i) {
+        const int j = i + D;
+        if (i >= D) pb[0] |= n2_of(L[i], A[i], B[i], LR[i], AR[i], BR[i]) <= n2max ? 1u << i : 0u;
+        pb[1] |= n2_of(L[j], A[j], B[j], LR[i], AR[i], BR[i]) <= n2max ? 1u << i : 0u;
+        pb[2] |= n2_of(L[i], A[i], B[i], L[j], A[j], B[j]) <= n2max ? 1u << i : 0u;
+        pb[3] |= n2_of(L[i], A[i], B[i], LR[j], AR[j], BR[j]) <= n2max ? 1u << i : 0u;
+    }
 }
-__device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
 
-// ---- tile wave (wave64, no LDS, no barrier, no wait) ---------------------------------------------------------------------
+// ---- count wave: sum over the tile's owned pixels of W[k,p] (Lab only) -> one packed atomic per tile ------------------------
+template <int D, int R>
+__device__ __forceinline__ void count_tile(const InstArgs& a, const Ws& ws, const Tile& t, float n2max, int tix) {
+    const int lane = threadIdx.x & 63;
+    uint32_t pb[4];
+    pred_bits<D, R>(ws.lab4, t, a.h, a.w, lane, n2max, pb);
+    const TileFlags f = tile_flags<D, R>(t, a.h, a.w, lane);
+    DirMasks m[4];
+    dir_masks<D>(f, pb, m);
+    int cnt = 0;
+#pragma unroll
+    for (int dir = 0; dir < 4; ++dir) cnt += __popc(m[dir].nA) + __popc(m[dir].nB);
+    cnt = wave_total_i32(cnt);
+    BXI_TW(2, tix, 2);
+    if (lane == 0)   // (arrival, sum W); integer adds commute: run-to-run identical
+        __hip_atomic_fetch_add(&ws.acc1[(size_t)((t.n * 7 + t.tile_r0 / R + t.tile_c0) & (kAcc1Words - 1)) * kAcc2Stride],
+                               (1ull << 40) | (unsigned long long)(unsigned int)cnt, BXI_RLX, BXI_AGENT);
+}
+
+// One round over the count words: true when every tile of the list has been counted; then *total = sum W over all instances.
+__device__ __forceinline__ bool counts_complete(const Ws& ws, int ntiles, double* total) {
+    const unsigned long long x = __hip_atomic_load(&ws.acc1[(size_t)(threadIdx.x & 63) * kAcc2Stride], BXI_RLX, BXI_AGENT);
+    const int arrived = wave_total_i32((int)(x >> 40));
+    *total = wave_total_f64((double)(x & ((1ull << 40) - 1ull)));       // exact: integers far below 2^53
+    return arrived == ntiles;
+}
+// thresh <= 0: every pair (padded ones too) weighs 1 (:1324), sum W = 8 x the box areas; no count waves then
+__device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, const Ws& ws) {
+    const int lane = threadIdx.x & 63;
+    double s = 0.0;
+    for (int m0 = 0; m0 < a.N; m0 += 64) {
+        const int m = m0 + lane;
+        if (m < a.N) {
+            const int4 e = ws.tab[m];
+            const int r0 = e.y & 0xffff, r1 = (int)((unsigned int)e.y >> 16), c0 = e.z & 0xffff, c1 = (int)((unsigned int)e.z >> 16);
+            s += 8.0 * (double)((r1 - r0) * (int64_t)(c1 - c0));
+        }
+    }
+    return wave_total_f64(s);
+}
+
+// ---- tile wave (wave64, no LDS, no barrier) ------------------------------------------------------------------------------
 // Every UNORDERED pair is evaluated once and feeds both of its pixels: f(p,q) = f(q,p), the two weights W[k,p] + W[7-k,q]
 // share the colour predicate.  Per pixel (a, b) = (sigmoid(x), sigmoid(-x)), t = a - b, u = a b.  Per pair (p, q):
 //   S = a_p a_q + b_p b_q ; pw = -log S ; d pw / d x_p = -t_q u_p / S ; d pw / d x_q = -t_p u_q / S      (pairwise.cu:38-61)
 // S cannot underflow while every |x| <= 34; tiles with a larger logit take the log-space path.
+// Its one wait: sum W (the normaliser is global, :1327-1328) from the count waves, which precede the tile waves in the grid
+// and never wait themselves; by the time a tile wave asks, they are long done.
 template <int D, int R>
-__device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float scale, float n2max, int zero_bit,
-                                          float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */, int tix) {
+__device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float upw_warm, float n2max, int zero_bit, int ntiles,
+                                          float& scale, bool& have_scale, float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
+                                          int tix) {
     constexpr int RD = TG<D, R>::RD;
     const int lane = threadIdx.x & 63;
     const int h = a.h, w = a.w, n = t.n;
@@ -819,28 +702,17 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     const float* Lg = a.logits + (int64_t)n * P;
     const int c = t.tile_c0 - D + lane;
     const bool col_owned = g_logits && lane >= D && lane < 64 - D && c < t.hc1;
-    // everything the tile needs is plain data of the previous launch, requested together
     float x[RD];
     load_plane<D, R>(Lg, t, h, w, lane, x);
-    uint32_t pbyte[R + D];
-    {
-        const unsigned char* pp = ws.pred + (int64_t)t.img * P;
-        const uint32_t cc = (uint32_t)min(max(c, 0), w - 1);
-#pragma unroll
-        for (int i = 0; i < R + D; ++i) pbyte[i] = pp[(uint32_t)min(max(t.tile_r0 - D + i, 0), h - 1) * (uint32_t)w + cc];
-    }
     float g[R];
     float num = 0.f;
 #pragma unroll
     for (int j = 0; j < R; ++j) g[j] = 0.f;
     bool slow = zero_bit != 0;
     if (!slow) {
+        uint32_t pb[4];
+        pred_bits<D, R>(ws.lab4, t, h, w, lane, n2max, pb);
         const TileFlags f = tile_flags<D, R>(t, h, w, lane);
-        uint32_t pb[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = 0; i < R + D; ++i)
-#pragma unroll
-            for (int d = 0; d < 4; ++d) pb[d] |= ((pbyte[i] >> d) & 1u) << i;
         DirMasks m[4];
         dir_masks<D>(f, pb, m);
         float pa_[RD], pb_[RD], pt_[RD], pu_[RD];    // this lane, rows [i, i + D] live
@@ -905,6 +777,21 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     BXI_TW(1, tix, 3);
     num = wave_total_f32(num);
     const long long fx = (long long)(num * kNumScale) + (1ll << 24);           // + 1.0: keeps the packed field non-negative
+    if (!have_scale) {           // wave-uniform; once per wave
+        double total_w = 0.0;
+        if (zero_bit) total_w = total_weight_all_pairs(a, ws);
+        else {
+            bool ok = false;
+            for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {
+                if (counts_complete(ws, ntiles, &total_w)) { ok = true; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
+        }
+        scale = upw_warm / fmaxf((float)total_w, 1.f);
+        have_scale = true;
+    }
+    BXI_TW(1, tix, 4);
     if (g_logits) {
         char* G = reinterpret_cast<char*>(g_logits + (int64_t)n * P);      // scalar base + 32-bit byte offset
 #pragma unroll
@@ -913,12 +800,25 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
             if (col_owned && r < h) add_f32(reinterpret_cast<float*>(G + (uint32_t)(r * w + c) * 4u), g[j] * scale);
         }
     }
-    BXI_TW(1, tix, 4);
+    BXI_TW(1, tix, 5);
     // this tile's share of sum W pw + its arrival: one atomic without return; the wave does not wait for it
     if (lane == 0)
         __hip_atomic_fetch_add(acc2_word(ws.acc2, n, t.tile_r0 / R + t.tile_c0 / TG<D, R>::TW), (1ull << 52) + (unsigned long long)fx, BXI_RLX, BXI_AGENT);
-    BXI_TW(1, tix, 5);
+    BXI_TW(1, tix, 6);
 }
+
+__device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = wave_total_f32(v[k]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[(threadIdx.x >> 6) * 4 + k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]);
+}
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
 
 // ---- leader workgroup (one per instance) -------------------------------------------------------------------------------
 //   partial maxima -> maxima -> sigmoid on those only -> both dice terms (:117-143) -> unit projection gradients, recorded as
@@ -968,13 +868,13 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const W
             sums[2] += Y * TY; sums[3] += Y * Y + TY * TY;
         }
     }
-    BXI_TW(2, n, 1);
+    BXI_TW(3, 1 + n, 1);
     block_sum4(sums, red);
     const float Ix = sums[0], Ux = sums[1] + 1e-5f, Iy = sums[2], Uy = sums[3] + 1e-5f;
     if (tid == 0)   // :130, summed over both axes :143; the datum is its own flag
         __hip_atomic_store(&ws.dice[n], (1ull << 32) | (unsigned long long)__float_as_uint((1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy)),
                            BXI_RLX, BXI_AGENT);
-    BXI_TW(2, n, 2);
+    BXI_TW(3, 1 + n, 2);
     if (g_logits) {
         // dice = 1 - 2I/U ; d dice/d u_j = (-2 t_j U + 4 I u_j) / U^2 ; chain through sigmoid ; mean over N
         const float invN = 1.f / (float)a.N;
@@ -1006,23 +906,7 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const W
             if (carg[c] != r) add_f32(G + (int64_t)r * w + c, ys[r] * upp);
         }
     }
-    BXI_TW(2, n, 3);
-}
-
-// sum W of the evaluation: the pool blocks' count words, or (thresh <= 0: every pair weighs 1, :1324) 8 x the box areas
-__device__ __forceinline__ double total_weight(const InstArgs& a, const Ws& ws, int zero_bit) {
-    const int lane = threadIdx.x & 63;
-    if (!zero_bit) return wave_total_f64((double)ws.sumw[(size_t)lane * kAcc2Stride]);      // exact: integers far below 2^53
-    double s = 0.0;
-    for (int m0 = 0; m0 < a.N; m0 += 64) {
-        const int m = m0 + lane;
-        if (m < a.N) {
-            const int4 e = ws.tab[m];
-            const int r0 = e.y & 0xffff, r1 = (int)((unsigned int)e.y >> 16), c0 = e.z & 0xffff, c1 = (int)((unsigned int)e.z >> 16);
-            s += 8.0 * (double)((r1 - r0) * (int64_t)(c1 - c0));
-        }
-    }
-    return wave_total_f64(s);
+    BXI_TW(3, 1 + n, 3);
 }
 
 __device__ __forceinline__ Tile tile_of(const int4& e, int D, int R, int TW, int n, int idx, int h, int w) {   // e: the instance's table entry (uniform)
@@ -1065,39 +949,68 @@ __device__ __forceinline__ bool finisher_round(const Ws& ws, int N, int b0, doub
     return true;
 }
 
-// grid: [N leaders][tile blocks (4 independent tile waves each, striding through the tile list)][finisher]
+// The tile of list position `ti`: the instance whose tile range holds it (table entries: 16 bytes per instance, the same lines
+// for every wave), then the tile's place inside the instance's hull.  e0 = this lane's entry of the first 64 (N < 64: all).
 template <int D, int R>
-__global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
-                                                       float n2max, int zero_bit, float* __restrict__ losses, float* __restrict__ g_logits,
-                                                       InstArgs a, Ws ws, LossState st, int n_items) {
+__device__ __forceinline__ Tile locate_tile(const Ws& ws, int N, const int4& e0, int ti, int h, int w) {
+    const int lane = threadIdx.x & 63;
+    int n = 0;
+    int4 e = make_int4(0, 0, 0, 0);
+    if (N < 64) {
+        const unsigned long long mask = __ballot(lane < N && (e0.x & 0xffffff) <= ti);
+        n = __popcll(mask) - 1;
+        e.x = __builtin_amdgcn_readlane(e0.x, n); e.y = __builtin_amdgcn_readlane(e0.y, n);
+        e.z = __builtin_amdgcn_readlane(e0.z, n); e.w = __builtin_amdgcn_readlane(e0.w, n);
+    } else {
+        for (int m0 = 0; m0 < N; m0 += 64) {
+            int4 em = make_int4(0, 0, 0, 0);
+            if (m0 + lane < N) em = ws.tab[m0 + lane];
+            const unsigned long long mask = __ballot(m0 + lane < N && (em.x & 0xffffff) <= ti);
+            const int cntm = __popcll(mask);
+            if (cntm == 0) break;
+            n = m0 + cntm - 1;
+            e.x = __builtin_amdgcn_readlane(em.x, cntm - 1); e.y = __builtin_amdgcn_readlane(em.y, cntm - 1);
+            e.z = __builtin_amdgcn_readlane(em.z, cntm - 1); e.w = __builtin_amdgcn_readlane(em.w, cntm - 1);
+            if (cntm < 64) break;
+        }
+    }
+    return tile_of(e, D, R, TG<D, R>::TW, n, ti - (e.x & 0xffffff), h, w);
+}
+
+// grid: [N leaders][n_cb count blocks][n_cb tile blocks][finisher]; a count / tile block = 4 independent waves striding through
+// the tile list.  The only waits: a tile wave for the count waves (earlier in the grid, never waiting themselves), the finisher
+// for everybody (nobody waits for it).  Every wait is bounded, and running out of it is loud: NaN losses, status word, poisoned
+// gradient (the reference surfaces launch failures through AT_CUDA_CHECK, pairwise.cu:173,200).
+template <int D, int R>
+__global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair3_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
+                                                       float n2max, int zero_bit, int n_cb, float* __restrict__ losses, float* __restrict__ g_logits,
+                                                       InstArgs a, Ws ws, LossState st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[16];
     const int blk = (int)blockIdx.x, lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int N = a.N;
     const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
     if (blk < N) {                                                     // ---- leader of instance blk
-        BXI_TW(2, blk, 0);
+        BXI_TW(3, 1 + blk, 0);
         leader_block(a, D, ws, st, blk, upp, g_logits, smem, red);
         return;
     }
-    if (blk == (int)gridDim.x - 1) {                                   // ---- finisher
-        // launch 1 is complete: its arrival counters go back to zero for the next evaluation
-        for (int i = threadIdx.x; i < n_items; i += 256) ws.item_cnt[i] = 0u;
+    if (blk == (int)gridDim.x - 1) {                                   // ---- finisher: one wave
         if (threadIdx.x >= 64) return;
         BXI_TW(3, 0, 0);
-        // final since the kernel boundary: requested before the polls, used after them
-        const double total_w = total_weight(a, ws, zero_bit);
-        const unsigned int fault = __hip_atomic_load(ws.fault, BXI_RLX, BXI_AGENT);
+        const int ntiles = __builtin_amdgcn_readfirstlane(ws.tab[N].x);
         bool ok = false;
-        double num = 0.0;
+        double num = 0.0, total_w = 0.0;
         float dsum = 0.f;
-        for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {        // waits only for workgroups that never wait themselves
+        for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {        // waits only for workgroups that never wait for it
             num = 0.0; dsum = 0.f;
-            bool all = true;
+            bool all = zero_bit ? true : counts_complete(ws, ntiles, &total_w);     // requested with the first pass's loads
             for (int b0 = 0; b0 < N && all; b0 += 64) all = finisher_round(ws, N, b0, &num, &dsum);
             if (all) { ok = true; break; }
             __builtin_amdgcn_s_sleep(2);
         }
+        if (zero_bit) total_w = total_weight_all_pairs(a, ws);
+        const unsigned int fault = __hip_atomic_load(ws.fault, BXI_RLX, BXI_AGENT);   // set by a tile wave BEFORE its arrival, if at all
         const unsigned int status = (unsigned int)__builtin_amdgcn_readfirstlane((int)(fault | (ok ? 0u : kFaultFinisher)));
         if (lane == 0) {
             const float denom = fmaxf((float)total_w, 1.f);                      // weights.sum().clamp(min=1.0), :1328
@@ -1107,46 +1020,25 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_ke
             losses[0] = l0; losses[1] = l1;
             if (st.scale) { *st.scale = warmup / denom; st.applied[0] = upp; st.applied[1] = upw; }
             if (st.status) st.status[0] = (int)status;
-            *ws.fault = 0u;
         }
-        ws.sumw[(size_t)lane * kAcc2Stride] = 0ull;                              // every tile wave has read it (or the evaluation is void)
         BXI_TW(3, 0, 1);
         return;
     }
-    const int wid = (blk - N) * kWaves + wave, nwaves = ((int)gridDim.x - 1 - N) * kWaves;
-    BXI_TW(1, wid, 0);
-    // the table (16 bytes per instance, the same lines for every wave) and the count words, requested together
+    const bool counting = blk < N + n_cb;
+    if (counting && zero_bit) return;                                  // sum W has a closed form then
+    const int wid = (counting ? blk - N : blk - N - n_cb) * kWaves + wave, nwaves = n_cb * kWaves;
+    BXI_TW(counting ? 2 : 1, wid, 0);
     int4 e0 = make_int4(0, 0, 0, 0);
     if (lane <= N) e0 = ws.tab[lane];
-    const double total_w = total_weight(a, ws, zero_bit);
     const int total = N < 64 ? __builtin_amdgcn_readlane(e0.x, N < 64 ? N : 0) : __builtin_amdgcn_readfirstlane(ws.tab[N].x);
-    if (wid >= total) return;
-    const float scale = upw * (warmup / fmaxf((float)total_w, 1.f));
     float* gbuf = reinterpret_cast<float*>(smem) + wave * ((R + 1) * 64);
+    float scale = 0.f;
+    bool have_scale = false;
     for (int ti = wid; ti < total; ti += nwaves) {
-        int n = 0;
-        int4 e = make_int4(0, 0, 0, 0);
-        if (N < 64) {
-            const unsigned long long mask = __ballot(lane < N && (e0.x & 0xffffff) <= ti);
-            n = __popcll(mask) - 1;
-            e.x = __builtin_amdgcn_readlane(e0.x, n); e.y = __builtin_amdgcn_readlane(e0.y, n);
-            e.z = __builtin_amdgcn_readlane(e0.z, n); e.w = __builtin_amdgcn_readlane(e0.w, n);
-        } else {
-            for (int m0 = 0; m0 < N; m0 += 64) {
-                int4 em = make_int4(0, 0, 0, 0);
-                if (m0 + lane < N) em = ws.tab[m0 + lane];
-                const unsigned long long mask = __ballot(m0 + lane < N && (em.x & 0xffffff) <= ti);
-                const int cntm = __popcll(mask);
-                if (cntm == 0) break;
-                n = m0 + cntm - 1;
-                e.x = __builtin_amdgcn_readlane(em.x, cntm - 1); e.y = __builtin_amdgcn_readlane(em.y, cntm - 1);
-                e.z = __builtin_amdgcn_readlane(em.z, cntm - 1); e.w = __builtin_amdgcn_readlane(em.w, cntm - 1);
-                if (cntm < 64) break;
-            }
-        }
-        const Tile t = tile_of(e, D, R, TG<D, R>::TW, n, ti - (e.x & 0xffffff), a.h, a.w);
-        BXI_TW(1, wid, 1);
-        math_tile<D, R>(a, ws, t, scale, n2max, zero_bit, g_logits, gbuf, wid);
+        const Tile t = locate_tile<D, R>(ws, N, e0, ti, a.h, a.w);
+        BXI_TW(counting ? 2 : 1, wid, 1);
+        if (counting) count_tile<D, R>(a, ws, t, n2max, wid);
+        else math_tile<D, R>(a, ws, t, upw * warmup, n2max, zero_bit, total, scale, have_scale, g_logits, gbuf, wid);
     }
 }
 
@@ -1261,26 +1153,19 @@ static HostPred host_pred(float thresh) {
     return p;
 }
 
-static unsigned int next_tag() {        // marks the Lab pixels of one evaluation; never the same for two consecutive evaluations
-    static std::atomic<unsigned int> counter{0x5a5a0000u};
-    unsigned int t = counter.fetch_add(1u, std::memory_order_relaxed) + 1u;
-    return t;
-}
-
 template <int D, int R>
-static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, float warmup, float n2max, int zero_bit, const Ws& ws,
-                        const LossState& st, float* losses, float* g_logits, const float* up_prj, const float* up_pw, int n_items) {
-    BXI_LAUNCH("pair", s, (pair3_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, up_prj, up_pw, warmup, n2max, zero_bit, losses, g_logits,
-               a, ws, st, n_items);
+static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, float warmup, float n2max, int zero_bit, int n_cb, const Ws& ws,
+                        const LossState& st, float* losses, float* g_logits, const float* up_prj, const float* up_pw) {
+    BXI_LAUNCH("pair", s, (pair3_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, up_prj, up_pw, warmup, n2max, zero_bit, n_cb, losses,
+               g_logits, a, ws, st);
 }
 
 }  // namespace v3
 
 size_t eval3_ws_bytes(int B, int N, int h, int w) { return v3::carve(nullptr, B, N, h, w, nullptr); }
-size_t eval3_sync_bytes() { return v3::kSyncBytes; }
 bool eval3_supported(int dil) { return dil >= 1 && dil <= v3::kMaxDilFused; }
 
-// One evaluation, two launches.  `workspace` starts with the sync region (zero between evaluations).
+// One evaluation, two launches.
 int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_instances* in, int dil, float warmup, const float* up_prj,
                  const float* up_pw, float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, int force_rows,
                  void* stream, const DynArgs* head, int head_C) {
@@ -1323,7 +1208,6 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     const int R = force_rows == 4 || force_rows == 8 ? force_rows : tile_rows_for(a.N);
     if (eval_cap(a.N, a.h, a.w, dil, R) >= (1 << 24)) return BXI_ERR_BAD_SHAPE;     // the table packs a tile prefix into 24 bits
     const HostPred pr = host_pred(color_thresh);
-    const unsigned int tag = next_tag();
 
     // ---- launch 1 --------------------------------------------------------------------------------------------------
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
@@ -1332,7 +1216,7 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     // one item = the 4 input rows of 64 pooled pixels.  The whole launch should be resident at once (5 workgroups per CU at
     // <= 96 VGPRs): a pool workgroup takes several items, the next one's loads in flight, when it is not.
     const int64_t n_items64 = (int64_t)batch->B * a.h * ((a.w + 63) / 64);
-    if (n_items64 > kMaxItems) return BXI_ERR_UNSUPPORTED;
+    if (n_items64 > 0x7fffffffLL) return BXI_ERR_BAD_SHAPE;
     const int n_items = (int)n_items64;
     const int room = env_pool_wgs * device_cus() - n_tab - (head ? 0 : n_stream);
     const int per = room > 0 ? (n_items + room - 1) / room : 8;
@@ -1351,8 +1235,8 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
         float* logits_out = const_cast<float*>(a.logits);
         const unsigned grid1 = (unsigned)(n_tab + n_pool + a.N * tiles);
 #define BXI_HEAD_LAUNCH(CC, RR)                                                                                                          \
-        BXI_LAUNCH("head_prep", s, (head_prep3_kernel<CC, RR>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, pr.n2max,  \
-                   pr.zero_bit, tag, ws, st, g_logits, *head, head->params, logits_out)
+        BXI_LAUNCH("head_prep", s, (head_prep3_kernel<CC, RR>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, ws, st,     \
+                   g_logits, *head, head->params, logits_out)
         if (head_C == 16 && head->rel) BXI_HEAD_LAUNCH(16, true);
         else if (head_C == 16) BXI_HEAD_LAUNCH(16, false);
         else if (head_C == 8 && head->rel) BXI_HEAD_LAUNCH(8, true);
@@ -1362,8 +1246,8 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     } else {
         if (lds1 < 8 * (size_t)kWaves * a.w) lds1 = 8 * (size_t)kWaves * a.w;
         if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
-        BXI_LAUNCH("prep", s, prep3_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R,
-                   pr.n2max, pr.zero_bit, tag, ws, st, g_logits, vec, env_pool_first);
+        BXI_LAUNCH("prep", s, prep3_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, ws, st,
+                   g_logits, vec, env_pool_first);
     }
     rc = check_launch();
     if (rc != BXI_OK) return rc;
@@ -1372,30 +1256,29 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
         if (rc != BXI_OK) return rc;
         const int64_t BP = (int64_t)batch->B * a.h * a.w;
         BXI_LAUNCH("pack_lab4", s, pack_lab4_kernel, dim3((unsigned)((BP + 255) / 256 > 2048 ? 2048 : (BP + 255) / 256)), dim3(256), 0, s,
-                   (const float*)ws.lab_planar, ws.lab4, batch->B, (int64_t)a.h * a.w, tag);
-        BXI_LAUNCH("affinity_all", s, affinity_all_kernel, dim3((unsigned)((n_items + kWaves - 1) / kWaves > 2048 ? 2048 : (n_items + kWaves - 1) / kWaves)),
-                   dim3(256), 0, s, a, pa.meta, ws, dil, pr.n2max, pr.zero_bit, n_items);
+                   (const float*)ws.lab_planar, ws.lab4, batch->B, (int64_t)a.h * a.w);
         rc = check_launch();
         if (rc != BXI_OK) return rc;
     }
 
     // ---- launch 2 --------------------------------------------------------------------------------------------------
     const int64_t cap = eval_cap(a.N, a.h, a.w, dil, R);
-    int64_t n_mb = (cap + kWaves - 1) / kWaves;
-    // the list length is device data: the tile waves stride through it; the launch should be resident in one round
+    int64_t n_cb = (cap + kWaves - 1) / kWaves;
+    // the list length is device data: the tile waves stride through it.  3 (R = 4) or 2 (R = 8) workgroups per CU are resident:
+    // leaders + count + tile blocks should fit in one round.
     static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 0);
     const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? 3 : 2);
-    const int room2 = occ * device_cus() - 1 - a.N;
-    if (n_mb > (room2 > 64 ? room2 : 64)) n_mb = room2 > 64 ? room2 : 64;
+    const int room2 = (occ * device_cus() - a.N - 1) / 2;
+    if (n_cb > (room2 > 64 ? room2 : 64)) n_cb = room2 > 64 ? room2 : 64;
     size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
     const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
     if (lds2 < lds_leader) lds2 = lds_leader;
     if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
-    const int grid = a.N + (int)n_mb + 1;                 // leaders + tile blocks + the finisher
+    const int grid = a.N + 2 * (int)n_cb + 1;             // leaders + count blocks + tile blocks + the finisher
 #define BXI_PAIR_CASE(DD)                                                                                                                  \
     case DD:                                                                                                                               \
-        if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, ws, st, losses, g_logits, up_prj, up_pw, n_items);  \
-        else launch_pair<DD, 8>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, ws, st, losses, g_logits, up_prj, up_pw, n_items);         \
+        if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, (int)n_cb, ws, st, losses, g_logits, up_prj, up_pw); \
+        else launch_pair<DD, 8>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, (int)n_cb, ws, st, losses, g_logits, up_prj, up_pw);        \
         break;
     switch (dil) {
         BXI_PAIR_CASE(1) BXI_PAIR_CASE(2) BXI_PAIR_CASE(3) BXI_PAIR_CASE(4)
@@ -1420,12 +1303,6 @@ int launch_rescale3(const bxi_instances* in, const float* g_prj, const float* g_
     hipStream_t s = as_stream(stream);
     BXI_LAUNCH("rescale", s, rescale3_kernel, dim3(8, a.N), dim3(256), 0, s, a, dil, st, g_prj, g_pw, g_logits);
     return check_launch();
-}
-
-int eval3_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
-    if (!workspace || workspace_bytes < v3::kSyncBytes || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
-    if (hipMemsetAsync(workspace, 0, v3::kSyncBytes, as_stream(stream)) != hipSuccess) { set_last_hip_error((int)hipGetLastError()); return BXI_ERR_LAUNCH; }
-    return BXI_OK;
 }
 
 }  // namespace bxi

@@ -194,10 +194,6 @@ class _EvalPlan:
         self.ws = torch.empty(max(lib.bxi_boxinst_eval_workspace_bytes(B, Hc, Wc, stride, N), 256), dtype=torch.uint8,
                               device=dev)
         self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), self.ws.numel()
-        # the arrival counters at the start of the workspace are zero between evaluations: once here, then every evaluation
-        # leaves them so (include/boxinst_hip.h, bxi_boxinst_eval_workspace_init)
-        with torch.cuda.device(dev):
-            _lib.check('bxi_boxinst_eval_workspace_init', lib.bxi_boxinst_eval_workspace_init(self.ws_ptr, self.ws_bytes, stream))
         self.state_bytes = (max(lib.bxi_boxinst_loss_state_bytes(N, h, w), 256) + 255) // 256 * 256
         self.grad_elems = N * h * w
         self.eval = lib.bxi_boxinst_eval_f32

@@ -177,13 +177,13 @@ int bxi_boxinst_loss_fwd_bwd_f32(const bxi_instances* inst_host, const uint8_t* 
 int bxi_boxinst_loss_backward_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw,
                                   int dilation, const void* state, float* g_logits, void* stream);
 
-/* The evaluation proper: forward AND finished backward in one host call, two launches (prep3, pair3; csrc/eval3.hip), in
- * which no workgroup ever waits for another one:
- *   launch 1: image side (stage A above: de-normalise, 4x4 pool, Lab), the colour predicates of stage B as one byte per pooled
- *             pixel and the pair-weight normaliser sum W (:1324-1328; both by the workgroup whose arrival completes a row
- *             segment's neighbourhood), next to the logit streaming (row / column maxima, zero-fill of g_logits; the
- *             instance's last-arriving workgroup finishes its projection term, :117-143) and the per-instance table;
- *   launch 2: the pairwise term per box tile (pairwise.cu:68-149 semantics), finished gradient, both loss scalars.
+/* The evaluation proper: forward AND finished backward in one host call, two launches (prep3, pair3; csrc/eval3.hip):
+ *   launch 1: image side (stage A above: de-normalise, 4x4 pool, Lab) next to the logit streaming (row / column maxima,
+ *             zero-fill of g_logits) and the per-instance table; nothing in it waits;
+ *   launch 2: projection term per instance (:117-143), pair weights and pairwise term per box tile (pairwise.cu:68-149 semantics;
+ *             colour affinity derived from Lab where it is needed, nothing of stage B is materialised), normaliser, both loss
+ *             scalars; the gradient's two parts are ADDED to the zero-filled buffer (at most two additions per element: the
+ *             result does not depend on their order).
  * losses[0] = loss_prj, losses[1] = loss_pairwise (device, f32), complete when the call's work is done.
  * g_logits [N,1,h,w] (nullable: forward only) receives the FINISHED gradient
  *       up_prj * d loss_prj / d logits  +  up_pw * d loss_pairwise / d logits,
@@ -192,22 +192,19 @@ int bxi_boxinst_loss_backward_f32(const bxi_instances* inst_host, const float* g
  *   Different factors later: bxi_boxinst_grad_rescale_f32.
  * warmup: min(_iter / pairwise_warmup, 1) (:1330-1331), evaluated on the host by the caller.
  * state (bxi_boxinst_loss_state_bytes, 256-B aligned; required with g_logits): arg-max positions, unit projection
- *   gradients, box rectangles, normaliser, the factors applied, and a status word.  Status 0 = fine.  Non-zero = the
- *   evaluation is void (an arrival counter was inconsistent -- the workspace was not initialised or is shared by two
- *   evaluations in flight -- or the finisher's bounded wait ran out): BOTH LOSSES ARE NaN then (the reference surfaces launch
- *   failures through AT_CUDA_CHECK, pairwise.cu:173,200; here mmdet's CheckInvalidLossHook fires), and
- *   bxi_boxinst_grad_rescale_f32 poisons the gradient.
- * workspace (bxi_boxinst_eval_workspace_bytes, 256-B aligned): scratch incl. Lab.  Its first bytes hold arrival counters that
- *   must be ZERO when an evaluation starts: call bxi_boxinst_eval_workspace_init once after allocating it (a hipMemsetAsync
- *   of that region on `stream`); every evaluation leaves them zero for the next one, whatever the shapes of the two.
- *   One evaluation per workspace in flight.
+ *   gradients, box rectangles, normaliser, the factors applied, and a status word.  Status 0 = fine.  Non-zero = one of the
+ *   second launch's bounded in-kernel waits ran out (tile waves wait for the count waves that precede them in the grid, the
+ *   finisher for everybody; neither is expected to): BOTH LOSSES ARE NaN then (the reference surfaces launch failures through
+ *   AT_CUDA_CHECK, pairwise.cu:173,200; here mmdet's CheckInvalidLossHook fires), and bxi_boxinst_grad_rescale_f32 poisons the
+ *   gradient.
+ * workspace (bxi_boxinst_eval_workspace_bytes, 256-B aligned): scratch incl. Lab; contents undefined after; every word
+ *   the second launch polls is zeroed by the first, so no initialisation is required.  One evaluation per workspace in flight.
  * batch_host->image_masks must be NULL (explicit masks: bxi_color_affinity_f32 + bxi_boxinst_loss_fwd_bwd_f32).
  * size == 3 and dilation <= 4 are built; others return BXI_ERR_UNSUPPORTED and the host composes section 1 + torch ops
  * as the reference does.  N == 0 writes two zeros (documented deviation; the reference yields NaN).
  * Strides other than 4 / unaligned canvases pool the image in launches of their own (same results, not the fast path). */
 size_t bxi_boxinst_eval_workspace_bytes(int B, int Hc, int Wc, int stride, int N);
-int bxi_boxinst_eval_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
-/* byte offset, inside `workspace`, of the Lab image the evaluation leaves behind: [B, Hc/stride, Wc/stride] x float4 (L, a, b, tag)
+/* byte offset, inside `workspace`, of the Lab image the evaluation leaves behind: [B, Hc/stride, Wc/stride] x float4 (L, a, b, 0)
  * -- what skimage.color.rgb2lab gives at condinst_head.py:1413-1416; exposed so that tests can compare it with scikit-image. */
 size_t bxi_boxinst_eval_workspace_lab_offset(void);
 int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host,

@@ -22,7 +22,6 @@ for seed in range(8):
     losses = torch.zeros(2, device=dev); grad = torch.empty_like(inst.logits)
     state = torch.empty(lib.bxi_boxinst_loss_state_bytes(inst.N, inst.h, inst.w), dtype=torch.uint8, device=dev)
     ws = torch.empty(lib.bxi_boxinst_eval_workspace_bytes(2, 800, 1024, 4, inst.N), dtype=torch.uint8, device=dev)
-    assert lib.bxi_boxinst_eval_workspace_init(ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream) == 0
     sets.append((batch, inst, losses, grad, state, ws, imgs, logits, gi, boxes))
 st = torch.cuda.current_stream().cuda_stream
 def ev(s):
@@ -61,17 +60,20 @@ sw = sw[sw[:, 7] > 0]; pw = pw[pw[:, 7] > 0]
 print('  stream waves:', len(sw), 'start', q(us(sw[:, 0] - t0)), '| loads+zero-fill issued', qd(sw[:, 1], sw[:, 0]), '| data + column max', qd(sw[:, 2], sw[:, 1]),
       '| butterflies', qd(sw[:, 3], sw[:, 2]), '| barrier', qd(sw[:, 4], sw[:, 3]), '| end', q(us(sw[:, 7] - t0)))
 print('  pool waves (last item of each):', len(pw), 'start', q(us(pw[:, 0] - t0)), '| loads + denorm at', q(us(pw[:, 1] - t0)), '| barrier 1', qd(pw[:, 2], pw[:, 1]),
-      '| Lab f', qd(pw[:, 3], pw[:, 2]), '| Lab stored + barrier', qd(pw[:, 4], pw[:, 3]), '| arrivals + segment tasks', qd(pw[:, 5], pw[:, 4]),
-      '| items done at', q(us(pw[:, 4] - t0)), '| end', q(us(pw[:, 7] - t0)))
+      '| Lab f', qd(pw[:, 3], pw[:, 2]), '| barrier 2', qd(pw[:, 4], pw[:, 3]), '| end', q(us(pw[:, 7] - t0)))
 prep_end = p[live, 7].max()
-mw = t[1]; allm = mw[mw[:, 0] > 0]; mw = allm[allm[:, 5] > 0]
-ld = t[2]; ld = ld[ld[:, 0] > 0]
-k0 = min(allm[:, 0].min(), ld[:, 0].min())
+mw = t[1]; allm = mw[mw[:, 0] > 0]; mw = allm[allm[:, 6] > 0]
+cw = t[2]; allc = cw[cw[:, 0] > 0]; cw = allc[allc[:, 2] > 0]
+ld = t[3][1:]; ld = ld[ld[:, 0] > 0]
+k0 = min(allm[:, 0].min(), ld[:, 0].min(), allc[:, 0].min())
 print('pair: first wave starts %.2f us after the last prep wave ended' % us(k0 - prep_end))
 print('  leaders', len(ld), 'start', q(us(ld[:, 0] - k0)), '| loads+maxima', qd(ld[:, 1], ld[:, 0]), '| sums + dice', qd(ld[:, 2], ld[:, 1]),
       '| coefficients + adds', qd(ld[:, 3], ld[:, 2]), '| dice at', q(us(ld[:, 2] - k0)), '| end', q(us(ld[:, 3] - k0)))
-print('  tile waves with a tile', len(mw), 'of', len(allm), 'start', q(us(mw[:, 0] - k0)), '| table -> tile', qd(mw[:, 1], mw[:, 0]), '| data arrived + masks', qd(mw[:, 2], mw[:, 1]),
-      '| pair math', qd(mw[:, 3], mw[:, 2]), '| adds issued', qd(mw[:, 4], mw[:, 3]), '| arrival issued', qd(mw[:, 5], mw[:, 4]), '| end', q(us(mw[:, 5] - k0)))
+print('  count waves with a tile', len(cw), 'of', len(allc), 'start', q(us(cw[:, 0] - k0)), '| table -> tile', qd(cw[:, 1], cw[:, 0]), '| Lab + predicates + count', qd(cw[:, 2], cw[:, 1]),
+      '| counted at', q(us(cw[:, 2] - k0)))
+print('  tile waves with a tile', len(mw), 'of', len(allm), 'start', q(us(mw[:, 0] - k0)), '| table -> tile', qd(mw[:, 1], mw[:, 0]), '| data + predicates + masks', qd(mw[:, 2], mw[:, 1]),
+      '| pair math', qd(mw[:, 3], mw[:, 2]), '| sum W', qd(mw[:, 4], mw[:, 3]), '| adds issued', qd(mw[:, 5], mw[:, 4]), '| arrival issued', qd(mw[:, 6], mw[:, 5]),
+      '| math done at', q(us(mw[:, 3] - k0)), '| end', q(us(mw[:, 6] - k0)))
 fw = t[3][0]
 print('  finisher: start %.2f end %.2f' % (us(fw[0] - k0), us(fw[1] - k0)))
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
