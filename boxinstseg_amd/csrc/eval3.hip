@@ -15,15 +15,18 @@
 //                   of the block's 32 rows -> partials for the leaders of the next launch
 //     pool blocks   the 4 input rows of 64 pooled pixels -> de-normalise, truncate, 4x4 mean, Lab (fp64) -> ONE 16-byte
 //                   store per pooled pixel
-//   launch 2  pair3_kernel   [leaders][count blocks][tile blocks][finisher]
+//   launch 2  pair3_kernel   [leaders][predicate blocks][tile blocks][finisher]
 //     leaders       one block per instance: partial maxima -> maxima -> sigmoid -> dice -> unit projection gradients, ADDED
 //                   (float atomic) at the arg-max positions of the zero-filled gradient.  Nobody waits for a leader but the finisher.
-//     count waves   one wave64 per box tile: the pair weights' sum from Lab alone -> one packed integer atomic per tile
+//     predicate waves  one wave64 per pooled row segment (64 pixels) of an image: the four colour predicates per pixel (one byte)
+//                   -- each unordered pair ONCE PER IMAGE, not once per instance and tile -- and the segment's share of the pair
+//                   weights' sum (a function of the image and the boxes only, :1324-1328) -> one packed integer atomic per segment
 //     tile waves    one wave64 per box tile (no LDS, no barrier): logits tile + halo in registers, every unordered pair
 //                   evaluated once; g_pw warm/max(sum W,1) d pw is ADDED (float atomic) to the gradient -- an element receives
 //                   at most two additions onto 0 (its tile's and its leader's), so the sum does not depend on their order;
-//                   the tile's share of sum W pw goes to an integer accumulator by an atomic without return.  Its one wait:
-//                   sum W (the normaliser is global) from the count waves, which precede it in the grid and never wait.
+//                   the tile's share of sum W pw goes to an integer accumulator by an atomic without return.  Its one wait,
+//                   when the logits have arrived and the per-pixel quantities are computed: every predicate wave has arrived
+//                   (they precede it in the grid and never wait), which also delivers sum W, the global normaliser.
 //     finisher      the last workgroup: polls the accumulators, writes the two loss values.
 // Every wait is bounded and running out of it is loud: NaN losses, a status word, a poisoned gradient (rescale3_kernel).
 // Table entries instead of a work list: a tile wave finds its tile from 16 bytes per instance that every wave reads (the same
@@ -74,12 +77,13 @@ __device__ __forceinline__ void add_f32(float* p, float v) {
 struct Ws {
     float4* lab4;                               // [B,h,w] (L, a, b, 0)
     float* lab_planar;                          // [B,3,h,w] only the generic pooling path (other strides, unaligned canvases) fills it
+    unsigned char* pred;                        // [B,h,w] bit d = colour predicate of pair direction d with this pixel as the step pixel
     unsigned long long* colpart;                // [N,n_cb,w] packed (max logit, first row) of a band of rows
     unsigned long long* rowkey;                 // [N,n_rp,h] packed (max logit, first column)
     int n_cb, n_rp;
     int4* tab;                                  // [N+1] {tile prefix | img << 24, r0 | r1 << 16, c0 | c1 << 16, vrow | vcol << 16}; [N].x = tiles
     // words polled inside pair3_kernel; zeroed by prep3_kernel's table waves, i.e. before a kernel boundary
-    unsigned long long* acc1;                   // [kAcc1Words] (one per 128 B) count waves: arrivals << 40 | sum W
+    unsigned long long* acc1;                   // [kAcc1Words] (one per 128 B) predicate waves: arrivals << 40 | sum W
     unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B) tile waves: arrivals << 52 | sum (W pw + 1) in 2^-24 units
     unsigned long long* dice;                   // [N]   leader: 1 << 32 | bits of the instance's dice loss (0 = not published)
     unsigned int* fault;                        // [1]   bit mask of waits that ran out (never expected)
@@ -106,6 +110,7 @@ static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
     const size_t P = (size_t)h * w, B1 = B > 0 ? B : 1;
     t.lab4 = (float4*)take(16 * B1 * P);
     t.lab_planar = (float*)take(12 * B1 * P);
+    t.pred = (unsigned char*)take(B1 * P);
     t.colpart = (unsigned long long*)take(8 * (size_t)N1 * (cb_max > Sn ? cb_max : Sn) * w);
     t.rowkey = (unsigned long long*)take(8 * (size_t)N1 * h * (rp_max > 1 ? rp_max : 1));
     t.n_cb = (int)Sn; t.n_rp = 1;
@@ -616,60 +621,74 @@ __device__ __forceinline__ void load_plane(const float* __restrict__ plane, cons
     }
 }
 
-// The colour predicates of a tile's steps from the Lab image (get_image_color_similarity :220-246 through unfold_wo_center's
-// offsets :190-217, thresholded as loss() does :1324): bit i of pb[d] = squared Lab distance of the pair of direction d at step i
-// <= n2max, i.e. sim >= thresh for a valid neighbour.  Right-neighbour values by wavefront rotations, as in the tile wave.
-template <int D, int R>
-__device__ __forceinline__ void pred_bits(const float4* __restrict__ lab4, const Tile& t, int h, int w, int lane, float n2max, uint32_t (&pb)[4]) {
-    constexpr int RD = TG<D, R>::RD;
-    float L[RD], A[RD], B[RD], LR[RD], AR[RD], BR[RD];
-    const float4* img = lab4 + (int64_t)t.img * h * w;
-    const uint32_t cc = (uint32_t)min(max(t.tile_c0 - D + lane, 0), w - 1);
-#pragma unroll
-    for (int j = 0; j < RD; ++j) {
-        const float4 v = img[(uint32_t)min(max(t.tile_r0 - D + j, 0), h - 1) * (uint32_t)w + cc];      // one 16-byte load per pixel
-        L[j] = v.x; A[j] = v.y; B[j] = v.z;
-    }
-#pragma unroll
-    for (int j = 0; j < RD; ++j) { LR[j] = lane_plus<D>(L[j]); AR[j] = lane_plus<D>(A[j]); BR[j] = lane_plus<D>(B[j]); }
-    pb[0] = pb[1] = pb[2] = pb[3] = 0u;
-#pragma unroll
-    for (int i = 0; i < R + D; ++i) {
-        const int j = i + D;
-        if (i >= D) pb[0] |= n2_of(L[i], A[i], B[i], LR[i], AR[i], BR[i]) <= n2max ? 1u << i : 0u;
-        pb[1] |= n2_of(L[j], A[j], B[j], LR[i], AR[i], BR[i]) <= n2max ? 1u << i : 0u;
-        pb[2] |= n2_of(L[i], A[i], B[i], L[j], A[j], B[j]) <= n2max ? 1u << i : 0u;
-        pb[3] |= n2_of(L[i], A[i], B[i], LR[j], AR[j], BR[j]) <= n2max ? 1u << i : 0u;
-    }
+// ---- predicate wave: one pooled row segment (64 pixels) of one image ------------------------------------------------------
+// The colour pairs whose step row is pooled row r of segment `seg` of image b -- directions (get_image_color_similarity :220-246
+// through unfold_wo_center's offsets :190-217, each unordered pair ONCE PER IMAGE, not once per instance and tile):
+//   0: (r, c) - (r, c+D)    1: (r+D, c) - (r, c+D)    2: (r, c) - (r+D, c)    3: (r, c) - (r+D, c+D)
+// -> one predicate byte per pixel (bit d: squared Lab distance <= n2max, i.e. sim >= thresh for a valid neighbour), and the
+// segment's share of  sum W = sum_n sum_{p in box n} sum_k [sim_k(p) >= thresh]  (:1324-1328): a pair (p, q) weighs
+// [p in box n][q valid] + [q in box n][p valid] for every instance n of the image.  One packed integer atomic per segment
+// (arrival, count) AFTER its bytes have been written through: who has seen every arrival may read every byte.
+__device__ __forceinline__ float lane_plus_n(float v, int d) {
+    int x = __float_as_int(v);
+    for (int s = 0; s < d; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+    return __int_as_float(x);
 }
-
-// ---- count wave: sum over the tile's owned pixels of W[k,p] (Lab only) -> one packed atomic per tile ------------------------
-template <int D, int R>
-__device__ __forceinline__ void count_tile(const InstArgs& a, const Ws& ws, const Tile& t, float n2max, int tix) {
-    const int lane = threadIdx.x & 63;
-    uint32_t pb[4];
-    pred_bits<D, R>(ws.lab4, t, a.h, a.w, lane, n2max, pb);
-    const TileFlags f = tile_flags<D, R>(t, a.h, a.w, lane);
-    DirMasks m[4];
-    dir_masks<D>(f, pb, m);
+__device__ __forceinline__ void pred_item(const InstArgs& a, const ImageMeta& meta, const Ws& ws, int D, float n2max, int item, int segs) {
+    const int h = a.h, w = a.w, lane = threadIdx.x & 63;
+    const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
+    const int c = seg * 64 + lane, cn = c + D;
+    const bool rowD = r + D < h;                                  // wave-uniform
+    const float4* L4 = ws.lab4 + (int64_t)b * h * w;
+    const int cc = min(c, w - 1), cx = min(lane >= 64 - D ? cn : c, w - 1), rD = min(r + D, h - 1);
+    // this row, the row D below, and for the last D lanes their right neighbours (they live in the next segment)
+    const float4 o0 = L4[(int64_t)r * w + cc], oD = L4[(int64_t)rD * w + cc], x0 = L4[(int64_t)r * w + cx], xD = L4[(int64_t)rD * w + cx];
+    // lane n: instance n's table entry (box cells, image), requested with the Lab
+    int4 rect = lane < a.N ? ws.tab[lane] : make_int4(-1, 0, 0, 0);
+    float nL = lane_plus_n(o0.x, D), nA = lane_plus_n(o0.y, D), nB = lane_plus_n(o0.z, D);
+    float mL = lane_plus_n(oD.x, D), mA = lane_plus_n(oD.y, D), mB = lane_plus_n(oD.z, D);
+    if (lane >= 64 - D) { nL = x0.x; nA = x0.y; nB = x0.z; mL = xD.x; mA = xD.y; mB = xD.z; }
+    const bool cin = c < w, nin = cn < w;
+    const bool p0 = cin && nin && n2_of(o0.x, o0.y, o0.z, nL, nA, nB) <= n2max;
+    const bool p1 = cin && nin && rowD && n2_of(oD.x, oD.y, oD.z, nL, nA, nB) <= n2max;
+    const bool p2 = cin && rowD && n2_of(o0.x, o0.y, o0.z, oD.x, oD.y, oD.z) <= n2max;
+    const bool p3 = cin && nin && rowD && n2_of(o0.x, o0.y, o0.z, mL, mA, mB) <= n2max;
+    if (cin) __hip_atomic_store(ws.pred + ((int64_t)b * h + r) * w + c, (unsigned char)((p0 ? 1 : 0) | (p1 ? 2 : 0) | (p2 ? 4 : 0) | (p3 ? 8 : 0)),
+                                BXI_RLX, BXI_AGENT);     // written through (sc1)
+    const int vrow = valid_cells(min(meta.img_h[b], meta.first_removed[b]), a.stride, h), vcol = valid_cells(meta.img_w[b], a.stride, w);
+    const bool v00 = r < vrow && c < vcol, v0n = r < vrow && cn < vcol, vD0 = r + D < vrow && c < vcol, vDn = r + D < vrow && cn < vcol;
+    // what a box containing the site adds:  (r, c)  (r, c+D)  (r+D, c)  (r+D, c+D)
+    const int s00 = (p0 && v0n) + (p2 && vD0) + (p3 && vDn), s0n = (p0 && v00) + (p1 && vD0), sD0 = (p1 && v0n) + (p2 && v00), sDn = (p3 && v00) ? 1 : 0;
     int cnt = 0;
-#pragma unroll
-    for (int dir = 0; dir < 4; ++dir) cnt += __popc(m[dir].nA) + __popc(m[dir].nB);
+    for (int m0 = 0; m0 < a.N; m0 += 64) {
+        if (m0) rect = m0 + lane < a.N ? ws.tab[m0 + lane] : make_int4(-1, 0, 0, 0);
+        // the instances of this image whose rows reach r or r + D: usually a handful
+        const int q0 = rect.y & 0xffff, q1 = (int)((unsigned int)rect.y >> 16);
+        unsigned long long mask = __ballot(m0 + lane < a.N && (int)((unsigned int)rect.x >> 24) == b && ((r >= q0 && r < q1) || (r + D >= q0 && r + D < q1)));
+        while (mask) {
+            const int n = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            const int ry = __builtin_amdgcn_readlane(rect.y, n), rz = __builtin_amdgcn_readlane(rect.z, n);
+            const int r0 = ry & 0xffff, r1 = (int)((unsigned int)ry >> 16), c0 = rz & 0xffff, c1 = (int)((unsigned int)rz >> 16);
+            const bool rr = r >= r0 && r < r1, rD2 = r + D >= r0 && r + D < r1;
+            const bool c_in = c >= c0 && c < c1, n_in = cn >= c0 && cn < c1;
+            cnt += (rr && c_in ? s00 : 0) + (rr && n_in ? s0n : 0) + (rD2 && c_in ? sD0 : 0) + (rD2 && n_in ? sDn : 0);
+        }
+    }
     cnt = wave_total_i32(cnt);
-    BXI_TW(2, tix, 2);
-    if (lane == 0)   // (arrival, sum W); integer adds commute: run-to-run identical
-        __hip_atomic_fetch_add(&ws.acc1[(size_t)((t.n * 7 + t.tile_r0 / R + t.tile_c0) & (kAcc1Words - 1)) * kAcc2Stride],
-                               (1ull << 40) | (unsigned long long)(unsigned int)cnt, BXI_RLX, BXI_AGENT);
+    drain_vmem();            // the bytes are in memory before anybody is told
+    if (lane == 0)           // (arrival, sum W); integer adds commute: run-to-run identical
+        __hip_atomic_fetch_add(&ws.acc1[(size_t)(item & (kAcc1Words - 1)) * kAcc2Stride], (1ull << 40) | (unsigned long long)(unsigned int)cnt, BXI_RLX, BXI_AGENT);
 }
 
-// One round over the count words: true when every tile of the list has been counted; then *total = sum W over all instances.
-__device__ __forceinline__ bool counts_complete(const Ws& ws, int ntiles, double* total) {
+// One round over the count words: true when every predicate wave has arrived; then *total = sum W over all instances.
+__device__ __forceinline__ bool counts_complete(const Ws& ws, int n_items, double* total) {
     const unsigned long long x = __hip_atomic_load(&ws.acc1[(size_t)(threadIdx.x & 63) * kAcc2Stride], BXI_RLX, BXI_AGENT);
     const int arrived = wave_total_i32((int)(x >> 40));
     *total = wave_total_f64((double)(x & ((1ull << 40) - 1ull)));       // exact: integers far below 2^53
-    return arrived == ntiles;
+    return arrived == n_items;
 }
-// thresh <= 0: every pair (padded ones too) weighs 1 (:1324), sum W = 8 x the box areas; no count waves then
+// thresh <= 0: every pair (padded ones too) weighs 1 (:1324), sum W = 8 x the box areas; no predicate waves then
 __device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, const Ws& ws) {
     const int lane = threadIdx.x & 63;
     double s = 0.0;
@@ -689,10 +708,10 @@ __device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, cons
 // share the colour predicate.  Per pixel (a, b) = (sigmoid(x), sigmoid(-x)), t = a - b, u = a b.  Per pair (p, q):
 //   S = a_p a_q + b_p b_q ; pw = -log S ; d pw / d x_p = -t_q u_p / S ; d pw / d x_q = -t_p u_q / S      (pairwise.cu:38-61)
 // S cannot underflow while every |x| <= 34; tiles with a larger logit take the log-space path.
-// Its one wait: sum W (the normaliser is global, :1327-1328) from the count waves, which precede the tile waves in the grid
-// and never wait themselves; by the time a tile wave asks, they are long done.
+// Its one wait, after the logits have arrived and the per-pixel quantities are computed: every predicate wave has arrived
+// (they precede the tile waves in the grid and never wait); that also delivers sum W, the global normaliser (:1327-1328).
 template <int D, int R>
-__device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float upw_warm, float n2max, int zero_bit, int ntiles,
+__device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float upw_warm, float n2max, int zero_bit, int n_items,
                                           float& scale, bool& have_scale, float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
                                           int tix) {
     constexpr int RD = TG<D, R>::RD;
@@ -708,19 +727,51 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     float num = 0.f;
 #pragma unroll
     for (int j = 0; j < R; ++j) g[j] = 0.f;
-    bool slow = zero_bit != 0;
+    // per-pixel quantities of this lane and of the lane D to its right: before the wait, they need the logits only
+    float pa_[RD], pb_[RD], pt_[RD], pu_[RD], aR[RD], bR[RD], tR[RD], uR[RD];
+    bool sat = false;
+#pragma unroll
+    for (int j = 0; j < RD; ++j) {
+        sat |= !(fabsf(x[j]) <= 34.f);
+        const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; pt_[j] = s.x - s.y; pu_[j] = s.x * s.y;
+        aR[j] = lane_plus<D>(pa_[j]); bR[j] = lane_plus<D>(pb_[j]); tR[j] = aR[j] - bR[j]; uR[j] = aR[j] * bR[j];
+    }
+    const bool slow = zero_bit != 0 || __any(sat);
+    BXI_TW(1, tix, 2);
+    if (!have_scale) {           // wave-uniform; once per wave
+        double total_w = 0.0;
+        if (zero_bit) total_w = total_weight_all_pairs(a, ws);
+        else {
+            bool ok = false;
+            for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {
+                if (counts_complete(ws, n_items, &total_w)) { ok = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
+        }
+        scale = upw_warm / fmaxf((float)total_w, 1.f);
+        have_scale = true;
+    }
+    BXI_TW(1, tix, 3);
     if (!slow) {
-        uint32_t pb[4];
-        pred_bits<D, R>(ws.lab4, t, h, w, lane, n2max, pb);
+        uint32_t pb[4] = {0u, 0u, 0u, 0u};
+        {
+            const unsigned char* pp = ws.pred + (int64_t)t.img * P;
+            const uint32_t cc = (uint32_t)min(max(c, 0), w - 1);
+            uint32_t pbyte[R + D];
+#pragma unroll
+            for (int i = 0; i < R + D; ++i) pbyte[i] = pp[(uint32_t)min(max(t.tile_r0 - D + i, 0), h - 1) * (uint32_t)w + cc];
+#pragma unroll
+            for (int i = 0; i < R + D; ++i)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) pb[d] |= ((pbyte[i] >> d) & 1u) << i;
+        }
         const TileFlags f = tile_flags<D, R>(t, h, w, lane);
         DirMasks m[4];
         dir_masks<D>(f, pb, m);
-        float pa_[RD], pb_[RD], pt_[RD], pu_[RD];    // this lane, rows [i, i + D] live
-        float aR[RD], bR[RD], tR[RD], uR[RD];        // the lane D to the right
         float gq[RD], gR[RD];                        // gradient of this lane's pixels / of lane + D's
-        bool sat = false;
 #pragma unroll
-        for (int j = 0; j < RD; ++j) { gq[j] = 0.f; gR[j] = 0.f; sat |= !(fabsf(x[j]) <= 34.f); }
+        for (int j = 0; j < RD; ++j) { gq[j] = 0.f; gR[j] = 0.f; }
         // pair weights as bytes, four rows per word: cw = W[k,A] + W[7-k,B] (gradient), dw = the same restricted to
         // pixels this tile owns (loss sum)
         uint32_t cw[4][(R + D + 3) / 4], dw[4][(R + D + 3) / 4];
@@ -731,14 +782,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
                 cw[dir][q4] = spread4((m[dir].mA >> (4 * q4)) & 15u) + spread4((m[dir].mB >> (4 * q4)) & 15u);
                 dw[dir][q4] = spread4((m[dir].nA >> (4 * q4)) & 15u) + spread4((m[dir].nB >> (4 * q4)) & 15u);
             }
-        BXI_TW(1, tix, 2);
-#define BXI_ROW(j)                                                                                                  \
-        {                                                                                                           \
-            const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; pt_[j] = s.x - s.y; pu_[j] = s.x * s.y;    \
-            aR[j] = lane_plus<D>(pa_[j]); bR[j] = lane_plus<D>(pb_[j]); tR[j] = aR[j] - bR[j]; uR[j] = aR[j] * bR[j]; \
-        }
-#pragma unroll
-        for (int j = 0; j < D; ++j) BXI_ROW(j)
+        BXI_TW(1, tix, 4);
         // one unordered pair: A = (row ra, this lane) ; B = (row rb of the lane `q` names) ; num collects -log2 S
 #define BXI_PAIR(i, ra, rb, qa, qb, qt, qu, dir, GA, GB)                                                            \
         {                                                                                                           \
@@ -753,7 +797,6 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
 #pragma unroll
         for (int i = 0; i < R + D; ++i) {
             const int j = i + D;
-            BXI_ROW(j)
             if (i >= D) BXI_PAIR(i, i, i, aR, bR, tR, uR, 0, gq[i], gR[i])
             BXI_PAIR(i, j, i, aR, bR, tR, uR, 1, gq[j], gR[i])
             BXI_PAIR(i, i, j, pa_, pb_, pt_, pu_, 2, gq[i], gq[j])
@@ -764,34 +807,16 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
             }
         }
         num *= 0.69314718055994531f;
-#undef BXI_ROW
 #undef BXI_PAIR
-        slow = __any(sat);
-    }
-    if (slow) {      // wave-uniform; rare
+    } else {         // wave-uniform; rare
         slow_tile<D, R>(Lg, ws.lab4, t, n2max, zero_bit, h, w, lane, gbuf);
         num = gbuf[R * 64 + lane];
 #pragma unroll
         for (int j = 0; j < R; ++j) g[j] = gbuf[j * 64 + lane];
     }
-    BXI_TW(1, tix, 3);
+    BXI_TW(1, tix, 5);
     num = wave_total_f32(num);
     const long long fx = (long long)(num * kNumScale) + (1ll << 24);           // + 1.0: keeps the packed field non-negative
-    if (!have_scale) {           // wave-uniform; once per wave
-        double total_w = 0.0;
-        if (zero_bit) total_w = total_weight_all_pairs(a, ws);
-        else {
-            bool ok = false;
-            for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {
-                if (counts_complete(ws, ntiles, &total_w)) { ok = true; break; }
-                __builtin_amdgcn_s_sleep(4);
-            }
-            if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
-        }
-        scale = upw_warm / fmaxf((float)total_w, 1.f);
-        have_scale = true;
-    }
-    BXI_TW(1, tix, 4);
     if (g_logits) {
         char* G = reinterpret_cast<char*>(g_logits + (int64_t)n * P);      // scalar base + 32-bit byte offset
 #pragma unroll
@@ -800,11 +825,11 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
             if (col_owned && r < h) add_f32(reinterpret_cast<float*>(G + (uint32_t)(r * w + c) * 4u), g[j] * scale);
         }
     }
-    BXI_TW(1, tix, 5);
+    BXI_TW(1, tix, 6);
     // this tile's share of sum W pw + its arrival: one atomic without return; the wave does not wait for it
     if (lane == 0)
         __hip_atomic_fetch_add(acc2_word(ws.acc2, n, t.tile_r0 / R + t.tile_c0 / TG<D, R>::TW), (1ull << 52) + (unsigned long long)fx, BXI_RLX, BXI_AGENT);
-    BXI_TW(1, tix, 6);
+    BXI_TW(1, tix, 7);
 }
 
 __device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
@@ -977,14 +1002,14 @@ __device__ __forceinline__ Tile locate_tile(const Ws& ws, int N, const int4& e0,
     return tile_of(e, D, R, TG<D, R>::TW, n, ti - (e.x & 0xffffff), h, w);
 }
 
-// grid: [N leaders][n_cb count blocks][n_cb tile blocks][finisher]; a count / tile block = 4 independent waves striding through
-// the tile list.  The only waits: a tile wave for the count waves (earlier in the grid, never waiting themselves), the finisher
-// for everybody (nobody waits for it).  Every wait is bounded, and running out of it is loud: NaN losses, status word, poisoned
-// gradient (the reference surfaces launch failures through AT_CUDA_CHECK, pairwise.cu:173,200).
+// grid: [N leaders][n_pb predicate blocks][n_tb tile blocks][finisher]; a predicate / tile block = 4 independent waves striding
+// through the pooled row segments / the tile list.  The only waits: a tile wave for the predicate waves (earlier in the grid,
+// never waiting themselves), the finisher for everybody (nobody waits for it).  Every wait is bounded, and running out of it is
+// loud: NaN losses, status word, poisoned gradient (the reference surfaces launch failures through AT_CUDA_CHECK, pairwise.cu:173,200).
 template <int D, int R>
-__global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair3_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
-                                                       float n2max, int zero_bit, int n_cb, float* __restrict__ losses, float* __restrict__ g_logits,
-                                                       InstArgs a, Ws ws, LossState st) {
+__global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
+                                                       float n2max, int zero_bit, int n_pb, int n_items, ImageMeta meta, float* __restrict__ losses,
+                                                       float* __restrict__ g_logits, InstArgs a, Ws ws, LossState st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[16];
     const int blk = (int)blockIdx.x, lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
@@ -995,19 +1020,25 @@ __global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair3_kernel(const floa
         leader_block(a, D, ws, st, blk, upp, g_logits, smem, red);
         return;
     }
+    if (blk < N + n_pb) {                                              // ---- predicate waves
+        if (zero_bit) return;                                          // every pair weighs 1: sum W has a closed form, the tiles take the log-space path
+        const int segs = (a.w + 63) >> 6, pid = (blk - N) * kWaves + wave;
+        BXI_TW(2, pid, 0);
+        for (int item = pid; item < n_items; item += n_pb * kWaves) pred_item(a, meta, ws, D, n2max, item, segs);
+        BXI_TW(2, pid, 1);
+        return;
+    }
     if (blk == (int)gridDim.x - 1) {                                   // ---- finisher: one wave
         if (threadIdx.x >= 64) return;
         BXI_TW(3, 0, 0);
-        const int ntiles = __builtin_amdgcn_readfirstlane(ws.tab[N].x);
         bool ok = false;
         double num = 0.0, total_w = 0.0;
         float dsum = 0.f;
         for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {        // waits only for workgroups that never wait for it
             num = 0.0; dsum = 0.f;
-            bool all = zero_bit ? true : counts_complete(ws, ntiles, &total_w);     // requested with the first pass's loads
+            bool all = zero_bit ? true : counts_complete(ws, n_items, &total_w);    // requested with the first pass's loads
             for (int b0 = 0; b0 < N && all; b0 += 64) all = finisher_round(ws, N, b0, &num, &dsum);
             if (all) { ok = true; break; }
-            __builtin_amdgcn_s_sleep(2);
         }
         if (zero_bit) total_w = total_weight_all_pairs(a, ws);
         const unsigned int fault = __hip_atomic_load(ws.fault, BXI_RLX, BXI_AGENT);   // set by a tile wave BEFORE its arrival, if at all
@@ -1024,10 +1055,8 @@ __global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair3_kernel(const floa
         BXI_TW(3, 0, 1);
         return;
     }
-    const bool counting = blk < N + n_cb;
-    if (counting && zero_bit) return;                                  // sum W has a closed form then
-    const int wid = (counting ? blk - N : blk - N - n_cb) * kWaves + wave, nwaves = n_cb * kWaves;
-    BXI_TW(counting ? 2 : 1, wid, 0);
+    const int wid = (blk - N - n_pb) * kWaves + wave, nwaves = ((int)gridDim.x - 1 - N - n_pb) * kWaves;
+    BXI_TW(1, wid, 0);
     int4 e0 = make_int4(0, 0, 0, 0);
     if (lane <= N) e0 = ws.tab[lane];
     const int total = N < 64 ? __builtin_amdgcn_readlane(e0.x, N < 64 ? N : 0) : __builtin_amdgcn_readfirstlane(ws.tab[N].x);
@@ -1036,9 +1065,8 @@ __global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair3_kernel(const floa
     bool have_scale = false;
     for (int ti = wid; ti < total; ti += nwaves) {
         const Tile t = locate_tile<D, R>(ws, N, e0, ti, a.h, a.w);
-        BXI_TW(counting ? 2 : 1, wid, 1);
-        if (counting) count_tile<D, R>(a, ws, t, n2max, wid);
-        else math_tile<D, R>(a, ws, t, upw * warmup, n2max, zero_bit, total, scale, have_scale, g_logits, gbuf, wid);
+        BXI_TW(1, wid, 1);
+        math_tile<D, R>(a, ws, t, upw * warmup, n2max, zero_bit, n_items, scale, have_scale, g_logits, gbuf, wid);
     }
 }
 
@@ -1154,10 +1182,10 @@ static HostPred host_pred(float thresh) {
 }
 
 template <int D, int R>
-static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, float warmup, float n2max, int zero_bit, int n_cb, const Ws& ws,
-                        const LossState& st, float* losses, float* g_logits, const float* up_prj, const float* up_pw) {
-    BXI_LAUNCH("pair", s, (pair3_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, up_prj, up_pw, warmup, n2max, zero_bit, n_cb, losses,
-               g_logits, a, ws, st);
+static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, float warmup, float n2max, int zero_bit, int n_pb, int n_items,
+                        const ImageMeta& meta, const Ws& ws, const LossState& st, float* losses, float* g_logits, const float* up_prj, const float* up_pw) {
+    BXI_LAUNCH("pair", s, (pair3_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, up_prj, up_pw, warmup, n2max, zero_bit, n_pb, n_items, meta,
+               losses, g_logits, a, ws, st);
 }
 
 }  // namespace v3
@@ -1263,22 +1291,24 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
 
     // ---- launch 2 --------------------------------------------------------------------------------------------------
     const int64_t cap = eval_cap(a.N, a.h, a.w, dil, R);
-    int64_t n_cb = (cap + kWaves - 1) / kWaves;
-    // the list length is device data: the tile waves stride through it.  3 (R = 4) or 2 (R = 8) workgroups per CU are resident:
-    // leaders + count + tile blocks should fit in one round.
+    int64_t n_tb = (cap + kWaves - 1) / kWaves;
+    // the tile list's length is device data: the tile waves stride through it.  The launch should be resident in one round:
+    // 4 (R = 4: <= 128 VGPRs) or 2 (R = 8) workgroups per CU; the predicate waves are short-lived.
     static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 0);
-    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? 3 : 2);
-    const int room2 = (occ * device_cus() - a.N - 1) / 2;
-    if (n_cb > (room2 > 64 ? room2 : 64)) n_cb = room2 > 64 ? room2 : 64;
+    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? (dil <= 3 ? 4 : 3) : 2);
+    const int slots = occ * device_cus() - a.N - 1;
+    int n_pb = (n_items + kWaves - 1) / kWaves;
+    if (n_pb > slots / 2) n_pb = slots / 2 > 1 ? slots / 2 : 1;
+    if (n_tb > slots - n_pb) n_tb = slots - n_pb > 64 ? slots - n_pb : 64;
     size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
     const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
     if (lds2 < lds_leader) lds2 = lds_leader;
     if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
-    const int grid = a.N + 2 * (int)n_cb + 1;             // leaders + count blocks + tile blocks + the finisher
+    const int grid = a.N + n_pb + (int)n_tb + 1;          // leaders + predicate blocks + tile blocks + the finisher
 #define BXI_PAIR_CASE(DD)                                                                                                                  \
     case DD:                                                                                                                               \
-        if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, (int)n_cb, ws, st, losses, g_logits, up_prj, up_pw); \
-        else launch_pair<DD, 8>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, (int)n_cb, ws, st, losses, g_logits, up_prj, up_pw);        \
+        if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, pa.meta, ws, st, losses, g_logits, up_prj, up_pw); \
+        else launch_pair<DD, 8>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, pa.meta, ws, st, losses, g_logits, up_prj, up_pw);        \
         break;
     switch (dil) {
         BXI_PAIR_CASE(1) BXI_PAIR_CASE(2) BXI_PAIR_CASE(3) BXI_PAIR_CASE(4)
