@@ -390,6 +390,7 @@ __device__ __forceinline__ void pool_block(const PoolArgs& pa, const Ws& ws, int
             const double f0 = fch[lane], f1 = fch[64 + lane], f2 = fch[128 + lane];
             ws.lab4[((int64_t)b * h + r) * w + c] = make_float4((float)__dadd_rn(__dmul_rn(116.0, f1), -16.0), (float)__dmul_rn(500.0, __dadd_rn(f0, -f1)),
                                                                 (float)__dmul_rn(200.0, __dadd_rn(f1, -f2)), 0.f);
+            ws.pred[((int64_t)b * h + r) * w + c] = 0;      // "not evaluated yet": the predicate waves of the next launch set bit 7
         }
         // the next trip's `part` writes come after this barrier; its `fch` writes after the next one, which wave 3 reaches only
         // after it has read `fch` here: no extra barrier needed
@@ -469,11 +470,13 @@ __global__ __launch_bounds__(256, 7) void head_prep3_kernel(PoolArgs pa, int n_p
 
 // ---- the image side for strides other than 4 / unaligned canvases: launches of their own (pool_rgb_generic of
 // color_affinity.hip -> Lab planes, then this repacking) -----------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_lab4_kernel(const float* __restrict__ lab, float4* __restrict__ lab4, int B, int64_t P) {
+__global__ __launch_bounds__(256) void pack_lab4_kernel(const float* __restrict__ lab, float4* __restrict__ lab4, unsigned char* __restrict__ pred, int B,
+                                                        int64_t P) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * P; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / P, p = i - b * P;
         const float* src = lab + b * 3 * P + p;
         lab4[i] = make_float4(src[0], src[P], src[2 * P], 0.f);
+        pred[i] = 0;
     }
 }
 
@@ -628,7 +631,7 @@ __device__ __forceinline__ void load_plane(const float* __restrict__ plane, cons
 // -> one predicate byte per pixel (bit d: squared Lab distance <= n2max, i.e. sim >= thresh for a valid neighbour), and the
 // segment's share of  sum W = sum_n sum_{p in box n} sum_k [sim_k(p) >= thresh]  (:1324-1328): a pair (p, q) weighs
 // [p in box n][q valid] + [q in box n][p valid] for every instance n of the image.  One packed integer atomic per segment
-// (arrival, count) AFTER its bytes have been written through: who has seen every arrival may read every byte.
+// (arrival, count).  A byte carries its own "evaluated" bit: a tile wave re-reads the few bytes it needs until they have it.
 __device__ __forceinline__ float lane_plus_n(float v, int d) {
     int x = __float_as_int(v);
     for (int s = 0; s < d; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
@@ -653,8 +656,8 @@ __device__ __forceinline__ void pred_item(const InstArgs& a, const ImageMeta& me
     const bool p1 = cin && nin && rowD && n2_of(oD.x, oD.y, oD.z, nL, nA, nB) <= n2max;
     const bool p2 = cin && rowD && n2_of(o0.x, o0.y, o0.z, oD.x, oD.y, oD.z) <= n2max;
     const bool p3 = cin && nin && rowD && n2_of(o0.x, o0.y, o0.z, mL, mA, mB) <= n2max;
-    if (cin) __hip_atomic_store(ws.pred + ((int64_t)b * h + r) * w + c, (unsigned char)((p0 ? 1 : 0) | (p1 ? 2 : 0) | (p2 ? 4 : 0) | (p3 ? 8 : 0)),
-                                BXI_RLX, BXI_AGENT);     // written through (sc1)
+    if (cin) __hip_atomic_store(ws.pred + ((int64_t)b * h + r) * w + c, (unsigned char)(0x80 | (p0 ? 1 : 0) | (p1 ? 2 : 0) | (p2 ? 4 : 0) | (p3 ? 8 : 0)),
+                                BXI_RLX, BXI_AGENT);     // bit 7: evaluated (launch 1 left 0); written through (sc1), read past the caches
     const int vrow = valid_cells(min(meta.img_h[b], meta.first_removed[b]), a.stride, h), vcol = valid_cells(meta.img_w[b], a.stride, w);
     const bool v00 = r < vrow && c < vcol, v0n = r < vrow && cn < vcol, vD0 = r + D < vrow && c < vcol, vDn = r + D < vrow && cn < vcol;
     // what a box containing the site adds:  (r, c)  (r, c+D)  (r+D, c)  (r+D, c+D)
@@ -676,7 +679,6 @@ __device__ __forceinline__ void pred_item(const InstArgs& a, const ImageMeta& me
         }
     }
     cnt = wave_total_i32(cnt);
-    drain_vmem();            // the bytes are in memory before anybody is told
     if (lane == 0)           // (arrival, sum W); integer adds commute: run-to-run identical
         __hip_atomic_fetch_add(&ws.acc1[(size_t)(item & (kAcc1Words - 1)) * kAcc2Stride], (1ull << 40) | (unsigned long long)(unsigned int)cnt, BXI_RLX, BXI_AGENT);
 }
@@ -708,8 +710,9 @@ __device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, cons
 // share the colour predicate.  Per pixel (a, b) = (sigmoid(x), sigmoid(-x)), t = a - b, u = a b.  Per pair (p, q):
 //   S = a_p a_q + b_p b_q ; pw = -log S ; d pw / d x_p = -t_q u_p / S ; d pw / d x_q = -t_p u_q / S      (pairwise.cu:38-61)
 // S cannot underflow while every |x| <= 34; tiles with a larger logit take the log-space path.
-// Its one wait, after the logits have arrived and the per-pixel quantities are computed: every predicate wave has arrived
-// (they precede the tile waves in the grid and never wait); that also delivers sum W, the global normaliser (:1327-1328).
+// Its waits: the predicate bytes of its own pixels (bit 7 set), when the logits have arrived and the per-pixel quantities are
+// computed; and, before the gradient goes out, sum W (the global normaliser, :1327-1328) = every predicate wave's arrival.  The
+// predicate waves precede the tile waves in the grid and never wait; by the time a tile wave asks they are normally done.
 template <int D, int R>
 __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float upw_warm, float n2max, int zero_bit, int n_items,
                                           float& scale, bool& have_scale, float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
@@ -738,29 +741,24 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     }
     const bool slow = zero_bit != 0 || __any(sat);
     BXI_TW(1, tix, 2);
-    if (!have_scale) {           // wave-uniform; once per wave
-        double total_w = 0.0;
-        if (zero_bit) total_w = total_weight_all_pairs(a, ws);
-        else {
-            bool ok = false;
-            for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {
-                if (counts_complete(ws, n_items, &total_w)) { ok = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
-        }
-        scale = upw_warm / fmaxf((float)total_w, 1.f);
-        have_scale = true;
-    }
-    BXI_TW(1, tix, 3);
     if (!slow) {
         uint32_t pb[4] = {0u, 0u, 0u, 0u};
         {
             const unsigned char* pp = ws.pred + (int64_t)t.img * P;
             const uint32_t cc = (uint32_t)min(max(c, 0), w - 1);
             uint32_t pbyte[R + D];
+            bool ok = false;
+            for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {     // its own few bytes, read past the caches; usually there at once
+                uint32_t all = 0x80u;
 #pragma unroll
-            for (int i = 0; i < R + D; ++i) pbyte[i] = pp[(uint32_t)min(max(t.tile_r0 - D + i, 0), h - 1) * (uint32_t)w + cc];
+                for (int i = 0; i < R + D; ++i) {
+                    pbyte[i] = __hip_atomic_load(pp + (uint32_t)min(max(t.tile_r0 - D + i, 0), h - 1) * (uint32_t)w + cc, BXI_RLX, BXI_AGENT);
+                    all &= pbyte[i];
+                }
+                if (__all(all != 0u)) { ok = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
 #pragma unroll
             for (int i = 0; i < R + D; ++i)
 #pragma unroll
@@ -782,7 +780,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
                 cw[dir][q4] = spread4((m[dir].mA >> (4 * q4)) & 15u) + spread4((m[dir].mB >> (4 * q4)) & 15u);
                 dw[dir][q4] = spread4((m[dir].nA >> (4 * q4)) & 15u) + spread4((m[dir].nB >> (4 * q4)) & 15u);
             }
-        BXI_TW(1, tix, 4);
+        BXI_TW(1, tix, 3);
         // one unordered pair: A = (row ra, this lane) ; B = (row rb of the lane `q` names) ; num collects -log2 S
 #define BXI_PAIR(i, ra, rb, qa, qb, qt, qu, dir, GA, GB)                                                            \
         {                                                                                                           \
@@ -817,6 +815,21 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     BXI_TW(1, tix, 5);
     num = wave_total_f32(num);
     const long long fx = (long long)(num * kNumScale) + (1ll << 24);           // + 1.0: keeps the packed field non-negative
+    if (!have_scale) {           // wave-uniform; once per wave
+        double total_w = 0.0;
+        if (zero_bit) total_w = total_weight_all_pairs(a, ws);
+        else {
+            bool ok = false;
+            for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {
+                if (counts_complete(ws, n_items, &total_w)) { ok = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
+        }
+        scale = upw_warm / fmaxf((float)total_w, 1.f);
+        have_scale = true;
+    }
+    BXI_TW(1, tix, 4);
     if (g_logits) {
         char* G = reinterpret_cast<char*>(g_logits + (int64_t)n * P);      // scalar base + 32-bit byte offset
 #pragma unroll
@@ -1284,7 +1297,7 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
         if (rc != BXI_OK) return rc;
         const int64_t BP = (int64_t)batch->B * a.h * a.w;
         BXI_LAUNCH("pack_lab4", s, pack_lab4_kernel, dim3((unsigned)((BP + 255) / 256 > 2048 ? 2048 : (BP + 255) / 256)), dim3(256), 0, s,
-                   (const float*)ws.lab_planar, ws.lab4, batch->B, (int64_t)a.h * a.w);
+                   (const float*)ws.lab_planar, ws.lab4, ws.pred, batch->B, (int64_t)a.h * a.w);
         rc = check_launch();
         if (rc != BXI_OK) return rc;
     }
