@@ -637,7 +637,8 @@ __device__ __forceinline__ float lane_plus_n(float v, int d) {
     for (int s = 0; s < d; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
     return __int_as_float(x);
 }
-__device__ __forceinline__ void pred_item(const InstArgs& a, const ImageMeta& meta, const Ws& ws, int D, float n2max, int item, int segs) {
+struct ValidCells { int vrow[BXI_MAX_IMAGES], vcol[BXI_MAX_IMAGES]; };   // per image: valid(q) <=> row(q) < vrow && col(q) < vcol (host: :1354-1369,:1405)
+__device__ __forceinline__ void pred_item(const InstArgs& a, const ValidCells& vc, const Ws& ws, int D, float n2max, int item, int segs) {
     const int h = a.h, w = a.w, lane = threadIdx.x & 63;
     const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
     const int c = seg * 64 + lane, cn = c + D;
@@ -658,7 +659,7 @@ __device__ __forceinline__ void pred_item(const InstArgs& a, const ImageMeta& me
     const bool p3 = cin && nin && rowD && n2_of(o0.x, o0.y, o0.z, mL, mA, mB) <= n2max;
     if (cin) __hip_atomic_store(ws.pred + ((int64_t)b * h + r) * w + c, (unsigned char)(0x80 | (p0 ? 1 : 0) | (p1 ? 2 : 0) | (p2 ? 4 : 0) | (p3 ? 8 : 0)),
                                 BXI_RLX, BXI_AGENT);     // bit 7: evaluated (launch 1 left 0); written through (sc1), read past the caches
-    const int vrow = valid_cells(min(meta.img_h[b], meta.first_removed[b]), a.stride, h), vcol = valid_cells(meta.img_w[b], a.stride, w);
+    const int vrow = vc.vrow[b], vcol = vc.vcol[b];
     const bool v00 = r < vrow && c < vcol, v0n = r < vrow && cn < vcol, vD0 = r + D < vrow && c < vcol, vDn = r + D < vrow && cn < vcol;
     // what a box containing the site adds:  (r, c)  (r, c+D)  (r+D, c)  (r+D, c+D)
     const int s00 = (p0 && v0n) + (p2 && vD0) + (p3 && vDn), s0n = (p0 && v00) + (p1 && vD0), sD0 = (p1 && v0n) + (p2 && v00), sDn = (p3 && v00) ? 1 : 0;
@@ -740,6 +741,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
         aR[j] = lane_plus<D>(pa_[j]); bR[j] = lane_plus<D>(pb_[j]); tR[j] = aR[j] - bR[j]; uR[j] = aR[j] * bR[j];
     }
     const bool slow = zero_bit != 0 || __any(sat);
+    unsigned long long early_counts = 0ull;
     BXI_TW(1, tix, 2);
     if (!slow) {
         uint32_t pb[4] = {0u, 0u, 0u, 0u};
@@ -759,6 +761,8 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
                 __builtin_amdgcn_s_sleep(8);
             }
             if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
+            // the count words, requested now and looked at after the pair loop: the predicate waves are normally all done by then
+            if (!have_scale) early_counts = __hip_atomic_load(&ws.acc1[(size_t)lane * kAcc2Stride], BXI_RLX, BXI_AGENT);
 #pragma unroll
             for (int i = 0; i < R + D; ++i)
 #pragma unroll
@@ -819,8 +823,9 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
         double total_w = 0.0;
         if (zero_bit) total_w = total_weight_all_pairs(a, ws);
         else {
-            bool ok = false;
-            for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {
+            bool ok = wave_total_i32((int)(early_counts >> 40)) == n_items;
+            if (ok) total_w = wave_total_f64((double)(early_counts & ((1ull << 40) - 1ull)));
+            for (unsigned spins = 0; !ok && spins <= kSpinLimit; ++spins) {
                 if (counts_complete(ws, n_items, &total_w)) { ok = true; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
@@ -964,16 +969,17 @@ __device__ __forceinline__ Tile tile_of(const int4& e, int D, int R, int TW, int
 
 // The finisher's round over instances [b0, b0 + 64): arrivals and sums of every tile (8 words per instance, arrival count and
 // sum in one word) and the leaders' dice losses, requested together.  Returns whether all are complete; adds their sums.
-__device__ __forceinline__ bool finisher_round(const Ws& ws, int N, int b0, double* num, float* dsum) {
+__device__ __forceinline__ unsigned int tiles_of(const Ws& ws, int N, int i) {
+    return i < N ? (unsigned int)((ws.tab[i + 1].x & 0xffffff) - (ws.tab[i].x & 0xffffff)) : 0u;
+}
+__device__ __forceinline__ bool finisher_round(const Ws& ws, int N, int b0, unsigned int expect, double* num, float* dsum) {
     const int lane = threadIdx.x & 63, i = b0 + lane;
     unsigned long long x = 0ull, dg = 1ull << 32;
-    unsigned int expect = 0u;
     if (i < N) {
         unsigned long long wd[kAcc2Split];
 #pragma unroll
         for (int sub = 0; sub < kAcc2Split; ++sub) wd[sub] = __hip_atomic_load(acc2_word(ws.acc2, i, sub), BXI_RLX, BXI_AGENT);
         dg = __hip_atomic_load(&ws.dice[i], BXI_RLX, BXI_AGENT);
-        expect = (unsigned int)((ws.tab[i + 1].x & 0xffffff) - (ws.tab[i].x & 0xffffff));
 #pragma unroll
         for (int sub = 0; sub < kAcc2Split; ++sub) x += wd[sub];
     }
@@ -1021,7 +1027,7 @@ __device__ __forceinline__ Tile locate_tile(const Ws& ws, int N, const int4& e0,
 // loud: NaN losses, status word, poisoned gradient (the reference surfaces launch failures through AT_CUDA_CHECK, pairwise.cu:173,200).
 template <int D, int R>
 __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
-                                                       float n2max, int zero_bit, int n_pb, int n_items, ImageMeta meta, float* __restrict__ losses,
+                                                       float n2max, int zero_bit, int n_pb, int n_items, ValidCells vc, float* __restrict__ losses,
                                                        float* __restrict__ g_logits, InstArgs a, Ws ws, LossState st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[16];
@@ -1037,7 +1043,7 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_ke
         if (zero_bit) return;                                          // every pair weighs 1: sum W has a closed form, the tiles take the log-space path
         const int segs = (a.w + 63) >> 6, pid = (blk - N) * kWaves + wave;
         BXI_TW(2, pid, 0);
-        for (int item = pid; item < n_items; item += n_pb * kWaves) pred_item(a, meta, ws, D, n2max, item, segs);
+        for (int item = pid; item < n_items; item += n_pb * kWaves) pred_item(a, vc, ws, D, n2max, item, segs);
         BXI_TW(2, pid, 1);
         return;
     }
@@ -1047,10 +1053,11 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_ke
         bool ok = false;
         double num = 0.0, total_w = 0.0;
         float dsum = 0.f;
+        const unsigned int expect0 = tiles_of(ws, N, lane);             // tiles of instance `lane`: launch-1 data, read once
         for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {        // waits only for workgroups that never wait for it
             num = 0.0; dsum = 0.f;
             bool all = zero_bit ? true : counts_complete(ws, n_items, &total_w);    // requested with the first pass's loads
-            for (int b0 = 0; b0 < N && all; b0 += 64) all = finisher_round(ws, N, b0, &num, &dsum);
+            for (int b0 = 0; b0 < N && all; b0 += 64) all = finisher_round(ws, N, b0, b0 ? tiles_of(ws, N, b0 + lane) : expect0, &num, &dsum);
             if (all) { ok = true; break; }
         }
         if (zero_bit) total_w = total_weight_all_pairs(a, ws);
@@ -1068,7 +1075,10 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_ke
         BXI_TW(3, 0, 1);
         return;
     }
-    const int wid = (blk - N - n_pb) * kWaves + wave, nwaves = ((int)gridDim.x - 1 - N - n_pb) * kWaves;
+    // consecutive tiles go to different workgroups (the list is shorter than the grid at the headline size: its waves would
+    // otherwise all sit in the first workgroups, several to a SIMD, next to idle ones)
+    const int n_tb = (int)gridDim.x - 1 - N - n_pb, nwaves = n_tb * kWaves;
+    const int wid = wave * n_tb + (blk - N - n_pb);
     BXI_TW(1, wid, 0);
     int4 e0 = make_int4(0, 0, 0, 0);
     if (lane <= N) e0 = ws.tab[lane];
@@ -1196,8 +1206,8 @@ static HostPred host_pred(float thresh) {
 
 template <int D, int R>
 static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, float warmup, float n2max, int zero_bit, int n_pb, int n_items,
-                        const ImageMeta& meta, const Ws& ws, const LossState& st, float* losses, float* g_logits, const float* up_prj, const float* up_pw) {
-    BXI_LAUNCH("pair", s, (pair3_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, up_prj, up_pw, warmup, n2max, zero_bit, n_pb, n_items, meta,
+                        const ValidCells& vc, const Ws& ws, const LossState& st, float* losses, float* g_logits, const float* up_prj, const float* up_pw) {
+    BXI_LAUNCH("pair", s, (pair3_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, up_prj, up_pw, warmup, n2max, zero_bit, n_pb, n_items, vc,
                losses, g_logits, a, ws, st);
 }
 
@@ -1318,10 +1328,17 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     if (lds2 < lds_leader) lds2 = lds_leader;
     if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
     const int grid = a.N + n_pb + (int)n_tb + 1;          // leaders + predicate blocks + tile blocks + the finisher
+    ValidCells vc = {};
+    for (int b = 0; b < batch->B; ++b) {                  // the device formula (valid_cells), evaluated here once per image
+        const int half = a.stride / 2;
+        auto cells = [&](int limit, int n) { const int v = limit - half <= 0 ? 0 : (limit - half + a.stride - 1) / a.stride; return v < n ? v : n; };
+        vc.vrow[b] = cells(pa.meta.img_h[b] < pa.meta.first_removed[b] ? pa.meta.img_h[b] : pa.meta.first_removed[b], a.h);
+        vc.vcol[b] = cells(pa.meta.img_w[b], a.w);
+    }
 #define BXI_PAIR_CASE(DD)                                                                                                                  \
     case DD:                                                                                                                               \
-        if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, pa.meta, ws, st, losses, g_logits, up_prj, up_pw); \
-        else launch_pair<DD, 8>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, pa.meta, ws, st, losses, g_logits, up_prj, up_pw);        \
+        if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw); \
+        else launch_pair<DD, 8>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw);        \
         break;
     switch (dil) {
         BXI_PAIR_CASE(1) BXI_PAIR_CASE(2) BXI_PAIR_CASE(3) BXI_PAIR_CASE(4)
