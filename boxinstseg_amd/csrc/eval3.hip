@@ -49,8 +49,9 @@ constexpr int kSBlk = kWaves * kSRows;          // rows per stream workgroup
 constexpr int kChunkC = 256;                    // columns per pass of a stream wave: 64 lanes x float4
 constexpr int kMaxDilFused = 4;
 constexpr unsigned kSpinLimit = 400000;         // bounded waits (~0.3 us per poll): far beyond any launch; running out is loud (NaN losses)
-constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
-constexpr int kAcc1Words = 64;                  // count-wave arrivals + sum W: 64 words, each in its own 128 bytes
+constexpr int kAcc2Stride = 16;                 // polled / atomically updated words sit in their own 128 bytes
+constexpr int kAcc2Words = 64;                  // tile arrivals + sum W pw: only the totals are ever needed (kAcc2Words words per 8192 possible tiles)
+constexpr int kAcc1Words = 64;                  // predicate-wave arrivals + sum W
 constexpr int kMaxInst = 65536;
 constexpr unsigned kFaultCounts = 1u, kFaultFinisher = 2u;
 
@@ -84,14 +85,13 @@ struct Ws {
     int4* tab;                                  // [N+1] {tile prefix | img << 24, r0 | r1 << 16, c0 | c1 << 16, vrow | vcol << 16}; [N].x = tiles
     // words polled inside pair3_kernel; zeroed by prep3_kernel's table waves, i.e. before a kernel boundary
     unsigned long long* acc1;                   // [kAcc1Words] (one per 128 B) predicate waves: arrivals << 40 | sum W
-    unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B) tile waves: arrivals << 52 | sum (W pw + 1) in 2^-24 units
+    unsigned long long* sumw;                   // [1]   complete count words << 40 | sum W (added by the predicate wave that completes a word)
+    unsigned long long* acc2;                   // [n_acc2] (one per 128 B) tile waves: arrivals << 48 | sum (W pw + 1) in 2^-24 units
+    int n_acc2;                                 // a multiple of 64, <= 128 tiles per word (a tile's sum < 2^40 units)
     unsigned long long* dice;                   // [N]   leader: 1 << 32 | bits of the instance's dice loss (0 = not published)
     unsigned int* fault;                        // [1]   bit mask of waits that ran out (never expected)
 };
 
-__device__ __forceinline__ unsigned long long* acc2_word(unsigned long long* acc2, int n, int sub) {
-    return acc2 + ((size_t)n * kAcc2Split + (sub & (kAcc2Split - 1))) * kAcc2Stride;
-}
 
 static inline int tile_width(int dil) { return 64 - 2 * dil; }
 static inline int64_t eval_cap(int N, int h, int w, int dil, int R) {
@@ -116,7 +116,9 @@ static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
     t.n_cb = (int)Sn; t.n_rp = 1;
     t.tab = (int4*)take(16 * (size_t)(N1 + 1));
     t.acc1 = (unsigned long long*)take(8 * (size_t)kAcc1Words * kAcc2Stride);
-    t.acc2 = (unsigned long long*)take(8 * (size_t)N1 * kAcc2Split * kAcc2Stride);
+    t.sumw = (unsigned long long*)take(8);
+    t.n_acc2 = kAcc2Words * (int)((eval_cap(N, h, w, 1, 4) + 8191) / 8192);
+    t.acc2 = (unsigned long long*)take(8 * (size_t)t.n_acc2 * kAcc2Stride);
     t.dice = (unsigned long long*)take(8 * (size_t)N1);
     t.fault = (unsigned int*)take(4);
     if (ws) *ws = t;
@@ -177,16 +179,14 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
     if (m < a.N) {
         ws.tab[m] = make_int4(prefix | (mine.img << 24), mine.r0 | (mine.r1 << 16), mine.c0 | (mine.c1 << 16), mine.vrow | (mine.vcol << 16));
         if (st.inst) { InstRec rc; rc.r0 = mine.r0; rc.r1 = mine.r1; rc.c0 = mine.c0; rc.c1 = mine.c1; rc.img = mine.img; rc.pad0 = rc.pad1 = rc.pad2 = 0; st.inst[m] = rc; }
-        // the words the next launch polls: zeroed here, i.e. before a kernel boundary (no hipMemsetAsync, no initialisation contract)
-#pragma unroll
-        for (int sub = 0; sub < kAcc2Split; ++sub) *acc2_word(ws.acc2, m, sub) = 0ull;
-        ws.dice[m] = 0ull;
+        ws.dice[m] = 0ull;      // polled by the next launch's finisher: zeroed here, i.e. before a kernel boundary
     } else if (m == a.N) {
         ws.tab[m] = make_int4(prefix, 0, 0, 0);
     }
-    if (k == 0) {
+    if (k == 0) {          // every word the next launch polls (no hipMemsetAsync, no initialisation contract)
         ws.acc1[(size_t)lane * kAcc2Stride] = 0ull;
-        if (lane == 0) { *ws.fault = 0u; if (st.status) { st.status[0] = 0; st.status[1] = R; } }
+        for (int i = lane; i < ws.n_acc2; i += 64) ws.acc2[(size_t)i * kAcc2Stride] = 0ull;
+        if (lane == 0) { *ws.sumw = 0ull; *ws.fault = 0u; if (st.status) { st.status[0] = 0; st.status[1] = R; } }
     }
 }
 
@@ -638,7 +638,7 @@ __device__ __forceinline__ float lane_plus_n(float v, int d) {
     return __int_as_float(x);
 }
 struct ValidCells { int vrow[BXI_MAX_IMAGES], vcol[BXI_MAX_IMAGES]; };   // per image: valid(q) <=> row(q) < vrow && col(q) < vcol (host: :1354-1369,:1405)
-__device__ __forceinline__ void pred_item(const InstArgs& a, const ValidCells& vc, const Ws& ws, int D, float n2max, int item, int segs) {
+__device__ __forceinline__ void pred_item(const InstArgs& a, const ValidCells& vc, const Ws& ws, int D, float n2max, int item, int segs, int n_items) {
     const int h = a.h, w = a.w, lane = threadIdx.x & 63;
     const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
     const int c = seg * 64 + lane, cn = c + D;
@@ -680,16 +680,23 @@ __device__ __forceinline__ void pred_item(const InstArgs& a, const ValidCells& v
         }
     }
     cnt = wave_total_i32(cnt);
-    if (lane == 0)           // (arrival, sum W); integer adds commute: run-to-run identical
-        __hip_atomic_fetch_add(&ws.acc1[(size_t)(item & (kAcc1Words - 1)) * kAcc2Stride], (1ull << 40) | (unsigned long long)(unsigned int)cnt, BXI_RLX, BXI_AGENT);
+    if (lane == 0) {         // (arrival, sum W); integer adds commute: run-to-run identical.  Nobody waits for this wave's exit.
+        const int k = item & (kAcc1Words - 1);
+        const unsigned long long mine = (1ull << 40) | (unsigned long long)(unsigned int)cnt;
+        const unsigned long long old = __hip_atomic_fetch_add(&ws.acc1[(size_t)k * kAcc2Stride], mine, BXI_RLX, BXI_AGENT);
+        const unsigned long long now = old + mine;
+        if ((int)(now >> 40) == (n_items - k + kAcc1Words - 1) / kAcc1Words)       // the word's last segment: forward the word's total
+            __hip_atomic_fetch_add(ws.sumw, (1ull << 40) | (now & ((1ull << 40) - 1ull)), BXI_RLX, BXI_AGENT);
+    }
 }
 
-// One round over the count words: true when every predicate wave has arrived; then *total = sum W over all instances.
+// True when every predicate wave has arrived; then *total = sum W over all instances.  ONE word, the same for every asker.
+__device__ __forceinline__ bool counts_word_complete(unsigned long long x, int n_items, double* total) {
+    *total = (double)(x & ((1ull << 40) - 1ull));                       // exact: an integer far below 2^53
+    return (int)(x >> 40) == (n_items < kAcc1Words ? n_items : kAcc1Words);
+}
 __device__ __forceinline__ bool counts_complete(const Ws& ws, int n_items, double* total) {
-    const unsigned long long x = __hip_atomic_load(&ws.acc1[(size_t)(threadIdx.x & 63) * kAcc2Stride], BXI_RLX, BXI_AGENT);
-    const int arrived = wave_total_i32((int)(x >> 40));
-    *total = wave_total_f64((double)(x & ((1ull << 40) - 1ull)));       // exact: integers far below 2^53
-    return arrived == n_items;
+    return counts_word_complete(__hip_atomic_load(ws.sumw, BXI_RLX, BXI_AGENT), n_items, total);
 }
 // thresh <= 0: every pair (padded ones too) weighs 1 (:1324), sum W = 8 x the box areas; no predicate waves then
 __device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, const Ws& ws) {
@@ -758,11 +765,11 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
                     all &= pbyte[i];
                 }
                 if (__all(all != 0u)) { ok = true; break; }
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(16);        // ~0.4 us: a few hundred waves may be asking
             }
             if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
             // the count words, requested now and looked at after the pair loop: the predicate waves are normally all done by then
-            if (!have_scale) early_counts = __hip_atomic_load(&ws.acc1[(size_t)lane * kAcc2Stride], BXI_RLX, BXI_AGENT);
+            if (!have_scale) early_counts = __hip_atomic_load(ws.sumw, BXI_RLX, BXI_AGENT);
 #pragma unroll
             for (int i = 0; i < R + D; ++i)
 #pragma unroll
@@ -823,8 +830,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
         double total_w = 0.0;
         if (zero_bit) total_w = total_weight_all_pairs(a, ws);
         else {
-            bool ok = wave_total_i32((int)(early_counts >> 40)) == n_items;
-            if (ok) total_w = wave_total_f64((double)(early_counts & ((1ull << 40) - 1ull)));
+            bool ok = counts_word_complete(early_counts, n_items, &total_w);
             for (unsigned spins = 0; !ok && spins <= kSpinLimit; ++spins) {
                 if (counts_complete(ws, n_items, &total_w)) { ok = true; break; }
                 __builtin_amdgcn_s_sleep(8);
@@ -846,7 +852,8 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     BXI_TW(1, tix, 6);
     // this tile's share of sum W pw + its arrival: one atomic without return; the wave does not wait for it
     if (lane == 0)
-        __hip_atomic_fetch_add(acc2_word(ws.acc2, n, t.tile_r0 / R + t.tile_c0 / TG<D, R>::TW), (1ull << 52) + (unsigned long long)fx, BXI_RLX, BXI_AGENT);
+        __hip_atomic_fetch_add(&ws.acc2[(size_t)((unsigned int)(n * 7 + t.tile_r0 / R + t.tile_c0) % (unsigned int)ws.n_acc2) * kAcc2Stride],
+                               (1ull << 48) + (unsigned long long)fx, BXI_RLX, BXI_AGENT);
     BXI_TW(1, tix, 7);
 }
 
@@ -969,28 +976,28 @@ __device__ __forceinline__ Tile tile_of(const int4& e, int D, int R, int TW, int
 
 // The finisher's round over instances [b0, b0 + 64): arrivals and sums of every tile (8 words per instance, arrival count and
 // sum in one word) and the leaders' dice losses, requested together.  Returns whether all are complete; adds their sums.
-__device__ __forceinline__ unsigned int tiles_of(const Ws& ws, int N, int i) {
-    return i < N ? (unsigned int)((ws.tab[i + 1].x & 0xffffff) - (ws.tab[i].x & 0xffffff)) : 0u;
-}
-__device__ __forceinline__ bool finisher_round(const Ws& ws, int N, int b0, unsigned int expect, double* num, float* dsum) {
+// The finisher's rounds.  Leaders: the dice losses of instances [b0, b0 + 64) (self-flagging words).  Tiles: the 64 arrival words
+// (arrival count and sum W pw in one word): the round in which everything turns out to be complete also delivered the data.
+__device__ __forceinline__ bool dice_round(const Ws& ws, int N, int b0, float* dsum) {
     const int lane = threadIdx.x & 63, i = b0 + lane;
-    unsigned long long x = 0ull, dg = 1ull << 32;
-    if (i < N) {
-        unsigned long long wd[kAcc2Split];
-#pragma unroll
-        for (int sub = 0; sub < kAcc2Split; ++sub) wd[sub] = __hip_atomic_load(acc2_word(ws.acc2, i, sub), BXI_RLX, BXI_AGENT);
-        dg = __hip_atomic_load(&ws.dice[i], BXI_RLX, BXI_AGENT);
-#pragma unroll
-        for (int sub = 0; sub < kAcc2Split; ++sub) x += wd[sub];
-    }
-    const bool have = (unsigned int)(x >> 52) == expect && (dg >> 32) != 0ull;
-    if (!__all(have)) return false;
-    const long long fixed = (long long)(x & ((1ull << 52) - 1ull)) - ((long long)expect << 24);   // the +1 per tile
-    *num += wave_total_f64(i < N ? (double)fixed : 0.0);
+    const unsigned long long dg = i < N ? __hip_atomic_load(&ws.dice[i], BXI_RLX, BXI_AGENT) : (1ull << 32);
+    if (!__all((dg >> 32) != 0ull)) return false;
     const float dv = i < N ? __uint_as_float((unsigned int)dg) : 0.f;
     const int m = min(64, N - b0);
     for (int k = 0; k < m; ++k) *dsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), k));   // index order: run-to-run identical
     return true;
+}
+__device__ __forceinline__ bool tiles_round(const Ws& ws, int ntiles, double* num) {
+    int arrived = 0;
+    double fixed = 0.0;
+    for (int i = threadIdx.x & 63; i < ws.n_acc2; i += 64) {            // one load per lane at the headline size
+        const unsigned long long x = __hip_atomic_load(&ws.acc2[(size_t)i * kAcc2Stride], BXI_RLX, BXI_AGENT);
+        arrived += (int)(x >> 48);
+        fixed += (double)((long long)(x & ((1ull << 48) - 1ull)) - ((long long)(x >> 48) << 24));       // the +1 per tile; exact
+    }
+    arrived = wave_total_i32(arrived);
+    *num = wave_total_f64(fixed);
+    return arrived == ntiles;
 }
 
 // The tile of list position `ti`: the instance whose tile range holds it (table entries: 16 bytes per instance, the same lines
@@ -1026,7 +1033,7 @@ __device__ __forceinline__ Tile locate_tile(const Ws& ws, int N, const int4& e0,
 // never waiting themselves), the finisher for everybody (nobody waits for it).  Every wait is bounded, and running out of it is
 // loud: NaN losses, status word, poisoned gradient (the reference surfaces launch failures through AT_CUDA_CHECK, pairwise.cu:173,200).
 template <int D, int R>
-__global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
+__global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : (R <= 6 ? 3 : 2))) void pair3_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
                                                        float n2max, int zero_bit, int n_pb, int n_items, ValidCells vc, float* __restrict__ losses,
                                                        float* __restrict__ g_logits, InstArgs a, Ws ws, LossState st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1043,24 +1050,34 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_ke
         if (zero_bit) return;                                          // every pair weighs 1: sum W has a closed form, the tiles take the log-space path
         const int segs = (a.w + 63) >> 6, pid = (blk - N) * kWaves + wave;
         BXI_TW(2, pid, 0);
-        for (int item = pid; item < n_items; item += n_pb * kWaves) pred_item(a, vc, ws, D, n2max, item, segs);
+        __builtin_amdgcn_s_setprio(3);                                 // the tile waves will ask for these bytes
+        for (int item = pid; item < n_items; item += n_pb * kWaves) pred_item(a, vc, ws, D, n2max, item, segs, n_items);
         BXI_TW(2, pid, 1);
         return;
     }
     if (blk == (int)gridDim.x - 1) {                                   // ---- finisher: one wave
         if (threadIdx.x >= 64) return;
         BXI_TW(3, 0, 0);
-        bool ok = false;
+        // waits only for workgroups that never wait for it: the leaders and the predicate waves (done early), then the tiles
+        const int ntiles = __builtin_amdgcn_readfirstlane(ws.tab[N].x);
+        bool ok = true;
         double num = 0.0, total_w = 0.0;
         float dsum = 0.f;
-        const unsigned int expect0 = tiles_of(ws, N, lane);             // tiles of instance `lane`: launch-1 data, read once
-        for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {        // waits only for workgroups that never wait for it
-            num = 0.0; dsum = 0.f;
-            bool all = zero_bit ? true : counts_complete(ws, n_items, &total_w);    // requested with the first pass's loads
-            for (int b0 = 0; b0 < N && all; b0 += 64) all = finisher_round(ws, N, b0, b0 ? tiles_of(ws, N, b0 + lane) : expect0, &num, &dsum);
-            if (all) { ok = true; break; }
+        unsigned spins = 0;
+        for (int b0 = 0; b0 < N && ok; b0 += 64) {
+            while (!dice_round(ws, N, b0, &dsum)) {
+                if (++spins > kSpinLimit) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
         }
         if (zero_bit) total_w = total_weight_all_pairs(a, ws);
+        else
+            while (ok && !counts_complete(ws, n_items, &total_w)) {
+                if (++spins > kSpinLimit) ok = false;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        while (ok && !tiles_round(ws, ntiles, &num))                    // one load per lane a round: the launch ends on this loop
+            if (++spins > kSpinLimit) ok = false;
         const unsigned int fault = __hip_atomic_load(ws.fault, BXI_RLX, BXI_AGENT);   // set by a tile wave BEFORE its arrival, if at all
         const unsigned int status = (unsigned int)__builtin_amdgcn_readfirstlane((int)(fault | (ok ? 0u : kFaultFinisher)));
         if (lane == 0) {
@@ -1075,10 +1092,7 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_ke
         BXI_TW(3, 0, 1);
         return;
     }
-    // consecutive tiles go to different workgroups (the list is shorter than the grid at the headline size: its waves would
-    // otherwise all sit in the first workgroups, several to a SIMD, next to idle ones)
-    const int n_tb = (int)gridDim.x - 1 - N - n_pb, nwaves = n_tb * kWaves;
-    const int wid = wave * n_tb + (blk - N - n_pb);
+    const int wid = (blk - N - n_pb) * kWaves + wave, nwaves = ((int)gridDim.x - 1 - N - n_pb) * kWaves;
     BXI_TW(1, wid, 0);
     int4 e0 = make_int4(0, 0, 0, 0);
     if (lane <= N) e0 = ws.tab[lane];
@@ -1256,7 +1270,7 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     static const int env_pool_first = env_int("BXI_POOL_FIRST", 1);
     static const int env_pool_wgs = env_int("BXI_POOL_WGS_PER_CU", 5);
     if (!force_rows) force_rows = env_rows;
-    const int R = force_rows == 4 || force_rows == 8 ? force_rows : tile_rows_for(a.N);
+    const int R = force_rows == 4 || force_rows == 5 || force_rows == 6 || force_rows == 8 ? force_rows : tile_rows_for(a.N);
     if (eval_cap(a.N, a.h, a.w, dil, R) >= (1 << 24)) return BXI_ERR_BAD_SHAPE;     // the table packs a tile prefix into 24 bits
     const HostPred pr = host_pred(color_thresh);
 
@@ -1318,7 +1332,7 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     // the tile list's length is device data: the tile waves stride through it.  The launch should be resident in one round:
     // 4 (R = 4: <= 128 VGPRs) or 2 (R = 8) workgroups per CU; the predicate waves are short-lived.
     static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 0);
-    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? (dil <= 3 ? 4 : 3) : 2);
+    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? (dil <= 3 ? 4 : 3) : (R <= 6 ? 3 : 2));
     const int slots = occ * device_cus() - a.N - 1;
     int n_pb = (n_items + kWaves - 1) / kWaves;
     if (n_pb > slots / 2) n_pb = slots / 2 > 1 ? slots / 2 : 1;
@@ -1338,6 +1352,8 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
 #define BXI_PAIR_CASE(DD)                                                                                                                  \
     case DD:                                                                                                                               \
         if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw); \
+        else if (R == 5) launch_pair<DD, 5>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw); \
+        else if (R == 6) launch_pair<DD, 6>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw); \
         else launch_pair<DD, 8>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw);        \
         break;
     switch (dil) {

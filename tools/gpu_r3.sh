@@ -14,11 +14,10 @@ except Exception as e:
 PY
 }
 i=0
-for cfg in "BXI_EVAL_V2=1" "BXI_POOL_FIRST=1" "BXI_POOL_FIRST=0" "BXI_POOL_FIRST=0 BXI_PAIR_WGS_PER_CU=3" "BXI_POOL_FIRST=0 BXI_TILE_ROWS=8" "BXI_EVAL_V2=1" "BXI_POOL_FIRST=0"; do
+for cfg in "BXI_EVAL_V2=1" "BXI_POOL_FIRST=0" "BXI_POOL_FIRST=0 BXI_TILE_ROWS=5" "BXI_POOL_FIRST=0 BXI_TILE_ROWS=6" "BXI_POOL_FIRST=0 BXI_PAIR_WGS_PER_CU=3" "BXI_POOL_FIRST=0"; do
   i=$((i+1))
   echo "== $cfg"
   env $cfg timeout 300 python bench.py --no-cpu-baseline --no-extras > gpurun_out/bench_ab$i.json 2> gpurun_out/bench_ab$i.err
   summ gpurun_out/bench_ab$i.json
 done
-BXI_POOL_FIRST=1 timeout 300 python tools/trace_eval.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/block_trace_pf1.txt
 BXI_POOL_FIRST=0 timeout 300 python tools/trace_eval.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/block_trace_pf0.txt
