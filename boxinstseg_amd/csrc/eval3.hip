@@ -49,9 +49,7 @@ constexpr int kSBlk = kWaves * kSRows;          // rows per stream workgroup
 constexpr int kChunkC = 256;                    // columns per pass of a stream wave: 64 lanes x float4
 constexpr int kMaxDilFused = 4;
 constexpr unsigned kSpinLimit = 400000;         // bounded waits (~0.3 us per poll): far beyond any launch; running out is loud (NaN losses)
-constexpr int kAcc2Stride = 16;                 // polled / atomically updated words sit in their own 128 bytes
-constexpr int kAcc2Words = 64;                  // tile arrivals + sum W pw: only the totals are ever needed (kAcc2Words words per 8192 possible tiles)
-constexpr int kAcc1Words = 64;                  // predicate-wave arrivals + sum W
+constexpr int kMaxSlots = 8192;                 // waves per role of launch 2 (4 x 256 CUs x 8 workgroups)
 constexpr int kMaxInst = 65536;
 constexpr unsigned kFaultCounts = 1u, kFaultFinisher = 2u;
 
@@ -84,10 +82,11 @@ struct Ws {
     int n_cb, n_rp;
     int4* tab;                                  // [N+1] {tile prefix | img << 24, r0 | r1 << 16, c0 | c1 << 16, vrow | vcol << 16}; [N].x = tiles
     // words polled inside pair3_kernel; zeroed by prep3_kernel's table waves, i.e. before a kernel boundary
-    unsigned long long* acc1;                   // [kAcc1Words] (one per 128 B) predicate waves: arrivals << 40 | sum W
-    unsigned long long* sumw;                   // [1]   complete count words << 40 | sum W (added by the predicate wave that completes a word)
-    unsigned long long* acc2;                   // [n_acc2] (one per 128 B) tile waves: arrivals << 48 | sum (W pw + 1) in 2^-24 units
-    int n_acc2;                                 // a multiple of 64, <= 128 tiles per word (a tile's sum < 2^40 units)
+    // one slot per wave of the next launch, written ONCE by that wave and only read by others (no atomics: a few arrivals on one
+    // word are performed one after the other, ~0.15 us each, and the launch ends on the last of them)
+    unsigned int* pslot;                        // [n_pw] predicate wave: 1 << 31 | its share of sum W
+    unsigned long long* tslot;                  // [n_tw] tile wave: 1 << 63 | its share of sum W pw in 2^-24 units
+    int n_pw, n_tw;                             // waves of the two roles (set per launch; <= kMaxSlots)
     unsigned long long* dice;                   // [N]   leader: 1 << 32 | bits of the instance's dice loss (0 = not published)
     unsigned int* fault;                        // [1]   bit mask of waits that ran out (never expected)
 };
@@ -115,10 +114,9 @@ static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
     t.rowkey = (unsigned long long*)take(8 * (size_t)N1 * h * (rp_max > 1 ? rp_max : 1));
     t.n_cb = (int)Sn; t.n_rp = 1;
     t.tab = (int4*)take(16 * (size_t)(N1 + 1));
-    t.acc1 = (unsigned long long*)take(8 * (size_t)kAcc1Words * kAcc2Stride);
-    t.sumw = (unsigned long long*)take(8);
-    t.n_acc2 = kAcc2Words * (int)((eval_cap(N, h, w, 1, 4) + 8191) / 8192);
-    t.acc2 = (unsigned long long*)take(8 * (size_t)t.n_acc2 * kAcc2Stride);
+    t.pslot = (unsigned int*)take(4 * (size_t)kMaxSlots);
+    t.tslot = (unsigned long long*)take(8 * (size_t)kMaxSlots);
+    t.n_pw = t.n_tw = 0;
     t.dice = (unsigned long long*)take(8 * (size_t)N1);
     t.fault = (unsigned int*)take(4);
     if (ws) *ws = t;
@@ -184,9 +182,9 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
         ws.tab[m] = make_int4(prefix, 0, 0, 0);
     }
     if (k == 0) {          // every word the next launch polls (no hipMemsetAsync, no initialisation contract)
-        ws.acc1[(size_t)lane * kAcc2Stride] = 0ull;
-        for (int i = lane; i < ws.n_acc2; i += 64) ws.acc2[(size_t)i * kAcc2Stride] = 0ull;
-        if (lane == 0) { *ws.sumw = 0ull; *ws.fault = 0u; if (st.status) { st.status[0] = 0; st.status[1] = R; } }
+        for (int i = lane; i < ws.n_pw; i += 64) ws.pslot[i] = 0u;
+        for (int i = lane; i < ws.n_tw; i += 64) ws.tslot[i] = 0ull;
+        if (lane == 0) { *ws.fault = 0u; if (st.status) { st.status[0] = 0; st.status[1] = R; } }
     }
 }
 
@@ -630,15 +628,15 @@ __device__ __forceinline__ void load_plane(const float* __restrict__ plane, cons
 //   0: (r, c) - (r, c+D)    1: (r+D, c) - (r, c+D)    2: (r, c) - (r+D, c)    3: (r, c) - (r+D, c+D)
 // -> one predicate byte per pixel (bit d: squared Lab distance <= n2max, i.e. sim >= thresh for a valid neighbour), and the
 // segment's share of  sum W = sum_n sum_{p in box n} sum_k [sim_k(p) >= thresh]  (:1324-1328): a pair (p, q) weighs
-// [p in box n][q valid] + [q in box n][p valid] for every instance n of the image.  One packed integer atomic per segment
-// (arrival, count).  A byte carries its own "evaluated" bit: a tile wave re-reads the few bytes it needs until they have it.
+// [p in box n][q valid] + [q in box n][p valid] for every instance n of the image (returned per lane; the wave's total goes
+// to its slot).  A byte carries its own "evaluated" bit: a tile wave re-reads the few bytes it needs until they have it.
 __device__ __forceinline__ float lane_plus_n(float v, int d) {
     int x = __float_as_int(v);
     for (int s = 0; s < d; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
     return __int_as_float(x);
 }
 struct ValidCells { int vrow[BXI_MAX_IMAGES], vcol[BXI_MAX_IMAGES]; };   // per image: valid(q) <=> row(q) < vrow && col(q) < vcol (host: :1354-1369,:1405)
-__device__ __forceinline__ void pred_item(const InstArgs& a, const ValidCells& vc, const Ws& ws, int D, float n2max, int item, int segs, int n_items) {
+__device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc, const Ws& ws, int D, float n2max, int item, int segs) {
     const int h = a.h, w = a.w, lane = threadIdx.x & 63;
     const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
     const int c = seg * 64 + lane, cn = c + D;
@@ -679,24 +677,20 @@ __device__ __forceinline__ void pred_item(const InstArgs& a, const ValidCells& v
             cnt += (rr && c_in ? s00 : 0) + (rr && n_in ? s0n : 0) + (rD2 && c_in ? sD0 : 0) + (rD2 && n_in ? sDn : 0);
         }
     }
-    cnt = wave_total_i32(cnt);
-    if (lane == 0) {         // (arrival, sum W); integer adds commute: run-to-run identical.  Nobody waits for this wave's exit.
-        const int k = item & (kAcc1Words - 1);
-        const unsigned long long mine = (1ull << 40) | (unsigned long long)(unsigned int)cnt;
-        const unsigned long long old = __hip_atomic_fetch_add(&ws.acc1[(size_t)k * kAcc2Stride], mine, BXI_RLX, BXI_AGENT);
-        const unsigned long long now = old + mine;
-        if ((int)(now >> 40) == (n_items - k + kAcc1Words - 1) / kAcc1Words)       // the word's last segment: forward the word's total
-            __hip_atomic_fetch_add(ws.sumw, (1ull << 40) | (now & ((1ull << 40) - 1ull)), BXI_RLX, BXI_AGENT);
-    }
+    return cnt;
 }
 
-// True when every predicate wave has arrived; then *total = sum W over all instances.  ONE word, the same for every asker.
-__device__ __forceinline__ bool counts_word_complete(unsigned long long x, int n_items, double* total) {
-    *total = (double)(x & ((1ull << 40) - 1ull));                       // exact: an integer far below 2^53
-    return (int)(x >> 40) == (n_items < kAcc1Words ? n_items : kAcc1Words);
-}
-__device__ __forceinline__ bool counts_complete(const Ws& ws, int n_items, double* total) {
-    return counts_word_complete(__hip_atomic_load(ws.sumw, BXI_RLX, BXI_AGENT), n_items, total);
+// sum W = the predicate waves' slots, all of them written (bit 31).  Each asker reads them all: 4 bytes per predicate wave.
+__device__ __forceinline__ bool slots_sum(const Ws& ws, double* total) {
+    unsigned long long sum = 0ull;
+    bool ok = true;
+    for (int i = threadIdx.x & 63; i < ws.n_pw; i += 64) {
+        const unsigned int x = __hip_atomic_load(ws.pslot + i, BXI_RLX, BXI_AGENT);
+        ok &= (x >> 31) != 0u;
+        sum += x & 0x7fffffffu;
+    }
+    *total = wave_total_f64((double)sum);                               // exact: integers far below 2^53
+    return __all(ok);
 }
 // thresh <= 0: every pair (padded ones too) weighs 1 (:1324), sum W = 8 x the box areas; no predicate waves then
 __device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, const Ws& ws) {
@@ -722,7 +716,7 @@ __device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, cons
 // computed; and, before the gradient goes out, sum W (the global normaliser, :1327-1328) = every predicate wave's arrival.  The
 // predicate waves precede the tile waves in the grid and never wait; by the time a tile wave asks they are normally done.
 template <int D, int R>
-__device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float upw_warm, float n2max, int zero_bit, int n_items,
+__device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float upw_warm, float n2max, int zero_bit, long long& acc_fx,
                                           float& scale, bool& have_scale, float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
                                           int tix) {
     constexpr int RD = TG<D, R>::RD;
@@ -748,7 +742,6 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
         aR[j] = lane_plus<D>(pa_[j]); bR[j] = lane_plus<D>(pb_[j]); tR[j] = aR[j] - bR[j]; uR[j] = aR[j] * bR[j];
     }
     const bool slow = zero_bit != 0 || __any(sat);
-    unsigned long long early_counts = 0ull;
     BXI_TW(1, tix, 2);
     if (!slow) {
         uint32_t pb[4] = {0u, 0u, 0u, 0u};
@@ -768,8 +761,11 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
                 __builtin_amdgcn_s_sleep(16);        // ~0.4 us: a few hundred waves may be asking
             }
             if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
-            // the count words, requested now and looked at after the pair loop: the predicate waves are normally all done by then
-            if (!have_scale) early_counts = __hip_atomic_load(ws.sumw, BXI_RLX, BXI_AGENT);
+            // sum W now, if every predicate wave happens to be done already (normally): nothing to ask for after the pair loop then
+            if (!have_scale) {
+                double tw;
+                if (slots_sum(ws, &tw)) { scale = upw_warm / fmaxf((float)tw, 1.f); have_scale = true; }
+            }
 #pragma unroll
             for (int i = 0; i < R + D; ++i)
 #pragma unroll
@@ -825,15 +821,15 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     }
     BXI_TW(1, tix, 5);
     num = wave_total_f32(num);
-    const long long fx = (long long)(num * kNumScale) + (1ll << 24);           // + 1.0: keeps the packed field non-negative
+    const long long fx = (long long)(num * kNumScale);
     if (!have_scale) {           // wave-uniform; once per wave
         double total_w = 0.0;
         if (zero_bit) total_w = total_weight_all_pairs(a, ws);
         else {
-            bool ok = counts_word_complete(early_counts, n_items, &total_w);
+            bool ok = false;
             for (unsigned spins = 0; !ok && spins <= kSpinLimit; ++spins) {
-                if (counts_complete(ws, n_items, &total_w)) { ok = true; break; }
-                __builtin_amdgcn_s_sleep(8);
+                if (slots_sum(ws, &total_w)) { ok = true; break; }
+                __builtin_amdgcn_s_sleep(16);
             }
             if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
         }
@@ -850,11 +846,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
         }
     }
     BXI_TW(1, tix, 6);
-    // this tile's share of sum W pw + its arrival: one atomic without return; the wave does not wait for it
-    if (lane == 0)
-        __hip_atomic_fetch_add(&ws.acc2[(size_t)((unsigned int)(n * 7 + t.tile_r0 / R + t.tile_c0) % (unsigned int)ws.n_acc2) * kAcc2Stride],
-                               (1ull << 48) + (unsigned long long)fx, BXI_RLX, BXI_AGENT);
-    BXI_TW(1, tix, 7);
+    acc_fx += fx;            // this tile's share of sum W pw: goes out with the wave's slot
 }
 
 __device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
@@ -976,8 +968,7 @@ __device__ __forceinline__ Tile tile_of(const int4& e, int D, int R, int TW, int
 
 // The finisher's round over instances [b0, b0 + 64): arrivals and sums of every tile (8 words per instance, arrival count and
 // sum in one word) and the leaders' dice losses, requested together.  Returns whether all are complete; adds their sums.
-// The finisher's rounds.  Leaders: the dice losses of instances [b0, b0 + 64) (self-flagging words).  Tiles: the 64 arrival words
-// (arrival count and sum W pw in one word): the round in which everything turns out to be complete also delivered the data.
+// The finisher's rounds.  Leaders: the dice losses of instances [b0, b0 + 64) (self-flagging words).
 __device__ __forceinline__ bool dice_round(const Ws& ws, int N, int b0, float* dsum) {
     const int lane = threadIdx.x & 63, i = b0 + lane;
     const unsigned long long dg = i < N ? __hip_atomic_load(&ws.dice[i], BXI_RLX, BXI_AGENT) : (1ull << 32);
@@ -986,18 +977,6 @@ __device__ __forceinline__ bool dice_round(const Ws& ws, int N, int b0, float* d
     const int m = min(64, N - b0);
     for (int k = 0; k < m; ++k) *dsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), k));   // index order: run-to-run identical
     return true;
-}
-__device__ __forceinline__ bool tiles_round(const Ws& ws, int ntiles, double* num) {
-    int arrived = 0;
-    double fixed = 0.0;
-    for (int i = threadIdx.x & 63; i < ws.n_acc2; i += 64) {            // one load per lane at the headline size
-        const unsigned long long x = __hip_atomic_load(&ws.acc2[(size_t)i * kAcc2Stride], BXI_RLX, BXI_AGENT);
-        arrived += (int)(x >> 48);
-        fixed += (double)((long long)(x & ((1ull << 48) - 1ull)) - ((long long)(x >> 48) << 24));       // the +1 per tile; exact
-    }
-    arrived = wave_total_i32(arrived);
-    *num = wave_total_f64(fixed);
-    return arrived == ntiles;
 }
 
 // The tile of list position `ti`: the instance whose tile range holds it (table entries: 16 bytes per instance, the same lines
@@ -1033,7 +1012,7 @@ __device__ __forceinline__ Tile locate_tile(const Ws& ws, int N, const int4& e0,
 // never waiting themselves), the finisher for everybody (nobody waits for it).  Every wait is bounded, and running out of it is
 // loud: NaN losses, status word, poisoned gradient (the reference surfaces launch failures through AT_CUDA_CHECK, pairwise.cu:173,200).
 template <int D, int R>
-__global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : (R <= 6 ? 3 : 2))) void pair3_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
+__global__ __launch_bounds__(256, (R <= 6 ? 3 : 2)) void pair3_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
                                                        float n2max, int zero_bit, int n_pb, int n_items, ValidCells vc, float* __restrict__ losses,
                                                        float* __restrict__ g_logits, InstArgs a, Ws ws, LossState st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1051,34 +1030,60 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : (R <= 6 ? 3 : 2))
         const int segs = (a.w + 63) >> 6, pid = (blk - N) * kWaves + wave;
         BXI_TW(2, pid, 0);
         __builtin_amdgcn_s_setprio(3);                                 // the tile waves will ask for these bytes
-        for (int item = pid; item < n_items; item += n_pb * kWaves) pred_item(a, vc, ws, D, n2max, item, segs, n_items);
+        int cnt = 0;
+        for (int item = pid; item < n_items; item += n_pb * kWaves) cnt += pred_item(a, vc, ws, D, n2max, item, segs);
+        cnt = wave_total_i32(cnt);
+        if (lane == 0) __hip_atomic_store(ws.pslot + pid, 0x80000000u | (unsigned int)cnt, BXI_RLX, BXI_AGENT);   // written once, through
         BXI_TW(2, pid, 1);
         return;
     }
-    if (blk == (int)gridDim.x - 1) {                                   // ---- finisher: one wave
-        if (threadIdx.x >= 64) return;
+    if (blk == (int)gridDim.x - 1) {                                   // ---- finisher
+        // waits only for workgroups that never wait for it: the leaders and the predicate waves (done early), then the tile waves
         BXI_TW(3, 0, 0);
-        // waits only for workgroups that never wait for it: the leaders and the predicate waves (done early), then the tiles
-        const int ntiles = __builtin_amdgcn_readfirstlane(ws.tab[N].x);
+        __shared__ double fin_d[kWaves];
+        __shared__ float fin_f;
+        __shared__ int fin_ok;
         bool ok = true;
-        double num = 0.0, total_w = 0.0;
+        double total_w = 0.0;
         float dsum = 0.f;
         unsigned spins = 0;
-        for (int b0 = 0; b0 < N && ok; b0 += 64) {
-            while (!dice_round(ws, N, b0, &dsum)) {
-                if (++spins > kSpinLimit) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(8);
+        if (wave == 0) {
+            for (int b0 = 0; b0 < N && ok; b0 += 64) {
+                while (!dice_round(ws, N, b0, &dsum)) {
+                    if (++spins > kSpinLimit) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
             }
+            if (zero_bit) total_w = total_weight_all_pairs(a, ws);
+            else
+                while (ok && !slots_sum(ws, &total_w)) {
+                    if (++spins > kSpinLimit) ok = false;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            if (lane == 0) { fin_f = dsum; fin_d[0] = total_w; fin_ok = ok ? 1 : 0; }
         }
-        if (zero_bit) total_w = total_weight_all_pairs(a, ws);
-        else
-            while (ok && !counts_complete(ws, n_items, &total_w)) {
-                if (++spins > kSpinLimit) ok = false;
-                __builtin_amdgcn_s_sleep(8);
+        __syncthreads();
+        ok = fin_ok != 0; dsum = fin_f; total_w = fin_d[0];
+        __syncthreads();
+        // every thread watches its own tile-wave slots (n_tw / 256 each): the launch ends on this loop
+        long long mine = 0;
+        for (;;) {
+            mine = 0;
+            bool have = true;
+            for (int i = threadIdx.x; i < ws.n_tw; i += 256) {
+                const unsigned long long x = __hip_atomic_load(ws.tslot + i, BXI_RLX, BXI_AGENT);
+                have &= (x >> 63) != 0ull;
+                mine += (long long)(x & ~(1ull << 63));
             }
-        while (ok && !tiles_round(ws, ntiles, &num))                    // one load per lane a round: the launch ends on this loop
-            if (++spins > kSpinLimit) ok = false;
-        const unsigned int fault = __hip_atomic_load(ws.fault, BXI_RLX, BXI_AGENT);   // set by a tile wave BEFORE its arrival, if at all
+            if (__syncthreads_and(have ? 1 : 0)) break;
+            if (++spins > kSpinLimit) { ok = false; break; }           // workgroup-uniform: the same count in every thread
+        }
+        const double wsum = wave_total_f64((double)mine);                // exact; fixed order: run-to-run identical
+        if (lane == 0) fin_d[wave] = wsum;
+        __syncthreads();
+        if (threadIdx.x >= 64) return;
+        const double num = (fin_d[0] + fin_d[1]) + (fin_d[2] + fin_d[3]);
+        const unsigned int fault = __hip_atomic_load(ws.fault, BXI_RLX, BXI_AGENT);   // set by a tile wave BEFORE its slot, if at all
         const unsigned int status = (unsigned int)__builtin_amdgcn_readfirstlane((int)(fault | (ok ? 0u : kFaultFinisher)));
         if (lane == 0) {
             const float denom = fmaxf((float)total_w, 1.f);                      // weights.sum().clamp(min=1.0), :1328
@@ -1100,11 +1105,15 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : (R <= 6 ? 3 : 2))
     float* gbuf = reinterpret_cast<float*>(smem) + wave * ((R + 1) * 64);
     float scale = 0.f;
     bool have_scale = false;
+    long long acc_fx = 0;
     for (int ti = wid; ti < total; ti += nwaves) {
         const Tile t = locate_tile<D, R>(ws, N, e0, ti, a.h, a.w);
         BXI_TW(1, wid, 1);
-        math_tile<D, R>(a, ws, t, upw * warmup, n2max, zero_bit, n_items, scale, have_scale, g_logits, gbuf, wid);
+        math_tile<D, R>(a, ws, t, upw * warmup, n2max, zero_bit, acc_fx, scale, have_scale, g_logits, gbuf, wid);
     }
+    // this wave's share of sum W pw, and the sign that it is done (EVERY tile-role wave writes its slot, once)
+    if (lane == 0) __hip_atomic_store(ws.tslot + wid, (1ull << 63) | (unsigned long long)acc_fx, BXI_RLX, BXI_AGENT);
+    BXI_TW(1, wid, 7);
 }
 
 // ---- rescale: g_logits finished for the factors recorded in `state` -> finished for (g_prj, g_pw) ----------------
@@ -1274,15 +1283,42 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     if (eval_cap(a.N, a.h, a.w, dil, R) >= (1 << 24)) return BXI_ERR_BAD_SHAPE;     // the table packs a tile prefix into 24 bits
     const HostPred pr = host_pred(color_thresh);
 
+    const int64_t n_items64 = (int64_t)batch->B * a.h * ((a.w + 63) / 64);
+    if (n_items64 > 0x7fffffffLL) return BXI_ERR_BAD_SHAPE;
+    const int n_items = (int)n_items64;
+    // launch 2's geometry (the table waves of launch 1 clear one slot per predicate / tile wave)
+    const int64_t cap = eval_cap(a.N, a.h, a.w, dil, R);
+    int64_t n_tb = (cap + kWaves - 1) / kWaves;
+    // the tile list's length is device data: the tile waves stride through it.  The launch should be resident in one round:
+    // 3 (R <= 6: <= 168 VGPRs) or 2 (R = 8) workgroups per CU; the predicate waves are short-lived.
+    static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 0);
+    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R <= 6 ? 3 : 2);
+    int slots = occ * device_cus() - a.N - 1;
+    if (slots > 2 * (kMaxSlots / kWaves)) slots = 2 * (kMaxSlots / kWaves);
+    int n_pb = (n_items + kWaves - 1) / kWaves;
+    if (n_pb > slots / 2) n_pb = slots / 2 > 1 ? slots / 2 : 1;
+    if (n_tb > slots - n_pb) n_tb = slots - n_pb > 64 ? slots - n_pb : 64;
+    if (n_pb * kWaves > kMaxSlots || n_tb * kWaves > kMaxSlots) return BXI_ERR_UNSUPPORTED;
+    ws.n_pw = n_pb * kWaves; ws.n_tw = (int)n_tb * kWaves;
+    size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
+    const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
+    if (lds2 < lds_leader) lds2 = lds_leader;
+    if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
+    const int grid = a.N + n_pb + (int)n_tb + 1;          // leaders + predicate blocks + tile blocks + the finisher
+    ValidCells vc = {};
+    for (int b = 0; b < batch->B; ++b) {                  // the device formula (valid_cells), evaluated here once per image
+        const int half = a.stride / 2;
+        auto cells = [&](int limit, int n) { const int v = limit - half <= 0 ? 0 : (limit - half + a.stride - 1) / a.stride; return v < n ? v : n; };
+        vc.vrow[b] = cells(pa.meta.img_h[b] < pa.meta.first_removed[b] ? pa.meta.img_h[b] : pa.meta.first_removed[b], a.h);
+        vc.vcol[b] = cells(pa.meta.img_w[b], a.w);
+    }
+
     // ---- launch 1 --------------------------------------------------------------------------------------------------
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
     const int Sn = (a.h + kSBlk - 1) / kSBlk;
     const int n_stream = a.N * Sn;
     // one item = the 4 input rows of 64 pooled pixels.  The whole launch should be resident at once (5 workgroups per CU at
     // <= 96 VGPRs): a pool workgroup takes several items, the next one's loads in flight, when it is not.
-    const int64_t n_items64 = (int64_t)batch->B * a.h * ((a.w + 63) / 64);
-    if (n_items64 > 0x7fffffffLL) return BXI_ERR_BAD_SHAPE;
-    const int n_items = (int)n_items64;
     const int room = env_pool_wgs * device_cus() - n_tab - (head ? 0 : n_stream);
     const int per = room > 0 ? (n_items + room - 1) / room : 8;
     const int n_pool = pooled_in_launch ? (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per) : 0;
@@ -1327,28 +1363,6 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     }
 
     // ---- launch 2 --------------------------------------------------------------------------------------------------
-    const int64_t cap = eval_cap(a.N, a.h, a.w, dil, R);
-    int64_t n_tb = (cap + kWaves - 1) / kWaves;
-    // the tile list's length is device data: the tile waves stride through it.  The launch should be resident in one round:
-    // 4 (R = 4: <= 128 VGPRs) or 2 (R = 8) workgroups per CU; the predicate waves are short-lived.
-    static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 0);
-    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? (dil <= 3 ? 4 : 3) : (R <= 6 ? 3 : 2));
-    const int slots = occ * device_cus() - a.N - 1;
-    int n_pb = (n_items + kWaves - 1) / kWaves;
-    if (n_pb > slots / 2) n_pb = slots / 2 > 1 ? slots / 2 : 1;
-    if (n_tb > slots - n_pb) n_tb = slots - n_pb > 64 ? slots - n_pb : 64;
-    size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
-    const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
-    if (lds2 < lds_leader) lds2 = lds_leader;
-    if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
-    const int grid = a.N + n_pb + (int)n_tb + 1;          // leaders + predicate blocks + tile blocks + the finisher
-    ValidCells vc = {};
-    for (int b = 0; b < batch->B; ++b) {                  // the device formula (valid_cells), evaluated here once per image
-        const int half = a.stride / 2;
-        auto cells = [&](int limit, int n) { const int v = limit - half <= 0 ? 0 : (limit - half + a.stride - 1) / a.stride; return v < n ? v : n; };
-        vc.vrow[b] = cells(pa.meta.img_h[b] < pa.meta.first_removed[b] ? pa.meta.img_h[b] : pa.meta.first_removed[b], a.h);
-        vc.vcol[b] = cells(pa.meta.img_w[b], a.w);
-    }
 #define BXI_PAIR_CASE(DD)                                                                                                                  \
     case DD:                                                                                                                               \
         if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw); \
