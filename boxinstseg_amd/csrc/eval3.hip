@@ -49,7 +49,8 @@ constexpr int kSBlk = kWaves * kSRows;          // rows per stream workgroup
 constexpr int kChunkC = 256;                    // columns per pass of a stream wave: 64 lanes x float4
 constexpr int kMaxDilFused = 4;
 constexpr unsigned kSpinLimit = 400000;         // bounded waits (~0.3 us per poll): far beyond any launch; running out is loud (NaN losses)
-constexpr int kMaxSlots = 8192;                 // waves per role of launch 2 (4 x 256 CUs x 8 workgroups)
+constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
+constexpr int kAcc1Words = 64;                  // count-wave arrivals + sum W: 64 words, each in its own 128 bytes
 constexpr int kMaxInst = 65536;
 constexpr unsigned kFaultCounts = 1u, kFaultFinisher = 2u;
 
@@ -82,15 +83,15 @@ struct Ws {
     int n_cb, n_rp;
     int4* tab;                                  // [N+1] {tile prefix | img << 24, r0 | r1 << 16, c0 | c1 << 16, vrow | vcol << 16}; [N].x = tiles
     // words polled inside pair3_kernel; zeroed by prep3_kernel's table waves, i.e. before a kernel boundary
-    // one slot per wave of the next launch, written ONCE by that wave and only read by others (no atomics: a few arrivals on one
-    // word are performed one after the other, ~0.15 us each, and the launch ends on the last of them)
-    unsigned int* pslot;                        // [n_pw] predicate wave: 1 << 31 | its share of sum W
-    unsigned long long* tslot;                  // [n_tw] tile wave: 1 << 63 | its share of sum W pw in 2^-24 units
-    int n_pw, n_tw;                             // waves of the two roles (set per launch; <= kMaxSlots)
+    unsigned long long* acc1;                   // [kAcc1Words] (one per 128 B) predicate waves: arrivals << 40 | sum W
+    unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B) tile waves: arrivals << 52 | sum (W pw + 1) in 2^-24 units
     unsigned long long* dice;                   // [N]   leader: 1 << 32 | bits of the instance's dice loss (0 = not published)
     unsigned int* fault;                        // [1]   bit mask of waits that ran out (never expected)
 };
 
+__device__ __forceinline__ unsigned long long* acc2_word(unsigned long long* acc2, int n, int sub) {
+    return acc2 + ((size_t)n * kAcc2Split + (sub & (kAcc2Split - 1))) * kAcc2Stride;
+}
 
 static inline int tile_width(int dil) { return 64 - 2 * dil; }
 static inline int64_t eval_cap(int N, int h, int w, int dil, int R) {
@@ -114,9 +115,8 @@ static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
     t.rowkey = (unsigned long long*)take(8 * (size_t)N1 * h * (rp_max > 1 ? rp_max : 1));
     t.n_cb = (int)Sn; t.n_rp = 1;
     t.tab = (int4*)take(16 * (size_t)(N1 + 1));
-    t.pslot = (unsigned int*)take(4 * (size_t)kMaxSlots);
-    t.tslot = (unsigned long long*)take(8 * (size_t)kMaxSlots);
-    t.n_pw = t.n_tw = 0;
+    t.acc1 = (unsigned long long*)take(8 * (size_t)kAcc1Words * kAcc2Stride);
+    t.acc2 = (unsigned long long*)take(8 * (size_t)N1 * kAcc2Split * kAcc2Stride);
     t.dice = (unsigned long long*)take(8 * (size_t)N1);
     t.fault = (unsigned int*)take(4);
     if (ws) *ws = t;
@@ -177,13 +177,15 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
     if (m < a.N) {
         ws.tab[m] = make_int4(prefix | (mine.img << 24), mine.r0 | (mine.r1 << 16), mine.c0 | (mine.c1 << 16), mine.vrow | (mine.vcol << 16));
         if (st.inst) { InstRec rc; rc.r0 = mine.r0; rc.r1 = mine.r1; rc.c0 = mine.c0; rc.c1 = mine.c1; rc.img = mine.img; rc.pad0 = rc.pad1 = rc.pad2 = 0; st.inst[m] = rc; }
-        ws.dice[m] = 0ull;      // polled by the next launch's finisher: zeroed here, i.e. before a kernel boundary
+        // the words the next launch polls: zeroed here, i.e. before a kernel boundary (no hipMemsetAsync, no initialisation contract)
+#pragma unroll
+        for (int sub = 0; sub < kAcc2Split; ++sub) *acc2_word(ws.acc2, m, sub) = 0ull;
+        ws.dice[m] = 0ull;
     } else if (m == a.N) {
         ws.tab[m] = make_int4(prefix, 0, 0, 0);
     }
-    if (k == 0) {          // every word the next launch polls (no hipMemsetAsync, no initialisation contract)
-        for (int i = lane; i < ws.n_pw; i += 64) ws.pslot[i] = 0u;
-        for (int i = lane; i < ws.n_tw; i += 64) ws.tslot[i] = 0ull;
+    if (k == 0) {
+        ws.acc1[(size_t)lane * kAcc2Stride] = 0ull;
         if (lane == 0) { *ws.fault = 0u; if (st.status) { st.status[0] = 0; st.status[1] = R; } }
     }
 }
@@ -628,15 +630,15 @@ __device__ __forceinline__ void load_plane(const float* __restrict__ plane, cons
 //   0: (r, c) - (r, c+D)    1: (r+D, c) - (r, c+D)    2: (r, c) - (r+D, c)    3: (r, c) - (r+D, c+D)
 // -> one predicate byte per pixel (bit d: squared Lab distance <= n2max, i.e. sim >= thresh for a valid neighbour), and the
 // segment's share of  sum W = sum_n sum_{p in box n} sum_k [sim_k(p) >= thresh]  (:1324-1328): a pair (p, q) weighs
-// [p in box n][q valid] + [q in box n][p valid] for every instance n of the image (returned per lane; the wave's total goes
-// to its slot).  A byte carries its own "evaluated" bit: a tile wave re-reads the few bytes it needs until they have it.
+// [p in box n][q valid] + [q in box n][p valid] for every instance n of the image.  One packed integer atomic per segment
+// (arrival, count).  A byte carries its own "evaluated" bit: a tile wave re-reads the few bytes it needs until they have it.
 __device__ __forceinline__ float lane_plus_n(float v, int d) {
     int x = __float_as_int(v);
     for (int s = 0; s < d; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
     return __int_as_float(x);
 }
 struct ValidCells { int vrow[BXI_MAX_IMAGES], vcol[BXI_MAX_IMAGES]; };   // per image: valid(q) <=> row(q) < vrow && col(q) < vcol (host: :1354-1369,:1405)
-__device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc, const Ws& ws, int D, float n2max, int item, int segs) {
+__device__ __forceinline__ void pred_item(const InstArgs& a, const ValidCells& vc, const Ws& ws, int D, float n2max, int item, int segs) {
     const int h = a.h, w = a.w, lane = threadIdx.x & 63;
     const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
     const int c = seg * 64 + lane, cn = c + D;
@@ -677,20 +679,17 @@ __device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc
             cnt += (rr && c_in ? s00 : 0) + (rr && n_in ? s0n : 0) + (rD2 && c_in ? sD0 : 0) + (rD2 && n_in ? sDn : 0);
         }
     }
-    return cnt;
+    cnt = wave_total_i32(cnt);
+    if (lane == 0)           // (arrival, sum W); integer adds commute: run-to-run identical
+        __hip_atomic_fetch_add(&ws.acc1[(size_t)(item & (kAcc1Words - 1)) * kAcc2Stride], (1ull << 40) | (unsigned long long)(unsigned int)cnt, BXI_RLX, BXI_AGENT);
 }
 
-// sum W = the predicate waves' slots, all of them written (bit 31).  Each asker reads them all: 4 bytes per predicate wave.
-__device__ __forceinline__ bool slots_sum(const Ws& ws, double* total) {
-    unsigned long long sum = 0ull;
-    bool ok = true;
-    for (int i = threadIdx.x & 63; i < ws.n_pw; i += 64) {
-        const unsigned int x = __hip_atomic_load(ws.pslot + i, BXI_RLX, BXI_AGENT);
-        ok &= (x >> 31) != 0u;
-        sum += x & 0x7fffffffu;
-    }
-    *total = wave_total_f64((double)sum);                               // exact: integers far below 2^53
-    return __all(ok);
+// One round over the count words: true when every predicate wave has arrived; then *total = sum W over all instances.
+__device__ __forceinline__ bool counts_complete(const Ws& ws, int n_items, double* total) {
+    const unsigned long long x = __hip_atomic_load(&ws.acc1[(size_t)(threadIdx.x & 63) * kAcc2Stride], BXI_RLX, BXI_AGENT);
+    const int arrived = wave_total_i32((int)(x >> 40));
+    *total = wave_total_f64((double)(x & ((1ull << 40) - 1ull)));       // exact: integers far below 2^53
+    return arrived == n_items;
 }
 // thresh <= 0: every pair (padded ones too) weighs 1 (:1324), sum W = 8 x the box areas; no predicate waves then
 __device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, const Ws& ws) {
@@ -716,7 +715,7 @@ __device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, cons
 // computed; and, before the gradient goes out, sum W (the global normaliser, :1327-1328) = every predicate wave's arrival.  The
 // predicate waves precede the tile waves in the grid and never wait; by the time a tile wave asks they are normally done.
 template <int D, int R>
-__device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float upw_warm, float n2max, int zero_bit, long long& acc_fx,
+__device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float upw_warm, float n2max, int zero_bit, int n_items,
                                           float& scale, bool& have_scale, float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
                                           int tix) {
     constexpr int RD = TG<D, R>::RD;
@@ -758,14 +757,9 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
                     all &= pbyte[i];
                 }
                 if (__all(all != 0u)) { ok = true; break; }
-                __builtin_amdgcn_s_sleep(16);        // ~0.4 us: a few hundred waves may be asking
+                __builtin_amdgcn_s_sleep(8);
             }
             if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
-            // sum W now, if every predicate wave happens to be done already (normally): nothing to ask for after the pair loop then
-            if (!have_scale) {
-                double tw;
-                if (slots_sum(ws, &tw)) { scale = upw_warm / fmaxf((float)tw, 1.f); have_scale = true; }
-            }
 #pragma unroll
             for (int i = 0; i < R + D; ++i)
 #pragma unroll
@@ -821,15 +815,15 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     }
     BXI_TW(1, tix, 5);
     num = wave_total_f32(num);
-    const long long fx = (long long)(num * kNumScale);
+    const long long fx = (long long)(num * kNumScale) + (1ll << 24);           // + 1.0: keeps the packed field non-negative
     if (!have_scale) {           // wave-uniform; once per wave
         double total_w = 0.0;
         if (zero_bit) total_w = total_weight_all_pairs(a, ws);
         else {
             bool ok = false;
-            for (unsigned spins = 0; !ok && spins <= kSpinLimit; ++spins) {
-                if (slots_sum(ws, &total_w)) { ok = true; break; }
-                __builtin_amdgcn_s_sleep(16);
+            for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {
+                if (counts_complete(ws, n_items, &total_w)) { ok = true; break; }
+                __builtin_amdgcn_s_sleep(8);
             }
             if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
         }
@@ -846,7 +840,10 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
         }
     }
     BXI_TW(1, tix, 6);
-    acc_fx += fx;            // this tile's share of sum W pw: goes out with the wave's slot
+    // this tile's share of sum W pw + its arrival: one atomic without return; the wave does not wait for it
+    if (lane == 0)
+        __hip_atomic_fetch_add(acc2_word(ws.acc2, n, t.tile_r0 / R + t.tile_c0 / TG<D, R>::TW), (1ull << 52) + (unsigned long long)fx, BXI_RLX, BXI_AGENT);
+    BXI_TW(1, tix, 7);
 }
 
 __device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
@@ -966,8 +963,6 @@ __device__ __forceinline__ Tile tile_of(const int4& e, int D, int R, int TW, int
     return t;
 }
 
-// The finisher's round over instances [b0, b0 + 64): arrivals and sums of every tile (8 words per instance, arrival count and
-// sum in one word) and the leaders' dice losses, requested together.  Returns whether all are complete; adds their sums.
 // The finisher's rounds.  Leaders: the dice losses of instances [b0, b0 + 64) (self-flagging words).
 __device__ __forceinline__ bool dice_round(const Ws& ws, int N, int b0, float* dsum) {
     const int lane = threadIdx.x & 63, i = b0 + lane;
@@ -1012,7 +1007,7 @@ __device__ __forceinline__ Tile locate_tile(const Ws& ws, int N, const int4& e0,
 // never waiting themselves), the finisher for everybody (nobody waits for it).  Every wait is bounded, and running out of it is
 // loud: NaN losses, status word, poisoned gradient (the reference surfaces launch failures through AT_CUDA_CHECK, pairwise.cu:173,200).
 template <int D, int R>
-__global__ __launch_bounds__(256, (R <= 6 ? 3 : 2)) void pair3_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
+__global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
                                                        float n2max, int zero_bit, int n_pb, int n_items, ValidCells vc, float* __restrict__ losses,
                                                        float* __restrict__ g_logits, InstArgs a, Ws ws, LossState st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1029,11 +1024,8 @@ __global__ __launch_bounds__(256, (R <= 6 ? 3 : 2)) void pair3_kernel(const floa
         if (zero_bit) return;                                          // every pair weighs 1: sum W has a closed form, the tiles take the log-space path
         const int segs = (a.w + 63) >> 6, pid = (blk - N) * kWaves + wave;
         BXI_TW(2, pid, 0);
-        __builtin_amdgcn_s_setprio(3);                                 // the tile waves will ask for these bytes
-        int cnt = 0;
-        for (int item = pid; item < n_items; item += n_pb * kWaves) cnt += pred_item(a, vc, ws, D, n2max, item, segs);
-        cnt = wave_total_i32(cnt);
-        if (lane == 0) __hip_atomic_store(ws.pslot + pid, 0x80000000u | (unsigned int)cnt, BXI_RLX, BXI_AGENT);   // written once, through
+        __builtin_amdgcn_s_setprio(3);                                 // short, and the tile waves will ask for these bytes
+        for (int item = pid; item < n_items; item += n_pb * kWaves) pred_item(a, vc, ws, D, n2max, item, segs);
         BXI_TW(2, pid, 1);
         return;
     }
@@ -1041,6 +1033,7 @@ __global__ __launch_bounds__(256, (R <= 6 ? 3 : 2)) void pair3_kernel(const floa
         // waits only for workgroups that never wait for it: the leaders and the predicate waves (done early), then the tile waves
         BXI_TW(3, 0, 0);
         __shared__ double fin_d[kWaves];
+        __shared__ int fin_i[kWaves];
         __shared__ float fin_f;
         __shared__ int fin_ok;
         bool ok = true;
@@ -1056,7 +1049,7 @@ __global__ __launch_bounds__(256, (R <= 6 ? 3 : 2)) void pair3_kernel(const floa
             }
             if (zero_bit) total_w = total_weight_all_pairs(a, ws);
             else
-                while (ok && !slots_sum(ws, &total_w)) {
+                while (ok && !counts_complete(ws, n_items, &total_w)) {
                     if (++spins > kSpinLimit) ok = false;
                     __builtin_amdgcn_s_sleep(8);
                 }
@@ -1064,18 +1057,25 @@ __global__ __launch_bounds__(256, (R <= 6 ? 3 : 2)) void pair3_kernel(const floa
         }
         __syncthreads();
         ok = fin_ok != 0; dsum = fin_f; total_w = fin_d[0];
+        const int ntiles = __builtin_amdgcn_readfirstlane(ws.tab[N].x);
         __syncthreads();
-        // every thread watches its own tile-wave slots (n_tw / 256 each): the launch ends on this loop
+        // every thread watches its own arrival words (N * 8 / 256 each: one at the headline size); the launch ends on this loop
         long long mine = 0;
+        spins = 0;
         for (;;) {
             mine = 0;
-            bool have = true;
-            for (int i = threadIdx.x; i < ws.n_tw; i += 256) {
-                const unsigned long long x = __hip_atomic_load(ws.tslot + i, BXI_RLX, BXI_AGENT);
-                have &= (x >> 63) != 0ull;
-                mine += (long long)(x & ~(1ull << 63));
+            int arrived = 0;
+            for (int i = threadIdx.x; i < N * kAcc2Split; i += 256) {
+                const unsigned long long x = __hip_atomic_load(ws.acc2 + (size_t)i * kAcc2Stride, BXI_RLX, BXI_AGENT);
+                arrived += (int)(x >> 52);
+                mine += (long long)(x & ((1ull << 52) - 1ull)) - ((long long)(x >> 52) << 24);       // the +1 per tile
             }
-            if (__syncthreads_and(have ? 1 : 0)) break;
+            arrived = wave_total_i32(arrived);
+            if (lane == 0) fin_i[wave] = arrived;
+            __syncthreads();
+            const bool all = (fin_i[0] + fin_i[1]) + (fin_i[2] + fin_i[3]) == ntiles;
+            __syncthreads();
+            if (all) break;
             if (++spins > kSpinLimit) { ok = false; break; }           // workgroup-uniform: the same count in every thread
         }
         const double wsum = wave_total_f64((double)mine);                // exact; fixed order: run-to-run identical
@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(256, (R <= 6 ? 3 : 2)) void pair3_kernel(const floa
         __syncthreads();
         if (threadIdx.x >= 64) return;
         const double num = (fin_d[0] + fin_d[1]) + (fin_d[2] + fin_d[3]);
-        const unsigned int fault = __hip_atomic_load(ws.fault, BXI_RLX, BXI_AGENT);   // set by a tile wave BEFORE its slot, if at all
+        const unsigned int fault = __hip_atomic_load(ws.fault, BXI_RLX, BXI_AGENT);   // set by a tile wave BEFORE its arrival, if at all
         const unsigned int status = (unsigned int)__builtin_amdgcn_readfirstlane((int)(fault | (ok ? 0u : kFaultFinisher)));
         if (lane == 0) {
             const float denom = fmaxf((float)total_w, 1.f);                      // weights.sum().clamp(min=1.0), :1328
@@ -1098,6 +1098,7 @@ __global__ __launch_bounds__(256, (R <= 6 ? 3 : 2)) void pair3_kernel(const floa
         return;
     }
     const int wid = (blk - N - n_pb) * kWaves + wave, nwaves = ((int)gridDim.x - 1 - N - n_pb) * kWaves;
+    __builtin_amdgcn_s_setprio(2);                                     // the launch ends on the tile waves, not on the leaders next to them
     BXI_TW(1, wid, 0);
     int4 e0 = make_int4(0, 0, 0, 0);
     if (lane <= N) e0 = ws.tab[lane];
@@ -1105,15 +1106,11 @@ __global__ __launch_bounds__(256, (R <= 6 ? 3 : 2)) void pair3_kernel(const floa
     float* gbuf = reinterpret_cast<float*>(smem) + wave * ((R + 1) * 64);
     float scale = 0.f;
     bool have_scale = false;
-    long long acc_fx = 0;
     for (int ti = wid; ti < total; ti += nwaves) {
         const Tile t = locate_tile<D, R>(ws, N, e0, ti, a.h, a.w);
         BXI_TW(1, wid, 1);
-        math_tile<D, R>(a, ws, t, upw * warmup, n2max, zero_bit, acc_fx, scale, have_scale, g_logits, gbuf, wid);
+        math_tile<D, R>(a, ws, t, upw * warmup, n2max, zero_bit, n_items, scale, have_scale, g_logits, gbuf, wid);
     }
-    // this wave's share of sum W pw, and the sign that it is done (EVERY tile-role wave writes its slot, once)
-    if (lane == 0) __hip_atomic_store(ws.tslot + wid, (1ull << 63) | (unsigned long long)acc_fx, BXI_RLX, BXI_AGENT);
-    BXI_TW(1, wid, 7);
 }
 
 // ---- rescale: g_logits finished for the factors recorded in `state` -> finished for (g_prj, g_pw) ----------------
@@ -1279,39 +1276,9 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     static const int env_pool_first = env_int("BXI_POOL_FIRST", 1);
     static const int env_pool_wgs = env_int("BXI_POOL_WGS_PER_CU", 5);
     if (!force_rows) force_rows = env_rows;
-    const int R = force_rows == 4 || force_rows == 5 || force_rows == 6 || force_rows == 8 ? force_rows : tile_rows_for(a.N);
+    const int R = force_rows == 4 || force_rows == 8 ? force_rows : tile_rows_for(a.N);
     if (eval_cap(a.N, a.h, a.w, dil, R) >= (1 << 24)) return BXI_ERR_BAD_SHAPE;     // the table packs a tile prefix into 24 bits
     const HostPred pr = host_pred(color_thresh);
-
-    const int64_t n_items64 = (int64_t)batch->B * a.h * ((a.w + 63) / 64);
-    if (n_items64 > 0x7fffffffLL) return BXI_ERR_BAD_SHAPE;
-    const int n_items = (int)n_items64;
-    // launch 2's geometry (the table waves of launch 1 clear one slot per predicate / tile wave)
-    const int64_t cap = eval_cap(a.N, a.h, a.w, dil, R);
-    int64_t n_tb = (cap + kWaves - 1) / kWaves;
-    // the tile list's length is device data: the tile waves stride through it.  The launch should be resident in one round:
-    // 3 (R <= 6: <= 168 VGPRs) or 2 (R = 8) workgroups per CU; the predicate waves are short-lived.
-    static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 0);
-    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R <= 6 ? 3 : 2);
-    int slots = occ * device_cus() - a.N - 1;
-    if (slots > 2 * (kMaxSlots / kWaves)) slots = 2 * (kMaxSlots / kWaves);
-    int n_pb = (n_items + kWaves - 1) / kWaves;
-    if (n_pb > slots / 2) n_pb = slots / 2 > 1 ? slots / 2 : 1;
-    if (n_tb > slots - n_pb) n_tb = slots - n_pb > 64 ? slots - n_pb : 64;
-    if (n_pb * kWaves > kMaxSlots || n_tb * kWaves > kMaxSlots) return BXI_ERR_UNSUPPORTED;
-    ws.n_pw = n_pb * kWaves; ws.n_tw = (int)n_tb * kWaves;
-    size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
-    const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
-    if (lds2 < lds_leader) lds2 = lds_leader;
-    if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
-    const int grid = a.N + n_pb + (int)n_tb + 1;          // leaders + predicate blocks + tile blocks + the finisher
-    ValidCells vc = {};
-    for (int b = 0; b < batch->B; ++b) {                  // the device formula (valid_cells), evaluated here once per image
-        const int half = a.stride / 2;
-        auto cells = [&](int limit, int n) { const int v = limit - half <= 0 ? 0 : (limit - half + a.stride - 1) / a.stride; return v < n ? v : n; };
-        vc.vrow[b] = cells(pa.meta.img_h[b] < pa.meta.first_removed[b] ? pa.meta.img_h[b] : pa.meta.first_removed[b], a.h);
-        vc.vcol[b] = cells(pa.meta.img_w[b], a.w);
-    }
 
     // ---- launch 1 --------------------------------------------------------------------------------------------------
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
@@ -1319,6 +1286,9 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     const int n_stream = a.N * Sn;
     // one item = the 4 input rows of 64 pooled pixels.  The whole launch should be resident at once (5 workgroups per CU at
     // <= 96 VGPRs): a pool workgroup takes several items, the next one's loads in flight, when it is not.
+    const int64_t n_items64 = (int64_t)batch->B * a.h * ((a.w + 63) / 64);
+    if (n_items64 > 0x7fffffffLL) return BXI_ERR_BAD_SHAPE;
+    const int n_items = (int)n_items64;
     const int room = env_pool_wgs * device_cus() - n_tab - (head ? 0 : n_stream);
     const int per = room > 0 ? (n_items + room - 1) / room : 8;
     const int n_pool = pooled_in_launch ? (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per) : 0;
@@ -1363,11 +1333,31 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     }
 
     // ---- launch 2 --------------------------------------------------------------------------------------------------
+    const int64_t cap = eval_cap(a.N, a.h, a.w, dil, R);
+    int64_t n_tb = (cap + kWaves - 1) / kWaves;
+    // the tile list's length is device data: the tile waves stride through it.  The launch should be resident in one round:
+    // 4 (R = 4: <= 128 VGPRs) or 2 (R = 8) workgroups per CU; the predicate waves are short-lived.
+    static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 0);
+    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? (dil <= 3 ? 4 : 3) : 2);
+    const int slots = occ * device_cus() - a.N - 1;
+    int n_pb = (n_items + kWaves - 1) / kWaves;
+    if (n_pb > slots / 2) n_pb = slots / 2 > 1 ? slots / 2 : 1;
+    if (n_tb > slots - n_pb) n_tb = slots - n_pb > 64 ? slots - n_pb : 64;
+    size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
+    const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
+    if (lds2 < lds_leader) lds2 = lds_leader;
+    if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
+    const int grid = a.N + n_pb + (int)n_tb + 1;          // leaders + predicate blocks + tile blocks + the finisher
+    ValidCells vc = {};
+    for (int b = 0; b < batch->B; ++b) {                  // the device formula (valid_cells), evaluated here once per image
+        const int half = a.stride / 2;
+        auto cells = [&](int limit, int n) { const int v = limit - half <= 0 ? 0 : (limit - half + a.stride - 1) / a.stride; return v < n ? v : n; };
+        vc.vrow[b] = cells(pa.meta.img_h[b] < pa.meta.first_removed[b] ? pa.meta.img_h[b] : pa.meta.first_removed[b], a.h);
+        vc.vcol[b] = cells(pa.meta.img_w[b], a.w);
+    }
 #define BXI_PAIR_CASE(DD)                                                                                                                  \
     case DD:                                                                                                                               \
         if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw); \
-        else if (R == 5) launch_pair<DD, 5>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw); \
-        else if (R == 6) launch_pair<DD, 6>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw); \
         else launch_pair<DD, 8>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw);        \
         break;
     switch (dil) {

@@ -72,7 +72,7 @@ print('  leaders', len(ld), 'start', q(us(ld[:, 0] - k0)), '| loads+maxima', qd(
 print('  predicate waves', len(cw), 'start', q(us(cw[:, 0] - k0)), '| segment(s) done', qd(cw[:, 1], cw[:, 0]), '| end', q(us(cw[:, 1] - k0)))
 print('  tile waves with a tile', len(mw), 'of', len(allm), 'start', q(us(mw[:, 0] - k0)), '| table -> tile', qd(mw[:, 1], mw[:, 0]), '| logits + per-pixel', qd(mw[:, 2], mw[:, 1]),
       '| predicate bytes + masks', qd(mw[:, 3], mw[:, 2]), '| pair math', qd(mw[:, 5], mw[:, 3]), '| sum W', qd(mw[:, 4], mw[:, 5]),
-      '| adds issued', qd(mw[:, 6], mw[:, 4]), '| slot written', qd(mw[:, 7], mw[:, 6]), '| bytes asked for at', q(us(mw[:, 2] - k0)), '| math done at', q(us(mw[:, 5] - k0)),
+      '| adds issued', qd(mw[:, 6], mw[:, 4]), '| arrival issued', qd(mw[:, 7], mw[:, 6]), '| bytes asked for at', q(us(mw[:, 2] - k0)), '| math done at', q(us(mw[:, 5] - k0)),
       '| end', q(us(mw[:, 7] - k0)))
 fw = t[3][0]
 print('  finisher: start %.2f end %.2f' % (us(fw[0] - k0), us(fw[1] - k0)))
