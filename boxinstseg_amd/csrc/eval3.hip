@@ -713,10 +713,12 @@ __device__ __forceinline__ bool reduce_slots(const Ws& ws) {
     for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {
         unsigned long long sum = 0ull;
         bool ok = true;
-        for (int i = lane; i < ws.n_pw; i += 64) {
-            const unsigned int x = __hip_atomic_load(ws.pslot + i, BXI_RLX, BXI_AGENT);
-            ok &= (x >> 31) != 0u;
-            sum += x & 0x7fffffffu;
+        for (int i0 = lane; i0 < ws.n_pw; i0 += 64 * 16) {             // sixteen loads in flight per lane (a loop of load -> use
+            unsigned int x[16];                                        // would make one round trip per slot)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = i0 + 64 * u < ws.n_pw ? __hip_atomic_load(ws.pslot + i0 + 64 * u, BXI_RLX, BXI_AGENT) : 0x80000000u;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { ok &= (x[u] >> 31) != 0u; sum += x[u] & 0x7fffffffu; }
         }
         if (__all(ok)) {
             const double tot = wave_total_f64((double)sum);              // exact

@@ -13,6 +13,7 @@ Reference interfaces mirrored (``condinst_head.py`` = ``mmdet/models/dense_heads
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -166,14 +167,15 @@ def box_bitmasks(gt_bboxes: Sequence[torch.Tensor], Hc: int, Wc: int, stride: in
 # loss
 # ------------------------------------------------------------------------------------------------
 class _EvalPlan:
-    """Everything about one evaluation that depends on shapes / metadata only, marshalled once: the two C structs,
-    their host arrays, and the (per stream) workspace.  A call then only patches five device pointers."""
+    """The two C structs of an evaluation and their host arrays, marshalled once per SHAPE CLASS -- (device, batch size, canvas,
+    stride, number of box lists, img_norm_cfg) -- and patched per call with everything a training iteration changes: image
+    shapes, rows removed, box counts, instance count, pointers.  (Real COCO iterations change all of those every step.)"""
 
-    def __init__(self, dev, stream, B, Hc, Wc, stride, N, h, w, img_h, img_w, rows_rm, mean, std, to_rgb, counts):
+    def __init__(self, B, Hc, Wc, stride, n_lists, mean, std, to_rgb):
         lib = _lib.load()
-        self._h, self._w, self._rm = _lib.int_array(img_h), _lib.int_array(img_w), _lib.int_array(rows_rm)
-        self._cnt = _lib.int_array(counts)
-        self._ptrs = _lib.ptr_array([0] * max(len(counts), 1))
+        self._h, self._w, self._rm = _lib.int_array([0] * B), _lib.int_array([0] * B), _lib.int_array([0] * B)
+        self._cnt = _lib.int_array([0] * n_lists)
+        self._ptrs = _lib.ptr_array([0] * max(n_lists, 1))
         b = _lib.ImageBatch()
         b.B, b.Hc, b.Wc = B, Hc, Wc
         b.img_h_host = C.cast(self._h, C.POINTER(C.c_int))
@@ -184,23 +186,43 @@ class _EvalPlan:
         b.to_rgb = int(to_rgb)
         b.image_masks = 0
         s = _lib.Instances()
-        s.N, s.h, s.w = N, h, w
+        s.h, s.w = Hc // stride, Wc // stride
         s.boxes_per_img_host = C.cast(self._ptrs, C.POINTER(C.c_void_p))
         s.gt_count_host = C.cast(self._cnt, C.POINTER(C.c_int))
-        s.B = len(counts)
+        s.B = n_lists
         s.Hc, s.Wc, s.stride = Hc, Wc, stride
         self.batch, self.inst = b, s
         self.batch_ref, self.inst_ref = C.byref(b), C.byref(s)
-        self.ws = torch.empty(max(lib.bxi_boxinst_eval_workspace_bytes(B, Hc, Wc, stride, N), 256), dtype=torch.uint8,
-                              device=dev)
-        self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), self.ws.numel()
-        self.state_bytes = (max(lib.bxi_boxinst_loss_state_bytes(N, h, w), 256) + 255) // 256 * 256
-        self.grad_elems = N * h * w
+        self.B, self.stride = B, stride
         self.eval = lib.bxi_boxinst_eval_f32
         self.rescale = lib.bxi_boxinst_grad_rescale_f32
+        self.ws = None                      # the workspace of the last call (tests look at it)
+
+    def patch(self, img_metas, bottom_pixels_removed: int, N: int, boxes) -> None:
+        h_, w_, rm_ = self._h, self._w, self._rm
+        for i, m in enumerate(img_metas):
+            shp = m['img_shape']
+            h_[i], w_[i] = shp[0], shp[1]
+            rm_[i] = int(bottom_pixels_removed * float(shp[0]) / float(m['ori_shape'][0]))     # condinst_head.py:1358-1361
+        cnt, ptrs = self._cnt, self._ptrs
+        for i, b in enumerate(boxes):
+            n = b.shape[0] if b.dim() == 2 else b.numel() // 4
+            cnt[i] = n
+            ptrs[i] = b.data_ptr() if n else 0
+        self.inst.N = N
 
 
-_PLANS: Dict[tuple, _EvalPlan] = {}
+class _Local(threading.local):
+    """Per host thread (one per device in the reference's launcher): plans are mutated per call, workspaces are in flight."""
+
+    def __init__(self):
+        self.plans: Dict[tuple, _EvalPlan] = {}
+        self.workspaces: Dict[tuple, torch.Tensor] = {}
+        self.sizes: Dict[tuple, Tuple[int, int]] = {}
+
+
+_TLS = _Local()
+_MAX_PLANS = 32
 DEBUG_KEEP_LAST = False          # tests: keep the last evaluation's buffer so that its status word can be read
 _LAST: Dict[str, object] = {}
 
@@ -215,6 +237,29 @@ def last_eval_status() -> Tuple[int, int]:
     return int(v[0]), int(v[1])
 
 
+def _workspace(dev: torch.device, stream: int, need: int) -> torch.Tensor:
+    """One grow-only workspace per (device, stream): evaluations on a stream are serialised, so they can share it; a larger
+    need replaces it (the old buffer goes back to the caching allocator, which keeps it alive for the work already queued)."""
+    key = (dev.index, stream)
+    ws = _TLS.workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _TLS.workspaces[key] = torch.empty(max(need + need // 4, 256), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def _sizes(N: int, h: int, w: int, B: int, Hc: int, Wc: int, stride: int) -> Tuple[int, int]:
+    """(state bytes rounded to 256, workspace bytes) -- two C calls, cached per shape."""
+    key = (N, h, w, B, Hc, Wc, stride)
+    v = _TLS.sizes.get(key)
+    if v is None:
+        lib = _lib.load()
+        if len(_TLS.sizes) > 4096:
+            _TLS.sizes.clear()
+        v = _TLS.sizes[key] = ((max(lib.bxi_boxinst_loss_state_bytes(N, h, w), 256) + 255) // 256 * 256,
+                               max(lib.bxi_boxinst_eval_workspace_bytes(B, Hc, Wc, stride, N), 256))
+    return v
+
+
 def _eval_plan(imgs, img_metas, mask_logits, gt_bboxes, stride: int, bottom_pixels_removed: int, stream: int) -> _EvalPlan:
     if imgs.dim() != 4 or imgs.size(1) != 3:
         raise RuntimeError(f'imgs must be [B,3,H,W], got {tuple(imgs.shape)}')
@@ -222,32 +267,32 @@ def _eval_plan(imgs, img_metas, mask_logits, gt_bboxes, stride: int, bottom_pixe
         raise RuntimeError(f'mask_logits must be [N,1,h,w], got {tuple(mask_logits.shape)}')
     B, _, Hc, Wc = imgs.shape
     N, _, h, w = mask_logits.shape
+    if len(img_metas) != B:
+        raise RuntimeError(f'{B} images but {len(img_metas)} img_metas')
+    if h * stride != Hc or w * stride != Wc:
+        raise RuntimeError(f'mask_logits {h}x{w} x stride {stride} != image canvas {Hc}x{Wc}')
     cfg = img_metas[0]['img_norm_cfg'] if B else None
-    key = (imgs.device.index, stream, B, Hc, Wc, stride, N, h, w, bottom_pixels_removed,
-           tuple((m['img_shape'][0], m['img_shape'][1], m['ori_shape'][0]) for m in img_metas),
-           None if cfg is None else (tuple(float(v) for v in cfg['mean']), tuple(float(v) for v in cfg['std']), bool(cfg['to_rgb'])),
-           tuple(int(b.shape[0]) if b.dim() == 2 else b.numel() // 4 for b in gt_bboxes))
-    plan = _PLANS.get(key)
+    for m in img_metas[1:]:
+        c2 = m['img_norm_cfg']
+        if c2 is not cfg and (list(c2['mean']) != list(cfg['mean']) or list(c2['std']) != list(cfg['std']) or
+                              bool(c2['to_rgb']) != bool(cfg['to_rgb'])):
+            raise RuntimeError('all images of a batch must share img_norm_cfg')
+    norm = None if cfg is None else (tuple(float(v) for v in cfg['mean']), tuple(float(v) for v in cfg['std']), bool(cfg['to_rgb']))
+    key = (imgs.device.index, B, Hc, Wc, stride, len(gt_bboxes), norm)
+    plans = _TLS.plans
+    plan = plans.get(key)
     if plan is None:
         if B > _lib.BXI_MAX_IMAGES or len(gt_bboxes) > _lib.BXI_MAX_IMAGES:
             raise RuntimeError(f'at most {_lib.BXI_MAX_IMAGES} images per call, got {B}')
-        if len(img_metas) != B:
-            raise RuntimeError(f'{B} images but {len(img_metas)} img_metas')
-        if h * stride != Hc or w * stride != Wc:
-            raise RuntimeError(f'mask_logits {h}x{w} x stride {stride} != image canvas {Hc}x{Wc}')
-        for m in img_metas[1:]:
-            c2 = m['img_norm_cfg']
-            if list(c2['mean']) != list(cfg['mean']) or list(c2['std']) != list(cfg['std']) or \
-                    bool(c2['to_rgb']) != bool(cfg['to_rgb']):
-                raise RuntimeError('all images of a batch must share img_norm_cfg')
-        mean, std, to_rgb = key[11] if cfg is not None else ((0.0,) * 3, (1.0,) * 3, True)
-        if len(_PLANS) > 64:
-            _PLANS.clear()
-        plan = _PLANS[key] = _EvalPlan(
-            imgs.device, stream, B, Hc, Wc, stride, N, h, w, [m['img_shape'][0] for m in img_metas],
-            [m['img_shape'][1] for m in img_metas],
-            [rows_removed(bottom_pixels_removed, m['img_shape'], m['ori_shape']) for m in img_metas], mean, std, to_rgb,
-            key[12])
+        mean, std, to_rgb = norm if norm is not None else ((0.0,) * 3, (1.0,) * 3, True)
+        if len(plans) >= _MAX_PLANS:
+            plans.pop(next(iter(plans)))            # the oldest entry; nothing is in flight on a plan (host arrays only)
+        plan = plans[key] = _EvalPlan(B, Hc, Wc, stride, len(gt_bboxes), mean, std, to_rgb)
+    plan.patch(img_metas, bottom_pixels_removed, N, gt_bboxes)
+    plan.state_bytes, ws_bytes = _sizes(N, h, w, B, Hc, Wc, stride)
+    plan.grad_elems = N * h * w
+    plan.ws = _workspace(imgs.device, stream, ws_bytes)
+    plan.ws_ptr, plan.ws_bytes = plan.ws.data_ptr(), plan.ws.numel()
     return plan
 
 
@@ -308,8 +353,6 @@ class BoxInstMaskLoss(torch.autograd.Function):
         plan.batch.imgs = imgs.data_ptr()
         plan.inst.logits = x.data_ptr()
         plan.inst.gt_inds = gi.data_ptr()
-        for i, b in enumerate(boxes):
-            plan._ptrs[i] = b.data_ptr() if b.numel() else 0
         grad = None
         if need_grad:
             grad = buf[256 + plan.state_bytes:].view(torch.float32).view(x.shape)
@@ -323,7 +366,8 @@ class BoxInstMaskLoss(torch.autograd.Function):
         if DEBUG_KEEP_LAST:
             _LAST.clear()
             _LAST.update(buf=buf, plan=plan, need_grad=need_grad)
-        return losses, grad, base + 256, plan, (imgs, x, gi, boxes, buf)
+        # the plan is shared by every evaluation of its shape class: backward() binds it again from what is kept here
+        return losses, grad, base + 256, plan, (imgs, x, gi, boxes, buf, ctx.metas, int(cfg['bottom_pixels_removed']))
 
     @staticmethod
     def _forward_bits(ctx, mask_logits, gt_inds, gt_bboxes, cfg, affinity_bits, need_grad):
@@ -364,11 +408,14 @@ class BoxInstMaskLoss(torch.autograd.Function):
             ctx.grad = None
         ctx.calls += 1
         dev = grad.device
-        if plan.inst.N > 0:
+        if grad.numel() > 0:
             if g_prj.dtype != torch.float32 or g_prj.device != dev:
                 g_prj = g_prj.to(device=dev, dtype=torch.float32)
             if g_pw.dtype != torch.float32 or g_pw.device != dev:
                 g_pw = g_pw.to(device=dev, dtype=torch.float32)
+            _, x, gi, boxes, _, metas, bpr = keep
+            plan.patch(metas, bpr, x.size(0), boxes)             # another evaluation of the same shape class may have come in between
+            plan.inst.logits, plan.inst.gt_inds = x.data_ptr(), gi.data_ptr()
             with torch.cuda.device(dev):
                 _lib.check('bxi_boxinst_grad_rescale_f32', plan.rescale(
                     plan.inst_ref, g_prj.data_ptr(), g_pw.data_ptr(), int(ctx.cfg['pairwise_dilation']), state,
@@ -427,8 +474,6 @@ class HeadBoxInstLoss(torch.autograd.Function):
         plan.batch.imgs = imgs_c.data_ptr()
         plan.inst.logits = logits.data_ptr()
         plan.inst.gt_inds = gi.data_ptr()
-        for i, b in enumerate(boxes):
-            plan._ptrs[i] = b.data_ptr() if b.numel() else 0
         with torch.cuda.device(dev):
             _lib.check('bxi_boxinst_head_eval_f32', _lib.load().bxi_boxinst_head_eval_f32(
                 plan.batch_ref, plan.inst_ref, feat_c.data_ptr(), Cf, Hs, Ws, params_c.data_ptr(), coors_c.data_ptr(),
@@ -439,7 +484,7 @@ class HeadBoxInstLoss(torch.autograd.Function):
         losses = buf[:8].view(torch.float32)
         ctx.save_for_backward(feat_c, params_c, coors_c, lvl, img, soi)
         ctx.grad = buf[256 + plan.state_bytes:].view(torch.float32).view(logits.shape)
-        ctx.state, ctx.plan, ctx.keep = base + 256, plan, (imgs_c, gi, boxes, buf)
+        ctx.state, ctx.plan, ctx.keep = base + 256, plan, (imgs_c, gi, boxes, buf, img_metas, int(cfg['bottom_pixels_removed']), logits)
         ctx.head_cfg, ctx.dil, ctx.need_grad = (int(in_stride), int(factor), int(bool(no_rel))), int(cfg['pairwise_dilation']), need_grad
         ctx.dtypes = (feat.dtype, params.dtype)
         ctx.mark_non_differentiable(logits) if not need_grad else None
@@ -464,6 +509,9 @@ class HeadBoxInstLoss(torch.autograd.Function):
         g_feat, g_params = torch.empty_like(feat), torch.empty_like(params)
         ws = torch.empty(max(lib.bxi_dynamic_mask_backward_workspace_bytes(B, Cf, Hs, Ws, N, no_rel), 256), dtype=torch.uint8,
                          device=dev)
+        _, gi_k, boxes_k, _, metas_k, bpr_k, logits_k = ctx.keep
+        plan.patch(metas_k, bpr_k, N, boxes_k)                  # another evaluation of the same shape class may have come in between
+        plan.inst.logits, plan.inst.gt_inds = logits_k.data_ptr(), gi_k.data_ptr()
         with torch.cuda.device(dev):
             _lib.check('bxi_boxinst_grad_rescale_f32', plan.rescale(plan.inst_ref, g_prj.data_ptr(), g_pw.data_ptr(), ctx.dil,
                                                                      ctx.state, grad.data_ptr(), stream))
