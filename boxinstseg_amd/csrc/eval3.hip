@@ -49,8 +49,8 @@ constexpr int kSBlk = kWaves * kSRows;          // rows per stream workgroup
 constexpr int kChunkC = 256;                    // columns per pass of a stream wave: 64 lanes x float4
 constexpr int kMaxDilFused = 4;
 constexpr unsigned kSpinLimit = 400000;         // bounded waits (~0.3 us per poll): far beyond any launch; running out is loud (NaN losses)
-constexpr int kAcc2Split = 16, kAcc2Stride = 16; // tile arrivals: sixteen words per instance, each in its own 128 bytes
-constexpr int kMaxPredWaves = 8192;             // one slot per predicate wave
+constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
+constexpr int kAcc1Words = 64;                  // count-wave arrivals + sum W: 64 words, each in its own 128 bytes
 constexpr int kMaxInst = 65536;
 constexpr unsigned kFaultCounts = 1u, kFaultFinisher = 2u;
 
@@ -83,9 +83,7 @@ struct Ws {
     int n_cb, n_rp;
     int4* tab;                                  // [N+1] {tile prefix | img << 24, r0 | r1 << 16, c0 | c1 << 16, vrow | vcol << 16}; [N].x = tiles
     // words polled inside pair3_kernel; zeroed by prep3_kernel's table waves, i.e. before a kernel boundary
-    unsigned int* pslot;                        // [n_pw] predicate wave: 1 << 31 | its share of sum W (written once, read by ONE reducer wave)
-    unsigned long long* sumw;                   // [1]    reducer: 1 << 63 | sum W (0 = not known yet)
-    int n_pw;                                   // predicate waves of the next launch (set per launch)
+    unsigned long long* acc1;                   // [kAcc1Words] (one per 128 B) predicate waves: arrivals << 40 | sum W
     unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B) tile waves: arrivals << 52 | sum (W pw + 1) in 2^-24 units
     unsigned long long* dice;                   // [N]   leader: 1 << 32 | bits of the instance's dice loss (0 = not published)
     unsigned int* fault;                        // [1]   bit mask of waits that ran out (never expected)
@@ -117,9 +115,7 @@ static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
     t.rowkey = (unsigned long long*)take(8 * (size_t)N1 * h * (rp_max > 1 ? rp_max : 1));
     t.n_cb = (int)Sn; t.n_rp = 1;
     t.tab = (int4*)take(16 * (size_t)(N1 + 1));
-    t.pslot = (unsigned int*)take(4 * (size_t)kMaxPredWaves);
-    t.sumw = (unsigned long long*)take(8);
-    t.n_pw = 0;
+    t.acc1 = (unsigned long long*)take(8 * (size_t)kAcc1Words * kAcc2Stride);
     t.acc2 = (unsigned long long*)take(8 * (size_t)N1 * kAcc2Split * kAcc2Stride);
     t.dice = (unsigned long long*)take(8 * (size_t)N1);
     t.fault = (unsigned int*)take(4);
@@ -189,23 +185,15 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
         ws.tab[m] = make_int4(prefix, 0, 0, 0);
     }
     if (k == 0) {
-        for (int i = lane; i < ws.n_pw; i += 64) ws.pslot[i] = 0u;
-        if (lane == 0) *ws.sumw = 0ull;
+        ws.acc1[(size_t)lane * kAcc2Stride] = 0ull;
         if (lane == 0) { *ws.fault = 0u; if (st.status) { st.status[0] = 0; st.status[1] = R; } }
     }
 }
 
 // ---- role 2: stream block = 4 waves x 8 rows of one instance map ---------------------------------------------------------
 struct LogitRows {
-    const float* L; int w, vec, nt;
-    __device__ __forceinline__ float4 operator()(int r, int c) const {
-        if (vec && nt) {
-            typedef float f4v_ __attribute__((ext_vector_type(4)));
-            const f4v_ t = __builtin_nontemporal_load(reinterpret_cast<const f4v_*>(L + (int64_t)r * w + c));
-            return make_float4(t.x, t.y, t.z, t.w);
-        }
-        return load4(L + (int64_t)r * w, c, w, vec);
-    }
+    const float* L; int w, vec;
+    __device__ __forceinline__ float4 operator()(int r, int c) const { return load4(L + (int64_t)r * w, c, w, vec); }
 };
 
 template <typename Src>
@@ -325,12 +313,7 @@ __device__ __forceinline__ double lab_f(const double* lut, int i, int r8, int g8
     return v > 0.008856 ? cbrt(v) : __dadd_rn(__dmul_rn(7.787, v), 16.0 / 116.0);
 }
 
-typedef float f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 load4_stream(const float* p, bool nt) {      // nt: read once, do not keep in the caches
-    const f4v t = nt ? __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p)) : *reinterpret_cast<const f4v*>(p);
-    return make_float4(t.x, t.y, t.z, t.w);
-}
-__device__ __forceinline__ void pool_load(const PoolArgs& pa, int item, int segs, int h, int w, float4 (&v)[3], bool nt) {
+__device__ __forceinline__ void pool_load(const PoolArgs& pa, int item, int segs, int h, int w, float4 (&v)[3]) {
     const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = seg * 64 + lane;
@@ -340,7 +323,7 @@ __device__ __forceinline__ void pool_load(const PoolArgs& pa, int item, int segs
     if (c < w) {
         const float* base = pa.imgs + (int64_t)b * 3 * plane + (int64_t)(4 * r + wv) * pa.Wc + 4 * c;
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) v[ch] = load4_stream(base + pa.dn.src_ch[ch] * plane, nt);
+        for (int ch = 0; ch < 3; ++ch) v[ch] = *reinterpret_cast<const float4*>(base + pa.dn.src_ch[ch] * plane);
     }
 }
 
@@ -351,16 +334,16 @@ __device__ __forceinline__ float n2_of(float L0, float A0, float B0, float L1, f
 
 // items first, first + step, ... < n_items
 __device__ __forceinline__ void pool_block(const PoolArgs& pa, const Ws& ws, int first, int step, int n_items, double* lut /*[256]*/,
-                                           int* part /*[4][3][64]*/, double* fch /*[3][64]*/, int tix, bool nt) {
+                                           int* part /*[4][3][64]*/, double* fch /*[3][64]*/, int tix) {
     const int h = pa.Hc >> 2, w = pa.Wc >> 2;
     const int segs = (w + 63) >> 6;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float4 v[3], nx[3];
-    pool_load(pa, first, segs, h, w, v, nt);
+    pool_load(pa, first, segs, h, w, v);
     lut[threadIdx.x] = kSrgbLut[threadIdx.x];            // staged while the image loads fly
     for (int item = first; item < n_items; item += step) {
         const bool more = item + step < n_items;         // workgroup-uniform
-        if (more) pool_load(pa, item + step, segs, h, w, nx, nt);
+        if (more) pool_load(pa, item + step, segs, h, w, nx);
         const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
         const int c = seg * 64 + lane;
         const int y = 4 * r + wv;
@@ -418,7 +401,7 @@ __device__ __forceinline__ void pool_block(const PoolArgs& pa, const Ws& ws, int
 
 // grid: [table blocks][pool blocks][stream blocks] (pool_first) or [table][stream][pool]
 __global__ __launch_bounds__(256, 5) void prep3_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, Ws ws, LossState st,
-                                                       float* __restrict__ g_logits, int vec, int pool_first, int flags) {
+                                                       float* __restrict__ g_logits, int vec, int pool_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
     const int Sn = (a.h + kSBlk - 1) / kSBlk;
@@ -438,13 +421,13 @@ __global__ __launch_bounds__(256, 5) void prep3_kernel(PoolArgs pa, int n_pool, 
         const int k = blk * kWaves + (int)(threadIdx.x >> 6);
         if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, ws, st, k);
     } else if (role == 2) {
-        const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec, (flags >> 1) & 1};
+        const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
         stream_block(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);
     } else {
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
         int* part = reinterpret_cast<int*>(fch + 3 * 64);
-        pool_block(pa, ws, idx, n_pool, n_items, lut, part, fch, tix, (flags & 1) != 0);
+        pool_block(pa, ws, idx, n_pool, n_items, lut, part, fch, tix);
     }
     BXI_TW(0, tix, 7);
 }
@@ -470,7 +453,7 @@ __global__ __launch_bounds__(256, 7) void head_prep3_kernel(PoolArgs pa, int n_p
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
         int* part = reinterpret_cast<int*>(fch + 3 * 64);
-        pool_block(pa, ws, blk - n_tab, n_pool, n_items, lut, part, fch, tix, false);
+        pool_block(pa, ws, blk - n_tab, n_pool, n_items, lut, part, fch, tix);
     } else {
         const int tiles_x = (da.W + kYC - 1) / kYC, tiles_y = (da.H + kYR - 1) / kYR;
         int t = blk - n_tab - n_pool;
@@ -647,8 +630,8 @@ __device__ __forceinline__ void load_plane(const float* __restrict__ plane, cons
 //   0: (r, c) - (r, c+D)    1: (r+D, c) - (r, c+D)    2: (r, c) - (r+D, c)    3: (r, c) - (r+D, c+D)
 // -> one predicate byte per pixel (bit d: squared Lab distance <= n2max, i.e. sim >= thresh for a valid neighbour), and the
 // segment's share of  sum W = sum_n sum_{p in box n} sum_k [sim_k(p) >= thresh]  (:1324-1328): a pair (p, q) weighs
-// [p in box n][q valid] + [q in box n][p valid] for every instance n of the image.  One packed integer atomic per segment
-// (arrival, count).  A byte carries its own "evaluated" bit: a tile wave re-reads the few bytes it needs until they have it.
+// [p in box n][q valid] + [q in box n][p valid] for every instance n of the image (returned per lane; the workgroup arrives
+// once with its total).  A byte carries its own "evaluated" bit: a tile wave re-reads the few bytes it needs until they have it.
 __device__ __forceinline__ float lane_plus_n(float v, int d) {
     int x = __float_as_int(v);
     for (int s = 0; s < d; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
@@ -699,35 +682,12 @@ __device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc
     return cnt;
 }
 
-// sum W, once the reducer wave has added up the predicate waves' slots: ONE word, the same for every asker
-__device__ __forceinline__ bool counts_complete(const Ws& ws, double* total) {
-    const unsigned long long x = __hip_atomic_load(ws.sumw, BXI_RLX, BXI_AGENT);
-    *total = (double)(x & ~(1ull << 63));                               // exact: an integer far below 2^53
-    return (x >> 63) != 0ull;
-}
-// The reducer (one wave of the finisher workgroup): all predicate waves' slots written -> their sum, published.  One reader of
-// the slots, one word for everybody else: no atomics (arrivals on one word are performed one after the other, ~0.15 us each),
-// no crowd reading through the coherent path.
-__device__ __forceinline__ bool reduce_slots(const Ws& ws) {
-    const int lane = threadIdx.x & 63;
-    for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {
-        unsigned long long sum = 0ull;
-        bool ok = true;
-        for (int i0 = lane; i0 < ws.n_pw; i0 += 64 * 16) {             // sixteen loads in flight per lane (a loop of load -> use
-            unsigned int x[16];                                        // would make one round trip per slot)
-#pragma unroll
-            for (int u = 0; u < 16; ++u) x[u] = i0 + 64 * u < ws.n_pw ? __hip_atomic_load(ws.pslot + i0 + 64 * u, BXI_RLX, BXI_AGENT) : 0x80000000u;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) { ok &= (x[u] >> 31) != 0u; sum += x[u] & 0x7fffffffu; }
-        }
-        if (__all(ok)) {
-            const double tot = wave_total_f64((double)sum);              // exact
-            if (lane == 0) __hip_atomic_store(ws.sumw, (1ull << 63) | (unsigned long long)tot, BXI_RLX, BXI_AGENT);
-            return true;
-        }
-        __builtin_amdgcn_s_sleep(4);
-    }
-    return false;
+// One round over the count words: true when every predicate wave has arrived; then *total = sum W over all instances.
+__device__ __forceinline__ bool counts_complete(const Ws& ws, int n_items, double* total) {
+    const unsigned long long x = __hip_atomic_load(&ws.acc1[(size_t)(threadIdx.x & 63) * kAcc2Stride], BXI_RLX, BXI_AGENT);
+    const int arrived = wave_total_i32((int)(x >> 40));
+    *total = wave_total_f64((double)(x & ((1ull << 40) - 1ull)));       // exact: integers far below 2^53
+    return arrived == n_items;
 }
 // thresh <= 0: every pair (padded ones too) weighs 1 (:1324), sum W = 8 x the box areas; no predicate waves then
 __device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, const Ws& ws) {
@@ -860,7 +820,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
         else {
             bool ok = false;
             for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {
-                if (counts_complete(ws, &total_w)) { ok = true; break; }
+                if (counts_complete(ws, n_items, &total_w)) { ok = true; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
             if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
@@ -1040,7 +1000,7 @@ __device__ __forceinline__ Tile locate_tile(const Ws& ws, int N, const int4& e0,
     return tile_of(e, D, R, TG<D, R>::TW, n, ti - (e.x & 0xffffff), h, w);
 }
 
-// grid: [N leaders][n_pb predicate blocks][n_tb tile blocks][finisher]; a predicate / tile block = 4 independent waves striding
+// grid: [n_pb predicate blocks][N leaders][n_tb tile blocks][finisher]; a predicate / tile block = 4 independent waves striding
 // through the pooled row segments / the tile list.  The only waits: a tile wave for the predicate waves (earlier in the grid,
 // never waiting themselves), the finisher for everybody (nobody waits for it).  Every wait is bounded, and running out of it is
 // loud: NaN losses, status word, poisoned gradient (the reference surfaces launch failures through AT_CUDA_CHECK, pairwise.cu:173,200).
@@ -1053,21 +1013,30 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_ke
     const int blk = (int)blockIdx.x, lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int N = a.N;
     const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
-    if (blk < N) {                                                     // ---- leader of instance blk
-        BXI_TW(3, 1 + blk, 0);
-        leader_block(a, D, ws, st, blk, upp, g_logits, smem, red);
-        return;
-    }
-    if (blk < N + n_pb) {                                              // ---- predicate waves
+    if (blk < n_pb) {                                                  // ---- predicate waves: first in the grid, everybody asks for their bytes
         if (zero_bit) return;                                          // every pair weighs 1: sum W has a closed form, the tiles take the log-space path
-        const int segs = (a.w + 63) >> 6, pid = (blk - N) * kWaves + wave;
+        const int segs = (a.w + 63) >> 6, pid = blk * kWaves + wave;
         BXI_TW(2, pid, 0);
         __builtin_amdgcn_s_setprio(3);                                 // short, and the tile waves will ask for these bytes
-        int cnt = 0;
-        for (int item = pid; item < n_items; item += n_pb * kWaves) cnt += pred_item(a, vc, ws, D, n2max, item, segs);
+        int cnt = 0, segments = 0;
+        for (int item = pid; item < n_items; item += n_pb * kWaves) { cnt += pred_item(a, vc, ws, D, n2max, item, segs); ++segments; }
         cnt = wave_total_i32(cnt);
-        if (lane == 0) __hip_atomic_store(ws.pslot + pid, 0x80000000u | (unsigned int)cnt, BXI_RLX, BXI_AGENT);   // once, written through
+        // ONE arrival per workgroup: arrivals on one word are performed one after the other (~0.15 us each), and the tile waves
+        // need the last one
+        __shared__ int pred_cnt[kWaves], pred_seg[kWaves];
+        if (lane == 0) { pred_cnt[wave] = cnt; pred_seg[wave] = segments; }
+        __syncthreads();
+        if (threadIdx.x == 0)    // (segments evaluated, sum W); integer adds commute: run-to-run identical
+            __hip_atomic_fetch_add(&ws.acc1[(size_t)(blk & (kAcc1Words - 1)) * kAcc2Stride],
+                                   ((unsigned long long)(unsigned int)((pred_seg[0] + pred_seg[1]) + (pred_seg[2] + pred_seg[3])) << 40) |
+                                       (unsigned long long)(unsigned int)((pred_cnt[0] + pred_cnt[1]) + (pred_cnt[2] + pred_cnt[3])),
+                                   BXI_RLX, BXI_AGENT);
         BXI_TW(2, pid, 1);
+        return;
+    }
+    if (blk < n_pb + N) {                                              // ---- leader of an instance
+        BXI_TW(3, 1 + blk - n_pb, 0);
+        leader_block(a, D, ws, st, blk - n_pb, upp, g_logits, smem, red);
         return;
     }
     if (blk == (int)gridDim.x - 1) {                                   // ---- finisher
@@ -1081,9 +1050,6 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_ke
         double total_w = 0.0;
         float dsum = 0.f;
         unsigned spins = 0;
-        if (wave == 1 && !zero_bit) {                                   // the reducer: sum W for the tile waves (and for wave 0 below)
-            if (!reduce_slots(ws) && lane == 0) atomicOr(ws.fault, kFaultCounts);
-        }
         if (wave == 0) {
             for (int b0 = 0; b0 < N && ok; b0 += 64) {
                 while (!dice_round(ws, N, b0, &dsum)) {
@@ -1093,7 +1059,7 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_ke
             }
             if (zero_bit) total_w = total_weight_all_pairs(a, ws);
             else
-                while (ok && !counts_complete(ws, &total_w)) {
+                while (ok && !counts_complete(ws, n_items, &total_w)) {
                     if (++spins > kSpinLimit) ok = false;
                     __builtin_amdgcn_s_sleep(8);
                 }
@@ -1318,41 +1284,11 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
                      (!g_logits || (reinterpret_cast<uintptr_t>(g_logits) & 15) == 0)) ? 1 : 0;
     static const int env_rows = env_int("BXI_TILE_ROWS", 0);            // developer knobs
     static const int env_pool_first = env_int("BXI_POOL_FIRST", 0);
-    static const int env_prep_flags = env_int("BXI_PREP_FLAGS", 0);
     static const int env_pool_wgs = env_int("BXI_POOL_WGS_PER_CU", 5);
     if (!force_rows) force_rows = env_rows;
     const int R = force_rows == 4 || force_rows == 8 ? force_rows : tile_rows_for(a.N);
     if (eval_cap(a.N, a.h, a.w, dil, R) >= (1 << 24)) return BXI_ERR_BAD_SHAPE;     // the table packs a tile prefix into 24 bits
     const HostPred pr = host_pred(color_thresh);
-
-    const int64_t n_items64 = (int64_t)batch->B * a.h * ((a.w + 63) / 64);
-    if (n_items64 > 0x7fffffffLL) return BXI_ERR_BAD_SHAPE;
-    const int n_items = (int)n_items64;
-    // launch 2's geometry first: the table waves of launch 1 clear one slot per predicate wave
-    const int64_t cap = eval_cap(a.N, a.h, a.w, dil, R);
-    int64_t n_tb = (cap + kWaves - 1) / kWaves;
-    // the tile list's length is device data: the tile waves stride through it.  The launch should be resident in one round:
-    // 4 (R = 4: <= 128 VGPRs) or 2 (R = 8) workgroups per CU; the predicate waves are short-lived.
-    static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 0);
-    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? (dil <= 3 ? 4 : 3) : 2);
-    const int slots = occ * device_cus() - a.N - 1;
-    int n_pb = (n_items + kWaves - 1) / kWaves;
-    if (n_pb > slots / 2) n_pb = slots / 2 > 1 ? slots / 2 : 1;
-    if (n_pb * kWaves > kMaxPredWaves) n_pb = kMaxPredWaves / kWaves;
-    ws.n_pw = n_pb * kWaves;
-    if (n_tb > slots - n_pb) n_tb = slots - n_pb > 64 ? slots - n_pb : 64;
-    size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
-    const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
-    if (lds2 < lds_leader) lds2 = lds_leader;
-    if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
-    const int grid = a.N + n_pb + (int)n_tb + 1;          // leaders + predicate blocks + tile blocks + the finisher
-    ValidCells vc = {};
-    for (int b = 0; b < batch->B; ++b) {                  // the device formula (valid_cells), evaluated here once per image
-        const int half = a.stride / 2;
-        auto cells = [&](int limit, int n) { const int v = limit - half <= 0 ? 0 : (limit - half + a.stride - 1) / a.stride; return v < n ? v : n; };
-        vc.vrow[b] = cells(pa.meta.img_h[b] < pa.meta.first_removed[b] ? pa.meta.img_h[b] : pa.meta.first_removed[b], a.h);
-        vc.vcol[b] = cells(pa.meta.img_w[b], a.w);
-    }
 
     // ---- launch 1 --------------------------------------------------------------------------------------------------
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
@@ -1360,6 +1296,9 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     const int n_stream = a.N * Sn;
     // one item = the 4 input rows of 64 pooled pixels.  The whole launch should be resident at once (5 workgroups per CU at
     // <= 96 VGPRs): a pool workgroup takes several items, the next one's loads in flight, when it is not.
+    const int64_t n_items64 = (int64_t)batch->B * a.h * ((a.w + 63) / 64);
+    if (n_items64 > 0x7fffffffLL) return BXI_ERR_BAD_SHAPE;
+    const int n_items = (int)n_items64;
     const int room = env_pool_wgs * device_cus() - n_tab - (head ? 0 : n_stream);
     const int per = room > 0 ? (n_items + room - 1) / room : 8;
     const int n_pool = pooled_in_launch ? (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per) : 0;
@@ -1389,7 +1328,7 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
         if (lds1 < 8 * (size_t)kWaves * a.w) lds1 = 8 * (size_t)kWaves * a.w;
         if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
         BXI_LAUNCH("prep", s, prep3_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, ws, st,
-                   g_logits, vec, env_pool_first, env_prep_flags);
+                   g_logits, vec, env_pool_first);
     }
     rc = check_launch();
     if (rc != BXI_OK) return rc;
@@ -1404,6 +1343,28 @@ int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_ins
     }
 
     // ---- launch 2 --------------------------------------------------------------------------------------------------
+    const int64_t cap = eval_cap(a.N, a.h, a.w, dil, R);
+    int64_t n_tb = (cap + kWaves - 1) / kWaves;
+    // the tile list's length is device data: the tile waves stride through it.  The launch should be resident in one round:
+    // 4 (R = 4: <= 128 VGPRs) or 2 (R = 8) workgroups per CU; the predicate waves are short-lived.
+    static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 0);
+    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? (dil <= 3 ? 4 : 3) : 2);
+    const int slots = occ * device_cus() - a.N - 1;
+    int n_pb = (n_items + kWaves - 1) / kWaves;
+    if (n_pb > slots / 2) n_pb = slots / 2 > 1 ? slots / 2 : 1;
+    if (n_tb > slots - n_pb) n_tb = slots - n_pb > 64 ? slots - n_pb : 64;
+    size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
+    const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
+    if (lds2 < lds_leader) lds2 = lds_leader;
+    if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
+    const int grid = a.N + n_pb + (int)n_tb + 1;          // leaders + predicate blocks + tile blocks + the finisher
+    ValidCells vc = {};
+    for (int b = 0; b < batch->B; ++b) {                  // the device formula (valid_cells), evaluated here once per image
+        const int half = a.stride / 2;
+        auto cells = [&](int limit, int n) { const int v = limit - half <= 0 ? 0 : (limit - half + a.stride - 1) / a.stride; return v < n ? v : n; };
+        vc.vrow[b] = cells(pa.meta.img_h[b] < pa.meta.first_removed[b] ? pa.meta.img_h[b] : pa.meta.first_removed[b], a.h);
+        vc.vcol[b] = cells(pa.meta.img_w[b], a.w);
+    }
 #define BXI_PAIR_CASE(DD)                                                                                                                  \
     case DD:                                                                                                                               \
         if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw); \

@@ -14,7 +14,7 @@ except Exception as e:
 PY
 }
 i=0
-for cfg in "BXI_EVAL_V2=1" "BXI_PREP_FLAGS=0" "BXI_PREP_FLAGS=3" "BXI_EVAL_V2=1" "BXI_PREP_FLAGS=0"; do
+for cfg in "BXI_EVAL_V2=1" "BXI_X=0" "BXI_EVAL_V2=1" "BXI_X=0"; do
   i=$((i+1))
   echo "== $cfg"
   env $cfg timeout 300 python bench.py --no-cpu-baseline --no-extras > gpurun_out/bench_ab$i.json 2> gpurun_out/bench_ab$i.err
