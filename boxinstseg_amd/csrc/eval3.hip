@@ -83,7 +83,8 @@ struct Ws {
     int n_cb, n_rp;
     int4* tab;                                  // [N+1] {tile prefix | img << 24, r0 | r1 << 16, c0 | c1 << 16, vrow | vcol << 16}; [N].x = tiles
     // words polled inside pair3_kernel; zeroed by prep3_kernel's table waves, i.e. before a kernel boundary
-    unsigned long long* acc1;                   // [kAcc1Words] (one per 128 B) predicate waves: arrivals << 40 | sum W
+    unsigned long long* acc1;                   // [kAcc1Words] (one per 128 B) predicate workgroups: segments evaluated << 40 | sum W
+    unsigned long long* sumw;                   // [1]   1 << 63 | sum W, published by the reducer wave once every segment is in (0 = not yet)
     unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B) tile waves: arrivals << 52 | sum (W pw + 1) in 2^-24 units
     unsigned long long* dice;                   // [N]   leader: 1 << 32 | bits of the instance's dice loss (0 = not published)
     unsigned int* fault;                        // [1]   bit mask of waits that ran out (never expected)
@@ -116,6 +117,7 @@ static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
     t.n_cb = (int)Sn; t.n_rp = 1;
     t.tab = (int4*)take(16 * (size_t)(N1 + 1));
     t.acc1 = (unsigned long long*)take(8 * (size_t)kAcc1Words * kAcc2Stride);
+    t.sumw = (unsigned long long*)take(8);
     t.acc2 = (unsigned long long*)take(8 * (size_t)N1 * kAcc2Split * kAcc2Stride);
     t.dice = (unsigned long long*)take(8 * (size_t)N1);
     t.fault = (unsigned int*)take(4);
@@ -186,6 +188,7 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
     }
     if (k == 0) {
         ws.acc1[(size_t)lane * kAcc2Stride] = 0ull;
+        if (lane == 0) *ws.sumw = 0ull;
         if (lane == 0) { *ws.fault = 0u; if (st.status) { st.status[0] = 0; st.status[1] = R; } }
     }
 }
@@ -682,12 +685,25 @@ __device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc
     return cnt;
 }
 
-// One round over the count words: true when every predicate wave has arrived; then *total = sum W over all instances.
+// sum W, once every pooled row segment has been evaluated: ONE word for the (hundreds of) askers; the reducer -- one wave of the
+// finisher workgroup -- watches the 64 count words and publishes it.
 __device__ __forceinline__ bool counts_complete(const Ws& ws, int n_items, double* total) {
-    const unsigned long long x = __hip_atomic_load(&ws.acc1[(size_t)(threadIdx.x & 63) * kAcc2Stride], BXI_RLX, BXI_AGENT);
-    const int arrived = wave_total_i32((int)(x >> 40));
-    *total = wave_total_f64((double)(x & ((1ull << 40) - 1ull)));       // exact: integers far below 2^53
-    return arrived == n_items;
+    (void)n_items;
+    const unsigned long long x = __hip_atomic_load(ws.sumw, BXI_RLX, BXI_AGENT);
+    *total = (double)(x & ~(1ull << 63));                               // exact: an integer far below 2^53
+    return (x >> 63) != 0ull;
+}
+__device__ __forceinline__ bool reduce_counts(const Ws& ws, int n_items) {
+    for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {
+        const unsigned long long x = __hip_atomic_load(&ws.acc1[(size_t)(threadIdx.x & 63) * kAcc2Stride], BXI_RLX, BXI_AGENT);
+        const int arrived = wave_total_i32((int)(x >> 40));
+        const double tot = wave_total_f64((double)(x & ((1ull << 40) - 1ull)));       // exact
+        if (arrived == n_items) {
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(ws.sumw, (1ull << 63) | (unsigned long long)tot, BXI_RLX, BXI_AGENT);
+            return true;
+        }
+    }
+    return false;
 }
 // thresh <= 0: every pair (padded ones too) weighs 1 (:1324), sum W = 8 x the box areas; no predicate waves then
 __device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, const Ws& ws) {
@@ -1050,6 +1066,7 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair3_ke
         double total_w = 0.0;
         float dsum = 0.f;
         unsigned spins = 0;
+        if (wave == 1 && !zero_bit && !reduce_counts(ws, n_items) && lane == 0) atomicOr(ws.fault, kFaultCounts);     // the reducer
         if (wave == 0) {
             for (int b0 = 0; b0 < N && ok; b0 += 64) {
                 while (!dice_round(ws, N, b0, &dsum)) {
