@@ -3,8 +3,8 @@
 
 Metric (BASELINE.json): pairwise+projection loss fwd+bwd images/sec @ 2x800x1024 x 32 instances.
 One *step* = one loss evaluation on a 2-image batch, through the C ABI of libboxinst_hip.so:
-  bxi_boxinst_eval_f32   prep (image pool + Lab || logit streaming || tables)  ->  pair (projection leaders, pair weights,
-                         pairwise term on the box tiles, normaliser, both loss scalars, FINISHED gradient)
+  bxi_boxinst_eval_f32   prep (image pool + Lab || logit streaming || table)  ->  pair (colour predicates + pair-weight sum per image,
+                         projection leaders, pairwise term on the box tiles, both loss scalars, FINISHED gradient)
 i.e. everything CondInstMaskHead.loss + .backward() do for mask_logits, from the normalised images, boxes and logits
 already resident in HBM to loss_prj, loss_pairwise and d(loss_prj + loss_pairwise)/d(mask_logits); the two upstream
 factors are read from device memory inside the kernels (ones here, as `loss.backward()` seeds them).
@@ -290,8 +290,15 @@ def worker(args):
                    'parallelism': f'replicas x{world} (no exchange step inside the path)'},
     }
     if dist is not None:
+        props = torch.cuda.get_device_properties(dev)
+        mine = {'rank': rank, 'device': dev.index, 'name': props.name, 'arch': getattr(props, 'gcnArchName', None),
+                'pci_bus_id': '%04x:%02x:%02x' % (getattr(props, 'pci_domain_id', 0), getattr(props, 'pci_bus_id', 0), getattr(props, 'pci_device_id', 0)),
+                'uuid': str(getattr(props, 'uuid', ''))}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
         result['multi_gpu'] = {
-            'world_size': dist.get_world_size(), 'backend': 'nccl (RCCL)',
+            'world_size': dist.get_world_size(), 'backend': 'nccl (RCCL)', 'ranks': ranks,
+            'distinct_devices': len({(r['pci_bus_id'], r['uuid']) for r in ranks}),
             'per_rank_images_per_s': 2 * args.steps / local_elapsed,
             'per_rank_images_per_s_without_collectives': 2 * args.steps / eval_only,
             'allreduce_per_evaluation': f'{(PARAM_CONV_FLOATS + 2) * 4} B (param_conv-sized gradient bucket + the 2 loss scalars), '
@@ -462,10 +469,48 @@ def module_api(sets, dev, n):
             head.loss(s.imgs, s.d['img_metas'], s.logits, s.gt_inds, s.boxes, None, None)
     fwd_only = time.perf_counter() - t0
     torch.cuda.synchronize(dev)
+    varying = module_api_varying(head, sets, dev, n)
     return {'images_per_s': 2 * n / el, 'us_per_call': el / n * 1e6, 'host_us_per_call': host / n * 1e6,
-            'loss_call_host_us_no_autograd': fwd_only / n * 1e6,
+            'loss_call_host_us_no_autograd': fwd_only / n * 1e6, 'varying_shapes': varying,
             'note': 'CondInstMaskHead.loss + backward() of the two scalars, eager PyTorch (gc frozen); host-bound: '
                     'the GPU work is `value`'}
+
+
+def module_api_varying(head, sets, dev, n):
+    """The module call when every iteration differs, as real COCO iterations do: img_shape / ori_shape, the number of GT boxes per
+    image and the number of instances change on every call (canvas fixed, as with a padded batch).  Host time of loss() alone."""
+    import gc
+    rng = np.random.default_rng(7)
+    calls = []
+    for i in range(16):
+        s = sets[i % len(sets)]
+        d = s.d
+        metas = []
+        for m in d['img_metas']:
+            ih, iw = int(rng.integers(d['H'] // 2, d['H'] + 1)), int(rng.integers(d['W'] // 2, d['W'] + 1))
+            metas.append(dict(m, img_shape=(ih, iw, 3), ori_shape=(int(ih * rng.uniform(0.4, 1.5)), int(iw * rng.uniform(0.4, 1.5)), 3)))
+        boxes = [b[:int(rng.integers(1, b.shape[0] + 1))].contiguous() for b in s.boxes]
+        G = sum(b.shape[0] for b in boxes)
+        N = int(rng.integers(max(G // 2, 1), G + 1))
+        gi = torch.from_numpy(rng.integers(0, G, N).astype(np.int64)).to(dev)
+        calls.append((s.imgs, metas, s.logits[:N].contiguous(), gi, boxes))
+    def once(i):
+        imgs, metas, x, gi, boxes = calls[i % len(calls)]
+        with torch.no_grad():
+            head.loss(imgs, metas, x, gi, boxes, None, None)
+    for i in range(32):
+        once(i)
+    torch.cuda.synchronize(dev)
+    gc.collect()
+    gc.freeze()
+    t0 = time.perf_counter()
+    for i in range(n):
+        once(i)
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize(dev)
+    gc.unfreeze()
+    return {'loss_call_host_us_no_autograd': host / n * 1e6,
+            'note': 'img_shape, ori_shape, boxes per image and instance count differ on every call (16 distinct calls, rotated)'}
 
 
 # algorithmic (compulsory) HBM bytes -- DESIGN.md section 4 / SURVEY 8(d).
@@ -489,12 +534,13 @@ def hull_fraction(d, dil=2, rows=8):
 def algorithmic_bytes(d, N, rows):
     """Compulsory HBM bytes per launch: per-unit figure x units of one launch."""
     px_in = d['B'] * d['H'] * d['W']          # input pixels:     12 B read each (3 x f32)
-    px_small = d['B'] * d['h'] * d['w']       # pooled pixels:    12 B written each (Lab, 3 x f32)
-    ipx = N * d['h'] * d['w']                 # instance-pixels:  4 B read (logit) + 4 B written (gradient)
-    f = hull_fraction(d, rows=rows)
+    px_small = d['B'] * d['h'] * d['w']       # pooled pixels:    16 B written (Lab as float4) + 1 B (predicate byte cleared) in prep;
+    ipx = N * d['h'] * d['w']                 #                   16 B read + 1 B written (predicate waves) in pair
+    f = hull_fraction(d, rows=rows)           # instance-pixels:  4 B read (logit) + 4 B written (zero-filled gradient) in prep
     return {
-        'prep': 12 * px_in + 12 * px_small + 4 * ipx + 4 * ipx,
-        'pair': int(4 * ipx * f) * 4 + int(4 * ipx * f),   # box tiles: logits + 3 Lab planes read, gradient written
+        'prep': 12 * px_in + 17 * px_small + 4 * ipx + 4 * ipx,
+        # box tiles: logits read (4 B), predicate byte read (1 B), gradient added at the L2 / memory side (4 B read + 4 B written)
+        'pair': 17 * px_small + int(ipx * f) * (4 + 1 + 8),
     }
 
 
@@ -508,7 +554,7 @@ def measured_traffic():
     """HBM bytes per launch from the committed PMC summary of this command (profiles/*_hbm_traffic.json, written by
     tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes) -> (dict, file) or (None, None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r02*_hbm_traffic.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r03*_hbm_traffic.json')))
     if not files:
         return None, None
     try:
@@ -545,10 +591,18 @@ def kernel_timing(lib, _lib, sets, stream, enqueue, steps, step_us, rows):
     stream.synchronize()
     raws = {name: np.array([evs[j].elapsed_time(evs[j + 1]) * 1e3 for j in range(0, len(evs) - 1, 2)])
             for name, evs in events.items()}                                                      # us
-    # An event pair adds queue packets of its own.  Their cost is calibrated against the un-instrumented
-    # timed region of this same run: (sum of bracketed durations per step - measured step time) / launches
-    # per step.  With it the per-kernel figures tile the step as rocprofv3's durations do.
-    bracket_us = max(0.0, (sum(float(np.mean(r)) for r in raws.values()) - step_us) / max(len(raws), 1))
+    # What an event pair costs by itself, measured on its own: pairs of events with NOTHING between them, queued behind the same
+    # parked stream.  (Round 2 defined this cost as whatever made the kernels tile the step, which made the per-kernel split a ratio,
+    # not a measurement.)  The per-kernel figures below are raw - this; rocprofv3's durations of the same command are in profiles/.
+    with torch.cuda.stream(stream):
+        torch.cuda._sleep(int(0.05 * 2.0e9))
+        empties = []
+        for _ in range(200):
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record(stream); b_.record(stream)
+            empties.append((a_, b_))
+    stream.synchronize()
+    bracket_us = float(np.median([a_.elapsed_time(b_) * 1e3 for a_, b_ in empties]))
     d0, N = sets[0].d, sets[0].inst.N
     alg = algorithmic_bytes(d0, N, rows)
     traffic, traffic_file = measured_traffic()
@@ -565,20 +619,21 @@ def kernel_timing(lib, _lib, sets, stream, enqueue, steps, step_us, rows):
                             'traffic': traffic.get(key.get(name, name)) if traffic else None}
     whole = survey_bytes(d0, N)
     ksum = sum(v['avg_us'] for v in per_kernel.values())
-    a = whole / (ksum * 1e-6) / 1e9
+    # the figure of merit is computed on the UN-INSTRUMENTED step time (kernels + their boundaries: what a training loop sees)
+    a = whole / (step_us * 1e-6) / 1e9
     return {
         'roofline': {'kernel': 'prep + pair = the whole evaluation', 'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBPS,
                      'unit': 'GB/s', 'frac': a / HBM_PEAK_GBPS,
                      'traffic': sum(traffic.values()) if traffic else None,
                      'traffic_source': traffic_file,
                      'algorithmic_bytes': whole, 'algorithmic_bytes_source': 'SURVEY 8(d): 39 322 240 B at 2x800x1024x32',
-                     'kernel_time_us': ksum, 'wall_step_us': step_us,
-                     'frac_on_wall_time': whole / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                     'timing': 'hipEvent pairs around each launch on the launching stream (bxi_set_launch_hook), minus the '
-                               'per-bracket cost calibrated against the un-instrumented step time (event_bracket_us); launches '
-                               'queued behind a parked stream, cold input sets; rocprofv3 durations of the same command in '
-                               'profiles/',
-                     'per_kernel': {k: {'avg_us': v['avg_us'], 'algorithmic_bytes': v['algorithmic_bytes'], 'frac': v['frac']}
+                     'time_us': step_us, 'time_source': 'ms_per_step of this run (un-instrumented, both launches and their boundaries)',
+                     'event_kernel_time_us': ksum, 'frac_on_event_kernel_time': whole / (ksum * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                     'timing': 'per kernel: hipEvent pairs around each launch on the launching stream (bxi_set_launch_hook), minus the '
+                               'cost of an empty pair measured separately (event_bracket_us); launches queued behind a parked stream, '
+                               'cold input sets.  rocprofv3 durations of the same command: profiles/',
+                     'per_kernel': {k: {'avg_us': v['avg_us'], 'raw_event_avg_us': v['raw_event_avg_us'],
+                                        'algorithmic_bytes': v['algorithmic_bytes'], 'frac': v['frac']}
                                     for k, v in per_kernel.items()}},
         'kernels': per_kernel,
         'event_bracket_us': bracket_us,

@@ -11,24 +11,15 @@ bxi_launch_hook g_hook = nullptr;
 void* g_hook_user = nullptr;
 
 size_t loss_ws_bytes(int N, int h, int w);
-size_t eval_ws_bytes(int N, int h, int w);
+size_t eval_ws_bytes(int B, int N, int h, int w);
 bool fused_eval_supported(int dil);
-int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thresh, const bxi_instances* in, int dil, float warmup,
-                      const float* up_prj, const float* up_pw, float* losses, float* g_logits, void* state, void* workspace,
-                      size_t workspace_bytes, int force_rows, void* stream, const DynArgs* head = nullptr, int head_C = 0);
-int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits,
-                   void* stream);
-
-size_t eval3_ws_bytes(int B, int N, int h, int w);
-bool eval3_supported(int dil);
-int launch_eval3(const bxi_image_batch* batch, float color_thresh, const bxi_instances* in, int dil, float warmup, const float* up_prj,
-                 const float* up_pw, float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, int force_rows,
-                 void* stream, const DynArgs* head = nullptr, int head_C = 0);
-int launch_rescale3(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits, void* stream);
+void debug_set_spin_limit(int limit);
+int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bxi_instances* in, int dil, float warmup, const float* up_prj,
+                      const float* up_pw, float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, int force_rows,
+                      void* stream, const DynArgs* head = nullptr, int head_C = 0);
+int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits, void* stream);
 
 static inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
-// developer switch for A/B runs on one box: BXI_EVAL_V2=1 takes the round-2 kernels (fused_eval.hip)
-static bool use_v2() { static const bool v = [] { const char* e = getenv("BXI_EVAL_V2"); return e && e[0] == '1'; }(); return v; }
 
 }  // namespace bxi
 
@@ -76,9 +67,7 @@ size_t bxi_boxinst_eval_workspace_bytes(int B, int Hc, int Wc, int stride, int N
     if (B < 0 || Hc <= 0 || Wc <= 0 || stride < 1 || N < 0) return 0;
     const int h = Hc / stride, w = Wc / stride;
     if (h <= 0 || w <= 0) return 0;
-    const size_t P = (size_t)h * w;
-    const size_t v2 = bxi::up256(sizeof(float) * (size_t)B * 3 * P) + bxi::eval_ws_bytes(N, h, w), v3 = bxi::eval3_ws_bytes(B, N, h, w);
-    return v2 > v3 ? v2 : v3;
+    return bxi::eval_ws_bytes(B, N, h, w);
 }
 
 size_t bxi_boxinst_eval_workspace_lab_offset(void) { return 0; }
@@ -97,15 +86,8 @@ int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances*
                                                          inst_host->N);
     if (!workspace || need == 0 || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255))
         return BXI_ERR_WORKSPACE;
-    if (!bxi::use_v2())
-        return bxi::launch_eval3(batch_host, color_thresh, inst_host, dilation, warmup, up_prj, up_pw, losses, g_logits, state, workspace,
-                                 workspace_bytes, 0, stream);
-    const size_t P = (size_t)inst_host->h * inst_host->w;
-    char* base = (char*)workspace;
-    float* lab = (float*)base;
-    char* lws = base + bxi::up256(sizeof(float) * (size_t)batch_host->B * 3 * P);
-    return bxi::launch_fused_eval(batch_host, lab, color_thresh, inst_host, dilation, warmup, up_prj, up_pw, losses, g_logits,
-                                  state, lws, workspace_bytes - (size_t)(lws - base), 0, stream);
+    return bxi::launch_fused_eval(batch_host, color_thresh, inst_host, dilation, warmup, up_prj, up_pw, losses, g_logits, state, workspace,
+                                  workspace_bytes, 0, stream);
 }
 
 int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host, const float* feat, int C, int Hs,
@@ -127,20 +109,14 @@ int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_insta
     if (rc != BXI_OK) return rc;
     const size_t need = bxi_boxinst_eval_workspace_bytes(batch_host->B, batch_host->Hc, batch_host->Wc, stride, inst_host->N);
     if (!workspace || need == 0 || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
-    if (!bxi::use_v2())
-        return bxi::launch_eval3(batch_host, color_thresh, inst_host, dilation, warmup, up_prj, up_pw, losses, g_logits, state, workspace,
-                                 workspace_bytes, 0, stream, &da, C);
-    const size_t P = (size_t)inst_host->h * inst_host->w;
-    char* base = (char*)workspace;
-    float* lab = (float*)base;
-    char* lws = base + bxi::up256(sizeof(float) * (size_t)batch_host->B * 3 * P);
-    return bxi::launch_fused_eval(batch_host, lab, color_thresh, inst_host, dilation, warmup, up_prj, up_pw, losses, g_logits, state, lws,
-                                  workspace_bytes - (size_t)(lws - base), 0, stream, &da, C);
+    return bxi::launch_fused_eval(batch_host, color_thresh, inst_host, dilation, warmup, up_prj, up_pw, losses, g_logits, state, workspace,
+                                  workspace_bytes, 0, stream, &da, C);
 }
+
+void bxi_debug_set_spin_limit(int limit) { bxi::debug_set_spin_limit(limit); }
 
 int bxi_boxinst_grad_rescale_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw, int dilation,
                                  const void* state, float* g_logits, void* stream) {
-    if (!bxi::use_v2()) return bxi::launch_rescale3(inst_host, g_prj, g_pw, dilation, state, g_logits, stream);
     return bxi::launch_rescale(inst_host, g_prj, g_pw, dilation, state, g_logits, stream);
 }
 

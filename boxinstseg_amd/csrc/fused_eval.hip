@@ -6,34 +6,39 @@
 //   get_image_color_similarity + unfold_wo_center                :190-246
 //   compute_project_term + dice_coefficient                      :117-143
 //   pairwise_nlog (CUDA op, pairwise.cu:68-149) + weights / normalise / warm-up   :1315-1332
-// and what autograd does behind them, with the upstream factors folded in, so that g_logits leaves the
-// second launch FINISHED (no third launch; round 1 needed loss_apply for that).
+// and what autograd does behind them, with the upstream factors folded in.
 //
-//   prep_kernel   256-thread workgroups, three roles                                   HBM stream
-//     table waves   per-instance box rectangle, the compacted list of box tiles (+ colour predicate), zeroed counters
-//     stream blocks 4 waves x 8 rows of one instance map: zero-fill of g_logits, row maxima (complete), column
-//                   maxima of the block's 32 rows (combined through LDS) -> Sn = ceil(h/32) partials per column
-//     pool blocks   4 waves = the 4 input rows of 64 pooled pixels: a lane loads 3 x float4 (1 KiB contiguous per
-//                   wave-load), de-normalises 12 values; the 4x4 sums meet in LDS, then three waves take one CIE
-//                   channel each (fp64) -> Lab f32.  Four times more, four times lighter waves than one lane per
-//                   pooled pixel: their arithmetic overlaps the other waves' loads (tools/micro/dispatch.hip, D).
-//   pair_kernel   256-thread workgroups, three roles + a one-wave finisher, dispatched in this order
-//     leaders       one per instance: column partials -> maxima -> sigmoid -> dice -> unit projection gradients
-//                   (published as self-flagging 8-byte granules, like its dice loss), projection gradient at the arg-max
-//                   positions outside the tiles
-//     count waves   one per box tile: sum of the pair weights W from Lab alone -> one packed atomic per tile
-//     math waves    one per box tile (wave64, no LDS, no barrier): the tile + halo lives in registers, a lane owns a
-//                   column; every unordered pair is evaluated ONCE and feeds both of its pixels (neighbour columns by
-//                   cross-lane moves); then reads sum W (complete: the count waves precede the math waves in the
-//                   grid, so nothing waits for a workgroup that may not have been dispatched), the leader's
-//                   coefficients, and stores  g = g_pw * warm/max(sum W,1) * d pw + g_prj * d prj.
-//     finisher      last block: one round of polls delivers both the completion check and the data of the two loss values
-// Data layout in HBM: everything NCHW / row-major as the reference hands it over; Lab [B,3,h,w] f32 is the only
-// materialised intermediate (1.2 MB at 2x800x1024).
+//   launch 1  prep_kernel   256-thread workgroups, three roles, nothing waits                              HBM stream
+//     table waves   per-instance table (tile prefix, box cells, image, valid-cell limits): 16 bytes per instance; zeroes the
+//                   words the next launch polls
+//     stream blocks 4 waves x 8 rows of one instance map: zero-fill of g_logits (written through), row maxima, column maxima
+//                   of the block's 32 rows -> partials for the leaders of the next launch
+//     pool blocks   the 4 input rows of 64 pooled pixels -> de-normalise, truncate, 4x4 mean, Lab (fp64) -> ONE 16-byte
+//                   store per pooled pixel
+//   launch 2  pair_kernel   [leaders][predicate blocks][tile blocks][finisher]
+//     leaders       one block per instance: partial maxima -> maxima -> sigmoid -> dice -> unit projection gradients, ADDED
+//                   (float atomic) at the arg-max positions of the zero-filled gradient.  Nobody waits for a leader but the finisher.
+//     predicate waves  one wave64 per pooled row segment (64 pixels) of an image: the four colour predicates per pixel (one byte)
+//                   -- each unordered pair ONCE PER IMAGE, not once per instance and tile -- and the segment's share of the pair
+//                   weights' sum (a function of the image and the boxes only, :1324-1328) -> one packed integer atomic per segment
+//     tile waves    one wave64 per box tile (no LDS, no barrier): logits tile + halo in registers, every unordered pair
+//                   evaluated once; g_pw warm/max(sum W,1) d pw is ADDED (float atomic) to the gradient -- an element receives
+//                   at most two additions onto 0 (its tile's and its leader's), so the sum does not depend on their order;
+//                   the tile's share of sum W pw goes to an integer accumulator by an atomic without return.  Its one wait,
+//                   when the logits have arrived and the per-pixel quantities are computed: every predicate wave has arrived
+//                   (they precede it in the grid and never wait), which also delivers sum W, the global normaliser.
+//     finisher      the last workgroup: polls the accumulators, writes the two loss values.
+// Every wait is bounded and running out of it is loud: NaN losses, a status word, a poisoned gradient (rescale_kernel).
+// Table entries instead of a work list: a tile wave finds its tile from 16 bytes per instance that every wave reads (the same
+// few cache lines), not from a record of its own behind a list length (two dependent misses right after the kernel boundary).
+// Data layout in HBM: everything NCHW / row-major as the reference hands it over; intermediates: Lab [B,h,w] float4 (1.6 MB at
+// 2x800x1024), column / row partial maxima, 16-byte table entries.
 #include "loss_common.hpp"
 #include "dynamic_head_device.hpp"
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
+#include <cmath>
 
 namespace bxi {
 
@@ -42,20 +47,14 @@ constexpr int kSRows = 8;                       // rows per stream wave
 constexpr int kSBlk = kWaves * kSRows;          // rows per stream workgroup
 constexpr int kChunkC = 256;                    // columns per pass of a stream wave: 64 lanes x float4
 constexpr int kMaxDilFused = 4;
-constexpr unsigned kSpinLimit = 200000;
-constexpr unsigned long long kGranuleInvalid = 0xffffffffull;
-// A math wave's arrival + its share of the loss sum is one atomic on its instance's word.  ~20 tile waves per instance arrive
-// within a microsecond; atomics on one word are performed one after the other (~0.15 us each): the last arrival became
-// visible ~3 us after it was issued, and the launch ends on it.  Eight words per instance, each in its own 128 bytes.
-constexpr int kAcc2Split = 8, kAcc2Stride = 16;
-// The count waves' sums likewise: only their total over all instances is ever needed (the normaliser is global, :1327-1328),
-// so they go to 64 words, one per lane of whoever adds them up; "every tile counted" = the arrivals add up to the list length.
-constexpr int kAcc1Words = 64;
-__device__ __forceinline__ unsigned long long* acc2_word(unsigned long long* acc2, int n, int sub) {
-    return acc2 + ((size_t)n * kAcc2Split + (sub & (kAcc2Split - 1))) * kAcc2Stride;
-}         // bounded waits (never reached: see the grid order above)
+constexpr int kSpinLimit = 400000;              // bounded waits (~0.3 us per poll): far beyond any launch; running out is loud (NaN losses)
+// developer / test hook (bxi_debug_set_spin_limit): 0 = kSpinLimit; negative = every bounded wait gives up at once
+static std::atomic<int> g_spin_limit{0};
+constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
+constexpr int kAcc1Words = 64;                  // count-wave arrivals + sum W: 64 words, each in its own 128 bytes
+constexpr int kMaxInst = 65536;
+constexpr unsigned kFaultCounts = 1u, kFaultFinisher = 2u;
 
-// developer tracing (-DBXI_TRACE builds only): per-WAVE phase stamps, see tools/trace_eval.py
 #ifdef BXI_TRACE
 #define BXI_TW(kid, idx, ph)                                                                                  \
     do {                                                                                                      \
@@ -69,147 +68,141 @@ __device__ __forceinline__ unsigned long long* acc2_word(unsigned long long* acc
 #define BXI_RLX __ATOMIC_RELAXED
 #define BXI_AGENT __HIP_MEMORY_SCOPE_AGENT
 
-struct WorkRec2 {                               // 64 B: all a tile wave needs, written by the table waves
-    int r0, r1, c0, c1;                         // cells whose sample lies in the GT box (bitmask == 1)
-    int img, n, tile_r0, tile_c0;
-    float n2max; int zero_bit, vr, vc;          // colour predicate; valid(q) <=> y(q) < vr && x(q) < vc (:1354-1369,:1405)
-    int hc1, pad0, pad1, pad2;                  // end column of the instance's tile hull (= dilated box)
-};
-
-struct EvalWs {                                 // carved from the caller's workspace
-    unsigned long long* colpart;                // [N,n_cb,w] packed (max logit, first row) of a band of rows (32: stream blocks; 16: head tiles)
-    unsigned long long* rowkey;                 // [N,n_rp,h] packed (max logit, first column); n_rp = 1 (stream blocks: whole rows) or the head's tiles in x
-    int n_cb, n_rp;                             // set per launch
-    InstRec* inst;                              // [N]
-    WorkRec2* work;                             // [cap]
-    int* nwork;                                 // [1]
-    unsigned int* expect;                       // [N]  tiles of the instance
-    // words polled inside pair_kernel; zeroed by prep_kernel's table waves (i.e. before a kernel boundary)
-    unsigned long long* acc1;                   // [kAcc1Words] (one per 128 B)  count waves : arrivals << 40 | sum W; all words together: every tile, the whole sum
-    unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B)  math waves : arrivals << 52 | sum (W pw + 1) in 2^-24 units
-    unsigned long long* dice;                   // [N] leader : 1 << 32 | bits of the instance's dice loss (0 = not published; zeroed by the table waves)
-};
-
-static inline int tile_width(int dil) { return 64 - 2 * dil; }
-static inline int eval_cap(int N, int h, int w, int dil, int R) {
-    const int tw = tile_width(dil);
-    return (N > 0 ? N : 1) * ((h + R - 1) / R) * ((w + tw - 1) / tw);
+// float add at the L2 without return (global_atomic_add_f32): the gradient is zero-filled by launch 1 and every element
+// receives at most two additions, so the result does not depend on their order
+__device__ __forceinline__ void add_f32(float* p, float v) {
+    (void)__builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)p, v);
 }
 
-static size_t carve_eval(void* base, int N, int h, int w, EvalWs* ws) {
+// ---- workspace ---------------------------------------------------------------------------------------------------------
+struct Ws {
+    float4* lab4;                               // [B,h,w] (L, a, b, 0)
+    float* lab_planar;                          // [B,3,h,w] only the generic pooling path (other strides, unaligned canvases) fills it
+    unsigned char* pred;                        // [B,h,w] bit d = colour predicate of pair direction d with this pixel as the step pixel
+    unsigned long long* colpart;                // [N,n_cb,w] packed (max logit, first row) of a band of rows
+    unsigned long long* rowkey;                 // [N,n_rp,h] packed (max logit, first column)
+    int n_cb, n_rp;
+    int4* tab;                                  // [N+1] {tile prefix | img << 24, r0 | r1 << 16, c0 | c1 << 16, vrow | vcol << 16}; [N].x = tiles
+    // words polled inside pair_kernel; zeroed by prep_kernel's table waves, i.e. before a kernel boundary
+    unsigned long long* acc1;                   // [kAcc1Words] (one per 128 B) predicate workgroups: segments evaluated << 40 | sum W
+    unsigned long long* sumw;                   // [1]   1 << 63 | sum W, published by the reducer wave once every segment is in (0 = not yet)
+    unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B) tile waves: arrivals << 52 | sum (W pw + 1) in 2^-24 units
+    unsigned long long* dice;                   // [N]   leader: 1 << 32 | bits of the instance's dice loss (0 = not published)
+    unsigned int* fault;                        // [1]   bit mask of waits that ran out (never expected)
+};
+
+__device__ __forceinline__ unsigned long long* acc2_word(unsigned long long* acc2, int n, int sub) {
+    return acc2 + ((size_t)n * kAcc2Split + (sub & (kAcc2Split - 1))) * kAcc2Stride;
+}
+
+static inline int tile_width(int dil) { return 64 - 2 * dil; }
+static inline int64_t eval_cap(int N, int h, int w, int dil, int R) {
+    const int tw = tile_width(dil);
+    return (int64_t)(N > 0 ? N : 1) * ((h + R - 1) / R) * ((w + tw - 1) / tw);
+}
+
+static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
     const int N1 = N > 0 ? N : 1;
     const size_t Sn = (size_t)(h + kSBlk - 1) / kSBlk;
     const size_t cb_max = (size_t)(h + kYR * 2 - 1) / (kYR * 2), rp_max = (size_t)(w + kYC * 2 - 1) / (kYC * 2);   // the head-fused launch's tiles
     size_t off = 0;
     char* p = (char*)base;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return p ? p + o : nullptr; };
-    EvalWs t;
+    Ws t;
+    const size_t P = (size_t)h * w, B1 = B > 0 ? B : 1;
+    t.lab4 = (float4*)take(16 * B1 * P);
+    t.lab_planar = (float*)take(12 * B1 * P);
+    t.pred = (unsigned char*)take(B1 * P);
     t.colpart = (unsigned long long*)take(8 * (size_t)N1 * (cb_max > Sn ? cb_max : Sn) * w);
     t.rowkey = (unsigned long long*)take(8 * (size_t)N1 * h * (rp_max > 1 ? rp_max : 1));
     t.n_cb = (int)Sn; t.n_rp = 1;
-    t.inst = (InstRec*)take(sizeof(InstRec) * (size_t)N1);
-    t.work = (WorkRec2*)take(sizeof(WorkRec2) * (size_t)eval_cap(N, h, w, 1, 4));   // the largest list any (dil, R) produces
-    t.nwork = (int*)take(sizeof(int));
-    t.expect = (unsigned int*)take(4 * (size_t)N1);
+    t.tab = (int4*)take(16 * (size_t)(N1 + 1));
     t.acc1 = (unsigned long long*)take(8 * (size_t)kAcc1Words * kAcc2Stride);
+    t.sumw = (unsigned long long*)take(8);
     t.acc2 = (unsigned long long*)take(8 * (size_t)N1 * kAcc2Split * kAcc2Stride);
     t.dice = (unsigned long long*)take(8 * (size_t)N1);
+    t.fault = (unsigned int*)take(4);
     if (ws) *ws = t;
     return off;
 }
 
 // ================================================================================================
-// prep_kernel
+// launch 1
 // ================================================================================================
-// ---- role 1: table waves (one wave per instance) -------------------------------------------------------------
-struct LaneBox2 { int r0, r1, c0, c1, img, tr0, ntr, hc0, hc1, ntc; };
-__device__ __forceinline__ LaneBox2 lane_box2(const InstArgs& a, int dil, int R, int m) {
-    LaneBox2 lb = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+// ---- role 1: table waves (one wave per 64 table entries) --------------------------------------------------------------
+struct LaneBox { int r0, r1, c0, c1, img, cnt, vrow, vcol; };
+__device__ __forceinline__ int valid_cells(int limit_px, int stride, int n) {     // cells r with r*stride + stride/2 < limit_px
+    const int half = stride / 2;
+    const int v = limit_px - half <= 0 ? 0 : (limit_px - half + stride - 1) / stride;
+    return min(v, n);
+}
+__device__ __forceinline__ LaneBox lane_box(const InstArgs& a, const ImageMeta& meta, int dil, int R, int m) {
+    LaneBox lb = {0, 0, 0, 0, 0, 0, 0, 0};
     const int64_t g = a.gt_inds[m];
     const float* bp = nullptr;
-    for (int b = 0; b < a.gt.B; ++b)      // uniform loop: the by-value kernel argument is never indexed per lane
-        if (g >= a.gt.first[b] && g < a.gt.first[b + 1]) { bp = a.gt.boxes[b] + 4 * (g - a.gt.first[b]); lb.img = b; }
+    int ih = 0, iw = 0, fr = 0;
+    for (int b = 0; b < a.gt.B; ++b)      // uniform loop: the by-value kernel arguments are never indexed per lane
+        if (g >= a.gt.first[b] && g < a.gt.first[b + 1]) {
+            bp = a.gt.boxes[b] + 4 * (g - a.gt.first[b]); lb.img = b;
+            ih = meta.img_h[b]; iw = meta.img_w[b]; fr = meta.first_removed[b];
+        }
     if (!bp) return lb;
+    lb.vrow = valid_cells(min(ih, fr), a.stride, a.h);      // valid(q) <=> y(q) < img_h && y(q) < first_removed && x(q) < img_w (:1354-1369,:1405)
+    lb.vcol = valid_cells(iw, a.stride, a.w);
     const Rect rc = box_rect(bp, a.Hc, a.Wc, a.stride, a.stride / 2, a.h, a.w);
     if (rc.r1 <= rc.r0 || rc.c1 <= rc.c0) return lb;
     lb.r0 = rc.r0; lb.r1 = rc.r1; lb.c0 = rc.c0; lb.c1 = rc.c1;
     const int r0 = max(rc.r0 - dil, 0), r1 = min(rc.r1 + dil, a.h);
-    lb.hc0 = max(rc.c0 - dil, 0); lb.hc1 = min(rc.c1 + dil, a.w);
-    lb.tr0 = r0 / R; lb.ntr = (r1 - 1) / R - r0 / R + 1;
+    const int hc0 = max(rc.c0 - dil, 0), hc1 = min(rc.c1 + dil, a.w);
     const int tw = 64 - 2 * dil;
-    lb.ntc = (lb.hc1 - lb.hc0 + tw - 1) / tw;
+    lb.cnt = ((r1 - 1) / R - r0 / R + 1) * ((hc1 - hc0 + tw - 1) / tw);
     return lb;
 }
 
-__device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& meta, int dil, int R, float thresh,
-                                           const EvalWs& ws, const LossState& st, int n) {
+__device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& meta, int dil, int R, const Ws& ws, const LossState& st, int k) {
     const int lane = threadIdx.x & 63;
-    int base = 0, total = 0;
-    LaneBox2 mine = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int m0 = 0; m0 < a.N; m0 += 64) {           // exclusive scan of the tile counts: deterministic offsets, no atomics
+    int base = 0, prefix = 0;
+    LaneBox mine = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m0 = 0; m0 <= 64 * k; m0 += 64) {       // exclusive scan of the tile counts: deterministic offsets, no atomics
         const int m = m0 + lane;
-        LaneBox2 lb = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (m < a.N) lb = lane_box2(a, dil, R, m);
-        const int cm = lb.ntr * lb.ntc;
-        int incl = cm;
+        LaneBox lb = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (m < a.N) lb = lane_box(a, meta, dil, R, m);
+        int incl = lb.cnt;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int o = __shfl_up(incl, off, 64);
             if (lane >= off) incl += o;
         }
-        if (n >= m0 && n < m0 + 64) {
-            const int src = n - m0;
-            base = total + __shfl(incl - cm, src, 64);
-            mine.r0 = __shfl(lb.r0, src, 64); mine.r1 = __shfl(lb.r1, src, 64);
-            mine.c0 = __shfl(lb.c0, src, 64); mine.c1 = __shfl(lb.c1, src, 64); mine.img = __shfl(lb.img, src, 64);
-            mine.tr0 = __shfl(lb.tr0, src, 64); mine.ntr = __shfl(lb.ntr, src, 64);
-            mine.hc0 = __shfl(lb.hc0, src, 64); mine.hc1 = __shfl(lb.hc1, src, 64); mine.ntc = __shfl(lb.ntc, src, 64);
-        }
-        total += __shfl(incl, 63, 64);
+        if (m0 == 64 * k) { prefix = base + incl - lb.cnt; mine = lb; }
+        base += __shfl(incl, 63, 64);
     }
-    const int cnt = mine.ntr * mine.ntc;
-    const Pred pr = make_pred(thresh);
-    const int img = __builtin_amdgcn_readfirstlane(mine.img);
-    const int vr = min(meta.img_h[img], meta.first_removed[img]), vc = meta.img_w[img];
-    if (lane == 0) {
-        if (n == 0) { *ws.nwork = total; if (st.status) { st.status[0] = 0; st.status[1] = R; } }
-        InstRec rc; rc.r0 = mine.r0; rc.r1 = mine.r1; rc.c0 = mine.c0; rc.c1 = mine.c1; rc.img = mine.img;
-        rc.pad0 = rc.pad1 = rc.pad2 = 0;
-        ws.inst[n] = rc;
-        if (st.inst) st.inst[n] = rc;
-        ws.expect[n] = (unsigned int)cnt;
+    const int m = 64 * k + lane;
+    if (m < a.N) {
+        ws.tab[m] = make_int4(prefix | (mine.img << 24), mine.r0 | (mine.r1 << 16), mine.c0 | (mine.c1 << 16), mine.vrow | (mine.vcol << 16));
+        if (st.inst) { InstRec rc; rc.r0 = mine.r0; rc.r1 = mine.r1; rc.c0 = mine.c0; rc.c1 = mine.c1; rc.img = mine.img; rc.pad0 = rc.pad1 = rc.pad2 = 0; st.inst[m] = rc; }
+        // the words the next launch polls: zeroed here, i.e. before a kernel boundary (no hipMemsetAsync, no initialisation contract)
+#pragma unroll
+        for (int sub = 0; sub < kAcc2Split; ++sub) *acc2_word(ws.acc2, m, sub) = 0ull;
+        ws.dice[m] = 0ull;
+    } else if (m == a.N) {
+        ws.tab[m] = make_int4(prefix, 0, 0, 0);
     }
-    if (n == 0) ws.acc1[lane * kAcc2Stride] = 0ull;
-    if (lane < kAcc2Split) *acc2_word(ws.acc2, n, lane) = 0ull;
-    if (lane == 0) ws.dice[n] = 0ull;
-    if (st.colk) {      // "not published yet" (the leaders of the next launch publish; its math waves poll)
-        for (int i = lane; i < a.w; i += 64) st.colk[(int64_t)n * a.w + i] = kGranuleInvalid;
-        for (int i = lane; i < a.h; i += 64) st.rowk[(int64_t)n * a.h + i] = kGranuleInvalid;
-    }
-    for (int i = lane; i < cnt; i += 64) {
-        WorkRec2 wr;
-        wr.r0 = mine.r0; wr.r1 = mine.r1; wr.c0 = mine.c0; wr.c1 = mine.c1; wr.img = mine.img; wr.n = n;
-        wr.tile_r0 = (mine.tr0 + i / mine.ntc) * R; wr.tile_c0 = mine.hc0 + (i % mine.ntc) * (64 - 2 * dil);
-        wr.n2max = pr.n2max; wr.zero_bit = pr.zero_bit; wr.vr = vr; wr.vc = vc;
-        wr.hc1 = mine.hc1; wr.pad0 = wr.pad1 = wr.pad2 = 0;
-        ws.work[base + i] = wr;
+    if (k == 0) {
+        ws.acc1[(size_t)lane * kAcc2Stride] = 0ull;
+        if (lane == 0) *ws.sumw = 0ull;
+        if (lane == 0) { *ws.fault = 0u; if (st.status) { st.status[0] = 0; st.status[1] = R; } }
     }
 }
 
-// ---- role 2: stream block = 4 waves x 8 rows of one instance map -----------------------------------------------
-//   - zero-fill of d loss / d logits first (depends on nothing; pair_kernel overwrites the box tiles);
-//   - all 8 row loads in flight together; per-row max / first arg-max by 8 interleaved butterflies;
-//   - per-column max / first arg-max over the wave's rows in registers, over the block's 4 waves through LDS.
-// `src(r, c)` hands over logits (r, c .. c + 3) of instance n: loaded (LogitRows) or produced on the spot by the dynamic mask
-// head (HeadRows, head-fused variant); every (r, c) is asked for exactly once.
+// ---- role 2: stream block = 4 waves x 8 rows of one instance map ---------------------------------------------------------
 struct LogitRows {
     const float* L; int w, vec;
     __device__ __forceinline__ float4 operator()(int r, int c) const { return load4(L + (int64_t)r * w, c, w, vec); }
 };
 
 template <typename Src>
-__device__ __forceinline__ void stream_block(const InstArgs& a, const EvalWs& ws, float* __restrict__ g_logits, int vec, int sb,
-                                             unsigned long long* colp /* LDS [kWaves][w] */, const Src& src) {
+__device__ __forceinline__ void stream_block(const InstArgs& a, const Ws& ws, float* __restrict__ g_logits, int vec, int sb,
+                                             unsigned long long* colp /* LDS [kWaves][w] */, const Src& src, int tix) {
     const int h = a.h, w = a.w;
     const int Sn = (h + kSBlk - 1) / kSBlk;
     const int n = sb / Sn, s = sb % Sn;
@@ -218,9 +211,8 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const EvalWs& ws
     const int64_t P = (int64_t)h * w;
     float* G = g_logits ? g_logits + (int64_t)n * P : nullptr;
     const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    if (G)   // written through: see store4_through
+    if (G)   // zero-fill of d loss / d logits (depends on nothing); written through: drains while the launch is still reading
         for (int cb = 0; cb < w; cb += kChunkC) {
             const int c = cb + lane * 4;
             if (c < w) {
@@ -228,7 +220,9 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const EvalWs& ws
                 for (int i = 0; i < kSRows; ++i)
                     if (r0 + i < r1) {
                         if (vec) store4_through(G + (int64_t)(r0 + i) * w + c, 0.f, 0.f, 0.f, 0.f);
-                        else store4(G + (int64_t)(r0 + i) * w, c, w, false, zero);
+                        else
+                            for (int j = 0; j < 4; ++j)
+                                if (c + j < w) __hip_atomic_store(G + (int64_t)(r0 + i) * w + c + j, 0.f, BXI_RLX, BXI_AGENT);
                     }
             }
         }
@@ -238,7 +232,7 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const EvalWs& ws
 #pragma unroll
         for (int i = 0; i < kSRows; ++i) v[i] = (r0 + i < r1 && c < w) ? src(r0 + i, c) : ninf;
     }
-    BXI_TW(0, (int)blockIdx.x * kWaves + wv, 1);
+    BXI_TW(0, tix, 1);
     float rmax[kSRows]; int rcol[kSRows];
 #pragma unroll
     for (int i = 0; i < kSRows; ++i) { rmax[i] = -INFINITY; rcol[i] = 0; }
@@ -271,7 +265,7 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const EvalWs& ws
 #pragma unroll
         for (int i = 0; i < kSRows; ++i) v[i] = (r0 + i < r1 && c2 < w) ? src(r0 + i, c2) : ninf;
     }
-    BXI_TW(0, (int)blockIdx.x * kWaves + wv, 2);
+    BXI_TW(0, tix, 2);
     float wmax[kSRows];
 #pragma unroll
     for (int i = 0; i < kSRows; ++i) wmax[i] = rmax[i];
@@ -298,9 +292,9 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const EvalWs& ws
         if (lane == i) mine = pack_max(wmax[i], (uint32_t)col);
     }
     if (lane < kSRows && r0 + lane < r1) ws.rowkey[(int64_t)n * h + r0 + lane] = mine;
-    BXI_TW(0, (int)blockIdx.x * kWaves + wv, 3);
+    BXI_TW(0, tix, 3);
     lds_barrier();
-    BXI_TW(0, (int)blockIdx.x * kWaves + wv, 4);
+    BXI_TW(0, tix, 4);
     for (int c = threadIdx.x; c < w; c += kWaves * 64) {
         unsigned long long k = colp[c];
 #pragma unroll
@@ -309,8 +303,7 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const EvalWs& ws
     }
 }
 
-// ---- role 3: pool block = the 4 input rows of 64 pooled pixels --------------------------------------------------
-// Arithmetic identical to pool_finish_s4 / rgb2lab_f32 (image_device.hpp), only distributed differently.
+// ---- role 3: pool block = the 4 input rows of 64 pooled pixels ---------
 __device__ __forceinline__ double lab_f(const double* lut, int i, int r8, int g8, int b8) {
     const double r = lut[r8], g = lut[g8], b = lut[b8];
     const double M[3][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}, {0.019334, 0.119193, 0.950227}};
@@ -338,9 +331,14 @@ __device__ __forceinline__ void pool_load(const PoolArgs& pa, int item, int segs
     }
 }
 
+__device__ __forceinline__ float n2_of(float L0, float A0, float B0, float L1, float A1, float B1) {
+    const float dL = L0 - L1, dA = A0 - A1, dB = B0 - B1;     // un-fused: the decision must equal get_image_color_similarity's (:237)
+    return __fadd_rn(__fadd_rn(__fmul_rn(dL, dL), __fmul_rn(dA, dA)), __fmul_rn(dB, dB));
+}
+
 // items first, first + step, ... < n_items
-__device__ __forceinline__ void pool_block(const PoolArgs& pa, int first, int step, int n_items, double* lut /*[256]*/,
-                                           int* part /*[4][3][64]*/, double* fch /*[3][64]*/) {
+__device__ __forceinline__ void pool_block(const PoolArgs& pa, const Ws& ws, int first, int step, int n_items, double* lut /*[256]*/,
+                                           int* part /*[4][3][64]*/, double* fch /*[3][64]*/, int tix) {
     const int h = pa.Hc >> 2, w = pa.Wc >> 2;
     const int segs = (w + 63) >> 6;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -378,9 +376,9 @@ __device__ __forceinline__ void pool_block(const PoolArgs& pa, int first, int st
         }
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) part[(wv * 3 + ch) * 64 + lane] = sum[ch];
-        BXI_TW(0, (int)blockIdx.x * kWaves + wv, 1);
+        BXI_TW(0, tix, 1);
         lds_barrier();
-        BXI_TW(0, (int)blockIdx.x * kWaves + wv, 2);
+        BXI_TW(0, tix, 2);
         if (wv < 3) {                                     // wave-uniform: wave i takes channel i of XYZ -> f_i
             int px[3];
 #pragma unroll
@@ -389,48 +387,77 @@ __device__ __forceinline__ void pool_block(const PoolArgs& pa, int first, int st
                           part[(3 * 3 + ch) * 64 + lane]) >> 4;
             fch[wv * 64 + lane] = lab_f(lut, wv, px[0], px[1], px[2]);
         }
-        BXI_TW(0, (int)blockIdx.x * kWaves + wv, 3);
+        BXI_TW(0, tix, 3);
         lds_barrier();
-        BXI_TW(0, (int)blockIdx.x * kWaves + wv, 4);
-        if (wv < 3 && act && pa.lab) {
-            const double f1 = fch[64 + lane];
-            float o;
-            if (wv == 0) o = (float)__dadd_rn(__dmul_rn(116.0, f1), -16.0);
-            else if (wv == 1) o = (float)__dmul_rn(500.0, __dadd_rn(fch[lane], -f1));
-            else o = (float)__dmul_rn(200.0, __dadd_rn(f1, -fch[128 + lane]));
-            const int64_t P = (int64_t)h * w;
-            pa.lab[((int64_t)b * 3 + wv) * P + (int64_t)r * w + c] = o;
+        BXI_TW(0, tix, 4);
+        if (wv == 3 && act) {       // one 16-byte store per pooled pixel (the wave that had no channel to compute)
+            const double f0 = fch[lane], f1 = fch[64 + lane], f2 = fch[128 + lane];
+            ws.lab4[((int64_t)b * h + r) * w + c] = make_float4((float)__dadd_rn(__dmul_rn(116.0, f1), -16.0), (float)__dmul_rn(500.0, __dadd_rn(f0, -f1)),
+                                                                (float)__dmul_rn(200.0, __dadd_rn(f1, -f2)), 0.f);
+            ws.pred[((int64_t)b * h + r) * w + c] = 0;      // "not evaluated yet": the predicate waves of the next launch set bit 7
         }
-        // the next trip's `part` / `fch` writes come after barriers every wave has to reach: no extra barrier needed
+        // the next trip's `part` writes come after this barrier; its `fch` writes after the next one, which wave 3 reaches only
+        // after it has read `fch` here: no extra barrier needed
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) v[ch] = nx[ch];
     }
 }
 
-// ---- head-fused first launch ----------------------------------------------------------------------------------------
+// grid: [table blocks][pool blocks][stream blocks] (pool_first) or [table][stream][pool]
+__global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, Ws ws, LossState st,
+                                                       float* __restrict__ g_logits, int vec, int pool_first) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
+    const int Sn = (a.h + kSBlk - 1) / kSBlk;
+    const int n_stream = a.N * Sn;
+    const int blk = (int)blockIdx.x;
+    const int tix = blk * kWaves + (int)(threadIdx.x >> 6);
+    (void)tix;
+    BXI_TW(0, tix, 0);
+    int role = 0, idx = blk;                              // 0 table, 1 pool, 2 stream
+    if (blk >= n_tab) {
+        idx = blk - n_tab;
+        const int n_a = pool_first ? n_pool : n_stream;
+        if (idx < n_a) role = pool_first ? 1 : 2;
+        else { idx -= n_a; role = pool_first ? 2 : 1; }
+    }
+    if (role == 0) {
+        const int k = blk * kWaves + (int)(threadIdx.x >> 6);
+        if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, ws, st, k);
+    } else if (role == 2) {
+        const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
+        stream_block(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);
+    } else {
+        double* lut = reinterpret_cast<double*>(smem);
+        double* fch = lut + 256;
+        int* part = reinterpret_cast<int*>(fch + 3 * 64);
+        pool_block(pa, ws, idx, n_pool, n_items, lut, part, fch, tix);
+    }
+    BXI_TW(0, tix, 7);
+}
+
+// ---- head-fused first launch ----------------------------------------------------------------------------
 // CondInstMaskHead.forward (condinst_head.py:1139-1164) and the evaluation's first launch as ONE grid of independent roles:
 //   [table blocks][pool blocks][head tiles: instance x 8 x 32 tiles of y -> 16 x 64 logits]
-// The head tiles are dyn_fwd_kernel's workgroups (dynamic_head_device.hpp) with an epilogue that does the stream role's job on
-// the tile they just produced: zero-fill of the gradient tile, per-row and per-column (value, first index) maxima as partials
-// for the leaders.  Nothing in the launch waits for anything else in it: the HBM-bound image pooling and the issue-bound MLP
-// simply run side by side, one launch, one boundary and one 6.5 MB read of the logits fewer than dyn_fwd + prep: 20.0 us against
-// 13.4 + 11.4 us (rocprofv3, tools/bench_head_fused.py).  (Pool blocks dealt evenly among the head tiles instead of first: 21.1 us.
-// The first attempt put the MLP into the stream blocks -- 224 workgroups, 4.5 dependent rounds a wave: 30.9 us.)
+// A head tile does the stream role's job on the tile it just produced: zero-filled gradient tile (written through), per-row and
+// per-column (value, first index) maxima as partials for the leaders.  Nothing in the launch waits for anything else in it.
 template <int C, bool REL>
-__global__ __launch_bounds__(256, 7) void head_prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, float thresh,
-                                                           EvalWs ws, LossState st, float* __restrict__ g_logits, DynArgs da,
-                                                           const float* __restrict__ params, float* __restrict__ logits_out) {
+__global__ __launch_bounds__(256, 7) void head_prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, Ws ws, LossState st,
+                                                            float* __restrict__ g_logits, DynArgs da, const float* __restrict__ params,
+                                                            float* __restrict__ logits_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int n_tab = (a.N + kWaves - 1) / kWaves;
+    const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
     const int blk = (int)blockIdx.x;
+    const int tix = blk * kWaves + (int)(threadIdx.x >> 6);
+    (void)tix;
     if (blk < n_tab) {
-        const int n = blk * kWaves + (int)(threadIdx.x >> 6);
-        if (n < a.N) table_wave(a, pa.meta, dil, R, thresh, ws, st, n);
+        const int k = blk * kWaves + (int)(threadIdx.x >> 6);
+        if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, ws, st, k);
     } else if (blk < n_tab + n_pool) {
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
         int* part = reinterpret_cast<int*>(fch + 3 * 64);
-        pool_block(pa, blk - n_tab, n_pool, n_items, lut, part, fch);
+        pool_block(pa, ws, blk - n_tab, n_pool, n_items, lut, part, fch, tix);
     } else {
         const int tiles_x = (da.W + kYC - 1) / kYC, tiles_y = (da.H + kYR - 1) / kYR;
         int t = blk - n_tab - n_pool;
@@ -445,37 +472,29 @@ __global__ __launch_bounds__(256, 7) void head_prep_kernel(PoolArgs pa, int n_po
     }
 }
 
-// grid: [ceil(N/4) table blocks][N*Sn stream blocks][pool blocks].  The table waves carry dependent scalar chains, so
-// they go first; the stream blocks precede the pool blocks because their data feeds the next launch's first workgroups.
-__global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, float thresh, EvalWs ws,
-                                                   LossState st, float* __restrict__ g_logits, int vec) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int n_tab = (a.N + kWaves - 1) / kWaves;
-    const int n_stream = a.N * ((a.h + kSBlk - 1) / kSBlk);
-    const int blk = (int)blockIdx.x;
-    const int tix = blk * kWaves + (int)(threadIdx.x >> 6);
-    (void)tix;
-    BXI_TW(0, tix, 0);
-    if (blk < n_tab) {
-        const int n = blk * kWaves + (int)(threadIdx.x >> 6);
-        if (n < a.N) table_wave(a, pa.meta, dil, R, thresh, ws, st, n);
-    } else if (blk < n_tab + n_stream) {
-        const int Sn = (a.h + kSBlk - 1) / kSBlk;
-        const LogitRows rows = {a.logits + (int64_t)((blk - n_tab) / Sn) * a.h * a.w, a.w, vec};
-        stream_block(a, ws, g_logits, vec, blk - n_tab, reinterpret_cast<unsigned long long*>(smem), rows);
-    } else {
-        double* lut = reinterpret_cast<double*>(smem);
-        double* fch = lut + 256;
-        int* part = reinterpret_cast<int*>(fch + 3 * 64);
-        pool_block(pa, blk - n_tab - n_stream, n_pool, n_items, lut, part, fch);
+// ---- the image side for strides other than 4 / unaligned canvases: launches of their own (pool_rgb_generic of
+// color_affinity.hip -> Lab planes, then this repacking) -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_lab4_kernel(const float* __restrict__ lab, float4* __restrict__ lab4, unsigned char* __restrict__ pred, int B,
+                                                        int64_t P) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * P; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / P, p = i - b * P;
+        const float* src = lab + b * 3 * P + p;
+        lab4[i] = make_float4(src[0], src[P], src[2 * P], 0.f);
+        pred[i] = 0;
     }
-    BXI_TW(0, tix, 7);
 }
 
 // ================================================================================================
-// pair_kernel
+// launch 2
 // ================================================================================================
 template <int D, int R> struct TG { static constexpr int RD = R + 2 * D, TW = 64 - 2 * D; };
+
+struct Tile {                                   // wave-uniform (SGPRs)
+    int r0, r1, c0, c1;                         // cells whose sample lies in the GT box (bitmask == 1)
+    int img, n, tile_r0, tile_c0;
+    int vrow, vcol;                             // valid(q) <=> row(q) < vrow && col(q) < vcol
+    int hc1;                                    // end column of the instance's tile hull (= dilated box)
+};
 
 struct TileFlags {   // bit j = data row j (map row tile_r0 - D + j) of this lane's column; R = the lane D to the right
     uint32_t ib, vd, ow, ibR, vdR, owR;       // in GT box ; valid image pixel ; owned by this tile
@@ -488,30 +507,27 @@ __device__ __forceinline__ uint32_t row_bits(int lo, int hi, int base, int n) { 
 }
 
 template <int D, int R>
-__device__ __forceinline__ TileFlags tile_flags(const WorkRec2& wr, int h, int w, int stride, int lane) {
+__device__ __forceinline__ TileFlags tile_flags(const Tile& t, int h, int w, int lane) {
     constexpr int RD = TG<D, R>::RD;
-    const int base = wr.tile_r0 - D;
-    const int cl = wr.tile_c0 - D + lane;
-    const int half = stride / 2;
-    const int vrow = wr.vr - half <= 0 ? 0 : (wr.vr - half + stride - 1) / stride;      // r valid <=> r*stride + half < vr
-    const int vcol = wr.vc - half <= 0 ? 0 : (wr.vc - half + stride - 1) / stride;
-    const uint32_t rows_box = row_bits(wr.r0, wr.r1, base, RD);
-    const uint32_t rows_val = row_bits(0, min(h, vrow), base, RD);
-    const uint32_t rows_own = row_bits(wr.tile_r0, min(wr.tile_r0 + R, h), base, RD);
-    const int cv = min(w, vcol);
+    const int base = t.tile_r0 - D;
+    const int cl = t.tile_c0 - D + lane;
+    const uint32_t rows_box = row_bits(t.r0, t.r1, base, RD);
+    const uint32_t rows_val = row_bits(0, min(h, t.vrow), base, RD);
+    const uint32_t rows_own = row_bits(t.tile_r0, min(t.tile_r0 + R, h), base, RD);
+    const int cv = min(w, t.vcol);
     TileFlags f;
     {
         const int c = cl, ln = lane;
-        f.ib = (c >= wr.c0 && c < wr.c1) ? rows_box : 0u;
+        f.ib = (c >= t.c0 && c < t.c1) ? rows_box : 0u;
         f.vd = (c >= 0 && c < cv) ? rows_val : 0u;
-        f.ow = (ln >= D && ln < 64 - D && c < wr.hc1) ? rows_own : 0u;
+        f.ow = (ln >= D && ln < 64 - D && c < t.hc1) ? rows_own : 0u;
     }
     {
         const int c = cl + D, ln = lane + D;
         const bool in = ln < 64;      // lanes without a right neighbour: every pair weight 0 (they receive some other lane's data)
-        f.ibR = (in && c >= wr.c0 && c < wr.c1) ? rows_box : 0u;
+        f.ibR = (in && c >= t.c0 && c < t.c1) ? rows_box : 0u;
         f.vdR = (in && c >= 0 && c < cv) ? rows_val : 0u;
-        f.owR = (in && ln >= D && ln < 64 - D && c < wr.hc1) ? rows_own : 0u;
+        f.owR = (in && ln >= D && ln < 64 - D && c < t.hc1) ? rows_own : 0u;
     }
     return f;
 }
@@ -519,98 +535,21 @@ __device__ __forceinline__ TileFlags tile_flags(const WorkRec2& wr, int h, int w
 // The four pair directions of a step i (j = i + D), every one between this lane and the lane D to its right or itself, so
 // that only right-neighbour values are ever fetched:
 //   0: A = (i, l)  B = (i, l + D)   |   1: A = (j, l)  B = (i, l + D)   |   2: A = (i, l)  B = (j, l)   |   3: A = (i, l)  B = (j, l + D)
-// masks, bit i = the pair of step i:  W[k, A] = mA, W[7 - k, B] = mB (zero_bit == 0: the fast paths are not taken otherwise),
-// and the same restricted to pixels this tile owns.
+// masks, bit i = the pair of step i:  W[k, A] = mA, W[7 - k, B] = mB, and the same restricted to pixels this tile owns;
+// `pb` = the colour predicates of the steps (launch 1's bytes, transposed).
 struct DirMasks { uint32_t mA, mB, nA, nB; };
 template <int D>
-__device__ __forceinline__ void dir_masks(const TileFlags& f, DirMasks (&m)[4]) {
+__device__ __forceinline__ void dir_masks(const TileFlags& f, const uint32_t (&pb)[4], DirMasks (&m)[4]) {
     m[0].mA = f.ib & f.vdR;          m[0].mB = f.ibR & f.vd;          m[0].nA = m[0].mA & f.ow;        m[0].nB = m[0].mB & f.owR;
     m[1].mA = (f.ib >> D) & f.vdR;   m[1].mB = f.ibR & (f.vd >> D);   m[1].nA = m[1].mA & (f.ow >> D); m[1].nB = m[1].mB & f.owR;
     m[2].mA = f.ib & (f.vd >> D);    m[2].mB = (f.ib >> D) & f.vd;    m[2].nA = m[2].mA & f.ow;        m[2].nB = m[2].mB & (f.ow >> D);
     m[3].mA = f.ib & (f.vdR >> D);   m[3].mB = (f.ibR >> D) & f.vd;   m[3].nA = m[3].mA & f.ow;        m[3].nB = m[3].mB & (f.owR >> D);
-}
-
-template <int D, int R>
-__device__ __forceinline__ void load_plane(const float* __restrict__ plane, const WorkRec2& wr, int h, int w, int lane,
-                                           float (&v)[R + 2 * D]) {
-    const uint32_t cc4 = (uint32_t)min(max(wr.tile_c0 - D + lane, 0), w - 1) * 4u;
-    const char* pb = reinterpret_cast<const char*>(plane);                       // scalar (the record is): base + 32-bit byte offset,
-#pragma unroll                                                                   // no 64-bit address arithmetic per load (one plane < 2^31 bytes)
-    for (int j = 0; j < R + 2 * D; ++j) {
-        const uint32_t rr = (uint32_t)min(max(wr.tile_r0 - D + j, 0), h - 1);       // clamped: pairs with a pixel outside the map weigh 0
-        v[j] = *reinterpret_cast<const float*>(pb + (rr * (uint32_t)w * 4u + cc4));
-    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { m[d].mA &= pb[d]; m[d].mB &= pb[d]; m[d].nA &= pb[d]; m[d].nB &= pb[d]; }
 }
 
 __device__ __forceinline__ uint32_t spread4(uint32_t x4) { return (x4 * 0x00204081u) & 0x01010101u; }   // bits 0..3 -> bytes 0..3
 
-__device__ __forceinline__ float n2_of(float L0, float A0, float B0, float L1, float A1, float B1) {
-    const float dL = L0 - L1, dA = A0 - A1, dB = B0 - B1;     // un-fused: the decision must equal the affinity kernel's
-    return __fadd_rn(__fadd_rn(__fmul_rn(dL, dL), __fmul_rn(dA, dA)), __fmul_rn(dB, dB));
-}
-
-// Generic (slow) evaluation of one tile: ordered pairs per owned pixel straight from global memory, pair value and
-// gradient in log space exactly as pairwise.cu:38-61.  Taken for thresh <= 0 (zero_bit: padded / masked-out neighbours
-// weigh 1) and for tiles with saturated logits (S underflows).  Returns the lane's sum W (and sum W pw, gradients -> gout).
-template <int D, int R>
-__device__ __forceinline__ int slow_tile(const float* __restrict__ Lg, const float* __restrict__ lab, int64_t P, int4 box, int img,
-                                      int tile_r0, int tile_c0, float n2max, int zero_bit, int vr, int vc, int hc1, int h,
-                                      int w, int stride, int lane, bool want_grad, float* gout /* LDS [R + 1][64]: gradients, then sum W pw */) {
-    struct { int r0, r1, c0, c1, img, tile_r0, tile_c0; float n2max; int zero_bit, vr, vc, hc1; } wr =
-        {box.x, box.y, box.z, box.w, img, tile_r0, tile_c0, n2max, zero_bit, vr, vc, hc1};
-    const int half = stride / 2;
-    const int c = wr.tile_c0 - D + lane;
-    const bool col_owned = lane >= D && lane < 64 - D && c < wr.hc1;
-    int cnt = 0;
-    float num = 0.f;
-    const float* L0p = lab + (int64_t)wr.img * 3 * P;
-#pragma unroll 1
-    for (int j = 0; j < R; ++j) {
-        const int r = wr.tile_r0 + j;
-        float gacc = 0.f;
-        if (col_owned && r < h) {
-            const bool in_p = r >= wr.r0 && r < wr.r1 && c >= wr.c0 && c < wr.c1;
-            const bool val_p = r * stride + half < wr.vr && c * stride + half < wr.vc;
-            const int64_t pi = (int64_t)r * w + c;
-            const float lp0 = L0p[pi], lp1 = L0p[P + pi], lp2 = L0p[2 * P + pi];
-            const float xa = want_grad ? Lg[pi] : 0.f;
-            const float ax = logsig(xa), bx = logsig(-xa);
-#pragma unroll 1
-            for (int k = 0; k < 8; ++k) {
-                const int kk = k < 4 ? k : k + 1;
-                const int r2 = r + (kk / 3 - 1) * D, c2 = c + (kk % 3 - 1) * D;
-                const bool inq = r2 >= 0 && r2 < h && c2 >= 0 && c2 < w;
-                uint32_t pn = 0u;
-                int64_t qi = 0;
-                if (inq) {
-                    qi = (int64_t)r2 * w + c2;
-                    pn = n2_of(lp0, lp1, lp2, L0p[qi], L0p[P + qi], L0p[2 * P + qi]) <= wr.n2max ? 1u : 0u;
-                }
-                const bool val_q = inq && r2 * stride + half < wr.vr && c2 * stride + half < wr.vc;
-                const bool in_q = inq && r2 >= wr.r0 && r2 < wr.r1 && c2 >= wr.c0 && c2 < wr.c1;
-                const uint32_t wp = in_p ? (val_q ? pn : (uint32_t)wr.zero_bit) : 0u;
-                const uint32_t wq = in_q ? (val_p ? pn : (uint32_t)wr.zero_bit) : 0u;
-                cnt += (int)wp;                                   // weights.sum() counts padded pairs too (:1328)
-                if (want_grad && inq && (wp + wq)) {
-                    const float xb = Lg[qi];
-                    const float ay = logsig(xb), by = logsig(-xb);
-                    const float e1 = ax + ay, e0 = bx + by;
-                    const float nl2 = logsig(fabsf(e1 - e0)) - fmaxf(e1, e0);
-                    num += (float)wp * nl2;
-                    gacc += (float)(wp + wq) * (-(expf(ay) - expf(by)) * expf(ax + bx + nl2));
-                }
-            }
-        }
-        if (want_grad) gout[j * 64 + lane] = gacc;
-    }
-    if (want_grad) gout[R * 64 + lane] = num;
-    return cnt;
-}
-
-// The value of lane + D / lane - D, by D wavefront rotations of one lane on the VALU's data-parallel path instead of a trip
-// through the LDS crossbar (ds_bpermute).  A rotation, not a shift: every lane receives something (the last D lanes receive
-// lanes 0..D-1: finite data of the same tile), so the instruction needs no "old" operand and no copy in front of it; whatever
-// those lanes compute from it is weighted 0 (TileFlags) or discarded by the caller.
 template <int D>
 __device__ __forceinline__ float lane_plus(float v) {
     int x = __float_as_int(v);
@@ -626,132 +565,227 @@ __device__ __forceinline__ float lane_minus(float v) {
     return __int_as_float(x);
 }
 
-// ---- count wave: sum over the tile's owned pixels of W[k,p] (Lab only) -------------------------------------------
+// Generic (slow) evaluation of one tile: ordered pairs per owned pixel straight from global memory, pair value and
+// gradient in log space exactly as pairwise.cu:38-61.  Taken for thresh <= 0 (zero_bit: padded / masked-out neighbours
+// weigh 1) and for tiles with saturated logits (S underflows).  Gradients -> gout, the lane's sum W pw -> gout[R].
 template <int D, int R>
-__device__ __forceinline__ void count_tile(const InstArgs& a, const float* __restrict__ lab, const EvalWs& ws, const WorkRec2& wr, int tix) {
-    constexpr int RD = TG<D, R>::RD;
-    const int lane = threadIdx.x & 63;
-    const int h = a.h, w = a.w;
-    const int64_t P = (int64_t)h * w;
-    int cnt = 0;
-    if (wr.zero_bit) {
-        cnt = slow_tile<D, R>(nullptr, lab, P, make_int4(wr.r0, wr.r1, wr.c0, wr.c1), wr.img, wr.tile_r0, wr.tile_c0, wr.n2max, wr.zero_bit,
-                                wr.vr, wr.vc, wr.hc1, h, w, a.stride, lane, false, nullptr);
-    } else {
-        float L[RD], A[RD], B[RD];
-        const float* lp = lab + (int64_t)wr.img * 3 * P;
-        load_plane<D, R>(lp, wr, h, w, lane, L);
-        load_plane<D, R>(lp + P, wr, h, w, lane, A);
-        load_plane<D, R>(lp + 2 * P, wr, h, w, lane, B);
-        const TileFlags f = tile_flags<D, R>(wr, h, w, a.stride, lane);
-        DirMasks m[4];
-        dir_masks<D>(f, m);
-        BXI_TW(2, tix, 1);
-        float LR[RD], AR[RD], BR[RD];
-#pragma unroll
-        for (int i = 0; i < RD; ++i) { LR[i] = lane_plus<D>(L[i]); AR[i] = lane_plus<D>(A[i]); BR[i] = lane_plus<D>(B[i]); }
-        uint32_t pb[4] = {0u, 0u, 0u, 0u};        // bit i = the colour predicate of the pair of step i
-#pragma unroll
-        for (int i = 0; i < R + D; ++i) {
-            const int j = i + D;
-            if (i == 1) BXI_TW(2, tix, 2);
-            if (i >= D) pb[0] |= n2_of(L[i], A[i], B[i], LR[i], AR[i], BR[i]) <= wr.n2max ? 1u << i : 0u;
-            pb[1] |= n2_of(L[j], A[j], B[j], LR[i], AR[i], BR[i]) <= wr.n2max ? 1u << i : 0u;
-            pb[2] |= n2_of(L[i], A[i], B[i], L[j], A[j], B[j]) <= wr.n2max ? 1u << i : 0u;
-            pb[3] |= n2_of(L[i], A[i], B[i], LR[j], AR[j], BR[j]) <= wr.n2max ? 1u << i : 0u;
+__device__ __forceinline__ void slow_tile(const float* __restrict__ Lg, const float4* __restrict__ lab4, const Tile& t, float n2max, int zero_bit,
+                                          int h, int w, int lane, float* gout /* LDS [R + 1][64] */) {
+    const int c = t.tile_c0 - D + lane;
+    const bool col_owned = lane >= D && lane < 64 - D && c < t.hc1;
+    float num = 0.f;
+    const float4* L0p = lab4 + (int64_t)t.img * h * w;
+#pragma unroll 1
+    for (int j = 0; j < R; ++j) {
+        const int r = t.tile_r0 + j;
+        float gacc = 0.f;
+        if (col_owned && r < h) {
+            const bool in_p = r >= t.r0 && r < t.r1 && c >= t.c0 && c < t.c1;
+            const bool val_p = r < t.vrow && c < t.vcol;
+            const int64_t pi = (int64_t)r * w + c;
+            const float4 lp = L0p[pi];
+            const float xa = Lg[pi];
+            const float ax = logsig(xa), bx = logsig(-xa);
+#pragma unroll 1
+            for (int k = 0; k < 8; ++k) {
+                const int kk = k < 4 ? k : k + 1;
+                const int r2 = r + (kk / 3 - 1) * D, c2 = c + (kk % 3 - 1) * D;
+                const bool inq = r2 >= 0 && r2 < h && c2 >= 0 && c2 < w;
+                uint32_t pn = 0u;
+                int64_t qi = 0;
+                if (inq) {
+                    qi = (int64_t)r2 * w + c2;
+                    const float4 lq = L0p[qi];
+                    pn = n2_of(lp.x, lp.y, lp.z, lq.x, lq.y, lq.z) <= n2max ? 1u : 0u;
+                }
+                const bool val_q = inq && r2 < t.vrow && c2 < t.vcol;
+                const bool in_q = inq && r2 >= t.r0 && r2 < t.r1 && c2 >= t.c0 && c2 < t.c1;
+                const uint32_t wp = in_p ? (val_q ? pn : (uint32_t)zero_bit) : 0u;
+                const uint32_t wq = in_q ? (val_p ? pn : (uint32_t)zero_bit) : 0u;
+                if (inq && (wp + wq)) {
+                    const float xb = Lg[qi];
+                    const float ay = logsig(xb), by = logsig(-xb);
+                    const float e1 = ax + ay, e0 = bx + by;
+                    const float nl2 = logsig(fabsf(e1 - e0)) - fmaxf(e1, e0);
+                    num += (float)wp * nl2;
+                    gacc += (float)(wp + wq) * (-(expf(ay) - expf(by)) * expf(ax + bx + nl2));
+                }
+            }
         }
-#pragma unroll
-        for (int dir = 0; dir < 4; ++dir) cnt += __popc(pb[dir] & m[dir].nA) + __popc(pb[dir] & m[dir].nB);
+        gout[j * 64 + lane] = gacc;
     }
-    cnt = wave_total_i32(cnt);
-    BXI_TW(2, tix, 3);
-    if (lane == 0)   // one packed atomic per tile: (arrival, sum W); integer adds commute -> run-to-run identical
-        __hip_atomic_fetch_add(&ws.acc1[((wr.n * 7 + wr.tile_r0 / R + wr.tile_c0) & (kAcc1Words - 1)) * kAcc2Stride],
-                               (1ull << 40) | (unsigned long long)(unsigned int)cnt, BXI_RLX, BXI_AGENT);
+    gout[R * 64 + lane] = num;
 }
 
-// One round over the count words: true when every tile of the list has been counted; then *total = sum W over all instances.
-__device__ __forceinline__ bool counts_complete(const EvalWs& ws, int nwork, double* total) {
-    const unsigned long long x = __hip_atomic_load(&ws.acc1[(threadIdx.x & 63) * kAcc2Stride], BXI_RLX, BXI_AGENT);
-    const double arrived = (double)wave_total_i32((int)(x >> 40)), s = wave_total_f64((double)(x & ((1ull << 40) - 1ull)));   // exact: integers far below 2^31 / 2^53
-    *total = s;
-    return arrived == (double)nwork;
-}
-
-// The finisher's round: everything the two loss values are made of, requested together -- the tile arrivals and sums W pw
-// (8 words per instance, arrival count and sum in one word), the dice granules, the count words -- so that the round in
-// which everything turns out to be complete is also the round that delivers the data (three dependent rounds past the
-// caches, ~1 us each, used to follow the last tile's arrival: check, sum W, then the sums again; the launch ends on them).
-// Instances [b0, b0 + 64).  Returns whether all of them are complete; adds their sums.
-__device__ __forceinline__ bool finisher_round(const EvalWs& ws, int N, int b0, unsigned int expect, double* num, float* dsum) {
-    const int lane = threadIdx.x & 63, i = b0 + lane;
-    unsigned long long x = 0ull, dg = 1ull << 32;
-    if (i < N) {
-        unsigned long long w[kAcc2Split];
-#pragma unroll
-        for (int sub = 0; sub < kAcc2Split; ++sub) w[sub] = __hip_atomic_load(acc2_word(ws.acc2, i, sub), BXI_RLX, BXI_AGENT);
-        dg = __hip_atomic_load(&ws.dice[i], BXI_RLX, BXI_AGENT);
-#pragma unroll
-        for (int sub = 0; sub < kAcc2Split; ++sub) x += w[sub];
-    }
-    const bool have = i >= N || ((unsigned int)(x >> 52) == expect && (dg >> 32) != 0ull);
-    if (!__all(have)) return false;
-    const long long fixed = (long long)(x & ((1ull << 52) - 1ull)) - ((long long)expect << 24);   // the +1 per tile
-    *num += wave_total_f64(i < N ? (double)fixed : 0.0);
-    const float dv = i < N ? __uint_as_float((unsigned int)dg) : 0.f;
-    const int m = min(64, N - b0);
-    for (int k = 0; k < m; ++k) *dsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), k));   // index order
-    return true;
-}
-
-__device__ __forceinline__ void write_losses(const LossState& st, int N, float warmup, double total_w, double num, float dsum,
-                                             float upp, float upw, float* __restrict__ losses) {
-    if ((threadIdx.x & 63) == 0) {
-        const float denom = fmaxf((float)total_w, 1.f);                      // weights.sum().clamp(min=1.0), :1328
-        losses[0] = dsum / (float)N;                                         // .mean(), :143
-        losses[1] = (float)((num / (double)kNumScale) / (double)denom) * warmup;   // :1327-1332
-        if (st.scale) { *st.scale = warmup / denom; st.applied[0] = upp; st.applied[1] = upw; }
-    }
-}
-
-// ---- math wave ---------------------------------------------------------------------------------------------------
 template <int D, int R>
-__device__ __forceinline__ void math_tile(const InstArgs& a, const float* __restrict__ lab, const EvalWs& ws, const LossState& st,
-                                          const WorkRec2& wr, float warmup, float upp, float upw, float* __restrict__ losses,
-                                          float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
-                                          double& total_w, bool& have_total, int nwork, int tix) {
+__device__ __forceinline__ void load_plane(const float* __restrict__ plane, const Tile& t, int h, int w, int lane, float (&v)[R + 2 * D]) {
+    const uint32_t cc4 = (uint32_t)min(max(t.tile_c0 - D + lane, 0), w - 1) * 4u;
+    const char* pb = reinterpret_cast<const char*>(plane);                       // scalar base + 32-bit byte offset (one plane < 2^31 bytes)
+#pragma unroll
+    for (int j = 0; j < R + 2 * D; ++j) {
+        const uint32_t rr = (uint32_t)min(max(t.tile_r0 - D + j, 0), h - 1);       // clamped: pairs with a pixel outside the map weigh 0
+        v[j] = *reinterpret_cast<const float*>(pb + (rr * (uint32_t)w * 4u + cc4));
+    }
+}
+
+// ---- predicate wave: one pooled row segment (64 pixels) of one image ------------------------------------------------------
+// The colour pairs whose step row is pooled row r of segment `seg` of image b -- directions (get_image_color_similarity :220-246
+// through unfold_wo_center's offsets :190-217, each unordered pair ONCE PER IMAGE, not once per instance and tile):
+//   0: (r, c) - (r, c+D)    1: (r+D, c) - (r, c+D)    2: (r, c) - (r+D, c)    3: (r, c) - (r+D, c+D)
+// -> one predicate byte per pixel (bit d: squared Lab distance <= n2max, i.e. sim >= thresh for a valid neighbour), and the
+// segment's share of  sum W = sum_n sum_{p in box n} sum_k [sim_k(p) >= thresh]  (:1324-1328): a pair (p, q) weighs
+// [p in box n][q valid] + [q in box n][p valid] for every instance n of the image (returned per lane; the workgroup arrives
+// once with its total).  A byte carries its own "evaluated" bit: a tile wave re-reads the few bytes it needs until they have it.
+__device__ __forceinline__ float lane_plus_n(float v, int d) {
+    int x = __float_as_int(v);
+    for (int s = 0; s < d; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+    return __int_as_float(x);
+}
+struct ValidCells { int vrow[BXI_MAX_IMAGES], vcol[BXI_MAX_IMAGES]; };   // per image: valid(q) <=> row(q) < vrow && col(q) < vcol (host: :1354-1369,:1405)
+__device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc, const Ws& ws, int D, float n2max, int item, int segs) {
+    const int h = a.h, w = a.w, lane = threadIdx.x & 63;
+    const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
+    const int c = seg * 64 + lane, cn = c + D;
+    const bool rowD = r + D < h;                                  // wave-uniform
+    const float4* L4 = ws.lab4 + (int64_t)b * h * w;
+    const int cc = min(c, w - 1), cx = min(lane >= 64 - D ? cn : c, w - 1), rD = min(r + D, h - 1);
+    // this row, the row D below, and for the last D lanes their right neighbours (they live in the next segment)
+    const float4 o0 = L4[(int64_t)r * w + cc], oD = L4[(int64_t)rD * w + cc], x0 = L4[(int64_t)r * w + cx], xD = L4[(int64_t)rD * w + cx];
+    // lane n: instance n's table entry (box cells, image), requested with the Lab
+    int4 rect = lane < a.N ? ws.tab[lane] : make_int4(-1, 0, 0, 0);
+    float nL = lane_plus_n(o0.x, D), nA = lane_plus_n(o0.y, D), nB = lane_plus_n(o0.z, D);
+    float mL = lane_plus_n(oD.x, D), mA = lane_plus_n(oD.y, D), mB = lane_plus_n(oD.z, D);
+    if (lane >= 64 - D) { nL = x0.x; nA = x0.y; nB = x0.z; mL = xD.x; mA = xD.y; mB = xD.z; }
+    const bool cin = c < w, nin = cn < w;
+    const bool p0 = cin && nin && n2_of(o0.x, o0.y, o0.z, nL, nA, nB) <= n2max;
+    const bool p1 = cin && nin && rowD && n2_of(oD.x, oD.y, oD.z, nL, nA, nB) <= n2max;
+    const bool p2 = cin && rowD && n2_of(o0.x, o0.y, o0.z, oD.x, oD.y, oD.z) <= n2max;
+    const bool p3 = cin && nin && rowD && n2_of(o0.x, o0.y, o0.z, mL, mA, mB) <= n2max;
+    if (cin) __hip_atomic_store(ws.pred + ((int64_t)b * h + r) * w + c, (unsigned char)(0x80 | (p0 ? 1 : 0) | (p1 ? 2 : 0) | (p2 ? 4 : 0) | (p3 ? 8 : 0)),
+                                BXI_RLX, BXI_AGENT);     // bit 7: evaluated (launch 1 left 0); written through (sc1), read past the caches
+    const int vrow = vc.vrow[b], vcol = vc.vcol[b];
+    const bool v00 = r < vrow && c < vcol, v0n = r < vrow && cn < vcol, vD0 = r + D < vrow && c < vcol, vDn = r + D < vrow && cn < vcol;
+    // what a box containing the site adds:  (r, c)  (r, c+D)  (r+D, c)  (r+D, c+D)
+    const int s00 = (p0 && v0n) + (p2 && vD0) + (p3 && vDn), s0n = (p0 && v00) + (p1 && vD0), sD0 = (p1 && v0n) + (p2 && v00), sDn = (p3 && v00) ? 1 : 0;
+    int cnt = 0;
+    for (int m0 = 0; m0 < a.N; m0 += 64) {
+        if (m0) rect = m0 + lane < a.N ? ws.tab[m0 + lane] : make_int4(-1, 0, 0, 0);
+        // the instances of this image whose rows reach r or r + D: usually a handful
+        const int q0 = rect.y & 0xffff, q1 = (int)((unsigned int)rect.y >> 16);
+        unsigned long long mask = __ballot(m0 + lane < a.N && (int)((unsigned int)rect.x >> 24) == b && ((r >= q0 && r < q1) || (r + D >= q0 && r + D < q1)));
+        while (mask) {
+            const int n = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            const int ry = __builtin_amdgcn_readlane(rect.y, n), rz = __builtin_amdgcn_readlane(rect.z, n);
+            const int r0 = ry & 0xffff, r1 = (int)((unsigned int)ry >> 16), c0 = rz & 0xffff, c1 = (int)((unsigned int)rz >> 16);
+            const bool rr = r >= r0 && r < r1, rD2 = r + D >= r0 && r + D < r1;
+            const bool c_in = c >= c0 && c < c1, n_in = cn >= c0 && cn < c1;
+            cnt += (rr && c_in ? s00 : 0) + (rr && n_in ? s0n : 0) + (rD2 && c_in ? sD0 : 0) + (rD2 && n_in ? sDn : 0);
+        }
+    }
+    return cnt;
+}
+
+// sum W, once every pooled row segment has been evaluated: ONE word for the (hundreds of) askers; the reducer -- one wave of the
+// finisher workgroup -- watches the 64 count words and publishes it.
+__device__ __forceinline__ bool counts_complete(const Ws& ws, int n_items, double* total) {
+    (void)n_items;
+    const unsigned long long x = __hip_atomic_load(ws.sumw, BXI_RLX, BXI_AGENT);
+    *total = (double)(x & ~(1ull << 63));                               // exact: an integer far below 2^53
+    return (x >> 63) != 0ull;
+}
+__device__ __forceinline__ bool reduce_counts(const Ws& ws, int n_items, int spin_limit) {
+    for (int spins = 0; spins <= spin_limit; ++spins) {
+        const unsigned long long x = __hip_atomic_load(&ws.acc1[(size_t)(threadIdx.x & 63) * kAcc2Stride], BXI_RLX, BXI_AGENT);
+        const int arrived = wave_total_i32((int)(x >> 40));
+        const double tot = wave_total_f64((double)(x & ((1ull << 40) - 1ull)));       // exact
+        if (arrived == n_items) {
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(ws.sumw, (1ull << 63) | (unsigned long long)tot, BXI_RLX, BXI_AGENT);
+            return true;
+        }
+    }
+    return false;
+}
+// thresh <= 0: every pair (padded ones too) weighs 1 (:1324), sum W = 8 x the box areas; no predicate waves then
+__device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, const Ws& ws) {
+    const int lane = threadIdx.x & 63;
+    double s = 0.0;
+    for (int m0 = 0; m0 < a.N; m0 += 64) {
+        const int m = m0 + lane;
+        if (m < a.N) {
+            const int4 e = ws.tab[m];
+            const int r0 = e.y & 0xffff, r1 = (int)((unsigned int)e.y >> 16), c0 = e.z & 0xffff, c1 = (int)((unsigned int)e.z >> 16);
+            s += 8.0 * (double)((r1 - r0) * (int64_t)(c1 - c0));
+        }
+    }
+    return wave_total_f64(s);
+}
+
+// ---- tile wave (wave64, no LDS, no barrier) ------------------------------------------------------------------------------
+// Every UNORDERED pair is evaluated once and feeds both of its pixels: f(p,q) = f(q,p), the two weights W[k,p] + W[7-k,q]
+// share the colour predicate.  Per pixel (a, b) = (sigmoid(x), sigmoid(-x)), t = a - b, u = a b.  Per pair (p, q):
+//   S = a_p a_q + b_p b_q ; pw = -log S ; d pw / d x_p = -t_q u_p / S ; d pw / d x_q = -t_p u_q / S      (pairwise.cu:38-61)
+// S cannot underflow while every |x| <= 34; tiles with a larger logit take the log-space path.
+// Its waits: the predicate bytes of its own pixels (bit 7 set), when the logits have arrived and the per-pixel quantities are
+// computed; and, before the gradient goes out, sum W (the global normaliser, :1327-1328) = every predicate wave's arrival.  The
+// predicate waves precede the tile waves in the grid and never wait; by the time a tile wave asks they are normally done.
+template <int D, int R>
+__device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float upw_warm, float n2max, int zero_bit, int n_items,
+                                          int spin_limit, float& scale, bool& have_scale, float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
+                                          int tix) {
     constexpr int RD = TG<D, R>::RD;
     const int lane = threadIdx.x & 63;
-    const int h = a.h, w = a.w, n = wr.n;
+    const int h = a.h, w = a.w, n = t.n;
     const int64_t P = (int64_t)h * w;
     const float* Lg = a.logits + (int64_t)n * P;
+    const int c = t.tile_c0 - D + lane;
+    const bool col_owned = g_logits && lane >= D && lane < 64 - D && c < t.hc1;
+    float x[RD];
+    load_plane<D, R>(Lg, t, h, w, lane, x);
     float g[R];
     float num = 0.f;
 #pragma unroll
     for (int j = 0; j < R; ++j) g[j] = 0.f;
-    bool slow = wr.zero_bit != 0;
-    if (!slow) {
-        float x[RD], L[RD], A[RD], B[RD];
-        const float* lp = lab + (int64_t)wr.img * 3 * P;
-        load_plane<D, R>(Lg, wr, h, w, lane, x);
-        load_plane<D, R>(lp, wr, h, w, lane, L);
-        load_plane<D, R>(lp + P, wr, h, w, lane, A);
-        load_plane<D, R>(lp + 2 * P, wr, h, w, lane, B);
-        const TileFlags f = tile_flags<D, R>(wr, h, w, a.stride, lane);
-        DirMasks m[4];
-        dir_masks<D>(f, m);
-        // Rolling window over the rows: at step i the pairs (row i -> rows i, i + D) are evaluated; what the rows above
-        // contributed is final then, so row i's gradient is collected (and its registers die) inside the loop.
-        // Per pixel: (a, b) = (sigmoid(x), sigmoid(-x)), t = a - b, u = a b.  Per pair (p, q):
-        //   S = a_p a_q + b_p b_q ; pw = -log S ; d pw / d x_p = -t_q u_p / S ; d pw / d x_q = -t_p u_q / S.
-        // S cannot underflow while every |x| <= 34 (then min(a, b) >= 1.7e-15 and S >= 3e-15); tiles with a larger logit
-        // take the log-space path below.
-        float pa_[RD], pb_[RD], pt_[RD], pu_[RD];    // this lane, rows [i, i + D] live
-        float aR[RD], bR[RD], tR[RD], uR[RD], LR[RD], AR[RD], BR[RD];   // the lane D to the right, rows [i, i + D] live
-        float gq[RD], gR[RD];                        // gradient of this lane's pixels / of lane + D's
-        bool sat = false;
+    // per-pixel quantities of this lane and of the lane D to its right: before the wait, they need the logits only
+    float pa_[RD], pb_[RD], pt_[RD], pu_[RD], aR[RD], bR[RD], tR[RD], uR[RD];
+    bool sat = false;
 #pragma unroll
-        for (int j = 0; j < RD; ++j) { gq[j] = 0.f; gR[j] = 0.f; sat |= !(fabsf(x[j]) <= 34.f); }
+    for (int j = 0; j < RD; ++j) {
+        sat |= !(fabsf(x[j]) <= 34.f);
+        const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; pt_[j] = s.x - s.y; pu_[j] = s.x * s.y;
+        aR[j] = lane_plus<D>(pa_[j]); bR[j] = lane_plus<D>(pb_[j]); tR[j] = aR[j] - bR[j]; uR[j] = aR[j] * bR[j];
+    }
+    const bool slow = zero_bit != 0 || __any(sat);
+    BXI_TW(1, tix, 2);
+    if (!slow) {
+        uint32_t pb[4] = {0u, 0u, 0u, 0u};
+        {
+            const unsigned char* pp = ws.pred + (int64_t)t.img * P;
+            const uint32_t cc = (uint32_t)min(max(c, 0), w - 1);
+            uint32_t pbyte[R + D] = {};
+            bool ok = false;
+            for (int spins = 0; spins <= spin_limit; ++spins) {          // its own few bytes, read past the caches; usually there at once
+                uint32_t all = 0x80u;
+#pragma unroll
+                for (int i = 0; i < R + D; ++i) {
+                    pbyte[i] = __hip_atomic_load(pp + (uint32_t)min(max(t.tile_r0 - D + i, 0), h - 1) * (uint32_t)w + cc, BXI_RLX, BXI_AGENT);
+                    all &= pbyte[i];
+                }
+                if (__all(all != 0u)) { ok = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
+#pragma unroll
+            for (int i = 0; i < R + D; ++i)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) pb[d] |= ((pbyte[i] >> d) & 1u) << i;
+        }
+        const TileFlags f = tile_flags<D, R>(t, h, w, lane);
+        DirMasks m[4];
+        dir_masks<D>(f, pb, m);
+        float gq[RD], gR[RD];                        // gradient of this lane's pixels / of lane + D's
+#pragma unroll
+        for (int j = 0; j < RD; ++j) { gq[j] = 0.f; gR[j] = 0.f; }
         // pair weights as bytes, four rows per word: cw = W[k,A] + W[7-k,B] (gradient), dw = the same restricted to
         // pixels this tile owns (loss sum)
         uint32_t cw[4][(R + D + 3) / 4], dw[4][(R + D + 3) / 4];
@@ -762,22 +796,12 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
                 cw[dir][q4] = spread4((m[dir].mA >> (4 * q4)) & 15u) + spread4((m[dir].mB >> (4 * q4)) & 15u);
                 dw[dir][q4] = spread4((m[dir].nA >> (4 * q4)) & 15u) + spread4((m[dir].nB >> (4 * q4)) & 15u);
             }
-        BXI_TW(1, tix, 1);
-#define BXI_ROW(j)                                                                                                  \
-        {                                                                                                           \
-            const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; pt_[j] = s.x - s.y; pu_[j] = s.x * s.y;    \
-            aR[j] = lane_plus<D>(pa_[j]); bR[j] = lane_plus<D>(pb_[j]); tR[j] = aR[j] - bR[j]; uR[j] = aR[j] * bR[j]; \
-            LR[j] = lane_plus<D>(L[j]); AR[j] = lane_plus<D>(A[j]); BR[j] = lane_plus<D>(B[j]);                     \
-        }
-#pragma unroll
-        for (int j = 0; j < D; ++j) BXI_ROW(j)
-        BXI_TW(1, tix, 2);
+        BXI_TW(1, tix, 3);
         // one unordered pair: A = (row ra, this lane) ; B = (row rb of the lane `q` names) ; num collects -log2 S
-#define BXI_PAIR(i, ra, rb, qa, qb, qt, qu, qL, qA, qB, dir, GA, GB)                                              \
+#define BXI_PAIR(i, ra, rb, qa, qb, qt, qu, dir, GA, GB)                                                            \
         {                                                                                                           \
-            const bool pn = n2_of(L[ra], A[ra], B[ra], qL[rb], qA[rb], qB[rb]) <= wr.n2max;                         \
-            const float gw = pn ? (float)((cw[dir][(i) >> 2] >> (8 * ((i) & 3))) & 255u) : 0.f;                     \
-            const float nw = pn ? (float)((dw[dir][(i) >> 2] >> (8 * ((i) & 3))) & 255u) : 0.f;                     \
+            const float gw = (float)((cw[dir][(i) >> 2] >> (8 * ((i) & 3))) & 255u);                                \
+            const float nw = (float)((dw[dir][(i) >> 2] >> (8 * ((i) & 3))) & 255u);                                \
             const float S = pa_[ra] * qa[rb] + pb_[ra] * qb[rb];                    /* P(y_A == y_B) */            \
             num -= nw * __builtin_amdgcn_logf(S);                                   /* v_log_f32 = log2 */         \
             const float mm = gw * __builtin_amdgcn_rcpf(S);                                                         \
@@ -787,91 +811,56 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const float* __rest
 #pragma unroll
         for (int i = 0; i < R + D; ++i) {
             const int j = i + D;
-            BXI_ROW(j)
-            if (i >= D) BXI_PAIR(i, i, i, aR, bR, tR, uR, LR, AR, BR, 0, gq[i], gR[i])
-            BXI_PAIR(i, j, i, aR, bR, tR, uR, LR, AR, BR, 1, gq[j], gR[i])
-            BXI_PAIR(i, i, j, pa_, pb_, pt_, pu_, L, A, B, 2, gq[i], gq[j])
-            BXI_PAIR(i, i, j, aR, bR, tR, uR, LR, AR, BR, 3, gq[i], gR[j])
+            if (i >= D) BXI_PAIR(i, i, i, aR, bR, tR, uR, 0, gq[i], gR[i])
+            BXI_PAIR(i, j, i, aR, bR, tR, uR, 1, gq[j], gR[i])
+            BXI_PAIR(i, i, j, pa_, pb_, pt_, pu_, 2, gq[i], gq[j])
+            BXI_PAIR(i, i, j, aR, bR, tR, uR, 3, gq[i], gR[j])
             if (i >= D) {     // row i is complete: collect what the lane D to the left computed for it
                 const float fromL = lane_minus<D>(gR[i]);
                 g[i - D] = gq[i] + (lane >= D ? fromL : 0.f);
             }
         }
         num *= 0.69314718055994531f;
-#undef BXI_ROW
 #undef BXI_PAIR
-        slow = __any(sat);
-    }
-    if (slow) {      // workgroup-divergent but wave-uniform; rare
-        const int cnt_unused = slow_tile<D, R>(Lg, lab, P, make_int4(wr.r0, wr.r1, wr.c0, wr.c1), wr.img, wr.tile_r0, wr.tile_c0, wr.n2max,
-                                               wr.zero_bit, wr.vr, wr.vc, wr.hc1, h, w, a.stride, lane, true, gbuf);
+    } else {         // wave-uniform; rare
+        slow_tile<D, R>(Lg, ws.lab4, t, n2max, zero_bit, h, w, lane, gbuf);
         num = gbuf[R * 64 + lane];
-        (void)cnt_unused;
 #pragma unroll
         for (int j = 0; j < R; ++j) g[j] = gbuf[j * 64 + lane];
     }
-    // ---- epilogue: one round of polls for everything the stores need, the arrival issued before and consumed after them ----
-    BXI_TW(1, tix, 3);
+    BXI_TW(1, tix, 5);
     num = wave_total_f32(num);
-    long long fx = (long long)(num * kNumScale) + (1ll << 24);           // + 1.0: keeps the packed field non-negative
-    {   // converted here, under the polls' latency, not between the stores and the arrival (the compiler sinks it there: lane 0 only)
-        int lo = (int)(fx & 0xffffffffll), hi = (int)(fx >> 32);
-        asm volatile("" : "+v"(lo), "+v"(hi));
-        fx = ((long long)hi << 32) | (long long)(unsigned int)lo;
-    }
-    const int c = wr.tile_c0 - D + lane;
-    const bool col_owned = g_logits && lane >= D && lane < 64 - D && c < wr.hc1;
-    const bool row_lane = g_logits && lane < R && wr.tile_r0 + lane < h;
-    // sum W: every count wave has arrived (they precede the math waves in the grid); projection coefficients: the leader of
-    // this instance publishes one 8-byte granule per column / row (write-through; the leaders precede every tile wave and
-    // never wait).  Both are read past this XCD's caches, in the same round.
-    bool ok = true;
-    unsigned long long ck = 0ull, rk = 0ull;
-    for (unsigned spins = 0;; ++spins) {
-        bool have = true;
-        double sw = 0.0;
-        bool counted = true;
-        if (!have_total) counted = counts_complete(ws, nwork, &sw);       // wave-uniform
-        if (col_owned) { ck = __hip_atomic_load(&st.colk[(int64_t)n * w + c], BXI_RLX, BXI_AGENT); have &= (unsigned int)ck != 0xffffffffu; }
-        if (row_lane) { rk = __hip_atomic_load(&st.rowk[(int64_t)n * h + wr.tile_r0 + lane], BXI_RLX, BXI_AGENT); have &= (unsigned int)rk != 0xffffffffu; }
-        if (counted && __all(have)) {
-            if (!have_total) { total_w = sw; have_total = true; }
-            break;
+    const long long fx = (long long)(num * kNumScale) + (1ll << 24);           // + 1.0: keeps the packed field non-negative
+    if (!have_scale) {           // wave-uniform; once per wave
+        double total_w = 0.0;
+        if (zero_bit) total_w = total_weight_all_pairs(a, ws);
+        else {
+            bool ok = false;
+            for (int spins = 0; spins <= spin_limit; ++spins) {
+                if (counts_complete(ws, n_items, &total_w)) { ok = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
         }
-        if (spins > kSpinLimit) { ok = false; break; }
-        __builtin_amdgcn_s_sleep(8);
+        scale = upw_warm / fmaxf((float)total_w, 1.f);
+        have_scale = true;
     }
-    if (!ok && lane == 0 && st.status) atomicOr(st.status, 1);
     BXI_TW(1, tix, 4);
     if (g_logits) {
-        const int carg = col_owned ? (int)(unsigned int)ck : -1;
-        const float gc = __uint_as_float((unsigned int)(ck >> 32));
-        const int rarg_l = row_lane ? (int)(unsigned int)rk : -1;
-        const float gr_l = __uint_as_float((unsigned int)(rk >> 32));
-        const float scale = upw * (warmup / fmaxf((float)total_w, 1.f));
         char* G = reinterpret_cast<char*>(g_logits + (int64_t)n * P);      // scalar base + 32-bit byte offset
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            const int r = wr.tile_r0 + j;
-            const int ra = __builtin_amdgcn_readlane(rarg_l, j);
-            const float gr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gr_l), j));
-            if (col_owned && r < h) {
-                float sp = 0.f;
-                if (carg == r) sp += gc;
-                if (ra == c) sp += gr;
-                *reinterpret_cast<float*>(G + (uint32_t)(r * w + c) * 4u) = g[j] * scale + sp * upp;
-            }
+            const int r = t.tile_r0 + j;
+            if (col_owned && r < h) add_f32(reinterpret_cast<float*>(G + (uint32_t)(r * w + c) * 4u), g[j] * scale);
         }
     }
-    BXI_TW(1, tix, 5);
-    // ---- this tile's share of sum W pw + its arrival: one atomic without return, the wave does not wait for it (a
-    // returning atomic on these 32 words costs ~3 us here); the finisher block at the end of the grid watches the counts
-    if (lane == 0)
-        __hip_atomic_fetch_add(acc2_word(ws.acc2, n, wr.tile_r0 / R + wr.tile_c0 / TG<D, R>::TW), (1ull << 52) + (unsigned long long)fx, BXI_RLX, BXI_AGENT);
     BXI_TW(1, tix, 6);
+    // this tile's share of sum W pw + its arrival: one atomic without return; the wave does not wait for it
+    if (lane == 0)
+        __hip_atomic_fetch_add(acc2_word(ws.acc2, n, t.tile_r0 / R + t.tile_c0 / TG<D, R>::TW), (1ull << 52) + (unsigned long long)fx, BXI_RLX, BXI_AGENT);
+    BXI_TW(1, tix, 7);
 }
 
-// ---- leader workgroup --------------------------------------------------------------------------------------------
 __device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = wave_total_f32(v[k]);
@@ -885,20 +874,25 @@ __device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
 }
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
 
-__device__ __forceinline__ void leader_block(const InstArgs& a, int dil, int R, const EvalWs& ws, const LossState& st, int n,
-                                             float upp, float* __restrict__ g_logits, unsigned char* smem, float* red) {
+// ---- leader workgroup (one per instance) -------------------------------------------------------------------------------
+//   partial maxima -> maxima -> sigmoid on those only -> both dice terms (:117-143) -> unit projection gradients, recorded as
+//   one 8-byte word per column / row (gradient bits << 32 | arg-max index) for bxi_boxinst_grad_rescale_f32 and ADDED to the
+//   gradient at the arg-max positions.  Nobody in this launch reads what a leader writes except the finisher (its dice loss).
+__device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const Ws& ws, const LossState& st, int n, float upp,
+                                             float* __restrict__ g_logits, unsigned char* smem, float* red) {
     const int h = a.h, w = a.w, tid = threadIdx.x;
     float* xs = reinterpret_cast<float*>(smem);   // [w] sigmoid of the column maxima, then their unit gradients
     float* ys = xs + w;                           // [h]
     int* carg = reinterpret_cast<int*>(ys + h);   // [w]
     int* rarg = carg + w;                         // [h]
-    const InstRec rec = ws.inst[n];
-    const InstBox ib = inst_from_rec(rec, dil, h, w);
+    const int4 e = ws.tab[n];
+    const int br0 = e.y & 0xffff, br1 = (int)((unsigned int)e.y >> 16), bc0 = e.z & 0xffff, bc1 = (int)((unsigned int)e.z >> 16);
+    const bool any = br1 > br0 && bc1 > bc0;
+    (void)dil;
     float sums[4] = {0.f, 0.f, 0.f, 0.f};   // I_x, U_x, I_y, U_y
-    // the partial maxima of a column / row: up to eight loads in flight at once (the band count is launch data, and a loop
-    // of load -> compare would walk through L2 once per band: 7 x 0.5 us at 200 rows)
+    // the partial maxima of a column / row: up to eight loads in flight at once
     auto best_key = [](const unsigned long long* __restrict__ part, int n_part, int64_t stride) {
-        unsigned long long k = part[0];
+        unsigned long long k = 0ull;
         for (int s0 = 0; s0 < n_part; s0 += 8) {
             unsigned long long o[8];
 #pragma unroll
@@ -916,149 +910,260 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, int R, 
         if (is_c) {
             const int c = i;
             const float X = sigmoid_acc(unpack_val(kc));
-            const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
+            const float TX = (any && c >= bc0 && c < bc1) ? 1.f : 0.f;
             xs[c] = X; carg[c] = (int)unpack_idx(kc);
             sums[0] += X * TX; sums[1] += X * X + TX * TX;
         }
         if (is_r) {
             const int r = i;
             const float Y = sigmoid_acc(unpack_val(kr));
-            const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
+            const float TY = (any && r >= br0 && r < br1) ? 1.f : 0.f;
             ys[r] = Y; rarg[r] = (int)unpack_idx(kr);
             sums[2] += Y * TY; sums[3] += Y * Y + TY * TY;
         }
     }
-    BXI_TW(3, n, 1);
+    BXI_TW(3, 1 + n, 1);
     block_sum4(sums, red);
-    BXI_TW(3, n, 2);
     const float Ix = sums[0], Ux = sums[1] + 1e-5f, Iy = sums[2], Uy = sums[3] + 1e-5f;
-    if (tid == 0)   // :130, summed over both axes :143
+    if (tid == 0)   // :130, summed over both axes :143; the datum is its own flag
         __hip_atomic_store(&ws.dice[n], (1ull << 32) | (unsigned long long)__float_as_uint((1.f - 2.f * Ix / Ux) + (1.f - 2.f * Iy / Uy)),
-                           BXI_RLX, BXI_AGENT);       // the datum is its own flag
+                           BXI_RLX, BXI_AGENT);
+    BXI_TW(3, 1 + n, 2);
     if (g_logits) {
         // dice = 1 - 2I/U ; d dice/d u_j = (-2 t_j U + 4 I u_j) / U^2 ; chain through sigmoid ; mean over N
         const float invN = 1.f / (float)a.N;
         for (int c = tid; c < w; c += 256) {
             const float X = xs[c];
-            const float TX = (ib.any && c >= ib.box.c0 && c < ib.box.c1) ? 1.f : 0.f;
+            const float TX = (any && c >= bc0 && c < bc1) ? 1.f : 0.f;
             const float gv = invN * ((-2.f * TX * Ux + 4.f * Ix * X) / (Ux * Ux)) * X * (1.f - X);
-            xs[c] = gv;     // one aligned 8-byte write-through store per column: the datum is its own flag
-            __hip_atomic_store(&st.colk[(int64_t)n * w + c], ((unsigned long long)__float_as_uint(gv) << 32) | (unsigned int)carg[c],
-                               BXI_RLX, BXI_AGENT);
+            xs[c] = gv;
+            st.colk[(int64_t)n * w + c] = ((unsigned long long)__float_as_uint(gv) << 32) | (unsigned int)carg[c];
         }
         for (int r = tid; r < h; r += 256) {
             const float Y = ys[r];
-            const float TY = (ib.any && r >= ib.box.r0 && r < ib.box.r1) ? 1.f : 0.f;
+            const float TY = (any && r >= br0 && r < br1) ? 1.f : 0.f;
             const float gv = invN * ((-2.f * TY * Uy + 4.f * Iy * Y) / (Uy * Uy)) * Y * (1.f - Y);
             ys[r] = gv;
-            __hip_atomic_store(&st.rowk[(int64_t)n * h + r], ((unsigned long long)__float_as_uint(gv) << 32) | (unsigned int)rarg[r],
-                               BXI_RLX, BXI_AGENT);
+            st.rowk[(int64_t)n * h + r] = ((unsigned long long)__float_as_uint(gv) << 32) | (unsigned int)rarg[r];
         }
-        BXI_TW(3, n, 3);
         __syncthreads();      // xs / ys now hold the gradients for every thread
-        // projection gradient at the arg-max positions OUTSIDE the tiles (prep_kernel left zeros there; the math waves
-        // own every pixel of the tile hull: rows of the R-aligned tiles x columns of the dilated box)
-        const int hr0 = ib.any ? (ib.dil.r0 / R) * R : 0, hr1 = ib.any ? min(h, ((ib.dil.r1 + R - 1) / R) * R) : 0;
-        const int hc0 = ib.dil.c0, hc1 = ib.any ? ib.dil.c1 : 0;
+        // one addition per arg-max position (a pixel that is its column's AND its row's arg-max gets their sum in one)
         float* G = g_logits + (int64_t)n * h * w;
         for (int c = tid; c < w; c += 256) {
             const int r = carg[c];
-            const bool in_t = r >= hr0 && r < hr1 && c >= hc0 && c < hc1;
-            if (!in_t) {
-                float v = xs[c];
-                if (rarg[r] == c) v += ys[r];
-                G[(int64_t)r * w + c] = v * upp;
-            }
+            float v = xs[c];
+            if (rarg[r] == c) v += ys[r];
+            add_f32(G + (int64_t)r * w + c, v * upp);
         }
         for (int r = tid; r < h; r += 256) {
             const int c = rarg[r];
-            const bool in_t = r >= hr0 && r < hr1 && c >= hc0 && c < hc1;
-            if (!in_t && carg[c] != r) G[(int64_t)r * w + c] = ys[r] * upp;
+            if (carg[c] != r) add_f32(G + (int64_t)r * w + c, ys[r] * upp);
         }
     }
+    BXI_TW(3, 1 + n, 3);
 }
 
-// grid: [N leader blocks][n_cb count blocks][n_cb math blocks][finisher]; a count / math block = 4 independent tile waves
-// striding through the work list; the finisher (one wave) writes the two loss values once everybody has arrived.  Every wait in a math wave is for a workgroup EARLIER in the grid (leader, count waves), and
-// those never wait themselves, so the launch cannot stall on an un-dispatched workgroup whatever its size.
+__device__ __forceinline__ Tile tile_of(const int4& e, int D, int R, int TW, int n, int idx, int h, int w) {   // e: the instance's table entry (uniform)
+    Tile t;
+    t.r0 = e.y & 0xffff; t.r1 = (int)((unsigned int)e.y >> 16); t.c0 = e.z & 0xffff; t.c1 = (int)((unsigned int)e.z >> 16);
+    t.img = (int)((unsigned int)e.x >> 24); t.n = n;
+    t.vrow = e.w & 0xffff; t.vcol = (int)((unsigned int)e.w >> 16);
+    const int dr0 = max(t.r0 - D, 0), hc0 = max(t.c0 - D, 0);
+    t.hc1 = min(t.c1 + D, w);
+    const int ntc = (t.hc1 - hc0 + TW - 1) / TW;
+    const int ti = idx / ntc, tj = idx - ti * ntc;
+    t.tile_r0 = (dr0 / R + ti) * R;
+    t.tile_c0 = hc0 + tj * TW;
+    (void)h;
+    return t;
+}
+
+// The finisher's rounds.  Leaders: the dice losses of instances [b0, b0 + 64) (self-flagging words).
+__device__ __forceinline__ bool dice_round(const Ws& ws, int N, int b0, float* dsum) {
+    const int lane = threadIdx.x & 63, i = b0 + lane;
+    const unsigned long long dg = i < N ? __hip_atomic_load(&ws.dice[i], BXI_RLX, BXI_AGENT) : (1ull << 32);
+    if (!__all((dg >> 32) != 0ull)) return false;
+    const float dv = i < N ? __uint_as_float((unsigned int)dg) : 0.f;
+    const int m = min(64, N - b0);
+    for (int k = 0; k < m; ++k) *dsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), k));   // index order: run-to-run identical
+    return true;
+}
+
+// The tile of list position `ti`: the instance whose tile range holds it (table entries: 16 bytes per instance, the same lines
+// for every wave), then the tile's place inside the instance's hull.  e0 = this lane's entry of the first 64 (N < 64: all).
 template <int D, int R>
-__global__ __launch_bounds__(256, (R == 4 ? 3 : 2)) void pair_kernel(const WorkRec2* __restrict__ work, const int* __restrict__ nwork_p,
-                                                   const float* __restrict__ lab, const float* __restrict__ up_prj,
-                                                   const float* __restrict__ up_pw, int n_cb, int dil, float warmup,
-                                                   float* __restrict__ losses, float* __restrict__ g_logits, InstArgs a, EvalWs ws,
-                                                   LossState st) {
+__device__ __forceinline__ Tile locate_tile(const Ws& ws, int N, const int4& e0, int ti, int h, int w) {
+    const int lane = threadIdx.x & 63;
+    int n = 0;
+    int4 e = make_int4(0, 0, 0, 0);
+    if (N < 64) {
+        const unsigned long long mask = __ballot(lane < N && (e0.x & 0xffffff) <= ti);
+        n = __popcll(mask) - 1;
+        e.x = __builtin_amdgcn_readlane(e0.x, n); e.y = __builtin_amdgcn_readlane(e0.y, n);
+        e.z = __builtin_amdgcn_readlane(e0.z, n); e.w = __builtin_amdgcn_readlane(e0.w, n);
+    } else {
+        for (int m0 = 0; m0 < N; m0 += 64) {
+            int4 em = make_int4(0, 0, 0, 0);
+            if (m0 + lane < N) em = ws.tab[m0 + lane];
+            const unsigned long long mask = __ballot(m0 + lane < N && (em.x & 0xffffff) <= ti);
+            const int cntm = __popcll(mask);
+            if (cntm == 0) break;
+            n = m0 + cntm - 1;
+            e.x = __builtin_amdgcn_readlane(em.x, cntm - 1); e.y = __builtin_amdgcn_readlane(em.y, cntm - 1);
+            e.z = __builtin_amdgcn_readlane(em.z, cntm - 1); e.w = __builtin_amdgcn_readlane(em.w, cntm - 1);
+            if (cntm < 64) break;
+        }
+    }
+    return tile_of(e, D, R, TG<D, R>::TW, n, ti - (e.x & 0xffffff), h, w);
+}
+
+// grid: [n_pb predicate blocks][N leaders][n_tb tile blocks][finisher]; a predicate / tile block = 4 independent waves striding
+// through the pooled row segments / the tile list.  The only waits: a tile wave for the predicate waves (earlier in the grid,
+// never waiting themselves), the finisher for everybody (nobody waits for it).  Every wait is bounded, and running out of it is
+// loud: NaN losses, status word, poisoned gradient (the reference surfaces launch failures through AT_CUDA_CHECK, pairwise.cu:173,200).
+template <int D, int R>
+__global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
+                                                       float n2max, int zero_bit, int n_pb, int n_items, int spin_limit, ValidCells vc, float* __restrict__ losses,
+                                                       float* __restrict__ g_logits, InstArgs a, Ws ws, LossState st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[16];
-    const int blk = (int)blockIdx.x;
+    const int blk = (int)blockIdx.x, lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const int N = a.N;
     const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
-    if (blk < a.N) {                                                   // ---- leader of instance blk
-        BXI_TW(3, blk, 0);
-        leader_block(a, dil, R, ws, st, blk, upp, g_logits, smem, red);
-        BXI_TW(3, blk, 4);
-        BXI_TW(3, blk, 5);
+    if (blk < n_pb) {                                                  // ---- predicate waves: first in the grid, everybody asks for their bytes
+        if (zero_bit) return;                                          // every pair weighs 1: sum W has a closed form, the tiles take the log-space path
+        const int segs = (a.w + 63) >> 6, pid = blk * kWaves + wave;
+        BXI_TW(2, pid, 0);
+        __builtin_amdgcn_s_setprio(3);                                 // short, and the tile waves will ask for these bytes
+        int cnt = 0, segments = 0;
+        for (int item = pid; item < n_items; item += n_pb * kWaves) { cnt += pred_item(a, vc, ws, D, n2max, item, segs); ++segments; }
+        cnt = wave_total_i32(cnt);
+        // ONE arrival per workgroup: arrivals on one word are performed one after the other (~0.15 us each), and the tile waves
+        // need the last one
+        __shared__ int pred_cnt[kWaves], pred_seg[kWaves];
+        if (lane == 0) { pred_cnt[wave] = cnt; pred_seg[wave] = segments; }
+        __syncthreads();
+        if (threadIdx.x == 0)    // (segments evaluated, sum W); integer adds commute: run-to-run identical
+            __hip_atomic_fetch_add(&ws.acc1[(size_t)(blk & (kAcc1Words - 1)) * kAcc2Stride],
+                                   ((unsigned long long)(unsigned int)((pred_seg[0] + pred_seg[1]) + (pred_seg[2] + pred_seg[3])) << 40) |
+                                       (unsigned long long)(unsigned int)((pred_cnt[0] + pred_cnt[1]) + (pred_cnt[2] + pred_cnt[3])),
+                                   BXI_RLX, BXI_AGENT);
+        BXI_TW(2, pid, 1);
         return;
     }
-    if (blk == (int)gridDim.x - 1) {                                   // ---- finisher: the last block of the grid, one wave
-        if (threadIdx.x >= 64) return;
-        // every leader and tile wave precedes this block in the grid and none of them waits for it
-        const int lane = threadIdx.x;
-        const int nwork = *nwork_p;
-        bool ok = false;
-        double total_w = 0.0, num = 0.0;
+    if (blk < n_pb + N) {                                              // ---- leader of an instance
+        BXI_TW(3, 1 + blk - n_pb, 0);
+        leader_block(a, D, ws, st, blk - n_pb, upp, g_logits, smem, red);
+        return;
+    }
+    if (blk == (int)gridDim.x - 1) {                                   // ---- finisher
+        // waits only for workgroups that never wait for it: the leaders and the predicate waves (done early), then the tile waves
+        BXI_TW(3, 0, 0);
+        __shared__ double fin_d[kWaves];
+        __shared__ int fin_i[kWaves];
+        __shared__ float fin_f;
+        __shared__ int fin_ok;
+        bool ok = true;
+        double total_w = 0.0;
         float dsum = 0.f;
-        for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {
-            num = 0.0; dsum = 0.f;
-            bool all = counts_complete(ws, nwork, &total_w);            // issued with the first pass's loads, used after them
-            for (int b0 = 0; b0 < a.N && all; b0 += 64)                    // (> 64 instances: the passes follow one another)
-                all = finisher_round(ws, a.N, b0, b0 + lane < a.N ? ws.expect[b0 + lane] : 0u, &num, &dsum) && all;
-            if (all) { ok = true; break; }
-            __builtin_amdgcn_s_sleep(2);
+        int spins = 0;
+        if (spin_limit < 0) ok = false;
+        if (wave == 1 && !zero_bit && !reduce_counts(ws, n_items, spin_limit) && lane == 0) atomicOr(ws.fault, kFaultCounts);     // the reducer
+        if (wave == 0) {
+            for (int b0 = 0; b0 < N && ok; b0 += 64) {
+                while (!dice_round(ws, N, b0, &dsum)) {
+                    if (++spins > spin_limit) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            if (zero_bit) total_w = total_weight_all_pairs(a, ws);
+            else
+                while (ok && !counts_complete(ws, n_items, &total_w)) {
+                    if (++spins > spin_limit) ok = false;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            if (lane == 0) { fin_f = dsum; fin_d[0] = total_w; fin_ok = ok ? 1 : 0; }
         }
-        if (!ok && lane == 0 && st.status) atomicOr(st.status, 2);
-        write_losses(st, a.N, warmup, total_w, num, dsum, upp, upw, losses);
+        __syncthreads();
+        ok = fin_ok != 0; dsum = fin_f; total_w = fin_d[0];
+        const int ntiles = __builtin_amdgcn_readfirstlane(ws.tab[N].x);
+        __syncthreads();
+        // every thread watches its own arrival words (N * 8 / 256 each: one at the headline size); the launch ends on this loop
+        long long mine = 0;
+        spins = 0;
+        for (;;) {
+            mine = 0;
+            int arrived = 0;
+            for (int i = threadIdx.x; i < N * kAcc2Split; i += 256) {
+                const unsigned long long x = __hip_atomic_load(ws.acc2 + (size_t)i * kAcc2Stride, BXI_RLX, BXI_AGENT);
+                arrived += (int)(x >> 52);
+                mine += (long long)(x & ((1ull << 52) - 1ull)) - ((long long)(x >> 52) << 24);       // the +1 per tile
+            }
+            arrived = wave_total_i32(arrived);
+            if (lane == 0) fin_i[wave] = arrived;
+            __syncthreads();
+            const bool all = (fin_i[0] + fin_i[1]) + (fin_i[2] + fin_i[3]) == ntiles;
+            __syncthreads();
+            if (all) break;
+            if (++spins > spin_limit) { ok = false; break; }           // workgroup-uniform: the same count in every thread
+        }
+        const double wsum = wave_total_f64((double)mine);                // exact; fixed order: run-to-run identical
+        if (lane == 0) fin_d[wave] = wsum;
+        __syncthreads();
+        if (threadIdx.x >= 64) return;
+        const double num = (fin_d[0] + fin_d[1]) + (fin_d[2] + fin_d[3]);
+        const unsigned int fault = __hip_atomic_load(ws.fault, BXI_RLX, BXI_AGENT);   // set by a tile wave BEFORE its arrival, if at all
+        const unsigned int status = (unsigned int)__builtin_amdgcn_readfirstlane((int)(fault | (ok ? 0u : kFaultFinisher)));
+        if (lane == 0) {
+            const float denom = fmaxf((float)total_w, 1.f);                      // weights.sum().clamp(min=1.0), :1328
+            float l0 = dsum / (float)N;                                          // .mean(), :143
+            float l1 = (float)((num / (double)kNumScale) / (double)denom) * warmup;   // :1327-1332
+            if (status) { l0 = __int_as_float(0x7fc00000); l1 = l0; }            // loud: mmdet's CheckInvalidLossHook fires
+            losses[0] = l0; losses[1] = l1;
+            if (st.scale) { *st.scale = warmup / denom; st.applied[0] = upp; st.applied[1] = upw; }
+            if (st.status) st.status[0] = (int)status;
+        }
+        BXI_TW(3, 0, 1);
         return;
     }
-    const int nwork = *nwork_p;
-    const int wave = (int)(threadIdx.x >> 6);
-    const bool counting = blk < a.N + n_cb;
-    const int first = ((counting ? blk - a.N : blk - a.N - n_cb) * kWaves) + wave;
-    const int stride_w = n_cb * kWaves;
-    const int tix = first;
-    (void)tix;
-    BXI_TW(counting ? 2 : 1, tix, 0);
+    const int wid = (blk - N - n_pb) * kWaves + wave, nwaves = ((int)gridDim.x - 1 - N - n_pb) * kWaves;
+    __builtin_amdgcn_s_setprio(2);                                     // the launch ends on the tile waves, not on the leaders next to them
+    BXI_TW(1, wid, 0);
+    int4 e0 = make_int4(0, 0, 0, 0);
+    if (lane <= N) e0 = ws.tab[lane];
+    const int total = N < 64 ? __builtin_amdgcn_readlane(e0.x, N < 64 ? N : 0) : __builtin_amdgcn_readfirstlane(ws.tab[N].x);
     float* gbuf = reinterpret_cast<float*>(smem) + wave * ((R + 1) * 64);
-    double total_w = 0.0;
-    bool have_total = false;
-    for (int wi = first; wi < nwork; wi += stride_w) {
-        WorkRec2 wr = work[wi];
-        // the record is the same in every lane: as scalars, the instance's planes become scalar bases and the tile's 32 loads take
-        // (scalar base + one shared 32-bit lane offset per row) instead of a 64-bit address computed per load
-#define BXI_SC(f) wr.f = __builtin_amdgcn_readfirstlane(wr.f)
-        BXI_SC(r0); BXI_SC(r1); BXI_SC(c0); BXI_SC(c1); BXI_SC(img); BXI_SC(n); BXI_SC(tile_r0); BXI_SC(tile_c0);
-        BXI_SC(zero_bit); BXI_SC(vr); BXI_SC(vc); BXI_SC(hc1);
-#undef BXI_SC
-        wr.n2max = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wr.n2max)));
-        if (counting) count_tile<D, R>(a, lab, ws, wr, tix);
-        else math_tile<D, R>(a, lab, ws, st, wr, warmup, upp, upw, losses, g_logits, gbuf, total_w, have_total, nwork, tix);
+    float scale = 0.f;
+    bool have_scale = false;
+    for (int ti = wid; ti < total; ti += nwaves) {
+        const Tile t = locate_tile<D, R>(ws, N, e0, ti, a.h, a.w);
+        BXI_TW(1, wid, 1);
+        math_tile<D, R>(a, ws, t, upw * warmup, n2max, zero_bit, n_items, spin_limit, scale, have_scale, g_logits, gbuf, wid);
     }
 }
 
 // ---- rescale: g_logits finished for the factors recorded in `state` -> finished for (g_prj, g_pw) ----------------
 // grid (8, N).  No-op when the factors are the recorded ones (the usual case: loss.backward() seeds both terms with 1).
-// The record is not updated (every block reads it): at most one effective rescale per evaluation.
+// An evaluation whose status word is set has no gradient: it is poisoned here, next to the NaN losses.
 __global__ __launch_bounds__(256) void rescale_kernel(InstArgs a, int dil, LossState st, const float* __restrict__ g_prj,
-                                                      const float* __restrict__ g_pw, float* __restrict__ g_logits) {
+                                                       const float* __restrict__ g_pw, float* __restrict__ g_logits) {
+    const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int h = a.h, w = a.w;
+    float* G = g_logits + (int64_t)n * h * w;
+    if (st.status[0] != 0) {
+        const int per = (h + gridDim.x - 1) / gridDim.x;
+        const int ra = s * per, rb = min(h, ra + per);
+        for (int i = tid; i < (rb - ra) * w; i += 256) G[(int64_t)ra * w + i] = __int_as_float(0x7fc00000);
+        return;
+    }
     const float np = *g_prj, nw = *g_pw, op = st.applied[0], ow = st.applied[1];
     if (np == op && nw == ow) return;
     const int R = st.status[1];
-    const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
-    const int h = a.h, w = a.w;
     const InstRec rec = st.inst[n];
     const InstBox ib = inst_from_rec(rec, dil, h, w);
     const int hr0 = ib.any ? (ib.dil.r0 / R) * R : 0, hr1 = ib.any ? min(h, ((ib.dil.r1 + R - 1) / R) * R) : 0;
     const int hc0 = ib.dil.c0, hc1 = ib.any ? ib.dil.c1 : 0;
     const float ratio = nw / ow;                      // recorded g_pw == 0 cannot be rescaled (documented)
-    float* G = g_logits + (int64_t)n * h * w;
     const unsigned long long* ckp = st.colk + (int64_t)n * w; const unsigned long long* rkp = st.rowk + (int64_t)n * h;
     auto carg = [&](int c) { return (int)(unsigned int)ckp[c]; };
     auto rarg = [&](int r) { return (int)(unsigned int)rkp[r]; };
@@ -1097,8 +1202,6 @@ __global__ __launch_bounds__(256) void rescale_kernel(InstArgs a, int dil, LossS
 __global__ void zero_losses2_kernel(float* losses) { losses[0] = 0.f; losses[1] = 0.f; }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-size_t eval_ws_bytes(int N, int h, int w) { return carve_eval(nullptr, N, h, w, nullptr); }
-
 // compute units of the current device (256 on an MI355X in SPX mode, 32 per partition in CPX): the grids are sized so that a
 // launch is resident in one round.  Cached per device ordinal; a wrong value costs time, never correctness.
 static int device_cus() {
@@ -1113,31 +1216,60 @@ static int device_cus() {
     return v;
 }
 
-static int tile_rows_for(int N, int h, int w, int dil) {
-    (void)h; (void)w; (void)dil;
-    // A tile wave's time is the length of its dependent chain, so 4-row tiles (6 row steps instead of 10, 1.2x the pair
-    // evaluations in total, three waves a SIMD at <= 168 VGPRs) win while the tile waves are resident together: measured
-    // 11.4 vs 12.2 us at 32 instances, 19.8 vs 20.9 us at 64, 41.8 vs 40.6 us at 128 (2 x 800 x 1024).  (Before the arrival
-    // words were split they lost everywhere: twice the atomics per word.)  The number of tiles is device data; the instance
-    // count is what the host has.  Developer knob: BXI_TILE_ROWS.
-    return N <= 96 ? 4 : 8;
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+static int tile_rows_for(int N) { return N <= 96 ? 4 : 8; }
+
+// (sim >= thresh) for a valid neighbour as a compare on the squared Lab distance: exp(-0.5 * sqrt(n2)) >= thresh  <=>  n2 <= n2max
+// (get_image_color_similarity :237 + the threshold of loss() :1324), n2max found by bisecting the f32 expression over the float
+// bit patterns (it is non-increasing in n2 >= 0, and positive floats order like their bit patterns).  Host arithmetic: sqrtf is
+// correctly rounded everywhere; expf is the C library's, as in the CPU reference path.
+struct HostPred { float n2max; int zero_bit; };
+static bool host_sim_pred(float n2, float thresh) { return expf(-sqrtf(n2) * 0.5f) >= thresh; }
+static HostPred host_pred(float thresh) {
+    static std::atomic<uint64_t> cache{~0ull};                          // (thresh bits << 32 | n2max bits) of the last call
+    uint32_t tb, nb;
+    memcpy(&tb, &thresh, 4);
+    const uint64_t c = cache.load(std::memory_order_relaxed);
+    HostPred p;
+    p.zero_bit = (0.f >= thresh) ? 1 : 0;                               // weight of a padded / masked-out neighbour (sim == 0)
+    if ((uint32_t)(c >> 32) == tb && c != ~0ull) { nb = (uint32_t)c; memcpy(&p.n2max, &nb, 4); return p; }
+    if (!host_sim_pred(0.f, thresh)) p.n2max = -1.f;                    // thresh > 1: never
+    else if (host_sim_pred(3.0e38f, thresh)) p.n2max = INFINITY;        // thresh <= 0 (exp underflows to 0): always
+    else {
+        uint32_t lo = 0u, hi;
+        const float big = 3.0e38f;
+        memcpy(&hi, &big, 4);                                           // pred(lo) true, pred(hi) false
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            float fm;
+            memcpy(&fm, &mid, 4);
+            if (host_sim_pred(fm, thresh)) lo = mid; else hi = mid;
+        }
+        memcpy(&p.n2max, &lo, 4);
+    }
+    memcpy(&nb, &p.n2max, 4);
+    cache.store(((uint64_t)tb << 32) | nb, std::memory_order_relaxed);
+    return p;
 }
-int eval_tile_rows(int N, int h, int w, int dil) { return tile_rows_for(N, h, w, dil); }
 
 template <int D, int R>
-static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, const float* lab, int dil, float warmup,
-                        const EvalWs& ws, const LossState& st, float* losses, float* g_logits, const float* up_prj,
-                        const float* up_pw, int n_cb) {
-    BXI_LAUNCH("pair", s, (pair_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, (const WorkRec2*)ws.work, (const int*)ws.nwork, lab,
-               up_prj, up_pw, n_cb, dil, warmup, losses, g_logits, a, ws, st);
+static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, float warmup, float n2max, int zero_bit, int n_pb, int n_items,
+                        const ValidCells& vc, const Ws& ws, const LossState& st, float* losses, float* g_logits, const float* up_prj, const float* up_pw) {
+    const int lim = g_spin_limit.load(std::memory_order_relaxed);
+    BXI_LAUNCH("pair", s, (pair_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, up_prj, up_pw, warmup, n2max, zero_bit, n_pb, n_items,
+               lim == 0 ? kSpinLimit : lim, vc,
+               losses, g_logits, a, ws, st);
 }
 
+size_t eval_ws_bytes(int B, int N, int h, int w) { return carve(nullptr, B, N, h, w, nullptr); }
 bool fused_eval_supported(int dil) { return dil >= 1 && dil <= kMaxDilFused; }
+void debug_set_spin_limit(int limit) { g_spin_limit.store(limit, std::memory_order_relaxed); }
 
-// One evaluation, two launches.  lab: [B,3,h,w] f32 scratch (prep fills, pair reads).
-int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thresh, const bxi_instances* in, int dil, float warmup,
-                      const float* up_prj, const float* up_pw, float* losses, float* g_logits, void* state, void* workspace,
-                      size_t workspace_bytes, int force_rows, void* stream, const DynArgs* head, int head_C) {
+// One evaluation, two launches.
+int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bxi_instances* in, int dil, float warmup, const float* up_prj,
+                 const float* up_pw, float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, int force_rows,
+                 void* stream, const DynArgs* head, int head_C) {
     InstArgs a;
     int rc = fill_inst(in, a);
     if (rc != BXI_OK) return rc;
@@ -1146,20 +1278,22 @@ int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thre
     hipStream_t s = as_stream(stream);
     PoolArgs pa = {};
     if (batch->Hc != in->Hc || batch->Wc != in->Wc || batch->B != in->B) return BXI_ERR_BAD_SHAPE;
-    rc = fill_pool_args(batch, nullptr, lab, pa);
+    rc = fill_pool_args(batch, nullptr, nullptr, pa);
     if (rc != BXI_OK) return rc;
-    if (batch->B > 0 && (!batch->imgs || !lab)) return BXI_ERR_NULL_POINTER;
+    if (batch->B > 0 && !batch->imgs) return BXI_ERR_NULL_POINTER;
     if (batch->image_masks) return BXI_ERR_UNSUPPORTED;   // explicit masks: use bxi_color_affinity_f32 + bits
     if (a.N == 0) {
         BXI_LAUNCH("zero_losses", s, zero_losses2_kernel, dim3(1), dim3(1), 0, s, losses);
         return check_launch();
     }
-    if (a.N > 65535) return BXI_ERR_BAD_SHAPE;
+    if (a.N >= kMaxInst || a.h > 65535 || a.w > 65535) return BXI_ERR_BAD_SHAPE;
+    if (batch->B <= 0) return BXI_ERR_BAD_SHAPE;
     if (g_logits && !state) return BXI_ERR_NULL_POINTER;
-    const size_t need = carve_eval(nullptr, a.N, a.h, a.w, nullptr);
+    const bool pooled_in_launch = pool_vec_ok(batch, a.stride);     // else: the generic pooling kernels in launches of their own
+    const size_t need = carve(nullptr, batch->B, a.N, a.h, a.w, nullptr);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
-    EvalWs ws;
-    carve_eval(workspace, a.N, a.h, a.w, &ws);
+    Ws ws;
+    carve(workspace, batch->B, a.N, a.h, a.w, &ws);
     LossState st = {};
     if (state) {
         if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
@@ -1167,34 +1301,30 @@ int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thre
     }
     const int vec = ((a.w & 3) == 0 && (reinterpret_cast<uintptr_t>(a.logits) & 15) == 0 &&
                      (!g_logits || (reinterpret_cast<uintptr_t>(g_logits) & 15) == 0)) ? 1 : 0;
-    static const int env_rows = [] { const char* e = getenv("BXI_TILE_ROWS"); return e ? atoi(e) : 0; }();   // developer knob
+    static const int env_rows = env_int("BXI_TILE_ROWS", 0);            // developer knobs
+    static const int env_pool_first = env_int("BXI_POOL_FIRST", 0);
+    static const int env_pool_wgs = env_int("BXI_POOL_WGS_PER_CU", 5);
     if (!force_rows) force_rows = env_rows;
-    const int R = force_rows == 4 || force_rows == 8 ? force_rows : tile_rows_for(a.N, a.h, a.w, dil);
+    const int R = force_rows == 4 || force_rows == 8 ? force_rows : tile_rows_for(a.N);
+    if (eval_cap(a.N, a.h, a.w, dil, R) >= (1 << 24)) return BXI_ERR_BAD_SHAPE;     // the table packs a tile prefix into 24 bits
+    const HostPred pr = host_pred(color_thresh);
 
     // ---- launch 1 --------------------------------------------------------------------------------------------------
-    int n_pool = 0, n_items = 0;
-    const int n_tab = (a.N + kWaves - 1) / kWaves;
-    const int n_stream = a.N * ((a.h + kSBlk - 1) / kSBlk);
-    if (batch->B > 0) {
-        if (pool_vec_ok(batch, a.stride)) {
-            // one item = the 4 input rows of 64 pooled pixels.  The whole launch should be resident at once (5 workgroups
-            // per CU at <= 96 VGPRs): a pool workgroup takes several items, the next one's loads in flight, when it is not.
-            n_items = batch->B * a.h * ((a.w + 63) / 64);
-            const int room = 5 * device_cus() - n_tab - (head ? 0 : n_stream);
-            const int per = room > 0 ? (n_items + room - 1) / room : 8;
-            n_pool = (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per);
-        }
-        else {                               // unaligned canvas / other strides: separate scalar pooling launch
-            rc = launch_pool(batch, a.stride, nullptr, lab, s);
-            if (rc != BXI_OK) return rc;
-        }
-    }
+    const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
+    const int Sn = (a.h + kSBlk - 1) / kSBlk;
+    const int n_stream = a.N * Sn;
+    // one item = the 4 input rows of 64 pooled pixels.  The whole launch should be resident at once (5 workgroups per CU at
+    // <= 96 VGPRs): a pool workgroup takes several items, the next one's loads in flight, when it is not.
+    const int64_t n_items64 = (int64_t)batch->B * a.h * ((a.w + 63) / 64);
+    if (n_items64 > 0x7fffffffLL) return BXI_ERR_BAD_SHAPE;
+    const int n_items = (int)n_items64;
+    const int room = env_pool_wgs * device_cus() - n_tab - (head ? 0 : n_stream);
+    const int per = room > 0 ? (n_items + room - 1) / room : 8;
+    const int n_pool = pooled_in_launch ? (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per) : 0;
     size_t lds1 = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
-    if (lds1 < 8 * (size_t)kWaves * a.w) lds1 = 8 * (size_t)kWaves * a.w;
     if (head) {
-        // the head-fused first launch (factor 2, vector rows, the pooled fast path): tables, pool blocks, head tiles
-        if (head->factor != 2 || !vec || head->H * 2 != a.h || head->W * 2 != a.w || head->N != a.N || head->B != in->B ||
-            (batch->B > 0 && !pool_vec_ok(batch, a.stride)))
+        // the head-fused first launch (factor 2, vector rows): tables, pool blocks, head tiles
+        if (head->factor != 2 || !vec || head->H * 2 != a.h || head->W * 2 != a.w || head->N != a.N || head->B != in->B || !pooled_in_launch)
             return BXI_ERR_UNSUPPORTED;
         const int tiles = ((head->H + kYR - 1) / kYR) * ((head->W + kYC - 1) / kYC);
         ws.n_cb = (head->H + kYR - 1) / kYR;
@@ -1204,40 +1334,60 @@ int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thre
         if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
         float* logits_out = const_cast<float*>(a.logits);
         const unsigned grid1 = (unsigned)(n_tab + n_pool + a.N * tiles);
-        if (head_C == 16 && head->rel)
-            BXI_LAUNCH("head_prep", s, (head_prep_kernel<16, true>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
-        else if (head_C == 16)
-            BXI_LAUNCH("head_prep", s, (head_prep_kernel<16, false>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
-        else if (head_C == 8 && head->rel)
-            BXI_LAUNCH("head_prep", s, (head_prep_kernel<8, true>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
-        else if (head_C == 8)
-            BXI_LAUNCH("head_prep", s, (head_prep_kernel<8, false>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, color_thresh, ws, st, g_logits, *head, head->params, logits_out);
-        else
-            return BXI_ERR_UNSUPPORTED;
+#define BXI_HEAD_LAUNCH(CC, RR)                                                                                                          \
+        BXI_LAUNCH("head_prep", s, (head_prep_kernel<CC, RR>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, ws, st,     \
+                   g_logits, *head, head->params, logits_out)
+        if (head_C == 16 && head->rel) BXI_HEAD_LAUNCH(16, true);
+        else if (head_C == 16) BXI_HEAD_LAUNCH(16, false);
+        else if (head_C == 8 && head->rel) BXI_HEAD_LAUNCH(8, true);
+        else if (head_C == 8) BXI_HEAD_LAUNCH(8, false);
+        else return BXI_ERR_UNSUPPORTED;
+#undef BXI_HEAD_LAUNCH
     } else {
+        if (lds1 < 8 * (size_t)kWaves * a.w) lds1 = 8 * (size_t)kWaves * a.w;
         if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
-        BXI_LAUNCH("prep", s, prep_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R,
-                   color_thresh, ws, st, g_logits, vec);
+        BXI_LAUNCH("prep", s, prep_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, ws, st,
+                   g_logits, vec, env_pool_first);
     }
     rc = check_launch();
     if (rc != BXI_OK) return rc;
+    if (!pooled_in_launch) {
+        rc = launch_pool(batch, a.stride, nullptr, ws.lab_planar, s);
+        if (rc != BXI_OK) return rc;
+        const int64_t BP = (int64_t)batch->B * a.h * a.w;
+        BXI_LAUNCH("pack_lab4", s, pack_lab4_kernel, dim3((unsigned)((BP + 255) / 256 > 2048 ? 2048 : (BP + 255) / 256)), dim3(256), 0, s,
+                   (const float*)ws.lab_planar, ws.lab4, ws.pred, batch->B, (int64_t)a.h * a.w);
+        rc = check_launch();
+        if (rc != BXI_OK) return rc;
+    }
 
     // ---- launch 2 --------------------------------------------------------------------------------------------------
-    const int cap = eval_cap(a.N, a.h, a.w, dil, R);
-    int n_cb = (cap + kWaves - 1) / kWaves;
-    // the list length is device data: the tile waves stride through it.  3 (R = 4: <= 168 VGPRs) or 2 (R = 8) workgroups per
-    // CU are resident: leaders + count + math blocks should fit in one round.
-    const int room2 = ((R == 4 ? 3 : 2) * device_cus() - a.N) / 2;
-    if (n_cb > (room2 > 64 ? room2 : 64)) n_cb = room2 > 64 ? room2 : 64;
+    const int64_t cap = eval_cap(a.N, a.h, a.w, dil, R);
+    int64_t n_tb = (cap + kWaves - 1) / kWaves;
+    // the tile list's length is device data: the tile waves stride through it.  The launch should be resident in one round:
+    // 4 (R = 4: <= 128 VGPRs) or 2 (R = 8) workgroups per CU; the predicate waves are short-lived.
+    static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 0);
+    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? (dil <= 3 ? 4 : 3) : 2);
+    const int slots = occ * device_cus() - a.N - 1;
+    int n_pb = (n_items + kWaves - 1) / kWaves;
+    if (n_pb > slots / 2) n_pb = slots / 2 > 1 ? slots / 2 : 1;
+    if (n_tb > slots - n_pb) n_tb = slots - n_pb > 64 ? slots - n_pb : 64;
     size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
     const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
     if (lds2 < lds_leader) lds2 = lds_leader;
     if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
-    const int grid = a.N + 2 * n_cb + 1;                 // + the finisher
-#define BXI_PAIR_CASE(DD)                                                                                                    \
-    case DD:                                                                                                                 \
-        if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, lab, dil, warmup, ws, st, losses, g_logits, up_prj, up_pw, n_cb);   \
-        else launch_pair<DD, 8>(s, grid, lds2, a, lab, dil, warmup, ws, st, losses, g_logits, up_prj, up_pw, n_cb);          \
+    const int grid = a.N + n_pb + (int)n_tb + 1;          // leaders + predicate blocks + tile blocks + the finisher
+    ValidCells vc = {};
+    for (int b = 0; b < batch->B; ++b) {                  // the device formula (valid_cells), evaluated here once per image
+        const int half = a.stride / 2;
+        auto cells = [&](int limit, int n) { const int v = limit - half <= 0 ? 0 : (limit - half + a.stride - 1) / a.stride; return v < n ? v : n; };
+        vc.vrow[b] = cells(pa.meta.img_h[b] < pa.meta.first_removed[b] ? pa.meta.img_h[b] : pa.meta.first_removed[b], a.h);
+        vc.vcol[b] = cells(pa.meta.img_w[b], a.w);
+    }
+#define BXI_PAIR_CASE(DD)                                                                                                                  \
+    case DD:                                                                                                                               \
+        if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw); \
+        else launch_pair<DD, 8>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw);        \
         break;
     switch (dil) {
         BXI_PAIR_CASE(1) BXI_PAIR_CASE(2) BXI_PAIR_CASE(3) BXI_PAIR_CASE(4)
@@ -1247,8 +1397,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float* lab, float color_thre
     return check_launch();
 }
 
-int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits,
-                   void* stream) {
+int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits, void* stream) {
     InstArgs a;
     int rc = fill_inst(in, a);
     if (rc != BXI_OK) return rc;

@@ -177,7 +177,7 @@ int bxi_boxinst_loss_fwd_bwd_f32(const bxi_instances* inst_host, const uint8_t* 
 int bxi_boxinst_loss_backward_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw,
                                   int dilation, const void* state, float* g_logits, void* stream);
 
-/* The evaluation proper: forward AND finished backward in one host call, two launches (prep3, pair3; csrc/eval3.hip):
+/* The evaluation proper: forward AND finished backward in one host call, two launches (prep, pair; csrc/fused_eval.hip):
  *   launch 1: image side (stage A above: de-normalise, 4x4 pool, Lab) next to the logit streaming (row / column maxima,
  *             zero-fill of g_logits) and the per-instance table; nothing in it waits;
  *   launch 2: projection term per instance (:117-143), pair weights and pairwise term per box tile (pairwise.cu:68-149 semantics;
@@ -230,6 +230,11 @@ int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_insta
                               int size, int dilation, float color_thresh, float warmup,
                               const float* up_prj, const float* up_pw, float* losses, float* g_logits, void* state,
                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* Test hook: the poll budget of the evaluation's bounded in-kernel waits.  0 = the built-in budget (far beyond any launch);
+ * negative = every bounded wait gives up at once, which makes the failure path observable: NaN losses, status word, and a
+ * gradient poisoned by bxi_boxinst_grad_rescale_f32.  Process-wide; not for production use. */
+void bxi_debug_set_spin_limit(int limit);
 
 /* g_logits finished by bxi_boxinst_eval_f32 for the factors recorded in `state`  ->  finished for (g_prj, g_pw)
  * (DEVICE scalars: the upstream gradients autograd hands over; no host sync).  The kernel returns at once when they

@@ -61,7 +61,7 @@ def test_loss_vs_reference(dev, name):
 
 
 def test_lab_kernels_match_real_scikit_image(dev):
-    """Both Lab producers on the GPU -- pool_rgb (get_targets API) and the pool blocks of prep3_kernel (the evaluation) -- against
+    """Both Lab producers on the GPU -- pool_rgb (get_targets API) and the pool blocks of prep_kernel (the evaluation) -- against
     skimage.color.rgb2lab itself (scikit-image 0.18.3; tests/golden/lab_skimage.npz, made by make_lab_golden.py in the build
     container): 65 536 colours as a 1024x1024 image of constant 4x4 blocks, so that every pooled pixel is one fixture colour."""
     import os
@@ -91,4 +91,4 @@ def test_lab_kernels_match_real_scikit_image(dev):
     from boxinstseg_amd import _lib
     off = _lib.load().bxi_boxinst_eval_workspace_lab_offset()
     lab4 = ws[off:off + 256 * 256 * 16].view(torch.float32).view(256, 256, 4).cpu().numpy()        # (L, a, b, tag) per pooled pixel
-    check(np.ascontiguousarray(lab4[:, :, :3].transpose(2, 0, 1)), 'prep3_kernel pool blocks')
+    check(np.ascontiguousarray(lab4[:, :, :3].transpose(2, 0, 1)), 'prep_kernel pool blocks')

@@ -261,6 +261,65 @@ def test_deterministic(dev):
     assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
 
 
+def test_wait_timeouts_are_loud(dev):
+    """The second launch's bounded waits (tile waves for the predicate bytes / the normaliser, the finisher for everybody) never run
+    out in practice; when they do -- forced here through the test hook -- the evaluation must not hand back plausible numbers: both
+    losses are NaN (mmdet's CheckInvalidLossHook fires, mmdet/core/hook/checkloss_hook.py:20-24), the status word is set and the
+    gradient is poisoned.  (The reference surfaces launch failures through AT_CUDA_CHECK, pairwise.cu:173,200.)"""
+    import math
+    from boxinstseg_amd import _lib, boxinst_mask_loss, functional as Fh
+    lib = _lib.load()
+    d = synthetic.cfg1(0)
+    good = hip_loss(d, dev)
+    lib.bxi_debug_set_spin_limit(-1)
+    try:
+        Fh.DEBUG_KEEP_LAST = True
+        t = to_dev(d, dev)
+        x = t['logits'].clone().requires_grad_(True)
+        out = boxinst_mask_loss(x, t['gt_inds'], t['gt_bboxes'], imgs=t['imgs'], img_metas=d['img_metas'])
+        (out['loss_prj'] + out['loss_pairwise']).backward()
+        torch.cuda.synchronize()
+        assert math.isnan(float(out['loss_prj'])) and math.isnan(float(out['loss_pairwise']))
+        status, _ = Fh.last_eval_status()
+        assert status != 0
+        assert bool(torch.isnan(x.grad).all())
+    finally:
+        lib.bxi_debug_set_spin_limit(0)
+    again = hip_loss(d, dev)                                   # and nothing sticks
+    assert again[0] == good[0] and again[1] == good[1] and np.array_equal(again[2], good[2])
+
+
+def test_two_streams_next_to_a_kernel_that_fills_the_gpu(dev):
+    """Two evaluations in flight on two streams while a third stream keeps every CU busy with matrix products: the in-kernel waits of
+    the second launch (tile waves for earlier workgroups of their own grid) must still be met -- a time-out would turn the losses
+    into NaN -- and the results must be those of the quiet, serial runs, bit for bit."""
+    from boxinstseg_amd import boxinst_mask_loss
+    ds = [synthetic.cfg1(7), synthetic.make_batch(B=2, H=192, W=256, boxes_per_img=4, seed=41, min_box=24, max_box=150)]
+    quiet = [hip_loss(d, dev) for d in ds]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    hog = torch.randn(4096, 4096, device=dev)
+    ts = [to_dev(d, dev) for d in ds]
+    xs = [t['logits'].clone().requires_grad_(True) for t in ts]
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(6):
+        with torch.cuda.stream(streams[2]):
+            for _ in range(4):
+                hog = (hog @ hog).clamp_(-1.0, 1.0)
+        outs = []
+        for k in (0, 1):
+            with torch.cuda.stream(streams[k]):
+                xs[k].grad = None
+                o = boxinst_mask_loss(xs[k], ts[k]['gt_inds'], ts[k]['gt_bboxes'], imgs=ts[k]['imgs'], img_metas=ds[k]['img_metas'],
+                                      out_stride=ds[k]['stride'])
+                (o['loss_prj'] + o['loss_pairwise']).backward()
+                outs.append(o)
+        torch.cuda.synchronize()
+        for k in (0, 1):
+            assert float(outs[k]['loss_prj']) == quiet[k][0] and float(outs[k]['loss_pairwise']) == quiet[k][1], (rep, k)
+            assert np.array_equal(xs[k].grad.cpu().numpy()[:, 0], quiet[k][2]), (rep, k)
+
+
 def test_loss_cfg2_full_size(dev):
     """The headline configuration against the C oracle (a few seconds of CPU)."""
     lp, lw = _check(synthetic.cfg2(0), dev)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): run one cfg-2 evaluation with the -DBXI_TRACE library and print per-wave phase timings
-(100 MHz wall clock) of prep3_kernel / pair3_kernel (csrc/eval3.hip).  Build first:
+(100 MHz wall clock) of prep_kernel / pair_kernel (csrc/fused_eval.hip).  Build first:
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBXI_TRACE -mllvm -amdgpu-kernarg-preload-count=16 \
         -o boxinstseg_amd/lib/libboxinst_hip_trace.so boxinstseg_amd/csrc/*.hip"""
 import os, sys, ctypes as C
@@ -10,7 +10,7 @@ from boxinstseg_amd import _lib, build as hb
 hb.LIB_PATH = os.path.join(hb.LIB_DIR, 'libboxinst_hip_trace.so')
 from boxinstseg_amd import functional as Fh, synthetic
 lib = _lib.load()
-lib.bxi_debug_set_trace3.argtypes = [C.c_void_p]
+lib.bxi_debug_set_trace2.argtypes = [C.c_void_p]
 dev = torch.device('cuda:0')
 ones = torch.ones(2, device=dev)
 sets = []
@@ -32,7 +32,7 @@ def ev(s):
 for i in range(60): ev(sets[i % 8])
 torch.cuda.synchronize()
 trace = torch.zeros((4, 8192, 8), dtype=torch.int64, device=dev)
-assert lib.bxi_debug_set_trace3(trace.data_ptr()) == 0
+assert lib.bxi_debug_set_trace2(trace.data_ptr()) == 0
 torch.cuda._sleep(int(0.02 * 2e9)); ev(sets[3]); torch.cuda.synchronize()
 t = trace.cpu().numpy().astype(np.float64)
 us = lambda x: x * 0.01
