@@ -412,6 +412,209 @@ __global__ __launch_bounds__(256) void pairwise3_bwd_kernel(const T* __restrict_
     }
 }
 
+// ---- f32, size == 3, rows of whole float4 (W % 4 == 0, 16-byte aligned planes): the "wide" kernels ------------------------------
+// The kernels above give a lane one column and four rows: 32 (forward) / 64 (backward) four-byte memory instructions per thread,
+// and at 52 MB of output / input the launch is bound by ISSUING them (MI355X_MICROARCH.md: epilogue store tails are store-issue
+// bound; 16-byte accesses halve them).  Here a thread owns FOUR ADJACENT PIXELS of one row of the 16 x 64 tile:
+//   forward   every pixel evaluates all eight of its pairs itself (f(p,q) = f(q,p) bit for bit, so the partner would get the same
+//             number): 8 x float4 stores per thread, aligned, no partner stores, no edge cases; the second evaluation of a pair
+//             is two multiply-adds and one v_log_f32 against 4 x fewer store instructions;
+//   backward  d f/d x_p summed over all eight taps by the pixel itself (the tap evaluations are the ones the branch-free body
+//             above already made; the LDS deposit slots, their zeroing and the second barrier go): 8 aligned float4 loads of
+//             g[k][p] + 8 dword-aligned float4 loads of the partner terms g[7-k][p + delta_k] per thread instead of 64 dword loads.
+// The neighbours' probabilities of the four pixels overlap: 3 rows x (4 + 2d) staged entries are read once per thread.
+// A tile with a logit beyond +-34 (S could underflow) takes a per-pixel log-space path straight from global memory, exactly
+// pairwise.cu:38-58 (block-uniform choice, no extra LDS).
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // a float4 at any dword address
+
+// staged tile: two planes of floats, s = sigmoid(x) and m = sigmoid(-x), rows padded to a multiple of 4 floats so that a thread
+// reads its 4 + 2 D neighbour columns of a row as whole float4 (ds_read_b128 at a 16-byte lane stride: conflict-free; 8-byte
+// (s, m) pairs at a 32-byte lane stride put 32 lanes on 8 banks)
+template <int D, int TC> struct PwGeom { static constexpr int PC = (TC + 2 * D + 3) & ~3, NW4 = (4 + 2 * D + 3) / 4; };
+
+template <int D, int TR, int TC>
+__device__ __forceinline__ void pw3_stage_probs(const float* __restrict__ L, int H, int W, int r0, int c0, float* ts, float* tm, bool& sat_out) {
+    constexpr int PR = TR + 2 * D, PCs = TC + 2 * D, PC = PwGeom<D, TC>::PC;
+    constexpr int kMaxE = (PR * PCs + 255) / 256;
+    float xv[kMaxE];
+    bool sat = false;
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) {
+        const int i = threadIdx.x + 256 * e;
+        const int r = r0 - D + i / PCs, cq = c0 - D + i % PCs;
+        xv[e] = 0.f;          // outside the map: never used as a neighbour (those taps weigh 0)
+        if (i < PR * PCs && (unsigned)r < (unsigned)H && (unsigned)cq < (unsigned)W) { xv[e] = L[(uint32_t)(r * W + cq)]; sat |= !(fabsf(xv[e]) <= 34.f); }
+    }
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) {
+        const int i = threadIdx.x + 256 * e;
+        if (i < PR * PCs) {
+            const float x = xv[e], en = fast_exp_neg(fabsf(x)), big = fast_rcp(1.f + en), small = en * big;   // sigmoid(|x|), sigmoid(-|x|)
+            const int o = (i / PCs) * PC + i % PCs;
+            ts[o] = x >= 0.f ? big : small;
+            tm[o] = x >= 0.f ? small : big;
+        }
+    }
+    sat_out = __syncthreads_or(sat ? 1 : 0) != 0;       // also: the staged tile is complete
+}
+
+// rows r - D, r, r + D ; columns c - D .. : the thread's window of one plane
+template <int D, int TC>
+__device__ __forceinline__ void pw3_window(const float* plane, int lr, int lc, float (&q)[3][4 * PwGeom<D, TC>::NW4]) {
+    constexpr int PC = PwGeom<D, TC>::PC, NW4 = PwGeom<D, TC>::NW4;
+#pragma unroll
+    for (int y = 0; y < 3; ++y)
+#pragma unroll
+        for (int x4 = 0; x4 < NW4; ++x4) {
+            const float4 v = *reinterpret_cast<const float4*>(plane + (lr + y * D) * PC + lc + 4 * x4);
+            q[y][4 * x4] = v.x; q[y][4 * x4 + 1] = v.y; q[y][4 * x4 + 2] = v.z; q[y][4 * x4 + 3] = v.w;
+        }
+}
+
+template <int D, int TR, int TC>
+__global__ __launch_bounds__(256) void pairwise3_fwd_wide_kernel(const float* __restrict__ logits, int H, int W, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_raw[];
+    constexpr int PC = PwGeom<D, TC>::PC, NWp = 4 * PwGeom<D, TC>::NW4;
+    static_assert(TR * TC == 1024 && TC % 4 == 0, "256 threads x four adjacent pixels");
+    const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int64_t n = t / tiles_y;
+    const int64_t P = (int64_t)H * W;
+    const int r0 = ty * TR, c0 = tx * TC;
+    const float* L = logits + n * P;
+    float* ts = reinterpret_cast<float*>(pw_raw);
+    float* tm = ts + (TR + 2 * D) * PC;
+    bool sat;
+    pw3_stage_probs<D, TR, TC>(L, H, W, r0, c0, ts, tm, sat);
+    const int lr = threadIdx.x / (TC / 4), lc = (threadIdx.x % (TC / 4)) * 4;
+    const int r = r0 + lr, c = c0 + lc;
+    if (r >= H || c >= W) return;                                        // W % 4 == 0: the four pixels are in the map together
+    char* ob = reinterpret_cast<char*>(out + n * 8 * P);                 // wave-uniform; 8 planes of one instance < 2^31 bytes (launcher)
+    const uint32_t plane = (uint32_t)P * 4u, pix = (uint32_t)(r * W + c) * 4u;
+    if (sat) {                                                           // rare: log space, straight from global memory
+        for (int i = 0; i < 4; ++i) {
+            const float here = L[r * W + c + i];
+            const float ax = logsig(here), bx = logsig(-here);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int kk = k < 4 ? k : k + 1, r2 = r + (kk / 3 - 1) * D, c2 = c + i + (kk % 3 - 1) * D;
+                float v = 0.f;
+                if (r2 >= 0 && r2 < H && c2 >= 0 && c2 < W) { const float there = L[r2 * W + c2]; v = pair_nlog(ax, bx, logsig(there), logsig(-there)); }
+                *reinterpret_cast<float*>(ob + (uint32_t)k * plane + pix + 4u * i) = v;
+            }
+        }
+        return;
+    }
+    float qs[3][NWp], qm[3][NWp];                                        // rows r - D, r, r + D ; columns c - D .. c + 3 + D
+    pw3_window<D, TC>(ts, lr, lc, qs);
+    pw3_window<D, TC>(tm, lr, lc, qm);
+    const bool r_lo = r - D >= 0, r_hi = r + D < H;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;
+        const bool row_in = dy < 0 ? r_lo : (dy > 0 ? r_hi : true);
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = row_in && (dx < 0 ? c + i - D >= 0 : (dx > 0 ? c + i + D < W : true));
+            const float S = qs[1][D + i] * qs[1 + dy][D + i + dx * D] + qm[1][D + i] * qm[1 + dy][D + i + dx * D];
+            v[i] = in ? -0.69314718055994531f * __builtin_amdgcn_logf(S) : 0.f;                 // pairwise.cu:43-44: padded pairs are 0
+        }
+        *reinterpret_cast<float4*>(ob + (uint32_t)k * plane + pix) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <int D, int TR, int TC>
+__global__ __launch_bounds__(256, 5) void pairwise3_bwd_wide_kernel(const float* __restrict__ logits, const float* __restrict__ g_pair, int H, int W,
+                                                                 float* __restrict__ g_logits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_raw[];
+    constexpr int PC = PwGeom<D, TC>::PC, NWp = 4 * PwGeom<D, TC>::NW4;
+    static_assert(TR * TC == 1024 && TC % 4 == 0, "256 threads x four adjacent pixels");
+    const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int64_t n = t / tiles_y;
+    const int64_t P = (int64_t)H * W;
+    const int r0 = ty * TR, c0 = tx * TC;
+    const float* L = logits + n * P;
+    const int lr = threadIdx.x / (TC / 4), lc = (threadIdx.x % (TC / 4)) * 4;
+    const int r = r0 + lr, c = c0 + lc;
+    const bool live = r < H && c < W;
+    // the gradient sums G = g[k][p] + g[7-k][q] of the thread's four pixels: 16 sixteen-byte loads, requested before the tile is
+    // staged so that they fly meanwhile.  A partner outside the map gets weight 0 later: its address only has to stay inside the
+    // instance's 8 planes (one clamp on the byte offset).
+    const char* gb = reinterpret_cast<const char*>(g_pair + n * 8 * P);  // wave-uniform base + 32-bit byte offsets
+    const int plane = (int)P * 4, lim = 8 * plane - 16;
+    const int pix = (min(r, H - 1) * W + min(c, W - 4)) * 4;
+    // PMC (profiles/r03_pairwise_op_pmc.txt): 91 MB come over the fabric for 59 MB of input and nearly every L2 request misses -- 5
+    // workgroups x 64 KB per CU in flight are far more than the 4 MB L2 of an XCD keeps, so the partner terms (the same lines, shifted)
+    // are fetched a second time.  Tried and measured: the two reads of a plane issued back to back (this form, 19.0 us), eight
+    // instructions apart (19.4), a memory round trip apart (22.8: more evictions), a resident grid walking its tiles with the next
+    // tile's loads in flight (21.2), 8 x 128 and 4 x 256 tiles (19.0 / 20.2).  What would remove the second fetch is staging the
+    // gradient planes through LDS (one fetch per workgroup + halo): not built.
+    float4 own[8];
+    f4u part[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 7 - j, kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;      // plane j is the partner plane of channel k = 7 - j
+        own[j] = *reinterpret_cast<const float4*>(gb + (uint32_t)(j * plane + pix));
+        const int nb = min(max(j * plane + pix + ((dy * D) * W + dx * D) * 4, 0), lim);
+        part[k] = *reinterpret_cast<const f4u*>(gb + (uint32_t)nb);
+    }
+    float4 G[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) G[k] = make_float4(own[k].x + part[k].x, own[k].y + part[k].y, own[k].z + part[k].z, own[k].w + part[k].w);
+    float* ts = reinterpret_cast<float*>(pw_raw);
+    float* tm = ts + (TR + 2 * D) * PC;
+    bool sat;
+    pw3_stage_probs<D, TR, TC>(L, H, W, r0, c0, ts, tm, sat);
+    if (!live) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (sat) {                                                           // rare: log space, straight from global memory (pairwise.cu:56-58)
+        for (int i = 0; i < 4; ++i) {
+            const float here = L[r * W + c + i];
+            const float ax = logsig(here), bx = logsig(-here);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int kk = k < 4 ? k : k + 1, r2 = r + (kk / 3 - 1) * D, c2 = c + i + (kk % 3 - 1) * D;
+                if (r2 >= 0 && r2 < H && c2 >= 0 && c2 < W) {
+                    const float there = L[r2 * W + c2];
+                    const float ay = logsig(there), by = logsig(-there);
+                    const float pair = pair_nlog(ax, bx, ay, by);
+                    const float g = i == 0 ? G[k].x : (i == 1 ? G[k].y : (i == 2 ? G[k].z : G[k].w));
+                    acc[i] += -(expf(ay) - expf(by)) * expf(ax + bx + pair) * g;
+                }
+            }
+        }
+    } else {
+        float qs[3][NWp], qm[3][NWp];
+        pw3_window<D, TC>(ts, lr, lc, qs);
+        pw3_window<D, TC>(tm, lr, lc, qm);
+        const bool r_lo = r - D >= 0, r_hi = r + D < H;
+        float up[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) up[i] = qs[1][D + i] * qm[1][D + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;
+            const bool row_in = dy < 0 ? r_lo : (dy > 0 ? r_hi : true);
+            const float g4[4] = {G[k].x, G[k].y, G[k].z, G[k].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float ns = qs[1 + dy][D + i + dx * D], nm = qm[1 + dy][D + i + dx * D];
+                const bool in = row_in && (dx < 0 ? c + i - D >= 0 : (dx > 0 ? c + i + D < W : true));
+                const float S = qs[1][D + i] * ns + qm[1][D + i] * nm;   // >= 3e-15: every |logit| <= 34
+                const float m = in ? g4[i] * fast_rcp(S) : 0.f;          // d f / d x_p = -(s_q - s'_q) s_p s'_p / S
+                acc[i] += -(ns - nm) * up[i] * m;
+            }
+        }
+    }
+    *reinterpret_cast<float4*>(g_logits + n * P + (int64_t)r * W + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
 template <typename T>
 static size_t pw3_lds(int d) { return sizeof(LogPair<T>) * (size_t)(kPwTR + 2 * d) * (kPwTC + 2 * d); }
 template <typename T>
@@ -429,10 +632,21 @@ static int launch_fwd(const T* logits, int N, int H, int W, int size, int dil, T
     if (size == 3 && dil <= kPwMaxDil) {
         const int64_t tiles = (int64_t)N * ((H + kPwTR - 1) / kPwTR) * ((W + kPwTC - 1) / kPwTC);
         if (fits_i32(tiles)) {
-            if (sizeof(T) == 4 && (int64_t)8 * H * W * 4 < ((int64_t)1 << 31)) {      // the fast kernel addresses an instance's planes by 32-bit byte offsets
+            if (sizeof(T) == 4 && (int64_t)8 * H * W * 4 < ((int64_t)1 << 31)) {      // the fast kernels address an instance's planes by 32-bit byte offsets
                 const dim3 g((unsigned)tiles), b(block);
                 const size_t lds = pw3_lds<T>(dil);
                 hipStream_t st = as_stream(stream);
+                const bool wide = dil <= 4 && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+                if (wide) {
+#define BXI_PWF(DD)                                                                                                                             \
+                    {                                                                                                                           \
+                        const size_t ldw = 2 * sizeof(float) * (size_t)(kPwTR + 2 * DD) * PwGeom<DD, kPwTC>::PC;                             \
+                        BXI_LAUNCH("pairwise_fwd", st, (pairwise3_fwd_wide_kernel<DD, kPwTR, kPwTC>), g, b, ldw, st, (const float*)logits, H, W, (float*)out); \
+                    }
+                    switch (dil) { case 1: BXI_PWF(1) break; case 2: BXI_PWF(2) break; case 3: BXI_PWF(3) break; default: BXI_PWF(4) break; }
+#undef BXI_PWF
+                    return check_launch();
+                }
                 switch (dil) {
                     case 1: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<1>, g, b, lds, st, (const float*)logits, H, W, dil, (float*)out); break;
                     case 2: BXI_LAUNCH("pairwise_fwd", st, pairwise3_fwd_fast_kernel<2>, g, b, lds, st, (const float*)logits, H, W, dil, (float*)out); break;
@@ -479,6 +693,17 @@ static int launch_bwd(const T* logits, const T* g_pair, int N, int H, int W, int
                 BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_kernel<T, DD>), g, b, lds, st, logits, g_pair, H, W, dil, g_logits);             \
             }
             if constexpr (sizeof(T) == 4) {
+                if (dil <= 4 && (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(g_pair) | reinterpret_cast<uintptr_t>(g_logits)) & 15) == 0) {
+#define BXI_PWB(DD)                                                                                                                             \
+                    {                                                                                                                           \
+                        const size_t ldw = 2 * sizeof(float) * (size_t)(kPwTR + 2 * DD) * PwGeom<DD, kPwTC>::PC;                             \
+                        BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_wide_kernel<DD, kPwTR, kPwTC>), g, b, ldw, st, (const float*)logits,     \
+                                   (const float*)g_pair, H, W, (float*)g_logits);                                                             \
+                    }
+                    switch (dil) { case 1: BXI_PWB(1) break; case 2: BXI_PWB(2) break; case 3: BXI_PWB(3) break; default: BXI_PWB(4) break; }
+#undef BXI_PWB
+                    return check_launch();
+                }
                 if (dil == 1) BXI_PW3_BWD(1)
                 else if (dil == 2) BXI_PW3_BWD(2)
                 else if (dil == 3) BXI_PW3_BWD(3)
