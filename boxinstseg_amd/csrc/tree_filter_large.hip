@@ -186,7 +186,9 @@ __global__ __launch_bounds__(kLT) void bfs_large_kernel(const int* __restrict__ 
         if (sv < 4) w.adj[4 * (size_t)v + sv] = (uint32_t)u;
     }
     __syncthreads();
+    int over = 0;                                       // a vertex with more than 4 neighbours: not a tree on a grid (edges would be dropped)
     for (int v = tid; v < V; v += kLT) {                // arrival order of the atomics -> ascending neighbour ids
+        over |= w.deg[v] > 4u ? 1 : 0;
         const int d = min((int)w.deg[v], 4);
         uint32_t a[4];
         for (int k = 0; k < 4; ++k) a[k] = k < d ? w.adj[4 * (size_t)v + k] : 0xffffffffu;
@@ -222,8 +224,11 @@ __global__ __launch_bounds__(kLT) void bfs_large_kernel(const int* __restrict__ 
         __syncthreads();                                // the next level's nodes are written
         lo = hi; hi = n;
     }
-    if (tid == 0) lv[0] = depth;
     const int nf = n;                                   // < V only for a disconnected input
+    // loud, not silent: a vertex of degree > 4 or an input that is not connected leaves depth = -1, which makes
+    // bxi_tree_refine_* poison its output (the reference's bfs.cu walks whatever it is given; refine.cu then reads garbage)
+    const int broken = __syncthreads_or(over) || nf < V;
+    if (tid == 0) lv[0] = broken ? -1 : depth;
     for (int p = tid; p < V; p += kLT) {
         const uint32_t v = p < nf ? w.nodev[p] : 0u;
         s_index[p] = (int)v;
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(kLT) void tree_refine_large_kernel(RefineArgsL a) {
     const int64_t cb = ((int64_t)b * a.C + ch) * V;
     const RefinePlaneL pl0 = a.pl[0], pl1 = a.pl[1];
     const bool two = a.n_planes > 1;
-    int bad = 0;
+    int bad = lv[0] < 0 ? 1 : 0;                                     // bxi_bfs_forward_i32 found the input not to be a connected grid tree
     for (int i = tid; i < V + kPadL; i += kLT) {
         if (i >= V) { rec[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
         const int p = si[i];

@@ -86,3 +86,17 @@ def parse_losses(losses: Dict[str, torch.Tensor], sync: bool = True, check_keys:
     else:
         log_vars = OrderedDict((k, v.detach()) for k, v in log_vars.items())
     return loss, log_vars
+
+
+def exclude_iter_from_ddp_broadcast(model) -> list:
+    """Call on the model BEFORE wrapping it in ``DistributedDataParallel``: lists every ``CondInstMaskHead._iter`` buffer in
+    ``model._ddp_params_and_buffers_to_ignore``.  DDP's default ``broadcast_buffers=True`` rewrites each buffer in place at the
+    start of every forward; ``_iter`` is identical on all ranks by construction (each rank counts its own calls,
+    condinst_head.py:1297), and a rewrite per iteration makes the head re-read it from the device (one host sync per step).
+    Returns the names added."""
+    from .mask_head import CondInstMaskHead
+    names = [f'{prefix}._iter' if prefix else '_iter' for prefix, m in model.named_modules() if isinstance(m, CondInstMaskHead)]
+    have = list(getattr(model, '_ddp_params_and_buffers_to_ignore', []))
+    model._ddp_params_and_buffers_to_ignore = have + [n for n in names if n not in have]
+    return names
+

@@ -24,6 +24,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import functional as F_hip
 from .dynamic import dynamic_mask_forward
 from .pairwise import pairwise_nlog
@@ -91,6 +92,10 @@ class CondInstMaskHead(nn.Module):
 
         self.register_buffer('sizes_of_interest', torch.tensor(list(sizes_of_interest)))
         self.register_buffer('_iter', torch.zeros([1]))
+        # DistributedDataParallel(broadcast_buffers=True) rewrites every buffer in place at the start of each forward; _iter is the
+        # same on every rank by construction (every rank counts its own calls), and a rewrite per iteration would invalidate the
+        # host mirror below (one sync per step).  boxinstseg_amd.dist.exclude_iter_from_ddp_broadcast(model) lists it in the
+        # wrapped model's _ddp_params_and_buffers_to_ignore (DDP reads that attribute from the module it wraps).
         self._iter_host: Optional[float] = 0.0     # mirror of _iter; None = unknown (state dict loaded)
         self.param_conv = nn.Conv2d(bbox_head_channels, self.num_gen_params, 3, stride=1, padding=1)
         self.init_weights()
@@ -172,13 +177,34 @@ class CondInstMaskHead(nn.Module):
         if not fused:
             logits = self(feat, params, coors, level_inds, img_inds)
             return logits, self.loss(imgs, img_metas, logits, gt_inds, gt_bboxes, gt_masks, gt_labels)
+        # the checks the two calls make (DynamicMaskHead.forward, BoxInstMaskLoss): the fused entry point gets raw pointers
+        n = params.size(0)
+        expect = sum(self.dy_weights) + sum(self.dy_biases)
+        if params.dim() != 2 or params.size(1) != expect:
+            raise RuntimeError(f'params must be [N,{expect}], got {tuple(params.shape)}')
+        if feat.size(1) != self.in_channels:
+            raise RuntimeError(f'mask features have {feat.size(1)} channels, the head was built for {self.in_channels}')
+        for name, t in (('coors', coors), ('level_inds', level_inds), ('img_inds', img_inds), ('gt_inds', gt_inds)):
+            if t.size(0) != n:
+                raise RuntimeError(f'{name} has {t.size(0)} entries for {n} instances')
+        if len(gt_bboxes) != imgs.size(0) or len(img_metas) != imgs.size(0):
+            raise RuntimeError(f'{imgs.size(0)} images but {len(gt_bboxes)} box lists / {len(img_metas)} img_metas')
         warmup = self._tick()
         cfg = dict(out_stride=self.out_stride, bottom_pixels_removed=self.bottom_pixels_removed, pairwise_size=self.pairwise_size,
                    pairwise_dilation=self.pairwise_dilation, pairwise_color_thresh=self.pairwise_color_thresh,
                    warmup_factor=warmup)
-        logits, loss_prj, loss_pw = F_hip.HeadBoxInstLoss.apply(
-            feat, params, coors, level_inds, img_inds, self.sizes_of_interest, (self.in_stride, factor, self.disable_rel_coors),
-            imgs, img_metas, gt_inds, gt_bboxes, cfg)
+        try:
+            logits, loss_prj, loss_pw = F_hip.HeadBoxInstLoss.apply(
+                feat, params, coors, level_inds, img_inds, self.sizes_of_interest, (self.in_stride, factor, self.disable_rel_coors),
+                imgs, img_metas, gt_inds, gt_bboxes, cfg)
+        except _lib.BoxInstHipError as e:
+            if e.status != _lib.BXI_ERR_UNSUPPORTED:
+                raise
+            # a configuration the fused launch is not built for after all (e.g. an image tensor that is not 16-byte aligned):
+            # the two calls, as documented; the iteration has been counted once already
+            logits = self(feat, params, coors, level_inds, img_inds)
+            losses = F_hip.boxinst_mask_loss(logits, gt_inds, gt_bboxes, imgs=imgs, img_metas=img_metas, **cfg)
+            return logits, losses
         return logits, {'loss_prj': loss_prj, 'loss_pairwise': loss_pw}
 
     def _composed_forward(self, feat, params, coors, level_inds, img_inds):

@@ -330,3 +330,24 @@ def test_composed_dynamic_head_for_shapes_outside_the_hip_build(convs, ch, cin, 
     assert torch.allclose(got, want, rtol=0, atol=1e-12)
     got.sum().backward()
     assert params.grad is not None and torch.isfinite(params.grad).all()
+
+
+def test_iter_buffer_is_listed_for_ddp_to_skip():
+    """DDP's broadcast_buffers would rewrite `_iter` in place every forward (one host sync per step afterwards): the helper lists it in
+    the wrapped model's `_ddp_params_and_buffers_to_ignore`, under its qualified name, without dropping what is already there."""
+    import torch.nn as nn
+    from boxinstseg_amd import CondInstMaskHead
+    from boxinstseg_amd.dist import exclude_iter_from_ddp_broadcast
+
+    class Det(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mask_head = CondInstMaskHead(in_channels=16, boxinst_enabled=True)
+            self._ddp_params_and_buffers_to_ignore = ['other']
+
+    m = Det()
+    assert exclude_iter_from_ddp_broadcast(m) == ['mask_head._iter']
+    assert m._ddp_params_and_buffers_to_ignore == ['other', 'mask_head._iter']
+    assert 'mask_head._iter' in dict(m.named_buffers())
+    exclude_iter_from_ddp_broadcast(m)
+    assert m._ddp_params_and_buffers_to_ignore.count('mask_head._iter') == 1
