@@ -553,8 +553,10 @@ __global__ __launch_bounds__(256, 5) void pairwise3_bwd_wide_kernel(const float*
     // workgroups x 64 KB per CU in flight are far more than the 4 MB L2 of an XCD keeps, so the partner terms (the same lines, shifted)
     // are fetched a second time.  Tried and measured: the two reads of a plane issued back to back (this form, 19.0 us), eight
     // instructions apart (19.4), a memory round trip apart (22.8: more evictions), a resident grid walking its tiles with the next
-    // tile's loads in flight (21.2), 8 x 128 and 4 x 256 tiles (19.0 / 20.2).  What would remove the second fetch is staging the
-    // gradient planes through LDS (one fetch per workgroup + halo): not built.
+    // tile's loads in flight (21.2), 8 x 128 and 4 x 256 tiles (19.0 / 20.2), and the gradient planes staged through LDS in the four
+    // channel pairs (j, 7 - j) -- one fetch per workgroup + 12 % halo, double-buffered: 21.3 us, four barrier-separated phases cost
+    // more than the second fetch).  A wave of this kernel lives ~11 us: 42 % of it waiting for memory, 44 % for an issue slot (20 waves
+    // a CU, ~115 VALU instructions per pixel); the launch needs 1.3 rounds of residency.  profiles/NOTES.md has the table.
     float4 own[8];
     f4u part[8];
 #pragma unroll
