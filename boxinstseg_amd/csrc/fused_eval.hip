@@ -15,18 +15,20 @@
 //                   of the block's 32 rows -> partials for the leaders of the next launch
 //     pool blocks   the 4 input rows of 64 pooled pixels -> de-normalise, truncate, 4x4 mean, Lab (fp64) -> ONE 16-byte
 //                   store per pooled pixel
-//   launch 2  pair_kernel   [leaders][predicate blocks][tile blocks][finisher]
+//   launch 2  pair_kernel   [predicate blocks][leaders][tile blocks][finisher]
 //     leaders       one block per instance: partial maxima -> maxima -> sigmoid -> dice -> unit projection gradients, ADDED
 //                   (float atomic) at the arg-max positions of the zero-filled gradient.  Nobody waits for a leader but the finisher.
 //     predicate waves  one wave64 per pooled row segment (64 pixels) of an image: the four colour predicates per pixel (one byte)
 //                   -- each unordered pair ONCE PER IMAGE, not once per instance and tile -- and the segment's share of the pair
-//                   weights' sum (a function of the image and the boxes only, :1324-1328) -> one packed integer atomic per segment
+//                   weights' sum (a function of the image and the boxes only, :1324-1328) -> one packed integer atomic per workgroup;
+//                   the finisher's second wave adds the 64 count words up and publishes ONE word (1 << 63 | sum W)
 //     tile waves    one wave64 per box tile (no LDS, no barrier): logits tile + halo in registers, every unordered pair
 //                   evaluated once; g_pw warm/max(sum W,1) d pw is ADDED (float atomic) to the gradient -- an element receives
 //                   at most two additions onto 0 (its tile's and its leader's), so the sum does not depend on their order;
-//                   the tile's share of sum W pw goes to an integer accumulator by an atomic without return.  Its one wait,
-//                   when the logits have arrived and the per-pixel quantities are computed: every predicate wave has arrived
-//                   (they precede it in the grid and never wait), which also delivers sum W, the global normaliser.
+//                   the tile's share of sum W pw goes to an integer accumulator by an atomic without return.  Its two waits:
+//                   its own predicate bytes (bit 7 = evaluated) before the pair loop, the published sum W (the global
+//                   normaliser) after it; both are produced by workgroups that precede it in the grid and never wait
+//                   for a tile.
 //     finisher      the last workgroup: polls the accumulators, writes the two loss values.
 // Every wait is bounded and running out of it is loud: NaN losses, a status word, a poisoned gradient (rescale_kernel).
 // Table entries instead of a work list: a tile wave finds its tile from 16 bytes per instance that every wave reads (the same

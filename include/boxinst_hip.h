@@ -193,7 +193,7 @@ int bxi_boxinst_loss_backward_f32(const bxi_instances* inst_host, const float* g
  * warmup: min(_iter / pairwise_warmup, 1) (:1330-1331), evaluated on the host by the caller.
  * state (bxi_boxinst_loss_state_bytes, 256-B aligned; required with g_logits): arg-max positions, unit projection
  *   gradients, box rectangles, normaliser, the factors applied, and a status word.  Status 0 = fine.  Non-zero = one of the
- *   second launch's bounded in-kernel waits ran out (tile waves wait for the count waves that precede them in the grid, the
+ *   second launch's bounded in-kernel waits ran out (tile waves wait for the predicate waves that precede them in the grid, the
  *   finisher for everybody; neither is expected to): BOTH LOSSES ARE NaN then (the reference surfaces launch failures through
  *   AT_CUDA_CHECK, pairwise.cu:173,200; here mmdet's CheckInvalidLossHook fires), and bxi_boxinst_grad_rescale_f32 poisons the
  *   gradient.
