@@ -243,6 +243,17 @@ def worker(args):
             n += 256
 
     run(args.warmup)
+    # launches per step, counted: the launch hook is called before and after every kernel launch the library makes
+    calls = []
+    cb_count = _lib.LAUNCH_HOOK(lambda name, phase, st, user: calls.append(name))
+    lib.bxi_set_launch_hook(C.cast(cb_count, C.c_void_p), None)
+    try:
+        enqueue(sets[0], stream.cuda_stream)
+    finally:
+        lib.bxi_set_launch_hook(None, None)
+    torch.cuda.synchronize(dev)
+    launches_per_step = len(calls) // 2
+    launched = sorted({c.decode() for c in calls})
     preroll()
     barrier()
     done = torch.cuda.Event()
@@ -286,7 +297,7 @@ def worker(args):
         'config': {'workload': 'BoxInst R-50 FPN loss path, 2x800x1024 synthetic batch, '
                                f'{sets[0].inst.N} instances, 1xMI355X per rank (BASELINE configs[1])',
                    'images_per_step': 2, 'instances': sets[0].inst.N, 'map': [sets[0].inst.h, sets[0].inst.w],
-                   'launch': args.mode, 'launches_per_step': 2, 'input_sets': args.sets, 'preroll_s': PREROLL_S,
+                   'launch': args.mode, 'launches_per_step': launches_per_step, 'kernels_per_step': launched, 'input_sets': args.sets, 'preroll_s': PREROLL_S,
                    'parallelism': f'replicas x{world} (no exchange step inside the path)'},
     }
     if dist is not None:
@@ -358,7 +369,7 @@ def worker(args):
             torch.cuda.synchronize(dev)
         el = time.perf_counter() - t1
         result['autograd_backward_extra'] = {'images_per_s': 2 * args.steps / el, 'us_per_step': el / args.steps * 1e6,
-                                             'note': 'bxi_boxinst_eval_f32 + bxi_boxinst_grad_rescale_f32 (3 launches): the C-ABI '
+                                             'note': 'bxi_boxinst_eval_f32 + bxi_boxinst_grad_rescale_f32 (one launch more than `value`): the C-ABI '
                                                      'sequence behind loss() + backward() when the upstream factors are only '
                                                      'known at backward time'}
         result['head_fused_extra'] = head_fused(lib, Fh, sets, dev, stream, args.steps)
@@ -378,8 +389,8 @@ def worker(args):
 def head_fused(lib, Fh, sets, dev, stream, steps):
     """Extra (not `value`): the step one level out -- CondInstMaskHead.forward + .loss at the C ABI, i.e. the
     dynamic mask head (16 mask-feature channels at stride 8, random parameters) producing the logits the evaluation consumes:
-    bxi_dynamic_mask_forward_f32 + bxi_boxinst_eval_f32 (3 launches) against bxi_boxinst_head_eval_f32 (2 launches: the head's
-    tiles run inside the evaluation's first launch)."""
+    bxi_dynamic_mask_forward_f32 + bxi_boxinst_eval_f32 (2 launches: the head, the single-launch evaluation) against
+    bxi_boxinst_head_eval_f32 (2 launches: the head's tiles run inside the two-launch evaluation's first launch)."""
     vp = C.c_void_p
     g = torch.Generator(device='cpu').manual_seed(0)
     packs = []
@@ -418,7 +429,7 @@ def head_fused(lib, Fh, sets, dev, stream, steps):
 
     out = {}
     with torch.cuda.stream(stream):
-        for name, fn in (('head_then_eval_3_launches', separate), ('head_eval_fused_2_launches', fused)):
+        for name, fn in (('head_then_eval_two_calls', separate), ('head_eval_fused_one_call', fused)):
             for i in range(50):
                 fn(packs[i % len(packs)])
             torch.cuda.synchronize(dev)
@@ -534,14 +545,13 @@ def hull_fraction(d, dil=2, rows=8):
 def algorithmic_bytes(d, N, rows):
     """Compulsory HBM bytes per launch: per-unit figure x units of one launch."""
     px_in = d['B'] * d['H'] * d['W']          # input pixels:     12 B read each (3 x f32)
-    px_small = d['B'] * d['h'] * d['w']       # pooled pixels:    16 B written (Lab as float4) + 1 B (predicate byte cleared) in prep;
-    ipx = N * d['h'] * d['w']                 #                   16 B read + 1 B written (predicate waves) in pair
-    f = hull_fraction(d, rows=rows)           # instance-pixels:  4 B read (logit) + 4 B written (zero-filled gradient) in prep
-    return {
-        'prep': 12 * px_in + 17 * px_small + 4 * ipx + 4 * ipx,
-        # box tiles: logits read (4 B), predicate byte read (1 B), gradient added at the L2 / memory side (4 B read + 4 B written)
-        'pair': 17 * px_small + int(ipx * f) * (4 + 1 + 8),
-    }
+    px_small = d['B'] * d['h'] * d['w']       # pooled pixels:    16 B written (Lab as a tagged float4) by the pool workgroups;
+    ipx = N * d['h'] * d['w']                 #                   16 B read + 4 B written (predicate word) by the predicate waves
+    f = hull_fraction(d, rows=rows)           # instance-pixels:  4 B read (logit) + 4 B written (zero-filled gradient) by the stream workgroups
+    front = 12 * px_in + 16 * px_small + 4 * ipx + 4 * ipx
+    # box tiles: logits read (4 B), predicate word read (4 B), gradient added at the memory side (4 B read + 4 B written)
+    back = 20 * px_small + int(ipx * f) * (4 + 4 + 8)
+    return {'prep': front, 'pair': back, 'eval1': front + back}     # two-launch form: prep + pair; single-launch form: eval1
 
 
 def survey_bytes(d, N):
@@ -606,7 +616,7 @@ def kernel_timing(lib, _lib, sets, stream, enqueue, steps, step_us, rows):
     d0, N = sets[0].d, sets[0].inst.N
     alg = algorithmic_bytes(d0, N, rows)
     traffic, traffic_file = measured_traffic()
-    key = {'prep': 'prep_kernel', 'pair': 'pair_kernel'}
+    key = {'prep': 'prep_kernel', 'pair': 'pair_kernel', 'eval1': 'eval1_kernel'}
     per_kernel = {}
     for name, raw in raws.items():
         durs = raw - bracket_us
@@ -622,12 +632,12 @@ def kernel_timing(lib, _lib, sets, stream, enqueue, steps, step_us, rows):
     # the figure of merit is computed on the UN-INSTRUMENTED step time (kernels + their boundaries: what a training loop sees)
     a = whole / (step_us * 1e-6) / 1e9
     return {
-        'roofline': {'kernel': 'prep + pair = the whole evaluation', 'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBPS,
+        'roofline': {'kernel': ' + '.join(sorted(per_kernel)) + ' = the whole evaluation', 'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBPS,
                      'unit': 'GB/s', 'frac': a / HBM_PEAK_GBPS,
-                     'traffic': sum(traffic.values()) if traffic else None,
+                     'traffic': sum(traffic[key[k]] for k in per_kernel if key.get(k) in traffic) if traffic and all(key.get(k) in traffic for k in per_kernel) else None,
                      'traffic_source': traffic_file,
                      'algorithmic_bytes': whole, 'algorithmic_bytes_source': 'SURVEY 8(d): 39 322 240 B at 2x800x1024x32',
-                     'time_us': step_us, 'time_source': 'ms_per_step of this run (un-instrumented, both launches and their boundaries)',
+                     'time_us': step_us, 'time_source': 'ms_per_step of this run (un-instrumented: every launch of a step and its boundary)',
                      'event_kernel_time_us': ksum, 'frac_on_event_kernel_time': whole / (ksum * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                      'timing': 'per kernel: hipEvent pairs around each launch on the launching stream (bxi_set_launch_hook), minus the '
                                'cost of an empty pair measured separately (event_bracket_us); launches queued behind a parked stream, '

@@ -69,6 +69,7 @@ SIGNATURES = {
                                           c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'bxi_debug_set_spin_limit': (None, [c_int]),
+    'bxi_debug_set_eval_form': (None, [c_int]),
     'bxi_boxinst_grad_rescale_f32': (c_int, [C.POINTER(Instances), c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                              c_void_p]),
     'bxi_dynamic_mask_forward_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,

@@ -14,6 +14,7 @@ size_t loss_ws_bytes(int N, int h, int w);
 size_t eval_ws_bytes(int B, int N, int h, int w);
 bool fused_eval_supported(int dil);
 void debug_set_spin_limit(int limit);
+void debug_set_eval_form(int form);
 int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bxi_instances* in, int dil, float warmup, const float* up_prj,
                       const float* up_pw, float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, int force_rows,
                       void* stream, const DynArgs* head = nullptr, int head_C = 0);
@@ -114,6 +115,7 @@ int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_insta
 }
 
 void bxi_debug_set_spin_limit(int limit) { bxi::debug_set_spin_limit(limit); }
+void bxi_debug_set_eval_form(int form) { bxi::debug_set_eval_form(form); }
 
 int bxi_boxinst_grad_rescale_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw, int dilation,
                                  const void* state, float* g_logits, void* stream) {

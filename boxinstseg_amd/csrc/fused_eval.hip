@@ -52,10 +52,17 @@ constexpr int kMaxDilFused = 4;
 constexpr int kSpinLimit = 400000;              // bounded waits (~0.3 us per poll): far beyond any launch; running out is loud (NaN losses)
 // developer / test hook (bxi_debug_set_spin_limit): 0 = kSpinLimit; negative = every bounded wait gives up at once
 static std::atomic<int> g_spin_limit{0};
+// developer / test hook (bxi_debug_set_eval_form): 0 = the library chooses (single launch where it applies); 2 = always two launches
+static std::atomic<int> g_form{0};
 constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
 constexpr int kAcc1Words = 64;                  // count-wave arrivals + sum W: 64 words, each in its own 128 bytes
 constexpr int kMaxInst = 65536;
 constexpr unsigned kFaultCounts = 1u, kFaultFinisher = 2u;
+// A wave whose bounded wait ran out says so IN the word the finisher waits for, so that the round that sees every arrival sees
+// every fault: bit 50 of a tile wave's arrival (the sum field stays below 2^46 for every shape the table admits), bit 39 of a
+// predicate workgroup's count arrival -> bit 62 of the published sum W, bit 33 of a leader's dice word.  (Several faults on one
+// word may carry into its arrival count: the finisher then never sees the count it waits for and runs out itself -- as loud.)
+constexpr unsigned long long kArrivalFault = 1ull << 50, kCountFault = 1ull << 39, kSumwFault = 1ull << 62, kDiceFault = 1ull << 33;
 
 #ifdef BXI_TRACE
 #define BXI_TW(kid, idx, ph)                                                                                  \
@@ -76,15 +83,39 @@ __device__ __forceinline__ void add_f32(float* p, float v) {
     (void)__builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)p, v);
 }
 
+// 16-byte load past the caches (sc1 = agent scope): what another workgroup of the SAME launch stored with store4_through /
+// store_u64x2_through.  One instruction per datum, so a tagged 16-byte record is seen whole or not at all.  The asm form is
+// invisible to the compiler's vmcnt bookkeeping, hence the wait inside the statement.
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u4v load16_past(const void* p) {
+    u4v v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void load16_past_x4(const void* p0, const void* p1, const void* p2, const void* p3, u4v& a, u4v& b, u4v& c, u4v& d) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
+__device__ __forceinline__ void load16_past_x5(const void* p0, const void* p1, const void* p2, const void* p3, const void* p4, u4v& a, u4v& b, u4v& c, u4v& d,
+                                               u4v& e) {
+    asm volatile("global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\tglobal_load_dwordx4 %2, %7, off sc1\n\t"
+                 "global_load_dwordx4 %3, %8, off sc1\n\tglobal_load_dwordx4 %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4) : "memory");
+}
+__device__ __forceinline__ float4 f4_of(const u4v& v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
+
 // ---- workspace ---------------------------------------------------------------------------------------------------------
 struct Ws {
     float4* lab4;                               // [B,h,w] (L, a, b, 0)
     float* lab_planar;                          // [B,3,h,w] only the generic pooling path (other strides, unaligned canvases) fills it
-    unsigned char* pred;                        // [B,h,w] bit d = colour predicate of pair direction d with this pixel as the step pixel
+    unsigned int* pred;                         // [B,h,w] epoch << 4 | bits; bit d = colour predicate of pair direction d with this pixel as the step pixel
     unsigned long long* colpart;                // [N,n_cb,w] packed (max logit, first row) of a band of rows
     unsigned long long* rowkey;                 // [N,n_rp,h] packed (max logit, first column)
     int n_cb, n_rp;
-    int4* tab;                                  // [N+1] {tile prefix | img << 24, r0 | r1 << 16, c0 | c1 << 16, vrow | vcol << 16}; [N].x = tiles
+    int4* tab;                                  // [N+1] {tile prefix | img << 24, r0 | r1 << 16, c0 | c1 << 16, epoch}; [N].x = tiles
+    unsigned int* bandflag;                     // [N,n_cb] epoch once a stream block's zero-fill and partial maxima are in memory (single-launch form)
+    unsigned int ep;                            // this evaluation's tag (1 .. 2^28 - 1): data another workgroup of the SAME launch reads carries it
     // words polled inside pair_kernel; zeroed by prep_kernel's table waves, i.e. before a kernel boundary
     unsigned long long* acc1;                   // [kAcc1Words] (one per 128 B) predicate workgroups: segments evaluated << 40 | sum W
     unsigned long long* sumw;                   // [1]   1 << 63 | sum W, published by the reducer wave once every segment is in (0 = not yet)
@@ -114,11 +145,13 @@ static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
     const size_t P = (size_t)h * w, B1 = B > 0 ? B : 1;
     t.lab4 = (float4*)take(16 * B1 * P);
     t.lab_planar = (float*)take(12 * B1 * P);
-    t.pred = (unsigned char*)take(B1 * P);
+    t.pred = (unsigned int*)take(4 * B1 * P);
     t.colpart = (unsigned long long*)take(8 * (size_t)N1 * (cb_max > Sn ? cb_max : Sn) * w);
     t.rowkey = (unsigned long long*)take(8 * (size_t)N1 * h * (rp_max > 1 ? rp_max : 1));
     t.n_cb = (int)Sn; t.n_rp = 1;
     t.tab = (int4*)take(16 * (size_t)(N1 + 1));
+    t.bandflag = (unsigned int*)take(4 * (size_t)N1 * (cb_max > Sn ? cb_max : Sn));
+    t.ep = 0u;
     t.acc1 = (unsigned long long*)take(8 * (size_t)kAcc1Words * kAcc2Stride);
     t.sumw = (unsigned long long*)take(8);
     t.acc2 = (unsigned long long*)take(8 * (size_t)N1 * kAcc2Split * kAcc2Stride);
@@ -161,7 +194,8 @@ __device__ __forceinline__ LaneBox lane_box(const InstArgs& a, const ImageMeta& 
     return lb;
 }
 
-__device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& meta, int dil, int R, const Ws& ws, const LossState& st, int k) {
+__device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& meta, int dil, int R, const Ws& ws, const LossState& st, int k,
+                                           bool write_status) {
     const int lane = threadIdx.x & 63;
     int base = 0, prefix = 0;
     LaneBox mine = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -179,21 +213,56 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
         base += __shfl(incl, 63, 64);
     }
     const int m = 64 * k + lane;
+    // the words that are polled later: zeroed here, written through, and DRAINED before the table entries that announce them go
+    // out -- whoever holds a tagged entry m (entry 0) may use instance m's accumulators (the global ones).  No hipMemsetAsync, no
+    // initialisation contract: in the two-launch form a kernel boundary follows anyway, in the single-launch form the tag orders it.
     if (m < a.N) {
-        ws.tab[m] = make_int4(prefix | (mine.img << 24), mine.r0 | (mine.r1 << 16), mine.c0 | (mine.c1 << 16), mine.vrow | (mine.vcol << 16));
         if (st.inst) { InstRec rc; rc.r0 = mine.r0; rc.r1 = mine.r1; rc.c0 = mine.c0; rc.c1 = mine.c1; rc.img = mine.img; rc.pad0 = rc.pad1 = rc.pad2 = 0; st.inst[m] = rc; }
-        // the words the next launch polls: zeroed here, i.e. before a kernel boundary (no hipMemsetAsync, no initialisation contract)
 #pragma unroll
-        for (int sub = 0; sub < kAcc2Split; ++sub) *acc2_word(ws.acc2, m, sub) = 0ull;
-        ws.dice[m] = 0ull;
-    } else if (m == a.N) {
-        ws.tab[m] = make_int4(prefix, 0, 0, 0);
+        for (int sub = 0; sub < kAcc2Split; ++sub) __hip_atomic_store(acc2_word(ws.acc2, m, sub), 0ull, BXI_RLX, BXI_AGENT);
+        __hip_atomic_store(&ws.dice[m], 0ull, BXI_RLX, BXI_AGENT);
     }
     if (k == 0) {
-        ws.acc1[(size_t)lane * kAcc2Stride] = 0ull;
-        if (lane == 0) *ws.sumw = 0ull;
-        if (lane == 0) { *ws.fault = 0u; if (st.status) { st.status[0] = 0; st.status[1] = R; } }
+        __hip_atomic_store(&ws.acc1[(size_t)lane * kAcc2Stride], 0ull, BXI_RLX, BXI_AGENT);
+        if (lane == 0) __hip_atomic_store(ws.sumw, 0ull, BXI_RLX, BXI_AGENT);
+        if (lane == 0) __hip_atomic_store(ws.fault, 0u, BXI_RLX, BXI_AGENT);
+        if (lane == 0 && st.status && write_status) { st.status[0] = 0; st.status[1] = R; }
     }
+    drain_vmem();
+    if (m < a.N)
+        store_u64x2_through(reinterpret_cast<unsigned long long*>(ws.tab + m),
+                            (unsigned long long)(unsigned int)(prefix | (mine.img << 24)) | ((unsigned long long)(unsigned int)(mine.r0 | (mine.r1 << 16)) << 32),
+                            (unsigned long long)(unsigned int)(mine.c0 | (mine.c1 << 16)) | ((unsigned long long)ws.ep << 32));
+    else if (m == a.N)
+        store_u64x2_through(reinterpret_cast<unsigned long long*>(ws.tab + m), (unsigned long long)(unsigned int)prefix, (unsigned long long)ws.ep << 32);
+}
+
+// This lane's table entry m (m <= N; `want` false: nothing).  Two-launch form: a plain load behind the kernel boundary.  Single-launch
+// form (ONE): read past the caches until every wanted entry carries this evaluation's tag -- the table workgroup is the first of
+// the grid and waits for nobody, so this is a wait for a workgroup that precedes the asker.  false = the bounded wait ran out.
+template <bool ONE>
+__device__ __forceinline__ bool tab_entry(const Ws& ws, int m, bool want, int spin_limit, int4& e) {
+    if (!ONE) { e = want ? ws.tab[m] : make_int4(0, 0, 0, 0); return true; }
+    for (int spins = 0; spins <= spin_limit; ++spins) {
+        const u4v v = load16_past(ws.tab + (want ? m : 0));
+        if (__all(!want || v.w == ws.ep)) {
+            e = want ? make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w) : make_int4(0, 0, 0, 0);
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    e = make_int4(0, 0, 0, 0);
+    return false;
+}
+// every entry 0..N tagged = every polled word of this evaluation zeroed (finisher, reducer)
+template <bool ONE>
+__device__ __forceinline__ bool table_complete(const Ws& ws, int N, int spin_limit) {
+    if (!ONE) return true;
+    const int lane = threadIdx.x & 63;
+    int4 e;
+    for (int m0 = 0; m0 <= N; m0 += 64)
+        if (!tab_entry<true>(ws, m0 + lane, m0 + lane <= N, spin_limit, e)) return false;
+    return true;
 }
 
 // ---- role 2: stream block = 4 waves x 8 rows of one instance map ---------------------------------------------------------
@@ -202,7 +271,7 @@ struct LogitRows {
     __device__ __forceinline__ float4 operator()(int r, int c) const { return load4(L + (int64_t)r * w, c, w, vec); }
 };
 
-template <typename Src>
+template <bool ONE, typename Src>
 __device__ __forceinline__ void stream_block(const InstArgs& a, const Ws& ws, float* __restrict__ g_logits, int vec, int sb,
                                              unsigned long long* colp /* LDS [kWaves][w] */, const Src& src, int tix) {
     const int h = a.h, w = a.w;
@@ -293,7 +362,10 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const Ws& ws, fl
         const int col = __builtin_amdgcn_readlane(rcol[i], first);
         if (lane == i) mine = pack_max(wmax[i], (uint32_t)col);
     }
-    if (lane < kSRows && r0 + lane < r1) ws.rowkey[(int64_t)n * h + r0 + lane] = mine;
+    if (lane < kSRows && r0 + lane < r1) {
+        if (ONE) __hip_atomic_store(&ws.rowkey[(int64_t)n * h + r0 + lane], mine, BXI_RLX, BXI_AGENT);     // written through: read by a leader of this launch
+        else ws.rowkey[(int64_t)n * h + r0 + lane] = mine;
+    }
     BXI_TW(0, tix, 3);
     lds_barrier();
     BXI_TW(0, tix, 4);
@@ -301,7 +373,15 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const Ws& ws, fl
         unsigned long long k = colp[c];
 #pragma unroll
         for (int u = 1; u < kWaves; ++u) { const unsigned long long o = colp[(size_t)u * w + c]; k = o > k ? o : k; }
-        ws.colpart[((int64_t)n * Sn + s) * w + c] = k;       // larger value, then smaller row
+        if (ONE) __hip_atomic_store(&ws.colpart[((int64_t)n * Sn + s) * w + c], k, BXI_RLX, BXI_AGENT);
+        else ws.colpart[((int64_t)n * Sn + s) * w + c] = k;       // larger value, then smaller row
+    }
+    if (ONE) {
+        // single-launch form: this band's zero-fill and partial maxima are in memory (every wave drains its own stores, the
+        // workgroup meets) before the band's flag says so to the instance's leader and to the tile waves that add onto these rows
+        drain_vmem();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&ws.bandflag[(int64_t)n * ws.n_cb + s], ws.ep, BXI_RLX, BXI_AGENT);
     }
 }
 
@@ -394,9 +474,10 @@ __device__ __forceinline__ void pool_block(const PoolArgs& pa, const Ws& ws, int
         BXI_TW(0, tix, 4);
         if (wv == 3 && act) {       // one 16-byte store per pooled pixel (the wave that had no channel to compute)
             const double f0 = fch[lane], f1 = fch[64 + lane], f2 = fch[128 + lane];
-            ws.lab4[((int64_t)b * h + r) * w + c] = make_float4((float)__dadd_rn(__dmul_rn(116.0, f1), -16.0), (float)__dmul_rn(500.0, __dadd_rn(f0, -f1)),
-                                                                (float)__dmul_rn(200.0, __dadd_rn(f1, -f2)), 0.f);
-            ws.pred[((int64_t)b * h + r) * w + c] = 0;      // "not evaluated yet": the predicate waves of the next launch set bit 7
+            // the fourth component is this evaluation's tag: a predicate wave of the SAME launch (single-launch form) re-reads a pixel
+            // until it carries it; the record is one 16-byte store, written through
+            store4_through(reinterpret_cast<float*>(ws.lab4 + ((int64_t)b * h + r) * w + c), (float)__dadd_rn(__dmul_rn(116.0, f1), -16.0),
+                           (float)__dmul_rn(500.0, __dadd_rn(f0, -f1)), (float)__dmul_rn(200.0, __dadd_rn(f1, -f2)), __uint_as_float(ws.ep));
         }
         // the next trip's `part` writes come after this barrier; its `fch` writes after the next one, which wave 3 reaches only
         // after it has read `fch` here: no extra barrier needed
@@ -425,10 +506,10 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, i
     }
     if (role == 0) {
         const int k = blk * kWaves + (int)(threadIdx.x >> 6);
-        if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, ws, st, k);
+        if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, ws, st, k, true);
     } else if (role == 2) {
         const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
-        stream_block(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);
+        stream_block<false>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);
     } else {
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
@@ -454,7 +535,7 @@ __global__ __launch_bounds__(256, 7) void head_prep_kernel(PoolArgs pa, int n_po
     (void)tix;
     if (blk < n_tab) {
         const int k = blk * kWaves + (int)(threadIdx.x >> 6);
-        if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, ws, st, k);
+        if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, ws, st, k, true);
     } else if (blk < n_tab + n_pool) {
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
@@ -476,13 +557,11 @@ __global__ __launch_bounds__(256, 7) void head_prep_kernel(PoolArgs pa, int n_po
 
 // ---- the image side for strides other than 4 / unaligned canvases: launches of their own (pool_rgb_generic of
 // color_affinity.hip -> Lab planes, then this repacking) -----------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_lab4_kernel(const float* __restrict__ lab, float4* __restrict__ lab4, unsigned char* __restrict__ pred, int B,
-                                                        int64_t P) {
+__global__ __launch_bounds__(256) void pack_lab4_kernel(const float* __restrict__ lab, float4* __restrict__ lab4, unsigned int ep, int B, int64_t P) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * P; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / P, p = i - b * P;
         const float* src = lab + b * 3 * P + p;
-        lab4[i] = make_float4(src[0], src[P], src[2 * P], 0.f);
-        pred[i] = 0;
+        lab4[i] = make_float4(src[0], src[P], src[2 * P], __uint_as_float(ep));
     }
 }
 
@@ -570,7 +649,7 @@ __device__ __forceinline__ float lane_minus(float v) {
 // Generic (slow) evaluation of one tile: ordered pairs per owned pixel straight from global memory, pair value and
 // gradient in log space exactly as pairwise.cu:38-61.  Taken for thresh <= 0 (zero_bit: padded / masked-out neighbours
 // weigh 1) and for tiles with saturated logits (S underflows).  Gradients -> gout, the lane's sum W pw -> gout[R].
-template <int D, int R>
+template <int D, int R, bool ONE>
 __device__ __forceinline__ void slow_tile(const float* __restrict__ Lg, const float4* __restrict__ lab4, const Tile& t, float n2max, int zero_bit,
                                           int h, int w, int lane, float* gout /* LDS [R + 1][64] */) {
     const int c = t.tile_c0 - D + lane;
@@ -585,7 +664,7 @@ __device__ __forceinline__ void slow_tile(const float* __restrict__ Lg, const fl
             const bool in_p = r >= t.r0 && r < t.r1 && c >= t.c0 && c < t.c1;
             const bool val_p = r < t.vrow && c < t.vcol;
             const int64_t pi = (int64_t)r * w + c;
-            const float4 lp = L0p[pi];
+            const float4 lp = ONE ? f4_of(load16_past(L0p + pi)) : L0p[pi];      // single-launch form: written by this launch, read past the caches
             const float xa = Lg[pi];
             const float ax = logsig(xa), bx = logsig(-xa);
 #pragma unroll 1
@@ -597,7 +676,7 @@ __device__ __forceinline__ void slow_tile(const float* __restrict__ Lg, const fl
                 int64_t qi = 0;
                 if (inq) {
                     qi = (int64_t)r2 * w + c2;
-                    const float4 lq = L0p[qi];
+                    const float4 lq = ONE ? f4_of(load16_past(L0p + qi)) : L0p[qi];
                     pn = n2_of(lp.x, lp.y, lp.z, lq.x, lq.y, lq.z) <= n2max ? 1u : 0u;
                 }
                 const bool val_q = inq && r2 < t.vrow && c2 < t.vcol;
@@ -644,7 +723,8 @@ __device__ __forceinline__ float lane_plus_n(float v, int d) {
     return __int_as_float(x);
 }
 struct ValidCells { int vrow[BXI_MAX_IMAGES], vcol[BXI_MAX_IMAGES]; };   // per image: valid(q) <=> row(q) < vrow && col(q) < vcol (host: :1354-1369,:1405)
-__device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc, const Ws& ws, int D, float n2max, int item, int segs) {
+template <bool ONE>
+__device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc, const Ws& ws, int D, float n2max, int item, int segs, int spin_limit, bool& ok) {
     const int h = a.h, w = a.w, lane = threadIdx.x & 63;
     const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
     const int c = seg * 64 + lane, cn = c + D;
@@ -652,9 +732,30 @@ __device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc
     const float4* L4 = ws.lab4 + (int64_t)b * h * w;
     const int cc = min(c, w - 1), cx = min(lane >= 64 - D ? cn : c, w - 1), rD = min(r + D, h - 1);
     // this row, the row D below, and for the last D lanes their right neighbours (they live in the next segment)
-    const float4 o0 = L4[(int64_t)r * w + cc], oD = L4[(int64_t)rD * w + cc], x0 = L4[(int64_t)r * w + cx], xD = L4[(int64_t)rD * w + cx];
+    float4 o0, oD, x0, xD;
     // lane n: instance n's table entry (box cells, image), requested with the Lab
-    int4 rect = lane < a.N ? ws.tab[lane] : make_int4(-1, 0, 0, 0);
+    int4 rect;
+    if (ONE) {
+        // single-launch form: the pool workgroups of THIS launch write these pixels (16-byte records carrying the evaluation's
+        // tag, written through); they precede this wave in the grid and wait for nobody
+        bool got = false;
+        for (int spins = 0; spins <= spin_limit; ++spins) {
+            u4v q0, q1, q2, q3, qe;      // the table entry travels with the pixels: one round trip
+            load16_past_x5(L4 + (int64_t)r * w + cc, L4 + (int64_t)rD * w + cc, L4 + (int64_t)r * w + cx, L4 + (int64_t)rD * w + cx,
+                           ws.tab + (lane < a.N ? lane : 0), q0, q1, q2, q3, qe);
+            if (__all(q0.w == ws.ep && q1.w == ws.ep && q2.w == ws.ep && q3.w == ws.ep && qe.w == ws.ep)) {
+                o0 = f4_of(q0); oD = f4_of(q1); x0 = f4_of(q2); xD = f4_of(q3);
+                rect = lane < a.N ? make_int4((int)qe.x, (int)qe.y, (int)qe.z, (int)qe.w) : make_int4(-1, 0, 0, 0);
+                got = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        if (!got) { ok = false; return 0; }
+    } else {
+        o0 = L4[(int64_t)r * w + cc]; oD = L4[(int64_t)rD * w + cc]; x0 = L4[(int64_t)r * w + cx]; xD = L4[(int64_t)rD * w + cx];
+        rect = lane < a.N ? ws.tab[lane] : make_int4(-1, 0, 0, 0);
+    }
     float nL = lane_plus_n(o0.x, D), nA = lane_plus_n(o0.y, D), nB = lane_plus_n(o0.z, D);
     float mL = lane_plus_n(oD.x, D), mA = lane_plus_n(oD.y, D), mB = lane_plus_n(oD.z, D);
     if (lane >= 64 - D) { nL = x0.x; nA = x0.y; nB = x0.z; mL = xD.x; mA = xD.y; mB = xD.z; }
@@ -663,15 +764,18 @@ __device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc
     const bool p1 = cin && nin && rowD && n2_of(oD.x, oD.y, oD.z, nL, nA, nB) <= n2max;
     const bool p2 = cin && rowD && n2_of(o0.x, o0.y, o0.z, oD.x, oD.y, oD.z) <= n2max;
     const bool p3 = cin && nin && rowD && n2_of(o0.x, o0.y, o0.z, mL, mA, mB) <= n2max;
-    if (cin) __hip_atomic_store(ws.pred + ((int64_t)b * h + r) * w + c, (unsigned char)(0x80 | (p0 ? 1 : 0) | (p1 ? 2 : 0) | (p2 ? 4 : 0) | (p3 ? 8 : 0)),
-                                BXI_RLX, BXI_AGENT);     // bit 7: evaluated (launch 1 left 0); written through (sc1), read past the caches
+    if (cin) __hip_atomic_store(ws.pred + ((int64_t)b * h + r) * w + c, (ws.ep << 4) | (p0 ? 1u : 0u) | (p1 ? 2u : 0u) | (p2 ? 4u : 0u) | (p3 ? 8u : 0u),
+                                BXI_RLX, BXI_AGENT);     // the evaluation's tag = "evaluated"; written through (sc1), read past the caches
     const int vrow = vc.vrow[b], vcol = vc.vcol[b];
     const bool v00 = r < vrow && c < vcol, v0n = r < vrow && cn < vcol, vD0 = r + D < vrow && c < vcol, vDn = r + D < vrow && cn < vcol;
     // what a box containing the site adds:  (r, c)  (r, c+D)  (r+D, c)  (r+D, c+D)
     const int s00 = (p0 && v0n) + (p2 && vD0) + (p3 && vDn), s0n = (p0 && v00) + (p1 && vD0), sD0 = (p1 && v0n) + (p2 && v00), sDn = (p3 && v00) ? 1 : 0;
     int cnt = 0;
     for (int m0 = 0; m0 < a.N; m0 += 64) {
-        if (m0) rect = m0 + lane < a.N ? ws.tab[m0 + lane] : make_int4(-1, 0, 0, 0);
+        if (m0) {
+            if (!tab_entry<ONE>(ws, m0 + lane, m0 + lane < a.N, spin_limit, rect)) { ok = false; return 0; }
+            if (m0 + lane >= a.N) rect = make_int4(-1, 0, 0, 0);
+        }
         // the instances of this image whose rows reach r or r + D: usually a handful
         const int q0 = rect.y & 0xffff, q1 = (int)((unsigned int)rect.y >> 16);
         unsigned long long mask = __ballot(m0 + lane < a.N && (int)((unsigned int)rect.x >> 24) == b && ((r >= q0 && r < q1) || (r + D >= q0 && r + D < q1)));
@@ -690,19 +794,22 @@ __device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc
 
 // sum W, once every pooled row segment has been evaluated: ONE word for the (hundreds of) askers; the reducer -- one wave of the
 // finisher workgroup -- watches the 64 count words and publishes it.
-__device__ __forceinline__ bool counts_complete(const Ws& ws, int n_items, double* total) {
+__device__ __forceinline__ bool counts_complete(const Ws& ws, int n_items, double* total, bool* fault) {
     (void)n_items;
     const unsigned long long x = __hip_atomic_load(ws.sumw, BXI_RLX, BXI_AGENT);
-    *total = (double)(x & ~(1ull << 63));                               // exact: an integer far below 2^53
+    *total = (double)(x & (kSumwFault - 1ull));                         // exact: an integer far below 2^53
+    if ((x >> 63) != 0ull && (x & kSumwFault)) *fault = true;
     return (x >> 63) != 0ull;
 }
 __device__ __forceinline__ bool reduce_counts(const Ws& ws, int n_items, int spin_limit) {
     for (int spins = 0; spins <= spin_limit; ++spins) {
         const unsigned long long x = __hip_atomic_load(&ws.acc1[(size_t)(threadIdx.x & 63) * kAcc2Stride], BXI_RLX, BXI_AGENT);
         const int arrived = wave_total_i32((int)(x >> 40));
-        const double tot = wave_total_f64((double)(x & ((1ull << 40) - 1ull)));       // exact
+        const double tot = wave_total_f64((double)(x & (kCountFault - 1ull)));        // exact
+        const bool flt = __any((x & kCountFault) != 0ull);
         if (arrived == n_items) {
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(ws.sumw, (1ull << 63) | (unsigned long long)tot, BXI_RLX, BXI_AGENT);
+            if ((threadIdx.x & 63) == 0)
+                __hip_atomic_store(ws.sumw, (1ull << 63) | (flt ? kSumwFault : 0ull) | (unsigned long long)tot, BXI_RLX, BXI_AGENT);
             return true;
         }
     }
@@ -731,7 +838,27 @@ __device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, cons
 // Its waits: the predicate bytes of its own pixels (bit 7 set), when the logits have arrived and the per-pixel quantities are
 // computed; and, before the gradient goes out, sum W (the global normaliser, :1327-1328) = every predicate wave's arrival.  The
 // predicate waves precede the tile waves in the grid and never wait; by the time a tile wave asks they are normally done.
+// A tile wave's own few predicate words (written through by the predicate waves, which precede it in the grid), read past the
+// caches until every one carries this evaluation's tag; usually they are there at once.
 template <int D, int R>
+__device__ __forceinline__ bool pred_words(const Ws& ws, const Tile& t, int h, int w, int c, int spin_limit, uint32_t (&pbyte)[R + D]) {
+    const unsigned int* pp = ws.pred + (int64_t)t.img * h * w;
+    const uint32_t cc = (uint32_t)min(max(c, 0), w - 1);
+    bool ok = false;
+    for (int spins = 0; spins <= spin_limit; ++spins) {
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < R + D; ++i) {
+            pbyte[i] = __hip_atomic_load(pp + (uint32_t)min(max(t.tile_r0 - D + i, 0), h - 1) * (uint32_t)w + cc, BXI_RLX, BXI_AGENT);
+            all = all && (pbyte[i] >> 4) == ws.ep;
+        }
+        if (__all(all)) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return ok;        // false: the caller's arrival says so, and the finisher turns both losses into NaN
+}
+
+template <int D, int R, bool ONE>
 __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float upw_warm, float n2max, int zero_bit, int n_items,
                                           int spin_limit, float& scale, bool& have_scale, float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
                                           int tix) {
@@ -758,25 +885,13 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
         aR[j] = lane_plus<D>(pa_[j]); bR[j] = lane_plus<D>(pb_[j]); tR[j] = aR[j] - bR[j]; uR[j] = aR[j] * bR[j];
     }
     const bool slow = zero_bit != 0 || __any(sat);
+    bool bad = false;          // a bounded wait of this wave ran out (never expected): its arrival carries the fact to the finisher
     BXI_TW(1, tix, 2);
     if (!slow) {
         uint32_t pb[4] = {0u, 0u, 0u, 0u};
         {
-            const unsigned char* pp = ws.pred + (int64_t)t.img * P;
-            const uint32_t cc = (uint32_t)min(max(c, 0), w - 1);
-            uint32_t pbyte[R + D] = {};
-            bool ok = false;
-            for (int spins = 0; spins <= spin_limit; ++spins) {          // its own few bytes, read past the caches; usually there at once
-                uint32_t all = 0x80u;
-#pragma unroll
-                for (int i = 0; i < R + D; ++i) {
-                    pbyte[i] = __hip_atomic_load(pp + (uint32_t)min(max(t.tile_r0 - D + i, 0), h - 1) * (uint32_t)w + cc, BXI_RLX, BXI_AGENT);
-                    all &= pbyte[i];
-                }
-                if (__all(all != 0u)) { ok = true; break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
+            uint32_t pbyte[R + D];
+            bad |= !pred_words<D, R>(ws, t, h, w, c, spin_limit, pbyte);
 #pragma unroll
             for (int i = 0; i < R + D; ++i)
 #pragma unroll
@@ -825,7 +940,11 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
         num *= 0.69314718055994531f;
 #undef BXI_PAIR
     } else {         // wave-uniform; rare
-        slow_tile<D, R>(Lg, ws.lab4, t, n2max, zero_bit, h, w, lane, gbuf);
+        if (ONE) {   // single-launch form: the tile's predicate words vouch for the Lab pixels the log-space path reads
+            uint32_t pbyte[R + D];
+            bad |= !pred_words<D, R>(ws, t, h, w, c, spin_limit, pbyte);
+        }
+        slow_tile<D, R, ONE>(Lg, ws.lab4, t, n2max, zero_bit, h, w, lane, gbuf);
         num = gbuf[R * 64 + lane];
 #pragma unroll
         for (int j = 0; j < R; ++j) g[j] = gbuf[j * 64 + lane];
@@ -833,18 +952,29 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     BXI_TW(1, tix, 5);
     num = wave_total_f32(num);
     const long long fx = (long long)(num * kNumScale) + (1ll << 24);           // + 1.0: keeps the packed field non-negative
-    if (!have_scale) {           // wave-uniform; once per wave
+    // single-launch form: the rows this tile adds onto were zero-filled by stream workgroups of THIS launch; their band flags are
+    // asked for in the same round as sum W
+    const int band0 = t.tile_r0 / kSBlk, band1 = (min(t.tile_r0 + R, h) - 1) / kSBlk;
+    bool bands_ok = !ONE || !g_logits;
+    if (!have_scale || !bands_ok) {           // wave-uniform
         double total_w = 0.0;
-        if (zero_bit) total_w = total_weight_all_pairs(a, ws);
-        else {
-            bool ok = false;
-            for (int spins = 0; spins <= spin_limit; ++spins) {
-                if (counts_complete(ws, n_items, &total_w)) { ok = true; break; }
-                __builtin_amdgcn_s_sleep(8);
+        bool ok = false;
+        for (int spins = 0; spins <= spin_limit; ++spins) {
+            unsigned int f0 = ws.ep, f1 = ws.ep;
+            if (!bands_ok) {
+                f0 = __hip_atomic_load(&ws.bandflag[(int64_t)n * ws.n_cb + band0], BXI_RLX, BXI_AGENT);
+                f1 = __hip_atomic_load(&ws.bandflag[(int64_t)n * ws.n_cb + band1], BXI_RLX, BXI_AGENT);
             }
-            if (!ok && lane == 0) atomicOr(ws.fault, kFaultCounts);        // loud: the finisher turns both losses into NaN
+            if (!have_scale) {
+                if (zero_bit) { total_w = total_weight_all_pairs(a, ws); have_scale = true; }
+                else have_scale = counts_complete(ws, n_items, &total_w, &bad);
+                if (have_scale) scale = upw_warm / fmaxf((float)total_w, 1.f);
+            }
+            bands_ok = f0 == ws.ep && f1 == ws.ep;
+            if (have_scale && bands_ok) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(8);
         }
-        scale = upw_warm / fmaxf((float)total_w, 1.f);
+        bad |= !ok;
         have_scale = true;
     }
     BXI_TW(1, tix, 4);
@@ -859,7 +989,8 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     BXI_TW(1, tix, 6);
     // this tile's share of sum W pw + its arrival: one atomic without return; the wave does not wait for it
     if (lane == 0)
-        __hip_atomic_fetch_add(acc2_word(ws.acc2, n, t.tile_r0 / R + t.tile_c0 / TG<D, R>::TW), (1ull << 52) + (unsigned long long)fx, BXI_RLX, BXI_AGENT);
+        __hip_atomic_fetch_add(acc2_word(ws.acc2, n, t.tile_r0 / R + t.tile_c0 / TG<D, R>::TW),
+                               (1ull << 52) + (unsigned long long)fx + (bad ? kArrivalFault : 0ull), BXI_RLX, BXI_AGENT);
     BXI_TW(1, tix, 7);
 }
 
@@ -880,14 +1011,34 @@ __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf
 //   partial maxima -> maxima -> sigmoid on those only -> both dice terms (:117-143) -> unit projection gradients, recorded as
 //   one 8-byte word per column / row (gradient bits << 32 | arg-max index) for bxi_boxinst_grad_rescale_f32 and ADDED to the
 //   gradient at the arg-max positions.  Nobody in this launch reads what a leader writes except the finisher (its dice loss).
+template <bool ONE>
 __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const Ws& ws, const LossState& st, int n, float upp,
-                                             float* __restrict__ g_logits, unsigned char* smem, float* red) {
+                                             float* __restrict__ g_logits, unsigned char* smem, float* red, int spin_limit) {
     const int h = a.h, w = a.w, tid = threadIdx.x;
     float* xs = reinterpret_cast<float*>(smem);   // [w] sigmoid of the column maxima, then their unit gradients
     float* ys = xs + w;                           // [h]
     int* carg = reinterpret_cast<int*>(ys + h);   // [w]
     int* rarg = carg + w;                         // [h]
-    const int4 e = ws.tab[n];
+    int4 e;
+    bool waited = tab_entry<ONE>(ws, n, true, spin_limit, e);
+    if (ONE) {
+        // single-launch form: the instance's partial maxima and the zero-fill of its map come from stream workgroups of THIS
+        // launch (earlier in the grid, waiting for nobody); one flag per band says they are in memory
+        const int lane = tid & 63;
+        for (int b0 = 0; b0 < ws.n_cb && waited; b0 += 64) {
+            bool got = false;
+            for (int spins = 0; spins <= spin_limit; ++spins) {
+                const unsigned int f = b0 + lane < ws.n_cb ? __hip_atomic_load(&ws.bandflag[(int64_t)n * ws.n_cb + b0 + lane], BXI_RLX, BXI_AGENT) : ws.ep;
+                if (__all(f == ws.ep)) { got = true; break; }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            waited = got;
+        }
+        if (!waited) {        // loud; nothing is computed from partial maxima that may be stale (their indices address the gradient)
+            if (tid == 0) __hip_atomic_store(&ws.dice[n], (1ull << 32) | kDiceFault, BXI_RLX, BXI_AGENT);
+            return;
+        }
+    }
     const int br0 = e.y & 0xffff, br1 = (int)((unsigned int)e.y >> 16), bc0 = e.z & 0xffff, bc1 = (int)((unsigned int)e.z >> 16);
     const bool any = br1 > br0 && bc1 > bc0;
     (void)dil;
@@ -898,7 +1049,8 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const W
         for (int s0 = 0; s0 < n_part; s0 += 8) {
             unsigned long long o[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) o[u] = part[(int64_t)min(s0 + u, n_part - 1) * stride];
+            for (int u = 0; u < 8; ++u)
+                o[u] = ONE ? __hip_atomic_load(part + (int64_t)min(s0 + u, n_part - 1) * stride, BXI_RLX, BXI_AGENT) : part[(int64_t)min(s0 + u, n_part - 1) * stride];
 #pragma unroll
             for (int u = 0; u < 8; ++u) k = o[u] > k ? o[u] : k;
         }
@@ -965,11 +1117,11 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const W
     BXI_TW(3, 1 + n, 3);
 }
 
-__device__ __forceinline__ Tile tile_of(const int4& e, int D, int R, int TW, int n, int idx, int h, int w) {   // e: the instance's table entry (uniform)
+__device__ __forceinline__ Tile tile_of(const int4& e, const ValidCells& vc, int D, int R, int TW, int n, int idx, int h, int w) {   // e: the instance's table entry (uniform)
     Tile t;
     t.r0 = e.y & 0xffff; t.r1 = (int)((unsigned int)e.y >> 16); t.c0 = e.z & 0xffff; t.c1 = (int)((unsigned int)e.z >> 16);
     t.img = (int)((unsigned int)e.x >> 24); t.n = n;
-    t.vrow = e.w & 0xffff; t.vcol = (int)((unsigned int)e.w >> 16);
+    t.vrow = vc.vrow[t.img]; t.vcol = vc.vcol[t.img];
     const int dr0 = max(t.r0 - D, 0), hc0 = max(t.c0 - D, 0);
     t.hc1 = min(t.c1 + D, w);
     const int ntc = (t.hc1 - hc0 + TW - 1) / TW;
@@ -981,10 +1133,11 @@ __device__ __forceinline__ Tile tile_of(const int4& e, int D, int R, int TW, int
 }
 
 // The finisher's rounds.  Leaders: the dice losses of instances [b0, b0 + 64) (self-flagging words).
-__device__ __forceinline__ bool dice_round(const Ws& ws, int N, int b0, float* dsum) {
+__device__ __forceinline__ bool dice_round(const Ws& ws, int N, int b0, float* dsum, bool* fault) {
     const int lane = threadIdx.x & 63, i = b0 + lane;
     const unsigned long long dg = i < N ? __hip_atomic_load(&ws.dice[i], BXI_RLX, BXI_AGENT) : (1ull << 32);
     if (!__all((dg >> 32) != 0ull)) return false;
+    if (__any((dg & kDiceFault) != 0ull)) *fault = true;
     const float dv = i < N ? __uint_as_float((unsigned int)dg) : 0.f;
     const int m = min(64, N - b0);
     for (int k = 0; k < m; ++k) *dsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), k));   // index order: run-to-run identical
@@ -993,8 +1146,8 @@ __device__ __forceinline__ bool dice_round(const Ws& ws, int N, int b0, float* d
 
 // The tile of list position `ti`: the instance whose tile range holds it (table entries: 16 bytes per instance, the same lines
 // for every wave), then the tile's place inside the instance's hull.  e0 = this lane's entry of the first 64 (N < 64: all).
-template <int D, int R>
-__device__ __forceinline__ Tile locate_tile(const Ws& ws, int N, const int4& e0, int ti, int h, int w) {
+template <int D, int R, bool ONE>
+__device__ __forceinline__ bool locate_tile(const Ws& ws, const ValidCells& vc, int N, const int4& e0, int ti, int h, int w, int spin_limit, Tile& out) {
     const int lane = threadIdx.x & 63;
     int n = 0;
     int4 e = make_int4(0, 0, 0, 0);
@@ -1005,8 +1158,8 @@ __device__ __forceinline__ Tile locate_tile(const Ws& ws, int N, const int4& e0,
         e.z = __builtin_amdgcn_readlane(e0.z, n); e.w = __builtin_amdgcn_readlane(e0.w, n);
     } else {
         for (int m0 = 0; m0 < N; m0 += 64) {
-            int4 em = make_int4(0, 0, 0, 0);
-            if (m0 + lane < N) em = ws.tab[m0 + lane];
+            int4 em;
+            if (!tab_entry<ONE>(ws, m0 + lane, m0 + lane < N, spin_limit, em)) return false;
             const unsigned long long mask = __ballot(m0 + lane < N && (em.x & 0xffffff) <= ti);
             const int cntm = __popcll(mask);
             if (cntm == 0) break;
@@ -1016,132 +1169,240 @@ __device__ __forceinline__ Tile locate_tile(const Ws& ws, int N, const int4& e0,
             if (cntm < 64) break;
         }
     }
-    return tile_of(e, D, R, TG<D, R>::TW, n, ti - (e.x & 0xffffff), h, w);
+    out = tile_of(e, vc, D, R, TG<D, R>::TW, n, ti - (e.x & 0xffffff), h, w);
+    return true;
 }
 
-// grid: [n_pb predicate blocks][N leaders][n_tb tile blocks][finisher]; a predicate / tile block = 4 independent waves striding
-// through the pooled row segments / the tile list.  The only waits: a tile wave for the predicate waves (earlier in the grid,
-// never waiting themselves), the finisher for everybody (nobody waits for it).  Every wait is bounded, and running out of it is
-// loud: NaN losses, status word, poisoned gradient (the reference surfaces launch failures through AT_CUDA_CHECK, pairwise.cu:173,200).
+// ---- the roles of the second launch (two-launch form) / of the back half of the single launch ----------------------------------
+// predicate workgroup `pblk` of n_pb: 4 independent waves striding through the pooled row segments
+template <int D, bool ONE>
+__device__ __forceinline__ void pred_role(const InstArgs& a, const ValidCells& vc, const Ws& ws, float n2max, int pblk, int n_pb, int n_items, int spin_limit) {
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const int segs = (a.w + 63) >> 6, pid = pblk * kWaves + wave;
+    BXI_TW(2, pid, 0);
+    __builtin_amdgcn_s_setprio(3);                                 // short, and the tile waves will ask for these words
+    int cnt = 0, segments = 0;
+    bool ok = true;
+    for (int item = pid; item < n_items && ok; item += n_pb * kWaves) { cnt += pred_item<ONE>(a, vc, ws, D, n2max, item, segs, spin_limit, ok); ++segments; }
+    cnt = wave_total_i32(cnt);
+    // ONE arrival per workgroup: arrivals on one word are performed one after the other (~0.15 us each), and the tile waves
+    // need the last one
+    __shared__ int pred_cnt[kWaves], pred_seg[kWaves], pred_bad[kWaves];
+    if (lane == 0) { pred_cnt[wave] = cnt; pred_seg[wave] = segments; pred_bad[wave] = ok ? 0 : 1; }
+    __syncthreads();
+    if (threadIdx.x == 0)    // (segments evaluated, sum W); integer adds commute: run-to-run identical
+        __hip_atomic_fetch_add(&ws.acc1[(size_t)(pblk & (kAcc1Words - 1)) * kAcc2Stride],
+                               ((unsigned long long)(unsigned int)((pred_seg[0] + pred_seg[1]) + (pred_seg[2] + pred_seg[3])) << 40) |
+                                   (unsigned long long)(unsigned int)((pred_cnt[0] + pred_cnt[1]) + (pred_cnt[2] + pred_cnt[3])) |
+                                   (((pred_bad[0] | pred_bad[1]) | (pred_bad[2] | pred_bad[3])) ? kCountFault : 0ull),      // loud
+                               BXI_RLX, BXI_AGENT);
+    BXI_TW(2, pid, 1);
+}
+
+// the last workgroup: waits only for workgroups that never wait for it -- the leaders and the predicate waves (done early), then
+// the tile waves -- and writes the two loss values
+template <bool ONE>
+__device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, const LossState& st, float upp, float upw, float warmup, int zero_bit, int n_items,
+                                              int spin_limit, int R, float* __restrict__ losses) {
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const int N = a.N;
+    BXI_TW(3, 0, 0);
+    __shared__ double fin_d[kWaves];
+    __shared__ int fin_i[kWaves];
+    __shared__ float fin_f;
+    __shared__ int fin_ok, fin_tiles, fin_flt, fin_b[kWaves];
+    bool ok = true, flt0 = false;
+    double total_w = 0.0;
+    float dsum = 0.f;
+    int spins = 0;
+    if (spin_limit < 0) ok = false;
+    if (wave == 1 && !zero_bit) {                                      // the reducer
+        // (single-launch form: the count words are this evaluation's only once the table says so -- before that they hold the
+        // previous evaluation's complete counts)
+        if (!(table_complete<ONE>(ws, 0, spin_limit) && reduce_counts(ws, n_items, spin_limit)) && lane == 0) atomicOr(ws.fault, kFaultCounts);
+    }
+    if (wave == 0) {
+        if (!table_complete<ONE>(ws, N, spin_limit)) ok = false;      // every polled word of this evaluation is zeroed from here on
+        int4 eN = make_int4(0, 0, 0, 0);
+        if (ok && !tab_entry<ONE>(ws, N, true, spin_limit, eN)) ok = false;
+        for (int b0 = 0; b0 < N && ok; b0 += 64) {
+            while (!dice_round(ws, N, b0, &dsum, &flt0)) {
+                if (++spins > spin_limit) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        if (zero_bit) total_w = total_weight_all_pairs(a, ws);
+        else
+            while (ok && !counts_complete(ws, n_items, &total_w, &flt0)) {
+                if (++spins > spin_limit) ok = false;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        if (lane == 0) { fin_f = dsum; fin_d[0] = total_w; fin_ok = ok ? 1 : 0; fin_tiles = eN.x; fin_flt = flt0 ? 1 : 0; }
+    }
+    __syncthreads();
+    ok = fin_ok != 0; dsum = fin_f; total_w = fin_d[0];
+    const int ntiles = fin_tiles;
+    __syncthreads();
+    // every thread watches its own arrival words (N * 8 / 256 each: one at the headline size); the launch ends on this loop
+    long long mine = 0;
+    unsigned int fault_seen = (ok ? 0u : kFaultFinisher) | (fin_flt ? kFaultCounts : 0u);
+    spins = 0;
+    for (; ok;) {
+        mine = 0;
+        int arrived = 0;
+        bool flt = false;
+        for (int i = threadIdx.x; i < N * kAcc2Split; i += 256) {
+            const unsigned long long x = __hip_atomic_load(ws.acc2 + (size_t)i * kAcc2Stride, BXI_RLX, BXI_AGENT);
+            arrived += (int)(x >> 52);
+            mine += (long long)(x & ((1ull << 52) - 1ull)) - ((long long)(x >> 52) << 24);       // the +1 per tile
+            flt |= (x & (3ull << 50)) != 0ull;                                                   // a tile wave's wait ran out
+        }
+        // the fault word (waves that gave up WITHOUT arriving set it; the finisher then runs out itself) rides in the same round
+        if (threadIdx.x == 0) fault_seen |= __hip_atomic_load(ws.fault, BXI_RLX, BXI_AGENT);
+        arrived = wave_total_i32(arrived);
+        const bool anyflt = __any(flt);
+        if (lane == 0) { fin_i[wave] = arrived; fin_b[wave] = anyflt ? 1 : 0; }
+        __syncthreads();
+        const bool all = (fin_i[0] + fin_i[1]) + (fin_i[2] + fin_i[3]) == ntiles;
+        if ((fin_b[0] | fin_b[1]) | (fin_b[2] | fin_b[3])) fault_seen |= kFaultCounts;
+        __syncthreads();
+        if (all) break;
+        if (++spins > spin_limit) { ok = false; break; }           // workgroup-uniform: the same count in every thread
+    }
+    const double wsum = wave_total_f64((double)mine);                // exact; fixed order: run-to-run identical
+    if (lane == 0) fin_d[wave] = wsum;
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const double num = (fin_d[0] + fin_d[1]) + (fin_d[2] + fin_d[3]);
+    const unsigned int status = (unsigned int)__builtin_amdgcn_readfirstlane((int)(fault_seen | (ok ? 0u : kFaultFinisher)));
+    if (lane == 0) {
+        const float denom = fmaxf((float)total_w, 1.f);                      // weights.sum().clamp(min=1.0), :1328
+        float l0 = dsum / (float)N;                                          // .mean(), :143
+        float l1 = (float)((num / (double)kNumScale) / (double)denom) * warmup;   // :1327-1332
+        if (status) { l0 = __int_as_float(0x7fc00000); l1 = l0; }            // loud: mmdet's CheckInvalidLossHook fires
+        losses[0] = l0; losses[1] = l1;
+        if (st.scale) { *st.scale = warmup / denom; st.applied[0] = upp; st.applied[1] = upw; }
+        if (st.status) { st.status[0] = (int)status; if (ONE) st.status[1] = R; }
+    }
+    BXI_TW(3, 0, 1);
+}
+
+// tile workgroup: 4 independent waves striding through the tile list (its length is device data)
+template <int D, int R, bool ONE>
+__device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& vc, const Ws& ws, float upw_warm, float n2max, int zero_bit, int n_items, int spin_limit,
+                                          float* __restrict__ g_logits, unsigned char* smem, int tblk, int n_tb) {
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const int N = a.N;
+    const int wid = tblk * kWaves + wave, nwaves = n_tb * kWaves;
+    __builtin_amdgcn_s_setprio(2);                                     // the launch ends on the tile waves, not on the leaders next to them
+    BXI_TW(1, wid, 0);
+    int4 e0, eN = make_int4(0, 0, 0, 0);
+    bool ok = tab_entry<ONE>(ws, lane, lane <= N, spin_limit, e0);
+    if (N >= 64) ok = ok && tab_entry<ONE>(ws, N, true, spin_limit, eN);
+    if (!ok) { if (lane == 0) atomicOr(ws.fault, kFaultCounts); return; }          // loud: the finisher misses this wave's arrivals too
+    const int total = N < 64 ? __builtin_amdgcn_readlane(e0.x, N < 64 ? N : 0) : __builtin_amdgcn_readfirstlane(eN.x);
+    float* gbuf = reinterpret_cast<float*>(smem) + wave * ((R + 1) * 64);
+    float scale = 0.f;
+    bool have_scale = false;
+    for (int ti = wid; ti < total; ti += nwaves) {
+        Tile t;
+        if (!locate_tile<D, R, ONE>(ws, vc, N, e0, ti, a.h, a.w, spin_limit, t)) { if (lane == 0) atomicOr(ws.fault, kFaultCounts); return; }
+        BXI_TW(1, wid, 1);
+        math_tile<D, R, ONE>(a, ws, t, upw_warm, n2max, zero_bit, n_items, spin_limit, scale, have_scale, g_logits, gbuf, wid);
+    }
+}
+
+// grid: [n_pb predicate blocks][N leaders][n_tb tile blocks][finisher].  The only waits: a tile wave for the predicate waves
+// (earlier in the grid, never waiting themselves), the finisher for everybody (nobody waits for it).  Every wait is bounded, and
+// running out of it is loud: NaN losses, status word, poisoned gradient (the reference surfaces launch failures through
+// AT_CUDA_CHECK, pairwise.cu:173,200).
 template <int D, int R>
 __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
                                                        float n2max, int zero_bit, int n_pb, int n_items, int spin_limit, ValidCells vc, float* __restrict__ losses,
                                                        float* __restrict__ g_logits, InstArgs a, Ws ws, LossState st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[16];
-    const int blk = (int)blockIdx.x, lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const int blk = (int)blockIdx.x;
     const int N = a.N;
     const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
-    if (blk < n_pb) {                                                  // ---- predicate waves: first in the grid, everybody asks for their bytes
+    if (blk < n_pb) {                                                  // ---- predicate waves: first in the grid, everybody asks for their words
         if (zero_bit) return;                                          // every pair weighs 1: sum W has a closed form, the tiles take the log-space path
-        const int segs = (a.w + 63) >> 6, pid = blk * kWaves + wave;
-        BXI_TW(2, pid, 0);
-        __builtin_amdgcn_s_setprio(3);                                 // short, and the tile waves will ask for these bytes
-        int cnt = 0, segments = 0;
-        for (int item = pid; item < n_items; item += n_pb * kWaves) { cnt += pred_item(a, vc, ws, D, n2max, item, segs); ++segments; }
-        cnt = wave_total_i32(cnt);
-        // ONE arrival per workgroup: arrivals on one word are performed one after the other (~0.15 us each), and the tile waves
-        // need the last one
-        __shared__ int pred_cnt[kWaves], pred_seg[kWaves];
-        if (lane == 0) { pred_cnt[wave] = cnt; pred_seg[wave] = segments; }
-        __syncthreads();
-        if (threadIdx.x == 0)    // (segments evaluated, sum W); integer adds commute: run-to-run identical
-            __hip_atomic_fetch_add(&ws.acc1[(size_t)(blk & (kAcc1Words - 1)) * kAcc2Stride],
-                                   ((unsigned long long)(unsigned int)((pred_seg[0] + pred_seg[1]) + (pred_seg[2] + pred_seg[3])) << 40) |
-                                       (unsigned long long)(unsigned int)((pred_cnt[0] + pred_cnt[1]) + (pred_cnt[2] + pred_cnt[3])),
-                                   BXI_RLX, BXI_AGENT);
-        BXI_TW(2, pid, 1);
-        return;
-    }
-    if (blk < n_pb + N) {                                              // ---- leader of an instance
+        pred_role<D, false>(a, vc, ws, n2max, blk, n_pb, n_items, spin_limit);
+    } else if (blk < n_pb + N) {                                       // ---- leader of an instance
         BXI_TW(3, 1 + blk - n_pb, 0);
-        leader_block(a, D, ws, st, blk - n_pb, upp, g_logits, smem, red);
+        leader_block<false>(a, D, ws, st, blk - n_pb, upp, g_logits, smem, red, spin_limit);
+    } else if (blk == (int)gridDim.x - 1) {
+        finisher_role<false>(a, ws, st, upp, upw, warmup, zero_bit, n_items, spin_limit, R, losses);
+    } else {
+        tile_role<D, R, false>(a, vc, ws, upw * warmup, n2max, zero_bit, n_items, spin_limit, g_logits, smem, blk - N - n_pb, (int)gridDim.x - 1 - N - n_pb);
+    }
+}
+
+// ---- the single-launch form ---------------------------------------------------------------------------------------------------
+// All roles in ONE grid, in this order:  [stream blocks (their first waves write the table)][pool blocks][N leaders][predicate blocks][tile blocks][finisher].
+// Workgroups are dispatched in grid order and every wait is for a workgroup EARLIER in the grid:
+//   table, stream, pool   wait for nobody;
+//   leader n              for the table entry n and the band flags of instance n (stream blocks);
+//   predicate wave        for the Lab pixels it reads (pool blocks; 16-byte records carrying the evaluation's tag) and the table;
+//   tile wave             for the table, its predicate words (tagged), sum W (reducer <- predicate blocks) and the band flags of
+//                         the rows it adds onto (stream blocks);
+//   finisher              for everybody.
+// So no waiter can hold a slot that a workgroup it waits for still needs.  What crosses workgroups is written through (sc1) and
+// read past the caches; what a flag announces is drained (s_waitcnt vmcnt(0)) before the flag goes out; what announces itself is
+// one 16-byte (or 4-byte) record written by one store.  Four workgroups per CU (<= 128 VGPRs: the tile role's budget): at the
+// headline size the table + stream + pool workgroups fill the GPU once, and the back half flows into the slots they leave -- the
+// kernel boundary of the two-launch form (~2.2 us) is gone.  The two-launch form stays for 8-row tiles (> 96 instances: 2
+// workgroups per CU would starve the front half), dilation 4, the head-fused first launch and the generic pooling path.
+template <int D>
+__global__ __launch_bounds__(256, 4) void eval1_kernel(PoolArgs pa, int n_pool, int n_items, int n_pb, int n_tb, InstArgs a, Ws ws, LossState st, ValidCells vc,
+                                                        const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup, float n2max, int spin_limit,
+                                                        float* __restrict__ losses, float* __restrict__ g_logits, int vec) {
+    constexpr int R = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float red[16];
+    const int N = a.N;
+    constexpr int n_tab = 0;                                  // (trace index layout: table, stream, pool)
+    const int Sn = (a.h + kSBlk - 1) / kSBlk;
+    const int n_stream = N * Sn;
+    const int blk = (int)blockIdx.x;
+    // role of this workgroup: 0 stream, 1 pool, 2 leader, 3 predicate, 4 tile, 5 finisher
+    int role, idx = blk;
+    if (idx < n_stream) role = 0;
+    else if ((idx -= n_stream) < n_pool) role = 1;
+    else if ((idx -= n_pool) < N) role = 2;
+    else if ((idx -= N) < n_pb) role = 3;
+    else if ((idx -= n_pb) < n_tb) role = 4;
+    else role = 5;
+    const int tix = (n_tab + (role == 0 ? idx : n_stream + idx)) * kWaves + (int)(threadIdx.x >> 6);
+    (void)tix;
+    if (role == 0) {
+        BXI_TW(0, tix, 0);
+        // the table is the first duty of the first stream workgroups' first waves (wave k of the table in workgroup k): a workgroup
+        // of its own would be the one workgroup too many for the front half to be resident at once at the headline size
+        if ((threadIdx.x >> 6) == 0 && 64 * idx <= N) table_wave(a, pa.meta, D, R, ws, st, idx, false);
+        const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
+        stream_block<true>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);
+        BXI_TW(0, tix, 7);
         return;
     }
-    if (blk == (int)gridDim.x - 1) {                                   // ---- finisher
-        // waits only for workgroups that never wait for it: the leaders and the predicate waves (done early), then the tile waves
-        BXI_TW(3, 0, 0);
-        __shared__ double fin_d[kWaves];
-        __shared__ int fin_i[kWaves];
-        __shared__ float fin_f;
-        __shared__ int fin_ok;
-        bool ok = true;
-        double total_w = 0.0;
-        float dsum = 0.f;
-        int spins = 0;
-        if (spin_limit < 0) ok = false;
-        if (wave == 1 && !zero_bit && !reduce_counts(ws, n_items, spin_limit) && lane == 0) atomicOr(ws.fault, kFaultCounts);     // the reducer
-        if (wave == 0) {
-            for (int b0 = 0; b0 < N && ok; b0 += 64) {
-                while (!dice_round(ws, N, b0, &dsum)) {
-                    if (++spins > spin_limit) { ok = false; break; }
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            }
-            if (zero_bit) total_w = total_weight_all_pairs(a, ws);
-            else
-                while (ok && !counts_complete(ws, n_items, &total_w)) {
-                    if (++spins > spin_limit) ok = false;
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            if (lane == 0) { fin_f = dsum; fin_d[0] = total_w; fin_ok = ok ? 1 : 0; }
-        }
-        __syncthreads();
-        ok = fin_ok != 0; dsum = fin_f; total_w = fin_d[0];
-        const int ntiles = __builtin_amdgcn_readfirstlane(ws.tab[N].x);
-        __syncthreads();
-        // every thread watches its own arrival words (N * 8 / 256 each: one at the headline size); the launch ends on this loop
-        long long mine = 0;
-        spins = 0;
-        for (;;) {
-            mine = 0;
-            int arrived = 0;
-            for (int i = threadIdx.x; i < N * kAcc2Split; i += 256) {
-                const unsigned long long x = __hip_atomic_load(ws.acc2 + (size_t)i * kAcc2Stride, BXI_RLX, BXI_AGENT);
-                arrived += (int)(x >> 52);
-                mine += (long long)(x & ((1ull << 52) - 1ull)) - ((long long)(x >> 52) << 24);       // the +1 per tile
-            }
-            arrived = wave_total_i32(arrived);
-            if (lane == 0) fin_i[wave] = arrived;
-            __syncthreads();
-            const bool all = (fin_i[0] + fin_i[1]) + (fin_i[2] + fin_i[3]) == ntiles;
-            __syncthreads();
-            if (all) break;
-            if (++spins > spin_limit) { ok = false; break; }           // workgroup-uniform: the same count in every thread
-        }
-        const double wsum = wave_total_f64((double)mine);                // exact; fixed order: run-to-run identical
-        if (lane == 0) fin_d[wave] = wsum;
-        __syncthreads();
-        if (threadIdx.x >= 64) return;
-        const double num = (fin_d[0] + fin_d[1]) + (fin_d[2] + fin_d[3]);
-        const unsigned int fault = __hip_atomic_load(ws.fault, BXI_RLX, BXI_AGENT);   // set by a tile wave BEFORE its arrival, if at all
-        const unsigned int status = (unsigned int)__builtin_amdgcn_readfirstlane((int)(fault | (ok ? 0u : kFaultFinisher)));
-        if (lane == 0) {
-            const float denom = fmaxf((float)total_w, 1.f);                      // weights.sum().clamp(min=1.0), :1328
-            float l0 = dsum / (float)N;                                          // .mean(), :143
-            float l1 = (float)((num / (double)kNumScale) / (double)denom) * warmup;   // :1327-1332
-            if (status) { l0 = __int_as_float(0x7fc00000); l1 = l0; }            // loud: mmdet's CheckInvalidLossHook fires
-            losses[0] = l0; losses[1] = l1;
-            if (st.scale) { *st.scale = warmup / denom; st.applied[0] = upp; st.applied[1] = upw; }
-            if (st.status) st.status[0] = (int)status;
-        }
-        BXI_TW(3, 0, 1);
+    if (role == 1) {
+        BXI_TW(0, tix, 0);
+        double* lut = reinterpret_cast<double*>(smem);
+        double* fch = lut + 256;
+        int* part = reinterpret_cast<int*>(fch + 3 * 64);
+        pool_block(pa, ws, idx, n_pool, n_items, lut, part, fch, tix);
+        BXI_TW(0, tix, 7);
         return;
     }
-    const int wid = (blk - N - n_pb) * kWaves + wave, nwaves = ((int)gridDim.x - 1 - N - n_pb) * kWaves;
-    __builtin_amdgcn_s_setprio(2);                                     // the launch ends on the tile waves, not on the leaders next to them
-    BXI_TW(1, wid, 0);
-    int4 e0 = make_int4(0, 0, 0, 0);
-    if (lane <= N) e0 = ws.tab[lane];
-    const int total = N < 64 ? __builtin_amdgcn_readlane(e0.x, N < 64 ? N : 0) : __builtin_amdgcn_readfirstlane(ws.tab[N].x);
-    float* gbuf = reinterpret_cast<float*>(smem) + wave * ((R + 1) * 64);
-    float scale = 0.f;
-    bool have_scale = false;
-    for (int ti = wid; ti < total; ti += nwaves) {
-        const Tile t = locate_tile<D, R>(ws, N, e0, ti, a.h, a.w);
-        BXI_TW(1, wid, 1);
-        math_tile<D, R>(a, ws, t, upw * warmup, n2max, zero_bit, n_items, spin_limit, scale, have_scale, g_logits, gbuf, wid);
+    const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
+    if (role == 2) {
+        BXI_TW(3, 1 + idx, 0);
+        leader_block<true>(a, D, ws, st, idx, upp, g_logits, smem, red, spin_limit);
+        return;
     }
+    if (role == 3) { pred_role<D, true>(a, vc, ws, n2max, idx, n_pb, n_items, spin_limit); return; }
+    if (role == 4) { tile_role<D, R, true>(a, vc, ws, upw * warmup, n2max, 0, n_items, spin_limit, g_logits, smem, idx, n_tb); return; }
+    finisher_role<true>(a, ws, st, upp, upw, warmup, 0, n_items, spin_limit, R, losses);
 }
 
 // ---- rescale: g_logits finished for the factors recorded in `state` -> finished for (g_prj, g_pw) ----------------
@@ -1267,6 +1528,7 @@ static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, 
 size_t eval_ws_bytes(int B, int N, int h, int w) { return carve(nullptr, B, N, h, w, nullptr); }
 bool fused_eval_supported(int dil) { return dil >= 1 && dil <= kMaxDilFused; }
 void debug_set_spin_limit(int limit) { g_spin_limit.store(limit, std::memory_order_relaxed); }
+void debug_set_eval_form(int form) { g_form.store(form, std::memory_order_relaxed); }
 
 // One evaluation, two launches.
 int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bxi_instances* in, int dil, float warmup, const float* up_prj,
@@ -1296,6 +1558,13 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
     Ws ws;
     carve(workspace, batch->B, a.N, a.h, a.w, &ws);
+    {   // this evaluation's tag: 1 .. 2^28 - 1, different from every recent evaluation's in this process
+        static std::atomic<unsigned int> epoch{0u};
+        unsigned int e = epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;
+        e &= 0x0fffffffu;
+        if (e == 0u) e = (epoch.fetch_add(1u, std::memory_order_relaxed) + 1u) & 0x0fffffffu;
+        ws.ep = e ? e : 1u;
+    }
     LossState st = {};
     if (state) {
         if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
@@ -1310,6 +1579,55 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     const int R = force_rows == 4 || force_rows == 8 ? force_rows : tile_rows_for(a.N);
     if (eval_cap(a.N, a.h, a.w, dil, R) >= (1 << 24)) return BXI_ERR_BAD_SHAPE;     // the table packs a tile prefix into 24 bits
     const HostPred pr = host_pred(color_thresh);
+    ValidCells vc = {};
+    for (int b = 0; b < batch->B; ++b) {                  // the device formula (valid_cells), evaluated here once per image
+        const int half = a.stride / 2;
+        auto cells = [&](int limit, int n) { const int v = limit - half <= 0 ? 0 : (limit - half + a.stride - 1) / a.stride; return v < n ? v : n; };
+        vc.vrow[b] = cells(pa.meta.img_h[b] < pa.meta.first_removed[b] ? pa.meta.img_h[b] : pa.meta.first_removed[b], a.h);
+        vc.vcol[b] = cells(pa.meta.img_w[b], a.w);
+    }
+    const int64_t n_items64 = (int64_t)batch->B * a.h * ((a.w + 63) / 64);
+    if (n_items64 > 0x7fffffffLL) return BXI_ERR_BAD_SHAPE;
+    const int n_items = (int)n_items64;
+    const int lim = g_spin_limit.load(std::memory_order_relaxed);
+    const int spin_limit = lim == 0 ? kSpinLimit : lim;
+
+    // ---- the single-launch form ---------------------------------------------------------------------------------------
+    static const int env_one = env_int("BXI_ONE_LAUNCH", 1);            // developer knob: 0 = always two launches
+    if (env_one && g_form.load(std::memory_order_relaxed) != 2 && !head && pooled_in_launch && R == 4 && dil <= 3 && !pr.zero_bit) {
+        static const int env_one_pool = env_int("BXI_ONE_POOL_WGS", 0);
+        const int Sn = (a.h + kSBlk - 1) / kSBlk;
+        const int n_stream = a.N * Sn;
+        const int slots = 4 * device_cus();
+        // the front half (table, stream, pool) should fill the GPU exactly once: a pool workgroup takes several items
+        // (measured and dropped: pool workgroups alone filling the GPU first, predicate and stream workgroups behind them -- the
+        // stream workgroups, and with them the band flags and the leaders, then end 8 us late: 22.9 us per evaluation against 18.3)
+        // (also measured and dropped: stream waves that hold their loads back for 1 - 4 us so that the pool workgroups' reads go
+        // first: 18.0 / 18.3 / 20.3 us against 17.96; pool workgroups of one item each: 18.3)
+        const int front = slots - n_stream;
+        const int room = env_one_pool > 0 ? env_one_pool : (front > slots / 4 ? front : slots / 4);
+        const int per = (n_items + room - 1) / room;
+        const int n_pool = (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per);
+        int n_pb = (n_items + kWaves - 1) / kWaves;
+        if (n_pb > slots / 2) n_pb = slots / 2;
+        int64_t n_tb = (eval_cap(a.N, a.h, a.w, dil, R) + kWaves - 1) / kWaves;
+        if (n_tb > slots / 2) n_tb = slots / 2;
+        size_t lds = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
+        if (lds < 8 * (size_t)kWaves * a.w) lds = 8 * (size_t)kWaves * a.w;
+        if (lds < sizeof(float) * (size_t)kWaves * (R + 1) * 64) lds = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
+        if (lds < 2 * sizeof(float) * (size_t)(a.h + a.w) + 16) lds = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
+        if (lds <= 36 * 1024) {                             // four workgroups per CU must fit
+            const unsigned grid = (unsigned)(n_stream + n_pool + a.N + n_pb + (int)n_tb + 1);
+#define BXI_ONE_CASE(DD)                                                                                                                    \
+            case DD:                                                                                                                        \
+                BXI_LAUNCH("eval1", s, (eval1_kernel<DD>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, up_prj, \
+                           up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec);                                                    \
+                break;
+            switch (dil) { BXI_ONE_CASE(1) BXI_ONE_CASE(2) BXI_ONE_CASE(3) default: return BXI_ERR_UNSUPPORTED; }
+#undef BXI_ONE_CASE
+            return check_launch();
+        }
+    }
 
     // ---- launch 1 --------------------------------------------------------------------------------------------------
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
@@ -1317,9 +1635,6 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     const int n_stream = a.N * Sn;
     // one item = the 4 input rows of 64 pooled pixels.  The whole launch should be resident at once (5 workgroups per CU at
     // <= 96 VGPRs): a pool workgroup takes several items, the next one's loads in flight, when it is not.
-    const int64_t n_items64 = (int64_t)batch->B * a.h * ((a.w + 63) / 64);
-    if (n_items64 > 0x7fffffffLL) return BXI_ERR_BAD_SHAPE;
-    const int n_items = (int)n_items64;
     const int room = env_pool_wgs * device_cus() - n_tab - (head ? 0 : n_stream);
     const int per = room > 0 ? (n_items + room - 1) / room : 8;
     const int n_pool = pooled_in_launch ? (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per) : 0;
@@ -1358,7 +1673,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         if (rc != BXI_OK) return rc;
         const int64_t BP = (int64_t)batch->B * a.h * a.w;
         BXI_LAUNCH("pack_lab4", s, pack_lab4_kernel, dim3((unsigned)((BP + 255) / 256 > 2048 ? 2048 : (BP + 255) / 256)), dim3(256), 0, s,
-                   (const float*)ws.lab_planar, ws.lab4, ws.pred, batch->B, (int64_t)a.h * a.w);
+                   (const float*)ws.lab_planar, ws.lab4, ws.ep, batch->B, (int64_t)a.h * a.w);
         rc = check_launch();
         if (rc != BXI_OK) return rc;
     }
@@ -1379,13 +1694,6 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     if (lds2 < lds_leader) lds2 = lds_leader;
     if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
     const int grid = a.N + n_pb + (int)n_tb + 1;          // leaders + predicate blocks + tile blocks + the finisher
-    ValidCells vc = {};
-    for (int b = 0; b < batch->B; ++b) {                  // the device formula (valid_cells), evaluated here once per image
-        const int half = a.stride / 2;
-        auto cells = [&](int limit, int n) { const int v = limit - half <= 0 ? 0 : (limit - half + a.stride - 1) / a.stride; return v < n ? v : n; };
-        vc.vrow[b] = cells(pa.meta.img_h[b] < pa.meta.first_removed[b] ? pa.meta.img_h[b] : pa.meta.first_removed[b], a.h);
-        vc.vcol[b] = cells(pa.meta.img_w[b], a.w);
-    }
 #define BXI_PAIR_CASE(DD)                                                                                                                  \
     case DD:                                                                                                                               \
         if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw); \

@@ -177,13 +177,16 @@ int bxi_boxinst_loss_fwd_bwd_f32(const bxi_instances* inst_host, const uint8_t* 
 int bxi_boxinst_loss_backward_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw,
                                   int dilation, const void* state, float* g_logits, void* stream);
 
-/* The evaluation proper: forward AND finished backward in one host call, two launches (prep, pair; csrc/fused_eval.hip):
- *   launch 1: image side (stage A above: de-normalise, 4x4 pool, Lab) next to the logit streaming (row / column maxima,
- *             zero-fill of g_logits) and the per-instance table; nothing in it waits;
- *   launch 2: projection term per instance (:117-143), pair weights and pairwise term per box tile (pairwise.cu:68-149 semantics;
- *             colour affinity derived from Lab where it is needed, nothing of stage B is materialised), normaliser, both loss
- *             scalars; the gradient's two parts are ADDED to the zero-filled buffer (at most two additions per element: the
- *             result does not depend on their order).
+/* The evaluation proper: forward AND finished backward in one host call (csrc/fused_eval.hip), as ONE launch (eval1) at the
+ * shipped configurations' shapes, otherwise as two (prep, pair):
+ *   front half / launch 1: image side (stage A above: de-normalise, 4x4 pool, Lab) next to the logit streaming (row / column
+ *             maxima, zero-fill of g_logits) and the per-instance table; nothing in it waits;
+ *   back half / launch 2: projection term per instance (:117-143), pair weights and pairwise term per box tile (pairwise.cu:68-149
+ *             semantics; colour affinity derived from Lab where it is needed, nothing of stage B is materialised), normaliser,
+ *             both loss scalars; the gradient's two parts are ADDED to the zero-filled buffer (at most two additions per
+ *             element: the result does not depend on their order).
+ *   In the single-launch form the back half's workgroups follow the front half's in the grid and wait (bounded, loud) only for
+ *   workgroups that precede them; what crosses workgroups carries a per-evaluation tag.
  * losses[0] = loss_prj, losses[1] = loss_pairwise (device, f32), complete when the call's work is done.
  * g_logits [N,1,h,w] (nullable: forward only) receives the FINISHED gradient
  *       up_prj * d loss_prj / d logits  +  up_pw * d loss_pairwise / d logits,
@@ -193,7 +196,7 @@ int bxi_boxinst_loss_backward_f32(const bxi_instances* inst_host, const float* g
  * warmup: min(_iter / pairwise_warmup, 1) (:1330-1331), evaluated on the host by the caller.
  * state (bxi_boxinst_loss_state_bytes, 256-B aligned; required with g_logits): arg-max positions, unit projection
  *   gradients, box rectangles, normaliser, the factors applied, and a status word.  Status 0 = fine.  Non-zero = one of the
- *   second launch's bounded in-kernel waits ran out (tile waves wait for the predicate waves that precede them in the grid, the
+ *   bounded in-kernel waits ran out (tile waves wait for the predicate waves that precede them in the grid, the
  *   finisher for everybody; neither is expected to): BOTH LOSSES ARE NaN then (the reference surfaces launch failures through
  *   AT_CUDA_CHECK, pairwise.cu:173,200; here mmdet's CheckInvalidLossHook fires), and bxi_boxinst_grad_rescale_f32 poisons the
  *   gradient.
@@ -235,6 +238,10 @@ int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_insta
  * negative = every bounded wait gives up at once, which makes the failure path observable: NaN losses, status word, and a
  * gradient poisoned by bxi_boxinst_grad_rescale_f32.  Process-wide; not for production use. */
 void bxi_debug_set_spin_limit(int limit);
+/* Test hook: which form of the evaluation bxi_boxinst_eval_f32 launches.  0 = the library chooses (the single-launch form where it
+ * applies: stride-4 aligned canvases, 4-row tiles (<= 96 instances), dilation <= 3, threshold > 0); 2 = always the two-launch form.
+ * Same results either way (tests run both).  Process-wide; not for production use. */
+void bxi_debug_set_eval_form(int form);
 
 /* g_logits finished by bxi_boxinst_eval_f32 for the factors recorded in `state`  ->  finished for (g_prj, g_pw)
  * (DEVICE scalars: the upstream gradients autograd hands over; no host sync).  The kernel returns at once when they

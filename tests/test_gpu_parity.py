@@ -261,7 +261,42 @@ def test_deterministic(dev):
     assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
 
 
-def test_wait_timeouts_are_loud(dev):
+@pytest.fixture(params=[0, 2], ids=['form_auto', 'form_two_launches'])
+def eval_form(request):
+    """bxi_boxinst_eval_f32 as the library chooses it (the single launch where it applies) and forced to two launches."""
+    from boxinstseg_amd import _lib
+    lib = _lib.load()
+    lib.bxi_debug_set_eval_form(request.param)
+    yield request.param
+    lib.bxi_debug_set_eval_form(0)
+
+
+def test_single_launch_and_two_launch_forms_agree_bit_for_bit(dev):
+    """The evaluation as ONE launch (back-half workgroups waiting, inside the launch, for front-half workgroups that precede them
+    in the grid; tagged records) and as two launches (a kernel boundary instead) must give the same bits: integer loss
+    accumulators, dice sums in index order, a gradient of at most two float additions onto a zero per element."""
+    from boxinstseg_amd import _lib
+    lib = _lib.load()
+    cases = [synthetic.cfg1(3), synthetic.cfg2(1),
+             synthetic.make_batch(B=3, H=160, W=224, boxes_per_img=3, seed=5, min_box=12, max_box=120, img_shapes=[[150, 200], [160, 224], [121, 183]]),
+             synthetic.make_batch(B=1, H=1056, W=96, boxes_per_img=2, seed=6, min_box=16, max_box=90),          # tall: many bands
+             synthetic.make_batch(B=2, H=128, W=1088, boxes_per_img=2, seed=7, min_box=16, max_box=300),        # wide: several chunks
+             synthetic.make_batch(B=2, H=256, W=256, boxes_per_img=40, seed=8, min_box=8, max_box=60)]          # 80 instances
+    for d in cases:
+        for dil in (1, 2, 3):
+            res = []
+            for form in (0, 2):
+                lib.bxi_debug_set_eval_form(form)
+                try:
+                    res.append(hip_loss(d, dev, pairwise_dilation=dil))
+                finally:
+                    lib.bxi_debug_set_eval_form(0)
+            a, b = res
+            assert a[0] == b[0] and a[1] == b[1], (dil, a[:2], b[:2])
+            assert np.array_equal(a[2], b[2]), dil
+
+
+def test_wait_timeouts_are_loud(dev, eval_form):
     """The second launch's bounded waits (tile waves for the predicate bytes / the normaliser, the finisher for everybody) never run
     out in practice; when they do -- forced here through the test hook -- the evaluation must not hand back plausible numbers: both
     losses are NaN (mmdet's CheckInvalidLossHook fires, mmdet/core/hook/checkloss_hook.py:20-24), the status word is set and the
@@ -289,7 +324,7 @@ def test_wait_timeouts_are_loud(dev):
     assert again[0] == good[0] and again[1] == good[1] and np.array_equal(again[2], good[2])
 
 
-def test_two_streams_next_to_a_kernel_that_fills_the_gpu(dev):
+def test_two_streams_next_to_a_kernel_that_fills_the_gpu(dev, eval_form):
     """Two evaluations in flight on two streams while a third stream keeps every CU busy with matrix products: the in-kernel waits of
     the second launch (tile waves for earlier workgroups of their own grid) must still be met -- a time-out would turn the losses
     into NaN -- and the results must be those of the quiet, serial runs, bit for bit."""

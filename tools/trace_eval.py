@@ -37,7 +37,7 @@ torch.cuda._sleep(int(0.02 * 2e9)); ev(sets[3]); torch.cuda.synchronize()
 t = trace.cpu().numpy().astype(np.float64)
 us = lambda x: x * 0.01
 N, Sn = 32, 7
-pool_first = int(os.environ.get('BXI_POOL_FIRST', '1'))
+pool_first = int(os.environ.get('BXI_POOL_FIRST', '0'))
 n_tab = 1 * 4
 n_stream = N * Sn * 4
 p = t[0]; live = p[:, 0] > 0
@@ -62,17 +62,22 @@ print('  stream waves:', len(sw), 'start', q(us(sw[:, 0] - t0)), '| loads+zero-f
 print('  pool waves (last item of each):', len(pw), 'start', q(us(pw[:, 0] - t0)), '| loads + denorm at', q(us(pw[:, 1] - t0)), '| barrier 1', qd(pw[:, 2], pw[:, 1]),
       '| Lab f', qd(pw[:, 3], pw[:, 2]), '| barrier 2', qd(pw[:, 4], pw[:, 3]), '| end', q(us(pw[:, 7] - t0)))
 prep_end = p[live, 7].max()
+one = os.environ.get('BXI_ONE_LAUNCH', '1') != '0'
 mw = t[1]; allm = mw[mw[:, 0] > 0]; mw = allm[allm[:, 7] > 0]
 cw = t[2]; cw = cw[cw[:, 0] > 0]
 ld = t[3][1:]; ld = ld[ld[:, 0] > 0]
-k0 = min(allm[:, 0].min(), ld[:, 0].min(), cw[:, 0].min())
-print('pair: first wave starts %.2f us after the last prep wave ended' % us(k0 - prep_end))
-print('  leaders', len(ld), 'start', q(us(ld[:, 0] - k0)), '| loads+maxima', qd(ld[:, 1], ld[:, 0]), '| sums + dice', qd(ld[:, 2], ld[:, 1]),
+if one:
+    k0 = t0
+    print('single launch: every time below is relative to the first wave of the launch; last front-half wave (table/stream/pool) ends at %.2f' % us(prep_end - t0))
+else:
+    k0 = min(allm[:, 0].min(), ld[:, 0].min(), cw[:, 0].min())
+    print('pair: first wave starts %.2f us after the last prep wave ended' % us(k0 - prep_end))
+print('  leaders', len(ld), 'start', q(us(ld[:, 0] - k0)), '| wait + loads + maxima', qd(ld[:, 1], ld[:, 0]), '| sums + dice', qd(ld[:, 2], ld[:, 1]),
       '| coefficients + adds', qd(ld[:, 3], ld[:, 2]), '| dice at', q(us(ld[:, 2] - k0)), '| end', q(us(ld[:, 3] - k0)))
 print('  predicate waves', len(cw), 'start', q(us(cw[:, 0] - k0)), '| segment(s) done', qd(cw[:, 1], cw[:, 0]), '| end', q(us(cw[:, 1] - k0)))
 print('  tile waves with a tile', len(mw), 'of', len(allm), 'start', q(us(mw[:, 0] - k0)), '| table -> tile', qd(mw[:, 1], mw[:, 0]), '| logits + per-pixel', qd(mw[:, 2], mw[:, 1]),
-      '| predicate bytes + masks', qd(mw[:, 3], mw[:, 2]), '| pair math', qd(mw[:, 5], mw[:, 3]), '| sum W', qd(mw[:, 4], mw[:, 5]),
-      '| adds issued', qd(mw[:, 6], mw[:, 4]), '| arrival issued', qd(mw[:, 7], mw[:, 6]), '| bytes asked for at', q(us(mw[:, 2] - k0)), '| math done at', q(us(mw[:, 5] - k0)),
+      '| predicate words + masks', qd(mw[:, 3], mw[:, 2]), '| pair math', qd(mw[:, 5], mw[:, 3]), '| sum W (+ band flags)', qd(mw[:, 4], mw[:, 5]),
+      '| adds issued', qd(mw[:, 6], mw[:, 4]), '| arrival issued', qd(mw[:, 7], mw[:, 6]), '| words asked for at', q(us(mw[:, 2] - k0)), '| math done at', q(us(mw[:, 5] - k0)),
       '| end', q(us(mw[:, 7] - k0)))
 fw = t[3][0]
 print('  finisher: start %.2f end %.2f' % (us(fw[0] - k0), us(fw[1] - k0)))
