@@ -57,6 +57,10 @@ static std::atomic<int> g_form{0};
 constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
 constexpr int kAcc1Words = 64;                  // count-wave arrivals + sum W: 64 words, each in its own 128 bytes
 constexpr int kMaxInst = 65536;
+#ifndef BXI_ONE_OCC
+#define BXI_ONE_OCC 4
+#endif
+constexpr int kOneOcc = BXI_ONE_OCC;           // workgroups per CU of the single-launch form (<= 128 VGPRs: the tile role's budget)
 constexpr unsigned kFaultCounts = 1u, kFaultFinisher = 2u;
 // A wave whose bounded wait ran out says so IN the word the finisher waits for, so that the round that sees every arrival sees
 // every fault: bit 50 of a tile wave's arrival (the sum field stays below 2^46 for every shape the table admits), bit 39 of a
@@ -1354,7 +1358,7 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair_ker
 // kernel boundary of the two-launch form (~2.2 us) is gone.  The two-launch form stays for 8-row tiles (> 96 instances: 2
 // workgroups per CU would starve the front half), dilation 4, the head-fused first launch and the generic pooling path.
 template <int D>
-__global__ __launch_bounds__(256, 4) void eval1_kernel(PoolArgs pa, int n_pool, int n_items, int n_pb, int n_tb, InstArgs a, Ws ws, LossState st, ValidCells vc,
+__global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_pool, int n_items, int n_pb, int n_tb, InstArgs a, Ws ws, LossState st, ValidCells vc,
                                                         const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup, float n2max, int spin_limit,
                                                         float* __restrict__ losses, float* __restrict__ g_logits, int vec) {
     constexpr int R = 4;
@@ -1598,7 +1602,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         static const int env_one_pool = env_int("BXI_ONE_POOL_WGS", 0);
         const int Sn = (a.h + kSBlk - 1) / kSBlk;
         const int n_stream = a.N * Sn;
-        const int slots = 4 * device_cus();
+        const int slots = kOneOcc * device_cus();
         // the front half (table, stream, pool) should fill the GPU exactly once: a pool workgroup takes several items
         // (measured and dropped: pool workgroups alone filling the GPU first, predicate and stream workgroups behind them -- the
         // stream workgroups, and with them the band flags and the leaders, then end 8 us late: 22.9 us per evaluation against 18.3)
