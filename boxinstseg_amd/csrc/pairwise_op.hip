@@ -528,12 +528,17 @@ __global__ __launch_bounds__(256) void pairwise3_fwd_wide_kernel(const float* __
 
 template <int D, int TR, int TC>
 __global__ __launch_bounds__(256, 5) void pairwise3_bwd_wide_kernel(const float* __restrict__ logits, const float* __restrict__ g_pair, int H, int W,
-                                                                 float* __restrict__ g_logits) {
+                                                                 float* __restrict__ g_logits, int xcd_swizzle) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pw_raw[];
     constexpr int PC = PwGeom<D, TC>::PC, NWp = 4 * PwGeom<D, TC>::NW4;
     static_assert(TR * TC == 1024 && TC % 4 == 0, "256 threads x four adjacent pixels");
     const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
-    int t = blockIdx.x;
+    // workgroups are dealt to the 8 XCDs round-robin by index; each XCD has its own L2.  Tile order = index order WITHIN an XCD, so
+    // that the tiles an XCD works on at one time are neighbours: the partner terms that reach into the next tile are then lines its
+    // own L2 has just fetched -- 19.2 -> 15.7 us at 32 x 200 x 256 (with the plain order a tile's four neighbours run on four other
+    // XCDs, and every halo line crosses the fabric again)
+    int t = xcd_swizzle ? (int)((blockIdx.x % 8u) * ((gridDim.x + 7u) / 8u) + blockIdx.x / 8u) : (int)blockIdx.x;
+    if (t >= (int)gridDim.x) return;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int64_t n = t / tiles_y;
@@ -696,11 +701,12 @@ static int launch_bwd(const T* logits, const T* g_pair, int N, int H, int W, int
             }
             if constexpr (sizeof(T) == 4) {
                 if (dil <= 4 && (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(g_pair) | reinterpret_cast<uintptr_t>(g_logits)) & 15) == 0) {
+                    static const int env_swz = getenv("BXI_PW_SWIZZLE") ? atoi(getenv("BXI_PW_SWIZZLE")) : 1;
 #define BXI_PWB(DD)                                                                                                                             \
                     {                                                                                                                           \
                         const size_t ldw = 2 * sizeof(float) * (size_t)(kPwTR + 2 * DD) * PwGeom<DD, kPwTC>::PC;                             \
                         BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_wide_kernel<DD, kPwTR, kPwTC>), g, b, ldw, st, (const float*)logits,     \
-                                   (const float*)g_pair, H, W, (float*)g_logits);                                                             \
+                                   (const float*)g_pair, H, W, (float*)g_logits, env_swz);                                                    \
                     }
                     switch (dil) { case 1: BXI_PWB(1) break; case 2: BXI_PWB(2) break; case 3: BXI_PWB(3) break; default: BXI_PWB(4) break; }
 #undef BXI_PWB

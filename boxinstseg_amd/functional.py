@@ -233,7 +233,7 @@ def last_eval_status() -> Tuple[int, int]:
         return 0, 0
     plan, buf = _LAST['plan'], _LAST['buf']
     off = 256 + _lib.load().bxi_boxinst_loss_state_status_offset(plan.inst.N, plan.inst.h, plan.inst.w)
-    v = buf[off:off + 8].view(torch.int32).cpu()
+    v = buf.view(torch.uint8)[off:off + 8].view(torch.int32).cpu()
     return int(v[0]), int(v[1])
 
 
@@ -328,7 +328,7 @@ class BoxInstMaskLoss(torch.autograd.Function):
         ctx.logits = mask_logits.detach()
         ctx.calls = 0
         losses, ctx.grad, ctx.state, ctx.plan, ctx.keep = BoxInstMaskLoss._evaluate(ctx, need_grad)
-        return losses[0], losses[1]
+        return losses.unbind(0)
 
     @staticmethod
     def _evaluate(ctx, need_grad: bool):
@@ -344,9 +344,9 @@ class BoxInstMaskLoss(torch.autograd.Function):
         plan = _eval_plan(imgs, ctx.metas, x, boxes, int(cfg['out_stride']), int(cfg['bottom_pixels_removed']), stream)
         if gi.numel() != plan.inst.N:
             raise RuntimeError(f'{plan.inst.N} instances but {gi.numel()} gt_inds')
-        # ONE allocation: [losses 256 B][state][gradient]
-        nbytes = 256 + (plan.state_bytes + 4 * plan.grad_elems if need_grad else 0)
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        # ONE allocation, as floats: [losses 256 B][state (a multiple of 256 B)][gradient]
+        nfl = 64 + (plan.state_bytes // 4 + plan.grad_elems if need_grad else 0)
+        buf = torch.empty(nfl, dtype=torch.float32, device=dev)
         base = buf.data_ptr()
         if base & 255:
             raise RuntimeError('allocator returned a buffer that is not 256-byte aligned')
@@ -355,14 +355,18 @@ class BoxInstMaskLoss(torch.autograd.Function):
         plan.inst.gt_inds = gi.data_ptr()
         grad = None
         if need_grad:
-            grad = buf[256 + plan.state_bytes:].view(torch.float32).view(x.shape)
-        with torch.cuda.device(dev):
-            _lib.check('bxi_boxinst_eval_f32', plan.eval(
-                plan.batch_ref, plan.inst_ref, int(cfg['pairwise_size']), int(cfg['pairwise_dilation']),
+            grad = buf[64 + plan.state_bytes // 4:].view(x.shape)
+        args = (plan.batch_ref, plan.inst_ref, int(cfg['pairwise_size']), int(cfg['pairwise_dilation']),
                 float(cfg['pairwise_color_thresh']), float(cfg['warmup_factor']), 0, 0, base,
                 base + 256 + plan.state_bytes if need_grad else 0, base + 256 if need_grad else 0,
-                plan.ws_ptr, plan.ws_bytes, stream))
-        losses = buf[:8].view(torch.float32)
+                plan.ws_ptr, plan.ws_bytes, stream)
+        if torch.cuda.current_device() == dev.index:          # the usual case: no device guard to set up and tear down
+            rc = plan.eval(*args)
+        else:
+            with torch.cuda.device(dev):
+                rc = plan.eval(*args)
+        _lib.check('bxi_boxinst_eval_f32', rc)
+        losses = buf[:2]
         if DEBUG_KEEP_LAST:
             _LAST.clear()
             _LAST.update(buf=buf, plan=plan, need_grad=need_grad)
