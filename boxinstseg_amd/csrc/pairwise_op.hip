@@ -526,8 +526,11 @@ __global__ __launch_bounds__(256) void pairwise3_fwd_wide_kernel(const float* __
     }
 }
 
+#ifndef BXI_PWB_OCC
+#define BXI_PWB_OCC 5
+#endif
 template <int D, int TR, int TC>
-__global__ __launch_bounds__(256, 5) void pairwise3_bwd_wide_kernel(const float* __restrict__ logits, const float* __restrict__ g_pair, int H, int W,
+__global__ __launch_bounds__(256, BXI_PWB_OCC) void pairwise3_bwd_wide_kernel(const float* __restrict__ logits, const float* __restrict__ g_pair, int H, int W,
                                                                  float* __restrict__ g_logits, int xcd_swizzle) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pw_raw[];
     constexpr int PC = PwGeom<D, TC>::PC, NWp = 4 * PwGeom<D, TC>::NW4;
@@ -554,14 +557,12 @@ __global__ __launch_bounds__(256, 5) void pairwise3_bwd_wide_kernel(const float*
     const char* gb = reinterpret_cast<const char*>(g_pair + n * 8 * P);  // wave-uniform base + 32-bit byte offsets
     const int plane = (int)P * 4, lim = 8 * plane - 16;
     const int pix = (min(r, H - 1) * W + min(c, W - 4)) * 4;
-    // PMC (profiles/r03_pairwise_op_pmc.txt): 91 MB come over the fabric for 59 MB of input and nearly every L2 request misses -- 5
-    // workgroups x 64 KB per CU in flight are far more than the 4 MB L2 of an XCD keeps, so the partner terms (the same lines, shifted)
-    // are fetched a second time.  Tried and measured: the two reads of a plane issued back to back (this form, 19.0 us), eight
-    // instructions apart (19.4), a memory round trip apart (22.8: more evictions), a resident grid walking its tiles with the next
-    // tile's loads in flight (21.2), 8 x 128 and 4 x 256 tiles (19.0 / 20.2), and the gradient planes staged through LDS in the four
-    // channel pairs (j, 7 - j) -- one fetch per workgroup + 12 % halo, double-buffered: 21.3 us, four barrier-separated phases cost
-    // more than the second fetch).  A wave of this kernel lives ~11 us: 42 % of it waiting for memory, 44 % for an issue slot (20 waves
-    // a CU, ~115 VALU instructions per pixel); the launch needs 1.3 rounds of residency.  profiles/NOTES.md has the table.
+    // PMC (profiles/r03_pairwise_op_pmc.txt): with the XCD-aware tile order above the launch fetches 59 MB for its 59 MB of input (the
+    // partner terms -- the same lines, shifted -- hit the XCD's L2; with the plain order: 91 MB, nearly every L2 request a miss, 19.2 us).
+    // What is left at 15.7-15.9 us: 1664 workgroups on 1280 slots (93 VGPRs: five waves a SIMD) = 1.3 rounds of residency; six / seven
+    // workgroups a CU (80 / 72 VGPRs, 4 / 23 spilled) measure 16.7-17.8 / 25.5 us.  Measured before the tile order was fixed (and all
+    // slower than this form then): the two reads of a plane eight instructions or a memory round trip apart, a resident grid walking its
+    // tiles with the next tile's loads in flight, 8 x 128 and 4 x 256 tiles, the gradient planes staged through LDS.  profiles/NOTES.md.
     float4 own[8];
     f4u part[8];
 #pragma unroll
