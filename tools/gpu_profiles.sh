@@ -1,5 +1,5 @@
 #!/bin/bash
-# Developer helper (GPU box): everything profiles/ is built from.  Usage: tools/gpu_profiles.sh r02 [eval-only]
+# Developer helper (GPU box): everything profiles/ is built from.  Usage: tools/gpu_profiles.sh r03 [eval-only]
 TAG=${1:-r02}
 ONLY=${2:-all}
 R=$GRAFT_REPO_ROOT
@@ -8,12 +8,15 @@ cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-kernel-timing --no-extras"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_eager -o $TAG -- $CMD > $R/gpurun_out/prof_eager.log 2>&1
 cut -d, -f1-4 $R/gpurun_out/prof_eager/${TAG}_kernel_stats.csv | head -6
+# the two-launch form of the same evaluation (what larger instance counts, dilation 4 and the head-fused call run)
+BXI_ONE_LAUNCH=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_two_launch -o $TAG -- $CMD > $R/gpurun_out/prof_two_launch.log 2>&1
+cut -d, -f1-4 $R/gpurun_out/prof_two_launch/${TAG}_kernel_stats.csv | head -4
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -o $TAG -- \
      python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-kernel-timing --no-extras > $R/gpurun_out/pmc_$c.log 2>&1
   ls $R/gpurun_out/pmc_$c | head -3
 done
-for t in pairwise_op dynamic_head discobox levelset tree_filter; do
+for t in pairwise_op dynamic_head head_fused discobox levelset tree_filter; do
   [ "$ONLY" = eval-only ] && break
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$t -o $TAG -- python $R/tools/bench_$t.py > $R/gpurun_out/${t}_bench.json 2> $R/gpurun_out/${t}_bench.err
   tail -c 300 $R/gpurun_out/${t}_bench.json | tr '\n' ' '; echo

@@ -21,7 +21,7 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 G, P = 'gpurun_out', 'profiles'
 os.makedirs(P, exist_ok=True)
 shutil.copy(f'{G}/prof_eager/{rnd}_kernel_stats.csv', f'{P}/{rnd}_kernel_stats_eager.csv')
-for row in ('pairwise_op', 'dynamic_head', 'discobox', 'levelset', 'tree_filter'):
+for row in ('pairwise_op', 'dynamic_head', 'head_fused', 'discobox', 'levelset', 'tree_filter', 'two_launch'):
     if os.path.exists(f'{G}/prof_{row}/{rnd}_kernel_stats.csv'):
         shutil.copy(f'{G}/prof_{row}/{rnd}_kernel_stats.csv', f'{P}/{rnd}_{row}_kernel_stats.csv')
     if os.path.exists(f'{G}/{row}_bench.json'):
@@ -66,7 +66,9 @@ with open(f'{P}/{rnd}_summary.md', 'w') as f:
 print(open(f'{P}/{rnd}_summary.md').read())
 
 # ---- the "next" rows: one table per tracked rocprofv3 kernel-stats file under profiles/ ------------------
-EXTRA = [('dynamic_head', 'f-2 dynamic mask head', 'tools/bench_dynamic_head.py'),
+EXTRA = [('two_launch', 'the same evaluation forced to its two-launch form (BXI_ONE_LAUNCH=0)', 'bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-kernel-timing --no-extras'),
+         ('dynamic_head', 'f-2 dynamic mask head', 'tools/bench_dynamic_head.py'),
+         ('head_fused', 'f-2 head fused into the evaluation', 'tools/bench_head_fused.py'),
          ('discobox', 'f-3 DiscoBox MeanField / mil_loss / dice_loss', 'tools/bench_discobox.py'),
          ('levelset', 'f-4 BoxProjectionLoss / LevelsetLoss / LCM', 'tools/bench_levelset.py'),
          ('tree_filter', 'f-4 tree_filter (mst / bfs / refine)', 'tools/bench_tree_filter.py'),
