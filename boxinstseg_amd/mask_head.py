@@ -151,9 +151,15 @@ class CondInstMaskHead(nn.Module):
         if not feat.is_cuda:
             raise RuntimeError('CondInstMaskHead.forward: feat must be a CUDA (HIP) tensor; no CPU path')
         if self.dynamic_convs != 3 or self.dynamic_channels != 8 or feat.size(1) not in (8, 16):
-            # every shipped config is 3 layers x 8 channels on 8 / 16 feature channels: that is what the HIP kernels are
-            # instantiated for.  The reference leaves the three numbers free (:1079-1089), so other heads run the same
-            # arithmetic composed of PyTorch-ROCm ops (still on the GPU; autograd supplies the backward).
+            # every shipped config is 3 layers x 8 channels on 8 / 16 feature channels: that is what the tuned HIP kernels are
+            # instantiated for.  The reference leaves the three numbers free (:1079-1089): up to 4 layers x 16 channels on 32
+            # feature channels run the general HIP kernels (csrc/dynamic_head_generic.hip); beyond that the same arithmetic
+            # composed of PyTorch-ROCm ops (still on the GPU; autograd supplies the backward).
+            from .dynamic import dynamic_mask_forward_generic, generic_supported
+            if generic_supported(self.dynamic_convs, self.dynamic_channels, feat.size(1), self.disable_rel_coors):
+                return dynamic_mask_forward_generic(feat, params, coors, level_inds, img_inds, self.sizes_of_interest,
+                                                    self.dynamic_convs, self.dynamic_channels, in_stride=self.in_stride,
+                                                    out_stride=self.out_stride, disable_rel_coors=self.disable_rel_coors)
             return self._composed_forward(feat, params, coors, level_inds, img_inds)
         return dynamic_mask_forward(feat, params, coors, level_inds, img_inds, self.sizes_of_interest,
                                     in_stride=self.in_stride, out_stride=self.out_stride,

@@ -278,6 +278,23 @@ int bxi_dynamic_mask_backward_f32(const float* feat, int B, int C, int H, int W,
                                   int disable_rel_coors, const float* g_logits, float* g_feat, float* g_params,
                                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same head for EVERY shape the reference's constructor admits (condinst_head.py:1079-1089 leaves dynamic_convs, dynamic_channels
+ * and in_channels free; the entries above are tuned for the shipped 3 layers x 8 channels on 8 / 16 feature channels):
+ *   layers = dynamic_convs in 1..4, channels = dynamic_channels in 1..16, C + 2 (relative coordinates) <= 34, any factor.
+ * params [N,P] as parse_dynamic_params (:1120-1137) splits them: all weights layer by layer (rows = output channels:
+ *   [channels x (C+2)], [channels x channels] x (layers-2), [1 x channels]; layers == 1: [1 x (C+2)]), then all biases.
+ * Other limits return BXI_ERR_UNSUPPORTED.  Backward: g_feat and g_params fully overwritten, no atomics, run-to-run identical. */
+int bxi_dynamic_mask_generic_forward_f32(const float* feat, int B, int C, int H, int W, const float* params, int N, int layers, int channels,
+                                         const float* coors, const int64_t* level_inds, const int64_t* img_inds,
+                                         const float* sizes_of_interest, int n_levels, int in_stride, int factor,
+                                         int disable_rel_coors, float* logits, void* stream);
+size_t bxi_dynamic_mask_generic_backward_workspace_bytes(int B, int C, int H, int W, int N, int layers, int channels, int disable_rel_coors);
+int bxi_dynamic_mask_generic_backward_f32(const float* feat, int B, int C, int H, int W, const float* params, int N, int layers, int channels,
+                                          const float* coors, const int64_t* level_inds, const int64_t* img_inds,
+                                          const float* sizes_of_interest, int n_levels, int in_stride, int factor,
+                                          int disable_rel_coors, const float* g_logits, float* g_feat, float* g_params,
+                                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* ===========================================================================================
  * 5. DiscoBox pseudo-label path -- mmdet/models/dense_heads/discobox_head.py:
  *    MeanField.__init__ (:591-613), MeanField.forward / simple_forward (:617-655),

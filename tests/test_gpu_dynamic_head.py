@@ -156,10 +156,89 @@ def test_dynamic_head_fuzz(dev, seed):
     assert _close_except_kinks(p.grad.cpu().numpy(), pt.grad.numpy(), 1e-4, inst), cfg
 
 
+@pytest.mark.parametrize('convs,ch,cin,no_rel,fac,shape', [
+    (1, 8, 8, False, 2, (2, 12, 20, 5)),        # a single layer: [1 x (C + 2)]
+    (2, 4, 6, False, 2, (2, 12, 20, 4)),
+    (3, 8, 16, False, 2, (2, 23, 37, 9)),       # the shipped shape through the general kernels
+    (3, 5, 7, True, 1, (1, 9, 33, 3)),          # channels padded 5 -> 8, no relative coordinates, no up-sampling
+    (4, 16, 32, False, 4, (2, 10, 35, 6)),      # the largest built: 4 layers x 16 channels on 32 + 2 inputs
+    (4, 12, 3, False, 3, (3, 17, 40, 7)),       # odd factor, channels padded 12 -> 16
+    (2, 2, 1, True, 2, (1, 8, 32, 2)),
+])
+def test_general_dynamic_head_shapes_in_hip(dev, convs, ch, cin, no_rel, fac, shape):
+    """Every head shape the reference's constructor admits up to 4 layers x 16 channels (condinst_head.py:1079-1089) runs HIP
+    kernels (csrc/dynamic_head_generic.hip), forward and backward: checked against the fp64 CPU evaluation of the composition
+    that tests/test_host_cpu.py pins to the reference's grouped-convolution formulation, values and both gradients."""
+    from boxinstseg_amd import CondInstMaskHead
+    from boxinstseg_amd import dynamic as dyn
+    B, H, W, N = shape
+    rng = np.random.default_rng(convs * 1000 + ch * 10 + cin)
+    head = CondInstMaskHead(in_channels=cin, dynamic_convs=convs, dynamic_channels=ch, boxinst_enabled=True, disable_rel_coors=no_rel,
+                            in_stride=8, out_stride=8 // fac if 8 % fac == 0 else 8)
+    if 8 % fac:                                             # factor 3: strides 12 / 4
+        head.in_stride, head.out_stride = 4 * fac, 4
+    assert dyn.generic_supported(convs, ch, cin, no_rel)
+    feat = rng.standard_normal((B, cin, H, W))
+    params = rng.standard_normal((N, head.num_gen_params)) * 0.4
+    coors = rng.uniform(0, head.in_stride * W, size=(N, 2))
+    lvl = rng.integers(0, 5, size=N); img = rng.integers(0, B, size=N)
+    g = rng.standard_normal((N, 1, fac * H, fac * W))
+    f64 = lambda a: torch.from_numpy(np.asarray(a, np.float64))
+    ft, pt = f64(feat).requires_grad_(True), f64(params).requires_grad_(True)
+    cpu = head.double()
+    want = cpu._composed_forward(ft, pt, f64(coors), torch.from_numpy(lvl), torch.from_numpy(img))
+    want.backward(f64(g))
+    f32 = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(dev)
+    fd, pd = f32(feat).requires_grad_(True), f32(params).requires_grad_(True)
+    gpu_head = CondInstMaskHead(in_channels=cin, dynamic_convs=convs, dynamic_channels=ch, boxinst_enabled=True, disable_rel_coors=no_rel).to(dev)
+    gpu_head.in_stride, gpu_head.out_stride = head.in_stride, head.out_stride
+    if (convs, ch) == (3, 8) and cin in (8, 16):            # the module would take the tuned kernels: call the general entry
+        got = dyn.dynamic_mask_forward_generic(fd, pd, f32(coors), torch.from_numpy(lvl).to(dev), torch.from_numpy(img).to(dev),
+                                               gpu_head.sizes_of_interest, convs, ch, in_stride=head.in_stride, out_stride=head.out_stride,
+                                               disable_rel_coors=no_rel)
+    else:
+        got = gpu_head(fd, pd, f32(coors), torch.from_numpy(lvl).to(dev), torch.from_numpy(img).to(dev))
+    assert got.shape == want.shape
+    got.backward(f32(g))
+    cfg = f'{convs} x {ch} on {cin} rel{not no_rel} f{fac}'
+    assert _close(got.detach().cpu().numpy(), want.detach().numpy(), 3e-5), cfg
+    pix = np.broadcast_to(np.arange(B * H * W).reshape(B, 1, H, W), feat.shape)
+    inst = np.broadcast_to(np.arange(N)[:, None], params.shape)
+    assert _close_except_kinks(fd.grad.cpu().numpy(), ft.grad.numpy(), 1e-4, pix), cfg
+    assert _close_except_kinks(pd.grad.cpu().numpy(), pt.grad.numpy(), 1e-4, inst), cfg
+    # run-to-run identical (no atomics anywhere)
+    fd2, pd2 = f32(feat).requires_grad_(True), f32(params).requires_grad_(True)
+    again = dyn.dynamic_mask_forward_generic(fd2, pd2, f32(coors), torch.from_numpy(lvl).to(dev), torch.from_numpy(img).to(dev),
+                                             gpu_head.sizes_of_interest, convs, ch, in_stride=head.in_stride, out_stride=head.out_stride,
+                                             disable_rel_coors=no_rel)
+    again.backward(f32(g))
+    assert torch.equal(again, got) and torch.equal(fd2.grad, fd.grad) and torch.equal(pd2.grad, pd.grad)
+
+
+def test_general_dynamic_head_empty_and_limits(dev):
+    from boxinstseg_amd import CondInstMaskHead
+    from boxinstseg_amd import dynamic as dyn
+    assert not dyn.generic_supported(5, 8, 8, False) and not dyn.generic_supported(3, 17, 8, False) and not dyn.generic_supported(3, 8, 33, False)
+    head = CondInstMaskHead(in_channels=6, dynamic_convs=2, dynamic_channels=4, boxinst_enabled=True).to(dev)
+    feat = torch.randn(2, 6, 12, 20, device=dev, requires_grad=True)
+    params = torch.zeros(0, head.num_gen_params, device=dev, requires_grad=True)
+    out = head(feat, params, torch.zeros(0, 2, device=dev), torch.zeros(0, dtype=torch.long, device=dev), torch.zeros(0, dtype=torch.long, device=dev))
+    assert out.shape == (0, 1, 24, 40)
+    out.sum().backward()
+    assert float(feat.grad.abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match='params must be'):
+        head(feat, torch.zeros(3, head.num_gen_params + 1, device=dev), torch.zeros(3, 2, device=dev), torch.zeros(3, dtype=torch.long, device=dev),
+             torch.zeros(3, dtype=torch.long, device=dev))
+    big = CondInstMaskHead(in_channels=6, dynamic_convs=2, dynamic_channels=20, boxinst_enabled=True).to(dev)     # beyond the build: composed
+    p = torch.randn(2, big.num_gen_params, device=dev)
+    y = big(feat.detach(), p, torch.rand(2, 2, device=dev) * 50, torch.tensor([0, 1], device=dev), torch.tensor([0, 1], device=dev))
+    assert y.shape == (2, 1, 24, 40) and torch.isfinite(y).all()
+
+
 def test_dynamic_head_shapes_outside_the_hip_build_run_composed(dev):
-    """dynamic_convs / dynamic_channels other than 3 / 8 (free in the reference, condinst_head.py:1079-1089): same arithmetic
-    from PyTorch-ROCm ops on the GPU (checked against its own fp64 CPU evaluation; the composition itself is pinned on
-    the CPU, tests/test_host_cpu.py), differentiable, and the built shape gives the same logits through either path."""
+    """dynamic_convs / dynamic_channels other than 3 / 8 (free in the reference, condinst_head.py:1079-1089) through the module:
+    checked against the fp64 CPU evaluation of the composition (pinned on the CPU, tests/test_host_cpu.py), differentiable, and the
+    built shape gives the same logits through the tuned kernels and through the composition of PyTorch-ROCm ops."""
     from boxinstseg_amd import CondInstMaskHead
     torch.manual_seed(3)
     head = CondInstMaskHead(in_channels=6, dynamic_convs=2, dynamic_channels=4, boxinst_enabled=True).to(dev)
