@@ -52,7 +52,8 @@ constexpr int kMaxDilFused = 4;
 constexpr int kSpinLimit = 400000;              // bounded waits (~0.3 us per poll): far beyond any launch; running out is loud (NaN losses)
 // developer / test hook (bxi_debug_set_spin_limit): 0 = kSpinLimit; negative = every bounded wait gives up at once
 static std::atomic<int> g_spin_limit{0};
-// developer / test hook (bxi_debug_set_eval_form): 0 = the library chooses (single launch where it applies); 2 = always two launches
+// developer / test hook (bxi_debug_set_eval_form), bits: 0 = the library chooses; 1 = the single launch whenever it is built for the shape
+// (also where it does not pay); 2 = always two launches; 8 = 8-row tiles (two launches)
 static std::atomic<int> g_form{0};
 constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
 constexpr int kAcc1Words = 64;                  // count-wave arrivals + sum W: 64 words, each in its own 128 bytes
@@ -1485,7 +1486,10 @@ static int device_cus() {
 
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
-static int tile_rows_for(int N) { return N <= 96 ? 4 : 8; }
+// Rows per tile.  4 everywhere: with the round-3 pair kernel the shorter tile wins at every instance count measured (two launches,
+// 200 x 256 maps: 39.4 vs 47.7 us at 128 instances, 74.8 vs 101.5 at 256, 164 us at 512); 8-row tiles stay instantiated for
+// BXI_TILE_ROWS=8 / force_rows (tests).
+static int tile_rows_for(int N) { (void)N; return 4; }
 
 // (sim >= thresh) for a valid neighbour as a compare on the squared Lab distance: exp(-0.5 * sqrt(n2)) >= thresh  <=>  n2 <= n2max
 // (get_image_color_similarity :237 + the threshold of loss() :1324), n2max found by bisecting the f32 expression over the float
@@ -1579,6 +1583,8 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     static const int env_rows = env_int("BXI_TILE_ROWS", 0);            // developer knobs
     static const int env_pool_first = env_int("BXI_POOL_FIRST", 0);
     static const int env_pool_wgs = env_int("BXI_POOL_WGS_PER_CU", 5);
+    const int form = g_form.load(std::memory_order_relaxed);
+    if (!force_rows && (form & 8)) force_rows = 8;
     if (!force_rows) force_rows = env_rows;
     const int R = force_rows == 4 || force_rows == 8 ? force_rows : tile_rows_for(a.N);
     if (eval_cap(a.N, a.h, a.w, dil, R) >= (1 << 24)) return BXI_ERR_BAD_SHAPE;     // the table packs a tile prefix into 24 bits
@@ -1598,11 +1604,16 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
 
     // ---- the single-launch form ---------------------------------------------------------------------------------------
     static const int env_one = env_int("BXI_ONE_LAUNCH", 1);            // developer knob: 0 = always two launches
-    if (env_one && g_form.load(std::memory_order_relaxed) != 2 && !head && pooled_in_launch && R == 4 && dil <= 3 && !pr.zero_bit) {
+    // The single launch pays off while its front half (stream + pool workgroups) is resident at once: measured 24.8 vs 27.0 us at
+    // 64 instances, 35.1 vs 33.9 at 96, 45.1 vs 39.4 at 128 (200 x 256 maps) -- hence: stream workgroups <= half the slots.
+    const int one_slots = kOneOcc * device_cus();
+    const bool one_fits = 2 * (int64_t)a.N * ((a.h + kSBlk - 1) / kSBlk) <= one_slots;
+    if (env_one && !(form & 2) && (one_fits || env_one == 2 || (form & 1)) && !head && pooled_in_launch && R == 4 && dil <= 3 &&
+        !pr.zero_bit) {
         static const int env_one_pool = env_int("BXI_ONE_POOL_WGS", 0);
         const int Sn = (a.h + kSBlk - 1) / kSBlk;
         const int n_stream = a.N * Sn;
-        const int slots = kOneOcc * device_cus();
+        const int slots = one_slots;
         // the front half (table, stream, pool) should fill the GPU exactly once: a pool workgroup takes several items
         // (measured and dropped: pool workgroups alone filling the GPU first, predicate and stream workgroups behind them -- the
         // stream workgroups, and with them the band flags and the leaders, then end 8 us late: 22.9 us per evaluation against 18.3)
@@ -1689,10 +1700,12 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     // 4 (R = 4: <= 128 VGPRs) or 2 (R = 8) workgroups per CU; the predicate waves are short-lived.
     static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 0);
     const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? (dil <= 3 ? 4 : 3) : 2);
-    const int slots = occ * device_cus() - a.N - 1;
+    // (the leaders are short-lived and are not counted; with them subtracted, 512 instances at two workgroups per CU left ONE
+    // predicate workgroup for the whole image side: 4.4 ms per evaluation)
+    const int slots = occ * device_cus() > 256 ? occ * device_cus() : 256;
     int n_pb = (n_items + kWaves - 1) / kWaves;
-    if (n_pb > slots / 2) n_pb = slots / 2 > 1 ? slots / 2 : 1;
-    if (n_tb > slots - n_pb) n_tb = slots - n_pb > 64 ? slots - n_pb : 64;
+    if (n_pb > slots / 2) n_pb = slots / 2;
+    if (n_tb > slots - n_pb) n_tb = slots - n_pb;
     size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
     const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
     if (lds2 < lds_leader) lds2 = lds_leader;

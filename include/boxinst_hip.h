@@ -238,9 +238,11 @@ int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_insta
  * negative = every bounded wait gives up at once, which makes the failure path observable: NaN losses, status word, and a
  * gradient poisoned by bxi_boxinst_grad_rescale_f32.  Process-wide; not for production use. */
 void bxi_debug_set_spin_limit(int limit);
-/* Test hook: which form of the evaluation bxi_boxinst_eval_f32 launches.  0 = the library chooses (the single-launch form where it
- * applies: stride-4 aligned canvases, 4-row tiles (<= 96 instances), dilation <= 3, threshold > 0); 2 = always the two-launch form.
- * Same results either way (tests run both).  Process-wide; not for production use. */
+/* Test hook: which form of the evaluation bxi_boxinst_eval_f32 launches.  Bits: 0 = the library chooses (the single-launch form where
+ * it is built -- stride-4 aligned canvases, dilation <= 3, threshold > 0 -- and pays: its stream workgroups, instances x ceil(h / 32),
+ * fill at most half the GPU); 1 = the single-launch form wherever it is built; 2 = always the two-launch form; 8 = 8-row tiles
+ * (two launches; the default is 4-row tiles).  The single- and two-launch forms give the same bits (tests run both).  Process-wide;
+ * not for production use. */
 void bxi_debug_set_eval_form(int form);
 
 /* g_logits finished by bxi_boxinst_eval_f32 for the factors recorded in `state`  ->  finished for (g_prj, g_pw)

@@ -176,6 +176,11 @@ def test_box_bitmasks(dev):
 # ---------------------------------------------------------------------------------------------
 # fused loss
 # ---------------------------------------------------------------------------------------------
+def Fh_status_rows():
+    from boxinstseg_amd import functional as Fh
+    return Fh.last_eval_status()[1]
+
+
 def _check(d, dev, warmup=1.0, up=None, tol=TOL):
     g = (1.0, 1.0) if up is None else up
     ref = oracle_path(d, warmup=warmup, g_prj=g[0], g_pw=g[1], want_targets=False)
@@ -289,7 +294,7 @@ def test_single_launch_and_two_launch_forms_agree_bit_for_bit(dev):
     for d in cases:
         for dil in (1, 2, 3):
             res = []
-            for form in (0, 2):
+            for form in (1, 2):              # the single launch wherever it is built / always two launches
                 lib.bxi_debug_set_eval_form(form)
                 try:
                     res.append(hip_loss(d, dev, pairwise_dilation=dil))
@@ -456,6 +461,24 @@ def test_loss_many_instances(dev):
     d = synthetic.make_batch(B=3, H=64, W=96, boxes_per_img=5, inst_per_box=20, seed=21, min_box=12, max_box=60)
     assert d['N'] == 300
     _check_cfg(d, dev)
+
+
+@pytest.mark.parametrize('form', [1, 2, 10], ids=['single_launch', 'two_launches', 'two_launches_8_row_tiles'])
+def test_loss_every_form_against_the_oracle(dev, form):
+    """Each form of the evaluation (bxi_debug_set_eval_form) against the C oracle: the single launch also where the library would not
+    choose it (300 instances: the stream workgroups alone exceed the GPU), two launches, and the 8-row tiles no default takes."""
+    from boxinstseg_amd import _lib
+    lib = _lib.load()
+    lib.bxi_debug_set_eval_form(form)
+    try:
+        _check(synthetic.cfg1(4), dev)
+        _check_cfg(synthetic.make_batch(B=3, H=64, W=96, boxes_per_img=5, inst_per_box=20, seed=21, min_box=12, max_box=60), dev)
+        _check_cfg(synthetic.make_batch(B=2, H=96, W=160, boxes_per_img=3, seed=26, min_box=16, max_box=90), dev, pairwise_dilation=3)
+        _check_cfg(synthetic.make_batch(B=1, H=1088, W=1344, boxes_per_img=3, seed=22, min_box=200, max_box=900), dev)
+        rows = Fh_status_rows()
+        assert rows == (8 if form & 8 else 4)
+    finally:
+        lib.bxi_debug_set_eval_form(0)
 
 
 def test_loss_tall_and_wide_map(dev):
