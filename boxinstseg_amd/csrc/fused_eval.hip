@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair_ker
 }
 
 // ---- the single-launch form ---------------------------------------------------------------------------------------------------
-// All roles in ONE grid, in this order:  [stream blocks (their first waves write the table)][pool blocks][N leaders][predicate blocks][tile blocks][finisher].
+// All roles in ONE grid, in this order:  [stream blocks (their first waves write the table)][pool blocks][predicate blocks][N leaders][tile blocks][finisher].
 // Workgroups are dispatched in grid order and every wait is for a workgroup EARLIER in the grid:
 //   table, stream, pool   wait for nobody;
 //   leader n              for the table entry n and the band flags of instance n (stream blocks);
@@ -1361,7 +1361,7 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair_ker
 template <int D>
 __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_pool, int n_items, int n_pb, int n_tb, InstArgs a, Ws ws, LossState st, ValidCells vc,
                                                         const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup, float n2max, int spin_limit,
-                                                        float* __restrict__ losses, float* __restrict__ g_logits, int vec) {
+                                                        float* __restrict__ losses, float* __restrict__ g_logits, int vec, int merge) {
     constexpr int R = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[16];
@@ -1374,9 +1374,9 @@ __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_
     int role, idx = blk;
     if (idx < n_stream) role = 0;
     else if ((idx -= n_stream) < n_pool) role = 1;
-    else if ((idx -= n_pool) < N) role = 2;
-    else if ((idx -= N) < n_pb) role = 3;
-    else if ((idx -= n_pb) < n_tb) role = 4;
+    else if ((idx -= n_pool) < n_pb) role = 3;
+    else if ((idx -= n_pb) < N) role = 2;
+    else if ((idx -= N) < n_tb) role = 4;
     else role = 5;
     const int tix = (n_tab + (role == 0 ? idx : n_stream + idx)) * kWaves + (int)(threadIdx.x >> 6);
     (void)tix;
@@ -1388,7 +1388,15 @@ __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_
         const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
         stream_block<true>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);
         BXI_TW(0, tix, 7);
-        return;
+        if (!merge) return;
+        // ... and stays as a tile workgroup: its four waves are the first tile waves, resident since the start of the launch, so their
+        // table -> tile -> logits -> per-pixel chain runs while the pool workgroups finish instead of behind a slot that has to come
+        // free first.  (It now waits for predicate workgroups LATER in the grid.  Those wait only for pool workgroups, which wait for
+        // nobody, and the host launches this form only while the stream workgroups leave at least half of the slots free: a
+        // predicate workgroup always finds a slot.)
+        __syncthreads();                                                   // the column-partial LDS becomes the tile waves' scratch
+        role = 4;
+        idx -= n_stream;                                                   // tile workgroup index idx + n_stream below
     }
     if (role == 1) {
         BXI_TW(0, tix, 0);
@@ -1406,7 +1414,11 @@ __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_
         return;
     }
     if (role == 3) { pred_role<D, true>(a, vc, ws, n2max, idx, n_pb, n_items, spin_limit); return; }
-    if (role == 4) { tile_role<D, R, true>(a, vc, ws, upw * warmup, n2max, 0, n_items, spin_limit, g_logits, smem, idx, n_tb); return; }
+    if (role == 4) {          // ONE call site for the stream workgroups that stay on and for the tile workgroups proper
+        const int shift = merge ? n_stream : 0;
+        tile_role<D, R, true>(a, vc, ws, upw * warmup, n2max, 0, n_items, spin_limit, g_logits, smem, idx + shift, n_tb + shift);
+        return;
+    }
     finisher_role<true>(a, ws, st, upp, upw, warmup, 0, n_items, spin_limit, R, losses);
 }
 
@@ -1627,16 +1639,20 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         if (n_pb > slots / 2) n_pb = slots / 2;
         int64_t n_tb = (eval_cap(a.N, a.h, a.w, dil, R) + kWaves - 1) / kWaves;
         if (n_tb > slots / 2) n_tb = slots / 2;
+        // the stream workgroups stay on as the first tile workgroups (only while they leave half of the slots to the rest of the grid)
+        static const int env_merge = env_int("BXI_ONE_MERGE", 1);
+        const int merge = env_merge && one_fits ? 1 : 0;
+        if (merge) n_tb = n_tb > n_stream ? n_tb - n_stream : 0;
         size_t lds = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
         if (lds < 8 * (size_t)kWaves * a.w) lds = 8 * (size_t)kWaves * a.w;
         if (lds < sizeof(float) * (size_t)kWaves * (R + 1) * 64) lds = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
         if (lds < 2 * sizeof(float) * (size_t)(a.h + a.w) + 16) lds = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
         if (lds <= 36 * 1024) {                             // four workgroups per CU must fit
-            const unsigned grid = (unsigned)(n_stream + n_pool + a.N + n_pb + (int)n_tb + 1);
+            const unsigned grid = (unsigned)(n_stream + n_pool + n_pb + a.N + (int)n_tb + 1);
 #define BXI_ONE_CASE(DD)                                                                                                                    \
             case DD:                                                                                                                        \
                 BXI_LAUNCH("eval1", s, (eval1_kernel<DD>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, up_prj, \
-                           up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec);                                                    \
+                           up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge);                                             \
                 break;
             switch (dil) { BXI_ONE_CASE(1) BXI_ONE_CASE(2) BXI_ONE_CASE(3) default: return BXI_ERR_UNSUPPORTED; }
 #undef BXI_ONE_CASE
