@@ -3,8 +3,9 @@
 
 Metric (BASELINE.json): pairwise+projection loss fwd+bwd images/sec @ 2x800x1024 x 32 instances.
 One *step* = one loss evaluation on a 2-image batch, through the C ABI of libboxinst_hip.so:
-  bxi_boxinst_eval_f32   prep (image pool + Lab || logit streaming || table)  ->  pair (colour predicates + pair-weight sum per image,
-                         projection leaders, pairwise term on the box tiles, both loss scalars, FINISHED gradient)
+  bxi_boxinst_eval_f32   ONE launch (eval1) at this size: front half (image pool + Lab || logit streaming || table) -> back half (colour
+                         predicates + pair-weight sum per image, projection leaders, pairwise term on the box tiles, both loss scalars,
+                         FINISHED gradient); other shapes: the same roles as two launches (prep, pair).  `config.kernels_per_step` says which
 i.e. everything CondInstMaskHead.loss + .backward() do for mask_logits, from the normalised images, boxes and logits
 already resident in HBM to loss_prj, loss_pairwise and d(loss_prj + loss_pairwise)/d(mask_logits); the two upstream
 factors are read from device memory inside the kernels (ones here, as `loss.backward()` seeds them).

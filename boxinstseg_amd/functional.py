@@ -305,7 +305,7 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 class BoxInstMaskLoss(torch.autograd.Function):
     """(loss_prj, loss_pairwise) = f(mask_logits); forward AND backward in ONE pass over the logits.
 
-    forward  : bxi_boxinst_eval_f32 (two launches) writes both scalars and the FINISHED gradient for unit upstream
+    forward  : bxi_boxinst_eval_f32 (one launch at the shipped shapes, otherwise two) writes both scalars and the FINISHED gradient for unit upstream
                factors -- what ``loss.backward()`` seeds the two terms with.
                (Precomputed affinity bits: bxi_boxinst_loss_fwd_bwd_f32 + bxi_boxinst_loss_backward_f32.)
     backward : bxi_boxinst_grad_rescale_f32 -- reads the two upstream scalars from device memory (no host sync) and returns
