@@ -15,6 +15,7 @@
 // Workgroup barriers order the global traffic: a workgroup runs on one CU, whose vector L1 is write-through, and every
 // array here is private to the workgroup.
 #include "common.hpp"
+#include <atomic>
 
 namespace bxi {
 
@@ -262,15 +263,32 @@ struct RefineArgsL {
     char* ws; size_t ws_stride;
 };
 constexpr int kPadL = 4;
-static size_t refine_large_block_bytes(int V) { return up16(16 * (size_t)(V + kPadL)) + up16(4 * (size_t)V) + up16(16 * (size_t)(V + kPadL)); }
+constexpr int kWinL = 4096;            // records per LDS window of the leaf->root walk (64 KB + 16 KB of level offsets); a power of two: slot = i & (kWinL - 1)
+static size_t refine_large_block_bytes(int V) { return up16(16 * (size_t)(V + kPadL)) + up16(4 * (size_t)V) + up16(16 * (size_t)(V + kPadL)) + 16; }
 size_t refine_large_ws_bytes(int B, int C, int V) { return refine_large_block_bytes(V) * (size_t)(B > 0 ? B : 1) * (size_t)C; }
 
-__global__ __launch_bounds__(kLT) void tree_refine_large_kernel(RefineArgsL a) {
-    const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, V = a.V;
+// per (graph, channel) block of the workspace: records, parents, the second buffer of the jump rounds, one flag word
+struct RefineBlkL { float4* rec; uint32_t* parent; float4* tmp; int* bad; };
+__device__ __forceinline__ RefineBlkL refine_blk(const RefineArgsL& a, int b, int ch) {
     char* wsb = a.ws + ((size_t)b * a.C + ch) * a.ws_stride;
-    float4* rec = reinterpret_cast<float4*>(wsb);
-    uint32_t* parent = reinterpret_cast<uint32_t*>(wsb + up16(16 * (size_t)(V + kPadL)));
-    float4* tmp = reinterpret_cast<float4*>(wsb + up16(16 * (size_t)(V + kPadL)) + up16(4 * (size_t)V));   // double buffer of the jump rounds
+    RefineBlkL r;
+    r.rec = reinterpret_cast<float4*>(wsb);
+    r.parent = reinterpret_cast<uint32_t*>(wsb + up16(16 * (size_t)(a.V + kPadL)));
+    r.tmp = reinterpret_cast<float4*>(wsb + up16(16 * (size_t)(a.V + kPadL)) + up16(4 * (size_t)a.V));
+    r.bad = reinterpret_cast<int*>(wsb + up16(16 * (size_t)(a.V + kPadL)) + up16(4 * (size_t)a.V) + up16(16 * (size_t)(a.V + kPadL)));
+    return r;
+}
+
+// The refinement of a large tree is five kinds of passes.  Four of them touch every node independently -- staging, the preparation of
+// the affine maps, the pointer-jumping rounds, the outputs -- and run ACROSS THE GPU (grid over the nodes x graph x channel; as one
+// 1024-thread workgroup per (graph, channel) each pass over 60 800 nodes cost ~60 us, fifteen of them most of a 1.3 ms launch); only
+// the leaf->root walk is a chain through the tree's depth and stays one workgroup per (graph, channel).
+
+// ---- pass 1: stage the records (sorted order), the parents, and check that the ordering is bxi_bfs_forward_i32's ----------------------
+__global__ __launch_bounds__(256) void refineL_stage_kernel(RefineArgsL a) {
+    const int b = blockIdx.y, ch = blockIdx.z, V = a.V;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const RefineBlkL w = refine_blk(a, b, ch);
     const int* lv = a.levels + (int64_t)b * (V + 2);
     const int* si = a.sorted_index + (int64_t)b * V;
     const int* sc = a.sorted_child + (int64_t)b * V * a.max_adj;
@@ -278,93 +296,177 @@ __global__ __launch_bounds__(kLT) void tree_refine_large_kernel(RefineArgsL a) {
     const int64_t cb = ((int64_t)b * a.C + ch) * V;
     const RefinePlaneL pl0 = a.pl[0], pl1 = a.pl[1];
     const bool two = a.n_planes > 1;
-    int bad = lv[0] < 0 ? 1 : 0;                                     // bxi_bfs_forward_i32 found the input not to be a connected grid tree
-    for (int i = tid; i < V + kPadL; i += kLT) {
-        if (i >= V) { rec[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
-        const int p = si[i];
-        float v0 = pl0.in ? pl0.in[cb + p] : 1.f;
-        if (pl0.in && pl0.pre_div) v0 /= pl0.pre_div[(int64_t)b * V + p];
-        if (pl0.in && pl0.pre_mul) v0 *= pl0.pre_mul[cb + p];
-        float v1 = (two && pl1.in) ? pl1.in[cb + p] : (two ? 1.f : 0.f);
-        if (two && pl1.in && pl1.pre_div) v1 /= pl1.pre_div[(int64_t)b * V + p];
-        if (two && pl1.in && pl1.pre_mul) v1 *= pl1.pre_mul[cb + p];
-        int c0 = 0, nc = 0;
-        bool open = true;                                            // children = the leading positive slots
-        for (int k = 0; k < 4; ++k) {
-            const int c = sc[(size_t)i * a.max_adj + min(k, a.max_adj - 1)];
-            open = open && k < a.max_adj && c > 0;
-            if (open) {
-                if (nc == 0) c0 = c; else if (c != c0 + nc) bad = 1;  // children must be contiguous (bxi_bfs_forward_i32 order)
-                ++nc;
+    if (i >= V + kPadL) return;
+    if (i >= V) { w.rec[i] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    int bad = (i == 0 && lv[0] < 0) ? 1 : 0;                         // bxi_bfs_forward_i32 found the input not to be a connected grid tree
+    const int p = si[i];
+    float v0 = pl0.in ? pl0.in[cb + p] : 1.f;
+    if (pl0.in && pl0.pre_div) v0 /= pl0.pre_div[(int64_t)b * V + p];
+    if (pl0.in && pl0.pre_mul) v0 *= pl0.pre_mul[cb + p];
+    float v1 = (two && pl1.in) ? pl1.in[cb + p] : (two ? 1.f : 0.f);
+    if (two && pl1.in && pl1.pre_div) v1 /= pl1.pre_div[(int64_t)b * V + p];
+    if (two && pl1.in && pl1.pre_mul) v1 *= pl1.pre_mul[cb + p];
+    int c0 = 0, nc = 0;
+    bool open = true;                                                // children = the leading positive slots
+    for (int k = 0; k < 4; ++k) {
+        const int c = sc[(size_t)i * a.max_adj + min(k, a.max_adj - 1)];
+        open = open && k < a.max_adj && c > 0;
+        if (open) {
+            if (nc == 0) c0 = c; else if (c != c0 + nc) bad = 1;      // children must be contiguous (bxi_bfs_forward_i32 order)
+            ++nc;
+        }
+    }
+    if (a.max_adj > 4 && sc[(size_t)i * a.max_adj + 4] > 0) bad = 1;
+    if (c0 + nc > V) { bad = 1; nc = 0; }
+    w.rec[i] = make_float4(v0, v1, i ? ew[i] : 0.f /* weight[0] = 0 (refine.cu:38) */, __uint_as_float((uint32_t)c0 | ((uint32_t)nc << 28)));
+    for (int k = 0; k < nc; ++k) w.parent[c0 + k] = (uint32_t)i;     // one writer per child
+    if (i == 0) w.parent[0] = 0u;
+    if (bad) atomicOr(w.bad, 1);                                      // (zeroed by launch_refine_large)
+}
+
+// ---- pass 2: leaf->root, U_i = x_i + sum_c w_c U_c (refine.cu:64-121): one workgroup per (graph, channel) ------------------------------
+// The trees of a 200 x 304 map are ~1500 levels deep and ~40 nodes wide: level by level out of global memory every level costs a
+// workgroup barrier and two dependent global round trips (~0.9 us).  Instead the node array is walked in WINDOWS of kWinL records
+// held in LDS: the nodes of a level and their children (the next level) are neighbours in BFS order, so a window holds a run of
+// consecutive levels; the workgroup loads it (coalesced), ONE wave walks its levels with no barrier and no global read in between
+// (its LDS operations execute in order: tree_filter.hip's tree_up), writing every finished record through to global memory.  A level
+// pair wider than the window falls back to the level-by-level form.
+__global__ __launch_bounds__(kLT) void refineL_up_kernel(RefineArgsL a) {
+    const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, V = a.V;
+    const RefineBlkL w = refine_blk(a, b, ch);
+    float4* rec = w.rec;
+    const int* lv = a.levels + (int64_t)b * (V + 2);
+    if (tid == 0 && *w.bad) {                                        // a foreign ordering fails loudly in the values
+        float4 r = rec[0]; r.x *= __builtin_nanf(""); r.y *= __builtin_nanf(""); rec[0] = r;
+    }
+    __syncthreads();
+    const int D = max(lv[0], 0);
+    extern __shared__ __attribute__((aligned(16))) unsigned char win_raw[];
+    float4* win = reinterpret_cast<float4*>(win_raw);                           // [kWinL] record i lives in slot i % kWinL
+    int* wlv = reinterpret_cast<int*>(win_raw + sizeof(float4) * kWinL);        // [kWinL + 2] level offsets of the window's levels
+    __shared__ int w_llo;
+    for (int cur = D - 1; cur >= 0;) {
+        // the window ends behind the children of level `cur` and starts at the lowest level whose first node still fits
+        const int whi = cur + 1 <= D - 1 ? lv[3 + cur] : lv[2 + cur];
+        const int bound = whi - kWinL;
+        if (tid < 64) {                                                          // 64-ary search for the smallest level l <= cur with lv[1 + l] >= bound
+            int a_ = 0, b_ = cur;
+            while (b_ > a_) {
+                const int step = (b_ - a_ + 63) / 64;
+                const int l = min(a_ + tid * step, b_);
+                const unsigned long long m = __ballot(lv[1 + l] >= bound);
+                const int k = m ? __ffsll((long long)m) - 1 : 63;
+                const int nb = min(a_ + k * step, b_);
+                a_ = k ? min(a_ + (k - 1) * step + 1, nb) : a_;
+                b_ = nb;
+            }
+            if (tid == 0) w_llo = lv[1 + cur] >= bound ? b_ : cur + 1;         // cur + 1: not even level `cur` and its children fit
+        }
+        __syncthreads();
+        const int llo = w_llo;
+        if (llo > cur) {                                                         // workgroup-uniform fallback: this level straight from global memory
+            const int lo = lv[1 + cur], hi = lv[2 + cur];
+            for (int i = lo + tid; i < hi; i += kLT) {
+                float4 r = rec[i];
+                const uint32_t f = __float_as_uint(r.w);
+                const int c0 = f & 0x0fffffffu, nc = f >> 28;
+                for (int k = 0; k < nc; ++k) { const float4 c = rec[c0 + k]; r.x += c.x * c.z; r.y += c.y * c.z; }
+                rec[i] = r;
+            }
+            __syncthreads();
+            --cur;
+            continue;
+        }
+        const int wlo = lv[1 + llo];
+        for (int i = wlo + tid; i < whi; i += kLT) win[i & (kWinL - 1)] = rec[i];      // levels > cur are final in global memory
+        for (int l = llo + tid; l <= cur + 1; l += kLT) wlv[l - llo] = lv[1 + l];
+        __syncthreads();
+        if (tid < 64) {
+            const int lane = tid;
+            for (int l = cur; l >= llo; --l) {
+                const int lo = wlv[l - llo], hi = wlv[l - llo + 1];
+                for (int i = lo + lane; i < hi; i += 64) {
+                    float4 r = win[i & (kWinL - 1)];
+                    const uint32_t f = __float_as_uint(r.w);
+                    const int c0 = f & 0x0fffffffu, nc = f >> 28;
+                    float4 chd[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) chd[k] = win[(c0 + k) & (kWinL - 1)];  // unconditional: one LDS round trip per level
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(chd[k].x), "+v"(chd[k].y), "+v"(chd[k].z));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        r.x = k < nc ? r.x + chd[k].x * chd[k].z : r.x;
+                        r.y = k < nc ? r.y + chd[k].y * chd[k].z : r.y;
+                    }
+                    win[i & (kWinL - 1)] = r;
+                    rec[i] = r;                                                  // written through; nobody reads it before the next barrier
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the level's LDS writes before the next level's reads (one wave: in order)
             }
         }
-        if (a.max_adj > 4 && sc[(size_t)i * a.max_adj + 4] > 0) bad = 1;
-        if (c0 + nc > V) { bad = 1; nc = 0; }
-        rec[i] = make_float4(v0, v1, i ? ew[i] : 0.f /* weight[0] = 0 (refine.cu:38) */, __uint_as_float((uint32_t)c0 | ((uint32_t)nc << 28)));
-        if (i == 0) parent[0] = 0u;
-    }
-    const float poison = __syncthreads_or(bad) ? __builtin_nanf("") : 1.f;   // a foreign ordering fails loudly in the values
-    for (int i = tid; i < V; i += kLT) {
-        const uint32_t f = __float_as_uint(rec[i].w);
-        const int c0 = f & 0x0fffffffu, nc = f >> 28;
-        for (int k = 0; k < nc; ++k) parent[c0 + k] = (uint32_t)i;           // one writer per child
-    }
-    if (tid == 0) { float4 r = rec[0]; r.x *= poison; r.y *= poison; rec[0] = r; }
-    __syncthreads();
-    // ---- leaf->root, level by level: U_i = x_i + sum_c w_c U_c (refine.cu:64-121) ------------------------------------------
-    const int D = lv[0];
-    for (int l = D - 1; l >= 0; --l) {
-        const int lo = lv[1 + l], hi = lv[2 + l];
-        for (int i = lo + tid; i < hi; i += kLT) {
-            float4 r = rec[i];
-            const uint32_t f = __float_as_uint(r.w);
-            const int c0 = f & 0x0fffffffu, nc = f >> 28;
-            for (int k = 0; k < nc; ++k) { const float4 c = rec[c0 + k]; r.x += c.x * c.z; r.y += c.y * c.z; }
-            rec[i] = r;
-        }
         __syncthreads();
+        cur = llo - 1;
     }
-    for (int q = 0; q < 2; ++q) {                                     // U of both planes (sorted order)
-        const RefinePlaneL& pl = q ? pl1 : pl0;
+}
+
+// ---- pass 3: U of both planes out (sorted order), and the affine maps D_c = A_c + B_c D_anc(c), A = U (1 - w^2), B = w (refine.cu:17-62) ----
+__global__ __launch_bounds__(256) void refineL_prep_kernel(RefineArgsL a) {
+    const int b = blockIdx.y, ch = blockIdx.z, V = a.V;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= V) return;
+    const RefineBlkL w = refine_blk(a, b, ch);
+    const int64_t cb = ((int64_t)b * a.C + ch) * V;
+    const float4 r = w.rec[i];
+    for (int q = 0; q < 2; ++q) {
+        const RefinePlaneL& pl = q ? a.pl[1] : a.pl[0];
         const bool per_tree = pl.in == nullptr;
         if (q >= a.n_planes || !pl.up_sorted || (per_tree && ch != 0)) continue;
-        float* uo = pl.up_sorted + (per_tree ? (int64_t)b * V : cb);
-        for (int i = tid; i < V; i += kLT) { const float4 r = rec[i]; uo[i] = q ? r.y : r.x; }
+        pl.up_sorted[(per_tree ? (int64_t)b * V : cb) + i] = q ? r.y : r.x;
     }
-    // ---- root->leaf by pointer jumping over affine maps: D_c = A_c + B_c D_anc(c), A = U (1 - w^2), B = w (refine.cu:17-62) ----
-    for (int i = tid; i < V; i += kLT) {
-        const float4 r = rec[i];
-        const float w = r.z, aa = 1.f - w * w;
-        rec[i] = i ? make_float4(r.x * aa, r.y * aa, w, __uint_as_float(parent[i])) : make_float4(r.x, r.y, 0.f, __uint_as_float(0xffffffffu));
+    const float wt = r.z, aa = 1.f - wt * wt;
+    w.rec[i] = i ? make_float4(r.x * aa, r.y * aa, wt, __uint_as_float(w.parent[i])) : make_float4(r.x, r.y, 0.f, __uint_as_float(0xffffffffu));
+}
+
+// ---- pass 4 (x ceil(log2 V)): one pointer-jumping round, src -> dst (a resolved node is copied) -----------------------------------------
+__global__ __launch_bounds__(256) void refineL_jump_kernel(RefineArgsL a, int flip) {
+    const int b = blockIdx.y, ch = blockIdx.z, V = a.V;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= V) return;
+    const RefineBlkL w = refine_blk(a, b, ch);
+    const float4* src = flip ? w.tmp : w.rec;
+    float4* dst = flip ? w.rec : w.tmp;
+    const float4 r = src[i];
+    const uint32_t an = __float_as_uint(r.w);
+    if (an == 0xffffffffu) { dst[i] = r; return; }
+    const float4 q = src[an];
+    dst[i] = make_float4(r.x + r.z * q.x, r.y + r.z * q.y, r.z * q.z, q.w);
+}
+
+// ---- pass 5: outputs ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void refineL_out_kernel(RefineArgsL a, int flip) {
+    const int b = blockIdx.y, ch = blockIdx.z, V = a.V;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= V) return;
+    const RefineBlkL w = refine_blk(a, b, ch);
+    const int64_t cb = ((int64_t)b * a.C + ch) * V;
+    const float4 d = (flip ? w.tmp : w.rec)[i];
+    const int p = a.sorted_index[(int64_t)b * V + i];
+    for (int q = 0; q < 2; ++q) {
+        const RefinePlaneL& pl = q ? a.pl[1] : a.pl[0];
+        if (q >= a.n_planes) continue;
+        const bool per_tree = pl.in == nullptr;
+        if (per_tree && ch != 0) continue;
+        const int64_t ob = per_tree ? (int64_t)b * V : cb;
+        if (pl.down_sorted) pl.down_sorted[ob + i] = q ? d.y : d.x;
+        if (pl.down_vertex) pl.down_vertex[ob + p] = q ? d.y : d.x;
     }
-    __syncthreads();
-    const int rounds = D > 1 ? 32 - __clz(D - 1) : 0;
-    float4* src = rec; float4* dst = tmp;
-    for (int k = 0; k < rounds; ++k) {
-        for (int i = tid; i < V; i += kLT) {
-            const float4 r = src[i];
-            const uint32_t an = __float_as_uint(r.w);
-            if (an == 0xffffffffu) { dst[i] = r; continue; }
-            const float4 q = src[an];
-            dst[i] = make_float4(r.x + r.z * q.x, r.y + r.z * q.y, r.z * q.z, q.w);
-        }
-        __syncthreads();
-        float4* t = src; src = dst; dst = t;
-    }
-    for (int i = tid; i < V; i += kLT) {
-        const float4 d = src[i];
-        const int p = si[i];
-        for (int q = 0; q < 2; ++q) {
-            const RefinePlaneL& pl = q ? pl1 : pl0;
-            if (q >= a.n_planes) continue;
-            const bool per_tree = pl.in == nullptr;
-            if (per_tree && ch != 0) continue;
-            const int64_t ob = per_tree ? (int64_t)b * V : cb;
-            if (pl.down_sorted) pl.down_sorted[ob + i] = q ? d.y : d.x;
-            if (pl.down_vertex) pl.down_vertex[ob + p] = q ? d.y : d.x;
-        }
-        if (a.out_vertex) a.out_vertex[cb + p] = d.y / d.x;
-    }
+    if (a.out_vertex) a.out_vertex[cb + p] = d.y / d.x;
+}
+
+__global__ void refineL_clear_kernel(RefineArgsL a) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < a.B * a.C) *refine_blk(a, i / a.C, i % a.C).bad = 0;
 }
 
 int launch_refine_large(const void* planes2 /* RefinePlaneL[2] layout */, const float* edge_weight, const int* sorted_index,
@@ -376,7 +478,26 @@ int launch_refine_large(const void* planes2 /* RefinePlaneL[2] layout */, const 
     a.edge_weight = edge_weight; a.sorted_index = sorted_index; a.sorted_child = sorted_child; a.levels = levels;
     a.out_vertex = out_vertex; a.B = B; a.C = C; a.V = V; a.max_adj = max_adj; a.n_planes = n_planes;
     a.ws = ws; a.ws_stride = refine_large_block_bytes(V);
-    BXI_LAUNCH("tree_refine_large", s, tree_refine_large_kernel, dim3(B, C), dim3(kLT), 0, s, a);
+    if (B > 65535 || C > 65535) return BXI_ERR_BAD_SHAPE;
+    const dim3 over_nodes((unsigned)((V + kPadL + 255) / 256), (unsigned)B, (unsigned)C);
+    BXI_LAUNCH("tree_refine_large_clear", s, refineL_clear_kernel, dim3((unsigned)((B * C + 63) / 64)), dim3(64), 0, s, a);
+    BXI_LAUNCH("tree_refine_large_stage", s, refineL_stage_kernel, over_nodes, dim3(256), 0, s, a);
+    {
+        const size_t lds = sizeof(float4) * kWinL + sizeof(int) * (kWinL + 2);
+        static std::atomic<int> attr_set{0};
+        if (!attr_set.load(std::memory_order_relaxed)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(refineL_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }
+            attr_set.store(1, std::memory_order_relaxed);
+        }
+        BXI_LAUNCH("tree_refine_large_up", s, refineL_up_kernel, dim3(B, C), dim3(kLT), lds, s, a);
+    }
+    BXI_LAUNCH("tree_refine_large_prep", s, refineL_prep_kernel, over_nodes, dim3(256), 0, s, a);
+    // the depth of the tree is device data: ceil(log2 V) rounds resolve any depth <= V (a resolved node is only copied)
+    int rounds = 0;
+    while ((1 << rounds) < V) ++rounds;
+    for (int k = 0; k < rounds; ++k) BXI_LAUNCH("tree_refine_large_jump", s, refineL_jump_kernel, over_nodes, dim3(256), 0, s, a, k & 1);
+    BXI_LAUNCH("tree_refine_large_out", s, refineL_out_kernel, over_nodes, dim3(256), 0, s, a, rounds & 1);
     return check_launch();
 }
 
