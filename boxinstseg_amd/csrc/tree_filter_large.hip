@@ -25,84 +25,104 @@ constexpr int kLT = 1024;
 __host__ __device__ static inline size_t up16(size_t v) { return (v + 15) / 16 * 16; }
 
 // ---------------------------------------------------------------------------------------------------
-struct MstLargeWs { u64* best; uint32_t* comp; uint32_t* link; uint32_t* chosen; };
+struct MstLargeWs { u64* best; uint32_t* comp; uint32_t* link; uint32_t* chosen; uint32_t* link2; };
 __host__ __device__ static size_t carve_mst_large(char* base, int E, int V, MstLargeWs* w) {
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += up16(b); return base ? base + o : nullptr; };
     MstLargeWs t;
     t.best = (u64*)take(8 * (size_t)V); t.comp = (uint32_t*)take(4 * (size_t)V); t.link = (uint32_t*)take(4 * (size_t)V);
     t.chosen = (uint32_t*)take(4 * (size_t)((E + 31) / 32));
+    t.link2 = (uint32_t*)take(4 * (size_t)V);
     if (w) *w = t;
     return off;
 }
 size_t mst_large_ws_bytes(int E, int V) { return carve_mst_large(nullptr, E, V, nullptr); }
 
-__global__ __launch_bounds__(kLT) void mst_large_kernel(const int* __restrict__ edge_index, const float* __restrict__ edge_weight, int E,
-                                                        int V, int* __restrict__ edge_out, int* __restrict__ n_out, char* ws_base,
-                                                        size_t ws_stride) {
-    __shared__ int flag, scan[17];
-    const int b = blockIdx.x, tid = threadIdx.x;
+// Boruvka ACROSS THE GPU: every phase of a round is a grid over the edges / vertices of all graphs, a kernel boundary between
+// phases is the grid barrier (one 1024-thread workgroup per graph took 2.5 ms at 60 800 vertices / 121 000 edges: 16 rounds of
+// ~120 edges per thread, each with two dependent atomics).  The number of rounds and of pointer-jumping steps is fixed on the host
+// (the component count at least halves per round: round r has at most V / 2^r components, so its hook chains need at most
+// ceil(log2 V) - r jumps); rounds after the tree is complete find no edge and change nothing.
+__device__ __forceinline__ MstLargeWs mst_ws(char* ws_base, size_t ws_stride, int b, int E, int V) {
     MstLargeWs w;
     carve_mst_large(ws_base + (size_t)b * ws_stride, E, V, &w);
-    u64* best = w.best; uint32_t* comp = w.comp; uint32_t* link = w.link; uint32_t* chosen = w.chosen;
+    return w;
+}
+__global__ __launch_bounds__(256) void mstL_init_kernel(int E, int V, char* ws_base, size_t ws_stride) {
+    const MstLargeWs w = mst_ws(ws_base, ws_stride, blockIdx.y, E, V);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < V) { w.comp[i] = (uint32_t)i; w.best[i] = ~0ull; }
+    if (i < (E + 31) / 32) w.chosen[i] = 0u;
+}
+// every edge between two components offers (weight bits, edge index) to both (64-bit atomic min at the memory side)
+__global__ __launch_bounds__(256) void mstL_offer_kernel(const int* __restrict__ edge_index, const float* __restrict__ edge_weight, int E, int V,
+                                                         char* ws_base, size_t ws_stride) {
+    const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const MstLargeWs w = mst_ws(ws_base, ws_stride, b, E, V);
     const int* idx = edge_index + (int64_t)b * E * 2;
-    const float* wt = edge_weight + (int64_t)b * E;
-    const int nwords = (E + 31) / 32;
-    for (int v = tid; v < V; v += kLT) comp[v] = (uint32_t)v;
-    for (int i = tid; i < nwords; i += kLT) chosen[i] = 0u;
-    __syncthreads();
-    for (int round = 0; round < 40; ++round) {
-        for (int v = tid; v < V; v += kLT) best[v] = ~0ull;
-        if (tid == 0) flag = 0;
-        __syncthreads();
-        for (int e = tid; e < E; e += kLT) {
-            const uint32_t cu = comp[idx[2 * e]], cv = comp[idx[2 * e + 1]];
-            if (cu != cv) {
-                const u64 key = ((u64)__float_as_uint(wt[e]) << 32) | (uint32_t)e;   // weights are >= 0: the bits order like the values
-                atomicMin(&best[cu], key);
-                atomicMin(&best[cv], key);
-            }
-        }
-        __syncthreads();
-        for (int c = tid; c < V; c += kLT) {
-            if (comp[c] != (uint32_t)c) continue;
-            const u64 k = best[c];
-            uint32_t to = (uint32_t)c;
-            if (k != ~0ull) {
-                const uint32_t e = (uint32_t)k;
-                atomicOr(&chosen[e >> 5], 1u << (e & 31));
-                const uint32_t cu = comp[idx[2 * e]], cv = comp[idx[2 * e + 1]];
-                to = cu == (uint32_t)c ? cv : cu;
-                flag = 1;
-            }
-            link[c] = to;
-        }
-        __syncthreads();
-        if (!flag) break;
-        for (int c = tid; c < V; c += kLT) {                             // two components that chose each other: the smaller id is the root
-            if (comp[c] != (uint32_t)c) continue;
-            const uint32_t o = link[c];
-            if (o != (uint32_t)c && link[o] == (uint32_t)c && (uint32_t)c < o) link[c] = (uint32_t)c;
-        }
-        __syncthreads();
-        for (int guard = 0; guard < 40; ++guard) {                       // pointer jumping (read phase / write phase)
-            if (tid == 0) flag = 0;
-            __syncthreads();
-            int changed = 0;
-            for (int c = tid; c < V; c += kLT) {
-                if (comp[c] != (uint32_t)c) continue;
-                const uint32_t p = link[c], gp = link[p];
-                if (gp != p) { link[c] = gp; changed = 1; }              // racing with p's own update only shortens the path further
-            }
-            if (changed) flag = 1;
-            __syncthreads();
-            if (!flag) break;
-            __syncthreads();
-        }
-        for (int v = tid; v < V; v += kLT) comp[v] = link[comp[v]];
-        __syncthreads();
+    const uint32_t cu = w.comp[idx[2 * e]], cv = w.comp[idx[2 * e + 1]];
+    if (cu != cv) {
+        const u64 key = ((u64)__float_as_uint(edge_weight[(int64_t)b * E + e]) << 32) | (uint32_t)e;   // weights are >= 0: the bits order like the values
+        atomicMin(&w.best[cu], key);
+        atomicMin(&w.best[cv], key);
     }
-    // tree edges in ascending edge order: each thread owns a contiguous run of bitmap words
+}
+// every component root takes its cheapest edge and hooks to the component at its other end
+__global__ __launch_bounds__(256) void mstL_hook_kernel(const int* __restrict__ edge_index, int E, int V, char* ws_base, size_t ws_stride) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= V) return;
+    const MstLargeWs w = mst_ws(ws_base, ws_stride, b, E, V);
+    if (w.comp[c] != (uint32_t)c) return;
+    const int* idx = edge_index + (int64_t)b * E * 2;
+    const u64 k = w.best[c];
+    uint32_t to = (uint32_t)c;
+    if (k != ~0ull) {
+        const uint32_t e = (uint32_t)k;
+        atomicOr(&w.chosen[e >> 5], 1u << (e & 31));
+        const uint32_t cu = w.comp[idx[2 * e]], cv = w.comp[idx[2 * e + 1]];
+        to = cu == (uint32_t)c ? cv : cu;
+    }
+    w.link[c] = to;
+}
+// two components that chose each other: the smaller id is the root (reads links of the previous kernel, writes its own)
+__global__ __launch_bounds__(256) void mstL_mutual_kernel(int E, int V, char* ws_base, size_t ws_stride) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= V) return;
+    const MstLargeWs w = mst_ws(ws_base, ws_stride, b, E, V);
+    if (w.comp[c] != (uint32_t)c) return;
+    const uint32_t o = w.link[c];
+    // (c < o decides alone: the partner, if it also points back, keeps its link to c)
+    if (o != (uint32_t)c && (uint32_t)c < o && w.link[o] == (uint32_t)c) w.link[c] = (uint32_t)c;
+}
+// one pointer-jumping step, out of place: link2[c] = link[link[c]]
+__global__ __launch_bounds__(256) void mstL_jump_kernel(int E, int V, char* ws_base, size_t ws_stride, int flip) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= V) return;
+    const MstLargeWs w = mst_ws(ws_base, ws_stride, b, E, V);
+    const uint32_t* src = flip ? w.link2 : w.link;
+    uint32_t* dst = flip ? w.link : w.link2;
+    if (w.comp[c] != (uint32_t)c) { dst[c] = src[c]; return; }
+    dst[c] = src[src[c]];
+}
+// comp[v] = root of comp[v]; the next round's offers start from scratch
+__global__ __launch_bounds__(256) void mstL_relabel_kernel(int E, int V, char* ws_base, size_t ws_stride, int flip) {
+    const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const MstLargeWs w = mst_ws(ws_base, ws_stride, b, E, V);
+    const uint32_t* lk = flip ? w.link2 : w.link;
+    w.comp[v] = lk[w.comp[v]];           // in place: a thread reads only its own entry of comp
+    w.best[v] = ~0ull;
+}
+// tree edges in ascending edge order (one workgroup per graph: each thread owns a contiguous run of bitmap words)
+__global__ __launch_bounds__(kLT) void mstL_emit_kernel(const int* __restrict__ edge_index, int E, int V, int* __restrict__ edge_out, int* __restrict__ n_out,
+                                                        char* ws_base, size_t ws_stride) {
+    __shared__ int scan[17];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const MstLargeWs w = mst_ws(ws_base, ws_stride, b, E, V);
+    const uint32_t* chosen = w.chosen;
+    const int* idx = edge_index + (int64_t)b * E * 2;
+    const int nwords = (E + 31) / 32;
     const int per = (nwords + kLT - 1) / kLT;
     const int w0 = min(tid * per, nwords), w1 = min(w0 + per, nwords);
     int cnt = 0;
@@ -131,8 +151,23 @@ __global__ __launch_bounds__(kLT) void mst_large_kernel(const int* __restrict__ 
 
 int launch_mst_large(const int* edge_index, const float* edge_weight, int B, int E, int V, int* edge_out, int* n_out, char* ws,
                      hipStream_t s) {
-    BXI_LAUNCH("mst_large", s, mst_large_kernel, dim3(B), dim3(kLT), 0, s, edge_index, edge_weight, E, V, edge_out, n_out, ws,
-               mst_large_ws_bytes(E, V));
+    if (B > 65535) return BXI_ERR_BAD_SHAPE;
+    const size_t stride = mst_large_ws_bytes(E, V);
+    const int nw = (E + 31) / 32;
+    const dim3 gv((unsigned)((V + 255) / 256), (unsigned)B), ge((unsigned)((E + 255) / 256), (unsigned)B);
+    const dim3 gi((unsigned)(((V > nw ? V : nw) + 255) / 256), (unsigned)B);
+    BXI_LAUNCH("mst_large_init", s, mstL_init_kernel, gi, dim3(256), 0, s, E, V, ws, stride);
+    int rounds = 0;
+    while ((1 << rounds) < V) ++rounds;
+    for (int r = 0; r < rounds; ++r) {
+        BXI_LAUNCH("mst_large_offer", s, mstL_offer_kernel, ge, dim3(256), 0, s, edge_index, edge_weight, E, V, ws, stride);
+        BXI_LAUNCH("mst_large_hook", s, mstL_hook_kernel, gv, dim3(256), 0, s, edge_index, E, V, ws, stride);
+        BXI_LAUNCH("mst_large_mutual", s, mstL_mutual_kernel, gv, dim3(256), 0, s, E, V, ws, stride);
+        const int jumps = rounds - r > 1 ? rounds - r : 1;
+        for (int j = 0; j < jumps; ++j) BXI_LAUNCH("mst_large_jump", s, mstL_jump_kernel, gv, dim3(256), 0, s, E, V, ws, stride, j & 1);
+        BXI_LAUNCH("mst_large_relabel", s, mstL_relabel_kernel, gv, dim3(256), 0, s, E, V, ws, stride, jumps & 1);
+    }
+    BXI_LAUNCH("mst_large_emit", s, mstL_emit_kernel, dim3(B), dim3(kLT), 0, s, edge_index, E, V, edge_out, n_out, ws, stride);
     return check_launch();
 }
 
