@@ -114,19 +114,17 @@ __global__ __launch_bounds__(256) void mstL_relabel_kernel(int E, int V, char* w
     w.comp[v] = lk[w.comp[v]];           // in place: a thread reads only its own entry of comp
     w.best[v] = ~0ull;
 }
-// tree edges in ascending edge order (one workgroup per graph: each thread owns a contiguous run of bitmap words)
-__global__ __launch_bounds__(kLT) void mstL_emit_kernel(const int* __restrict__ edge_index, int E, int V, int* __restrict__ edge_out, int* __restrict__ n_out,
-                                                        char* ws_base, size_t ws_stride) {
+// tree edges in ascending edge order: (1) exclusive prefix of the bitmap words' popcounts (one workgroup per graph: a few thousand
+// words), (2) a thread per word writes its edges at its prefix
+__global__ __launch_bounds__(kLT) void mstL_scan_kernel(int E, int V, int* __restrict__ n_out, char* ws_base, size_t ws_stride) {
     __shared__ int scan[17];
     const int b = blockIdx.x, tid = threadIdx.x;
     const MstLargeWs w = mst_ws(ws_base, ws_stride, b, E, V);
-    const uint32_t* chosen = w.chosen;
-    const int* idx = edge_index + (int64_t)b * E * 2;
     const int nwords = (E + 31) / 32;
     const int per = (nwords + kLT - 1) / kLT;
     const int w0 = min(tid * per, nwords), w1 = min(w0 + per, nwords);
     int cnt = 0;
-    for (int i = w0; i < w1; ++i) cnt += __popc(chosen[i]);
+    for (int i = w0; i < w1; ++i) cnt += __popc(w.chosen[i]);
     const int lane = tid & 63, wave = tid >> 6;
     int incl = cnt;
 #pragma unroll
@@ -136,17 +134,25 @@ __global__ __launch_bounds__(kLT) void mstL_emit_kernel(const int* __restrict__ 
     if (tid == 0) { int s = 0; for (int i = 0; i < 16; ++i) { const int t = scan[i]; scan[i] = s; s += t; } scan[16] = s; }
     __syncthreads();
     int pos = scan[wave] + incl - cnt;
-    int* out = edge_out + (int64_t)b * (V - 1) * 2;
-    for (int i = w0; i < w1; ++i) {
-        uint32_t m = chosen[i];
-        while (m) {
-            const int e = i * 32 + __ffs((int)m) - 1;
-            m &= m - 1;
-            if (pos < V - 1) { out[2 * pos] = idx[2 * e]; out[2 * pos + 1] = idx[2 * e + 1]; }
-            ++pos;
-        }
-    }
+    uint32_t* pre = w.link;                               // the links are done with: the words' prefixes live there (nwords <= V)
+    for (int i = w0; i < w1; ++i) { pre[i] = (uint32_t)pos; pos += __popc(w.chosen[i]); }
     if (tid == 0) n_out[b] = scan[16];
+}
+__global__ __launch_bounds__(256) void mstL_emit_kernel(const int* __restrict__ edge_index, int E, int V, int* __restrict__ edge_out, char* ws_base,
+                                                        size_t ws_stride) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= (E + 31) / 32) return;
+    const MstLargeWs w = mst_ws(ws_base, ws_stride, b, E, V);
+    const int* idx = edge_index + (int64_t)b * E * 2;
+    int* out = edge_out + (int64_t)b * (V - 1) * 2;
+    uint32_t m = w.chosen[i];
+    int pos = (int)w.link[i];
+    while (m) {
+        const int e = i * 32 + __ffs((int)m) - 1;
+        m &= m - 1;
+        if (pos < V - 1) *reinterpret_cast<int2*>(out + 2 * pos) = *reinterpret_cast<const int2*>(idx + 2 * e);
+        ++pos;
+    }
 }
 
 int launch_mst_large(const int* edge_index, const float* edge_weight, int B, int E, int V, int* edge_out, int* n_out, char* ws,
@@ -167,18 +173,21 @@ int launch_mst_large(const int* edge_index, const float* edge_weight, int B, int
         for (int j = 0; j < jumps; ++j) BXI_LAUNCH("mst_large_jump", s, mstL_jump_kernel, gv, dim3(256), 0, s, E, V, ws, stride, j & 1);
         BXI_LAUNCH("mst_large_relabel", s, mstL_relabel_kernel, gv, dim3(256), 0, s, E, V, ws, stride, jumps & 1);
     }
-    BXI_LAUNCH("mst_large_emit", s, mstL_emit_kernel, dim3(B), dim3(kLT), 0, s, edge_index, E, V, edge_out, n_out, ws, stride);
+    if (nw > V) return BXI_ERR_UNSUPPORTED;               // (the word prefixes reuse the link array; E <= 8 V is checked by the caller)
+    BXI_LAUNCH("mst_large_scan", s, mstL_scan_kernel, dim3(B), dim3(kLT), 0, s, E, V, n_out, ws, stride);
+    BXI_LAUNCH("mst_large_emit", s, mstL_emit_kernel, dim3((unsigned)((nw + 255) / 256), (unsigned)B), dim3(256), 0, s, edge_index, E, V, edge_out, ws, stride);
     return check_launch();
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct BfsLargeWs { uint32_t* adj; uint32_t* deg; uint32_t* nodev; uint32_t* nodep; uint32_t* pos_of; };
+struct BfsLargeWs { uint32_t* adj; uint32_t* deg; uint32_t* nodev; uint32_t* nodep; uint32_t* pos_of; int* flag; int* nf; };
 __host__ __device__ static size_t carve_bfs_large(char* base, int V, BfsLargeWs* w) {
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += up16(b); return base ? base + o : nullptr; };
     BfsLargeWs t;
     t.adj = (uint32_t*)take(16 * (size_t)V); t.deg = (uint32_t*)take(4 * (size_t)V); t.nodev = (uint32_t*)take(4 * (size_t)(V + 1));
     t.nodep = (uint32_t*)take(4 * (size_t)(V + 1)); t.pos_of = (uint32_t*)take(4 * (size_t)V);
+    t.flag = (int*)take(4); t.nf = (int*)take(4);
     if (w) *w = t;
     return off;
 }
@@ -200,41 +209,103 @@ __device__ __forceinline__ int block_excl_scan(int v, int* part /*[17]*/, int& t
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(kLT) void bfs_large_kernel(const int* __restrict__ tree, int V, int max_adj, int* __restrict__ sorted_index,
-                                                        int* __restrict__ sorted_parent, int* __restrict__ sorted_child,
-                                                        int* __restrict__ levels, char* ws_base, size_t ws_stride) {
-    __shared__ int part[17];
-    const int b = blockIdx.x, tid = threadIdx.x;
+// BFS of a large tree: the passes over the vertices / edges (adjacency, sorting, outputs) run ACROSS THE GPU; only the level walk
+// -- a chain through the tree's depth, ~1500 levels at 200 x 304 -- is one workgroup per graph, and while the frontier is at most
+// 64 nodes wide (the usual case: ~40) it is ONE WAVE with the frontier in LDS: per level one dependent global round trip (the
+// adjacency of the frontier's nodes), four ballots for the children's places, no workgroup barrier.
+__device__ __forceinline__ BfsLargeWs bfs_ws(char* ws_base, size_t ws_stride, int b, int V) {
     BfsLargeWs w;
     carve_bfs_large(ws_base + (size_t)b * ws_stride, V, &w);
+    return w;
+}
+__global__ __launch_bounds__(256) void bfsL_zero_kernel(int V, int max_adj, int* __restrict__ sorted_child, char* ws_base, size_t ws_stride) {
+    const int b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    if (i < V) w.deg[i] = 0u;
+    if (i == 0) *w.flag = 0;
+    if (i < (int64_t)V * max_adj) sorted_child[(int64_t)b * V * max_adj + i] = 0;
+}
+__global__ __launch_bounds__(256) void bfsL_adj_kernel(const int* __restrict__ tree, int V, char* ws_base, size_t ws_stride) {
+    const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= V - 1) return;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
     const int* ed = tree + (int64_t)b * (V - 1) * 2;
-    int* s_index = sorted_index + (int64_t)b * V;
-    int* s_parent = sorted_parent + (int64_t)b * V;
-    int* s_child = sorted_child + (int64_t)b * V * max_adj;
+    const int u = ed[2 * e], v = ed[2 * e + 1];           // adjacency (a vertex of a grid tree has at most 4 neighbours)
+    const unsigned su = atomicAdd(&w.deg[u], 1u), sv = atomicAdd(&w.deg[v], 1u);
+    if (su < 4) w.adj[4 * (size_t)u + su] = (uint32_t)v;
+    if (sv < 4) w.adj[4 * (size_t)v + sv] = (uint32_t)u;
+}
+__global__ __launch_bounds__(256) void bfsL_sort_kernel(int V, char* ws_base, size_t ws_stride) {
+    const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    if (w.deg[v] > 4u) atomicOr(w.flag, 1);              // more than 4 neighbours: not a tree on a grid (edges would be dropped)
+    const int d = min((int)w.deg[v], 4);                  // arrival order of the atomics -> ascending neighbour ids
+    uint32_t a[4];
+    for (int k = 0; k < 4; ++k) a[k] = k < d ? w.adj[4 * (size_t)v + k] : 0xffffffffu;
+    for (int i = 1; i < 4; ++i) for (int j = i; j > 0 && a[j - 1] > a[j]; --j) { const uint32_t t = a[j]; a[j] = a[j - 1]; a[j - 1] = t; }
+    *reinterpret_cast<uint4*>(w.adj + 4 * (size_t)v) = make_uint4(a[0], a[1], a[2], a[3]);
+}
+
+__global__ __launch_bounds__(kLT) void bfsL_walk_kernel(int V, int* __restrict__ levels, char* ws_base, size_t ws_stride) {
+    __shared__ int part[17];
+    __shared__ uint32_t fv[256], fp[256];                 // the next frontier of the one-wave form (<= 4 children of <= 64 nodes)
+    __shared__ int s_lo, s_hi, s_n, s_depth;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
     int* lv = levels + (int64_t)b * (V + 2);
-    for (int i = tid; i < V; i += kLT) w.deg[i] = 0u;
-    for (int i = tid; i < V * max_adj; i += kLT) s_child[i] = 0;
-    __syncthreads();
-    for (int e = tid; e < V - 1; e += kLT) {            // adjacency (a vertex of a grid tree has at most 4 neighbours)
-        const int u = ed[2 * e], v = ed[2 * e + 1];
-        const unsigned su = atomicAdd(&w.deg[u], 1u), sv = atomicAdd(&w.deg[v], 1u);
-        if (su < 4) w.adj[4 * (size_t)u + su] = (uint32_t)v;
-        if (sv < 4) w.adj[4 * (size_t)v + sv] = (uint32_t)u;
+    if (tid == 0) { w.nodev[0] = 0u; w.nodep[0] = 0xffffffffu; lv[1] = 0; fv[0] = 0u; fp[0] = 0xffffffffu; }
+    // every adjacency record is read exactly once by the walk, one dependent read per level: bring the table (16 B per vertex, 1 MB at
+    // 200 x 304) into this XCD's L2 first, with the whole workgroup, so that the walk's reads are L2 hits instead of trips to HBM
+    {
+        uint32_t sink = 0u;
+        for (int v = tid; v < V; v += kLT) { const uint4 q = *reinterpret_cast<const uint4*>(w.adj + 4 * (size_t)v); sink ^= q.x ^ q.y ^ q.z ^ q.w; }
+        asm volatile("" ::"v"(sink));
     }
-    __syncthreads();
-    int over = 0;                                       // a vertex with more than 4 neighbours: not a tree on a grid (edges would be dropped)
-    for (int v = tid; v < V; v += kLT) {                // arrival order of the atomics -> ascending neighbour ids
-        over |= w.deg[v] > 4u ? 1 : 0;
-        const int d = min((int)w.deg[v], 4);
-        uint32_t a[4];
-        for (int k = 0; k < 4; ++k) a[k] = k < d ? w.adj[4 * (size_t)v + k] : 0xffffffffu;
-        for (int i = 1; i < 4; ++i) for (int j = i; j > 0 && a[j - 1] > a[j]; --j) { const uint32_t t = a[j]; a[j] = a[j - 1]; a[j - 1] = t; }
-        for (int k = 0; k < 4; ++k) w.adj[4 * (size_t)v + k] = a[k];
-    }
-    if (tid == 0) { w.nodev[0] = 0u; w.nodep[0] = 0xffffffffu; lv[1] = 0; }
     __syncthreads();
     int lo = 0, hi = 1, n = 1, depth = 0;
     while (lo < hi) {                                   // workgroup-uniform
+        if (hi - lo <= 64) {
+            // ---- one wave walks while the frontier stays narrow; the other waves wait at the barrier below
+            if (tid < 64) {
+                const int lane = tid;
+                while (lo < hi && hi - lo <= 64) {
+                    const bool act = lane < hi - lo;
+                    const uint32_t cur = act ? fv[lane] : 0u, par = act ? fp[lane] : 0u;
+                    const uint4 q = act ? *reinterpret_cast<const uint4*>(w.adj + 4 * (size_t)cur) : make_uint4(~0u, ~0u, ~0u, ~0u);
+                    const uint32_t nb[4] = {q.x, q.y, q.z, q.w};
+                    bool ok[4];
+                    int before = 0, mine = 0, total = 0;
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        ok[k] = act && nb[k] != 0xffffffffu && nb[k] != par;
+                        const unsigned long long m = __ballot(ok[k]);
+                        before += __popcll(m & lt);
+                        total += __popcll(m);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every lane has read its frontier slot before it is overwritten
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (ok[k]) {
+                            const int slot = before + mine;
+                            fv[slot] = nb[k]; fp[slot] = cur;
+                            w.nodev[n + slot] = nb[k]; w.nodep[n + slot] = cur;
+                            ++mine;
+                        }
+                    ++depth;
+                    if (lane == 0) lv[1 + depth] = hi;                           // off[depth] = end of this level
+                    lo = hi; hi = n + total; n += total;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the next frontier is in LDS (one wave: its LDS operations execute in order)
+                }
+                if (lane == 0) { s_lo = lo; s_hi = hi; s_n = n; s_depth = depth; }
+            }
+            __syncthreads();                             // also: the walking wave's global stores of nodev / nodep are done (vmcnt) before others read them
+            lo = s_lo; hi = s_hi; n = s_n; depth = s_depth;
+            __syncthreads();
+            continue;
+        }
         for (int base = lo; base < hi; base += kLT) {
             const int i = base + tid;
             const bool act = i < hi;
@@ -252,7 +323,10 @@ __global__ __launch_bounds__(kLT) void bfs_large_kernel(const int* __restrict__ 
             const int pos = n + block_excl_scan(nch, part, total);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (ok[k]) { w.nodev[pos + rank[k]] = nb[k]; w.nodep[pos + rank[k]] = cur; }
+                if (ok[k]) {
+                    w.nodev[pos + rank[k]] = nb[k]; w.nodep[pos + rank[k]] = cur;
+                    if (pos + rank[k] - hi < 256) { fv[pos + rank[k] - hi] = nb[k]; fp[pos + rank[k] - hi] = cur; }   // in case the next level is narrow (n == hi when a level starts)
+                }
             n += total;
         }
         ++depth;
@@ -260,30 +334,45 @@ __global__ __launch_bounds__(kLT) void bfs_large_kernel(const int* __restrict__ 
         __syncthreads();                                // the next level's nodes are written
         lo = hi; hi = n;
     }
-    const int nf = n;                                   // < V only for a disconnected input
     // loud, not silent: a vertex of degree > 4 or an input that is not connected leaves depth = -1, which makes
     // bxi_tree_refine_* poison its output (the reference's bfs.cu walks whatever it is given; refine.cu then reads garbage)
-    const int broken = __syncthreads_or(over) || nf < V;
-    if (tid == 0) lv[0] = broken ? -1 : depth;
-    for (int p = tid; p < V; p += kLT) {
-        const uint32_t v = p < nf ? w.nodev[p] : 0u;
-        s_index[p] = (int)v;
-        if (p < nf) w.pos_of[v] = (uint32_t)p;
-    }
-    __syncthreads();
-    for (int p = tid; p < V; p += kLT) {
-        if (p == 0 || p >= nf) { s_parent[p] = 0; continue; }
-        const uint32_t pv = w.nodep[p];
-        const int pp = (int)w.pos_of[pv];
-        s_parent[p] = pp;
-        int k = 0;                                      // rank among the (contiguous) siblings
-        while (k < 3 && p - k - 1 >= 1 && w.nodep[p - k - 1] == pv) ++k;
-        if (k < max_adj) s_child[(size_t)pp * max_adj + k] = p;
-    }
+    if (tid == 0) { lv[0] = (*w.flag || n < V) ? -1 : depth; *w.nf = n; }
+}
+__global__ __launch_bounds__(256) void bfsL_index_kernel(int V, int* __restrict__ sorted_index, char* ws_base, size_t ws_stride) {
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= V) return;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    const int nf = *w.nf;                               // < V only for a disconnected input
+    const uint32_t v = p < nf ? w.nodev[p] : 0u;
+    sorted_index[(int64_t)b * V + p] = (int)v;
+    if (p < nf) w.pos_of[v] = (uint32_t)p;
+}
+__global__ __launch_bounds__(256) void bfsL_parent_kernel(int V, int max_adj, int* __restrict__ sorted_parent, int* __restrict__ sorted_child, char* ws_base,
+                                                          size_t ws_stride) {
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= V) return;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    const int nf = *w.nf;
+    int* s_parent = sorted_parent + (int64_t)b * V;
+    if (p == 0 || p >= nf) { s_parent[p] = 0; return; }
+    const uint32_t pv = w.nodep[p];
+    const int pp = (int)w.pos_of[pv];
+    s_parent[p] = pp;
+    int k = 0;                                          // rank among the (contiguous) siblings
+    while (k < 3 && p - k - 1 >= 1 && w.nodep[p - k - 1] == pv) ++k;
+    if (k < max_adj) sorted_child[(int64_t)b * V * max_adj + (size_t)pp * max_adj + k] = p;
 }
 
 int launch_bfs_large(const int* tree, int B, int V, int max_adj, int* si, int* sp, int* sc, int* levels, char* ws, hipStream_t s) {
-    BXI_LAUNCH("bfs_large", s, bfs_large_kernel, dim3(B), dim3(kLT), 0, s, tree, V, max_adj, si, sp, sc, levels, ws, bfs_large_ws_bytes(V));
+    if (B > 65535) return BXI_ERR_BAD_SHAPE;
+    const size_t stride = bfs_large_ws_bytes(V);
+    const dim3 gv((unsigned)((V + 255) / 256), (unsigned)B), gz((unsigned)(((int64_t)V * max_adj + 255) / 256), (unsigned)B);
+    BXI_LAUNCH("bfs_large_zero", s, bfsL_zero_kernel, gz, dim3(256), 0, s, V, max_adj, sc, ws, stride);
+    BXI_LAUNCH("bfs_large_adj", s, bfsL_adj_kernel, gv, dim3(256), 0, s, tree, V, ws, stride);
+    BXI_LAUNCH("bfs_large_sort", s, bfsL_sort_kernel, gv, dim3(256), 0, s, V, ws, stride);
+    BXI_LAUNCH("bfs_large_walk", s, bfsL_walk_kernel, dim3(B), dim3(kLT), 0, s, V, levels, ws, stride);
+    BXI_LAUNCH("bfs_large_index", s, bfsL_index_kernel, gv, dim3(256), 0, s, V, si, ws, stride);
+    BXI_LAUNCH("bfs_large_parent", s, bfsL_parent_kernel, gv, dim3(256), 0, s, V, max_adj, sp, sc, ws, stride);
     return check_launch();
 }
 
