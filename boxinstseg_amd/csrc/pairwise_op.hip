@@ -703,10 +703,17 @@ static int launch_bwd(const T* logits, const T* g_pair, int N, int H, int W, int
             if constexpr (sizeof(T) == 4) {
                 if (dil <= 4 && (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(g_pair) | reinterpret_cast<uintptr_t>(g_logits)) & 15) == 0) {
                     static const int env_swz = getenv("BXI_PW_SWIZZLE") ? atoi(getenv("BXI_PW_SWIZZLE")) : 1;
+#ifndef BXI_PWB_TR
+#define BXI_PWB_TR 16
+#define BXI_PWB_TC 64
+#endif
+                    const int64_t tiles_b = (int64_t)N * ((H + BXI_PWB_TR - 1) / BXI_PWB_TR) * ((W + BXI_PWB_TC - 1) / BXI_PWB_TC);
+                    if (!fits_i32(tiles_b)) return BXI_ERR_BAD_SHAPE;
+                    const dim3 gb((unsigned)tiles_b);
 #define BXI_PWB(DD)                                                                                                                             \
                     {                                                                                                                           \
-                        const size_t ldw = 2 * sizeof(float) * (size_t)(kPwTR + 2 * DD) * PwGeom<DD, kPwTC>::PC;                             \
-                        BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_wide_kernel<DD, kPwTR, kPwTC>), g, b, ldw, st, (const float*)logits,     \
+                        const size_t ldw = 2 * sizeof(float) * (size_t)(BXI_PWB_TR + 2 * DD) * PwGeom<DD, BXI_PWB_TC>::PC;                    \
+                        BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_wide_kernel<DD, BXI_PWB_TR, BXI_PWB_TC>), gb, b, ldw, st, (const float*)logits, \
                                    (const float*)g_pair, H, W, (float*)g_logits, env_swz);                                                    \
                     }
                     switch (dil) { case 1: BXI_PWB(1) break; case 2: BXI_PWB(2) break; case 3: BXI_PWB(3) break; default: BXI_PWB(4) break; }
