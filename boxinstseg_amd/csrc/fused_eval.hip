@@ -1,4 +1,5 @@
-// fused_eval.hip -- the BoxInst loss evaluation (forward AND finished backward) in TWO launches on gfx950.
+// fused_eval.hip -- the BoxInst loss evaluation (forward AND finished backward) on gfx950: ONE launch (eval1_kernel, the roles below in
+// one grid) where the shipped shapes allow it, otherwise TWO (prep_kernel, pair_kernel).
 //
 // Replaces (reference, LiWentomng/BoxInstSeg) CondInstMaskHead.loss with boxinst_enabled,
 // condinst_head.py:1288-1343, together with everything it calls:
@@ -15,13 +16,13 @@
 //                   of the block's 32 rows -> partials for the leaders of the next launch
 //     pool blocks   the 4 input rows of 64 pooled pixels -> de-normalise, truncate, 4x4 mean, Lab (fp64) -> ONE 16-byte
 //                   store per pooled pixel
-//   launch 2  pair_kernel   [predicate blocks][leaders][tile blocks][finisher]
+//   launch 2  pair_kernel   [predicate blocks][reducer][leaders][tile blocks][finisher]
 //     leaders       one block per instance: partial maxima -> maxima -> sigmoid -> dice -> unit projection gradients, ADDED
 //                   (float atomic) at the arg-max positions of the zero-filled gradient.  Nobody waits for a leader but the finisher.
 //     predicate waves  one wave64 per pooled row segment (64 pixels) of an image: the four colour predicates per pixel (one byte)
 //                   -- each unordered pair ONCE PER IMAGE, not once per instance and tile -- and the segment's share of the pair
 //                   weights' sum (a function of the image and the boxes only, :1324-1328) -> one packed integer atomic per workgroup;
-//                   the finisher's second wave adds the 64 count words up and publishes ONE word (1 << 63 | sum W)
+//                   the reducer (one wave, right behind them in the grid) adds the 64 count words up and publishes ONE word (1 << 63 | sum W)
 //     tile waves    one wave64 per box tile (no LDS, no barrier): logits tile + halo in registers, every unordered pair
 //                   evaluated once; g_pw warm/max(sum W,1) d pw is ADDED (float atomic) to the gradient -- an element receives
 //                   at most two additions onto 0 (its tile's and its leader's), so the sum does not depend on their order;
@@ -1204,6 +1205,17 @@ __device__ __forceinline__ void pred_role(const InstArgs& a, const ValidCells& v
     BXI_TW(2, pid, 1);
 }
 
+// the reducer: ONE wave, in a workgroup of its own right behind the predicate workgroups -- EARLIER in the grid than every tile
+// workgroup that waits for what it publishes (it used to be a wave of the finisher, the LAST workgroup: on a stream with fewer
+// slots than tile workgroups the finisher could not start while the tile waves, holding every slot, waited for it).  It waits
+// only for predicate workgroups.  (Single-launch form: the count words are this evaluation's only once the table says so --
+// before that they hold the previous evaluation's complete counts.)
+template <bool ONE>
+__device__ __forceinline__ void reducer_role(const Ws& ws, int zero_bit, int n_items, int spin_limit) {
+    if (threadIdx.x >= 64 || zero_bit) return;
+    if (!(table_complete<ONE>(ws, 0, spin_limit) && reduce_counts(ws, n_items, spin_limit)) && threadIdx.x == 0) atomicOr(ws.fault, kFaultCounts);
+}
+
 // the last workgroup: waits only for workgroups that never wait for it -- the leaders and the predicate waves (done early), then
 // the tile waves -- and writes the two loss values
 template <bool ONE>
@@ -1221,11 +1233,6 @@ __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, c
     float dsum = 0.f;
     int spins = 0;
     if (spin_limit < 0) ok = false;
-    if (wave == 1 && !zero_bit) {                                      // the reducer
-        // (single-launch form: the count words are this evaluation's only once the table says so -- before that they hold the
-        // previous evaluation's complete counts)
-        if (!(table_complete<ONE>(ws, 0, spin_limit) && reduce_counts(ws, n_items, spin_limit)) && lane == 0) atomicOr(ws.fault, kFaultCounts);
-    }
     if (wave == 0) {
         if (!table_complete<ONE>(ws, N, spin_limit)) ok = false;      // every polled word of this evaluation is zeroed from here on
         int4 eN = make_int4(0, 0, 0, 0);
@@ -1317,7 +1324,7 @@ __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& v
     }
 }
 
-// grid: [n_pb predicate blocks][N leaders][n_tb tile blocks][finisher].  The only waits: a tile wave for the predicate waves
+// grid: [n_pb predicate blocks][reducer][N leaders][n_tb tile blocks][finisher].  The only waits: a tile wave for the predicate waves
 // (earlier in the grid, never waiting themselves), the finisher for everybody (nobody waits for it).  Every wait is bounded, and
 // running out of it is loud: NaN losses, status word, poisoned gradient (the reference surfaces launch failures through
 // AT_CUDA_CHECK, pairwise.cu:173,200).
@@ -1333,18 +1340,20 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair_ker
     if (blk < n_pb) {                                                  // ---- predicate waves: first in the grid, everybody asks for their words
         if (zero_bit) return;                                          // every pair weighs 1: sum W has a closed form, the tiles take the log-space path
         pred_role<D, false>(a, vc, ws, n2max, blk, n_pb, n_items, spin_limit);
-    } else if (blk < n_pb + N) {                                       // ---- leader of an instance
-        BXI_TW(3, 1 + blk - n_pb, 0);
-        leader_block<false>(a, D, ws, st, blk - n_pb, upp, g_logits, smem, red, spin_limit);
+    } else if (blk == n_pb) {                                          // ---- the reducer
+        reducer_role<false>(ws, zero_bit, n_items, spin_limit);
+    } else if (blk < n_pb + 1 + N) {                                   // ---- leader of an instance
+        BXI_TW(3, 1 + blk - n_pb - 1, 0);
+        leader_block<false>(a, D, ws, st, blk - n_pb - 1, upp, g_logits, smem, red, spin_limit);
     } else if (blk == (int)gridDim.x - 1) {
         finisher_role<false>(a, ws, st, upp, upw, warmup, zero_bit, n_items, spin_limit, R, losses);
     } else {
-        tile_role<D, R, false>(a, vc, ws, upw * warmup, n2max, zero_bit, n_items, spin_limit, g_logits, smem, blk - N - n_pb, (int)gridDim.x - 1 - N - n_pb);
+        tile_role<D, R, false>(a, vc, ws, upw * warmup, n2max, zero_bit, n_items, spin_limit, g_logits, smem, blk - N - n_pb - 1, (int)gridDim.x - 2 - N - n_pb);
     }
 }
 
 // ---- the single-launch form ---------------------------------------------------------------------------------------------------
-// All roles in ONE grid, in this order:  [stream blocks (their first waves write the table)][pool blocks][predicate blocks][N leaders][tile blocks][finisher].
+// All roles in ONE grid, in this order:  [stream blocks (their first waves write the table)][pool blocks][predicate blocks][reducer][N leaders][tile blocks][finisher].
 // Workgroups are dispatched in grid order and every wait is for a workgroup EARLIER in the grid:
 //   table, stream, pool   wait for nobody;
 //   leader n              for the table entry n and the band flags of instance n (stream blocks);
@@ -1370,12 +1379,13 @@ __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_
     const int Sn = (a.h + kSBlk - 1) / kSBlk;
     const int n_stream = N * Sn;
     const int blk = (int)blockIdx.x;
-    // role of this workgroup: 0 stream, 1 pool, 2 leader, 3 predicate, 4 tile, 5 finisher
+    // role of this workgroup: 0 stream, 1 pool, 2 leader, 3 predicate, 4 tile, 5 finisher, 6 reducer
     int role, idx = blk;
     if (idx < n_stream) role = 0;
     else if ((idx -= n_stream) < n_pool) role = 1;
     else if ((idx -= n_pool) < n_pb) role = 3;
-    else if ((idx -= n_pb) < N) role = 2;
+    else if ((idx -= n_pb) < 1) role = 6;                              // the reducer
+    else if ((idx -= 1) < N) role = 2;
     else if ((idx -= N) < n_tb) role = 4;
     else role = 5;
     const int tix = (n_tab + (role == 0 ? idx : n_stream + idx)) * kWaves + (int)(threadIdx.x >> 6);
@@ -1414,6 +1424,7 @@ __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_
         return;
     }
     if (role == 3) { pred_role<D, true>(a, vc, ws, n2max, idx, n_pb, n_items, spin_limit); return; }
+    if (role == 6) { reducer_role<true>(ws, 0, n_items, spin_limit); return; }
     if (role == 4) {          // ONE call site for the stream workgroups that stay on and for the tile workgroups proper
         const int shift = merge ? n_stream : 0;
         tile_role<D, R, true>(a, vc, ws, upw * warmup, n2max, 0, n_items, spin_limit, g_logits, smem, idx + shift, n_tb + shift);
@@ -1497,6 +1508,31 @@ static int device_cus() {
 }
 
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+// Compute units the stream may use: a CU mask (hipExtStreamCreateWithCUMask, ROC_GLOBAL_CU_MASK) leaves fewer than the device has.
+// The single-launch form needs to know (its stream workgroups must leave free slots for the workgroups they wait for).  Cached per
+// stream handle (a handful of streams per process); a failing query counts as "the whole device".
+static int stream_cus(hipStream_t s, int device_total) {
+    struct Entry { std::atomic<uintptr_t> key; std::atomic<int> cus; };
+    static Entry cache[8];
+    const uintptr_t k = reinterpret_cast<uintptr_t>(s) + 1;            // +1: the null stream is a key too
+    for (auto& e : cache)
+        if (e.key.load(std::memory_order_acquire) == k) return e.cus.load(std::memory_order_relaxed);
+    uint32_t mask[32] = {};
+    int n = device_total;
+    if (hipExtStreamGetCUMask(s, 32, mask) == hipSuccess) {
+        int bits = 0;
+        for (uint32_t m : mask) bits += __builtin_popcount(m);
+        if (bits > 0 && bits < n) n = bits;
+    } else {
+        (void)hipGetLastError();
+    }
+    static std::atomic<unsigned> next{0};
+    Entry& e = cache[next.fetch_add(1, std::memory_order_relaxed) % 8];
+    e.cus.store(n, std::memory_order_relaxed);
+    e.key.store(k, std::memory_order_release);
+    return n;
+}
 
 // Rows per tile.  4 everywhere: with the round-3 pair kernel the shorter tile wins at every instance count measured (two launches,
 // 200 x 256 maps: 39.4 vs 47.7 us at 128 instances, 74.8 vs 101.5 at 256, 164 us at 512); 8-row tiles stay instantiated for
@@ -1619,7 +1655,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     // The single launch pays off while its front half (stream + pool workgroups) is resident at once: measured 24.8 vs 27.0 us at
     // 64 instances, 35.1 vs 33.9 at 96, 45.1 vs 39.4 at 128 (200 x 256 maps) -- hence: stream workgroups <= half the slots.
     const int one_slots = kOneOcc * device_cus();
-    const bool one_fits = 2 * (int64_t)a.N * ((a.h + kSBlk - 1) / kSBlk) <= one_slots;
+    const bool one_fits = 2 * (int64_t)a.N * ((a.h + kSBlk - 1) / kSBlk) <= one_slots && stream_cus(s, device_cus()) >= device_cus();
     if (env_one && !(form & 2) && (one_fits || env_one == 2 || (form & 1)) && !head && pooled_in_launch && R == 4 && dil <= 3 &&
         !pr.zero_bit) {
         static const int env_one_pool = env_int("BXI_ONE_POOL_WGS", 0);
@@ -1648,7 +1684,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         if (lds < sizeof(float) * (size_t)kWaves * (R + 1) * 64) lds = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
         if (lds < 2 * sizeof(float) * (size_t)(a.h + a.w) + 16) lds = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
         if (lds <= 36 * 1024) {                             // four workgroups per CU must fit
-            const unsigned grid = (unsigned)(n_stream + n_pool + n_pb + a.N + (int)n_tb + 1);
+            const unsigned grid = (unsigned)(n_stream + n_pool + n_pb + 1 + a.N + (int)n_tb + 1);
 #define BXI_ONE_CASE(DD)                                                                                                                    \
             case DD:                                                                                                                        \
                 BXI_LAUNCH("eval1", s, (eval1_kernel<DD>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, up_prj, \
@@ -1718,7 +1754,8 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? (dil <= 3 ? 4 : 3) : 2);
     // (the leaders are short-lived and are not counted; with them subtracted, 512 instances at two workgroups per CU left ONE
     // predicate workgroup for the whole image side: 4.4 ms per evaluation)
-    const int slots = occ * device_cus() > 256 ? occ * device_cus() : 256;
+    const int cus2 = stream_cus(s, device_cus());                      // a CU-masked stream has fewer
+    const int slots = occ * cus2 > 64 ? occ * cus2 : 64;
     int n_pb = (n_items + kWaves - 1) / kWaves;
     if (n_pb > slots / 2) n_pb = slots / 2;
     if (n_tb > slots - n_pb) n_tb = slots - n_pb;
@@ -1726,7 +1763,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
     if (lds2 < lds_leader) lds2 = lds_leader;
     if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
-    const int grid = a.N + n_pb + (int)n_tb + 1;          // leaders + predicate blocks + tile blocks + the finisher
+    const int grid = n_pb + 1 + a.N + (int)n_tb + 1;      // predicate blocks + the reducer + leaders + tile blocks + the finisher
 #define BXI_PAIR_CASE(DD)                                                                                                                  \
     case DD:                                                                                                                               \
         if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw); \

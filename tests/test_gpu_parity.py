@@ -305,6 +305,44 @@ def test_single_launch_and_two_launch_forms_agree_bit_for_bit(dev):
             assert np.array_equal(a[2], b[2]), dil
 
 
+def test_stream_with_a_cu_mask_takes_the_two_launch_form(dev):
+    """The single-launch form sizes its grid for the whole device; on a stream restricted to a few CUs (hipExtStreamCreateWithCUMask)
+    its stream workgroups would hold every slot while waiting for workgroups that cannot start.  The library asks the stream for its
+    mask and takes the two-launch form there (no waiter depends on a workgroup that still needs a slot): same bits, status 0."""
+    import ctypes as C
+    from boxinstseg_amd import _lib, boxinst_mask_loss, functional as Fh
+    lib = _lib.load()
+    hip = C.CDLL('libamdhip64.so')
+    stream = C.c_void_p()
+    mask = (C.c_uint32 * 8)(0xffffffff, 0, 0, 0, 0, 0, 0, 0)             # 32 of the 256 CUs
+    assert hip.hipExtStreamCreateWithCUMask(C.byref(stream), 8, mask) == 0
+    try:
+        d = synthetic.cfg2(2)
+        quiet = hip_loss(d, dev)
+        names = []
+        cb = _lib.LAUNCH_HOOK(lambda name, phase, st, user: names.append(name.decode()))
+        ext = torch.cuda.ExternalStream(stream.value, device=dev)
+        t = to_dev(d, dev)
+        torch.cuda.synchronize()
+        Fh.DEBUG_KEEP_LAST = True
+        lib.bxi_set_launch_hook(C.cast(cb, C.c_void_p), None)
+        try:
+            with torch.cuda.stream(ext):
+                x = t['logits'].clone().requires_grad_(True)
+                out = boxinst_mask_loss(x, t['gt_inds'], t['gt_bboxes'], imgs=t['imgs'], img_metas=d['img_metas'])
+                (out['loss_prj'] + out['loss_pairwise']).backward()
+        finally:
+            lib.bxi_set_launch_hook(None, None)
+        torch.cuda.synchronize()
+        assert 'eval1' not in names and 'prep' in names and 'pair' in names, names
+        assert Fh.last_eval_status()[0] == 0
+        assert float(out['loss_prj']) == quiet[0] and float(out['loss_pairwise']) == quiet[1]
+        assert np.array_equal(x.grad.cpu().numpy()[:, 0], quiet[2])
+    finally:
+        torch.cuda.synchronize()
+        hip.hipStreamDestroy(stream)
+
+
 def test_wait_timeouts_are_loud(dev, eval_form):
     """The second launch's bounded waits (tile waves for the predicate bytes / the normaliser, the finisher for everybody) never run
     out in practice; when they do -- forced here through the test hook -- the evaluation must not hand back plausible numbers: both
