@@ -50,7 +50,8 @@ constexpr int kSRows = 8;                       // rows per stream wave
 constexpr int kSBlk = kWaves * kSRows;          // rows per stream workgroup
 constexpr int kChunkC = 256;                    // columns per pass of a stream wave: 64 lanes x float4
 constexpr int kMaxDilFused = 4;
-constexpr int kSpinLimit = 400000;              // bounded waits (~0.3 us per poll): far beyond any launch; running out is loud (NaN losses)
+constexpr int kSpinLimit = 4000000;             // bounded waits (0.3 - 1 us per poll: seconds): far beyond any launch, also one that shares the GPU
+                                                // with long-running kernels of other streams; running out is loud (NaN losses)
 // developer / test hook (bxi_debug_set_spin_limit): 0 = kSpinLimit; negative = every bounded wait gives up at once
 static std::atomic<int> g_spin_limit{0};
 // developer / test hook (bxi_debug_set_eval_form), bits: 0 = the library chooses; 1 = the single launch whenever it is built for the shape
