@@ -42,6 +42,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <ctime>
 
 namespace bxi {
 
@@ -1510,6 +1511,20 @@ static int device_cus() {
 
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
+// true when an evaluation was enqueued on a DIFFERENT stream within the last 2 ms (host clock): evaluations in flight side by side
+static bool other_stream_recently(hipStream_t s) {
+    static std::atomic<uintptr_t> last_stream{0};
+    static std::atomic<int64_t> last_ns{0}, other_ns{0};
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    const int64_t now = (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+    const uintptr_t me = reinterpret_cast<uintptr_t>(s) + 1;
+    const uintptr_t prev = last_stream.exchange(me, std::memory_order_relaxed);
+    const int64_t prev_ns = last_ns.exchange(now, std::memory_order_relaxed);
+    if (prev != 0 && prev != me && now - prev_ns < 2000000ll) other_ns.store(now, std::memory_order_relaxed);
+    return now - other_ns.load(std::memory_order_relaxed) < 2000000ll && other_ns.load(std::memory_order_relaxed) != 0;
+}
+
 // Compute units the stream may use: a CU mask (hipExtStreamCreateWithCUMask, ROC_GLOBAL_CU_MASK) leaves fewer than the device has.
 // The single-launch form needs to know (its stream workgroups must leave free slots for the workgroups they wait for).  Cached per
 // stream handle (a handful of streams per process); a failing query counts as "the whole device".
@@ -1677,8 +1692,12 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         int64_t n_tb = (eval_cap(a.N, a.h, a.w, dil, R) + kWaves - 1) / kWaves;
         if (n_tb > slots / 2) n_tb = slots / 2;
         // the stream workgroups stay on as the first tile workgroups (only while they leave half of the slots to the rest of the grid)
+        // ... unless evaluations are being enqueued on SEVERAL streams at once: each would hold its stream workgroups' slots while
+        // waiting, and three or four of them leave no room for anybody's pool workgroups (measured: 2.4 ms per evaluation with four
+        // streams in flight, against 10 us without the staying-on).  The host cannot see what else runs on the device, but it does
+        // see its own callers: another stream within the last 2 ms means concurrent evaluations.
         static const int env_merge = env_int("BXI_ONE_MERGE", 1);
-        const int merge = env_merge && one_fits ? 1 : 0;
+        const int merge = env_merge && one_fits && !other_stream_recently(s) ? 1 : 0;
         if (merge) n_tb = n_tb > n_stream ? n_tb - n_stream : 0;
         size_t lds = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
         if (lds < 8 * (size_t)kWaves * a.w) lds = 8 * (size_t)kWaves * a.w;

@@ -18,7 +18,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 for t in pairwise_op dynamic_head head_fused discobox levelset tree_filter; do
   [ "$ONLY" = eval-only ] && break
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$t -o $TAG -- python $R/tools/bench_$t.py > $R/gpurun_out/${t}_bench.json 2> $R/gpurun_out/${t}_bench.err
+  # kernel durations under the profiler; the wall-clock JSON from a run WITHOUT it (a row of ~200 tiny launches is twice as slow under rocprofv3)
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$t -o $TAG -- python $R/tools/bench_$t.py > /dev/null 2> $R/gpurun_out/${t}_bench.err
+  timeout 300 python $R/tools/bench_$t.py > $R/gpurun_out/${t}_bench.json 2>> $R/gpurun_out/${t}_bench.err
   tail -c 300 $R/gpurun_out/${t}_bench.json | tr '\n' ' '; echo
 done
 cd $R && python tools/trace_eval.py 2>&1 | grep -v amdgpu.ids > gpurun_out/block_trace.txt; tail -3 gpurun_out/block_trace.txt | cut -c1-300
