@@ -1630,7 +1630,9 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
     Ws ws;
     carve(workspace, batch->B, a.N, a.h, a.w, &ws);
-    {   // this evaluation's tag: 1 .. 2^28 - 1, different from every recent evaluation's in this process
+    {   // this evaluation's tag: 1 .. 2^28 - 1, different from every recent evaluation's in this process.  (It wraps after 2.7e8
+        // evaluations; a stale record could then only pass for a fresh one if its bytes had not been rewritten by ANY of them --
+        // every evaluation rewrites every record of its shape -- and were read again by a shape that reaches them.)
         static std::atomic<unsigned int> epoch{0u};
         unsigned int e = epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;
         e &= 0x0fffffffu;
