@@ -173,25 +173,21 @@ static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
 // launch 1
 // ================================================================================================
 // ---- role 1: table waves (one wave per 64 table entries) --------------------------------------------------------------
-struct LaneBox { int r0, r1, c0, c1, img, cnt, vrow, vcol; };
+struct LaneBox { int r0, r1, c0, c1, img, cnt; };
 __device__ __forceinline__ int valid_cells(int limit_px, int stride, int n) {     // cells r with r*stride + stride/2 < limit_px
     const int half = stride / 2;
     const int v = limit_px - half <= 0 ? 0 : (limit_px - half + stride - 1) / stride;
     return min(v, n);
 }
 __device__ __forceinline__ LaneBox lane_box(const InstArgs& a, const ImageMeta& meta, int dil, int R, int m) {
-    LaneBox lb = {0, 0, 0, 0, 0, 0, 0, 0};
+    LaneBox lb = {0, 0, 0, 0, 0, 0};
     const int64_t g = a.gt_inds[m];
     const float* bp = nullptr;
-    int ih = 0, iw = 0, fr = 0;
     for (int b = 0; b < a.gt.B; ++b)      // uniform loop: the by-value kernel arguments are never indexed per lane
         if (g >= a.gt.first[b] && g < a.gt.first[b + 1]) {
             bp = a.gt.boxes[b] + 4 * (g - a.gt.first[b]); lb.img = b;
-            ih = meta.img_h[b]; iw = meta.img_w[b]; fr = meta.first_removed[b];
         }
     if (!bp) return lb;
-    lb.vrow = valid_cells(min(ih, fr), a.stride, a.h);      // valid(q) <=> y(q) < img_h && y(q) < first_removed && x(q) < img_w (:1354-1369,:1405)
-    lb.vcol = valid_cells(iw, a.stride, a.w);
     const Rect rc = box_rect(bp, a.Hc, a.Wc, a.stride, a.stride / 2, a.h, a.w);
     if (rc.r1 <= rc.r0 || rc.c1 <= rc.c0) return lb;
     lb.r0 = rc.r0; lb.r1 = rc.r1; lb.c0 = rc.c0; lb.c1 = rc.c1;
@@ -206,10 +202,10 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
                                            bool write_status) {
     const int lane = threadIdx.x & 63;
     int base = 0, prefix = 0;
-    LaneBox mine = {0, 0, 0, 0, 0, 0, 0, 0};
+    LaneBox mine = {0, 0, 0, 0, 0, 0};
     for (int m0 = 0; m0 <= 64 * k; m0 += 64) {       // exclusive scan of the tile counts: deterministic offsets, no atomics
         const int m = m0 + lane;
-        LaneBox lb = {0, 0, 0, 0, 0, 0, 0, 0};
+        LaneBox lb = {0, 0, 0, 0, 0, 0};
         if (m < a.N) lb = lane_box(a, meta, dil, R, m);
         int incl = lb.cnt;
 #pragma unroll
