@@ -211,23 +211,25 @@ def worker(args):
                 graphs.append(g)
         stream.synchronize()
 
+    st = stream.cuda_stream
+
     def run(n_steps: int, first: int = 0, comm: bool = True) -> None:
+        # (called with `stream` current: the measurement below runs inside ONE `with torch.cuda.stream(stream)` block, so that the
+        # timed region holds the steps and not the harness's context switch)
         works = []
-        with torch.cuda.stream(stream):
-            st = stream.cuda_stream
-            for i in range(first, first + n_steps):
-                k = i % len(sets)
-                if graphs is not None:
-                    graphs[k].replay()
-                else:
-                    enqueue(sets[k], st)
-                if dist is not None and comm:
-                    bucket[k][-2:].copy_(sets[k].losses, non_blocking=True)      # the two logged scalars ride in the bucket
-                    works.append(dist.all_reduce(bucket[k], async_op=True))
-                    if len(works) > 2 * len(sets):                                # bound the work queue, keep buffers safe
-                        works.pop(0).wait()
-            for wk in works:
-                wk.wait()
+        for i in range(first, first + n_steps):
+            k = i % len(sets)
+            if graphs is not None:
+                graphs[k].replay()
+            else:
+                enqueue(sets[k], st)
+            if dist is not None and comm:
+                bucket[k][-2:].copy_(sets[k].losses, non_blocking=True)      # the two logged scalars ride in the bucket
+                works.append(dist.all_reduce(bucket[k], async_op=True))
+                if len(works) > 2 * len(sets):                                # bound the work queue, keep buffers safe
+                    works.pop(0).wait()
+        for wk in works:
+            wk.wait()
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -243,6 +245,8 @@ def worker(args):
             torch.cuda.synchronize(dev)
             n += 256
 
+    prev_stream = torch.cuda.current_stream(dev)
+    torch.cuda.set_stream(stream)          # `stream` stays current from here to the end of the timed region
     run(args.warmup)
     # launches per step, counted: the launch hook is called before and after every kernel launch the library makes
     calls = []
@@ -266,6 +270,7 @@ def worker(args):
     elapsed = time.perf_counter() - t0
     torch.cuda.synchronize(dev)
     barrier()
+    torch.cuda.set_stream(prev_stream)
     local_elapsed = elapsed
     allreduce_us = None
     if dist is not None:
