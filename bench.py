@@ -17,11 +17,12 @@ reads cold data.  Before the timed region the GPU is kept busy for >= 0.15 s wha
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 `python bench.py --gpus N` without RANK in the environment spawns the N ranks itself (one process per GPU, backend nccl
-= RCCL).  The path has no exchange step (every unit is rank-local): ranks are weak-scaled replicas.  What a
-training job all-reduces AROUND the path is in the timed region for N > 1: per evaluation ONE RCCL all-reduce of a
-buffer the size of the mask head's `param_conv` parameters (537 065 f32 = 2.15 MB, mmdet/models/detectors/base.py:201-217
-+ DDP) carrying the two loss scalars in its tail, issued asynchronously so that it overlaps the next evaluations.
-Rank 0 prints ONE JSON line.
+= RCCL).  The path has no exchange step (every unit is rank-local): ranks are weak-scaled replicas and the timed region
+holds no collective (RCCL carries the barriers around it and the MAX over the ranks' clocks).  What a training job all-reduces AROUND
+the path is measured beside it, as an extra (`multi_gpu.*_extra`): per evaluation ONE RCCL all-reduce of a buffer the size of the mask
+head's `param_conv` parameters (537 065 f32 = 2.15 MB, mmdet/models/detectors/base.py:201-217 + DDP) carrying the two loss scalars in
+its tail, issued asynchronously so that it overlaps the next evaluations.
+Rank 0 prints ONE JSON line on stdout (whatever libraries print there -- RCCL's version banner -- is sent to stderr).
 """
 from __future__ import annotations
 
@@ -119,6 +120,11 @@ def main():
 
 
 def worker(args):
+    # stdout carries ONE JSON line: everything else a library prints there (RCCL's version banner at communicator creation) goes to
+    # stderr -- file descriptor 1 is pointed at stderr for the duration, the JSON is written to a duplicate of the original
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -263,7 +269,7 @@ def worker(args):
     barrier()
     done = torch.cuda.Event()
     t0 = time.perf_counter()
-    run(args.steps, first=args.warmup)
+    run(args.steps, first=args.warmup, comm=False)   # the path has no exchange step: no collective in the timed region
     done.record(stream)
     while not done.query():              # completion observed by polling: a blocking synchronize adds its wake-up latency
         pass                             # (10-30 us: 5 % of a 20-step run) to the interval; the synchronize still follows
@@ -285,12 +291,16 @@ def worker(args):
                 dist.all_reduce(bucket[i % len(bucket)])
         torch.cuda.synchronize(dev)
         allreduce_us = (time.perf_counter() - t1) / 100 * 1e6
-        # and the evaluations alone on this rank (no collective in the loop)
+        # extra (not `value`): the same steps with what a training job all-reduces AROUND the path riding along -- per evaluation one
+        # asynchronous RCCL all-reduce of a param_conv-sized bucket carrying the two loss scalars, overlapping the next evaluations
         preroll()
+        barrier()
+        torch.cuda.set_stream(stream)
         t1 = time.perf_counter()
-        run(args.steps, comm=False)
+        run(args.steps, comm=True)
         torch.cuda.synchronize(dev)
-        eval_only = time.perf_counter() - t1
+        with_comm = time.perf_counter() - t1
+        torch.cuda.set_stream(prev_stream)
     images = 2 * args.steps * world
     value = images / elapsed
     step_us = elapsed / args.steps * 1e6
@@ -317,9 +327,10 @@ def worker(args):
             'world_size': dist.get_world_size(), 'backend': 'nccl (RCCL)', 'ranks': ranks,
             'distinct_devices': len({(r['pci_bus_id'], r['uuid']) for r in ranks}),
             'per_rank_images_per_s': 2 * args.steps / local_elapsed,
-            'per_rank_images_per_s_without_collectives': 2 * args.steps / eval_only,
-            'allreduce_per_evaluation': f'{(PARAM_CONV_FLOATS + 2) * 4} B (param_conv-sized gradient bucket + the 2 loss scalars), '
-                                        'async, overlapping the following evaluations',
+            'per_rank_images_per_s_with_bucket_allreduce_extra': 2 * args.steps / with_comm,
+            'allreduce_per_evaluation_extra': f'{(PARAM_CONV_FLOATS + 2) * 4} B (param_conv-sized gradient bucket + the 2 loss scalars), '
+                                              'async, overlapping the following evaluations; NOT part of `value`: the path has no '
+                                              'exchange step, this is what DDP does around it',
             'allreduce_alone_us': allreduce_us}
     if parity is not None:
         result['parity'] = parity
@@ -386,10 +397,11 @@ def worker(args):
         result.update(kernel_timing(lib, _lib, sets, stream, enqueue, min(max(args.steps, 50), 200), step_us, status[1]))
     if cpu_leg is not None:
         result['cpu_baseline'] = cpu_leg
-    if rank == 0:
-        print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        json_out.write(json.dumps(result) + '\n')
+        json_out.flush()
 
 
 def head_fused(lib, Fh, sets, dev, stream, steps):
