@@ -1509,8 +1509,12 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 
 // true when an evaluation was enqueued on a DIFFERENT stream within the last 2 ms (host clock): evaluations in flight side by side
 static bool other_stream_recently(hipStream_t s) {
-    static std::atomic<uintptr_t> last_stream{0};
-    static std::atomic<int64_t> last_ns{0}, other_ns{0};
+    struct PerDevice { std::atomic<uintptr_t> last_stream{0}; std::atomic<int64_t> last_ns{0}, other_ns{0}; };
+    static PerDevice per_device[64];                  // streams of different devices do not compete for slots
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    std::atomic<uintptr_t>& last_stream = per_device[dev].last_stream;
+    std::atomic<int64_t>&last_ns = per_device[dev].last_ns, &other_ns = per_device[dev].other_ns;
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     const int64_t now = (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
@@ -1527,7 +1531,9 @@ static bool other_stream_recently(hipStream_t s) {
 static int stream_cus(hipStream_t s, int device_total) {
     struct Entry { std::atomic<uintptr_t> key; std::atomic<int> cus; };
     static Entry cache[8];
-    const uintptr_t k = reinterpret_cast<uintptr_t>(s) + 1;            // +1: the null stream is a key too
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    const uintptr_t k = (reinterpret_cast<uintptr_t>(s) + 1) ^ ((uintptr_t)(unsigned)dev << 56);   // +1: the null stream is a key too; per device
     for (auto& e : cache)
         if (e.key.load(std::memory_order_acquire) == k) return e.cus.load(std::memory_order_relaxed);
     uint32_t mask[32] = {};
