@@ -215,6 +215,18 @@ def test_general_dynamic_head_shapes_in_hip(dev, convs, ch, cin, no_rel, fac, sh
     assert torch.equal(again, got) and torch.equal(fd2.grad, fd.grad) and torch.equal(pd2.grad, pd.grad)
 
 
+@pytest.mark.parametrize('seed', range(10))
+def test_general_dynamic_head_fuzz(dev, seed):
+    """Random head shapes inside the general kernels' limits (1-4 layers, 2-16 channels, 1-32 feature channels, with / without relative
+    coordinates, factors 1-4, ragged instance -> image maps, maps that are not multiples of the 8 x 32 tile)."""
+    r = np.random.default_rng(7700 + seed)
+    convs, ch, cin = int(r.integers(1, 5)), int(r.integers(2, 17)), int(r.integers(1, 33))
+    no_rel = bool(r.integers(0, 2))
+    fac = int(r.integers(1, 5))
+    shape = (int(r.integers(1, 4)), int(r.integers(1, 30)), int(r.integers(1, 70)), int(r.integers(1, 12)))
+    test_general_dynamic_head_shapes_in_hip(dev, convs, ch, cin, no_rel, fac, shape)
+
+
 def test_general_dynamic_head_empty_and_limits(dev):
     from boxinstseg_amd import CondInstMaskHead
     from boxinstseg_amd import dynamic as dyn
