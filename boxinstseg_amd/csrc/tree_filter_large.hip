@@ -387,7 +387,8 @@ struct RefineArgsL {
     char* ws; size_t ws_stride;
 };
 constexpr int kPadL = 4;
-constexpr int kWinL = 4096;            // records per LDS window of the leaf->root walk (64 KB + 16 KB of level offsets); a power of two: slot = i & (kWinL - 1)
+constexpr int kWinL = 8192;            // records per LDS window of the leaf->root walk (128 KB); a power of two: slot = i & (kWinL - 1)
+constexpr int kWinLv = 2048;           // levels per window at most (8 KB of level offsets)
 static size_t refine_large_block_bytes(int V) { return up16(16 * (size_t)(V + kPadL)) + up16(4 * (size_t)V) + up16(16 * (size_t)(V + kPadL)) + 16; }
 size_t refine_large_ws_bytes(int B, int C, int V) { return refine_large_block_bytes(V) * (size_t)(B > 0 ? B : 1) * (size_t)C; }
 
@@ -467,14 +468,14 @@ __global__ __launch_bounds__(kLT) void refineL_up_kernel(RefineArgsL a) {
     const int D = max(lv[0], 0);
     extern __shared__ __attribute__((aligned(16))) unsigned char win_raw[];
     float4* win = reinterpret_cast<float4*>(win_raw);                           // [kWinL] record i lives in slot i % kWinL
-    int* wlv = reinterpret_cast<int*>(win_raw + sizeof(float4) * kWinL);        // [kWinL + 2] level offsets of the window's levels
+    int* wlv = reinterpret_cast<int*>(win_raw + sizeof(float4) * kWinL);        // [kWinLv + 2] level offsets of the window's levels
     __shared__ int w_llo;
     for (int cur = D - 1; cur >= 0;) {
         // the window ends behind the children of level `cur` and starts at the lowest level whose first node still fits
         const int whi = cur + 1 <= D - 1 ? lv[3 + cur] : lv[2 + cur];
         const int bound = whi - kWinL;
         if (tid < 64) {                                                          // 64-ary search for the smallest level l <= cur with lv[1 + l] >= bound
-            int a_ = 0, b_ = cur;
+            int a_ = max(0, cur - (kWinLv - 2)), b_ = cur;                       // (at most kWinLv levels per window)
             while (b_ > a_) {
                 const int step = (b_ - a_ + 63) / 64;
                 const int l = min(a_ + tid * step, b_);
@@ -507,15 +508,23 @@ __global__ __launch_bounds__(kLT) void refineL_up_kernel(RefineArgsL a) {
         __syncthreads();
         if (tid < 64) {
             const int lane = tid;
+            const float* winf = reinterpret_cast<const float*>(win);
+            int lo = wlv[cur - llo], hi = wlv[cur - llo + 1];
+            // the child-range word of a node never changes: the next level's words are fetched while this level is computed, so
+            // that a level costs ONE dependent LDS round trip (own values + children together), not two
+            uint32_t fpre = __float_as_uint(winf[4 * ((lo + lane) & (kWinL - 1)) + 3]);
             for (int l = cur; l >= llo; --l) {
-                const int lo = wlv[l - llo], hi = wlv[l - llo + 1];
+                const int nlo = l > llo ? wlv[l - 1 - llo] : lo;
+                const uint32_t fnext = __float_as_uint(winf[4 * ((nlo + lane) & (kWinL - 1)) + 3]);
+                bool first = true;
                 for (int i = lo + lane; i < hi; i += 64) {
-                    float4 r = win[i & (kWinL - 1)];
-                    const uint32_t f = __float_as_uint(r.w);
+                    const uint32_t f = first ? fpre : __float_as_uint(winf[4 * (i & (kWinL - 1)) + 3]);
+                    first = false;
                     const int c0 = f & 0x0fffffffu, nc = f >> 28;
+                    float4 r = win[i & (kWinL - 1)];
                     float4 chd[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) chd[k] = win[(c0 + k) & (kWinL - 1)];  // unconditional: one LDS round trip per level
+                    for (int k = 0; k < 4; ++k) chd[k] = win[(c0 + k) & (kWinL - 1)];  // unconditional
 #pragma unroll
                     for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(chd[k].x), "+v"(chd[k].y), "+v"(chd[k].z));
 #pragma unroll
@@ -527,6 +536,7 @@ __global__ __launch_bounds__(kLT) void refineL_up_kernel(RefineArgsL a) {
                     rec[i] = r;                                                  // written through; nobody reads it before the next barrier
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the level's LDS writes before the next level's reads (one wave: in order)
+                fpre = fnext; hi = lo; lo = nlo;
             }
         }
         __syncthreads();
@@ -607,7 +617,7 @@ int launch_refine_large(const void* planes2 /* RefinePlaneL[2] layout */, const 
     BXI_LAUNCH("tree_refine_large_clear", s, refineL_clear_kernel, dim3((unsigned)((B * C + 63) / 64)), dim3(64), 0, s, a);
     BXI_LAUNCH("tree_refine_large_stage", s, refineL_stage_kernel, over_nodes, dim3(256), 0, s, a);
     {
-        const size_t lds = sizeof(float4) * kWinL + sizeof(int) * (kWinL + 2);
+        const size_t lds = sizeof(float4) * kWinL + sizeof(int) * (kWinLv + 2);
         static std::atomic<int> attr_set{0};
         if (!attr_set.load(std::memory_order_relaxed)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(refineL_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
