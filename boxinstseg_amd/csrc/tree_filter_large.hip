@@ -25,14 +25,13 @@ constexpr int kLT = 1024;
 __host__ __device__ static inline size_t up16(size_t v) { return (v + 15) / 16 * 16; }
 
 // ---------------------------------------------------------------------------------------------------
-struct MstLargeWs { u64* best; uint32_t* comp; uint32_t* link; uint32_t* chosen; uint32_t* link2; };
+struct MstLargeWs { u64* best; uint32_t* comp; uint32_t* link; uint32_t* chosen; };
 __host__ __device__ static size_t carve_mst_large(char* base, int E, int V, MstLargeWs* w) {
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += up16(b); return base ? base + o : nullptr; };
     MstLargeWs t;
     t.best = (u64*)take(8 * (size_t)V); t.comp = (uint32_t*)take(4 * (size_t)V); t.link = (uint32_t*)take(4 * (size_t)V);
     t.chosen = (uint32_t*)take(4 * (size_t)((E + 31) / 32));
-    t.link2 = (uint32_t*)take(4 * (size_t)V);
     if (w) *w = t;
     return off;
 }
@@ -40,9 +39,8 @@ size_t mst_large_ws_bytes(int E, int V) { return carve_mst_large(nullptr, E, V, 
 
 // Boruvka ACROSS THE GPU: every phase of a round is a grid over the edges / vertices of all graphs, a kernel boundary between
 // phases is the grid barrier (one 1024-thread workgroup per graph took 2.5 ms at 60 800 vertices / 121 000 edges: 16 rounds of
-// ~120 edges per thread, each with two dependent atomics).  The number of rounds and of pointer-jumping steps is fixed on the host
-// (the component count at least halves per round: round r has at most V / 2^r components, so its hook chains need at most
-// ceil(log2 V) - r jumps); rounds after the tree is complete find no edge and change nothing.
+// ~120 edges per thread, each with two dependent atomics).  The number of rounds is fixed on the host (the component count at least
+// halves per round: ceil(log2 V) rounds); rounds after the tree is complete find no edge and change nothing.
 __device__ __forceinline__ MstLargeWs mst_ws(char* ws_base, size_t ws_stride, int b, int E, int V) {
     MstLargeWs w;
     carve_mst_large(ws_base + (size_t)b * ws_stride, E, V, &w);
@@ -95,23 +93,25 @@ __global__ __launch_bounds__(256) void mstL_mutual_kernel(int E, int V, char* ws
     // (c < o decides alone: the partner, if it also points back, keeps its link to c)
     if (o != (uint32_t)c && (uint32_t)c < o && w.link[o] == (uint32_t)c) w.link[c] = (uint32_t)c;
 }
-// one pointer-jumping step, out of place: link2[c] = link[link[c]]
-__global__ __launch_bounds__(256) void mstL_jump_kernel(int E, int V, char* ws_base, size_t ws_stride, int flip) {
-    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= V) return;
-    const MstLargeWs w = mst_ws(ws_base, ws_stride, b, E, V);
-    const uint32_t* src = flip ? w.link2 : w.link;
-    uint32_t* dst = flip ? w.link : w.link2;
-    if (w.comp[c] != (uint32_t)c) { dst[c] = src[c]; return; }
-    dst[c] = src[src[c]];
-}
 // comp[v] = root of comp[v]; the next round's offers start from scratch
-__global__ __launch_bounds__(256) void mstL_relabel_kernel(int E, int V, char* ws_base, size_t ws_stride, int flip) {
+__global__ __launch_bounds__(256) void mstL_relabel_kernel(int E, int V, char* ws_base, size_t ws_stride) {
     const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
     if (v >= V) return;
     const MstLargeWs w = mst_ws(ws_base, ws_stride, b, E, V);
-    const uint32_t* lk = flip ? w.link2 : w.link;
-    w.comp[v] = lk[w.comp[v]];           // in place: a thread reads only its own entry of comp
+    uint32_t* lk = w.link;
+    // The hook chains are walked here (a root points to itself), with PATH HALVING: every node a walker passes is re-pointed at its
+    // grandparent, so concurrent walkers shorten each other's way and even a chain as long as the graph (a 1 x V strip with
+    // increasing weights) costs O(log) steps per thread.  The re-pointing races with other readers, harmlessly: a link only ever
+    // moves to an ancestor, and the root a walk ends at is the chain's one self-pointing node whatever it saw on the way.
+    uint32_t r = w.comp[v];
+    for (;;) {
+        const uint32_t p = lk[r];
+        if (p == r) break;
+        const uint32_t gp = lk[p];
+        if (gp != p) lk[r] = gp;
+        r = gp;
+    }
+    w.comp[v] = r;
     w.best[v] = ~0ull;
 }
 // tree edges in ascending edge order: (1) exclusive prefix of the bitmap words' popcounts (one workgroup per graph: a few thousand
@@ -169,9 +169,9 @@ int launch_mst_large(const int* edge_index, const float* edge_weight, int B, int
         BXI_LAUNCH("mst_large_offer", s, mstL_offer_kernel, ge, dim3(256), 0, s, edge_index, edge_weight, E, V, ws, stride);
         BXI_LAUNCH("mst_large_hook", s, mstL_hook_kernel, gv, dim3(256), 0, s, edge_index, E, V, ws, stride);
         BXI_LAUNCH("mst_large_mutual", s, mstL_mutual_kernel, gv, dim3(256), 0, s, E, V, ws, stride);
-        const int jumps = rounds - r > 1 ? rounds - r : 1;
-        for (int j = 0; j < jumps; ++j) BXI_LAUNCH("mst_large_jump", s, mstL_jump_kernel, gv, dim3(256), 0, s, E, V, ws, stride, j & 1);
-        BXI_LAUNCH("mst_large_relabel", s, mstL_relabel_kernel, gv, dim3(256), 0, s, E, V, ws, stride, jumps & 1);
+        // (pointer-jumping kernels in front of the relabel kernel's halving walk -- ceil(log2 V) - r, 3, 2, 1 of them -- measured 680,
+        // 330-370, 290-305, 235-243 us per MST at 200 x 304 against 195-216 us without: every launch costs more than the steps it saves)
+        BXI_LAUNCH("mst_large_relabel", s, mstL_relabel_kernel, gv, dim3(256), 0, s, E, V, ws, stride);
     }
     if (nw > V) return BXI_ERR_UNSUPPORTED;               // (the word prefixes reuse the link array; E <= 8 V is checked by the caller)
     BXI_LAUNCH("mst_large_scan", s, mstL_scan_kernel, dim3(B), dim3(kLT), 0, s, E, V, n_out, ws, stride);
