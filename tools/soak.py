@@ -7,16 +7,22 @@ import numpy as np, torch
 from boxinstseg_amd import functional as Fh, synthetic
 from tests.helpers import to_dev
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+hog = len(sys.argv) > 2 and sys.argv[2] == 'hog'      # a second stream keeps every CU busy with matrix products meanwhile
 dev = torch.device('cuda:0')
 Fh.DEBUG_KEEP_LAST = True
 cases = [synthetic.cfg2(0), synthetic.cfg1(0), synthetic.make_batch(B=2, H=800, W=1024, boxes_per_img=16, inst_per_box=2, seed=3),
          synthetic.make_batch(B=3, H=160, W=224, boxes_per_img=3, seed=5, min_box=12, max_box=120, img_shapes=[[150, 200], [160, 224], [121, 183]])]
 bad = 0
 t0 = time.time()
+hs = torch.cuda.Stream(device=dev)
+hm = torch.randn(4096, 4096, device=dev)
 for ci, d in enumerate(cases):
     t = to_dev(d, dev)
     first = None
     for i in range(n):
+        if hog and i % 4 == 0:
+            with torch.cuda.stream(hs):
+                hm = (hm @ hm).clamp_(-1.0, 1.0)
         x = t['logits'].clone().requires_grad_(True)
         out = Fh.boxinst_mask_loss(x, t['gt_inds'], t['gt_bboxes'], imgs=t['imgs'], img_metas=d['img_metas'], out_stride=d['stride'])
         (out['loss_prj'] + out['loss_pairwise']).backward()
