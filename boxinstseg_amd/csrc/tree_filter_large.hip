@@ -180,14 +180,14 @@ int launch_mst_large(const int* edge_index, const float* edge_weight, int B, int
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct BfsLargeWs { uint32_t* adj; uint32_t* deg; uint32_t* nodev; uint32_t* nodep; uint32_t* pos_of; int* flag; int* nf; };
+struct BfsLargeWs { uint32_t* adj; uint32_t* deg; uint32_t* nodev; uint32_t* nodep; uint32_t* pos_of; int* flag; int* nf; int* gw; unsigned char* gmask; };
 __host__ __device__ static size_t carve_bfs_large(char* base, int V, BfsLargeWs* w) {
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += up16(b); return base ? base + o : nullptr; };
     BfsLargeWs t;
     t.adj = (uint32_t*)take(16 * (size_t)V); t.deg = (uint32_t*)take(4 * (size_t)V); t.nodev = (uint32_t*)take(4 * (size_t)(V + 1));
     t.nodep = (uint32_t*)take(4 * (size_t)(V + 1)); t.pos_of = (uint32_t*)take(4 * (size_t)V);
-    t.flag = (int*)take(4); t.nf = (int*)take(4);
+    t.flag = (int*)take(4); t.nf = (int*)take(4); t.gw = (int*)take(4); t.gmask = (unsigned char*)take((size_t)V);
     if (w) *w = t;
     return off;
 }
@@ -210,9 +210,11 @@ __device__ __forceinline__ int block_excl_scan(int v, int* part /*[17]*/, int& t
 }
 
 // BFS of a large tree: the passes over the vertices / edges (adjacency, sorting, outputs) run ACROSS THE GPU; only the level walk
-// -- a chain through the tree's depth, ~1500 levels at 200 x 304 -- is one workgroup per graph, and while the frontier is at most
-// 64 nodes wide (the usual case: ~40) it is ONE WAVE with the frontier in LDS: per level one dependent global round trip (the
-// adjacency of the frontier's nodes), four ballots for the children's places, no workgroup barrier.
+// -- a chain through the tree's depth, ~1700 levels at 200 x 304 -- is one workgroup per graph, and while the frontier is at most
+// 256 nodes wide (measured on random 200 x 304 trees: mean 35, max ~115) it is ONE WAVE with the frontier in LDS: per level one dependent read of the adjacency of the
+// frontier's nodes, four ballots for the children's places, no workgroup barrier.  A tree on a 4-connected grid (what the callers
+// build: tree_filter_oracle / MinimumSpanningTree over grid edges) keeps that adjacency as four bits per vertex in LDS, so the walk
+// makes no global read at all; any other tree of degree <= 4 reads the 16-byte records from (warmed) L2.
 __device__ __forceinline__ BfsLargeWs bfs_ws(char* ws_base, size_t ws_stride, int b, int V) {
     BfsLargeWs w;
     carve_bfs_large(ws_base + (size_t)b * ws_stride, V, &w);
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256) void bfsL_zero_kernel(int V, int max_adj, int*
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
     if (i < V) w.deg[i] = 0u;
-    if (i == 0) *w.flag = 0;
+    if (i == 0) { *w.flag = 0; *w.gw = 0; }
     if (i < (int64_t)V * max_adj) sorted_child[(int64_t)b * V * max_adj + i] = 0;
 }
 __global__ __launch_bounds__(256) void bfsL_adj_kernel(const int* __restrict__ tree, int V, char* ws_base, size_t ws_stride) {
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(256) void bfsL_adj_kernel(const int* __restrict__ t
     const unsigned su = atomicAdd(&w.deg[u], 1u), sv = atomicAdd(&w.deg[v], 1u);
     if (su < 4) w.adj[4 * (size_t)u + su] = (uint32_t)v;
     if (sv < 4) w.adj[4 * (size_t)v + sv] = (uint32_t)u;
+    atomicMax(w.gw, u > v ? u - v : v - u);              // on a 4-connected grid: its width
 }
 __global__ __launch_bounds__(256) void bfsL_sort_kernel(int V, char* ws_base, size_t ws_stride) {
     const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
@@ -246,63 +249,169 @@ __global__ __launch_bounds__(256) void bfsL_sort_kernel(int V, char* ws_base, si
     for (int k = 0; k < 4; ++k) a[k] = k < d ? w.adj[4 * (size_t)v + k] : 0xffffffffu;
     for (int i = 1; i < 4; ++i) for (int j = i; j > 0 && a[j - 1] > a[j]; --j) { const uint32_t t = a[j]; a[j] = a[j - 1]; a[j - 1] = t; }
     *reinterpret_cast<uint4*>(w.adj + 4 * (size_t)v) = make_uint4(a[0], a[1], a[2], a[3]);
+    // a tree on a 4-connected grid of width W (what mst() is given: every edge joins v and v +- 1 or v +- W) has its whole adjacency
+    // in four bits per vertex -- v - W, v - 1, v + 1, v + W, which is also the ascending order -- and then fits LDS
+    const int W = *w.gw;
+    unsigned m = 0u;
+    bool grid = W > 1;
+    for (int k = 0; k < d; ++k) {
+        const int delta = (int)a[k] - v;
+        const int bit = delta == -W ? 0 : (delta == -1 ? 1 : (delta == 1 ? 2 : (delta == W ? 3 : -1)));
+        if (bit < 0) grid = false; else m |= 1u << bit;
+    }
+    w.gmask[v] = (unsigned char)m;
+    if (!grid) atomicOr(w.flag, 2);
 }
 
-__global__ __launch_bounds__(kLT) void bfsL_walk_kernel(int V, int* __restrict__ levels, char* ws_base, size_t ws_stride) {
-    __shared__ int part[17];
-    __shared__ uint32_t fv[256], fp[256];                 // the next frontier of the one-wave form (<= 4 children of <= 64 nodes)
-    __shared__ int s_lo, s_hi, s_n, s_depth;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
-    int* lv = levels + (int64_t)b * (V + 2);
-    if (tid == 0) { w.nodev[0] = 0u; w.nodep[0] = 0xffffffffu; lv[1] = 0; fv[0] = 0u; fp[0] = 0xffffffffu; }
-    // every adjacency record is read exactly once by the walk, one dependent read per level: bring the table (16 B per vertex, 1 MB at
-    // 200 x 304) into this XCD's L2 first, with the whole workgroup, so that the walk's reads are L2 hits instead of trips to HBM
-    {
-        uint32_t sink = 0u;
-        for (int v = tid; v < V; v += kLT) { const uint4 q = *reinterpret_cast<const uint4*>(w.adj + 4 * (size_t)v); sink ^= q.x ^ q.y ^ q.z ^ q.w; }
-        asm volatile("" ::"v"(sink));
-    }
-    __syncthreads();
+constexpr int kBfsNarrow = 256;                    // widest frontier the one-wave form walks (four nodes per lane)
+constexpr int kBfsNext = 3 * kBfsNarrow + 4;
+constexpr int kBfsMaskCap = 128 * 1024;            // vertices whose 4-bit adjacency (a byte each) the walk keeps in LDS
+struct BfsWalkLds {
+    int part[17];
+    uint2 fr[2][kBfsNext];                              // the frontier of the one-wave form and the next one; <= 3 children of <= 256 nodes (the root: 4).
+                                                        // General trees: (vertex, parent) pairs.  Grid trees: the same bytes as two buffers of words.
+    int s_lo, s_hi, s_n, s_depth;
+};
+// ---- grid trees: a node is ONE word, vertex | (one-hot direction of its parent) << 20, in LDS and in nodev (nodep is not used); the
+// directions are 0: v - W, 1: v - 1, 2: v + 1, 3: v + W.  The walk's loop has no global LOAD in it, so nothing ever waits for its global
+// stores (gfx9 counts loads and stores in one vmcnt: with a load in the loop every level also waits for the previous level's stores),
+// and it is short: one wave alone issues an instruction every ~5 cycles, so the level time is the instruction count (profiles/NOTES.md R3-2c).
+constexpr uint32_t kBfsVtx = 0xFFFFFu;
+static_assert(kBfsMaskCap <= (int)kBfsVtx, "a grid node is vertex | direction << 20");
+__device__ __forceinline__ bool bfs_grid_mode(const BfsLargeWs& w, int V) { return !(*w.flag & 2) && V <= kBfsMaskCap; }
+__device__ __forceinline__ uint32_t bfs_grid_parent(uint32_t e, int GW) {
+    const uint32_t v = e & kBfsVtx, pm = e >> 20;
+    return (pm & 1u) ? v - (uint32_t)GW : ((pm & 2u) ? v - 1u : ((pm & 4u) ? v + 1u : v + (uint32_t)GW));
+}
+__device__ __forceinline__ void bfs_walk_grid(int V, int GW, int* __restrict__ lv, const BfsLargeWs& w, const unsigned char* lmask, BfsWalkLds& L) {
+    const int tid = threadIdx.x;
+    uint32_t* fr0 = reinterpret_cast<uint32_t*>(&L.fr[0][0]);     // two buffers of kBfsNext words
+    const uint32_t off[4] = {(uint32_t)-GW, 0xffffffffu, 1u, (uint32_t)GW};
     int lo = 0, hi = 1, n = 1, depth = 0;
     while (lo < hi) {                                   // workgroup-uniform
-        if (hi - lo <= 64) {
-            // ---- one wave walks while the frontier stays narrow; the other waves wait at the barrier below
+        if (hi - lo <= kBfsNarrow) {
+            // ---- one wave walks while the frontier stays narrow, 64 nodes at a time in frontier order; a node is written to nodev when it
+            // is PROCESSED (one coalesced store per 64 nodes), its children go to the other LDS buffer.  On entry the frontier is in buffer 0.
             if (tid < 64) {
                 const int lane = tid;
-                while (lo < hi && hi - lo <= 64) {
-                    const bool act = lane < hi - lo;
-                    const uint32_t cur = act ? fv[lane] : 0u, par = act ? fp[lane] : 0u;
-                    const uint4 q = act ? *reinterpret_cast<const uint4*>(w.adj + 4 * (size_t)cur) : make_uint4(~0u, ~0u, ~0u, ~0u);
-                    const uint32_t nb[4] = {q.x, q.y, q.z, q.w};
-                    bool ok[4];
-                    int before = 0, mine = 0, total = 0;
-                    const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        ok[k] = act && nb[k] != 0xffffffffu && nb[k] != par;
-                        const unsigned long long m = __ballot(ok[k]);
-                        before += __popcll(m & lt);
-                        total += __popcll(m);
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every lane has read its frontier slot before it is overwritten
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (ok[k]) {
-                            const int slot = before + mine;
-                            fv[slot] = nb[k]; fp[slot] = cur;
-                            w.nodev[n + slot] = nb[k]; w.nodep[n + slot] = cur;
-                            ++mine;
+                int cb = 0;
+                while (lo < hi && hi - lo <= kBfsNarrow) {
+                    const int width = hi - lo;
+                    const uint32_t* cur_f = fr0 + cb * kBfsNext;
+                    uint32_t* next_f = fr0 + (cb ^ 1) * kBfsNext;
+                    int total = 0;
+                    for (int c = 0; c < width; c += 64) {
+                        uint32_t e = 0u, m = 0u;
+                        if (c + lane < width) {
+                            e = cur_f[c + lane];
+                            w.nodev[lo + c + lane] = e;
+                            m = (uint32_t)lmask[e & kBfsVtx] & ~(e >> 20);
                         }
+                        const uint32_t cur = e & kBfsVtx;
+                        int slot = total;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned long long mk = __ballot((m >> k) & 1u);
+                            slot = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, (uint32_t)slot));
+                            total += __popcll(mk);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if ((m >> k) & 1u) { next_f[slot] = (cur + off[k]) | ((8u >> k) << 20); ++slot; }
+                    }
                     ++depth;
                     if (lane == 0) lv[1 + depth] = hi;                           // off[depth] = end of this level
                     lo = hi; hi = n + total; n += total;
+                    cb ^= 1;
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the next frontier is in LDS (one wave: its LDS operations execute in order)
                 }
-                if (lane == 0) { s_lo = lo; s_hi = hi; s_n = n; s_depth = depth; }
+                // a frontier too wide for one wave: the workgroup continues from nodev
+                if (lo < hi) { const uint32_t* f = fr0 + cb * kBfsNext; for (int i = lane; i < hi - lo; i += 64) w.nodev[lo + i] = f[i]; }
+                if (lane == 0) { L.s_lo = lo; L.s_hi = hi; L.s_n = n; L.s_depth = depth; }
+            }
+            __syncthreads();                             // also: the walking wave's global stores are done (vmcnt) before others read them
+            lo = L.s_lo; hi = L.s_hi; n = L.s_n; depth = L.s_depth;
+            __syncthreads();
+            continue;
+        }
+        for (int base = lo; base < hi; base += kLT) {
+            const int i = base + tid;
+            const uint32_t e = i < hi ? w.nodev[i] : 0u;
+            const uint32_t cur = e & kBfsVtx;
+            const uint32_t m = i < hi ? ((uint32_t)lmask[cur] & ~(e >> 20)) : 0u;
+            int total;
+            int slot = n + block_excl_scan(__popc(m), L.part, total);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((m >> k) & 1u) {
+                    const uint32_t ne = (cur + off[k]) | ((8u >> k) << 20);
+                    w.nodev[slot] = ne;
+                    if (slot - hi < kBfsNarrow) fr0[slot - hi] = ne;             // in case the next level is narrow (n == hi when a level starts)
+                    ++slot;
+                }
+            n += total;
+        }
+        ++depth;
+        if (tid == 0) lv[1 + depth] = hi;               // off[depth] = end of this level
+        __syncthreads();                                // the next level's nodes are written
+        lo = hi; hi = n;
+    }
+    if (tid == 0) { lv[0] = ((*w.flag & 1) || n < V) ? -1 : depth; *w.nf = n; }
+}
+// ---- any other tree of degree <= 4: nodes are (vertex, parent) pairs, the adjacency is read from (warmed) L2
+__device__ __forceinline__ void bfs_walk_general(int V, int* __restrict__ lv, const BfsLargeWs& w, BfsWalkLds& L) {
+    const int tid = threadIdx.x;
+    auto neighbours = [&](bool act, uint32_t cur, uint32_t (&nb)[4]) {
+        const uint4 q = act ? *reinterpret_cast<const uint4*>(w.adj + 4 * (size_t)cur) : make_uint4(~0u, ~0u, ~0u, ~0u);
+        nb[0] = q.x; nb[1] = q.y; nb[2] = q.z; nb[3] = q.w;
+    };
+    int lo = 0, hi = 1, n = 1, depth = 0;
+    while (lo < hi) {                                   // workgroup-uniform
+        if (hi - lo <= kBfsNarrow) {
+            // ---- one wave walks while the frontier stays narrow (64 nodes at a time, in frontier order; the next frontier goes to the
+            // other LDS buffer); the other waves wait at the barrier below.  On entry the frontier is in buffer 0.
+            if (tid < 64) {
+                const int lane = tid;
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                int cb = 0;
+                while (lo < hi && hi - lo <= kBfsNarrow) {
+                    const int width = hi - lo;
+                    int total = 0;
+                    for (int c = 0; c < width; c += 64) {
+                        const bool act = c + lane < width;
+                        const uint2 e = act ? L.fr[cb][c + lane] : make_uint2(0u, 0u);
+                        const uint32_t cur = e.x, par = e.y;
+                        uint32_t nb[4];
+                        neighbours(act, cur, nb);
+                        bool ok[4];
+                        int before = 0, mine = 0, tot_c = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            ok[k] = act && nb[k] != 0xffffffffu && nb[k] != par;
+                            const unsigned long long m = __ballot(ok[k]);
+                            before += __popcll(m & lt);
+                            tot_c += __popcll(m);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (ok[k]) {
+                                const int slot = total + before + mine;
+                                L.fr[cb ^ 1][slot] = make_uint2(nb[k], cur);
+                                w.nodev[n + slot] = nb[k]; w.nodep[n + slot] = cur;
+                                ++mine;
+                            }
+                        total += tot_c;
+                    }
+                    ++depth;
+                    if (lane == 0) lv[1 + depth] = hi;                           // off[depth] = end of this level
+                    lo = hi; hi = n + total; n += total;
+                    cb ^= 1;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the next frontier is in LDS (one wave: its LDS operations execute in order)
+                }
+                if (lane == 0) { L.s_lo = lo; L.s_hi = hi; L.s_n = n; L.s_depth = depth; }
             }
             __syncthreads();                             // also: the walking wave's global stores of nodev / nodep are done (vmcnt) before others read them
-            lo = s_lo; hi = s_hi; n = s_n; depth = s_depth;
+            lo = L.s_lo; hi = L.s_hi; n = L.s_n; depth = L.s_depth;
             __syncthreads();
             continue;
         }
@@ -312,20 +421,20 @@ __global__ __launch_bounds__(kLT) void bfsL_walk_kernel(int V, int* __restrict__
             const uint32_t cur = act ? w.nodev[i] : 0u, par = act ? w.nodep[i] : 0u;
             uint32_t nb[4]; int rank[4]; bool ok[4];
             int nch = 0;
+            neighbours(act, cur, nb);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                nb[k] = act ? w.adj[4 * (size_t)cur + k] : 0xffffffffu;
                 ok[k] = act && nb[k] != 0xffffffffu && nb[k] != par;
                 rank[k] = nch;
                 nch += ok[k] ? 1 : 0;
             }
             int total;
-            const int pos = n + block_excl_scan(nch, part, total);
+            const int pos = n + block_excl_scan(nch, L.part, total);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (ok[k]) {
                     w.nodev[pos + rank[k]] = nb[k]; w.nodep[pos + rank[k]] = cur;
-                    if (pos + rank[k] - hi < 256) { fv[pos + rank[k] - hi] = nb[k]; fp[pos + rank[k] - hi] = cur; }   // in case the next level is narrow (n == hi when a level starts)
+                    if (pos + rank[k] - hi < kBfsNarrow) L.fr[0][pos + rank[k] - hi] = make_uint2(nb[k], cur);   // in case the next level is narrow (n == hi when a level starts)
                 }
             n += total;
         }
@@ -336,14 +445,43 @@ __global__ __launch_bounds__(kLT) void bfsL_walk_kernel(int V, int* __restrict__
     }
     // loud, not silent: a vertex of degree > 4 or an input that is not connected leaves depth = -1, which makes
     // bxi_tree_refine_* poison its output (the reference's bfs.cu walks whatever it is given; refine.cu then reads garbage)
-    if (tid == 0) { lv[0] = (*w.flag || n < V) ? -1 : depth; *w.nf = n; }
+    if (tid == 0) { lv[0] = ((*w.flag & 1) || n < V) ? -1 : depth; *w.nf = n; }
+}
+__global__ __launch_bounds__(kLT) void bfsL_walk_kernel(int V, int* __restrict__ levels, char* ws_base, size_t ws_stride) {
+    extern __shared__ unsigned char lmask[];            // [V] in grid mode
+    __shared__ BfsWalkLds L;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    int* lv = levels + (int64_t)b * (V + 2);
+    // Grid mode (the tree lives on a 4-connected grid and its byte-per-vertex adjacency fits LDS): the walk never reads global memory.
+    // Otherwise every adjacency record is read exactly once, one dependent global read per level: the table (16 B per vertex) is
+    // brought into this XCD's L2 first, with the whole workgroup, so that the walk's reads are L2 hits instead of trips to HBM.
+    // (readfirstlane: the two words are waited for HERE, not by a vmcnt(0) inside the walk's loop at their first use)
+    const bool gridm = __builtin_amdgcn_readfirstlane((int)bfs_grid_mode(w, V)) != 0;           // workgroup-uniform
+    const int GW = __builtin_amdgcn_readfirstlane(*w.gw);
+    if (tid == 0) {
+        lv[1] = 0; w.nodev[0] = 0u; w.nodep[0] = 0xffffffffu;
+        if (gridm) reinterpret_cast<uint32_t*>(&L.fr[0][0])[0] = 0u; else L.fr[0][0] = make_uint2(0u, 0xffffffffu);
+    }
+    if (gridm) {
+        const uint32_t* g4 = reinterpret_cast<const uint32_t*>(w.gmask);          // gmask is 16-byte aligned in the workspace, and padded
+        uint32_t* l4 = reinterpret_cast<uint32_t*>(lmask);
+        for (int v = tid; v < (V + 3) / 4; v += kLT) l4[v] = g4[v];
+    } else {
+        uint32_t sink = 0u;
+        for (int v = tid; v < V; v += kLT) { const uint4 q = *reinterpret_cast<const uint4*>(w.adj + 4 * (size_t)v); sink ^= q.x ^ q.y ^ q.z ^ q.w; }
+        asm volatile("" ::"v"(sink));
+    }
+    __syncthreads();
+    if (gridm) bfs_walk_grid(V, GW, lv, w, lmask, L);
+    else bfs_walk_general(V, lv, w, L);
 }
 __global__ __launch_bounds__(256) void bfsL_index_kernel(int V, int* __restrict__ sorted_index, char* ws_base, size_t ws_stride) {
     const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
     if (p >= V) return;
     const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
     const int nf = *w.nf;                               // < V only for a disconnected input
-    const uint32_t v = p < nf ? w.nodev[p] : 0u;
+    const uint32_t v = p < nf ? (bfs_grid_mode(w, V) ? (w.nodev[p] & kBfsVtx) : w.nodev[p]) : 0u;
     sorted_index[(int64_t)b * V + p] = (int)v;
     if (p < nf) w.pos_of[v] = (uint32_t)p;
 }
@@ -355,11 +493,14 @@ __global__ __launch_bounds__(256) void bfsL_parent_kernel(int V, int max_adj, in
     const int nf = *w.nf;
     int* s_parent = sorted_parent + (int64_t)b * V;
     if (p == 0 || p >= nf) { s_parent[p] = 0; return; }
-    const uint32_t pv = w.nodep[p];
+    const bool gridm = bfs_grid_mode(w, V);
+    const int GW = *w.gw;
+    auto parent_of = [&](int q) { return gridm ? bfs_grid_parent(w.nodev[q], GW) : w.nodep[q]; };
+    const uint32_t pv = parent_of(p);
     const int pp = (int)w.pos_of[pv];
     s_parent[p] = pp;
     int k = 0;                                          // rank among the (contiguous) siblings
-    while (k < 3 && p - k - 1 >= 1 && w.nodep[p - k - 1] == pv) ++k;
+    while (k < 3 && p - k - 1 >= 1 && parent_of(p - k - 1) == pv) ++k;
     if (k < max_adj) sorted_child[(int64_t)b * V * max_adj + (size_t)pp * max_adj + k] = p;
 }
 
@@ -370,7 +511,18 @@ int launch_bfs_large(const int* tree, int B, int V, int max_adj, int* si, int* s
     BXI_LAUNCH("bfs_large_zero", s, bfsL_zero_kernel, gz, dim3(256), 0, s, V, max_adj, sc, ws, stride);
     BXI_LAUNCH("bfs_large_adj", s, bfsL_adj_kernel, gv, dim3(256), 0, s, tree, V, ws, stride);
     BXI_LAUNCH("bfs_large_sort", s, bfsL_sort_kernel, gv, dim3(256), 0, s, V, ws, stride);
-    BXI_LAUNCH("bfs_large_walk", s, bfsL_walk_kernel, dim3(B), dim3(kLT), 0, s, V, levels, ws, stride);
+    {
+        const size_t lds = V <= kBfsMaskCap ? (size_t)(V + 15) / 16 * 16 : 0;
+        if (lds > 48 * 1024) {
+            static std::atomic<int> attr_set{0};
+            if (!attr_set.load(std::memory_order_relaxed)) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bfsL_walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+                if (e != hipSuccess) { set_last_hip_error((int)e); return BXI_ERR_LAUNCH; }
+                attr_set.store(1, std::memory_order_relaxed);
+            }
+        }
+        BXI_LAUNCH("bfs_large_walk", s, bfsL_walk_kernel, dim3(B), dim3(kLT), lds, s, V, levels, ws, stride);
+    }
     BXI_LAUNCH("bfs_large_index", s, bfsL_index_kernel, gv, dim3(256), 0, s, V, si, ws, stride);
     BXI_LAUNCH("bfs_large_parent", s, bfsL_parent_kernel, gv, dim3(256), 0, s, V, max_adj, sp, sc, ws, stride);
     return check_launch();
