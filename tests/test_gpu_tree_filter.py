@@ -274,20 +274,17 @@ def test_large_mst_selects_the_reference_tree(built, dev, H, W):
         assert ids == sorted(ids) and len(ids) == V - 1
 
 
-def test_large_bfs_is_a_valid_deterministic_order(built, dev):
-    from boxinstseg_amd import bfs, mst
-    H, W = 200, 304
-    rng = np.random.default_rng(5)
-    V = H * W
-    idx = tfo.grid_edges(H, W)
-    wt = (rng.uniform(size=(2, len(idx))) + 1).astype(np.float32)
-    tree = mst(torch.from_numpy(idx)[None].repeat(2, 1, 1).to(dev), torch.from_numpy(wt).to(dev), V)
+def _check_bfs(tree, V):
+    """bfs() of tree [B, V - 1, 2] twice: deterministic, a permutation rooted at 0, parents before children, the tree's own edges,
+    levels = the depth histogram, children contiguous and pointing back."""
+    from boxinstseg_amd import bfs
     si, sp, sc = bfs(tree, 4)
     si2, sp2, sc2 = bfs(tree, 4)
     assert torch.equal(si, si2) and torch.equal(sp, sp2) and torch.equal(sc, sc2)
     lv = si._bxi_levels.cpu().numpy()
     si, sp, sc, t = si.cpu().numpy(), sp.cpu().numpy(), sc.cpu().numpy(), tree.cpu().numpy()
-    for b in range(2):
+    widest = 0
+    for b in range(t.shape[0]):
         assert np.array_equal(np.sort(si[b]), np.arange(V)) and si[b, 0] == 0
         assert (sp[b, 1:] < np.arange(1, V)).all() and sp[b, 0] == 0
         a, c = si[b, 1:], si[b, sp[b, 1:]]
@@ -300,6 +297,7 @@ def test_large_bfs_is_a_valid_deterministic_order(built, dev):
         D = lv[b, 0]
         assert D == depth.max() + 1 and lv[b, 1] == 0 and lv[b, 1 + D] == V
         assert np.array_equal(np.searchsorted(depth, np.arange(D)), lv[b, 1:1 + D])
+        widest = max(widest, int(np.diff(lv[b, 1:2 + D]).max()))
         nch = (sc[b] > 0).sum(1)
         assert nch.sum() == V - 1
         first = sc[b, :, 0]
@@ -308,6 +306,55 @@ def test_large_bfs_is_a_valid_deterministic_order(built, dev):
             m = nch > k
             assert (sc[b, m, k] == first[m] + k).all()
         assert (sp[b, first[has]] == np.nonzero(has)[0]).all()
+        # siblings in ascending vertex order (bfs.cu walks the adjacency list, which the reference fills in edge order = ascending)
+        sib = sp[b, 2:] == sp[b, 1:-1]
+        assert (si[b, 2:][sib] > si[b, 1:-1][sib]).all()
+    return widest
+
+
+def test_large_bfs_is_a_valid_deterministic_order(built, dev):
+    from boxinstseg_amd import mst
+    H, W = 200, 304
+    rng = np.random.default_rng(5)
+    V = H * W
+    idx = tfo.grid_edges(H, W)
+    wt = (rng.uniform(size=(2, len(idx))) + 1).astype(np.float32)
+    tree = mst(torch.from_numpy(idx)[None].repeat(2, 1, 1).to(dev), torch.from_numpy(wt).to(dev), V)
+    _check_bfs(tree, V)
+
+
+def _comb(H, W):
+    """the top row as a spine, every column a tooth: from vertex 0 the frontier grows to min(H, W) nodes"""
+    e = [(c, c + 1) for c in range(W - 1)] + [(r * W + c, (r + 1) * W + c) for r in range(H - 1) for c in range(W)]
+    return np.asarray(e, np.int32)
+
+
+@pytest.mark.parametrize('kind', ['grid_wide_frontier', 'relabelled', 'relabelled_wide_frontier', 'strip'])
+def test_large_bfs_forms(built, dev, kind):
+    """The level walk has a grid form (adjacency as four bits per vertex in LDS) and a general one (16-byte records), and each of them a
+    one-wave form (frontier <= 256 nodes) and a workgroup form: every combination, and the 1 x V strip (grid width 1: general form)."""
+    from boxinstseg_amd import mst
+    rng = np.random.default_rng(11)
+    if kind == 'strip':
+        V = 20000
+        t = np.stack([np.arange(V - 1), np.arange(1, V)], 1).astype(np.int32)
+        widest = _check_bfs(torch.from_numpy(t)[None].to(dev), V)
+        assert widest == 1
+        return
+    if kind == 'relabelled':
+        H, W = 120, 136
+        idx = tfo.grid_edges(H, W)
+        wt = (rng.uniform(size=(1, len(idx))) + 1).astype(np.float32)
+        t = mst(torch.from_numpy(idx)[None].to(dev), torch.from_numpy(wt).to(dev), H * W).cpu().numpy()[0]
+    else:
+        H, W = 300, 300
+        t = _comb(H, W)
+    V = H * W
+    if kind.startswith('relabelled'):
+        perm = rng.permutation(V).astype(np.int32)                  # the same tree, no longer v +- 1 / v +- W
+        t = perm[t]
+    widest = _check_bfs(torch.from_numpy(np.ascontiguousarray(t))[None].to(dev), V)
+    assert (widest > 256) == kind.endswith('wide_frontier'), widest
 
 
 @pytest.mark.parametrize('low', [True, False])
