@@ -15,7 +15,7 @@
 
 namespace bxi {
 
-constexpr int kLsMaxC = 8;
+constexpr int kLsMaxC = 8;        // target channels a launch of the partial sums keeps in registers; more channels = more launches (groups of 8)
 
 __device__ __forceinline__ double block_sum_f64_ls(double v, double* red /*[16]*/) {
     v = wave_sum_f64(v);
@@ -34,14 +34,15 @@ constexpr int kLsSlices = 8;      // workgroups per instance in the forward (a s
 
 template <bool VEC>
 __global__ __launch_bounds__(1024) void levelset_partial_kernel(const float* __restrict__ ms, const float* __restrict__ tg, int N, int C,
-                                                                int H, int W, double* __restrict__ state) {
+                                                                int H, int W, double* __restrict__ state, int c0) {
     __shared__ double red[16 * (2 + 4 * kLsMaxC)];
     const int n = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x;
     const int64_t HW = (int64_t)H * W;
     const int64_t chunk = ((HW + kLsSlices - 1) / kLsSlices + 3) & ~(int64_t)3;
     const int64_t lo = sl * chunk, hi = lo + chunk < HW ? lo + chunk : HW;
     const float* f0 = ms + (int64_t)n * 2 * HW;
-    const float* T = tg + (int64_t)n * C * HW;
+    const float* T = tg + ((int64_t)n * C + c0) * HW;              // this launch: channels c0 .. c0 + Cg - 1
+    const int Cg = C - c0 < kLsMaxC ? C - c0 : kLsMaxC;
     double S[2] = {0.0, 0.0}, A[2][kLsMaxC], Q[2][kLsMaxC];
 #pragma unroll
     for (int c = 0; c < kLsMaxC; ++c) { A[0][c] = A[1][c] = Q[0][c] = Q[1][c] = 0.0; }
@@ -53,13 +54,13 @@ __global__ __launch_bounds__(1024) void levelset_partial_kernel(const float* __r
             float4 t4[kLsMaxC];
 #pragma unroll
             for (int c = 0; c < kLsMaxC; ++c)
-                if (c < C) t4[c] = *reinterpret_cast<const float4*>(T + (int64_t)c * HW + p0);
+                if (c < Cg) t4[c] = *reinterpret_cast<const float4*>(T + (int64_t)c * HW + p0);
             const float fv[4] = {f4.x, f4.y, f4.z, f4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) { S[0] += (double)fv[u]; S[1] += (double)gv[u]; }
 #pragma unroll
             for (int c = 0; c < kLsMaxC; ++c)
-                if (c < C) {
+                if (c < Cg) {
                     const float tv[4] = {t4[c].x, t4[c].y, t4[c].z, t4[c].w};
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(1024) void levelset_partial_kernel(const float* __r
         for (int u = 0; u < 4; ++u) { S[0] += (double)fv[u]; S[1] += (double)gv[u]; }
 #pragma unroll
         for (int c = 0; c < kLsMaxC; ++c)
-            if (c < C) {
+            if (c < Cg) {
                 float tv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) tv[u] = T[(int64_t)c * HW + pc[u]];
@@ -102,11 +103,11 @@ __global__ __launch_bounds__(1024) void levelset_partial_kernel(const float* __r
     // dependent cross-lane steps and two barriers: ~1 us per sum, 14 sums at C = 3), one LDS hand-over, one barrier, then
     // thread q adds the 16 wave partials of sum q in wave order -- the same additions in the same order as before.
     double* part = state + (int64_t)N * ls_stride(C) + ((int64_t)n * kLsSlices + sl) * ls_stride(C);
-    const int n_sums = ls_stride(C);
+    const int n_sums = ls_stride(Cg);
     S[0] = wave_sum_f64(S[0]); S[1] = wave_sum_f64(S[1]);
 #pragma unroll
     for (int c = 0; c < kLsMaxC; ++c)
-        if (c < C) {
+        if (c < Cg) {
             A[0][c] = wave_sum_f64(A[0][c]); A[1][c] = wave_sum_f64(A[1][c]);
             Q[0][c] = wave_sum_f64(Q[0][c]); Q[1][c] = wave_sum_f64(Q[1][c]);
         }
@@ -115,16 +116,18 @@ __global__ __launch_bounds__(1024) void levelset_partial_kernel(const float* __r
         r[0] = S[0]; r[1] = S[1];
 #pragma unroll
         for (int c = 0; c < kLsMaxC; ++c)
-            if (c < C) {
-                r[2 + c] = A[0][c]; r[2 + C + c] = A[1][c];
-                r[2 + 2 * C + c] = Q[0][c]; r[2 + 3 * C + c] = Q[1][c];
+            if (c < Cg) {
+                r[2 + c] = A[0][c]; r[2 + Cg + c] = A[1][c];
+                r[2 + 2 * Cg + c] = Q[0][c]; r[2 + 3 * Cg + c] = Q[1][c];
             }
     }
     __syncthreads();
     if (tid < n_sums) {
         double s = 0.0;
         for (int wv = 0; wv < 16; ++wv) s += red[wv * (2 + 4 * kLsMaxC) + tid];     // fixed order
-        part[tid] = s;
+        // sum `tid` of this group -> its place among all C channels (S[2] is the same in every group's launch: same data, same order)
+        const int q = tid - 2;
+        part[tid < 2 ? tid : 2 + (q / Cg) * C + c0 + q % Cg] = s;
     }
 }
 
@@ -190,6 +193,42 @@ __global__ __launch_bounds__(256) void levelset_bwd_kernel(const float* __restri
         for (int c = 0; c < kLsMaxC; ++c)
             if (c < C) g_tg[((int64_t)n * C + c) * HW + p] = (float)(w * gt[c]);
     }
+}
+
+// more than kLsMaxC target channels: the same sums in the same order (per side over c; per channel side 0 then side 1), channel by channel
+__global__ __launch_bounds__(256) void levelset_bwd_anyc_kernel(const float* __restrict__ ms, const float* __restrict__ tg,
+                                                                const float* __restrict__ pixel_num, int N, int C, int H, int W,
+                                                                double weight, const double* __restrict__ state,
+                                                                const float* __restrict__ g_loss, float* __restrict__ g_ms,
+                                                                float* __restrict__ g_tg) {
+    const int64_t HW = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)N * HW) return;
+    const int n = (int)(i / HW);
+    const int64_t p = i % HW;
+    const double* st = state + (int64_t)n * ls_stride(C);
+    const double w = (double)g_loss[n] * weight / ((double)C * (double)pixel_num[n]);
+    const float* f0 = ms + (int64_t)n * 2 * HW;
+    const double f[2] = {(double)f0[p], (double)f0[HW + p]};
+    const double s[2] = {st[0], st[1]};
+    const double sc[2] = {s[0] > 1e-5 ? s[0] : 1e-5, s[1] > 1e-5 ? s[1] : 1e-5};
+    double gm[2] = {0.0, 0.0};
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+        const double t = tg[((int64_t)n * C + c) * HW + p];
+        double gt = 0.0;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const double a = st[2 + side * C + c], R = st[2 + 2 * C + side * C + c];
+            const double d = t - a;
+            const double da_df = (t - (s[side] >= 1e-5 ? a : 0.0)) / sc[side];
+            gm[side] += d * d - 2.0 * R * da_df;
+            gt += 2.0 * d * f[side] - 2.0 * R * f[side] / sc[side];
+        }
+        if (g_tg) g_tg[((int64_t)n * C + c) * HW + p] = (float)(w * gt);
+    }
+    g_ms[((int64_t)n * 2 + 0) * HW + p] = (float)(w * gm[0]);
+    g_ms[((int64_t)n * 2 + 1) * HW + p] = (float)(w * gm[1]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -524,14 +563,14 @@ __global__ __launch_bounds__(256) void lcm_refine_step_kernel(const float* __res
 extern "C" {
 
 size_t bxi_levelset_state_bytes(int N, int C) {
-    if (N < 0 || C <= 0 || C > bxi::kLsMaxC) return 0;
+    if (N < 0 || C <= 0 || C > 4096) return 0;
     return sizeof(double) * (size_t)(N > 0 ? N : 1) * (2 + 4 * C) * (1 + bxi::kLsSlices);
 }
 
 int bxi_levelset_loss_forward_f32(const float* mask_score, const float* target, const float* pixel_num, int N, int C, int H,
                                   int W, float loss_weight, float* loss, void* state, void* stream) {
     if (N < 0 || H <= 0 || W <= 0 || C <= 0) return BXI_ERR_BAD_SHAPE;
-    if (C > bxi::kLsMaxC) return BXI_ERR_UNSUPPORTED;
+    if (C > 4096) return BXI_ERR_UNSUPPORTED;
     if (N == 0) return BXI_OK;
     if (!mask_score || !target || !pixel_num || !loss || !state) return BXI_ERR_NULL_POINTER;
     if (!bxi::fits_i32((int64_t)N * H * W * (C > 2 ? C : 2))) return BXI_ERR_BAD_SHAPE;
@@ -539,14 +578,17 @@ int bxi_levelset_loss_forward_f32(const float* mask_score, const float* target, 
     hipStream_t s = bxi::as_stream(stream);
     if (N > 65535) return BXI_ERR_UNSUPPORTED;
     const bool vec = ((int64_t)H * W) % 4 == 0 && ((reinterpret_cast<uintptr_t>(mask_score) | reinterpret_cast<uintptr_t>(target)) & 15) == 0;
-    if (vec)
-        BXI_LAUNCH("levelset_partial", s, bxi::levelset_partial_kernel<true>, dim3(bxi::kLsSlices, N), dim3(1024), 0, s, mask_score, target, N,
-                   C, H, W, reinterpret_cast<double*>(state));
-    else
-        BXI_LAUNCH("levelset_partial", s, bxi::levelset_partial_kernel<false>, dim3(bxi::kLsSlices, N), dim3(1024), 0, s, mask_score, target, N,
-                   C, H, W, reinterpret_cast<double*>(state));
-    int rc = bxi::check_launch();
-    if (rc != BXI_OK) return rc;
+    int rc = BXI_OK;
+    for (int c0 = 0; c0 < C; c0 += bxi::kLsMaxC) {                  // the shipped losses have C = 3 and C = 5: one launch
+        if (vec)
+            BXI_LAUNCH("levelset_partial", s, bxi::levelset_partial_kernel<true>, dim3(bxi::kLsSlices, N), dim3(1024), 0, s, mask_score, target,
+                       N, C, H, W, reinterpret_cast<double*>(state), c0);
+        else
+            BXI_LAUNCH("levelset_partial", s, bxi::levelset_partial_kernel<false>, dim3(bxi::kLsSlices, N), dim3(1024), 0, s, mask_score, target,
+                       N, C, H, W, reinterpret_cast<double*>(state), c0);
+        rc = bxi::check_launch();
+        if (rc != BXI_OK) return rc;
+    }
     BXI_LAUNCH("levelset_finish", s, bxi::levelset_finish_kernel, dim3((N + 63) / 64), dim3(64), 0, s, pixel_num, N, C, (double)loss_weight,
                loss, reinterpret_cast<double*>(state));
     return bxi::check_launch();
@@ -556,14 +598,18 @@ int bxi_levelset_loss_backward_f32(const float* mask_score, const float* target,
                                    int W, float loss_weight, const void* state, const float* g_loss, float* g_mask_score,
                                    float* g_target, void* stream) {
     if (N < 0 || H <= 0 || W <= 0 || C <= 0) return BXI_ERR_BAD_SHAPE;
-    if (C > bxi::kLsMaxC) return BXI_ERR_UNSUPPORTED;
+    if (C > 4096) return BXI_ERR_UNSUPPORTED;
     if (N == 0) return BXI_OK;
     if (!mask_score || !target || !pixel_num || !state || !g_loss || !g_mask_score) return BXI_ERR_NULL_POINTER;
     if (!bxi::fits_i32((int64_t)N * H * W * (C > 2 ? C : 2))) return BXI_ERR_BAD_SHAPE;
     hipStream_t s = bxi::as_stream(stream);
     const unsigned grid = (unsigned)(((int64_t)N * H * W + 255) / 256);
-    BXI_LAUNCH("levelset_bwd", s, bxi::levelset_bwd_kernel, dim3(grid), dim3(256), 0, s, mask_score, target, pixel_num, N, C, H, W,
-               (double)loss_weight, reinterpret_cast<const double*>(state), g_loss, g_mask_score, g_target);
+    if (C <= bxi::kLsMaxC)
+        BXI_LAUNCH("levelset_bwd", s, bxi::levelset_bwd_kernel, dim3(grid), dim3(256), 0, s, mask_score, target, pixel_num, N, C, H, W,
+                   (double)loss_weight, reinterpret_cast<const double*>(state), g_loss, g_mask_score, g_target);
+    else
+        BXI_LAUNCH("levelset_bwd", s, bxi::levelset_bwd_anyc_kernel, dim3(grid), dim3(256), 0, s, mask_score, target, pixel_num, N, C, H, W,
+                   (double)loss_weight, reinterpret_cast<const double*>(state), g_loss, g_mask_score, g_target);
     return bxi::check_launch();
 }
 

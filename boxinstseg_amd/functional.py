@@ -490,6 +490,7 @@ class HeadBoxInstLoss(torch.autograd.Function):
         ctx.grad = buf[256 + plan.state_bytes:].view(torch.float32).view(logits.shape)
         ctx.state, ctx.plan, ctx.keep = base + 256, plan, (imgs_c, gi, boxes, buf, img_metas, int(cfg['bottom_pixels_removed']), logits)
         ctx.head_cfg, ctx.dil, ctx.need_grad = (int(in_stride), int(factor), int(bool(no_rel))), int(cfg['pairwise_dilation']), need_grad
+        ctx.cfg, ctx.calls = cfg, 0
         ctx.dtypes = (feat.dtype, params.dtype)
         ctx.mark_non_differentiable(logits) if not need_grad else None
         return logits, losses[0], losses[1]
@@ -498,13 +499,29 @@ class HeadBoxInstLoss(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, g_logits_in, g_prj, g_pw):
         feat, params, coors, lvl, img, soi = ctx.saved_tensors
-        grad, plan = ctx.grad, ctx.plan
-        if grad is None:
-            raise RuntimeError('HeadBoxInstLoss.backward called twice: evaluate again (retain_graph is not supported here)')
-        ctx.grad = None
-        dev = grad.device
+        dev = feat.device
         lib = _lib.load()
         stream = torch.cuda.current_stream(dev).cuda_stream
+        grad, plan, state = ctx.grad, ctx.plan, ctx.state
+        ctx.grad = None
+        if ctx.calls > 0:
+            # re-entrant backward (retain_graph=True; the reference's composed graph allows it): the first buffer was finished in place
+            # for the first call's upstream factors, so the loss is evaluated again from the logits that were kept
+            cfg = ctx.cfg
+            imgs_k, gi_k, boxes_k, _, metas_k, bpr_k, logits_k = ctx.keep
+            plan = _eval_plan(imgs_k, metas_k, logits_k, boxes_k, int(cfg['out_stride']), bpr_k, stream)
+            again = torch.empty(64 + plan.state_bytes // 4 + plan.grad_elems, dtype=torch.float32, device=dev)
+            base = again.data_ptr()
+            plan.batch.imgs, plan.inst.logits, plan.inst.gt_inds = imgs_k.data_ptr(), logits_k.data_ptr(), gi_k.data_ptr()
+            with torch.cuda.device(dev):
+                _lib.check('bxi_boxinst_eval_f32', plan.eval(
+                    plan.batch_ref, plan.inst_ref, int(cfg['pairwise_size']), int(cfg['pairwise_dilation']),
+                    float(cfg['pairwise_color_thresh']), float(cfg['warmup_factor']), 0, 0, base, base + 256 + plan.state_bytes,
+                    base + 256, plan.ws_ptr, plan.ws_bytes, stream))
+            grad, state = again[64 + plan.state_bytes // 4:].view(logits_k.shape), base + 256
+        elif grad is None:
+            raise RuntimeError('HeadBoxInstLoss.backward without a gradient request')
+        ctx.calls += 1
         g_prj = g_prj.to(device=dev, dtype=torch.float32)
         g_pw = g_pw.to(device=dev, dtype=torch.float32)
         in_stride, factor, no_rel = ctx.head_cfg
@@ -518,7 +535,7 @@ class HeadBoxInstLoss(torch.autograd.Function):
         plan.inst.logits, plan.inst.gt_inds = logits_k.data_ptr(), gi_k.data_ptr()
         with torch.cuda.device(dev):
             _lib.check('bxi_boxinst_grad_rescale_f32', plan.rescale(plan.inst_ref, g_prj.data_ptr(), g_pw.data_ptr(), ctx.dil,
-                                                                     ctx.state, grad.data_ptr(), stream))
+                                                                     state, grad.data_ptr(), stream))
             if g_logits_in is not None:
                 grad = grad + g_logits_in.to(torch.float32)
             _lib.check('bxi_dynamic_mask_backward_f32', lib.bxi_dynamic_mask_backward_f32(

@@ -356,7 +356,7 @@ int bxi_projection_loss_forward_f32(const float* mask_scores, const float* box_b
                                     float* loss, void* state, void* stream);
 
 /* LevelsetLoss.forward (:13-18) = loss_weight * region_levelset(mask_score, target) / pixel_num.
- * mask_score [N,2,H,W] (foreground, background scores), target [N,C,H,W] (C <= 8), pixel_num [N]; loss [N].
+ * mask_score [N,2,H,W] (foreground, background scores), target [N,C,H,W] (any C; channels beyond 8 cost one more launch of the partial sums per 8), pixel_num [N]; loss [N].
  * state (bxi_levelset_state_bytes) keeps the region sums / means for the backward. */
 size_t bxi_levelset_state_bytes(int N, int C);
 int bxi_levelset_loss_forward_f32(const float* mask_score, const float* target, const float* pixel_num, int N, int C, int H,

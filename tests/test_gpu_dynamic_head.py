@@ -312,3 +312,47 @@ def test_head_fused_into_the_loss_evaluation(dev, C, no_rel, N):
         assert abs(float(a[i]) - float(b[i])) <= 1e-5 * max(abs(float(b[i])), 1e-6), (i, float(a[i]), float(b[i]))
     for i in (3, 4):
         assert (a[i] - b[i]).abs().max() <= 2e-4 * max(float(b[i].abs().max()), 1e-8), (i, float((a[i] - b[i]).abs().max()), float(b[i].abs().max()))
+
+
+
+def test_head_fused_backward_twice_with_retain_graph(dev):
+    """The reference's composed graph (forward() then loss()) can be differentiated twice with retain_graph=True; the head-fused node
+    finishes its gradient in place for the first call's upstream factors, so a second call evaluates the loss again from the kept logits:
+    each call's gradients equal those of a fresh evaluation with the same weights."""
+    from boxinstseg_amd import CondInstMaskHead, synthetic
+    d = synthetic.cfg1(2)
+    imgs = torch.from_numpy(d['imgs']).to(dev)
+    B, H, W = imgs.shape[0], imgs.shape[2], imgs.shape[3]
+    boxes = [torch.from_numpy(b).to(dev) for b in d['gt_bboxes']]
+    gt_inds = torch.from_numpy(d['gt_inds']).to(dev)
+    n = gt_inds.numel()
+    counts = np.cumsum([0] + [b.shape[0] for b in boxes])
+    img_inds = torch.tensor([int(np.searchsorted(counts, int(g), side='right') - 1) for g in gt_inds.cpu()], device=dev)
+    torch.manual_seed(3)
+    head = CondInstMaskHead(in_channels=8, boxinst_enabled=True, max_proposals=-1, topk_per_img=64).to(dev)
+    head.set_iter(5000)
+    feat = torch.randn(B, 8, H // 8, W // 8, device=dev)
+    params = 0.3 * torch.randn(n, head.num_gen_params, device=dev)
+    coors = torch.rand(n, 2, device=dev) * torch.tensor([W, H], device=dev)
+    lvl = torch.randint(0, 5, (n,), device=dev)
+
+    def evaluate():
+        f = feat.clone().requires_grad_(True); p = params.clone().requires_grad_(True)
+        it = int(head._iter.item())
+        _, losses = head.forward_loss(f, p, coors, lvl, img_inds, imgs, d['img_metas'], gt_inds, boxes, fuse_head=True)
+        head.set_iter(it)                               # the same warm-up factor for every evaluation of this test
+        return f, p, losses
+
+    weights = [(1.0, 2.0), (0.5, 3.0), (1.0, 1.0)]
+    f, p, losses = evaluate()
+    got = []
+    for k, (a, b) in enumerate(weights):
+        f.grad = p.grad = None
+        (a * losses['loss_prj'] + b * losses['loss_pairwise']).backward(retain_graph=k + 1 < len(weights))
+        got.append((f.grad.clone(), p.grad.clone()))
+    for (a, b), (gf, gp) in zip(weights, got):
+        f2, p2, l2 = evaluate()
+        (a * l2['loss_prj'] + b * l2['loss_pairwise']).backward()
+        assert torch.isfinite(gf).all() and float(gf.abs().max()) > 0
+        assert (gf - f2.grad).abs().max() <= 1e-5 * float(f2.grad.abs().max()), (a, b)
+        assert (gp - p2.grad).abs().max() <= 1e-5 * float(p2.grad.abs().max()), (a, b)
