@@ -63,7 +63,7 @@ def test_abi_argument_validation_without_device():
     assert lib.bxi_meanfield_forward_f32(None, 1, 4, 4, 3, None, None, 0, None, 1, 10, 0.7, None, 0.01, None, None, None, 0, None) == -3   # base >= 0.5
     assert lib.bxi_meanfield_workspace_bytes(2, 10, 130) == 3 * 8 * 2 * 10 * 3
     assert lib.bxi_mil_loss_forward_f32(None, None, 0, 1, 4, 4, None, None, None) == -1
-    assert lib.bxi_levelset_loss_forward_f32(None, None, None, 1, 9, 4, 4, 1.0, None, None, None) == -4            # C > 8
+    assert lib.bxi_levelset_loss_forward_f32(None, None, None, 1, 5000, 4, 4, 1.0, None, None, None) == -4         # C > 4096
     assert lib.bxi_levelset_state_bytes(3, 2) == 8 * 3 * 10 * 9
     assert lib.bxi_lcm_refine_f32(None, None, 1, 4, 4, 0, 10, 0, None, None, 0, None) == -3                         # dilation < 1
     assert lib.bxi_mst_forward_i32(None, None, 1, 10, 20000, None, None, 0, None) == -1                             # large graphs are served (workspace arrays): NULL pointers
