@@ -13,7 +13,7 @@ from . import build as _build
 c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
 BXI_MAX_IMAGES = 64
-BXI_ABI_VERSION = 3
+BXI_ABI_VERSION = 4
 
 STATUS = {0: 'BXI_OK', -1: 'BXI_ERR_NULL_POINTER', -2: 'BXI_ERR_BAD_SHAPE', -3: 'BXI_ERR_BAD_ARGUMENT',
           -4: 'BXI_ERR_UNSUPPORTED', -5: 'BXI_ERR_WORKSPACE', -6: 'BXI_ERR_LAUNCH', -7: 'BXI_ERR_NO_DEVICE'}
@@ -34,7 +34,7 @@ class Instances(C.Structure):
     _fields_ = [('logits', c_void_p), ('N', c_int), ('h', c_int), ('w', c_int),
                 ('gt_inds', c_void_p), ('boxes_per_img_host', C.POINTER(c_void_p)),
                 ('gt_count_host', C.POINTER(c_int)), ('B', c_int), ('Hc', c_int), ('Wc', c_int),
-                ('stride', c_int)]
+                ('stride', c_int), ('iter_counter', c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/boxinst_hip.h (tests check this)

@@ -1293,6 +1293,7 @@ __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, c
         losses[0] = l0; losses[1] = l1;
         if (st.scale) { *st.scale = warmup / denom; st.applied[0] = upp; st.applied[1] = upw; }
         if (st.status) { st.status[0] = (int)status; if (ONE) st.status[1] = R; }
+        if (st.iter) atomicAdd(st.iter, 1.0f);                               // self._iter += 1, condinst_head.py:1297
     }
     BXI_TW(3, 0, 1);
 }
@@ -1488,7 +1489,7 @@ __global__ __launch_bounds__(256) void rescale_kernel(InstArgs a, int dil, LossS
     }
 }
 
-__global__ void zero_losses2_kernel(float* losses) { losses[0] = 0.f; losses[1] = 0.f; }
+__global__ void zero_losses2_kernel(float* losses, float* iter) { losses[0] = 0.f; losses[1] = 0.f; if (iter) atomicAdd(iter, 1.0f); }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 // compute units of the current device (256 on an MI355X in SPX mode, 32 per partition in CPX): the grids are sized so that a
@@ -1621,7 +1622,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     if (batch->B > 0 && !batch->imgs) return BXI_ERR_NULL_POINTER;
     if (batch->image_masks) return BXI_ERR_UNSUPPORTED;   // explicit masks: use bxi_color_affinity_f32 + bits
     if (a.N == 0) {
-        BXI_LAUNCH("zero_losses", s, zero_losses2_kernel, dim3(1), dim3(1), 0, s, losses);
+        BXI_LAUNCH("zero_losses", s, zero_losses2_kernel, dim3(1), dim3(1), 0, s, losses, in->iter_counter);
         return check_launch();
     }
     if (a.N >= kMaxInst || a.h > 65535 || a.w > 65535) return BXI_ERR_BAD_SHAPE;
@@ -1646,6 +1647,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
         carve_state(state, a.N, a.h, a.w, &st);
     }
+    st.iter = in->iter_counter;
     const int vec = ((a.w & 3) == 0 && (reinterpret_cast<uintptr_t>(a.logits) & 15) == 0 &&
                      (!g_logits || (reinterpret_cast<uintptr_t>(g_logits) & 15) == 0)) ? 1 : 0;
     static const int env_rows = env_int("BXI_TILE_ROWS", 0);            // developer knobs
@@ -1810,7 +1812,7 @@ int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_p
     if (!g_prj || !g_pw || !state || !g_logits) return BXI_ERR_NULL_POINTER;
     if (a.N > 65535) return BXI_ERR_BAD_SHAPE;
     if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
-    LossState st;
+    LossState st = {};
     carve_state(const_cast<void*>(state), a.N, a.h, a.w, &st);
     hipStream_t s = as_stream(stream);
     BXI_LAUNCH("rescale", s, rescale_kernel, dim3(8, a.N), dim3(256), 0, s, a, dil, st, g_prj, g_pw, g_logits);

@@ -37,6 +37,7 @@ struct LossState {            // what the backward / rescale entry points need (
     unsigned long long* colk; // [N,w] fused_eval.hip: (unit gradient bits << 32) | arg-max row ; low word 0xffffffff = not published yet
     unsigned long long* rowk; // [N,h] same for the rows
     int* status;              // [2]   {0 or a bit mask of protocol time-outs (never expected), tile rows R} (fused_eval.hip)
+    float* iter;              // bxi_instances.iter_counter (not part of `state`): + 1.0f by the evaluation's finisher
 };
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -28,6 +28,16 @@ def _require_cuda(**tensors: Optional[torch.Tensor]) -> None:
             raise RuntimeError(f'{name} must be a CUDA (HIP) tensor: boxinstseg_amd has no CPU path')
 
 
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def _current_stream(dev: torch.device) -> int:
+    """The current stream's handle (the raw getter skips building a Stream object: 0.3 instead of 1.9 us)."""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(dev.index if dev.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
 def _stream(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -210,6 +220,7 @@ class _EvalPlan:
             cnt[i] = n
             ptrs[i] = b.data_ptr() if n else 0
         self.inst.N = N
+        self.inst.iter_counter = 0          # set by the one caller that owns an iteration counter, after this
 
 
 class _Local(threading.local):
@@ -334,7 +345,7 @@ class BoxInstMaskLoss(torch.autograd.Function):
     def _evaluate(ctx, need_grad: bool):
         cfg, logits = ctx.cfg, ctx.logits
         dev = logits.device
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _current_stream(dev)
         imgs, x = _f32c(ctx.imgs), _f32c(logits)
         gi = ctx.gt_inds
         if gi.dtype != torch.int64 or gi.device != dev or not gi.is_contiguous():
@@ -353,9 +364,12 @@ class BoxInstMaskLoss(torch.autograd.Function):
         plan.batch.imgs = imgs.data_ptr()
         plan.inst.logits = x.data_ptr()
         plan.inst.gt_inds = gi.data_ptr()
+        it = cfg.get('iter_counter')
+        if it is not None and ctx.calls == 0:           # counted once per loss() call, not again by a re-entrant backward
+            plan.inst.iter_counter = it.data_ptr()
         grad = None
         if need_grad:
-            grad = buf[64 + plan.state_bytes // 4:].view(x.shape)
+            grad = buf.as_strided(x.shape, x.stride(), 64 + plan.state_bytes // 4)          # one view, not a slice and a reshape
         args = (plan.batch_ref, plan.inst_ref, int(cfg['pairwise_size']), int(cfg['pairwise_dilation']),
                 float(cfg['pairwise_color_thresh']), float(cfg['warmup_factor']), 0, 0, base,
                 base + 256 + plan.state_bytes if need_grad else 0, base + 256 if need_grad else 0,
@@ -423,7 +437,7 @@ class BoxInstMaskLoss(torch.autograd.Function):
             with torch.cuda.device(dev):
                 _lib.check('bxi_boxinst_grad_rescale_f32', plan.rescale(
                     plan.inst_ref, g_prj.data_ptr(), g_pw.data_ptr(), int(ctx.cfg['pairwise_dilation']), state,
-                    grad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+                    grad.data_ptr(), _current_stream(dev)))
         if grad.dtype != ctx.in_dtype:
             grad = grad.to(ctx.in_dtype)
         return grad, None, None, None, None, None, None
@@ -469,7 +483,7 @@ class HeadBoxInstLoss(torch.autograd.Function):
         lvl, img, soi, gi = i64(level_inds), i64(img_inds), f32(sizes_of_interest), i64(gt_inds)
         boxes = [b.detach().to(device=dev, dtype=torch.float32).contiguous() for b in gt_bboxes]
         imgs_c = _f32c(imgs)
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _current_stream(dev)
         logits = torch.empty((N, 1, Hs * factor, Ws * factor), dtype=torch.float32, device=dev)
         plan = _eval_plan(imgs_c, img_metas, logits, boxes, int(cfg['out_stride']), int(cfg['bottom_pixels_removed']), stream)
         need_grad = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
@@ -478,6 +492,8 @@ class HeadBoxInstLoss(torch.autograd.Function):
         plan.batch.imgs = imgs_c.data_ptr()
         plan.inst.logits = logits.data_ptr()
         plan.inst.gt_inds = gi.data_ptr()
+        if cfg.get('iter_counter') is not None:
+            plan.inst.iter_counter = cfg['iter_counter'].data_ptr()
         with torch.cuda.device(dev):
             _lib.check('bxi_boxinst_head_eval_f32', _lib.load().bxi_boxinst_head_eval_f32(
                 plan.batch_ref, plan.inst_ref, feat_c.data_ptr(), Cf, Hs, Ws, params_c.data_ptr(), coors_c.data_ptr(),
@@ -501,7 +517,7 @@ class HeadBoxInstLoss(torch.autograd.Function):
         feat, params, coors, lvl, img, soi = ctx.saved_tensors
         dev = feat.device
         lib = _lib.load()
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _current_stream(dev)
         grad, plan, state = ctx.grad, ctx.plan, ctx.state
         ctx.grad = None
         if ctx.calls > 0:
@@ -549,11 +565,14 @@ def boxinst_mask_loss(mask_logits: torch.Tensor, gt_inds: torch.Tensor, gt_bboxe
                       imgs: Optional[torch.Tensor] = None, img_metas: Optional[Sequence[dict]] = None,
                       affinity_bits: Optional[torch.Tensor] = None, out_stride: int = 4,
                       bottom_pixels_removed: int = 10, pairwise_size: int = 3, pairwise_dilation: int = 2,
-                      pairwise_color_thresh: float = 0.3, warmup_factor: float = 1.0) -> Dict[str, torch.Tensor]:
+                      pairwise_color_thresh: float = 0.3, warmup_factor: float = 1.0,
+                      iter_counter: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """The BoxInst branch of ``CondInstMaskHead.loss`` (condinst_head.py:1297-1337) as one call.
 
     Either ``imgs`` + ``img_metas`` (targets are computed on the device from the network input) or
     precomputed ``affinity_bits`` (from :func:`color_affinity`) must be given.
+    ``iter_counter`` (images path only): a float32 device scalar the evaluation adds 1 to inside its last launch -- the module's
+    ``self._iter += 1`` (condinst_head.py:1297) without a launch of its own.
     Returns ``{'loss_prj', 'loss_pairwise'}`` attached to the autograd graph of ``mask_logits``.
     Built for ``pairwise_size == 3`` and ``pairwise_dilation <= 4`` (``fused_supported``); other windows are
     composed from the op-level kernels by ``CondInstMaskHead._composed_loss``.
@@ -566,6 +585,12 @@ def boxinst_mask_loss(mask_logits: torch.Tensor, gt_inds: torch.Tensor, gt_bboxe
     cfg = dict(out_stride=out_stride, bottom_pixels_removed=bottom_pixels_removed, pairwise_size=pairwise_size,
                pairwise_dilation=pairwise_dilation, pairwise_color_thresh=pairwise_color_thresh,
                warmup_factor=warmup_factor)
+    if iter_counter is not None:
+        if affinity_bits is not None:
+            raise RuntimeError('iter_counter is counted by the evaluation from images; with affinity_bits add to it yourself')
+        if iter_counter.dtype != torch.float32 or iter_counter.device != mask_logits.device or iter_counter.numel() != 1:
+            raise RuntimeError('iter_counter must be one float32 on the device of mask_logits')
+        cfg['iter_counter'] = iter_counter
     loss_prj, loss_pw = BoxInstMaskLoss.apply(mask_logits, imgs, img_metas, gt_inds, list(gt_bboxes), cfg,
                                               affinity_bits)
     return {'loss_prj': loss_prj, 'loss_pairwise': loss_pw}

@@ -119,19 +119,30 @@ class CondInstMaskHead(nn.Module):
         self._iter_host = float(value)
         self._iter_seen = (self._iter._version, self._iter.data_ptr())
 
-    def _tick(self) -> float:
+    def _tick(self, in_evaluation: bool = False) -> float:
         """``self._iter += 1`` (condinst_head.py:1297) and the warm-up factor (:1330-1331), sync-free.
 
         The host mirror is trusted only while nobody else wrote the buffer: any in-place write (``fill_``, ``copy_``, a DDP
         buffer broadcast, ``load_state_dict``) bumps the tensor's version counter, a replaced buffer (``.to()``) changes its
-        storage -- either is noticed here without a synchronisation, and the value is re-read once."""
-        seen = (self._iter._version, self._iter.data_ptr())
+        storage -- either is noticed here without a synchronisation, and the value is re-read once.
+
+        ``in_evaluation``: the caller hands ``self._iter`` to the loss evaluation, whose last launch adds the 1 (``iter_counter``
+        of ``bxi_instances``; stream-ordered like the ``+=`` it replaces, and it does not touch the version counter) -- a 9 us
+        launch of its own otherwise."""
+        it = self._iter                                   # (a buffer: every `self._iter` goes through Module.__getattr__)
+        seen = (it._version, it.data_ptr())
         if self._iter_host is None or getattr(self, '_iter_seen', None) != seen:
-            self._iter_host = float(self._iter.item())
-        self._iter += 1
+            self._iter_host = float(it.item())
+        if not in_evaluation:
+            it += 1
+            seen = (it._version, seen[1])
         self._iter_host += 1.0
-        self._iter_seen = (self._iter._version, self._iter.data_ptr())
+        self._iter_seen = seen
         return min(self._iter_host / float(self._warmup_iters), 1.0)
+
+    def _counts_in_evaluation(self, like: torch.Tensor) -> bool:
+        it = self._iter
+        return it.dtype == torch.float32 and it.device == like.device and it.numel() == 1
 
     # ---- the producer of mask_logits (SURVEY 8(f-2)) -------------------------------------------------------
     def parse_dynamic_params(self, params):
@@ -195,19 +206,24 @@ class CondInstMaskHead(nn.Module):
                 raise RuntimeError(f'{name} has {t.size(0)} entries for {n} instances')
         if len(gt_bboxes) != imgs.size(0) or len(img_metas) != imgs.size(0):
             raise RuntimeError(f'{imgs.size(0)} images but {len(gt_bboxes)} box lists / {len(img_metas)} img_metas')
-        warmup = self._tick()
+        in_eval = self._counts_in_evaluation(feat)
+        warmup = self._tick(in_eval)
         cfg = dict(out_stride=self.out_stride, bottom_pixels_removed=self.bottom_pixels_removed, pairwise_size=self.pairwise_size,
                    pairwise_dilation=self.pairwise_dilation, pairwise_color_thresh=self.pairwise_color_thresh,
                    warmup_factor=warmup)
+        if in_eval:
+            cfg['iter_counter'] = self._iter
         try:
             logits, loss_prj, loss_pw = F_hip.HeadBoxInstLoss.apply(
                 feat, params, coors, level_inds, img_inds, self.sizes_of_interest, (self.in_stride, factor, self.disable_rel_coors),
                 imgs, img_metas, gt_inds, gt_bboxes, cfg)
         except _lib.BoxInstHipError as e:
             if e.status != _lib.BXI_ERR_UNSUPPORTED:
+                self._iter_host = None
                 raise
             # a configuration the fused launch is not built for after all (e.g. an image tensor that is not 16-byte aligned):
             # the two calls, as documented; the iteration has been counted once already
+            # (nothing has been launched by the refused call, so the evaluation below is still the one that adds the 1)
             logits = self(feat, params, coors, level_inds, img_inds)
             losses = F_hip.boxinst_mask_loss(logits, gt_inds, gt_bboxes, imgs=imgs, img_metas=img_metas, **cfg)
             return logits, losses
@@ -339,15 +355,20 @@ class CondInstMaskHead(nn.Module):
         if not mask_logits.is_cuda:
             raise RuntimeError('CondInstMaskHead.loss: mask_logits must be a CUDA (HIP) tensor; '
                                'boxinstseg_amd has no CPU loss path')
+        if self.boxinst_enabled and F_hip.fused_supported(self.pairwise_size, self.pairwise_dilation):
+            in_eval = self._counts_in_evaluation(mask_logits)
+            try:
+                return F_hip.boxinst_mask_loss(
+                    mask_logits, gt_inds, gt_bboxes, imgs=imgs, img_metas=img_metas, out_stride=self.out_stride,
+                    bottom_pixels_removed=self.bottom_pixels_removed, pairwise_size=self.pairwise_size,
+                    pairwise_dilation=self.pairwise_dilation, pairwise_color_thresh=self.pairwise_color_thresh,
+                    warmup_factor=self._tick(in_eval), iter_counter=self._iter if in_eval else None)
+            except BaseException:
+                self._iter_host = None          # a refused call may not have counted: re-read the buffer next time
+                raise
         warmup = self._tick()
         if not self.boxinst_enabled:
             return {'loss_mask': self._supervised_loss(mask_logits, gt_inds, gt_masks)}
-        if F_hip.fused_supported(self.pairwise_size, self.pairwise_dilation):
-            return F_hip.boxinst_mask_loss(
-                mask_logits, gt_inds, gt_bboxes, imgs=imgs, img_metas=img_metas, out_stride=self.out_stride,
-                bottom_pixels_removed=self.bottom_pixels_removed, pairwise_size=self.pairwise_size,
-                pairwise_dilation=self.pairwise_dilation, pairwise_color_thresh=self.pairwise_color_thresh,
-                warmup_factor=warmup)
         return self._composed_loss(imgs, img_metas, mask_logits, gt_inds, gt_bboxes, warmup)
 
     def _composed_loss(self, imgs, img_metas, mask_logits, gt_inds, gt_bboxes, warmup: float):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BXI_ABI_VERSION 3
+#define BXI_ABI_VERSION 4
 #define BXI_MAX_IMAGES 64   /* images per call (per-image metadata travels in kernel arguments) */
 
 typedef enum bxi_status {
@@ -146,6 +146,10 @@ typedef struct bxi_instances {
     int B;
     int Hc, Wc;               /* canvas size in pixels (h*stride, w*stride)                        */
     int stride;               /* out_stride                                                       */
+    float* iter_counter;      /* optional (NULL = none): device float the evaluation entry points
+                                 (bxi_boxinst_eval_f32, bxi_boxinst_head_eval_f32) add 1.0f to, inside
+                                 their last launch -- `self._iter += 1`, condinst_head.py:1297, without
+                                 a launch of its own.  Other entry points ignore it.                */
 } bxi_instances;
 
 size_t bxi_boxinst_loss_workspace_bytes(int N, int h, int w);

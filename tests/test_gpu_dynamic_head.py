@@ -340,6 +340,7 @@ def test_head_fused_backward_twice_with_retain_graph(dev):
         f = feat.clone().requires_grad_(True); p = params.clone().requires_grad_(True)
         it = int(head._iter.item())
         _, losses = head.forward_loss(f, p, coors, lvl, img_inds, imgs, d['img_metas'], gt_inds, boxes, fuse_head=True)
+        assert float(head._iter) == it + 1              # counted inside the head-fused evaluation's last launch
         head.set_iter(it)                               # the same warm-up factor for every evaluation of this test
         return f, p, losses
 

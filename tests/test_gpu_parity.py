@@ -462,6 +462,70 @@ def test_head_loss_and_targets(dev):
                   [b.cpu() for b in t['gt_bboxes']], None, None)
 
 
+def test_iteration_counter_is_advanced_by_the_evaluation(dev):
+    """`self._iter += 1` (condinst_head.py:1297) rides in the evaluation's last launch: the buffer advances by exactly one per loss()
+    call in every form of the evaluation (single launch, two launches, no instances, head-fused, no_grad, re-entrant backward counts
+    once), the host mirror follows it without a sync, external writes are noticed, and the launch count of a call drops by one."""
+    import ctypes as C
+    from boxinstseg_amd import CondInstMaskHead, _lib
+    d = synthetic.cfg1(0)
+    t = to_dev(d, dev)
+    head = CondInstMaskHead(in_channels=16, boxinst_enabled=True, topk_per_img=64, max_proposals=-1, pairwise_warmup=100).to(dev)
+    lib = _lib.load()
+    expect = 0.0
+    for form in (0, 2):
+        lib.bxi_debug_set_eval_form(form)
+        try:
+            for grad in (True, False):
+                x = t['logits'].clone().requires_grad_(grad)
+                with torch.set_grad_enabled(grad):
+                    out = head.loss(t['imgs'], d['img_metas'], x, t['gt_inds'], t['gt_bboxes'], None, None)
+                expect += 1.0
+                assert float(head._iter) == expect and head._iter_host == expect
+                if grad:                                    # two backward passes through one node: still one iteration
+                    (out['loss_prj'] + out['loss_pairwise']).backward(retain_graph=True)
+                    (out['loss_prj'] + 2 * out['loss_pairwise']).backward()
+                    assert float(head._iter) == expect
+        finally:
+            lib.bxi_debug_set_eval_form(0)
+    # warm-up factor from the mirror = the reference's min(_iter / warmup, 1) with the incremented value
+    x = t['logits'].clone()
+    with torch.no_grad():
+        a = head.loss(t['imgs'], d['img_metas'], x, t['gt_inds'], t['gt_bboxes'], None, None)
+    expect += 1.0
+    head.set_iter(100 * 7)                                   # factor 1 from here on
+    with torch.no_grad():
+        b = head.loss(t['imgs'], d['img_metas'], x, t['gt_inds'], t['gt_bboxes'], None, None)
+    assert float(head._iter) == 701.0
+    assert rel(float(a['loss_pairwise']), float(b['loss_pairwise']) * expect / 100.0) <= 1e-6
+    # no instances: the zero-loss launch counts
+    with torch.no_grad():
+        head.loss(t['imgs'], d['img_metas'], x[:0], t['gt_inds'][:0], t['gt_bboxes'], None, None)
+    assert float(head._iter) == 702.0
+    # an external in-place write is noticed (version counter), the kernel's own increments are not mistaken for one
+    head._iter.fill_(5.0)
+    with torch.no_grad():
+        head.loss(t['imgs'], d['img_metas'], x, t['gt_inds'], t['gt_bboxes'], None, None)
+    assert float(head._iter) == 6.0 and head._iter_host == 6.0
+    # a refused call does not leave the mirror ahead of the buffer
+    with pytest.raises(RuntimeError):
+        head.loss(t['imgs'], d['img_metas'], x[:, :, :-1].contiguous(), t['gt_inds'], t['gt_bboxes'], None, None)
+    with torch.no_grad():
+        head.loss(t['imgs'], d['img_metas'], x, t['gt_inds'], t['gt_bboxes'], None, None)
+    assert float(head._iter) == 7.0
+    # one launch per call at this size, counted through the launch hook
+    calls = []
+    cb = _lib.LAUNCH_HOOK(lambda name, phase, st, user: calls.append(name))
+    lib.bxi_set_launch_hook(C.cast(cb, C.c_void_p), None)
+    try:
+        with torch.no_grad():
+            head.loss(t['imgs'], d['img_metas'], x, t['gt_inds'], t['gt_bboxes'], None, None)
+    finally:
+        lib.bxi_set_launch_hook(None, None)
+    torch.cuda.synchronize()
+    assert len(calls) // 2 <= 2 and float(head._iter) == 8.0
+
+
 def test_head_composed_window5(dev):
     """pairwise_size=5 goes through the op-level kernels + torch glue; compare with the oracle."""
     from boxinstseg_amd import CondInstMaskHead
