@@ -336,6 +336,8 @@ def worker(args):
         result['parity'] = parity
 
     extras = rank == 0 and world == 1 and not args.no_extras
+    # the extras are not `value`: each runs its own count of steps (the driver's 20-step invocation is too short a sample for them)
+    n_extra = max(args.steps, 300)
     # ---- extra (not `value`): independent evaluations pipelined over several HIP streams ------------------------
     if extras and args.mode == 'eager':
         extra = {}
@@ -347,12 +349,12 @@ def worker(args):
             run_multi(64)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
-            run_multi(args.steps)
+            run_multi(n_extra)
             torch.cuda.synchronize(dev)
             el = time.perf_counter() - t1
-            extra[f'{ns}_streams'] = {'images_per_s': 2 * args.steps / el, 'us_per_step': el / args.steps * 1e6}
+            extra[f'{ns}_streams'] = {'images_per_s': 2 * n_extra / el, 'us_per_step': el / n_extra * 1e6}
         torch.cuda.synchronize(dev)
-        n_host = min(args.steps, 200)              # few enough that the queue never fills: the host's own cost per call
+        n_host = 200              # few enough that the queue never fills: the host's own cost per call
         t1 = time.perf_counter()
         for i in range(n_host):
             enqueue(sets[i % len(sets)], stream.cuda_stream)
@@ -368,29 +370,29 @@ def worker(args):
                 enqueue(sets[0], st)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(n_extra):
                 enqueue(sets[0], st)
             torch.cuda.synchronize(dev)
         el = time.perf_counter() - t1
-        result['warm_cache_extra'] = {'images_per_s': 2 * args.steps / el, 'us_per_step': el / args.steps * 1e6,
+        result['warm_cache_extra'] = {'images_per_s': 2 * n_extra / el, 'us_per_step': el / n_extra * 1e6,
                                       'note': 'ONE input set re-used (inputs L2 / Infinity-Cache resident); `value` rotates over '
                                               f'{args.sets} sets so that every read is cold'}
         # ---- extra: evaluation + the rescale launch autograd's backward() adds (returns at once for unit factors) ----
         with torch.cuda.stream(stream):
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
-            for i in range(args.steps):
+            for i in range(n_extra):
                 s = sets[i % len(sets)]
                 enqueue(s, st)
                 f_rescale(*s.rescale_args, st)
             torch.cuda.synchronize(dev)
         el = time.perf_counter() - t1
-        result['autograd_backward_extra'] = {'images_per_s': 2 * args.steps / el, 'us_per_step': el / args.steps * 1e6,
+        result['autograd_backward_extra'] = {'images_per_s': 2 * n_extra / el, 'us_per_step': el / n_extra * 1e6,
                                              'note': 'bxi_boxinst_eval_f32 + bxi_boxinst_grad_rescale_f32 (one launch more than `value`): the C-ABI '
                                                      'sequence behind loss() + backward() when the upstream factors are only '
                                                      'known at backward time'}
-        result['head_fused_extra'] = head_fused(lib, Fh, sets, dev, stream, args.steps)
-        result['module_api'] = module_api(sets, dev, min(args.steps, 300))
+        result['head_fused_extra'] = head_fused(lib, Fh, sets, dev, stream, n_extra)
+        result['module_api'] = module_api(sets, dev, 300)
 
     # ---- per-kernel durations with HIP events on the launching stream (rank 0, N == 1) ------------
     if rank == 0 and world == 1 and not args.no_kernel_timing:
