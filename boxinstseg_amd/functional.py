@@ -434,10 +434,14 @@ class BoxInstMaskLoss(torch.autograd.Function):
             _, x, gi, boxes, _, metas, bpr = keep
             plan.patch(metas, bpr, x.size(0), boxes)             # another evaluation of the same shape class may have come in between
             plan.inst.logits, plan.inst.gt_inds = x.data_ptr(), gi.data_ptr()
-            with torch.cuda.device(dev):
-                _lib.check('bxi_boxinst_grad_rescale_f32', plan.rescale(
-                    plan.inst_ref, g_prj.data_ptr(), g_pw.data_ptr(), int(ctx.cfg['pairwise_dilation']), state,
-                    grad.data_ptr(), _current_stream(dev)))
+            args = (plan.inst_ref, g_prj.data_ptr(), g_pw.data_ptr(), int(ctx.cfg['pairwise_dilation']), state,
+                    grad.data_ptr(), _current_stream(dev))
+            if torch.cuda.current_device() == dev.index:          # the usual case: no device guard to set up and tear down
+                rc = plan.rescale(*args)
+            else:
+                with torch.cuda.device(dev):
+                    rc = plan.rescale(*args)
+            _lib.check('bxi_boxinst_grad_rescale_f32', rc)
         if grad.dtype != ctx.in_dtype:
             grad = grad.to(ctx.in_dtype)
         return grad, None, None, None, None, None, None
