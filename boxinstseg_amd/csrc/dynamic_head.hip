@@ -39,16 +39,17 @@ namespace bxi {
 template <int C, bool REL, int F>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void dyn_fwd_kernel(DynArgs a, const float* __restrict__ params, float* __restrict__ logits) {
-    constexpr int kHalo = (kYR + 2) * (kYC + 2);
-    __shared__ float ytile[kHalo];
-    const int tiles_x = (a.W + kYC - 1) / kYC, tiles_y = (a.H + kYR - 1) / kYR;
+    constexpr int kHalo = (kFwdR + 1 + DynHalo<F>::after) * (kFwdC + 1 + DynHalo<F>::after);
+    constexpr int TR = kHalo <= 512 ? kFwdR : kYR;           // factors that need the halo on all four sides keep the 8-row tile
+    __shared__ float ytile[512];
+    const int tiles_x = (a.W + kFwdC - 1) / kFwdC, tiles_y = (a.H + TR - 1) / TR;
     int t = blockIdx.x;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int n = t / tiles_y;
     BXI_T(3, blockIdx.x, 0);
-    dyn_tile_forward<C, REL, F, false>(a, params, logits, n, ty, tx, ytile, nullptr, nullptr, DynEpi{});
-    BXI_T(3, blockIdx.x, 3);
+    dyn_tile_forward<C, REL, F, false, TR, kFwdC>(a, params, logits, n, ty, tx, ytile, nullptr, nullptr, DynEpi{});
+    BXI_T(3, blockIdx.x, 4);
 }
 
 // ---- backward --------------------------------------------------------------------------------------
@@ -465,7 +466,8 @@ int bxi_dynamic_mask_forward_f32(const float* feat, int B, int C, int H, int W, 
     if (N == 0) return BXI_OK;
     if (!logits) return BXI_ERR_NULL_POINTER;
     hipStream_t s = bxi::as_stream(stream);
-    const unsigned grid = (unsigned)(N * bxi::dyn_tiles(H, W));
+    const int fwd_rows = (factor == 1 || factor == 2) ? bxi::kFwdR : bxi::kYR;          // as dyn_fwd_kernel chooses
+    const unsigned grid = (unsigned)(N * ((H + fwd_rows - 1) / fwd_rows) * ((W + bxi::kFwdC - 1) / bxi::kFwdC));
     BXI_DYN_DISPATCH(C, a.rel, factor, BXI_LAUNCH("dyn_fwd", s, (bxi::dyn_fwd_kernel<KC, KR, KF>), dim3(grid), dim3(256), 0, s, a, params, logits));
     return bxi::check_launch();
 }

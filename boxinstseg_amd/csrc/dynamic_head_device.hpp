@@ -7,7 +7,11 @@
 namespace bxi {
 
 constexpr int kDC = 8;            // dynamic_channels (configs/boxinst: 8)
-constexpr int kYR = 8, kYC = 32;  // y tile (pixels at in_stride resolution) per workgroup
+constexpr int kYR = 8, kYC = 32;  // y tile (pixels at in_stride resolution) per workgroup: the backward (thread = pixel) and the head-fused launch
+constexpr int kFwdR = 14, kFwdC = 32;   // y tile of the forward kernel (factors 1, 2): with its halo 15 x 33 = 495 pixels on the 512 (thread, pixel)
+                                        // slots of a workgroup; 1024 workgroups instead of 1664 at 32 x 100 x 128: 13.3 -> 12.9 us
+constexpr int kHeadR = 8;               // rows of a head tile inside the evaluation's first launch (any multiple of 2 up to 14; measured with
+                                        // 14: head_prep 20.1 -> 21.2 us -- that launch is not bound by the head tiles' arithmetic)
 constexpr int kSlots = 8;         // instance slots per (image, tile) in the backward
 constexpr int kRowPad = kYR * kYC;       // LDS row stride of the staged operand rows
 
@@ -151,52 +155,66 @@ struct DynEpi {
                                     //    them after an arrival counter (eval3.hip: the instance's last tile is its leader)
 };
 
-// One workgroup: y on an 8 x 32 tile (+ 1 halo) of instance n, up-sampled to the logits tile.  Thread t evaluates pixels 2t and
+// One workgroup: y on a TR x TC tile (+ halo) of instance n, up-sampled to the logits tile.  Thread t evaluates pixels 2t and
 // 2t+1 of the halo tile (each weight feeds both), y goes to LDS, the up-sampled tile is written with float2 / float4 stores.
-template <int C, bool REL, int F, bool EPI>
+// Halo: one row above and one column to the left; below / to the right only when the factor needs it -- for factors 1 and 2 the last
+// output row of a tile samples its last y row with weight 1 (upsample_src: fraction 0), so the 8 x 32 tile stages 9 x 33 pixels, not
+// 10 x 34, and a 14 x 32 tile's 495 fill the 512 (thread, pixel) slots of a workgroup (8 x 32: 340 of 512).
+template <int F> struct DynHalo { static constexpr int after = (F == 1 || F == 2) ? 0 : 1; };
+template <int C, bool REL, int F, bool EPI, int TR = kYR, int TC = kYC>
 __device__ __forceinline__ void dyn_tile_forward(const DynArgs& a, const float* __restrict__ params, float* __restrict__ logits, int n,
-                                                 int ty, int tx, float* ytile /* LDS [(kYR+2)*(kYC+2)] */,
-                                                 float* otile /* LDS [kYR*F][kYC*F], EPI */,
-                                                 unsigned long long* ckeys /* LDS [4][kYC*F], EPI */, const DynEpi& ep) {
+                                                 int ty, int tx, float* ytile /* LDS [(TR+1+after)*(TC+1+after)] */,
+                                                 float* otile /* LDS [TR*F][TC*F], EPI */,
+                                                 unsigned long long* ckeys /* LDS [4][TC*F], EPI */, const DynEpi& ep) {
     using D = Dyn<C, REL>;
-    constexpr int kHalo = (kYR + 2) * (kYC + 2);
+    constexpr int HB = DynHalo<F>::after, PW = TC + 1 + HB, PH = TR + 1 + HB;
+    constexpr int kHalo = PH * PW;
+    static_assert(kHalo <= 512, "two pixels per thread");
+    constexpr int kYR = TR, kYC = TC;                       // (shadow the namespace constants below)
     const int tid = threadIdx.x;
     // the instance's 233 parameters are wave-uniform: scalar loads, SGPR operands of the FMAs (no LDS, no VGPRs)
     const float* __restrict__ wts = params + (int64_t)n * D::P;
     const int b = (int)a.img[n];
-    // y on the tile plus one pixel of halo on every side (rows r0-1 .. r0+kYR): 340 pixels on 256 threads.
+    // y on the tile plus its halo (rows r0-1 .. r0+kYR-1+HB): up to 512 pixels on 256 threads.
     // Both pixels of a thread are loaded (clamped coordinates, no branch) before either is evaluated.
     const int r0 = ty * kYR, c0 = tx * kYC;
     const int eA = 2 * tid, eB = 2 * tid + 1;
-    const int rA = r0 - 1 + eA / (kYC + 2), cA = c0 - 1 + eA % (kYC + 2);
-    const int rB = r0 - 1 + eB / (kYC + 2), cB = c0 - 1 + eB % (kYC + 2);
+    const int rA = r0 - 1 + eA / PW, cA = c0 - 1 + eA % PW;
+    const int rB = r0 - 1 + eB / PW, cB = c0 - 1 + eB % PW;
     const bool vA = eA < kHalo && rA >= 0 && rA < a.H && cA >= 0 && cA < a.W;
     const bool vB = eB < kHalo && rB >= 0 && rB < a.H && cB >= 0 && cB < a.W;
     if (eA < kHalo) {
         float inA[D::CIN], inB[D::CIN], yA, yB;
         load_inputs<C, REL>(a, n, b, min(max(rA, 0), a.H - 1), min(max(cA, 0), a.W - 1), inA);
         load_inputs<C, REL>(a, n, b, min(max(rB, 0), a.H - 1), min(max(cB, 0), a.W - 1), inB);
+#ifdef BXI_TRACE
+        if (!EPI) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BXI_T(3, blockIdx.x, 1); }
+#endif
         mlp_forward2<C, REL>(wts, inA, inB, yA, yB);
         ytile[eA] = vA ? yA : 0.f;
         if (eB < kHalo) ytile[eB] = vB ? yB : 0.f;
     }
+    if (!EPI) BXI_T(3, blockIdx.x, 2);
     __syncthreads();
+    if (!EPI) BXI_T(3, blockIdx.x, 3);
     const int f = factor_of<F>(a), OH = a.H * f, OW = a.W * f;
     constexpr int VW = F == 0 ? 1 : (F % 4 == 0 ? 4 : (F % 2 == 0 ? 2 : 1));   // outputs per store
     const int R0 = r0 * f, C0 = c0 * f;
     const int row_w = kYC * f / VW;                          // stores per output row of the tile
     float* out = logits + (int64_t)n * OH * OW;
-    auto Y = [&](int r, int c) { return ytile[(r - r0 + 1) * (kYC + 2) + (c - c0 + 1)]; };
+    auto Y = [&](int r, int c) { return ytile[(r - r0 + 1) * PW + (c - c0 + 1)]; };
     for (int i = tid; i < kYR * f * row_w; i += 256) {
         const int R = R0 + i / row_w, Cc = C0 + (i % row_w) * VW;
         if (R >= OH || Cc >= OW) continue;
         int y0, y1; float fy;
         upsample_src(R, f, a.H, y0, y1, fy);
+        if (HB == 0) y1 = min(y1, r0 + kYR - 1);             // past the staged rows only with weight 0: keep the operand finite
         float v[VW];
 #pragma unroll
         for (int k = 0; k < VW; ++k) {
             int x0, x1; float fx;
             upsample_src(Cc + k, f, a.W, x0, x1, fx);
+            if (HB == 0) x1 = min(x1, c0 + kYC - 1);
             const float top = (1.f - fx) * Y(y0, x0) + fx * Y(y0, x1);
             const float bot = (1.f - fx) * Y(y1, x0) + fx * Y(y1, x1);
             v[k] = (1.f - fy) * top + fy * bot;
@@ -211,7 +229,7 @@ __device__ __forceinline__ void dyn_tile_forward(const DynArgs& a, const float* 
         }
     }
     if constexpr (EPI) {
-        static_assert(!EPI || (F == 2 && kYC * F == 64 && kYR * F == 16), "the epilogue maps a lane to a column of a 16 x 64 tile");
+        static_assert(!EPI || (F == 2 && kYC * F == 64 && (kYR * F) % 4 == 0), "the epilogue maps a lane to a column of a 64-wide tile, a wave to a quarter of its rows");
         constexpr int TW = kYC * F, TH = kYR * F;
         __syncthreads();
         const int wv = tid >> 6, lane = tid & 63, c = C0 + lane;
@@ -231,10 +249,12 @@ __device__ __forceinline__ void dyn_tile_forward(const DynArgs& a, const float* 
         }
         ckeys[wv * TW + lane] = ck;
         if (ep.g_zero) {                                                                            // the tile of d loss / d logits
-            const int zr = R0 + tid / (TW / 4), zc = C0 + (tid % (TW / 4)) * 4;
-            if (zr < OH && zc < OW) {
-                float* dst = ep.g_zero + ((int64_t)n * OH + zr) * OW + zc;
-                if (ep.through) store4_through(dst, 0.f, 0.f, 0.f, 0.f); else *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int z = tid; z < TH * (TW / 4); z += 256) {
+                const int zr = R0 + z / (TW / 4), zc = C0 + (z % (TW / 4)) * 4;
+                if (zr < OH && zc < OW) {
+                    float* dst = ep.g_zero + ((int64_t)n * OH + zr) * OW + zc;
+                    if (ep.through) store4_through(dst, 0.f, 0.f, 0.f, 0.f); else *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         }
         __syncthreads();

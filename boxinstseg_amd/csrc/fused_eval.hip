@@ -546,16 +546,16 @@ __global__ __launch_bounds__(256, 7) void head_prep_kernel(PoolArgs pa, int n_po
         int* part = reinterpret_cast<int*>(fch + 3 * 64);
         pool_block(pa, ws, blk - n_tab, n_pool, n_items, lut, part, fch, tix);
     } else {
-        const int tiles_x = (da.W + kYC - 1) / kYC, tiles_y = (da.H + kYR - 1) / kYR;
+        const int tiles_x = (da.W + kYC - 1) / kYC, tiles_y = (da.H + kHeadR - 1) / kHeadR;
         int t = blk - n_tab - n_pool;
         const int tx = t % tiles_x; t /= tiles_x;
         const int ty = t % tiles_y;
         const int n = t / tiles_y;
         unsigned long long* ckeys = reinterpret_cast<unsigned long long*>(smem);          // [4][64]
-        float* otile = reinterpret_cast<float*>(ckeys + 4 * 64);                          // [16][64]
-        float* ytile = otile + 16 * 64;                                                   // [(kYR+2)*(kYC+2)]
+        float* otile = reinterpret_cast<float*>(ckeys + 4 * 64);                          // [2 kHeadR][64]
+        float* ytile = otile + 2 * kHeadR * 64;                                           // [(kHeadR+1)*(kYC+1)]
         const DynEpi ep = {ws.colpart, ws.rowkey, g_logits, ws.n_cb, ws.n_rp, 0};
-        dyn_tile_forward<C, REL, 2, true>(da, params, logits_out, n, ty, tx, ytile, otile, ckeys, ep);
+        dyn_tile_forward<C, REL, 2, true, kHeadR, kYC>(da, params, logits_out, n, ty, tx, ytile, otile, ckeys, ep);
     }
 }
 
@@ -1604,6 +1604,7 @@ size_t eval_ws_bytes(int B, int N, int h, int w) { return carve(nullptr, B, N, h
 bool fused_eval_supported(int dil) { return dil >= 1 && dil <= kMaxDilFused; }
 void debug_set_spin_limit(int limit) { g_spin_limit.store(limit, std::memory_order_relaxed); }
 void debug_set_eval_form(int form) { g_form.store(form, std::memory_order_relaxed); }
+int debug_eval_form() { return g_form.load(std::memory_order_relaxed); }
 
 // One evaluation, two launches.
 int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bxi_instances* in, int dil, float warmup, const float* up_prj,
@@ -1736,10 +1737,10 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         // the head-fused first launch (factor 2, vector rows): tables, pool blocks, head tiles
         if (head->factor != 2 || !vec || head->H * 2 != a.h || head->W * 2 != a.w || head->N != a.N || head->B != in->B || !pooled_in_launch)
             return BXI_ERR_UNSUPPORTED;
-        const int tiles = ((head->H + kYR - 1) / kYR) * ((head->W + kYC - 1) / kYC);
-        ws.n_cb = (head->H + kYR - 1) / kYR;
+        const int tiles = ((head->H + kHeadR - 1) / kHeadR) * ((head->W + kYC - 1) / kYC);
+        ws.n_cb = (head->H + kHeadR - 1) / kHeadR;
         ws.n_rp = (head->W + kYC - 1) / kYC;
-        const size_t lds_head = 8 * 4 * 64 + sizeof(float) * (16 * 64 + (kYR + 2) * (kYC + 2));
+        const size_t lds_head = 8 * 4 * 64 + sizeof(float) * (2 * kHeadR * 64 + 512);
         if (lds1 < lds_head) lds1 = lds_head;
         if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
         float* logits_out = const_cast<float*>(a.logits);

@@ -180,7 +180,13 @@ int launch_mst_large(const int* edge_index, const float* edge_weight, int B, int
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct BfsLargeWs { uint32_t* adj; uint32_t* deg; uint32_t* nodev; uint32_t* nodep; uint32_t* pos_of; int* flag; int* nf; int* gw; unsigned char* gmask; };
+struct BfsLargeWs {
+    uint32_t* adj; uint32_t* deg; uint32_t* nodev; uint32_t* nodep; uint32_t* pos_of; int* flag; int* nf; int* gw; unsigned char* gmask;
+    // the Euler-tour form (below): two list rankings over the 4V arc slots, per-vertex results, the pairs of the radix sort
+    unsigned long long* e1; unsigned long long* e2; int* pk; uint32_t* cnt; uint32_t* key[2]; uint32_t* val[2]; uint32_t* hist; int* bad; int* maxdep;
+};
+constexpr int kEulerMaxV = (1 << 20) - 1;          // arc ids (and the end marker 4V) < 2^22 and counts < 2^21 share one 64-bit word
+constexpr int kSortTile = 1024, kSortBits = 9, kSortBuckets = 1 << kSortBits;
 __host__ __device__ static size_t carve_bfs_large(char* base, int V, BfsLargeWs* w) {
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += up16(b); return base ? base + o : nullptr; };
@@ -188,6 +194,13 @@ __host__ __device__ static size_t carve_bfs_large(char* base, int V, BfsLargeWs*
     t.adj = (uint32_t*)take(16 * (size_t)V); t.deg = (uint32_t*)take(4 * (size_t)V); t.nodev = (uint32_t*)take(4 * (size_t)(V + 1));
     t.nodep = (uint32_t*)take(4 * (size_t)(V + 1)); t.pos_of = (uint32_t*)take(4 * (size_t)V);
     t.flag = (int*)take(4); t.nf = (int*)take(4); t.gw = (int*)take(4); t.gmask = (unsigned char*)take((size_t)V);
+    const bool euler = V <= kEulerMaxV;
+    const size_t nblk = ((size_t)V + kSortTile - 1) / kSortTile;
+    t.e1 = (unsigned long long*)take(euler ? 32 * (size_t)V : 0); t.e2 = (unsigned long long*)take(euler ? 32 * (size_t)V : 0);
+    t.pk = (int*)take(euler ? 4 * (size_t)V : 0); t.cnt = (uint32_t*)take(euler ? 4 * (size_t)(V + 1) : 0);
+    for (int q = 0; q < 2; ++q) { t.key[q] = (uint32_t*)take(euler ? 4 * (size_t)V : 0); t.val[q] = (uint32_t*)take(euler ? 4 * (size_t)V : 0); }
+    t.hist = (uint32_t*)take(euler ? 4 * (size_t)kSortBuckets * nblk : 0);
+    t.bad = (int*)take(4); t.maxdep = (int*)take(4);
     if (w) *w = t;
     return off;
 }
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(256) void bfsL_zero_kernel(int V, int max_adj, int*
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
     if (i < V) w.deg[i] = 0u;
-    if (i == 0) { *w.flag = 0; *w.gw = 0; }
+    if (i == 0) { *w.flag = 0; *w.gw = 0; *w.bad = 0; *w.maxdep = 0; }
     if (i < (int64_t)V * max_adj) sorted_child[(int64_t)b * V * max_adj + i] = 0;
 }
 __global__ __launch_bounds__(256) void bfsL_adj_kernel(const int* __restrict__ tree, int V, char* ws_base, size_t ws_stride) {
@@ -504,6 +517,279 @@ __global__ __launch_bounds__(256) void bfsL_parent_kernel(int V, int max_adj, in
     if (k < max_adj) sorted_child[(int64_t)b * V * max_adj + (size_t)pp * max_adj + k] = p;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// The Euler-tour form of the BFS: no walk through the tree's depth at all.  The level walk above is ~1700 dependent steps of one wave at
+// 200 x 304 (0.61 ms); here every pass is grid-wide and their number depends on log V only:
+//   1. every undirected edge is two ARCS, arc (v -> adj[v][k]) = slot 4v + k; the successor "after arriving at u from v, leave for the
+//      neighbour that follows v in u's list (cyclically)" strings all arcs into one cycle, cut where it would return to arc 0: a list
+//      from arc 0 = (0 -> adj[0][0]) to the last arc back into the root;
+//   2. LIST RANKING by pointer jumping gives every arc its distance to the end of the list; of the two arcs of an edge the one earlier
+//      in the tour leads AWAY from the root, which tells every vertex its parent;
+//   3. a second tour that visits the children of every vertex in ascending order (the order bfs.cu appends them in) is ranked with two
+//      weights, "leads down" / "leads up": the suffix counts at the arc (parent -> v) give v's PREORDER number and its DEPTH;
+//   4. BFS order = by depth, within a depth by preorder (subtrees are contiguous in preorder, so on every level the preorder of the nodes is
+//      the preorder of their parents, then the child order -- the queue's order): a stable LSD radix sort of the preorder sequence by depth;
+//      the level offsets are the scanned depth histogram.
+// Pointer jumping is done IN PLACE and asynchronously: a slot holds (successor, weight of the arcs from this one up to, not including, the
+// successor) in ONE 64-bit word, so any value a thread reads -- this launch's or a staler one from its XCD's L2 -- is a correct pair, and
+// jumping over it keeps the pair correct; every launch makes each thread jump kEulerJumps times over values at least as advanced as the
+// previous launch left them, so ceil(log(arcs) / log(kEulerJumps + 1)) launches reach the end from everywhere.  Integer sums: the result is exact and
+// the same on every run whatever the interleaving.
+// Input that is not a connected tree of degree <= 4 leaves arcs that never reach the end of the list: reported as by the walk (levels[0] = -1).
+constexpr int kEulerJumps = 4;
+__device__ __forceinline__ unsigned long long e1_pack(uint32_t succ, uint32_t dist) { return ((unsigned long long)dist << 32) | succ; }
+__device__ __forceinline__ unsigned long long e2_pack(uint32_t succ, uint32_t down, uint32_t up) {
+    return ((unsigned long long)up << 43) | ((unsigned long long)down << 22) | succ;
+}
+__device__ __forceinline__ uint32_t e2_succ(unsigned long long x) { return (uint32_t)x & 0x3fffffu; }
+__device__ __forceinline__ uint32_t e2_down(unsigned long long x) { return (uint32_t)(x >> 22) & 0x1fffffu; }
+__device__ __forceinline__ uint32_t e2_up(unsigned long long x) { return (uint32_t)(x >> 43); }
+// index of vertex v in u's (sorted) neighbour list, or -1
+__device__ __forceinline__ int nb_index(const BfsLargeWs& w, uint32_t u, uint32_t v, int du) {
+    const uint4 q = *reinterpret_cast<const uint4*>(w.adj + 4 * (size_t)u);
+    return (du > 0 && q.x == v) ? 0 : ((du > 1 && q.y == v) ? 1 : ((du > 2 && q.z == v) ? 2 : ((du > 3 && q.w == v) ? 3 : -1)));
+}
+__global__ __launch_bounds__(256) void bfsE_succ1_kernel(int V, char* ws_base, size_t ws_stride) {
+    const int b = blockIdx.y;
+    const uint32_t a = blockIdx.x * 256 + threadIdx.x, SENT = 4u * (uint32_t)V;
+    if (a >= SENT) return;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    const uint32_t v = a >> 2;
+    const int k = (int)(a & 3u), d = (int)min(w.deg[v], 4u);
+    unsigned long long out = e1_pack(SENT, 0u);                        // a slot without an arc
+    if (k < d) {
+        const uint32_t u = w.adj[a];
+        if (u < (uint32_t)V) {
+            const int du = (int)min(w.deg[u], 4u), j = nb_index(w, u, v, du);
+            if (j >= 0) {
+                const uint32_t s = 4u * u + (uint32_t)(j + 1 == du ? 0 : j + 1);
+                out = e1_pack(s == 0u ? SENT : s, 1u);                  // the arc that would lead back to arc 0 ends the list
+            } else atomicOr(w.bad, 1);
+        } else atomicOr(w.bad, 1);
+    }
+    w.e1[a] = out;
+}
+__global__ __launch_bounds__(256) void bfsE_rank1_kernel(int V, char* ws_base, size_t ws_stride) {
+    const int b = blockIdx.y;
+    const uint32_t a = blockIdx.x * 256 + threadIdx.x, SENT = 4u * (uint32_t)V;
+    if (a >= SENT) return;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    unsigned long long p = w.e1[a];
+#pragma unroll
+    for (int it = 0; it < kEulerJumps; ++it) {
+        const uint32_t s = (uint32_t)p;
+        if (s >= SENT) break;
+        const unsigned long long q = w.e1[s];
+        p = e1_pack((uint32_t)q, (uint32_t)(p >> 32) + (uint32_t)(q >> 32));
+    }
+    w.e1[a] = p;
+}
+// parent of every vertex: the one neighbour whose arc towards v comes earlier in the tour than v's arc towards it
+__global__ __launch_bounds__(256) void bfsE_parent_kernel(int V, char* ws_base, size_t ws_stride) {
+    const int b = blockIdx.y;
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= (uint32_t)V) return;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    const uint32_t SENT = 4u * (uint32_t)V;
+    const int d = (int)min(w.deg[v], 4u);
+    int pk = -1, ups = 0;
+    bool ended = true;
+    for (int k = 0; k < d; ++k) {
+        const unsigned long long mine = w.e1[4u * v + k];
+        const uint32_t u = w.adj[4u * v + k];
+        if (u >= (uint32_t)V) continue;
+        const int j = nb_index(w, u, v, (int)min(w.deg[u], 4u));
+        if (j < 0) continue;
+        const unsigned long long theirs = w.e1[4u * u + j];
+        ended = ended && (uint32_t)mine >= SENT && (uint32_t)theirs >= SENT;
+        if ((uint32_t)(mine >> 32) < (uint32_t)(theirs >> 32)) { pk = k; ++ups; }      // fewer arcs left: later in the tour: this arc leads up
+    }
+    if (!ended || ups != (v == 0u ? 0 : 1)) atomicOr(w.bad, 1);       // an arc that never reached the end of the list: not one connected tree
+    w.pk[v] = pk;
+    w.cnt[v] = 0u;
+    if (v == 0u) w.cnt[V] = 0u;
+}
+__global__ __launch_bounds__(256) void bfsE_succ2_kernel(int V, char* ws_base, size_t ws_stride) {
+    const int b = blockIdx.y;
+    const uint32_t a = blockIdx.x * 256 + threadIdx.x, SENT = 4u * (uint32_t)V;
+    if (a >= SENT) return;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    const uint32_t v = a >> 2;
+    const int k = (int)(a & 3u), d = (int)min(w.deg[v], 4u);
+    unsigned long long out = e2_pack(SENT, 0u, 0u);
+    if (k < d) {
+        const uint32_t u = w.adj[a];
+        if (u < (uint32_t)V) {
+            const int du = (int)min(w.deg[u], 4u), pu = w.pk[u];
+            if (k != w.pk[v]) {                                        // down: arriving at u from its parent -> its first child, or straight back up
+                const int c = pu == 0 ? 1 : 0;
+                out = e2_pack(c < du ? 4u * u + c : (pu >= 0 ? 4u * u + pu : SENT), 1u, 0u);
+            } else {                                                   // up: arriving at u from its child v -> u's next child, or on up, or the end
+                int c = nb_index(w, u, v, du) + 1;
+                if (c == pu) ++c;
+                out = e2_pack(c < du ? 4u * u + c : (pu >= 0 ? 4u * u + pu : SENT), 0u, 1u);
+            }
+        }
+    }
+    w.e2[a] = out;
+}
+__global__ __launch_bounds__(256) void bfsE_rank2_kernel(int V, char* ws_base, size_t ws_stride) {
+    const int b = blockIdx.y;
+    const uint32_t a = blockIdx.x * 256 + threadIdx.x, SENT = 4u * (uint32_t)V;
+    if (a >= SENT) return;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    unsigned long long p = w.e2[a];
+#pragma unroll
+    for (int it = 0; it < kEulerJumps; ++it) {
+        const uint32_t s = e2_succ(p);
+        if (s >= SENT) break;
+        const unsigned long long q = w.e2[s];
+        p = e2_pack(e2_succ(q), e2_down(p) + e2_down(q), e2_up(p) + e2_up(q));
+    }
+    w.e2[a] = p;
+}
+// preorder number and depth of every vertex from the suffix counts at its parent's arc towards it; the preorder sequence (depth, vertex)
+// and the depth histogram
+__global__ __launch_bounds__(256) void bfsE_place_kernel(int V, char* ws_base, size_t ws_stride) {
+    const int b = blockIdx.y;
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    const uint32_t SENT = 4u * (uint32_t)V;
+    uint32_t pre = 0u, dep = 0u;
+    bool ok = v < (uint32_t)V;                                             // (no early return: the whole wave meets at the shuffles below)
+    if (ok && v != 0u) {
+        const int pk = w.pk[v];
+        ok = pk >= 0;
+        if (ok) {
+            const uint32_t p = w.adj[4u * v + pk];
+            const int j = p < (uint32_t)V ? nb_index(w, p, v, (int)min(w.deg[p], 4u)) : -1;
+            ok = j >= 0;
+            if (ok) {
+                const unsigned long long x = w.e2[4u * p + j];
+                const uint32_t down = e2_down(x), up = e2_up(x);           // arcs leading down / up from this one to the end, inclusive
+                ok = e2_succ(x) >= SENT && down >= 1u && down <= (uint32_t)V - 1u && up <= (uint32_t)V - 1u;
+                pre = (uint32_t)V - down;                                   // = (V - 1) - down + 1: down arcs up to and including this one
+                dep = pre - ((uint32_t)V - 1u - up);                        // minus the up arcs before it
+                ok = ok && dep >= 1u && dep <= pre;
+            }
+        }
+        if (!ok) atomicOr(w.bad, 1);
+    }
+    if (ok) {
+        w.key[0][pre] = dep; w.val[0][pre] = v;                             // (a permutation when the input is a tree)
+        atomicAdd(&w.cnt[dep], 1u);
+    }
+    int md = ok ? (int)dep : 0;                                             // one atomic per wave on the shared word, not one per vertex
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) md = max(md, __shfl_xor(md, off, kWave));
+    if ((threadIdx.x & 63) == 0 && md > 0) atomicMax(w.maxdep, md);
+}
+// level offsets: lv[1 + d] = number of vertices of depth < d (one workgroup per graph; D levels)
+__global__ __launch_bounds__(kLT) void bfsE_levels_kernel(int V, int* __restrict__ levels, char* ws_base, size_t ws_stride) {
+    __shared__ int part[17];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    int* lv = levels + (int64_t)b * (V + 2);
+    const bool bad = (*w.flag & 1) || *w.bad;
+    const int D = bad ? 0 : *w.maxdep + 1;
+    int base = 0;
+    for (int d0 = 0; d0 < D; d0 += kLT) {
+        const int d = d0 + tid;
+        const int c = d < D ? (int)w.cnt[d] : 0;
+        int total;
+        // (block_excl_scan sums values 0..4 per thread elsewhere; the counts here are arbitrary ints: the same code)
+        const int ex = block_excl_scan(c, part, total);
+        if (d < D) lv[1 + d] = base + ex;
+        base += total;
+    }
+    if (tid == 0) {
+        const bool whole = !bad && base == V;
+        lv[0] = whole ? D : -1;
+        if (whole) lv[1 + D] = V;
+        *w.nf = whole ? V : 0;
+        if (!whole) atomicOr(w.bad, 1);
+        atomicOr(w.flag, 2);                            // nodev / nodep below are plain (vertex, parent) arrays, not the walk's grid words
+    }
+}
+// ---- stable LSD radix sort of the (depth, vertex) pairs, kSortBits bits a pass, one wave per tile of kSortTile pairs -------------------
+__device__ __forceinline__ unsigned long long same_digit_lanes(uint32_t digit, bool valid) {
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < kSortBits; ++bit) {
+        const unsigned long long m = __ballot((digit >> bit) & 1u);
+        peers &= ((digit >> bit) & 1u) ? m : ~m;
+    }
+    return peers;
+}
+__global__ __launch_bounds__(64) void bfsE_sort_hist_kernel(int V, int pass, char* ws_base, size_t ws_stride) {
+    __shared__ uint32_t h[kSortBuckets];
+    const int b = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x, nblk = gridDim.x;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    const uint32_t* key = w.key[pass & 1];
+    for (int i = lane; i < kSortBuckets; i += 64) h[i] = 0u;
+    __syncthreads();
+    for (int i = blk * kSortTile + lane; i < min((blk + 1) * kSortTile, V); i += 64) atomicAdd(&h[(key[i] >> (pass * kSortBits)) & (kSortBuckets - 1)], 1u);
+    __syncthreads();
+    for (int i = lane; i < kSortBuckets; i += 64) w.hist[(size_t)i * nblk + blk] = h[i];          // bucket-major: one scan gives every tile its places
+}
+__global__ __launch_bounds__(kLT) void bfsE_sort_scan_kernel(int V, int nblk, char* ws_base, size_t ws_stride) {
+    __shared__ int part[17];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    const int n = kSortBuckets * nblk;
+    constexpr int E = 8;                                 // consecutive entries per thread: 30 720 entries at 200 x 304 are four trips, not thirty
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += kLT * E) {
+        const int i = i0 + tid * E;
+        uint32_t c[E];
+        int mine = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { c[e] = i + e < n ? w.hist[i + e] : 0u; mine += (int)c[e]; }
+        int total;
+        int at = base + block_excl_scan(mine, part, total);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { if (i + e < n) w.hist[i + e] = (uint32_t)at; at += (int)c[e]; }
+        base += total;
+    }
+}
+__global__ __launch_bounds__(64) void bfsE_sort_scatter_kernel(int V, int pass, char* ws_base, size_t ws_stride) {
+    __shared__ uint32_t place[kSortBuckets];
+    const int b = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x, nblk = gridDim.x;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    const uint32_t* key = w.key[pass & 1]; const uint32_t* val = w.val[pass & 1];
+    uint32_t* key_o = w.key[(pass & 1) ^ 1]; uint32_t* val_o = w.val[(pass & 1) ^ 1];
+    for (int i = lane; i < kSortBuckets; i += 64) place[i] = w.hist[(size_t)i * nblk + blk];
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int end = min((blk + 1) * kSortTile, V);
+    for (int i0 = blk * kSortTile; i0 < end; i0 += 64) {              // strips in order: the sort is stable
+        const int i = i0 + lane;
+        const bool valid = i < end;
+        const uint32_t k = valid ? key[i] : 0u, x = valid ? val[i] : 0u;
+        const uint32_t digit = (k >> (pass * kSortBits)) & (kSortBuckets - 1);
+        const unsigned long long peers = same_digit_lanes(digit, valid);
+        if (valid) {
+            const uint32_t at = place[digit] + (uint32_t)__popcll(peers & lt);
+            if (at < (uint32_t)V) { key_o[at] = k; val_o[at] = x; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // everybody has read `place` before the group leaders advance it
+        if (valid && (peers >> lane) == 1ull) place[digit] += (uint32_t)__popcll(peers);   // the highest lane of every group
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+__global__ __launch_bounds__(256) void bfsE_fill_kernel(int V, int src, char* ws_base, size_t ws_stride) {
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= V) return;
+    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
+    const uint32_t v = *w.bad ? 0u : w.val[src][p];
+    const int pk = v < (uint32_t)V ? w.pk[v] : -1;
+    w.nodev[p] = v < (uint32_t)V ? v : 0u;
+    w.nodep[p] = (p == 0 || pk < 0) ? 0xffffffffu : w.adj[4u * v + pk];
+}
+
+int debug_eval_form();      // fused_eval.hip: bit 16 = the level walk instead of the Euler tour (tests compare the two)
+
 int launch_bfs_large(const int* tree, int B, int V, int max_adj, int* si, int* sp, int* sc, int* levels, char* ws, hipStream_t s) {
     if (B > 65535) return BXI_ERR_BAD_SHAPE;
     const size_t stride = bfs_large_ws_bytes(V);
@@ -511,7 +797,30 @@ int launch_bfs_large(const int* tree, int B, int V, int max_adj, int* si, int* s
     BXI_LAUNCH("bfs_large_zero", s, bfsL_zero_kernel, gz, dim3(256), 0, s, V, max_adj, sc, ws, stride);
     BXI_LAUNCH("bfs_large_adj", s, bfsL_adj_kernel, gv, dim3(256), 0, s, tree, V, ws, stride);
     BXI_LAUNCH("bfs_large_sort", s, bfsL_sort_kernel, gv, dim3(256), 0, s, V, ws, stride);
-    {
+    if (V <= kEulerMaxV && V >= 2 && !(debug_eval_form() & 16)) {
+        const dim3 ga((unsigned)((4 * (size_t)V + 255) / 256), (unsigned)B);
+        // a launch is only guaranteed to see what the PREVIOUS launch wrote: each of a thread's jumps then adds at least the span its target
+        // had when the launch began, so a launch multiplies every span by at least kEulerJumps + 1 (by 2^kEulerJumps when it sees its own)
+        int rounds = 0;
+        for (long long span = 1; span < 2ll * V; span *= kEulerJumps + 1) ++rounds;
+        BXI_LAUNCH("bfs_euler_succ1", s, bfsE_succ1_kernel, ga, dim3(256), 0, s, V, ws, stride);
+        for (int r = 0; r < rounds; ++r) BXI_LAUNCH("bfs_euler_rank1", s, bfsE_rank1_kernel, ga, dim3(256), 0, s, V, ws, stride);
+        BXI_LAUNCH("bfs_euler_parent", s, bfsE_parent_kernel, gv, dim3(256), 0, s, V, ws, stride);
+        BXI_LAUNCH("bfs_euler_succ2", s, bfsE_succ2_kernel, ga, dim3(256), 0, s, V, ws, stride);
+        for (int r = 0; r < rounds; ++r) BXI_LAUNCH("bfs_euler_rank2", s, bfsE_rank2_kernel, ga, dim3(256), 0, s, V, ws, stride);
+        BXI_LAUNCH("bfs_euler_place", s, bfsE_place_kernel, gv, dim3(256), 0, s, V, ws, stride);
+        BXI_LAUNCH("bfs_euler_levels", s, bfsE_levels_kernel, dim3(B), dim3(kLT), 0, s, V, levels, ws, stride);
+        int key_bits = 1;
+        while ((1ll << key_bits) < (long long)V) ++key_bits;                     // depths are < V
+        const int passes = (key_bits + kSortBits - 1) / kSortBits;
+        const int nblk = (V + kSortTile - 1) / kSortTile;
+        for (int pass = 0; pass < passes; ++pass) {
+            BXI_LAUNCH("bfs_euler_sort_hist", s, bfsE_sort_hist_kernel, dim3(nblk, B), dim3(64), 0, s, V, pass, ws, stride);
+            BXI_LAUNCH("bfs_euler_sort_scan", s, bfsE_sort_scan_kernel, dim3(B), dim3(kLT), 0, s, V, nblk, ws, stride);
+            BXI_LAUNCH("bfs_euler_sort_scatter", s, bfsE_sort_scatter_kernel, dim3(nblk, B), dim3(64), 0, s, V, pass, ws, stride);
+        }
+        BXI_LAUNCH("bfs_euler_fill", s, bfsE_fill_kernel, gv, dim3(256), 0, s, V, passes & 1, ws, stride);
+    } else {
         const size_t lds = V <= kBfsMaskCap ? (size_t)(V + 15) / 16 * 16 : 0;
         if (lds > 48 * 1024) {
             static std::atomic<int> attr_set{0};

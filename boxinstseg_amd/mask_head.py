@@ -130,12 +130,15 @@ class CondInstMaskHead(nn.Module):
         of ``bxi_instances``; stream-ordered like the ``+=`` it replaces, and it does not touch the version counter) -- a 9 us
         launch of its own otherwise."""
         it = self._iter                                   # (a buffer: every `self._iter` goes through Module.__getattr__)
-        seen = (it._version, it.data_ptr())
-        if self._iter_host is None or getattr(self, '_iter_seen', None) != seen:
+        try:
+            seen = (it._version, it.data_ptr())
+        except RuntimeError:                              # an inference-mode tensor has no version counter: never trust the mirror
+            seen = None
+        if self._iter_host is None or seen is None or getattr(self, '_iter_seen', None) != seen:
             self._iter_host = float(it.item())
         if not in_evaluation:
             it += 1
-            seen = (it._version, seen[1])
+            seen = (it._version, seen[1]) if seen is not None else None
         self._iter_host += 1.0
         self._iter_seen = seen
         return min(self._iter_host / float(self._warmup_iters), 1.0)

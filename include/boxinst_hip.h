@@ -245,8 +245,8 @@ void bxi_debug_set_spin_limit(int limit);
 /* Test hook: which form of the evaluation bxi_boxinst_eval_f32 launches.  Bits: 0 = the library chooses (the single-launch form where
  * it is built -- stride-4 aligned canvases, dilation <= 3, threshold > 0 -- and pays: its stream workgroups, instances x ceil(h / 32),
  * fill at most half the GPU); 1 = the single-launch form wherever it is built; 2 = always the two-launch form; 8 = 8-row tiles
- * (two launches; the default is 4-row tiles).  The single- and two-launch forms give the same bits (tests run both).  Process-wide;
- * not for production use. */
+ * (two launches; the default is 4-row tiles); 16 = bxi_bfs_forward_i32 walks large trees level by level instead of ranking their
+ * Euler tour.  The forms give the same bits (tests run them against each other).  Process-wide; not for production use. */
 void bxi_debug_set_eval_form(int form);
 
 /* g_logits finished by bxi_boxinst_eval_f32 for the factors recorded in `state`  ->  finished for (g_prj, g_pw)

@@ -277,10 +277,20 @@ def test_large_mst_selects_the_reference_tree(built, dev, H, W):
 def _check_bfs(tree, V):
     """bfs() of tree [B, V - 1, 2] twice: deterministic, a permutation rooted at 0, parents before children, the tree's own edges,
     levels = the depth histogram, children contiguous and pointing back."""
-    from boxinstseg_amd import bfs
+    from boxinstseg_amd import bfs, _lib
     si, sp, sc = bfs(tree, 4)
     si2, sp2, sc2 = bfs(tree, 4)
     assert torch.equal(si, si2) and torch.equal(sp, sp2) and torch.equal(sc, sc2)
+    # the level walk (debug form 16) and the Euler-tour ranking (the default) are two algorithms for the same order
+    lib = _lib.load()
+    lib.bxi_debug_set_eval_form(16)
+    try:
+        si3, sp3, sc3 = bfs(tree, 4)
+    finally:
+        lib.bxi_debug_set_eval_form(0)
+    assert torch.equal(si, si3) and torch.equal(sp, sp3) and torch.equal(sc, sc3)
+    for la, lb in zip(si._bxi_levels.cpu(), si3._bxi_levels.cpu()):
+        assert int(la[0]) == int(lb[0]) > 0 and torch.equal(la[:int(la[0]) + 2], lb[:int(la[0]) + 2])
     lv = si._bxi_levels.cpu().numpy()
     si, sp, sc, t = si.cpu().numpy(), sp.cpu().numpy(), sc.cpu().numpy(), tree.cpu().numpy()
     widest = 0
@@ -329,10 +339,42 @@ def _comb(H, W):
     return np.asarray(e, np.int32)
 
 
-@pytest.mark.parametrize('kind', ['grid_wide_frontier', 'relabelled', 'relabelled_wide_frontier', 'strip'])
+@pytest.mark.parametrize('form', [0, 16])
+def test_large_bfs_reports_input_it_cannot_represent(built, dev, form):
+    """More than 4 neighbours, or an edge list that is not one connected tree (V - 1 edges with a cycle somewhere): levels[0] = -1 from both
+    forms of the large BFS (the Euler-tour ranking and the level walk), every output index in range, and a good graph in the same batch
+    is not affected."""
+    from boxinstseg_amd import bfs, _lib
+    V = 12000
+    path = np.stack([np.arange(V - 1), np.arange(1, V)], 1).astype(np.int32)
+    star = path.copy()
+    star[5:10, 0] = 5                                       # 5-6, 5-7, 5-8, 5-9, 5-10 next to 4-5: six neighbours
+    star[5:10, 1] = np.arange(6, 11)
+    loop = path.copy()
+    loop[V - 4] = (V - 3, V - 1)                            # 0 .. V-4 a path; V-3, V-2, V-1 a triangle of their own
+    trees = torch.from_numpy(np.stack([path, star, loop, path])).to(dev)
+    lib = _lib.load()
+    lib.bxi_debug_set_eval_form(form)
+    try:
+        si, sp, sc = bfs(trees, 4)
+        torch.cuda.synchronize()
+    finally:
+        lib.bxi_debug_set_eval_form(0)
+    lv = si._bxi_levels.cpu().numpy()
+    assert lv[0, 0] == V and lv[3, 0] == V                  # a path from vertex 0: one vertex per level
+    assert lv[1, 0] == -1 and lv[2, 0] == -1
+    for t in (si, sp):
+        assert int(t.min()) >= 0 and int(t.max()) < V
+    assert int(sc.min()) >= 0 and int(sc.max()) < V
+    assert np.array_equal(si[0].cpu().numpy(), np.arange(V)) and np.array_equal(si[3].cpu().numpy(), np.arange(V))
+
+
+@pytest.mark.parametrize('kind', ['grid_wide_frontier', 'relabelled', 'relabelled_wide_frontier', 'strip', 'three_sort_passes_wide_frontier'])
 def test_large_bfs_forms(built, dev, kind):
-    """The level walk has a grid form (adjacency as four bits per vertex in LDS) and a general one (16-byte records), and each of them a
-    one-wave form (frontier <= 256 nodes) and a workgroup form: every combination, and the 1 x V strip (grid width 1: general form)."""
+    """bfs() of a large tree ranks its Euler tour; the level walk (debug form 16, compared bit for bit inside _check_bfs) has a grid form
+    (adjacency as four bits per vertex in LDS) and a general one (16-byte records), and each of them a one-wave form (frontier <= 256
+    nodes) and a workgroup form: every combination, the 1 x V strip (grid width 1: general form; V levels), and a tree whose depths need
+    three passes of the radix sort."""
     from boxinstseg_amd import mst
     rng = np.random.default_rng(11)
     if kind == 'strip':
@@ -347,7 +389,7 @@ def test_large_bfs_forms(built, dev, kind):
         wt = (rng.uniform(size=(1, len(idx))) + 1).astype(np.float32)
         t = mst(torch.from_numpy(idx)[None].to(dev), torch.from_numpy(wt).to(dev), H * W).cpu().numpy()[0]
     else:
-        H, W = 300, 300
+        H, W = (520, 512) if kind.startswith('three') else (300, 300)      # 266 240 vertices: depths need 19 bits, three 9-bit passes
         t = _comb(H, W)
     V = H * W
     if kind.startswith('relabelled'):

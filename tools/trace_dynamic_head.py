@@ -28,7 +28,7 @@ trace = torch.zeros((5, 8192, 8), dtype=torch.int64, device=dev)
 assert lib.bxi_debug_set_trace_dyn(trace.data_ptr()) == 0
 step(); torch.cuda.synchronize()
 t = trace.cpu().numpy()
-for kid, name, nph in ((3, 'dyn_fwd', 4), (4, 'dyn_bwd', 5)):
+for kid, name, nph in ((3, 'dyn_fwd', 5), (4, 'dyn_bwd', 5)):     # dyn_fwd: start, inputs loaded, MLP done, barrier, stores issued
     a = t[kid]; used = a[:, 0] > 0; a = a[used].astype(np.float64)
     if not len(a): continue
     t0 = a[:, 0].min()
