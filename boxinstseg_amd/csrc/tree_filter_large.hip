@@ -183,7 +183,7 @@ int launch_mst_large(const int* edge_index, const float* edge_weight, int B, int
 struct BfsLargeWs {
     uint32_t* adj; uint32_t* deg; uint32_t* nodev; uint32_t* nodep; uint32_t* pos_of; int* flag; int* nf; int* gw; unsigned char* gmask;
     // the Euler-tour form (below): two list rankings over the 4V arc slots, per-vertex results, the pairs of the radix sort
-    unsigned long long* e1; unsigned long long* e2; int* pk; uint32_t* cnt; uint32_t* key[2]; uint32_t* val[2]; uint32_t* hist; int* bad; int* maxdep;
+    unsigned long long* e1; unsigned long long* e2; int* pk; uint32_t* key[2]; uint32_t* val[2]; uint32_t* hist; int* bad;
 };
 constexpr int kEulerMaxV = (1 << 20) - 1;          // arc ids (and the end marker 4V) < 2^22 and counts < 2^21 share one 64-bit word
 constexpr int kSortTile = 1024, kSortBits = 9, kSortBuckets = 1 << kSortBits;
@@ -197,10 +197,10 @@ __host__ __device__ static size_t carve_bfs_large(char* base, int V, BfsLargeWs*
     const bool euler = V <= kEulerMaxV;
     const size_t nblk = ((size_t)V + kSortTile - 1) / kSortTile;
     t.e1 = (unsigned long long*)take(euler ? 32 * (size_t)V : 0); t.e2 = (unsigned long long*)take(euler ? 32 * (size_t)V : 0);
-    t.pk = (int*)take(euler ? 4 * (size_t)V : 0); t.cnt = (uint32_t*)take(euler ? 4 * (size_t)(V + 1) : 0);
+    t.pk = (int*)take(euler ? 4 * (size_t)V : 0);
     for (int q = 0; q < 2; ++q) { t.key[q] = (uint32_t*)take(euler ? 4 * (size_t)V : 0); t.val[q] = (uint32_t*)take(euler ? 4 * (size_t)V : 0); }
-    t.hist = (uint32_t*)take(euler ? 4 * (size_t)kSortBuckets * nblk : 0);
-    t.bad = (int*)take(4); t.maxdep = (int*)take(4);
+    t.hist = (uint32_t*)take(euler ? 4 * (size_t)kSortBuckets * (nblk + 1) : 0);       // [tile][bucket], then the buckets' bases
+    t.bad = (int*)take(4);
     if (w) *w = t;
     return off;
 }
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void bfsL_zero_kernel(int V, int max_adj, int*
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
     if (i < V) w.deg[i] = 0u;
-    if (i == 0) { *w.flag = 0; *w.gw = 0; *w.bad = 0; *w.maxdep = 0; }
+    if (i == 0) { *w.flag = 0; *w.gw = 0; *w.bad = 0; }
     if (i < (int64_t)V * max_adj) sorted_child[(int64_t)b * V * max_adj + i] = 0;
 }
 __global__ __launch_bounds__(256) void bfsL_adj_kernel(const int* __restrict__ tree, int V, char* ws_base, size_t ws_stride) {
@@ -607,8 +607,6 @@ __global__ __launch_bounds__(256) void bfsE_parent_kernel(int V, char* ws_base, 
     }
     if (!ended || ups != (v == 0u ? 0 : 1)) atomicOr(w.bad, 1);       // an arc that never reached the end of the list: not one connected tree
     w.pk[v] = pk;
-    w.cnt[v] = 0u;
-    if (v == 0u) w.cnt[V] = 0u;
 }
 __global__ __launch_bounds__(256) void bfsE_succ2_kernel(int V, char* ws_base, size_t ws_stride) {
     const int b = blockIdx.y;
@@ -649,8 +647,7 @@ __global__ __launch_bounds__(256) void bfsE_rank2_kernel(int V, char* ws_base, s
     }
     w.e2[a] = p;
 }
-// preorder number and depth of every vertex from the suffix counts at its parent's arc towards it; the preorder sequence (depth, vertex)
-// and the depth histogram
+// preorder number and depth of every vertex from the suffix counts at its parent's arc towards it -> the preorder sequence (depth, vertex)
 __global__ __launch_bounds__(256) void bfsE_place_kernel(int V, char* ws_base, size_t ws_stride) {
     const int b = blockIdx.y;
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
@@ -676,41 +673,7 @@ __global__ __launch_bounds__(256) void bfsE_place_kernel(int V, char* ws_base, s
         }
         if (!ok) atomicOr(w.bad, 1);
     }
-    if (ok) {
-        w.key[0][pre] = dep; w.val[0][pre] = v;                             // (a permutation when the input is a tree)
-        atomicAdd(&w.cnt[dep], 1u);
-    }
-    int md = ok ? (int)dep : 0;                                             // one atomic per wave on the shared word, not one per vertex
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) md = max(md, __shfl_xor(md, off, kWave));
-    if ((threadIdx.x & 63) == 0 && md > 0) atomicMax(w.maxdep, md);
-}
-// level offsets: lv[1 + d] = number of vertices of depth < d (one workgroup per graph; D levels)
-__global__ __launch_bounds__(kLT) void bfsE_levels_kernel(int V, int* __restrict__ levels, char* ws_base, size_t ws_stride) {
-    __shared__ int part[17];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
-    int* lv = levels + (int64_t)b * (V + 2);
-    const bool bad = (*w.flag & 1) || *w.bad;
-    const int D = bad ? 0 : *w.maxdep + 1;
-    int base = 0;
-    for (int d0 = 0; d0 < D; d0 += kLT) {
-        const int d = d0 + tid;
-        const int c = d < D ? (int)w.cnt[d] : 0;
-        int total;
-        // (block_excl_scan sums values 0..4 per thread elsewhere; the counts here are arbitrary ints: the same code)
-        const int ex = block_excl_scan(c, part, total);
-        if (d < D) lv[1 + d] = base + ex;
-        base += total;
-    }
-    if (tid == 0) {
-        const bool whole = !bad && base == V;
-        lv[0] = whole ? D : -1;
-        if (whole) lv[1 + D] = V;
-        *w.nf = whole ? V : 0;
-        if (!whole) atomicOr(w.bad, 1);
-        atomicOr(w.flag, 2);                            // nodev / nodep below are plain (vertex, parent) arrays, not the walk's grid words
-    }
+    if (ok) { w.key[0][pre] = dep; w.val[0][pre] = v; }                     // (a permutation when the input is a tree)
 }
 // ---- stable LSD radix sort of the (depth, vertex) pairs, kSortBits bits a pass, one wave per tile of kSortTile pairs -------------------
 __device__ __forceinline__ unsigned long long same_digit_lanes(uint32_t digit, bool valid) {
@@ -724,34 +687,38 @@ __device__ __forceinline__ unsigned long long same_digit_lanes(uint32_t digit, b
 }
 __global__ __launch_bounds__(64) void bfsE_sort_hist_kernel(int V, int pass, char* ws_base, size_t ws_stride) {
     __shared__ uint32_t h[kSortBuckets];
-    const int b = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x, nblk = gridDim.x;
+    const int b = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x;
     const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
     const uint32_t* key = w.key[pass & 1];
     for (int i = lane; i < kSortBuckets; i += 64) h[i] = 0u;
     __syncthreads();
     for (int i = blk * kSortTile + lane; i < min((blk + 1) * kSortTile, V); i += 64) atomicAdd(&h[(key[i] >> (pass * kSortBits)) & (kSortBuckets - 1)], 1u);
     __syncthreads();
-    for (int i = lane; i < kSortBuckets; i += 64) w.hist[(size_t)i * nblk + blk] = h[i];          // bucket-major: one scan gives every tile its places
+    for (int i = lane; i < kSortBuckets; i += 64) w.hist[(size_t)blk * kSortBuckets + i] = h[i];  // tile-major: coalesced here, in the scan and in the scatter
 }
+// places: thread d runs down bucket d's counts over the tiles (coalesced across the threads; the counts become the exclusive prefix inside
+// the bucket), then the bucket totals are scanned: a pair's place = base[bucket] + prefix[tile][bucket] + its rank in the tile.
+// (As one flat scan of the 512 x 60 counters in bucket-major order this kernel took 30 us: every load of a thread's run of entries
+// touched 64 different lines, on one CU.)
 __global__ __launch_bounds__(kLT) void bfsE_sort_scan_kernel(int V, int nblk, char* ws_base, size_t ws_stride) {
     __shared__ int part[17];
     const int b = blockIdx.x, tid = threadIdx.x;
     const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
-    const int n = kSortBuckets * nblk;
-    constexpr int E = 8;                                 // consecutive entries per thread: 30 720 entries at 200 x 304 are four trips, not thirty
-    int base = 0;
-    for (int i0 = 0; i0 < n; i0 += kLT * E) {
-        const int i = i0 + tid * E;
-        uint32_t c[E];
-        int mine = 0;
+    int run = 0;
+    if (tid < kSortBuckets)
+        for (int blk0 = 0; blk0 < nblk; blk0 += 16) {                  // sixteen loads in flight, then their stores (the same array: the compiler
+            uint32_t c[16];                                            // would otherwise order every load behind the previous store)
 #pragma unroll
-        for (int e = 0; e < E; ++e) { c[e] = i + e < n ? w.hist[i + e] : 0u; mine += (int)c[e]; }
-        int total;
-        int at = base + block_excl_scan(mine, part, total);
+            for (int e = 0; e < 16; ++e) c[e] = blk0 + e < nblk ? w.hist[(size_t)(blk0 + e) * kSortBuckets + tid] : 0u;
 #pragma unroll
-        for (int e = 0; e < E; ++e) { if (i + e < n) w.hist[i + e] = (uint32_t)at; at += (int)c[e]; }
-        base += total;
-    }
+            for (int e = 0; e < 16; ++e) {
+                if (blk0 + e < nblk) w.hist[(size_t)(blk0 + e) * kSortBuckets + tid] = (uint32_t)run;
+                run += (int)c[e];
+            }
+        }
+    int total;
+    const int base = block_excl_scan(tid < kSortBuckets ? run : 0, part, total);
+    if (tid < kSortBuckets) w.hist[(size_t)nblk * kSortBuckets + tid] = (uint32_t)base;
 }
 __global__ __launch_bounds__(64) void bfsE_sort_scatter_kernel(int V, int pass, char* ws_base, size_t ws_stride) {
     __shared__ uint32_t place[kSortBuckets];
@@ -759,14 +726,22 @@ __global__ __launch_bounds__(64) void bfsE_sort_scatter_kernel(int V, int pass, 
     const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
     const uint32_t* key = w.key[pass & 1]; const uint32_t* val = w.val[pass & 1];
     uint32_t* key_o = w.key[(pass & 1) ^ 1]; uint32_t* val_o = w.val[(pass & 1) ^ 1];
-    for (int i = lane; i < kSortBuckets; i += 64) place[i] = w.hist[(size_t)i * nblk + blk];
+    for (int i = lane; i < kSortBuckets; i += 64) place[i] = w.hist[(size_t)nblk * kSortBuckets + i] + w.hist[(size_t)blk * kSortBuckets + i];
     __syncthreads();
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int end = min((blk + 1) * kSortTile, V);
-    for (int i0 = blk * kSortTile; i0 < end; i0 += 64) {              // strips in order: the sort is stable
-        const int i = i0 + lane;
+    constexpr int NS = kSortTile / 64;
+    uint32_t ks[NS], xs[NS];                                            // the whole tile's pairs first: their loads fly together
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        const int i = blk * kSortTile + 64 * q + lane;
+        ks[q] = i < end ? key[i] : 0u; xs[q] = i < end ? val[i] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {                                      // strips in order: the sort is stable
+        const int i = blk * kSortTile + 64 * q + lane;
         const bool valid = i < end;
-        const uint32_t k = valid ? key[i] : 0u, x = valid ? val[i] : 0u;
+        const uint32_t k = ks[q], x = xs[q];
         const uint32_t digit = (k >> (pass * kSortBits)) & (kSortBuckets - 1);
         const unsigned long long peers = same_digit_lanes(digit, valid);
         if (valid) {
@@ -778,14 +753,27 @@ __global__ __launch_bounds__(64) void bfsE_sort_scatter_kernel(int V, int pass, 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
-__global__ __launch_bounds__(256) void bfsE_fill_kernel(int V, int src, char* ws_base, size_t ws_stride) {
+// the sorted pairs -> nodev / nodep (what bfsL_index / bfsL_parent turn into the outputs) and the level offsets: depths are sorted, every
+// depth up to the last occurs, so level d starts where the key changes to d
+__global__ __launch_bounds__(256) void bfsE_fill_kernel(int V, int src, int* __restrict__ levels, char* ws_base, size_t ws_stride) {
     const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
     if (p >= V) return;
     const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
-    const uint32_t v = *w.bad ? 0u : w.val[src][p];
+    int* lv = levels + (int64_t)b * (V + 2);
+    const bool bad = (*w.flag & 1) || *w.bad;
+    const uint32_t v = bad ? 0u : w.val[src][p];
     const int pk = v < (uint32_t)V ? w.pk[v] : -1;
     w.nodev[p] = v < (uint32_t)V ? v : 0u;
     w.nodep[p] = (p == 0 || pk < 0) ? 0xffffffffu : w.adj[4u * v + pk];
+    if (!bad) {
+        const uint32_t d = w.key[src][p];
+        if (p == 0 || w.key[src][p - 1] != d) { if (d < (uint32_t)V) lv[1 + d] = p; }
+        if (p == V - 1) { lv[0] = (int)d + 1; if (d < (uint32_t)V) lv[2 + d] = V; }
+    } else if (p == 0) lv[0] = -1;
+    if (p == 0) {
+        *w.nf = bad ? 0 : V;
+        atomicOr(w.flag, 2);                            // nodev / nodep are plain (vertex, parent) arrays here, not the walk's grid words
+    }
 }
 
 int debug_eval_form();      // fused_eval.hip: bit 16 = the level walk instead of the Euler tour (tests compare the two)
@@ -809,7 +797,6 @@ int launch_bfs_large(const int* tree, int B, int V, int max_adj, int* si, int* s
         BXI_LAUNCH("bfs_euler_succ2", s, bfsE_succ2_kernel, ga, dim3(256), 0, s, V, ws, stride);
         for (int r = 0; r < rounds; ++r) BXI_LAUNCH("bfs_euler_rank2", s, bfsE_rank2_kernel, ga, dim3(256), 0, s, V, ws, stride);
         BXI_LAUNCH("bfs_euler_place", s, bfsE_place_kernel, gv, dim3(256), 0, s, V, ws, stride);
-        BXI_LAUNCH("bfs_euler_levels", s, bfsE_levels_kernel, dim3(B), dim3(kLT), 0, s, V, levels, ws, stride);
         int key_bits = 1;
         while ((1ll << key_bits) < (long long)V) ++key_bits;                     // depths are < V
         const int passes = (key_bits + kSortBits - 1) / kSortBits;
@@ -819,7 +806,7 @@ int launch_bfs_large(const int* tree, int B, int V, int max_adj, int* si, int* s
             BXI_LAUNCH("bfs_euler_sort_scan", s, bfsE_sort_scan_kernel, dim3(B), dim3(kLT), 0, s, V, nblk, ws, stride);
             BXI_LAUNCH("bfs_euler_sort_scatter", s, bfsE_sort_scatter_kernel, dim3(nblk, B), dim3(64), 0, s, V, pass, ws, stride);
         }
-        BXI_LAUNCH("bfs_euler_fill", s, bfsE_fill_kernel, gv, dim3(256), 0, s, V, passes & 1, ws, stride);
+        BXI_LAUNCH("bfs_euler_fill", s, bfsE_fill_kernel, gv, dim3(256), 0, s, V, passes & 1, levels, ws, stride);
     } else {
         const size_t lds = V <= kBfsMaskCap ? (size_t)(V + 15) / 16 * 16 : 0;
         if (lds > 48 * 1024) {
