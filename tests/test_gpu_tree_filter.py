@@ -339,6 +339,33 @@ def _comb(H, W):
     return np.asarray(e, np.int32)
 
 
+@pytest.mark.parametrize('seed', range(6))
+def test_large_bfs_random_trees(built, dev, seed):
+    """Random trees of degree <= 4 that are not grid trees at all (random attachment, random labels, edges in random order and direction):
+    validity (a BFS order of this tree from vertex 0, siblings in ascending vertex order -- bfs.cu's own sibling order is the arrival order
+    of its atomics) and the Euler-tour form against the level walk bit for bit (_check_bfs)."""
+    rng = np.random.default_rng(100 + seed)
+    V = int(rng.integers(10201, 30000))
+    deg = np.zeros(V, np.int64)
+    edges = np.zeros((V - 1, 2), np.int64)
+    open_ = [0]                                               # vertices that can still take a neighbour
+    for v in range(1, V):
+        k = int(rng.integers(0, len(open_))) if seed % 2 else max(len(open_) - 1 - int(rng.integers(0, 3)), 0)   # bushy / deep trees
+        u = open_[k]
+        edges[v - 1] = (u, v)
+        deg[u] += 1; deg[v] += 1
+        if deg[u] == 4:
+            open_[k] = open_[-1]; open_.pop()
+        open_.append(v)
+    perm = rng.permutation(V)
+    edges = perm[edges]
+    flip = rng.random(V - 1) < 0.5
+    edges[flip] = edges[flip][:, ::-1]
+    edges = edges[rng.permutation(V - 1)].astype(np.int32)
+    tree = torch.from_numpy(np.ascontiguousarray(edges))[None].to(dev)
+    _check_bfs(tree, V)
+
+
 @pytest.mark.parametrize('form', [0, 16])
 def test_large_bfs_reports_input_it_cannot_represent(built, dev, form):
     """More than 4 neighbours, or an edge list that is not one connected tree (V - 1 edges with a cycle somewhere): levels[0] = -1 from both
