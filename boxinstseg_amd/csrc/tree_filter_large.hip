@@ -837,11 +837,11 @@ struct RefineArgsL {
 constexpr int kPadL = 4;
 constexpr int kWinL = 8192;            // records per LDS window of the leaf->root walk (128 KB); a power of two: slot = i & (kWinL - 1)
 constexpr int kWinLv = 2048;           // levels per window at most (8 KB of level offsets)
-static size_t refine_large_block_bytes(int V) { return up16(16 * (size_t)(V + kPadL)) + up16(4 * (size_t)V) + up16(16 * (size_t)(V + kPadL)) + 16; }
+static size_t refine_large_block_bytes(int V) { return up16(16 * (size_t)(V + kPadL)) + up16(4 * (size_t)V) + up16(16 * (size_t)(V + kPadL)) + 16 + 3 * up16(4 * (size_t)V); }
 size_t refine_large_ws_bytes(int B, int C, int V) { return refine_large_block_bytes(V) * (size_t)(B > 0 ? B : 1) * (size_t)C; }
 
 // per (graph, channel) block of the workspace: records, parents, the second buffer of the jump rounds, one flag word
-struct RefineBlkL { float4* rec; uint32_t* parent; float4* tmp; int* bad; };
+struct RefineBlkL { float4* rec; uint32_t* parent; float4* tmp; int* bad; uint32_t* dep; uint32_t* lo0; uint32_t* lo1; };   // (no arrays: a runtime index would put the struct in scratch)
 __device__ __forceinline__ RefineBlkL refine_blk(const RefineArgsL& a, int b, int ch) {
     char* wsb = a.ws + ((size_t)b * a.C + ch) * a.ws_stride;
     RefineBlkL r;
@@ -849,6 +849,10 @@ __device__ __forceinline__ RefineBlkL refine_blk(const RefineArgsL& a, int b, in
     r.parent = reinterpret_cast<uint32_t*>(wsb + up16(16 * (size_t)(a.V + kPadL)));
     r.tmp = reinterpret_cast<float4*>(wsb + up16(16 * (size_t)(a.V + kPadL)) + up16(4 * (size_t)a.V));
     r.bad = reinterpret_cast<int*>(wsb + up16(16 * (size_t)(a.V + kPadL)) + up16(4 * (size_t)a.V) + up16(16 * (size_t)(a.V + kPadL)));
+    char* more = reinterpret_cast<char*>(r.bad) + 16;                 // the depth-free leaf->root pass: depth and descendant-range starts
+    r.dep = reinterpret_cast<uint32_t*>(more);
+    r.lo0 = reinterpret_cast<uint32_t*>(more + up16(4 * (size_t)a.V));
+    r.lo1 = reinterpret_cast<uint32_t*>(more + 2 * up16(4 * (size_t)a.V));
     return r;
 }
 
@@ -992,14 +996,89 @@ __global__ __launch_bounds__(kLT) void refineL_up_kernel(RefineArgsL a) {
     }
 }
 
+// ---- pass 2, depth-free form: U = (I - A)^-1 x with A[parent, child] = w_child, as (I + A)(I + A^2)(I + A^4)... applied to x ----------------
+// A^(2^k) links every node to its 2^k-th ancestor with the product of the weights on the way, so round k is
+//     S_{k+1}[i] = S_k[i] + sum over the descendants j of i exactly 2^k levels down of P_k[j] S_k[j]
+// (S_k[i] = the terms of U_i from descendants less than 2^k levels down; P_k[j] = product of the 2^k weights above j), together with the
+// usual doubling of (ancestor, product).  In BFS order the descendants of i at a given distance are a CONTIGUOUS range of one level, and
+// the ranges of the nodes of a level tile it in order: lo_k[i] = first position, 2^k levels down, whose 2^k-th ancestor is >= i; the range
+// ends at lo_k[i + 1] (or the level's end), and lo_{k+1}[i] = lo_k[lo_k[i]] -- no search after the first round.  ceil(log2 D) <= ceil(log2 V)
+// grid-wide rounds instead of D dependent steps of one wave (1 720 at 200 x 304: 0.44 ms a launch); a sum runs over its range in position
+// order, so the result is run-to-run identical; its association differs from refine.cu's child-by-child order (rounding only).
+constexpr uint32_t kNoAnc = 0xffffffffu;
+__device__ __forceinline__ int level_end(const int* lv, int D, int t, int V) { return t < D ? lv[2 + t] : V; }
+__global__ __launch_bounds__(256) void refineL_upd_init_kernel(RefineArgsL a) {
+    const int b = blockIdx.y, ch = blockIdx.z, V = a.V;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= V) return;
+    const RefineBlkL w = refine_blk(a, b, ch);
+    const int* lv = a.levels + (int64_t)b * (V + 2);
+    const int D = max(lv[0], 0);
+    float4 r = w.rec[i];
+    if (i == 0 && *w.bad) { r.x *= __builtin_nanf(""); r.y *= __builtin_nanf(""); }     // a foreign ordering fails loudly in the values
+    int d = 0;                                                       // depth: the last level that starts at or before i
+    for (int lo = 0, hi = D; lo < hi;) { const int mid = (lo + hi + 1) >> 1; if (mid < D && lv[1 + mid] <= i) { lo = mid; d = mid; } else hi = mid - 1; }
+    w.dep[i] = (uint32_t)d;
+    uint32_t first = (uint32_t)V;                                    // lo_0: the first child position of i or of the next node that has one
+    if (d + 1 < D) {
+        int lo = lv[2 + d], hi = level_end(lv, D, d + 1, V);         // level d + 1; parents are non-decreasing along it
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (w.parent[mid] >= (uint32_t)i) hi = mid; else lo = mid + 1; }
+        first = (uint32_t)lo;
+    }
+    w.lo0[i] = first;
+    r.w = __uint_as_float(i ? w.parent[i] : kNoAnc);
+    w.rec[i] = r;
+}
+__global__ __launch_bounds__(256) void refineL_upd_round_kernel(RefineArgsL a, int k, int flip) {
+    const int b = blockIdx.y, ch = blockIdx.z, V = a.V;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= V) return;
+    const RefineBlkL w = refine_blk(a, b, ch);
+    const int* lv = a.levels + (int64_t)b * (V + 2);
+    const int D = max(lv[0], 0);
+    const float4* src = flip ? w.tmp : w.rec;
+    float4* dst = flip ? w.rec : w.tmp;
+    const uint32_t* lo_s = flip ? w.lo1 : w.lo0;
+    uint32_t* lo_d = flip ? w.lo0 : w.lo1;
+    const long long step = 1ll << k;
+    if (step >= (long long)D) return;                               // nothing is that far apart: the result stays where round ceil(log2 D) - 1 left it
+    float4 r = src[i];
+    const int d = (int)w.dep[i], t = d + (int)step;
+    uint32_t lo_next = (uint32_t)V;
+    if (t < D) {
+        const int q0 = (int)lo_s[i], t_end = level_end(lv, D, t, V);
+        const int q1 = i + 1 < level_end(lv, D, d, V) ? (int)lo_s[i + 1] : t_end;
+        float sx = 0.f, sy = 0.f;
+        for (int q = q0; q < q1; q += 8) {                           // eight loads in flight (one at a time, a 100-node range is 100 round trips)
+            float4 c[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c[e] = src[min(q + e, q1 - 1)];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (q + e < q1) { sx += c[e].z * c[e].x; sy += c[e].z * c[e].y; }
+        }
+        r.x += sx; r.y += sy;
+        // the range 2^(k+1) levels down starts where the range of the first node of this one starts
+        const long long t2 = (long long)d + 2 * step;
+        if (t2 < (long long)D) lo_next = q0 < t_end ? lo_s[q0] : (uint32_t)level_end(lv, D, (int)t2, V);
+    }
+    const uint32_t an = __float_as_uint(r.w);
+    if (an != kNoAnc) { const float4 q = src[an]; r.z *= q.z; r.w = q.w; } else r.z = 0.f;
+    dst[i] = r;
+    lo_d[i] = lo_next;
+}
+
 // ---- pass 3: U of both planes out (sorted order), and the affine maps D_c = A_c + B_c D_anc(c), A = U (1 - w^2), B = w (refine.cu:17-62) ----
-__global__ __launch_bounds__(256) void refineL_prep_kernel(RefineArgsL a) {
+__global__ __launch_bounds__(256) void refineL_prep_kernel(RefineArgsL a, int doubled) {
     const int b = blockIdx.y, ch = blockIdx.z, V = a.V;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= V) return;
     const RefineBlkL w = refine_blk(a, b, ch);
     const int64_t cb = ((int64_t)b * a.C + ch) * V;
-    const float4 r = w.rec[i];
+    int from_tmp = 0;                                               // the depth-free pass ran ceil(log2 D) effective rounds, rec -> tmp -> rec ...
+    if (doubled) { const int D = max(a.levels[(int64_t)b * (V + 2)], 0); int n = 0; while ((1ll << n) < (long long)D) ++n; from_tmp = n & 1; }
+    float4 r = (from_tmp ? w.tmp : w.rec)[i];
+    r.z = i ? a.edge_weight[(int64_t)b * V + i] : 0.f;              // (the depth-free pass turned .z into a product of weights)
     for (int q = 0; q < 2; ++q) {
         const RefinePlaneL& pl = q ? a.pl[1] : a.pl[0];
         const bool per_tree = pl.in == nullptr;
@@ -1064,7 +1143,15 @@ int launch_refine_large(const void* planes2 /* RefinePlaneL[2] layout */, const 
     const dim3 over_nodes((unsigned)((V + kPadL + 255) / 256), (unsigned)B, (unsigned)C);
     BXI_LAUNCH("tree_refine_large_clear", s, refineL_clear_kernel, dim3((unsigned)((B * C + 63) / 64)), dim3(64), 0, s, a);
     BXI_LAUNCH("tree_refine_large_stage", s, refineL_stage_kernel, over_nodes, dim3(256), 0, s, a);
-    {
+    int doubled = 0;
+    if (!(debug_eval_form() & 16)) {
+        const dim3 nodes((unsigned)((V + 255) / 256), (unsigned)B, (unsigned)C);
+        int up_rounds = 0;
+        while ((1ll << up_rounds) < (long long)V) ++up_rounds;       // the depth is device data; rounds beyond it copy
+        BXI_LAUNCH("tree_refine_large_up_init", s, refineL_upd_init_kernel, nodes, dim3(256), 0, s, a);
+        for (int k = 0; k < up_rounds; ++k) BXI_LAUNCH("tree_refine_large_up_round", s, refineL_upd_round_kernel, nodes, dim3(256), 0, s, a, k, k & 1);
+        doubled = 1;
+    } else {
         const size_t lds = sizeof(float4) * kWinL + sizeof(int) * (kWinLv + 2);
         static std::atomic<int> attr_set{0};
         if (!attr_set.load(std::memory_order_relaxed)) {
@@ -1074,7 +1161,7 @@ int launch_refine_large(const void* planes2 /* RefinePlaneL[2] layout */, const 
         }
         BXI_LAUNCH("tree_refine_large_up", s, refineL_up_kernel, dim3(B, C), dim3(kLT), lds, s, a);
     }
-    BXI_LAUNCH("tree_refine_large_prep", s, refineL_prep_kernel, over_nodes, dim3(256), 0, s, a);
+    BXI_LAUNCH("tree_refine_large_prep", s, refineL_prep_kernel, over_nodes, dim3(256), 0, s, a, doubled);
     // the depth of the tree is device data: ceil(log2 V) rounds resolve any depth <= V (a resolved node is only copied)
     int rounds = 0;
     while ((1 << rounds) < V) ++rounds;

@@ -426,8 +426,19 @@ def test_large_bfs_forms(built, dev, kind):
     assert (widest > 256) == kind.endswith('wide_frontier'), widest
 
 
+@pytest.fixture(params=[0, 16], ids=['depth_free', 'level_walks'])
+def large_form(request):
+    """Both forms of the large-tree kernels: the default (Euler-tour BFS, leaf->root pass by doubling over the levels) and the level walks
+    (bxi_debug_set_eval_form bit 16)."""
+    from boxinstseg_amd import _lib
+    lib = _lib.load()
+    lib.bxi_debug_set_eval_form(request.param)
+    yield request.param
+    lib.bxi_debug_set_eval_form(0)
+
+
 @pytest.mark.parametrize('low', [True, False])
-def test_large_refine_forward_backward_vs_oracle(built, dev, low):
+def test_large_refine_forward_backward_vs_oracle(built, dev, low, large_form):
     from boxinstseg_amd import bfs, mst, refine
     H, W, C, B = 200, 304, 2, 2
     rng = np.random.default_rng(11 + low)
