@@ -1005,6 +1005,12 @@ __global__ __launch_bounds__(kLT) void refineL_up_kernel(RefineArgsL a) {
 // ends at lo_k[i + 1] (or the level's end), and lo_{k+1}[i] = lo_k[lo_k[i]] -- no search after the first round.  ceil(log2 D) <= ceil(log2 V)
 // grid-wide rounds instead of D dependent steps of one wave (1 720 at 200 x 304: 0.44 ms a launch); a sum runs over its range in position
 // order, so the result is run-to-run identical; its association differs from refine.cu's child-by-child order (rounding only).
+__device__ __forceinline__ int rounds_for_depth(const RefineArgsL& a, int b) {      // smallest n with 2^n >= D: what a tree of D levels needs
+    const int D = max(a.levels[(int64_t)b * (a.V + 2)], 0);
+    int n = 0;
+    while ((1ll << n) < (long long)D) ++n;
+    return n;
+}
 constexpr uint32_t kNoAnc = 0xffffffffu;
 __device__ __forceinline__ int level_end(const int* lv, int D, int t, int V) { return t < D ? lv[2 + t] : V; }
 __global__ __launch_bounds__(256) void refineL_upd_init_kernel(RefineArgsL a) {
@@ -1029,10 +1035,11 @@ __global__ __launch_bounds__(256) void refineL_upd_init_kernel(RefineArgsL a) {
     r.w = __uint_as_float(i ? w.parent[i] : kNoAnc);
     w.rec[i] = r;
 }
+constexpr int kUpdCoop = 24;           // a range longer than this is summed by the whole wave
 __global__ __launch_bounds__(256) void refineL_upd_round_kernel(RefineArgsL a, int k, int flip) {
     const int b = blockIdx.y, ch = blockIdx.z, V = a.V;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= V) return;
+    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const bool live = i < V;                                        // (no early return: the wave sums long ranges together)
     const RefineBlkL w = refine_blk(a, b, ch);
     const int* lv = a.levels + (int64_t)b * (V + 2);
     const int D = max(lv[0], 0);
@@ -1042,14 +1049,24 @@ __global__ __launch_bounds__(256) void refineL_upd_round_kernel(RefineArgsL a, i
     uint32_t* lo_d = flip ? w.lo0 : w.lo1;
     const long long step = 1ll << k;
     if (step >= (long long)D) return;                               // nothing is that far apart: the result stays where round ceil(log2 D) - 1 left it
-    float4 r = src[i];
-    const int d = (int)w.dep[i], t = d + (int)step;
+    float4 r = live ? src[i] : make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoAnc));
+    const int d = live ? (int)w.dep[i] : 0;
+    const long long t = (long long)d + step;
+    const bool has = live && t < (long long)D;
     uint32_t lo_next = (uint32_t)V;
-    if (t < D) {
-        const int q0 = (int)lo_s[i], t_end = level_end(lv, D, t, V);
-        const int q1 = i + 1 < level_end(lv, D, d, V) ? (int)lo_s[i + 1] : t_end;
-        float sx = 0.f, sy = 0.f;
-        for (int q = q0; q < q1; q += 8) {                           // eight loads in flight (one at a time, a 100-node range is 100 round trips)
+    int q0 = 0, q1 = 0;
+    if (has) {
+        const int t_end = level_end(lv, D, (int)t, V);
+        q0 = (int)lo_s[i];
+        q1 = i + 1 < level_end(lv, D, d, V) ? (int)lo_s[i + 1] : t_end;
+        // the range 2^(k+1) levels down starts where the range of the first node of this one starts
+        const long long t2 = (long long)d + 2 * step;
+        if (t2 < (long long)D) lo_next = q0 < t_end ? lo_s[q0] : (uint32_t)level_end(lv, D, (int)t2, V);
+    }
+    float sx = 0.f, sy = 0.f;
+    const bool big = q1 - q0 > kUpdCoop;
+    if (!big)
+        for (int q = q0; q < q1; q += 8) {                           // eight loads in flight (one at a time, a range is one round trip per node)
             float4 c[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) c[e] = src[min(q + e, q1 - 1)];
@@ -1057,11 +1074,19 @@ __global__ __launch_bounds__(256) void refineL_upd_round_kernel(RefineArgsL a, i
             for (int e = 0; e < 8; ++e)
                 if (q + e < q1) { sx += c[e].z * c[e].x; sy += c[e].z * c[e].y; }
         }
-        r.x += sx; r.y += sy;
-        // the range 2^(k+1) levels down starts where the range of the first node of this one starts
-        const long long t2 = (long long)d + 2 * step;
-        if (t2 < (long long)D) lo_next = q0 < t_end ? lo_s[q0] : (uint32_t)level_end(lv, D, (int)t2, V);
+    // the few long ranges of the late rounds (a node near the root owns a whole level slice): lane l takes nodes l, l + 64, ...; the
+    // partial sums meet in a butterfly -- a fixed order, as everything here
+    for (unsigned long long m = __ballot(big); m; m &= m - 1) {
+        const int L = __ffsll((long long)m) - 1;
+        const int a0 = __shfl(q0, L, kWave), a1 = __shfl(q1, L, kWave);
+        float px = 0.f, py = 0.f;
+        for (int q = a0 + lane; q < a1; q += 64) { const float4 c = src[q]; px += c.z * c.x; py += c.z * c.y; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { px += __shfl_xor(px, off, kWave); py += __shfl_xor(py, off, kWave); }
+        if (lane == L) { sx = px; sy = py; }
     }
+    if (!live) return;
+    r.x += sx; r.y += sy;
     const uint32_t an = __float_as_uint(r.w);
     if (an != kNoAnc) { const float4 q = src[an]; r.z *= q.z; r.w = q.w; } else r.z = 0.f;
     dst[i] = r;
@@ -1075,8 +1100,7 @@ __global__ __launch_bounds__(256) void refineL_prep_kernel(RefineArgsL a, int do
     if (i >= V) return;
     const RefineBlkL w = refine_blk(a, b, ch);
     const int64_t cb = ((int64_t)b * a.C + ch) * V;
-    int from_tmp = 0;                                               // the depth-free pass ran ceil(log2 D) effective rounds, rec -> tmp -> rec ...
-    if (doubled) { const int D = max(a.levels[(int64_t)b * (V + 2)], 0); int n = 0; while ((1ll << n) < (long long)D) ++n; from_tmp = n & 1; }
+    const int from_tmp = doubled ? (rounds_for_depth(a, b) & 1) : 0;   // the depth-free pass ran that many effective rounds, rec -> tmp -> rec ...
     float4 r = (from_tmp ? w.tmp : w.rec)[i];
     r.z = i ? a.edge_weight[(int64_t)b * V + i] : 0.f;              // (the depth-free pass turned .z into a product of weights)
     for (int q = 0; q < 2; ++q) {
@@ -1090,10 +1114,12 @@ __global__ __launch_bounds__(256) void refineL_prep_kernel(RefineArgsL a, int do
 }
 
 // ---- pass 4 (x ceil(log2 V)): one pointer-jumping round, src -> dst (a resolved node is copied) -----------------------------------------
-__global__ __launch_bounds__(256) void refineL_jump_kernel(RefineArgsL a, int flip) {
+__global__ __launch_bounds__(256) void refineL_jump_kernel(RefineArgsL a, int k) {
     const int b = blockIdx.y, ch = blockIdx.z, V = a.V;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= V) return;
+    if (k >= rounds_for_depth(a, b)) return;                         // every node is resolved: the launch count is fixed on the host for any depth
+    const int flip = k & 1;
     const RefineBlkL w = refine_blk(a, b, ch);
     const float4* src = flip ? w.tmp : w.rec;
     float4* dst = flip ? w.rec : w.tmp;
@@ -1105,10 +1131,11 @@ __global__ __launch_bounds__(256) void refineL_jump_kernel(RefineArgsL a, int fl
 }
 
 // ---- pass 5: outputs ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void refineL_out_kernel(RefineArgsL a, int flip) {
+__global__ __launch_bounds__(256) void refineL_out_kernel(RefineArgsL a) {
     const int b = blockIdx.y, ch = blockIdx.z, V = a.V;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= V) return;
+    const int flip = rounds_for_depth(a, b) & 1;
     const RefineBlkL w = refine_blk(a, b, ch);
     const int64_t cb = ((int64_t)b * a.C + ch) * V;
     const float4 d = (flip ? w.tmp : w.rec)[i];
@@ -1165,8 +1192,8 @@ int launch_refine_large(const void* planes2 /* RefinePlaneL[2] layout */, const 
     // the depth of the tree is device data: ceil(log2 V) rounds resolve any depth <= V (a resolved node is only copied)
     int rounds = 0;
     while ((1 << rounds) < V) ++rounds;
-    for (int k = 0; k < rounds; ++k) BXI_LAUNCH("tree_refine_large_jump", s, refineL_jump_kernel, over_nodes, dim3(256), 0, s, a, k & 1);
-    BXI_LAUNCH("tree_refine_large_out", s, refineL_out_kernel, over_nodes, dim3(256), 0, s, a, rounds & 1);
+    for (int k = 0; k < rounds; ++k) BXI_LAUNCH("tree_refine_large_jump", s, refineL_jump_kernel, over_nodes, dim3(256), 0, s, a, k);
+    BXI_LAUNCH("tree_refine_large_out", s, refineL_out_kernel, over_nodes, dim3(256), 0, s, a);
     return check_launch();
 }
 
