@@ -25,13 +25,14 @@ constexpr int kLT = 1024;
 __host__ __device__ static inline size_t up16(size_t v) { return (v + 15) / 16 * 16; }
 
 // ---------------------------------------------------------------------------------------------------
-struct MstLargeWs { u64* best; uint32_t* comp; uint32_t* link; uint32_t* chosen; };
+struct MstLargeWs { u64* best; uint32_t* comp; uint32_t* link; uint32_t* chosen; int* act; };   // act[r]: an edge was offered in round r (r < 32); act[32]: the tree is complete
 __host__ __device__ static size_t carve_mst_large(char* base, int E, int V, MstLargeWs* w) {
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += up16(b); return base ? base + o : nullptr; };
     MstLargeWs t;
     t.best = (u64*)take(8 * (size_t)V); t.comp = (uint32_t*)take(4 * (size_t)V); t.link = (uint32_t*)take(4 * (size_t)V);
     t.chosen = (uint32_t*)take(4 * (size_t)((E + 31) / 32));
+    t.act = (int*)take(4 * 33);
     if (w) *w = t;
     return off;
 }
@@ -40,7 +41,8 @@ size_t mst_large_ws_bytes(int E, int V) { return carve_mst_large(nullptr, E, V, 
 // Boruvka ACROSS THE GPU: every phase of a round is a grid over the edges / vertices of all graphs, a kernel boundary between
 // phases is the grid barrier (one 1024-thread workgroup per graph took 2.5 ms at 60 800 vertices / 121 000 edges: 16 rounds of
 // ~120 edges per thread, each with two dependent atomics).  The number of rounds is fixed on the host (the component count at least
-// halves per round: ceil(log2 V) rounds); rounds after the tree is complete find no edge and change nothing.
+// halves per round: ceil(log2 V) rounds); the first round that offers no edge marks the tree complete and every later launch returns at
+// once (a grid graph needs about nine of the sixteen rounds at 200 x 304).
 __device__ __forceinline__ MstLargeWs mst_ws(char* ws_base, size_t ws_stride, int b, int E, int V) {
     MstLargeWs w;
     carve_mst_large(ws_base + (size_t)b * ws_stride, E, V, &w);
@@ -51,26 +53,31 @@ __global__ __launch_bounds__(256) void mstL_init_kernel(int E, int V, char* ws_b
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < V) { w.comp[i] = (uint32_t)i; w.best[i] = ~0ull; }
     if (i < (E + 31) / 32) w.chosen[i] = 0u;
+    if (i < 33) w.act[i] = 0;
 }
 // every edge between two components offers (weight bits, edge index) to both (64-bit atomic min at the memory side)
 __global__ __launch_bounds__(256) void mstL_offer_kernel(const int* __restrict__ edge_index, const float* __restrict__ edge_weight, int E, int V,
-                                                         char* ws_base, size_t ws_stride) {
+                                                         char* ws_base, size_t ws_stride, int round) {
     const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
     if (e >= E) return;
     const MstLargeWs w = mst_ws(ws_base, ws_stride, b, E, V);
+    if (w.act[32]) return;
     const int* idx = edge_index + (int64_t)b * E * 2;
     const uint32_t cu = w.comp[idx[2 * e]], cv = w.comp[idx[2 * e + 1]];
     if (cu != cv) {
+        if (w.act[round] == 0) w.act[round] = 1;                      // (every writer writes 1; the word is read by the NEXT kernels only)
         const u64 key = ((u64)__float_as_uint(edge_weight[(int64_t)b * E + e]) << 32) | (uint32_t)e;   // weights are >= 0: the bits order like the values
         atomicMin(&w.best[cu], key);
         atomicMin(&w.best[cv], key);
     }
 }
 // every component root takes its cheapest edge and hooks to the component at its other end
-__global__ __launch_bounds__(256) void mstL_hook_kernel(const int* __restrict__ edge_index, int E, int V, char* ws_base, size_t ws_stride) {
+__global__ __launch_bounds__(256) void mstL_hook_kernel(const int* __restrict__ edge_index, int E, int V, char* ws_base, size_t ws_stride, int round) {
     const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
     if (c >= V) return;
     const MstLargeWs w = mst_ws(ws_base, ws_stride, b, E, V);
+    if (w.act[round] == 0) { if (c == 0) w.act[32] = 1; return; }   // no edge joins two components: one component, the tree is complete
+                                                                     // (act[32] is read by later kernels only; this one decides on act[round] alone)
     if (w.comp[c] != (uint32_t)c) return;
     const int* idx = edge_index + (int64_t)b * E * 2;
     const u64 k = w.best[c];
@@ -84,20 +91,22 @@ __global__ __launch_bounds__(256) void mstL_hook_kernel(const int* __restrict__ 
     w.link[c] = to;
 }
 // two components that chose each other: the smaller id is the root (reads links of the previous kernel, writes its own)
-__global__ __launch_bounds__(256) void mstL_mutual_kernel(int E, int V, char* ws_base, size_t ws_stride) {
+__global__ __launch_bounds__(256) void mstL_mutual_kernel(int E, int V, char* ws_base, size_t ws_stride, int round) {
     const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
     if (c >= V) return;
     const MstLargeWs w = mst_ws(ws_base, ws_stride, b, E, V);
+    if (w.act[round] == 0) return;
     if (w.comp[c] != (uint32_t)c) return;
     const uint32_t o = w.link[c];
     // (c < o decides alone: the partner, if it also points back, keeps its link to c)
     if (o != (uint32_t)c && (uint32_t)c < o && w.link[o] == (uint32_t)c) w.link[c] = (uint32_t)c;
 }
 // comp[v] = root of comp[v]; the next round's offers start from scratch
-__global__ __launch_bounds__(256) void mstL_relabel_kernel(int E, int V, char* ws_base, size_t ws_stride) {
+__global__ __launch_bounds__(256) void mstL_relabel_kernel(int E, int V, char* ws_base, size_t ws_stride, int round) {
     const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
     if (v >= V) return;
     const MstLargeWs w = mst_ws(ws_base, ws_stride, b, E, V);
+    if (w.act[round] == 0) return;
     uint32_t* lk = w.link;
     // The hook chains are walked here (a root points to itself), with PATH HALVING: every node a walker passes is re-pointed at its
     // grandparent, so concurrent walkers shorten each other's way and even a chain as long as the graph (a 1 x V strip with
@@ -166,12 +175,12 @@ int launch_mst_large(const int* edge_index, const float* edge_weight, int B, int
     int rounds = 0;
     while ((1 << rounds) < V) ++rounds;
     for (int r = 0; r < rounds; ++r) {
-        BXI_LAUNCH("mst_large_offer", s, mstL_offer_kernel, ge, dim3(256), 0, s, edge_index, edge_weight, E, V, ws, stride);
-        BXI_LAUNCH("mst_large_hook", s, mstL_hook_kernel, gv, dim3(256), 0, s, edge_index, E, V, ws, stride);
-        BXI_LAUNCH("mst_large_mutual", s, mstL_mutual_kernel, gv, dim3(256), 0, s, E, V, ws, stride);
+        BXI_LAUNCH("mst_large_offer", s, mstL_offer_kernel, ge, dim3(256), 0, s, edge_index, edge_weight, E, V, ws, stride, r);
+        BXI_LAUNCH("mst_large_hook", s, mstL_hook_kernel, gv, dim3(256), 0, s, edge_index, E, V, ws, stride, r);
+        BXI_LAUNCH("mst_large_mutual", s, mstL_mutual_kernel, gv, dim3(256), 0, s, E, V, ws, stride, r);
         // (pointer-jumping kernels in front of the relabel kernel's halving walk -- ceil(log2 V) - r, 3, 2, 1 of them -- measured 680,
         // 330-370, 290-305, 235-243 us per MST at 200 x 304 against 195-216 us without: every launch costs more than the steps it saves)
-        BXI_LAUNCH("mst_large_relabel", s, mstL_relabel_kernel, gv, dim3(256), 0, s, E, V, ws, stride);
+        BXI_LAUNCH("mst_large_relabel", s, mstL_relabel_kernel, gv, dim3(256), 0, s, E, V, ws, stride, r);
     }
     if (nw > V) return BXI_ERR_UNSUPPORTED;               // (the word prefixes reuse the link array; E <= 8 V is checked by the caller)
     BXI_LAUNCH("mst_large_scan", s, mstL_scan_kernel, dim3(B), dim3(kLT), 0, s, E, V, n_out, ws, stride);
