@@ -470,6 +470,50 @@ def test_large_refine_forward_backward_vs_oracle(built, dev, low, large_form):
             assert np.abs(wd.grad[b].cpu().numpy() - gw).max() <= 1e-4 * max(np.abs(gw).max(), 1.0)
 
 
+@pytest.mark.parametrize('shape', ['strip', 'comb', 'bushy'])
+def test_large_refine_tree_shapes(built, dev, shape, large_form):
+    """The extremes of the depth-free leaf->root pass: a 1 x V strip (V levels of one node: every doubling round is effective), a comb
+    (long teeth, levels up to 120 nodes wide, long descendant ranges near the root), a bushy random tree (few levels, wide ranges:
+    the whole-wave sums) -- forward and the feature gradient against the fp64 oracle, in both forms."""
+    from boxinstseg_amd import bfs, refine
+    rng = np.random.default_rng({'strip': 1, 'comb': 2, 'bushy': 3}[shape])
+    if shape == 'strip':
+        V = 12000
+        t = np.stack([np.arange(V - 1), np.arange(1, V)], 1)
+    elif shape == 'comb':
+        H, W = 110, 120
+        V = H * W
+        t = _comb(H, W)
+    else:
+        V = 20000
+        deg = np.zeros(V, np.int64)
+        t = np.zeros((V - 1, 2), np.int64)
+        open_ = [0]
+        for v in range(1, V):
+            k = int(rng.integers(0, min(len(open_), 3)))          # attach near the oldest open vertex: shallow and wide
+            u = open_[k]
+            t[v - 1] = (u, v)
+            deg[u] += 1; deg[v] += 1
+            if deg[u] == 4:
+                open_.pop(k)
+            open_.append(v)
+    tree = torch.from_numpy(np.ascontiguousarray(t.astype(np.int32)))[None].to(dev)
+    si, sp, sc = bfs(tree, 4)
+    sin, spn, scn = si.cpu().numpy(), sp.cpu().numpy(), sc.cpu().numpy()
+    C = 2
+    x = rng.standard_normal((1, C, V)).astype(np.float32)
+    g = rng.standard_normal((1, C, V)).astype(np.float32)
+    w = rng.uniform(0.55, 1.0, (1, V)).astype(np.float32)          # weights in sorted order (refine.cu: weight[0] is unused)
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    out = refine(xd, torch.from_numpy(w).to(dev), si, sp, sc, True)
+    out.backward(torch.from_numpy(g).to(dev))
+    want, saved = tfo.refine_forward(x[0].astype(np.float64), w[0].astype(np.float64), sin[0], spn[0], scn[0])
+    assert np.isfinite(want).all()
+    assert np.abs(out[0].detach().cpu().numpy() - want).max() <= 2e-5 * max(np.abs(want).max(), 1.0)
+    gf = tfo.refine_backward_feature(g[0].astype(np.float64), w[0].astype(np.float64), sin[0], spn[0], scn[0], saved)
+    assert np.abs(xd.grad[0].cpu().numpy() - gf).max() <= 2e-5 * max(np.abs(gf).max(), 1.0)
+
+
 @pytest.mark.skipif(not tfo.ref_kernels_available(), reason='oracle/_ref/libtreekernels_ref.so not built (make -C oracle ref)')
 def test_large_refine_vs_reference_kernels_live_200x304(built, dev):
     """BoxLevelSet's size against the reference's OWN bfs.cu / refine.cu kernels run on this host's CPU
