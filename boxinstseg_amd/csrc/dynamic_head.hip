@@ -114,8 +114,8 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <int C, bool REL, int F>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8)))
 void dyn_bwd_kernel(DynArgs a, const float* __restrict__ params, const float* __restrict__ params_again,
-                    const float* __restrict__ g_logits, float* __restrict__ feat_part /*[kSlots,B,C,H,W]*/,
-                    float* __restrict__ param_part /*[N,T,P]*/) {
+                    const float* __restrict__ g_logits, float* __restrict__ feat_part /*[slots,B,C,H,W]*/,
+                    float* __restrict__ param_part /*[N,T,P]*/, int slots /* 1 .. kSlots workgroups share an (image, tile) */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using D = Dyn<C, REL>;
     constexpr int CIN = D::CIN;
@@ -123,11 +123,11 @@ void dyn_bwd_kernel(DynArgs a, const float* __restrict__ params, const float* __
     constexpr int kOnes = NROW, kZeros = NROW + 1;
     constexpr int kChunkN = 1024;                           // instance ids scanned per pass
     float* rows = lds;                                      // [NROW + 2][kRowPad]
-    __shared__ int mine[kChunkN / kSlots + 2];              // this workgroup's instances of the current chunk
+    __shared__ int mine[kChunkN + 2];                       // this workgroup's instances of the current chunk
     __shared__ int n_mine;
     const int tiles_x = (a.W + kYC - 1) / kYC, tiles_y = (a.H + kYR - 1) / kYR, T = tiles_x * tiles_y;
     int t = blockIdx.x;
-    const int slot = t % kSlots; t /= kSlots;
+    const int slot = t % slots; t /= slots;
     const int tile = t % T;
     const int b = t / T;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -228,15 +228,15 @@ void dyn_bwd_kernel(DynArgs a, const float* __restrict__ params, const float* __
         const int cnt = min(kChunkN, a.N - nb);
         __syncthreads();
         if (tid < kWave) {
-            int s0 = seen, mine0 = (seen + kSlots - 1 - slot) / kSlots, nm = 0;
+            int s0 = seen, mine0 = (seen + slots - 1 - slot) / slots, nm = 0;
             for (int base = 0; base < cnt; base += kWave) {
                 const int k = base + tid;
                 const bool hit = k < cnt && (int)a.img[nb + k] == b;
                 const unsigned long long m = __ballot(hit);
                 const int ord = s0 + __popcll(m & ((1ull << tid) - 1ull));     // ordinal among image b's instances
-                if (hit && ord % kSlots == slot) mine[ord / kSlots - mine0] = k;
+                if (hit && ord % slots == slot) mine[ord / slots - mine0] = k;
                 const int tot = __popcll(m);
-                nm = (s0 + tot + kSlots - 1 - slot) / kSlots - mine0;
+                nm = (s0 + tot + slots - 1 - slot) / slots - mine0;
                 s0 += tot;
             }
             if (tid == 0) n_mine = nm;
@@ -388,15 +388,15 @@ void dyn_bwd_kernel(DynArgs a, const float* __restrict__ params, const float* __
 
 __global__ __launch_bounds__(256) void dyn_reduce_kernel(const float* __restrict__ feat_part, int64_t feat_elems,
                                                          float* __restrict__ g_feat, const float* __restrict__ param_part,
-                                                         int N, int T, int P, float* __restrict__ g_params) {
+                                                         int N, int T, int P, float* __restrict__ g_params, int slots) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < feat_elems) {
         float v[kSlots];
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) v[s] = feat_part[s * feat_elems + i];
+        for (int s = 0; s < kSlots; ++s) v[s] = s < slots ? feat_part[s * feat_elems + i] : 0.f;
         float acc = 0.f;
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) acc += v[s];
+        for (int s = 0; s < kSlots; ++s) acc += v[s];                  // fixed order (absent slots add 0)
         g_feat[i] = acc;
     }
     const int64_t j = i - ((feat_elems + 255) / 256) * 256;
@@ -498,14 +498,18 @@ int bxi_dynamic_mask_backward_f32(const float* feat, int B, int C, int H, int W,
     float* param_part = (float*)((char*)workspace + (sizeof(float) * (size_t)bxi::kSlots * feat_elems + 255) / 256 * 256);
     const int cin = C + (a.rel ? 2 : 0);
     const size_t lds = sizeof(float) * ((size_t)(1 + 4 * bxi::kDC + cin + 2) * bxi::kRowPad);
-    const unsigned grid = (unsigned)(B * T * bxi::kSlots);
+    // Workgroups per (image, tile): each walks every slots-th instance of its image.  Few instances per image: 4, so that the launch is
+    // resident at once (2 x 52 x 4 = 416 workgroups on 512 slots at 2 x 100 x 128: 27.1 -> 25.2 us at 32 instances); many: 8 (at 128
+    // instances 4 slots measure 88 us against 79: more instances per workgroup than the single round saves).
+    const int slots = N <= 16 * B ? 4 : bxi::kSlots;
+    const unsigned grid = (unsigned)(B * T * slots);
     BXI_DYN_DISPATCH(C, a.rel, factor, BXI_LAUNCH("dyn_bwd", s, (bxi::dyn_bwd_kernel<KC, KR, KF>), dim3(grid), dim3(256), lds, s, a, params, params, g_logits,
-                                          feat_part, param_part));
+                                          feat_part, param_part, slots));
     rc = bxi::check_launch();
     if (rc != BXI_OK) return rc;
     const int64_t nb = (feat_elems + 255) / 256 + ((int64_t)N * P + 255) / 256;
     BXI_LAUNCH("dyn_reduce", s, bxi::dyn_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, s, feat_part, feat_elems, g_feat,
-               param_part, N, T, P, g_params);
+               param_part, N, T, P, g_params, slots);
     return bxi::check_launch();
 }
 
