@@ -192,7 +192,8 @@ int launch_mst_large(const int* edge_index, const float* edge_weight, int B, int
 struct BfsLargeWs {
     uint32_t* adj; uint32_t* deg; uint32_t* nodev; uint32_t* nodep; uint32_t* pos_of; int* flag; int* nf; int* gw; unsigned char* gmask;
     // the Euler-tour form (below): two list rankings over the 4V arc slots, per-vertex results, the pairs of the radix sort
-    unsigned long long* e1; unsigned long long* e2; int* pk; uint32_t* key[2]; uint32_t* val[2]; uint32_t* hist; int* bad;
+    unsigned long long* e1; unsigned long long* e2; int* pk; uint32_t* key0; uint32_t* key1; uint32_t* val0; uint32_t* val1; uint32_t* hist; int* bad;
+    // (named pointers, not arrays: a pointer array indexed by the pass parity cost the refine rounds a factor of three, profiles/NOTES.md R3-2e)
 };
 constexpr int kEulerMaxV = (1 << 20) - 1;          // arc ids (and the end marker 4V) < 2^22 and counts < 2^21 share one 64-bit word
 constexpr int kSortTile = 1024, kSortBits = 9, kSortBuckets = 1 << kSortBits;
@@ -207,7 +208,8 @@ __host__ __device__ static size_t carve_bfs_large(char* base, int V, BfsLargeWs*
     const size_t nblk = ((size_t)V + kSortTile - 1) / kSortTile;
     t.e1 = (unsigned long long*)take(euler ? 32 * (size_t)V : 0); t.e2 = (unsigned long long*)take(euler ? 32 * (size_t)V : 0);
     t.pk = (int*)take(euler ? 4 * (size_t)V : 0);
-    for (int q = 0; q < 2; ++q) { t.key[q] = (uint32_t*)take(euler ? 4 * (size_t)V : 0); t.val[q] = (uint32_t*)take(euler ? 4 * (size_t)V : 0); }
+    t.key0 = (uint32_t*)take(euler ? 4 * (size_t)V : 0); t.val0 = (uint32_t*)take(euler ? 4 * (size_t)V : 0);
+    t.key1 = (uint32_t*)take(euler ? 4 * (size_t)V : 0); t.val1 = (uint32_t*)take(euler ? 4 * (size_t)V : 0);
     t.hist = (uint32_t*)take(euler ? 4 * (size_t)kSortBuckets * (nblk + 1) : 0);       // [tile][bucket], then the buckets' bases
     t.bad = (int*)take(4);
     if (w) *w = t;
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(256) void bfsE_place_kernel(int V, char* ws_base, s
         }
         if (!ok) atomicOr(w.bad, 1);
     }
-    if (ok) { w.key[0][pre] = dep; w.val[0][pre] = v; }                     // (a permutation when the input is a tree)
+    if (ok) { w.key0[pre] = dep; w.val0[pre] = v; }                     // (a permutation when the input is a tree)
 }
 // ---- stable LSD radix sort of the (depth, vertex) pairs, kSortBits bits a pass, one wave per tile of kSortTile pairs -------------------
 __device__ __forceinline__ unsigned long long same_digit_lanes(uint32_t digit, bool valid) {
@@ -698,7 +700,7 @@ __global__ __launch_bounds__(64) void bfsE_sort_hist_kernel(int V, int pass, cha
     __shared__ uint32_t h[kSortBuckets];
     const int b = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x;
     const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
-    const uint32_t* key = w.key[pass & 1];
+    const uint32_t* key = (pass & 1) ? w.key1 : w.key0;
     for (int i = lane; i < kSortBuckets; i += 64) h[i] = 0u;
     __syncthreads();
     for (int i = blk * kSortTile + lane; i < min((blk + 1) * kSortTile, V); i += 64) atomicAdd(&h[(key[i] >> (pass * kSortBits)) & (kSortBuckets - 1)], 1u);
@@ -733,8 +735,8 @@ __global__ __launch_bounds__(64) void bfsE_sort_scatter_kernel(int V, int pass, 
     __shared__ uint32_t place[kSortBuckets];
     const int b = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x, nblk = gridDim.x;
     const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
-    const uint32_t* key = w.key[pass & 1]; const uint32_t* val = w.val[pass & 1];
-    uint32_t* key_o = w.key[(pass & 1) ^ 1]; uint32_t* val_o = w.val[(pass & 1) ^ 1];
+    const uint32_t* key = (pass & 1) ? w.key1 : w.key0; const uint32_t* val = (pass & 1) ? w.val1 : w.val0;
+    uint32_t* key_o = (pass & 1) ? w.key0 : w.key1; uint32_t* val_o = (pass & 1) ? w.val0 : w.val1;
     for (int i = lane; i < kSortBuckets; i += 64) place[i] = w.hist[(size_t)nblk * kSortBuckets + i] + w.hist[(size_t)blk * kSortBuckets + i];
     __syncthreads();
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -770,13 +772,14 @@ __global__ __launch_bounds__(256) void bfsE_fill_kernel(int V, int src, int* __r
     const BfsLargeWs w = bfs_ws(ws_base, ws_stride, b, V);
     int* lv = levels + (int64_t)b * (V + 2);
     const bool bad = (*w.flag & 1) || *w.bad;
-    const uint32_t v = bad ? 0u : w.val[src][p];
+    const uint32_t* keys = src ? w.key1 : w.key0;
+    const uint32_t v = bad ? 0u : (src ? w.val1 : w.val0)[p];
     const int pk = v < (uint32_t)V ? w.pk[v] : -1;
     w.nodev[p] = v < (uint32_t)V ? v : 0u;
     w.nodep[p] = (p == 0 || pk < 0) ? 0xffffffffu : w.adj[4u * v + pk];
     if (!bad) {
-        const uint32_t d = w.key[src][p];
-        if (p == 0 || w.key[src][p - 1] != d) { if (d < (uint32_t)V) lv[1 + d] = p; }
+        const uint32_t d = keys[p];
+        if (p == 0 || keys[p - 1] != d) { if (d < (uint32_t)V) lv[1 + d] = p; }
         if (p == V - 1) { lv[0] = (int)d + 1; if (d < (uint32_t)V) lv[2 + d] = V; }
     } else if (p == 0) lv[0] = -1;
     if (p == 0) {
