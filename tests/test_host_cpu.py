@@ -94,6 +94,12 @@ def test_head_constructor_and_state_dict_match_reference_contract():
     other = bx.build_head(dict(type='CondInstMaskHead', **kw))
     other.load_state_dict(head.state_dict())
     assert other._iter_host is None and abs(other._tick() - 0.2501) < 1e-7 and float(other._iter) == 2501.0
+    # when the loss evaluation advances the buffer itself (bxi_instances.iter_counter), _tick only moves the mirror; the buffer is what
+    # the kernel made it (here: nothing), and an external write -- version counter -- is still noticed afterwards
+    assert abs(other._tick(True) - 0.2502) < 1e-7 and float(other._iter) == 2501.0 and other._iter_host == 2502.0
+    other._iter.fill_(10.0)
+    assert abs(other._tick(True) - 0.0011) < 1e-9 and other._iter_host == 11.0
+    assert other._counts_in_evaluation(torch.zeros(1)) and not other._counts_in_evaluation(torch.zeros(1, device='meta'))
     with pytest.raises(AssertionError):
         bx.CondInstMaskHead(max_proposals=500, topk_per_img=64)
     with pytest.raises(KeyError):
