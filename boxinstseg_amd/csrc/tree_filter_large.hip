@@ -55,21 +55,35 @@ __global__ __launch_bounds__(256) void mstL_init_kernel(int E, int V, char* ws_b
     if (i < (E + 31) / 32) w.chosen[i] = 0u;
     if (i < 33) w.act[i] = 0;
 }
-// every edge between two components offers (weight bits, edge index) to both (64-bit atomic min at the memory side)
+// every edge between two components offers (weight bits, edge index) to both (64-bit atomic min at the memory side).  In the late rounds a
+// handful of components take every offer -- 121 000 atomics on a few words: 12-15 us a round -- so a wave whose offers all go to one
+// component (neighbouring edges: the usual case) sends their minimum, once.
+__device__ __forceinline__ void offer_min(u64* best, uint32_t comp, u64 key, bool act) {
+    const unsigned long long m = __ballot(act);
+    if (!m) return;
+    const int first = __ffsll((long long)m) - 1;
+    const uint32_t c0 = (uint32_t)__shfl((int)comp, first, 64);
+    if (__all(!act || comp == c0)) {
+        const u64 k = ~wave_max_u64(act ? ~key : 0ull);                     // the minimum over the active lanes
+        if ((int)(threadIdx.x & 63) == first) atomicMin(&best[c0], k);
+    } else if (act) atomicMin(&best[comp], key);
+}
 __global__ __launch_bounds__(256) void mstL_offer_kernel(const int* __restrict__ edge_index, const float* __restrict__ edge_weight, int E, int V,
                                                          char* ws_base, size_t ws_stride, int round) {
     const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= E) return;
     const MstLargeWs w = mst_ws(ws_base, ws_stride, b, E, V);
-    if (w.act[32]) return;
+    if (w.act[32]) return;                                           // (uniform: the whole launch returns)
     const int* idx = edge_index + (int64_t)b * E * 2;
-    const uint32_t cu = w.comp[idx[2 * e]], cv = w.comp[idx[2 * e + 1]];
-    if (cu != cv) {
+    uint32_t cu = 0u, cv = 0u;
+    if (e < E) { cu = w.comp[idx[2 * e]]; cv = w.comp[idx[2 * e + 1]]; }
+    const bool act = e < E && cu != cv;
+    u64 key = ~0ull;
+    if (act) {
         if (w.act[round] == 0) w.act[round] = 1;                      // (every writer writes 1; the word is read by the NEXT kernels only)
-        const u64 key = ((u64)__float_as_uint(edge_weight[(int64_t)b * E + e]) << 32) | (uint32_t)e;   // weights are >= 0: the bits order like the values
-        atomicMin(&w.best[cu], key);
-        atomicMin(&w.best[cv], key);
+        key = ((u64)__float_as_uint(edge_weight[(int64_t)b * E + e]) << 32) | (uint32_t)e;   // weights are >= 0: the bits order like the values
     }
+    offer_min(w.best, cu, key, act);
+    offer_min(w.best, cv, key, act);
 }
 // every component root takes its cheapest edge and hooks to the component at its other end
 __global__ __launch_bounds__(256) void mstL_hook_kernel(const int* __restrict__ edge_index, int E, int V, char* ws_base, size_t ws_stride, int round) {
