@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void bfsL_parent_kernel(int V, int max_adj, in
 //      weights, "leads down" / "leads up": the suffix counts at the arc (parent -> v) give v's PREORDER number and its DEPTH;
 //   4. BFS order = by depth, within a depth by preorder (subtrees are contiguous in preorder, so on every level the preorder of the nodes is
 //      the preorder of their parents, then the child order -- the queue's order): a stable LSD radix sort of the preorder sequence by depth;
-//      the level offsets are the scanned depth histogram.
+//      level d starts where the sorted key changes to d.
 // Pointer jumping is done IN PLACE and asynchronously: a slot holds (successor, weight of the arcs from this one up to, not including, the
 // successor) in ONE 64-bit word, so any value a thread reads -- this launch's or a staler one from its XCD's L2 -- is a correct pair, and
 // jumping over it keeps the pair correct; every launch makes each thread jump kEulerJumps times over values at least as advanced as the
