@@ -551,7 +551,8 @@ __global__ __launch_bounds__(256) void bfsL_parent_kernel(int V, int max_adj, in
 //      from arc 0 = (0 -> adj[0][0]) to the last arc back into the root;
 //   2. LIST RANKING by pointer jumping gives every arc its distance to the end of the list; of the two arcs of an edge the one earlier
 //      in the tour leads AWAY from the root, which tells every vertex its parent;
-//   3. a second tour that visits the children of every vertex in ascending order (the order bfs.cu appends them in) is ranked with two
+//   3. a second tour that visits the children of every vertex in ascending order (this library's sibling order; bfs.cu's is the arrival
+//      order of its atomics) is ranked with two
 //      weights, "leads down" / "leads up": the suffix counts at the arc (parent -> v) give v's PREORDER number and its DEPTH;
 //   4. BFS order = by depth, within a depth by preorder (subtrees are contiguous in preorder, so on every level the preorder of the nodes is
 //      the preorder of their parents, then the child order -- the queue's order): a stable LSD radix sort of the preorder sequence by depth;
