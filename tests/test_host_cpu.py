@@ -357,3 +357,30 @@ def test_iter_buffer_is_listed_for_ddp_to_skip():
     assert 'mask_head._iter' in dict(m.named_buffers())
     exclude_iter_from_ddp_broadcast(m)
     assert m._ddp_params_and_buffers_to_ignore.count('mask_head._iter') == 1
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """The two structs that cross the C ABI by pointer: size and every field offset of the ctypes mirrors (boxinstseg_amd/_lib.py) equal
+    what a C compiler makes of include/boxinst_hip.h (a field added to one side only would shift everything behind it silently)."""
+    import shutil, subprocess
+    from boxinstseg_amd import _lib
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no C compiler')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mirrors = {'bxi_image_batch': _lib.ImageBatch, 'bxi_instances': _lib.Instances}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "boxinst_hip.h"', 'int main(void) {']
+    for cname, cls in mirrors.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run([gcc, '-std=c99', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in mirrors.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f'{cname}.{fname}']) == getattr(cls, fname).offset, f'{cname}.{fname}'
