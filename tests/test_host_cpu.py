@@ -63,6 +63,13 @@ def test_abi_argument_validation_without_device():
     assert lib.bxi_meanfield_forward_f32(None, 1, 4, 4, 3, None, None, 0, None, 1, 10, 0.7, None, 0.01, None, None, None, 0, None) == -3   # base >= 0.5
     assert lib.bxi_meanfield_workspace_bytes(2, 10, 130) == 3 * 8 * 2 * 10 * 3
     assert lib.bxi_mil_loss_forward_f32(None, None, 0, 1, 4, 4, None, None, None) == -1
+    # tree_filter workspaces: none where the graph fits LDS; beyond, the Euler-tour BFS needs two 64-bit words per arc slot (4 per vertex)
+    # up to 2^20 - 1 vertices, the level walk beyond that far less; refine: two record buffers + parents + the doubling pass's arrays
+    V = 200 * 304
+    assert lib.bxi_bfs_workspace_bytes(2, 96 * 96) == 0 and lib.bxi_tree_refine_workspace_bytes(2, 5, 96 * 96) == 0
+    assert lib.bxi_bfs_workspace_bytes(1, V) >= 64 * V and lib.bxi_bfs_workspace_bytes(2, V) == 2 * lib.bxi_bfs_workspace_bytes(1, V)
+    assert lib.bxi_bfs_workspace_bytes(1, 1 << 21) < 64 * (1 << 21)
+    assert lib.bxi_tree_refine_workspace_bytes(2, 5, V) >= 2 * 5 * V * (16 + 16 + 4 + 12)
     assert lib.bxi_levelset_loss_forward_f32(None, None, None, 1, 5000, 4, 4, 1.0, None, None, None) == -4         # C > 4096
     assert lib.bxi_levelset_state_bytes(3, 2) == 8 * 3 * 10 * 9
     assert lib.bxi_lcm_refine_f32(None, None, 1, 4, 4, 0, 10, 0, None, None, 0, None) == -3                         # dilation < 1
