@@ -23,5 +23,11 @@ for t in pairwise_op dynamic_head head_fused discobox levelset tree_filter; do
   timeout 300 python $R/tools/bench_$t.py > $R/gpurun_out/${t}_bench.json 2>> $R/gpurun_out/${t}_bench.err
   tail -c 300 $R/gpurun_out/${t}_bench.json | tr '\n' ' '; echo
 done
-cd $R && python tools/trace_eval.py 2>&1 | grep -v amdgpu.ids > gpurun_out/block_trace.txt; tail -3 gpurun_out/block_trace.txt | cut -c1-300
+cd $R
+# the per-wave trace needs the -DBXI_TRACE build of the library (tools/trace_eval.py's docstring); it is not kept in the tree
+if [ -f boxinstseg_amd/lib/libboxinst_hip_trace.so ]; then
+  python tools/trace_eval.py 2>&1 | grep -v amdgpu.ids > gpurun_out/block_trace.txt; tail -3 gpurun_out/block_trace.txt | cut -c1-300
+else
+  rm -f gpurun_out/block_trace.txt; echo "no trace build: block trace skipped"
+fi
 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 600 gpurun_out/bench_default.json
