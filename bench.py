@@ -54,6 +54,7 @@ def parse_args(argv=None):
                     help='graph: one hipGraph per input set, replayed; eager: direct C-ABI calls')
     ap.add_argument('--sets', type=int, default=8, help='independent input sets rotated through')
     ap.add_argument('--inst-per-box', type=int, default=1)
+    ap.add_argument('--flags', type=int, default=0, help='BXI_EVAL_* flags of every timed evaluation (0 = the library chooses)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-extras', '--no-pipelined', dest='no_extras', action='store_true',
@@ -66,7 +67,7 @@ def parse_args(argv=None):
 class EvalSet:
     """One synthetic 2x800x1024 / 32-instance batch resident on the device + its output buffers."""
 
-    def __init__(self, lib, Fh, synthetic, dev, seed, inst_per_box, ones):
+    def __init__(self, lib, Fh, synthetic, dev, seed, inst_per_box, ones, flags=0):
         d = synthetic.cfg2(seed=seed, inst_per_box=inst_per_box)
         self.d = d
         self.imgs = torch.from_numpy(d['imgs']).to(dev)
@@ -79,7 +80,8 @@ class EvalSet:
         self.losses = torch.zeros(2, device=dev)
         self.grad = torch.empty_like(self.inst.logits)
         self.state = torch.empty(lib.bxi_boxinst_loss_state_bytes(N, h, w), dtype=torch.uint8, device=dev)
-        self.ws = torch.empty(lib.bxi_boxinst_eval_workspace_bytes(d['B'], d['H'], d['W'], d['stride'], N),
+        # zeroed ONCE, as the C ABI asks (the workspace carries the evaluation's tag counter); never touched by the host again
+        self.ws = torch.zeros(lib.bxi_boxinst_eval_workspace_bytes(d['B'], d['H'], d['W'], d['stride'], N),
                               dtype=torch.uint8, device=dev)
         # the C-ABI argument lists, marshalled once (what a training loop that keeps its buffers does): only the
         # stream is appended per call
@@ -87,7 +89,7 @@ class EvalSet:
         self.eval_args = (C.byref(self.batch.struct), C.byref(self.inst.struct), C.c_int(3), C.c_int(2), C.c_float(0.3),
                           C.c_float(1.0), vp(ones.data_ptr()), vp(ones.data_ptr() + 4), vp(self.losses.data_ptr()),
                           vp(self.grad.data_ptr()), vp(self.state.data_ptr()), vp(self.ws.data_ptr()),
-                          C.c_size_t(self.ws.numel()))
+                          C.c_size_t(self.ws.numel()), C.c_uint(flags))
         self.rescale_args = (C.byref(self.inst.struct), vp(ones.data_ptr()), vp(ones.data_ptr() + 4), C.c_int(2),
                              vp(self.state.data_ptr()), vp(self.grad.data_ptr()))
 
@@ -153,13 +155,15 @@ def worker(args):
     assert lib.bxi_check_device(dev.index) == 0, 'not a gfx950 device'
 
     ones = torch.ones(2, device=dev)            # upstream gradients of loss_prj / loss_pairwise
-    sets = [EvalSet(lib, Fh, synthetic, dev, seed=1000 * rank + i, inst_per_box=args.inst_per_box, ones=ones)
+    sets = [EvalSet(lib, Fh, synthetic, dev, seed=1000 * rank + i, inst_per_box=args.inst_per_box, ones=ones, flags=args.flags)
             for i in range(args.sets)]
     stream = torch.cuda.Stream(device=dev)
     f_eval, f_rescale = lib.bxi_boxinst_eval_f32, lib.bxi_boxinst_grad_rescale_f32
 
-    def enqueue(s: EvalSet, st: int) -> None:
-        rc = f_eval(*s.eval_args, st)
+    def enqueue(s: EvalSet, st: int, shared: bool = False) -> None:
+        # shared: evaluations in flight side by side on several streams -- the caller says so (BXI_EVAL_SHARED_DEVICE), the library
+        # does not guess
+        rc = f_eval(*s.eval_args, st) if not shared else f_eval(*s.eval_args[:-1], C.c_uint(args.flags | _lib.EVAL_SHARED_DEVICE), st)
         if rc != 0:
             raise RuntimeError(f'C ABI status {rc}: {_lib.status_string(rc)}')
 
@@ -257,11 +261,11 @@ def worker(args):
     # launches per step, counted: the launch hook is called before and after every kernel launch the library makes
     calls = []
     cb_count = _lib.LAUNCH_HOOK(lambda name, phase, st, user: calls.append(name))
-    lib.bxi_set_launch_hook(C.cast(cb_count, C.c_void_p), None)
+    lib.bxi_dev_set_launch_hook(C.cast(cb_count, C.c_void_p), None)
     try:
         enqueue(sets[0], stream.cuda_stream)
     finally:
-        lib.bxi_set_launch_hook(None, None)
+        lib.bxi_dev_set_launch_hook(None, None)
     torch.cuda.synchronize(dev)
     launches_per_step = len(calls) // 2
     launched = sorted({c.decode() for c in calls})
@@ -345,7 +349,7 @@ def worker(args):
             streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
             def run_multi(n_steps):
                 for i in range(n_steps):
-                    enqueue(sets[i % len(sets)], streams[i % ns].cuda_stream)     # a set (and its workspace) stays on one stream
+                    enqueue(sets[i % len(sets)], streams[i % ns].cuda_stream, shared=True)     # a set (and its workspace) stays on one stream
             run_multi(64)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
@@ -470,7 +474,6 @@ def module_api(sets, dev, n):
     from boxinstseg_amd import CondInstMaskHead
     head = CondInstMaskHead(in_channels=16, boxinst_enabled=True, topk_per_img=64, max_proposals=-1).to(dev)
     head._iter.fill_(20000.0)
-    head._iter_host = None
     xs = [s.logits.clone().requires_grad_(True) for s in sets]
 
     def once(i):
@@ -595,7 +598,7 @@ def measured_traffic():
 
 
 def kernel_timing(lib, _lib, sets, stream, enqueue, steps, step_us, rows):
-    """Bracket every kernel launch with HIP events (bxi_set_launch_hook) over `steps` eager steps."""
+    """Bracket every kernel launch with HIP events (bxi_dev_set_launch_hook) over `steps` eager steps."""
     events = {}
 
     def hook(name, phase, st, user):
@@ -612,12 +615,12 @@ def kernel_timing(lib, _lib, sets, stream, enqueue, steps, step_us, rows):
         # when the GPU gets to it: the event pairs then bracket kernels that run back to back, exactly as
         # in the timed region (otherwise they would also measure the host's enqueue latency)
         torch.cuda._sleep(int(0.1 * 2.0e9))
-        lib.bxi_set_launch_hook(C.cast(cb, C.c_void_p), None)
+        lib.bxi_dev_set_launch_hook(C.cast(cb, C.c_void_p), None)
         try:
             for i in range(steps):
                 enqueue(sets[i % len(sets)], stream.cuda_stream)
         finally:
-            lib.bxi_set_launch_hook(None, None)
+            lib.bxi_dev_set_launch_hook(None, None)
     stream.synchronize()
     raws = {name: np.array([evs[j].elapsed_time(evs[j + 1]) * 1e3 for j in range(0, len(evs) - 1, 2)])
             for name, evs in events.items()}                                                      # us
@@ -659,7 +662,7 @@ def kernel_timing(lib, _lib, sets, stream, enqueue, steps, step_us, rows):
                      'algorithmic_bytes': whole, 'algorithmic_bytes_source': 'SURVEY 8(d): 39 322 240 B at 2x800x1024x32',
                      'time_us': step_us, 'time_source': 'ms_per_step of this run (un-instrumented: every launch of a step and its boundary)',
                      'event_kernel_time_us': ksum, 'frac_on_event_kernel_time': whole / (ksum * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                     'timing': 'per kernel: hipEvent pairs around each launch on the launching stream (bxi_set_launch_hook), minus the '
+                     'timing': 'per kernel: hipEvent pairs around each launch on the launching stream (bxi_dev_set_launch_hook), minus the '
                                'cost of an empty pair measured separately (event_bracket_us); launches queued behind a parked stream, '
                                'cold input sets.  rocprofv3 durations of the same command: profiles/',
                      'per_kernel': {k: {'avg_us': v['avg_us'], 'raw_event_avg_us': v['raw_event_avg_us'],

@@ -13,7 +13,9 @@ from . import build as _build
 c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
 BXI_MAX_IMAGES = 64
-BXI_ABI_VERSION = 4
+BXI_ABI_VERSION = 5
+# `flags` of bxi_boxinst_eval_f32 / bxi_boxinst_head_eval_f32 (include/boxinst_hip.h)
+EVAL_SINGLE_LAUNCH, EVAL_TWO_LAUNCHES, EVAL_NO_STAY_ON, EVAL_TILE_ROWS_8, EVAL_SHARED_DEVICE, EVAL_WAITS_GIVE_UP = 1, 2, 4, 8, 16, 256
 
 STATUS = {0: 'BXI_OK', -1: 'BXI_ERR_NULL_POINTER', -2: 'BXI_ERR_BAD_SHAPE', -3: 'BXI_ERR_BAD_ARGUMENT',
           -4: 'BXI_ERR_UNSUPPORTED', -5: 'BXI_ERR_WORKSPACE', -6: 'BXI_ERR_LAUNCH', -7: 'BXI_ERR_NO_DEVICE'}
@@ -37,13 +39,14 @@ class Instances(C.Structure):
                 ('stride', c_int), ('iter_counter', c_void_p)]
 
 
-# name -> (restype, argtypes); must list every symbol of include/boxinst_hip.h (tests check this)
+# name -> (restype, argtypes); must list every symbol of include/boxinst_hip.h and include/boxinst_hip_dev.h (tests check this)
 SIGNATURES = {
     'bxi_abi_version': (c_int, []),
     'bxi_status_string': (C.c_char_p, [c_int]),
     'bxi_last_hip_error': (c_int, []),
     'bxi_check_device': (c_int, [c_int]),
-    'bxi_set_launch_hook': (None, [c_void_p, c_void_p]),
+    'bxi_dev_set_launch_hook': (None, [c_void_p, c_void_p]),           # boxinst_hip_dev.h (bench / tests only)
+    'bxi_dev_set_tree_level_walk': (None, [c_int]),                    # boxinst_hip_dev.h (tests only)
     'bxi_pairwise_nlog_forward_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'bxi_pairwise_nlog_forward_f64': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'bxi_pairwise_nlog_backward_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -57,19 +60,19 @@ SIGNATURES = {
     'bxi_boxinst_loss_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'bxi_boxinst_loss_state_bytes': (c_size_t, [c_int, c_int, c_int]),
     'bxi_boxinst_loss_state_status_offset': (c_size_t, [c_int, c_int, c_int]),
+    'bxi_boxinst_loss_state_warmup_offset': (c_size_t, [c_int, c_int, c_int]),
     'bxi_boxinst_loss_fwd_bwd_f32': (c_int, [C.POINTER(Instances), c_void_p, c_int, c_int, c_float, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'bxi_boxinst_loss_backward_f32': (c_int, [C.POINTER(Instances), c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                              c_void_p]),
     'bxi_boxinst_eval_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'bxi_boxinst_eval_workspace_lab_offset': (c_size_t, []),
+    'bxi_boxinst_eval_workspace_init': (c_int, [c_void_p, c_size_t, c_void_p]),
     'bxi_boxinst_eval_f32': (c_int, [C.POINTER(ImageBatch), C.POINTER(Instances), c_int, c_int, c_float, c_float,
-                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, C.c_uint, c_void_p]),
     'bxi_boxinst_head_eval_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
-                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    'bxi_debug_set_spin_limit': (None, [c_int]),
-    'bxi_debug_set_eval_form': (None, [c_int]),
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, C.c_uint, c_void_p]),
     'bxi_boxinst_grad_rescale_f32': (c_int, [C.POINTER(Instances), c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                              c_void_p]),
     'bxi_dynamic_mask_forward_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,

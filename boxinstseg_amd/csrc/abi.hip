@@ -1,22 +1,24 @@
 // abi.hip -- library-level entry points of libboxinst_hip.so (see include/boxinst_hip.h).
 #include "common.hpp"
 #include "dynamic_head_device.hpp"
+#include "../../include/boxinst_hip_dev.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace bxi {
 
 static thread_local int g_last_hip_error = 0;
 void set_last_hip_error(int e) { g_last_hip_error = e; }
-bxi_launch_hook g_hook = nullptr;
-void* g_hook_user = nullptr;
+std::atomic<bxi_launch_hook> g_hook{nullptr};         // developer hook (include/boxinst_hip_dev.h); not part of the production ABI
+std::atomic<void*> g_hook_user{nullptr};
 
 size_t loss_ws_bytes(int N, int h, int w);
 size_t eval_ws_bytes(int B, int N, int h, int w);
 bool fused_eval_supported(int dil);
-void debug_set_spin_limit(int limit);
-void debug_set_eval_form(int form);
+void dev_set_tree_level_walk(int on);
+int eval_ws_init(void* workspace, size_t bytes, void* stream);
 int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bxi_instances* in, int dil, float warmup, const float* up_prj,
-                      const float* up_pw, float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, int force_rows,
+                      const float* up_pw, float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, unsigned flags,
                       void* stream, const DynArgs* head = nullptr, int head_C = 0);
 int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits, void* stream);
 
@@ -44,10 +46,12 @@ const char* bxi_status_string(int status) {
 
 int bxi_last_hip_error(void) { return bxi::g_last_hip_error; }
 
-void bxi_set_launch_hook(bxi_launch_hook hook, void* user) {
-    bxi::g_hook_user = user;
-    bxi::g_hook = hook;
+void bxi_dev_set_launch_hook(bxi_launch_hook hook, void* user) {
+    bxi::g_hook.store(nullptr, std::memory_order_release);          // never a new hook with the old user pointer
+    bxi::g_hook_user.store(user, std::memory_order_release);
+    bxi::g_hook.store(hook, std::memory_order_release);
 }
+void bxi_dev_set_tree_level_walk(int on) { bxi::dev_set_tree_level_walk(on); }
 
 int bxi_check_device(int ordinal) {
     int count = 0;
@@ -73,9 +77,13 @@ size_t bxi_boxinst_eval_workspace_bytes(int B, int Hc, int Wc, int stride, int N
 
 size_t bxi_boxinst_eval_workspace_lab_offset(void) { return 0; }
 
+int bxi_boxinst_eval_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    return bxi::eval_ws_init(workspace, workspace_bytes, stream);
+}
+
 int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host, int size, int dilation,
                          float color_thresh, float warmup, const float* up_prj, const float* up_pw, float* losses,
-                         float* g_logits, void* state, void* workspace, size_t workspace_bytes, void* stream) {
+                         float* g_logits, void* state, void* workspace, size_t workspace_bytes, unsigned int flags, void* stream) {
     if (!batch_host || !inst_host) return BXI_ERR_NULL_POINTER;
     if (size < 1 || (size & 1) == 0 || dilation < 1) return BXI_ERR_BAD_ARGUMENT;
     if (size != 3 || !bxi::fused_eval_supported(dilation)) return BXI_ERR_UNSUPPORTED;
@@ -87,16 +95,20 @@ int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances*
                                                          inst_host->N);
     if (!workspace || need == 0 || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255))
         return BXI_ERR_WORKSPACE;
+    if (flags & ~(unsigned)BXI_EVAL_ALL_FLAGS) return BXI_ERR_BAD_ARGUMENT;
+    if ((flags & BXI_EVAL_SINGLE_LAUNCH) && (flags & BXI_EVAL_TWO_LAUNCHES)) return BXI_ERR_BAD_ARGUMENT;
     return bxi::launch_fused_eval(batch_host, color_thresh, inst_host, dilation, warmup, up_prj, up_pw, losses, g_logits, state, workspace,
-                                  workspace_bytes, 0, stream);
+                                  workspace_bytes, flags, stream);
 }
 
 int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host, const float* feat, int C, int Hs,
                               int Ws, const float* params, const float* coors, const int64_t* level_inds, const int64_t* img_inds,
                               const float* sizes_of_interest, int n_levels, int in_stride, int factor, int disable_rel_coors,
                               int size, int dilation, float color_thresh, float warmup, const float* up_prj, const float* up_pw,
-                              float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, void* stream) {
+                              float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, unsigned int flags,
+                              void* stream) {
     if (!batch_host || !inst_host) return BXI_ERR_NULL_POINTER;
+    if (flags & ~(unsigned)BXI_EVAL_ALL_FLAGS) return BXI_ERR_BAD_ARGUMENT;
     if (size < 1 || (size & 1) == 0 || dilation < 1) return BXI_ERR_BAD_ARGUMENT;
     if (size != 3 || !bxi::fused_eval_supported(dilation)) return BXI_ERR_UNSUPPORTED;
     const int stride = inst_host->stride;
@@ -111,11 +123,8 @@ int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_insta
     const size_t need = bxi_boxinst_eval_workspace_bytes(batch_host->B, batch_host->Hc, batch_host->Wc, stride, inst_host->N);
     if (!workspace || need == 0 || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
     return bxi::launch_fused_eval(batch_host, color_thresh, inst_host, dilation, warmup, up_prj, up_pw, losses, g_logits, state, workspace,
-                                  workspace_bytes, 0, stream, &da, C);
+                                  workspace_bytes, flags, stream, &da, C);
 }
-
-void bxi_debug_set_spin_limit(int limit) { bxi::debug_set_spin_limit(limit); }
-void bxi_debug_set_eval_form(int form) { bxi::debug_set_eval_form(form); }
 
 int bxi_boxinst_grad_rescale_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw, int dilation,
                                  const void* state, float* g_logits, void* stream) {

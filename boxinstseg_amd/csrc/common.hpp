@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #include "../../include/boxinst_hip.h"
 
@@ -25,12 +26,15 @@ inline int check_launch() {
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // measurement hook (bxi_set_launch_hook): brackets one kernel launch
-extern bxi_launch_hook g_hook;
-extern void* g_hook_user;
+typedef void (*bxi_launch_hook)(const char* kernel_name, int phase, void* stream, void* user);      // include/boxinst_hip_dev.h
+extern std::atomic<bxi_launch_hook> g_hook;
+extern std::atomic<void*> g_hook_user;
 struct LaunchScope {
-    const char* name; hipStream_t s;
-    LaunchScope(const char* n, hipStream_t st) : name(n), s(st) { if (g_hook) g_hook(name, 0, (void*)s, g_hook_user); }
-    ~LaunchScope() { if (g_hook) g_hook(name, 1, (void*)s, g_hook_user); }
+    const char* name; hipStream_t s; bxi_launch_hook hook; void* user;
+    LaunchScope(const char* n, hipStream_t st) : name(n), s(st), hook(g_hook.load(std::memory_order_acquire)), user(nullptr) {
+        if (hook) { user = g_hook_user.load(std::memory_order_acquire); hook(name, 0, (void*)s, user); }
+    }
+    ~LaunchScope() { if (hook) hook(name, 1, (void*)s, user); }
 };
 
 #define BXI_LAUNCH(label, stream, ...)                 \

@@ -51,13 +51,11 @@ constexpr int kSRows = 8;                       // rows per stream wave
 constexpr int kSBlk = kWaves * kSRows;          // rows per stream workgroup
 constexpr int kChunkC = 256;                    // columns per pass of a stream wave: 64 lanes x float4
 constexpr int kMaxDilFused = 4;
-constexpr int kSpinLimit = 4000000;             // bounded waits (0.3 - 1 us per poll: seconds): far beyond any launch, also one that shares the GPU
-                                                // with long-running kernels of other streams; running out is loud (NaN losses)
-// developer / test hook (bxi_debug_set_spin_limit): 0 = kSpinLimit; negative = every bounded wait gives up at once
-static std::atomic<int> g_spin_limit{0};
-// developer / test hook (bxi_debug_set_eval_form), bits: 0 = the library chooses; 1 = the single launch whenever it is built for the shape
-// (also where it does not pay); 2 = always two launches; 8 = 8-row tiles (two launches)
-static std::atomic<int> g_form{0};
+constexpr int kSpinLimit = 250000;              // bounded waits (0.3 - 1 us per poll: ~0.1 - 0.25 s): far beyond any launch, also one that shares
+                                                // the GPU with other streams' kernels; running out is loud (NaN losses, status word) and the
+                                                // host side then takes the two-launch form, whose every wait is for an EARLIER workgroup
+// bits of the `flags` argument of bxi_boxinst_eval_f32 (include/boxinst_hip.h: BXI_EVAL_*); per call, no process-wide state
+constexpr unsigned kFlagSingle = 1u, kFlagTwo = 2u, kFlagNoStay = 4u, kFlagRows8 = 8u, kFlagShared = 16u, kFlagGiveUp = 256u;
 constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
 constexpr int kAcc1Words = 64;                  // count-wave arrivals + sum W: 64 words, each in its own 128 bytes
 constexpr int kMaxInst = 65536;
@@ -123,7 +121,11 @@ struct Ws {
     int n_cb, n_rp;
     int4* tab;                                  // [N+1] {tile prefix | img << 24, r0 | r1 << 16, c0 | c1 << 16, epoch}; [N].x = tiles
     unsigned int* bandflag;                     // [N,n_cb] epoch once a stream block's zero-fill and partial maxima are in memory (single-launch form)
-    unsigned int ep;                            // this evaluation's tag (1 .. 2^28 - 1): data another workgroup of the SAME launch reads carries it
+    unsigned int* epoch;                        // [1] tag of the last evaluation FINISHED on this workspace (0 after the one-time zeroing); only the
+                                                // finisher writes it, as its last act
+    unsigned int ep;                            // this evaluation's tag (1 .. 2^28 - 1) = epoch + 1, read ON THE DEVICE by every kernel (with_tag):
+                                                // data another workgroup of the SAME launch reads carries it.  Nothing about it is a kernel
+                                                // argument, so a captured launch replayed from a hipGraph draws a fresh tag every time
     // words polled inside pair_kernel; zeroed by prep_kernel's table waves, i.e. before a kernel boundary
     unsigned long long* acc1;                   // [kAcc1Words] (one per 128 B) predicate workgroups: segments evaluated << 40 | sum W
     unsigned long long* sumw;                   // [1]   1 << 63 | sum W, published by the reducer wave once every segment is in (0 = not yet)
@@ -134,6 +136,24 @@ struct Ws {
 
 __device__ __forceinline__ unsigned long long* acc2_word(unsigned long long* acc2, int n, int sub) {
     return acc2 + ((size_t)n * kAcc2Split + (sub & (kAcc2Split - 1))) * kAcc2Stride;
+}
+
+// This evaluation's tag: one more than the tag of the last evaluation that FINISHED on this workspace.  Every kernel of an evaluation
+// reads the word when its waves start; only the finisher -- the last workgroup, which has by then seen every other wave of the
+// launch arrive (each tile wave arrives exactly once, with or without tiles) -- writes it.  Evaluations that share a workspace are
+// serialised by their stream, so the word is stable while anybody reads it.
+__device__ __forceinline__ unsigned int next_tag(unsigned int e) { const unsigned int t = (e + 1u) & 0x0fffffffu; return t ? t : 1u; }
+__device__ __forceinline__ Ws with_tag(Ws ws) {
+    ws.ep = next_tag((unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ws.epoch, BXI_RLX, BXI_AGENT)));
+    return ws;
+}
+// min(_iter / pairwise_warmup, 1) (condinst_head.py:1330-1331).  warmup >= 0: the caller's value.  warmup < 0: -warmup is
+// pairwise_warmup and the factor comes from the device counter as it stands after this call's `self._iter += 1` (:1297; the finisher
+// adds the 1 at the very end, behind every reader): a float32 add, then Python's double division, then the f32 operand of the multiply.
+__device__ __forceinline__ float resolve_warmup(float warmup, const float* iter) {
+    if (warmup >= 0.f) return warmup;
+    const float it = __fadd_rn(__hip_atomic_load(iter, BXI_RLX, BXI_AGENT), 1.0f);
+    return (float)fmin((double)it / (double)(-warmup), 1.0);
 }
 
 static inline int tile_width(int dil) { return 64 - 2 * dil; }
@@ -165,6 +185,7 @@ static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
     t.acc2 = (unsigned long long*)take(8 * (size_t)N1 * kAcc2Split * kAcc2Stride);
     t.dice = (unsigned long long*)take(8 * (size_t)N1);
     t.fault = (unsigned int*)take(4);
+    t.epoch = (unsigned int*)take(4);
     if (ws) *ws = t;
     return off;
 }
@@ -491,9 +512,10 @@ __device__ __forceinline__ void pool_block(const PoolArgs& pa, const Ws& ws, int
 }
 
 // grid: [table blocks][pool blocks][stream blocks] (pool_first) or [table][stream][pool]
-__global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, Ws ws, LossState st,
+__global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, Ws ws_in, LossState st,
                                                        float* __restrict__ g_logits, int vec, int pool_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Ws ws = with_tag(ws_in);
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
     const int Sn = (a.h + kSBlk - 1) / kSBlk;
     const int n_stream = a.N * Sn;
@@ -529,10 +551,11 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, i
 // A head tile does the stream role's job on the tile it just produced: zero-filled gradient tile (written through), per-row and
 // per-column (value, first index) maxima as partials for the leaders.  Nothing in the launch waits for anything else in it.
 template <int C, bool REL>
-__global__ __launch_bounds__(256, 7) void head_prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, Ws ws, LossState st,
+__global__ __launch_bounds__(256, 7) void head_prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, Ws ws_in, LossState st,
                                                             float* __restrict__ g_logits, DynArgs da, const float* __restrict__ params,
                                                             float* __restrict__ logits_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Ws ws = with_tag(ws_in);
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
     const int blk = (int)blockIdx.x;
     const int tix = blk * kWaves + (int)(threadIdx.x >> 6);
@@ -561,7 +584,9 @@ __global__ __launch_bounds__(256, 7) void head_prep_kernel(PoolArgs pa, int n_po
 
 // ---- the image side for strides other than 4 / unaligned canvases: launches of their own (pool_rgb_generic of
 // color_affinity.hip -> Lab planes, then this repacking) -----------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_lab4_kernel(const float* __restrict__ lab, float4* __restrict__ lab4, unsigned int ep, int B, int64_t P) {
+__global__ __launch_bounds__(256) void pack_lab4_kernel(const float* __restrict__ lab, float4* __restrict__ lab4, const unsigned int* __restrict__ epoch, int B,
+                                                         int64_t P) {
+    const unsigned int ep = next_tag(*epoch);          // as with_tag: the evaluation's tag is device state, never a kernel argument
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * P; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / P, p = i - b * P;
         const float* src = lab + b * 3 * P + p;
@@ -865,7 +890,7 @@ __device__ __forceinline__ bool pred_words(const Ws& ws, const Tile& t, int h, i
 template <int D, int R, bool ONE>
 __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float upw_warm, float n2max, int zero_bit, int n_items,
                                           int spin_limit, float& scale, bool& have_scale, float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
-                                          int tix) {
+                                          int tix, long long& fx_sum, bool& bad_out) {
     constexpr int RD = TG<D, R>::RD;
     const int lane = threadIdx.x & 63;
     const int h = a.h, w = a.w, n = t.n;
@@ -955,7 +980,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     }
     BXI_TW(1, tix, 5);
     num = wave_total_f32(num);
-    const long long fx = (long long)(num * kNumScale) + (1ll << 24);           // + 1.0: keeps the packed field non-negative
+    fx_sum += (long long)(num * kNumScale);                                    // this tile's share of sum W pw, fixed point: integer adds commute
     // single-launch form: the rows this tile adds onto were zero-filled by stream workgroups of THIS launch; their band flags are
     // asked for in the same round as sum W
     const int band0 = t.tile_r0 / kSBlk, band1 = (min(t.tile_r0 + R, h) - 1) / kSBlk;
@@ -991,11 +1016,17 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
         }
     }
     BXI_TW(1, tix, 6);
-    // this tile's share of sum W pw + its arrival: one atomic without return; the wave does not wait for it
-    if (lane == 0)
-        __hip_atomic_fetch_add(acc2_word(ws.acc2, n, t.tile_r0 / R + t.tile_c0 / TG<D, R>::TW),
-                               (1ull << 52) + (unsigned long long)fx + (bad ? kArrivalFault : 0ull), BXI_RLX, BXI_AGENT);
-    BXI_TW(1, tix, 7);
+    bad_out |= bad;
+}
+
+// A tile wave's ONE arrival, with or without tiles: its share of sum W pw (+ 1.0: keeps the packed field non-negative -- S may exceed 1 by
+// a rounding) and whether one of its bounded waits ran out, as one atomic without return on one of the N x 8 arrival words (each in its
+// own 128 bytes).  The finisher counts WAVES, so its last act -- advancing the workspace's epoch -- comes after every tile wave of
+// the launch has read the epoch (an idle wave that started late could otherwise draw the NEXT evaluation's tag and wait for nobody).
+__device__ __forceinline__ void tile_wave_arrives(const Ws& ws, int N, int wid, long long fx_sum, bool bad) {
+    if ((threadIdx.x & 63) == 0)
+        __hip_atomic_fetch_add(ws.acc2 + (size_t)(wid % (N * kAcc2Split)) * kAcc2Stride,
+                               (1ull << 52) + (unsigned long long)(fx_sum + (1ll << 24)) + (bad ? kArrivalFault : 0ull), BXI_RLX, BXI_AGENT);
 }
 
 __device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
@@ -1218,14 +1249,14 @@ __device__ __forceinline__ void reducer_role(const Ws& ws, int zero_bit, int n_i
 // the tile waves -- and writes the two loss values
 template <bool ONE>
 __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, const LossState& st, float upp, float upw, float warmup, int zero_bit, int n_items,
-                                              int spin_limit, int R, float* __restrict__ losses) {
+                                              int spin_limit, int R, int n_tile_waves, float* __restrict__ losses) {
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int N = a.N;
     BXI_TW(3, 0, 0);
     __shared__ double fin_d[kWaves];
     __shared__ int fin_i[kWaves];
     __shared__ float fin_f;
-    __shared__ int fin_ok, fin_tiles, fin_flt, fin_b[kWaves];
+    __shared__ int fin_ok, fin_flt, fin_b[kWaves];
     bool ok = true, flt0 = false;
     double total_w = 0.0;
     float dsum = 0.f;
@@ -1233,8 +1264,6 @@ __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, c
     if (spin_limit < 0) ok = false;
     if (wave == 0) {
         if (!table_complete<ONE>(ws, N, spin_limit)) ok = false;      // every polled word of this evaluation is zeroed from here on
-        int4 eN = make_int4(0, 0, 0, 0);
-        if (ok && !tab_entry<ONE>(ws, N, true, spin_limit, eN)) ok = false;
         for (int b0 = 0; b0 < N && ok; b0 += 64) {
             while (!dice_round(ws, N, b0, &dsum, &flt0)) {
                 if (++spins > spin_limit) { ok = false; break; }
@@ -1247,11 +1276,10 @@ __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, c
                 if (++spins > spin_limit) ok = false;
                 __builtin_amdgcn_s_sleep(8);
             }
-        if (lane == 0) { fin_f = dsum; fin_d[0] = total_w; fin_ok = ok ? 1 : 0; fin_tiles = eN.x; fin_flt = flt0 ? 1 : 0; }
+        if (lane == 0) { fin_f = dsum; fin_d[0] = total_w; fin_ok = ok ? 1 : 0; fin_flt = flt0 ? 1 : 0; }
     }
     __syncthreads();
     ok = fin_ok != 0; dsum = fin_f; total_w = fin_d[0];
-    const int ntiles = fin_tiles;
     __syncthreads();
     // every thread watches its own arrival words (N * 8 / 256 each: one at the headline size); the launch ends on this loop
     long long mine = 0;
@@ -1273,7 +1301,7 @@ __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, c
         const bool anyflt = __any(flt);
         if (lane == 0) { fin_i[wave] = arrived; fin_b[wave] = anyflt ? 1 : 0; }
         __syncthreads();
-        const bool all = (fin_i[0] + fin_i[1]) + (fin_i[2] + fin_i[3]) == ntiles;
+        const bool all = (fin_i[0] + fin_i[1]) + (fin_i[2] + fin_i[3]) == n_tile_waves;    // every tile wave arrives once, tiles or not
         if ((fin_b[0] | fin_b[1]) | (fin_b[2] | fin_b[3])) fault_seen |= kFaultCounts;
         __syncthreads();
         if (all) break;
@@ -1291,9 +1319,11 @@ __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, c
         float l1 = (float)((num / (double)kNumScale) / (double)denom) * warmup;   // :1327-1332
         if (status) { l0 = __int_as_float(0x7fc00000); l1 = l0; }            // loud: mmdet's CheckInvalidLossHook fires
         losses[0] = l0; losses[1] = l1;
-        if (st.scale) { *st.scale = warmup / denom; st.applied[0] = upp; st.applied[1] = upw; }
+        if (st.scale) { st.scale[0] = warmup / denom; st.scale[1] = warmup; st.applied[0] = upp; st.applied[1] = upw; }   // [1]: the warm-up factor applied
         if (st.status) { st.status[0] = (int)status; if (ONE) st.status[1] = R; }
         if (st.iter) atomicAdd(st.iter, 1.0f);                               // self._iter += 1, condinst_head.py:1297
+        // the evaluation is over: every other wave of it has been seen to arrive, so nobody reads the epoch any more
+        __hip_atomic_store(ws.epoch, ws.ep, BXI_RLX, BXI_AGENT);
     }
     BXI_TW(3, 0, 1);
 }
@@ -1310,17 +1340,23 @@ __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& v
     int4 e0, eN = make_int4(0, 0, 0, 0);
     bool ok = tab_entry<ONE>(ws, lane, lane <= N, spin_limit, e0);
     if (N >= 64) ok = ok && tab_entry<ONE>(ws, N, true, spin_limit, eN);
-    if (!ok) { if (lane == 0) atomicOr(ws.fault, kFaultCounts); return; }          // loud: the finisher misses this wave's arrivals too
+    // (a wave whose table wait ran out still arrives, saying so: the finisher then ends at once, loud, instead of running out itself.
+    // The table's own zeroing of the arrival words precedes its entries, so without an entry the arrival may be wiped -- then the finisher
+    // does run out: as loud)
+    if (!ok) { tile_wave_arrives(ws, N, wid, 0, true); return; }
     const int total = N < 64 ? __builtin_amdgcn_readlane(e0.x, N < 64 ? N : 0) : __builtin_amdgcn_readfirstlane(eN.x);
     float* gbuf = reinterpret_cast<float*>(smem) + wave * ((R + 1) * 64);
     float scale = 0.f;
-    bool have_scale = false;
-    for (int ti = wid; ti < total; ti += nwaves) {
+    bool have_scale = false, bad = false;
+    long long fx_sum = 0;
+    for (int ti = wid; ti < total && !bad; ti += nwaves) {
         Tile t;
-        if (!locate_tile<D, R, ONE>(ws, vc, N, e0, ti, a.h, a.w, spin_limit, t)) { if (lane == 0) atomicOr(ws.fault, kFaultCounts); return; }
+        if (!locate_tile<D, R, ONE>(ws, vc, N, e0, ti, a.h, a.w, spin_limit, t)) { bad = true; break; }
         BXI_TW(1, wid, 1);
-        math_tile<D, R, ONE>(a, ws, t, upw_warm, n2max, zero_bit, n_items, spin_limit, scale, have_scale, g_logits, gbuf, wid);
+        math_tile<D, R, ONE>(a, ws, t, upw_warm, n2max, zero_bit, n_items, spin_limit, scale, have_scale, g_logits, gbuf, wid, fx_sum, bad);
     }
+    tile_wave_arrives(ws, N, wid, fx_sum, bad);
+    BXI_TW(1, wid, 7);
 }
 
 // grid: [n_pb predicate blocks][reducer][N leaders][n_tb tile blocks][finisher].  The only waits: a tile wave for the predicate waves
@@ -1330,9 +1366,10 @@ __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& v
 template <int D, int R>
 __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
                                                        float n2max, int zero_bit, int n_pb, int n_items, int spin_limit, ValidCells vc, float* __restrict__ losses,
-                                                       float* __restrict__ g_logits, InstArgs a, Ws ws, LossState st) {
+                                                       float* __restrict__ g_logits, InstArgs a, Ws ws_in, LossState st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[16];
+    const Ws ws = with_tag(ws_in);
     const int blk = (int)blockIdx.x;
     const int N = a.N;
     const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
@@ -1345,9 +1382,10 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair_ker
         BXI_TW(3, 1 + blk - n_pb - 1, 0);
         leader_block<false>(a, D, ws, st, blk - n_pb - 1, upp, g_logits, smem, red, spin_limit);
     } else if (blk == (int)gridDim.x - 1) {
-        finisher_role<false>(a, ws, st, upp, upw, warmup, zero_bit, n_items, spin_limit, R, losses);
+        finisher_role<false>(a, ws, st, upp, upw, resolve_warmup(warmup, st.iter), zero_bit, n_items, spin_limit, R, ((int)gridDim.x - 2 - N - n_pb) * kWaves, losses);
     } else {
-        tile_role<D, R, false>(a, vc, ws, upw * warmup, n2max, zero_bit, n_items, spin_limit, g_logits, smem, blk - N - n_pb - 1, (int)gridDim.x - 2 - N - n_pb);
+        tile_role<D, R, false>(a, vc, ws, upw * resolve_warmup(warmup, st.iter), n2max, zero_bit, n_items, spin_limit, g_logits, smem, blk - N - n_pb - 1,
+                               (int)gridDim.x - 2 - N - n_pb);
     }
 }
 
@@ -1367,12 +1405,13 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair_ker
 // kernel boundary of the two-launch form (~2.2 us) is gone.  The two-launch form stays for 8-row tiles (> 96 instances: 2
 // workgroups per CU would starve the front half), dilation 4, the head-fused first launch and the generic pooling path.
 template <int D>
-__global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_pool, int n_items, int n_pb, int n_tb, InstArgs a, Ws ws, LossState st, ValidCells vc,
+__global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_pool, int n_items, int n_pb, int n_tb, InstArgs a, Ws ws_in, LossState st, ValidCells vc,
                                                         const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup, float n2max, int spin_limit,
                                                         float* __restrict__ losses, float* __restrict__ g_logits, int vec, int merge) {
     constexpr int R = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[16];
+    const Ws ws = with_tag(ws_in);
     const int N = a.N;
     constexpr int n_tab = 0;                                  // (trace index layout: table, stream, pool)
     const int Sn = (a.h + kSBlk - 1) / kSBlk;
@@ -1426,10 +1465,10 @@ __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_
     if (role == 6) { reducer_role<true>(ws, 0, n_items, spin_limit); return; }
     if (role == 4) {          // ONE call site for the stream workgroups that stay on and for the tile workgroups proper
         const int shift = merge ? n_stream : 0;
-        tile_role<D, R, true>(a, vc, ws, upw * warmup, n2max, 0, n_items, spin_limit, g_logits, smem, idx + shift, n_tb + shift);
+        tile_role<D, R, true>(a, vc, ws, upw * resolve_warmup(warmup, st.iter), n2max, 0, n_items, spin_limit, g_logits, smem, idx + shift, n_tb + shift);
         return;
     }
-    finisher_role<true>(a, ws, st, upp, upw, warmup, 0, n_items, spin_limit, R, losses);
+    finisher_role<true>(a, ws, st, upp, upw, resolve_warmup(warmup, st.iter), 0, n_items, spin_limit, R, (n_tb + (merge ? n_stream : 0)) * kWaves, losses);
 }
 
 // ---- rescale: g_logits finished for the factors recorded in `state` -> finished for (g_prj, g_pw) ----------------
@@ -1508,22 +1547,11 @@ static int device_cus() {
 
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
-// true when an evaluation was enqueued on a DIFFERENT stream within the last 2 ms (host clock): evaluations in flight side by side
-static bool other_stream_recently(hipStream_t s) {
-    struct PerDevice { std::atomic<uintptr_t> last_stream{0}; std::atomic<int64_t> last_ns{0}, other_ns{0}; };
-    static PerDevice per_device[64];                  // streams of different devices do not compete for slots
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    std::atomic<uintptr_t>& last_stream = per_device[dev].last_stream;
-    std::atomic<int64_t>&last_ns = per_device[dev].last_ns, &other_ns = per_device[dev].other_ns;
-    timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    const int64_t now = (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
-    const uintptr_t me = reinterpret_cast<uintptr_t>(s) + 1;
-    const uintptr_t prev = last_stream.exchange(me, std::memory_order_relaxed);
-    const int64_t prev_ns = last_ns.exchange(now, std::memory_order_relaxed);
-    if (prev != 0 && prev != me && now - prev_ns < 2000000ll) other_ns.store(now, std::memory_order_relaxed);
-    return now - other_ns.load(std::memory_order_relaxed) < 2000000ll && other_ns.load(std::memory_order_relaxed) != 0;
+// A stream that is being captured into a hipGraph: the launch is recorded, not run; what the host decides here is frozen into the graph
+static bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
 }
 
 // Compute units the stream may use: a CU mask (hipExtStreamCreateWithCUMask, ROC_GLOBAL_CU_MASK) leaves fewer than the device has.
@@ -1592,23 +1620,24 @@ static HostPred host_pred(float thresh) {
 }
 
 template <int D, int R>
-static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, float warmup, float n2max, int zero_bit, int n_pb, int n_items,
+static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, float warmup, float n2max, int zero_bit, int n_pb, int n_items, int spin_limit,
                         const ValidCells& vc, const Ws& ws, const LossState& st, float* losses, float* g_logits, const float* up_prj, const float* up_pw) {
-    const int lim = g_spin_limit.load(std::memory_order_relaxed);
     BXI_LAUNCH("pair", s, (pair_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, up_prj, up_pw, warmup, n2max, zero_bit, n_pb, n_items,
-               lim == 0 ? kSpinLimit : lim, vc,
-               losses, g_logits, a, ws, st);
+               spin_limit, vc, losses, g_logits, a, ws, st);
 }
 
 size_t eval_ws_bytes(int B, int N, int h, int w) { return carve(nullptr, B, N, h, w, nullptr); }
 bool fused_eval_supported(int dil) { return dil >= 1 && dil <= kMaxDilFused; }
-void debug_set_spin_limit(int limit) { g_spin_limit.store(limit, std::memory_order_relaxed); }
-void debug_set_eval_form(int form) { g_form.store(form, std::memory_order_relaxed); }
-int debug_eval_form() { return g_form.load(std::memory_order_relaxed); }
+// the one-time initialisation of a workspace: all zero (epoch 0, no record carries a tag an evaluation will draw)
+int eval_ws_init(void* workspace, size_t bytes, void* stream) {
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
+    if (hipMemsetAsync(workspace, 0, bytes, as_stream(stream)) != hipSuccess) { set_last_hip_error((int)hipGetLastError()); return BXI_ERR_LAUNCH; }
+    return BXI_OK;
+}
 
 // One evaluation, two launches.
 int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bxi_instances* in, int dil, float warmup, const float* up_prj,
-                 const float* up_pw, float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, int force_rows,
+                 const float* up_pw, float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, unsigned flags,
                  void* stream, const DynArgs* head, int head_C) {
     InstArgs a;
     int rc = fill_inst(in, a);
@@ -1622,6 +1651,8 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     if (rc != BXI_OK) return rc;
     if (batch->B > 0 && !batch->imgs) return BXI_ERR_NULL_POINTER;
     if (batch->image_masks) return BXI_ERR_UNSUPPORTED;   // explicit masks: use bxi_color_affinity_f32 + bits
+    if (warmup < 0.f && !in->iter_counter) return BXI_ERR_NULL_POINTER;     // the factor is to come from the device counter
+    if (!(warmup == warmup)) return BXI_ERR_BAD_ARGUMENT;
     if (a.N == 0) {
         BXI_LAUNCH("zero_losses", s, zero_losses2_kernel, dim3(1), dim3(1), 0, s, losses, in->iter_counter);
         return check_launch();
@@ -1634,15 +1665,6 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
     Ws ws;
     carve(workspace, batch->B, a.N, a.h, a.w, &ws);
-    {   // this evaluation's tag: 1 .. 2^28 - 1, different from every recent evaluation's in this process.  (It wraps after 2.7e8
-        // evaluations; a stale record could then only pass for a fresh one if its bytes had not been rewritten by ANY of them --
-        // every evaluation rewrites every record of its shape -- and were read again by a shape that reaches them.)
-        static std::atomic<unsigned int> epoch{0u};
-        unsigned int e = epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;
-        e &= 0x0fffffffu;
-        if (e == 0u) e = (epoch.fetch_add(1u, std::memory_order_relaxed) + 1u) & 0x0fffffffu;
-        ws.ep = e ? e : 1u;
-    }
     LossState st = {};
     if (state) {
         if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
@@ -1654,9 +1676,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     static const int env_rows = env_int("BXI_TILE_ROWS", 0);            // developer knobs
     static const int env_pool_first = env_int("BXI_POOL_FIRST", 0);
     static const int env_pool_wgs = env_int("BXI_POOL_WGS_PER_CU", 5);
-    const int form = g_form.load(std::memory_order_relaxed);
-    if (!force_rows && (form & 8)) force_rows = 8;
-    if (!force_rows) force_rows = env_rows;
+    const int force_rows = (flags & kFlagRows8) ? 8 : env_rows;
     const int R = force_rows == 4 || force_rows == 8 ? force_rows : tile_rows_for(a.N);
     if (eval_cap(a.N, a.h, a.w, dil, R) >= (1 << 24)) return BXI_ERR_BAD_SHAPE;     // the table packs a tile prefix into 24 bits
     const HostPred pr = host_pred(color_thresh);
@@ -1670,8 +1690,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     const int64_t n_items64 = (int64_t)batch->B * a.h * ((a.w + 63) / 64);
     if (n_items64 > 0x7fffffffLL) return BXI_ERR_BAD_SHAPE;
     const int n_items = (int)n_items64;
-    const int lim = g_spin_limit.load(std::memory_order_relaxed);
-    const int spin_limit = lim == 0 ? kSpinLimit : lim;
+    const int spin_limit = (flags & kFlagGiveUp) ? -1 : kSpinLimit;
 
     // ---- the single-launch form ---------------------------------------------------------------------------------------
     static const int env_one = env_int("BXI_ONE_LAUNCH", 1);            // developer knob: 0 = always two launches
@@ -1679,7 +1698,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     // 64 instances, 35.1 vs 33.9 at 96, 45.1 vs 39.4 at 128 (200 x 256 maps) -- hence: stream workgroups <= half the slots.
     const int one_slots = kOneOcc * device_cus();
     const bool one_fits = 2 * (int64_t)a.N * ((a.h + kSBlk - 1) / kSBlk) <= one_slots && stream_cus(s, device_cus()) >= device_cus();
-    if (env_one && !(form & 2) && (one_fits || env_one == 2 || (form & 1)) && !head && pooled_in_launch && R == 4 && dil <= 3 &&
+    if (env_one && !(flags & kFlagTwo) && (one_fits || env_one == 2 || (flags & kFlagSingle)) && !head && pooled_in_launch && R == 4 && dil <= 3 &&
         !pr.zero_bit) {
         static const int env_one_pool = env_int("BXI_ONE_POOL_WGS", 0);
         const int Sn = (a.h + kSBlk - 1) / kSBlk;
@@ -1699,12 +1718,13 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         int64_t n_tb = (eval_cap(a.N, a.h, a.w, dil, R) + kWaves - 1) / kWaves;
         if (n_tb > slots / 2) n_tb = slots / 2;
         // the stream workgroups stay on as the first tile workgroups (only while they leave half of the slots to the rest of the grid)
-        // ... unless evaluations are being enqueued on SEVERAL streams at once: each would hold its stream workgroups' slots while
-        // waiting, and three or four of them leave no room for anybody's pool workgroups (measured: 2.4 ms per evaluation with four
-        // streams in flight, against 10 us without the staying-on).  The host cannot see what else runs on the device, but it does
-        // see its own callers: another stream within the last 2 ms means concurrent evaluations.
+        // ... unless evaluations run on SEVERAL streams at once: each would hold its stream workgroups' slots while waiting, and three
+        // or four of them leave no room for anybody's pool workgroups (measured: 2.4 ms per evaluation with four streams in flight,
+        // against 10 us without the staying-on).  The library cannot see what else runs on the device and does not guess: the CALLER
+        // says so (BXI_EVAL_SHARED_DEVICE / BXI_EVAL_NO_STAY_ON; boxinstseg_amd/functional.py sets it once a second stream has been
+        // seen on the device).  A launch that is being captured into a graph may be replayed next to anything: no staying-on either.
         static const int env_merge = env_int("BXI_ONE_MERGE", 1);
-        const int merge = env_merge && one_fits && !other_stream_recently(s) ? 1 : 0;
+        const int merge = env_merge && one_fits && !(flags & (kFlagNoStay | kFlagShared)) && !stream_is_capturing(s) ? 1 : 0;
         if (merge) n_tb = n_tb > n_stream ? n_tb - n_stream : 0;
         size_t lds = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
         if (lds < 8 * (size_t)kWaves * a.w) lds = 8 * (size_t)kWaves * a.w;
@@ -1733,6 +1753,12 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     const int per = room > 0 ? (n_items + room - 1) / room : 8;
     const int n_pool = pooled_in_launch ? (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per) : 0;
     size_t lds1 = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
+    // every refusal comes BEFORE the first launch: a refused call has enqueued nothing (callers fall back to other entry points)
+    size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
+    const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
+    if (lds2 < lds_leader) lds2 = lds_leader;
+    if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
+    if (head && head_C != 8 && head_C != 16) return BXI_ERR_UNSUPPORTED;
     if (head) {
         // the head-fused first launch (factor 2, vector rows): tables, pool blocks, head tiles
         if (head->factor != 2 || !vec || head->H * 2 != a.h || head->W * 2 != a.w || head->N != a.N || head->B != in->B || !pooled_in_launch)
@@ -1767,7 +1793,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         if (rc != BXI_OK) return rc;
         const int64_t BP = (int64_t)batch->B * a.h * a.w;
         BXI_LAUNCH("pack_lab4", s, pack_lab4_kernel, dim3((unsigned)((BP + 255) / 256 > 2048 ? 2048 : (BP + 255) / 256)), dim3(256), 0, s,
-                   (const float*)ws.lab_planar, ws.lab4, ws.ep, batch->B, (int64_t)a.h * a.w);
+                   (const float*)ws.lab_planar, ws.lab4, (const unsigned int*)ws.epoch, batch->B, (int64_t)a.h * a.w);
         rc = check_launch();
         if (rc != BXI_OK) return rc;
     }
@@ -1786,15 +1812,11 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     int n_pb = (n_items + kWaves - 1) / kWaves;
     if (n_pb > slots / 2) n_pb = slots / 2;
     if (n_tb > slots - n_pb) n_tb = slots - n_pb;
-    size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
-    const size_t lds_leader = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
-    if (lds2 < lds_leader) lds2 = lds_leader;
-    if (lds2 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
     const int grid = n_pb + 1 + a.N + (int)n_tb + 1;      // predicate blocks + the reducer + leaders + tile blocks + the finisher
 #define BXI_PAIR_CASE(DD)                                                                                                                  \
     case DD:                                                                                                                               \
-        if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw); \
-        else launch_pair<DD, 8>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, vc, ws, st, losses, g_logits, up_prj, up_pw);        \
+        if (R == 4) launch_pair<DD, 4>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, spin_limit, vc, ws, st, losses, g_logits, up_prj, up_pw); \
+        else launch_pair<DD, 8>(s, grid, lds2, a, warmup, pr.n2max, pr.zero_bit, n_pb, n_items, spin_limit, vc, ws, st, losses, g_logits, up_prj, up_pw);        \
         break;
     switch (dil) {
         BXI_PAIR_CASE(1) BXI_PAIR_CASE(2) BXI_PAIR_CASE(3) BXI_PAIR_CASE(4)

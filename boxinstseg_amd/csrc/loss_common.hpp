@@ -51,7 +51,7 @@ static inline size_t carve_state(void* base, int N, int h, int w, LossState* st)
     float* gcol = (float*)take(sizeof(float) * (size_t)N * w);
     float* grow = (float*)take(sizeof(float) * (size_t)N * h);
     InstRec* inst = (InstRec*)take(32 * (size_t)(N > 0 ? N : 1));
-    float* scale = (float*)take(sizeof(float));
+    float* scale = (float*)take(2 * sizeof(float));     // [0] warmup / max(sum W, 1); [1] the warm-up factor itself (fused_eval.hip)
     float* applied = (float*)take(2 * sizeof(float));
     unsigned long long* colk = (unsigned long long*)take(8 * (size_t)N * w);
     unsigned long long* rowk = (unsigned long long*)take(8 * (size_t)N * h);

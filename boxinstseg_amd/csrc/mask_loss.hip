@@ -825,6 +825,13 @@ size_t bxi_boxinst_loss_state_status_offset(int N, int h, int w) {
     bxi::carve_state(base, N, h, w, &st);
     return (size_t)((char*)st.status - base);
 }
+size_t bxi_boxinst_loss_state_warmup_offset(int N, int h, int w) {
+    if (N < 0 || h <= 0 || w <= 0) return 0;
+    bxi::LossState st;
+    char base[1];
+    bxi::carve_state(base, N, h, w, &st);
+    return (size_t)((char*)(st.scale + 1) - base);
+}
 
 int bxi_boxinst_loss_fwd_bwd_f32(const bxi_instances* inst_host, const uint8_t* affinity, int size, int dilation,
                                  float warmup, float* losses, float* g_logits, void* state, void* workspace,

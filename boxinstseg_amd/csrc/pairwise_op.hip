@@ -540,8 +540,14 @@ __global__ __launch_bounds__(256, BXI_PWB_OCC) void pairwise3_bwd_wide_kernel(co
     // that the tiles an XCD works on at one time are neighbours: the partner terms that reach into the next tile are then lines its
     // own L2 has just fetched -- 19.2 -> 15.7 us at 32 x 200 x 256 (with the plain order a tile's four neighbours run on four other
     // XCDs, and every halo line crosses the fabric again)
-    int t = xcd_swizzle ? (int)((blockIdx.x % 8u) * ((gridDim.x + 7u) / 8u) + blockIdx.x / 8u) : (int)blockIdx.x;
-    if (t >= (int)gridDim.x) return;
+    // The map is a bijection on [0, G) for EVERY grid size G = 8 q + r: XCD x owns q + (x < r) consecutive tiles starting at
+    // x q + min(x, r), and workgroup i (XCD i mod 8, its (i / 8)-th workgroup there) takes the (i / 8)-th of them; i / 8 < q + (x < r)
+    // because i < G.  (Round 3 used x * ceil(G / 8) + i / 8 and skipped tiles whenever G mod 8 != 0.)
+    int t = (int)blockIdx.x;
+    if (xcd_swizzle) {
+        const unsigned x = blockIdx.x % 8u, q = gridDim.x / 8u, r = gridDim.x % 8u;
+        t = (int)(x * q + (x < r ? x : r) + blockIdx.x / 8u);
+    }
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int64_t n = t / tiles_y;

@@ -803,7 +803,11 @@ __global__ __launch_bounds__(256) void bfsE_fill_kernel(int V, int src, int* __r
     }
 }
 
-int debug_eval_form();      // fused_eval.hip: bit 16 = the level walk instead of the Euler tour (tests compare the two)
+// developer hook (include/boxinst_hip_dev.h, bxi_dev_set_tree_level_walk): the level walk instead of the Euler tour / the doubling rounds
+// (tests compare the two); not part of the production ABI
+static std::atomic<int> g_level_walk{0};
+void dev_set_tree_level_walk(int on) { g_level_walk.store(on ? 1 : 0, std::memory_order_relaxed); }
+static inline bool level_walk() { return g_level_walk.load(std::memory_order_relaxed) != 0; }
 
 int launch_bfs_large(const int* tree, int B, int V, int max_adj, int* si, int* sp, int* sc, int* levels, char* ws, hipStream_t s) {
     if (B > 65535) return BXI_ERR_BAD_SHAPE;
@@ -812,7 +816,7 @@ int launch_bfs_large(const int* tree, int B, int V, int max_adj, int* si, int* s
     BXI_LAUNCH("bfs_large_zero", s, bfsL_zero_kernel, gz, dim3(256), 0, s, V, max_adj, sc, ws, stride);
     BXI_LAUNCH("bfs_large_adj", s, bfsL_adj_kernel, gv, dim3(256), 0, s, tree, V, ws, stride);
     BXI_LAUNCH("bfs_large_sort", s, bfsL_sort_kernel, gv, dim3(256), 0, s, V, ws, stride);
-    if (V <= kEulerMaxV && V >= 2 && !(debug_eval_form() & 16)) {
+    if (V <= kEulerMaxV && V >= 2 && !level_walk()) {
         const dim3 ga((unsigned)((4 * (size_t)V + 255) / 256), (unsigned)B);
         // a launch is only guaranteed to see what the PREVIOUS launch wrote: each of a thread's jumps then adds at least the span its target
         // had when the launch began, so a launch multiplies every span by at least kEulerJumps + 1 (by 2^kEulerJumps when it sees its own)
@@ -1198,7 +1202,7 @@ int launch_refine_large(const void* planes2 /* RefinePlaneL[2] layout */, const 
     BXI_LAUNCH("tree_refine_large_clear", s, refineL_clear_kernel, dim3((unsigned)((B * C + 63) / 64)), dim3(64), 0, s, a);
     BXI_LAUNCH("tree_refine_large_stage", s, refineL_stage_kernel, over_nodes, dim3(256), 0, s, a);
     int doubled = 0;
-    if (!(debug_eval_form() & 16)) {
+    if (!level_walk()) {
         const dim3 nodes((unsigned)((V + 255) / 256), (unsigned)B, (unsigned)C);
         int up_rounds = 0;
         while ((1ll << up_rounds) < (long long)V) ++up_rounds;       // the depth is device data; rounds beyond it copy

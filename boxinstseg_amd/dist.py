@@ -72,12 +72,17 @@ def parse_losses(losses: Dict[str, torch.Tensor], sync: bool = True, check_keys:
         keys = list(log_vars.keys())
         if check_keys:
             n, dg = float(len(keys)), float(_key_digest(keys))
-            guard = torch.tensor([n, -n, dg, -dg], device=loss.device, dtype=torch.float64)
+            guard = torch.tensor([n, -n, dg, -dg, 0.0], device=loss.device, dtype=torch.float64)
+            # the host read below is the one sync point of the call: a non-finite total rides along (an evaluation whose bounded
+            # in-kernel wait ran out hands back NaN losses, include/boxinst_hip.h section 3) and is seen by EVERY rank
+            guard[4] = (~torch.isfinite(loss.detach())).to(torch.float64)
             dist.all_reduce(guard, op=dist.ReduceOp.MAX)
             g = guard.tolist()
             assert g[0] == -g[1] == n and g[2] == -g[3] == dg, (
                 f'loss log variables differ across ranks: this rank logs {len(keys)} keys {",".join(keys)}; '
                 f'count range [{-g[1]:.0f}, {g[0]:.0f}]')
+            if g[4] != 0.0:
+                _note_fault('a non-finite loss on some rank')
         packed = torch.stack([log_vars[k].detach().float() for k in keys])
         dist.all_reduce(packed)                                   # one RCCL all-reduce for every logged value
         packed = packed / world
@@ -88,12 +93,31 @@ def parse_losses(losses: Dict[str, torch.Tensor], sync: bool = True, check_keys:
     return loss, log_vars
 
 
+def _note_fault(what: str) -> None:
+    from . import functional
+    functional.note_fault(what)
+
+
+def to_host(log_vars: Dict[str, torch.Tensor]) -> 'OrderedDict[str, float]':
+    """The ``.item()`` of every logged value (what base.py:216-217 does per key) as ONE device-to-host copy.  This is where losses
+    reach the host anyway, so it is also where a faulted evaluation (NaN losses) is noticed: from then on this thread's evaluations
+    take the two-launch form (``functional.note_fault``)."""
+    keys = list(log_vars.keys())
+    if not keys:
+        return OrderedDict()
+    vals = torch.stack([log_vars[k].detach().float().reshape(()) for k in keys]).tolist()
+    out = OrderedDict(zip(keys, vals))
+    if any(v != v or v in (float('inf'), float('-inf')) for k, v in out.items() if k in ('loss_prj', 'loss_pairwise')):
+        _note_fault('non-finite loss_prj / loss_pairwise')
+    return out
+
+
 def exclude_iter_from_ddp_broadcast(model) -> list:
     """Call on the model BEFORE wrapping it in ``DistributedDataParallel``: lists every ``CondInstMaskHead._iter`` buffer in
     ``model._ddp_params_and_buffers_to_ignore``.  DDP's default ``broadcast_buffers=True`` rewrites each buffer in place at the
     start of every forward; ``_iter`` is identical on all ranks by construction (each rank counts its own calls,
-    condinst_head.py:1297), and a rewrite per iteration makes the head re-read it from the device (one host sync per step).
-    Returns the names added."""
+    condinst_head.py:1297), so the broadcast only costs a small collective per iteration (the head keeps no host copy of the
+    counter any more, so a rewrite is harmless).  Optional.  Returns the names added."""
     from .mask_head import CondInstMaskHead
     names = [f'{prefix}._iter' if prefix else '_iter' for prefix, m in model.named_modules() if isinstance(m, CondInstMaskHead)]
     have = list(getattr(model, '_ddp_params_and_buffers_to_ignore', []))

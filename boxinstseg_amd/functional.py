@@ -12,8 +12,10 @@ Reference interfaces mirrored (``condinst_head.py`` = ``mmdet/models/dense_heads
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import threading
+import warnings
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -230,6 +232,8 @@ class _Local(threading.local):
         self.plans: Dict[tuple, _EvalPlan] = {}
         self.workspaces: Dict[tuple, torch.Tensor] = {}
         self.sizes: Dict[tuple, Tuple[int, int]] = {}
+        self.flags = 0                      # BXI_EVAL_* bits every evaluation of this thread is launched with (eval_flags, note_fault)
+        self.forced: Optional[int] = None   # tests: the flags instead of what this module would choose
 
 
 _TLS = _Local()
@@ -250,12 +254,57 @@ def last_eval_status() -> Tuple[int, int]:
 
 def _workspace(dev: torch.device, stream: int, need: int) -> torch.Tensor:
     """One grow-only workspace per (device, stream): evaluations on a stream are serialised, so they can share it; a larger
-    need replaces it (the old buffer goes back to the caching allocator, which keeps it alive for the work already queued)."""
+    need replaces it (the old buffer goes back to the caching allocator, which keeps it alive for the work already queued).
+    ZEROED when it is allocated and never written by the host again -- the C ABI's contract (include/boxinst_hip.h, section 3): the
+    workspace carries the tag counter that tells one evaluation's records from another's."""
     key = (dev.index, stream)
     ws = _TLS.workspaces.get(key)
     if ws is None or ws.numel() < need:
-        ws = _TLS.workspaces[key] = torch.empty(max(need + need // 4, 256), dtype=torch.uint8, device=dev)
+        ws = _TLS.workspaces[key] = torch.zeros(max(need + need // 4, 256), dtype=torch.uint8, device=dev)
+        # A second stream on this device: evaluations may now run side by side, and the library is told so from here on (sticky;
+        # BXI_EVAL_SHARED_DEVICE: no workgroup may hold a slot while it waits for workgroups later in the grid).  The library
+        # itself never guesses what else runs on the device.
+        if sum(1 for k in _TLS.workspaces if k[0] == dev.index) > 1:
+            _TLS.flags |= _lib.EVAL_SHARED_DEVICE
     return ws
+
+
+def eval_launch_flags() -> int:
+    """The ``flags`` argument of the evaluation entry points for this host thread."""
+    return _TLS.flags if _TLS.forced is None else _TLS.forced
+
+
+@contextlib.contextmanager
+def eval_flags(flags: int):
+    """Tests / benchmarks: launch every evaluation of this thread with exactly these ``BXI_EVAL_*`` flags inside the block."""
+    prev, _TLS.forced = _TLS.forced, int(flags)
+    try:
+        yield
+    finally:
+        _TLS.forced = prev
+
+
+def reset_eval_state(drop_workspaces: bool = True) -> None:
+    """Forget this thread's sticky launch flags (and, by default, its workspaces: the next evaluation allocates a zeroed one)."""
+    _TLS.flags = 0
+    if drop_workspaces:
+        _TLS.workspaces.clear()
+    else:
+        for ws in _TLS.workspaces.values():
+            ws.zero_()
+
+
+def note_fault(what: str = '') -> None:
+    """An evaluation reported a non-zero status / non-finite losses (a bounded in-kernel wait ran out -- never expected on a GPU
+    the process has to itself): from now on this thread takes the two-launch form, whose every wait is for a workgroup EARLIER
+    in its grid (progress whatever else occupies the device), and its workspaces are zeroed again as the ABI asks after a fault.
+    Called where losses reach the host anyway (``dist.parse_losses``); never synchronises by itself."""
+    if not (_TLS.flags & _lib.EVAL_TWO_LAUNCHES):
+        warnings.warn('boxinstseg_amd: an evaluation reported a fault%s; taking the two-launch form from here on'
+                      % (f' ({what})' if what else ''), RuntimeWarning, stacklevel=2)
+    _TLS.flags = (_TLS.flags | _lib.EVAL_TWO_LAUNCHES) & ~_lib.EVAL_SINGLE_LAUNCH
+    for ws in _TLS.workspaces.values():
+        ws.zero_()
 
 
 def _sizes(N: int, h: int, w: int, B: int, Hc: int, Wc: int, stride: int) -> Tuple[int, int]:
@@ -370,10 +419,18 @@ class BoxInstMaskLoss(torch.autograd.Function):
         grad = None
         if need_grad:
             grad = buf.as_strided(x.shape, x.stride(), 64 + plan.state_bytes // 4)          # one view, not a slice and a reshape
+        # the warm-up factor: by value, or (warmup_iters given with the counter) evaluated on the device from the counter -- no host
+        # mirror of `_iter`, and right under hipGraph replay.  A re-entrant backward evaluates again with factor 1 and folds the FIRST
+        # evaluation's recorded factor into the upstream gradient (backward()).
+        warm = float(cfg['warmup_factor'])
+        if ctx.calls > 0 and cfg.get('warmup_iters') is not None:
+            warm = 1.0
+        elif it is not None and cfg.get('warmup_iters') is not None:
+            warm = -float(cfg['warmup_iters'])
         args = (plan.batch_ref, plan.inst_ref, int(cfg['pairwise_size']), int(cfg['pairwise_dilation']),
-                float(cfg['pairwise_color_thresh']), float(cfg['warmup_factor']), 0, 0, base,
+                float(cfg['pairwise_color_thresh']), warm, 0, 0, base,
                 base + 256 + plan.state_bytes if need_grad else 0, base + 256 if need_grad else 0,
-                plan.ws_ptr, plan.ws_bytes, stream)
+                plan.ws_ptr, plan.ws_bytes, eval_launch_flags(), stream)
         if torch.cuda.current_device() == dev.index:          # the usual case: no device guard to set up and tear down
             rc = plan.eval(*args)
         else:
@@ -420,7 +477,12 @@ class BoxInstMaskLoss(torch.autograd.Function):
         if ctx.grad is None and ctx.calls == 0:
             raise RuntimeError('BoxInstMaskLoss.backward without a gradient request')
         if ctx.calls > 0:            # re-entrant backward: the first buffer now belongs to autograd
+            first_buf, first_x = ctx.keep[4], ctx.keep[1]
             _, grad, state, plan, keep = BoxInstMaskLoss._evaluate(ctx, True)
+            if ctx.cfg.get('warmup_iters') is not None and ctx.cfg.get('iter_counter') is not None:
+                # evaluated with factor 1 (the counter has moved on): the factor the first evaluation applied is in its state
+                off = 64 + _lib.load().bxi_boxinst_loss_state_warmup_offset(first_x.size(0), first_x.size(2), first_x.size(3)) // 4
+                g_pw = g_pw.to(device=grad.device, dtype=torch.float32) * first_buf[off]
         else:
             grad, state, plan, keep = ctx.grad, ctx.state, ctx.plan, ctx.keep
             ctx.grad = None
@@ -503,8 +565,9 @@ class HeadBoxInstLoss(torch.autograd.Function):
                 plan.batch_ref, plan.inst_ref, feat_c.data_ptr(), Cf, Hs, Ws, params_c.data_ptr(), coors_c.data_ptr(),
                 lvl.data_ptr(), img.data_ptr(), soi.data_ptr(), soi.numel(), int(in_stride), int(factor), int(bool(no_rel)),
                 int(cfg['pairwise_size']), int(cfg['pairwise_dilation']), float(cfg['pairwise_color_thresh']),
-                float(cfg['warmup_factor']), 0, 0, base, base + 256 + plan.state_bytes, base + 256, plan.ws_ptr,
-                plan.ws_bytes, stream))
+                -float(cfg['warmup_iters']) if (cfg.get('iter_counter') is not None and cfg.get('warmup_iters') is not None)
+                else float(cfg['warmup_factor']), 0, 0, base, base + 256 + plan.state_bytes, base + 256, plan.ws_ptr,
+                plan.ws_bytes, eval_launch_flags(), stream))
         losses = buf[:8].view(torch.float32)
         ctx.save_for_backward(feat_c, params_c, coors_c, lvl, img, soi)
         ctx.grad = buf[256 + plan.state_bytes:].view(torch.float32).view(logits.shape)
@@ -534,11 +597,16 @@ class HeadBoxInstLoss(torch.autograd.Function):
             base = again.data_ptr()
             plan.batch.imgs, plan.inst.logits, plan.inst.gt_inds = imgs_k.data_ptr(), logits_k.data_ptr(), gi_k.data_ptr()
             with torch.cuda.device(dev):
+                dev_warm = cfg.get('warmup_iters') is not None and cfg.get('iter_counter') is not None
                 _lib.check('bxi_boxinst_eval_f32', plan.eval(
                     plan.batch_ref, plan.inst_ref, int(cfg['pairwise_size']), int(cfg['pairwise_dilation']),
-                    float(cfg['pairwise_color_thresh']), float(cfg['warmup_factor']), 0, 0, base, base + 256 + plan.state_bytes,
-                    base + 256, plan.ws_ptr, plan.ws_bytes, stream))
+                    float(cfg['pairwise_color_thresh']), 1.0 if dev_warm else float(cfg['warmup_factor']), 0, 0, base,
+                    base + 256 + plan.state_bytes, base + 256, plan.ws_ptr, plan.ws_bytes, eval_launch_flags(), stream))
             grad, state = again[64 + plan.state_bytes // 4:].view(logits_k.shape), base + 256
+            if dev_warm:         # the factor the first evaluation applied (recorded in its state), folded into the upstream gradient
+                first = ctx.keep[3]
+                off = 256 + lib.bxi_boxinst_loss_state_warmup_offset(logits_k.size(0), logits_k.size(2), logits_k.size(3))
+                g_pw = g_pw.to(device=dev, dtype=torch.float32) * first[off:off + 4].view(torch.float32)[0]
         elif grad is None:
             raise RuntimeError('HeadBoxInstLoss.backward without a gradient request')
         ctx.calls += 1
@@ -570,13 +638,15 @@ def boxinst_mask_loss(mask_logits: torch.Tensor, gt_inds: torch.Tensor, gt_bboxe
                       affinity_bits: Optional[torch.Tensor] = None, out_stride: int = 4,
                       bottom_pixels_removed: int = 10, pairwise_size: int = 3, pairwise_dilation: int = 2,
                       pairwise_color_thresh: float = 0.3, warmup_factor: float = 1.0,
-                      iter_counter: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                      iter_counter: Optional[torch.Tensor] = None, warmup_iters: Optional[float] = None) -> Dict[str, torch.Tensor]:
     """The BoxInst branch of ``CondInstMaskHead.loss`` (condinst_head.py:1297-1337) as one call.
 
     Either ``imgs`` + ``img_metas`` (targets are computed on the device from the network input) or
     precomputed ``affinity_bits`` (from :func:`color_affinity`) must be given.
     ``iter_counter`` (images path only): a float32 device scalar the evaluation adds 1 to inside its last launch -- the module's
-    ``self._iter += 1`` (condinst_head.py:1297) without a launch of its own.
+    ``self._iter += 1`` (condinst_head.py:1297) without a launch of its own.  With ``warmup_iters`` (``pairwise_warmup``) the warm-up
+    factor ``min(_iter / warmup_iters, 1)`` (:1330-1331) is evaluated ON THE DEVICE from that counter and ``warmup_factor`` is ignored:
+    no host copy of the counter exists, and a captured hipGraph ramps as the eager loop does.
     Returns ``{'loss_prj', 'loss_pairwise'}`` attached to the autograd graph of ``mask_logits``.
     Built for ``pairwise_size == 3`` and ``pairwise_dilation <= 4`` (``fused_supported``); other windows are
     composed from the op-level kernels by ``CondInstMaskHead._composed_loss``.
@@ -595,6 +665,12 @@ def boxinst_mask_loss(mask_logits: torch.Tensor, gt_inds: torch.Tensor, gt_bboxe
         if iter_counter.dtype != torch.float32 or iter_counter.device != mask_logits.device or iter_counter.numel() != 1:
             raise RuntimeError('iter_counter must be one float32 on the device of mask_logits')
         cfg['iter_counter'] = iter_counter
+        if warmup_iters is not None:
+            if not float(warmup_iters) > 0:
+                raise RuntimeError('warmup_iters must be positive')
+            cfg['warmup_iters'] = float(warmup_iters)
+    elif warmup_iters is not None:
+        raise RuntimeError('warmup_iters needs iter_counter (the factor is evaluated from the device counter)')
     loss_prj, loss_pw = BoxInstMaskLoss.apply(mask_logits, imgs, img_metas, gt_inds, list(gt_bboxes), cfg,
                                               affinity_bits)
     return {'loss_prj': loss_prj, 'loss_pairwise': loss_pw}

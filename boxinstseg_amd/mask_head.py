@@ -92,11 +92,9 @@ class CondInstMaskHead(nn.Module):
 
         self.register_buffer('sizes_of_interest', torch.tensor(list(sizes_of_interest)))
         self.register_buffer('_iter', torch.zeros([1]))
-        # DistributedDataParallel(broadcast_buffers=True) rewrites every buffer in place at the start of each forward; _iter is the
-        # same on every rank by construction (every rank counts its own calls), and a rewrite per iteration would invalidate the
-        # host mirror below (one sync per step).  boxinstseg_amd.dist.exclude_iter_from_ddp_broadcast(model) lists it in the
-        # wrapped model's _ddp_params_and_buffers_to_ignore (DDP reads that attribute from the module it wraps).
-        self._iter_host: Optional[float] = 0.0     # mirror of _iter; None = unknown (state dict loaded)
+        # `_iter` lives on the device only: the loss evaluation adds the 1 (condinst_head.py:1297) in its last launch and evaluates
+        # the warm-up factor (:1330-1331) from it in the kernels -- no `.item()` per iteration (the reference's sync), no host copy
+        # to keep in step with load_state_dict / DDP buffer broadcasts / fill_().
         self.param_conv = nn.Conv2d(bbox_head_channels, self.num_gen_params, 3, stride=1, padding=1)
         self.init_weights()
 
@@ -109,39 +107,16 @@ class CondInstMaskHead(nn.Module):
             if self.param_conv.bias is not None:
                 nn.init.constant_(self.param_conv.bias, cfg.get('bias', 0))
 
-    def _load_from_state_dict(self, *args, **kwargs):
-        super()._load_from_state_dict(*args, **kwargs)
-        self._iter_host = None       # re-read from the buffer on the next loss() call (one sync)
-
     def set_iter(self, value: float) -> None:
-        """Set the iteration counter (buffer and host mirror together), e.g. when resuming by hand."""
+        """Set the iteration counter, e.g. when resuming by hand (``load_state_dict`` restores it like any buffer)."""
         self._iter.fill_(float(value))
-        self._iter_host = float(value)
-        self._iter_seen = (self._iter._version, self._iter.data_ptr())
 
-    def _tick(self, in_evaluation: bool = False) -> float:
-        """``self._iter += 1`` (condinst_head.py:1297) and the warm-up factor (:1330-1331), sync-free.
-
-        The host mirror is trusted only while nobody else wrote the buffer: any in-place write (``fill_``, ``copy_``, a DDP
-        buffer broadcast, ``load_state_dict``) bumps the tensor's version counter, a replaced buffer (``.to()``) changes its
-        storage -- either is noticed here without a synchronisation, and the value is re-read once.
-
-        ``in_evaluation``: the caller hands ``self._iter`` to the loss evaluation, whose last launch adds the 1 (``iter_counter``
-        of ``bxi_instances``; stream-ordered like the ``+=`` it replaces, and it does not touch the version counter) -- a 9 us
-        launch of its own otherwise."""
-        it = self._iter                                   # (a buffer: every `self._iter` goes through Module.__getattr__)
-        try:
-            seen = (it._version, it.data_ptr())
-        except RuntimeError:                              # an inference-mode tensor has no version counter: never trust the mirror
-            seen = None
-        if self._iter_host is None or seen is None or getattr(self, '_iter_seen', None) != seen:
-            self._iter_host = float(it.item())
-        if not in_evaluation:
-            it += 1
-            seen = (it._version, seen[1]) if seen is not None else None
-        self._iter_host += 1.0
-        self._iter_seen = seen
-        return min(self._iter_host / float(self._warmup_iters), 1.0)
+    def _tick(self) -> float:
+        """``self._iter += 1`` and ``min(self._iter.item() / warmup_iters, 1)`` exactly as the reference (condinst_head.py:1297,
+        1330-1331), host sync included.  Only the paths that do not go through the fused evaluation use it (other window sizes, the
+        fully supervised branch, a counter that is not a float32 scalar on the logits' device)."""
+        self._iter += 1
+        return min(self._iter.item() / float(self._warmup_iters), 1.0)
 
     def _counts_in_evaluation(self, like: torch.Tensor) -> bool:
         it = self._iter
@@ -210,23 +185,22 @@ class CondInstMaskHead(nn.Module):
         if len(gt_bboxes) != imgs.size(0) or len(img_metas) != imgs.size(0):
             raise RuntimeError(f'{imgs.size(0)} images but {len(gt_bboxes)} box lists / {len(img_metas)} img_metas')
         in_eval = self._counts_in_evaluation(feat)
-        warmup = self._tick(in_eval)
         cfg = dict(out_stride=self.out_stride, bottom_pixels_removed=self.bottom_pixels_removed, pairwise_size=self.pairwise_size,
                    pairwise_dilation=self.pairwise_dilation, pairwise_color_thresh=self.pairwise_color_thresh,
-                   warmup_factor=warmup)
-        if in_eval:
+                   warmup_factor=1.0 if in_eval else self._tick())
+        if in_eval:          # counted and ramped on the device
             cfg['iter_counter'] = self._iter
+            cfg['warmup_iters'] = float(self._warmup_iters)
         try:
             logits, loss_prj, loss_pw = F_hip.HeadBoxInstLoss.apply(
                 feat, params, coors, level_inds, img_inds, self.sizes_of_interest, (self.in_stride, factor, self.disable_rel_coors),
                 imgs, img_metas, gt_inds, gt_bboxes, cfg)
         except _lib.BoxInstHipError as e:
             if e.status != _lib.BXI_ERR_UNSUPPORTED:
-                self._iter_host = None
                 raise
             # a configuration the fused launch is not built for after all (e.g. an image tensor that is not 16-byte aligned):
-            # the two calls, as documented; the iteration has been counted once already
-            # (nothing has been launched by the refused call, so the evaluation below is still the one that adds the 1)
+            # the two calls, as documented.  The library refuses BEFORE its first launch, so nothing has been enqueued or counted:
+            # the evaluation below is the one that adds the 1 (a host-side _tick() above has counted already and is not repeated).
             logits = self(feat, params, coors, level_inds, img_inds)
             losses = F_hip.boxinst_mask_loss(logits, gt_inds, gt_bboxes, imgs=imgs, img_metas=img_metas, **cfg)
             return logits, losses
@@ -360,15 +334,12 @@ class CondInstMaskHead(nn.Module):
                                'boxinstseg_amd has no CPU loss path')
         if self.boxinst_enabled and F_hip.fused_supported(self.pairwise_size, self.pairwise_dilation):
             in_eval = self._counts_in_evaluation(mask_logits)
-            try:
-                return F_hip.boxinst_mask_loss(
-                    mask_logits, gt_inds, gt_bboxes, imgs=imgs, img_metas=img_metas, out_stride=self.out_stride,
-                    bottom_pixels_removed=self.bottom_pixels_removed, pairwise_size=self.pairwise_size,
-                    pairwise_dilation=self.pairwise_dilation, pairwise_color_thresh=self.pairwise_color_thresh,
-                    warmup_factor=self._tick(in_eval), iter_counter=self._iter if in_eval else None)
-            except BaseException:
-                self._iter_host = None          # a refused call may not have counted: re-read the buffer next time
-                raise
+            return F_hip.boxinst_mask_loss(
+                mask_logits, gt_inds, gt_bboxes, imgs=imgs, img_metas=img_metas, out_stride=self.out_stride,
+                bottom_pixels_removed=self.bottom_pixels_removed, pairwise_size=self.pairwise_size,
+                pairwise_dilation=self.pairwise_dilation, pairwise_color_thresh=self.pairwise_color_thresh,
+                warmup_factor=1.0 if in_eval else self._tick(), iter_counter=self._iter if in_eval else None,
+                warmup_iters=float(self._warmup_iters) if in_eval else None)
         warmup = self._tick()
         if not self.boxinst_enabled:
             return {'loss_mask': self._supervised_loss(mask_logits, gt_inds, gt_masks)}

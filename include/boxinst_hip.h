@@ -14,11 +14,16 @@
  *   - every pointer is a DEVICE pointer owned by the caller unless its name ends in `_host`.
  *   - allocation-free: outputs and workspace are supplied by the caller (size from *_workspace_bytes).
  *   - asynchronous: work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
- *     null stream); no host synchronisation, no hidden copies; safe under hipGraph capture.
+ *     null stream); no host synchronisation, no hidden copies.  hipGraph capture: every entry point may be
+ *     captured and the graph replayed with the CONTENTS of its buffers changed between replays -- nothing a
+ *     replay must renew is a kernel argument (the evaluation's per-call tag lives in its workspace, section 3;
+ *     a warm-up factor that changes per replay is read from `iter_counter`: pass warmup < 0).
  *   - return value: BXI_OK (0) or a negative bxi_status; never throws.  The reference reports the
  *     same conditions by TORCH_CHECK / AT_CUDA_CHECK (pairwise.cu:7-13,173,200); the Python
  *     shim turns a non-zero status into RuntimeError.
- *   - re-entrant, no global mutable state; one host thread per device is the expected use.
+ *   - re-entrant, no process-wide mutable state: what varies is an argument (`flags` of the evaluation).  The few
+ *     developer hooks (launch bracketing for benchmarks, a test switch of the tree filter) are declared in
+ *     boxinst_hip_dev.h, not here.  One host thread per device is the expected use.
  *   - tensors are dense, row-major (NCHW like the reference), fp32 unless the name says _f64.
  */
 #ifndef BOXINST_HIP_H
@@ -31,7 +36,7 @@
 extern "C" {
 #endif
 
-#define BXI_ABI_VERSION 4
+#define BXI_ABI_VERSION 5
 #define BXI_MAX_IMAGES 64   /* images per call (per-image metadata travels in kernel arguments) */
 
 typedef enum bxi_status {
@@ -51,13 +56,6 @@ const char* bxi_status_string(int status);
 int bxi_last_hip_error(void);
 /* 0 if device `ordinal` exists and is gfx950, BXI_ERR_NO_DEVICE otherwise. */
 int bxi_check_device(int ordinal);
-
-/* Measurement aid (bench.py): `hook(kernel_name, phase, stream, user)` is called on the host right
- * before (phase 0) and right after (phase 1) each kernel launch this library enqueues, so the caller
- * can bracket individual kernels with hipEvents on the launching stream.  NULL removes the hook.
- * Process-wide; set it only while no other thread is inside the library. */
-typedef void (*bxi_launch_hook)(const char* kernel_name, int phase, void* stream, void* user);
-void bxi_set_launch_hook(bxi_launch_hook hook, void* user);
 
 /* ===========================================================================================
  * 1. Op level -- replaces the pybind11 module `pairwise_ext` (bind.cpp:15-36)
@@ -156,6 +154,9 @@ size_t bxi_boxinst_loss_workspace_bytes(int N, int h, int w);
 size_t bxi_boxinst_loss_state_bytes(int N, int h, int w);
 /* byte offset, inside `state`, of two int32: {status (0 = fine; see bxi_boxinst_eval_f32), tile rows used}. */
 size_t bxi_boxinst_loss_state_status_offset(int N, int h, int w);
+/* byte offset, inside `state`, of one float: the warm-up factor bxi_boxinst_eval_f32 applied (given by value, or evaluated on the
+ * device from iter_counter) -- what a second evaluation of the same iteration has to be given (a re-entrant backward). */
+size_t bxi_boxinst_loss_state_warmup_offset(int N, int h, int w);
 
 /* Forward (+ the bulk of the backward):
  * losses[0] = loss_prj, losses[1] = loss_pairwise (device, f32), complete when the call's work is done.
@@ -197,15 +198,22 @@ int bxi_boxinst_loss_backward_f32(const bxi_instances* inst_host, const float* g
  *   every element written; up_prj / up_pw are DEVICE scalars read by the kernels (no host sync), NULL = 1 -- what
  *   `loss.backward()` seeds the two terms with (mmdet/core/optimizers hooks; a loss scale is known before the forward).
  *   Different factors later: bxi_boxinst_grad_rescale_f32.
- * warmup: min(_iter / pairwise_warmup, 1) (:1330-1331), evaluated on the host by the caller.
+ * warmup >= 0: min(_iter / pairwise_warmup, 1) (:1330-1331), evaluated on the host by the caller.
+ * warmup <  0: -warmup is pairwise_warmup and the factor is evaluated ON THE DEVICE from inst_host->iter_counter (required then)
+ *   as it stands after this call's `_iter += 1` (:1297): (float)min((double)(iter + 1.0f) / pairwise_warmup, 1.0) -- Python's
+ *   arithmetic at :1330-1331.  No host mirror of the counter, and a captured graph ramps correctly.
+ * flags: BXI_EVAL_* below, 0 = the library chooses.
  * state (bxi_boxinst_loss_state_bytes, 256-B aligned; required with g_logits): arg-max positions, unit projection
  *   gradients, box rectangles, normaliser, the factors applied, and a status word.  Status 0 = fine.  Non-zero = one of the
  *   bounded in-kernel waits ran out (tile waves wait for the predicate waves that precede them in the grid, the
  *   finisher for everybody; neither is expected to): BOTH LOSSES ARE NaN then (the reference surfaces launch failures through
  *   AT_CUDA_CHECK, pairwise.cu:173,200; here mmdet's CheckInvalidLossHook fires), and bxi_boxinst_grad_rescale_f32 poisons the
  *   gradient.
- * workspace (bxi_boxinst_eval_workspace_bytes, 256-B aligned): scratch incl. Lab; contents undefined after; every word
- *   the second launch polls is zeroed by the first, so no initialisation is required.  One evaluation per workspace in flight.
+ * workspace (bxi_boxinst_eval_workspace_bytes, 256-B aligned): scratch incl. Lab.  ZERO IT ONCE after allocating it
+ *   (bxi_boxinst_eval_workspace_init, or any memset ordered before the first evaluation) and never write to it again: it carries the
+ *   tag counter ("epoch") that tells this evaluation's records from earlier ones', advanced on the device by each evaluation's last
+ *   workgroup.  It may be shared by evaluations of any shapes as long as they are serialised (one stream); evaluations that may
+ *   overlap (several streams) need a workspace each.  After an evaluation that reported a non-zero status, zero it again.
  * batch_host->image_masks must be NULL (explicit masks: bxi_color_affinity_f32 + bxi_boxinst_loss_fwd_bwd_f32).
  * size == 3 and dilation <= 4 are built; others return BXI_ERR_UNSUPPORTED and the host composes section 1 + torch ops
  * as the reference does.  N == 0 writes two zeros (documented deviation; the reference yields NaN).
@@ -214,11 +222,28 @@ size_t bxi_boxinst_eval_workspace_bytes(int B, int Hc, int Wc, int stride, int N
 /* byte offset, inside `workspace`, of the Lab image the evaluation leaves behind: [B, Hc/stride, Wc/stride] x float4 (L, a, b, 0)
  * -- what skimage.color.rgb2lab gives at condinst_head.py:1413-1416; exposed so that tests can compare it with scikit-image. */
 size_t bxi_boxinst_eval_workspace_lab_offset(void);
+/* hipMemsetAsync(workspace, 0, workspace_bytes) on `stream`: the one-time initialisation described above. */
+int bxi_boxinst_eval_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
+/* `flags` of the two evaluation entry points.  The forms give the same bits (tests run them against each other). */
+#define BXI_EVAL_SINGLE_LAUNCH   1u   /* the single-launch form wherever it is built (stride-4 aligned canvases, dilation <= 3, threshold
+                                         > 0), also where the library would not choose it (its stream workgroups, instances x ceil(h / 32),
+                                         fill more than half the GPU)                                                                    */
+#define BXI_EVAL_TWO_LAUNCHES    2u   /* always the two-launch form: every in-kernel wait is for a workgroup EARLIER in its grid, so it
+                                         makes progress whatever else occupies the device; the host side switches to it after an
+                                         evaluation that reported a non-zero status                                                      */
+#define BXI_EVAL_NO_STAY_ON      4u   /* single launch without the stream workgroups staying on as tile workgroups                      */
+#define BXI_EVAL_TILE_ROWS_8     8u   /* 8-row tiles (two launches; the default is 4-row tiles)                                         */
+#define BXI_EVAL_SHARED_DEVICE  16u   /* other work (evaluations on other streams, collectives, other processes) may run on the device
+                                         at the same time: nothing in the launch may hold execution slots while it waits for workgroups
+                                         that come later in the grid (implies NO_STAY_ON).  The library does not guess this              */
+#define BXI_EVAL_WAITS_GIVE_UP 256u   /* TEST ONLY: every bounded in-kernel wait gives up at once, which makes the failure path
+                                         observable (NaN losses, status word, poisoned gradient); zero the workspace afterwards          */
+#define BXI_EVAL_ALL_FLAGS (1u | 2u | 4u | 8u | 16u | 256u)
 int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host,
                          int size, int dilation, float color_thresh, float warmup,
                          const float* up_prj, const float* up_pw,
                          float* losses, float* g_logits, void* state,
-                         void* workspace, size_t workspace_bytes, void* stream);
+                         void* workspace, size_t workspace_bytes, unsigned int flags, void* stream);
 
 /* The same evaluation with the producer of the logits inside its first launch: replaces
  * CondInstMaskHead.forward (condinst_head.py:1139-1164) followed by CondInstMaskHead.loss (:1288-1343), the two calls
@@ -236,18 +261,7 @@ int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_insta
                               int in_stride, int factor, int disable_rel_coors,
                               int size, int dilation, float color_thresh, float warmup,
                               const float* up_prj, const float* up_pw, float* losses, float* g_logits, void* state,
-                              void* workspace, size_t workspace_bytes, void* stream);
-
-/* Test hook: the poll budget of the evaluation's bounded in-kernel waits.  0 = the built-in budget (far beyond any launch);
- * negative = every bounded wait gives up at once, which makes the failure path observable: NaN losses, status word, and a
- * gradient poisoned by bxi_boxinst_grad_rescale_f32.  Process-wide; not for production use. */
-void bxi_debug_set_spin_limit(int limit);
-/* Test hook: which form of the evaluation bxi_boxinst_eval_f32 launches.  Bits: 0 = the library chooses (the single-launch form where
- * it is built -- stride-4 aligned canvases, dilation <= 3, threshold > 0 -- and pays: its stream workgroups, instances x ceil(h / 32),
- * fill at most half the GPU); 1 = the single-launch form wherever it is built; 2 = always the two-launch form; 8 = 8-row tiles
- * (two launches; the default is 4-row tiles); 16 = bxi_bfs_forward_i32 walks large trees level by level instead of ranking their
- * Euler tour.  The forms give the same bits (tests run them against each other).  Process-wide; not for production use. */
-void bxi_debug_set_eval_form(int form);
+                              void* workspace, size_t workspace_bytes, unsigned int flags, void* stream);
 
 /* g_logits finished by bxi_boxinst_eval_f32 for the factors recorded in `state`  ->  finished for (g_prj, g_pw)
  * (DEVICE scalars: the upstream gradients autograd hands over; no host sync).  The kernel returns at once when they

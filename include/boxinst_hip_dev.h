@@ -1,0 +1,27 @@
+/*
+ * boxinst_hip_dev.h -- developer / test hooks of libboxinst_hip.so.  NOT part of the production ABI (include/boxinst_hip.h is
+ * state-free: everything that varies is an argument); these two are process-wide switches for the benchmark harness and the test
+ * suite, kept in atomics, and nothing in boxinstseg_amd/ calls them.
+ */
+#ifndef BOXINST_HIP_DEV_H
+#define BOXINST_HIP_DEV_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Measurement aid (bench.py): `hook(kernel_name, phase, stream, user)` is called on the host right before (phase 0) and right
+ * after (phase 1) each kernel launch the library enqueues, so the caller can bracket individual kernels with hipEvents on the
+ * launching stream -- the reference has no counterpart (its two launches, pairwise.cu:165-173,192-200, are timed from outside).
+ * NULL removes the hook. */
+typedef void (*bxi_launch_hook)(const char* kernel_name, int phase, void* stream, void* user);
+void bxi_dev_set_launch_hook(bxi_launch_hook hook, void* user);
+
+/* Test switch: bxi_bfs_forward_i32 / bxi_tree_refine_* walk large trees level by level (the reference's own order, bfs.cu:46-98,
+ * refine.cu:70-199) instead of ranking their Euler tour / doubling; the two give the same bits and tests compare them. */
+void bxi_dev_set_tree_level_walk(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -41,7 +41,7 @@ def test_loss_vs_reference(dev, name):
     g = load(name)
     head = CondInstMaskHead(in_channels=16, boxinst_enabled=True, max_proposals=-1, topk_per_img=64).to(dev)
     it = round(float(g['warmup']) * 10000) - 1
-    head._iter.fill_(float(it)); head._iter_host = float(it)
+    head._iter.fill_(float(it))
     counts = [int(c) for c in g['gt_count']]
     boxes = [torch.from_numpy(b).to(dev) for b in np.split(g['boxes'], np.cumsum(counts)[:-1])]
     cfg = dict(mean=np.array([123.675, 116.28, 103.53], np.float32), std=np.array([58.395, 57.12, 57.375], np.float32),

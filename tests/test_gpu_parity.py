@@ -105,6 +105,31 @@ def test_pairwise_op_backward_mixed_saturation(dev):
     assert np.abs(xt.grad.cpu().numpy()[:, 0] - want_g).max() <= 2e-5 * max(1.0, np.abs(want_g).max())
 
 
+@pytest.mark.parametrize('shape', [(1, 200, 256), (3, 200, 256), (1, 16, 64), (5, 40, 192), (31, 56, 128)])
+def test_pairwise_op_backward_covers_every_tile(dev, shape):
+    """The f32 size-3 backward deals its 16x64 tiles to the workgroups in an XCD-aware order; the order has to be a bijection for
+    EVERY tile count (round 3's skipped tiles whenever the count was not a multiple of 8: 52 tiles per 200x256 map times an odd
+    N).  The output buffer of the C ABI call is pre-filled with NaN, so a tile nobody wrote cannot pass."""
+    from boxinstseg_amd import _lib
+    from oracle import c_oracle
+    rng = np.random.default_rng(17)
+    x = (rng.standard_normal(shape) * 3).astype(np.float32)
+    want = c_oracle.pairwise_nlog_fwd(x, 3, 2)
+    gp = rng.standard_normal(want.shape).astype(np.float32)
+    want_g = c_oracle.pairwise_nlog_bwd(x, want, gp, 3, 2)
+    xt = torch.from_numpy(x[:, None]).to(dev)
+    pw = torch.from_numpy(want).to(dev)
+    gpt = torch.from_numpy(gp).to(dev)
+    g = torch.full_like(xt, float('nan'))
+    lib = _lib.load()
+    rc = lib.bxi_pairwise_nlog_backward_f32(xt.data_ptr(), pw.data_ptr(), gpt.data_ptr(), shape[0], shape[1], shape[2], 3, 2, g.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    got = g.cpu().numpy()[:, 0]
+    assert np.isfinite(got).all(), 'tiles left unwritten: %d elements' % int((~np.isfinite(got)).sum())
+    assert np.abs(got - want_g).max() <= 2e-5 * max(1.0, np.abs(want_g).max())
+
+
 def test_pairwise_op_errors(dev):
     from boxinstseg_amd import pairwise_nlog, pairwise_nlog_forward
     with pytest.raises(RuntimeError, match='CUDA'):
@@ -273,19 +298,16 @@ def test_deterministic(dev):
 @pytest.fixture(params=[0, 2], ids=['form_auto', 'form_two_launches'])
 def eval_form(request):
     """bxi_boxinst_eval_f32 as the library chooses it (the single launch where it applies) and forced to two launches."""
-    from boxinstseg_amd import _lib
-    lib = _lib.load()
-    lib.bxi_debug_set_eval_form(request.param)
-    yield request.param
-    lib.bxi_debug_set_eval_form(0)
+    from boxinstseg_amd import functional as Fh
+    with Fh.eval_flags(request.param):          # BXI_EVAL_* flags of every evaluation inside the test (per call, no library state)
+        yield request.param
 
 
 def test_single_launch_and_two_launch_forms_agree_bit_for_bit(dev):
     """The evaluation as ONE launch (back-half workgroups waiting, inside the launch, for front-half workgroups that precede them
     in the grid; tagged records) and as two launches (a kernel boundary instead) must give the same bits: integer loss
     accumulators, dice sums in index order, a gradient of at most two float additions onto a zero per element."""
-    from boxinstseg_amd import _lib
-    lib = _lib.load()
+    from boxinstseg_amd import functional as Fh
     cases = [synthetic.cfg1(3), synthetic.cfg2(1),
              synthetic.make_batch(B=3, H=160, W=224, boxes_per_img=3, seed=5, min_box=12, max_box=120, img_shapes=[[150, 200], [160, 224], [121, 183]]),
              synthetic.make_batch(B=1, H=1056, W=96, boxes_per_img=2, seed=6, min_box=16, max_box=90),          # tall: many bands
@@ -294,13 +316,11 @@ def test_single_launch_and_two_launch_forms_agree_bit_for_bit(dev):
     for d in cases:
         for dil in (1, 2, 3):
             res = []
-            for form in (1, 2):              # the single launch wherever it is built / always two launches
-                lib.bxi_debug_set_eval_form(form)
-                try:
+            for form in (1, 1 | 4, 2):       # the single launch wherever it is built (with / without the staying-on) / always two launches
+                with Fh.eval_flags(form):
                     res.append(hip_loss(d, dev, pairwise_dilation=dil))
-                finally:
-                    lib.bxi_debug_set_eval_form(0)
-            a, b = res
+            a, a2, b = res
+            assert a[0] == a2[0] and a[1] == a2[1] and np.array_equal(a[2], a2[2]), dil
             assert a[0] == b[0] and a[1] == b[1], (dil, a[:2], b[:2])
             assert np.array_equal(a[2], b[2]), dil
 
@@ -325,14 +345,14 @@ def test_stream_with_a_cu_mask_takes_the_two_launch_form(dev):
         t = to_dev(d, dev)
         torch.cuda.synchronize()
         Fh.DEBUG_KEEP_LAST = True
-        lib.bxi_set_launch_hook(C.cast(cb, C.c_void_p), None)
+        lib.bxi_dev_set_launch_hook(C.cast(cb, C.c_void_p), None)
         try:
-            with torch.cuda.stream(ext):
+            with torch.cuda.stream(ext), Fh.eval_flags(0):       # (a second stream: this module would say SHARED_DEVICE; here the library's own choice is the test)
                 x = t['logits'].clone().requires_grad_(True)
                 out = boxinst_mask_loss(x, t['gt_inds'], t['gt_bboxes'], imgs=t['imgs'], img_metas=d['img_metas'])
                 (out['loss_prj'] + out['loss_pairwise']).backward()
         finally:
-            lib.bxi_set_launch_hook(None, None)
+            lib.bxi_dev_set_launch_hook(None, None)
         torch.cuda.synchronize()
         assert 'eval1' not in names and 'prep' in names and 'pair' in names, names
         assert Fh.last_eval_status()[0] == 0
@@ -350,11 +370,9 @@ def test_wait_timeouts_are_loud(dev, eval_form):
     gradient is poisoned.  (The reference surfaces launch failures through AT_CUDA_CHECK, pairwise.cu:173,200.)"""
     import math
     from boxinstseg_amd import _lib, boxinst_mask_loss, functional as Fh
-    lib = _lib.load()
     d = synthetic.cfg1(0)
     good = hip_loss(d, dev)
-    lib.bxi_debug_set_spin_limit(-1)
-    try:
+    with Fh.eval_flags(eval_form | _lib.EVAL_WAITS_GIVE_UP):
         Fh.DEBUG_KEEP_LAST = True
         t = to_dev(d, dev)
         x = t['logits'].clone().requires_grad_(True)
@@ -365,8 +383,7 @@ def test_wait_timeouts_are_loud(dev, eval_form):
         status, _ = Fh.last_eval_status()
         assert status != 0
         assert bool(torch.isnan(x.grad).all())
-    finally:
-        lib.bxi_debug_set_spin_limit(0)
+    Fh.reset_eval_state(drop_workspaces=False)                 # the ABI: zero the workspace after a faulted evaluation
     again = hip_loss(d, dev)                                   # and nothing sticks
     assert again[0] == good[0] and again[1] == good[1] and np.array_equal(again[2], good[2])
 
@@ -445,8 +462,7 @@ def test_head_loss_and_targets(dev):
     ref = oracle_path(d, warmup=0.0002)
     t = to_dev(d, dev)
     head = CondInstMaskHead(in_channels=16, boxinst_enabled=True, topk_per_img=64, max_proposals=-1).to(dev)
-    head._iter.fill_(1.0)
-    head._iter_host = None                                    # as after load_state_dict
+    head._iter.fill_(1.0)                                     # the counter is device state only (as after load_state_dict)
     logits = t['logits'].clone().requires_grad_(True)
     out = head.loss(t['imgs'], d['img_metas'], logits, t['gt_inds'], t['gt_bboxes'], None, None)
     assert set(out) == {'loss_prj', 'loss_pairwise'}
@@ -465,30 +481,31 @@ def test_head_loss_and_targets(dev):
 def test_iteration_counter_is_advanced_by_the_evaluation(dev):
     """`self._iter += 1` (condinst_head.py:1297) rides in the evaluation's last launch: the buffer advances by exactly one per loss()
     call in every form of the evaluation (single launch, two launches, no instances, head-fused, no_grad, re-entrant backward counts
-    once), the host mirror follows it without a sync, external writes are noticed, and the launch count of a call drops by one."""
+    once); the warm-up factor is evaluated on the device from it (no host copy), external writes simply count, a re-entrant backward
+    uses the FIRST evaluation's factor although the counter has moved on, and the launch count of a call drops by one."""
     import ctypes as C
-    from boxinstseg_amd import CondInstMaskHead, _lib
+    from boxinstseg_amd import CondInstMaskHead, _lib, functional as Fh
     d = synthetic.cfg1(0)
     t = to_dev(d, dev)
     head = CondInstMaskHead(in_channels=16, boxinst_enabled=True, topk_per_img=64, max_proposals=-1, pairwise_warmup=100).to(dev)
     lib = _lib.load()
     expect = 0.0
     for form in (0, 2):
-        lib.bxi_debug_set_eval_form(form)
-        try:
+        with Fh.eval_flags(form):
             for grad in (True, False):
                 x = t['logits'].clone().requires_grad_(grad)
                 with torch.set_grad_enabled(grad):
                     out = head.loss(t['imgs'], d['img_metas'], x, t['gt_inds'], t['gt_bboxes'], None, None)
                 expect += 1.0
-                assert float(head._iter) == expect and head._iter_host == expect
+                assert float(head._iter) == expect
                 if grad:                                    # two backward passes through one node: still one iteration
                     (out['loss_prj'] + out['loss_pairwise']).backward(retain_graph=True)
-                    (out['loss_prj'] + 2 * out['loss_pairwise']).backward()
+                    g1 = x.grad.clone(); x.grad = None
+                    (out['loss_prj'] + out['loss_pairwise']).backward()
                     assert float(head._iter) == expect
-        finally:
-            lib.bxi_debug_set_eval_form(0)
-    # warm-up factor from the mirror = the reference's min(_iter / warmup, 1) with the incremented value
+                    # the second pass evaluated again, with the counter one further -- and still the first pass's warm-up factor
+                    assert float((x.grad - g1).abs().max()) <= 1e-6 * float(g1.abs().max())
+    # warm-up factor = the reference's min(_iter / warmup, 1) with the incremented value
     x = t['logits'].clone()
     with torch.no_grad():
         a = head.loss(t['imgs'], d['img_metas'], x, t['gt_inds'], t['gt_bboxes'], None, None)
@@ -502,12 +519,13 @@ def test_iteration_counter_is_advanced_by_the_evaluation(dev):
     with torch.no_grad():
         head.loss(t['imgs'], d['img_metas'], x[:0], t['gt_inds'][:0], t['gt_bboxes'], None, None)
     assert float(head._iter) == 702.0
-    # an external in-place write is noticed (version counter), the kernel's own increments are not mistaken for one
+    # an external in-place write simply counts: there is no host copy to fall out of step
     head._iter.fill_(5.0)
     with torch.no_grad():
-        head.loss(t['imgs'], d['img_metas'], x, t['gt_inds'], t['gt_bboxes'], None, None)
-    assert float(head._iter) == 6.0 and head._iter_host == 6.0
-    # a refused call does not leave the mirror ahead of the buffer
+        c = head.loss(t['imgs'], d['img_metas'], x, t['gt_inds'], t['gt_bboxes'], None, None)
+    assert float(head._iter) == 6.0
+    assert rel(float(c['loss_pairwise']), float(b['loss_pairwise']) * 6.0 / 100.0) <= 1e-6
+    # a refused call counts nothing
     with pytest.raises(RuntimeError):
         head.loss(t['imgs'], d['img_metas'], x[:, :, :-1].contiguous(), t['gt_inds'], t['gt_bboxes'], None, None)
     with torch.no_grad():
@@ -516,12 +534,12 @@ def test_iteration_counter_is_advanced_by_the_evaluation(dev):
     # one launch per call at this size, counted through the launch hook
     calls = []
     cb = _lib.LAUNCH_HOOK(lambda name, phase, st, user: calls.append(name))
-    lib.bxi_set_launch_hook(C.cast(cb, C.c_void_p), None)
+    lib.bxi_dev_set_launch_hook(C.cast(cb, C.c_void_p), None)
     try:
         with torch.no_grad():
             head.loss(t['imgs'], d['img_metas'], x, t['gt_inds'], t['gt_bboxes'], None, None)
     finally:
-        lib.bxi_set_launch_hook(None, None)
+        lib.bxi_dev_set_launch_hook(None, None)
     torch.cuda.synchronize()
     assert len(calls) // 2 <= 2 and float(head._iter) == 8.0
 
@@ -565,22 +583,18 @@ def test_loss_many_instances(dev):
     _check_cfg(d, dev)
 
 
-@pytest.mark.parametrize('form', [1, 2, 10], ids=['single_launch', 'two_launches', 'two_launches_8_row_tiles'])
+@pytest.mark.parametrize('form', [1, 5, 2, 10], ids=['single_launch', 'single_launch_no_stay_on', 'two_launches', 'two_launches_8_row_tiles'])
 def test_loss_every_form_against_the_oracle(dev, form):
-    """Each form of the evaluation (bxi_debug_set_eval_form) against the C oracle: the single launch also where the library would not
-    choose it (300 instances: the stream workgroups alone exceed the GPU), two launches, and the 8-row tiles no default takes."""
-    from boxinstseg_amd import _lib
-    lib = _lib.load()
-    lib.bxi_debug_set_eval_form(form)
-    try:
+    """Each form of the evaluation (the BXI_EVAL_* flags of the call) against the C oracle: the single launch also where the library
+    would not choose it (300 instances: the stream workgroups alone exceed the GPU), two launches, and the 8-row tiles no default takes."""
+    from boxinstseg_amd import functional as Fh
+    with Fh.eval_flags(form):
         _check(synthetic.cfg1(4), dev)
         _check_cfg(synthetic.make_batch(B=3, H=64, W=96, boxes_per_img=5, inst_per_box=20, seed=21, min_box=12, max_box=60), dev)
         _check_cfg(synthetic.make_batch(B=2, H=96, W=160, boxes_per_img=3, seed=26, min_box=16, max_box=90), dev, pairwise_dilation=3)
         _check_cfg(synthetic.make_batch(B=1, H=1088, W=1344, boxes_per_img=3, seed=22, min_box=200, max_box=900), dev)
         rows = Fh_status_rows()
         assert rows == (8 if form & 8 else 4)
-    finally:
-        lib.bxi_debug_set_eval_form(0)
 
 
 def test_loss_tall_and_wide_map(dev):
@@ -657,3 +671,195 @@ def test_loss_fuzz(dev, seed):
     assert rel(lw, ref['loss_pairwise']) <= TOL or abs(lw - ref['loss_pairwise']) < 1e-7, (lw, ref['loss_pairwise'])
     err, ties = grad_report(grad, ref['grad'], d['mask_logits'][:, 0])
     assert err <= TOL, f'grad err {err:.3e} ({ties} ambiguous arg-max lines excluded); cfg {B}x{H}x{W} s{stride} {kw}'
+
+
+# ---------------------------------------------------------------------------------------------
+# hipGraph replay, shared devices, fall-back after a fault
+# ---------------------------------------------------------------------------------------------
+def _abi_eval_setup(d, dev, lib, Fh, iter_value):
+    """One evaluation's buffers at the C ABI, all persistent (what a captured graph refers to)."""
+    t = to_dev(d, dev)
+    batch = Fh._Batch(t['imgs'], d['img_metas'], 10)
+    inst = Fh._Inst(t['logits'], t['gt_inds'], t['gt_bboxes'], d['H'], d['W'], d['stride'])
+    N, h, w = inst.N, inst.h, inst.w
+    it = torch.full((1,), float(iter_value), device=dev)
+    inst.struct.iter_counter = it.data_ptr()
+    bufs = dict(t=t, batch=batch, inst=inst, it=it, losses=torch.zeros(2, device=dev), grad=torch.empty_like(inst.logits),
+                state=torch.empty(lib.bxi_boxinst_loss_state_bytes(N, h, w), dtype=torch.uint8, device=dev),
+                ws=torch.zeros(lib.bxi_boxinst_eval_workspace_bytes(d['B'], d['H'], d['W'], d['stride'], N), dtype=torch.uint8, device=dev))
+    return bufs
+
+
+@pytest.mark.parametrize('flags', [1, 2], ids=['single_launch', 'two_launches'])
+@pytest.mark.parametrize('size', ['cfg1', 'medium'])
+def test_hipgraph_replay_with_changed_inputs(dev, flags, size):
+    """ONE evaluation captured into a hipGraph and replayed with the CONTENTS of imgs, mask_logits, the box tensors and gt_inds
+    overwritten in place between replays -- the reason to replay in training.  Nothing a replay must renew may be a kernel argument:
+    the evaluation's tag is drawn on the device from the workspace's epoch word (a by-value tag would make the second replay accept
+    the first replay's records: stale predicates, stale losses), and the warm-up factor comes from the device counter
+    (condinst_head.py:1297,1330-1331: state that changes per call).  Every replay: status 0, losses and gradient within 1e-4 of the
+    oracle FOR THAT REPLAY'S inputs and iteration."""
+    import ctypes as C
+    from boxinstseg_amd import _lib, functional as Fh
+    lib = _lib.load()
+    mk = (lambda s: synthetic.cfg1(s)) if size == 'cfg1' else \
+         (lambda s: synthetic.make_batch(B=2, H=320, W=512, boxes_per_img=5, seed=40 + s, min_box=24, max_box=200))
+    ds = [mk(s) for s in range(5)]
+    W_IT = 8.0                                               # pairwise_warmup: the ramp is still moving over these replays
+    b = _abi_eval_setup(ds[0], dev, lib, Fh, iter_value=2.0)
+    off = lib.bxi_boxinst_loss_state_status_offset(b['inst'].N, b['inst'].h, b['inst'].w)
+    stream = torch.cuda.Stream(device=dev)
+
+    def call(st):
+        rc = lib.bxi_boxinst_eval_f32(C.byref(b['batch'].struct), C.byref(b['inst'].struct), 3, 2, 0.3, -W_IT, None, None,
+                                      b['losses'].data_ptr(), b['grad'].data_ptr(), b['state'].data_ptr(), b['ws'].data_ptr(),
+                                      b['ws'].numel(), flags, st)
+        assert rc == 0, _lib.status_string(rc)
+
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        call(stream.cuda_stream)                              # one eager evaluation first (iteration 3)
+        stream.synchronize()
+        with torch.cuda.graph(graph, stream=stream):
+            call(torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    assert float(b['it']) == 3.0                              # capturing runs nothing
+    for k, d in enumerate(ds[1:] + ds[:1]):
+        # overwrite the inputs IN PLACE (same shapes, same counts per image: those are the graph's frozen arguments)
+        b['t']['imgs'].copy_(torch.from_numpy(d['imgs']))
+        b['t']['logits'].copy_(torch.from_numpy(d['mask_logits']))
+        b['t']['gt_inds'].copy_(torch.from_numpy(d['gt_inds']))
+        for dst, src in zip(b['t']['gt_bboxes'], d['gt_bboxes']):
+            assert dst.shape == src.shape
+            dst.copy_(torch.from_numpy(src))
+        b['losses'].fill_(-1.0)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        it_now = 3.0 + k + 1.0
+        assert float(b['it']) == it_now
+        ref = oracle_path(d, warmup=min(it_now / W_IT, 1.0), want_targets=False)
+        status = b['state'][off:off + 8].view(torch.int32).cpu().tolist()
+        assert status[0] == 0, f'replay {k}: status {status[0]}'
+        got = b['losses'].cpu().numpy()
+        assert rel(float(got[0]), ref['loss_prj']) <= TOL and rel(float(got[1]), ref['loss_pairwise']) <= TOL, (k, got, ref['loss_prj'], ref['loss_pairwise'])
+        err, _ = grad_report(b['grad'].cpu().numpy()[:, 0], ref['grad'], d['mask_logits'][:, 0])
+        assert err <= TOL, (k, err)
+
+
+def test_evaluation_next_to_a_kernel_holding_a_quarter_of_the_cus(dev):
+    """What an RCCL all-reduce does during DDP's backward: a second stream keeps a fixed share of the compute units busy (here a
+    CU-masked stream: 64 of the 256 CUs running matrix products back to back) while evaluations run in the form the library chooses
+    on a device it believes it has to itself -- the single launch whose stream workgroups stay on.  They must finish with status 0 and
+    the quiet run's bits, with a bounded slowdown (the launch needs 1024 slots and finds 768: its pool workgroups take two rounds)."""
+    import ctypes as C
+    import time
+    from boxinstseg_amd import _lib, boxinst_mask_loss, functional as Fh
+    lib = _lib.load()
+    hip = C.CDLL('libamdhip64.so')
+    hstream = C.c_void_p()
+    mask = (C.c_uint32 * 8)(0xffffffff, 0xffffffff, 0, 0, 0, 0, 0, 0)                  # 64 of the 256 CUs
+    assert hip.hipExtStreamCreateWithCUMask(C.byref(hstream), 8, mask) == 0
+    try:
+        d = synthetic.cfg2(3)
+        quiet = hip_loss(d, dev)
+        t = to_dev(d, dev)
+        hog_stream = torch.cuda.ExternalStream(hstream.value, device=dev)
+        hog = torch.randn(4096, 4096, device=dev)
+        work = torch.cuda.Stream(device=dev)
+        names = []
+        cb = _lib.LAUNCH_HOOK(lambda name, phase, st, user: names.append(name.decode()))
+        Fh.DEBUG_KEEP_LAST = True
+        torch.cuda.synchronize()
+        with torch.cuda.stream(hog_stream):
+            for _ in range(40):                                                         # ~tens of ms on 64 CUs
+                hog = (hog @ hog).clamp_(-1.0, 1.0)
+        lib.bxi_dev_set_launch_hook(C.cast(cb, C.c_void_p), None)
+        t0 = time.perf_counter()
+        try:
+            with torch.cuda.stream(work), Fh.eval_flags(0):
+                for rep in range(20):
+                    x = t['logits'].clone().requires_grad_(True)
+                    out = boxinst_mask_loss(x, t['gt_inds'], t['gt_bboxes'], imgs=t['imgs'], img_metas=d['img_metas'])
+                    (out['loss_prj'] + out['loss_pairwise']).backward()
+                work.synchronize()
+        finally:
+            lib.bxi_dev_set_launch_hook(None, None)
+        busy = not hog_stream.query()                                                   # the hog was still running when the work ended
+        el = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        assert 'eval1' in names, names
+        assert Fh.last_eval_status()[0] == 0
+        assert float(out['loss_prj']) == quiet[0] and float(out['loss_pairwise']) == quiet[1]
+        assert np.array_equal(x.grad.cpu().numpy()[:, 0], quiet[2])
+        assert el < 0.5, f'{el * 1e3:.1f} ms for 20 evaluations next to the hog (bounded waits are ~0.1 s each when they run out)'
+        assert busy, 'the hog finished before the evaluations did: the test did not overlap them'
+    finally:
+        torch.cuda.synchronize()
+        hip.hipStreamDestroy(hstream)
+
+
+def _two_process_worker(rank, seed_base, n, q):
+    import numpy as np, torch
+    from boxinstseg_amd import synthetic as syn, functional as Fh
+    from tests.helpers import hip_loss
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    d = syn.cfg2(seed_base + rank)
+    first = hip_loss(d, dev)
+    ok = True
+    for _ in range(n):
+        again = hip_loss(d, dev)                   # asserts status 0 inside
+        ok = ok and again[0] == first[0] and again[1] == first[1] and np.array_equal(again[2], first[2])
+    q.put((rank, ok, first[0], first[1]))
+
+
+def test_two_processes_share_one_device(dev):
+    """Two PROCESSES evaluating on cuda:0 at the same time (what MPS-style sharing or a co-located job does): neither sees the other
+    through any host-side bookkeeping.  Every evaluation of both must report status 0 and reproduce its own first result bit for
+    bit; the losses must be the oracle's."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_process_worker, args=(r, 50, 60, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, lp, lw in res:
+        assert ok, f'process {rank}: results changed between evaluations'
+        ref = oracle_path(synthetic.cfg2(50 + rank), want_targets=False)
+        assert rel(lp, ref['loss_prj']) <= TOL and rel(lw, ref['loss_pairwise']) <= TOL
+
+
+def test_fault_is_noticed_where_losses_reach_the_host_and_the_next_evaluations_take_two_launches(dev):
+    """A bounded wait that runs out gives NaN losses (loud).  Where the losses reach the host anyway (dist.to_host / the key guard of
+    dist.parse_losses) the fault is noticed, the workspaces are zeroed again and from then on this thread's evaluations take the
+    two-launch form -- every wait of which is for an earlier workgroup of its grid -- instead of poisoning every iteration."""
+    import ctypes as C
+    import math
+    import warnings
+    from boxinstseg_amd import _lib, boxinst_mask_loss, dist as bdist, functional as Fh
+    lib = _lib.load()
+    d = synthetic.cfg2(4)
+    good = hip_loss(d, dev)
+    t = to_dev(d, dev)
+    with Fh.eval_flags(_lib.EVAL_WAITS_GIVE_UP):
+        out = boxinst_mask_loss(t['logits'], t['gt_inds'], t['gt_bboxes'], imgs=t['imgs'], img_metas=d['img_metas'])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        vals = bdist.to_host(out)
+    assert math.isnan(vals['loss_prj']) and math.isnan(vals['loss_pairwise'])
+    assert any('two-launch' in str(x.message) for x in w)
+    assert Fh.eval_launch_flags() & _lib.EVAL_TWO_LAUNCHES
+    names = []
+    cb = _lib.LAUNCH_HOOK(lambda name, phase, st, user: names.append(name.decode()))
+    lib.bxi_dev_set_launch_hook(C.cast(cb, C.c_void_p), None)
+    try:
+        again = hip_loss(d, dev)
+    finally:
+        lib.bxi_dev_set_launch_hook(None, None)
+    assert 'prep' in names and 'pair' in names and 'eval1' not in names, names
+    assert again[0] == good[0] and again[1] == good[1] and np.array_equal(again[2], good[2])

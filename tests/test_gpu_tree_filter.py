@@ -281,13 +281,13 @@ def _check_bfs(tree, V):
     si, sp, sc = bfs(tree, 4)
     si2, sp2, sc2 = bfs(tree, 4)
     assert torch.equal(si, si2) and torch.equal(sp, sp2) and torch.equal(sc, sc2)
-    # the level walk (debug form 16) and the Euler-tour ranking (the default) are two algorithms for the same order
+    # the level walk (bxi_dev_set_tree_level_walk) and the Euler-tour ranking (the default) are two algorithms for the same order
     lib = _lib.load()
-    lib.bxi_debug_set_eval_form(16)
+    lib.bxi_dev_set_tree_level_walk(1)
     try:
         si3, sp3, sc3 = bfs(tree, 4)
     finally:
-        lib.bxi_debug_set_eval_form(0)
+        lib.bxi_dev_set_tree_level_walk(0)
     assert torch.equal(si, si3) and torch.equal(sp, sp3) and torch.equal(sc, sc3)
     for la, lb in zip(si._bxi_levels.cpu(), si3._bxi_levels.cpu()):
         assert int(la[0]) == int(lb[0]) > 0 and torch.equal(la[:int(la[0]) + 2], lb[:int(la[0]) + 2])
@@ -381,12 +381,12 @@ def test_large_bfs_reports_input_it_cannot_represent(built, dev, form):
     loop[V - 4] = (V - 3, V - 1)                            # 0 .. V-4 a path; V-3, V-2, V-1 a triangle of their own
     trees = torch.from_numpy(np.stack([path, star, loop, path])).to(dev)
     lib = _lib.load()
-    lib.bxi_debug_set_eval_form(form)
+    lib.bxi_dev_set_tree_level_walk(1 if form else 0)
     try:
         si, sp, sc = bfs(trees, 4)
         torch.cuda.synchronize()
     finally:
-        lib.bxi_debug_set_eval_form(0)
+        lib.bxi_dev_set_tree_level_walk(0)
     lv = si._bxi_levels.cpu().numpy()
     assert lv[0, 0] == V and lv[3, 0] == V                  # a path from vertex 0: one vertex per level
     assert lv[1, 0] == -1 and lv[2, 0] == -1
@@ -429,12 +429,12 @@ def test_large_bfs_forms(built, dev, kind):
 @pytest.fixture(params=[0, 16], ids=['depth_free', 'level_walks'])
 def large_form(request):
     """Both forms of the large-tree kernels: the default (Euler-tour BFS, leaf->root pass by doubling over the levels) and the level walks
-    (bxi_debug_set_eval_form bit 16)."""
+    (bxi_dev_set_tree_level_walk, include/boxinst_hip_dev.h)."""
     from boxinstseg_amd import _lib
     lib = _lib.load()
-    lib.bxi_debug_set_eval_form(request.param)
+    lib.bxi_dev_set_tree_level_walk(1 if request.param else 0)
     yield request.param
-    lib.bxi_debug_set_eval_form(0)
+    lib.bxi_dev_set_tree_level_walk(0)
 
 
 @pytest.mark.parametrize('low', [True, False])

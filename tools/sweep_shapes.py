@@ -18,14 +18,14 @@ def build(B, H, W, bpi, ipb, stride, seed, dil):
     batch = Fh._Batch(imgs, d['img_metas'], 10); inst = Fh._Inst(logits, gi, boxes, d['H'], d['W'], stride)
     losses = torch.zeros(2, device=dev); grad = torch.empty_like(inst.logits)
     state = torch.empty(max(lib.bxi_boxinst_loss_state_bytes(inst.N, inst.h, inst.w), 256), dtype=torch.uint8, device=dev)
-    ws = torch.empty(max(lib.bxi_boxinst_eval_workspace_bytes(B, H, W, stride, inst.N), 256), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(max(lib.bxi_boxinst_eval_workspace_bytes(B, H, W, stride, inst.N), 256), dtype=torch.uint8, device=dev)
     return (batch, inst, losses, grad, state, ws, imgs, logits, gi, boxes, d)
 
 
 def run(s, dil):
     batch, inst, losses, grad, state, ws = s[:6]
     rc = lib.bxi_boxinst_eval_f32(C.byref(batch.struct), C.byref(inst.struct), 3, dil, 0.3, 1.0, ones.data_ptr(), ones.data_ptr() + 4,
-                                  losses.data_ptr(), grad.data_ptr(), state.data_ptr(), ws.data_ptr(), ws.numel(), st)
+                                  losses.data_ptr(), grad.data_ptr(), state.data_ptr(), ws.data_ptr(), ws.numel(), int(os.environ.get('BXI_FLAGS', '0')), st)
     assert rc == 0, rc
 
 

@@ -21,13 +21,13 @@ for seed in range(8):
     batch = Fh._Batch(imgs, d['img_metas'], 10); inst = Fh._Inst(logits, gi, boxes, d['H'], d['W'], 4)
     losses = torch.zeros(2, device=dev); grad = torch.empty_like(inst.logits)
     state = torch.empty(lib.bxi_boxinst_loss_state_bytes(inst.N, inst.h, inst.w), dtype=torch.uint8, device=dev)
-    ws = torch.empty(lib.bxi_boxinst_eval_workspace_bytes(2, 800, 1024, 4, inst.N), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(lib.bxi_boxinst_eval_workspace_bytes(2, 800, 1024, 4, inst.N), dtype=torch.uint8, device=dev)
     sets.append((batch, inst, losses, grad, state, ws, imgs, logits, gi, boxes))
 st = torch.cuda.current_stream().cuda_stream
 def ev(s):
     batch, inst, losses, grad, state, ws = s[:6]
     rc = lib.bxi_boxinst_eval_f32(C.byref(batch.struct), C.byref(inst.struct), 3, 2, 0.3, 1.0, ones.data_ptr(), ones.data_ptr() + 4,
-                                  losses.data_ptr(), grad.data_ptr(), state.data_ptr(), ws.data_ptr(), ws.numel(), st)
+                                  losses.data_ptr(), grad.data_ptr(), state.data_ptr(), ws.data_ptr(), ws.numel(), int(os.environ.get('BXI_FLAGS', '0')), st)
     assert rc == 0, rc
 for i in range(60): ev(sets[i % 8])
 torch.cuda.synchronize()
