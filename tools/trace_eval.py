@@ -60,7 +60,8 @@ sw = sw[sw[:, 7] > 0]; pw = pw[pw[:, 7] > 0]
 print('  stream waves:', len(sw), 'start', q(us(sw[:, 0] - t0)), '| loads+zero-fill issued', qd(sw[:, 1], sw[:, 0]), '| data + column max', qd(sw[:, 2], sw[:, 1]),
       '| butterflies', qd(sw[:, 3], sw[:, 2]), '| barrier', qd(sw[:, 4], sw[:, 3]), '| end', q(us(sw[:, 7] - t0)))
 print('  pool waves (last item of each):', len(pw), 'start', q(us(pw[:, 0] - t0)), '| loads + denorm at', q(us(pw[:, 1] - t0)), '| barrier 1', qd(pw[:, 2], pw[:, 1]),
-      '| Lab f', qd(pw[:, 3], pw[:, 2]), '| barrier 2', qd(pw[:, 4], pw[:, 3]), '| end', q(us(pw[:, 7] - t0)))
+      '| Lab f', qd(pw[:, 3], pw[:, 2]), '| barrier 2', qd(pw[:, 4], pw[:, 3]), '| windows (pool-side predicates) done after', qd(pw[:, 5], pw[:, 4]),
+      '| count arrival after', qd(pw[:, 6], pw[:, 5]), '| end', q(us(pw[:, 7] - t0)))
 prep_end = p[live, 7].max()
 one = os.environ.get('BXI_ONE_LAUNCH', '1') != '0'
 mw = t[1]; allm = mw[mw[:, 0] > 0]; mw = allm[allm[:, 7] > 0]
