@@ -179,6 +179,14 @@ def worker(args):
         raise SystemExit(f'in-kernel wait timed out (status {status[0]}): refusing to time')
     parity = None
     cpu_leg = None
+    if world > 1 and not args.no_cpu_baseline:
+        # N > 1: EVERY rank checks its own first set against the C oracle before anything is timed (the checker only: the timed CPU
+        # baseline stays a rank-0, N == 1 figure), and one rank's mismatch fails the whole run
+        parity = parity_gate_only(sets[0])
+        bad = torch.tensor([0.0 if parity['ok'] else 1.0], device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if float(bad.item()) != 0.0:
+            raise SystemExit(f'parity gate failed on some rank (this rank {rank}: {parity}), refusing to time')
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_leg, ref = cpu_baseline(sets[0].d, args.cpu_seconds)
         got = sets[0].losses.cpu().numpy()
@@ -308,6 +316,7 @@ def worker(args):
     images = 2 * args.steps * world
     value = images / elapsed
     step_us = elapsed / args.steps * 1e6
+    sol = speed_of_light(lib, sets, dev, stream, args.steps, args.warmup) if rank == 0 else None
 
     result = {
         'metric': 'pairwise+projection loss fwd+bwd images/sec @2x800x1024x32inst',
@@ -325,6 +334,8 @@ def worker(args):
         mine = {'rank': rank, 'device': dev.index, 'name': props.name, 'arch': getattr(props, 'gcnArchName', None),
                 'pci_bus_id': '%04x:%02x:%02x' % (getattr(props, 'pci_domain_id', 0), getattr(props, 'pci_bus_id', 0), getattr(props, 'pci_device_id', 0)),
                 'uuid': str(getattr(props, 'uuid', ''))}
+        if parity is not None:
+            mine['parity'] = parity
         ranks = [None] * world
         dist.all_gather_object(ranks, mine)
         result['multi_gpu'] = {
@@ -395,12 +406,26 @@ def worker(args):
                                              'note': 'bxi_boxinst_eval_f32 + bxi_boxinst_grad_rescale_f32 (one launch more than `value`): the C-ABI '
                                                      'sequence behind loss() + backward() when the upstream factors are only '
                                                      'known at backward time'}
+        result['extras'] = {}
+        for ipb in (2, 4):           # the shape real training runs: topk_per_img=64 x samples_per_gpu=2 -> up to 128 instances per evaluation
+            result['extras'][f'n{32 * ipb}'] = instance_count_extra(lib, _lib, Fh, synthetic, dev, stream, ones, ipb, args.flags)
+        result['extras'].update(rows_extra())
         result['head_fused_extra'] = head_fused(lib, Fh, sets, dev, stream, n_extra)
         result['module_api'] = module_api(sets, dev, 300)
 
     # ---- per-kernel durations with HIP events on the launching stream (rank 0, N == 1) ------------
     if rank == 0 and world == 1 and not args.no_kernel_timing:
         result.update(kernel_timing(lib, _lib, sets, stream, enqueue, min(max(args.steps, 50), 200), step_us, status[1]))
+    if sol is not None:
+        # the floor of THIS launch shape on this part, measured in the same run on the same cold sets: the evaluation's bytes moved by
+        # the evaluation's grid with no arithmetic and no workgroup waiting for another (csrc/sol_eval.hip)
+        rf = result.setdefault('roofline', {'bound': 'hbm', 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'achieved': survey_bytes(sets[0].d, sets[0].inst.N) / (step_us * 1e-6) / 1e9,
+                                            'frac': survey_bytes(sets[0].d, sets[0].inst.N) / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 'traffic': None,
+                                            'algorithmic_bytes': survey_bytes(sets[0].d, sets[0].inst.N), 'time_us': step_us})
+        rf['sol_us'] = sol['us_per_step']
+        rf['frac_of_sol'] = sol['us_per_step'] / step_us
+        rf['sol'] = sol
+
     if cpu_leg is not None:
         result['cpu_baseline'] = cpu_leg
     if dist is not None:
@@ -408,6 +433,211 @@ def worker(args):
     if rank == 0:
         json_out.write(json.dumps(result) + '\n')
         json_out.flush()
+
+
+def speed_of_light(lib, sets, dev, stream, steps, warmup):
+    """The byte-only stand-in of the single-launch evaluation (bxi_dev_sol_eval_f32, csrc/sol_eval.hip): the same grid -- workgroups per
+    role, four per CU -- performing the same loads and stores on the same rotating cold input sets, with no arithmetic and no workgroup
+    waiting for another; timed exactly like `value` (K back-to-back launches on one stream, un-instrumented wall time)."""
+    vp = C.c_void_p
+    packs = []
+    for s in sets:
+        d = s.d
+        scratch = torch.empty(20 * d['B'] * d['h'] * d['w'] + 256, dtype=torch.uint8, device=dev)
+        g = torch.empty_like(s.inst.logits)
+        packs.append((vp(s.imgs.data_ptr()), d['B'], d['H'], d['W'], vp(s.inst.logits.data_ptr()), s.inst.N, s.inst.h, s.inst.w, vp(g.data_ptr()),
+                      vp(scratch.data_ptr()), C.c_size_t(scratch.numel()), scratch, g))
+    st = stream.cuda_stream
+    f = lib.bxi_dev_sol_eval_f32
+
+    def run(n):
+        for i in range(n):
+            pk = packs[i % len(packs)]
+            rc = f(*pk[:11], st)
+            if rc != 0:
+                raise RuntimeError(f'bxi_dev_sol_eval_f32: status {rc}')
+    n = max(steps, 300)
+    with torch.cuda.stream(stream):
+        run(max(warmup, 50))
+        torch.cuda.synchronize(dev)
+        done = torch.cuda.Event()
+        t0 = time.perf_counter()
+        run(n)
+        done.record(stream)
+        while not done.query():
+            pass
+        el = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+    d0 = sets[0].d
+    moved = algorithmic_bytes(d0, sets[0].inst.N, 4)['eval1']
+    return {'us_per_step': el / n * 1e6, 'steps': n, 'bytes_moved_per_launch': moved, 'GBps': moved / (el / n) / 1e9,
+            'what': 'ONE launch with eval1_kernel\'s grid (same workgroups per role, 4 per CU) doing the evaluation\'s loads and stores, no arithmetic, '
+                    'no in-grid dependency; same cold sets, timed like `value` (launch boundary included)'}
+
+
+def instance_count_extra(lib, _lib, Fh, synthetic, dev, stream, ones, inst_per_box, flags, n_sets=6, steps=400):
+    """Extra (not `value`): the same evaluation with 2 / 4 instances per box -- N = 64 / 128, what configs/boxinst/boxinst_r50_fpn_1x_coco.py:65,125
+    (topk_per_img=64, samples_per_gpu=2) gives condinst_head.py:1190-1225 -- timed like `value` on rotating cold sets, with its own
+    roofline: SURVEY 8(d)'s compulsory bytes at that N / step time / HBM peak."""
+    sets = [EvalSet(lib, Fh, synthetic, dev, seed=7000 + i, inst_per_box=inst_per_box, ones=ones, flags=flags) for i in range(n_sets)]
+    st = stream.cuda_stream
+    f_eval = lib.bxi_boxinst_eval_f32
+    calls = []
+    cb = _lib.LAUNCH_HOOK(lambda name, phase, s_, user: calls.append(name.decode()))
+
+    def run(n):
+        for i in range(n):
+            rc = f_eval(*sets[i % n_sets].eval_args, st)
+            if rc != 0:
+                raise RuntimeError(f'C ABI status {rc}')
+    with torch.cuda.stream(stream):
+        lib.bxi_dev_set_launch_hook(C.cast(cb, C.c_void_p), None)
+        try:
+            run(1)
+        finally:
+            lib.bxi_dev_set_launch_hook(None, None)
+        run(60)
+        torch.cuda.synchronize(dev)
+        done = torch.cuda.Event()
+        t0 = time.perf_counter()
+        run(steps)
+        done.record(stream)
+        while not done.query():
+            pass
+        el = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+    s0 = sets[0]
+    off = lib.bxi_boxinst_loss_state_status_offset(s0.inst.N, s0.inst.h, s0.inst.w)
+    status = s0.state[off:off + 8].view(torch.int32).cpu().tolist()
+    nbytes = survey_bytes(s0.d, s0.inst.N)
+    us = el / steps * 1e6
+    return {'instances': s0.inst.N, 'us_per_step': us, 'images_per_s': 2 * steps / el, 'algorithmic_bytes': nbytes,
+            'achieved_GBps': nbytes / (us * 1e-6) / 1e9, 'frac': nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+            'kernels_per_step': sorted(set(calls)), 'status': status[0], 'steps': steps, 'input_sets': n_sets}
+
+
+def rows_extra():
+    """Extras (not `value`): one entry per row of SURVEY 8(a)/(f) that the timed step does not contain -- the op-level pairwise_nlog
+    (a-9..a-11) and the "next" rows f-2..f-4 -- so that the driver's record holds them too.  Each is the developer bench of that row
+    (tools/bench_*.py: event-timed batches of calls through the Python API, no profiler), run in this process; `frac` is on the row's
+    compulsory bytes (stated) against the HBM peak where the row is a streaming kernel, `bound` says what limits it where it is not."""
+    import contextlib
+    import io
+    import runpy
+
+    def run_tool(name):
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf):
+                runpy.run_path(os.path.join(ROOT, 'tools', name), run_name='__main__')
+            return json.loads(buf.getvalue()[buf.getvalue().index('{'):])
+        except Exception as e:                                   # an extra never takes the headline down
+            return {'error': f'{type(e).__name__}: {e}'[:300]}
+
+    def frac(nbytes, us):
+        return nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS
+
+    out = {}
+    r = run_tool('bench_pairwise_op.py')
+    if 'error' not in r:
+        f32 = r['torch.float32']
+        nb = 32 * 200 * 256 * 4
+        out['pairwise_op'] = {'shape': '[32,1,200,256] f32, size 3, dilation 2 (pairwise.cu:68-202)', 'fwd_us': f32['fwd_us'], 'bwd_us': f32['bwd_us'],
+                              'fwd_bytes': 9 * nb, 'bwd_bytes': 10 * nb, 'fwd_frac': frac(9 * nb, f32['fwd_us']), 'bwd_frac': frac(10 * nb, f32['bwd_us']),
+                              'bytes_model': 'forward: logits read + 8 planes written; backward: logits + 8 upstream planes read + gradient written',
+                              'f64_fwd_us': r['torch.float64']['fwd_us'], 'f64_bwd_us': r['torch.float64']['bwd_us']}
+    else:
+        out['pairwise_op'] = r
+    # (the dynamic head and the tree filter are timed here rather than through their tools/ scripts: those also time comparison paths
+    # that live under oracle/, which bench.py touches in its cpu_baseline leg only)
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    def ev(fn, n=60, warm=8):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_.record()
+        for _ in range(n):
+            fn()
+        b_.record()
+        torch.cuda.synchronize()
+        return a_.elapsed_time(b_) / n * 1e3
+    try:
+        from boxinstseg_amd import dynamic_mask_forward
+        g = torch.Generator(device='cpu').manual_seed(0)
+        N, B, Cf, H, W = 32, 2, 16, 100, 128
+        feat = torch.randn(B, Cf, H, W, generator=g).to(dev).requires_grad_(True)
+        params = (torch.randn(N, 233, generator=g) * 0.3).to(dev).requires_grad_(True)
+        coors = (torch.rand(N, 2, generator=g) * 1000).to(dev)
+        lvl, img = torch.randint(0, 5, (N,), generator=g).to(dev), torch.randint(0, B, (N,), generator=g).to(dev)
+        soi = torch.tensor([64, 128, 256, 512, 1024], device=dev)
+        gout = torch.randn(N, 1, 2 * H, 2 * W, generator=g).to(dev)
+
+        def fwd():
+            return dynamic_mask_forward(feat, params, coors, lvl, img, soi)
+
+        def fwd_bwd():
+            fwd().backward(gout)
+            feat.grad = None
+            params.grad = None
+        with torch.no_grad():
+            t_f = ev(fwd)
+        feat_b, logit_b = B * Cf * H * W * 4, N * 4 * H * W * 4
+        out['f2_dynamic_head'] = {'shape': '32 instances, feat [2,16,100,128] -> logits [32,1,200,256] (condinst_head.py:1139-1164)', 'fwd_us': t_f,
+                                  'fwd_bwd_us': ev(fwd_bwd), 'fwd_bytes': feat_b + logit_b, 'fwd_frac': frac(feat_b + logit_b, t_f),
+                                  'bound': 'issue (a workgroup\'s load -> 3-layer MLP -> store chain, DESIGN_NEXT_ROWS 3.5), not HBM; '
+                                           'wall time through the Python API'}
+    except Exception as e:
+        out['f2_dynamic_head'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+    try:
+        from boxinstseg_amd import MinimumSpanningTree, TreeFilter2D
+        g = torch.Generator().manual_seed(0)
+        mstm, tf = MinimumSpanningTree(TreeFilter2D.norm2_distance), TreeFilter2D()
+        Bt, Nt, Ht = 2, 16, 96
+        img_t, lst = torch.rand(Bt, 3, Ht, Ht, generator=g).to(dev), torch.rand(Bt, 8, Ht, Ht, generator=g).to(dev)
+        rep_i = torch.arange(Nt) % Bt
+        pred = torch.rand(Nt, 1, Ht, Ht, generator=g).to(dev).requires_grad_(True)
+        ti, tl = mstm(img_t)[rep_i], mstm(lst)[rep_i]
+        imgs_n, lst_n = img_t[rep_i], lst[rep_i]
+
+        def filt():
+            a_ = tf(feature_in=pred, embed_in=imgs_n, tree=ti)
+            b_ = tf(a_, lst_n, tl, low_tree=False)
+            (a_.sum() + b_.sum()).backward()
+            pred.grad = None
+        img2 = torch.rand(1, 3, 200, 304, generator=g).to(dev)
+        feat2 = torch.rand(1, 5, 200, 304, generator=g).to(dev).requires_grad_(True)
+        t2 = mstm(img2)
+
+        def filt2():
+            tf(feature_in=feat2, embed_in=img2, tree=t2).sum().backward()
+            feat2.grad = None
+        out['f4_tree_filter'] = {'small_96x96_B2_N16': {'two_msts_us': ev(lambda: (mstm(img_t), mstm(lst)), n=20, warm=3), 'two_filters_fwd_bwd_us': ev(filt, n=20, warm=3)},
+                                 'large_200x304_C5': {'mst_us': ev(lambda: mstm(img2), n=5, warm=1), 'filter_fwd_bwd_us': ev(filt2, n=5, warm=1)},
+                                 'bound': 'latency: graph-serial (MST phases, BFS ranking, leaf->root / root->leaf passes are dependent launches / LDS walks); '
+                                          'mmdet/ops/tree_filter/**'}
+    except Exception as e:
+        out['f4_tree_filter'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+    r = run_tool('bench_discobox.py')
+    if 'error' not in r:
+        n16 = r['n16']
+        out['f3_discobox'] = {'shape': '16 instances at 200x304, 10 mean-field iterations (discobox_head.py:585-655)', 'meanfield_us': n16['hip_meanfield_us'],
+                              'mil_fwd_bwd_us': n16['hip_mil_fwd_bwd_us'], 'bound': 'latency: a chain of 10 dependent stencil launches over 3.9 MB (no HBM roofline applies)',
+                              'torch_rocm_meanfield_us': n16['torch_rocm_meanfield_us'], 'label_mismatch_vs_torch_rocm': n16['label_mismatch_vs_torch_rocm']}
+    else:
+        out['f3_discobox'] = r
+    r = run_tool('bench_levelset.py')
+    if 'error' not in r:
+        n16 = r['N16']
+        out['f4_box2mask_losses'] = {'shape': '16 instances at 200x304 (projection, level set), 96x96 (LCM, 10 iterations)',
+                                     'projection_fwd_bwd_us': n16['hip_projection_fwd_bwd_us'], 'levelset_fwd_bwd_us': n16['hip_levelset_fwd_bwd_us'],
+                                     'lcm_fwd_bwd_us': n16['hip_lcm_fwd_bwd_us'], 'bound': 'latency / host launch (a few small launches each; wall time through the Python API)',
+                                     'torch_rocm_projection_fwd_bwd_us': n16['torch_rocm_projection_fwd_bwd_us'],
+                                     'torch_rocm_levelset_fwd_bwd_us': n16['torch_rocm_levelset_fwd_bwd_us'], 'torch_rocm_lcm_fwd_bwd_us': n16['torch_rocm_lcm_fwd_bwd_us']}
+    else:
+        out['f4_box2mask_losses'] = r
+    return out
 
 
 def head_fused(lib, Fh, sets, dev, stream, steps):
@@ -482,7 +712,7 @@ def module_api(sets, dev, n):
         (out['loss_prj'] + out['loss_pairwise']).backward()
         x.grad = None
 
-    for i in range(30):
+    for i in range(400):             # the first few hundred calls of a process run at up to twice the steady-state host time
         once(i)
     torch.cuda.synchronize(dev)
     gc.collect()
@@ -504,10 +734,64 @@ def module_api(sets, dev, n):
     fwd_only = time.perf_counter() - t0
     torch.cuda.synchronize(dev)
     varying = module_api_varying(head, sets, dev, n)
+    # for scale: a plain PyTorch graph of the same shape (two reductions of the logits, their sum, backward) -- what the autograd
+    # engine and three eager launches cost on this host whatever the nodes do
+    w = sets[0].logits.clone().requires_grad_(True)
+
+    def torch_only():
+        (w.sum() + w.mean()).backward()
+        w.grad = None
+    for _ in range(100):
+        torch_only()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        torch_only()
+    torch_ref = (time.perf_counter() - t0) / n * 1e6
+    torch.cuda.synchronize(dev)
     return {'images_per_s': 2 * n / el, 'us_per_call': el / n * 1e6, 'host_us_per_call': host / n * 1e6,
             'loss_call_host_us_no_autograd': fwd_only / n * 1e6, 'varying_shapes': varying,
+            'torch_only_same_graph_shape_host_us': torch_ref, 'forward_loss': module_forward_loss(sets, dev, min(n, 200)),
             'note': 'CondInstMaskHead.loss + backward() of the two scalars, eager PyTorch (gc frozen); host-bound: '
-                    'the GPU work is `value`'}
+                    'the GPU work is `value`.  torch_only_same_graph_shape_host_us = (w.sum() + w.mean()).backward() on the same '
+                    'logits: the autograd engine\'s round and three eager launches, i.e. the part of us_per_call that is not this library'}
+
+
+def module_forward_loss(sets, dev, n):
+    """CondInstMaskHead.forward_loss -- forward() + loss() (+ backward to the mask features and the dynamic parameters) as ONE module
+    call -- with the head fused into the evaluation's first launch and as the two calls (the default), mmdet/models/detectors/condinst.py:69-75."""
+    from boxinstseg_amd import CondInstMaskHead
+    head = CondInstMaskHead(in_channels=16, boxinst_enabled=True, topk_per_img=64, max_proposals=-1).to(dev)
+    head._iter.fill_(20000.0)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    packs = []
+    for s in sets:
+        d, N = s.d, s.inst.N
+        feat = torch.randn(d['B'], 16, d['H'] // 8, d['W'] // 8, generator=g).to(dev).requires_grad_(True)
+        params = (0.3 * torch.randn(N, 233, generator=g)).to(dev).requires_grad_(True)
+        coors = (torch.rand(N, 2, generator=g) * torch.tensor([float(d['W']), float(d['H'])])).to(dev)
+        lvl = torch.randint(0, 5, (N,), generator=g).to(dev)
+        counts = np.cumsum([0] + [b.shape[0] for b in d['gt_bboxes']])
+        img = torch.tensor([int(np.searchsorted(counts, int(x), side='right') - 1) for x in d['gt_inds']], dtype=torch.int64).to(dev)
+        packs.append((feat, params, coors, lvl, img))
+    out = {}
+    for name, fused in (('two_calls_us', False), ('fused_head_us', True)):
+        def once(i):
+            s, (feat, params, coors, lvl, img) = sets[i % len(sets)], packs[i % len(sets)]
+            _, losses = head.forward_loss(feat, params, coors, lvl, img, s.imgs, s.d['img_metas'], s.gt_inds, s.boxes, fuse_head=fused)
+            (losses['loss_prj'] + losses['loss_pairwise']).backward()
+            feat.grad = None
+            params.grad = None
+        for i in range(40):
+            once(i)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(n):
+            once(i)
+        torch.cuda.synchronize(dev)
+        out[name] = (time.perf_counter() - t0) / n * 1e6
+    out['default'] = 'two calls (fuse_head=False)'
+    return out
 
 
 def module_api_varying(head, sets, dev, n):
@@ -671,6 +955,21 @@ def kernel_timing(lib, _lib, sets, stream, enqueue, steps, step_us, rows):
         'kernels': per_kernel,
         'event_bracket_us': bracket_us,
     }
+
+
+def parity_gate_only(s):
+    """The C oracle (OpenMP) as the checker of one evaluated set: losses <= 1e-4 rel, gradient <= 1e-4 of its max (arg-max ties excluded
+    and counted).  Used on every rank of an N > 1 run; the N == 1 run's gate is part of cpu_baseline()'s leg below."""
+    from tests.helpers import grad_report, oracle_path
+    ref = oracle_path(s.d, want_targets=False)
+    got = s.losses.cpu().numpy()
+    g = s.grad.cpu().numpy()[:, 0]
+    g_err, n_ties = grad_report(g, ref['grad'], s.d['mask_logits'][:, 0])
+    out = dict(loss_prj_rel=float(abs(got[0] - ref['loss_prj']) / abs(ref['loss_prj'])),
+               loss_pairwise_rel=float(abs(got[1] - ref['loss_pairwise']) / abs(ref['loss_pairwise'])), grad_rel_max=float(g_err),
+               ambiguous_argmax_lines_excluded=int(n_ties))
+    out['ok'] = bool(max(out['loss_prj_rel'], out['loss_pairwise_rel'], out['grad_rel_max']) <= 1e-4)
+    return out
 
 
 def cpu_baseline(d, budget_s):

@@ -47,6 +47,8 @@ SIGNATURES = {
     'bxi_check_device': (c_int, [c_int]),
     'bxi_dev_set_launch_hook': (None, [c_void_p, c_void_p]),           # boxinst_hip_dev.h (bench / tests only)
     'bxi_dev_set_tree_level_walk': (None, [c_int]),                    # boxinst_hip_dev.h (tests only)
+    'bxi_dev_sol_eval_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                     c_void_p]),                        # boxinst_hip_dev.h (bench only)
     'bxi_pairwise_nlog_forward_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'bxi_pairwise_nlog_forward_f64': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'bxi_pairwise_nlog_backward_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -75,6 +77,7 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, C.c_uint, c_void_p]),
     'bxi_boxinst_grad_rescale_f32': (c_int, [C.POINTER(Instances), c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                              c_void_p]),
+    'bxi_boxinst_grad_rescale_nhw_f32': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'bxi_dynamic_mask_forward_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'bxi_dynamic_mask_backward_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),

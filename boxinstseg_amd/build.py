@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libboxinst_hip.so')
-SOURCES = ['abi.hip', 'pairwise_op.hip', 'color_affinity.hip', 'mask_loss.hip', 'fused_eval.hip', 'dynamic_head.hip', 'dynamic_head_generic.hip', 'meanfield.hip', 'levelset.hip', 'tree_filter.hip', 'tree_filter_large.hip']
+SOURCES = ['abi.hip', 'pairwise_op.hip', 'color_affinity.hip', 'mask_loss.hip', 'fused_eval.hip', 'dynamic_head.hip', 'dynamic_head_generic.hip', 'meanfield.hip', 'levelset.hip', 'tree_filter.hip', 'tree_filter_large.hip', 'sol_eval.hip']
 HEADERS = ['common.hpp', 'image_device.hpp', 'loss_common.hpp', 'dynamic_head_device.hpp', 'srgb_lut.h', os.path.join('..', '..', 'include', 'boxinst_hip.h'),
            os.path.join('..', '..', 'include', 'boxinst_hip_dev.h')]
 ARCH = 'gfx950'

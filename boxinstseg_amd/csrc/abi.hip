@@ -21,6 +21,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
                       const float* up_pw, float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, unsigned flags,
                       void* stream, const DynArgs* head = nullptr, int head_C = 0);
 int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits, void* stream);
+int launch_rescale_nhw(int N, int h, int w, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits, void* stream);
 
 static inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -129,6 +130,10 @@ int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_insta
 int bxi_boxinst_grad_rescale_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw, int dilation,
                                  const void* state, float* g_logits, void* stream) {
     return bxi::launch_rescale(inst_host, g_prj, g_pw, dilation, state, g_logits, stream);
+}
+int bxi_boxinst_grad_rescale_nhw_f32(int N, int h, int w, const float* g_prj, const float* g_pw, int dilation, const void* state,
+                                     float* g_logits, void* stream) {
+    return bxi::launch_rescale_nhw(N, h, w, g_prj, g_pw, dilation, state, g_logits, stream);
 }
 
 }  // extern "C"

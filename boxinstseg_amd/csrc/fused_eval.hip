@@ -58,7 +58,6 @@ constexpr int kSpinLimit = 250000;              // bounded waits (0.3 - 1 us per
 constexpr unsigned kFlagSingle = 1u, kFlagTwo = 2u, kFlagNoStay = 4u, kFlagRows8 = 8u, kFlagShared = 16u, kFlagGiveUp = 256u;
 constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
 constexpr int kAcc1Words = 64;                  // count-wave arrivals + sum W: 64 words, each in its own 128 bytes
-constexpr int kDirectWords = 16;                // all-resident form: the pool workgroups' count arrivals go to the first 16 of them
 constexpr int kMaxInst = 65536;
 #ifndef BXI_ONE_OCC
 #define BXI_ONE_OCC 4
@@ -81,7 +80,7 @@ constexpr unsigned long long kArrivalFault = 1ull << 50, kCountFault = 1ull << 3
 #define BXI_TW(kid, idx, ph) do {} while (0)
 #endif
 
-// developer build (-DBXI_ABLATE, tools/ablate.sh): switch parts of the evaluation OFF (results become wrong) to see, without the
+// developer build (-DBXI_ABLATE, tools/ablate.py): switch parts of the evaluation OFF (results become wrong) to see, without the
 // distortion of a trace, what the step time is sensitive to.  Never in the shipped library: BXI_AB(x) is the constant false there.
 #ifdef BXI_ABLATE
 static __device__ int g_ablate = 0;
@@ -308,7 +307,7 @@ struct LogitRows {
 
 template <bool ONE, typename Src>
 __device__ __forceinline__ void stream_block(const InstArgs& a, const Ws& ws, float* __restrict__ g_logits, int vec, int sb,
-                                             unsigned long long* colp /* LDS [kWaves][w] */, const Src& src, int tix, int zf = 0) {
+                                             unsigned long long* colp /* LDS [kWaves][w] */, const Src& src, int tix) {
     const int h = a.h, w = a.w;
     const int Sn = (h + kSBlk - 1) / kSBlk;
     const int n = sb / Sn, s = sb % Sn;
@@ -318,10 +317,7 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const Ws& ws, fl
     float* G = g_logits ? g_logits + (int64_t)n * P : nullptr;
     const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 
-    // zero-fill of d loss / d logits (depends on nothing); written through: drains while the launch is still reading.
-    // zf: 0 = before the loads are issued, 1 = right behind the first loads, 2 = after the maxima (just before the band flag)
-    auto zero_fill = [&]() {
-        if (!G || BXI_AB(16)) return;
+    if (G && !BXI_AB(16))   // zero-fill of d loss / d logits (depends on nothing); written through: drains while the launch is still reading
         for (int cb = 0; cb < w; cb += kChunkC) {
             const int c = cb + lane * 4;
             if (c < w) {
@@ -335,15 +331,12 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const Ws& ws, fl
                     }
             }
         }
-    };
-    if (zf == 0) zero_fill();
     float4 v[kSRows];
     {
         const int c = lane * 4;
 #pragma unroll
         for (int i = 0; i < kSRows; ++i) v[i] = (r0 + i < r1 && c < w && !BXI_AB(64)) ? src(r0 + i, c) : ninf;
     }
-    if (zf == 1) zero_fill();
     BXI_TW(0, tix, 1);
     float rmax[kSRows]; int rcol[kSRows];
 #pragma unroll
@@ -417,7 +410,6 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const Ws& ws, fl
         if (ONE) __hip_atomic_store(&ws.colpart[((int64_t)n * Sn + s) * w + c], k, BXI_RLX, BXI_AGENT);
         else ws.colpart[((int64_t)n * Sn + s) * w + c] = k;       // larger value, then smaller row
     }
-    if (zf >= 2) zero_fill();
     if (ONE) {
         // single-launch form: this band's zero-fill and partial maxima are in memory (every wave drains its own stores, the
         // workgroup meets) before the band's flag says so to the instance's leader and to the tile waves that add onto these rows
@@ -455,148 +447,18 @@ __device__ __forceinline__ void pool_load(const PoolArgs& pa, int item, int segs
     }
 }
 
-
 __device__ __forceinline__ float n2_of(float L0, float A0, float B0, float L1, float A1, float B1) {
     const float dL = L0 - L1, dA = A0 - A1, dB = B0 - B1;     // un-fused: the decision must equal get_image_color_similarity's (:237)
     return __fadd_rn(__fadd_rn(__fmul_rn(dL, dL), __fmul_rn(dA, dA)), __fmul_rn(dB, dB));
 }
-struct ValidCells { int vrow[BXI_MAX_IMAGES], vcol[BXI_MAX_IMAGES]; };   // per image: valid(q) <=> row(q) < vrow && col(q) < vcol (host: :1354-1369,:1405)
-__device__ __forceinline__ float lane_plus_n(float v, int d) {
-    int x = __float_as_int(v);
-    for (int s = 0; s < d; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
-    return __int_as_float(x);
-}
-__device__ __forceinline__ float lane_minus_n(float v, int d) {
-    int x = __float_as_int(v);
-    for (int s = 0; s < d; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
-    return __int_as_float(x);
-}
 
-// What the pairs of ONE step site (r, c) add to  sum W = sum_n sum_{p in box n} sum_k [sim_k(p) >= thresh]  (:1324-1328), given the
-// site's four colour predicates (p0: (r,c)-(r,c+D); p1: (r+D,c)-(r,c+D); p2: (r,c)-(r+D,c); p3: (r,c)-(r+D,c+D); each already false where a
-// pixel lies outside the map): a pair (p, q) weighs [p in box n][q valid] + [q in box n][p valid] for every instance n of the image.
-// `rect` = lane n's table entry of instance n (first 64 instances; further ones are fetched here).  Every lane of the wave must call.
-template <bool ONE>
-__device__ __forceinline__ int site_weight(const InstArgs& a, const ValidCells& vc, const Ws& ws, int D, int b, int r, int c, bool p0, bool p1, bool p2,
-                                           bool p3, int4 rect, int spin_limit, bool& ok) {
-    const int lane = threadIdx.x & 63, cn = c + D;
-    const int vrow = vc.vrow[b], vcol = vc.vcol[b];
-    const bool v00 = r < vrow && c < vcol, v0n = r < vrow && cn < vcol, vD0 = r + D < vrow && c < vcol, vDn = r + D < vrow && cn < vcol;
-    // what a box containing the site adds:  (r, c)  (r, c+D)  (r+D, c)  (r+D, c+D)
-    const int s00 = (p0 && v0n) + (p2 && vD0) + (p3 && vDn), s0n = (p0 && v00) + (p1 && vD0), sD0 = (p1 && v0n) + (p2 && v00), sDn = (p3 && v00) ? 1 : 0;
-    int cnt = 0;
-    for (int m0 = 0; m0 < a.N; m0 += 64) {
-        if (m0) {
-            if (!tab_entry<ONE>(ws, m0 + lane, m0 + lane < a.N, spin_limit, rect)) { ok = false; return 0; }
-            if (m0 + lane >= a.N) rect = make_int4(-1, 0, 0, 0);
-        }
-        // the instances of this image whose rows reach r or r + D: usually a handful
-        const int q0 = rect.y & 0xffff, q1 = (int)((unsigned int)rect.y >> 16);
-        unsigned long long mask = __ballot(m0 + lane < a.N && (int)((unsigned int)rect.x >> 24) == b && ((r >= q0 && r < q1) || (r + D >= q0 && r + D < q1)));
-        while (mask) {
-            const int n = __ffsll((long long)mask) - 1;
-            mask &= mask - 1ull;
-            const int ry = __builtin_amdgcn_readlane(rect.y, n), rz = __builtin_amdgcn_readlane(rect.z, n);
-            const int r0 = ry & 0xffff, r1 = (int)((unsigned int)ry >> 16), c0 = rz & 0xffff, c1 = (int)((unsigned int)rz >> 16);
-            const bool rr = r >= r0 && r < r1, rD2 = r + D >= r0 && r + D < r1;
-            const bool c_in = c >= c0 && c < c1, n_in = cn >= c0 && cn < c1;
-            cnt += (rr && c_in ? s00 : 0) + (rr && n_in ? s0n : 0) + (rD2 && c_in ? sD0 : 0) + (rD2 && n_in ? sDn : 0);
-        }
-    }
-    return cnt;
-}
-__device__ __forceinline__ void store_pred(const Ws& ws, int64_t site, bool p0, bool p1, bool p2, bool p3) {
-    // the evaluation's tag = "evaluated"; written through (sc1), read past the caches
-    __hip_atomic_store(ws.pred + site, (ws.ep << 4) | (p0 ? 1u : 0u) | (p1 ? 2u : 0u) | (p2 ? 4u : 0u) | (p3 ? 8u : 0u), BXI_RLX, BXI_AGENT);
-}
-
-// ---- the colour predicates by the POOL workgroups (single-launch form) --------------------------------------------------------------
-// The window of pool item (b, r, seg) -- the 64 pooled pixels (r, co), co = 64 seg + lane -- holds the step sites whose LAST pixel (in
-// raster order) is one of them: every pair is then between this item's row r and the row D above it, in columns co - D .. co, i.e.
-// pixels of items that PRECEDE this one.  With the items dealt to the pool workgroups in contiguous runs, a window only ever waits for
-// workgroups that precede its own in the grid (and wait for nobody while they pool), so the pool workgroups evaluate the predicates
-// themselves -- no predicate workgroups that first need an execution slot to come free (1.5 - 2 us behind the last Lab record), and no
-// wait on a workgroup that may not be resident.  Sites per lane:
-//   (a) r >= D:                      (r - D, co - D): all four pairs          A = (r-D, co-D)  B = (r-D, co)  C = (r, co-D)  own = (r, co)
-//   (b) r >= D, co >= w - D:         (r - D, co):     only the vertical pair (no column co + D):  B - own
-//   (c) r >= h - D:                  (r, co - D):     only the horizontal pair (no row r + D):    C - own
-//   (d) r >= h - D, co >= w - D:     (r, co):         no pair at all (the word still has to carry the tag)
-// so every site of the map is written exactly once.  B comes from item (r - D, seg); A and C are B and own shifted by D lanes, except
-// in the first D lanes, which fetch them from the last columns of segment seg - 1.  `own`: the wave that stored the record hands its
-// registers over (own_reg); other waves read it back.  Returns this lane's share of sum W; ok = false: a bounded wait ran out.
-__device__ __forceinline__ int pool_window(const InstArgs& a, const ValidCells& vc, const Ws& ws, int D, float n2max, int item, int segs, int spin_limit,
-                                           bool own_reg, float oL, float oA, float oB, bool& ok) {
-    const int h = a.h, w = a.w, lane = threadIdx.x & 63;
-    const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
-    const int co = seg * 64 + lane, cs = co - D;
-    const bool up = r >= D, act = co < w, edge = lane < D && seg > 0;      // up: wave-uniform
-    const float4* L4 = ws.lab4 + (int64_t)b * h * w;
-    const void* tab0 = ws.tab;                                             // a record that carries the tag as soon as the table is out
-    const void* pB = up && act ? (const void*)(L4 + (int64_t)(r - D) * w + co) : tab0;
-    const void* pA = up && act && edge ? (const void*)(L4 + (int64_t)(r - D) * w + cs) : tab0;
-    const void* pC = act && edge ? (const void*)(L4 + (int64_t)r * w + cs) : tab0;
-    const void* pO = act && !own_reg ? (const void*)(L4 + (int64_t)r * w + co) : tab0;
-    u4v qB, qA, qC, qO, qe;
-    bool got = false;
-    // A wave that polled all of this while it waits would re-read 5 KB past the caches per round -- with every pool workgroup doing
-    // so while the image stream is still saturating HBM, the polling alone would be HBM-peak traffic (measured: +2 us per evaluation).
-    // So the wait itself is ONE 16-byte record for the whole wave (every lane asks for the same address: one request): the last
-    // pixel of the item D rows up, whose wave stores its 64 records with one instruction.  Only then the full, verifying round.
-    if (up) {
-        const void* probe = L4 + (int64_t)(r - D) * w + min(seg * 64 + 63, w - 1);
-        for (int spins = 0; spins <= spin_limit; ++spins) {
-            if (load16_past(probe).w == ws.ep) break;
-            __builtin_amdgcn_s_sleep(24);
-        }
-    }
-    for (int spins = 0; spins <= spin_limit; ++spins) {
-        load16_past_x5(pB, pA, pC, pO, ws.tab + (lane < a.N ? lane : 0), qB, qA, qC, qO, qe);
-        if (__all(qB.w == ws.ep && qA.w == ws.ep && qC.w == ws.ep && qO.w == ws.ep && qe.w == ws.ep)) { got = true; break; }
-        __builtin_amdgcn_s_sleep(16);
-    }
-    if (!got) { ok = false; return 0; }
-    const int4 rect = lane < a.N ? make_int4((int)qe.x, (int)qe.y, (int)qe.z, (int)qe.w) : make_int4(-1, 0, 0, 0);
-    if (!own_reg) { const float4 o = f4_of(qO); oL = o.x; oA = o.y; oB = o.z; }
-    const float4 Bv = f4_of(qB);
-    float AL = lane_minus_n(Bv.x, D), AA = lane_minus_n(Bv.y, D), AB = lane_minus_n(Bv.z, D);
-    float CL = lane_minus_n(oL, D), CA = lane_minus_n(oA, D), CB = lane_minus_n(oB, D);
-    if (lane < D) { const float4 ea = f4_of(qA), ec = f4_of(qC); AL = ea.x; AA = ea.y; AB = ea.z; CL = ec.x; CA = ec.y; CB = ec.z; }
-    const bool left = act && (lane >= D || seg > 0);                       // the site D columns to the left exists (cs >= 0)
-    const bool tail = act && co >= w - D;                                  // no column co + D
-    const int64_t row0 = ((int64_t)b * h + r) * w;
-    int cnt = 0;
-    if (up) {
-        const bool p0 = left && n2_of(AL, AA, AB, Bv.x, Bv.y, Bv.z) <= n2max;
-        const bool p1 = left && n2_of(CL, CA, CB, Bv.x, Bv.y, Bv.z) <= n2max;
-        const bool p2 = left && n2_of(AL, AA, AB, CL, CA, CB) <= n2max;
-        const bool p3 = left && n2_of(AL, AA, AB, oL, oA, oB) <= n2max;
-        if (left) store_pred(ws, row0 - (int64_t)D * w + cs, p0, p1, p2, p3);
-        cnt += site_weight<true>(a, vc, ws, D, b, r - D, cs, p0, p1, p2, p3, rect, spin_limit, ok);
-        if (__any(tail)) {                                                 // the last segment of a row only
-            const bool q2 = tail && n2_of(Bv.x, Bv.y, Bv.z, oL, oA, oB) <= n2max;
-            if (tail) store_pred(ws, row0 - (int64_t)D * w + co, false, false, q2, false);
-            cnt += site_weight<true>(a, vc, ws, D, b, r - D, co, false, false, q2, false, rect, spin_limit, ok);
-        }
-    }
-    if (r >= h - D) {                                                      // wave-uniform: the last D rows have no row r + D
-        const bool q0 = left && n2_of(CL, CA, CB, oL, oA, oB) <= n2max;
-        if (left) store_pred(ws, row0 + cs, q0, false, false, false);
-        cnt += site_weight<true>(a, vc, ws, D, b, r, cs, q0, false, false, false, rect, spin_limit, ok);
-        if (tail) store_pred(ws, row0 + co, false, false, false, false);
-    }
-    return cnt;
-}
-
-// items first, first + step, ... < n_items.  `pw` != nullptr (single-launch form, step == 1: a contiguous run of items): the workgroup
-// also evaluates the colour predicates of its items' windows (pool_window) and arrives once with their share of sum W.
-struct PoolPred { const InstArgs* a; const ValidCells* vc; int D; float n2max; int spin_limit; };
+// items first, first + step, ... < n_items
 __device__ __forceinline__ void pool_block(const PoolArgs& pa, const Ws& ws, int first, int step, int n_items, double* lut /*[256]*/,
-                                           int* part /*[4][3][64]*/, double* fch /*[3][64]*/, int tix, const PoolPred* pw = nullptr) {
+                                           int* part /*[4][3][64]*/, double* fch /*[3][64]*/, int tix) {
     const int h = pa.Hc >> 2, w = pa.Wc >> 2;
     const int segs = (w + 63) >> 6;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float4 v[3], nx[3];
-    float ownL = 0.f, ownA = 0.f, ownB = 0.f;            // wave 3: the Lab record it stored last (the last item's)
     pool_load(pa, first, segs, h, w, v);
     lut[threadIdx.x] = kSrgbLut[threadIdx.x];            // staged while the image loads fly
     for (int item = first; item < n_items; item += step) {
@@ -648,35 +510,13 @@ __device__ __forceinline__ void pool_block(const PoolArgs& pa, const Ws& ws, int
             const double f0 = fch[lane], f1 = fch[64 + lane], f2 = fch[128 + lane];
             // the fourth component is this evaluation's tag: a predicate wave of the SAME launch (single-launch form) re-reads a pixel
             // until it carries it; the record is one 16-byte store, written through
-            ownL = (float)__dadd_rn(__dmul_rn(116.0, f1), -16.0); ownA = (float)__dmul_rn(500.0, __dadd_rn(f0, -f1));
-            ownB = (float)__dmul_rn(200.0, __dadd_rn(f1, -f2));
-            store4_through(reinterpret_cast<float*>(ws.lab4 + ((int64_t)b * h + r) * w + c), ownL, ownA, ownB, __uint_as_float(ws.ep));
+            store4_through(reinterpret_cast<float*>(ws.lab4 + ((int64_t)b * h + r) * w + c), (float)__dadd_rn(__dmul_rn(116.0, f1), -16.0),
+                           (float)__dmul_rn(500.0, __dadd_rn(f0, -f1)), (float)__dmul_rn(200.0, __dadd_rn(f1, -f2)), __uint_as_float(ws.ep));
         }
         // the next trip's `part` writes come after this barrier; its `fch` writes after the next one, which wave 3 reaches only
         // after it has read `fch` here: no extra barrier needed
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) v[ch] = nx[ch];
-    }
-    if (pw) {                                             // workgroup-uniform
-        // the windows of this workgroup's items: the last one by the wave that holds its record in registers (the critical one: it
-        // starts while the record's store is still on its way), the earlier ones by the other three waves, from memory
-        const int n_mine = n_items - first;               // step == 1
-        int cnt = 0;
-        bool ok = true;
-        if (wv == 3) cnt = pool_window(*pw->a, *pw->vc, ws, pw->D, pw->n2max, n_items - 1, segs, pw->spin_limit, true, ownL, ownA, ownB, ok);
-        else
-            for (int k = wv; k < n_mine - 1; k += 3) cnt += pool_window(*pw->a, *pw->vc, ws, pw->D, pw->n2max, first + k, segs, pw->spin_limit, false, 0.f, 0.f, 0.f, ok);
-        cnt = wave_total_i32(cnt);
-        BXI_TW(0, tix, 5);
-        lds_barrier();                                    // `part` is free again
-        if (lane == 0) { part[wv] = cnt; part[4 + wv] = ok ? 0 : 1; }
-        lds_barrier();
-        if (threadIdx.x == 0)     // ONE arrival per workgroup: (windows evaluated, sum W); integer adds commute: run-to-run identical
-            __hip_atomic_fetch_add(&ws.acc1[(size_t)(blockIdx.x & (kDirectWords - 1)) * kAcc2Stride],
-                                   ((unsigned long long)(unsigned int)n_mine << 40) | (unsigned long long)(unsigned int)((part[0] + part[1]) + (part[2] + part[3])) |
-                                       (((part[4] | part[5]) | (part[6] | part[7])) ? kCountFault : 0ull),
-                                   BXI_RLX, BXI_AGENT);
-        BXI_TW(0, tix, 6);
     }
 }
 
@@ -915,6 +755,12 @@ __device__ __forceinline__ void load_plane(const float* __restrict__ plane, cons
 // segment's share of  sum W = sum_n sum_{p in box n} sum_k [sim_k(p) >= thresh]  (:1324-1328): a pair (p, q) weighs
 // [p in box n][q valid] + [q in box n][p valid] for every instance n of the image (returned per lane; the workgroup arrives
 // once with its total).  A byte carries its own "evaluated" bit: a tile wave re-reads the few bytes it needs until they have it.
+__device__ __forceinline__ float lane_plus_n(float v, int d) {
+    int x = __float_as_int(v);
+    for (int s = 0; s < d; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+    return __int_as_float(x);
+}
+struct ValidCells { int vrow[BXI_MAX_IMAGES], vcol[BXI_MAX_IMAGES]; };   // per image: valid(q) <=> row(q) < vrow && col(q) < vcol (host: :1354-1369,:1405)
 template <bool ONE>
 __device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc, const Ws& ws, int D, float n2max, int item, int segs, int spin_limit, bool& ok) {
     const int h = a.h, w = a.w, lane = threadIdx.x & 63;
@@ -956,8 +802,32 @@ __device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc
     const bool p1 = cin && nin && rowD && n2_of(oD.x, oD.y, oD.z, nL, nA, nB) <= n2max;
     const bool p2 = cin && rowD && n2_of(o0.x, o0.y, o0.z, oD.x, oD.y, oD.z) <= n2max;
     const bool p3 = cin && nin && rowD && n2_of(o0.x, o0.y, o0.z, mL, mA, mB) <= n2max;
-    if (cin) store_pred(ws, ((int64_t)b * h + r) * w + c, p0, p1, p2, p3);
-    return site_weight<ONE>(a, vc, ws, D, b, r, c, p0, p1, p2, p3, rect, spin_limit, ok);
+    if (cin) __hip_atomic_store(ws.pred + ((int64_t)b * h + r) * w + c, (ws.ep << 4) | (p0 ? 1u : 0u) | (p1 ? 2u : 0u) | (p2 ? 4u : 0u) | (p3 ? 8u : 0u),
+                                BXI_RLX, BXI_AGENT);     // the evaluation's tag = "evaluated"; written through (sc1), read past the caches
+    const int vrow = vc.vrow[b], vcol = vc.vcol[b];
+    const bool v00 = r < vrow && c < vcol, v0n = r < vrow && cn < vcol, vD0 = r + D < vrow && c < vcol, vDn = r + D < vrow && cn < vcol;
+    // what a box containing the site adds:  (r, c)  (r, c+D)  (r+D, c)  (r+D, c+D)
+    const int s00 = (p0 && v0n) + (p2 && vD0) + (p3 && vDn), s0n = (p0 && v00) + (p1 && vD0), sD0 = (p1 && v0n) + (p2 && v00), sDn = (p3 && v00) ? 1 : 0;
+    int cnt = 0;
+    for (int m0 = 0; m0 < a.N; m0 += 64) {
+        if (m0) {
+            if (!tab_entry<ONE>(ws, m0 + lane, m0 + lane < a.N, spin_limit, rect)) { ok = false; return 0; }
+            if (m0 + lane >= a.N) rect = make_int4(-1, 0, 0, 0);
+        }
+        // the instances of this image whose rows reach r or r + D: usually a handful
+        const int q0 = rect.y & 0xffff, q1 = (int)((unsigned int)rect.y >> 16);
+        unsigned long long mask = __ballot(m0 + lane < a.N && (int)((unsigned int)rect.x >> 24) == b && ((r >= q0 && r < q1) || (r + D >= q0 && r + D < q1)));
+        while (mask) {
+            const int n = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            const int ry = __builtin_amdgcn_readlane(rect.y, n), rz = __builtin_amdgcn_readlane(rect.z, n);
+            const int r0 = ry & 0xffff, r1 = (int)((unsigned int)ry >> 16), c0 = rz & 0xffff, c1 = (int)((unsigned int)rz >> 16);
+            const bool rr = r >= r0 && r < r1, rD2 = r + D >= r0 && r + D < r1;
+            const bool c_in = c >= c0 && c < c1, n_in = cn >= c0 && cn < c1;
+            cnt += (rr && c_in ? s00 : 0) + (rr && n_in ? s0n : 0) + (rD2 && c_in ? sD0 : 0) + (rD2 && n_in ? sDn : 0);
+        }
+    }
+    return cnt;
 }
 
 // sum W, once every pooled row segment has been evaluated: ONE word for the (hundreds of) askers; the reducer -- one wave of the
@@ -968,18 +838,6 @@ __device__ __forceinline__ bool counts_complete(const Ws& ws, int n_items, doubl
     *total = (double)(x & (kSumwFault - 1ull));                         // exact: an integer far below 2^53
     if ((x >> 63) != 0ull && (x & kSumwFault)) *fault = true;
     return (x >> 63) != 0ull;
-}
-// The same without a reducer in between (all-resident form): the pool workgroups arrive on kDirectWords count words (16: ~50 arrivals
-// each, ~13 ns apiece), and whoever needs sum W reads all of them with ONE load instruction -- a hop less between the last predicate and
-// the tile waves than count words -> reducer -> published word.
-__device__ __forceinline__ bool counts_complete_direct(const Ws& ws, int n_items, double* total, bool* fault) {
-    const int lane = threadIdx.x & 63;
-    const unsigned long long x = __hip_atomic_load(&ws.acc1[(size_t)(lane & (kDirectWords - 1)) * kAcc2Stride], BXI_RLX, BXI_AGENT);
-    const unsigned long long mine = lane < kDirectWords ? x : 0ull;
-    const int arrived = wave_total_i32((int)(mine >> 40));
-    *total = wave_total_f64((double)(mine & (kCountFault - 1ull)));                 // exact
-    if (__any((mine & kCountFault) != 0ull)) *fault = true;
-    return arrived == n_items;
 }
 __device__ __forceinline__ bool reduce_counts(const Ws& ws, int n_items, int spin_limit) {
     for (int spins = 0; spins <= spin_limit; ++spins) {
@@ -1041,7 +899,7 @@ __device__ __forceinline__ bool pred_words(const Ws& ws, const Tile& t, int h, i
 template <int D, int R, bool ONE>
 __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float upw_warm, float n2max, int zero_bit, int n_items,
                                           int spin_limit, float& scale, bool& have_scale, float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
-                                          int tix, long long& fx_sum, bool& bad_out, bool direct) {
+                                          int tix, long long& fx_sum, bool& bad_out) {
     constexpr int RD = TG<D, R>::RD;
     const int lane = threadIdx.x & 63;
     const int h = a.h, w = a.w, n = t.n;
@@ -1150,7 +1008,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
             }
             if (!have_scale) {
                 if (zero_bit) { total_w = total_weight_all_pairs(a, ws); have_scale = true; }
-                else have_scale = direct ? counts_complete_direct(ws, n_items, &total_w, &bad) : counts_complete(ws, n_items, &total_w, &bad);
+                else have_scale = counts_complete(ws, n_items, &total_w, &bad);
                 if (have_scale) scale = upw_warm / fmaxf((float)total_w, 1.f);
             }
             bands_ok = f0 == ws.ep && f1 == ws.ep;
@@ -1365,8 +1223,7 @@ __device__ __forceinline__ bool locate_tile(const Ws& ws, const ValidCells& vc, 
 // ---- the roles of the second launch (two-launch form) / of the back half of the single launch ----------------------------------
 // predicate workgroup `pblk` of n_pb: 4 independent waves striding through the pooled row segments
 template <int D, bool ONE>
-__device__ __forceinline__ void pred_role(const InstArgs& a, const ValidCells& vc, const Ws& ws, float n2max, int pblk, int n_pb, int n_items, int spin_limit,
-                                          bool direct = false) {
+__device__ __forceinline__ void pred_role(const InstArgs& a, const ValidCells& vc, const Ws& ws, float n2max, int pblk, int n_pb, int n_items, int spin_limit) {
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int segs = (a.w + 63) >> 6, pid = pblk * kWaves + wave;
     BXI_TW(2, pid, 0);
@@ -1381,7 +1238,7 @@ __device__ __forceinline__ void pred_role(const InstArgs& a, const ValidCells& v
     if (lane == 0) { pred_cnt[wave] = cnt; pred_seg[wave] = segments; pred_bad[wave] = ok ? 0 : 1; }
     __syncthreads();
     if (threadIdx.x == 0)    // (segments evaluated, sum W); integer adds commute: run-to-run identical
-        __hip_atomic_fetch_add(&ws.acc1[(size_t)(pblk & ((direct ? kDirectWords : kAcc1Words) - 1)) * kAcc2Stride],
+        __hip_atomic_fetch_add(&ws.acc1[(size_t)(pblk & (kAcc1Words - 1)) * kAcc2Stride],
                                ((unsigned long long)(unsigned int)((pred_seg[0] + pred_seg[1]) + (pred_seg[2] + pred_seg[3])) << 40) |
                                    (unsigned long long)(unsigned int)((pred_cnt[0] + pred_cnt[1]) + (pred_cnt[2] + pred_cnt[3])) |
                                    (((pred_bad[0] | pred_bad[1]) | (pred_bad[2] | pred_bad[3])) ? kCountFault : 0ull),      // loud
@@ -1404,7 +1261,7 @@ __device__ __forceinline__ void reducer_role(const Ws& ws, int zero_bit, int n_i
 // the tile waves -- and writes the two loss values
 template <bool ONE>
 __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, const LossState& st, float upp, float upw, float warmup, int zero_bit, int n_items,
-                                              int spin_limit, int R, int n_tile_waves, float* __restrict__ losses, bool direct = false) {
+                                              int spin_limit, int R, int n_tile_waves, float* __restrict__ losses) {
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int N = a.N;
     BXI_TW(3, 0, 0);
@@ -1427,7 +1284,7 @@ __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, c
         }
         if (zero_bit) total_w = total_weight_all_pairs(a, ws);
         else
-            while (ok && !(direct ? counts_complete_direct(ws, n_items, &total_w, &flt0) : counts_complete(ws, n_items, &total_w, &flt0))) {
+            while (ok && !counts_complete(ws, n_items, &total_w, &flt0)) {
                 if (++spins > spin_limit) ok = false;
                 __builtin_amdgcn_s_sleep(8);
             }
@@ -1486,7 +1343,7 @@ __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, c
 // tile workgroup: 4 independent waves striding through the tile list (its length is device data)
 template <int D, int R, bool ONE>
 __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& vc, const Ws& ws, float upw_warm, float n2max, int zero_bit, int n_items, int spin_limit,
-                                          float* __restrict__ g_logits, unsigned char* smem, int tblk, int n_tb, bool direct = false) {
+                                          float* __restrict__ g_logits, unsigned char* smem, int tblk, int n_tb) {
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int N = a.N;
     const int wid = tblk * kWaves + wave, nwaves = n_tb * kWaves;
@@ -1508,7 +1365,7 @@ __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& v
         Tile t;
         if (!locate_tile<D, R, ONE>(ws, vc, N, e0, ti, a.h, a.w, spin_limit, t)) { bad = true; break; }
         BXI_TW(1, wid, 1);
-        math_tile<D, R, ONE>(a, ws, t, upw_warm, n2max, zero_bit, n_items, spin_limit, scale, have_scale, g_logits, gbuf, wid, fx_sum, bad, direct);
+        math_tile<D, R, ONE>(a, ws, t, upw_warm, n2max, zero_bit, n_items, spin_limit, scale, have_scale, g_logits, gbuf, wid, fx_sum, bad);
     }
     tile_wave_arrives(ws, N, wid, fx_sum, bad);
     BXI_TW(1, wid, 7);
@@ -1562,36 +1419,25 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair_ker
 template <int D>
 __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_pool, int n_items, int n_pb, int n_tb, InstArgs a, Ws ws_in, LossState st, ValidCells vc,
                                                         const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup, float n2max, int spin_limit,
-                                                        float* __restrict__ losses, float* __restrict__ g_logits, int vec_zf, int merge) {
+                                                        float* __restrict__ losses, float* __restrict__ g_logits, int vec, int merge) {
     constexpr int R = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[16];
     const Ws ws = with_tag(ws_in);
-    const int vec = vec_zf & 1, zf = vec_zf >> 4;           // (one kernel argument for both)
     const int N = a.N;
     constexpr int n_tab = 0;                                  // (trace index layout: table, stream, pool)
     const int Sn = (a.h + kSBlk - 1) / kSBlk;
     const int n_stream = N * Sn;
     const int blk = (int)blockIdx.x;
-    // role of this workgroup: 0 stream, 1 pool, 2 leader, 3 predicate, 4 tile, 5 finisher, 6 reducer.
-    // merge bit 0: the stream workgroups stay on as tile workgroups.  merge bit 1: the ALL-RESIDENT form -- the grid is
-    // [stream][pool][(tile)][finisher]: the pool workgroups evaluate the colour predicates of their own items' windows (n_pb == 0) and
-    // then stay on as tile workgroups too, stream workgroup (n, band 0) is instance n's leader before it turns to tiles, and sum W is
-    // read from the count words directly (no reducer).  Nothing in the launch waits for an execution slot to come free: the two slot
-    // hand-overs of the round-3 grid (pool -> predicate workgroups, pool -> leaders / tile workgroups, ~1.75 us each) are gone.
-    const bool stay = (merge & 1) != 0, resident = (merge & 2) != 0, direct = (merge & 6) != 0;     // bit 2: no reducer, sum W read from the count words
-    int role, idx = blk, tblk = 0, lead_n = 0;
+    // role of this workgroup: 0 stream, 1 pool, 2 leader, 3 predicate, 4 tile, 5 finisher, 6 reducer
+    int role, idx = blk;
     if (idx < n_stream) role = 0;
     else if ((idx -= n_stream) < n_pool) role = 1;
-    else {
-        idx -= n_pool;
-        const int n_red = direct ? 0 : 1, n_lead = resident ? 0 : N;
-        if (idx < n_pb) role = 3;
-        else if ((idx -= n_pb) < n_red) role = 6;                      // the reducer
-        else if ((idx -= n_red) < n_lead) { role = 2; lead_n = idx; }
-        else if ((idx -= n_lead) < n_tb) { role = 4; tblk = idx + (stay ? n_stream : 0) + (resident ? n_pool : 0); }
-        else role = 5;
-    }
+    else if ((idx -= n_pool) < n_pb) role = 3;
+    else if ((idx -= n_pb) < 1) role = 6;                              // the reducer
+    else if ((idx -= 1) < N) role = 2;
+    else if ((idx -= N) < n_tb) role = 4;
+    else role = 5;
     const int tix = (n_tab + (role == 0 ? idx : n_stream + idx)) * kWaves + (int)(threadIdx.x >> 6);
     (void)tix;
     if (role == 0) {
@@ -1600,53 +1446,41 @@ __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_
         // of its own would be the one workgroup too many for the front half to be resident at once at the headline size
         if ((threadIdx.x >> 6) == 0 && 64 * idx <= N) table_wave(a, pa.meta, D, R, ws, st, idx, false);
         const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
-        stream_block<true>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix, zf);
+        stream_block<true>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);
         BXI_TW(0, tix, 7);
-        if (!stay) return;
+        if (!merge) return;
         // ... and stays as a tile workgroup: its four waves are the first tile waves, resident since the start of the launch, so their
         // table -> tile -> logits -> per-pixel chain runs while the pool workgroups finish instead of behind a slot that has to come
         // free first.  (It now waits for predicate workgroups LATER in the grid.  Those wait only for pool workgroups, which wait for
         // nobody, and the host launches this form only while the stream workgroups leave at least half of the slots free: a
         // predicate workgroup always finds a slot.)
-        __syncthreads();                                                   // the column-partial LDS becomes the next role's scratch
-        tblk = idx;
-        if (resident && idx % Sn == 0) { role = 2; lead_n = idx / Sn; }    // first the instance's leader (its other bands' workgroups are resident)
-        else role = 4;
+        __syncthreads();                                                   // the column-partial LDS becomes the tile waves' scratch
+        role = 4;
+        idx -= n_stream;                                                   // tile workgroup index idx + n_stream below
     }
     if (role == 1) {
         BXI_TW(0, tix, 0);
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
         int* part = reinterpret_cast<int*>(fch + 3 * 64);
-        if (n_pb == 0) {      // no predicate workgroups: the pool workgroups evaluate the windows of their (contiguous) items themselves
-            const int per = (n_items + n_pool - 1) / n_pool;
-            const PoolPred pw = {&a, &vc, D, n2max, spin_limit};
-            if (idx * per < n_items) pool_block(pa, ws, idx * per, 1, min(n_items, (idx + 1) * per), lut, part, fch, tix, &pw);
-        } else {
-            pool_block(pa, ws, idx, n_pool, n_items, lut, part, fch, tix);
-        }
+        pool_block(pa, ws, idx, n_pool, n_items, lut, part, fch, tix);
         BXI_TW(0, tix, 7);
-        if (!resident) return;
-        __syncthreads();                                                   // ... and stays on as a tile workgroup
-        role = 4;
-        tblk = n_stream + idx;
+        return;
     }
     const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
     if (role == 2) {
-        BXI_TW(3, 1 + lead_n, 0);
-        leader_block<true>(a, D, ws, st, lead_n, upp, g_logits, smem, red, spin_limit);
-        if (!resident) return;
-        __syncthreads();
-        role = 4;
-    }
-    if (role == 3) { pred_role<D, true>(a, vc, ws, n2max, idx, n_pb, n_items, spin_limit, direct); return; }
-    if (role == 6) { reducer_role<true>(ws, 0, n_items, spin_limit); return; }
-    const int n_tile_blocks = n_tb + (stay ? n_stream : 0) + (resident ? n_pool : 0);
-    if (role == 4) {          // ONE call site for the workgroups that stay on and for the tile workgroups proper
-        tile_role<D, R, true>(a, vc, ws, upw * resolve_warmup(warmup, st.iter), n2max, 0, n_items, spin_limit, g_logits, smem, tblk, n_tile_blocks, direct);
+        BXI_TW(3, 1 + idx, 0);
+        leader_block<true>(a, D, ws, st, idx, upp, g_logits, smem, red, spin_limit);
         return;
     }
-    finisher_role<true>(a, ws, st, upp, upw, resolve_warmup(warmup, st.iter), 0, n_items, spin_limit, R, n_tile_blocks * kWaves, losses, direct);
+    if (role == 3) { pred_role<D, true>(a, vc, ws, n2max, idx, n_pb, n_items, spin_limit); return; }
+    if (role == 6) { reducer_role<true>(ws, 0, n_items, spin_limit); return; }
+    if (role == 4) {          // ONE call site for the stream workgroups that stay on and for the tile workgroups proper
+        const int shift = merge ? n_stream : 0;
+        tile_role<D, R, true>(a, vc, ws, upw * resolve_warmup(warmup, st.iter), n2max, 0, n_items, spin_limit, g_logits, smem, idx + shift, n_tb + shift);
+        return;
+    }
+    finisher_role<true>(a, ws, st, upp, upw, resolve_warmup(warmup, st.iter), 0, n_items, spin_limit, R, (n_tb + (merge ? n_stream : 0)) * kWaves, losses);
 }
 
 // ---- rescale: g_logits finished for the factors recorded in `state` -> finished for (g_prj, g_pw) ----------------
@@ -1879,7 +1713,6 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     if (env_one && !(flags & kFlagTwo) && (one_fits || env_one == 2 || (flags & kFlagSingle)) && !head && pooled_in_launch && R == 4 && dil <= 3 &&
         !pr.zero_bit) {
         static const int env_one_pool = env_int("BXI_ONE_POOL_WGS", 0);
-        static const int env_zf = env_int("BXI_ZF", 0);                 // developer knob: when the stream workgroups zero-fill (stream_block)
         const int Sn = (a.h + kSBlk - 1) / kSBlk;
         const int n_stream = a.N * Sn;
         const int slots = one_slots;
@@ -1892,19 +1725,10 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         const int room = env_one_pool > 0 ? env_one_pool : (front > slots / 4 ? front : slots / 4);
         const int per = (n_items + room - 1) / room;
         const int n_pool = (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per);
-        // the colour predicates: by the pool workgroups themselves (windows that depend on earlier items only; n_pb = 0), or by
-        // predicate workgroups of their own behind them (BXI_POOL_PRED=0: the round-3 arrangement, kept for A/B)
-        static const int env_pool_pred = env_int("BXI_POOL_PRED", 0);
         int n_pb = (n_items + kWaves - 1) / kWaves;
         if (n_pb > slots / 2) n_pb = slots / 2;
-        if (env_pool_pred && (int64_t)n_pool * per >= n_items) n_pb = 0;
         int64_t n_tb = (eval_cap(a.N, a.h, a.w, dil, R) + kWaves - 1) / kWaves;
         if (n_tb > slots / 2) n_tb = slots / 2;
-        // the all-resident form: every workgroup of the launch but the finisher holds a slot from the start (stream + pool <= the slots)
-        static const int env_resident = env_int("BXI_RESIDENT", 0);
-        const bool resident = env_resident && one_fits && n_stream + n_pool <= slots && (int64_t)n_pool * per >= n_items &&
-                              !(flags & (kFlagNoStay | kFlagShared)) && !stream_is_capturing(s);
-        if (resident) n_pb = 0;
         // the stream workgroups stay on as the first tile workgroups (only while they leave half of the slots to the rest of the grid)
         // ... unless evaluations run on SEVERAL streams at once: each would hold its stream workgroups' slots while waiting, and three
         // or four of them leave no room for anybody's pool workgroups (measured: 2.4 ms per evaluation with four streams in flight,
@@ -1912,22 +1736,18 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         // says so (BXI_EVAL_SHARED_DEVICE / BXI_EVAL_NO_STAY_ON; boxinstseg_amd/functional.py sets it once a second stream has been
         // seen on the device).  A launch that is being captured into a graph may be replayed next to anything: no staying-on either.
         static const int env_merge = env_int("BXI_ONE_MERGE", 1);
-        int merge = env_merge && one_fits && !(flags & (kFlagNoStay | kFlagShared)) && !stream_is_capturing(s) ? 1 : 0;
+        const int merge = env_merge && one_fits && !(flags & (kFlagNoStay | kFlagShared)) && !stream_is_capturing(s) ? 1 : 0;
         if (merge) n_tb = n_tb > n_stream ? n_tb - n_stream : 0;
-        if (resident && merge) { merge |= 2; n_tb = n_tb > n_pool ? n_tb - n_pool : 0; }
-        static const int env_direct = env_int("BXI_DIRECT", 0);          // developer knob: no reducer workgroup, sum W read from 16 count words
-        if (env_direct && !(merge & 2)) merge |= 4;
         size_t lds = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
         if (lds < 8 * (size_t)kWaves * a.w) lds = 8 * (size_t)kWaves * a.w;
         if (lds < sizeof(float) * (size_t)kWaves * (R + 1) * 64) lds = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
         if (lds < 2 * sizeof(float) * (size_t)(a.h + a.w) + 16) lds = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
         if (lds <= 36 * 1024) {                             // four workgroups per CU must fit
-            const unsigned grid = (merge & 2) ? (unsigned)(n_stream + n_pool + (int)n_tb + 1)
-                                              : (unsigned)(n_stream + n_pool + n_pb + ((merge & 4) ? 0 : 1) + a.N + (int)n_tb + 1);
+            const unsigned grid = (unsigned)(n_stream + n_pool + n_pb + 1 + a.N + (int)n_tb + 1);
 #define BXI_ONE_CASE(DD)                                                                                                                    \
             case DD:                                                                                                                        \
                 BXI_LAUNCH("eval1", s, (eval1_kernel<DD>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, up_prj, \
-                           up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec | (env_zf << 4), merge);                             \
+                           up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge);                                             \
                 break;
             switch (dil) { BXI_ONE_CASE(1) BXI_ONE_CASE(2) BXI_ONE_CASE(3) default: return BXI_ERR_UNSUPPORTED; }
 #undef BXI_ONE_CASE
@@ -2003,7 +1823,10 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     const int slots = occ * cus2 > 64 ? occ * cus2 : 64;
     int n_pb = (n_items + kWaves - 1) / kWaves;
     if (n_pb > slots / 2) n_pb = slots / 2;
-    if (n_tb > slots - n_pb) n_tb = slots - n_pb;
+    // (the predicate workgroups are short-lived: the tile workgroups behind them in the grid take their slots as they leave, so the
+    // tile workgroups are sized for the slots, not for what the predicate workgroups leave over -- BXI_PAIR_TB_FULL=0: the round-3 sizing)
+    static const int env_tb_full = env_int("BXI_PAIR_TB_FULL", 1);
+    if (n_tb > (env_tb_full ? slots : slots - n_pb)) n_tb = env_tb_full ? slots : slots - n_pb;
     const int grid = n_pb + 1 + a.N + (int)n_tb + 1;      // predicate blocks + the reducer + leaders + tile blocks + the finisher
 #define BXI_PAIR_CASE(DD)                                                                                                                  \
     case DD:                                                                                                                               \
@@ -2015,6 +1838,23 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         default: return BXI_ERR_UNSUPPORTED;
     }
 #undef BXI_PAIR_CASE
+    return check_launch();
+}
+
+// the same from the three numbers the kernel needs of the instances (the autograd node's backward keeps those, not the structs)
+int launch_rescale_nhw(int N, int h, int w, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits, void* stream) {
+    if (N < 0 || h <= 0 || w <= 0) return BXI_ERR_BAD_SHAPE;
+    if (!fused_eval_supported(dil)) return BXI_ERR_UNSUPPORTED;
+    if (N == 0) return BXI_OK;
+    if (!g_prj || !g_pw || !state || !g_logits) return BXI_ERR_NULL_POINTER;
+    if (N > 65535) return BXI_ERR_BAD_SHAPE;
+    if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
+    InstArgs a = {};
+    a.N = N; a.h = h; a.w = w;
+    LossState st = {};
+    carve_state(const_cast<void*>(state), N, h, w, &st);
+    hipStream_t s = as_stream(stream);
+    BXI_LAUNCH("rescale", s, rescale_kernel, dim3(8, N), dim3(256), 0, s, a, dil, st, g_prj, g_pw, g_logits);
     return check_launch();
 }
 

@@ -208,6 +208,7 @@ class _EvalPlan:
         self.B, self.stride = B, stride
         self.eval = lib.bxi_boxinst_eval_f32
         self.rescale = lib.bxi_boxinst_grad_rescale_f32
+        self.rescale_nhw = lib.bxi_boxinst_grad_rescale_nhw_f32
         self.ws = None                      # the workspace of the last call (tests look at it)
 
     def patch(self, img_metas, bottom_pixels_removed: int, N: int, boxes) -> None:
@@ -232,6 +233,7 @@ class _Local(threading.local):
         self.plans: Dict[tuple, _EvalPlan] = {}
         self.workspaces: Dict[tuple, torch.Tensor] = {}
         self.sizes: Dict[tuple, Tuple[int, int]] = {}
+        self.norms: Dict[tuple, tuple] = {}
         self.flags = 0                      # BXI_EVAL_* bits every evaluation of this thread is launched with (eval_flags, note_fault)
         self.forced: Optional[int] = None   # tests: the flags instead of what this module would choose
 
@@ -334,10 +336,21 @@ def _eval_plan(imgs, img_metas, mask_logits, gt_bboxes, stride: int, bottom_pixe
     cfg = img_metas[0]['img_norm_cfg'] if B else None
     for m in img_metas[1:]:
         c2 = m['img_norm_cfg']
-        if c2 is not cfg and (list(c2['mean']) != list(cfg['mean']) or list(c2['std']) != list(cfg['std']) or
-                              bool(c2['to_rgb']) != bool(cfg['to_rgb'])):
+        if c2 is not cfg and (c2['mean'] is not cfg['mean'] or c2['std'] is not cfg['std'] or bool(c2['to_rgb']) != bool(cfg['to_rgb'])) and \
+                (list(c2['mean']) != list(cfg['mean']) or list(c2['std']) != list(cfg['std']) or bool(c2['to_rgb']) != bool(cfg['to_rgb'])):
             raise RuntimeError('all images of a batch must share img_norm_cfg')
-    norm = None if cfg is None else (tuple(float(v) for v in cfg['mean']), tuple(float(v) for v in cfg['std']), bool(cfg['to_rgb']))
+    norm = None
+    if cfg is not None:
+        # mmdet's Normalize transform hands every sample the SAME mean / std arrays in a fresh dict: remember the conversion per array pair
+        mean_o, std_o = cfg['mean'], cfg['std']
+        hit = _TLS.norms.get((id(mean_o), id(std_o)))
+        if hit is not None and hit[0] is mean_o and hit[1] is std_o:
+            norm = (hit[2], hit[3], bool(cfg['to_rgb']))
+        else:
+            norm = (tuple(float(v) for v in mean_o), tuple(float(v) for v in std_o), bool(cfg['to_rgb']))
+            if len(_TLS.norms) > 64:
+                _TLS.norms.clear()
+            _TLS.norms[(id(mean_o), id(std_o))] = (mean_o, std_o, norm[0], norm[1])
     key = (imgs.device.index, B, Hc, Wc, stride, len(gt_bboxes), norm)
     plans = _TLS.plans
     plan = plans.get(key)
@@ -493,17 +506,17 @@ class BoxInstMaskLoss(torch.autograd.Function):
                 g_prj = g_prj.to(device=dev, dtype=torch.float32)
             if g_pw.dtype != torch.float32 or g_pw.device != dev:
                 g_pw = g_pw.to(device=dev, dtype=torch.float32)
-            _, x, gi, boxes, _, metas, bpr = keep
-            plan.patch(metas, bpr, x.size(0), boxes)             # another evaluation of the same shape class may have come in between
-            plan.inst.logits, plan.inst.gt_inds = x.data_ptr(), gi.data_ptr()
-            args = (plan.inst_ref, g_prj.data_ptr(), g_pw.data_ptr(), int(ctx.cfg['pairwise_dilation']), state,
+            x = keep[1]
+            # (N, h, w) is all the rescale needs of the instances: nothing of the shape class's shared plan is touched here
+            args = (x.size(0), x.size(2), x.size(3), g_prj.data_ptr(), g_pw.data_ptr(), int(ctx.cfg['pairwise_dilation']), state,
                     grad.data_ptr(), _current_stream(dev))
             if torch.cuda.current_device() == dev.index:          # the usual case: no device guard to set up and tear down
-                rc = plan.rescale(*args)
+                rc = plan.rescale_nhw(*args)
             else:
                 with torch.cuda.device(dev):
-                    rc = plan.rescale(*args)
-            _lib.check('bxi_boxinst_grad_rescale_f32', rc)
+                    rc = plan.rescale_nhw(*args)
+            if rc:
+                _lib.check('bxi_boxinst_grad_rescale_nhw_f32', rc)
         if grad.dtype != ctx.in_dtype:
             grad = grad.to(ctx.in_dtype)
         return grad, None, None, None, None, None, None

@@ -269,6 +269,10 @@ int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_insta
  * a recorded up_pw of 0 cannot be rescaled. */
 int bxi_boxinst_grad_rescale_f32(const bxi_instances* inst_host, const float* g_prj, const float* g_pw, int dilation,
                                  const void* state, float* g_logits, void* stream);
+/* The same from (N, h, w) alone -- all the kernel needs of the instances (the rectangles are in `state`): what an autograd node keeps
+ * for its backward (torch.autograd.Function.backward of the reference's op, pairwise.py:17-26, likewise keeps tensors, not structs). */
+int bxi_boxinst_grad_rescale_nhw_f32(int N, int h, int w, const float* g_prj, const float* g_pw, int dilation, const void* state,
+                                     float* g_logits, void* stream);
 
 /* ===========================================================================================
  * 4. The producer of mask_logits -- replaces CondInstMaskHead.forward (condinst_head.py:1139-1164):

@@ -6,6 +6,8 @@
 #ifndef BOXINST_HIP_DEV_H
 #define BOXINST_HIP_DEV_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -20,6 +22,14 @@ void bxi_dev_set_launch_hook(bxi_launch_hook hook, void* user);
 /* Test switch: bxi_bfs_forward_i32 / bxi_tree_refine_* walk large trees level by level (the reference's own order, bfs.cu:46-98,
  * refine.cu:70-199) instead of ranking their Euler tour / doubling; the two give the same bits and tests compare them. */
 void bxi_dev_set_tree_level_walk(int on);
+
+/* Measuring stick (bench.py `roofline.sol_us`): ONE launch with the single-launch evaluation's grid -- the same numbers of 256-thread
+ * workgroups per role, four per CU -- that performs the evaluation's loads and stores (imgs [B,3,Hc,Wc] read, logits [N,1,h,w] read,
+ * g_logits zero-filled and added to on the tile hulls, the Lab / predicate intermediates written and re-read in `workspace`:
+ * >= 20 * B * h * w + 256 bytes) with no arithmetic and NO dependency between workgroups.  Requires Hc == 4 h, Wc == 4 w, w % 4 == 0.
+ * Leaves garbage in g_logits / workspace.  csrc/sol_eval.hip. */
+int bxi_dev_sol_eval_f32(const float* imgs, int B, int Hc, int Wc, const float* logits, int N, int h, int w, float* g_logits,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }
