@@ -712,8 +712,19 @@ def module_api(sets, dev, n):
         (out['loss_prj'] + out['loss_pairwise']).backward()
         x.grad = None
 
-    for i in range(400):             # the first few hundred calls of a process run at up to twice the steady-state host time
-        once(i)
+    # the first ~second of eager autograd work in a process runs at up to THREE times the steady-state host time (measured:
+    # 239 -> 123 -> 75 us per call over the first 7000 calls, a plain torch graph alongside 155 -> 78 -> 62; tools/host_profile3.py):
+    # warm until the figure has settled, bounded
+    t_w, k_w, last = time.perf_counter(), 0, None
+    while time.perf_counter() - t_w < 4.0:
+        t1 = time.perf_counter()
+        for i in range(500):
+            once(k_w + i)
+        k_w += 500
+        cur = (time.perf_counter() - t1) / 500
+        if last is not None and cur > 0.97 * last and k_w >= 3000:
+            break
+        last = cur
     torch.cuda.synchronize(dev)
     gc.collect()
     gc.freeze()                      # the collector otherwise walks the whole application heap every few hundred allocations
@@ -775,22 +786,26 @@ def module_forward_loss(sets, dev, n):
         img = torch.tensor([int(np.searchsorted(counts, int(x), side='right') - 1) for x in d['gt_inds']], dtype=torch.int64).to(dev)
         packs.append((feat, params, coors, lvl, img))
     out = {}
-    for name, fused in (('two_calls_us', False), ('fused_head_us', True)):
-        def once(i):
-            s, (feat, params, coors, lvl, img) = sets[i % len(sets)], packs[i % len(sets)]
-            _, losses = head.forward_loss(feat, params, coors, lvl, img, s.imgs, s.d['img_metas'], s.gt_inds, s.boxes, fuse_head=fused)
-            (losses['loss_prj'] + losses['loss_pairwise']).backward()
-            feat.grad = None
-            params.grad = None
-        for i in range(40):
-            once(i)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for i in range(n):
-            once(i)
-        torch.cuda.synchronize(dev)
-        out[name] = (time.perf_counter() - t0) / n * 1e6
-    out['default'] = 'two calls (fuse_head=False)'
+    def once(i, fused):
+        s, (feat, params, coors, lvl, img) = sets[i % len(sets)], packs[i % len(sets)]
+        _, losses = head.forward_loss(feat, params, coors, lvl, img, s.imgs, s.d['img_metas'], s.gt_inds, s.boxes, fuse_head=fused)
+        (losses['loss_prj'] + losses['loss_pairwise']).backward()
+        feat.grad = None
+        params.grad = None
+    for i in range(300):
+        once(i, bool(i & 1))
+    torch.cuda.synchronize(dev)
+    acc = {False: [], True: []}
+    for rnd in range(4):                         # A / B / A / B: whichever runs first in a process is otherwise the slower one
+        for fused in (False, True):
+            t0 = time.perf_counter()
+            for i in range(n):
+                once(i, fused)
+            torch.cuda.synchronize(dev)
+            acc[fused].append((time.perf_counter() - t0) / n * 1e6)
+    out['two_calls_us'], out['fused_head_us'] = float(np.median(acc[False])), float(np.median(acc[True]))
+    out['rounds'] = {'two_calls_us': acc[False], 'fused_head_us': acc[True]}
+    out['default'] = 'fused (fuse_head=True)' if CondInstMaskHead.forward_loss.__defaults__[-1] else 'two calls (fuse_head=False)'
     return out
 
 

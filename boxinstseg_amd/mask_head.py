@@ -155,15 +155,15 @@ class CondInstMaskHead(nn.Module):
                                     disable_rel_coors=self.disable_rel_coors)
 
     def forward_loss(self, feat, params, coors, level_inds, img_inds, imgs, img_metas, gt_inds, gt_bboxes, gt_masks=None,
-                     gt_labels=None, fuse_head: bool = False):
+                     gt_labels=None, fuse_head: bool = True):
         """``mask_logits = self(feat, params, coors, level_inds, img_inds)`` followed by ``self.loss(imgs, img_metas, mask_logits,
         gt_inds, gt_bboxes, gt_masks, gt_labels)`` -- the two calls ``CondInst.forward_train`` makes back to back
         (``mmdet/models/detectors/condinst.py:71-74``) -- as ONE call.  With ``fuse_head=True`` (and where the shapes allow) the
         dynamic head is evaluated inside the loss evaluation's first launch (``bxi_boxinst_head_eval_f32``): its tiles run side by
         side with the image pooling and leave, besides the logits, the projection maxima and the zero-filled gradient -- one read of
-        the logits fewer.  Measured (round 3, `profiles/r03_head_fused_bench.json`): 28.5 us against 30.1 us for the two calls at the
-        C ABI (5 %), but through this module the fused node's backward costs more host time than it saves on the device, so the
-        DEFAULT IS THE TWO CALLS; pass ``fuse_head=True`` to choose the fused launch.
+        the logits fewer.  Measured: 28.5 us against 30.1 us of GPU time for the two calls at the C ABI (5 %), and through this module
+        146 us against 148 us of host time per forward_loss + backward (bench.py `module_api.forward_loss`, variants alternated: the
+        variant a process times FIRST is up to twice as slow, which is what round 3's 655-vs-375 us figure had measured).
         Returns ``(mask_logits, losses)``; every configuration the fused launch is not built for takes the two calls."""
         factor = self.in_stride // self.out_stride
         fused = (fuse_head and self.boxinst_enabled and feat.is_cuda and params.size(0) > 0 and factor == 2 and self.dynamic_convs == 3 and
