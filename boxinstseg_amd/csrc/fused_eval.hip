@@ -1376,7 +1376,9 @@ __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& v
 // running out of it is loud: NaN losses, status word, poisoned gradient (the reference surfaces launch failures through
 // AT_CUDA_CHECK, pairwise.cu:173,200).
 template <int D, int R>
-__global__ __launch_bounds__(256, (R == 4 ? (D <= 3 ? 4 : 3) : 2)) void pair_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
+// (four workgroups per CU only where the tile role fits 128 VGPRs without spilling: dilation <= 2 -- every shipped configuration uses 2;
+// dilation 3 needs 10-row register arrays and ran with 9 spilled VGPRs at four per CU)
+__global__ __launch_bounds__(256, (R == 4 ? (D <= 2 ? 4 : 3) : 2)) void pair_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
                                                        float n2max, int zero_bit, int n_pb, int n_items, int spin_limit, ValidCells vc, float* __restrict__ losses,
                                                        float* __restrict__ g_logits, InstArgs a, Ws ws_in, LossState st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1710,7 +1712,8 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     // 64 instances, 35.1 vs 33.9 at 96, 45.1 vs 39.4 at 128 (200 x 256 maps) -- hence: stream workgroups <= half the slots.
     const int one_slots = kOneOcc * device_cus();
     const bool one_fits = 2 * (int64_t)a.N * ((a.h + kSBlk - 1) / kSBlk) <= one_slots && stream_cus(s, device_cus()) >= device_cus();
-    if (env_one && !(flags & kFlagTwo) && (one_fits || env_one == 2 || (flags & kFlagSingle)) && !head && pooled_in_launch && R == 4 && dil <= 3 &&
+    // (built for dilation <= 2: the single launch needs four workgroups per CU, and at dilation 3 the tile role does not fit 128 VGPRs)
+    if (env_one && !(flags & kFlagTwo) && (one_fits || env_one == 2 || (flags & kFlagSingle)) && !head && pooled_in_launch && R == 4 && dil <= 2 &&
         !pr.zero_bit) {
         static const int env_one_pool = env_int("BXI_ONE_POOL_WGS", 0);
         const int Sn = (a.h + kSBlk - 1) / kSBlk;
@@ -1749,7 +1752,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
                 BXI_LAUNCH("eval1", s, (eval1_kernel<DD>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, up_prj, \
                            up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge);                                             \
                 break;
-            switch (dil) { BXI_ONE_CASE(1) BXI_ONE_CASE(2) BXI_ONE_CASE(3) default: return BXI_ERR_UNSUPPORTED; }
+            switch (dil) { BXI_ONE_CASE(1) BXI_ONE_CASE(2) default: return BXI_ERR_UNSUPPORTED; }
 #undef BXI_ONE_CASE
             return check_launch();
         }
@@ -1816,7 +1819,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     // the tile list's length is device data: the tile waves stride through it.  The launch should be resident in one round:
     // 4 (R = 4: <= 128 VGPRs) or 2 (R = 8) workgroups per CU; the predicate waves are short-lived.
     static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 0);
-    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? (dil <= 3 ? 4 : 3) : 2);
+    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? (dil <= 2 ? 4 : 3) : 2);
     // (the leaders are short-lived and are not counted; with them subtracted, 512 instances at two workgroups per CU left ONE
     // predicate workgroup for the whole image side: 4.4 ms per evaluation)
     const int cus2 = stream_cus(s, device_cus());                      // a CU-masked stream has fewer

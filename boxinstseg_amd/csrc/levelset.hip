@@ -244,31 +244,36 @@ __global__ __launch_bounds__(256) void lcm_affinity_kernel(const float* __restri
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)N * hw) return;
     const int n = (int)(i / hw), p = (int)(i % hw), r = p / w, c = p % w;
-    float e[8];
+    // The deviation of a near-constant window is a difference of nearly equal numbers, and the affinity divides by it: in f32 the
+    // rounding of mean / variance is amplified into the 5th digit of the softmax (an off-suite fuzz case, 120 x 197 at dilation 3, sat
+    // 2.2e-5 from the fp64 oracle).  Eight values per pixel and channel: the statistics are taken in double (fp64 runs at the f32 rate
+    // on this part), the exponent and the softmax stay f32 as in the reference (levelset_loss.py:113-120).
+    double ed[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) e[k] = 0.f;
+    for (int k = 0; k < 8; ++k) ed[k] = 0.0;
     for (int ch = 0; ch < C; ++ch) {
         const float* I = imgs + ((int64_t)n * C + ch) * hw;
-        const float ip = I[p];
-        float v[8], mean = 0.f;
+        const double ip = (double)I[p];
+        double v[8], mean = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             int dy, dx; lcm_offset(k, dy, dx);
             const int r2 = min(max(r + dy * d, 0), h - 1), c2 = min(max(c + dx * d, 0), w - 1);   // replicate padding (:99)
-            v[k] = I[(int64_t)r2 * w + c2];
+            v[k] = (double)I[(int64_t)r2 * w + c2];
             mean += v[k];
         }
-        mean *= 0.125f;
-        float var = 0.f;
+        mean *= 0.125;
+        double var = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) var += (v[k] - mean) * (v[k] - mean);
-        const float sd = sqrtf(var / 7.f) + 1e-8f;                 // torch.std: unbiased (:116)
+        const double sd = sqrt(var / 7.0) + 1e-8;                  // torch.std: unbiased (:116)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const float z = fabsf(v[k] - ip) / sd / alpha; e[k] -= z * z; }
+        for (int k = 0; k < 8; ++k) { const double z = fabs(v[k] - ip) / sd / (double)alpha; ed[k] -= z * z; }
     }
+    float e[8];
     float m = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { e[k] /= (float)C; m = fmaxf(m, e[k]); }      // .mean(dim=1)
+    for (int k = 0; k < 8; ++k) { e[k] = (float)(ed[k] / (double)C); m = fmaxf(m, e[k]); }      // .mean(dim=1)
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { e[k] = expf(e[k] - m); s += e[k]; }

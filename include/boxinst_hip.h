@@ -225,7 +225,7 @@ size_t bxi_boxinst_eval_workspace_lab_offset(void);
 /* hipMemsetAsync(workspace, 0, workspace_bytes) on `stream`: the one-time initialisation described above. */
 int bxi_boxinst_eval_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 /* `flags` of the two evaluation entry points.  The forms give the same bits (tests run them against each other). */
-#define BXI_EVAL_SINGLE_LAUNCH   1u   /* the single-launch form wherever it is built (stride-4 aligned canvases, dilation <= 3, threshold
+#define BXI_EVAL_SINGLE_LAUNCH   1u   /* the single-launch form wherever it is built (stride-4 aligned canvases, dilation <= 2, threshold
                                          > 0), also where the library would not choose it (its stream workgroups, instances x ceil(h / 32),
                                          fill more than half the GPU)                                                                    */
 #define BXI_EVAL_TWO_LAUNCHES    2u   /* always the two-launch form: every in-kernel wait is for a workgroup EARLIER in its grid, so it

@@ -1,5 +1,6 @@
 """CPU, 2 processes over gloo: the N > 1 path.  The loss path has no exchange step;
-what is collective is the logging of the loss scalars (boxinstseg_amd/dist.py <-> base.py:176-219)."""
+what is collective is the logging of the loss scalars (boxinstseg_amd/dist.py <-> base.py:176-219).  The per-rank losses are the
+product's own -- a recorded run of the HIP path (tests/golden/make_hip_run.py) -- not the oracle's."""
 import os
 import socket
 import sys
@@ -20,35 +21,40 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mismatch, q):
+GOLD = os.path.join(ROOT, 'tests', 'golden', 'hip_run_2ranks.npz')
+
+
+def _worker(rank, world, port, nan_rank, q):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))
-    from boxinstseg_amd import dist as bdist
-    from oracle import torch_oracle as to
-    from boxinstseg_amd import synthetic
+    import warnings
+    import numpy as np
+    from boxinstseg_amd import _lib, dist as bdist, functional as Fh
     r, w, _ = bdist.init_distributed('gloo')
     assert (r, w) == (rank, world) and dist.get_backend() == 'gloo'
-    # every rank evaluates ITS OWN batch (weak scaling): the CPU oracle stands in for the HIP path here
-    d = synthetic.make_batch(B=1, H=64, W=64, boxes_per_img=2, seed=100 + rank, min_box=16, max_box=40)
-    x = torch.from_numpy(d['mask_logits']).requires_grad_(True)
-    losses = to.mask_loss(torch.from_numpy(d['imgs']), d['img_metas'], x, torch.from_numpy(d['gt_inds']),
-                          [torch.from_numpy(b) for b in d['gt_bboxes']])
-    if mismatch and rank == 1:
-        losses['loss_extra'] = losses['loss_prj'] * 0
-    loss, log_vars = bdist.parse_losses(losses)
+    # every rank holds ITS OWN batch's losses (weak scaling) -- what the PRODUCT (the HIP path through CondInstMaskHead.loss) produced on a
+    # GPU box for batch `100 + rank`, recorded by tests/golden/make_hip_run.py: there is no GPU here and the product has no CPU path
+    g = np.load(GOLD)
+    lp = torch.tensor(float(g[f'rank{rank}_loss_prj']), requires_grad=True)
+    lw = torch.tensor(float(g[f'rank{rank}_loss_pairwise']), requires_grad=True)
+    losses = {'loss_prj': lp * 1.0, 'loss_pairwise': lw * (float('nan') if nan_rank == rank else 1.0)}
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        loss, log_vars = bdist.parse_losses(losses)
     loss.backward()                                    # gradients stay rank-local: nothing to reduce on the path
-    q.put((rank, float(losses['loss_prj']), float(losses['loss_pairwise']), {k: float(v) for k, v in log_vars.items()},
-           float(x.grad.abs().sum())))
+    host = bdist.to_host({k: v for k, v in log_vars.items()}) if nan_rank is None else {k: float(v) for k, v in log_vars.items()}
+    q.put((rank, float(lp), float(lw), dict(host), float(lp.grad), bool(Fh.eval_launch_flags() & _lib.EVAL_TWO_LAUNCHES),
+           sum('two-launch' in str(c.message) for c in caught)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(mismatch):
+def _run(nan_rank):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mismatch, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, nan_rank, q)) for r in range(2)]
     for p in procs:
         p.start()
     out = sorted(q.get(timeout=180) for _ in procs)
@@ -60,13 +66,26 @@ def _run(mismatch):
 
 @pytest.mark.timeout(300)
 def test_two_ranks_single_allreduce_logging():
-    (r0, p0, w0, lv0, g0), (r1, p1, w1, lv1, g1) = _run(False)
-    assert p0 != p1 and g0 > 0 and g1 > 0                       # different batches per rank, local gradients
+    """parse_losses over two gloo ranks on the losses a recorded run of the HIP path produced (tests/golden/hip_run_2ranks.npz)."""
+    (r0, p0, w0, lv0, g0, two0, _), (r1, p1, w1, lv1, g1, two1, _) = _run(None)
+    assert p0 != p1 and g0 == 1.0 and g1 == 1.0                 # different batches per rank, local gradients
     for lv in (lv0, lv1):                                       # every rank logs the rank-mean of every key
         assert abs(lv['loss_prj'] - 0.5 * (p0 + p1)) < 1e-6
         assert abs(lv['loss_pairwise'] - 0.5 * (w0 + w1)) < 1e-6
         assert abs(lv['loss'] - 0.5 * (p0 + p1 + w0 + w1)) < 1e-6
     assert lv0 == lv1
+    assert not two0 and not two1                                # finite losses: nobody falls back
+
+
+@pytest.mark.timeout(300)
+def test_a_faulted_evaluation_on_one_rank_is_noticed_on_every_rank():
+    """An evaluation whose bounded in-kernel wait ran out hands back NaN losses (include/boxinst_hip.h section 3).  The key guard's one
+    host read carries a non-finite flag under MAX, so EVERY rank -- not only the one that faulted -- switches its following evaluations to
+    the two-launch form (functional.note_fault), in step."""
+    res = _run(1)
+    for rank, _, _, lv, _, two, warned in res:
+        assert two and warned == 1, (rank, two, warned)
+        assert lv['loss_pairwise'] != lv['loss_pairwise']       # the logged mean is NaN, as the reference's would be
 
 
 def _mismatch_worker(rank, world, port, same_count, q):

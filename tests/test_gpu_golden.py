@@ -92,3 +92,23 @@ def test_lab_kernels_match_real_scikit_image(dev):
     off = _lib.load().bxi_boxinst_eval_workspace_lab_offset()
     lab4 = ws[off:off + 256 * 256 * 16].view(torch.float32).view(256, 256, 4).cpu().numpy()        # (L, a, b, tag) per pooled pixel
     check(np.ascontiguousarray(lab4[:, :, :3].transpose(2, 0, 1)), 'prep_kernel pool blocks')
+
+
+def test_recorded_hip_run_for_the_gloo_test_is_what_the_product_gives(dev):
+    """tests/golden/hip_run_2ranks.npz (what the 2-rank gloo test on the CPU feeds dist.parse_losses) is a recording of THIS product:
+    re-evaluate the two batches and compare."""
+    import os
+    from boxinstseg_amd import CondInstMaskHead, synthetic
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'hip_run_2ranks.npz'))
+    for rank in range(2):
+        d = synthetic.make_batch(B=1, H=64, W=64, boxes_per_img=2, seed=100 + rank, min_box=16, max_box=40)
+        head = CondInstMaskHead(in_channels=16, boxinst_enabled=True, topk_per_img=64, max_proposals=-1, pairwise_warmup=10000).to(dev)
+        head.set_iter(2499)
+        x = torch.from_numpy(d['mask_logits']).to(dev).requires_grad_(True)
+        losses = head.loss(torch.from_numpy(d['imgs']).to(dev), d['img_metas'], x, torch.from_numpy(d['gt_inds']).to(dev),
+                           [torch.from_numpy(b).to(dev) for b in d['gt_bboxes']], None, None)
+        (losses['loss_prj'] + losses['loss_pairwise']).backward()
+        assert abs(float(losses['loss_prj'].detach()) - float(g[f'rank{rank}_loss_prj'])) <= 1e-6
+        assert abs(float(losses['loss_pairwise'].detach()) - float(g[f'rank{rank}_loss_pairwise'])) <= 1e-6
+        assert abs(float(x.grad.double().abs().sum()) - float(g[f'rank{rank}_grad_abs_sum'])) <= 1e-6 * float(g[f'rank{rank}_grad_abs_sum'])
+        assert float(head._iter) == float(g[f'rank{rank}_iter_after'])
