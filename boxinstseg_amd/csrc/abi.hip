@@ -76,7 +76,7 @@ size_t bxi_boxinst_eval_workspace_bytes(int B, int Hc, int Wc, int stride, int N
     return bxi::eval_ws_bytes(B, N, h, w);
 }
 
-size_t bxi_boxinst_eval_workspace_lab_offset(void) { return 0; }
+size_t bxi_boxinst_eval_workspace_lab_offset(void) { return 256; }      // behind the epoch word (fused_eval.hip: carve)
 
 int bxi_boxinst_eval_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
     return bxi::eval_ws_init(workspace, workspace_bytes, stream);

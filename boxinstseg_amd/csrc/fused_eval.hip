@@ -180,6 +180,9 @@ static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return p ? p + o : nullptr; };
     Ws t;
     const size_t P = (size_t)h * w, B1 = B > 0 ? B : 1;
+    // the epoch word FIRST, at offset 0 whatever the shape: evaluations of different shapes share a workspace (one per stream), and the
+    // tag counter that tells their records apart must be the same word for all of them (everything behind it moves with the shape)
+    t.epoch = (unsigned int*)take(4);
     t.lab4 = (float4*)take(16 * B1 * P);
     t.lab_planar = (float*)take(12 * B1 * P);
     t.pred = (unsigned int*)take(4 * B1 * P);
@@ -194,7 +197,6 @@ static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
     t.acc2 = (unsigned long long*)take(8 * (size_t)N1 * kAcc2Split * kAcc2Stride);
     t.dice = (unsigned long long*)take(8 * (size_t)N1);
     t.fault = (unsigned int*)take(4);
-    t.epoch = (unsigned int*)take(4);
     if (ws) *ws = t;
     return off;
 }
@@ -1677,8 +1679,23 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     const bool pooled_in_launch = pool_vec_ok(batch, a.stride);     // else: the generic pooling kernels in launches of their own
     const size_t need = carve(nullptr, batch->B, a.N, a.h, a.w, nullptr);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
+    // The layout is a function of (B, h, w) and of the workspace's SIZE, not of this call's instance count: the per-instance regions are
+    // carved for the largest count the size admits, so every evaluation of this canvas on this workspace finds every kind of record at
+    // the same address, whatever N it has.  A word that ever held a tag then only ever holds tags of the same kind (or the zero of the
+    // one-time initialisation), and tags grow monotonically -- a stale word can never pass for a fresh one.  (With the layout moving
+    // with N, a small tag could meet an old PAYLOAD word of the same value -- a predicate word is 16 * tag + bits -- found by
+    // tools/extended_fuzz.py: intermittent wrong results, status 0.)
+    int n_cap = a.N;
+    {
+        int lo = a.N, hi = kMaxInst - 1;           // carve() is non-decreasing in N
+        while (lo < hi) {
+            const int mid = lo + (hi - lo + 1) / 2;
+            if (carve(nullptr, batch->B, mid, a.h, a.w, nullptr) <= workspace_bytes) lo = mid; else hi = mid - 1;
+        }
+        n_cap = lo;
+    }
     Ws ws;
-    carve(workspace, batch->B, a.N, a.h, a.w, &ws);
+    carve(workspace, batch->B, n_cap, a.h, a.w, &ws);
     LossState st = {};
     if (state) {
         if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;

@@ -231,7 +231,7 @@ class _Local(threading.local):
 
     def __init__(self):
         self.plans: Dict[tuple, _EvalPlan] = {}
-        self.workspaces: Dict[tuple, torch.Tensor] = {}
+        self.workspaces: Dict[tuple, Tuple[torch.Tensor, int]] = {}
         self.sizes: Dict[tuple, Tuple[int, int]] = {}
         self.norms: Dict[tuple, tuple] = {}
         self.flags = 0                      # BXI_EVAL_* bits every evaluation of this thread is launched with (eval_flags, note_fault)
@@ -254,21 +254,33 @@ def last_eval_status() -> Tuple[int, int]:
     return int(v[0]), int(v[1])
 
 
-def _workspace(dev: torch.device, stream: int, need: int) -> torch.Tensor:
-    """One grow-only workspace per (device, stream): evaluations on a stream are serialised, so they can share it; a larger
-    need replaces it (the old buffer goes back to the caching allocator, which keeps it alive for the work already queued).
-    ZEROED when it is allocated and never written by the host again -- the C ABI's contract (include/boxinst_hip.h, section 3): the
-    workspace carries the tag counter that tells one evaluation's records from another's."""
-    key = (dev.index, stream)
-    ws = _TLS.workspaces.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _TLS.workspaces[key] = torch.zeros(max(need + need // 4, 256), dtype=torch.uint8, device=dev)
+_MAX_WORKSPACES = 64
+
+
+def _workspace(dev: torch.device, stream: int, canvas: tuple, N: int) -> torch.Tensor:
+    """One workspace per (device, stream, canvas = (B, Hc, Wc, stride)): the C ABI's contract (include/boxinst_hip.h, section 3) is one
+    LAYOUT per workspace -- the layout is fixed by the canvas and the workspace's size, every word only ever holds one kind of record,
+    which is what makes the evaluation's tags safe -- ZEROED when it is allocated and never written by the host again.  Evaluations on
+    a stream are serialised, so they share it whatever their instance count, up to the count it was sized for (rounded up to a
+    multiple of 32, then grow-only: a larger N replaces it with a fresh zeroed one; the old buffer goes back to the caching allocator,
+    which keeps it alive for the work already queued).  Padded training batches come in a few dozen canvases: LRU of 64, ~2 MB each."""
+    key = (dev.index, stream) + canvas
+    hit = _TLS.workspaces.get(key)
+    if hit is None or hit[1] < N:
+        n_cap = max((N + 31) // 32 * 32, 32 if hit is None else 2 * hit[1])
+        B, Hc, Wc, stride = canvas
+        need = max(_lib.load().bxi_boxinst_eval_workspace_bytes(B, Hc, Wc, stride, n_cap), 256)
+        if hit is None and len(_TLS.workspaces) >= _MAX_WORKSPACES:
+            _TLS.workspaces.pop(next(iter(_TLS.workspaces)))
         # A second stream on this device: evaluations may now run side by side, and the library is told so from here on (sticky;
         # BXI_EVAL_SHARED_DEVICE: no workgroup may hold a slot while it waits for workgroups later in the grid).  The library
         # itself never guesses what else runs on the device.
-        if sum(1 for k in _TLS.workspaces if k[0] == dev.index) > 1:
+        if any(k[0] == dev.index and k[1] != stream for k in _TLS.workspaces):
             _TLS.flags |= _lib.EVAL_SHARED_DEVICE
-    return ws
+        hit = _TLS.workspaces[key] = (torch.zeros(need, dtype=torch.uint8, device=dev), n_cap)
+    elif len(_TLS.workspaces) > 1:
+        _TLS.workspaces[key] = _TLS.workspaces.pop(key)          # most recently used last
+    return hit[0]
 
 
 def eval_launch_flags() -> int:
@@ -292,7 +304,7 @@ def reset_eval_state(drop_workspaces: bool = True) -> None:
     if drop_workspaces:
         _TLS.workspaces.clear()
     else:
-        for ws in _TLS.workspaces.values():
+        for ws, _ in _TLS.workspaces.values():
             ws.zero_()
 
 
@@ -305,7 +317,7 @@ def note_fault(what: str = '') -> None:
         warnings.warn('boxinstseg_amd: an evaluation reported a fault%s; taking the two-launch form from here on'
                       % (f' ({what})' if what else ''), RuntimeWarning, stacklevel=2)
     _TLS.flags = (_TLS.flags | _lib.EVAL_TWO_LAUNCHES) & ~_lib.EVAL_SINGLE_LAUNCH
-    for ws in _TLS.workspaces.values():
+    for ws, _ in _TLS.workspaces.values():
         ws.zero_()
 
 
@@ -362,9 +374,9 @@ def _eval_plan(imgs, img_metas, mask_logits, gt_bboxes, stride: int, bottom_pixe
             plans.pop(next(iter(plans)))            # the oldest entry; nothing is in flight on a plan (host arrays only)
         plan = plans[key] = _EvalPlan(B, Hc, Wc, stride, len(gt_bboxes), mean, std, to_rgb)
     plan.patch(img_metas, bottom_pixels_removed, N, gt_bboxes)
-    plan.state_bytes, ws_bytes = _sizes(N, h, w, B, Hc, Wc, stride)
+    plan.state_bytes, _ = _sizes(N, h, w, B, Hc, Wc, stride)
     plan.grad_elems = N * h * w
-    plan.ws = _workspace(imgs.device, stream, ws_bytes)
+    plan.ws = _workspace(imgs.device, stream, (B, Hc, Wc, stride), N)
     plan.ws_ptr, plan.ws_bytes = plan.ws.data_ptr(), plan.ws.numel()
     return plan
 

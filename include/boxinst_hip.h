@@ -212,8 +212,11 @@ int bxi_boxinst_loss_backward_f32(const bxi_instances* inst_host, const float* g
  * workspace (bxi_boxinst_eval_workspace_bytes, 256-B aligned): scratch incl. Lab.  ZERO IT ONCE after allocating it
  *   (bxi_boxinst_eval_workspace_init, or any memset ordered before the first evaluation) and never write to it again: it carries the
  *   tag counter ("epoch") that tells this evaluation's records from earlier ones', advanced on the device by each evaluation's last
- *   workgroup.  It may be shared by evaluations of any shapes as long as they are serialised (one stream); evaluations that may
- *   overlap (several streams) need a workspace each.  After an evaluation that reported a non-zero status, zero it again.
+ *   workgroup.  ONE workspace serves ONE canvas -- (B, Hc, Wc, stride) -- at ONE size: its layout is a function of those and of
+ *   workspace_bytes alone (the per-instance regions are carved for the largest N the size admits), so evaluations with any N up to
+ *   the N it was sized for share it, serialised on one stream; every word then only ever holds one kind of record, which is what makes
+ *   the tags safe.  Another canvas, a larger N or overlapping evaluations (several streams) need a workspace of their own; to re-use
+ *   the memory for another layout, or after an evaluation that reported a non-zero status, zero it again first.
  * batch_host->image_masks must be NULL (explicit masks: bxi_color_affinity_f32 + bxi_boxinst_loss_fwd_bwd_f32).
  * size == 3 and dilation <= 4 are built; others return BXI_ERR_UNSUPPORTED and the host composes section 1 + torch ops
  * as the reference does.  N == 0 writes two zeros (documented deviation; the reference yields NaN).

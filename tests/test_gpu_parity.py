@@ -673,6 +673,52 @@ def test_loss_fuzz(dev, seed):
     assert err <= TOL, f'grad err {err:.3e} ({ties} ambiguous arg-max lines excluded); cfg {B}x{H}x{W} s{stride} {kw}'
 
 
+def test_many_shapes_in_one_process_without_resets(dev):
+    """Forty evaluations of changing canvases, instance counts, strides and dilations back to back, with no reset in between (the suite's
+    fixture resets after every test; tools/extended_fuzz.py, which found this, does not).  Every canvas gets a workspace of its own
+    (one LAYOUT per workspace: include/boxinst_hip.h, section 3): with one workspace for all shapes, a small tag met an old payload word
+    of the same value at an address where the new layout keeps a tag (a predicate word is 16 * tag + bits) -- intermittent wrong
+    results with status 0, and through a stale table entry out-of-bounds tile coordinates."""
+    _check(synthetic.cfg2(7), dev)
+    for seed in range(24, 64):
+        test_loss_fuzz(dev, seed)
+    _check(synthetic.cfg1(8), dev)
+
+
+def test_one_workspace_serves_every_instance_count_of_its_canvas(dev):
+    """At the C ABI: ONE workspace, sized for 24 instances of a 2 x 128 x 192 canvas and zeroed once, serves 48 evaluations whose
+    instance count changes every time (8 / 16 / 24 / 3).  The layout is a function of the canvas and the workspace's size alone, so
+    every kind of record keeps its address while N moves and the tags -- 1 .. 48 here, crossing 16, 32: the values old predicate words
+    of tags 1, 2 carry -- stay safe.  Every evaluation: status 0, losses and gradient within 1e-4 of the oracle."""
+    import ctypes as C
+    from boxinstseg_amd import _lib, functional as Fh
+    lib = _lib.load()
+    ds = [synthetic.make_batch(B=2, H=128, W=192, boxes_per_img=4, inst_per_box=k, seed=300 + k, min_box=16, max_box=120) for k in (1, 2, 3)]
+    small = synthetic.make_batch(B=2, H=128, W=192, boxes_per_img=4, inst_per_box=1, seed=310, min_box=16, max_box=120)
+    small['gt_inds'] = small['gt_inds'][:3].copy(); small['mask_logits'] = small['mask_logits'][:3].copy(); small['N'] = 3
+    ds.append(small)
+    refs = [oracle_path(d, want_targets=False) for d in ds]
+    ws = torch.zeros(lib.bxi_boxinst_eval_workspace_bytes(2, 128, 192, 4, 24), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for k in range(48):
+        d, ref = ds[k % 4], refs[k % 4]
+        t = to_dev(d, dev)
+        batch = Fh._Batch(t['imgs'], d['img_metas'], 10)
+        inst = Fh._Inst(t['logits'], t['gt_inds'], t['gt_bboxes'], d['H'], d['W'], d['stride'])
+        losses, grad = torch.zeros(2, device=dev), torch.empty_like(inst.logits)
+        state = torch.empty(lib.bxi_boxinst_loss_state_bytes(inst.N, inst.h, inst.w), dtype=torch.uint8, device=dev)
+        rc = lib.bxi_boxinst_eval_f32(C.byref(batch.struct), C.byref(inst.struct), 3, 2, 0.3, 1.0, None, None, losses.data_ptr(), grad.data_ptr(),
+                                      state.data_ptr(), ws.data_ptr(), ws.numel(), 1 if k % 3 else 2, st)
+        assert rc == 0, _lib.status_string(rc)
+        torch.cuda.synchronize()
+        off = lib.bxi_boxinst_loss_state_status_offset(inst.N, inst.h, inst.w)
+        assert state[off:off + 4].view(torch.int32).item() == 0, k
+        got = losses.cpu().numpy()
+        assert rel(float(got[0]), ref['loss_prj']) <= TOL and rel(float(got[1]), ref['loss_pairwise']) <= TOL, (k, got, ref['loss_prj'], ref['loss_pairwise'])
+        err, _ = grad_report(grad.cpu().numpy()[:, 0], ref['grad'], d['mask_logits'][:, 0])
+        assert err <= TOL, (k, err)
+
+
 # ---------------------------------------------------------------------------------------------
 # hipGraph replay, shared devices, fall-back after a fault
 # ---------------------------------------------------------------------------------------------
