@@ -71,11 +71,19 @@ constexpr unsigned kFaultCounts = 1u, kFaultFinisher = 2u;
 constexpr unsigned long long kArrivalFault = 1ull << 50, kCountFault = 1ull << 39, kSumwFault = 1ull << 62, kDiceFault = 1ull << 33;
 
 #ifdef BXI_TRACE
+#ifdef BXI_TRACE_LIGHT      // only the first and the last stamp of a wave: two stores per wave instead of eight (the full trace lengthens the launch by half)
+#define BXI_TW(kid, idx, ph)                                                                                  \
+    do {                                                                                                      \
+        if (((ph) == 0 || (ph) == 7 || (kid) >= 2) && (threadIdx.x & 63) == 0 && g_trace && (idx) >= 0 && (idx) < ::bxi::kTraceBlocks) \
+            g_trace[((size_t)(kid) * ::bxi::kTraceBlocks + (idx)) * ::bxi::kTracePhases + (ph)] = wall_clock64(); \
+    } while (0)
+#else
 #define BXI_TW(kid, idx, ph)                                                                                  \
     do {                                                                                                      \
         if ((threadIdx.x & 63) == 0 && g_trace && (idx) >= 0 && (idx) < ::bxi::kTraceBlocks)                  \
             g_trace[((size_t)(kid) * ::bxi::kTraceBlocks + (idx)) * ::bxi::kTracePhases + (ph)] = wall_clock64(); \
     } while (0)
+#endif
 #else
 #define BXI_TW(kid, idx, ph) do {} while (0)
 #endif
@@ -1069,12 +1077,21 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const W
     int* carg = reinterpret_cast<int*>(ys + h);   // [w]
     int* rarg = carg + w;                         // [h]
     int4 e;
-    bool waited = tab_entry<ONE>(ws, n, true, spin_limit, e);
+    bool waited;
     if (ONE) {
         // single-launch form: the instance's partial maxima and the zero-fill of its map come from stream workgroups of THIS
-        // launch (earlier in the grid, waiting for nobody); one flag per band says they are in memory
+        // launch (earlier in the grid, waiting for nobody); one flag per band says they are in memory.  The table entry and the
+        // (first 64) band flags are asked for in ONE round trip -- both are self-announcing words, and by the time a leader gets a
+        // slot both are normally there; the partial maxima themselves are only asked for once their flags have been seen.
         const int lane = tid & 63;
-        for (int b0 = 0; b0 < ws.n_cb && waited; b0 += 64) {
+        waited = false;
+        for (int spins = 0; spins <= spin_limit; ++spins) {
+            const unsigned int f = lane < ws.n_cb ? __hip_atomic_load(&ws.bandflag[(int64_t)n * ws.n_cb + lane], BXI_RLX, BXI_AGENT) : ws.ep;
+            const u4v v = load16_past(ws.tab + n);                 // (its wait covers the flag load issued before it)
+            if (__all(f == ws.ep && v.w == ws.ep)) { e = make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w); waited = true; break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        for (int b0 = 64; b0 < ws.n_cb && waited; b0 += 64) {
             bool got = false;
             for (int spins = 0; spins <= spin_limit; ++spins) {
                 const unsigned int f = b0 + lane < ws.n_cb ? __hip_atomic_load(&ws.bandflag[(int64_t)n * ws.n_cb + b0 + lane], BXI_RLX, BXI_AGENT) : ws.ep;
@@ -1087,6 +1104,8 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const W
             if (tid == 0) __hip_atomic_store(&ws.dice[n], (1ull << 32) | kDiceFault, BXI_RLX, BXI_AGENT);
             return;
         }
+    } else {
+        waited = tab_entry<false>(ws, n, true, spin_limit, e);
     }
     const int br0 = e.y & 0xffff, br1 = (int)((unsigned int)e.y >> 16), bc0 = e.z & 0xffff, bc1 = (int)((unsigned int)e.z >> 16);
     const bool any = br1 > br0 && bc1 > bc0;
@@ -1149,7 +1168,7 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const W
             ys[r] = gv;
             st.rowk[(int64_t)n * h + r] = ((unsigned long long)__float_as_uint(gv) << 32) | (unsigned int)rarg[r];
         }
-        __syncthreads();      // xs / ys now hold the gradients for every thread
+        lds_barrier();        // xs / ys now hold the gradients for every thread (LDS only: the record stores above need not have landed)
         // one addition per arg-max position (a pixel that is its column's AND its row's arg-max gets their sum in one)
         float* G = g_logits + (int64_t)n * h * w;
         for (int c = tid; c < w; c += 256) {
@@ -1238,7 +1257,9 @@ __device__ __forceinline__ void pred_role(const InstArgs& a, const ValidCells& v
     // need the last one
     __shared__ int pred_cnt[kWaves], pred_seg[kWaves], pred_bad[kWaves];
     if (lane == 0) { pred_cnt[wave] = cnt; pred_seg[wave] = segments; pred_bad[wave] = ok ? 0 : 1; }
-    __syncthreads();
+    // an LDS-only barrier: __syncthreads() would also wait for this wave's predicate-word stores to be acknowledged (~1 us) before the
+    // count -- which the tile waves' normaliser hangs on -- could leave; the words announce themselves, nobody infers them from the count
+    lds_barrier();
     if (threadIdx.x == 0)    // (segments evaluated, sum W); integer adds commute: run-to-run identical
         __hip_atomic_fetch_add(&ws.acc1[(size_t)(pblk & (kAcc1Words - 1)) * kAcc2Stride],
                                ((unsigned long long)(unsigned int)((pred_seg[0] + pred_seg[1]) + (pred_seg[2] + pred_seg[3])) << 40) |
@@ -1782,8 +1803,16 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     // one item = the 4 input rows of 64 pooled pixels.  The whole launch should be resident at once (5 workgroups per CU at
     // <= 96 VGPRs): a pool workgroup takes several items, the next one's loads in flight, when it is not.
     const int room = env_pool_wgs * device_cus() - n_tab - (head ? 0 : n_stream);
-    const int per = room > 0 ? (n_items + room - 1) / room : 8;
+    // ... but never more than two items per pool workgroup: its items are a dependent chain (load -> sums -> Lab -> store, ~2.5 us each), and
+    // with many instances -- 896 stream workgroups at 128 -- the few pool workgroups the slots leave would each drag four or five of them
+    // behind the HBM stream (the first launch's last 5 us at 128 instances).  Then the launch exceeds the slots and its tail workgroups
+    // take them as they come free; the pool workgroups go FIRST in that case, the image side being the longer chain.  Measured: 40.1 ->
+    // 38.5 us per evaluation at 128 instances, 75.8 -> 70.3 at 256 (BXI_PREP_ITEMS=<n>: developer override)
+    static const int env_prep_items = env_int("BXI_PREP_ITEMS", 0);
+    int per = env_prep_items > 0 ? env_prep_items : (room > 0 ? (n_items + room - 1) / room : 8);
+    if (env_prep_items <= 0 && per > 2) per = 2;
     const int n_pool = pooled_in_launch ? (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per) : 0;
+    const int pool_first = env_pool_first || (!head && n_tab + n_stream + n_pool > env_pool_wgs * device_cus()) ? 1 : 0;
     size_t lds1 = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
     // every refusal comes BEFORE the first launch: a refused call has enqueued nothing (callers fall back to other entry points)
     size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
@@ -1816,7 +1845,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         if (lds1 < 8 * (size_t)kWaves * a.w) lds1 = 8 * (size_t)kWaves * a.w;
         if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
         BXI_LAUNCH("prep", s, prep_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, ws, st,
-                   g_logits, vec, env_pool_first);
+                   g_logits, vec, pool_first);
     }
     rc = check_launch();
     if (rc != BXI_OK) return rc;
