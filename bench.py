@@ -886,7 +886,7 @@ def measured_traffic():
     """HBM bytes per launch from the committed PMC summary of this command (profiles/*_hbm_traffic.json, written by
     tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes) -> (dict, file) or (None, None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r03*_hbm_traffic.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r0*_hbm_traffic.json')))
     if not files:
         return None, None
     try:
