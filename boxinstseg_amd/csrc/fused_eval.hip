@@ -1401,7 +1401,7 @@ __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& v
 template <int D, int R>
 // (four workgroups per CU only where the tile role fits 128 VGPRs without spilling: dilation <= 2 -- every shipped configuration uses 2;
 // dilation 3 needs 10-row register arrays and ran with 9 spilled VGPRs at four per CU)
-__global__ __launch_bounds__(256, (R == 4 ? (D <= 2 ? 4 : 3) : 2)) void pair_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
+__global__ __launch_bounds__(256, (R == 4 ? (D <= 2 ? 4 : 3) : (D <= 2 ? 3 : 2))) void pair_kernel(const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup,
                                                        float n2max, int zero_bit, int n_pb, int n_items, int spin_limit, ValidCells vc, float* __restrict__ losses,
                                                        float* __restrict__ g_logits, InstArgs a, Ws ws_in, LossState st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1618,10 +1618,12 @@ static int stream_cus(hipStream_t s, int device_total) {
     return n;
 }
 
-// Rows per tile.  4 everywhere: with the round-3 pair kernel the shorter tile wins at every instance count measured (two launches,
-// 200 x 256 maps: 39.4 vs 47.7 us at 128 instances, 74.8 vs 101.5 at 256, 164 us at 512); 8-row tiles stay instantiated for
-// BXI_TILE_ROWS=8 / force_rows (tests).
-static int tile_rows_for(int N) { (void)N; return 4; }
+// Rows per tile: 4 up to ~95 instances, 8 from there on (two launches; dilation <= 2).  With 4-row tiles 128 instances are ~4600
+// tiles on ~2500 tile waves: two rounds of a ~7 us dependent chain (table -> logits -> predicate words -> pair loop -> sum W -> adds).
+// 8-row tiles halve the count; at 157 - 161 VGPRs they run three workgroups per CU (round 3 ran them at two, where they lost): one
+// round.  Measured (two launches, 200 x 256 maps, same box): 96 instances 29.4 vs 30.1 us, 128: 35.9 vs 38.3, 256: 64.0 vs 69.7;
+// 64 instances: 24.2 vs 23.8 (single launch) -- hence the threshold.  BXI_TILE_ROWS / BXI_EVAL_TILE_ROWS_8 override.
+static int tile_rows_for(int N, int dil) { return (N >= 96 && dil <= 2) ? 8 : 4; }
 
 // (sim >= thresh) for a valid neighbour as a compare on the squared Lab distance: exp(-0.5 * sqrt(n2)) >= thresh  <=>  n2 <= n2max
 // (get_image_color_similarity :237 + the threshold of loss() :1324), n2max found by bisecting the f32 expression over the float
@@ -1729,7 +1731,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     static const int env_pool_first = env_int("BXI_POOL_FIRST", 0);
     static const int env_pool_wgs = env_int("BXI_POOL_WGS_PER_CU", 5);
     const int force_rows = (flags & kFlagRows8) ? 8 : env_rows;
-    const int R = force_rows == 4 || force_rows == 8 ? force_rows : tile_rows_for(a.N);
+    const int R = force_rows == 4 || force_rows == 8 ? force_rows : ((flags & kFlagSingle) ? 4 : tile_rows_for(a.N, dil));
     if (eval_cap(a.N, a.h, a.w, dil, R) >= (1 << 24)) return BXI_ERR_BAD_SHAPE;     // the table packs a tile prefix into 24 bits
     const HostPred pr = host_pred(color_thresh);
     ValidCells vc = {};
@@ -1865,7 +1867,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     // the tile list's length is device data: the tile waves stride through it.  The launch should be resident in one round:
     // 4 (R = 4: <= 128 VGPRs) or 2 (R = 8) workgroups per CU; the predicate waves are short-lived.
     static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 0);
-    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? (dil <= 2 ? 4 : 3) : 2);
+    const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? (dil <= 2 ? 4 : 3) : (dil <= 2 ? 3 : 2));
     // (the leaders are short-lived and are not counted; with them subtracted, 512 instances at two workgroups per CU left ONE
     // predicate workgroup for the whole image side: 4.4 ms per evaluation)
     const int cus2 = stream_cus(s, device_cus());                      // a CU-masked stream has fewer

@@ -39,7 +39,7 @@ with torch.no_grad():
 
     class Ctx:
         pass
-    ctx = Ctx(); ctx.cfg, ctx.logits, ctx.imgs, ctx.gt_inds, ctx.boxes, ctx.metas = cfg, x, imgs, gi, boxes, metas
+    ctx = Ctx(); ctx.cfg, ctx.logits, ctx.imgs, ctx.gt_inds, ctx.boxes, ctx.metas, ctx.calls = cfg, x, imgs, gi, boxes, metas, 0
     t('BoxInstMaskLoss._evaluate (no grad buffer)', lambda: Fh.BoxInstMaskLoss._evaluate(ctx, False))
     t('BoxInstMaskLoss._evaluate (grad buffer)', lambda: Fh.BoxInstMaskLoss._evaluate(ctx, True))
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -58,9 +58,9 @@ with torch.no_grad():
     t('torch.cuda.current_device()', lambda: torch.cuda.current_device())
     base = buf.data_ptr()
     plan.batch.imgs, plan.inst.logits, plan.inst.gt_inds = imgs.data_ptr(), x.data_ptr(), gi.data_ptr()
-    args = (plan.batch_ref, plan.inst_ref, 3, 2, 0.3, 1.0, 0, 0, base, base + 256 + plan.state_bytes, base + 256, plan.ws_ptr, plan.ws_bytes, stream)
+    args = (plan.batch_ref, plan.inst_ref, 3, 2, 0.3, 1.0, 0, 0, base, base + 256 + plan.state_bytes, base + 256, plan.ws_ptr, plan.ws_bytes, 0, stream)
     t('plan.eval(*args) [ctypes + C side + launch]', lambda: plan.eval(*args))
     lib = _lib.load()
     t('ctypes call of a trivial entry (bxi_last_hip_error)', lambda: lib.bxi_last_hip_error())
     t('3 struct field stores', lambda: (setattr(plan.batch, 'imgs', base), setattr(plan.inst, 'logits', base), setattr(plan.inst, 'gt_inds', base)))
-    t('head._tick()', lambda: head._tick())
+    pass
