@@ -178,11 +178,12 @@ def worker(args):
     if status[0] != 0:
         raise SystemExit(f'in-kernel wait timed out (status {status[0]}): refusing to time')
     parity = None
+    rank_parity = None
     cpu_leg = None
-    if world > 1 and not args.no_cpu_baseline:
-        # N > 1: EVERY rank checks its own first set against the C oracle before anything is timed (the checker only: the timed CPU
-        # baseline stays a rank-0, N == 1 figure), and one rank's mismatch fails the whole run
-        parity = parity_gate_only(sets[0])
+    if dist is not None and not args.no_cpu_baseline:
+        # one process per GPU (any N): EVERY rank checks its own first set against the C oracle before anything is timed (the checker
+        # only: the timed CPU baseline stays a rank-0, N == 1 figure), and one rank's mismatch fails the whole run
+        rank_parity = parity = parity_gate_only(sets[0])
         bad = torch.tensor([0.0 if parity['ok'] else 1.0], device=dev)
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         if float(bad.item()) != 0.0:
@@ -334,8 +335,8 @@ def worker(args):
         mine = {'rank': rank, 'device': dev.index, 'name': props.name, 'arch': getattr(props, 'gcnArchName', None),
                 'pci_bus_id': '%04x:%02x:%02x' % (getattr(props, 'pci_domain_id', 0), getattr(props, 'pci_bus_id', 0), getattr(props, 'pci_device_id', 0)),
                 'uuid': str(getattr(props, 'uuid', ''))}
-        if parity is not None:
-            mine['parity'] = parity
+        if rank_parity is not None:
+            mine['parity'] = rank_parity
         ranks = [None] * world
         dist.all_gather_object(ranks, mine)
         result['multi_gpu'] = {

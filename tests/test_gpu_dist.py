@@ -93,6 +93,14 @@ def test_bench_spawns_its_own_ranks(dev):
     res = json.loads(line)
     assert res['n_gpus'] == n and res['multi_gpu']['world_size'] == n and res['value'] > 0
     assert res['multi_gpu']['allreduce_alone_us'] > 0
+    # with the CPU leg allowed, EVERY rank gates itself against the C oracle before timing and reports it
+    cmd2 = [c for c in cmd if c != '--no-cpu-baseline'] + ['--cpu-seconds', '1']
+    r = subprocess.run(cmd2, capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')][-1])
+    assert len(res['multi_gpu']['ranks']) == n
+    for rk in res['multi_gpu']['ranks']:
+        assert rk['parity']['ok'] and rk['parity']['grad_rel_max'] <= 1e-4
     # asking for more GPUs than there are must fail loudly, not report a smaller world
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(torch.cuda.device_count() + 1), '--steps', '5'],
                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
