@@ -543,9 +543,14 @@ def rows_extra():
     if 'error' not in r:
         f32 = r['torch.float32']
         nb = 32 * 200 * 256 * 4
-        out['pairwise_op'] = {'shape': '[32,1,200,256] f32, size 3, dilation 2 (pairwise.cu:68-202)', 'fwd_us': f32['fwd_us'], 'bwd_us': f32['bwd_us'],
+        out['pairwise_op'] = {'shape': '[32,1,200,256] f32, size 3, dilation 2 (pairwise.cu:68-202); COLD inputs (6 rotating sets > Infinity Cache)',
+                              'fwd_us': f32['fwd_us'], 'bwd_us': f32['bwd_us'], 'fwd_warm_us': f32.get('fwd_warm_us'), 'bwd_warm_us': f32.get('bwd_warm_us'),
                               'fwd_bytes': 9 * nb, 'bwd_bytes': 10 * nb, 'fwd_frac': frac(9 * nb, f32['fwd_us']), 'bwd_frac': frac(10 * nb, f32['bwd_us']),
                               'bytes_model': 'forward: logits read + 8 planes written; backward: logits + 8 upstream planes read + gradient written',
+                              'fwd_sol_us': f32.get('fwd_sol_us'), 'bwd_sol_us': f32.get('bwd_sol_us'),
+                              'fwd_frac_of_sol': f32['fwd_sol_us'] / f32['fwd_us'] if f32.get('fwd_sol_us') else None,
+                              'bwd_frac_of_sol': f32['bwd_sol_us'] / f32['bwd_us'] if f32.get('bwd_sol_us') else None,
+                              'sol': 'the same bytes moved by a copy kernel (bxi_dev_sol_pairwise_f32: 16-byte accesses, nothing computed), timed the same way',
                               'f64_fwd_us': r['torch.float64']['fwd_us'], 'f64_bwd_us': r['torch.float64']['bwd_us']}
     else:
         out['pairwise_op'] = r

@@ -49,6 +49,7 @@ SIGNATURES = {
     'bxi_dev_set_tree_level_walk': (None, [c_int]),                    # boxinst_hip_dev.h (tests only)
     'bxi_dev_sol_eval_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
                                      c_void_p]),                        # boxinst_hip_dev.h (bench only)
+    'bxi_dev_sol_pairwise_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),   # boxinst_hip_dev.h (bench only)
     'bxi_pairwise_nlog_forward_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'bxi_pairwise_nlog_forward_f64': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'bxi_pairwise_nlog_backward_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -91,7 +91,40 @@ __global__ __launch_bounds__(256, 4) void sol_eval_kernel(SolArgs a) {
     (void)smem;
 }
 
+// ---- the op-level pairwise_nlog kernels' bytes (pairwise.cu:68-202 at size 3: 8 planes), nothing else ------------------------------------
+// mode 0: the forward's traffic -- logits [N,1,H,W] read, planes [N,8,H,W] written; mode 1: the backward's -- logits and planes read,
+// out [N,1,H,W] written.  16-byte accesses, a wave's accesses contiguous, one pass per thread: what a copy can do on this part.
+__global__ __launch_bounds__(256) void sol_pairwise_kernel(const float4* __restrict__ logits, float4* __restrict__ planes, float4* __restrict__ out,
+                                                           long n4, int mode) {
+    const long T = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += T) {
+        const float4 a = logits[i];
+        if (mode == 0) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) planes[p * n4 + i] = make_float4(a.x + p, a.y, a.z, a.w);
+        } else {
+            float4 q[8], s = a;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) q[p] = planes[p * n4 + i];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) { s.x += q[p].x; s.y += q[p].y; s.z += q[p].z; s.w += q[p].w; }
+            out[i] = s;
+        }
+    }
+}
+
 }  // namespace bxi
+
+extern "C" int bxi_dev_sol_pairwise_f32(const float* logits, float* planes, float* out, int N, int H, int W, int mode, void* stream) {
+    if (!logits || !planes || (mode == 1 && !out)) return BXI_ERR_NULL_POINTER;
+    const long n = (long)N * H * W;
+    if (N <= 0 || H <= 0 || W <= 0 || (n & 3) || mode < 0 || mode > 1) return BXI_ERR_BAD_SHAPE;
+    const long n4 = n / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 > 1664 ? 1664 : (n4 + 255) / 256);
+    hipStream_t s = bxi::as_stream(stream);
+    BXI_LAUNCH("sol_pairwise", s, bxi::sol_pairwise_kernel, dim3(grid), dim3(256), 0, s, (const float4*)logits, (float4*)planes, (float4*)out, n4, mode);
+    return bxi::check_launch();
+}
 
 extern "C" int bxi_dev_sol_eval_f32(const float* imgs, int B, int Hc, int Wc, const float* logits, int N, int h, int w, float* g_logits, void* workspace,
                                     size_t workspace_bytes, void* stream) {

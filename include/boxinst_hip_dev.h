@@ -30,6 +30,10 @@ void bxi_dev_set_tree_level_walk(int on);
  * Leaves garbage in g_logits / workspace.  csrc/sol_eval.hip. */
 int bxi_dev_sol_eval_f32(const float* imgs, int B, int Hc, int Wc, const float* logits, int N, int h, int w, float* g_logits,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The same for the op-level kernels (tools/bench_pairwise_op.py, bench.py `extras.pairwise_op.*_sol_us`): the bytes of
+ * pairwise_nlog's forward (mode 0: logits [N,1,H,W] read, planes [N,8,H,W] written) or backward (mode 1: logits and planes read, out
+ * [N,1,H,W] written; pairwise.cu:68-202 at size 3) moved by a copy -- 16-byte accesses, nothing computed.  N*H*W % 4 == 0. */
+int bxi_dev_sol_pairwise_f32(const float* logits, float* planes, float* out, int N, int H, int W, int mode, void* stream);
 
 #ifdef __cplusplus
 }
