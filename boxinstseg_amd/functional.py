@@ -235,6 +235,7 @@ class _Local(threading.local):
         self.sizes: Dict[tuple, Tuple[int, int]] = {}
         self.norms: Dict[tuple, tuple] = {}
         self.flags = 0                      # BXI_EVAL_* bits every evaluation of this thread is launched with (eval_flags, note_fault)
+        self.wait_free = False              # after a fault in the two-launch form: the launches-only path (no in-kernel wait at all)
         self.forced: Optional[int] = None   # tests: the flags instead of what this module would choose
 
 
@@ -301,6 +302,7 @@ def eval_flags(flags: int):
 def reset_eval_state(drop_workspaces: bool = True) -> None:
     """Forget this thread's sticky launch flags (and, by default, its workspaces: the next evaluation allocates a zeroed one)."""
     _TLS.flags = 0
+    _TLS.wait_free = False
     if drop_workspaces:
         _TLS.workspaces.clear()
     else:
@@ -312,8 +314,16 @@ def note_fault(what: str = '') -> None:
     """An evaluation reported a non-zero status / non-finite losses (a bounded in-kernel wait ran out -- never expected on a GPU
     the process has to itself): from now on this thread takes the two-launch form, whose every wait is for a workgroup EARLIER
     in its grid (progress whatever else occupies the device), and its workspaces are zeroed again as the ABI asks after a fault.
-    Called where losses reach the host anyway (``dist.parse_losses``); never synchronises by itself."""
-    if not (_TLS.flags & _lib.EVAL_TWO_LAUNCHES):
+    Called where losses reach the host anyway (``dist.parse_losses``); never synchronises by itself.
+    A fault while ALREADY in the two-launch form (workgroups are not being dispatched in grid order, or the device is starved for
+    longer than the waits' bound) takes the last step down: the path without any in-kernel wait -- ``bxi_color_affinity_f32`` +
+    ``bxi_boxinst_loss_fwd_bwd_f32`` + ``bxi_boxinst_loss_backward_f32``, four launches ordered by the stream alone."""
+    if _TLS.flags & _lib.EVAL_TWO_LAUNCHES:
+        if not _TLS.wait_free:
+            warnings.warn('boxinstseg_amd: an evaluation in the two-launch form reported a fault%s; taking the path without in-kernel '
+                          'waits from here on' % (f' ({what})' if what else ''), RuntimeWarning, stacklevel=2)
+        _TLS.wait_free = True
+    else:
         warnings.warn('boxinstseg_amd: an evaluation reported a fault%s; taking the two-launch form from here on'
                       % (f' ({what})' if what else ''), RuntimeWarning, stacklevel=2)
     _TLS.flags = (_TLS.flags | _lib.EVAL_TWO_LAUNCHES) & ~_lib.EVAL_SINGLE_LAUNCH
@@ -696,6 +706,19 @@ def boxinst_mask_loss(mask_logits: torch.Tensor, gt_inds: torch.Tensor, gt_bboxe
             cfg['warmup_iters'] = float(warmup_iters)
     elif warmup_iters is not None:
         raise RuntimeError('warmup_iters needs iter_counter (the factor is evaluated from the device counter)')
+    if affinity_bits is None and _TLS.wait_free and _TLS.forced is None and pairwise_dilation <= 8:
+        # the last step of the fall-back ladder (note_fault): targets and loss as separate launches, no in-kernel wait anywhere.
+        # The counter is advanced and read on the host, as the reference does (condinst_head.py:1297,1330-1331): one sync per call
+        # on a path that exists for a device in trouble.
+        if iter_counter is not None:
+            iter_counter += 1
+            if warmup_iters is not None:
+                cfg['warmup_factor'] = min(float(iter_counter.item()) / float(warmup_iters), 1.0)
+            cfg.pop('iter_counter', None)
+            cfg.pop('warmup_iters', None)
+        _, affinity_bits, _ = color_affinity(imgs, img_metas, out_stride=out_stride, bottom_pixels_removed=bottom_pixels_removed,
+                                             pairwise_size=pairwise_size, pairwise_dilation=pairwise_dilation,
+                                             pairwise_color_thresh=pairwise_color_thresh, want_similarity=False, want_bits=True)
     loss_prj, loss_pw = BoxInstMaskLoss.apply(mask_logits, imgs, img_metas, gt_inds, list(gt_bboxes), cfg,
                                               affinity_bits)
     return {'loss_prj': loss_prj, 'loss_pairwise': loss_pw}

@@ -909,3 +909,30 @@ def test_fault_is_noticed_where_losses_reach_the_host_and_the_next_evaluations_t
         lib.bxi_dev_set_launch_hook(None, None)
     assert 'prep' in names and 'pair' in names and 'eval1' not in names, names
     assert again[0] == good[0] and again[1] == good[1] and np.array_equal(again[2], good[2])
+    # ... and a fault while ALREADY in the two-launch form takes the last step down: the path without any in-kernel wait
+    # (colour-affinity bits, then bxi_boxinst_loss_fwd_bwd_f32 / _backward_f32: launches ordered by the stream alone)
+    with warnings.catch_warnings(record=True) as w2:
+        warnings.simplefilter('always')
+        Fh.note_fault('forced by the test')
+    assert any('without in-kernel waits' in str(x.message) for x in w2)
+    names.clear()
+    lib.bxi_dev_set_launch_hook(C.cast(cb, C.c_void_p), None)
+    try:
+        ref = oracle_path(d, want_targets=False)
+        x = t['logits'].clone().requires_grad_(True)
+        out = boxinst_mask_loss(x, t['gt_inds'], t['gt_bboxes'], imgs=t['imgs'], img_metas=d['img_metas'])
+        (out['loss_prj'] + out['loss_pairwise']).backward()
+        torch.cuda.synchronize()
+    finally:
+        lib.bxi_dev_set_launch_hook(None, None)
+    assert not ({'eval1', 'prep', 'pair'} & set(names)) and 'box' in names and 'stage1' in names, names
+    assert rel(float(out['loss_prj']), ref['loss_prj']) <= TOL and rel(float(out['loss_pairwise']), ref['loss_pairwise']) <= TOL
+    err, _ = grad_report(x.grad.cpu().numpy()[:, 0], ref['grad'], d['mask_logits'][:, 0])
+    assert err <= TOL, err
+    # the module's counter still counts and ramps on that path (on the host, as the reference: condinst_head.py:1297,1330-1331)
+    from boxinstseg_amd import CondInstMaskHead
+    head = CondInstMaskHead(in_channels=16, boxinst_enabled=True, topk_per_img=64, max_proposals=-1, pairwise_warmup=100).to(dev)
+    head.set_iter(49)
+    with torch.no_grad():
+        o2 = head.loss(t['imgs'], d['img_metas'], t['logits'], t['gt_inds'], t['gt_bboxes'], None, None)
+    assert float(head._iter) == 50.0 and rel(float(o2['loss_pairwise']), 0.5 * ref['loss_pairwise']) <= TOL
