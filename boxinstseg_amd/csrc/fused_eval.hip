@@ -97,6 +97,26 @@ static __device__ int g_ablate = 0;
 #define BXI_AB(bit) false
 #endif
 
+// back-off between the polls of the bounded in-grid waits, in units of 64 clocks (tuning knobs; A/B of 1 .. 32 on one box moved the step by +-0.15 us at most: the waits are not what the launch ends on)
+#ifndef BXI_SLEEP_TAB
+#define BXI_SLEEP_TAB 16
+#endif
+#ifndef BXI_SLEEP_PRED
+#define BXI_SLEEP_PRED 16
+#endif
+#ifndef BXI_SLEEP_WORDS
+#define BXI_SLEEP_WORDS 8
+#endif
+#ifndef BXI_SLEEP_SUMW
+#define BXI_SLEEP_SUMW 8
+#endif
+#ifndef BXI_SLEEP_LEAD
+#define BXI_SLEEP_LEAD 4
+#endif
+#ifndef BXI_SLEEP_FIN
+#define BXI_SLEEP_FIN 2
+#endif
+
 #define BXI_RLX __ATOMIC_RELAXED
 #define BXI_AGENT __HIP_MEMORY_SCOPE_AGENT
 
@@ -293,7 +313,7 @@ __device__ __forceinline__ bool tab_entry(const Ws& ws, int m, bool want, int sp
             e = want ? make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w) : make_int4(0, 0, 0, 0);
             return true;
         }
-        __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_s_sleep(BXI_SLEEP_TAB);
     }
     e = make_int4(0, 0, 0, 0);
     return false;
@@ -797,7 +817,7 @@ __device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc
                 got = true;
                 break;
             }
-            __builtin_amdgcn_s_sleep(16);
+            __builtin_amdgcn_s_sleep(BXI_SLEEP_PRED);
         }
         if (!got) { ok = false; return 0; }
     } else {
@@ -901,7 +921,7 @@ __device__ __forceinline__ bool pred_words(const Ws& ws, const Tile& t, int h, i
             all = all && (pbyte[i] >> 4) == ws.ep;
         }
         if (__all(all)) { ok = true; break; }
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(BXI_SLEEP_WORDS);
     }
     return ok;        // false: the caller's arrival says so, and the finisher turns both losses into NaN
 }
@@ -1023,7 +1043,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
             }
             bands_ok = f0 == ws.ep && f1 == ws.ep;
             if (have_scale && bands_ok) { ok = true; break; }
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(BXI_SLEEP_SUMW);
         }
         bad |= !ok;
         have_scale = true;
@@ -1089,14 +1109,14 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const W
             const unsigned int f = lane < ws.n_cb ? __hip_atomic_load(&ws.bandflag[(int64_t)n * ws.n_cb + lane], BXI_RLX, BXI_AGENT) : ws.ep;
             const u4v v = load16_past(ws.tab + n);                 // (its wait covers the flag load issued before it)
             if (__all(f == ws.ep && v.w == ws.ep)) { e = make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w); waited = true; break; }
-            __builtin_amdgcn_s_sleep(16);
+            __builtin_amdgcn_s_sleep(BXI_SLEEP_LEAD);
         }
         for (int b0 = 64; b0 < ws.n_cb && waited; b0 += 64) {
             bool got = false;
             for (int spins = 0; spins <= spin_limit; ++spins) {
                 const unsigned int f = b0 + lane < ws.n_cb ? __hip_atomic_load(&ws.bandflag[(int64_t)n * ws.n_cb + b0 + lane], BXI_RLX, BXI_AGENT) : ws.ep;
                 if (__all(f == ws.ep)) { got = true; break; }
-                __builtin_amdgcn_s_sleep(16);
+                __builtin_amdgcn_s_sleep(BXI_SLEEP_LEAD);
             }
             waited = got;
         }
@@ -1302,14 +1322,14 @@ __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, c
         for (int b0 = 0; b0 < N && ok; b0 += 64) {
             while (!dice_round(ws, N, b0, &dsum, &flt0)) {
                 if (++spins > spin_limit) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(BXI_SLEEP_FIN);
             }
         }
         if (zero_bit) total_w = total_weight_all_pairs(a, ws);
         else
             while (ok && !counts_complete(ws, n_items, &total_w, &flt0)) {
                 if (++spins > spin_limit) ok = false;
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(BXI_SLEEP_FIN);
             }
         if (lane == 0) { fin_f = dsum; fin_d[0] = total_w; fin_ok = ok ? 1 : 0; fin_flt = flt0 ? 1 : 0; }
     }
