@@ -30,7 +30,13 @@
 //                   its own predicate bytes (bit 7 = evaluated) before the pair loop, the published sum W (the global
 //                   normaliser) after it; both are produced by workgroups that precede it in the grid and never wait
 //                   for a tile.
-//     finisher      the last workgroup: polls the accumulators, writes the two loss values.
+//     finisher      the last workgroup: polls the accumulators (every tile wave arrives exactly once, with or without tiles), writes the two
+//                   loss values and, as its last act, advances the workspace's epoch.
+// What one workgroup hands to another inside a launch carries the evaluation's TAG = epoch + 1; the epoch is word 0 of the workspace,
+// read on the device by every kernel of an evaluation (with_tag) -- nothing about it is a kernel argument, so a captured launch replayed
+// from a hipGraph is as correct as an eager one; the warm-up factor likewise (resolve_warmup).  The workspace is zeroed once and keeps ONE
+// layout (a function of the canvas and of its size), so a tag field only ever holds tags.  The launch's form is the caller's `flags`
+// (include/boxinst_hip.h: BXI_EVAL_*): the library keeps no process-wide state and guesses nothing about what else runs on the device.
 // Every wait is bounded and running out of it is loud: NaN losses, a status word, a poisoned gradient (rescale_kernel).
 // Table entries instead of a work list: a tile wave finds its tile from 16 bytes per instance that every wave reads (the same
 // few cache lines), not from a record of its own behind a list length (two dependent misses right after the kernel boundary).
@@ -146,6 +152,22 @@ __device__ __forceinline__ void load16_past_x5(const void* p0, const void* p1, c
                  "global_load_dwordx4 %3, %8, off sc1\n\tglobal_load_dwordx4 %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4) : "memory");
 }
+__device__ __forceinline__ u4v load16_past_epoch(const void* p, const unsigned int* epoch, unsigned int& ep_word) {
+    u4v v;
+    asm volatile("global_load_dword %1, %3, %4\n\tglobal_load_dwordx4 %0, %2, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v), "=&v"(ep_word) : "v"(p), "v"(0), "s"(epoch) : "memory");
+    return v;
+}
+// ... and the workspace's epoch word in the same round trip (a wave that does not know the evaluation's tag yet: with_tag)
+__device__ __forceinline__ void load16_past_x5_epoch(const void* p0, const void* p1, const void* p2, const void* p3, const void* p4, const unsigned int* epoch,
+                                                     u4v& a, u4v& b, u4v& c, u4v& d, u4v& e, unsigned int& ep_word) {
+    asm volatile("global_load_dword %5, %11, %12\n\tglobal_load_dwordx4 %0, %6, off sc1\n\tglobal_load_dwordx4 %1, %7, off sc1\n\t"
+                 "global_load_dwordx4 %2, %8, off sc1\n\tglobal_load_dwordx4 %3, %9, off sc1\n\tglobal_load_dwordx4 %4, %10, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(ep_word)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(0), "s"(epoch)
+                 : "memory");
+}
 __device__ __forceinline__ float4 f4_of(const u4v& v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
 
 // ---- workspace ---------------------------------------------------------------------------------------------------------
@@ -175,13 +197,20 @@ __device__ __forceinline__ unsigned long long* acc2_word(unsigned long long* acc
     return acc2 + ((size_t)n * kAcc2Split + (sub & (kAcc2Split - 1))) * kAcc2Stride;
 }
 
-// This evaluation's tag: one more than the tag of the last evaluation that FINISHED on this workspace.  Every kernel of an evaluation
-// reads the word when its waves start; only the finisher -- the last workgroup, which has by then seen every other wave of the
-// launch arrive (each tile wave arrives exactly once, with or without tiles) -- writes it.  Evaluations that share a workspace are
-// serialised by their stream, so the word is stable while anybody reads it.
+// This evaluation's tag: one more than the tag of the last evaluation that FINISHED on this workspace.  Every wave of an evaluation
+// reads the word; only the finisher -- the last workgroup, which has by then seen every other wave of the launch arrive (each tile
+// wave arrives exactly once, with or without tiles) -- writes it.  Evaluations that share a workspace are serialised by their stream,
+// so the word is stable while anybody reads it, and a reader is always a LATER kernel than the writer: a scalar load (constant cache,
+// invalidated at every dispatch) on one side, a plain store on the other.  What it costs is WHERE it is read: a wave that reads it
+// first thing starts one dependent memory round trip late -- the whole launch with it (18.1 against 17.4 us with the tag as a kernel
+// argument, same box).  The roles that head the launch's dependency chain (stream, pool) therefore read it behind their first loads
+// (`after_loads`), where the round trip hides; the others wait for somebody anyway.  Likewise the finisher's store: written through
+// (sc1) it is acknowledged ~0.3 us later than a plain one, and the launch ends on it.
 __device__ __forceinline__ unsigned int next_tag(unsigned int e) { const unsigned int t = (e + 1u) & 0x0fffffffu; return t ? t : 1u; }
 __device__ __forceinline__ Ws with_tag(Ws ws) {
-    ws.ep = next_tag((unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ws.epoch, BXI_RLX, BXI_AGENT)));
+    unsigned int e;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e) : "s"(ws.epoch) : "memory");
+    ws.ep = next_tag(e);
     return ws;
 }
 // min(_iter / pairwise_warmup, 1) (condinst_head.py:1330-1331).  warmup >= 0: the caller's value.  warmup < 0: -warmup is
@@ -335,9 +364,13 @@ struct LogitRows {
     __device__ __forceinline__ float4 operator()(int r, int c) const { return load4(L + (int64_t)r * w, c, w, vec); }
 };
 
-template <bool ONE, typename Src>
-__device__ __forceinline__ void stream_block(const InstArgs& a, const Ws& ws, float* __restrict__ g_logits, int vec, int sb,
-                                             unsigned long long* colp /* LDS [kWaves][w] */, const Src& src, int tix) {
+struct NoHook { __device__ __forceinline__ void operator()(Ws&) const {} };
+
+// `after_loads(ws)` runs once the zero-fill stores and the first loads are issued: the place for work whose latency should hide
+// behind them (the evaluation's tag, read from the device: with_tag)
+template <bool ONE, typename Src, typename Hook = NoHook>
+__device__ __forceinline__ void stream_block(const InstArgs& a, Ws& ws, float* __restrict__ g_logits, int vec, int sb,
+                                             unsigned long long* colp /* LDS [kWaves][w] */, const Src& src, int tix, const Hook& after_loads = Hook()) {
     const int h = a.h, w = a.w;
     const int Sn = (h + kSBlk - 1) / kSBlk;
     const int n = sb / Sn, s = sb % Sn;
@@ -367,6 +400,7 @@ __device__ __forceinline__ void stream_block(const InstArgs& a, const Ws& ws, fl
 #pragma unroll
         for (int i = 0; i < kSRows; ++i) v[i] = (r0 + i < r1 && c < w && !BXI_AB(64)) ? src(r0 + i, c) : ninf;
     }
+    after_loads(ws);
     BXI_TW(0, tix, 1);
     float rmax[kSRows]; int rcol[kSRows];
 #pragma unroll
@@ -483,13 +517,15 @@ __device__ __forceinline__ float n2_of(float L0, float A0, float B0, float L1, f
 }
 
 // items first, first + step, ... < n_items
-__device__ __forceinline__ void pool_block(const PoolArgs& pa, const Ws& ws, int first, int step, int n_items, double* lut /*[256]*/,
-                                           int* part /*[4][3][64]*/, double* fch /*[3][64]*/, int tix) {
+template <typename Hook = NoHook>
+__device__ __forceinline__ void pool_block(const PoolArgs& pa, Ws& ws, int first, int step, int n_items, double* lut /*[256]*/,
+                                           int* part /*[4][3][64]*/, double* fch /*[3][64]*/, int tix, const Hook& after_loads = Hook()) {
     const int h = pa.Hc >> 2, w = pa.Wc >> 2;
     const int segs = (w + 63) >> 6;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float4 v[3], nx[3];
     pool_load(pa, first, segs, h, w, v);
+    after_loads(ws);
     lut[threadIdx.x] = kSrgbLut[threadIdx.x];            // staged while the image loads fly
     for (int item = first; item < n_items; item += step) {
         const bool more = item + step < n_items;         // workgroup-uniform
@@ -554,7 +590,7 @@ __device__ __forceinline__ void pool_block(const PoolArgs& pa, const Ws& ws, int
 __global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, Ws ws_in, LossState st,
                                                        float* __restrict__ g_logits, int vec, int pool_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Ws ws = with_tag(ws_in);
+    Ws ws = ws_in;                                        // the tag is read where a role needs it (with_tag), behind its loads
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
     const int Sn = (a.h + kSBlk - 1) / kSBlk;
     const int n_stream = a.N * Sn;
@@ -571,15 +607,15 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, i
     }
     if (role == 0) {
         const int k = blk * kWaves + (int)(threadIdx.x >> 6);
-        if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, ws, st, k, true);
+        if (64 * k <= a.N) { ws = with_tag(ws); table_wave(a, pa.meta, dil, R, ws, st, k, true); }
     } else if (role == 2) {
         const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
-        stream_block<false>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);
+        stream_block<false>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);     // (no tagged record in this form)
     } else {
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
         int* part = reinterpret_cast<int*>(fch + 3 * 64);
-        pool_block(pa, ws, idx, n_pool, n_items, lut, part, fch, tix);
+        pool_block(pa, ws, idx, n_pool, n_items, lut, part, fch, tix, [&](Ws& w_) { w_ = with_tag(w_); });
     }
     BXI_TW(0, tix, 7);
 }
@@ -594,7 +630,7 @@ __global__ __launch_bounds__(256, 7) void head_prep_kernel(PoolArgs pa, int n_po
                                                             float* __restrict__ g_logits, DynArgs da, const float* __restrict__ params,
                                                             float* __restrict__ logits_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Ws ws = with_tag(ws_in);
+    Ws ws = with_tag(ws_in);
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
     const int blk = (int)blockIdx.x;
     const int tix = blk * kWaves + (int)(threadIdx.x >> 6);
@@ -792,7 +828,7 @@ __device__ __forceinline__ float lane_plus_n(float v, int d) {
 }
 struct ValidCells { int vrow[BXI_MAX_IMAGES], vcol[BXI_MAX_IMAGES]; };   // per image: valid(q) <=> row(q) < vrow && col(q) < vcol (host: :1354-1369,:1405)
 template <bool ONE>
-__device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc, const Ws& ws, int D, float n2max, int item, int segs, int spin_limit, bool& ok) {
+__device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc, Ws& ws, int D, float n2max, int item, int segs, int spin_limit, bool& ok) {
     const int h = a.h, w = a.w, lane = threadIdx.x & 63;
     const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
     const int c = seg * 64 + lane, cn = c + D;
@@ -809,8 +845,14 @@ __device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc
         bool got = false;
         for (int spins = 0; spins <= spin_limit; ++spins) {
             u4v q0, q1, q2, q3, qe;      // the table entry travels with the pixels: one round trip
-            load16_past_x5(L4 + (int64_t)r * w + cc, L4 + (int64_t)rD * w + cc, L4 + (int64_t)r * w + cx, L4 + (int64_t)rD * w + cx,
-                           ws.tab + (lane < a.N ? lane : 0), q0, q1, q2, q3, qe);
+            if (ws.ep == 0u) {           // wave-uniform: this wave's first poll -- the evaluation's tag travels with it too (with_tag)
+                unsigned int e;
+                load16_past_x5_epoch(L4 + (int64_t)r * w + cc, L4 + (int64_t)rD * w + cc, L4 + (int64_t)r * w + cx, L4 + (int64_t)rD * w + cx,
+                                     ws.tab + (lane < a.N ? lane : 0), ws.epoch, q0, q1, q2, q3, qe, e);
+                ws.ep = next_tag((unsigned int)__builtin_amdgcn_readfirstlane((int)e));
+            } else
+                load16_past_x5(L4 + (int64_t)r * w + cc, L4 + (int64_t)rD * w + cc, L4 + (int64_t)r * w + cx, L4 + (int64_t)rD * w + cx,
+                               ws.tab + (lane < a.N ? lane : 0), q0, q1, q2, q3, qe);
             if (__all(q0.w == ws.ep && q1.w == ws.ep && q2.w == ws.ep && q3.w == ws.ep && qe.w == ws.ep)) {
                 o0 = f4_of(q0); oD = f4_of(q1); x0 = f4_of(q2); xD = f4_of(q3);
                 rect = lane < a.N ? make_int4((int)qe.x, (int)qe.y, (int)qe.z, (int)qe.w) : make_int4(-1, 0, 0, 0);
@@ -1089,7 +1131,7 @@ __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf
 //   one 8-byte word per column / row (gradient bits << 32 | arg-max index) for bxi_boxinst_grad_rescale_f32 and ADDED to the
 //   gradient at the arg-max positions.  Nobody in this launch reads what a leader writes except the finisher (its dice loss).
 template <bool ONE>
-__device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const Ws& ws, const LossState& st, int n, float upp,
+__device__ __forceinline__ void leader_block(const InstArgs& a, int dil, Ws ws /* .ep == 0: the first poll fetches the tag */, const LossState& st, int n, float upp,
                                              float* __restrict__ g_logits, unsigned char* smem, float* red, int spin_limit) {
     const int h = a.h, w = a.w, tid = threadIdx.x;
     float* xs = reinterpret_cast<float*>(smem);   // [w] sigmoid of the column maxima, then their unit gradients
@@ -1106,8 +1148,15 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const W
         const int lane = tid & 63;
         waited = false;
         for (int spins = 0; spins <= spin_limit; ++spins) {
-            const unsigned int f = lane < ws.n_cb ? __hip_atomic_load(&ws.bandflag[(int64_t)n * ws.n_cb + lane], BXI_RLX, BXI_AGENT) : ws.ep;
-            const u4v v = load16_past(ws.tab + n);                 // (its wait covers the flag load issued before it)
+            unsigned int f = lane < ws.n_cb ? __hip_atomic_load(&ws.bandflag[(int64_t)n * ws.n_cb + lane], BXI_RLX, BXI_AGENT) : 0u;
+            u4v v;                                                  // (its wait covers the flag load issued before it)
+            if (ws.ep == 0u) {                                      // wave-uniform: the first poll brings the evaluation's tag along (with_tag)
+                unsigned int ew;
+                v = load16_past_epoch(ws.tab + n, ws.epoch, ew);
+                ws.ep = next_tag((unsigned int)__builtin_amdgcn_readfirstlane((int)ew));
+            } else
+                v = load16_past(ws.tab + n);
+            if (lane >= ws.n_cb) f = ws.ep;
             if (__all(f == ws.ep && v.w == ws.ep)) { e = make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w); waited = true; break; }
             __builtin_amdgcn_s_sleep(BXI_SLEEP_LEAD);
         }
@@ -1188,7 +1237,8 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, const W
             ys[r] = gv;
             st.rowk[(int64_t)n * h + r] = ((unsigned long long)__float_as_uint(gv) << 32) | (unsigned int)rarg[r];
         }
-        lds_barrier();        // xs / ys now hold the gradients for every thread (LDS only: the record stores above need not have landed)
+        lds_barrier();
+        // xs / ys now hold the gradients for every thread (LDS only: the record stores above need not have landed)
         // one addition per arg-max position (a pixel that is its column's AND its row's arg-max gets their sum in one)
         float* G = g_logits + (int64_t)n * h * w;
         for (int c = tid; c < w; c += 256) {
@@ -1264,7 +1314,7 @@ __device__ __forceinline__ bool locate_tile(const Ws& ws, const ValidCells& vc, 
 // ---- the roles of the second launch (two-launch form) / of the back half of the single launch ----------------------------------
 // predicate workgroup `pblk` of n_pb: 4 independent waves striding through the pooled row segments
 template <int D, bool ONE>
-__device__ __forceinline__ void pred_role(const InstArgs& a, const ValidCells& vc, const Ws& ws, float n2max, int pblk, int n_pb, int n_items, int spin_limit) {
+__device__ __forceinline__ void pred_role(const InstArgs& a, const ValidCells& vc, Ws ws /* .ep == 0: the first poll fetches the tag */, float n2max, int pblk, int n_pb, int n_items, int spin_limit) {
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int segs = (a.w + 63) >> 6, pid = pblk * kWaves + wave;
     BXI_TW(2, pid, 0);
@@ -1378,7 +1428,7 @@ __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, c
         if (st.status) { st.status[0] = (int)status; if (ONE) st.status[1] = R; }
         if (st.iter) atomicAdd(st.iter, 1.0f);                               // self._iter += 1, condinst_head.py:1297
         // the evaluation is over: every other wave of it has been seen to arrive, so nobody reads the epoch any more
-        __hip_atomic_store(ws.epoch, ws.ep, BXI_RLX, BXI_AGENT);
+        *ws.epoch = ws.ep;      // (a plain store: see with_tag)
     }
     BXI_TW(3, 0, 1);
 }
@@ -1468,7 +1518,7 @@ __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_
     constexpr int R = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[16];
-    const Ws ws = with_tag(ws_in);
+    Ws ws = ws_in;
     const int N = a.N;
     constexpr int n_tab = 0;                                  // (trace index layout: table, stream, pool)
     const int Sn = (a.h + kSBlk - 1) / kSBlk;
@@ -1489,9 +1539,11 @@ __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_
         BXI_TW(0, tix, 0);
         // the table is the first duty of the first stream workgroups' first waves (wave k of the table in workgroup k): a workgroup
         // of its own would be the one workgroup too many for the front half to be resident at once at the headline size
-        if ((threadIdx.x >> 6) == 0 && 64 * idx <= N) table_wave(a, pa.meta, D, R, ws, st, idx, false);
         const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
-        stream_block<true>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);
+        stream_block<true>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix, [&](Ws& w_) {
+            w_ = with_tag(w_);
+            if ((threadIdx.x >> 6) == 0 && 64 * idx <= N) table_wave(a, pa.meta, D, R, w_, st, idx, false);
+        });
         BXI_TW(0, tix, 7);
         if (!merge) return;
         // ... and stays as a tile workgroup: its four waves are the first tile waves, resident since the start of the launch, so their
@@ -1508,10 +1560,12 @@ __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
         int* part = reinterpret_cast<int*>(fch + 3 * 64);
-        pool_block(pa, ws, idx, n_pool, n_items, lut, part, fch, tix);
+        pool_block(pa, ws, idx, n_pool, n_items, lut, part, fch, tix, [&](Ws& w_) { w_ = with_tag(w_); });
         BXI_TW(0, tix, 7);
         return;
     }
+    // (a stream workgroup that stays on has its tag already; predicate waves and leaders get it with their first poll)
+    if (blk >= n_stream && role != 3 && role != 2) ws = with_tag(ws);
     const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
     if (role == 2) {
         BXI_TW(3, 1 + idx, 0);
@@ -1681,8 +1735,8 @@ static HostPred host_pred(float thresh) {
 template <int D, int R>
 static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, float warmup, float n2max, int zero_bit, int n_pb, int n_items, int spin_limit,
                         const ValidCells& vc, const Ws& ws, const LossState& st, float* losses, float* g_logits, const float* up_prj, const float* up_pw) {
-    BXI_LAUNCH("pair", s, (pair_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, up_prj, up_pw, warmup, n2max, zero_bit, n_pb, n_items,
-               spin_limit, vc, losses, g_logits, a, ws, st);
+    BXI_LAUNCH("pair", s, (pair_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, up_prj, up_pw, warmup, n2max, zero_bit,
+               n_pb, n_items, spin_limit, vc, losses, g_logits, a, ws, st);
 }
 
 size_t eval_ws_bytes(int B, int N, int h, int w) { return carve(nullptr, B, N, h, w, nullptr); }
@@ -1866,8 +1920,8 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     } else {
         if (lds1 < 8 * (size_t)kWaves * a.w) lds1 = 8 * (size_t)kWaves * a.w;
         if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
-        BXI_LAUNCH("prep", s, prep_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, ws, st,
-                   g_logits, vec, pool_first);
+        BXI_LAUNCH("prep", s, prep_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, a, dil,
+                   R, ws, st, g_logits, vec, pool_first);
     }
     rc = check_launch();
     if (rc != BXI_OK) return rc;

@@ -2,7 +2,7 @@
 # usage: ab_lib.sh lib1.so lib2.so ... ; bench per library, twice, interleaved (one box)
 mkdir -p gpurun_out
 i=0
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for lib in "$@"; do
   i=$((i+1))
   timeout 300 python tools/with_lib.py $lib bench.py --no-cpu-baseline --no-extras --no-kernel-timing > gpurun_out/abl$i.json 2> gpurun_out/abl$i.err

@@ -7,7 +7,7 @@ import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from boxinstseg_amd import _lib, build as hb
-hb.LIB_PATH = os.path.join(hb.LIB_DIR, 'libboxinst_hip_trace.so')
+hb.LIB_PATH = os.path.join(hb.LIB_DIR, os.environ.get('TRACE_LIB', 'libboxinst_hip_trace.so'))
 from boxinstseg_amd import functional as Fh, synthetic
 lib = _lib.load()
 lib.bxi_debug_set_trace2.argtypes = [C.c_void_p]
