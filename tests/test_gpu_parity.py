@@ -719,6 +719,50 @@ def test_one_workspace_serves_every_instance_count_of_its_canvas(dev):
         assert err <= TOL, (k, err)
 
 
+def test_workspace_epoch_advances_once_per_evaluation_and_follows_the_workspace_across_streams(dev):
+    """The evaluation's tag is `epoch + 1`, the epoch word 0 of the workspace: read by a SCALAR load (constant cache) by every wave, written
+    by a PLAIN store of the finisher (csrc/fused_eval.hip: with_tag).  That is only right if every later kernel -- on whatever stream /
+    hardware queue the caller serialises it behind -- sees the store: 30 evaluations alternating between three streams (each waits for
+    the previous one's event) and between the two forms on ONE workspace; after evaluation k the word holds k, and every evaluation is
+    within 1e-4 of the oracle with status 0.  (A stale epoch would make an evaluation accept the previous one's records.)"""
+    import ctypes as C
+    from boxinstseg_amd import _lib, functional as Fh
+    lib = _lib.load()
+    ds = [synthetic.make_batch(B=2, H=128, W=192, boxes_per_img=4, inst_per_box=2, seed=520 + k, min_box=16, max_box=120) for k in range(3)]
+    refs = [oracle_path(d, want_targets=False) for d in ds]
+    ws = torch.zeros(lib.bxi_boxinst_eval_workspace_bytes(2, 128, 192, 4, 16), dtype=torch.uint8, device=dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    sets = []
+    for d in ds:
+        t = to_dev(d, dev)
+        batch = Fh._Batch(t['imgs'], d['img_metas'], 10)
+        inst = Fh._Inst(t['logits'], t['gt_inds'], t['gt_bboxes'], d['H'], d['W'], d['stride'])
+        sets.append(dict(t=t, batch=batch, inst=inst, losses=torch.zeros(2, device=dev), grad=torch.empty_like(inst.logits),
+                         state=torch.empty(lib.bxi_boxinst_loss_state_bytes(inst.N, inst.h, inst.w), dtype=torch.uint8, device=dev)))
+    torch.cuda.synchronize()
+    prev = None
+    for k in range(30):
+        b, ref, s = sets[k % 3], refs[k % 3], streams[(k * 2) % 3 if k % 5 else k % 3]
+        if prev is not None:
+            s.wait_event(prev)                                   # the caller's serialisation: the only ordering between the streams
+        rc = lib.bxi_boxinst_eval_f32(C.byref(b['batch'].struct), C.byref(b['inst'].struct), 3, 2, 0.3, 1.0, None, None, b['losses'].data_ptr(),
+                                      b['grad'].data_ptr(), b['state'].data_ptr(), ws.data_ptr(), ws.numel(),
+                                      _lib.EVAL_SHARED_DEVICE | (_lib.EVAL_TWO_LAUNCHES if k % 4 == 3 else 0), s.cuda_stream)
+        assert rc == 0, _lib.status_string(rc)
+        prev = torch.cuda.Event()
+        prev.record(s)
+        if k % 3 == 2 or k == 29:                                # (checked every third evaluation: the others run back to back across streams)
+            torch.cuda.synchronize()
+            assert int(ws[:4].view(torch.int32).item()) == k + 1, (k, int(ws[:4].view(torch.int32).item()))
+            inst = b['inst']
+            off = lib.bxi_boxinst_loss_state_status_offset(inst.N, inst.h, inst.w)
+            assert b['state'][off:off + 4].view(torch.int32).item() == 0, k
+            got = b['losses'].cpu().numpy()
+            assert rel(float(got[0]), ref['loss_prj']) <= TOL and rel(float(got[1]), ref['loss_pairwise']) <= TOL, (k, got)
+            err, _ = grad_report(b['grad'].cpu().numpy()[:, 0], ref['grad'], ds[k % 3]['mask_logits'][:, 0])
+            assert err <= TOL, (k, err)
+
+
 # ---------------------------------------------------------------------------------------------
 # hipGraph replay, shared devices, fall-back after a fault
 # ---------------------------------------------------------------------------------------------
