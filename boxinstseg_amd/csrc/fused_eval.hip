@@ -863,8 +863,12 @@ __device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc
         }
         if (!got) { ok = false; return 0; }
     } else {
+        const bool untagged = ws.ep == 0u;                           // wave-uniform: this wave's first item -- the epoch word rides with its loads
+        unsigned int ew = 0u;
+        if (untagged) ew = *ws.epoch;                                // (a plain load: the word was written by an earlier kernel)
         o0 = L4[(int64_t)r * w + cc]; oD = L4[(int64_t)rD * w + cc]; x0 = L4[(int64_t)r * w + cx]; xD = L4[(int64_t)rD * w + cx];
         rect = lane < a.N ? ws.tab[lane] : make_int4(-1, 0, 0, 0);
+        if (untagged) ws.ep = next_tag((unsigned int)__builtin_amdgcn_readfirstlane((int)ew));
     }
     float nL = lane_plus_n(o0.x, D), nA = lane_plus_n(o0.y, D), nB = lane_plus_n(o0.z, D);
     float mL = lane_plus_n(oD.x, D), mA = lane_plus_n(oD.y, D), mB = lane_plus_n(oD.z, D);
@@ -1476,14 +1480,16 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 2 ? 4 : 3) : (D <= 2 ? 3 : 2))
                                                        float* __restrict__ g_logits, InstArgs a, Ws ws_in, LossState st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[16];
-    const Ws ws = with_tag(ws_in);
     const int blk = (int)blockIdx.x;
     const int N = a.N;
-    const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
     if (blk < n_pb) {                                                  // ---- predicate waves: first in the grid, everybody asks for their words
         if (zero_bit) return;                                          // every pair weighs 1: sum W has a closed form, the tiles take the log-space path
-        pred_role<D, false>(a, vc, ws, n2max, blk, n_pb, n_items, spin_limit);
-    } else if (blk == n_pb) {                                          // ---- the reducer
+        pred_role<D, false>(a, vc, ws_in /* no tag yet: it comes with the wave's first loads (pred_item) */, n2max, blk, n_pb, n_items, spin_limit);
+        return;
+    }
+    const Ws ws = with_tag(ws_in);
+    const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
+    if (blk == n_pb) {                                          // ---- the reducer
         reducer_role<false>(ws, zero_bit, n_items, spin_limit);
     } else if (blk < n_pb + 1 + N) {                                   // ---- leader of an instance
         BXI_TW(3, 1 + blk - n_pb - 1, 0);
