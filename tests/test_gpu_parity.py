@@ -761,6 +761,22 @@ def test_workspace_epoch_advances_once_per_evaluation_and_follows_the_workspace_
             assert rel(float(got[0]), ref['loss_prj']) <= TOL and rel(float(got[1]), ref['loss_pairwise']) <= TOL, (k, got)
             err, _ = grad_report(b['grad'].cpu().numpy()[:, 0], ref['grad'], ds[k % 3]['mask_logits'][:, 0])
             assert err <= TOL, (k, err)
+    # ... and back to back on ONE stream with no host synchronisation in between (what a training loop does): 40 more, both forms
+    s = streams[0]
+    for k in range(30, 70):
+        b = sets[k % 3]
+        rc = lib.bxi_boxinst_eval_f32(C.byref(b['batch'].struct), C.byref(b['inst'].struct), 3, 2, 0.3, 1.0, None, None, b['losses'].data_ptr(),
+                                      b['grad'].data_ptr(), b['state'].data_ptr(), ws.data_ptr(), ws.numel(),
+                                      _lib.EVAL_TWO_LAUNCHES if k % 4 == 3 else 0, s.cuda_stream)
+        assert rc == 0, _lib.status_string(rc)
+    torch.cuda.synchronize()
+    assert int(ws[:4].view(torch.int32).item()) == 70
+    for j in range(3):
+        inst = sets[j]['inst']
+        off = lib.bxi_boxinst_loss_state_status_offset(inst.N, inst.h, inst.w)
+        assert sets[j]['state'][off:off + 4].view(torch.int32).item() == 0, j
+        got = sets[j]['losses'].cpu().numpy()
+        assert rel(float(got[0]), refs[j]['loss_prj']) <= TOL and rel(float(got[1]), refs[j]['loss_pairwise']) <= TOL, (j, got)
 
 
 # ---------------------------------------------------------------------------------------------
