@@ -853,6 +853,62 @@ def test_hipgraph_replay_with_changed_inputs(dev, flags, size):
         assert err <= TOL, (k, err)
 
 
+@pytest.mark.parametrize('flags', [1, 2, 0], ids=['single_launch', 'two_launches', 'mixed'])
+def test_hipgraph_with_three_evaluations_on_one_workspace(dev, flags):
+    """THREE evaluations (three input sets, ONE workspace) captured into ONE hipGraph: consecutive kernel nodes of a graph, each of which
+    must see the epoch word the node before it wrote (the tag is read by a scalar load -- csrc/fused_eval.hip: with_tag -- so this is
+    a statement about what a graph launch invalidates between its nodes).  Replayed four times with the inputs of all three overwritten
+    in place in between: every evaluation within 1e-4 of the oracle for that replay's inputs, status 0, and the epoch word counts
+    every evaluation."""
+    import ctypes as C
+    from boxinstseg_amd import _lib, functional as Fh
+    lib = _lib.load()
+    mk = lambda s: synthetic.make_batch(B=2, H=256, W=384, boxes_per_img=4, seed=140 + s, min_box=24, max_box=160)
+    ds = [mk(s) for s in range(6)]
+    bs = [_abi_eval_setup(ds[j], dev, lib, Fh, iter_value=0.0) for j in range(3)]
+    ws = bs[0]['ws']                                          # (same shapes: the first set's workspace serves all three)
+    stream = torch.cuda.Stream(device=dev)
+    form = lambda j: flags if flags else (1 if j != 1 else 2)
+
+    def call(j, st):
+        b = bs[j]
+        rc = lib.bxi_boxinst_eval_f32(C.byref(b['batch'].struct), C.byref(b['inst'].struct), 3, 2, 0.3, 1.0, None, None,
+                                      b['losses'].data_ptr(), b['grad'].data_ptr(), b['state'].data_ptr(), ws.data_ptr(), ws.numel(), form(j), st)
+        assert rc == 0, _lib.status_string(rc)
+
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        call(0, stream.cuda_stream)                           # one eager evaluation first
+        stream.synchronize()
+        with torch.cuda.graph(graph, stream=stream):
+            for j in range(3):
+                call(j, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    assert int(ws[:4].view(torch.int32).item()) == 1
+    for k in range(4):
+        cur = [ds[(k + j) % 6] for j in range(3)]
+        for b, d in zip(bs, cur):
+            b['t']['imgs'].copy_(torch.from_numpy(d['imgs']))
+            b['t']['logits'].copy_(torch.from_numpy(d['mask_logits']))
+            b['t']['gt_inds'].copy_(torch.from_numpy(d['gt_inds']))
+            for dst, src in zip(b['t']['gt_bboxes'], d['gt_bboxes']):
+                assert dst.shape == src.shape
+                dst.copy_(torch.from_numpy(src))
+            b['losses'].fill_(-1.0)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert int(ws[:4].view(torch.int32).item()) == 1 + 3 * (k + 1)
+        for j, (b, d) in enumerate(zip(bs, cur)):
+            ref = oracle_path(d, want_targets=False)
+            off = lib.bxi_boxinst_loss_state_status_offset(b['inst'].N, b['inst'].h, b['inst'].w)
+            assert b['state'][off:off + 4].view(torch.int32).item() == 0, (k, j)
+            got = b['losses'].cpu().numpy()
+            assert rel(float(got[0]), ref['loss_prj']) <= TOL and rel(float(got[1]), ref['loss_pairwise']) <= TOL, (k, j, got, ref['loss_prj'], ref['loss_pairwise'])
+            err, _ = grad_report(b['grad'].cpu().numpy()[:, 0], ref['grad'], d['mask_logits'][:, 0])
+            assert err <= TOL, (k, j, err)
+
+
 def test_evaluation_next_to_a_kernel_holding_a_quarter_of_the_cus(dev):
     """What an RCCL all-reduce does during DDP's backward: a second stream keeps a fixed share of the compute units busy (here a
     CU-masked stream: 64 of the 256 CUs running matrix products back to back) while evaluations run in the form the library chooses
