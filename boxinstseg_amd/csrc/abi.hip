@@ -20,6 +20,8 @@ int eval_ws_init(void* workspace, size_t bytes, void* stream);
 int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bxi_instances* in, int dil, float warmup, const float* up_prj,
                       const float* up_pw, float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, unsigned flags,
                       void* stream, const DynArgs* head = nullptr, int head_C = 0);
+int launch_targets(const bxi_image_batch* batch, const float* const* boxes_per_img_host, const int* gt_count_host, int stride, int dil, float color_thresh,
+                   void* workspace, size_t workspace_bytes, void* stream);
 int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits, void* stream);
 int launch_rescale_nhw(int N, int h, int w, const float* g_prj, const float* g_pw, int dil, const void* state, float* g_logits, void* stream);
 
@@ -82,6 +84,27 @@ int bxi_boxinst_eval_workspace_init(void* workspace, size_t workspace_bytes, voi
     return bxi::eval_ws_init(workspace, workspace_bytes, stream);
 }
 
+int bxi_boxinst_targets_f32(const bxi_image_batch* batch_host, const float* const* boxes_per_img_host, const int* gt_count_host, int stride, int size,
+                            int dilation, float color_thresh, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!batch_host || !boxes_per_img_host || !gt_count_host) return BXI_ERR_NULL_POINTER;
+    if (size < 1 || (size & 1) == 0 || dilation < 1 || stride < 1) return BXI_ERR_BAD_ARGUMENT;
+    if (size != 3 || !bxi::fused_eval_supported(dilation)) return BXI_ERR_UNSUPPORTED;
+    const size_t need = bxi_boxinst_eval_workspace_bytes(batch_host->B, batch_host->Hc, batch_host->Wc, stride, 0);
+    if (!workspace || need == 0 || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
+    return bxi::launch_targets(batch_host, boxes_per_img_host, gt_count_host, stride, dilation, color_thresh, workspace, workspace_bytes, stream);
+}
+
+// the combinations of `flags` that contradict each other
+static bool bad_eval_flags(unsigned int flags) {
+    if (flags & ~(unsigned)BXI_EVAL_ALL_FLAGS) return true;
+    const unsigned int form = flags & (BXI_EVAL_SINGLE_LAUNCH | BXI_EVAL_TWO_LAUNCHES | BXI_EVAL_PRED_IN_PAIR | BXI_EVAL_PRED_IN_PREP);
+    if ((flags & BXI_EVAL_SINGLE_LAUNCH) && form != BXI_EVAL_SINGLE_LAUNCH) return true;
+    if ((flags & BXI_EVAL_PRED_IN_PAIR) && (flags & BXI_EVAL_PRED_IN_PREP)) return true;
+    if ((flags & BXI_EVAL_TILE_ROWS_8) && (flags & BXI_EVAL_TILE_ROWS_4)) return true;
+    if ((flags & BXI_EVAL_TARGETS_READY) && (flags & (BXI_EVAL_PRED_IN_PAIR | BXI_EVAL_PRED_IN_PREP))) return true;
+    return false;
+}
+
 int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host, int size, int dilation,
                          float color_thresh, float warmup, const float* up_prj, const float* up_pw, float* losses,
                          float* g_logits, void* state, void* workspace, size_t workspace_bytes, unsigned int flags, void* stream) {
@@ -96,8 +119,7 @@ int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances*
                                                          inst_host->N);
     if (!workspace || need == 0 || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255))
         return BXI_ERR_WORKSPACE;
-    if (flags & ~(unsigned)BXI_EVAL_ALL_FLAGS) return BXI_ERR_BAD_ARGUMENT;
-    if ((flags & BXI_EVAL_SINGLE_LAUNCH) && (flags & BXI_EVAL_TWO_LAUNCHES)) return BXI_ERR_BAD_ARGUMENT;
+    if (bad_eval_flags(flags)) return BXI_ERR_BAD_ARGUMENT;
     return bxi::launch_fused_eval(batch_host, color_thresh, inst_host, dilation, warmup, up_prj, up_pw, losses, g_logits, state, workspace,
                                   workspace_bytes, flags, stream);
 }
@@ -109,7 +131,7 @@ int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_insta
                               float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, unsigned int flags,
                               void* stream) {
     if (!batch_host || !inst_host) return BXI_ERR_NULL_POINTER;
-    if (flags & ~(unsigned)BXI_EVAL_ALL_FLAGS) return BXI_ERR_BAD_ARGUMENT;
+    if (bad_eval_flags(flags)) return BXI_ERR_BAD_ARGUMENT;      // (the forms the head-fused first launch is not built in are not taken: two launches)
     if (size < 1 || (size & 1) == 0 || dilation < 1) return BXI_ERR_BAD_ARGUMENT;
     if (size != 3 || !bxi::fused_eval_supported(dilation)) return BXI_ERR_UNSUPPORTED;
     const int stride = inst_host->stride;

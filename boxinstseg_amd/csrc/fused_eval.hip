@@ -57,11 +57,18 @@ constexpr int kSRows = 8;                       // rows per stream wave
 constexpr int kSBlk = kWaves * kSRows;          // rows per stream workgroup
 constexpr int kChunkC = 256;                    // columns per pass of a stream wave: 64 lanes x float4
 constexpr int kMaxDilFused = 4;
-constexpr int kSpinLimit = 250000;              // bounded waits (0.3 - 1 us per poll: ~0.1 - 0.25 s): far beyond any launch, also one that shares
-                                                // the GPU with other streams' kernels; running out is loud (NaN losses, status word) and the
-                                                // host side then takes the two-launch form, whose every wait is for an EARLIER workgroup
+constexpr int kSpinLimit = 4000000;             // bounded waits (0.3 - 1 us per poll: seconds): a bound, not a schedule -- a transient stall (another
+                                                // process time-slicing the GPU, a long kernel on another stream while stream workgroups stay on) must
+                                                // not turn an iteration's losses into NaN; running out is loud (NaN losses, status word) and the host
+                                                // side then takes the two-launch form, whose every wait is for an EARLIER workgroup
 // bits of the `flags` argument of bxi_boxinst_eval_f32 (include/boxinst_hip.h: BXI_EVAL_*); per call, no process-wide state
-constexpr unsigned kFlagSingle = 1u, kFlagTwo = 2u, kFlagNoStay = 4u, kFlagRows8 = 8u, kFlagShared = 16u, kFlagGiveUp = 256u;
+constexpr unsigned kFlagSingle = 1u, kFlagTwo = 2u, kFlagNoStay = 4u, kFlagRows8 = 8u, kFlagShared = 16u, kFlagPredInPair = 32u, kFlagPredInPrep = 64u,
+                   kFlagTargetsReady = 128u, kFlagGiveUp = 256u, kFlagRows4 = 512u;
+constexpr int kBoxCap = 1024;                   // GT boxes per batch bxi_boxinst_targets_f32 keeps pair counts for
+constexpr int kBoxSplit = 8;                    // count words per box (each in its own 128 bytes): arrivals on one word are performed one after the other
+constexpr int kFoldFrom = 96;                   // two launches: from this many instances on the image-only chain (predicates, counts, sum W) runs at the
+                                                // tail of the FIRST launch, under its logit stream (fewer: in the second, as in round 4)
+constexpr unsigned int kMaxTag = 0x0fffffffu;   // tags are 28 bits (a predicate word is tag << 4 | bits)
 constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
 constexpr int kAcc1Words = 64;                  // count-wave arrivals + sum W: 64 words, each in its own 128 bytes
 constexpr int kMaxInst = 65536;
@@ -191,6 +198,17 @@ struct Ws {
     unsigned long long* acc2;                   // [N][kAcc2Split] (one per 128 B) tile waves: arrivals << 52 | sum (W pw + 1) in 2^-24 units
     unsigned long long* dice;                   // [N]   leader: 1 << 32 | bits of the instance's dice loss (0 = not published)
     unsigned int* fault;                        // [1]   bit mask of waits that ran out (never expected)
+    // what bxi_boxinst_targets_f32 leaves for evaluations with BXI_EVAL_TARGETS_READY (next to lab4 / pred)
+    // (ONE pointer for the three regions: every field of this structure is a pair of scalar registers in every role of every kernel)
+    unsigned char* tgt;                         // +0: tkey [1] u32, digest of the geometry / window / threshold the targets were computed for (0 = none)
+                                                // +256: boxtab [kBoxCap] int4 per GT box {img << 24, r0 | r1 << 16, c0 | c1 << 16, 0}: what its predicate waves count against
+                                                // +256 + 16 kBoxCap: boxcnt [kBoxCap][kBoxSplit] u64 (one per 128 B) per GT box: sum over its pixels p and the 8
+                                                //   neighbours k of [sim_k(p) >= thresh]
+    unsigned int pred_any;                      // 1: lab4 / pred come from bxi_boxinst_targets_f32 (an earlier launch): their tag field is not this evaluation's
+    unsigned int ws_n16;                        // size of the workspace in 16-byte units (the finisher zeroes all of it when the tag counter is about to wrap)
+    __host__ __device__ __forceinline__ unsigned int* tkey() const { return reinterpret_cast<unsigned int*>(tgt); }
+    __host__ __device__ __forceinline__ int4* boxtab() const { return reinterpret_cast<int4*>(tgt + 256); }
+    __host__ __device__ __forceinline__ unsigned long long* boxcnt() const { return reinterpret_cast<unsigned long long*>(tgt + 256 + 16 * (size_t)kBoxCap); }
 };
 
 __device__ __forceinline__ unsigned long long* acc2_word(unsigned long long* acc2, int n, int sub) {
@@ -243,12 +261,13 @@ static size_t carve(void* base, int B, int N, int h, int w, Ws* ws) {
     t.lab4 = (float4*)take(16 * B1 * P);
     t.lab_planar = (float*)take(12 * B1 * P);
     t.pred = (unsigned int*)take(4 * B1 * P);
+    t.tgt = (unsigned char*)take(256 + 16 * (size_t)kBoxCap + 8 * (size_t)kBoxCap * kBoxSplit * kAcc2Stride);
     t.colpart = (unsigned long long*)take(8 * (size_t)N1 * (cb_max > Sn ? cb_max : Sn) * w);
     t.rowkey = (unsigned long long*)take(8 * (size_t)N1 * h * (rp_max > 1 ? rp_max : 1));
     t.n_cb = (int)Sn; t.n_rp = 1;
     t.tab = (int4*)take(16 * (size_t)(N1 + 1));
     t.bandflag = (unsigned int*)take(4 * (size_t)N1 * (cb_max > Sn ? cb_max : Sn));
-    t.ep = 0u;
+    t.ep = 0u; t.pred_any = 0u; t.ws_n16 = 0u;
     t.acc1 = (unsigned long long*)take(8 * (size_t)kAcc1Words * kAcc2Stride);
     t.sumw = (unsigned long long*)take(8);
     t.acc2 = (unsigned long long*)take(8 * (size_t)N1 * kAcc2Split * kAcc2Stride);
@@ -287,8 +306,13 @@ __device__ __forceinline__ LaneBox lane_box(const InstArgs& a, const ImageMeta& 
     return lb;
 }
 
+__device__ __forceinline__ void publish_gathered_sumw(const InstArgs& a, const Ws& ws, int G, unsigned int key);
+// `ready` != 0 (BXI_EVAL_TARGETS_READY; the value is the number of GT boxes + 1): the image side was evaluated by an earlier call (bxi_boxinst_targets_f32); sum W is then a GATHER --
+// sum over the instances of their GT box's pair count (:1324-1328: the weights of instance n are its box's bitmask times the image's
+// affinity mask, a function of the box and the image only) -- that the first table wave does behind its entries, instead of the
+// predicate -> count -> reducer chain.  `key`: the digest of what the targets were computed for; a mismatch is a fault (loud).
 __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& meta, int dil, int R, const Ws& ws, const LossState& st, int k,
-                                           bool write_status) {
+                                           bool write_status, int ready = 0, unsigned int key = 0u) {
     const int lane = threadIdx.x & 63;
     int base = 0, prefix = 0;
     LaneBox mine = {0, 0, 0, 0, 0, 0};
@@ -328,6 +352,33 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
                             (unsigned long long)(unsigned int)(mine.c0 | (mine.c1 << 16)) | ((unsigned long long)ws.ep << 32));
     else if (m == a.N)
         store_u64x2_through(reinterpret_cast<unsigned long long*>(ws.tab + m), (unsigned long long)(unsigned int)prefix, (unsigned long long)ws.ep << 32);
+    if (k != 0 || ready < 0) return;                // (ready < 0: targets ready, sum W is gathered by the reducer workgroup -- the single-launch form)
+    if (!ready) {       // an evaluation that computes the image side itself overwrites lab4 / pred: targets an earlier call left are gone
+        if (lane == 0) *ws.tkey() = 0u;
+        return;
+    }
+    publish_gathered_sumw(a, ws, ready - 1, key);
+}
+
+// sum W = sum over the instances of their GT box's pair count (bxi_boxinst_targets_f32 left the counts): one wave
+__device__ __forceinline__ void publish_gathered_sumw(const InstArgs& a, const Ws& ws, int G, unsigned int key) {
+    const int lane = threadIdx.x & 63;
+    const unsigned int have = __hip_atomic_load(ws.tkey(), BXI_RLX, BXI_AGENT);
+    double tot = 0.0;
+    for (int m0 = 0; m0 < a.N; m0 += 64) {
+        const int mm = m0 + lane;
+        const int64_t g = mm < a.N ? a.gt_inds[mm] : -1;
+        if (g >= 0 && g < G && g < kBoxCap) {
+            unsigned long long c[kBoxSplit];
+#pragma unroll
+            for (int j = 0; j < kBoxSplit; ++j) c[j] = __hip_atomic_load(ws.boxcnt() + ((size_t)g * kBoxSplit + j) * kAcc2Stride, BXI_RLX, BXI_AGENT);
+#pragma unroll
+            for (int j = 0; j < kBoxSplit; ++j) tot += (double)c[j];
+        }
+    }
+    tot = wave_total_f64(tot);                                             // exact: integers far below 2^53
+    if (lane == 0)
+        __hip_atomic_store(ws.sumw, (1ull << 63) | (have != key || key == 0u ? kSumwFault : 0ull) | (unsigned long long)tot, BXI_RLX, BXI_AGENT);
 }
 
 // This lane's table entry m (m <= N; `want` false: nothing).  Two-launch form: a plain load behind the kernel boundary.  Single-launch
@@ -586,39 +637,7 @@ __device__ __forceinline__ void pool_block(const PoolArgs& pa, Ws& ws, int first
     }
 }
 
-// grid: [table blocks][pool blocks][stream blocks] (pool_first) or [table][stream][pool]
-__global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, Ws ws_in, LossState st,
-                                                       float* __restrict__ g_logits, int vec, int pool_first) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Ws ws = ws_in;                                        // the tag is read where a role needs it (with_tag), behind its loads
-    const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
-    const int Sn = (a.h + kSBlk - 1) / kSBlk;
-    const int n_stream = a.N * Sn;
-    const int blk = (int)blockIdx.x;
-    const int tix = blk * kWaves + (int)(threadIdx.x >> 6);
-    (void)tix;
-    BXI_TW(0, tix, 0);
-    int role = 0, idx = blk;                              // 0 table, 1 pool, 2 stream
-    if (blk >= n_tab) {
-        idx = blk - n_tab;
-        const int n_a = pool_first ? n_pool : n_stream;
-        if (idx < n_a) role = pool_first ? 1 : 2;
-        else { idx -= n_a; role = pool_first ? 2 : 1; }
-    }
-    if (role == 0) {
-        const int k = blk * kWaves + (int)(threadIdx.x >> 6);
-        if (64 * k <= a.N) { ws = with_tag(ws); table_wave(a, pa.meta, dil, R, ws, st, k, true); }
-    } else if (role == 2) {
-        const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
-        stream_block<false>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);     // (no tagged record in this form)
-    } else {
-        double* lut = reinterpret_cast<double*>(smem);
-        double* fch = lut + 256;
-        int* part = reinterpret_cast<int*>(fch + 3 * 64);
-        pool_block(pa, ws, idx, n_pool, n_items, lut, part, fch, tix, [&](Ws& w_) { w_ = with_tag(w_); });
-    }
-    BXI_TW(0, tix, 7);
-}
+// (prep_kernel, the first launch of the two-launch form, follows the roles of the second launch below: its folded form runs two of them)
 
 // ---- head-fused first launch ----------------------------------------------------------------------------
 // CondInstMaskHead.forward (condinst_head.py:1139-1164) and the evaluation's first launch as ONE grid of independent roles:
@@ -628,7 +647,7 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, i
 template <int C, bool REL>
 __global__ __launch_bounds__(256, 7) void head_prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, Ws ws_in, LossState st,
                                                             float* __restrict__ g_logits, DynArgs da, const float* __restrict__ params,
-                                                            float* __restrict__ logits_out) {
+                                                            float* __restrict__ logits_out, int ready, unsigned int key) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ws ws = with_tag(ws_in);
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
@@ -637,7 +656,7 @@ __global__ __launch_bounds__(256, 7) void head_prep_kernel(PoolArgs pa, int n_po
     (void)tix;
     if (blk < n_tab) {
         const int k = blk * kWaves + (int)(threadIdx.x >> 6);
-        if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, ws, st, k, true);
+        if (64 * k <= a.N) table_wave(a, pa.meta, dil, R, ws, st, k, true, ready, key);
     } else if (blk < n_tab + n_pool) {
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
@@ -827,9 +846,13 @@ __device__ __forceinline__ float lane_plus_n(float v, int d) {
     return __int_as_float(x);
 }
 struct ValidCells { int vrow[BXI_MAX_IMAGES], vcol[BXI_MAX_IMAGES]; };   // per image: valid(q) <=> row(q) < vrow && col(q) < vcol (host: :1354-1369,:1405)
-template <bool ONE>
-__device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc, Ws& ws, int D, float n2max, int item, int segs, int spin_limit, bool& ok) {
-    const int h = a.h, w = a.w, lane = threadIdx.x & 63;
+// PER_BOX (bxi_boxinst_targets_f32's second launch; never ONE): the rectangles are the GT BOXES' (ws.boxtab, n_ent of them) instead of the
+// instances', and what a box containing a site adds is kept PER BOX (`boxacc`, LDS of the workgroup, one counter per box) instead of
+// summed -- the evaluation that follows gathers sum W from its instances' boxes.  No tag is read or written (the consumer is a later launch).
+template <bool ONE, bool PER_BOX = false>
+__device__ __forceinline__ int pred_item(int h, int w, int n_ent, const ValidCells& vc, Ws& ws, int D, float n2max, int item, int segs, int spin_limit, bool& ok,
+                                         int* boxacc = nullptr) {
+    const int lane = threadIdx.x & 63;
     const int seg = item % segs, r = (item / segs) % h, b = item / (segs * h);
     const int c = seg * 64 + lane, cn = c + D;
     const bool rowD = r + D < h;                                  // wave-uniform
@@ -848,14 +871,14 @@ __device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc
             if (ws.ep == 0u) {           // wave-uniform: this wave's first poll -- the evaluation's tag travels with it too (with_tag)
                 unsigned int e;
                 load16_past_x5_epoch(L4 + (int64_t)r * w + cc, L4 + (int64_t)rD * w + cc, L4 + (int64_t)r * w + cx, L4 + (int64_t)rD * w + cx,
-                                     ws.tab + (lane < a.N ? lane : 0), ws.epoch, q0, q1, q2, q3, qe, e);
+                                     ws.tab + (lane < n_ent ? lane : 0), ws.epoch, q0, q1, q2, q3, qe, e);
                 ws.ep = next_tag((unsigned int)__builtin_amdgcn_readfirstlane((int)e));
             } else
                 load16_past_x5(L4 + (int64_t)r * w + cc, L4 + (int64_t)rD * w + cc, L4 + (int64_t)r * w + cx, L4 + (int64_t)rD * w + cx,
-                               ws.tab + (lane < a.N ? lane : 0), q0, q1, q2, q3, qe);
+                               ws.tab + (lane < n_ent ? lane : 0), q0, q1, q2, q3, qe);
             if (__all(q0.w == ws.ep && q1.w == ws.ep && q2.w == ws.ep && q3.w == ws.ep && qe.w == ws.ep)) {
                 o0 = f4_of(q0); oD = f4_of(q1); x0 = f4_of(q2); xD = f4_of(q3);
-                rect = lane < a.N ? make_int4((int)qe.x, (int)qe.y, (int)qe.z, (int)qe.w) : make_int4(-1, 0, 0, 0);
+                rect = lane < n_ent ? make_int4((int)qe.x, (int)qe.y, (int)qe.z, (int)qe.w) : make_int4(-1, 0, 0, 0);
                 got = true;
                 break;
             }
@@ -863,11 +886,11 @@ __device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc
         }
         if (!got) { ok = false; return 0; }
     } else {
-        const bool untagged = ws.ep == 0u;                           // wave-uniform: this wave's first item -- the epoch word rides with its loads
+        const bool untagged = !PER_BOX && ws.ep == 0u;               // wave-uniform: this wave's first item -- the epoch word rides with its loads
         unsigned int ew = 0u;
         if (untagged) ew = *ws.epoch;                                // (a plain load: the word was written by an earlier kernel)
         o0 = L4[(int64_t)r * w + cc]; oD = L4[(int64_t)rD * w + cc]; x0 = L4[(int64_t)r * w + cx]; xD = L4[(int64_t)rD * w + cx];
-        rect = lane < a.N ? ws.tab[lane] : make_int4(-1, 0, 0, 0);
+        rect = lane < n_ent ? (PER_BOX ? ws.boxtab()[lane] : ws.tab[lane]) : make_int4(-1, 0, 0, 0);
         if (untagged) ws.ep = next_tag((unsigned int)__builtin_amdgcn_readfirstlane((int)ew));
     }
     float nL = lane_plus_n(o0.x, D), nA = lane_plus_n(o0.y, D), nB = lane_plus_n(o0.z, D);
@@ -885,14 +908,15 @@ __device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc
     // what a box containing the site adds:  (r, c)  (r, c+D)  (r+D, c)  (r+D, c+D)
     const int s00 = (p0 && v0n) + (p2 && vD0) + (p3 && vDn), s0n = (p0 && v00) + (p1 && vD0), sD0 = (p1 && v0n) + (p2 && v00), sDn = (p3 && v00) ? 1 : 0;
     int cnt = 0;
-    for (int m0 = 0; m0 < a.N; m0 += 64) {
+    for (int m0 = 0; m0 < n_ent; m0 += 64) {
         if (m0) {
-            if (!tab_entry<ONE>(ws, m0 + lane, m0 + lane < a.N, spin_limit, rect)) { ok = false; return 0; }
-            if (m0 + lane >= a.N) rect = make_int4(-1, 0, 0, 0);
+            if (PER_BOX) rect = m0 + lane < n_ent ? ws.boxtab()[m0 + lane] : make_int4(-1, 0, 0, 0);
+            else if (!tab_entry<ONE>(ws, m0 + lane, m0 + lane < n_ent, spin_limit, rect)) { ok = false; return 0; }
+            if (m0 + lane >= n_ent) rect = make_int4(-1, 0, 0, 0);
         }
         // the instances of this image whose rows reach r or r + D: usually a handful
         const int q0 = rect.y & 0xffff, q1 = (int)((unsigned int)rect.y >> 16);
-        unsigned long long mask = __ballot(m0 + lane < a.N && (int)((unsigned int)rect.x >> 24) == b && ((r >= q0 && r < q1) || (r + D >= q0 && r + D < q1)));
+        unsigned long long mask = __ballot(m0 + lane < n_ent && (int)((unsigned int)rect.x >> 24) == b && ((r >= q0 && r < q1) || (r + D >= q0 && r + D < q1)));
         while (mask) {
             const int n = __ffsll((long long)mask) - 1;
             mask &= mask - 1ull;
@@ -900,7 +924,12 @@ __device__ __forceinline__ int pred_item(const InstArgs& a, const ValidCells& vc
             const int r0 = ry & 0xffff, r1 = (int)((unsigned int)ry >> 16), c0 = rz & 0xffff, c1 = (int)((unsigned int)rz >> 16);
             const bool rr = r >= r0 && r < r1, rD2 = r + D >= r0 && r + D < r1;
             const bool c_in = c >= c0 && c < c1, n_in = cn >= c0 && cn < c1;
-            cnt += (rr && c_in ? s00 : 0) + (rr && n_in ? s0n : 0) + (rD2 && c_in ? sD0 : 0) + (rD2 && n_in ? sDn : 0);
+            const int add = (rr && c_in ? s00 : 0) + (rr && n_in ? s0n : 0) + (rD2 && c_in ? sD0 : 0) + (rD2 && n_in ? sDn : 0);
+            if (PER_BOX) {
+                const int tot = wave_total_i32(add);
+                if (lane == 0 && tot) atomicAdd(&boxacc[m0 + n], tot);       // LDS; flushed once per workgroup (targets_pred_kernel)
+            } else
+                cnt += add;
         }
     }
     return cnt;
@@ -958,13 +987,14 @@ template <int D, int R>
 __device__ __forceinline__ bool pred_words(const Ws& ws, const Tile& t, int h, int w, int c, int spin_limit, uint32_t (&pbyte)[R + D]) {
     const unsigned int* pp = ws.pred + (int64_t)t.img * h * w;
     const uint32_t cc = (uint32_t)min(max(c, 0), w - 1);
+    const unsigned int want = ws.pred_any ? 0u : ws.ep;       // words an earlier launch left (bxi_boxinst_targets_f32) carry tag 0: no tag of this evaluation
     bool ok = false;
     for (int spins = 0; spins <= spin_limit; ++spins) {
         bool all = true;
 #pragma unroll
         for (int i = 0; i < R + D; ++i) {
             pbyte[i] = __hip_atomic_load(pp + (uint32_t)min(max(t.tile_r0 - D + i, 0), h - 1) * (uint32_t)w + cc, BXI_RLX, BXI_AGENT);
-            all = all && (pbyte[i] >> 4) == ws.ep;
+            all = all && (pbyte[i] >> 4) == want;
         }
         if (__all(all)) { ok = true; break; }
         __builtin_amdgcn_s_sleep(BXI_SLEEP_WORDS);
@@ -1317,15 +1347,18 @@ __device__ __forceinline__ bool locate_tile(const Ws& ws, const ValidCells& vc, 
 
 // ---- the roles of the second launch (two-launch form) / of the back half of the single launch ----------------------------------
 // predicate workgroup `pblk` of n_pb: 4 independent waves striding through the pooled row segments
-template <int D, bool ONE>
-__device__ __forceinline__ void pred_role(const InstArgs& a, const ValidCells& vc, Ws ws /* .ep == 0: the first poll fetches the tag */, float n2max, int pblk, int n_pb, int n_items, int spin_limit) {
+template <bool ONE>
+__device__ __forceinline__ void pred_role(const InstArgs& a, const ValidCells& vc, Ws ws /* .ep == 0: the first poll fetches the tag */, int D, float n2max, int pblk, int n_pb, int n_items, int spin_limit) {
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int segs = (a.w + 63) >> 6, pid = pblk * kWaves + wave;
     BXI_TW(2, pid, 0);
     __builtin_amdgcn_s_setprio(3);                                 // short, and the tile waves will ask for these words
     int cnt = 0, segments = 0;
     bool ok = true;
-    for (int item = pid; item < n_items && ok; item += n_pb * kWaves) { cnt += pred_item<ONE>(a, vc, ws, D, n2max, item, segs, spin_limit, ok); ++segments; }
+    for (int item = pid; item < n_items && ok; item += n_pb * kWaves) { cnt += pred_item<ONE>(a.h, a.w, a.N, vc, ws, D, n2max, item, segs, spin_limit, ok); ++segments; }
+    // the evaluation whose tag is the last one: the finisher zeroes the workspace behind it (the tag counter starts again), so every store of
+    // this evaluation must have landed before its arrival can be seen (the predicate words otherwise announce themselves)
+    if (ws.ep == kMaxTag) drain_vmem();
     cnt = wave_total_i32(cnt);
     // ONE arrival per workgroup: arrivals on one word are performed one after the other (~0.15 us each), and the tile waves
     // need the last one
@@ -1350,7 +1383,7 @@ __device__ __forceinline__ void pred_role(const InstArgs& a, const ValidCells& v
 // before that they hold the previous evaluation's complete counts.)
 template <bool ONE>
 __device__ __forceinline__ void reducer_role(const Ws& ws, int zero_bit, int n_items, int spin_limit) {
-    if (threadIdx.x >= 64 || zero_bit) return;
+    if (threadIdx.x >= 64 || zero_bit || n_items <= 0) return;      // n_items <= 0: sum W is already published (an earlier launch, or the table wave)
     if (!(table_complete<ONE>(ws, 0, spin_limit) && reduce_counts(ws, n_items, spin_limit)) && threadIdx.x == 0) atomicOr(ws.fault, kFaultCounts);
 }
 
@@ -1432,7 +1465,18 @@ __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, c
         if (st.status) { st.status[0] = (int)status; if (ONE) st.status[1] = R; }
         if (st.iter) atomicAdd(st.iter, 1.0f);                               // self._iter += 1, condinst_head.py:1297
         // the evaluation is over: every other wave of it has been seen to arrive, so nobody reads the epoch any more
-        *ws.epoch = ws.ep;      // (a plain store: see with_tag)
+        if (ws.ep != kMaxTag) *ws.epoch = ws.ep;      // (a plain store: see with_tag)
+    }
+    if (ws.ep == kMaxTag) {
+        // The tag counter is about to wrap: records of 2^28 evaluations ago would pass for fresh ones (table entries and arrival words of
+        // instances beyond the current count keep their tags until an evaluation that large comes again).  So this evaluation ends by
+        // returning the workspace to its initial state -- all zero, epoch 0 -- as bxi_boxinst_eval_workspace_init does: every other wave
+        // has arrived, and in this evaluation every wave drains its stores before it arrives (pred_role; the others always do).
+        // Once per 2^28 - 1 evaluations, ~3 MB by one wave.  (Targets an earlier bxi_boxinst_targets_f32 left in the workspace go too:
+        // an evaluation that counts on them finds key 0 and says so, loud.)
+        uint4* z = reinterpret_cast<uint4*>(ws.epoch);
+        const size_t n16 = ws.ws_n16;
+        for (size_t i = lane; i < n16; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     BXI_TW(3, 0, 1);
 }
@@ -1468,6 +1512,60 @@ __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& v
     BXI_TW(1, wid, 7);
 }
 
+// ---- launch 1 of the two-launch form ------------------------------------------------------------------------------------------
+// what the first launch needs beyond its streams (by value: 1 KB of valid-cell limits is only read by the predicate waves of the folded form)
+struct PrepTail {
+    int n_pb;                // > 0: the FOLDED form -- predicate workgroups + the reducer at the tail of this launch (they wait, bounded, for pool
+                             // workgroups earlier in the grid; everything the second launch needs of the image side is then in memory at the kernel
+                             // boundary, and its tile waves wait for nobody)
+    int ready;               // BXI_EVAL_TARGETS_READY (the number of GT boxes + 1): no pool workgroups; the first table wave gathers sum W from the boxes' pair counts
+    unsigned int key;        // ... and checks that the targets in the workspace are the ones this call means
+    float n2max;
+    int spin_limit;
+};
+
+// grid: [table blocks][pool blocks][stream blocks] (pool_first) or [table][stream][pool], then (folded form) [predicate blocks][reducer]
+__global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, Ws ws_in, LossState st,
+                                                       float* __restrict__ g_logits, int vec, int pool_first, PrepTail tl, ValidCells vc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Ws ws = ws_in;                                        // the tag is read where a role needs it (with_tag), behind its loads
+    const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
+    const int Sn = (a.h + kSBlk - 1) / kSBlk;
+    const int n_stream = a.N * Sn;
+    const int blk = (int)blockIdx.x;
+    const int tix = blk * kWaves + (int)(threadIdx.x >> 6);
+    (void)tix;
+    BXI_TW(0, tix, 0);
+    int role = 0, idx = blk;                              // 0 table, 1 pool, 2 stream, 3 predicate, 4 reducer
+    if (blk >= n_tab) {
+        idx = blk - n_tab;
+        const int n_a = pool_first ? n_pool : n_stream, n_b = pool_first ? n_stream : n_pool;
+        if (idx < n_a) role = pool_first ? 1 : 2;
+        else if ((idx -= n_a) < n_b) role = pool_first ? 2 : 1;
+        else if ((idx -= n_b) < tl.n_pb) role = 3;
+        else role = 4;
+    }
+    if (role == 0) {
+        const int k = blk * kWaves + (int)(threadIdx.x >> 6);
+        if (64 * k <= a.N) { ws = with_tag(ws); table_wave(a, pa.meta, dil, R, ws, st, k, true, tl.ready, tl.key); }
+    } else if (role == 2) {
+        const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
+        stream_block<false>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);     // (no tagged record in this form)
+    } else if (role == 1) {
+        double* lut = reinterpret_cast<double*>(smem);
+        double* fch = lut + 256;
+        int* part = reinterpret_cast<int*>(fch + 3 * 64);
+        pool_block(pa, ws, idx, n_pool, n_items, lut, part, fch, tix, [&](Ws& w_) { w_ = with_tag(w_); });
+    } else if (role == 3) {
+        // the Lab records of THIS launch's pool workgroups (tagged, written through; they precede this workgroup in the grid and wait for
+        // nobody) and the table: the single-launch form's protocol
+        pred_role<true>(a, vc, ws, dil, tl.n2max, idx, tl.n_pb, n_items, tl.spin_limit);
+    } else {
+        reducer_role<true>(with_tag(ws), 0, n_items, tl.spin_limit);
+    }
+    BXI_TW(0, tix, 7);
+}
+
 // grid: [n_pb predicate blocks][reducer][N leaders][n_tb tile blocks][finisher].  The only waits: a tile wave for the predicate waves
 // (earlier in the grid, never waiting themselves), the finisher for everybody (nobody waits for it).  Every wait is bounded, and
 // running out of it is loud: NaN losses, status word, poisoned gradient (the reference surfaces launch failures through
@@ -1484,13 +1582,13 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 2 ? 4 : 3) : (D <= 2 ? 3 : 2))
     const int N = a.N;
     if (blk < n_pb) {                                                  // ---- predicate waves: first in the grid, everybody asks for their words
         if (zero_bit) return;                                          // every pair weighs 1: sum W has a closed form, the tiles take the log-space path
-        pred_role<D, false>(a, vc, ws_in /* no tag yet: it comes with the wave's first loads (pred_item) */, n2max, blk, n_pb, n_items, spin_limit);
+        pred_role<false>(a, vc, ws_in /* no tag yet: it comes with the wave's first loads (pred_item) */, D, n2max, blk, n_pb, n_items, spin_limit);
         return;
     }
     const Ws ws = with_tag(ws_in);
     const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
     if (blk == n_pb) {                                          // ---- the reducer
-        reducer_role<false>(ws, zero_bit, n_items, spin_limit);
+        reducer_role<false>(ws, zero_bit, n_pb > 0 ? n_items : 0, spin_limit);      // (no predicate workgroups here: sum W is in memory already)
     } else if (blk < n_pb + 1 + N) {                                   // ---- leader of an instance
         BXI_TW(3, 1 + blk - n_pb - 1, 0);
         leader_block<false>(a, D, ws, st, blk - n_pb - 1, upp, g_logits, smem, red, spin_limit);
@@ -1520,7 +1618,7 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 2 ? 4 : 3) : (D <= 2 ? 3 : 2))
 template <int D>
 __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_pool, int n_items, int n_pb, int n_tb, InstArgs a, Ws ws_in, LossState st, ValidCells vc,
                                                         const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup, float n2max, int spin_limit,
-                                                        float* __restrict__ losses, float* __restrict__ g_logits, int vec, int merge) {
+                                                        float* __restrict__ losses, float* __restrict__ g_logits, int vec, int merge, int ready, unsigned int key) {
     constexpr int R = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[16];
@@ -1548,7 +1646,7 @@ __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_
         const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
         stream_block<true>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix, [&](Ws& w_) {
             w_ = with_tag(w_);
-            if ((threadIdx.x >> 6) == 0 && 64 * idx <= N) table_wave(a, pa.meta, D, R, w_, st, idx, false);
+            if ((threadIdx.x >> 6) == 0 && 64 * idx <= N) table_wave(a, pa.meta, D, R, w_, st, idx, false, ready ? -1 : 0, 0u);
         });
         BXI_TW(0, tix, 7);
         if (!merge) return;
@@ -1578,14 +1676,67 @@ __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_
         leader_block<true>(a, D, ws, st, idx, upp, g_logits, smem, red, spin_limit);
         return;
     }
-    if (role == 3) { pred_role<D, true>(a, vc, ws, n2max, idx, n_pb, n_items, spin_limit); return; }
-    if (role == 6) { reducer_role<true>(ws, 0, n_items, spin_limit); return; }
+    if (role == 3) { pred_role<true>(a, vc, ws, D, n2max, idx, n_pb, n_items, spin_limit); return; }
+    if (role == 6) {
+        if (!ready) reducer_role<true>(ws, 0, n_items, spin_limit);
+        else if (threadIdx.x < 64) {
+            // targets ready: sum W is a gather over the instances' boxes, published once the table says this evaluation's polled words are zeroed
+            // (the table wave is a wave of the first stream workgroup: earlier in the grid, waiting for nobody)
+            if (table_complete<true>(ws, 0, spin_limit)) publish_gathered_sumw(a, ws, ready - 1, key);
+            else if (threadIdx.x == 0) atomicOr(ws.fault, kFaultCounts);
+        }
+        return;
+    }
     if (role == 4) {          // ONE call site for the stream workgroups that stay on and for the tile workgroups proper
         const int shift = merge ? n_stream : 0;
         tile_role<D, R, true>(a, vc, ws, upw * resolve_warmup(warmup, st.iter), n2max, 0, n_items, spin_limit, g_logits, smem, idx + shift, n_tb + shift);
         return;
     }
     finisher_role<true>(a, ws, st, upp, upw, resolve_warmup(warmup, st.iter), 0, n_items, spin_limit, R, (n_tb + (merge ? n_stream : 0)) * kWaves, losses);
+}
+
+// ---- bxi_boxinst_targets_f32: the image side alone, ahead of the evaluation ------------------------------------------------------
+// CondInstMaskHead.loss computes its targets from `imgs` and `gt_bboxes` alone (get_targets, condinst_head.py:1298-1299, :1345-1448) --
+// both exist before the backbone runs (condinst.py:53 vs :73).  Two launches with NO in-kernel wait (a kernel boundary between them), so the
+// call makes progress next to anything: launch 1 = the pool workgroups of prep_kernel (Lab records, tag field 0) + one workgroup that writes
+// the box table and zeroes the boxes' count words; launch 2 = the predicate waves over the box table, per-box pair counts.
+__global__ __launch_bounds__(256, 5) void targets_pool_kernel(PoolArgs pa, int n_pool, int n_items, GtTable gt, int Hc, int Wc, int stride, int h, int w, Ws ws,
+                                                               unsigned int key) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (blockIdx.x == 0) {
+        const int G = gt.first[gt.B];
+        for (int g = threadIdx.x; g < G; g += 256) {
+            int img = 0;
+            const float* bp = gt_box(gt, g, img);
+            const Rect rc = box_rect(bp, Hc, Wc, stride, stride / 2, h, w);
+            ws.boxtab()[g] = make_int4(img << 24, rc.r0 | (rc.r1 << 16), rc.c0 | (rc.c1 << 16), 0);
+#pragma unroll
+            for (int j = 0; j < kBoxSplit; ++j) ws.boxcnt()[((size_t)g * kBoxSplit + j) * kAcc2Stride] = 0ull;
+        }
+        if (threadIdx.x == 0) *ws.tkey() = key;
+        return;
+    }
+    double* lut = reinterpret_cast<double*>(smem);
+    double* fch = lut + 256;
+    int* part = reinterpret_cast<int*>(fch + 3 * 64);
+    pool_block(pa, ws, (int)blockIdx.x - 1, n_pool, n_items, lut, part, fch, 0);
+}
+
+__global__ __launch_bounds__(256) void targets_pred_kernel(int h, int w, int G, ValidCells vc, Ws ws, int D, float n2max, int n_pb, int n_items) {
+    __shared__ int boxacc[kBoxCap];
+    for (int g = threadIdx.x; g < G; g += 256) boxacc[g] = 0;
+    __syncthreads();
+    const int wave = (int)(threadIdx.x >> 6);
+    const int segs = (w + 63) >> 6;
+    bool ok = true;
+    for (int item = (int)blockIdx.x * kWaves + wave; item < n_items; item += n_pb * kWaves)
+        (void)pred_item<false, true>(h, w, G, vc, ws, D, n2max, item, segs, 0, ok, boxacc);
+    __syncthreads();
+    // one arrival per (workgroup, box it met): integer adds commute -- run-to-run identical
+    for (int g = threadIdx.x; g < G; g += 256) {
+        const int v = boxacc[g];
+        if (v) __hip_atomic_fetch_add(ws.boxcnt() + ((size_t)g * kBoxSplit + (blockIdx.x & (kBoxSplit - 1))) * kAcc2Stride, (unsigned long long)v, BXI_RLX, BXI_AGENT);
+    }
 }
 
 // ---- rescale: g_logits finished for the factors recorded in `state` -> finished for (g_prj, g_pw) ----------------
@@ -1662,7 +1813,14 @@ static int device_cus() {
     return v;
 }
 
+// Developer knobs (tools/ A/B scripts): read from the environment ONLY in a -DBXI_DEV build.  The shipped library reads nothing from the
+// process environment: what varies is an argument (`flags`), as include/boxinst_hip.h promises.
+#ifdef BXI_DEV
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#define BXI_KNOB(name, dflt) ([]() -> int { static const int v = env_int(name, dflt); return v; }())
+#else
+#define BXI_KNOB(name, dflt) (dflt)
+#endif
 
 // A stream that is being captured into a hipGraph: the launch is recorded, not run; what the host decides here is frozen into the graph
 static bool stream_is_capturing(hipStream_t s) {
@@ -1705,6 +1863,26 @@ static int stream_cus(hipStream_t s, int device_total) {
 // 64 instances: 24.2 vs 23.8 (single launch) -- hence the threshold.  BXI_TILE_ROWS / BXI_EVAL_TILE_ROWS_8 override.
 static int tile_rows_for(int N, int dil) { return (N >= 96 && dil <= 2) ? 8 : 4; }
 
+// digest of what targets are computed FOR -- canvas, stride, window, threshold, per image its shape, rows removed and box count -- kept in
+// the workspace by bxi_boxinst_targets_f32 and compared on the device by an evaluation that counts on them (FNV-1a; never 0)
+static unsigned int targets_key(const PoolArgs& pa, int B, int Hc, int Wc, int stride, int dil, float n2max, const int* first /* [B + 1] */) {
+    unsigned int hsh = 2166136261u;
+    auto mix = [&](unsigned int v) { for (int i = 0; i < 4; ++i) { hsh ^= (v >> (8 * i)) & 255u; hsh *= 16777619u; } };
+    unsigned int nb;
+    memcpy(&nb, &n2max, 4);
+    mix((unsigned)B); mix((unsigned)Hc); mix((unsigned)Wc); mix((unsigned)stride); mix((unsigned)dil); mix(nb);
+    for (int b = 0; b < B; ++b) { mix((unsigned)pa.meta.img_h[b]); mix((unsigned)pa.meta.img_w[b]); mix((unsigned)pa.meta.first_removed[b]); mix((unsigned)(first[b + 1] - first[b])); }
+    return hsh ? hsh : 1u;
+}
+static void valid_cells_of(const PoolArgs& pa, int B, int stride, int h, int w, ValidCells& vc) {
+    for (int b = 0; b < B; ++b) {                  // the device formula (valid_cells), evaluated here once per image
+        const int half = stride / 2;
+        auto cells = [&](int limit, int n) { const int v = limit - half <= 0 ? 0 : (limit - half + stride - 1) / stride; return v < n ? v : n; };
+        vc.vrow[b] = cells(pa.meta.img_h[b] < pa.meta.first_removed[b] ? pa.meta.img_h[b] : pa.meta.first_removed[b], h);
+        vc.vcol[b] = cells(pa.meta.img_w[b], w);
+    }
+}
+
 // (sim >= thresh) for a valid neighbour as a compare on the squared Lab distance: exp(-0.5 * sqrt(n2)) >= thresh  <=>  n2 <= n2max
 // (get_image_color_similarity :237 + the threshold of loss() :1324), n2max found by bisecting the f32 expression over the float
 // bit patterns (it is non-increasing in n2 >= 0, and positive floats order like their bit patterns).  Host arithmetic: sqrtf is
@@ -1741,7 +1919,7 @@ static HostPred host_pred(float thresh) {
 template <int D, int R>
 static void launch_pair(hipStream_t s, int grid, size_t lds, const InstArgs& a, float warmup, float n2max, int zero_bit, int n_pb, int n_items, int spin_limit,
                         const ValidCells& vc, const Ws& ws, const LossState& st, float* losses, float* g_logits, const float* up_prj, const float* up_pw) {
-    BXI_LAUNCH("pair", s, (pair_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, up_prj, up_pw, warmup, n2max, zero_bit,
+    BXI_LAUNCH(n_pb > 0 ? "pair" : "pair_tiles", s, (pair_kernel<D, R>), dim3((unsigned)grid), dim3(256), lds, s, up_prj, up_pw, warmup, n2max, zero_bit,
                n_pb, n_items, spin_limit, vc, losses, g_logits, a, ws, st);
 }
 
@@ -1754,7 +1932,82 @@ int eval_ws_init(void* workspace, size_t bytes, void* stream) {
     return BXI_OK;
 }
 
-// One evaluation, two launches.
+// the per-instance capacity a workspace of this size admits for this canvas (the layout is a function of both, never of a call's N)
+static int ws_capacity(int B, int h, int w, int N, size_t workspace_bytes) {
+    // (a pure function of (B, h, w, size): the last answer is kept per host thread -- a training loop asks the same question every
+    // iteration, and the search is sixteen layouts)
+    struct Last { int B, h, w, n_cap; size_t bytes; };
+    static thread_local Last last = {0, 0, 0, 0, 0};
+    if (last.bytes == workspace_bytes && last.B == B && last.h == h && last.w == w && last.n_cap >= N) return last.n_cap;
+    int lo = N, hi = kMaxInst - 1;           // carve() is non-decreasing in N
+    while (lo < hi) {
+        const int mid = lo + (hi - lo + 1) / 2;
+        if (carve(nullptr, B, mid, h, w, nullptr) <= workspace_bytes) lo = mid; else hi = mid - 1;
+    }
+    last = Last{B, h, w, lo, workspace_bytes};
+    return lo;
+}
+
+// bxi_boxinst_targets_f32: Lab, predicate words and per-GT-box pair counts into the workspace, ahead of the evaluation
+int launch_targets(const bxi_image_batch* batch, const float* const* boxes_per_img_host, const int* gt_count_host, int stride, int dil, float color_thresh,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+    if (!batch || !workspace) return BXI_ERR_NULL_POINTER;
+    if (!fused_eval_supported(dil)) return BXI_ERR_UNSUPPORTED;
+    if (batch->B <= 0 || batch->B > BXI_MAX_IMAGES || stride < 1 || batch->Hc % stride || batch->Wc % stride) return BXI_ERR_BAD_SHAPE;
+    if (!batch->imgs) return BXI_ERR_NULL_POINTER;
+    if (batch->image_masks) return BXI_ERR_UNSUPPORTED;
+    hipStream_t s = as_stream(stream);
+    PoolArgs pa = {};
+    int rc = fill_pool_args(batch, nullptr, nullptr, pa);
+    if (rc != BXI_OK) return rc;
+    GtTable gt;
+    int G = 0;
+    rc = fill_gt_table(boxes_per_img_host, gt_count_host, batch->B, gt, G);
+    if (rc != BXI_OK) return rc;
+    if (G > kBoxCap) return BXI_ERR_UNSUPPORTED;           // the evaluation then computes its targets itself (no BXI_EVAL_TARGETS_READY)
+    const int h = batch->Hc / stride, w = batch->Wc / stride;
+    if (h > 65535 || w > 65535) return BXI_ERR_BAD_SHAPE;
+    const HostPred pr = host_pred(color_thresh);
+    if (pr.zero_bit) return BXI_ERR_UNSUPPORTED;           // every pair weighs 1: nothing of the image is needed ahead
+    const size_t need = carve(nullptr, batch->B, 0, h, w, nullptr);
+    if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
+    Ws ws;
+    carve(workspace, batch->B, ws_capacity(batch->B, h, w, 0, workspace_bytes), h, w, &ws);
+    ws.ws_n16 = (unsigned int)(workspace_bytes / 16);
+    ValidCells vc = {};
+    valid_cells_of(pa, batch->B, stride, h, w, vc);
+    const int64_t n_items64 = (int64_t)batch->B * h * ((w + 63) / 64);
+    if (n_items64 > 0x7fffffffLL) return BXI_ERR_BAD_SHAPE;
+    const int n_items = (int)n_items64;
+    const unsigned int key = targets_key(pa, batch->B, batch->Hc, batch->Wc, stride, dil, pr.n2max, gt.first);
+    const bool pooled_in_launch = pool_vec_ok(batch, stride);
+    const int slots = 5 * device_cus();
+    int n_pool = 0;
+    if (pooled_in_launch) {
+        const int per = (n_items + slots - 1) / slots;
+        n_pool = (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per);
+    }
+    const size_t lds1 = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
+    BXI_LAUNCH("targets_pool", s, targets_pool_kernel, dim3((unsigned)(1 + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, gt, batch->Hc, batch->Wc, stride, h, w,
+               ws, key);
+    rc = check_launch();
+    if (rc != BXI_OK) return rc;
+    if (!pooled_in_launch) {       // other strides / unaligned canvases: the generic pooling kernels, then the repacking into 16-byte records
+        rc = launch_pool(batch, stride, nullptr, ws.lab_planar, s);
+        if (rc != BXI_OK) return rc;
+        const int64_t BP = (int64_t)batch->B * h * w;
+        BXI_LAUNCH("pack_lab4", s, pack_lab4_kernel, dim3((unsigned)((BP + 255) / 256 > 2048 ? 2048 : (BP + 255) / 256)), dim3(256), 0, s,
+                   (const float*)ws.lab_planar, ws.lab4, (const unsigned int*)ws.epoch, batch->B, (int64_t)h * w);
+        rc = check_launch();
+        if (rc != BXI_OK) return rc;
+    }
+    int n_pb = (n_items + kWaves - 1) / kWaves;
+    if (n_pb > 8 * device_cus()) n_pb = 8 * device_cus();
+    BXI_LAUNCH("targets_pred", s, targets_pred_kernel, dim3((unsigned)n_pb), dim3(256), 0, s, h, w, G, vc, ws, dil, pr.n2max, n_pb, n_items);
+    return check_launch();
+}
+
+// One evaluation: one launch (eval1) or two (prep, pair).
 int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bxi_instances* in, int dil, float warmup, const float* up_prj,
                  const float* up_pw, float* losses, float* g_logits, void* state, void* workspace, size_t workspace_bytes, unsigned flags,
                  void* stream, const DynArgs* head, int head_C) {
@@ -1766,9 +2019,11 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     hipStream_t s = as_stream(stream);
     PoolArgs pa = {};
     if (batch->Hc != in->Hc || batch->Wc != in->Wc || batch->B != in->B) return BXI_ERR_BAD_SHAPE;
+    // the image side is in the workspace (bxi_boxinst_targets_f32): `imgs` is not read.  (The kernels get the number of GT boxes + 1.)
+    const int ready = (flags & kFlagTargetsReady) ? a.gt.first[a.gt.B] + 1 : 0;
     rc = fill_pool_args(batch, nullptr, nullptr, pa);
     if (rc != BXI_OK) return rc;
-    if (batch->B > 0 && !batch->imgs) return BXI_ERR_NULL_POINTER;
+    if (batch->B > 0 && !batch->imgs && !ready) return BXI_ERR_NULL_POINTER;
     if (batch->image_masks) return BXI_ERR_UNSUPPORTED;   // explicit masks: use bxi_color_affinity_f32 + bits
     if (warmup < 0.f && !in->iter_counter) return BXI_ERR_NULL_POINTER;     // the factor is to come from the device counter
     if (!(warmup == warmup)) return BXI_ERR_BAD_ARGUMENT;
@@ -1779,7 +2034,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     if (a.N >= kMaxInst || a.h > 65535 || a.w > 65535) return BXI_ERR_BAD_SHAPE;
     if (batch->B <= 0) return BXI_ERR_BAD_SHAPE;
     if (g_logits && !state) return BXI_ERR_NULL_POINTER;
-    const bool pooled_in_launch = pool_vec_ok(batch, a.stride);     // else: the generic pooling kernels in launches of their own
+    const bool pooled_in_launch = ready || pool_vec_ok(batch, a.stride);     // else: the generic pooling kernels in launches of their own
     const size_t need = carve(nullptr, batch->B, a.N, a.h, a.w, nullptr);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) return BXI_ERR_WORKSPACE;
     // The layout is a function of (B, h, w) and of the workspace's SIZE, not of this call's instance count: the per-instance regions are
@@ -1788,25 +2043,10 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     // one-time initialisation), and tags grow monotonically -- a stale word can never pass for a fresh one.  (With the layout moving
     // with N, a small tag could meet an old PAYLOAD word of the same value -- a predicate word is 16 * tag + bits -- found by
     // tools/extended_fuzz.py: intermittent wrong results, status 0.)
-    int n_cap = a.N;
-    {
-        // (the capacity is a pure function of (B, h, w, size): the last answer is kept per host thread -- a training loop asks the same
-        // question every iteration, and the search is sixteen layouts)
-        struct Last { int B, h, w, n_cap; size_t bytes; };
-        static thread_local Last last = {0, 0, 0, 0, 0};
-        if (last.bytes == workspace_bytes && last.B == batch->B && last.h == a.h && last.w == a.w && last.n_cap >= a.N) n_cap = last.n_cap;
-        else {
-            int lo = a.N, hi = kMaxInst - 1;           // carve() is non-decreasing in N
-            while (lo < hi) {
-                const int mid = lo + (hi - lo + 1) / 2;
-                if (carve(nullptr, batch->B, mid, a.h, a.w, nullptr) <= workspace_bytes) lo = mid; else hi = mid - 1;
-            }
-            n_cap = lo;
-            last = Last{batch->B, a.h, a.w, n_cap, workspace_bytes};
-        }
-    }
     Ws ws;
-    carve(workspace, batch->B, n_cap, a.h, a.w, &ws);
+    carve(workspace, batch->B, ws_capacity(batch->B, a.h, a.w, a.N, workspace_bytes), a.h, a.w, &ws);
+    ws.ws_n16 = (unsigned int)(workspace_bytes / 16);
+    ws.pred_any = ready ? 1u : 0u;
     LossState st = {};
     if (state) {
         if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
@@ -1815,35 +2055,32 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     st.iter = in->iter_counter;
     const int vec = ((a.w & 3) == 0 && (reinterpret_cast<uintptr_t>(a.logits) & 15) == 0 &&
                      (!g_logits || (reinterpret_cast<uintptr_t>(g_logits) & 15) == 0)) ? 1 : 0;
-    static const int env_rows = env_int("BXI_TILE_ROWS", 0);            // developer knobs
-    static const int env_pool_first = env_int("BXI_POOL_FIRST", 0);
-    static const int env_pool_wgs = env_int("BXI_POOL_WGS_PER_CU", 5);
-    const int force_rows = (flags & kFlagRows8) ? 8 : env_rows;
+    const int env_rows = BXI_KNOB("BXI_TILE_ROWS", 0);            // developer knobs (-DBXI_DEV builds only)
+    const int env_pool_first = BXI_KNOB("BXI_POOL_FIRST", 0);
+    const int env_pool_wgs = BXI_KNOB("BXI_POOL_WGS_PER_CU", 5);
+    const int force_rows = (flags & kFlagRows8) ? 8 : ((flags & kFlagRows4) ? 4 : env_rows);
     const int R = force_rows == 4 || force_rows == 8 ? force_rows : ((flags & kFlagSingle) ? 4 : tile_rows_for(a.N, dil));
     if (eval_cap(a.N, a.h, a.w, dil, R) >= (1 << 24)) return BXI_ERR_BAD_SHAPE;     // the table packs a tile prefix into 24 bits
     const HostPred pr = host_pred(color_thresh);
+    if (ready && pr.zero_bit) return BXI_ERR_UNSUPPORTED;       // (bxi_boxinst_targets_f32 refuses thresholds <= 0 as well)
     ValidCells vc = {};
-    for (int b = 0; b < batch->B; ++b) {                  // the device formula (valid_cells), evaluated here once per image
-        const int half = a.stride / 2;
-        auto cells = [&](int limit, int n) { const int v = limit - half <= 0 ? 0 : (limit - half + a.stride - 1) / a.stride; return v < n ? v : n; };
-        vc.vrow[b] = cells(pa.meta.img_h[b] < pa.meta.first_removed[b] ? pa.meta.img_h[b] : pa.meta.first_removed[b], a.h);
-        vc.vcol[b] = cells(pa.meta.img_w[b], a.w);
-    }
+    valid_cells_of(pa, batch->B, a.stride, a.h, a.w, vc);
     const int64_t n_items64 = (int64_t)batch->B * a.h * ((a.w + 63) / 64);
     if (n_items64 > 0x7fffffffLL) return BXI_ERR_BAD_SHAPE;
     const int n_items = (int)n_items64;
     const int spin_limit = (flags & kFlagGiveUp) ? -1 : kSpinLimit;
+    const unsigned int key = ready ? targets_key(pa, batch->B, batch->Hc, batch->Wc, a.stride, dil, pr.n2max, a.gt.first) : 0u;
 
     // ---- the single-launch form ---------------------------------------------------------------------------------------
-    static const int env_one = env_int("BXI_ONE_LAUNCH", 1);            // developer knob: 0 = always two launches
+    const int env_one = BXI_KNOB("BXI_ONE_LAUNCH", 1);            // developer knob: 0 = always two launches
     // The single launch pays off while its front half (stream + pool workgroups) is resident at once: measured 24.8 vs 27.0 us at
     // 64 instances, 35.1 vs 33.9 at 96, 45.1 vs 39.4 at 128 (200 x 256 maps) -- hence: stream workgroups <= half the slots.
     const int one_slots = kOneOcc * device_cus();
     const bool one_fits = 2 * (int64_t)a.N * ((a.h + kSBlk - 1) / kSBlk) <= one_slots && stream_cus(s, device_cus()) >= device_cus();
     // (built for dilation <= 2: the single launch needs four workgroups per CU, and at dilation 3 the tile role does not fit 128 VGPRs)
-    if (env_one && !(flags & kFlagTwo) && (one_fits || env_one == 2 || (flags & kFlagSingle)) && !head && pooled_in_launch && R == 4 && dil <= 2 &&
-        !pr.zero_bit) {
-        static const int env_one_pool = env_int("BXI_ONE_POOL_WGS", 0);
+    if (env_one && !(flags & (kFlagTwo | kFlagPredInPair | kFlagPredInPrep)) && (one_fits || env_one == 2 || (flags & kFlagSingle)) && !head && pooled_in_launch &&
+        R == 4 && dil <= 2 && !pr.zero_bit) {
+        const int env_one_pool = BXI_KNOB("BXI_ONE_POOL_WGS", 0);
         const int Sn = (a.h + kSBlk - 1) / kSBlk;
         const int n_stream = a.N * Sn;
         const int slots = one_slots;
@@ -1855,8 +2092,8 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         const int front = slots - n_stream;
         const int room = env_one_pool > 0 ? env_one_pool : (front > slots / 4 ? front : slots / 4);
         const int per = (n_items + room - 1) / room;
-        const int n_pool = (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per);
-        int n_pb = (n_items + kWaves - 1) / kWaves;
+        const int n_pool = ready ? 0 : (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per);
+        int n_pb = ready ? 0 : (n_items + kWaves - 1) / kWaves;
         if (n_pb > slots / 2) n_pb = slots / 2;
         int64_t n_tb = (eval_cap(a.N, a.h, a.w, dil, R) + kWaves - 1) / kWaves;
         if (n_tb > slots / 2) n_tb = slots / 2;
@@ -1866,7 +2103,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         // against 10 us without the staying-on).  The library cannot see what else runs on the device and does not guess: the CALLER
         // says so (BXI_EVAL_SHARED_DEVICE / BXI_EVAL_NO_STAY_ON; boxinstseg_amd/functional.py sets it once a second stream has been
         // seen on the device).  A launch that is being captured into a graph may be replayed next to anything: no staying-on either.
-        static const int env_merge = env_int("BXI_ONE_MERGE", 1);
+        const int env_merge = BXI_KNOB("BXI_ONE_MERGE", 1);
         const int merge = env_merge && one_fits && !(flags & (kFlagNoStay | kFlagShared)) && !stream_is_capturing(s) ? 1 : 0;
         if (merge) n_tb = n_tb > n_stream ? n_tb - n_stream : 0;
         size_t lds = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
@@ -1877,8 +2114,8 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
             const unsigned grid = (unsigned)(n_stream + n_pool + n_pb + 1 + a.N + (int)n_tb + 1);
 #define BXI_ONE_CASE(DD)                                                                                                                    \
             case DD:                                                                                                                        \
-                BXI_LAUNCH("eval1", s, (eval1_kernel<DD>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, up_prj, \
-                           up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge);                                             \
+                BXI_LAUNCH(ready ? "eval1_ready" : "eval1", s, (eval1_kernel<DD>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, up_prj, \
+                           up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge, ready, key);                                 \
                 break;
             switch (dil) { BXI_ONE_CASE(1) BXI_ONE_CASE(2) default: return BXI_ERR_UNSUPPORTED; }
 #undef BXI_ONE_CASE
@@ -1898,11 +2135,24 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     // behind the HBM stream (the first launch's last 5 us at 128 instances).  Then the launch exceeds the slots and its tail workgroups
     // take them as they come free; the pool workgroups go FIRST in that case, the image side being the longer chain.  Measured: 40.1 ->
     // 38.5 us per evaluation at 128 instances, 75.8 -> 70.3 at 256 (BXI_PREP_ITEMS=<n>: developer override)
-    static const int env_prep_items = env_int("BXI_PREP_ITEMS", 0);
+    const int env_prep_items = BXI_KNOB("BXI_PREP_ITEMS", 0);
     int per = env_prep_items > 0 ? env_prep_items : (room > 0 ? (n_items + room - 1) / room : 8);
     if (env_prep_items <= 0 && per > 2) per = 2;
-    const int n_pool = pooled_in_launch ? (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per) : 0;
-    const int pool_first = env_pool_first || (!head && n_tab + n_stream + n_pool > env_pool_wgs * device_cus()) ? 1 : 0;
+    const int n_pool = pooled_in_launch && !ready ? (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per) : 0;
+    // The FOLDED form: the image-only chain -- predicate words, their counts, sum W -- at the tail of THIS launch: the predicate workgroups
+    // wait (bounded) for pool workgroups earlier in the grid, the reducer for them; at the kernel boundary everything the second launch
+    // needs of the image side is in memory and its tile waves wait for nobody.  With many instances the first launch is a long logit
+    // stream (52 MB at 128) that the image side (20 MB, pool workgroups first) hides under.  From kFoldFrom instances on, or as asked.
+    const bool can_fold = !ready && !head && pooled_in_launch && !pr.zero_bit;
+    const bool fold = can_fold && ((flags & kFlagPredInPrep) || (!(flags & kFlagPredInPair) && a.N >= BXI_KNOB("BXI_FOLD_FROM", kFoldFrom)));
+    PrepTail tl = {};
+    tl.ready = ready; tl.key = key; tl.n2max = pr.n2max; tl.spin_limit = spin_limit;
+    if (fold) {
+        tl.n_pb = (n_items + kWaves - 1) / kWaves;
+        const int cap = env_pool_wgs * device_cus() / 2;
+        if (tl.n_pb > cap) tl.n_pb = cap;
+    }
+    const int pool_first = env_pool_first || fold || (!head && n_tab + n_stream + n_pool > env_pool_wgs * device_cus()) ? 1 : 0;
     size_t lds1 = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
     // every refusal comes BEFORE the first launch: a refused call has enqueued nothing (callers fall back to other entry points)
     size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
@@ -1924,7 +2174,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         const unsigned grid1 = (unsigned)(n_tab + n_pool + a.N * tiles);
 #define BXI_HEAD_LAUNCH(CC, RR)                                                                                                          \
         BXI_LAUNCH("head_prep", s, (head_prep_kernel<CC, RR>), dim3(grid1), dim3(256), lds1, s, pa, n_pool, n_items, a, dil, R, ws, st,     \
-                   g_logits, *head, head->params, logits_out)
+                   g_logits, *head, head->params, logits_out, ready, key)
         if (head_C == 16 && head->rel) BXI_HEAD_LAUNCH(16, true);
         else if (head_C == 16) BXI_HEAD_LAUNCH(16, false);
         else if (head_C == 8 && head->rel) BXI_HEAD_LAUNCH(8, true);
@@ -1934,19 +2184,23 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     } else {
         if (lds1 < 8 * (size_t)kWaves * a.w) lds1 = 8 * (size_t)kWaves * a.w;
         if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
-        BXI_LAUNCH("prep", s, prep_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, a, dil,
-                   R, ws, st, g_logits, vec, pool_first);
+        BXI_LAUNCH(fold ? "prep_fold" : (ready ? "prep_ready" : "prep"), s, prep_kernel, dim3((unsigned)(n_tab + n_stream + n_pool + (fold ? tl.n_pb + 1 : 0))), dim3(256), lds1, s, pa, n_pool, n_items, a, dil,
+                   R, ws, st, g_logits, vec, pool_first, tl, vc);
     }
     rc = check_launch();
     if (rc != BXI_OK) return rc;
+    // From here on a launch of this evaluation is enqueued: records carrying its tag are (or will be) in the workspace while the epoch only
+    // moves with the finisher.  An error return below would leave them behind an unchanged epoch -- the next evaluation would draw the same
+    // tag and take them for its own -- so the workspace is returned to its initial state (stream-ordered) on that path.
+    auto fail = [&](int code) { (void)hipMemsetAsync(workspace, 0, workspace_bytes, s); (void)hipGetLastError(); return code; };
     if (!pooled_in_launch) {
         rc = launch_pool(batch, a.stride, nullptr, ws.lab_planar, s);
-        if (rc != BXI_OK) return rc;
+        if (rc != BXI_OK) return fail(rc);
         const int64_t BP = (int64_t)batch->B * a.h * a.w;
         BXI_LAUNCH("pack_lab4", s, pack_lab4_kernel, dim3((unsigned)((BP + 255) / 256 > 2048 ? 2048 : (BP + 255) / 256)), dim3(256), 0, s,
                    (const float*)ws.lab_planar, ws.lab4, (const unsigned int*)ws.epoch, batch->B, (int64_t)a.h * a.w);
         rc = check_launch();
-        if (rc != BXI_OK) return rc;
+        if (rc != BXI_OK) return fail(rc);
     }
 
     // ---- launch 2 --------------------------------------------------------------------------------------------------
@@ -1954,17 +2208,17 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     int64_t n_tb = (cap + kWaves - 1) / kWaves;
     // the tile list's length is device data: the tile waves stride through it.  The launch should be resident in one round:
     // 4 (R = 4: <= 128 VGPRs) or 2 (R = 8) workgroups per CU; the predicate waves are short-lived.
-    static const int env_pair_wgs = env_int("BXI_PAIR_WGS_PER_CU", 0);
+    const int env_pair_wgs = BXI_KNOB("BXI_PAIR_WGS_PER_CU", 0);
     const int occ = env_pair_wgs > 0 ? env_pair_wgs : (R == 4 ? (dil <= 2 ? 4 : 3) : (dil <= 2 ? 3 : 2));
     // (the leaders are short-lived and are not counted; with them subtracted, 512 instances at two workgroups per CU left ONE
     // predicate workgroup for the whole image side: 4.4 ms per evaluation)
     const int cus2 = stream_cus(s, device_cus());                      // a CU-masked stream has fewer
     const int slots = occ * cus2 > 64 ? occ * cus2 : 64;
-    int n_pb = (n_items + kWaves - 1) / kWaves;
+    int n_pb = (fold || ready) ? 0 : (n_items + kWaves - 1) / kWaves;  // (folded / targets ready: the image side is in memory at this kernel's start)
     if (n_pb > slots / 2) n_pb = slots / 2;
     // (the predicate workgroups are short-lived: the tile workgroups behind them in the grid take their slots as they leave, so the
     // tile workgroups are sized for the slots, not for what the predicate workgroups leave over -- BXI_PAIR_TB_FULL=0: the round-3 sizing)
-    static const int env_tb_full = env_int("BXI_PAIR_TB_FULL", 1);
+    const int env_tb_full = BXI_KNOB("BXI_PAIR_TB_FULL", 1);
     if (n_tb > (env_tb_full ? slots : slots - n_pb)) n_tb = env_tb_full ? slots : slots - n_pb;
     const int grid = n_pb + 1 + a.N + (int)n_tb + 1;      // predicate blocks + the reducer + leaders + tile blocks + the finisher
 #define BXI_PAIR_CASE(DD)                                                                                                                  \
@@ -1974,10 +2228,11 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         break;
     switch (dil) {
         BXI_PAIR_CASE(1) BXI_PAIR_CASE(2) BXI_PAIR_CASE(3) BXI_PAIR_CASE(4)
-        default: return BXI_ERR_UNSUPPORTED;
+        default: return fail(BXI_ERR_UNSUPPORTED);
     }
 #undef BXI_PAIR_CASE
-    return check_launch();
+    rc = check_launch();
+    return rc == BXI_OK ? rc : fail(rc);
 }
 
 // the same from the three numbers the kernel needs of the instances (the autograd node's backward keeps those, not the structs)

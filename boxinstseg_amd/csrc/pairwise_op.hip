@@ -708,7 +708,11 @@ static int launch_bwd(const T* logits, const T* g_pair, int N, int H, int W, int
             }
             if constexpr (sizeof(T) == 4) {
                 if (dil <= 4 && (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(g_pair) | reinterpret_cast<uintptr_t>(g_logits)) & 15) == 0) {
+#ifdef BXI_DEV                                       // developer knob (tools/ A/B scripts); the shipped library reads nothing from the environment
                     static const int env_swz = getenv("BXI_PW_SWIZZLE") ? atoi(getenv("BXI_PW_SWIZZLE")) : 1;
+#else
+                    constexpr int env_swz = 1;
+#endif
 #ifndef BXI_PWB_TR
 #define BXI_PWB_TR 16
 #define BXI_PWB_TC 64

@@ -237,6 +237,8 @@ class _Local(threading.local):
         self.flags = 0                      # BXI_EVAL_* bits every evaluation of this thread is launched with (eval_flags, note_fault)
         self.wait_free = False              # after a fault in the two-launch form: the launches-only path (no in-kernel wait at all)
         self.forced: Optional[int] = None   # tests: the flags instead of what this module would choose
+        self.prepared: Dict[tuple, list] = {}   # (device, canvas) -> rotating workspaces of prepare_targets
+        self.prepared_next: Dict[tuple, int] = {}
 
 
 _TLS = _Local()
@@ -276,12 +278,98 @@ def _workspace(dev: torch.device, stream: int, canvas: tuple, N: int) -> torch.T
         # A second stream on this device: evaluations may now run side by side, and the library is told so from here on (sticky;
         # BXI_EVAL_SHARED_DEVICE: no workgroup may hold a slot while it waits for workgroups later in the grid).  The library
         # itself never guesses what else runs on the device.
-        if any(k[0] == dev.index and k[1] != stream for k in _TLS.workspaces):
+        if any(k[0] == dev.index and k[1] != stream for k in _TLS.workspaces) and not (_TLS.flags & _lib.EVAL_SHARED_DEVICE):
             _TLS.flags |= _lib.EVAL_SHARED_DEVICE
+            warnings.warn('boxinstseg_amd: evaluations on a second stream of device %d seen; this thread launches every evaluation '
+                          'with BXI_EVAL_SHARED_DEVICE from here on (reset_eval_state() forgets it)' % dev.index, RuntimeWarning, stacklevel=3)
         hit = _TLS.workspaces[key] = (torch.zeros(need, dtype=torch.uint8, device=dev), n_cap)
     elif len(_TLS.workspaces) > 1:
         _TLS.workspaces[key] = _TLS.workspaces.pop(key)          # most recently used last
     return hit[0]
+
+
+class PreparedTargets:
+    """What :func:`prepare_targets` leaves: a workspace holding Lab, the predicate words and the per-box pair counts of ONE batch, the
+    event that says they are there, and what they were computed from (so that ``loss()`` can tell whether they are its batch's)."""
+    __slots__ = ('ws', 'n_cap', 'event', 'match', 'slot', 'refs')
+
+    def matches(self, imgs: torch.Tensor, gt_bboxes, cfg: Dict) -> bool:
+        return self.match == _targets_match_key(imgs, gt_bboxes, cfg)
+
+
+def _targets_match_key(imgs, gt_bboxes, cfg) -> tuple:
+    return (imgs.data_ptr(), tuple(imgs.shape), imgs._version, tuple((b.data_ptr(), tuple(b.shape), b._version) for b in gt_bboxes),
+            int(cfg['out_stride']), int(cfg['bottom_pixels_removed']), int(cfg['pairwise_size']), int(cfg['pairwise_dilation']),
+            float(cfg['pairwise_color_thresh']))
+
+
+_PREPARED_SLOTS = 2              # targets of iteration i + 1 may be prepared while the loss of iteration i is still queued
+_PREPARED_N_CAP = 256            # instances a prepared workspace is sized for (topk_per_img = 64 x samples_per_gpu <= 4)
+
+
+def prepare_targets(imgs: torch.Tensor, img_metas: Sequence[dict], gt_bboxes: Sequence[torch.Tensor], *, out_stride: int = 4,
+                    bottom_pixels_removed: int = 10, pairwise_size: int = 3, pairwise_dilation: int = 2,
+                    pairwise_color_thresh: float = 0.3, stream: Optional['torch.cuda.Stream'] = None) -> Optional[PreparedTargets]:
+    """The image side of ``CondInstMaskHead.loss`` ahead of time (``bxi_boxinst_targets_f32``): ``get_targets`` (condinst_head.py
+    :1298-1299, :1345-1448) needs only the network input and the GT boxes, both of which exist before the backbone runs
+    (``mmdet/models/detectors/condinst.py:53`` vs ``:73``).  Enqueued on ``stream`` (a side stream, ordered behind the current one; ``None``
+    = the current stream), it takes image -> Lab -> colour predicates -> pair counts off the loss's critical path; hand the result to
+    :func:`boxinst_mask_loss` (``targets=``).  Returns ``None`` where the library does not build it (more than 1024 GT boxes, a
+    threshold <= 0, another window): the loss then computes its targets itself, as without this call."""
+    _require_cuda(imgs=imgs)
+    if _TLS.wait_free or not fused_supported(pairwise_size, pairwise_dilation):
+        return None
+    dev = imgs.device
+    imgs_c = _f32c(imgs)
+    boxes = [b if (b.dtype == torch.float32 and b.device == dev and b.is_contiguous()) else
+             b.detach().to(device=dev, dtype=torch.float32).contiguous() for b in gt_bboxes]
+    batch = _Batch(imgs_c, img_metas, bottom_pixels_removed)
+    if len(boxes) != batch.B:
+        raise RuntimeError(f'{batch.B} images but {len(boxes)} box lists')
+    if batch.Hc % out_stride or batch.Wc % out_stride:
+        raise RuntimeError(f'canvas {batch.Hc}x{batch.Wc} is not a multiple of out_stride {out_stride}')
+    canvas = (batch.B, batch.Hc, batch.Wc, int(out_stride))
+    key = (dev.index,) + canvas
+    slots = _TLS.prepared.get(key)
+    lib = _lib.load()
+    if slots is None:
+        if len(_TLS.prepared) >= 16:
+            _TLS.prepared.pop(next(iter(_TLS.prepared)))
+        need = max(lib.bxi_boxinst_eval_workspace_bytes(*canvas, _PREPARED_N_CAP), 256)
+        slots = _TLS.prepared[key] = [dict(ws=torch.zeros(need, dtype=torch.uint8, device=dev), free=None) for _ in range(_PREPARED_SLOTS)]
+        _TLS.prepared_next[key] = 0
+    k = _TLS.prepared_next[key]
+    _TLS.prepared_next[key] = (k + 1) % len(slots)
+    slot = slots[k]
+    cur = torch.cuda.current_stream(dev)
+    st = cur if stream is None else stream
+    ptrs = _lib.ptr_array(b.data_ptr() if b.numel() else 0 for b in boxes)
+    cnt = _lib.int_array(b.shape[0] if b.dim() == 2 else b.numel() // 4 for b in boxes)
+    with torch.cuda.device(dev):
+        if stream is not None:
+            st.wait_stream(cur)                     # the images (and boxes) are produced on the current stream
+        if slot['free'] is not None:
+            st.wait_event(slot['free'])             # the evaluation that last read this workspace
+        rc = lib.bxi_boxinst_targets_f32(C.byref(batch.struct), C.cast(ptrs, C.POINTER(C.c_void_p)), C.cast(cnt, C.POINTER(C.c_int)),
+                                         int(out_stride), int(pairwise_size), int(pairwise_dilation), float(pairwise_color_thresh),
+                                         slot['ws'].data_ptr(), slot['ws'].numel(), st.cuda_stream)
+        if rc == _lib.BXI_ERR_UNSUPPORTED:
+            return None
+        _lib.check('bxi_boxinst_targets_f32', rc)
+        ev = torch.cuda.Event()
+        ev.record(st)
+    if stream is not None:                          # the caching allocator must not hand these to somebody else while the side stream reads them
+        imgs_c.record_stream(st)
+        for b in boxes:
+            if b.numel():
+                b.record_stream(st)
+    t = PreparedTargets()
+    t.ws, t.n_cap, t.event, t.slot = slot['ws'], _PREPARED_N_CAP, ev, slot
+    cfg = dict(out_stride=out_stride, bottom_pixels_removed=bottom_pixels_removed, pairwise_size=pairwise_size,
+               pairwise_dilation=pairwise_dilation, pairwise_color_thresh=pairwise_color_thresh)
+    t.match = _targets_match_key(imgs_c, boxes, cfg)
+    t.refs = (imgs_c, boxes)
+    return t
 
 
 def eval_launch_flags() -> int:
@@ -299,15 +387,27 @@ def eval_flags(flags: int):
         _TLS.forced = prev
 
 
+def _drop_or_zero_workspaces(drop: bool) -> None:
+    """After a fault the ABI asks for a zeroed workspace.  DROPPED, the next evaluation allocates a fresh zeroed one and the old buffer
+    goes back to the caching allocator, which keeps it alive for work already queued on whatever stream used it; zeroed in place
+    (tests: the same memory again), each workspace is zeroed ON ITS OWN STREAM -- the host never writes a workspace on a stream other
+    than the one its evaluations are serialised on."""
+    _TLS.prepared.clear()
+    _TLS.prepared_next.clear()
+    if drop:
+        _TLS.workspaces.clear()
+        return
+    lib = _lib.load()
+    for key, (ws, _) in _TLS.workspaces.items():
+        with torch.cuda.device(ws.device):
+            _lib.check('bxi_boxinst_eval_workspace_init', lib.bxi_boxinst_eval_workspace_init(ws.data_ptr(), ws.numel(), key[1]))
+
+
 def reset_eval_state(drop_workspaces: bool = True) -> None:
     """Forget this thread's sticky launch flags (and, by default, its workspaces: the next evaluation allocates a zeroed one)."""
     _TLS.flags = 0
     _TLS.wait_free = False
-    if drop_workspaces:
-        _TLS.workspaces.clear()
-    else:
-        for ws, _ in _TLS.workspaces.values():
-            ws.zero_()
+    _drop_or_zero_workspaces(drop_workspaces)
 
 
 def note_fault(what: str = '') -> None:
@@ -327,8 +427,7 @@ def note_fault(what: str = '') -> None:
         warnings.warn('boxinstseg_amd: an evaluation reported a fault%s; taking the two-launch form from here on'
                       % (f' ({what})' if what else ''), RuntimeWarning, stacklevel=2)
     _TLS.flags = (_TLS.flags | _lib.EVAL_TWO_LAUNCHES) & ~_lib.EVAL_SINGLE_LAUNCH
-    for ws, _ in _TLS.workspaces.values():
-        ws.zero_()
+    _drop_or_zero_workspaces(True)
 
 
 def _sizes(N: int, h: int, w: int, B: int, Hc: int, Wc: int, stride: int) -> Tuple[int, int]:
@@ -439,6 +538,18 @@ class BoxInstMaskLoss(torch.autograd.Function):
         plan = _eval_plan(imgs, ctx.metas, x, boxes, int(cfg['out_stride']), int(cfg['bottom_pixels_removed']), stream)
         if gi.numel() != plan.inst.N:
             raise RuntimeError(f'{plan.inst.N} instances but {gi.numel()} gt_inds')
+        # targets prepared ahead (prepare_targets): THEIR workspace, behind their event; only for the first evaluation of this node, and
+        # only if they were computed from this very batch (else the evaluation computes its own, as without them)
+        flags = eval_launch_flags()
+        tg = cfg.get('targets') if ctx.calls == 0 else None
+        if tg is not None and not _TLS.wait_free and plan.inst.N <= tg.n_cap and tg.ws.device == dev and tg.matches(imgs, boxes, cfg) and \
+                not (flags & (_lib.EVAL_PRED_IN_PAIR | _lib.EVAL_PRED_IN_PREP)):
+            torch.cuda.current_stream(dev).wait_event(tg.event)
+            plan.ws = tg.ws
+            plan.ws_ptr, plan.ws_bytes = tg.ws.data_ptr(), tg.ws.numel()
+            flags |= _lib.EVAL_TARGETS_READY
+        else:
+            tg = None
         # ONE allocation, as floats: [losses 256 B][state (a multiple of 256 B)][gradient]
         nfl = 64 + (plan.state_bytes // 4 + plan.grad_elems if need_grad else 0)
         buf = torch.empty(nfl, dtype=torch.float32, device=dev)
@@ -465,13 +576,17 @@ class BoxInstMaskLoss(torch.autograd.Function):
         args = (plan.batch_ref, plan.inst_ref, int(cfg['pairwise_size']), int(cfg['pairwise_dilation']),
                 float(cfg['pairwise_color_thresh']), warm, 0, 0, base,
                 base + 256 + plan.state_bytes if need_grad else 0, base + 256 if need_grad else 0,
-                plan.ws_ptr, plan.ws_bytes, eval_launch_flags(), stream)
+                plan.ws_ptr, plan.ws_bytes, flags, stream)
         if torch.cuda.current_device() == dev.index:          # the usual case: no device guard to set up and tear down
             rc = plan.eval(*args)
         else:
             with torch.cuda.device(dev):
                 rc = plan.eval(*args)
         _lib.check('bxi_boxinst_eval_f32', rc)
+        if tg is not None:              # the next prepare_targets that takes this workspace waits for this evaluation
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            tg.slot['free'] = ev
         losses = buf[:2]
         if DEBUG_KEEP_LAST:
             _LAST.clear()
@@ -673,7 +788,8 @@ def boxinst_mask_loss(mask_logits: torch.Tensor, gt_inds: torch.Tensor, gt_bboxe
                       affinity_bits: Optional[torch.Tensor] = None, out_stride: int = 4,
                       bottom_pixels_removed: int = 10, pairwise_size: int = 3, pairwise_dilation: int = 2,
                       pairwise_color_thresh: float = 0.3, warmup_factor: float = 1.0,
-                      iter_counter: Optional[torch.Tensor] = None, warmup_iters: Optional[float] = None) -> Dict[str, torch.Tensor]:
+                      iter_counter: Optional[torch.Tensor] = None, warmup_iters: Optional[float] = None,
+                      targets: Optional[PreparedTargets] = None) -> Dict[str, torch.Tensor]:
     """The BoxInst branch of ``CondInstMaskHead.loss`` (condinst_head.py:1297-1337) as one call.
 
     Either ``imgs`` + ``img_metas`` (targets are computed on the device from the network input) or
@@ -682,6 +798,9 @@ def boxinst_mask_loss(mask_logits: torch.Tensor, gt_inds: torch.Tensor, gt_bboxe
     ``self._iter += 1`` (condinst_head.py:1297) without a launch of its own.  With ``warmup_iters`` (``pairwise_warmup``) the warm-up
     factor ``min(_iter / warmup_iters, 1)`` (:1330-1331) is evaluated ON THE DEVICE from that counter and ``warmup_factor`` is ignored:
     no host copy of the counter exists, and a captured hipGraph ramps as the eager loop does.
+    ``targets``: what :func:`prepare_targets` returned for THIS batch (same ``imgs`` tensor, same boxes, same parameters; anything else
+    is ignored and the evaluation computes its targets itself): the evaluation then launches only the logit stream, the leaders, the
+    tiles and the finisher (``BXI_EVAL_TARGETS_READY``) -- bit-equal results.
     Returns ``{'loss_prj', 'loss_pairwise'}`` attached to the autograd graph of ``mask_logits``.
     Built for ``pairwise_size == 3`` and ``pairwise_dilation <= 4`` (``fused_supported``); other windows are
     composed from the op-level kernels by ``CondInstMaskHead._composed_loss``.
@@ -694,6 +813,8 @@ def boxinst_mask_loss(mask_logits: torch.Tensor, gt_inds: torch.Tensor, gt_bboxe
     cfg = dict(out_stride=out_stride, bottom_pixels_removed=bottom_pixels_removed, pairwise_size=pairwise_size,
                pairwise_dilation=pairwise_dilation, pairwise_color_thresh=pairwise_color_thresh,
                warmup_factor=warmup_factor)
+    if targets is not None and affinity_bits is None:
+        cfg['targets'] = targets
     if iter_counter is not None:
         if affinity_bits is not None:
             raise RuntimeError('iter_counter is counted by the evaluation from images; with affinity_bits add to it yourself')

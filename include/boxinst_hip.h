@@ -21,9 +21,10 @@
  *   - return value: BXI_OK (0) or a negative bxi_status; never throws.  The reference reports the
  *     same conditions by TORCH_CHECK / AT_CUDA_CHECK (pairwise.cu:7-13,173,200); the Python
  *     shim turns a non-zero status into RuntimeError.
- *   - re-entrant, no process-wide mutable state: what varies is an argument (`flags` of the evaluation).  The few
- *     developer hooks (launch bracketing for benchmarks, a test switch of the tree filter) are declared in
- *     boxinst_hip_dev.h, not here.  One host thread per device is the expected use.
+ *   - re-entrant, no process-wide mutable state, and nothing is read from the process environment: what varies is an
+ *     argument (`flags` of the evaluation).  The few developer hooks (launch bracketing for benchmarks, a test switch of
+ *     the tree filter) are declared in boxinst_hip_dev.h, not here; the A/B knobs of tools/ exist only in a -DBXI_DEV
+ *     build.  One host thread per device is the expected use.
  *   - tensors are dense, row-major (NCHW like the reference), fp32 unless the name says _f64.
  */
 #ifndef BOXINST_HIP_H
@@ -36,7 +37,7 @@
 extern "C" {
 #endif
 
-#define BXI_ABI_VERSION 5
+#define BXI_ABI_VERSION 6
 #define BXI_MAX_IMAGES 64   /* images per call (per-image metadata travels in kernel arguments) */
 
 typedef enum bxi_status {
@@ -220,13 +221,36 @@ int bxi_boxinst_loss_backward_f32(const bxi_instances* inst_host, const float* g
  * batch_host->image_masks must be NULL (explicit masks: bxi_color_affinity_f32 + bxi_boxinst_loss_fwd_bwd_f32).
  * size == 3 and dilation <= 4 are built; others return BXI_ERR_UNSUPPORTED and the host composes section 1 + torch ops
  * as the reference does.  N == 0 writes two zeros (documented deviation; the reference yields NaN).
- * Strides other than 4 / unaligned canvases pool the image in launches of their own (same results, not the fast path). */
+ * Strides other than 4 / unaligned canvases pool the image in launches of their own (same results, not the fast path).
+ * The tag counter is 28 bits wide; the evaluation that draws its last value ends by returning the workspace to the all-zero state
+ * itself (its last workgroup, after every other wave has arrived and drained its stores), so no caller ever has to count evaluations.
+ * An ERROR return of an evaluation entry point after its first launch was enqueued (BXI_ERR_LAUNCH of a later launch) leaves a
+ * stream-ordered memset of the whole workspace behind it: the workspace is usable again without further ado. */
 size_t bxi_boxinst_eval_workspace_bytes(int B, int Hc, int Wc, int stride, int N);
 /* byte offset, inside `workspace`, of the Lab image the evaluation leaves behind: [B, Hc/stride, Wc/stride] x float4 (L, a, b, 0)
  * -- what skimage.color.rgb2lab gives at condinst_head.py:1413-1416; exposed so that tests can compare it with scikit-image. */
 size_t bxi_boxinst_eval_workspace_lab_offset(void);
 /* hipMemsetAsync(workspace, 0, workspace_bytes) on `stream`: the one-time initialisation described above. */
 int bxi_boxinst_eval_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
+/* The image side alone, AHEAD of the evaluation -- replaces the `self.get_targets(gt_bboxes, gt_masks, imgs, img_metas)` call at the
+ * top of CondInstMaskHead.loss (condinst_head.py:1298-1299; get_targets :1345-1393, get_bitmasks_from_boxes :1395-1448,
+ * get_image_color_similarity :220-246).  Its inputs -- the network input and the GT boxes -- exist before the backbone runs
+ * (mmdet/models/detectors/condinst.py:53 vs :73), so a caller can enqueue this on a side stream at the top of forward_train and take
+ * the image -> Lab -> colour predicates -> pair-count chain off the loss's critical path.  Leaves in `workspace` (the evaluation's own,
+ * same canvas, same size rules): Lab [B,h,w] float4, the predicate words [B,h,w], and PER GT BOX the count
+ *   sum over the box's pixels p and the 8 neighbours k of [sim_k(p) >= color_thresh]   (:1324-1325 for one instance of that box),
+ * so that the evaluation's normaliser sum W (:1327-1328) is a gather over gt_inds.  Two launches, no in-kernel wait (a kernel boundary
+ * in between): makes progress next to anything.  Then bxi_boxinst_eval_f32(..., flags | BXI_EVAL_TARGETS_READY, ...) on the SAME
+ * workspace, stream-ordered behind this call (same stream, or an event), with the same batch geometry / boxes / stride / window /
+ * threshold: it launches only the logit stream, the leaders, the tiles and the finisher, reads no image (batch_host->imgs may be NULL)
+ * and waits for nothing on the image side.  A digest of (canvas, stride, window, threshold, per image: shape, rows removed, box count) is
+ * kept with the targets and compared ON THE DEVICE by the evaluation: a mismatch, or targets overwritten by an evaluation without the flag
+ * (which computes its own), gives NaN losses and a non-zero status -- never a plausible wrong number.  Several evaluations may use one
+ * set of targets (a re-entrant backward).  At most 1024 GT boxes per batch and color_thresh > 0, else BXI_ERR_UNSUPPORTED (call the
+ * evaluation without the flag).  Results are bit-equal to the evaluation without the flag. */
+int bxi_boxinst_targets_f32(const bxi_image_batch* batch_host, const float* const* boxes_per_img_host, const int* gt_count_host,
+                            int stride, int size, int dilation, float color_thresh, void* workspace, size_t workspace_bytes, void* stream);
+
 /* `flags` of the two evaluation entry points.  The forms give the same bits (tests run them against each other). */
 #define BXI_EVAL_SINGLE_LAUNCH   1u   /* the single-launch form wherever it is built (stride-4 aligned canvases, dilation <= 2, threshold
                                          > 0), also where the library would not choose it (its stream workgroups, instances x ceil(h / 32),
@@ -235,13 +259,21 @@ int bxi_boxinst_eval_workspace_init(void* workspace, size_t workspace_bytes, voi
                                          makes progress whatever else occupies the device; the host side switches to it after an
                                          evaluation that reported a non-zero status                                                      */
 #define BXI_EVAL_NO_STAY_ON      4u   /* single launch without the stream workgroups staying on as tile workgroups                      */
-#define BXI_EVAL_TILE_ROWS_8     8u   /* 8-row tiles (two launches; the default is 4-row tiles)                                         */
+#define BXI_EVAL_TILE_ROWS_8     8u   /* 8-row tiles (two launches).  Default: 4-row tiles up to 95 instances, 8-row tiles from 96 on
+                                         (dilation <= 2)                                                                                */
 #define BXI_EVAL_SHARED_DEVICE  16u   /* other work (evaluations on other streams, collectives, other processes) may run on the device
                                          at the same time: nothing in the launch may hold execution slots while it waits for workgroups
                                          that come later in the grid (implies NO_STAY_ON).  The library does not guess this              */
+#define BXI_EVAL_PRED_IN_PAIR   32u   /* two launches, the colour predicates / pair counts / sum W in the SECOND one (the form of up to 95
+                                         instances)                                                                                      */
+#define BXI_EVAL_PRED_IN_PREP   64u   /* two launches, the image-only chain at the tail of the FIRST one, under its logit stream: the
+                                         second launch's tile waves wait for nobody (the form from 96 instances on).  In both two-launch
+                                         forms every in-kernel wait is for a workgroup EARLIER in its grid                               */
+#define BXI_EVAL_TARGETS_READY 128u   /* the image side is in the workspace already: bxi_boxinst_targets_f32 above                       */
+#define BXI_EVAL_TILE_ROWS_4   512u   /* 4-row tiles whatever the instance count                                                         */
 #define BXI_EVAL_WAITS_GIVE_UP 256u   /* TEST ONLY: every bounded in-kernel wait gives up at once, which makes the failure path
                                          observable (NaN losses, status word, poisoned gradient); zero the workspace afterwards          */
-#define BXI_EVAL_ALL_FLAGS (1u | 2u | 4u | 8u | 16u | 256u)
+#define BXI_EVAL_ALL_FLAGS (1u | 2u | 4u | 8u | 16u | 32u | 64u | 128u | 256u | 512u)
 int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host,
                          int size, int dilation, float color_thresh, float warmup,
                          const float* up_prj, const float* up_pw,

@@ -316,13 +316,16 @@ def test_single_launch_and_two_launch_forms_agree_bit_for_bit(dev):
     for d in cases:
         for dil in (1, 2, 3):
             res = []
-            for form in (1, 1 | 4, 2):       # the single launch wherever it is built (with / without the staying-on) / always two launches
+            # the single launch wherever it is built (with / without the staying-on) / two launches with the predicates in the second /
+            # two launches with the image-only chain folded into the first
+            for form in (1, 1 | 4, 2 | 32, 2 | 64):
                 with Fh.eval_flags(form):
                     res.append(hip_loss(d, dev, pairwise_dilation=dil))
-            a, a2, b = res
+            a, a2, b, c = res
             assert a[0] == a2[0] and a[1] == a2[1] and np.array_equal(a[2], a2[2]), dil
             assert a[0] == b[0] and a[1] == b[1], (dil, a[:2], b[:2])
             assert np.array_equal(a[2], b[2]), dil
+            assert a[0] == c[0] and a[1] == c[1] and np.array_equal(a[2], c[2]), (dil, a[:2], c[:2])
 
 
 def test_stream_with_a_cu_mask_takes_the_two_launch_form(dev):
@@ -451,6 +454,37 @@ def test_loss_vs_fp64_oracle(dev, cfg):
 
 def test_loss_cfg2_two_per_box(dev):
     _check(synthetic.cfg2(1, inst_per_box=2), dev)
+
+
+def test_loss_cfg2_four_per_box(dev):
+    """The shape real training runs: configs/boxinst/boxinst_r50_fpn_1x_coco.py:65 (topk_per_img=64) x :125 (samples_per_gpu=2) -> up to 128
+    instances per evaluation (condinst_head.py:1190-1225), at the full 2 x 800 x 1024 canvas.  Default flags: the library takes two
+    launches in the FOLDED form there -- the image-only chain (pool workgroups first, then, behind the logit stream, the predicate
+    workgroups and the reducer) inside the first launch, a second launch of leaders, 8-row tiles and the finisher that waits for
+    nothing on the image side.  Losses and gradient within 1e-4 of the C oracle, status 0."""
+    import ctypes as C
+    from boxinstseg_amd import _lib, functional as Fh
+    lib = _lib.load()
+    d = synthetic.cfg2(3, inst_per_box=4)
+    assert d['N'] == 128
+    names = []
+    cb = _lib.LAUNCH_HOOK(lambda name, phase, st, user: names.append(name.decode()))
+    lib.bxi_dev_set_launch_hook(C.cast(cb, C.c_void_p), None)
+    try:
+        _check(d, dev)
+    finally:
+        lib.bxi_dev_set_launch_hook(None, None)
+    assert 'prep_fold' in names and 'pair_tiles' in names and 'eval1' not in names and 'pair' not in names, names
+    assert Fh.last_eval_status() == (0, 8)
+    # ... the same bits with the predicates in the second launch (round 4's form) and with 4-row tiles in the folded form: the forms differ
+    # in where work runs, not in what is computed -- except the tile height, which changes the order of the float additions inside a tile
+    base = hip_loss(d, dev)
+    with Fh.eval_flags(_lib.EVAL_TWO_LAUNCHES | _lib.EVAL_PRED_IN_PAIR):
+        other = hip_loss(d, dev)
+    assert base[0] == other[0] and base[1] == other[1] and np.array_equal(base[2], other[2])
+    with Fh.eval_flags(_lib.EVAL_PRED_IN_PREP | _lib.EVAL_TILE_ROWS_4):
+        _check(d, dev)
+        assert Fh.last_eval_status() == (0, 4)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -583,7 +617,8 @@ def test_loss_many_instances(dev):
     _check_cfg(d, dev)
 
 
-@pytest.mark.parametrize('form', [1, 5, 2, 10], ids=['single_launch', 'single_launch_no_stay_on', 'two_launches', 'two_launches_8_row_tiles'])
+@pytest.mark.parametrize('form', [1, 5, 2 | 32, 10 | 32, 64, 64 | 8],
+                         ids=['single_launch', 'single_launch_no_stay_on', 'two_launches', 'two_launches_8_row_tiles', 'folded', 'folded_8_row_tiles'])
 def test_loss_every_form_against_the_oracle(dev, form):
     """Each form of the evaluation (the BXI_EVAL_* flags of the call) against the C oracle: the single launch also where the library
     would not choose it (300 instances: the stream workgroups alone exceed the GPU), two launches, and the 8-row tiles no default takes."""
@@ -777,6 +812,176 @@ def test_workspace_epoch_advances_once_per_evaluation_and_follows_the_workspace_
         assert sets[j]['state'][off:off + 4].view(torch.int32).item() == 0, j
         got = sets[j]['losses'].cpu().numpy()
         assert rel(float(got[0]), refs[j]['loss_prj']) <= TOL and rel(float(got[1]), refs[j]['loss_pairwise']) <= TOL, (j, got)
+
+
+# ---------------------------------------------------------------------------------------------
+# targets ahead of the evaluation (bxi_boxinst_targets_f32 + BXI_EVAL_TARGETS_READY)
+# ---------------------------------------------------------------------------------------------
+def _loss_with_targets(d, dev, stream=None, **kw):
+    from boxinstseg_amd import boxinst_mask_loss, functional as Fh
+    Fh.DEBUG_KEEP_LAST = True
+    t = to_dev(d, dev)
+    tg = Fh.prepare_targets(t['imgs'], d['img_metas'], t['gt_bboxes'], out_stride=d['stride'], stream=stream,
+                            **{k: v for k, v in kw.items() if k in ('pairwise_dilation', 'pairwise_color_thresh', 'bottom_pixels_removed')})
+    assert tg is not None
+    x = t['logits'].clone().requires_grad_(True)
+    out = boxinst_mask_loss(x, t['gt_inds'], t['gt_bboxes'], imgs=t['imgs'], img_metas=d['img_metas'], out_stride=d['stride'], targets=tg, **kw)
+    (out['loss_prj'] + out['loss_pairwise']).backward()
+    torch.cuda.synchronize()
+    return float(out['loss_prj'].detach()), float(out['loss_pairwise'].detach()), x.grad.cpu().numpy()[:, 0]
+
+
+@pytest.mark.parametrize('form', [0, 2], ids=['form_auto', 'form_two_launches'])
+def test_targets_ahead_give_the_fused_evaluation_bit_for_bit(dev, form):
+    """bxi_boxinst_targets_f32 (Lab, predicate words, per-box pair counts into the workspace; condinst_head.py:1298-1299 computes the same
+    targets from imgs + gt_bboxes alone) followed by the evaluation with BXI_EVAL_TARGETS_READY -- only the logit stream, leaders, tiles and
+    finisher are launched, sum W is a gather over gt_inds -- must give the bits of the evaluation that computes the image side itself:
+    cfg-1, cfg-2 (32 and 128 instances), a ragged batch with two instances per box, an image without boxes, dilations 1 and 3, and with
+    the targets computed on a side stream."""
+    import ctypes as C
+    from boxinstseg_amd import _lib, functional as Fh
+    lib = _lib.load()
+    ragged = synthetic.make_batch(B=2, H=96, W=160, boxes_per_img=3, inst_per_box=2, seed=7, img_shapes=[(96, 131), (70, 160)],
+                                  ori_shapes=[(48, 66), (210, 480)], min_box=16, max_box=80)
+    empty = synthetic.make_batch(B=2, H=64, W=64, boxes_per_img=2, seed=9, min_box=16, max_box=40)
+    empty['gt_bboxes'][0] = np.zeros((0, 4), np.float32)
+    empty['gt_inds'] = np.array([0, 1, 1], np.int64)
+    empty['mask_logits'] = empty['mask_logits'][:3]
+    side = torch.cuda.Stream(device=dev)
+    cases = [(synthetic.cfg1(3), {}, None), (synthetic.cfg2(1), {}, None), (synthetic.cfg2(2, inst_per_box=4), {}, side), (ragged, {}, side), (empty, {}, None),
+             (ragged, dict(pairwise_dilation=1), None), (synthetic.cfg1(5), dict(pairwise_dilation=3, pairwise_color_thresh=0.5), None)]
+    for d, kw, stream in cases:
+        with Fh.eval_flags(form):
+            want = hip_loss(d, dev, **kw)
+            names = []
+            cb = _lib.LAUNCH_HOOK(lambda name, phase, st, user: names.append(name.decode()))
+            lib.bxi_dev_set_launch_hook(C.cast(cb, C.c_void_p), None)
+            try:
+                got = _loss_with_targets(d, dev, stream=stream, **kw)
+            finally:
+                lib.bxi_dev_set_launch_hook(None, None)
+        assert 'targets_pool' in names and 'targets_pred' in names, names
+        assert ('eval1_ready' in names) or ('prep_ready' in names and 'pair_tiles' in names), names      # no image role was launched by the evaluation
+        assert Fh.last_eval_status()[0] == 0
+        assert got[0] == want[0] and got[1] == want[1], (d['N'], kw, got[:2], want[:2])
+        assert np.array_equal(got[2], want[2]), (d['N'], kw)
+
+
+def test_targets_through_the_module_api_and_stale_targets_are_ignored(dev):
+    """CondInstMaskHead.prepare_targets(imgs, img_metas, gt_bboxes) at the top of an iteration, loss() later: same bits as loss() alone; targets
+    prepared for ANOTHER batch are not used (the evaluation computes its own); the iteration counter ramps as without them."""
+    from boxinstseg_amd import CondInstMaskHead
+    d, d2 = synthetic.cfg1(0), synthetic.cfg1(1)
+    t, t2 = to_dev(d, dev), to_dev(d2, dev)
+    outs = []
+    for prepare in (None, 'own', 'other'):
+        head = CondInstMaskHead(in_channels=16, boxinst_enabled=True, topk_per_img=64, max_proposals=-1).to(dev)
+        head._iter.fill_(4321.0)
+        if prepare == 'own':
+            assert head.prepare_targets(t['imgs'], d['img_metas'], t['gt_bboxes'], stream=torch.cuda.Stream(device=dev))
+        elif prepare == 'other':
+            assert head.prepare_targets(t2['imgs'], d2['img_metas'], t2['gt_bboxes'])
+        x = t['logits'].clone().requires_grad_(True)
+        out = head.loss(t['imgs'], d['img_metas'], x, t['gt_inds'], t['gt_bboxes'], None, None)
+        (out['loss_prj'] + out['loss_pairwise']).backward()
+        torch.cuda.synchronize()
+        assert float(head._iter) == 4322.0
+        outs.append((float(out['loss_prj']), float(out['loss_pairwise']), x.grad.cpu().numpy()))
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and o[1] == outs[0][1] and np.array_equal(o[2], outs[0][2])
+
+
+def test_targets_that_do_not_belong_to_the_evaluation_are_loud(dev):
+    """At the C ABI: BXI_EVAL_TARGETS_READY on a workspace whose targets were computed for another threshold, or were overwritten by an
+    evaluation that computed its own, or were never computed: the digest kept with the targets does not match -> NaN losses, status != 0,
+    never a plausible number.  After bxi_boxinst_targets_f32 with the right arguments: the fused evaluation's bits, twice (targets serve
+    several evaluations)."""
+    import ctypes as C
+    import math
+    from boxinstseg_amd import _lib, functional as Fh
+    lib = _lib.load()
+    d = synthetic.make_batch(B=2, H=128, W=192, boxes_per_img=4, inst_per_box=2, seed=77, min_box=16, max_box=120)
+    b = _abi_eval_setup(d, dev, lib, Fh, 0)
+    b['inst'].struct.iter_counter = 0
+    st = torch.cuda.current_stream(dev).cuda_stream
+    off = lib.bxi_boxinst_loss_state_status_offset(b['inst'].N, b['inst'].h, b['inst'].w)
+    boxes = b['inst']
+
+    def ev(flags, thresh=0.3):
+        rc = lib.bxi_boxinst_eval_f32(C.byref(b['batch'].struct), C.byref(b['inst'].struct), 3, 2, thresh, 1.0, None, None, b['losses'].data_ptr(),
+                                      b['grad'].data_ptr(), b['state'].data_ptr(), b['ws'].data_ptr(), b['ws'].numel(), flags, st)
+        assert rc == 0, _lib.status_string(rc)
+        torch.cuda.synchronize()
+        return b['losses'].cpu().numpy().copy(), b['grad'].cpu().numpy().copy(), int(b['state'][off:off + 4].view(torch.int32).item())
+
+    def targets(thresh=0.3):
+        rc = lib.bxi_boxinst_targets_f32(C.byref(b['batch'].struct), boxes.struct.boxes_per_img_host, boxes.struct.gt_count_host, d['stride'], 3, 2, thresh,
+                                         b['ws'].data_ptr(), b['ws'].numel(), st)
+        assert rc == 0, _lib.status_string(rc)
+
+    want = ev(0)
+    assert want[2] == 0
+    for form in (0, _lib.EVAL_TWO_LAUNCHES):
+        got = ev(_lib.EVAL_TARGETS_READY | form)                    # never computed (the fused evaluation above cleared the digest)
+        assert got[2] != 0 and math.isnan(got[0][0]) and math.isnan(got[0][1]), got
+        b['ws'].zero_()
+        targets(0.5)
+        got = ev(_lib.EVAL_TARGETS_READY | form)                    # another threshold
+        assert got[2] != 0 and math.isnan(got[0][0])
+        b['ws'].zero_()
+        targets()
+        for _ in range(2):
+            got = ev(_lib.EVAL_TARGETS_READY | form)
+            assert got[2] == 0 and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        ev(form)                                                    # computes its own targets: the prepared ones are gone
+        got = ev(_lib.EVAL_TARGETS_READY | form)
+        assert got[2] != 0 and math.isnan(got[0][0])
+        b['ws'].zero_()
+    # refusals: a threshold <= 0 (every pair weighs 1: nothing of the image is needed ahead), the flag together with a predicate placement
+    assert lib.bxi_boxinst_targets_f32(C.byref(b['batch'].struct), boxes.struct.boxes_per_img_host, boxes.struct.gt_count_host, d['stride'], 3, 2, 0.0,
+                                       b['ws'].data_ptr(), b['ws'].numel(), st) == _lib.BXI_ERR_UNSUPPORTED
+    assert lib.bxi_boxinst_eval_f32(C.byref(b['batch'].struct), C.byref(b['inst'].struct), 3, 2, 0.3, 1.0, None, None, b['losses'].data_ptr(),
+                                    b['grad'].data_ptr(), b['state'].data_ptr(), b['ws'].data_ptr(), b['ws'].numel(),
+                                    _lib.EVAL_TARGETS_READY | _lib.EVAL_PRED_IN_PREP, st) == -3
+
+
+def test_tag_counter_wraps_by_zeroing_the_workspace(dev):
+    """The evaluation's tag is 28 bits.  The evaluation that draws the last value (2^28 - 1) ends by returning the workspace to the all-zero
+    state on the device (finisher, after every other wave has arrived with its stores drained), so records of 2^28 evaluations ago can
+    never pass for fresh ones and no caller has to count: the epoch word is preset to 2^28 - 4 on a zeroed workspace, then eight evaluations
+    of alternating instance counts and forms -- every one within 1e-4 of the oracle with status 0, the epoch word reading 2^28 - 3,
+    2^28 - 2, 0 (wrapped: all of the workspace zero), 1, 2, ..."""
+    import ctypes as C
+    from boxinstseg_amd import _lib, functional as Fh
+    lib = _lib.load()
+    ds = [synthetic.make_batch(B=2, H=128, W=192, boxes_per_img=4, inst_per_box=k, seed=600 + k, min_box=16, max_box=120) for k in (3, 1, 2)]
+    refs = [oracle_path(d, want_targets=False) for d in ds]
+    ws = torch.zeros(lib.bxi_boxinst_eval_workspace_bytes(2, 128, 192, 4, 24), dtype=torch.uint8, device=dev)
+    top = (1 << 28) - 1
+    ws[:4].view(torch.int32).fill_(top - 3)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    forms = [0, _lib.EVAL_TWO_LAUNCHES | _lib.EVAL_PRED_IN_PAIR, 0, _lib.EVAL_PRED_IN_PREP, 0, _lib.EVAL_TWO_LAUNCHES, 0, _lib.EVAL_PRED_IN_PREP]
+    expect_epoch = [top - 2, top - 1, 0, 1, 2, 3, 4, 5]
+    for k in range(8):
+        d, ref = ds[k % 3], refs[k % 3]
+        t = to_dev(d, dev)
+        batch = Fh._Batch(t['imgs'], d['img_metas'], 10)
+        inst = Fh._Inst(t['logits'], t['gt_inds'], t['gt_bboxes'], d['H'], d['W'], d['stride'])
+        losses, grad = torch.zeros(2, device=dev), torch.empty_like(inst.logits)
+        state = torch.empty(lib.bxi_boxinst_loss_state_bytes(inst.N, inst.h, inst.w), dtype=torch.uint8, device=dev)
+        rc = lib.bxi_boxinst_eval_f32(C.byref(batch.struct), C.byref(inst.struct), 3, 2, 0.3, 1.0, None, None, losses.data_ptr(), grad.data_ptr(),
+                                      state.data_ptr(), ws.data_ptr(), ws.numel(), forms[k], st)
+        assert rc == 0, _lib.status_string(rc)
+        torch.cuda.synchronize()
+        assert int(ws[:4].view(torch.int32).item()) == expect_epoch[k], (k, int(ws[:4].view(torch.int32).item()))
+        if expect_epoch[k] == 0:
+            assert int(ws.view(torch.int32).ne(0).sum().item()) == 0, 'the wrap leaves the workspace all zero'
+        off = lib.bxi_boxinst_loss_state_status_offset(inst.N, inst.h, inst.w)
+        assert state[off:off + 4].view(torch.int32).item() == 0, k
+        got = losses.cpu().numpy()
+        assert rel(float(got[0]), ref['loss_prj']) <= TOL and rel(float(got[1]), ref['loss_pairwise']) <= TOL, (k, got, ref['loss_prj'], ref['loss_pairwise'])
+        err, _ = grad_report(grad.cpu().numpy()[:, 0], ref['grad'], d['mask_logits'][:, 0])
+        assert err <= TOL, (k, err)
 
 
 # ---------------------------------------------------------------------------------------------
