@@ -66,7 +66,8 @@ constexpr unsigned kFlagSingle = 1u, kFlagTwo = 2u, kFlagNoStay = 4u, kFlagRows8
                    kFlagTargetsReady = 128u, kFlagGiveUp = 256u, kFlagRows4 = 512u;
 constexpr int kBoxCap = 1024;                   // GT boxes per batch bxi_boxinst_targets_f32 keeps pair counts for
 constexpr int kBoxSplit = 8;                    // count words per box (each in its own 128 bytes): arrivals on one word are performed one after the other
-constexpr int kFoldFrom = 96;                   // two launches: from this many instances on the image-only chain (predicates, counts, sum W) runs at the
+constexpr int kLongFrom = 96;                   // single launch, long form (8-row tiles) from this many instances on
+constexpr int kFoldFrom = 1 << 30;                   // two launches: from this many instances on the image-only chain (predicates, counts, sum W) runs at the
                                                 // tail of the FIRST launch, under its logit stream (fewer: in the second, as in round 4)
 constexpr unsigned int kMaxTag = 0x0fffffffu;   // tags are 28 bits (a predicate word is tag << 4 | bits)
 constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
@@ -1539,7 +1540,8 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, i
     int role = 0, idx = blk;                              // 0 table, 1 pool, 2 stream, 3 predicate, 4 reducer
     if (blk >= n_tab) {
         idx = blk - n_tab;
-        const int n_a = pool_first ? n_pool : n_stream, n_b = pool_first ? n_stream : n_pool;
+        constexpr bool pool_first = R == 8;                      // the long form (a run-time switch here costs the short form a stack slot)
+    const int n_a = pool_first ? n_pool : n_stream, n_b = pool_first ? n_stream : n_pool;
         if (idx < n_a) role = pool_first ? 1 : 2;
         else if ((idx -= n_a) < n_b) role = pool_first ? 2 : 1;
         else if ((idx -= n_b) < tl.n_pb) role = 3;
@@ -1580,7 +1582,7 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 2 ? 4 : 3) : (D <= 2 ? 3 : 2))
     __shared__ float red[16];
     const int blk = (int)blockIdx.x;
     const int N = a.N;
-    if (blk < n_pb) {                                                  // ---- predicate waves: first in the grid, everybody asks for their words
+    if (blk < n_pb) {                                                // ---- predicate waves: first in the grid, everybody asks for their words
         if (zero_bit) return;                                          // every pair weighs 1: sum W has a closed form, the tiles take the log-space path
         pred_role<false>(a, vc, ws_in /* no tag yet: it comes with the wave's first loads (pred_item) */, D, n2max, blk, n_pb, n_items, spin_limit);
         return;
@@ -1615,11 +1617,15 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 2 ? 4 : 3) : (D <= 2 ? 3 : 2))
 // headline size the table + stream + pool workgroups fill the GPU once, and the back half flows into the slots they leave -- the
 // kernel boundary of the two-launch form (~2.2 us) is gone.  The two-launch form stays for 8-row tiles (> 96 instances: 2
 // workgroups per CU would starve the front half), dilation 4, the head-fused first launch and the generic pooling path.
-template <int D>
-__global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_pool, int n_items, int n_pb, int n_tb, InstArgs a, Ws ws_in, LossState st, ValidCells vc,
+// R = 8 ("the long form", three workgroups per CU): the same grid for MANY instances.  With 4-row tiles 128 instances are ~4600 tiles on at most
+// half the slots' waves -- every tile wave then walks two or three tiles, each a ~7 us dependent chain, one after the other (45 us per
+// evaluation).  8-row tiles are ~2300, one per wave, and the whole back half runs while the front half still streams: no kernel boundary,
+// the tile waves' arithmetic under the logit stream.  Nothing here waits for a workgroup LATER in the grid (no staying-on: `merge` = 0),
+// so the form makes progress at any residency; the pool workgroups go first (`pool_first`), the image side being the longer chain.
+template <int D, int R>
+__global__ __launch_bounds__(256, (R == 4 ? kOneOcc : 3)) void eval1_kernel(PoolArgs pa, int n_pool, int n_items, int n_pb, int n_tb, InstArgs a, Ws ws_in, LossState st, ValidCells vc,
                                                         const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup, float n2max, int spin_limit,
                                                         float* __restrict__ losses, float* __restrict__ g_logits, int vec, int merge, int ready, unsigned int key) {
-    constexpr int R = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[16];
     Ws ws = ws_in;
@@ -1630,15 +1636,18 @@ __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_
     const int blk = (int)blockIdx.x;
     // role of this workgroup: 0 stream, 1 pool, 2 leader, 3 predicate, 4 tile, 5 finisher, 6 reducer
     int role, idx = blk;
-    if (idx < n_stream) role = 0;
-    else if ((idx -= n_stream) < n_pool) role = 1;
-    else if ((idx -= n_pool) < n_pb) role = 3;
+    constexpr bool pool_first = R == 8;                      // the long form (a run-time switch here costs the short form a stack slot)
+    const int n_a = pool_first ? n_pool : n_stream, n_b = pool_first ? n_stream : n_pool;      // grid: [stream][pool] or [pool][stream], then the back half
+    if (idx < n_a) role = pool_first ? 1 : 0;
+    else if ((idx -= n_a) < n_b) role = pool_first ? 0 : 1;
+    else if ((idx -= n_b) < n_pb) role = 3;
     else if ((idx -= n_pb) < 1) role = 6;                              // the reducer
     else if ((idx -= 1) < N) role = 2;
     else if ((idx -= N) < n_tb) role = 4;
     else role = 5;
     const int tix = (n_tab + (role == 0 ? idx : n_stream + idx)) * kWaves + (int)(threadIdx.x >> 6);
     (void)tix;
+    bool stayed = false;
     if (role == 0) {
         BXI_TW(0, tix, 0);
         // the table is the first duty of the first stream workgroups' first waves (wave k of the table in workgroup k): a workgroup
@@ -1657,6 +1666,7 @@ __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_
         // predicate workgroup always finds a slot.)
         __syncthreads();                                                   // the column-partial LDS becomes the tile waves' scratch
         role = 4;
+        stayed = true;
         idx -= n_stream;                                                   // tile workgroup index idx + n_stream below
     }
     if (role == 1) {
@@ -1669,7 +1679,7 @@ __global__ __launch_bounds__(256, kOneOcc) void eval1_kernel(PoolArgs pa, int n_
         return;
     }
     // (a stream workgroup that stays on has its tag already; predicate waves and leaders get it with their first poll)
-    if (blk >= n_stream && role != 3 && role != 2) ws = with_tag(ws);
+    if (!stayed && role != 3 && role != 2) ws = with_tag(ws);
     const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
     if (role == 2) {
         BXI_TW(3, 1 + idx, 0);
@@ -2059,7 +2069,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     const int env_pool_first = BXI_KNOB("BXI_POOL_FIRST", 0);
     const int env_pool_wgs = BXI_KNOB("BXI_POOL_WGS_PER_CU", 5);
     const int force_rows = (flags & kFlagRows8) ? 8 : ((flags & kFlagRows4) ? 4 : env_rows);
-    const int R = force_rows == 4 || force_rows == 8 ? force_rows : ((flags & kFlagSingle) ? 4 : tile_rows_for(a.N, dil));
+    const int R = force_rows == 4 || force_rows == 8 ? force_rows : tile_rows_for(a.N, dil);
     if (eval_cap(a.N, a.h, a.w, dil, R) >= (1 << 24)) return BXI_ERR_BAD_SHAPE;     // the table packs a tile prefix into 24 bits
     const HostPred pr = host_pred(color_thresh);
     if (ready && pr.zero_bit) return BXI_ERR_UNSUPPORTED;       // (bxi_boxinst_targets_f32 refuses thresholds <= 0 as well)
@@ -2078,12 +2088,24 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     const int one_slots = kOneOcc * device_cus();
     const bool one_fits = 2 * (int64_t)a.N * ((a.h + kSBlk - 1) / kSBlk) <= one_slots && stream_cus(s, device_cus()) >= device_cus();
     // (built for dilation <= 2: the single launch needs four workgroups per CU, and at dilation 3 the tile role does not fit 128 VGPRs)
-    if (env_one && !(flags & (kFlagTwo | kFlagPredInPair | kFlagPredInPrep)) && (one_fits || env_one == 2 || (flags & kFlagSingle)) && !head && pooled_in_launch &&
-        R == 4 && dil <= 2 && !pr.zero_bit) {
+    // Two shapes of the single launch: the SHORT form (4-row tiles, four workgroups per CU, the stream workgroups staying on as the first tile
+    // workgroups) while its front half is resident at once; the LONG form (8-row tiles, three per CU, pool workgroups first, nobody waits for a
+    // later workgroup) for many instances, where the short form's tile waves would each walk several tiles one after the other.
+    const bool whole_device = stream_cus(s, device_cus()) >= device_cus();
+    // Measured (2 x 800 x 1024, us per evaluation, one box): 128 instances long form 36.9 vs two launches 37.1, 96: 32.3 vs 31.6 -- no gain
+    // (three workgroups per CU slow the front half down by what the kernel boundary costs), so the library takes the long form only where it
+    // is asked to (BXI_EVAL_SINGLE_LAUNCH with 8-row tiles) and, with the targets ready (no front half to slow down), from kLongFrom on.
+    // With the targets ready and fewer instances two launches win over the short form (14.6 vs 15.1 at 32, 19.1 vs 19.9 at 64).
+    // (Measured and dropped: a second launch that reads its predicate words by plain loads ahead of the logits and has sum W up front --
+    // 14.85 vs 14.65 at 32 instances, 31.9 vs 31.0 at 128: the tile role is bound by its arithmetic and memory pipeline, not by that hop.)
+    const bool long_form = R == 8 && dil <= 2 && ((flags & kFlagSingle) || (ready && a.N >= BXI_KNOB("BXI_LONG_FROM", kLongFrom) && whole_device && !(flags & kFlagShared)));
+    const bool short_ok = one_fits && !(ready && BXI_KNOB("BXI_READY_TWO", 1));
+    if (env_one && !(flags & (kFlagTwo | kFlagPredInPair | kFlagPredInPrep)) && (short_ok || env_one == 2 || (flags & kFlagSingle) || long_form) && !head && pooled_in_launch &&
+        (R == 4 || long_form) && dil <= 2 && !pr.zero_bit) {
         const int env_one_pool = BXI_KNOB("BXI_ONE_POOL_WGS", 0);
         const int Sn = (a.h + kSBlk - 1) / kSBlk;
         const int n_stream = a.N * Sn;
-        const int slots = one_slots;
+        const int slots = long_form ? 3 * device_cus() : one_slots;
         // the front half (table, stream, pool) should fill the GPU exactly once: a pool workgroup takes several items
         // (measured and dropped: pool workgroups alone filling the GPU first, predicate and stream workgroups behind them -- the
         // stream workgroups, and with them the band flags and the leaders, then end 8 us late: 22.9 us per evaluation against 18.3)
@@ -2091,12 +2113,15 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         // first: 18.0 / 18.3 / 20.3 us against 17.96; pool workgroups of one item each: 18.3)
         const int front = slots - n_stream;
         const int room = env_one_pool > 0 ? env_one_pool : (front > slots / 4 ? front : slots / 4);
-        const int per = (n_items + room - 1) / room;
+        int per = (n_items + room - 1) / room;
+        if (long_form && per > 2) per = 2;        // (never more than two items per pool workgroup: launch_fused_eval's first launch below)
         const int n_pool = ready ? 0 : (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per);
         int n_pb = ready ? 0 : (n_items + kWaves - 1) / kWaves;
         if (n_pb > slots / 2) n_pb = slots / 2;
         int64_t n_tb = (eval_cap(a.N, a.h, a.w, dil, R) + kWaves - 1) / kWaves;
-        if (n_tb > slots / 2) n_tb = slots / 2;
+        // (the short form leaves half of the slots to the workgroups its staying-on stream workgroups wait for; the long form has no such wait:
+        // one tile per wave while the slots last)
+        if (n_tb > (long_form ? slots : slots / 2)) n_tb = long_form ? slots : slots / 2;
         // the stream workgroups stay on as the first tile workgroups (only while they leave half of the slots to the rest of the grid)
         // ... unless evaluations run on SEVERAL streams at once: each would hold its stream workgroups' slots while waiting, and three
         // or four of them leave no room for anybody's pool workgroups (measured: 2.4 ms per evaluation with four streams in flight,
@@ -2104,7 +2129,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         // says so (BXI_EVAL_SHARED_DEVICE / BXI_EVAL_NO_STAY_ON; boxinstseg_amd/functional.py sets it once a second stream has been
         // seen on the device).  A launch that is being captured into a graph may be replayed next to anything: no staying-on either.
         const int env_merge = BXI_KNOB("BXI_ONE_MERGE", 1);
-        const int merge = env_merge && one_fits && !(flags & (kFlagNoStay | kFlagShared)) && !stream_is_capturing(s) ? 1 : 0;
+        const int merge = env_merge && !long_form && one_fits && !(flags & (kFlagNoStay | kFlagShared)) && !stream_is_capturing(s) ? 1 : 0;
         if (merge) n_tb = n_tb > n_stream ? n_tb - n_stream : 0;
         size_t lds = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
         if (lds < 8 * (size_t)kWaves * a.w) lds = 8 * (size_t)kWaves * a.w;
@@ -2114,8 +2139,12 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
             const unsigned grid = (unsigned)(n_stream + n_pool + n_pb + 1 + a.N + (int)n_tb + 1);
 #define BXI_ONE_CASE(DD)                                                                                                                    \
             case DD:                                                                                                                        \
-                BXI_LAUNCH(ready ? "eval1_ready" : "eval1", s, (eval1_kernel<DD>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, up_prj, \
-                           up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge, ready, key);                                 \
+                if (long_form)                                                                                                              \
+                    BXI_LAUNCH(ready ? "eval1_ready" : "eval1", s, (eval1_kernel<DD, 8>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, \
+                               up_prj, up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge, ready, key);          \
+                else                                                                                                                        \
+                    BXI_LAUNCH(ready ? "eval1_ready" : "eval1", s, (eval1_kernel<DD, 4>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, \
+                               up_prj, up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge, ready, key);          \
                 break;
             switch (dil) { BXI_ONE_CASE(1) BXI_ONE_CASE(2) default: return BXI_ERR_UNSUPPORTED; }
 #undef BXI_ONE_CASE

@@ -458,10 +458,11 @@ def test_loss_cfg2_two_per_box(dev):
 
 def test_loss_cfg2_four_per_box(dev):
     """The shape real training runs: configs/boxinst/boxinst_r50_fpn_1x_coco.py:65 (topk_per_img=64) x :125 (samples_per_gpu=2) -> up to 128
-    instances per evaluation (condinst_head.py:1190-1225), at the full 2 x 800 x 1024 canvas.  Default flags: the library takes two
-    launches in the FOLDED form there -- the image-only chain (pool workgroups first, then, behind the logit stream, the predicate
-    workgroups and the reducer) inside the first launch, a second launch of leaders, 8-row tiles and the finisher that waits for
-    nothing on the image side.  Losses and gradient within 1e-4 of the C oracle, status 0."""
+    instances per evaluation (condinst_head.py:1190-1225), at the full 2 x 800 x 1024 canvas.  Default flags: two launches there, the
+    first with its pool workgroups ahead of the stream workgroups (the launch exceeds the execution slots), the second with 8-row tiles
+    at three workgroups per CU.  Losses and gradient within 1e-4 of the C oracle, status 0; and the other forms built for this size --
+    the FOLDED two launches (image-only chain at the tail of the first launch, a second launch that waits for nothing on the image
+    side) and the LONG single launch (8-row tiles, pool workgroups first) -- give the same bits."""
     import ctypes as C
     from boxinstseg_amd import _lib, functional as Fh
     lib = _lib.load()
@@ -474,14 +475,22 @@ def test_loss_cfg2_four_per_box(dev):
         _check(d, dev)
     finally:
         lib.bxi_dev_set_launch_hook(None, None)
-    assert 'prep_fold' in names and 'pair_tiles' in names and 'eval1' not in names and 'pair' not in names, names
+    assert 'prep' in names and 'pair' in names and 'eval1' not in names, names
     assert Fh.last_eval_status() == (0, 8)
-    # ... the same bits with the predicates in the second launch (round 4's form) and with 4-row tiles in the folded form: the forms differ
-    # in where work runs, not in what is computed -- except the tile height, which changes the order of the float additions inside a tile
+    # the forms differ in where work runs, not in what is computed -- except the tile height, which changes the order of the float
+    # additions inside a tile (4-row tiles: against the oracle)
     base = hip_loss(d, dev)
-    with Fh.eval_flags(_lib.EVAL_TWO_LAUNCHES | _lib.EVAL_PRED_IN_PAIR):
-        other = hip_loss(d, dev)
-    assert base[0] == other[0] and base[1] == other[1] and np.array_equal(base[2], other[2])
+    for form, kernels in ((_lib.EVAL_PRED_IN_PREP, ('prep_fold', 'pair_tiles')), (_lib.EVAL_SINGLE_LAUNCH | _lib.EVAL_TILE_ROWS_8, ('eval1',))):
+        names.clear()
+        lib.bxi_dev_set_launch_hook(C.cast(cb, C.c_void_p), None)
+        try:
+            with Fh.eval_flags(form):
+                other = hip_loss(d, dev)
+        finally:
+            lib.bxi_dev_set_launch_hook(None, None)
+        assert set(kernels) <= set(names), (form, names)
+        assert Fh.last_eval_status() == (0, 8)
+        assert base[0] == other[0] and base[1] == other[1] and np.array_equal(base[2], other[2]), form
     with Fh.eval_flags(_lib.EVAL_PRED_IN_PREP | _lib.EVAL_TILE_ROWS_4):
         _check(d, dev)
         assert Fh.last_eval_status() == (0, 4)
@@ -617,8 +626,9 @@ def test_loss_many_instances(dev):
     _check_cfg(d, dev)
 
 
-@pytest.mark.parametrize('form', [1, 5, 2 | 32, 10 | 32, 64, 64 | 8],
-                         ids=['single_launch', 'single_launch_no_stay_on', 'two_launches', 'two_launches_8_row_tiles', 'folded', 'folded_8_row_tiles'])
+@pytest.mark.parametrize('form', [1, 5, 2 | 32, 10 | 32, 64, 64 | 8, 1 | 8],
+                         ids=['single_launch', 'single_launch_no_stay_on', 'two_launches', 'two_launches_8_row_tiles', 'folded', 'folded_8_row_tiles',
+                              'single_launch_long'])
 def test_loss_every_form_against_the_oracle(dev, form):
     """Each form of the evaluation (the BXI_EVAL_* flags of the call) against the C oracle: the single launch also where the library
     would not choose it (300 instances: the stream workgroups alone exceed the GPU), two launches, and the 8-row tiles no default takes."""

@@ -44,7 +44,10 @@ def main():
              'fold_r4': L.EVAL_PRED_IN_PREP | L.EVAL_TILE_ROWS_4, 'fold_r8': L.EVAL_PRED_IN_PREP | L.EVAL_TILE_ROWS_8,
              'pair_r4': L.EVAL_TWO_LAUNCHES | L.EVAL_PRED_IN_PAIR | L.EVAL_TILE_ROWS_4,
              'ready': L.EVAL_TARGETS_READY, 'ready_two': L.EVAL_TARGETS_READY | L.EVAL_TWO_LAUNCHES,
-             'ready_two_r4': L.EVAL_TARGETS_READY | L.EVAL_TWO_LAUNCHES | L.EVAL_TILE_ROWS_4, 'targets_only': -1}
+             'ready_two_r4': L.EVAL_TARGETS_READY | L.EVAL_TWO_LAUNCHES | L.EVAL_TILE_ROWS_4, 'targets_only': -1,
+             'ready_single': L.EVAL_TARGETS_READY | L.EVAL_SINGLE_LAUNCH, 'ready_single_nostay': L.EVAL_TARGETS_READY | L.EVAL_SINGLE_LAUNCH | L.EVAL_NO_STAY_ON,
+             'single_any': L.EVAL_SINGLE_LAUNCH, 'long': L.EVAL_SINGLE_LAUNCH | L.EVAL_TILE_ROWS_8,
+             'ready_long': L.EVAL_TARGETS_READY | L.EVAL_SINGLE_LAUNCH | L.EVAL_TILE_ROWS_8}
     if args.forms:
         forms = {k: v for k, v in forms.items() if k in args.forms.split(',')}
     out = {}
@@ -87,7 +90,7 @@ def main():
         status = {}
         for rep in range(args.reps):
             for name, form in forms.items():
-                if (form >= 0) and (form & L.EVAL_SINGLE_LAUNCH) and N > 70:
+                if (form >= 0) and name == 'single' and N > 70:
                     continue
                 res[name].append(round(timed(form), 2))
                 if form >= 0:
