@@ -1540,8 +1540,7 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, i
     int role = 0, idx = blk;                              // 0 table, 1 pool, 2 stream, 3 predicate, 4 reducer
     if (blk >= n_tab) {
         idx = blk - n_tab;
-        constexpr bool pool_first = R == 8;                      // the long form (a run-time switch here costs the short form a stack slot)
-    const int n_a = pool_first ? n_pool : n_stream, n_b = pool_first ? n_stream : n_pool;
+        const int n_a = pool_first ? n_pool : n_stream, n_b = pool_first ? n_stream : n_pool;
         if (idx < n_a) role = pool_first ? 1 : 2;
         else if ((idx -= n_a) < n_b) role = pool_first ? 2 : 1;
         else if ((idx -= n_b) < tl.n_pb) role = 3;
