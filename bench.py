@@ -408,8 +408,12 @@ def worker(args):
                                                      'sequence behind loss() + backward() when the upstream factors are only '
                                                      'known at backward time'}
         result['extras'] = {}
+        try:
+            result['extras'].update(targets_ahead(lib, _lib, sets, dev, stream, n_extra))
+        except Exception as e:
+            result['extras']['targets_ahead_error'] = f'{type(e).__name__}: {e}'[:300]
         for ipb in (2, 4):           # the shape real training runs: topk_per_img=64 x samples_per_gpu=2 -> up to 128 instances per evaluation
-            result['extras'][f'n{32 * ipb}'] = instance_count_extra(lib, _lib, Fh, synthetic, dev, stream, ones, ipb, args.flags)
+            result['extras'][f'n{32 * ipb}'] = instance_count_extra(lib, _lib, Fh, synthetic, dev, stream, ones, ipb, args.flags, gate=not args.no_cpu_baseline)
         result['extras'].update(rows_extra())
         result['head_fused_extra'] = head_fused(lib, Fh, sets, dev, stream, n_extra)
         result['module_api'] = module_api(sets, dev, 300)
@@ -476,7 +480,7 @@ def speed_of_light(lib, sets, dev, stream, steps, warmup):
                     'no in-grid dependency; same cold sets, timed like `value` (launch boundary included)'}
 
 
-def instance_count_extra(lib, _lib, Fh, synthetic, dev, stream, ones, inst_per_box, flags, n_sets=6, steps=400):
+def instance_count_extra(lib, _lib, Fh, synthetic, dev, stream, ones, inst_per_box, flags, n_sets=6, steps=400, gate=True):
     """Extra (not `value`): the same evaluation with 2 / 4 instances per box -- N = 64 / 128, what configs/boxinst/boxinst_r50_fpn_1x_coco.py:65,125
     (topk_per_img=64, samples_per_gpu=2) gives condinst_head.py:1190-1225 -- timed like `value` on rotating cold sets, with its own
     roofline: SURVEY 8(d)'s compulsory bytes at that N / step time / HBM peak."""
@@ -512,9 +516,164 @@ def instance_count_extra(lib, _lib, Fh, synthetic, dev, stream, ones, inst_per_b
     status = s0.state[off:off + 8].view(torch.int32).cpu().tolist()
     nbytes = survey_bytes(s0.d, s0.inst.N)
     us = el / steps * 1e6
-    return {'instances': s0.inst.N, 'us_per_step': us, 'images_per_s': 2 * steps / el, 'algorithmic_bytes': nbytes,
-            'achieved_GBps': nbytes / (us * 1e-6) / 1e9, 'frac': nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-            'kernels_per_step': sorted(set(calls)), 'status': status[0], 'steps': steps, 'input_sets': n_sets}
+    out = {'instances': s0.inst.N, 'us_per_step': us, 'images_per_s': 2 * steps / el, 'algorithmic_bytes': nbytes,
+           'achieved_GBps': nbytes / (us * 1e-6) / 1e9, 'frac': nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+           'kernels_per_step': sorted(set(calls)), 'status': status[0], 'tile_rows': status[1], 'steps': steps, 'input_sets': n_sets}
+    if gate:
+        # (the checker, as in the cpu_baseline leg: the C oracle on the set the last timed step of set 0 left its results for)
+        with torch.cuda.stream(stream):
+            run(1)
+            torch.cuda.synchronize(dev)
+        out['parity'] = parity_gate_only(s0)
+    # the floor of this shape: its bytes in one launch with nothing else in it (as roofline.sol_us at 32 instances)
+    sol = speed_of_light(lib, sets, dev, stream, 300, 40)
+    out['sol_us'] = sol['us_per_step']
+    out['frac_of_sol'] = sol['us_per_step'] / us
+    # ... and with the targets ahead (bxi_boxinst_targets_f32 once per set, then BXI_EVAL_TARGETS_READY): what a training iteration
+    # that calls prepare_targets at the top of forward_train pays at loss time
+    out['loss_given_targets'] = targets_ahead(lib, _lib, sets, dev, stream, steps, with_pipeline=False)['loss_given_targets']
+    return out
+
+
+def targets_ahead(lib, _lib, sets, dev, stream, steps, with_pipeline=True):
+    """Extras (not `value`): the evaluation split where the reference's data flow allows it -- get_targets needs only imgs + gt_bboxes
+    (condinst_head.py:1298-1299; both exist before the backbone runs, condinst.py:53 vs :73):
+      targets_only        bxi_boxinst_targets_f32 alone (two launches): SURVEY 8(d)'s K1 bytes, 22 937 600 at 2 x 800 x 1024
+      loss_given_targets  bxi_boxinst_eval_f32 with BXI_EVAL_TARGETS_READY (logit stream, leaders, tiles, finisher): K2 + K3 bytes,
+                          16 384 640 at 32 instances -- the GPU leg beside cpu_baseline.loss_given_similarity_ms
+      two_stage_pipelined targets of set i + 1 on a second stream under the loss of set i (one hipGraph of 2 x sets steps, replayed: the
+                          host's event bookkeeping would otherwise bound it), whole-evaluation bytes per step
+    each timed like `value` on the rotating cold sets; the split evaluation is checked bit for bit against the un-split one."""
+    vp = C.c_void_p
+    st = stream.cuda_stream
+    N = sets[0].inst.N
+    d0 = sets[0].d
+    f_eval, f_tgt = lib.bxi_boxinst_eval_f32, lib.bxi_boxinst_targets_f32
+    ready = _lib.EVAL_TARGETS_READY
+
+    def targets(s, on):
+        rc = f_tgt(C.byref(s.batch.struct), s.inst.struct.boxes_per_img_host, s.inst.struct.gt_count_host, 4, 3, 2, 0.3, s.ws.data_ptr(), s.ws.numel(), on)
+        if rc != 0:
+            raise RuntimeError(f'bxi_boxinst_targets_f32: status {rc}')
+
+    def ev(s, flags, on):
+        rc = f_eval(*s.eval_args[:-1], C.c_uint(flags), on)
+        if rc != 0:
+            raise RuntimeError(f'bxi_boxinst_eval_f32: status {rc}')
+
+    def timed(fn, n):
+        with torch.cuda.stream(stream):
+            for i in range(40):
+                fn(i)
+            torch.cuda.synchronize(dev)
+            done = torch.cuda.Event()
+            t0 = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            done.record(stream)
+            while not done.query():
+                pass
+            el = time.perf_counter() - t0
+            torch.cuda.synchronize(dev)
+        return el / n * 1e6
+
+    out = {}
+    # bit-for-bit: the un-split evaluation of set 0, then targets + the split one
+    with torch.cuda.stream(stream):
+        ev(sets[0], 0, st)
+        torch.cuda.synchronize(dev)
+        want = (sets[0].losses.clone(), sets[0].grad.clone())
+        targets(sets[0], st)
+        ev(sets[0], ready, st)
+        torch.cuda.synchronize(dev)
+    off = lib.bxi_boxinst_loss_state_status_offset(N, sets[0].inst.h, sets[0].inst.w)
+    status = sets[0].state[off:off + 8].view(torch.int32).cpu().tolist()
+    same = bool(torch.equal(want[0], sets[0].losses) and torch.equal(want[1], sets[0].grad))
+    us_t = timed(lambda i: targets(sets[i % len(sets)], st), steps)
+    k1 = 12 * d0['B'] * d0['H'] * d0['W'] + 4 * 8 * d0['B'] * d0['h'] * d0['w']
+    out['targets_only'] = {'us_per_step': us_t, 'algorithmic_bytes': k1, 'frac': k1 / (us_t * 1e-6) / 1e9 / HBM_PEAK_GBPS, 'launches': 2,
+                           'bytes_model': 'SURVEY 8(d) K1: imgs read + the similarity map written (here: Lab records + predicate words + per-box counts)'}
+    with torch.cuda.stream(stream):
+        for s in sets:
+            targets(s, st)
+    calls = []
+    cb = _lib.LAUNCH_HOOK(lambda name, phase, s_, user: calls.append(name.decode()))
+    lib.bxi_dev_set_launch_hook(C.cast(cb, C.c_void_p), None)
+    try:
+        with torch.cuda.stream(stream):
+            ev(sets[0], ready, st)
+    finally:
+        lib.bxi_dev_set_launch_hook(None, None)
+    us_l = timed(lambda i: ev(sets[i % len(sets)], ready, st), steps)
+    k23 = 8 * N * d0['h'] * d0['w'] + 4 * 8 * d0['B'] * d0['h'] * d0['w'] + 640
+    lg = {'us_per_step': us_l, 'instances': N, 'algorithmic_bytes': k23, 'frac': k23 / (us_l * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+          'kernels_per_step': sorted(set(calls)), 'status': status[0], 'bit_equal_to_unsplit_evaluation': same,
+          'bytes_model': 'SURVEY 8(d) K2 + K3: logits read + gradient written + the similarity map read'}
+    # its floor: the same bytes in one launch with the evaluation's stream / tile grid and nothing else (no image roles)
+    packs = []
+    for s in sets:
+        scratch = torch.empty(20 * d0['B'] * d0['h'] * d0['w'] + 256, dtype=torch.uint8, device=dev)
+        g = torch.empty_like(s.inst.logits)
+        packs.append((vp(0), d0['B'], d0['H'], d0['W'], vp(s.inst.logits.data_ptr()), N, s.inst.h, s.inst.w, vp(g.data_ptr()), vp(scratch.data_ptr()),
+                      C.c_size_t(scratch.numel()), scratch, g))
+
+    def sol(i):
+        rc = lib.bxi_dev_sol_eval_f32(*packs[i % len(packs)][:11], st)
+        if rc != 0:
+            raise RuntimeError(f'bxi_dev_sol_eval_f32: status {rc}')
+    lg['sol_us'] = timed(sol, max(steps, 300))
+    lg['frac_of_sol'] = lg['sol_us'] / us_l
+    out['loss_given_targets'] = lg
+    if not with_pipeline:
+        return out
+    # ---- two stages on two streams, as ONE hipGraph (2 x sets steps per replay)
+    try:
+        side = torch.cuda.Stream(device=dev)
+        K = 2 * len(sets)
+        with torch.cuda.stream(stream):
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                main = torch.cuda.current_stream(dev)
+                ev_done = [None] * len(sets)
+                e_fork = torch.cuda.Event()
+                e_fork.record(main)
+                side.wait_event(e_fork)                          # (the side stream joins the capture, once: a fork per step would order
+                for i in range(K):                               # every targets call behind the previous step's evaluation)
+                    k = i % len(sets)
+                    if ev_done[k] is not None:
+                        side.wait_event(ev_done[k])              # the evaluation that last used this workspace
+                    targets(sets[k], side.cuda_stream)
+                    e_t = torch.cuda.Event()
+                    e_t.record(side)
+                    main.wait_event(e_t)
+                    ev(sets[k], ready | _lib.EVAL_SHARED_DEVICE, main.cuda_stream)
+                    ev_done[k] = torch.cuda.Event()
+                    ev_done[k].record(main)
+            for _ in range(5):
+                g.replay()
+            torch.cuda.synchronize(dev)
+            reps = max(steps // K, 10)
+            done = torch.cuda.Event()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                g.replay()
+            done.record(stream)
+            while not done.query():
+                pass
+            el = time.perf_counter() - t0
+            torch.cuda.synchronize(dev)
+        us = el / (reps * K) * 1e6
+        whole = survey_bytes(d0, N)
+        status = sets[0].state[off:off + 8].view(torch.int32).cpu().tolist()
+        out['two_stage_pipelined'] = {'us_per_step': us, 'images_per_s': 2e6 / us, 'algorithmic_bytes': whole, 'frac': whole / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                      'status': status[0], 'steps_per_graph': K,
+                                      'note': 'as captured every targets call still precedes ITS evaluation in the graph; what overlaps is the targets of '
+                                              'step i + 1 with the evaluation of step i'}
+    except Exception as e:                                       # an extra never takes the headline down
+        out['two_stage_pipelined'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+        torch.cuda.synchronize(dev)
+    return out
 
 
 def rows_extra():
@@ -643,6 +802,42 @@ def rows_extra():
                                      'torch_rocm_levelset_fwd_bwd_us': n16['torch_rocm_levelset_fwd_bwd_us'], 'torch_rocm_lcm_fwd_bwd_us': n16['torch_rocm_lcm_fwd_bwd_us']}
     else:
         out['f4_box2mask_losses'] = r
+    # ---- the streaming kernels of the (f) rows against the HBM peak, each on its stated compulsory bytes (C ABI calls, event-timed batches)
+    try:
+        from boxinstseg_amd import _lib
+        lib = _lib.load()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        g = torch.Generator().manual_seed(1)
+        fr = {}
+        N, Cc, H, W = 100, 3, 200, 304                    # Box2Mask: 100 queries (box2mask_head.py:269-335)
+        ms, T = torch.rand(N, 2, H, W, generator=g).to(dev), torch.rand(N, Cc, H, W, generator=g).to(dev)
+        pn, loss = torch.full((N,), float(H * W), device=dev), torch.empty(N, device=dev)
+        state = torch.empty(max(lib.bxi_levelset_state_bytes(N, Cc), 256), dtype=torch.uint8, device=dev)
+        t_ = ev(lambda: lib.bxi_levelset_loss_forward_f32(ms.data_ptr(), T.data_ptr(), pn.data_ptr(), N, Cc, H, W, 1.0, loss.data_ptr(), state.data_ptr(), st), n=100)
+        nb = N * (2 + Cc) * H * W * 4
+        fr['levelset_partial_kernel'] = {'call': 'bxi_levelset_loss_forward_f32, 100 x (2 + 3) x 200 x 304', 'us': t_, 'bytes': nb, 'frac': frac(nb, t_),
+                                         'bytes_model': 'mask scores (2 planes) + targets (C planes) read once (warm: 122 MB < the Infinity Cache)'}
+        img96, aff = torch.rand(N, 3, 96, 96, generator=g).to(dev), torch.empty(N, 8, 96, 96, device=dev)
+        t_ = ev(lambda: lib.bxi_lcm_affinity_f32(img96.data_ptr(), N, 3, 96, 96, 2, 0.3, aff.data_ptr(), st), n=100)
+        nb = N * (3 + 8) * 96 * 96 * 4
+        fr['lcm_affinity_kernel'] = {'call': 'bxi_lcm_affinity_f32, 100 x 3 x 96 x 96 -> 100 x 8 x 96 x 96', 'us': t_, 'bytes': nb, 'frac': frac(nb, t_),
+                                     'bytes_model': 'images read + 8 affinity planes written (4 MB: a launch of this size is bound by its ramp, ~2 us, not by HBM)'}
+        from boxinstseg_amd.discobox import meanfield_forward, meanfield_kernel
+        Bm, Nm = 2, 16
+        ker = meanfield_kernel(torch.rand(Bm, 3, H, W, generator=g).to(dev))
+        xm, tm = torch.rand(Nm, H, W, generator=g).to(dev), (torch.rand(Nm, H, W, generator=g) > 0.5).float().to(dev)
+        ii = (torch.arange(Nm) % Bm).to(dev)
+        with torch.no_grad():
+            t10 = ev(lambda: meanfield_forward(ker, xm, tm, 20, 0.5, img_inds=ii), n=40)
+            t0_ = ev(lambda: meanfield_forward(ker, xm, tm, 10, 0.5, img_inds=ii), n=40)
+        per = (t10 - t0_) / 10
+        nb = Bm * 9 * H * W * 4 + 2 * Nm * H * W // 8
+        fr['mf_step_kernel'] = {'call': 'one mean-field update of 16 instances at 200 x 304 ((20 iterations - 10 iterations) / 10)', 'us': per, 'bytes': nb,
+                                'frac': frac(nb, per), 'bytes_model': 'the 9 kernel planes of each image read once + one bit plane per instance in and out '
+                                '(4.5 MB per update: launch-bound, ~3 us per dependent launch)'}
+        out['f_streaming_kernels'] = fr
+    except Exception as e:
+        out['f_streaming_kernels'] = {'error': f'{type(e).__name__}: {e}'[:300]}
     return out
 
 
@@ -944,7 +1139,8 @@ def kernel_timing(lib, _lib, sets, stream, enqueue, steps, step_us, rows):
     d0, N = sets[0].d, sets[0].inst.N
     alg = algorithmic_bytes(d0, N, rows)
     traffic, traffic_file = measured_traffic()
-    key = {'prep': 'prep_kernel', 'pair': 'pair_kernel', 'eval1': 'eval1_kernel'}
+    key = {'prep': 'prep_kernel', 'pair': 'pair_kernel', 'eval1': 'eval1_kernel', 'prep_fold': 'prep_kernel', 'prep_ready': 'prep_kernel',
+           'pair_tiles': 'pair_kernel', 'eval1_ready': 'eval1_kernel'}
     per_kernel = {}
     for name, raw in raws.items():
         durs = raw - bracket_us
@@ -1000,8 +1196,7 @@ def cpu_baseline(d, budget_s):
     from oracle import torch_oracle as to
     from tests.helpers import oracle_path
     host_cores = os.cpu_count() or 1
-    cores = min(host_cores, 32)            # torch CPU ops stop scaling (and thrash) far below a 256-thread host
-    torch.set_num_threads(cores)
+    cores = min(host_cores, 32)            # torch CPU ops stop scaling (and thrash) far below a 256-thread host: both are measured below
     imgs = torch.from_numpy(d['imgs'])
     gi = torch.from_numpy(d['gt_inds'])
     boxes = [torch.from_numpy(b) for b in d['gt_bboxes']]
@@ -1011,14 +1206,27 @@ def cpu_baseline(d, budget_s):
         out = to.mask_loss(imgs, d['img_metas'], x, gi, boxes)
         (out['loss_prj'] + out['loss_pairwise']).backward()
 
-    once()                                              # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        once()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 10:
-            break
+    def sample(threads, budget, most):
+        torch.set_num_threads(threads)
+        once()                                          # warm-up
+        k, t_ = 0, time.perf_counter()
+        while True:
+            once()
+            k += 1
+            e_ = time.perf_counter() - t_
+            if e_ > budget or k >= most:
+                return k, e_
+
+    n, el = sample(cores, budget_s, 10)
+    # BASELINE.md section 3 asks for ALL host cores as well: a second, shorter sample at os.cpu_count() threads; the better of the two is `value`
+    by_threads = {str(cores): {'value': 2 * n / el, 'ms_per_eval': el / n * 1e3, 'evaluations': n}}
+    more = min(host_cores, 64)              # (all 256 threads of the driver's host, measured once -- profiles/r05_cpu_threads.json: 34.4 s per evaluation,
+    if more > cores:                        # 0.058 images/s, and the 256 spinning OpenMP workers slowed every host-bound figure measured after it)
+        n2, el2 = sample(more, min(budget_s, 6.0), 4)
+        by_threads[str(more)] = {'value': 2 * n2 / el2, 'ms_per_eval': el2 / n2 * 1e3, 'evaluations': n2}
+        if 2 * n2 / el2 > 2 * n / el:
+            n, el, cores = n2, el2, more
+        torch.set_num_threads(cores)
     # (i) the loss given the similarity map and (ii) the colour-affinity precompute, timed separately; and
     # the same evaluation on ONE core (a single run each: bounded)
     t1 = time.perf_counter()
@@ -1048,7 +1256,7 @@ def cpu_baseline(d, budget_s):
     return {'value': 2 * n / el, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n} full evaluations (targets + loss fwd+bwd) of the same 2x800x1024x{len(d["gt_inds"])} '
                       f'workload with the torch-CPU restatement of the reference path, {cores} threads',
-            'ms_per_eval': el / n * 1e3, 'host_cores': host_cores, **split,
+            'ms_per_eval': el / n * 1e3, 'host_cores': host_cores, 'by_threads': by_threads, **split,
             'c_oracle_openmp': {'value': 2 / t_c, 'unit': 'images/s', 'ms_per_eval': t_c * 1e3}}, ref
 
 

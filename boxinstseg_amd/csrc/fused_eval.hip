@@ -1826,7 +1826,7 @@ static int device_cus() {
 // process environment: what varies is an argument (`flags`), as include/boxinst_hip.h promises.
 #ifdef BXI_DEV
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-#define BXI_KNOB(name, dflt) ([]() -> int { static const int v = env_int(name, dflt); return v; }())
+#define BXI_KNOB(name, dflt) ([&]() -> int { static const int set = getenv(name) ? 1 : 0; static const int v = env_int(name, 0); return set ? v : (dflt); }())
 #else
 #define BXI_KNOB(name, dflt) (dflt)
 #endif
@@ -2118,9 +2118,11 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         int n_pb = ready ? 0 : (n_items + kWaves - 1) / kWaves;
         if (n_pb > slots / 2) n_pb = slots / 2;
         int64_t n_tb = (eval_cap(a.N, a.h, a.w, dil, R) + kWaves - 1) / kWaves;
-        // (the short form leaves half of the slots to the workgroups its staying-on stream workgroups wait for; the long form has no such wait:
-        // one tile per wave while the slots last)
-        if (n_tb > (long_form ? slots : slots / 2)) n_tb = long_form ? slots : slots / 2;
+        // One tile per wave while the slots last: a wave that walks two tiles runs two ~7 us dependent chains one after the other.  (Round 4
+        // capped the tile workgroups at half the slots; they are the LAST workgroups of the grid and wait only for earlier ones, so nothing
+        // depends on their number -- 64 instances: 24.1 -> 22.9 us per evaluation, 32 instances unchanged: their 289 were below the cap.)
+        const int tb_cap = BXI_KNOB("BXI_ONE_TB_CAP", slots);
+        if (n_tb > tb_cap) n_tb = tb_cap;
         // the stream workgroups stay on as the first tile workgroups (only while they leave half of the slots to the rest of the grid)
         // ... unless evaluations run on SEVERAL streams at once: each would hold its stream workgroups' slots while waiting, and three
         // or four of them leave no room for anybody's pool workgroups (measured: 2.4 ms per evaluation with four streams in flight,

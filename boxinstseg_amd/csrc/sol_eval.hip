@@ -128,8 +128,8 @@ extern "C" int bxi_dev_sol_pairwise_f32(const float* logits, float* planes, floa
 
 extern "C" int bxi_dev_sol_eval_f32(const float* imgs, int B, int Hc, int Wc, const float* logits, int N, int h, int w, float* g_logits, void* workspace,
                                     size_t workspace_bytes, void* stream) {
-    if (!imgs || !logits || !g_logits || !workspace) return BXI_ERR_NULL_POINTER;
-    if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || Hc != 4 * h || Wc != 4 * w || (w & 3)) return BXI_ERR_BAD_SHAPE;
+    if (!logits || !g_logits || !workspace) return BXI_ERR_NULL_POINTER;          // imgs == NULL: the loss-given-targets bytes (no image roles)
+    if (B <= 0 || N <= 0 || h < 12 || w < 68 || Hc != 4 * h || Wc != 4 * w || (w & 3)) return BXI_ERR_BAD_SHAPE;   // (the tile role's stand-in rows / columns)
     const size_t Pp = (size_t)B * h * w;
     if (workspace_bytes < 16 * Pp + 4 * Pp + 256) return BXI_ERR_WORKSPACE;
     bxi::SolArgs a;
@@ -149,6 +149,7 @@ extern "C" int bxi_dev_sol_eval_f32(const float* imgs, int B, int Hc, int Wc, co
     const int per = (a.n_items + room - 1) / room;
     a.n_pool = (a.n_items + per - 1) / per;
     a.n_pb = (a.n_items + 3) / 4 > slots / 2 ? slots / 2 : (a.n_items + 3) / 4;
+    if (!imgs) a.n_pool = a.n_pb = 0;
     a.n_lead = N;
     a.tiles = (int)((int64_t)N * h * w * 36 / 51200 / 32);     // 1152 at 32 x 200 x 256 (the headline batch has 1153)
     a.n_tb = (a.tiles + 3) / 4;

@@ -26,7 +26,8 @@ void bxi_dev_set_tree_level_walk(int on);
 /* Measuring stick (bench.py `roofline.sol_us`): ONE launch with the single-launch evaluation's grid -- the same numbers of 256-thread
  * workgroups per role, four per CU -- that performs the evaluation's loads and stores (imgs [B,3,Hc,Wc] read, logits [N,1,h,w] read,
  * g_logits zero-filled and added to on the tile hulls, the Lab / predicate intermediates written and re-read in `workspace`:
- * >= 20 * B * h * w + 256 bytes) with no arithmetic and NO dependency between workgroups.  Requires Hc == 4 h, Wc == 4 w, w % 4 == 0.
+ * >= 20 * B * h * w + 256 bytes) with no arithmetic and NO dependency between workgroups.  Requires Hc == 4 h, Wc == 4 w, w % 4 == 0, h >= 12, w >= 68.
+ * imgs == NULL: without the image roles -- the bytes of an evaluation whose targets are ready (BXI_EVAL_TARGETS_READY).
  * Leaves garbage in g_logits / workspace.  csrc/sol_eval.hip. */
 int bxi_dev_sol_eval_f32(const float* imgs, int B, int Hc, int Wc, const float* logits, int N, int h, int w, float* g_logits,
                          void* workspace, size_t workspace_bytes, void* stream);
