@@ -32,8 +32,11 @@ __device__ __forceinline__ double block_sum_f64_ls(double v, double* red /*[16]*
 __device__ __forceinline__ int ls_stride(int C) { return 2 + 4 * C; }
 constexpr int kLsSlices = 8;      // workgroups per instance in the forward (a single one per instance is latency bound)
 
+// (512 threads: 2 + 4 C double-precision running sums per thread, 34 at C = 8, next to the C + 2 float4 in flight do not fit the 128 registers of a
+// 1024-thread workgroup)
+constexpr int kLsThreads = 512;
 template <bool VEC>
-__global__ __launch_bounds__(1024) void levelset_partial_kernel(const float* __restrict__ ms, const float* __restrict__ tg, int N, int C,
+__global__ __launch_bounds__(kLsThreads) void levelset_partial_kernel(const float* __restrict__ ms, const float* __restrict__ tg, int N, int C,
                                                                 int H, int W, double* __restrict__ state, int c0) {
     __shared__ double red[16 * (2 + 4 * kLsMaxC)];
     const int n = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x;
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(1024) void levelset_partial_kernel(const float* __r
     if (VEC) {
         // H*W a multiple of 4 and 16-byte aligned planes (host check): 4 consecutive pixels per thread and trip as float4
         // loads (2 + C wave loads of 1 KiB instead of 8 + 4C of 256 B); `chunk` and `hi` are multiples of 4 then
-        for (int64_t p0 = lo + 4 * tid; p0 < hi; p0 += 4 * 1024) {
+        for (int64_t p0 = lo + 4 * tid; p0 < hi; p0 += 4 * kLsThreads) {
             const float4 f4 = *reinterpret_cast<const float4*>(f0 + p0), g4 = *reinterpret_cast<const float4*>(f0 + HW + p0);
             float4 t4[kLsMaxC];
 #pragma unroll
@@ -71,18 +74,18 @@ __global__ __launch_bounds__(1024) void levelset_partial_kernel(const float* __r
                 }
         }
     } else
-    for (int64_t p0 = lo + tid; p0 < hi; p0 += 4 * 1024) {        // 4 pixels per trip: their loads are independent
+    for (int64_t p0 = lo + tid; p0 < hi; p0 += 4 * kLsThreads) {        // 4 pixels per trip: their loads are independent
         // unconditional loads at a clamped index (a guarded load becomes a branch, and branches serialise the loads);
         // a pixel past the end gets zero scores, which add nothing to any sum
         float fv[4], gv[4];
         int64_t pc[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int64_t p = p0 + u * 1024; pc[u] = p < hi ? p : hi - 1; }
+        for (int u = 0; u < 4; ++u) { const int64_t p = p0 + u * kLsThreads; pc[u] = p < hi ? p : hi - 1; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) { fv[u] = f0[pc[u]]; gv[u] = f0[HW + pc[u]]; }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (p0 + u * 1024 >= hi) { fv[u] = 0.f; gv[u] = 0.f; }
+            if (p0 + u * kLsThreads >= hi) { fv[u] = 0.f; gv[u] = 0.f; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) { S[0] += (double)fv[u]; S[1] += (double)gv[u]; }
 #pragma unroll
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(1024) void levelset_partial_kernel(const float* __r
     __syncthreads();
     if (tid < n_sums) {
         double s = 0.0;
-        for (int wv = 0; wv < 16; ++wv) s += red[wv * (2 + 4 * kLsMaxC) + tid];     // fixed order
+        for (int wv = 0; wv < kLsThreads / 64; ++wv) s += red[wv * (2 + 4 * kLsMaxC) + tid];     // fixed order
         // sum `tid` of this group -> its place among all C channels (S[2] is the same in every group's launch: same data, same order)
         const int q = tid - 2;
         part[tid < 2 ? tid : 2 + (q / Cg) * C + c0 + q % Cg] = s;
@@ -456,7 +459,11 @@ __global__ __launch_bounds__(kLcmPadThreads) void lcm_adjoint_pad_kernel(const f
     float* gp = lcm_planes + nq;
     const float* A = aff + (int64_t)n * 8 * hw;
     for (int i = tid; i < nq; i += kLcmPadThreads) gz[i] = 0.f;
-    float coef[kLcmPadSPT][8];
+    // The transposed coefficients live in registers for the reference's shape (96 x 96, d = 2: everything about an index is a compile-time
+    // constant).  The run-time-shape variant would need 80 registers for them next to run-time strides: it re-reads them (L2-resident,
+    // 32 B per pixel and instance) in every iteration instead of spilling them -- the same values in the same order.
+    constexpr bool kRegCoef = H != 0;
+    float coef[kRegCoef ? kLcmPadSPT : 1][8];
     int sbase[kLcmPadSPT];          // index into gz of the top-left-most source of padded position s; -1: no position
 #pragma unroll
     for (int j = 0; j < kLcmPadSPT; ++j) {
@@ -466,12 +473,14 @@ __global__ __launch_bounds__(kLcmPadThreads) void lcm_adjoint_pad_kernel(const f
             const int sr = s / wp, sc = s % wp;
             // source of tap k: pixel (sr - (dy + 1) d, sc - (dx + 1) d); in gz (shifted by 2d): (sr + (1 - dy) d, sc + (1 - dx) d)
             sbase[j] = sr * wq + sc;
+            if constexpr (kRegCoef) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                int dy, dx; lcm_offset(k, dy, dx);
-                const int pr = sr - (dy + 1) * d, pc = sc - (dx + 1) * d;
-                const bool in = pr >= 0 && pr < h && pc >= 0 && pc < w;
-                coef[j][k] = in ? A[(int64_t)k * hw + pr * w + pc] : 0.f;
+                for (int k = 0; k < 8; ++k) {
+                    int dy, dx; lcm_offset(k, dy, dx);
+                    const int pr = sr - (dy + 1) * d, pc = sc - (dx + 1) * d;
+                    const bool in = pr >= 0 && pr < h && pc >= 0 && pc < w;
+                    coef[j][k] = in ? A[(int64_t)k * hw + pr * w + pc] : 0.f;
+                }
             }
         }
     }
@@ -507,16 +516,38 @@ __global__ __launch_bounds__(kLcmPadThreads) void lcm_adjoint_pad_kernel(const f
     for (int p = tid; p < hw; p += kLcmPadThreads) gz[(p / w + 2 * d) * wq + p % w + 2 * d] = gout[(int64_t)n * hw + p];
     __syncthreads();
     for (int it = 0; it < iters; ++it) {
+        if constexpr (kRegCoef) {
 #pragma unroll
-        for (int j = 0; j < kLcmPadSPT; ++j) {
-            if (sbase[j] < 0) continue;
-            float acc = 0.f;
+            for (int j = 0; j < kLcmPadSPT; ++j) {
+                if (sbase[j] < 0) continue;
+                float acc = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                int dy, dx; lcm_offset(k, dy, dx);
-                acc += coef[j][k] * gz[sbase[j] + (1 - dy) * d * wq + (1 - dx) * d];
+                for (int k = 0; k < 8; ++k) {
+                    int dy, dx; lcm_offset(k, dy, dx);
+                    acc += coef[j][k] * gz[sbase[j] + (1 - dy) * d * wq + (1 - dx) * d];
+                }
+                gp[tid + j * kLcmPadThreads] = acc;
             }
-            gp[tid + j * kLcmPadThreads] = acc;
+        } else {
+#pragma unroll 1
+            for (int s = tid; s < hp * wp; s += kLcmPadThreads) {        // (nothing per position is kept across iterations: see kRegCoef)
+                const int sr = s / wp, sc = s % wp, sb = sr * wq + sc;
+                float cf[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    int dy, dx; lcm_offset(k, dy, dx);
+                    const int pr = sr - (dy + 1) * d, pc = sc - (dx + 1) * d;
+                    const bool in = pr >= 0 && pr < h && pc >= 0 && pc < w;
+                    cf[k] = in ? A[(int64_t)k * hw + pr * w + pc] : 0.f;
+                }
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    int dy, dx; lcm_offset(k, dy, dx);
+                    acc += cf[k] * gz[sb + (1 - dy) * d * wq + (1 - dx) * d];
+                }
+                gp[s] = acc;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -586,10 +617,10 @@ int bxi_levelset_loss_forward_f32(const float* mask_score, const float* target, 
     int rc = BXI_OK;
     for (int c0 = 0; c0 < C; c0 += bxi::kLsMaxC) {                  // the shipped losses have C = 3 and C = 5: one launch
         if (vec)
-            BXI_LAUNCH("levelset_partial", s, bxi::levelset_partial_kernel<true>, dim3(bxi::kLsSlices, N), dim3(1024), 0, s, mask_score, target,
+            BXI_LAUNCH("levelset_partial", s, bxi::levelset_partial_kernel<true>, dim3(bxi::kLsSlices, N), dim3(bxi::kLsThreads), 0, s, mask_score, target,
                        N, C, H, W, reinterpret_cast<double*>(state), c0);
         else
-            BXI_LAUNCH("levelset_partial", s, bxi::levelset_partial_kernel<false>, dim3(bxi::kLsSlices, N), dim3(1024), 0, s, mask_score, target,
+            BXI_LAUNCH("levelset_partial", s, bxi::levelset_partial_kernel<false>, dim3(bxi::kLsSlices, N), dim3(bxi::kLsThreads), 0, s, mask_score, target,
                        N, C, H, W, reinterpret_cast<double*>(state), c0);
         rc = bxi::check_launch();
         if (rc != BXI_OK) return rc;

@@ -161,6 +161,17 @@ template <typename T> struct ProbPair { T s, m; };      // sigmoid(x), sigmoid(-
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // 1 ulp
 __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
 // exp(-a), a >= 0: v_exp_f32 (2^x, ~1 ulp) on a * log2(e) -- the staged probabilities need 1e-6, not the last bit
+static int pw_device_cus() {              // compute units of the current device (cached per ordinal; a wrong value costs time, never correctness)
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cached[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 __device__ __forceinline__ float fast_exp_neg(float a) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * a); }
 __device__ __forceinline__ double fast_exp_neg(double a) { return exp(-a); }
 
@@ -529,13 +540,21 @@ __global__ __launch_bounds__(256) void pairwise3_fwd_wide_kernel(const float* __
 #ifndef BXI_PWB_OCC
 #define BXI_PWB_OCC 5
 #endif
-template <int D, int TR, int TC>
-__global__ __launch_bounds__(256, BXI_PWB_OCC) void pairwise3_bwd_wide_kernel(const float* __restrict__ logits, const float* __restrict__ g_pair, int H, int W,
+// XR > 0: the workgroup's tile has XR MORE rows (XR * TC == 256), of which every thread takes ONE pixel in a second phase, after its four
+// adjacent ones -- a tile of TR + XR = 20 rows makes 32 x 200 x 256 exactly 1280 workgroups = ONE residency round at five workgroups per CU
+// (16-row tiles: 1664 workgroups = 1.3 rounds, the second one a quarter full and as long as the first), with no partly filled last tile
+// row (200 = 10 x 20) and a smaller halo share of the staged tile (24 x 68 for 20 x 64 instead of 20 x 68 for 16 x 64).  The second phase
+// re-uses the first one's registers: the kernel stays at five workgroups per CU.
+// (dilation 3 / 4: a 3 x 10 / 3 x 12 window per plane -- one workgroup per CU fewer instead of spilled registers)
+template <int D, int TR, int TC, int XR = 0>
+__global__ __launch_bounds__(256, (D <= 2 ? BXI_PWB_OCC : BXI_PWB_OCC - 1)) void pairwise3_bwd_wide_kernel(const float* __restrict__ logits, const float* __restrict__ g_pair, int H, int W,
                                                                  float* __restrict__ g_logits, int xcd_swizzle) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pw_raw[];
     constexpr int PC = PwGeom<D, TC>::PC, NWp = 4 * PwGeom<D, TC>::NW4;
     static_assert(TR * TC == 1024 && TC % 4 == 0, "256 threads x four adjacent pixels");
-    const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
+    static_assert(XR == 0 || XR * TC == 256, "second phase: one pixel per thread");
+    constexpr int TRT = TR + XR;
+    const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TRT - 1) / TRT;
     // workgroups are dealt to the 8 XCDs round-robin by index; each XCD has its own L2.  Tile order = index order WITHIN an XCD, so
     // that the tiles an XCD works on at one time are neighbours: the partner terms that reach into the next tile are then lines its
     // own L2 has just fetched -- 19.2 -> 15.7 us at 32 x 200 x 256 (with the plain order a tile's four neighbours run on four other
@@ -552,7 +571,7 @@ __global__ __launch_bounds__(256, BXI_PWB_OCC) void pairwise3_bwd_wide_kernel(co
     const int ty = t % tiles_y;
     const int64_t n = t / tiles_y;
     const int64_t P = (int64_t)H * W;
-    const int r0 = ty * TR, c0 = tx * TC;
+    const int r0 = ty * TRT, c0 = tx * TC;
     const float* L = logits + n * P;
     const int lr = threadIdx.x / (TC / 4), lc = (threadIdx.x % (TC / 4)) * 4;
     const int r = r0 + lr, c = c0 + lc;
@@ -582,10 +601,11 @@ __global__ __launch_bounds__(256, BXI_PWB_OCC) void pairwise3_bwd_wide_kernel(co
 #pragma unroll
     for (int k = 0; k < 8; ++k) G[k] = make_float4(own[k].x + part[k].x, own[k].y + part[k].y, own[k].z + part[k].z, own[k].w + part[k].w);
     float* ts = reinterpret_cast<float*>(pw_raw);
-    float* tm = ts + (TR + 2 * D) * PC;
+    float* tm = ts + (TRT + 2 * D) * PC;
     bool sat;
-    pw3_stage_probs<D, TR, TC>(L, H, W, r0, c0, ts, tm, sat);
-    if (!live) return;
+    pw3_stage_probs<D, TRT, TC>(L, H, W, r0, c0, ts, tm, sat);
+    if (XR == 0 && !live) return;
+    if (live) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (sat) {                                                           // rare: log space, straight from global memory (pairwise.cu:56-58)
         for (int i = 0; i < 4; ++i) {
@@ -627,6 +647,55 @@ __global__ __launch_bounds__(256, BXI_PWB_OCC) void pairwise3_bwd_wide_kernel(co
         }
     }
     *reinterpret_cast<float4*>(g_logits + n * P + (int64_t)r * W + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    if (XR > 0) {
+        // ---- second phase: ONE pixel of rows TR .. TR + XR - 1 per thread (its requests go out when the first phase's registers are free)
+        const int lr2 = TR + (int)threadIdx.x / TC, lc2 = (int)threadIdx.x % TC;
+        const int r2 = r0 + lr2, c2 = c0 + lc2;
+        if (r2 >= H || c2 >= W) return;
+        const int pix2 = (r2 * W + c2) * 4, lim2 = 8 * plane - 4;
+        float a2 = 0.f;
+        if (sat) {                                                       // rare: log space, straight from global memory (pairwise.cu:56-58)
+            const float here = L[r2 * W + c2];
+            const float ax = logsig(here), bx = logsig(-here);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1, r3 = r2 + dy * D, c3 = c2 + dx * D;
+                if (r3 >= 0 && r3 < H && c3 >= 0 && c3 < W) {
+                    const float there = L[r3 * W + c3];
+                    const float ay = logsig(there), by = logsig(-there);
+                    const float pair = pair_nlog(ax, bx, ay, by);
+                    const float g = g_pair[(n * 8 + k) * P + (int64_t)r2 * W + c2] + g_pair[(n * 8 + (7 - k)) * P + (int64_t)r3 * W + c3];
+                    a2 += -(expf(ay) - expf(by)) * expf(ax + bx + pair) * g;
+                }
+            }
+        } else {
+            float G2[8];
+            {
+                float o2[8], p2[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 7 - j, kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;
+                    o2[j] = *reinterpret_cast<const float*>(gb + (uint32_t)(j * plane + pix2));
+                    const int nb = min(max(j * plane + pix2 + ((dy * D) * W + dx * D) * 4, 0), lim2);
+                    p2[k] = *reinterpret_cast<const float*>(gb + (uint32_t)nb);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) G2[k] = o2[k] + p2[k];
+            }
+            const float s0 = ts[(lr2 + D) * PC + lc2 + D], m0 = tm[(lr2 + D) * PC + lc2 + D], up2 = s0 * m0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;
+                const bool in = (dy < 0 ? r2 - D >= 0 : (dy > 0 ? r2 + D < H : true)) && (dx < 0 ? c2 - D >= 0 : (dx > 0 ? c2 + D < W : true));
+                const float ns = ts[(lr2 + D + dy * D) * PC + lc2 + D + dx * D], nm = tm[(lr2 + D + dy * D) * PC + lc2 + D + dx * D];
+                const float S = s0 * ns + m0 * nm;
+                const float m = in ? G2[k] * fast_rcp(S) : 0.f;
+                a2 += -(ns - nm) * up2 * m;
+            }
+        }
+        g_logits[n * P + (int64_t)r2 * W + c2] = a2;
+    }
 }
 
 template <typename T>
@@ -717,14 +786,28 @@ static int launch_bwd(const T* logits, const T* g_pair, int N, int H, int W, int
 #define BXI_PWB_TR 16
 #define BXI_PWB_TC 64
 #endif
-                    const int64_t tiles_b = (int64_t)N * ((H + BXI_PWB_TR - 1) / BXI_PWB_TR) * ((W + BXI_PWB_TC - 1) / BXI_PWB_TC);
+                    // 16-row tiles, or 20-row tiles (16 rows of four pixels per thread + 4 rows of one): whichever needs fewer residency
+                    // rounds x rows (five workgroups per CU), then whichever pads the map's height less.  32 x 200 x 256: 1664 workgroups
+                    // = 2 rounds of 16 rows against 1280 = ONE round of 20.
+                    constexpr int kXR = 256 / BXI_PWB_TC;
+                    const int64_t cols_b = (W + BXI_PWB_TC - 1) / BXI_PWB_TC;
+                    const int64_t t16 = (int64_t)N * ((H + BXI_PWB_TR - 1) / BXI_PWB_TR) * cols_b, t20 = (int64_t)N * ((H + BXI_PWB_TR + kXR - 1) / (BXI_PWB_TR + kXR)) * cols_b;
+                    const int64_t slots_b = (int64_t)(dil <= 2 ? BXI_PWB_OCC : BXI_PWB_OCC - 1) * pw_device_cus();
+                    const int64_t c16 = ((t16 + slots_b - 1) / slots_b) * BXI_PWB_TR, c20 = ((t20 + slots_b - 1) / slots_b) * (BXI_PWB_TR + kXR);
+                    const int64_t p16 = (int64_t)((H + BXI_PWB_TR - 1) / BXI_PWB_TR) * BXI_PWB_TR, p20 = (int64_t)((H + BXI_PWB_TR + kXR - 1) / (BXI_PWB_TR + kXR)) * (BXI_PWB_TR + kXR);
+                    const bool tall = BXI_PWB_TR * BXI_PWB_TC == 1024 && kXR * BXI_PWB_TC == 256 && (c20 < c16 || (t16 <= slots_b && t20 <= slots_b && p20 < p16));
+                    const int64_t tiles_b = tall ? t20 : t16;
                     if (!fits_i32(tiles_b)) return BXI_ERR_BAD_SHAPE;
                     const dim3 gb((unsigned)tiles_b);
 #define BXI_PWB(DD)                                                                                                                             \
                     {                                                                                                                           \
-                        const size_t ldw = 2 * sizeof(float) * (size_t)(BXI_PWB_TR + 2 * DD) * PwGeom<DD, BXI_PWB_TC>::PC;                    \
-                        BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_wide_kernel<DD, BXI_PWB_TR, BXI_PWB_TC>), gb, b, ldw, st, (const float*)logits, \
-                                   (const float*)g_pair, H, W, (float*)g_logits, env_swz);                                                    \
+                        const size_t ldw = 2 * sizeof(float) * (size_t)(BXI_PWB_TR + (tall ? kXR : 0) + 2 * DD) * PwGeom<DD, BXI_PWB_TC>::PC; \
+                        if (tall)                                                                                                               \
+                            BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_wide_kernel<DD, BXI_PWB_TR, BXI_PWB_TC, kXR>), gb, b, ldw, st, (const float*)logits, \
+                                       (const float*)g_pair, H, W, (float*)g_logits, env_swz);                                                \
+                        else                                                                                                                    \
+                            BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_wide_kernel<DD, BXI_PWB_TR, BXI_PWB_TC>), gb, b, ldw, st, (const float*)logits, \
+                                       (const float*)g_pair, H, W, (float*)g_logits, env_swz);                                                \
                     }
                     switch (dil) { case 1: BXI_PWB(1) break; case 2: BXI_PWB(2) break; case 3: BXI_PWB(3) break; default: BXI_PWB(4) break; }
 #undef BXI_PWB
