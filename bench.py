@@ -531,7 +531,11 @@ def instance_count_extra(lib, _lib, Fh, synthetic, dev, stream, ones, inst_per_b
     out['frac_of_sol'] = sol['us_per_step'] / us
     # ... and with the targets ahead (bxi_boxinst_targets_f32 once per set, then BXI_EVAL_TARGETS_READY): what a training iteration
     # that calls prepare_targets at the top of forward_train pays at loss time
-    out['loss_given_targets'] = targets_ahead(lib, _lib, sets, dev, stream, steps, with_pipeline=False)['loss_given_targets']
+    ta = targets_ahead(lib, _lib, sets, dev, stream, steps, with_pipeline=s0.inst.N >= 128)
+    out['loss_given_targets'] = ta['loss_given_targets']
+    for k_ in ('two_stage_pipelined', 'under_a_backbone_standin'):
+        if k_ in ta:
+            out[k_] = ta[k_]
     return out
 
 
@@ -541,8 +545,8 @@ def targets_ahead(lib, _lib, sets, dev, stream, steps, with_pipeline=True):
       targets_only        bxi_boxinst_targets_f32 alone (two launches): SURVEY 8(d)'s K1 bytes, 22 937 600 at 2 x 800 x 1024
       loss_given_targets  bxi_boxinst_eval_f32 with BXI_EVAL_TARGETS_READY (logit stream, leaders, tiles, finisher): K2 + K3 bytes,
                           16 384 640 at 32 instances -- the GPU leg beside cpu_baseline.loss_given_similarity_ms
-      two_stage_pipelined targets of set i + 1 on a second stream under the loss of set i (one hipGraph of 2 x sets steps, replayed: the
-                          host's event bookkeeping would otherwise bound it), whole-evaluation bytes per step
+      two_stage_pipelined targets of set i + 1 on a second stream under the loss of set i (eager, events between the streams), whole-evaluation
+                          bytes per step; host-bound at 32 instances (four launches + four event calls per step from one thread)
     each timed like `value` on the rotating cold sets; the split evaluation is checked bit for bit against the un-split one."""
     vp = C.c_void_p
     st = stream.cuda_stream
@@ -626,52 +630,109 @@ def targets_ahead(lib, _lib, sets, dev, stream, steps, with_pipeline=True):
     out['loss_given_targets'] = lg
     if not with_pipeline:
         return out
-    # ---- two stages on two streams, as ONE hipGraph (2 x sets steps per replay)
+    # ---- two stages on two streams (eager; events order the two uses of a workspace): the targets of step i + 1 on the side stream
+    # while the loss of step i runs on the main one
     try:
         side = torch.cuda.Stream(device=dev)
-        K = 2 * len(sets)
+        n = len(sets)
+        t_done = [torch.cuda.Event() for _ in range(n)]
+        e_done = [torch.cuda.Event() for _ in range(n)]
+        side_st = side.cuda_stream
+
+        def pipelined(steps_):
+            used = [False] * n
+            side.wait_stream(stream)
+            targets(sets[0], side_st)
+            t_done[0].record(side)
+            for i in range(steps_):
+                k, kn = i % n, (i + 1) % n
+                if used[kn]:
+                    side.wait_event(e_done[kn])          # the evaluation that last read this workspace
+                targets(sets[kn], side_st)
+                t_done[kn].record(side)
+                stream.wait_event(t_done[k])
+                ev(sets[k], ready | _lib.EVAL_SHARED_DEVICE, st)
+                e_done[k].record(stream)
+                used[k] = True
+            stream.wait_stream(side)
         with torch.cuda.stream(stream):
+            pipelined(64)
             torch.cuda.synchronize(dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=stream):
-                main = torch.cuda.current_stream(dev)
-                ev_done = [None] * len(sets)
-                e_fork = torch.cuda.Event()
-                e_fork.record(main)
-                side.wait_event(e_fork)                          # (the side stream joins the capture, once: a fork per step would order
-                for i in range(K):                               # every targets call behind the previous step's evaluation)
-                    k = i % len(sets)
-                    if ev_done[k] is not None:
-                        side.wait_event(ev_done[k])              # the evaluation that last used this workspace
-                    targets(sets[k], side.cuda_stream)
-                    e_t = torch.cuda.Event()
-                    e_t.record(side)
-                    main.wait_event(e_t)
-                    ev(sets[k], ready | _lib.EVAL_SHARED_DEVICE, main.cuda_stream)
-                    ev_done[k] = torch.cuda.Event()
-                    ev_done[k].record(main)
-            for _ in range(5):
-                g.replay()
-            torch.cuda.synchronize(dev)
-            reps = max(steps // K, 10)
             done = torch.cuda.Event()
             t0 = time.perf_counter()
-            for _ in range(reps):
-                g.replay()
+            pipelined(steps)
             done.record(stream)
             while not done.query():
                 pass
             el = time.perf_counter() - t0
             torch.cuda.synchronize(dev)
-        us = el / (reps * K) * 1e6
+            # the host's share: the same calls with nothing to wait for on the device would take this long to ENQUEUE
+            t1 = time.perf_counter()
+            pipelined(100)
+            host_us = (time.perf_counter() - t1) / 100 * 1e6
+            torch.cuda.synchronize(dev)
+        us = el / steps * 1e6
         whole = survey_bytes(d0, N)
         status = sets[0].state[off:off + 8].view(torch.int32).cpu().tolist()
         out['two_stage_pipelined'] = {'us_per_step': us, 'images_per_s': 2e6 / us, 'algorithmic_bytes': whole, 'frac': whole / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                                      'status': status[0], 'steps_per_graph': K,
-                                      'note': 'as captured every targets call still precedes ITS evaluation in the graph; what overlaps is the targets of '
-                                              'step i + 1 with the evaluation of step i'}
+                                      'status': status[0], 'serial_us': us_t + us_l, 'host_enqueue_us_per_step': host_us,
+                                      'note': 'eager, two streams: per step four launches, two event records and two event waits from ONE host thread -- '
+                                              'where host_enqueue_us_per_step is not below us_per_step the figure is bound by the host, not by the device'}
     except Exception as e:                                       # an extra never takes the headline down
         out['two_stage_pipelined'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+        torch.cuda.synchronize(dev)
+    # ---- what the split is FOR: the targets under the backbone.  A training iteration is [backbone ... head][loss]; get_targets needs
+    # nothing the backbone produces (condinst.py:53 vs :73).  Stand-in for the backbone: a chain of bf16 matrix products on the main
+    # stream (compute-bound, every CU busy), the loss behind it.  (a) the un-split evaluation behind the stand-in; (b) the targets on a
+    # side stream WHILE the stand-in runs, then the evaluation with BXI_EVAL_TARGETS_READY.  GPU time per iteration, events on the main stream.
+    try:
+        side = torch.cuda.Stream(device=dev)
+        side_st = side.cuda_stream
+        hog_a = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+        hog_b = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+        hog_c = torch.empty_like(hog_a)
+
+        def backbone():
+            torch.mm(hog_a, hog_b, out=hog_c)
+            torch.mm(hog_c, hog_b, out=hog_a)
+
+        def iteration(split, i):
+            s = sets[i % len(sets)]
+            if split:
+                side.wait_stream(stream)                  # (the images of this iteration exist; the previous loss is done with the workspace)
+                targets(s, side_st)
+            backbone()
+            if split:
+                stream.wait_stream(side)
+                ev(s, ready | _lib.EVAL_SHARED_DEVICE, st)
+            else:
+                ev(s, 0, st)
+
+        res = {}
+        with torch.cuda.stream(stream):
+            for name, split in (('unsplit', False), ('targets_under_the_standin', True), ('standin_alone', None)):
+                def one(i):
+                    if split is None:
+                        backbone()
+                    else:
+                        iteration(split, i)
+                for i in range(20):
+                    one(i)
+                torch.cuda.synchronize(dev)
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a_.record(stream)
+                for i in range(200):
+                    one(i)
+                b_.record(stream)
+                torch.cuda.synchronize(dev)
+                res[name] = a_.elapsed_time(b_) / 200 * 1e3
+        out['under_a_backbone_standin'] = {
+            'us_per_iteration': res, 'loss_cost_unsplit_us': res['unsplit'] - res['standin_alone'],
+            'loss_cost_with_targets_ahead_us': res['targets_under_the_standin'] - res['standin_alone'],
+            'standin': 'two 4096^3 bf16 matrix products per iteration on the main stream (torch.mm)',
+            'note': 'the second figure contains whatever the concurrent targets kernels cost the stand-in'}
+    except Exception as e:
+        out['under_a_backbone_standin'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         torch.cuda.synchronize(dev)
     return out
 
@@ -828,8 +889,8 @@ def rows_extra():
         xm, tm = torch.rand(Nm, H, W, generator=g).to(dev), (torch.rand(Nm, H, W, generator=g) > 0.5).float().to(dev)
         ii = (torch.arange(Nm) % Bm).to(dev)
         with torch.no_grad():
-            t10 = ev(lambda: meanfield_forward(ker, xm, tm, 20, 0.5, img_inds=ii), n=40)
-            t0_ = ev(lambda: meanfield_forward(ker, xm, tm, 10, 0.5, img_inds=ii), n=40)
+            t10 = ev(lambda: meanfield_forward(ker, xm, tm, 20, 0.45, img_inds=ii), n=40)
+            t0_ = ev(lambda: meanfield_forward(ker, xm, tm, 10, 0.45, img_inds=ii), n=40)
         per = (t10 - t0_) / 10
         nb = Bm * 9 * H * W * 4 + 2 * Nm * H * W // 8
         fr['mf_step_kernel'] = {'call': 'one mean-field update of 16 instances at 200 x 304 ((20 iterations - 10 iterations) / 10)', 'us': per, 'bytes': nb,

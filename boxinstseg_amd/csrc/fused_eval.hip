@@ -1709,7 +1709,8 @@ __global__ __launch_bounds__(256, (R == 4 ? kOneOcc : 3)) void eval1_kernel(Pool
 // both exist before the backbone runs (condinst.py:53 vs :73).  Two launches with NO in-kernel wait (a kernel boundary between them), so the
 // call makes progress next to anything: launch 1 = the pool workgroups of prep_kernel (Lab records, tag field 0) + one workgroup that writes
 // the box table and zeroes the boxes' count words; launch 2 = the predicate waves over the box table, per-box pair counts.
-__global__ __launch_bounds__(256, 5) void targets_pool_kernel(PoolArgs pa, int n_pool, int n_items, GtTable gt, int Hc, int Wc, int stride, int h, int w, Ws ws,
+// (seven workgroups per CU -- the pool role needs 66 registers --: the 1600 items of a 2 x 800 x 1024 batch are resident at once, one item each)
+__global__ __launch_bounds__(256, 7) void targets_pool_kernel(PoolArgs pa, int n_pool, int n_items, GtTable gt, int Hc, int Wc, int stride, int h, int w, Ws ws,
                                                                unsigned int key) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (blockIdx.x == 0) {
@@ -1990,7 +1991,7 @@ int launch_targets(const bxi_image_batch* batch, const float* const* boxes_per_i
     const int n_items = (int)n_items64;
     const unsigned int key = targets_key(pa, batch->B, batch->Hc, batch->Wc, stride, dil, pr.n2max, gt.first);
     const bool pooled_in_launch = pool_vec_ok(batch, stride);
-    const int slots = 5 * device_cus();
+    const int slots = 7 * device_cus();
     int n_pool = 0;
     if (pooled_in_launch) {
         const int per = (n_items + slots - 1) / slots;
