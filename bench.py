@@ -975,7 +975,7 @@ def module_api(sets, dev, n):
         x.grad = None
 
     # the first ~second of eager autograd work in a process runs at up to THREE times the steady-state host time (measured:
-    # 239 -> 123 -> 75 us per call over the first 7000 calls, a plain torch graph alongside 155 -> 78 -> 62; tools/host_profile3.py):
+    # 239 -> 123 -> 75 us per call over the first 7000 calls, a plain torch graph alongside 155 -> 78 -> 62; profiles/NOTES.md R4-5):
     # warm until the figure has settled, bounded
     t_w, k_w, last = time.perf_counter(), 0, None
     while time.perf_counter() - t_w < 4.0:

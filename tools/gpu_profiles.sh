@@ -1,16 +1,27 @@
 #!/bin/bash
-# Developer helper (GPU box): everything profiles/ is built from.  Usage: tools/gpu_profiles.sh r03 [eval-only]
-TAG=${1:-r02}
+# Developer helper (GPU box): everything profiles/ is built from.  Usage: tools/gpu_profiles.sh r05 [eval-only]
+TAG=${1:-r05}
 ONLY=${2:-all}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-kernel-timing --no-extras"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_eager -o $TAG -- $CMD > $R/gpurun_out/prof_eager.log 2>&1
-cut -d, -f1-4 $R/gpurun_out/prof_eager/${TAG}_kernel_stats.csv | head -6
-# the two-launch form of the same evaluation (what larger instance counts, dilation 4 and the head-fused call run)
-BXI_ONE_LAUNCH=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_two_launch -o $TAG -- $CMD > $R/gpurun_out/prof_two_launch.log 2>&1
-cut -d, -f1-4 $R/gpurun_out/prof_two_launch/${TAG}_kernel_stats.csv | head -4
+prof() {   # prof <dir> <command...>: rocprofv3 kernel stats of one command -> gpurun_out/<dir>/<TAG>_kernel_stats.csv
+  local d=$1; shift
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$d -o $TAG -- "$@" > $R/gpurun_out/$d.log 2>&1
+  cut -d, -f1-4 $R/gpurun_out/$d/${TAG}_kernel_stats.csv | head -5
+}
+prof prof_eager $CMD
+# the two-launch form of the same evaluation (BXI_EVAL_TWO_LAUNCHES | BXI_EVAL_PRED_IN_PAIR = 34: what larger instance counts, dilation 3 / 4
+# and the head-fused call run); the shape real training runs, 128 instances (default form, folded form 64, long single launch 9);
+# the targets-ahead pair (bxi_boxinst_targets_f32 + BXI_EVAL_TARGETS_READY) at 32 and 128 instances
+prof prof_two_launch $CMD --flags 34
+prof prof_n128 $CMD --inst-per-box 4 --sets 6
+prof prof_n128_fold $CMD --inst-per-box 4 --sets 6 --flags 64
+prof prof_n128_long $CMD --inst-per-box 4 --sets 6 --flags 9
+prof prof_n64 $CMD --inst-per-box 2 --sets 6
+prof prof_targets_n32 python $R/tools/ab_forms.py --ipb 1 --forms ready,targets_only --reps 1 --steps 300 --sets 6
+prof prof_targets_n128 python $R/tools/ab_forms.py --ipb 4 --forms ready,targets_only --reps 1 --steps 300 --sets 6
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -o $TAG -- \
      python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-kernel-timing --no-extras > $R/gpurun_out/pmc_$c.log 2>&1
@@ -24,9 +35,9 @@ for t in pairwise_op dynamic_head head_fused discobox levelset tree_filter; do
   tail -c 300 $R/gpurun_out/${t}_bench.json | tr '\n' ' '; echo
 done
 cd $R
-# the per-wave trace needs the -DBXI_TRACE build of the library (tools/trace_eval.py's docstring); it is not kept in the tree
+# the per-wave trace needs the -DBXI_TRACE build of the library (tools/trace_forms.py's docstring); it is not kept in the tree
 if [ -f boxinstseg_amd/lib/libboxinst_hip_trace.so ]; then
-  python tools/trace_eval.py 2>&1 | grep -v amdgpu.ids > gpurun_out/block_trace.txt; tail -3 gpurun_out/block_trace.txt | cut -c1-300
+  (python tools/trace_forms.py; IPB=4 python tools/trace_forms.py; IPB=4 BXI_FLAGS=130 python tools/trace_forms.py) 2>&1 | grep -v amdgpu.ids > gpurun_out/block_trace.txt; tail -3 gpurun_out/block_trace.txt | cut -c1-300
 else
   rm -f gpurun_out/block_trace.txt; echo "no trace build: block trace skipped"
 fi
