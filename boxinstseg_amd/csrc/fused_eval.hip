@@ -1621,10 +1621,14 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 2 ? 4 : 3) : (D <= 2 ? 3 : 2))
 // evaluation).  8-row tiles are ~2300, one per wave, and the whole back half runs while the front half still streams: no kernel boundary,
 // the tile waves' arithmetic under the logit stream.  Nothing here waits for a workgroup LATER in the grid (no staying-on: `merge` = 0),
 // so the form makes progress at any residency; the pool workgroups go first (`pool_first`), the image side being the longer chain.
-template <int D, int R>
+// READY (BXI_EVAL_TARGETS_READY): an instantiation of its own -- no pool / predicate role, table workgroups at the head of the grid, sum W
+// gathered by the reducer workgroup -- so that the un-split kernel stays what it was (the same registers, no extra argument).
+template <int D, int R, bool READY>
 __global__ __launch_bounds__(256, (R == 4 ? kOneOcc : 3)) void eval1_kernel(PoolArgs pa, int n_pool, int n_items, int n_pb, int n_tb, InstArgs a, Ws ws_in, LossState st, ValidCells vc,
                                                         const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup, float n2max, int spin_limit,
-                                                        float* __restrict__ losses, float* __restrict__ g_logits, int vec, int merge, int ready, unsigned int key) {
+                                                        float* __restrict__ losses, float* __restrict__ g_logits, int vec, int merge, int ready_in, unsigned int key,
+                                                        int n_tabw_in) {
+    const int ready = READY ? ready_in : 0, n_tabw = READY ? n_tabw_in : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[16];
     Ws ws = ws_in;
@@ -1633,8 +1637,16 @@ __global__ __launch_bounds__(256, (R == 4 ? kOneOcc : 3)) void eval1_kernel(Pool
     const int Sn = (a.h + kSBlk - 1) / kSBlk;
     const int n_stream = N * Sn;
     const int blk = (int)blockIdx.x;
+    // n_tabw > 0 (targets ready): the table has workgroups of its own at the head of the grid.  With the image side in memory the table IS the
+    // head of every chain (tile waves, leaders), and as a duty of a stream wave behind its zero-fill and loads it came ~5 us into the launch
+    // (its drain waits for that wave's 8 KB of written-through stores) and made the first instance's band the last one.
+    if (READY && blk < n_tabw) {
+        const int k = blk * kWaves + (int)(threadIdx.x >> 6);
+        if (64 * k <= N) table_wave(a, pa.meta, D, R, with_tag(ws), st, k, false, -1, 0u);
+        return;
+    }
     // role of this workgroup: 0 stream, 1 pool, 2 leader, 3 predicate, 4 tile, 5 finisher, 6 reducer
-    int role, idx = blk;
+    int role, idx = blk - n_tabw;
     constexpr bool pool_first = R == 8;                      // the long form (a run-time switch here costs the short form a stack slot)
     const int n_a = pool_first ? n_pool : n_stream, n_b = pool_first ? n_stream : n_pool;      // grid: [stream][pool] or [pool][stream], then the back half
     if (idx < n_a) role = pool_first ? 1 : 0;
@@ -1654,7 +1666,7 @@ __global__ __launch_bounds__(256, (R == 4 ? kOneOcc : 3)) void eval1_kernel(Pool
         const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
         stream_block<true>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix, [&](Ws& w_) {
             w_ = with_tag(w_);
-            if ((threadIdx.x >> 6) == 0 && 64 * idx <= N) table_wave(a, pa.meta, D, R, w_, st, idx, false, ready ? -1 : 0, 0u);
+            if (!READY && (threadIdx.x >> 6) == 0 && 64 * idx <= N) table_wave(a, pa.meta, D, R, w_, st, idx, false, 0, 0u);
         });
         BXI_TW(0, tix, 7);
         if (!merge) return;
@@ -1668,7 +1680,7 @@ __global__ __launch_bounds__(256, (R == 4 ? kOneOcc : 3)) void eval1_kernel(Pool
         stayed = true;
         idx -= n_stream;                                                   // tile workgroup index idx + n_stream below
     }
-    if (role == 1) {
+    if (!READY && role == 1) {
         BXI_TW(0, tix, 0);
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
@@ -1685,9 +1697,9 @@ __global__ __launch_bounds__(256, (R == 4 ? kOneOcc : 3)) void eval1_kernel(Pool
         leader_block<true>(a, D, ws, st, idx, upp, g_logits, smem, red, spin_limit);
         return;
     }
-    if (role == 3) { pred_role<true>(a, vc, ws, D, n2max, idx, n_pb, n_items, spin_limit); return; }
+    if (!READY && role == 3) { pred_role<true>(a, vc, ws, D, n2max, idx, n_pb, n_items, spin_limit); return; }
     if (role == 6) {
-        if (!ready) reducer_role<true>(ws, 0, n_items, spin_limit);
+        if (!READY) reducer_role<true>(ws, 0, n_items, spin_limit);
         else if (threadIdx.x < 64) {
             // targets ready: sum W is a gather over the instances' boxes, published once the table says this evaluation's polled words are zeroed
             // (the table wave is a wave of the first stream workgroup: earlier in the grid, waiting for nobody)
@@ -2095,11 +2107,13 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     // Measured (2 x 800 x 1024, us per evaluation, one box): 128 instances long form 36.9 vs two launches 37.1, 96: 32.3 vs 31.6 -- no gain
     // (three workgroups per CU slow the front half down by what the kernel boundary costs), so the library takes the long form only where it
     // is asked to (BXI_EVAL_SINGLE_LAUNCH with 8-row tiles) and, with the targets ready (no front half to slow down), from kLongFrom on.
-    // With the targets ready and fewer instances two launches win over the short form (14.6 vs 15.1 at 32, 19.1 vs 19.9 at 64).
+    // With the targets ready the short form has table workgroups of its own at the head of the grid (eval1_kernel<D, R, true>): 14.4 vs 14.6 us
+    // for two launches at 32 instances, 18.6 vs 19.0 at 64 (as a duty of a stream wave behind its loads the table came ~5 us into the launch:
+    // 15.1 / 19.9).
     // (Measured and dropped: a second launch that reads its predicate words by plain loads ahead of the logits and has sum W up front --
     // 14.85 vs 14.65 at 32 instances, 31.9 vs 31.0 at 128: the tile role is bound by its arithmetic and memory pipeline, not by that hop.)
     const bool long_form = R == 8 && dil <= 2 && ((flags & kFlagSingle) || (ready && a.N >= BXI_KNOB("BXI_LONG_FROM", kLongFrom) && whole_device && !(flags & kFlagShared)));
-    const bool short_ok = one_fits && !(ready && BXI_KNOB("BXI_READY_TWO", 1));
+    const bool short_ok = one_fits && !(ready && BXI_KNOB("BXI_READY_TWO", 0));
     if (env_one && !(flags & (kFlagTwo | kFlagPredInPair | kFlagPredInPrep)) && (short_ok || env_one == 2 || (flags & kFlagSingle) || long_form) && !head && pooled_in_launch &&
         (R == 4 || long_form) && dil <= 2 && !pr.zero_bit) {
         const int env_one_pool = BXI_KNOB("BXI_ONE_POOL_WGS", 0);
@@ -2138,15 +2152,22 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         if (lds < sizeof(float) * (size_t)kWaves * (R + 1) * 64) lds = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
         if (lds < 2 * sizeof(float) * (size_t)(a.h + a.w) + 16) lds = 2 * sizeof(float) * (size_t)(a.h + a.w) + 16;
         if (lds <= 36 * 1024) {                             // four workgroups per CU must fit
-            const unsigned grid = (unsigned)(n_stream + n_pool + n_pb + 1 + a.N + (int)n_tb + 1);
+            const int n_tabw = ready ? ((a.N + 64) / 64 + kWaves - 1) / kWaves : 0;
+            const unsigned grid = (unsigned)(n_tabw + n_stream + n_pool + n_pb + 1 + a.N + (int)n_tb + 1);
 #define BXI_ONE_CASE(DD)                                                                                                                    \
             case DD:                                                                                                                        \
-                if (long_form)                                                                                                              \
-                    BXI_LAUNCH(ready ? "eval1_ready" : "eval1", s, (eval1_kernel<DD, 8>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, \
-                               up_prj, up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge, ready, key);          \
+                if (long_form && ready)                                                                                                     \
+                    BXI_LAUNCH("eval1_ready", s, (eval1_kernel<DD, 8, true>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, \
+                               up_prj, up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge, ready, key, n_tabw);                  \
+                else if (long_form)                                                                                                         \
+                    BXI_LAUNCH("eval1", s, (eval1_kernel<DD, 8, false>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, \
+                               up_prj, up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge, ready, key, n_tabw);                  \
+                else if (ready)                                                                                                             \
+                    BXI_LAUNCH("eval1_ready", s, (eval1_kernel<DD, 4, true>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, \
+                               up_prj, up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge, ready, key, n_tabw);                  \
                 else                                                                                                                        \
-                    BXI_LAUNCH(ready ? "eval1_ready" : "eval1", s, (eval1_kernel<DD, 4>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, \
-                               up_prj, up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge, ready, key);          \
+                    BXI_LAUNCH("eval1", s, (eval1_kernel<DD, 4, false>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, \
+                               up_prj, up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge, ready, key, n_tabw);                  \
                 break;
             switch (dil) { BXI_ONE_CASE(1) BXI_ONE_CASE(2) default: return BXI_ERR_UNSUPPORTED; }
 #undef BXI_ONE_CASE
