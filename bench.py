@@ -888,7 +888,7 @@ def rows_extra():
         t_ = ev(lambda: lib.bxi_lcm_affinity_f32(img96.data_ptr(), N, 3, 96, 96, 2, 0.3, aff.data_ptr(), st), n=100)
         nb = N * (3 + 8) * 96 * 96 * 4
         fr['lcm_affinity_kernel'] = {'call': 'bxi_lcm_affinity_f32, 100 x 3 x 96 x 96 -> 100 x 8 x 96 x 96', 'us': t_, 'bytes': nb, 'frac': frac(nb, t_),
-                                     'bytes_model': 'images read + 8 affinity planes written (4 MB: a launch of this size is bound by its ramp, ~2 us, not by HBM)'}
+                                     'bytes_model': 'images read + 8 affinity planes written; bound by its double-precision statistics (a square root and a division per pixel and channel), not by HBM'}
         from boxinstseg_amd.discobox import meanfield_forward, meanfield_kernel
         Bm, Nm = 2, 16
         ker = meanfield_kernel(torch.rand(Bm, 3, H, W, generator=g).to(dev))

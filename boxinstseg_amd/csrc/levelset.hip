@@ -270,13 +270,17 @@ __global__ __launch_bounds__(256) void lcm_affinity_kernel(const float* __restri
 #pragma unroll
         for (int k = 0; k < 8; ++k) var += (v[k] - mean) * (v[k] - mean);
         const double sd = sqrt(var / 7.0) + 1e-8;                  // torch.std: unbiased (:116)
+        // ONE double-precision division per pixel and channel instead of sixteen (each is ~40 instructions: the kernel took 49 us for 4 MB):
+        // |v - ip| / sd / alpha = |v - ip| * (1 / (sd alpha)) to within two roundings of a double, nine digits below the f32 the result becomes
+        const double inv = 1.0 / (sd * (double)alpha);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const double z = fabs(v[k] - ip) / sd / (double)alpha; ed[k] -= z * z; }
+        for (int k = 0; k < 8; ++k) { const double z = fabs(v[k] - ip) * inv; ed[k] -= z * z; }
     }
     float e[8];
     float m = -INFINITY;
+    const double invC = 1.0 / (double)C;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { e[k] = (float)(ed[k] / (double)C); m = fmaxf(m, e[k]); }      // .mean(dim=1)
+    for (int k = 0; k < 8; ++k) { e[k] = (float)(ed[k] * invC); m = fmaxf(m, e[k]); }      // .mean(dim=1)
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { e[k] = expf(e[k] - m); s += e[k]; }

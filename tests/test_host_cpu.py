@@ -56,6 +56,16 @@ def test_abi_argument_validation_without_device():
     assert lib.bxi_pairwise_nlog_forward_f32(None, 1, 4, 4, 3, 0, None, None) == -3       # dilation < 1
     assert lib.bxi_pairwise_nlog_forward_f32(None, 1, 4, 4, 3, 2, None, None) == -1       # NULL pointers
     assert lib.bxi_pairwise_nlog_forward_f32(None, 0, 4, 4, 3, 2, None, None) == 0        # N == 0: no-op
+    # the targets-ahead entry point (ABI 6): NULL pointers, an even window, a window the fused path is not built for -- before anything touches a device
+    assert lib.bxi_boxinst_targets_f32(None, None, None, 4, 3, 2, 0.3, None, 0, None) == -1
+    b = _lib.ImageBatch(); b.B, b.Hc, b.Wc = 1, 64, 64
+    import ctypes as C
+    ptrs, cnt = (C.c_void_p * 1)(0), (C.c_int * 1)(0)
+    assert lib.bxi_boxinst_targets_f32(C.byref(b), ptrs, cnt, 4, 4, 2, 0.3, None, 0, None) == -3       # even window
+    assert lib.bxi_boxinst_targets_f32(C.byref(b), ptrs, cnt, 4, 5, 2, 0.3, None, 0, None) == -4       # 5 x 5: composed from the op-level kernels instead
+    assert lib.bxi_boxinst_targets_f32(C.byref(b), ptrs, cnt, 4, 3, 2, 0.3, None, 0, None) == -5       # no workspace
+    # the evaluation's workspace now carries the targets regions (box table + per-box pair counts: ~1 MB) whatever N
+    assert lib.bxi_boxinst_eval_workspace_bytes(2, 800, 1024, 4, 32) > 1024 * 8 * 128
     assert lib.bxi_boxinst_loss_workspace_bytes(32, 200, 256) > 32 * 25 * 256 * 5
     assert lib.bxi_boxinst_loss_workspace_bytes(-1, 200, 256) == 0
     assert lib.bxi_boxinst_loss_state_bytes(32, 200, 256) >= 32 * 456 * 8
