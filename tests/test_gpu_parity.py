@@ -688,6 +688,51 @@ def test_loss_box_edge_cases(dev):
     _check_cfg(d, dev)
 
 
+def _fuzz_case(seed):
+    rng = np.random.default_rng(9000 + seed)
+    stride = int(rng.choice([4, 4, 4, 8]))
+    B = int(rng.integers(1, 4))
+    H = int(rng.integers(3, 14)) * 16 + int(rng.choice([0, 0, stride, 2 * stride]))
+    W = int(rng.integers(3, 20)) * 16 + int(rng.choice([0, 0, stride, 3 * stride]))
+    shapes = [(int(rng.integers(H // 2, H + 1)), int(rng.integers(W // 2, W + 1))) for _ in range(B)]
+    d = synthetic.make_batch(B=B, H=H, W=W, boxes_per_img=int(rng.integers(0, 7)), inst_per_box=int(rng.integers(1, 4)),
+                             stride=stride, seed=100 + seed, img_shapes=shapes, min_box=8.0, max_box=float(max(H, W)),
+                             logit_scale=float(rng.choice([0.5, 2.0, 6.0])))
+    kw = dict(pairwise_dilation=int(rng.integers(1, 4)), pairwise_color_thresh=float(rng.choice([0.1, 0.3, 0.5, 0.8])),
+              bottom_pixels_removed=int(rng.integers(0, 40)))
+    warm = float(rng.choice([1.0, 0.37]))
+    up = (float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.5, 2.0)))
+    return d, kw, warm, up
+
+
+@pytest.mark.parametrize('seed', list(range(100, 112)))
+def test_loss_fuzz_forms_and_targets_ahead(dev, seed):
+    """The same seeded shapes as test_loss_fuzz through every OTHER form of the evaluation -- two launches with the predicates in the second /
+    folded into the first, the long single launch, and the targets-ahead split (bxi_boxinst_targets_f32 + BXI_EVAL_TARGETS_READY, also
+    through the generic pooling path of stride 8) --: each must give the default form's bits when its tile height is the default's
+    (the long form's 8-row tiles: within 1e-4 of it), with status 0."""
+    from boxinstseg_amd import _lib, functional as Fh
+    d, kw, warm, up = _fuzz_case(seed)
+    if d['N'] == 0:
+        return
+    want = hip_loss(d, dev, warmup=warm, up=up, **kw)
+    rows = Fh.last_eval_status()[1]
+    for form in (_lib.EVAL_TWO_LAUNCHES | _lib.EVAL_PRED_IN_PAIR, _lib.EVAL_PRED_IN_PREP, _lib.EVAL_SINGLE_LAUNCH | _lib.EVAL_TILE_ROWS_8):
+        with Fh.eval_flags(form):
+            got = hip_loss(d, dev, warmup=warm, up=up, **kw)
+        if Fh.last_eval_status()[1] == rows:
+            assert got[0] == want[0] and got[1] == want[1] and np.array_equal(got[2], want[2]), (form, got[:2], want[:2])
+        else:
+            assert got[0] == want[0] and rel(got[1], want[1]) <= TOL, (form, got[:2], want[:2])
+            assert np.abs(got[2] - want[2]).max() <= TOL * np.abs(want[2]).max()
+    got = _loss_with_targets(d, dev, warmup=warm, up=up, **kw)
+    assert Fh.last_eval_status()[0] == 0
+    if Fh.last_eval_status()[1] == rows:
+        assert got[0] == want[0] and got[1] == want[1] and np.array_equal(got[2], want[2]), (got[:2], want[:2])
+    else:
+        assert got[0] == want[0] and rel(got[1], want[1]) <= TOL and np.abs(got[2] - want[2]).max() <= TOL * np.abs(want[2]).max()
+
+
 @pytest.mark.parametrize('seed', list(range(24)))
 def test_loss_fuzz(dev, seed):
     """Seeded sweep over shapes and parameters nobody hand-picked: canvas sizes that are / are not multiples of the
@@ -827,7 +872,7 @@ def test_workspace_epoch_advances_once_per_evaluation_and_follows_the_workspace_
 # ---------------------------------------------------------------------------------------------
 # targets ahead of the evaluation (bxi_boxinst_targets_f32 + BXI_EVAL_TARGETS_READY)
 # ---------------------------------------------------------------------------------------------
-def _loss_with_targets(d, dev, stream=None, **kw):
+def _loss_with_targets(d, dev, stream=None, warmup=1.0, up=None, **kw):
     from boxinstseg_amd import boxinst_mask_loss, functional as Fh
     Fh.DEBUG_KEEP_LAST = True
     t = to_dev(d, dev)
@@ -835,8 +880,12 @@ def _loss_with_targets(d, dev, stream=None, **kw):
                             **{k: v for k, v in kw.items() if k in ('pairwise_dilation', 'pairwise_color_thresh', 'bottom_pixels_removed')})
     assert tg is not None
     x = t['logits'].clone().requires_grad_(True)
-    out = boxinst_mask_loss(x, t['gt_inds'], t['gt_bboxes'], imgs=t['imgs'], img_metas=d['img_metas'], out_stride=d['stride'], targets=tg, **kw)
-    (out['loss_prj'] + out['loss_pairwise']).backward()
+    out = boxinst_mask_loss(x, t['gt_inds'], t['gt_bboxes'], imgs=t['imgs'], img_metas=d['img_metas'], out_stride=d['stride'], targets=tg,
+                            warmup_factor=warmup, **kw)
+    if up is None:
+        (out['loss_prj'] + out['loss_pairwise']).backward()
+    else:
+        (up[0] * out['loss_prj'] + up[1] * out['loss_pairwise']).backward()
     torch.cuda.synchronize()
     return float(out['loss_prj'].detach()), float(out['loss_pairwise'].detach()), x.grad.cpu().numpy()[:, 0]
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): the seeded fuzz tests of the suite over many more seeds than the suite carries
-(`python tools/extended_fuzz.py 24 400`): main loss path, dynamic head, DiscoBox, tree_filter.  Prints failures, exits 1 on any."""
+(`python tools/extended_fuzz.py 24 400`): main loss path (default form; every other form + the targets-ahead split against it), dynamic head, DiscoBox, tree_filter.  Prints failures, exits 1 on any."""
 import os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
@@ -10,7 +10,7 @@ lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (24, 200
 dev = torch.device('cuda:0')
 from tests import test_gpu_parity as tp, test_gpu_dynamic_head as td, test_gpu_discobox as tdb, test_gpu_tree_filter as tt, test_gpu_levelset as tl
 import numpy as np
-suites = [('loss', lambda s: tp.test_loss_fuzz(dev, s)), ('dynamic_head', lambda s: td.test_dynamic_head_fuzz(dev, s)),
+suites = [('loss', lambda s: tp.test_loss_fuzz(dev, s)), ('loss_forms', lambda s: tp.test_loss_fuzz_forms_and_targets_ahead(dev, s)), ('dynamic_head', lambda s: td.test_dynamic_head_fuzz(dev, s)),
           ('discobox', lambda s: tdb.test_meanfield_fuzz(True, dev, s)),
           ('tree_filter', lambda s: tt.test_tree_filter_fuzz(True, dev, s)), ('levelset', lambda s: levelset_case(s)), ('lcm', lambda s: lcm_case(s))]
 
