@@ -714,29 +714,32 @@ def targets_ahead(lib, _lib, sets, dev, stream, steps, with_pipeline=True):
             else:
                 ev(s, 0, st)
 
-        res = {}
+        # the three variants ALTERNATE, one event pair per iteration, medians: the matrix products' own duration drifts by several us over a
+        # run (clocks), more than what is being measured
+        variants = (('standin_alone', None), ('unsplit', False), ('targets_under_the_standin', True))
+        pairs = {name: [] for name, _ in variants}
         with torch.cuda.stream(stream):
-            for name, split in (('unsplit', False), ('targets_under_the_standin', True), ('standin_alone', None)):
-                def one(i):
-                    if split is None:
-                        backbone()
-                    else:
-                        iteration(split, i)
-                for i in range(20):
-                    one(i)
-                torch.cuda.synchronize(dev)
+            for i in range(30):
+                iteration(bool(i & 1), i)
+            torch.cuda.synchronize(dev)
+            for i in range(3 * 150):
+                name, split = variants[i % 3]
                 a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a_.record(stream)
-                for i in range(200):
-                    one(i)
+                if split is None:
+                    backbone()
+                else:
+                    iteration(split, i // 3)
                 b_.record(stream)
-                torch.cuda.synchronize(dev)
-                res[name] = a_.elapsed_time(b_) / 200 * 1e3
+                pairs[name].append((a_, b_))
+            torch.cuda.synchronize(dev)
+        res = {name: float(np.median([a_.elapsed_time(b_) * 1e3 for a_, b_ in evs])) for name, evs in pairs.items()}
         out['under_a_backbone_standin'] = {
             'us_per_iteration': res, 'loss_cost_unsplit_us': res['unsplit'] - res['standin_alone'],
             'loss_cost_with_targets_ahead_us': res['targets_under_the_standin'] - res['standin_alone'],
             'standin': 'two 4096^3 bf16 matrix products per iteration on the main stream (torch.mm)',
-            'note': 'the second figure contains whatever the concurrent targets kernels cost the stand-in'}
+            'note': 'medians over 150 iterations per variant, the variants alternating (one event pair per iteration); the second figure contains '
+                    'whatever the concurrent targets kernels cost the stand-in'}
     except Exception as e:
         out['under_a_backbone_standin'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         torch.cuda.synchronize(dev)
