@@ -132,6 +132,7 @@ int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_insta
                               void* stream) {
     if (!batch_host || !inst_host) return BXI_ERR_NULL_POINTER;
     if (bad_eval_flags(flags)) return BXI_ERR_BAD_ARGUMENT;      // (the forms the head-fused first launch is not built in are not taken: two launches)
+    if (flags & BXI_EVAL_TARGETS_READY) return BXI_ERR_UNSUPPORTED;   // (targets ahead: bxi_dynamic_mask_forward_f32 + bxi_boxinst_eval_f32)
     if (size < 1 || (size & 1) == 0 || dilation < 1) return BXI_ERR_BAD_ARGUMENT;
     if (size != 3 || !bxi::fused_eval_supported(dilation)) return BXI_ERR_UNSUPPORTED;
     const int stride = inst_host->stride;

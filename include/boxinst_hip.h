@@ -289,7 +289,8 @@ int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances*
  * bxi_dynamic_mask_backward_f32 with g_logits, read them).  One launch, its kernel boundary and one 6.5 MB read fewer than
  * bxi_dynamic_mask_forward_f32 + bxi_boxinst_eval_f32 (20 us against 13.4 + 11.4 us at 2 x 800 x 1024 x 32).  Built for
  * factor == 2, C in {8, 16}, 16-byte aligned rows (w % 4 == 0), the 4x-pooled image path; anything else (and N == 0) returns
- * BXI_ERR_UNSUPPORTED: call the two entries instead.  Workspace / state / upstream factors as bxi_boxinst_eval_f32. */
+ * BXI_ERR_UNSUPPORTED: call the two entries instead (also with BXI_EVAL_TARGETS_READY: the head-fused launch computes the image side itself).
+ * Workspace / state / upstream factors as bxi_boxinst_eval_f32. */
 int bxi_boxinst_head_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host,
                               const float* feat, int C, int Hs, int Ws, const float* params, const float* coors,
                               const int64_t* level_inds, const int64_t* img_inds, const float* sizes_of_interest, int n_levels,
