@@ -291,10 +291,11 @@ def _workspace(dev: torch.device, stream: int, canvas: tuple, N: int) -> torch.T
 class PreparedTargets:
     """What :func:`prepare_targets` leaves: a workspace holding Lab, the predicate words and the per-box pair counts of ONE batch, the
     event that says they are there, and what they were computed from (so that ``loss()`` can tell whether they are its batch's)."""
-    __slots__ = ('ws', 'n_cap', 'event', 'match', 'slot', 'refs')
+    __slots__ = ('ws', 'n_cap', 'event', 'match', 'slot', 'refs', 'gen')
 
     def matches(self, imgs: torch.Tensor, gt_bboxes, cfg: Dict) -> bool:
-        return self.match == _targets_match_key(imgs, gt_bboxes, cfg)
+        # (the slot's generation: a later prepare_targets that took the same rotating workspace has overwritten these targets)
+        return self.slot.get('gen') == self.gen and self.match == _targets_match_key(imgs, gt_bboxes, cfg)
 
 
 def _targets_match_key(imgs, gt_bboxes, cfg) -> tuple:
@@ -336,7 +337,7 @@ def prepare_targets(imgs: torch.Tensor, img_metas: Sequence[dict], gt_bboxes: Se
         if len(_TLS.prepared) >= 16:
             _TLS.prepared.pop(next(iter(_TLS.prepared)))
         need = max(lib.bxi_boxinst_eval_workspace_bytes(*canvas, _PREPARED_N_CAP), 256)
-        slots = _TLS.prepared[key] = [dict(ws=torch.zeros(need, dtype=torch.uint8, device=dev), free=None) for _ in range(_PREPARED_SLOTS)]
+        slots = _TLS.prepared[key] = [dict(ws=torch.zeros(need, dtype=torch.uint8, device=dev), free=None, gen=0) for _ in range(_PREPARED_SLOTS)]
         _TLS.prepared_next[key] = 0
     k = _TLS.prepared_next[key]
     _TLS.prepared_next[key] = (k + 1) % len(slots)
@@ -364,7 +365,8 @@ def prepare_targets(imgs: torch.Tensor, img_metas: Sequence[dict], gt_bboxes: Se
             if b.numel():
                 b.record_stream(st)
     t = PreparedTargets()
-    t.ws, t.n_cap, t.event, t.slot = slot['ws'], _PREPARED_N_CAP, ev, slot
+    slot['gen'] += 1
+    t.ws, t.n_cap, t.event, t.slot, t.gen = slot['ws'], _PREPARED_N_CAP, ev, slot, slot['gen']
     cfg = dict(out_stride=out_stride, bottom_pixels_removed=bottom_pixels_removed, pairwise_size=pairwise_size,
                pairwise_dilation=pairwise_dilation, pairwise_color_thresh=pairwise_color_thresh)
     t.match = _targets_match_key(imgs_c, boxes, cfg)

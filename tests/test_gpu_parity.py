@@ -948,6 +948,18 @@ def test_targets_through_the_module_api_and_stale_targets_are_ignored(dev):
         outs.append((float(out['loss_prj']), float(out['loss_pairwise']), x.grad.cpu().numpy()))
     for o in outs[1:]:
         assert o[0] == outs[0][0] and o[1] == outs[0][1] and np.array_equal(o[2], outs[0][2])
+    # targets whose rotating workspace a LATER prepare_targets took (three calls, two workspaces per canvas) are not used either
+    from boxinstseg_amd import boxinst_mask_loss, functional as Fh
+    first = Fh.prepare_targets(t['imgs'], d['img_metas'], t['gt_bboxes'])
+    for _ in range(2):
+        assert Fh.prepare_targets(t2['imgs'], d2['img_metas'], t2['gt_bboxes']) is not None
+    assert not first.matches(t['imgs'], t['gt_bboxes'], dict(out_stride=4, bottom_pixels_removed=10, pairwise_size=3, pairwise_dilation=2, pairwise_color_thresh=0.3))
+    x = t['logits'].clone().requires_grad_(True)
+    out = boxinst_mask_loss(x, t['gt_inds'], t['gt_bboxes'], imgs=t['imgs'], img_metas=d['img_metas'], targets=first)
+    (out['loss_prj'] + out['loss_pairwise']).backward()
+    torch.cuda.synchronize()
+    want = hip_loss(d, dev)                       # (warm-up factor 1, as the direct call above)
+    assert float(out['loss_prj']) == want[0] and float(out['loss_pairwise']) == want[1] and np.array_equal(x.grad.cpu().numpy()[:, 0], want[2])
 
 
 def test_targets_that_do_not_belong_to_the_evaluation_are_loud(dev):
