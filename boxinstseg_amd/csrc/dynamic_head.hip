@@ -17,7 +17,10 @@
 //                  (each weight feeds both), y goes to LDS, the up-sampled tile is written with float2/float4
 //                  stores.  Reads the feature tile (L2-resident, 4*C B per y pixel per instance), writes
 //                  4*f^2 B per y pixel per instance.
-// dyn_bwd_kernel   grid = B x tiles x kSlots.  A workgroup owns one 8x32 tile of one image and every
+// dyn_bwd2_kernel  (factors 1 and 2: every shipped configuration) the same work as dyn_bwd_kernel below at FOUR workgroups per CU: <= 128
+//                  registers, 38 KB of LDS -- the operand rows in two passes of 2 x 5 output blocks, the tile's features staged once;
+//                  described at the kernel.
+// dyn_bwd_kernel   (factor 4 and the run-time factor) grid = B x tiles x kSlots.  A workgroup owns one 8x32 tile of one image and every
 //                  kSlots-th instance of that image (list compacted by wave 0 with ballots):
 //                    phase 1 (thread = pixel): dy by the transposed interpolation (a fixed (2f-1)^2 tap window,
 //                       offsets/weights kept in registers, the next instance's taps prefetched), forward
@@ -29,7 +32,8 @@
 //                       -> one partial per (instance, tile).
 //                  No atomics: partials are reduced in fixed order by dyn_reduce_kernel.
 // dyn_reduce_kernel  g_params[n,q] = sum over tiles ; g_feat[b,c,p] = sum over slots.
-// Measured (MI355X, B=2 C=16 100x128 -> 200x256, rocprofv3): N=32: fwd 13.3 us, bwd 29.6 us, reduce 6.0 us
+// Measured (MI355X, B=2 C=16 100x128 -> 200x256, rocprofv3, round 5): N=32: fwd 12.0 us, bwd 27.2-27.8 us (dyn_bwd_kernel: 28.2-28.8), reduce 5.6 us;
+// N=128: fwd 31 us, bwd 70.0-70.8 us (dyn_bwd_kernel: 78.6-79.4), reduce 6.3 us
 // (PyTorch-ROCm running the reference's op sequence: 228 us forward, 785 us forward+backward).
 #include "dynamic_head_device.hpp"
 
@@ -386,6 +390,289 @@ void dyn_bwd_kernel(DynArgs a, const float* __restrict__ params, const float* __
     BXI_T(4, blockIdx.x, 4);
 }
 
+// ---- backward, second form: four workgroups per CU ---------------------------------------------------------------------
+// The same two phases per (tile, instance) with two thirds of the LDS and 128 registers, so that FOUR workgroups share a CU instead of two
+// (the kernel is a chain of scalar-load waits, LDS round trips and barriers: a SIMD that holds two waves idles through most of them):
+//   * the tile's feature rows are the same for every instance: staged ONCE (C rows), read back per instance instead of held in registers;
+//   * the operand rows of an instance go through one 16-row region in TWO passes -- (dh2, h1) -> dW1, db1 ; (dh1 | rel, features) -> dW0, db0 --
+//     each a 2 x 5 block of outputs per thread (20 accumulators instead of 40).  LDS rows (256 floats each):
+//         [rel 0..1][features 0..C-1][ones] [region 0..15][ones][pad]      the columns of a pass are CONSECUTIVE rows: one offset register
+//     (pass A: rel, features, ones, <first region row: an output nobody stores>; pass B: region 8..15 = h1, ones, pad);
+//   * dW2 / db2 (nine sums of dout x h2) never touch the operand rows: products in registers, reduced over the 16 lanes of a DPP row, sixteen
+//     row partials per workgroup summed in fixed order by nine threads;
+//   * the taps of dy are separable (three row offsets / weights, three column offsets / weights) and are loaded at the top of an instance,
+//     consumed after the forward pass: nothing of them is live during the contractions.
+// Run-to-run identical like the first form (no atomics; fixed summation order), not bit-identical to it (the order differs).
+template <int C, bool REL, int F>
+__global__ __launch_bounds__(256, 4)
+void dyn_bwd2_kernel(DynArgs a, const float* __restrict__ params, const float* __restrict__ params_again,
+                     const float* __restrict__ g_logits, float* __restrict__ feat_part /*[slots,B,C,H,W]*/,
+                     float* __restrict__ param_part /*[N,T,P]*/, int slots) {
+    static_assert(F == 1 || F == 2, "the (2F-1)^2 taps of dy are kept per thread");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using D = Dyn<C, REL>;
+    constexpr int CIN = D::CIN, off = REL ? 2 : 0;
+    constexpr int kOnesA = CIN, RX = CIN + 1, kOnesB = RX + 16;   // rows; RX + 17 = pad
+    constexpr int kChunkN = 256;
+    float* rows = lds;                                      // [CIN + 1 + 16 + 2][kRowPad]
+    __shared__ int mine[kChunkN + 2];
+    __shared__ int n_mine;
+    __shared__ float red2[16 * 12];                         // dW2 / db2: one partial per DPP row of the workgroup
+    const int tiles_x = (a.W + kYC - 1) / kYC, tiles_y = (a.H + kYR - 1) / kYR, T = tiles_x * tiles_y;
+    int t = blockIdx.x;
+    const int slot = t % slots; t /= slots;
+    const int tile = t % T;
+    const int b = t / T;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int tid = threadIdx.x;
+    const int lr = tid / kYC, lc = tid % kYC;
+    const int r = ty * kYR + lr, c = tx * kYC + lc;
+    const bool valid = r < a.H && c < a.W;
+    const int rr = min(r, a.H - 1), cc = min(c, a.W - 1);
+    const int OH = a.H * F, OW = a.W * F;
+    constexpr int P = D::P, w1 = D::W1, w2 = D::W2;
+    const int64_t HW = (int64_t)a.H * a.W;
+    rows[kOnesA * kRowPad + tid] = 1.f;
+    rows[kOnesB * kRowPad + tid] = 1.f;
+    rows[(kOnesB + 1) * kRowPad + tid] = 0.f;
+    {
+        const float* fb = a.feat + (int64_t)b * C * HW;
+        const unsigned po = (unsigned)(rr * a.W + cc);
+        float xf[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) xf[k] = (fb + (int64_t)k * HW)[po];
+#pragma unroll
+        for (int k = 0; k < C; ++k) rows[(off + k) * kRowPad + tid] = valid ? xf[k] : 0.f;      // pixels outside the map stage zeros
+    }
+    // d y[r][c] = sum_i wy[i] sum_j wx[j] g[Rs + i][Cs + j] (gather_dy's window, separable)
+    constexpr int NT = 2 * F - 1;
+    unsigned roff[NT], coff[NT];
+    float wy[NT], wx[NT];
+    {
+        const int half = F / 2;
+        const int Rs = rr == 0 ? 0 : F * rr - F + 1 + half, Cs = cc == 0 ? 0 : F * cc - F + 1 + half;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            wy[i] = valid && Rs + i < OH ? upsample_weight(Rs + i, rr, F, a.H) : 0.f;              // (dout = 0 outside the map)
+            wx[i] = Cs + i < OW ? upsample_weight(Cs + i, cc, F, a.W) : 0.f;
+            roff[i] = (unsigned)(min(Rs + i, OH - 1) * OW);
+            coff[i] = (unsigned)min(Cs + i, OW - 1);
+        }
+    }
+
+    v2f dfeat[C / 2];
+#pragma unroll
+    for (int k = 0; k < C / 2; ++k) dfeat[k] = v2f{0.f, 0.f};
+
+    // ---- the thread's two phase-2 roles: a 2 x 5 block of dW0|db0 (pass A) and of dW1|db1 (pass B) over the pixels {4 (16 j + sl) .. +3} ----
+    constexpr int NG0 = (CIN + 1 + 4) / 5, NBA = 4 * NG0, NBB = 8;
+    static_assert(NBA * 16 <= 256, "pass-A blocks must fit the workgroup");
+    static_assert(5 * NG0 - 1 <= RX + 17, "the padded columns of pass A stay inside the rows");
+    const int blk = tid >> 4, sl = tid & 15;
+    const unsigned long long m_b0 = __ballot(sl & 1), m_b1 = __ballot(sl & 2), m_b2 = __ballot(sl & 4), m_b3 = __ballot(sl & 8);
+    constexpr unsigned kNone = 0xffffffffu;                 // (unsigned element offsets: the stores address as base + 32-bit offset)
+    int aA, bA, aB, bB;
+    unsigned qA = kNone, qB = kNone;
+    {
+        const int ex = sl / 5, ey = sl % 5;                  // the output this lane stores: element sl < 10 of the block
+        int og = blk / NG0, ig = blk % NG0;
+        aA = (RX + 2 * og) * kRowPad + 4 * sl;
+        bA = (5 * ig) * kRowPad + 4 * sl;                    // columns = rows 5 ig .. 5 ig + 4: inputs, ones (row CIN), then nobody's
+        if (sl < 10 && blk < NBA) {
+            const int i = 5 * ig + ey;
+            if (i < CIN) qA = (2 * og + ex) * CIN + i;
+            else if (i == CIN) qA = D::B0 + 2 * og + ex;
+        }
+        og = (blk / 2) & 3; ig = blk % 2;
+        aB = (RX + 2 * og) * kRowPad + 4 * sl;
+        bB = (RX + kDC + 5 * ig) * kRowPad + 4 * sl;         // columns = h1 0..7, ones, pad
+        if (sl < 10 && blk < NBB) {
+            const int i = 5 * ig + ey;
+            if (i < kDC) qB = w1 + (2 * og + ex) * kDC + i;
+            else if (i == kDC) qB = D::B1 + 2 * og + ex;
+        }
+    }
+    // one pass: acc[x][y] = sum over the 256 staged pixels of row (a0 + x) x row (b0 + y); lane sl < 10 of a block stores element sl
+    auto contract = [&](int a0, int b0, unsigned q, float* dst) {
+        v2f acc2[2][5];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 5; ++y) acc2[x][y] = v2f{0.f, 0.f};
+#pragma unroll 1
+        for (int jj = 0; jj < kYR * kYC / 64; ++jj) {
+            float4 av[2], bv[5];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) av[x] = *reinterpret_cast<const float4*>(rows + a0 + x * kRowPad + jj * 64);
+#pragma unroll
+            for (int y = 0; y < 5; ++y) bv[y] = *reinterpret_cast<const float4*>(rows + b0 + y * kRowPad + jj * 64);
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 5; ++y) {
+                    acc2[x][y] = pk_fma(v2f{av[x].x, av[x].y}, v2f{bv[y].x, bv[y].y}, acc2[x][y]);
+                    acc2[x][y] = pk_fma(v2f{av[x].z, av[x].w}, v2f{bv[y].z, bv[y].w}, acc2[x][y]);
+                }
+        }
+        float v[10];
+#pragma unroll
+        for (int e = 0; e < 10; ++e) v[e] = row16_sum(acc2[e / 5][e % 5].x + acc2[e / 5][e % 5].y);
+        float l1[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) l1[i] = lane_select(m_b0, v[2 * i + 1], v[2 * i]);
+        const float l2a = lane_select(m_b1, l1[1], l1[0]), l2b = lane_select(m_b1, l1[3], l1[2]);
+        const float l3 = lane_select(m_b2, l2b, l2a);
+        const float out = lane_select(m_b3, l1[4], l3);
+        // (base in scalar registers + a 32-bit byte offset: left to the compiler the address becomes a 64-bit register pair per store, kept -- and
+        //  spilled -- across the whole instance loop)
+        if (q != kNone) asm volatile("global_store_dword %0, %1, %2" ::"v"(q * 4u), "v"(out), "s"(dst) : "memory");
+    };
+
+    int seen = 0;
+    for (int nb = 0; nb < a.N; nb += kChunkN) {
+        const int cnt = min(kChunkN, a.N - nb);
+        __syncthreads();
+        if (tid < kWave) {
+            int s0 = seen, mine0 = (seen + slots - 1 - slot) / slots, nm = 0;
+            for (int base = 0; base < cnt; base += kWave) {
+                const int k = base + tid;
+                const bool hit = k < cnt && (int)a.img[nb + k] == b;
+                const unsigned long long m = __ballot(hit);
+                const int ord = s0 + __popcll(m & ((1ull << tid) - 1ull));
+                if (hit && ord % slots == slot) mine[ord / slots - mine0] = k;
+                const int tot = __popcll(m);
+                nm = (s0 + tot + slots - 1 - slot) / slots - mine0;
+                s0 += tot;
+            }
+            if (tid == 0) n_mine = nm;
+            seen = s0;
+        }
+        __syncthreads();
+        seen = __shfl(seen, 0, kWave);
+        const int M = n_mine;
+        for (int m = 0; m < M; ++m) {
+            const int n = nb + __builtin_amdgcn_readfirstlane(mine[m]);
+            float* dst = param_part + ((int64_t)n * T + tile) * P;
+            // ---- phase 1: thread = pixel ------------------------------------------------------------------
+            float g[NT * NT];
+            {
+                const float* gz = g_logits + (int64_t)n * OH * OW;
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int jx = 0; jx < NT; ++jx) g[i * NT + jx] = gz[roff[i] + coff[jx]];
+            }
+            const float* __restrict__ wts = params + (int64_t)n * P;
+            v2f in2[CIN / 2], h1[kDC / 2], h2[kDC / 2], dh2[kDC / 2], dh1[kDC / 2];
+            if constexpr (REL) {
+                const float soi = a.soi[a.level[n]];
+                in2[0] = v2f{(a.coors[2 * n] - (float)(cc * a.in_stride + a.in_stride / 2)) / soi,
+                             (a.coors[2 * n + 1] - (float)(rr * a.in_stride + a.in_stride / 2)) / soi};
+                if (!valid) in2[0] = v2f{0.f, 0.f};
+                rows[0 * kRowPad + tid] = in2[0].x;          // (read in pass A only: the previous instance's pass A is behind a barrier)
+                rows[1 * kRowPad + tid] = in2[0].y;
+            }
+#pragma unroll
+            for (int k = 0; k < C / 2; ++k) in2[off / 2 + k] = v2f{rows[(off + 2 * k) * kRowPad + tid], rows[(off + 2 * k + 1) * kRowPad + tid]};
+            (void)mlp_forward<C, REL>(wts, in2, h1, h2);
+            if (!valid) {
+#pragma unroll
+                for (int i = 0; i < kDC / 2; ++i) h1[i] = h2[i] = v2f{0.f, 0.f};
+            }
+            float dout = 0.f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                float rowsum = 0.f;
+#pragma unroll
+                for (int jx = 0; jx < NT; ++jx) rowsum += wx[jx] * g[i * NT + jx];
+                dout += wy[i] * rowsum;
+            }
+            const float* __restrict__ wts_b = params_again + (int64_t)n * P;
+            const v2f dout2 = {dout, dout};
+#pragma unroll
+            for (int i = 0; i < kDC / 2; ++i) {
+                const v2f d = dout2 * w2_at(wts_b, w2 + 2 * i);
+                dh2[i] = v2f{h2[i].x > 0.f ? d.x : 0.f, h2[i].y > 0.f ? d.y : 0.f};
+            }
+            // dW2 | db2: nine products, summed over the DPP row here, over the workgroup's sixteen rows after the barrier
+            {
+                float p9[9];
+#pragma unroll
+                for (int i = 0; i < kDC / 2; ++i) { const v2f pr = dout2 * h2[i]; p9[2 * i] = pr.x; p9[2 * i + 1] = pr.y; }
+                p9[8] = dout;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) p9[i] = row16_sum(p9[i]);
+                if (sl == 0) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) red2[blk * 12 + i] = p9[i];
+                }
+            }
+            // pass B operands: dh2, h1
+#pragma unroll
+            for (int i = 0; i < kDC; ++i) {
+                rows[(RX + i) * kRowPad + tid] = (i & 1) ? dh2[i / 2].y : dh2[i / 2].x;
+                rows[(RX + kDC + i) * kRowPad + tid] = (i & 1) ? h1[i / 2].y : h1[i / 2].x;
+            }
+#pragma unroll
+            for (int i = 0; i < kDC / 2; ++i) dh1[i] = v2f{0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < kDC; ++o) {
+                const float so = (o & 1) ? dh2[o / 2].y : dh2[o / 2].x;
+                const v2f bo = {so, so};
+#pragma unroll
+                for (int i = 0; i < kDC / 2; ++i) dh1[i] = pk_fma(bo, w2_at(wts_b, w1 + o * kDC + 2 * i), dh1[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < kDC / 2; ++i) dh1[i] = v2f{h1[i].x > 0.f ? dh1[i].x : 0.f, h1[i].y > 0.f ? dh1[i].y : 0.f};
+#pragma unroll
+            for (int o = 0; o < kDC; ++o) {
+                if (o % 4 == 0) {
+#pragma unroll
+                    for (int kk = 0; kk < C / 2; ++kk) asm volatile("" : "+v"(dfeat[kk]));
+                    BXI_SEGMENT();
+                }
+                const float so = (o & 1) ? dh1[o / 2].y : dh1[o / 2].x;
+                const v2f bo = {so, so};
+#pragma unroll
+                for (int kk = 0; kk < C / 2; ++kk) dfeat[kk] = pk_fma(bo, w2_at(wts_b, o * CIN + off + 2 * kk), dfeat[kk]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < C / 2; ++kk) asm volatile("" : "+v"(dfeat[kk]));
+            BXI_SEGMENT();
+            lds_barrier();
+            // ---- pass B: dW1 | db1 (blocks 0..7), and the nine threads that finish dW2 | db2 ------------------------------
+            if (blk < NBB) contract(aB, bB, qB, dst);
+            if (tid >= 192 && tid < 192 + 9) {               // (a wave that has no pass-B block)
+                unsigned i = (unsigned)(tid - 192);
+                asm volatile("" : "+v"(i));                  // (one address register + sixteen immediate offsets, not sixteen hoisted addresses)
+                float sum = 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) sum += red2[u * 12 + i];
+                const unsigned qq = i < (unsigned)kDC ? w2 + i : (unsigned)D::B2;
+                asm volatile("global_store_dword %0, %1, %2" ::"v"(qq * 4u), "v"(sum), "s"(dst) : "memory");
+            }
+            lds_barrier();
+            // pass A operands: dh1 (rel and the features are in their rows already)
+#pragma unroll
+            for (int i = 0; i < kDC; ++i) rows[(RX + i) * kRowPad + tid] = (i & 1) ? dh1[i / 2].y : dh1[i / 2].x;
+            lds_barrier();
+            if (blk < NBA) contract(aA, bA, qA, dst);
+            lds_barrier();
+        }
+    }
+    {
+        // (the pixel's offset is derived again here: computed at the top it is a register pair held -- spilled -- through the instance loop)
+        int tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));
+        const int r2 = ty * kYR + tid2 / kYC, c2 = tx * kYC + tid2 % kYC;
+        if (r2 < a.H && c2 < a.W) {
+            float* o = feat_part + (((int64_t)slot * a.B + b) * C) * HW + (unsigned)(r2 * a.W + c2);
+#pragma unroll
+            for (int k = 0; k < C; ++k) o[k * HW] = (k & 1) ? dfeat[k / 2].y : dfeat[k / 2].x;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void dyn_reduce_kernel(const float* __restrict__ feat_part, int64_t feat_elems,
                                                          float* __restrict__ g_feat, const float* __restrict__ param_part,
                                                          int N, int T, int P, float* __restrict__ g_params, int slots) {
@@ -498,13 +785,48 @@ int bxi_dynamic_mask_backward_f32(const float* feat, int B, int C, int H, int W,
     float* param_part = (float*)((char*)workspace + (sizeof(float) * (size_t)bxi::kSlots * feat_elems + 255) / 256 * 256);
     const int cin = C + (a.rel ? 2 : 0);
     const size_t lds = sizeof(float) * ((size_t)(1 + 4 * bxi::kDC + cin + 2) * bxi::kRowPad);
-    // Workgroups per (image, tile): each walks every slots-th instance of its image.  Few instances per image: 4, so that the launch is
-    // resident at once (2 x 52 x 4 = 416 workgroups on 512 slots at 2 x 100 x 128: 27.1 -> 25.2 us at 32 instances); many: 8 (at 128
-    // instances 4 slots measure 88 us against 79: more instances per workgroup than the single round saves).
-    const int slots = N <= 16 * B ? 4 : bxi::kSlots;
-    const unsigned grid = (unsigned)(B * T * slots);
-    BXI_DYN_DISPATCH(C, a.rel, factor, BXI_LAUNCH("dyn_bwd", s, (bxi::dyn_bwd_kernel<KC, KR, KF>), dim3(grid), dim3(256), lds, s, a, params, params, g_logits,
-                                          feat_part, param_part, slots));
+    // Workgroups per (image, tile): each walks every slots-th instance of its image.
+#ifdef BXI_DEV
+    static const int form = getenv("BXI_DYN_BWD_FORM") ? atoi(getenv("BXI_DYN_BWD_FORM")) : 2;      // A/B of the two forms (developer build only)
+    static const int env_slots = getenv("BXI_DYN_BWD_SLOTS") ? atoi(getenv("BXI_DYN_BWD_SLOTS")) : 0;
+#else
+    constexpr int form = 2, env_slots = 0;
+#endif
+    int slots;
+    if (form == 2 && (factor == 1 || factor == 2)) {
+        // dyn_bwd2_kernel, four workgroups per CU (1024 slots on the 256 CUs): as many slots per (image, tile) as keep the launch resident at
+        // once -- 2 x 52 x 8 = 832 workgroups at 2 x 100 x 128 --, all of them when there are many instances.  Measured against dyn_bwd_kernel
+        // (rocprofv3, same box, 2 x 16 x 100 x 128 -> 200 x 256): 32 instances 28.2-28.8 -> 27.2-27.8 us (the reduction over 8 instead of 4
+        // feature partials: 5.1 -> 5.6 us), 128 instances 78.6-79.4 -> 70.0-70.8 us; 4 / 6 / 7 slots at 32 instances: 31.3 / 29.8 / 29.9 us.
+        const int cap = 4 * 256 / (B * T);
+        slots = N > 16 * B || cap >= bxi::kSlots ? bxi::kSlots : (cap < 1 ? 1 : cap);
+        if (env_slots > 0) slots = env_slots;
+        const size_t lds2 = sizeof(float) * ((size_t)(cin + 1 + 16 + 2) * bxi::kRowPad);
+        const unsigned grid2 = (unsigned)(B * T * slots);
+#define BXI_DYN2(KC, KR, KF) BXI_LAUNCH("dyn_bwd", s, (bxi::dyn_bwd2_kernel<KC, KR, KF>), dim3(grid2), dim3(256), lds2, s, a, params, params, g_logits, feat_part, param_part, slots)
+        if (factor == 2) {
+            if (C == 16 && a.rel) BXI_DYN2(16, true, 2); else if (C == 16) BXI_DYN2(16, false, 2); else if (a.rel) BXI_DYN2(8, true, 2); else BXI_DYN2(8, false, 2);
+        } else {
+            if (C == 16 && a.rel) BXI_DYN2(16, true, 1); else if (C == 16) BXI_DYN2(16, false, 1); else if (a.rel) BXI_DYN2(8, true, 1); else BXI_DYN2(8, false, 1);
+        }
+#undef BXI_DYN2
+    } else {
+        // dyn_bwd_kernel (factor 4 and the run-time factor: their (2f-1)^2 tap windows do not fit dyn_bwd2_kernel's registers), two workgroups per
+        // CU.  Few instances per image: 4 slots, so that the launch is resident at once (2 x 52 x 4 = 416 workgroups on 512 slots); many: 8.
+        slots = N <= 16 * B ? 4 : bxi::kSlots;
+        if (env_slots > 0) slots = env_slots;
+        const unsigned grid = (unsigned)(B * T * slots);
+#define BXI_DYN1(KC, KR, KF) BXI_LAUNCH("dyn_bwd", s, (bxi::dyn_bwd_kernel<KC, KR, KF>), dim3(grid), dim3(256), lds, s, a, params, params, g_logits, feat_part, param_part, slots)
+#define BXI_DYN1_F(KF) do { if (C == 16 && a.rel) BXI_DYN1(16, true, KF); else if (C == 16) BXI_DYN1(16, false, KF); else if (a.rel) BXI_DYN1(8, true, KF); else BXI_DYN1(8, false, KF); } while (0)
+        if (factor == 4) BXI_DYN1_F(4);
+#ifdef BXI_DEV
+        else if (factor == 2) BXI_DYN1_F(2);
+        else if (factor == 1) BXI_DYN1_F(1);
+#endif
+        else BXI_DYN1_F(0);
+#undef BXI_DYN1_F
+#undef BXI_DYN1
+    }
     rc = bxi::check_launch();
     if (rc != BXI_OK) return rc;
     const int64_t nb = (feat_elems + 255) / 256 + ((int64_t)N * P + 255) / 256;

@@ -47,9 +47,10 @@ def test_dynamic_head_vs_reference_fixture(dev, case):
     assert _close(gp, g[f'{case}_gparams'], 2e-5)
 
 
-@pytest.mark.parametrize('shape', [(2, 16, 100, 128, 32), (3, 8, 37, 50, 70), (1, 16, 8, 32, 1)])
+@pytest.mark.parametrize('shape', [(2, 16, 100, 128, 32), (3, 8, 37, 50, 70), (1, 16, 8, 32, 1), (2, 16, 100, 128, 128), (4, 8, 100, 128, 9)])
 def test_dynamic_head_vs_oracle_large(dev, shape):
-    """BoxInst R-50 shape (2 x 16 x 100 x 128 features, 32 instances -> 200 x 256 logits) and ragged ones."""
+    """BoxInst R-50 shape (2 x 16 x 100 x 128 features, 32 instances -> 200 x 256 logits; 128 instances = topk 64 x 2 images: eight
+    slots per (image, tile), eight instances per backward workgroup) and ragged ones (4 images x 52 tiles: four slots fit the launch)."""
     from oracle import torch_oracle as to
     B, C, H, W, N = shape
     rng = np.random.default_rng(sum(shape))
