@@ -1021,13 +1021,33 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
 #pragma unroll
     for (int j = 0; j < R; ++j) g[j] = 0.f;
     // per-pixel quantities of this lane and of the lane D to its right: before the wait, they need the logits only
-    float pa_[RD], pb_[RD], pt_[RD], pu_[RD], aR[RD], bR[RD], tR[RD], uR[RD];
+#ifndef BXI_PK_PAIRS
+#define BXI_PK_PAIRS 1
+#endif
+    // PK (even dilation): rows 2k, 2k + 1 ride in the two halves of packed FP32 instructions (v_pk_mul / v_pk_fma: two pairs per instruction;
+    // the conversions and the two transcendentals per pair stay scalar).  Every row's gradient receives the same terms in the same order.
+    constexpr bool PK = BXI_PK_PAIRS && D % 2 == 0 && RD % 2 == 0;
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    float pa_[PK ? 1 : RD], pb_[PK ? 1 : RD], pt_[PK ? 1 : RD], pu_[PK ? 1 : RD], aR[PK ? 1 : RD], bR[PK ? 1 : RD], tR[PK ? 1 : RD], uR[PK ? 1 : RD];
+    v2 pa2[PK ? RD / 2 : 1], pb2[PK ? RD / 2 : 1], pt2[PK ? RD / 2 : 1], pu2[PK ? RD / 2 : 1], aR2[PK ? RD / 2 : 1], bR2[PK ? RD / 2 : 1],
+        tR2[PK ? RD / 2 : 1], uR2[PK ? RD / 2 : 1];
     bool sat = false;
+    if constexpr (PK) {
+#pragma unroll
+        for (int k = 0; k < RD / 2; ++k) {
+            sat |= !(fabsf(x[2 * k]) <= 34.f) || !(fabsf(x[2 * k + 1]) <= 34.f);
+            const float2 s0 = sig_pair(x[2 * k]), s1 = sig_pair(x[2 * k + 1]);
+            pa2[k] = v2{s0.x, s1.x}; pb2[k] = v2{s0.y, s1.y};
+            aR2[k] = v2{lane_plus<D>(s0.x), lane_plus<D>(s1.x)}; bR2[k] = v2{lane_plus<D>(s0.y), lane_plus<D>(s1.y)};
+            pt2[k] = pa2[k] - pb2[k]; pu2[k] = pa2[k] * pb2[k]; tR2[k] = aR2[k] - bR2[k]; uR2[k] = aR2[k] * bR2[k];
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < RD; ++j) {
         sat |= !(fabsf(x[j]) <= 34.f);
         const float2 s = sig_pair(x[j]); pa_[j] = s.x; pb_[j] = s.y; pt_[j] = s.x - s.y; pu_[j] = s.x * s.y;
         aR[j] = lane_plus<D>(pa_[j]); bR[j] = lane_plus<D>(pb_[j]); tR[j] = aR[j] - bR[j]; uR[j] = aR[j] * bR[j];
+    }
     }
     const bool slow = zero_bit != 0 || __any(sat);
     bool bad = false;          // a bounded wait of this wave ran out (never expected): its arrival carries the fact to the finisher
@@ -1046,9 +1066,15 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
         const TileFlags f = tile_flags<D, R>(t, h, w, lane);
         DirMasks m[4];
         dir_masks<D>(f, pb, m);
-        float gq[RD], gR[RD];                        // gradient of this lane's pixels / of lane + D's
+        float gq[PK ? 1 : RD], gR[PK ? 1 : RD];      // gradient of this lane's pixels / of lane + D's
+        v2 gq2[PK ? RD / 2 : 1], gR2[PK ? RD / 2 : 1];
+        if constexpr (PK) {
 #pragma unroll
-        for (int j = 0; j < RD; ++j) { gq[j] = 0.f; gR[j] = 0.f; }
+            for (int k = 0; k < RD / 2; ++k) { gq2[k] = v2{0.f, 0.f}; gR2[k] = v2{0.f, 0.f}; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RD; ++j) { gq[j] = 0.f; gR[j] = 0.f; }
+        }
         // pair weights as bytes, four rows per word: cw = W[k,A] + W[7-k,B] (gradient), dw = the same restricted to
         // pixels this tile owns (loss sum)
         uint32_t cw[4][(R + D + 3) / 4], dw[4][(R + D + 3) / 4];
@@ -1071,6 +1097,39 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
             GA -= mm * qt[rb] * pu_[ra];                                                                            \
             GB -= mm * pt_[ra] * qu[rb];                                                                            \
         }
+        if constexpr (PK) {
+            v2 num2 = {0.f, 0.f};
+            // two unordered pairs: rows (2 ka, 2 ka + 1) of this lane against rows (2 kb, 2 kb + 1) of the lane `q` names; bytes 2 ip, 2 ip + 1 of the weights
+#define BXI_PAIR2(ip, ka, kb, qa, qb, qt, qu, dir, GA, GB)                                                          \
+            {                                                                                                       \
+                const uint32_t cwd = cw[dir][(2 * (ip)) >> 2] >> (8 * ((2 * (ip)) & 3));                              \
+                const uint32_t dwd = dw[dir][(2 * (ip)) >> 2] >> (8 * ((2 * (ip)) & 3));                              \
+                const v2 gw = {(float)(cwd & 255u), (float)((cwd >> 8) & 255u)};                                      \
+                const v2 nw = {(float)(dwd & 255u), (float)((dwd >> 8) & 255u)};                                      \
+                const v2 S = pa2[ka] * qa[kb] + pb2[ka] * qb[kb];                                                     \
+                const v2 lg = {__builtin_amdgcn_logf(S.x), __builtin_amdgcn_logf(S.y)};                               \
+                num2 -= nw * lg;                                                                                      \
+                const v2 rc = {__builtin_amdgcn_rcpf(S.x), __builtin_amdgcn_rcpf(S.y)};                               \
+                const v2 mm = gw * rc;                                                                                \
+                GA -= mm * qt[kb] * pu2[ka];                                                                          \
+                GB -= mm * pt2[ka] * qu[kb];                                                                          \
+            }
+#pragma unroll
+            for (int ip = 0; ip < (R + D) / 2; ++ip) {
+                const int jp = ip + D / 2;
+                if (2 * ip >= D) BXI_PAIR2(ip, ip, ip, aR2, bR2, tR2, uR2, 0, gq2[ip], gR2[ip])
+                BXI_PAIR2(ip, jp, ip, aR2, bR2, tR2, uR2, 1, gq2[jp], gR2[ip])
+                BXI_PAIR2(ip, ip, jp, pa2, pb2, pt2, pu2, 2, gq2[ip], gq2[jp])
+                BXI_PAIR2(ip, ip, jp, aR2, bR2, tR2, uR2, 3, gq2[ip], gR2[jp])
+                if (2 * ip >= D) {
+                    const float fromL0 = lane_minus<D>(gR2[ip].x), fromL1 = lane_minus<D>(gR2[ip].y);
+                    g[2 * ip - D] = gq2[ip].x + (lane >= D ? fromL0 : 0.f);
+                    g[2 * ip + 1 - D] = gq2[ip].y + (lane >= D ? fromL1 : 0.f);
+                }
+            }
+#undef BXI_PAIR2
+            num = num2.x + num2.y;
+        } else {
 #pragma unroll
         for (int i = 0; i < R + D; ++i) {
             if (BXI_AB(2)) break;
@@ -1083,6 +1142,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
                 const float fromL = lane_minus<D>(gR[i]);
                 g[i - D] = gq[i] + (lane >= D ? fromL : 0.f);
             }
+        }
         }
         num *= 0.69314718055994531f;
 #undef BXI_PAIR
