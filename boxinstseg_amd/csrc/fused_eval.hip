@@ -1026,6 +1026,9 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
 #endif
     // PK (even dilation): rows 2k, 2k + 1 ride in the two halves of packed FP32 instructions (v_pk_mul / v_pk_fma: two pairs per instruction;
     // the conversions and the two transcendentals per pair stay scalar).  Every row's gradient receives the same terms in the same order.
+    // 122 -> 106 registers at <2, 4>, 159 -> 138 at <2, 8>; 17.43 -> 17.07 us per evaluation at 32 instances (same box).  (The 8-row role
+    // fits 113 registers when t and u are made again per pair -- four workgroups per CU --: slower, and the targets-ready long form then
+    // stalled for seconds at 128 instances with every slot of the device taken from the start: profiles/NOTES.md R5-7.  Not built.)
     constexpr bool PK = BXI_PK_PAIRS && D % 2 == 0 && RD % 2 == 0;
     typedef float v2 __attribute__((ext_vector_type(2)));
     float pa_[PK ? 1 : RD], pb_[PK ? 1 : RD], pt_[PK ? 1 : RD], pu_[PK ? 1 : RD], aR[PK ? 1 : RD], bR[PK ? 1 : RD], tR[PK ? 1 : RD], uR[PK ? 1 : RD];
