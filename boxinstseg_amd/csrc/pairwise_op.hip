@@ -537,6 +537,18 @@ __global__ __launch_bounds__(256) void pairwise3_fwd_wide_kernel(const float* __
     }
 }
 
+// developer trace of these kernels (-DBXI_PW_TRACE; tools/micro/pw_bwd.hip): wall-clock stamps collected in scalar registers, written by the
+// workgroup's first lane at the end -- no memory wait in the middle (BXI_T's pointer load would drain the requests in flight)
+#ifdef BXI_PW_TRACE
+static __device__ long long* g_pw_trace = nullptr;
+#define PWT_DECL long long pwt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PWT(ph) do { long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); pwt_[ph] = t_; } while (0)
+#define PWT_FLUSH(kid) do { if (threadIdx.x == 0 && g_pw_trace) for (int ph_ = 0; ph_ < 8; ++ph_) g_pw_trace[((size_t)(kid) * 8192 + blockIdx.x) * 8 + ph_] = pwt_[ph_]; } while (0)
+#else
+#define PWT_DECL do {} while (0)
+#define PWT(ph) do {} while (0)
+#define PWT_FLUSH(kid) do {} while (0)
+#endif
 #ifndef BXI_PWB_OCC
 #define BXI_PWB_OCC 5
 #endif
@@ -588,6 +600,8 @@ __global__ __launch_bounds__(256, (D <= 2 ? BXI_PWB_OCC : BXI_PWB_OCC - 1)) void
     // workgroups a CU (80 / 72 VGPRs, 4 / 23 spilled) measure 16.7-17.8 / 25.5 us.  Measured before the tile order was fixed (and all
     // slower than this form then): the two reads of a plane eight instructions or a memory round trip apart, a resident grid walking its
     // tiles with the next tile's loads in flight, 8 x 128 and 4 x 256 tiles, the gradient planes staged through LDS.  profiles/NOTES.md.
+    PWT_DECL;
+    PWT(0);
     float4 own[8];
     f4u part[8];
 #pragma unroll
@@ -603,7 +617,9 @@ __global__ __launch_bounds__(256, (D <= 2 ? BXI_PWB_OCC : BXI_PWB_OCC - 1)) void
     float* ts = reinterpret_cast<float*>(pw_raw);
     float* tm = ts + (TRT + 2 * D) * PC;
     bool sat;
+    PWT(1);
     pw3_stage_probs<D, TRT, TC>(L, H, W, r0, c0, ts, tm, sat);
+    PWT(3);
     if (XR == 0 && !live) return;
     if (live) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -648,6 +664,7 @@ __global__ __launch_bounds__(256, (D <= 2 ? BXI_PWB_OCC : BXI_PWB_OCC - 1)) void
     }
     *reinterpret_cast<float4*>(g_logits + n * P + (int64_t)r * W + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
+    PWT(5);
     if (XR > 0) {
         // ---- second phase: ONE pixel of rows TR .. TR + XR - 1 per thread (its requests go out when the first phase's registers are free)
         const int lr2 = TR + (int)threadIdx.x / TC, lc2 = (int)threadIdx.x % TC;
@@ -696,6 +713,413 @@ __global__ __launch_bounds__(256, (D <= 2 ? BXI_PWB_OCC : BXI_PWB_OCC - 1)) void
         }
         g_logits[n * P + (int64_t)r2 * W + c2] = a2;
     }
+    PWT(7);
+    PWT_FLUSH(0);
+}
+
+// ---- f32, size == 3, W % 4 == 0: every UNORDERED pair once ("pair" kernel) ---------------------------------------------------------
+// The wide backward above lets every pixel evaluate all eight of its taps: each pair {p, q} is evaluated twice, and each element of the
+// upstream gradient is fetched twice (once as g[k][p], once as the partner term g[7-k][.] of a neighbour).  But the pair has ONE
+//     S = s_p s_q + s'_p s'_q ,  ONE 1/S ,  ONE G = g[k][p] + g[7-k][q]                                              (pairwise.cu:52-66)
+// and feeds d/dx_p = -u_p (t_q G/S) and d/dx_q = -u_q (t_p G/S)   (t = s - s', u = s s').  Here the EARLIER pixel p of a pair (k = 4..7:
+// q to the right in the row, or in the row D below) evaluates it, keeps t_q G/S and hands t_p G/S to q; the factor -u is applied by the
+// owner of a pixel at the end.  A thread owns four adjacent pixels of a row (16-byte loads, as above): 8 float4 loads (g[4..7] at p,
+// g[3..0] at the four later partners) instead of 16, 16 pair evaluations instead of 32.  How a share reaches q:
+//   same row (k = 4)      q = p + D columns: the thread's own later pixel, or the next lane's (DPP row_shr:1 -- a tile row is 16 lanes = one DPP row)
+//   row + D (k = 5, 6, 7) the three shares aimed at one column are summed in registers; the D columns that spill to the left / right belong to
+//                         the pixels of the neighbouring lanes' threads (DPP row_shl:1 / row_shr:1); the thread then owns the COMPLETE downward
+//                         share of the four pixels below it and writes them, one writer per cell, to an LDS plane V[row + D]
+// Pairs whose earlier pixel lies OUTSIDE the tile (top D rows, D columns at the left / right edge) cannot be handed over by another workgroup:
+// in an "edge" pass every thread takes one such pixel x of the tile and evaluates only its share of the backward taps that leave the tile
+// (k = 0..3, G = g[k][x] + g[7-k][q]) into a second plane E -- D (TC + 2 TRT - 2D) pixels, <= 4 taps each: ~4 % more evaluations instead of 100 %.
+// XR > 0: XR more rows of ONE pixel per thread (wave = row, lane = column; wave_shr / wave_shl DPP for the column shifts), so that
+// 32 x 200 x 256 is 1280 workgroups = one residency round at five per CU, exactly as the wide kernel's second phase -- but its loads go out
+// with the first phase's (8 + 8 + 8 dwords more in flight fit now that the first phase needs 32 registers of gradient, not 64).
+// Out-of-map neighbours are staged as x = 0 (s = s' = 1/2, t = 0 exactly): their pairs contribute 0 by arithmetic, G is forced to 0 by a select
+// (a NaN / inf elsewhere in the upstream gradient must not leak through a clamped address).  Sums per pixel: own four taps, then the row share,
+// then V, then E -- a fixed order, run-to-run identical.
+#ifndef BXI_PWP_X
+#define BXI_PWP_X 0          // timing experiments (wrong results): 1 no edge loads, 2 no extra-row loads, 4 main requests before the others
+#endif
+#define BXI_DPP_ROW_SHL1 0x101
+#define BXI_DPP_ROW_SHR1 0x111
+#define BXI_DPP_WAVE_SHL1 0x130
+#define BXI_DPP_WAVE_SHR1 0x138
+template <int CTRL>
+__device__ __forceinline__ float dpp_zero(float v) {       // lanes without a source get 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL, int N>
+__device__ __forceinline__ float dpp_zero_n(float v) {
+#pragma unroll
+    for (int s = 0; s < N; ++s) v = dpp_zero<CTRL>(v);
+    return v;
+}
+
+// one pixel's gradient in log space straight from global memory, every tap (pairwise.cu:56-58): tiles with a logit beyond +-34
+__device__ __forceinline__ float pw3_bwd_exact_px(const float* __restrict__ L, const float* __restrict__ gp, int64_t P, int H, int W, int r, int c, int d) {
+    const float here = L[r * W + c];
+    const float ax = logsig(here), bx = logsig(-here);
+    float acc = 0.f;
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+        const int kk = k < 4 ? k : k + 1, r2 = r + (kk / 3 - 1) * d, c2 = c + (kk % 3 - 1) * d;
+        if (r2 >= 0 && r2 < H && c2 >= 0 && c2 < W) {
+            const float there = L[r2 * W + c2];
+            const float ay = logsig(there), by = logsig(-there);
+            const float pair = pair_nlog(ax, bx, ay, by);
+            const float g = gp[k * P + (int64_t)r * W + c] + gp[(7 - k) * P + (int64_t)r2 * W + c2];
+            acc += -(expf(ay) - expf(by)) * expf(ax + bx + pair) * g;
+        }
+    }
+    return acc;
+}
+
+template <int D, int XR> struct PwPairGeom {
+    static constexpr int TR = 16, TC = 64, TRT = TR + XR, PC = PwGeom<D, TC>::PC, PR = TRT + 2 * D;
+    // edge items: (tap k = 0..2, top row a < D, quad) -- 4 pixels each; then the strips, D pixels each: (left, tap 0, row a >= D), (left, tap 3, any row), (right, tap 2, row a >= D)
+    static constexpr int kTopItems = 3 * D * (TC / 4), kStripRows = TRT - D, kStripItems = 2 * kStripRows + TRT;   // (the left tap 3 leaves the tile in EVERY row)
+    static constexpr int kStripLane0 = (kTopItems + 63) / 64 * 64;      // strip items start at a wave boundary: they are another load instruction
+    static_assert(kStripLane0 + kStripItems <= 256, "one edge item per thread");
+    // staging: B = the quads of the rows no thread owns as its four pixels (extra rows, halo rows above and below), C = the halo columns
+    static constexpr int kQuadsB = (XR + 2 * D) * (TC / 4), kColsC = PR * 2 * D;
+    static_assert(kQuadsB <= 256 && kColsC <= 256, "one of each per thread");
+    static constexpr int kEtop = 3 * D * TC, kEstrip = 3 * TRT * 4;      // floats
+    static constexpr size_t lds_bytes = sizeof(float) * (2 * (size_t)PR * PC + (size_t)TRT * TC + kEtop + kEstrip + 4);
+};
+
+template <int D, int XR>
+__global__ __launch_bounds__(256, (D <= 2 ? BXI_PWB_OCC : BXI_PWB_OCC - 1)) void pairwise3_bwd_pair_kernel(const float* __restrict__ logits, const float* __restrict__ g_pair, int H, int W,
+                                                                 float* __restrict__ g_logits, int xcd_swizzle) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_raw[];
+    typedef PwPairGeom<D, XR> Gm;
+    constexpr int TR = Gm::TR, TC = Gm::TC, TRT = Gm::TRT, PC = Gm::PC, PR = Gm::PR, NWp = 4 * PwGeom<D, TC>::NW4;
+    static_assert(D >= 1 && D <= 4, "the column spill of a thread reaches the adjacent lane only");
+    static_assert(XR == 0 || XR * TC == 256, "second phase: one pixel per thread, wave = row");
+    const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TRT - 1) / TRT;
+    int t = (int)blockIdx.x;                                             // XCD-aware tile order: see pairwise3_bwd_wide_kernel
+    if (xcd_swizzle) {
+        const unsigned x = blockIdx.x % 8u, q = gridDim.x / 8u, r = gridDim.x % 8u;
+        t = (int)(x * q + (x < r ? x : r) + blockIdx.x / 8u);
+    }
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int64_t n = t / tiles_y;
+    const int64_t P = (int64_t)H * W;
+    const int r0 = ty * TRT, c0 = tx * TC;
+    const float* L = logits + n * P;
+    const int tid = (int)threadIdx.x;
+    // Addresses: a wave-uniform base in scalar registers -- the instance's logits, its gradient planes, plane k shifted by D rows -- + ONE
+    // per-lane byte offset per pixel (+ the column shift as the instruction's immediate offset).  The bases are made opaque so that the
+    // compiler does not re-associate them into per-lane 64-bit pointers (two address registers per load, where the loads of a thread all
+    // have to be in flight together).  A tap that leaves the map gets weight 0 later; its address only has to stay inside the instance's
+    // 8 planes: it does, |tap offset| < one plane (launcher).
+    typedef const __attribute__((address_space(1))) char* gptr;        // global address space, kept through the asm statements below
+    typedef const __attribute__((address_space(1))) float* gf1;
+    typedef float f4a __attribute__((ext_vector_type(4)));                // a float4 at a 16-byte address (a plain vector: HIP's float4 class does not load from an address space)
+    typedef const __attribute__((address_space(1))) f4a* gf4;
+    typedef const __attribute__((address_space(1))) f4u* gf4u;
+    typedef float fDv __attribute__((ext_vector_type(D == 1 ? 2 : D), aligned(4)));   // D adjacent pixels at any dword address: one load instruction (D = 1: a plain float)
+    typedef const __attribute__((address_space(1))) fDv* gfD;
+    struct fD { float v[D]; };
+    auto loadD = [](gptr p_) { fD r_; if constexpr (D == 1) r_.v[0] = *(gf1)p_; else { const fDv t_ = *(gfD)p_; for (int i = 0; i < D; ++i) r_.v[i] = t_[i]; } return r_; };
+    gptr pb[8];                                                          // plane k
+    gptr pdn[3];                                                         // plane k (0..2) + D rows: the partners below
+    gptr gb = (gptr)(g_pair + n * 8 * P), lb = (gptr)L;
+    {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { pb[k] = gb + k * P * 4; asm volatile("" : "+s"(pb[k])); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pdn[k] = gb + k * P * 4 + (int64_t)D * W * 4; asm volatile("" : "+s"(pdn[k])); }
+        asm volatile("" : "+s"(gb)); asm volatile("" : "+s"(lb));
+    }
+    const int plane = (int)P * 4;
+    PWT_DECL;
+    PWT(0);
+    // ---- requests, in the order their data is needed (loads return in order), as few and as wide as they can be: beyond its bytes a launch
+    // pays ~0.16 us per load instruction of a workgroup (profiles/NOTES.md R6-1) -- the first version of this kernel asked for the staged logits
+    // and the edge pixels one dword at a time (15 + 16 instructions per thread) and ran 21.4 us where the same kernel without them took 13.7.
+    // 1: the logits.  A: the thread's own four pixels; B: a quad of the rows nobody owns as four pixels (extra rows, halo rows); C: a halo column cell
+    const int lrA = tid / (TC / 4), lcA = (tid % (TC / 4)) * 4;
+    auto rowB = [&](int th) { const int rb = th / (TC / 4); return rb < XR ? TR + rb : (rb < XR + D ? rb - XR - D : TRT + rb - XR - D); };   // tile row of B quad `th`
+    f4a xa, xb;           // (xb, xc and the edge registers below are written and read under the same thread-index conditions: no
+    float xc;             //  zero defaults -- a default's v_mov would have to wait for the other branch's load into the same register)
+    xa = *(gf4)(lb + (uint32_t)((min(r0 + lrA, H - 1) * W + min(c0 + lcA, W - 4)) * 4));
+    if (tid < Gm::kQuadsB) xb = *(gf4)(lb + (uint32_t)((min(max(r0 + rowB(tid), 0), H - 1) * W + min(c0 + (tid % (TC / 4)) * 4, W - 4)) * 4));
+    if (tid >= 256 - Gm::kColsC) {
+        const int ci = tid - (256 - Gm::kColsC), pr = ci / (2 * D), hc = ci % (2 * D);
+        xc = *(gf1)(lb + (uint32_t)((min(max(r0 - D + pr, 0), H - 1) * W + min(max(c0 - D + (hc < D ? hc : TC + hc), 0), W - 1)) * 4));
+    }
+    // 2: the edge item -- pixels of the tile with an EARLIER partner outside it (taps k = 0..3 = (-D,-D) (-D,0) (-D,+D) (0,-D)): g[k] at the pixels, g[7-k] at the partners
+    f4a eo4; f4u ep4;
+    fD eoD, epD;
+    auto top_item = [&](int th, int& k, int& a, int& b) { k = th / (D * (TC / 4)); a = (th % (D * (TC / 4))) / (TC / 4); b = (th % (TC / 4)) * 4; };
+    auto strip_item = [&](int th, int& k, int& a, int& b, int& dy, int& dx) -> int {
+        const int s_ = th - Gm::kStripLane0, w = s_ < Gm::kStripRows ? 0 : (s_ < Gm::kStripRows + TRT ? 1 : 2);   // 0: left, tap 0 ; 1: left, tap 3 ; 2: right, tap 2
+        a = w == 0 ? D + s_ : (w == 1 ? s_ - Gm::kStripRows : D + s_ - Gm::kStripRows - TRT);
+        k = w == 0 ? 0 : (w == 1 ? 3 : 2); b = w == 2 ? TC - D : 0; dy = w == 1 ? 0 : -1; dx = w == 2 ? 1 : -1;
+        return w;
+    };
+    if (tid < Gm::kTopItems) {
+        int k, a, b;
+        top_item(tid, k, a, b);
+        const int pixe = (min(r0 + a, H - 1) * W + min(c0 + b, W - 4)) * 4;
+        eo4 = *(gf4)(gb + (uint32_t)(k * plane + pixe));
+        ep4 = *(gf4u)(gb + (uint32_t)((7 - k) * plane + pixe - D * W * 4 + (k - 1) * D * 4));
+    } else if (tid >= Gm::kStripLane0 && tid < Gm::kStripLane0 + Gm::kStripItems) {
+        int k, a, b, dy, dx;
+        strip_item(tid, k, a, b, dy, dx);
+        const int pixe = (min(r0 + a, H - 1) * W + min(c0 + b, W - D)) * 4;
+        eoD = loadD(gb + (uint32_t)(k * plane + pixe));
+        epD = loadD(gb + (uint32_t)((7 - k) * plane + pixe + (dy * D * W + dx * D) * 4));
+    }
+    // 3: the one pixel of the extra rows: g[4..7] at p, g[3..0] at the later partner (k = 4 + j: (0,+D) (+D,-D) (+D,0) (+D,+D); its channel is 7 - k)
+    float xo[4], xp[4];
+    if (XR > 0) {
+        const int pix2 = (min(r0 + TR + tid / TC, H - 1) * W + min(c0 + tid % TC, W - 1)) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int dy = j == 0 ? 0 : 1, dx = j == 0 ? 1 : j - 2;
+            if (BXI_PWP_X & 2) { xo[j] = 0.f; xp[j] = (float)dx; continue; }
+            xo[j] = *(gf1)(pb[4 + j] + (uint32_t)pix2);
+            xp[j] = *(gf1)((dy ? pdn[3 - j] : pb[3 - j]) + (uint32_t)pix2 + dx * D * 4);
+        }
+    }
+    // 4: four adjacent pixels of a row, the same planes as sixteen-byte loads
+    f4a own[4];
+    f4u part[4];
+    {
+        uint32_t pix = (uint32_t)((min(r0 + lrA, H - 1) * W + min(c0 + lcA, W - 4)) * 4);
+        asm volatile("" : "+v"(pix));                                    // (its own register: shared with the logits' offset the loads below came out with 64-bit per-lane addresses)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int dy = j == 0 ? 0 : 1, dx = j == 0 ? 1 : j - 2;
+            own[j] = *(gf4)(pb[4 + j] + (uint32_t)pix);
+            part[j] = *(gf4u)((dy ? pdn[3 - j] : pb[3 - j]) + (uint32_t)pix + dx * D * 4);
+        }
+    }
+    // (everything below is derived from a thread index the compiler cannot see through: nothing of it is computed -- and kept in registers --
+    // while the registers of the requests above are being filled)
+    int th = tid;
+    asm volatile("" : "+v"(th));
+    PWT(1);
+    const int lr = th / (TC / 4), lc = (th % (TC / 4)) * 4;
+    const int r = r0 + lr, c = c0 + lc;
+    const bool live = r < H && c < W;                                   // W % 4 == 0: the four pixels are in the map together
+    const int lr2 = TR + th / TC, lc2 = th % TC;
+    const int r2 = r0 + lr2, c2 = c0 + lc2;
+    const bool live2 = XR > 0 && r2 < H && c2 < W;
+    // ---- the staged tile: s = sigmoid(x), s' = sigmoid(-x), two planes (rows padded to whole float4; staged row / column = tile row / column + D);
+    // out-of-map positions are x = 0 (s = s' = 1/2, t = 0: their pairs vanish by arithmetic)
+    float* ts = reinterpret_cast<float*>(pw_raw);
+    float* tm = ts + PR * PC;
+    float* Vp = tm + PR * PC;                                            // [TRT][TC]: the complete share from the row D above
+    float* Et = Vp + TRT * TC;                                           // [3][D][TC]: top rows' shares from above the tile, by tap
+    float* Es = Et + Gm::kEtop;                                          // [3][TRT][4]: left tap 0, left tap 3, right tap 2 -- D pixels per row
+    int* satw = reinterpret_cast<int*>(Es + Gm::kEstrip);                // [4]: one flag per wave
+    bool sat = false;
+    auto stage = [&](float x, int o) {
+        sat |= !(fabsf(x) <= 34.f);
+        const float en = fast_exp_neg(fabsf(x)), big = fast_rcp(1.f + en), small = en * big;       // sigmoid(|x|), sigmoid(-|x|)
+        ts[o] = x >= 0.f ? big : small;
+        tm[o] = x >= 0.f ? small : big;
+    };
+    {
+        const bool col_in = c < W;
+        const bool inA = r < H && col_in;
+        const float a4[4] = {xa.x, xa.y, xa.z, xa.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage(inA ? a4[i] : 0.f, (lr + D) * PC + lc + D + i);
+        if (th < Gm::kQuadsB) {
+            const int trB = rowB(th);
+            const bool inB = (unsigned)(r0 + trB) < (unsigned)H && col_in;
+            const float b4[4] = {xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stage(inB ? b4[i] : 0.f, (trB + D) * PC + lc + D + i);
+        }
+        if (th >= 256 - Gm::kColsC) {
+            const int ci = th - (256 - Gm::kColsC), pr = ci / (2 * D), hc = ci % (2 * D), sc = hc < D ? hc : TC + hc;
+            const bool inC = (unsigned)(r0 - D + pr) < (unsigned)H && (unsigned)(c0 - D + sc) < (unsigned)W;
+            stage(inC ? xc : 0.f, pr * PC + sc);
+        }
+    }
+    if ((th & 63) == 0) satw[th >> 6] = __any(sat) ? 1 : 0;
+    PWT(2);
+    lds_barrier();                                                       // the staged tile is complete (the gradient requests stay in flight)
+    PWT(3);
+    if (satw[0] | satw[1] | satw[2] | satw[3]) {                         // rare, block-uniform: log space, straight from global memory
+        if (live) {
+            float a4[4];
+            for (int i = 0; i < 4; ++i) a4[i] = pw3_bwd_exact_px(L, g_pair + n * 8 * P, P, H, W, r, c + i, D);
+            *reinterpret_cast<float4*>(g_logits + n * P + (int64_t)r * W + c) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+        }
+        if (live2) g_logits[n * P + (int64_t)r2 * W + c2] = pw3_bwd_exact_px(L, g_pair + n * 8 * P, P, H, W, r2, c2, D);
+        return;
+    }
+    // ---- edge pass: the shares that come from outside the tile, one writer per cell: Et[tap][row][column], Es[which][row][pixel]
+    if (th < Gm::kTopItems) {
+        int k, a, b;
+        top_item(th, k, a, b);
+        const int dx = k - 1;
+        const bool rows_in = r0 + a < H && r0 + a - D >= 0 && c0 + b < W;
+        const float o4[4] = {eo4.x, eo4.y, eo4.z, eo4.w}, p4[4] = {ep4.x, ep4.y, ep4.z, ep4.w};
+        float sh[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = (a + D) * PC + b + D + i;
+            const float sp = ts[o], mp = tm[o], sq = ts[o - D * PC + dx * D], mq = tm[o - D * PC + dx * D];
+            const bool in = rows_in && (unsigned)(c0 + b + i + dx * D) < (unsigned)W;
+            const float G = in ? o4[i] + p4[i] : 0.f;
+            sh[i] = (sq - mq) * (G * fast_rcp(sp * sq + mp * mq));
+        }
+        *reinterpret_cast<float4*>(Et + (k * D + a) * TC + b) = make_float4(sh[0], sh[1], sh[2], sh[3]);
+    } else if (th >= Gm::kStripLane0 && th < Gm::kStripLane0 + Gm::kStripItems) {
+        int k, a, b, dy, dx;
+        const int w = strip_item(th, k, a, b, dy, dx);
+        const bool rows_in = r0 + a < H && (unsigned)(c0 + b + dx * D) < (unsigned)W && c0 + b < W;      // D <= 4, W % 4 == 0, tiles start at multiples of 64: the D partners are in the map together
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const int o = (a + D) * PC + b + D + i;
+            const float sp = ts[o], mp = tm[o], sq = ts[o + dy * D * PC + dx * D], mq = tm[o + dy * D * PC + dx * D];
+            const float G = rows_in ? eoD.v[i] + epD.v[i] : 0.f;
+            Es[(w * TRT + a) * 4 + i] = (sq - mq) * (G * fast_rcp(sp * sq + mp * mq));
+        }
+    }
+    PWT(4);
+    // ---- the extra rows: one pixel per thread (wave = row, lane = column)
+    float acc2 = 0.f;
+    if (XR > 0) {
+        const float* s_ = ts + (lr2 + D) * PC + lc2 + D;
+        const float* m_ = tm + (lr2 + D) * PC + lc2 + D;
+        const float sp = s_[0], mp = m_[0], tp = sp - mp;
+        const bool row_d = live2 && r2 + D < H, c_lo = c2 - D >= 0, c_hi = c2 + D < W;
+        float sh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int off = j == 0 ? D : D * PC + (j - 2) * D;
+            const float sq = s_[off], mq = m_[off];
+            const bool in = j == 0 ? (live2 && c_hi) : (row_d && (j == 1 ? c_lo : (j == 3 ? c_hi : true)));
+            const float G = in ? xo[j] + xp[j] : 0.f;
+            const float cc = G * fast_rcp(sp * sq + mp * mq);
+            acc2 += (sq - mq) * cc;
+            sh[j] = tp * cc;
+        }
+        acc2 += dpp_zero_n<BXI_DPP_WAVE_SHR1, D>(sh[0]);
+        const float v2 = sh[2] + dpp_zero_n<BXI_DPP_WAVE_SHL1, D>(sh[1]) + dpp_zero_n<BXI_DPP_WAVE_SHR1, D>(sh[3]);
+        if (lr2 + D < TRT) Vp[(lr2 + D) * TC + lc2] = v2;                 // wave-uniform
+    }
+    PWT(5);
+    // ---- four adjacent pixels, their four later pairs each.  Two stages -- the pairs within the row, then those with the row D below
+    float acc[4];
+    {
+        auto window = [&](const float* pl, int row, float (&v)[NWp]) {  // staged row `row`, columns c - D .. c + 3 + D of one plane
+#pragma unroll
+            for (int x4 = 0; x4 < NWp / 4; ++x4) {
+                const float4 a = *reinterpret_cast<const float4*>(pl + row * PC + lc + 4 * x4);
+                v[4 * x4] = a.x; v[4 * x4 + 1] = a.y; v[4 * x4 + 2] = a.z; v[4 * x4 + 3] = a.w;
+            }
+        };
+        float sp[4], mp[4], tp[4], hz[4];
+        {
+            float sr[NWp], mr[NWp];
+            window(ts, lr + D, sr); window(tm, lr + D, mr);
+            const float o4[4] = {own[0].x, own[0].y, own[0].z, own[0].w}, p4[4] = {part[0].x, part[0].y, part[0].z, part[0].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sp[i] = sr[D + i]; mp[i] = mr[D + i]; tp[i] = sp[i] - mp[i];
+                const float sq = sr[2 * D + i], mq = mr[2 * D + i];
+                const float G = live && c + i + D < W ? o4[i] + p4[i] : 0.f;
+                const float cc = G * fast_rcp(sp[i] * sq + mp[i] * mq);  // S >= 3e-15: every |logit| <= 34
+                acc[i] = (sq - mq) * cc;                                 // p's share of the pair
+                hz[i] = tp[i] * cc;                                      // q's
+            }
+        }
+        float dn[4 + 2 * D];
+#pragma unroll
+        for (int j = 0; j < 4 + 2 * D; ++j) dn[j] = 0.f;
+        {
+            float sd[NWp], md[NWp];
+            window(ts, lr + 2 * D, sd); window(tm, lr + 2 * D, md);
+            const bool row_d = live && r + D < H;
+#pragma unroll
+            for (int j = 1; j < 4; ++j) {
+                const float o4[4] = {own[j].x, own[j].y, own[j].z, own[j].w}, p4[4] = {part[j].x, part[j].y, part[j].z, part[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int q = (j - 1) * D + i;                       // the partner's column in the window
+                    const bool in = row_d && (j == 1 ? c + i - D >= 0 : (j == 3 ? c + i + D < W : true));
+                    const float G = in ? o4[i] + p4[i] : 0.f;
+                    const float cc = G * fast_rcp(sp[i] * sd[q] + mp[i] * md[q]);
+                    acc[i] += (sd[q] - md[q]) * cc;
+                    dn[q] += tp[i] * cc;
+                }
+            }
+        }
+        // the row share: from the thread's own earlier pixel, or the previous lane's
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += i >= D ? hz[i - D] : dpp_zero<BXI_DPP_ROW_SHR1>(hz[i + 4 - D]);
+        // the share for the row below: own columns + the next lane's left spill + the previous lane's right spill
+        float vd[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vd[i] = dn[D + i];
+            if (i >= 4 - D) vd[i] += dpp_zero<BXI_DPP_ROW_SHL1>(dn[i - (4 - D)]);
+            if (i < D) vd[i] += dpp_zero<BXI_DPP_ROW_SHR1>(dn[D + 4 + i]);
+        }
+        if (XR >= D || lr + D < TRT) *reinterpret_cast<float4*>(Vp + (lr + D) * TC + lc) = make_float4(vd[0], vd[1], vd[2], vd[3]);
+    }
+    PWT(6);
+    lds_barrier();
+    // ---- every pixel: own taps + the row share (above), + the share from the row above, + the shares from outside the tile (taps in order) ; x -u
+    // (positions derived again from the thread index: nothing but the sums above stays in registers across the passes)
+    asm volatile("" : "+v"(th));
+    {
+        const int gr = th / (TC / 4), gc = (th % (TC / 4)) * 4;
+        if (r0 + gr < H && c0 + gc < W) {
+            float e4[4] = {0.f, 0.f, 0.f, 0.f};
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr >= D) {
+                v = *reinterpret_cast<const float4*>(Vp + gr * TC + gc);
+                if (gc == 0) {
+#pragma unroll
+                    for (int i = 0; i < D; ++i) e4[i] = Es[(0 * TRT + gr) * 4 + i] + Es[(1 * TRT + gr) * 4 + i];
+                }
+                if (gc == TC - 4) {                                      // (D == 4: a 64-column tile's first and last quad differ)
+#pragma unroll
+                    for (int i = 4 - D; i < 4; ++i) e4[i] = Es[(2 * TRT + gr) * 4 + i - (4 - D)];
+                }
+            } else {
+                const float4 e0 = *reinterpret_cast<const float4*>(Et + (0 * D + gr) * TC + gc), e1 = *reinterpret_cast<const float4*>(Et + (1 * D + gr) * TC + gc),
+                             e2 = *reinterpret_cast<const float4*>(Et + (2 * D + gr) * TC + gc);
+                e4[0] = (e0.x + e1.x) + e2.x; e4[1] = (e0.y + e1.y) + e2.y; e4[2] = (e0.z + e1.z) + e2.z; e4[3] = (e0.w + e1.w) + e2.w;
+                if (gc == 0) {                                           // the left neighbour (tap 3) of the first D columns is outside the tile too
+#pragma unroll
+                    for (int i = 0; i < D; ++i) e4[i] += Es[(1 * TRT + gr) * 4 + i];
+                }
+            }
+            const float v4[4] = {v.x, v.y, v.z, v.w};
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float u = ts[(gr + D) * PC + gc + D + i] * tm[(gr + D) * PC + gc + D + i];
+                o[i] = -u * ((acc[i] + v4[i]) + e4[i]);
+            }
+            *reinterpret_cast<float4*>(g_logits + n * P + (int64_t)(r0 + gr) * W + c0 + gc) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    if (XR > 0) {
+        const int gr = TR + th / TC, gc = th % TC;
+        if (r0 + gr < H && c0 + gc < W) {
+            const float v = Vp[gr * TC + gc];
+            float e = 0.f;
+            if (gc < D) e = Es[(0 * TRT + gr) * 4 + gc] + Es[(1 * TRT + gr) * 4 + gc];
+            if (gc >= TC - D) e = Es[(2 * TRT + gr) * 4 + gc - (TC - D)];
+            const float u = ts[(gr + D) * PC + gc + D] * tm[(gr + D) * PC + gc + D];
+            g_logits[n * P + (int64_t)(r0 + gr) * W + c0 + gc] = -u * ((acc2 + v) + e);
+        }
+    }
+    PWT(7);
+    PWT_FLUSH(1);
 }
 
 template <typename T>
@@ -799,10 +1223,20 @@ static int launch_bwd(const T* logits, const T* g_pair, int N, int H, int W, int
                     const int64_t tiles_b = tall ? t20 : t16;
                     if (!fits_i32(tiles_b)) return BXI_ERR_BAD_SHAPE;
                     const dim3 gb((unsigned)tiles_b);
+#ifndef BXI_PWB_PAIR
+#define BXI_PWB_PAIR 1
+#endif
 #define BXI_PWB(DD)                                                                                                                             \
                     {                                                                                                                           \
                         const size_t ldw = 2 * sizeof(float) * (size_t)(BXI_PWB_TR + (tall ? kXR : 0) + 2 * DD) * PwGeom<DD, BXI_PWB_TC>::PC; \
-                        if (tall)                                                                                                               \
+                        if (BXI_PWB_PAIR && BXI_PWB_TR == 16 && BXI_PWB_TC == 64 && H >= 2) {                                                          \
+                            if (tall)                                                                                                           \
+                                BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_pair_kernel<DD, 4>), gb, b, (PwPairGeom<DD, 4>::lds_bytes), st,     \
+                                           (const float*)logits, (const float*)g_pair, H, W, (float*)g_logits, env_swz);                        \
+                            else                                                                                                                \
+                                BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_pair_kernel<DD, 0>), gb, b, (PwPairGeom<DD, 0>::lds_bytes), st,     \
+                                           (const float*)logits, (const float*)g_pair, H, W, (float*)g_logits, env_swz);                        \
+                        } else if (tall)                                                                                                        \
                             BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_wide_kernel<DD, BXI_PWB_TR, BXI_PWB_TC, kXR>), gb, b, ldw, st, (const float*)logits, \
                                        (const float*)g_pair, H, W, (float*)g_logits, env_swz);                                                \
                         else                                                                                                                    \
