@@ -23,12 +23,16 @@ def hipcc() -> str:
     return exe
 
 
+FLAGS = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+         # -amdgpu-kernarg-preload-count: the first kernel arguments arrive in SGPRs with the wave instead of through a
+         # scalar load from the kernarg segment (one dependent memory round trip less at the start of every wave)
+         '-mllvm', '-amdgpu-kernarg-preload-count=16']
+
+
 def command(extra: List[str] | None = None, out: str | None = None) -> List[str]:
-    # -amdgpu-kernarg-preload-count: the first kernel arguments arrive in SGPRs with the wave instead of through a
-    # scalar load from the kernarg segment (one dependent memory round trip less at the start of every wave)
-    return [hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wall',
-            '-Wno-unused-function', '-mllvm', '-amdgpu-kernarg-preload-count=16', *(extra or []), '-o', out or LIB_PATH,
-            *[os.path.join(CSRC, s) for s in SOURCES]]
+    """The one-command form (every source in one hipcc call): what a maintainer would type; build() below compiles the
+    same sources with the same flags, one object per source in parallel, and links them."""
+    return [hipcc(), *FLAGS, '-shared', *(extra or []), '-o', out or LIB_PATH, *[os.path.join(CSRC, s) for s in SOURCES]]
 
 
 def is_stale() -> bool:
@@ -39,7 +43,26 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def _compile_and_link(out: str, extra: List[str], verbose: bool) -> None:
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    with tempfile.TemporaryDirectory(prefix='bxi_build_') as tmp:
+        def one(src: str) -> str:
+            obj = os.path.join(tmp, src.replace('.hip', '.o'))
+            cmd = [hipcc(), *FLAGS, *extra, '-c', os.path.join(CSRC, src), '-o', obj]
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.run(cmd, check=True)
+            return obj
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
+            objs = list(pool.map(one, SOURCES))
+        link = [hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', out, *objs]
+        if verbose:
+            print(' '.join(link))
+        subprocess.run(link, check=True)
+
+
+def build(force: bool = False, verbose: bool = False, extra: List[str] | None = None) -> str:
     """Compile every HIP source into boxinstseg_amd/lib/libboxinst_hip.so; returns its path."""
     if force or is_stale():
         import fcntl
@@ -50,11 +73,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 # link into a temporary name and rename: a process that dlopens LIB_PATH meanwhile sees the old or the new
                 # library, never a partially written one, and a failed compile leaves no truncated file behind
                 tmp = os.path.join(LIB_DIR, f'.libboxinst_hip.{os.getpid()}.so.tmp')
-                cmd = command(out=tmp)
-                if verbose:
-                    print(' '.join(cmd))
                 try:
-                    subprocess.run(cmd, check=True)
+                    _compile_and_link(tmp, list(extra or []), verbose)
                     os.replace(tmp, LIB_PATH)
                 finally:
                     if os.path.exists(tmp):

@@ -6,7 +6,8 @@
 // Roofline: HBM.  Forward moves 4*(1+K) B per pixel (K = size^2-1 output planes, write-bound);
 // backward 4*(1+K+1) B per pixel (g_pairwise read once through L2: every element is used by the
 // pixel itself (channel k) and by one neighbour (channel K-1-k)).  size == 3 runs the tiled kernels
-// further down (13.1 us / 20.7 us at 32x200x256 f32); the two kernels below serve the other window sizes.
+// further down (12.8 us / 15.4 us at 32x200x256 f32, cold, against 12.7 for a copy of the backward's bytes); the two kernels below serve
+// the other window sizes.
 #include "common.hpp"
 
 namespace bxi {
@@ -423,16 +424,16 @@ __global__ __launch_bounds__(256) void pairwise3_bwd_kernel(const T* __restrict_
     }
 }
 
-// ---- f32, size == 3, rows of whole float4 (W % 4 == 0, 16-byte aligned planes): the "wide" kernels ------------------------------
+// ---- f32, size == 3, rows of whole float4 (W % 4 == 0, 16-byte aligned planes): the "wide" forward, the "pair" backward ---------
 // The kernels above give a lane one column and four rows: 32 (forward) / 64 (backward) four-byte memory instructions per thread,
 // and at 52 MB of output / input the launch is bound by ISSUING them (MI355X_MICROARCH.md: epilogue store tails are store-issue
 // bound; 16-byte accesses halve them).  Here a thread owns FOUR ADJACENT PIXELS of one row of the 16 x 64 tile:
 //   forward   every pixel evaluates all eight of its pairs itself (f(p,q) = f(q,p) bit for bit, so the partner would get the same
 //             number): 8 x float4 stores per thread, aligned, no partner stores, no edge cases; the second evaluation of a pair
 //             is two multiply-adds and one v_log_f32 against 4 x fewer store instructions;
-//   backward  d f/d x_p summed over all eight taps by the pixel itself (the tap evaluations are the ones the branch-free body
-//             above already made; the LDS deposit slots, their zeroing and the second barrier go): 8 aligned float4 loads of
-//             g[k][p] + 8 dword-aligned float4 loads of the partner terms g[7-k][p + delta_k] per thread instead of 64 dword loads.
+//   backward  every UNORDERED pair once (further down).  Rounds 3-5 summed d f/d x_p over all eight taps in the pixel itself: 16 float4
+//             loads per thread, every gradient element fetched twice (tools/micro/pw_bwd_wide_ref.inc keeps that kernel as the
+//             measuring stick: 19.4 us where the pair kernel takes 15.4 and a copy of the bytes 12.7, same box, cold).
 // The neighbours' probabilities of the four pixels overlap: 3 rows x (4 + 2d) staged entries are read once per thread.
 // A tile with a logit beyond +-34 (S could underflow) takes a per-pixel log-space path straight from global memory, exactly
 // pairwise.cu:38-58 (block-uniform choice, no extra LDS).
@@ -549,177 +550,9 @@ static __device__ long long* g_pw_trace = nullptr;
 #define PWT(ph) do {} while (0)
 #define PWT_FLUSH(kid) do {} while (0)
 #endif
-#ifndef BXI_PWB_OCC
-#define BXI_PWB_OCC 5
-#endif
-// XR > 0: the workgroup's tile has XR MORE rows (XR * TC == 256), of which every thread takes ONE pixel in a second phase, after its four
-// adjacent ones -- a tile of TR + XR = 20 rows makes 32 x 200 x 256 exactly 1280 workgroups = ONE residency round at five workgroups per CU
-// (16-row tiles: 1664 workgroups = 1.3 rounds, the second one a quarter full and as long as the first), with no partly filled last tile
-// row (200 = 10 x 20) and a smaller halo share of the staged tile (24 x 68 for 20 x 64 instead of 20 x 68 for 16 x 64).  The second phase
-// re-uses the first one's registers: the kernel stays at five workgroups per CU.
-// (dilation 3 / 4: a 3 x 10 / 3 x 12 window per plane -- one workgroup per CU fewer instead of spilled registers)
-template <int D, int TR, int TC, int XR = 0>
-__global__ __launch_bounds__(256, (D <= 2 ? BXI_PWB_OCC : BXI_PWB_OCC - 1)) void pairwise3_bwd_wide_kernel(const float* __restrict__ logits, const float* __restrict__ g_pair, int H, int W,
-                                                                 float* __restrict__ g_logits, int xcd_swizzle) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char pw_raw[];
-    constexpr int PC = PwGeom<D, TC>::PC, NWp = 4 * PwGeom<D, TC>::NW4;
-    static_assert(TR * TC == 1024 && TC % 4 == 0, "256 threads x four adjacent pixels");
-    static_assert(XR == 0 || XR * TC == 256, "second phase: one pixel per thread");
-    constexpr int TRT = TR + XR;
-    const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TRT - 1) / TRT;
-    // workgroups are dealt to the 8 XCDs round-robin by index; each XCD has its own L2.  Tile order = index order WITHIN an XCD, so
-    // that the tiles an XCD works on at one time are neighbours: the partner terms that reach into the next tile are then lines its
-    // own L2 has just fetched -- 19.2 -> 15.7 us at 32 x 200 x 256 (with the plain order a tile's four neighbours run on four other
-    // XCDs, and every halo line crosses the fabric again)
-    // The map is a bijection on [0, G) for EVERY grid size G = 8 q + r: XCD x owns q + (x < r) consecutive tiles starting at
-    // x q + min(x, r), and workgroup i (XCD i mod 8, its (i / 8)-th workgroup there) takes the (i / 8)-th of them; i / 8 < q + (x < r)
-    // because i < G.  (Round 3 used x * ceil(G / 8) + i / 8 and skipped tiles whenever G mod 8 != 0.)
-    int t = (int)blockIdx.x;
-    if (xcd_swizzle) {
-        const unsigned x = blockIdx.x % 8u, q = gridDim.x / 8u, r = gridDim.x % 8u;
-        t = (int)(x * q + (x < r ? x : r) + blockIdx.x / 8u);
-    }
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y;
-    const int64_t n = t / tiles_y;
-    const int64_t P = (int64_t)H * W;
-    const int r0 = ty * TRT, c0 = tx * TC;
-    const float* L = logits + n * P;
-    const int lr = threadIdx.x / (TC / 4), lc = (threadIdx.x % (TC / 4)) * 4;
-    const int r = r0 + lr, c = c0 + lc;
-    const bool live = r < H && c < W;
-    // the gradient sums G = g[k][p] + g[7-k][q] of the thread's four pixels: 16 sixteen-byte loads, requested before the tile is
-    // staged so that they fly meanwhile.  A partner outside the map gets weight 0 later: its address only has to stay inside the
-    // instance's 8 planes (one clamp on the byte offset).
-    const char* gb = reinterpret_cast<const char*>(g_pair + n * 8 * P);  // wave-uniform base + 32-bit byte offsets
-    const int plane = (int)P * 4, lim = 8 * plane - 16;
-    const int pix = (min(r, H - 1) * W + min(c, W - 4)) * 4;
-    // PMC (profiles/r03_pairwise_op_pmc.txt): with the XCD-aware tile order above the launch fetches 59 MB for its 59 MB of input (the
-    // partner terms -- the same lines, shifted -- hit the XCD's L2; with the plain order: 91 MB, nearly every L2 request a miss, 19.2 us).
-    // What is left at 15.7-15.9 us: 1664 workgroups on 1280 slots (93 VGPRs: five waves a SIMD) = 1.3 rounds of residency; six / seven
-    // workgroups a CU (80 / 72 VGPRs, 4 / 23 spilled) measure 16.7-17.8 / 25.5 us.  Measured before the tile order was fixed (and all
-    // slower than this form then): the two reads of a plane eight instructions or a memory round trip apart, a resident grid walking its
-    // tiles with the next tile's loads in flight, 8 x 128 and 4 x 256 tiles, the gradient planes staged through LDS.  profiles/NOTES.md.
-    PWT_DECL;
-    PWT(0);
-    float4 own[8];
-    f4u part[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = 7 - j, kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;      // plane j is the partner plane of channel k = 7 - j
-        own[j] = *reinterpret_cast<const float4*>(gb + (uint32_t)(j * plane + pix));
-        const int nb = min(max(j * plane + pix + ((dy * D) * W + dx * D) * 4, 0), lim);
-        part[k] = *reinterpret_cast<const f4u*>(gb + (uint32_t)nb);
-    }
-    float4 G[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) G[k] = make_float4(own[k].x + part[k].x, own[k].y + part[k].y, own[k].z + part[k].z, own[k].w + part[k].w);
-    float* ts = reinterpret_cast<float*>(pw_raw);
-    float* tm = ts + (TRT + 2 * D) * PC;
-    bool sat;
-    PWT(1);
-    pw3_stage_probs<D, TRT, TC>(L, H, W, r0, c0, ts, tm, sat);
-    PWT(3);
-    if (XR == 0 && !live) return;
-    if (live) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (sat) {                                                           // rare: log space, straight from global memory (pairwise.cu:56-58)
-        for (int i = 0; i < 4; ++i) {
-            const float here = L[r * W + c + i];
-            const float ax = logsig(here), bx = logsig(-here);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int kk = k < 4 ? k : k + 1, r2 = r + (kk / 3 - 1) * D, c2 = c + i + (kk % 3 - 1) * D;
-                if (r2 >= 0 && r2 < H && c2 >= 0 && c2 < W) {
-                    const float there = L[r2 * W + c2];
-                    const float ay = logsig(there), by = logsig(-there);
-                    const float pair = pair_nlog(ax, bx, ay, by);
-                    const float g = i == 0 ? G[k].x : (i == 1 ? G[k].y : (i == 2 ? G[k].z : G[k].w));
-                    acc[i] += -(expf(ay) - expf(by)) * expf(ax + bx + pair) * g;
-                }
-            }
-        }
-    } else {
-        float qs[3][NWp], qm[3][NWp];
-        pw3_window<D, TC>(ts, lr, lc, qs);
-        pw3_window<D, TC>(tm, lr, lc, qm);
-        const bool r_lo = r - D >= 0, r_hi = r + D < H;
-        float up[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) up[i] = qs[1][D + i] * qm[1][D + i];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;
-            const bool row_in = dy < 0 ? r_lo : (dy > 0 ? r_hi : true);
-            const float g4[4] = {G[k].x, G[k].y, G[k].z, G[k].w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float ns = qs[1 + dy][D + i + dx * D], nm = qm[1 + dy][D + i + dx * D];
-                const bool in = row_in && (dx < 0 ? c + i - D >= 0 : (dx > 0 ? c + i + D < W : true));
-                const float S = qs[1][D + i] * ns + qm[1][D + i] * nm;   // >= 3e-15: every |logit| <= 34
-                const float m = in ? g4[i] * fast_rcp(S) : 0.f;          // d f / d x_p = -(s_q - s'_q) s_p s'_p / S
-                acc[i] += -(ns - nm) * up[i] * m;
-            }
-        }
-    }
-    *reinterpret_cast<float4*>(g_logits + n * P + (int64_t)r * W + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    }
-    PWT(5);
-    if (XR > 0) {
-        // ---- second phase: ONE pixel of rows TR .. TR + XR - 1 per thread (its requests go out when the first phase's registers are free)
-        const int lr2 = TR + (int)threadIdx.x / TC, lc2 = (int)threadIdx.x % TC;
-        const int r2 = r0 + lr2, c2 = c0 + lc2;
-        if (r2 >= H || c2 >= W) return;
-        const int pix2 = (r2 * W + c2) * 4, lim2 = 8 * plane - 4;
-        float a2 = 0.f;
-        if (sat) {                                                       // rare: log space, straight from global memory (pairwise.cu:56-58)
-            const float here = L[r2 * W + c2];
-            const float ax = logsig(here), bx = logsig(-here);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1, r3 = r2 + dy * D, c3 = c2 + dx * D;
-                if (r3 >= 0 && r3 < H && c3 >= 0 && c3 < W) {
-                    const float there = L[r3 * W + c3];
-                    const float ay = logsig(there), by = logsig(-there);
-                    const float pair = pair_nlog(ax, bx, ay, by);
-                    const float g = g_pair[(n * 8 + k) * P + (int64_t)r2 * W + c2] + g_pair[(n * 8 + (7 - k)) * P + (int64_t)r3 * W + c3];
-                    a2 += -(expf(ay) - expf(by)) * expf(ax + bx + pair) * g;
-                }
-            }
-        } else {
-            float G2[8];
-            {
-                float o2[8], p2[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = 7 - j, kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;
-                    o2[j] = *reinterpret_cast<const float*>(gb + (uint32_t)(j * plane + pix2));
-                    const int nb = min(max(j * plane + pix2 + ((dy * D) * W + dx * D) * 4, 0), lim2);
-                    p2[k] = *reinterpret_cast<const float*>(gb + (uint32_t)nb);
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) G2[k] = o2[k] + p2[k];
-            }
-            const float s0 = ts[(lr2 + D) * PC + lc2 + D], m0 = tm[(lr2 + D) * PC + lc2 + D], up2 = s0 * m0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int kk = k < 4 ? k : k + 1, dy = kk / 3 - 1, dx = kk % 3 - 1;
-                const bool in = (dy < 0 ? r2 - D >= 0 : (dy > 0 ? r2 + D < H : true)) && (dx < 0 ? c2 - D >= 0 : (dx > 0 ? c2 + D < W : true));
-                const float ns = ts[(lr2 + D + dy * D) * PC + lc2 + D + dx * D], nm = tm[(lr2 + D + dy * D) * PC + lc2 + D + dx * D];
-                const float S = s0 * ns + m0 * nm;
-                const float m = in ? G2[k] * fast_rcp(S) : 0.f;
-                a2 += -(ns - nm) * up2 * m;
-            }
-        }
-        g_logits[n * P + (int64_t)r2 * W + c2] = a2;
-    }
-    PWT(7);
-    PWT_FLUSH(0);
-}
-
 // ---- f32, size == 3, W % 4 == 0: every UNORDERED pair once ("pair" kernel) ---------------------------------------------------------
-// The wide backward above lets every pixel evaluate all eight of its taps: each pair {p, q} is evaluated twice, and each element of the
-// upstream gradient is fetched twice (once as g[k][p], once as the partner term g[7-k][.] of a neighbour).  But the pair has ONE
+// Letting every pixel evaluate all eight of its taps evaluates each pair {p, q} twice and fetches each element of the upstream gradient
+// twice (once as g[k][p], once as the partner term g[7-k][.] of a neighbour).  But the pair has ONE
 //     S = s_p s_q + s'_p s'_q ,  ONE 1/S ,  ONE G = g[k][p] + g[7-k][q]                                              (pairwise.cu:52-66)
 // and feeds d/dx_p = -u_p (t_q G/S) and d/dx_q = -u_q (t_p G/S)   (t = s - s', u = s s').  Here the EARLIER pixel p of a pair (k = 4..7:
 // q to the right in the row, or in the row D below) evaluates it, keeps t_q G/S and hands t_p G/S to q; the factor -u is applied by the
@@ -738,8 +571,8 @@ __global__ __launch_bounds__(256, (D <= 2 ? BXI_PWB_OCC : BXI_PWB_OCC - 1)) void
 // Out-of-map neighbours are staged as x = 0 (s = s' = 1/2, t = 0 exactly): their pairs contribute 0 by arithmetic, G is forced to 0 by a select
 // (a NaN / inf elsewhere in the upstream gradient must not leak through a clamped address).  Sums per pixel: own four taps, then the row share,
 // then V, then E -- a fixed order, run-to-run identical.
-#ifndef BXI_PWP_X
-#define BXI_PWP_X 0          // timing experiments (wrong results): 1 no edge loads, 2 no extra-row loads, 4 main requests before the others
+#ifndef BXI_PWP_OCC
+#define BXI_PWP_OCC 5
 #endif
 #define BXI_DPP_ROW_SHL1 0x101
 #define BXI_DPP_ROW_SHR1 0x111
@@ -789,7 +622,7 @@ template <int D, int XR> struct PwPairGeom {
 };
 
 template <int D, int XR>
-__global__ __launch_bounds__(256, (D <= 2 ? BXI_PWB_OCC : BXI_PWB_OCC - 1)) void pairwise3_bwd_pair_kernel(const float* __restrict__ logits, const float* __restrict__ g_pair, int H, int W,
+__global__ __launch_bounds__(256, BXI_PWP_OCC) void pairwise3_bwd_pair_kernel(const float* __restrict__ logits, const float* __restrict__ g_pair, int H, int W,
                                                                  float* __restrict__ g_logits, int xcd_swizzle) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pw_raw[];
     typedef PwPairGeom<D, XR> Gm;
@@ -798,9 +631,12 @@ __global__ __launch_bounds__(256, (D <= 2 ? BXI_PWB_OCC : BXI_PWB_OCC - 1)) void
     static_assert(XR == 0 || XR * TC == 256, "second phase: one pixel per thread, wave = row");
     const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TRT - 1) / TRT;
     int t = (int)blockIdx.x;                                             // XCD-aware tile order: see pairwise3_bwd_wide_kernel
-    if (xcd_swizzle) {
+    if (xcd_swizzle == 1) {
         const unsigned x = blockIdx.x % 8u, q = gridDim.x / 8u, r = gridDim.x % 8u;
         t = (int)(x * q + (x < r ? x : r) + blockIdx.x / 8u);
+    } else if (xcd_swizzle >= 2) {                                       // groups of (xcd_swizzle - 1) tile rows stay on one XCD; consecutive groups on consecutive XCDs
+        const unsigned gsz = (unsigned)tiles_x * (unsigned)(xcd_swizzle - 1), full = gridDim.x / (8u * gsz) * (8u * gsz);
+        if (blockIdx.x < full) { const unsigned x = blockIdx.x % 8u, j = blockIdx.x / 8u; t = (int)((8u * (j / gsz) + x) * gsz + j % gsz); }
     }
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
@@ -880,7 +716,6 @@ __global__ __launch_bounds__(256, (D <= 2 ? BXI_PWB_OCC : BXI_PWB_OCC - 1)) void
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int dy = j == 0 ? 0 : 1, dx = j == 0 ? 1 : j - 2;
-            if (BXI_PWP_X & 2) { xo[j] = 0.f; xp[j] = (float)dx; continue; }
             xo[j] = *(gf1)(pb[4 + j] + (uint32_t)pix2);
             xp[j] = *(gf1)((dy ? pdn[3 - j] : pb[3 - j]) + (uint32_t)pix2 + dx * D * 4);
         }
@@ -1200,48 +1035,31 @@ static int launch_bwd(const T* logits, const T* g_pair, int N, int H, int W, int
                 BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_kernel<T, DD>), g, b, lds, st, logits, g_pair, H, W, dil, g_logits);             \
             }
             if constexpr (sizeof(T) == 4) {
-                if (dil <= 4 && (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(g_pair) | reinterpret_cast<uintptr_t>(g_logits)) & 15) == 0) {
-#ifdef BXI_DEV                                       // developer knob (tools/ A/B scripts); the shipped library reads nothing from the environment
-                    static const int env_swz = getenv("BXI_PW_SWIZZLE") ? atoi(getenv("BXI_PW_SWIZZLE")) : 1;
-#else
-                    constexpr int env_swz = 1;
-#endif
-#ifndef BXI_PWB_TR
-#define BXI_PWB_TR 16
-#define BXI_PWB_TC 64
-#endif
+                // (H >= 2: a tap's offset stays below one plane, so that every address of the pair kernel lies inside the instance's 8 planes)
+                if (dil <= 4 && (W & 3) == 0 && H >= 2 && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(g_pair) | reinterpret_cast<uintptr_t>(g_logits)) & 15) == 0) {
                     // 16-row tiles, or 20-row tiles (16 rows of four pixels per thread + 4 rows of one): whichever needs fewer residency
                     // rounds x rows (five workgroups per CU), then whichever pads the map's height less.  32 x 200 x 256: 1664 workgroups
                     // = 2 rounds of 16 rows against 1280 = ONE round of 20.
-                    constexpr int kXR = 256 / BXI_PWB_TC;
-                    const int64_t cols_b = (W + BXI_PWB_TC - 1) / BXI_PWB_TC;
-                    const int64_t t16 = (int64_t)N * ((H + BXI_PWB_TR - 1) / BXI_PWB_TR) * cols_b, t20 = (int64_t)N * ((H + BXI_PWB_TR + kXR - 1) / (BXI_PWB_TR + kXR)) * cols_b;
-                    const int64_t slots_b = (int64_t)(dil <= 2 ? BXI_PWB_OCC : BXI_PWB_OCC - 1) * pw_device_cus();
-                    const int64_t c16 = ((t16 + slots_b - 1) / slots_b) * BXI_PWB_TR, c20 = ((t20 + slots_b - 1) / slots_b) * (BXI_PWB_TR + kXR);
-                    const int64_t p16 = (int64_t)((H + BXI_PWB_TR - 1) / BXI_PWB_TR) * BXI_PWB_TR, p20 = (int64_t)((H + BXI_PWB_TR + kXR - 1) / (BXI_PWB_TR + kXR)) * (BXI_PWB_TR + kXR);
-                    const bool tall = BXI_PWB_TR * BXI_PWB_TC == 1024 && kXR * BXI_PWB_TC == 256 && (c20 < c16 || (t16 <= slots_b && t20 <= slots_b && p20 < p16));
+                    constexpr int kTR = 16, kTC = 64, kXR = 256 / kTC;
+                    const int64_t cols_b = (W + kTC - 1) / kTC;
+                    const int64_t t16 = (int64_t)N * ((H + kTR - 1) / kTR) * cols_b, t20 = (int64_t)N * ((H + kTR + kXR - 1) / (kTR + kXR)) * cols_b;
+                    const int64_t slots_b = (int64_t)BXI_PWP_OCC * pw_device_cus();
+                    const int64_t c16 = ((t16 + slots_b - 1) / slots_b) * kTR, c20 = ((t20 + slots_b - 1) / slots_b) * (kTR + kXR);
+                    const int64_t p16 = (int64_t)((H + kTR - 1) / kTR) * kTR, p20 = (int64_t)((H + kTR + kXR - 1) / (kTR + kXR)) * (kTR + kXR);
+                    const bool tall = c20 < c16 || (t16 <= slots_b && t20 <= slots_b && p20 < p16);
                     const int64_t tiles_b = tall ? t20 : t16;
                     if (!fits_i32(tiles_b)) return BXI_ERR_BAD_SHAPE;
                     const dim3 gb((unsigned)tiles_b);
-#ifndef BXI_PWB_PAIR
-#define BXI_PWB_PAIR 1
-#endif
+                    // tile order: groups of two tile rows on one XCD, consecutive groups on consecutive XCDs (kernel: xcd_swizzle = 1 + rows per group)
+                    constexpr int kSwz = 3;
 #define BXI_PWB(DD)                                                                                                                             \
                     {                                                                                                                           \
-                        const size_t ldw = 2 * sizeof(float) * (size_t)(BXI_PWB_TR + (tall ? kXR : 0) + 2 * DD) * PwGeom<DD, BXI_PWB_TC>::PC; \
-                        if (BXI_PWB_PAIR && BXI_PWB_TR == 16 && BXI_PWB_TC == 64 && H >= 2) {                                                          \
-                            if (tall)                                                                                                           \
-                                BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_pair_kernel<DD, 4>), gb, b, (PwPairGeom<DD, 4>::lds_bytes), st,     \
-                                           (const float*)logits, (const float*)g_pair, H, W, (float*)g_logits, env_swz);                        \
-                            else                                                                                                                \
-                                BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_pair_kernel<DD, 0>), gb, b, (PwPairGeom<DD, 0>::lds_bytes), st,     \
-                                           (const float*)logits, (const float*)g_pair, H, W, (float*)g_logits, env_swz);                        \
-                        } else if (tall)                                                                                                        \
-                            BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_wide_kernel<DD, BXI_PWB_TR, BXI_PWB_TC, kXR>), gb, b, ldw, st, (const float*)logits, \
-                                       (const float*)g_pair, H, W, (float*)g_logits, env_swz);                                                \
+                        if (tall)                                                                                                               \
+                            BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_pair_kernel<DD, kXR>), gb, b, (PwPairGeom<DD, kXR>::lds_bytes), st,   \
+                                       (const float*)logits, (const float*)g_pair, H, W, (float*)g_logits, kSwz);                               \
                         else                                                                                                                    \
-                            BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_wide_kernel<DD, BXI_PWB_TR, BXI_PWB_TC>), gb, b, ldw, st, (const float*)logits, \
-                                       (const float*)g_pair, H, W, (float*)g_logits, env_swz);                                                \
+                            BXI_LAUNCH("pairwise_bwd", st, (pairwise3_bwd_pair_kernel<DD, 0>), gb, b, (PwPairGeom<DD, 0>::lds_bytes), st,       \
+                                       (const float*)logits, (const float*)g_pair, H, W, (float*)g_logits, kSwz);                               \
                     }
                     switch (dil) { case 1: BXI_PWB(1) break; case 2: BXI_PWB(2) break; case 3: BXI_PWB(3) break; default: BXI_PWB(4) break; }
 #undef BXI_PWB

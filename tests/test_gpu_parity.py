@@ -130,6 +130,57 @@ def test_pairwise_op_backward_covers_every_tile(dev, shape):
     assert np.abs(got - want_g).max() <= 2e-5 * max(1.0, np.abs(want_g).max())
 
 
+@pytest.mark.parametrize('shape,dil', [((2, 37, 132), 1), ((2, 37, 132), 2), ((2, 37, 132), 3), ((2, 37, 132), 4), ((3, 45, 68), 4), ((1, 23, 200), 3),
+                                       ((5, 2, 8), 1), ((4, 3, 4), 2), ((2, 5, 64), 4), ((1, 20, 64), 2), ((7, 41, 256), 2), ((2, 100, 320), 1)])
+def test_pairwise_op_pair_backward_shapes(dev, shape, dil):
+    """The f32 size-3 backward for W % 4 == 0 evaluates every unordered pair once (pairwise3_bwd_pair_kernel): the share of the later pixel travels
+    by DPP / through LDS inside a 16- or 20-row x 64-column tile, pairs across a tile border are evaluated as edge items.  Every dilation the
+    kernel is built for, maps narrower / shorter than a tile, ragged last tiles in both directions, 16- and 20-row tile forms, against the oracle
+    (pairwise.cu:106-149); the output is pre-filled with NaN."""
+    from boxinstseg_amd import _lib
+    from oracle import c_oracle
+    rng = np.random.default_rng(23)
+    x = (rng.standard_normal(shape) * 3).astype(np.float32)
+    want = c_oracle.pairwise_nlog_fwd(x, 3, dil)
+    gp = rng.standard_normal(want.shape).astype(np.float32)
+    want_g = c_oracle.pairwise_nlog_bwd(x, want, gp, 3, dil)
+    xt = torch.from_numpy(x[:, None]).to(dev)
+    pw = torch.from_numpy(want).to(dev)
+    gpt = torch.from_numpy(gp).to(dev)
+    g = torch.full_like(xt, float('nan'))
+    lib = _lib.load()
+    rc = lib.bxi_pairwise_nlog_backward_f32(xt.data_ptr(), pw.data_ptr(), gpt.data_ptr(), shape[0], shape[1], shape[2], 3, dil, g.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    got = g.cpu().numpy()[:, 0]
+    assert np.isfinite(got).all(), 'pixels left unwritten: %d' % int((~np.isfinite(got)).sum())
+    assert np.abs(got - want_g).max() <= 2e-5 * max(1.0, np.abs(want_g).max())
+
+
+def test_pairwise_op_backward_ignores_gradient_of_padded_taps(dev):
+    """pairwise.cu:118-121 skips a tap that leaves the map: whatever the upstream gradient holds there (inf, NaN) must not reach g_logits.
+    The pair kernel reads those positions through in-bounds addresses and forces their sum to 0 by a select, not by a multiplication."""
+    from boxinstseg_amd import pairwise_nlog_backward, pairwise_nlog_forward
+    from oracle import c_oracle
+    rng = np.random.default_rng(29)
+    x = (rng.standard_normal((2, 24, 72)) * 2).astype(np.float32)
+    pw = c_oracle.pairwise_nlog_fwd(x, 3, 2)
+    gp = rng.standard_normal(pw.shape).astype(np.float32)
+    want_g = c_oracle.pairwise_nlog_bwd(x, pw, gp, 3, 2)
+    bad = gp.copy()
+    H, W = x.shape[1:]
+    for k in range(8):
+        kk = k if k < 4 else k + 1
+        dy, dx = (kk // 3 - 1) * 2, (kk % 3 - 1) * 2
+        rr, cc = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+        out = (rr + dy < 0) | (rr + dy >= H) | (cc + dx < 0) | (cc + dx >= W)
+        bad[:, k][:, out] = np.where(rng.random(out.sum()) < 0.5, np.inf, np.nan)
+    xt = torch.from_numpy(x[:, None]).to(dev)
+    got = pairwise_nlog_backward(3, 2, xt, pairwise_nlog_forward(3, 2, xt), torch.from_numpy(bad).to(dev)).cpu().numpy()[:, 0]
+    assert np.isfinite(got).all()
+    assert np.abs(got - want_g).max() <= 2e-5 * max(1.0, np.abs(want_g).max())
+
+
 def test_pairwise_op_errors(dev):
     from boxinstseg_amd import pairwise_nlog, pairwise_nlog_forward
     with pytest.raises(RuntimeError, match='CUDA'):
