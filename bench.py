@@ -435,6 +435,35 @@ def worker(args):
         rf['frac_of_sol'] = sol['us_per_step'] / step_us
         rf['sol'] = sol
 
+    # The driver's record keeps `config`, `roofline` and `cpu_baseline` of this line (and the last few KB of its text): the figures the
+    # documents quote besides the headline -- the shapes training runs (64 / 128 instances), the loss with the targets made ahead, the op-level
+    # pairwise_nlog kernels -- go INTO `roofline` as short scalars (us = microseconds per call, frac = algorithmic bytes / time / HBM peak,
+    # sol_us = the same bytes moved by a copy in the same run, ok = the oracle gate of that shape).
+    if 'roofline' in result and 'extras' in result:
+        ex, shapes = result['extras'], {}
+        def r4(v):
+            return None if v is None else round(float(v), 4)
+        for key in ('n64', 'n128'):
+            e = ex.get(key)
+            if isinstance(e, dict) and 'us_per_step' in e:
+                par = e.get('parity') or {}
+                shapes[key] = {'us': r4(e['us_per_step']), 'frac': r4(e['frac']), 'sol_us': r4(e.get('sol_us')),
+                               'ok': bool(par.get('ok')) if par else None,
+                               'given_targets_us': r4((e.get('loss_given_targets') or {}).get('us_per_step'))}
+        lg = ex.get('loss_given_targets')
+        if isinstance(lg, dict) and 'us_per_step' in lg:
+            shapes['n32_given_targets'] = {'us': r4(lg['us_per_step']), 'frac': r4(lg.get('frac'))}
+        po = ex.get('pairwise_op')
+        if isinstance(po, dict) and 'bwd_us' in po:
+            both = (po['fwd_bytes'] + po['bwd_bytes']) / ((po['fwd_us'] + po['bwd_us']) * 1e-6) / 1e9 / HBM_PEAK_GBPS
+            shapes['pairwise_op'] = {'fwd_us': r4(po['fwd_us']), 'bwd_us': r4(po['bwd_us']), 'fwd_frac': r4(po['fwd_frac']), 'bwd_frac': r4(po['bwd_frac']),
+                                     'fwd_sol_us': r4(po.get('fwd_sol_us')), 'bwd_sol_us': r4(po.get('bwd_sol_us')),
+                                     'bwd_frac_of_sol': r4(po.get('bwd_frac_of_sol')), 'fwd_bwd_frac': r4(both)}
+        ma = result.get('module_api')
+        if isinstance(ma, dict) and 'us_per_call' in ma:
+            shapes['module_api_us'] = r4(ma['us_per_call'])
+        result['roofline']['shapes'] = shapes
+
     if c_oracle_leg is not None:
         cpu_leg = cpu_baseline(sets[0].d, args.cpu_seconds)
         cpu_leg['c_oracle_openmp'] = c_oracle_leg
@@ -442,6 +471,9 @@ def worker(args):
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
+        for key in ('roofline', 'cpu_baseline'):          # last in the line: the driver keeps the line's tail
+            if key in result:
+                result[key] = result.pop(key)
         json_out.write(json.dumps(result) + '\n')
         json_out.flush()
 
