@@ -57,7 +57,10 @@ constexpr int kSRows = 8;                       // rows per stream wave
 constexpr int kSBlk = kWaves * kSRows;          // rows per stream workgroup
 constexpr int kChunkC = 256;                    // columns per pass of a stream wave: 64 lanes x float4
 constexpr int kMaxDilFused = 4;
-constexpr int kSpinLimit = 4000000;             // bounded waits (0.3 - 1 us per poll: seconds): a bound, not a schedule -- a transient stall (another
+#ifndef BXI_SPIN_LIMIT
+#define BXI_SPIN_LIMIT 4000000
+#endif
+constexpr int kSpinLimit = BXI_SPIN_LIMIT;             // bounded waits (0.3 - 1 us per poll: seconds): a bound, not a schedule -- a transient stall (another
                                                 // process time-slicing the GPU, a long kernel on another stream while stream workgroups stay on) must
                                                 // not turn an iteration's losses into NaN; running out is loud (NaN losses, status word) and the host
                                                 // side then takes the two-launch form, whose every wait is for an EARLIER workgroup
@@ -75,6 +78,16 @@ constexpr int kAcc1Words = 64;                  // count-wave arrivals + sum W: 
 constexpr int kMaxInst = 65536;
 #ifndef BXI_ONE_OCC
 #define BXI_ONE_OCC 4
+#endif
+#ifndef BXI_LONG_OCC
+#define BXI_LONG_OCC 3      // workgroups per CU of the 8-row single-launch forms (138 VGPRs; a developer build may force 4: profiles/NOTES.md R6-3)
+#endif
+// developer builds (-DBXI_WAITLOG): the longest wait of every bounded in-grid wait, by site, in polls -- which wait a slow launch sat in
+#ifdef BXI_WAITLOG
+static __device__ unsigned int g_waitlog[16];
+#define BXI_WL(site, spins) do { if ((spins) > 1000 && (threadIdx.x & 63) == 0) atomicMax(&g_waitlog[site], (unsigned int)(spins)); } while (0)
+#else
+#define BXI_WL(site, spins) do {} while (0)
 #endif
 constexpr int kOneOcc = BXI_ONE_OCC;           // workgroups per CU of the single-launch form (<= 128 VGPRs: the tile role's budget)
 constexpr unsigned kFaultCounts = 1u, kFaultFinisher = 2u;
@@ -392,6 +405,7 @@ __device__ __forceinline__ bool tab_entry(const Ws& ws, int m, bool want, int sp
         const u4v v = load16_past(ws.tab + (want ? m : 0));
         if (__all(!want || v.w == ws.ep)) {
             e = want ? make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w) : make_int4(0, 0, 0, 0);
+            BXI_WL(1, spins);
             return true;
         }
         __builtin_amdgcn_s_sleep(BXI_SLEEP_TAB);
@@ -881,6 +895,7 @@ __device__ __forceinline__ int pred_item(int h, int w, int n_ent, const ValidCel
                 o0 = f4_of(q0); oD = f4_of(q1); x0 = f4_of(q2); xD = f4_of(q3);
                 rect = lane < n_ent ? make_int4((int)qe.x, (int)qe.y, (int)qe.z, (int)qe.w) : make_int4(-1, 0, 0, 0);
                 got = true;
+                BXI_WL(2, spins);
                 break;
             }
             __builtin_amdgcn_s_sleep(BXI_SLEEP_PRED);
@@ -954,6 +969,7 @@ __device__ __forceinline__ bool reduce_counts(const Ws& ws, int n_items, int spi
         if (arrived == n_items) {
             if ((threadIdx.x & 63) == 0)
                 __hip_atomic_store(ws.sumw, (1ull << 63) | (flt ? kSumwFault : 0ull) | (unsigned long long)tot, BXI_RLX, BXI_AGENT);
+            BXI_WL(3, spins);
             return true;
         }
     }
@@ -997,7 +1013,7 @@ __device__ __forceinline__ bool pred_words(const Ws& ws, const Tile& t, int h, i
             pbyte[i] = __hip_atomic_load(pp + (uint32_t)min(max(t.tile_r0 - D + i, 0), h - 1) * (uint32_t)w + cc, BXI_RLX, BXI_AGENT);
             all = all && (pbyte[i] >> 4) == want;
         }
-        if (__all(all)) { ok = true; break; }
+        if (__all(all)) { ok = true; BXI_WL(4, spins); break; }
         __builtin_amdgcn_s_sleep(BXI_SLEEP_WORDS);
     }
     return ok;        // false: the caller's arrival says so, and the finisher turns both losses into NaN
@@ -1182,7 +1198,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
                 if (have_scale) scale = upw_warm / fmaxf((float)total_w, 1.f);
             }
             bands_ok = f0 == ws.ep && f1 == ws.ep;
-            if (have_scale && bands_ok) { ok = true; break; }
+            if (have_scale && bands_ok) { ok = true; BXI_WL(5, spins); break; }
             __builtin_amdgcn_s_sleep(BXI_SLEEP_SUMW);
         }
         bad |= !ok;
@@ -1205,9 +1221,16 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
 // a rounding) and whether one of its bounded waits ran out, as one atomic without return on one of the N x 8 arrival words (each in its
 // own 128 bytes).  The finisher counts WAVES, so its last act -- advancing the workspace's epoch -- comes after every tile wave of
 // the launch has read the epoch (an idle wave that started late could otherwise draw the NEXT evaluation's tag and wait for nobody).
+// WHICH word: one of an instance whose table entry this wave has SEEN tagged -- the table wave of instances 64 k .. 64 k + 63 zeroes their arrival
+// words and drains before it writes their entries, and a tile wave checks entries 0 .. 63 and N only (tile_role).  Rounds 3-5 spread the arrivals
+// over all N x 8 words: in the single-launch forms a tile wave could then arrive on a word of instances 64 .. N - 1 that the SECOND table wave --
+// draining its written-through zeroes under the logit stream's traffic -- had not zeroed yet; the zero wiped the arrival, the finisher never saw its
+// count, ran out (status 2, NaN losses for that evaluation) after kSpinLimit polls = 4.1 s.  Seen five times in 4800 evaluations with the 8-row
+// kernels at four workgroups per CU and 128 instances, where the tile workgroups start just as the stream workgroups' traffic lets the table's
+// drains complete (profiles/NOTES.md R5-7, R6-3: the stall's length follows kSpinLimit, the wait that runs out is the finisher's).
 __device__ __forceinline__ void tile_wave_arrives(const Ws& ws, int N, int wid, long long fx_sum, bool bad) {
     if ((threadIdx.x & 63) == 0)
-        __hip_atomic_fetch_add(ws.acc2 + (size_t)(wid % (N * kAcc2Split)) * kAcc2Stride,
+        __hip_atomic_fetch_add(ws.acc2 + (size_t)(wid % ((N < 64 ? N : 64) * kAcc2Split)) * kAcc2Stride,
                                (1ull << 52) + (unsigned long long)(fx_sum + (1ll << 24)) + (bad ? kArrivalFault : 0ull), BXI_RLX, BXI_AGENT);
 }
 
@@ -1255,14 +1278,14 @@ __device__ __forceinline__ void leader_block(const InstArgs& a, int dil, Ws ws /
             } else
                 v = load16_past(ws.tab + n);
             if (lane >= ws.n_cb) f = ws.ep;
-            if (__all(f == ws.ep && v.w == ws.ep)) { e = make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w); waited = true; break; }
+            if (__all(f == ws.ep && v.w == ws.ep)) { e = make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w); waited = true; BXI_WL(6, spins); break; }
             __builtin_amdgcn_s_sleep(BXI_SLEEP_LEAD);
         }
         for (int b0 = 64; b0 < ws.n_cb && waited; b0 += 64) {
             bool got = false;
             for (int spins = 0; spins <= spin_limit; ++spins) {
                 const unsigned int f = b0 + lane < ws.n_cb ? __hip_atomic_load(&ws.bandflag[(int64_t)n * ws.n_cb + b0 + lane], BXI_RLX, BXI_AGENT) : ws.ep;
-                if (__all(f == ws.ep)) { got = true; break; }
+                if (__all(f == ws.ep)) { got = true; BXI_WL(7, spins); break; }
                 __builtin_amdgcn_s_sleep(BXI_SLEEP_LEAD);
             }
             waited = got;
@@ -1482,6 +1505,7 @@ __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, c
                 if (++spins > spin_limit) ok = false;
                 __builtin_amdgcn_s_sleep(BXI_SLEEP_FIN);
             }
+        BXI_WL(8, spins);
         if (lane == 0) { fin_f = dsum; fin_d[0] = total_w; fin_ok = ok ? 1 : 0; fin_flt = flt0 ? 1 : 0; }
     }
     __syncthreads();
@@ -1513,6 +1537,7 @@ __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, c
         if (all) break;
         if (++spins > spin_limit) { ok = false; break; }           // workgroup-uniform: the same count in every thread
     }
+    BXI_WL(10, spins);
     const double wsum = wave_total_f64((double)mine);                // exact; fixed order: run-to-run identical
     if (lane == 0) fin_d[wave] = wsum;
     __syncthreads();
@@ -1687,7 +1712,7 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 2 ? 4 : 3) : (D <= 2 ? 3 : 2))
 // READY (BXI_EVAL_TARGETS_READY): an instantiation of its own -- no pool / predicate role, table workgroups at the head of the grid, sum W
 // gathered by the reducer workgroup -- so that the un-split kernel stays what it was (the same registers, no extra argument).
 template <int D, int R, bool READY>
-__global__ __launch_bounds__(256, (R == 4 ? kOneOcc : 3)) void eval1_kernel(PoolArgs pa, int n_pool, int n_items, int n_pb, int n_tb, InstArgs a, Ws ws_in, LossState st, ValidCells vc,
+__global__ __launch_bounds__(256, (R == 4 ? kOneOcc : BXI_LONG_OCC)) void eval1_kernel(PoolArgs pa, int n_pool, int n_items, int n_pb, int n_tb, InstArgs a, Ws ws_in, LossState st, ValidCells vc,
                                                         const float* __restrict__ up_prj, const float* __restrict__ up_pw, float warmup, float n2max, int spin_limit,
                                                         float* __restrict__ losses, float* __restrict__ g_logits, int vec, int merge, int ready_in, unsigned int key,
                                                         int n_tabw_in) {
@@ -2182,7 +2207,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         const int env_one_pool = BXI_KNOB("BXI_ONE_POOL_WGS", 0);
         const int Sn = (a.h + kSBlk - 1) / kSBlk;
         const int n_stream = a.N * Sn;
-        const int slots = long_form ? 3 * device_cus() : one_slots;
+        const int slots = long_form ? BXI_LONG_OCC * device_cus() : one_slots;
         // the front half (table, stream, pool) should fill the GPU exactly once: a pool workgroup takes several items
         // (measured and dropped: pool workgroups alone filling the GPU first, predicate and stream workgroups behind them -- the
         // stream workgroups, and with them the band flags and the leaders, then end 8 us late: 22.9 us per evaluation against 18.3)
@@ -2385,6 +2410,13 @@ int launch_rescale(const bxi_instances* in, const float* g_prj, const float* g_p
 
 }  // namespace bxi
 
+#ifdef BXI_WAITLOG
+extern "C" int bxi_debug_waitlog(unsigned int* out16, int reset) {   // developer builds only
+    int rc = (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(bxi::g_waitlog), 16 * sizeof(unsigned int));
+    if (rc == 0 && reset) { unsigned int z[16] = {0}; rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(bxi::g_waitlog), z, sizeof(z)); }
+    return rc;
+}
+#endif
 #ifdef BXI_ABLATE
 extern "C" int bxi_debug_set_ablate(int bits) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(bxi::g_ablate), &bits, sizeof(bits)); }
 #endif
