@@ -13,10 +13,9 @@ from . import build as _build
 c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
 BXI_MAX_IMAGES = 64
-BXI_ABI_VERSION = 6
+BXI_ABI_VERSION = 7
 # `flags` of bxi_boxinst_eval_f32 / bxi_boxinst_head_eval_f32 (include/boxinst_hip.h)
-EVAL_SINGLE_LAUNCH, EVAL_TWO_LAUNCHES, EVAL_NO_STAY_ON, EVAL_TILE_ROWS_8, EVAL_SHARED_DEVICE, EVAL_WAITS_GIVE_UP = 1, 2, 4, 8, 16, 256
-EVAL_PRED_IN_PAIR, EVAL_PRED_IN_PREP, EVAL_TARGETS_READY, EVAL_TILE_ROWS_4 = 32, 64, 128, 512
+EVAL_SINGLE_LAUNCH, EVAL_TWO_LAUNCHES, EVAL_TILE_ROWS_8, EVAL_TILE_ROWS_4, EVAL_SHARED_DEVICE, EVAL_TARGETS_READY, EVAL_WAITS_GIVE_UP = 1, 2, 4, 8, 16, 32, 64
 
 STATUS = {0: 'BXI_OK', -1: 'BXI_ERR_NULL_POINTER', -2: 'BXI_ERR_BAD_SHAPE', -3: 'BXI_ERR_BAD_ARGUMENT',
           -4: 'BXI_ERR_UNSUPPORTED', -5: 'BXI_ERR_WORKSPACE', -6: 'BXI_ERR_LAUNCH', -7: 'BXI_ERR_NO_DEVICE'}

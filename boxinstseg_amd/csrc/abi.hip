@@ -97,11 +97,8 @@ int bxi_boxinst_targets_f32(const bxi_image_batch* batch_host, const float* cons
 // the combinations of `flags` that contradict each other
 static bool bad_eval_flags(unsigned int flags) {
     if (flags & ~(unsigned)BXI_EVAL_ALL_FLAGS) return true;
-    const unsigned int form = flags & (BXI_EVAL_SINGLE_LAUNCH | BXI_EVAL_TWO_LAUNCHES | BXI_EVAL_PRED_IN_PAIR | BXI_EVAL_PRED_IN_PREP);
-    if ((flags & BXI_EVAL_SINGLE_LAUNCH) && form != BXI_EVAL_SINGLE_LAUNCH) return true;
-    if ((flags & BXI_EVAL_PRED_IN_PAIR) && (flags & BXI_EVAL_PRED_IN_PREP)) return true;
+    if ((flags & BXI_EVAL_SINGLE_LAUNCH) && (flags & BXI_EVAL_TWO_LAUNCHES)) return true;
     if ((flags & BXI_EVAL_TILE_ROWS_8) && (flags & BXI_EVAL_TILE_ROWS_4)) return true;
-    if ((flags & BXI_EVAL_TARGETS_READY) && (flags & (BXI_EVAL_PRED_IN_PAIR | BXI_EVAL_PRED_IN_PREP))) return true;
     return false;
 }
 

@@ -45,6 +45,20 @@ struct LaunchScope {
 
 inline bool fits_i32(int64_t v) { return v >= 0 && v <= 0x7fffffffLL; }
 
+// compute units of the current device (256 on an MI355X in SPX mode, 32 per partition in CPX): grids are sized so that a launch is
+// resident in one round.  Cached per device ordinal; a wrong value costs time, never correctness.
+inline int device_cus() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cached[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 // ---- developer tracing (-DBXI_TRACE builds only; never in the shipped library) ---------------
 // BXI_T(kernel_id, block, phase) stores the 100 MHz wall clock of lane 0 into a global buffer.
 #ifdef BXI_TRACE

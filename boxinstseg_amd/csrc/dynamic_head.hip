@@ -794,11 +794,11 @@ int bxi_dynamic_mask_backward_f32(const float* feat, int B, int C, int H, int W,
 #endif
     int slots;
     if (form == 2 && (factor == 1 || factor == 2)) {
-        // dyn_bwd2_kernel, four workgroups per CU (1024 slots on the 256 CUs): as many slots per (image, tile) as keep the launch resident at
+        // dyn_bwd2_kernel, four workgroups per CU (1024 slots on 256 CUs): as many slots per (image, tile) as keep the launch resident at
         // once -- 2 x 52 x 8 = 832 workgroups at 2 x 100 x 128 --, all of them when there are many instances.  Measured against dyn_bwd_kernel
         // (rocprofv3, same box, 2 x 16 x 100 x 128 -> 200 x 256): 32 instances 28.2-28.8 -> 27.2-27.8 us (the reduction over 8 instead of 4
         // feature partials: 5.1 -> 5.6 us), 128 instances 78.6-79.4 -> 70.0-70.8 us; 4 / 6 / 7 slots at 32 instances: 31.3 / 29.8 / 29.9 us.
-        const int cap = 4 * 256 / (B * T);
+        const int cap = 4 * bxi::device_cus() / (B * T);
         slots = N > 16 * B || cap >= bxi::kSlots ? bxi::kSlots : (cap < 1 ? 1 : cap);
         if (env_slots > 0) slots = env_slots;
         const size_t lds2 = sizeof(float) * ((size_t)(cin + 1 + 16 + 2) * bxi::kRowPad);

@@ -65,13 +65,11 @@ constexpr int kSpinLimit = BXI_SPIN_LIMIT;             // bounded waits (0.3 - 1
                                                 // not turn an iteration's losses into NaN; running out is loud (NaN losses, status word) and the host
                                                 // side then takes the two-launch form, whose every wait is for an EARLIER workgroup
 // bits of the `flags` argument of bxi_boxinst_eval_f32 (include/boxinst_hip.h: BXI_EVAL_*); per call, no process-wide state
-constexpr unsigned kFlagSingle = 1u, kFlagTwo = 2u, kFlagNoStay = 4u, kFlagRows8 = 8u, kFlagShared = 16u, kFlagPredInPair = 32u, kFlagPredInPrep = 64u,
-                   kFlagTargetsReady = 128u, kFlagGiveUp = 256u, kFlagRows4 = 512u;
+constexpr unsigned kFlagSingle = BXI_EVAL_SINGLE_LAUNCH, kFlagTwo = BXI_EVAL_TWO_LAUNCHES, kFlagRows8 = BXI_EVAL_TILE_ROWS_8, kFlagRows4 = BXI_EVAL_TILE_ROWS_4,
+                   kFlagShared = BXI_EVAL_SHARED_DEVICE, kFlagTargetsReady = BXI_EVAL_TARGETS_READY, kFlagGiveUp = BXI_EVAL_WAITS_GIVE_UP;
 constexpr int kBoxCap = 1024;                   // GT boxes per batch bxi_boxinst_targets_f32 keeps pair counts for
 constexpr int kBoxSplit = 8;                    // count words per box (each in its own 128 bytes): arrivals on one word are performed one after the other
 constexpr int kLongFrom = 96;                   // single launch, long form (8-row tiles) from this many instances on
-constexpr int kFoldFrom = 1 << 30;                   // two launches: from this many instances on the image-only chain (predicates, counts, sum W) runs at the
-                                                // tail of the FIRST launch, under its logit stream (fewer: in the second, as in round 4)
 constexpr unsigned int kMaxTag = 0x0fffffffu;   // tags are 28 bits (a predicate word is tag << 4 | bits)
 constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
 constexpr int kAcc1Words = 64;                  // count-wave arrivals + sum W: 64 words, each in its own 128 bytes
@@ -374,11 +372,17 @@ __device__ __forceinline__ void table_wave(const InstArgs& a, const ImageMeta& m
     publish_gathered_sumw(a, ws, ready - 1, key);
 }
 
-// sum W = sum over the instances of their GT box's pair count (bxi_boxinst_targets_f32 left the counts): one wave
+// sum W = sum over the instances of their GT box's pair count (bxi_boxinst_targets_f32 left the counts): one wave.
+// The targets must be THIS call's: the digest `key` covers the geometry and the box COUNTS (host data); the box COORDINATES are device data, so
+// every instance's box is mapped to its cells again here -- from the evaluation's own boxes -- and compared with the rectangle the targets call
+// recorded for that box (the counts were taken inside it).  A mismatch is a fault: NaN losses and a status word, never the old boxes' normaliser
+// under the new boxes' rectangles.  (The IMAGE's pixels are not compared -- the evaluation does not read them with the targets ready: that the
+// targets were made from this batch's images is the caller's side of the contract, include/boxinst_hip.h.)
 __device__ __forceinline__ void publish_gathered_sumw(const InstArgs& a, const Ws& ws, int G, unsigned int key) {
     const int lane = threadIdx.x & 63;
     const unsigned int have = __hip_atomic_load(ws.tkey(), BXI_RLX, BXI_AGENT);
     double tot = 0.0;
+    bool other_boxes = false;
     for (int m0 = 0; m0 < a.N; m0 += 64) {
         const int mm = m0 + lane;
         const int64_t g = mm < a.N ? a.gt_inds[mm] : -1;
@@ -386,13 +390,22 @@ __device__ __forceinline__ void publish_gathered_sumw(const InstArgs& a, const W
             unsigned long long c[kBoxSplit];
 #pragma unroll
             for (int j = 0; j < kBoxSplit; ++j) c[j] = __hip_atomic_load(ws.boxcnt() + ((size_t)g * kBoxSplit + j) * kAcc2Stride, BXI_RLX, BXI_AGENT);
+            const int4 rec = ws.boxtab()[g];                        // (img << 24, r0 | r1 << 16, c0 | c1 << 16, 0): written by an earlier launch
+            const float* bp = nullptr;
+            int img = 0;
+            for (int b = 0; b < a.gt.B; ++b)                         // uniform loop: the by-value kernel arguments are never indexed per lane
+                if (g >= a.gt.first[b] && g < a.gt.first[b + 1]) { bp = a.gt.boxes[b] + 4 * (g - a.gt.first[b]); img = b; }
+            Rect rc = {0, 0, 0, 0};
+            if (bp) rc = box_rect(bp, a.Hc, a.Wc, a.stride, a.stride / 2, a.h, a.w);
+            other_boxes |= !bp || rec.x != (img << 24) || rec.y != (rc.r0 | (rc.r1 << 16)) || rec.z != (rc.c0 | (rc.c1 << 16));
 #pragma unroll
             for (int j = 0; j < kBoxSplit; ++j) tot += (double)c[j];
         }
     }
     tot = wave_total_f64(tot);                                             // exact: integers far below 2^53
+    const bool bad = __any(other_boxes) || have != key || key == 0u;
     if (lane == 0)
-        __hip_atomic_store(ws.sumw, (1ull << 63) | (have != key || key == 0u ? kSumwFault : 0ull) | (unsigned long long)tot, BXI_RLX, BXI_AGENT);
+        __hip_atomic_store(ws.sumw, (1ull << 63) | (bad ? kSumwFault : 0ull) | (unsigned long long)tot, BXI_RLX, BXI_AGENT);
 }
 
 // This lane's table entry m (m <= N; `want` false: nothing).  Two-launch form: a plain load behind the kernel boundary.  Single-launch
@@ -1591,6 +1604,9 @@ __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& v
     float scale = 0.f;
     bool have_scale = false, bad = false;
     long long fx_sum = 0;
+    // (tiles are dealt wave by wave: the first workgroups' four waves each take one, the last quarter of the workgroups at 128 instances none.
+    // Dealt workgroup by workgroup -- three per workgroup, nine per CU instead of twelve or eight -- the launch is SLOWER: 38.4 vs 37.2 us at 128
+    // instances, 32.1 vs 31.1 at 96, targets ready 30.3 vs 28.7: the early workgroups' waves start their chains first.  profiles/NOTES.md R6-5)
     for (int ti = wid; ti < total && !bad; ti += nwaves) {
         Tile t;
         if (!locate_tile<D, R, ONE>(ws, vc, N, e0, ti, a.h, a.w, spin_limit, t)) { bad = true; break; }
@@ -1602,20 +1618,17 @@ __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& v
 }
 
 // ---- launch 1 of the two-launch form ------------------------------------------------------------------------------------------
-// what the first launch needs beyond its streams (by value: 1 KB of valid-cell limits is only read by the predicate waves of the folded form)
+// what the first launch needs beyond its streams
 struct PrepTail {
-    int n_pb;                // > 0: the FOLDED form -- predicate workgroups + the reducer at the tail of this launch (they wait, bounded, for pool
-                             // workgroups earlier in the grid; everything the second launch needs of the image side is then in memory at the kernel
-                             // boundary, and its tile waves wait for nobody)
     int ready;               // BXI_EVAL_TARGETS_READY (the number of GT boxes + 1): no pool workgroups; the first table wave gathers sum W from the boxes' pair counts
     unsigned int key;        // ... and checks that the targets in the workspace are the ones this call means
-    float n2max;
-    int spin_limit;
 };
 
-// grid: [table blocks][pool blocks][stream blocks] (pool_first) or [table][stream][pool], then (folded form) [predicate blocks][reducer]
+// grid: [table blocks][pool blocks][stream blocks] (pool_first) or [table][stream][pool].  Nobody in this launch waits for anybody.
+// (Round 5 also built a FOLDED form -- predicate workgroups and the reducer at this launch's tail, under its logit stream -- and measured it
+// slower at every instance count, 37.9 vs 36.5 us at 128: profiles/NOTES.md R5-1.  Gone with ABI 7.)
 __global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, int n_items, InstArgs a, int dil, int R, Ws ws_in, LossState st,
-                                                       float* __restrict__ g_logits, int vec, int pool_first, PrepTail tl, ValidCells vc) {
+                                                       float* __restrict__ g_logits, int vec, int pool_first, PrepTail tl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ws ws = ws_in;                                        // the tag is read where a role needs it (with_tag), behind its loads
     const int n_tab = ((a.N + 64) / 64 + kWaves - 1) / kWaves;
@@ -1625,14 +1638,13 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, i
     const int tix = blk * kWaves + (int)(threadIdx.x >> 6);
     (void)tix;
     BXI_TW(0, tix, 0);
-    int role = 0, idx = blk;                              // 0 table, 1 pool, 2 stream, 3 predicate, 4 reducer
+    int role = 0, idx = blk;                              // 0 table, 1 pool, 2 stream
     if (blk >= n_tab) {
         idx = blk - n_tab;
         const int n_a = pool_first ? n_pool : n_stream, n_b = pool_first ? n_stream : n_pool;
+        (void)n_b;
         if (idx < n_a) role = pool_first ? 1 : 2;
-        else if ((idx -= n_a) < n_b) role = pool_first ? 2 : 1;
-        else if ((idx -= n_b) < tl.n_pb) role = 3;
-        else role = 4;
+        else { idx -= n_a; role = pool_first ? 2 : 1; }
     }
     if (role == 0) {
         const int k = blk * kWaves + (int)(threadIdx.x >> 6);
@@ -1640,17 +1652,11 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, i
     } else if (role == 2) {
         const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
         stream_block<false>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);     // (no tagged record in this form)
-    } else if (role == 1) {
+    } else {
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
         int* part = reinterpret_cast<int*>(fch + 3 * 64);
         pool_block(pa, ws, idx, n_pool, n_items, lut, part, fch, tix, [&](Ws& w_) { w_ = with_tag(w_); });
-    } else if (role == 3) {
-        // the Lab records of THIS launch's pool workgroups (tagged, written through; they precede this workgroup in the grid and wait for
-        // nobody) and the table: the single-launch form's protocol
-        pred_role<true>(a, vc, ws, dil, tl.n2max, idx, tl.n_pb, n_items, tl.spin_limit);
-    } else {
-        reducer_role<true>(with_tag(ws), 0, n_items, tl.spin_limit);
     }
     BXI_TW(0, tix, 7);
 }
@@ -1909,20 +1915,6 @@ __global__ __launch_bounds__(256) void rescale_kernel(InstArgs a, int dil, LossS
 __global__ void zero_losses2_kernel(float* losses, float* iter) { losses[0] = 0.f; losses[1] = 0.f; if (iter) atomicAdd(iter, 1.0f); }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-// compute units of the current device (256 on an MI355X in SPX mode, 32 per partition in CPX): the grids are sized so that a
-// launch is resident in one round.  Cached per device ordinal; a wrong value costs time, never correctness.
-static int device_cus() {
-    static std::atomic<int> cached[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    int v = cached[dev].load(std::memory_order_relaxed);
-    if (v == 0) {
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        cached[dev].store(v, std::memory_order_relaxed);
-    }
-    return v;
-}
-
 // Developer knobs (tools/ A/B scripts): read from the environment ONLY in a -DBXI_DEV build.  The shipped library reads nothing from the
 // process environment: what varies is an argument (`flags`), as include/boxinst_hip.h promises.
 #ifdef BXI_DEV
@@ -2200,9 +2192,11 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     // 15.1 / 19.9).
     // (Measured and dropped: a second launch that reads its predicate words by plain loads ahead of the logits and has sum W up front --
     // 14.85 vs 14.65 at 32 instances, 31.9 vs 31.0 at 128: the tile role is bound by its arithmetic and memory pipeline, not by that hop.)
-    const bool long_form = R == 8 && dil <= 2 && ((flags & kFlagSingle) || (ready && a.N >= BXI_KNOB("BXI_LONG_FROM", kLongFrom) && whole_device && !(flags & kFlagShared)));
+    // (the long form exists with the targets ready only: with the image side in the launch it measured 36.9 vs 37.1 us for two launches at 128 instances,
+    // 32.3 vs 31.6 at 96 -- no gain -- and left the library with ABI 7: BXI_EVAL_SINGLE_LAUNCH | BXI_EVAL_TILE_ROWS_8 without targets runs two launches)
+    const bool long_form = R == 8 && dil <= 2 && ready && ((flags & kFlagSingle) || (a.N >= BXI_KNOB("BXI_LONG_FROM", kLongFrom) && whole_device && !(flags & kFlagShared)));
     const bool short_ok = one_fits && !(ready && BXI_KNOB("BXI_READY_TWO", 0));
-    if (env_one && !(flags & (kFlagTwo | kFlagPredInPair | kFlagPredInPrep)) && (short_ok || env_one == 2 || (flags & kFlagSingle) || long_form) && !head && pooled_in_launch &&
+    if (env_one && !(flags & kFlagTwo) && (short_ok || env_one == 2 || (flags & kFlagSingle) || long_form) && !head && pooled_in_launch &&
         (R == 4 || long_form) && dil <= 2 && !pr.zero_bit) {
         const int env_one_pool = BXI_KNOB("BXI_ONE_POOL_WGS", 0);
         const int Sn = (a.h + kSBlk - 1) / kSBlk;
@@ -2230,10 +2224,10 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         // ... unless evaluations run on SEVERAL streams at once: each would hold its stream workgroups' slots while waiting, and three
         // or four of them leave no room for anybody's pool workgroups (measured: 2.4 ms per evaluation with four streams in flight,
         // against 10 us without the staying-on).  The library cannot see what else runs on the device and does not guess: the CALLER
-        // says so (BXI_EVAL_SHARED_DEVICE / BXI_EVAL_NO_STAY_ON; boxinstseg_amd/functional.py sets it once a second stream has been
+        // says so (BXI_EVAL_SHARED_DEVICE; boxinstseg_amd/functional.py sets it once a second stream has been
         // seen on the device).  A launch that is being captured into a graph may be replayed next to anything: no staying-on either.
         const int env_merge = BXI_KNOB("BXI_ONE_MERGE", 1);
-        const int merge = env_merge && !long_form && one_fits && !(flags & (kFlagNoStay | kFlagShared)) && !stream_is_capturing(s) ? 1 : 0;
+        const int merge = env_merge && !long_form && one_fits && !(flags & kFlagShared) && !stream_is_capturing(s) ? 1 : 0;
         if (merge) n_tb = n_tb > n_stream ? n_tb - n_stream : 0;
         size_t lds = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
         if (lds < 8 * (size_t)kWaves * a.w) lds = 8 * (size_t)kWaves * a.w;
@@ -2244,11 +2238,8 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
             const unsigned grid = (unsigned)(n_tabw + n_stream + n_pool + n_pb + 1 + a.N + (int)n_tb + 1);
 #define BXI_ONE_CASE(DD)                                                                                                                    \
             case DD:                                                                                                                        \
-                if (long_form && ready)                                                                                                     \
+                if (long_form)                                                                                                              \
                     BXI_LAUNCH("eval1_ready", s, (eval1_kernel<DD, 8, true>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, \
-                               up_prj, up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge, ready, key, n_tabw);                  \
-                else if (long_form)                                                                                                         \
-                    BXI_LAUNCH("eval1", s, (eval1_kernel<DD, 8, false>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, \
                                up_prj, up_pw, warmup, pr.n2max, spin_limit, losses, g_logits, vec, merge, ready, key, n_tabw);                  \
                 else if (ready)                                                                                                             \
                     BXI_LAUNCH("eval1_ready", s, (eval1_kernel<DD, 4, true>), dim3(grid), dim3(256), lds, s, pa, n_pool, n_items, n_pb, (int)n_tb, a, ws, st, vc, \
@@ -2279,20 +2270,9 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     int per = env_prep_items > 0 ? env_prep_items : (room > 0 ? (n_items + room - 1) / room : 8);
     if (env_prep_items <= 0 && per > 2) per = 2;
     const int n_pool = pooled_in_launch && !ready ? (n_items + (per < 1 ? 1 : per) - 1) / (per < 1 ? 1 : per) : 0;
-    // The FOLDED form: the image-only chain -- predicate words, their counts, sum W -- at the tail of THIS launch: the predicate workgroups
-    // wait (bounded) for pool workgroups earlier in the grid, the reducer for them; at the kernel boundary everything the second launch
-    // needs of the image side is in memory and its tile waves wait for nobody.  With many instances the first launch is a long logit
-    // stream (52 MB at 128) that the image side (20 MB, pool workgroups first) hides under.  From kFoldFrom instances on, or as asked.
-    const bool can_fold = !ready && !head && pooled_in_launch && !pr.zero_bit;
-    const bool fold = can_fold && ((flags & kFlagPredInPrep) || (!(flags & kFlagPredInPair) && a.N >= BXI_KNOB("BXI_FOLD_FROM", kFoldFrom)));
     PrepTail tl = {};
-    tl.ready = ready; tl.key = key; tl.n2max = pr.n2max; tl.spin_limit = spin_limit;
-    if (fold) {
-        tl.n_pb = (n_items + kWaves - 1) / kWaves;
-        const int cap = env_pool_wgs * device_cus() / 2;
-        if (tl.n_pb > cap) tl.n_pb = cap;
-    }
-    const int pool_first = env_pool_first || fold || (!head && n_tab + n_stream + n_pool > env_pool_wgs * device_cus()) ? 1 : 0;
+    tl.ready = ready; tl.key = key;
+    const int pool_first = env_pool_first || (!head && n_tab + n_stream + n_pool > env_pool_wgs * device_cus()) ? 1 : 0;
     size_t lds1 = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
     // every refusal comes BEFORE the first launch: a refused call has enqueued nothing (callers fall back to other entry points)
     size_t lds2 = sizeof(float) * (size_t)kWaves * (R + 1) * 64;
@@ -2324,8 +2304,8 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     } else {
         if (lds1 < 8 * (size_t)kWaves * a.w) lds1 = 8 * (size_t)kWaves * a.w;
         if (lds1 > 64 * 1024) return BXI_ERR_UNSUPPORTED;
-        BXI_LAUNCH(fold ? "prep_fold" : (ready ? "prep_ready" : "prep"), s, prep_kernel, dim3((unsigned)(n_tab + n_stream + n_pool + (fold ? tl.n_pb + 1 : 0))), dim3(256), lds1, s, pa, n_pool, n_items, a, dil,
-                   R, ws, st, g_logits, vec, pool_first, tl, vc);
+        BXI_LAUNCH(ready ? "prep_ready" : "prep", s, prep_kernel, dim3((unsigned)(n_tab + n_stream + n_pool)), dim3(256), lds1, s, pa, n_pool, n_items, a, dil,
+                   R, ws, st, g_logits, vec, pool_first, tl);
     }
     rc = check_launch();
     if (rc != BXI_OK) return rc;
@@ -2354,7 +2334,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     // predicate workgroup for the whole image side: 4.4 ms per evaluation)
     const int cus2 = stream_cus(s, device_cus());                      // a CU-masked stream has fewer
     const int slots = occ * cus2 > 64 ? occ * cus2 : 64;
-    int n_pb = (fold || ready) ? 0 : (n_items + kWaves - 1) / kWaves;  // (folded / targets ready: the image side is in memory at this kernel's start)
+    int n_pb = ready ? 0 : (n_items + kWaves - 1) / kWaves;  // (targets ready: the image side is in memory at this kernel's start)
     if (n_pb > slots / 2) n_pb = slots / 2;
     // (the predicate workgroups are short-lived: the tile workgroups behind them in the grid take their slots as they leave, so the
     // tile workgroups are sized for the slots, not for what the predicate workgroups leave over -- BXI_PAIR_TB_FULL=0: the round-3 sizing)

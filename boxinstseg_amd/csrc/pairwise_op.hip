@@ -162,17 +162,6 @@ template <typename T> struct ProbPair { T s, m; };      // sigmoid(x), sigmoid(-
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // 1 ulp
 __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
 // exp(-a), a >= 0: v_exp_f32 (2^x, ~1 ulp) on a * log2(e) -- the staged probabilities need 1e-6, not the last bit
-static int pw_device_cus() {              // compute units of the current device (cached per ordinal; a wrong value costs time, never correctness)
-    static std::atomic<int> cached[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    int v = cached[dev].load(std::memory_order_relaxed);
-    if (v == 0) {
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        cached[dev].store(v, std::memory_order_relaxed);
-    }
-    return v;
-}
 __device__ __forceinline__ float fast_exp_neg(float a) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * a); }
 __device__ __forceinline__ double fast_exp_neg(double a) { return exp(-a); }
 
@@ -1043,7 +1032,7 @@ static int launch_bwd(const T* logits, const T* g_pair, int N, int H, int W, int
                     constexpr int kTR = 16, kTC = 64, kXR = 256 / kTC;
                     const int64_t cols_b = (W + kTC - 1) / kTC;
                     const int64_t t16 = (int64_t)N * ((H + kTR - 1) / kTR) * cols_b, t20 = (int64_t)N * ((H + kTR + kXR - 1) / (kTR + kXR)) * cols_b;
-                    const int64_t slots_b = (int64_t)BXI_PWP_OCC * pw_device_cus();
+                    const int64_t slots_b = (int64_t)BXI_PWP_OCC * device_cus();
                     const int64_t c16 = ((t16 + slots_b - 1) / slots_b) * kTR, c20 = ((t20 + slots_b - 1) / slots_b) * (kTR + kXR);
                     const int64_t p16 = (int64_t)((H + kTR - 1) / kTR) * kTR, p20 = (int64_t)((H + kTR + kXR - 1) / (kTR + kXR)) * (kTR + kXR);
                     const bool tall = c20 < c16 || (t16 <= slots_b && t20 <= slots_b && p20 < p16);

@@ -306,6 +306,7 @@ def _targets_match_key(imgs, gt_bboxes, cfg) -> tuple:
 
 _PREPARED_SLOTS = 2              # targets of iteration i + 1 may be prepared while the loss of iteration i is still queued
 _PREPARED_N_CAP = 256            # instances a prepared workspace is sized for (topk_per_img = 64 x samples_per_gpu <= 4)
+_PREPARED_CANVASES = 8           # canvases with prepared workspaces kept per thread (2 x ~50 MB each at 2 x 800 x 1024)
 
 
 def prepare_targets(imgs: torch.Tensor, img_metas: Sequence[dict], gt_bboxes: Sequence[torch.Tensor], *, out_stride: int = 4,
@@ -334,7 +335,7 @@ def prepare_targets(imgs: torch.Tensor, img_metas: Sequence[dict], gt_bboxes: Se
     slots = _TLS.prepared.get(key)
     lib = _lib.load()
     if slots is None:
-        if len(_TLS.prepared) >= 16:
+        if len(_TLS.prepared) >= _PREPARED_CANVASES:     # (multi-scale training: the oldest canvas goes; its blocks return to the allocator stream-safely)
             _TLS.prepared.pop(next(iter(_TLS.prepared)))
         need = max(lib.bxi_boxinst_eval_workspace_bytes(*canvas, _PREPARED_N_CAP), 256)
         slots = _TLS.prepared[key] = [dict(ws=torch.zeros(need, dtype=torch.uint8, device=dev), free=None, gen=0) for _ in range(_PREPARED_SLOTS)]
@@ -364,6 +365,9 @@ def prepare_targets(imgs: torch.Tensor, img_metas: Sequence[dict], gt_bboxes: Se
         for b in boxes:
             if b.numel():
                 b.record_stream(st)
+        # ... nor the workspace itself, should its slot be dropped (canvas cap, reset_eval_state, a fault) while targets nobody consumed are
+        # still being written on the side stream
+        slot['ws'].record_stream(st)
     t = PreparedTargets()
     slot['gen'] += 1
     t.ws, t.n_cap, t.event, t.slot, t.gen = slot['ws'], _PREPARED_N_CAP, ev, slot, slot['gen']
@@ -544,8 +548,7 @@ class BoxInstMaskLoss(torch.autograd.Function):
         # only if they were computed from this very batch (else the evaluation computes its own, as without them)
         flags = eval_launch_flags()
         tg = cfg.get('targets') if ctx.calls == 0 else None
-        if tg is not None and not _TLS.wait_free and plan.inst.N <= tg.n_cap and tg.ws.device == dev and tg.matches(imgs, boxes, cfg) and \
-                not (flags & (_lib.EVAL_PRED_IN_PAIR | _lib.EVAL_PRED_IN_PREP)):
+        if tg is not None and not _TLS.wait_free and plan.inst.N <= tg.n_cap and tg.ws.device == dev and tg.matches(imgs, boxes, cfg):
             torch.cuda.current_stream(dev).wait_event(tg.event)
             plan.ws = tg.ws
             plan.ws_ptr, plan.ws_bytes = tg.ws.data_ptr(), tg.ws.numel()

@@ -168,7 +168,9 @@ class CondInstMaskHead(nn.Module):
         factor = self.in_stride // self.out_stride
         # (after a fault in the two-launch form this thread takes the path without any in-kernel wait -- functional.note_fault -- which the
         # head-fused launch is not: the two calls then)
-        fused = (fuse_head and not F_hip._TLS.wait_free and self.boxinst_enabled and feat.is_cuda and params.size(0) > 0 and factor == 2 and self.dynamic_convs == 3 and
+        # (targets prepared for this batch -- prepare_targets -- are consumed by loss(): the head-fused launch computes the image side itself,
+        # so with targets waiting the two calls are the cheaper path and the prepared ones do not stay alive unused)
+        fused = (fuse_head and getattr(self, '_prepared', None) is None and not F_hip._TLS.wait_free and self.boxinst_enabled and feat.is_cuda and params.size(0) > 0 and factor == 2 and self.dynamic_convs == 3 and
                  self.dynamic_channels == 8 and feat.size(1) in (8, 16) and feat.size(3) % 2 == 0 and
                  F_hip.fused_supported(self.pairwise_size, self.pairwise_dilation) and self.out_stride == 4 and
                  imgs.size(2) % 4 == 0 and imgs.size(3) % 4 == 0 and

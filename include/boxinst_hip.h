@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define BXI_ABI_VERSION 6
+#define BXI_ABI_VERSION 7
 #define BXI_MAX_IMAGES 64   /* images per call (per-image metadata travels in kernel arguments) */
 
 typedef enum bxi_status {
@@ -243,37 +243,41 @@ int bxi_boxinst_eval_workspace_init(void* workspace, size_t workspace_bytes, voi
  * in between): makes progress next to anything.  Then bxi_boxinst_eval_f32(..., flags | BXI_EVAL_TARGETS_READY, ...) on the SAME
  * workspace, stream-ordered behind this call (same stream, or an event), with the same batch geometry / boxes / stride / window /
  * threshold: it launches only the logit stream, the leaders, the tiles and the finisher, reads no image (batch_host->imgs may be NULL)
- * and waits for nothing on the image side.  A digest of (canvas, stride, window, threshold, per image: shape, rows removed, box count) is
- * kept with the targets and compared ON THE DEVICE by the evaluation: a mismatch, or targets overwritten by an evaluation without the flag
- * (which computes its own), gives NaN losses and a non-zero status -- never a plausible wrong number.  Several evaluations may use one
+ * and waits for nothing on the image side.  A digest of (canvas, stride, window, threshold, per image: shape, rows removed, box count) and
+ * the cell rectangle of every GT box are kept with the targets and compared ON THE DEVICE by the evaluation (which maps its own boxes to
+ * cells again): a mismatch, or targets overwritten by an evaluation without the flag (which computes its own), gives NaN losses and a
+ * non-zero status -- never a plausible wrong number.  What the device cannot check is the IMAGE: the evaluation does not read it with the
+ * targets ready, so that the targets were made from this batch's pixels is the caller's side of the contract.  Several evaluations may use one
  * set of targets (a re-entrant backward).  At most 1024 GT boxes per batch and color_thresh > 0, else BXI_ERR_UNSUPPORTED (call the
  * evaluation without the flag).  Results are bit-equal to the evaluation without the flag. */
 int bxi_boxinst_targets_f32(const bxi_image_batch* batch_host, const float* const* boxes_per_img_host, const int* gt_count_host,
                             int stride, int size, int dilation, float color_thresh, void* workspace, size_t workspace_bytes, void* stream);
 
-/* `flags` of the two evaluation entry points.  The forms give the same bits (tests run them against each other). */
-#define BXI_EVAL_SINGLE_LAUNCH   1u   /* the single-launch form wherever it is built (stride-4 aligned canvases, dilation <= 2, threshold
-                                         > 0), also where the library would not choose it (its stream workgroups, instances x ceil(h / 32),
-                                         fill more than half the GPU)                                                                    */
-#define BXI_EVAL_TWO_LAUNCHES    2u   /* always the two-launch form: every in-kernel wait is for a workgroup EARLIER in its grid, so it
-                                         makes progress whatever else occupies the device; the host side switches to it after an
-                                         evaluation that reported a non-zero status                                                      */
-#define BXI_EVAL_NO_STAY_ON      4u   /* single launch without the stream workgroups staying on as tile workgroups                      */
-#define BXI_EVAL_TILE_ROWS_8     8u   /* 8-row tiles (two launches).  Default: 4-row tiles up to 95 instances, 8-row tiles from 96 on
-                                         (dilation <= 2)                                                                                */
+/* `flags` of the two evaluation entry points.  The forms give the same bits (tests run them against each other).
+ * What the library runs by itself (flags == 0), at dilation <= 2 on a stride-4 aligned canvas:
+ *   - ONE launch (4-row tiles, four workgroups per CU) while its stream workgroups -- instances x ceil(h / 32) -- fill at most half the GPU
+ *     (up to 73 instances of 200 x 256 maps);
+ *   - beyond that TWO launches (table + logit stream + image pooling | predicates + leaders + tiles + finisher): 4-row tiles up to 95
+ *     instances, 8-row tiles from 96 on.  Every in-kernel wait of this form is for a workgroup EARLIER in its grid;
+ *   - with BXI_EVAL_TARGETS_READY the same two shapes without the image side, and from 96 instances on ONE launch with 8-row tiles
+ *     (three workgroups per CU, nobody waits for a later workgroup).
+ * Other dilations / canvases: two launches (+ the generic pooling launches).  ABI 7 removed the forms that lost their measurements
+ * (BXI_EVAL_PRED_IN_PREP, the 8-row single launch with the image side in it) and folded BXI_EVAL_NO_STAY_ON into BXI_EVAL_SHARED_DEVICE. */
+#define BXI_EVAL_SINGLE_LAUNCH   1u   /* the single-launch form wherever it is built, also where the library would not choose it (its stream
+                                         workgroups fill more than half the GPU).  Not built -- two launches then, silently --: dilation > 2,
+                                         threshold <= 0, generic pooling, and 8-row tiles without BXI_EVAL_TARGETS_READY                  */
+#define BXI_EVAL_TWO_LAUNCHES    2u   /* always the two-launch form: it makes progress whatever else occupies the device; the host side
+                                         switches to it after an evaluation that reported a non-zero status                              */
+#define BXI_EVAL_TILE_ROWS_8     4u   /* 8-row tiles whatever the instance count                                                         */
+#define BXI_EVAL_TILE_ROWS_4     8u   /* 4-row tiles whatever the instance count                                                         */
 #define BXI_EVAL_SHARED_DEVICE  16u   /* other work (evaluations on other streams, collectives, other processes) may run on the device
                                          at the same time: nothing in the launch may hold execution slots while it waits for workgroups
-                                         that come later in the grid (implies NO_STAY_ON).  The library does not guess this              */
-#define BXI_EVAL_PRED_IN_PAIR   32u   /* two launches, the colour predicates / pair counts / sum W in the SECOND one (the form of up to 95
-                                         instances)                                                                                      */
-#define BXI_EVAL_PRED_IN_PREP   64u   /* two launches, the image-only chain at the tail of the FIRST one, under its logit stream: the
-                                         second launch's tile waves wait for nobody (the form from 96 instances on).  In both two-launch
-                                         forms every in-kernel wait is for a workgroup EARLIER in its grid                               */
-#define BXI_EVAL_TARGETS_READY 128u   /* the image side is in the workspace already: bxi_boxinst_targets_f32 above                       */
-#define BXI_EVAL_TILE_ROWS_4   512u   /* 4-row tiles whatever the instance count                                                         */
-#define BXI_EVAL_WAITS_GIVE_UP 256u   /* TEST ONLY: every bounded in-kernel wait gives up at once, which makes the failure path
+                                         that come later in the grid (the single launch's stream workgroups do not stay on as tile
+                                         workgroups; no 8-row single launch by default).  The library does not guess this               */
+#define BXI_EVAL_TARGETS_READY  32u   /* the image side is in the workspace already: bxi_boxinst_targets_f32 above                       */
+#define BXI_EVAL_WAITS_GIVE_UP  64u   /* TEST ONLY: every bounded in-kernel wait gives up at once, which makes the failure path
                                          observable (NaN losses, status word, poisoned gradient); zero the workspace afterwards          */
-#define BXI_EVAL_ALL_FLAGS (1u | 2u | 4u | 8u | 16u | 32u | 64u | 128u | 256u | 512u)
+#define BXI_EVAL_ALL_FLAGS (1u | 2u | 4u | 8u | 16u | 32u | 64u)
 int bxi_boxinst_eval_f32(const bxi_image_batch* batch_host, const bxi_instances* inst_host,
                          int size, int dilation, float color_thresh, float warmup,
                          const float* up_prj, const float* up_pw,

@@ -364,19 +364,18 @@ def test_single_launch_and_two_launch_forms_agree_bit_for_bit(dev):
              synthetic.make_batch(B=1, H=1056, W=96, boxes_per_img=2, seed=6, min_box=16, max_box=90),          # tall: many bands
              synthetic.make_batch(B=2, H=128, W=1088, boxes_per_img=2, seed=7, min_box=16, max_box=300),        # wide: several chunks
              synthetic.make_batch(B=2, H=256, W=256, boxes_per_img=40, seed=8, min_box=8, max_box=60)]          # 80 instances
+    from boxinstseg_amd import _lib
     for d in cases:
         for dil in (1, 2, 3):
             res = []
-            # the single launch wherever it is built (with / without the staying-on) / two launches with the predicates in the second /
-            # two launches with the image-only chain folded into the first
-            for form in (1, 1 | 4, 2 | 32, 2 | 64):
-                with Fh.eval_flags(form):
+            # the single launch wherever it is built, with / without the stream workgroups staying on (BXI_EVAL_SHARED_DEVICE), and two launches
+            for form in (_lib.EVAL_SINGLE_LAUNCH, _lib.EVAL_SINGLE_LAUNCH | _lib.EVAL_SHARED_DEVICE, _lib.EVAL_TWO_LAUNCHES):
+                with Fh.eval_flags(form):                         # (dilation 3: the single launch is not built -- two launches whatever is asked)
                     res.append(hip_loss(d, dev, pairwise_dilation=dil))
-            a, a2, b, c = res
+            a, a2, b = res
             assert a[0] == a2[0] and a[1] == a2[1] and np.array_equal(a[2], a2[2]), dil
             assert a[0] == b[0] and a[1] == b[1], (dil, a[:2], b[:2])
             assert np.array_equal(a[2], b[2]), dil
-            assert a[0] == c[0] and a[1] == c[1] and np.array_equal(a[2], c[2]), (dil, a[:2], c[:2])
 
 
 def test_stream_with_a_cu_mask_takes_the_two_launch_form(dev):
@@ -511,9 +510,9 @@ def test_loss_cfg2_four_per_box(dev):
     """The shape real training runs: configs/boxinst/boxinst_r50_fpn_1x_coco.py:65 (topk_per_img=64) x :125 (samples_per_gpu=2) -> up to 128
     instances per evaluation (condinst_head.py:1190-1225), at the full 2 x 800 x 1024 canvas.  Default flags: two launches there, the
     first with its pool workgroups ahead of the stream workgroups (the launch exceeds the execution slots), the second with 8-row tiles
-    at three workgroups per CU.  Losses and gradient within 1e-4 of the C oracle, status 0; and the other forms built for this size --
-    the FOLDED two launches (image-only chain at the tail of the first launch, a second launch that waits for nothing on the image
-    side) and the LONG single launch (8-row tiles, pool workgroups first) -- give the same bits."""
+    at three workgroups per CU.  Losses and gradient within 1e-4 of the C oracle, status 0; the other form built for this size -- the targets made
+    ahead and ONE launch with 8-row tiles (the default with targets from 96 instances on) -- gives the same bits; the 8-row single launch with the
+    image side in it left the library with ABI 7: asking for it runs two launches."""
     import ctypes as C
     from boxinstseg_amd import _lib, functional as Fh
     lib = _lib.load()
@@ -531,18 +530,25 @@ def test_loss_cfg2_four_per_box(dev):
     # the forms differ in where work runs, not in what is computed -- except the tile height, which changes the order of the float
     # additions inside a tile (4-row tiles: against the oracle)
     base = hip_loss(d, dev)
-    for form, kernels in ((_lib.EVAL_PRED_IN_PREP, ('prep_fold', 'pair_tiles')), (_lib.EVAL_SINGLE_LAUNCH | _lib.EVAL_TILE_ROWS_8, ('eval1',))):
-        names.clear()
-        lib.bxi_dev_set_launch_hook(C.cast(cb, C.c_void_p), None)
-        try:
-            with Fh.eval_flags(form):
-                other = hip_loss(d, dev)
-        finally:
-            lib.bxi_dev_set_launch_hook(None, None)
-        assert set(kernels) <= set(names), (form, names)
-        assert Fh.last_eval_status() == (0, 8)
-        assert base[0] == other[0] and base[1] == other[1] and np.array_equal(base[2], other[2]), form
-    with Fh.eval_flags(_lib.EVAL_PRED_IN_PREP | _lib.EVAL_TILE_ROWS_4):
+    names.clear()
+    lib.bxi_dev_set_launch_hook(C.cast(cb, C.c_void_p), None)
+    try:
+        other = _loss_with_targets(d, dev)
+    finally:
+        lib.bxi_dev_set_launch_hook(None, None)
+    assert 'eval1_ready' in names and 'pair' not in names, names
+    assert Fh.last_eval_status() == (0, 8)
+    assert base[0] == other[0] and base[1] == other[1] and np.array_equal(base[2], other[2])
+    names.clear()
+    lib.bxi_dev_set_launch_hook(C.cast(cb, C.c_void_p), None)
+    try:
+        with Fh.eval_flags(_lib.EVAL_SINGLE_LAUNCH | _lib.EVAL_TILE_ROWS_8):
+            other = hip_loss(d, dev)
+    finally:
+        lib.bxi_dev_set_launch_hook(None, None)
+    assert 'prep' in names and 'pair' in names and 'eval1' not in names, names       # (not built without targets: two launches)
+    assert base[0] == other[0] and base[1] == other[1] and np.array_equal(base[2], other[2])
+    with Fh.eval_flags(_lib.EVAL_TWO_LAUNCHES | _lib.EVAL_TILE_ROWS_4):
         _check(d, dev)
         assert Fh.last_eval_status() == (0, 4)
 
@@ -677,20 +683,21 @@ def test_loss_many_instances(dev):
     _check_cfg(d, dev)
 
 
-@pytest.mark.parametrize('form', [1, 5, 2 | 32, 10 | 32, 64, 64 | 8, 1 | 8],
-                         ids=['single_launch', 'single_launch_no_stay_on', 'two_launches', 'two_launches_8_row_tiles', 'folded', 'folded_8_row_tiles',
-                              'single_launch_long'])
+@pytest.mark.parametrize('form', ['single_launch', 'single_launch_shared_device', 'two_launches', 'two_launches_8_row_tiles', 'two_launches_4_row_tiles'])
 def test_loss_every_form_against_the_oracle(dev, form):
     """Each form of the evaluation (the BXI_EVAL_* flags of the call) against the C oracle: the single launch also where the library
-    would not choose it (300 instances: the stream workgroups alone exceed the GPU), two launches, and the 8-row tiles no default takes."""
-    from boxinstseg_amd import functional as Fh
-    with Fh.eval_flags(form):
+    would not choose it (300 instances: the stream workgroups alone exceed the GPU), two launches, and the tile heights no default takes."""
+    from boxinstseg_amd import _lib, functional as Fh
+    flags = {'single_launch': _lib.EVAL_SINGLE_LAUNCH, 'single_launch_shared_device': _lib.EVAL_SINGLE_LAUNCH | _lib.EVAL_SHARED_DEVICE,
+             'two_launches': _lib.EVAL_TWO_LAUNCHES, 'two_launches_8_row_tiles': _lib.EVAL_TWO_LAUNCHES | _lib.EVAL_TILE_ROWS_8,
+             'two_launches_4_row_tiles': _lib.EVAL_TWO_LAUNCHES | _lib.EVAL_TILE_ROWS_4}[form]
+    with Fh.eval_flags(flags):
         _check(synthetic.cfg1(4), dev)
         _check_cfg(synthetic.make_batch(B=3, H=64, W=96, boxes_per_img=5, inst_per_box=20, seed=21, min_box=12, max_box=60), dev)
         _check_cfg(synthetic.make_batch(B=2, H=96, W=160, boxes_per_img=3, seed=26, min_box=16, max_box=90), dev, pairwise_dilation=3)
         _check_cfg(synthetic.make_batch(B=1, H=1088, W=1344, boxes_per_img=3, seed=22, min_box=200, max_box=900), dev)
         rows = Fh_status_rows()
-        assert rows == (8 if form & 8 else 4)
+        assert rows == (8 if flags & _lib.EVAL_TILE_ROWS_8 else 4)
 
 
 def test_loss_tall_and_wide_map(dev):
@@ -758,17 +765,16 @@ def _fuzz_case(seed):
 
 @pytest.mark.parametrize('seed', list(range(100, 112)))
 def test_loss_fuzz_forms_and_targets_ahead(dev, seed):
-    """The same seeded shapes as test_loss_fuzz through every OTHER form of the evaluation -- two launches with the predicates in the second /
-    folded into the first, the long single launch, and the targets-ahead split (bxi_boxinst_targets_f32 + BXI_EVAL_TARGETS_READY, also
-    through the generic pooling path of stride 8) --: each must give the default form's bits when its tile height is the default's
-    (the long form's 8-row tiles: within 1e-4 of it), with status 0."""
+    """The same seeded shapes as test_loss_fuzz through every OTHER form of the evaluation -- two launches, two launches with 8-row tiles, and the
+    targets-ahead split (bxi_boxinst_targets_f32 + BXI_EVAL_TARGETS_READY, also through the generic pooling path of stride 8) --: each must give the
+    default form's bits when its tile height is the default's (8-row tiles: within 1e-4 of it), with status 0."""
     from boxinstseg_amd import _lib, functional as Fh
     d, kw, warm, up = _fuzz_case(seed)
     if d['N'] == 0:
         return
     want = hip_loss(d, dev, warmup=warm, up=up, **kw)
     rows = Fh.last_eval_status()[1]
-    for form in (_lib.EVAL_TWO_LAUNCHES | _lib.EVAL_PRED_IN_PAIR, _lib.EVAL_PRED_IN_PREP, _lib.EVAL_SINGLE_LAUNCH | _lib.EVAL_TILE_ROWS_8):
+    for form in (_lib.EVAL_TWO_LAUNCHES, _lib.EVAL_TWO_LAUNCHES | _lib.EVAL_TILE_ROWS_8):
         with Fh.eval_flags(form):
             got = hip_loss(d, dev, warmup=warm, up=up, **kw)
         if Fh.last_eval_status()[1] == rows:
@@ -1015,8 +1021,8 @@ def test_targets_through_the_module_api_and_stale_targets_are_ignored(dev):
 
 def test_targets_that_do_not_belong_to_the_evaluation_are_loud(dev):
     """At the C ABI: BXI_EVAL_TARGETS_READY on a workspace whose targets were computed for another threshold, or were overwritten by an
-    evaluation that computed its own, or were never computed: the digest kept with the targets does not match -> NaN losses, status != 0,
-    never a plausible number.  After bxi_boxinst_targets_f32 with the right arguments: the fused evaluation's bits, twice (targets serve
+    evaluation that computed its own, or were never computed, or were computed for other BOXES of the same counts: the digest kept with the
+    targets (or the box rectangles recorded with them) does not match -> NaN losses, status != 0, never a plausible number.  After bxi_boxinst_targets_f32 with the right arguments: the fused evaluation's bits, twice (targets serve
     several evaluations)."""
     import ctypes as C
     import math
@@ -1055,16 +1061,29 @@ def test_targets_that_do_not_belong_to_the_evaluation_are_loud(dev):
         for _ in range(2):
             got = ev(_lib.EVAL_TARGETS_READY | form)
             assert got[2] == 0 and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        # targets of OTHER BOXES with the same geometry and the same box counts (round-5 advice: the host-side digest cannot see device data):
+        # the evaluation maps its own boxes to cells again and compares them with the rectangles the targets were counted in
+        keep = [bx.clone() for bx in b['t']['gt_bboxes']]
+        for bx in b['t']['gt_bboxes']:
+            bx[0, 0] += 24.0; bx[0, 2] += 24.0                      # one box moved by six cells, in place: same pointers, same counts
+        got = ev(_lib.EVAL_TARGETS_READY | form)
+        assert got[2] != 0 and math.isnan(got[0][0]) and math.isnan(got[0][1]), got
+        for bx, k_ in zip(b['t']['gt_bboxes'], keep):
+            bx.copy_(k_)
+        b['ws'].zero_()
+        targets()
+        got = ev(_lib.EVAL_TARGETS_READY | form)
+        assert got[2] == 0 and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
         ev(form)                                                    # computes its own targets: the prepared ones are gone
         got = ev(_lib.EVAL_TARGETS_READY | form)
         assert got[2] != 0 and math.isnan(got[0][0])
         b['ws'].zero_()
-    # refusals: a threshold <= 0 (every pair weighs 1: nothing of the image is needed ahead), the flag together with a predicate placement
+    # refusals: a threshold <= 0 (every pair weighs 1: nothing of the image is needed ahead), contradicting flags
     assert lib.bxi_boxinst_targets_f32(C.byref(b['batch'].struct), boxes.struct.boxes_per_img_host, boxes.struct.gt_count_host, d['stride'], 3, 2, 0.0,
                                        b['ws'].data_ptr(), b['ws'].numel(), st) == _lib.BXI_ERR_UNSUPPORTED
     assert lib.bxi_boxinst_eval_f32(C.byref(b['batch'].struct), C.byref(b['inst'].struct), 3, 2, 0.3, 1.0, None, None, b['losses'].data_ptr(),
                                     b['grad'].data_ptr(), b['state'].data_ptr(), b['ws'].data_ptr(), b['ws'].numel(),
-                                    _lib.EVAL_TARGETS_READY | _lib.EVAL_PRED_IN_PREP, st) == -3
+                                    _lib.EVAL_SINGLE_LAUNCH | _lib.EVAL_TWO_LAUNCHES, st) == -3
 
 
 def test_tag_counter_wraps_by_zeroing_the_workspace(dev):
@@ -1082,7 +1101,7 @@ def test_tag_counter_wraps_by_zeroing_the_workspace(dev):
     top = (1 << 28) - 1
     ws[:4].view(torch.int32).fill_(top - 3)
     st = torch.cuda.current_stream(dev).cuda_stream
-    forms = [0, _lib.EVAL_TWO_LAUNCHES | _lib.EVAL_PRED_IN_PAIR, 0, _lib.EVAL_PRED_IN_PREP, 0, _lib.EVAL_TWO_LAUNCHES, 0, _lib.EVAL_PRED_IN_PREP]
+    forms = [0, _lib.EVAL_TWO_LAUNCHES, 0, _lib.EVAL_TWO_LAUNCHES | _lib.EVAL_TILE_ROWS_8, 0, _lib.EVAL_TWO_LAUNCHES, 0, _lib.EVAL_SINGLE_LAUNCH]
     expect_epoch = [top - 2, top - 1, 0, 1, 2, 3, 4, 5]
     for k in range(8):
         d, ref = ds[k % 3], refs[k % 3]

@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f'{n} declared in include/boxinst_hip.h but not exported'
         assert n in _lib.SIGNATURES, f'{n} has no ctypes signature'
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.bxi_abi_version() == _lib.BXI_ABI_VERSION == 6
+    assert lib.bxi_abi_version() == _lib.BXI_ABI_VERSION == 7
     for code, name in _lib.STATUS.items():
         assert _lib.status_string(code) and 'unknown' not in _lib.status_string(code)
     assert 'unknown' in _lib.status_string(-99)

@@ -40,13 +40,12 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     st = stream.cuda_stream
     L = _lib
-    forms = {'auto': 0, 'single': L.EVAL_SINGLE_LAUNCH, 'pair': L.EVAL_TWO_LAUNCHES | L.EVAL_PRED_IN_PAIR, 'fold': L.EVAL_PRED_IN_PREP,
-             'fold_r4': L.EVAL_PRED_IN_PREP | L.EVAL_TILE_ROWS_4, 'fold_r8': L.EVAL_PRED_IN_PREP | L.EVAL_TILE_ROWS_8,
-             'pair_r4': L.EVAL_TWO_LAUNCHES | L.EVAL_PRED_IN_PAIR | L.EVAL_TILE_ROWS_4,
+    forms = {'auto': 0, 'single': L.EVAL_SINGLE_LAUNCH, 'pair': L.EVAL_TWO_LAUNCHES,
+             'pair_r4': L.EVAL_TWO_LAUNCHES | L.EVAL_TILE_ROWS_4, 'pair_r8': L.EVAL_TWO_LAUNCHES | L.EVAL_TILE_ROWS_8,
              'ready': L.EVAL_TARGETS_READY, 'ready_two': L.EVAL_TARGETS_READY | L.EVAL_TWO_LAUNCHES,
              'ready_two_r4': L.EVAL_TARGETS_READY | L.EVAL_TWO_LAUNCHES | L.EVAL_TILE_ROWS_4, 'targets_only': -1,
-             'ready_single': L.EVAL_TARGETS_READY | L.EVAL_SINGLE_LAUNCH, 'ready_single_nostay': L.EVAL_TARGETS_READY | L.EVAL_SINGLE_LAUNCH | L.EVAL_NO_STAY_ON,
-             'single_any': L.EVAL_SINGLE_LAUNCH, 'long': L.EVAL_SINGLE_LAUNCH | L.EVAL_TILE_ROWS_8,
+             'ready_single': L.EVAL_TARGETS_READY | L.EVAL_SINGLE_LAUNCH, 'ready_single_nostay': L.EVAL_TARGETS_READY | L.EVAL_SINGLE_LAUNCH | L.EVAL_SHARED_DEVICE,
+             'single_any': L.EVAL_SINGLE_LAUNCH,
              'ready_long': L.EVAL_TARGETS_READY | L.EVAL_SINGLE_LAUNCH | L.EVAL_TILE_ROWS_8}
     if args.forms:
         forms = {k: v for k, v in forms.items() if k in args.forms.split(',')}

@@ -34,7 +34,7 @@ def main():
             big2.copy_(big)
 
     L = _lib
-    forms = {'auto': 0, 'two_launches': L.EVAL_TWO_LAUNCHES | L.EVAL_PRED_IN_PAIR, 'folded': L.EVAL_PRED_IN_PREP, 'no_stay_on': L.EVAL_NO_STAY_ON}
+    forms = {'auto': 0, 'two_launches': L.EVAL_TWO_LAUNCHES, 'no_stay_on': L.EVAL_SHARED_DEVICE}
     out = {}
     for ipb in args.ipb:
         sets = [bench.EvalSet(lib, Fh, synthetic, dev, seed=7000 + i, inst_per_box=ipb, ones=ones, flags=0) for i in range(6)]

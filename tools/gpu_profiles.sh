@@ -12,13 +12,11 @@ prof() {   # prof <dir> <command...>: rocprofv3 kernel stats of one command -> g
   cut -d, -f1-4 $R/gpurun_out/$d/${TAG}_kernel_stats.csv | head -5
 }
 prof prof_eager $CMD
-# the two-launch form of the same evaluation (BXI_EVAL_TWO_LAUNCHES | BXI_EVAL_PRED_IN_PAIR = 34: what larger instance counts, dilation 3 / 4
-# and the head-fused call run); the shape real training runs, 128 instances (default form, folded form 64, long single launch 9);
+# the two-launch form of the same evaluation (BXI_EVAL_TWO_LAUNCHES = 2: what larger instance counts, dilation 3 / 4
+# and the head-fused call run); the shape real training runs, 128 and 64 instances (default form);
 # the targets-ahead pair (bxi_boxinst_targets_f32 + BXI_EVAL_TARGETS_READY) at 32 and 128 instances
-prof prof_two_launch $CMD --flags 34
+prof prof_two_launch $CMD --flags 2
 prof prof_n128 $CMD --inst-per-box 4 --sets 6
-prof prof_n128_fold $CMD --inst-per-box 4 --sets 6 --flags 64
-prof prof_n128_long $CMD --inst-per-box 4 --sets 6 --flags 9
 prof prof_n64 $CMD --inst-per-box 2 --sets 6
 prof prof_targets_n32 python $R/tools/ab_forms.py --ipb 1 --forms ready,targets_only --reps 1 --steps 300 --sets 6
 prof prof_targets_n128 python $R/tools/ab_forms.py --ipb 4 --forms ready,targets_only --reps 1 --steps 300 --sets 6

@@ -24,8 +24,8 @@ def main():
     dev = torch.device('cuda', 0); torch.cuda.set_device(0)
     ones = torch.ones(2, device=dev)
     stream = torch.cuda.Stream(device=dev); st = stream.cuda_stream
-    forms = {'auto': 0, 'ready': L.EVAL_TARGETS_READY, 'two': L.EVAL_TWO_LAUNCHES | L.EVAL_PRED_IN_PAIR, 'fold': L.EVAL_PRED_IN_PREP,
-             'long': L.EVAL_SINGLE_LAUNCH | L.EVAL_TILE_ROWS_8, 'ready_long': L.EVAL_TARGETS_READY | L.EVAL_SINGLE_LAUNCH | L.EVAL_TILE_ROWS_8}
+    forms = {'auto': 0, 'ready': L.EVAL_TARGETS_READY, 'two': L.EVAL_TWO_LAUNCHES,
+             'ready_long': L.EVAL_TARGETS_READY | L.EVAL_SINGLE_LAUNCH | L.EVAL_TILE_ROWS_8}
     out = {}
     for ipb in args.ipb:
         sets = [bench.EvalSet(lib, Fh, synthetic, dev, seed=7000 + i, inst_per_box=ipb, ones=ones, flags=0) for i in range(6)]

@@ -25,7 +25,7 @@ lib = _lib.load(); L = _lib
 dev = torch.device('cuda', 0); torch.cuda.set_device(0)
 ones = torch.ones(2, device=dev)
 stream = torch.cuda.Stream(device=dev); st = stream.cuda_stream
-forms = {'auto': 0, 'ready': L.EVAL_TARGETS_READY, 'two': L.EVAL_TWO_LAUNCHES | L.EVAL_PRED_IN_PAIR,
+forms = {'auto': 0, 'ready': L.EVAL_TARGETS_READY, 'two': L.EVAL_TWO_LAUNCHES,
          'ready_long': L.EVAL_TARGETS_READY | L.EVAL_SINGLE_LAUNCH | L.EVAL_TILE_ROWS_8, 'ready_two': L.EVAL_TARGETS_READY | L.EVAL_TWO_LAUNCHES}
 form = forms[args.form]
 has_log = hasattr(lib, 'bxi_debug_waitlog')

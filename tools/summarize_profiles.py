@@ -68,11 +68,9 @@ print(open(f'{P}/{rnd}_summary.md').read())
 
 # ---- the "next" rows: one table per tracked rocprofv3 kernel-stats file under profiles/ ------------------
 BENCH = 'bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-kernel-timing --no-extras'
-EXTRA = [('two_launch', 'the same evaluation in its two-launch form (`--flags 34` = BXI_EVAL_TWO_LAUNCHES | BXI_EVAL_PRED_IN_PAIR)', BENCH + ' --flags 34'),
+EXTRA = [('two_launch', 'the same evaluation in its two-launch form (`--flags 2` = BXI_EVAL_TWO_LAUNCHES)', BENCH + ' --flags 2'),
          ('n64', '64 instances (2 per box), default form', BENCH + ' --inst-per-box 2 --sets 6'),
          ('n128', '128 instances (4 per box: what configs/boxinst/boxinst_r50_fpn_1x_coco.py:65,125 trains at), default form', BENCH + ' --inst-per-box 4 --sets 6'),
-         ('n128_fold', '128 instances, folded two launches (`--flags 64` = BXI_EVAL_PRED_IN_PREP: image-only chain at the tail of launch 1)', BENCH + ' --inst-per-box 4 --sets 6 --flags 64'),
-         ('n128_long', '128 instances, long single launch (`--flags 9` = BXI_EVAL_SINGLE_LAUNCH | BXI_EVAL_TILE_ROWS_8)', BENCH + ' --inst-per-box 4 --sets 6 --flags 9'),
          ('targets_n32', 'targets ahead at 32 instances: bxi_boxinst_targets_f32 (targets_pool + targets_pred) and the evaluation with BXI_EVAL_TARGETS_READY', 'tools/ab_forms.py --ipb 1 --forms ready,targets_only --reps 1 --steps 300 --sets 6'),
          ('targets_n128', 'targets ahead at 128 instances', 'tools/ab_forms.py --ipb 4 --forms ready,targets_only --reps 1 --steps 300 --sets 6'),
          ('dynamic_head', 'f-2 dynamic mask head', 'tools/bench_dynamic_head.py'),
