@@ -403,10 +403,10 @@ void dyn_bwd_kernel(DynArgs a, const float* __restrict__ params, const float* __
 //   * the taps of dy are separable (three row offsets / weights, three column offsets / weights) and are loaded at the top of an instance,
 //     consumed after the forward pass: nothing of them is live during the contractions.
 // Run-to-run identical like the first form (no atomics; fixed summation order), not bit-identical to it (the order differs).
-#ifndef BXI_DYN_MFMA
-#define BXI_DYN_MFMA 1
-#endif
-typedef float v4f __attribute__((ext_vector_type(4)));
+// (Round 6 put the two contractions on the matrix pipe -- v_mfma_f32_16x16x4_f32, a wave contracting its own 64 pixels from a pixel-major,
+// odd-stride operand layout, no cross-lane reduction left: 102 registers, every test green, and SLOWER: 29.0 vs 28.0 us at 32 instances, 70.8 vs
+// 67.7 at 128.  48 MFMAs per wave and instance at 29 % tile use (M = 8 of 16; N = 9, 16, 3 of 16) occupy the pipe longer than the 120 packed FMAs
+// and their DPP sums occupy the VALU, and workgroups that run in step hide little of it.  Commit 535283b; profiles/NOTES.md R6-6.)
 template <int C, bool REL, int F>
 __global__ __launch_bounds__(256, 4)
 void dyn_bwd2_kernel(DynArgs a, const float* __restrict__ params, const float* __restrict__ params_again,
@@ -418,13 +418,7 @@ void dyn_bwd2_kernel(DynArgs a, const float* __restrict__ params, const float* _
     constexpr int CIN = D::CIN, off = REL ? 2 : 0;
     constexpr int kOnesA = CIN, RX = CIN + 1, kOnesB = RX + 16;   // rows; RX + 17 = pad
     constexpr int kChunkN = 256;
-    float* rows = lds;                                      // [CIN + 1 + 16 + 2][kRowPad]  (matrix-pipe form: [kRowPad pixels][RS operand rows])
-    // operand (row, pixel).  The matrix-pipe contraction reads, per step, sixteen ROWS of four pixels 16 apart: pixel-major with an odd stride
-    // (RS = CIN + 19) puts the sixty-four lanes of such a read -- and of every per-pixel access -- on sixty-four banks; row-major (the stride
-    // 256 of the VALU form, whose float4 reads run along the pixels) would put the sixteen rows on ONE bank.
-    constexpr int RS = CIN + 1 + 16 + 2;
-    static_assert(RS % 2 == 1, "an odd pixel stride: conflict-free");
-    auto RI = [](int row, int pix) { return BXI_DYN_MFMA ? pix * RS + row : row * kRowPad + pix; };
+    float* rows = lds;                                      // [CIN + 1 + 16 + 2][kRowPad]
     __shared__ int mine[kChunkN + 2];
     __shared__ int n_mine;
     __shared__ float red2[16 * 12];                         // dW2 / db2: one partial per DPP row of the workgroup
@@ -442,9 +436,9 @@ void dyn_bwd2_kernel(DynArgs a, const float* __restrict__ params, const float* _
     const int OH = a.H * F, OW = a.W * F;
     constexpr int P = D::P, w1 = D::W1, w2 = D::W2;
     const int64_t HW = (int64_t)a.H * a.W;
-    rows[RI(kOnesA, tid)] = 1.f;
-    rows[RI(kOnesB, tid)] = 1.f;
-    rows[RI(kOnesB + 1, tid)] = 0.f;
+    rows[kOnesA * kRowPad + tid] = 1.f;
+    rows[kOnesB * kRowPad + tid] = 1.f;
+    rows[(kOnesB + 1) * kRowPad + tid] = 0.f;
     {
         const float* fb = a.feat + (int64_t)b * C * HW;
         const unsigned po = (unsigned)(rr * a.W + cc);
@@ -452,7 +446,7 @@ void dyn_bwd2_kernel(DynArgs a, const float* __restrict__ params, const float* _
 #pragma unroll
         for (int k = 0; k < C; ++k) xf[k] = (fb + (int64_t)k * HW)[po];
 #pragma unroll
-        for (int k = 0; k < C; ++k) rows[RI(off + k, tid)] = valid ? xf[k] : 0.f;      // pixels outside the map stage zeros
+        for (int k = 0; k < C; ++k) rows[(off + k) * kRowPad + tid] = valid ? xf[k] : 0.f;      // pixels outside the map stage zeros
     }
     // d y[r][c] = sum_i wy[i] sum_j wx[j] g[Rs + i][Cs + j] (gather_dy's window, separable)
     constexpr int NT = 2 * F - 1;
@@ -538,37 +532,6 @@ void dyn_bwd2_kernel(DynArgs a, const float* __restrict__ params, const float* _
         if (q != kNone) asm volatile("global_store_dword %0, %1, %2" ::"v"(q * 4u), "v"(out), "s"(dst) : "memory");
     };
 
-    // ---- the same contractions on the matrix pipe (BXI_DYN_MFMA): a wave contracts ITS OWN 64 pixels -- the columns its own lanes staged, so no barrier
-    // stands between the staging and the products -- with v_mfma_f32_16x16x4_f32 (exact f32, the vector rate, on a pipe the VALU does not use):
-    //   D[m][n] += sum_k A[m][k] B[k][n],  lane l supplies A[l % 16][l / 16] and B[l / 16][l % 16];  step s takes the pixels 16 (l / 16) + s:
-    //   A = operand row RX + m (dh2 / dh1; rows 8..15 of D are nobody's), B = operand row b_row0 + n (consecutive rows: inputs | ones, h1 | ones).
-    // Sixteen steps x (1 + ceil((CIN + 1) / 16)) blocks per wave and instance; the wave's partial sums go to its own columns of the h1 rows, the
-    // four waves' partials are summed in wave order by one thread per output.  No cross-lane reduction anywhere.
-    constexpr int NBLK_A = (CIN + 1 + 15) / 16;
-    const int wv = tid >> 6, ln = tid & 63, r16 = ln & 15, kq = ln >> 4;
-    // the products of one pass: A = operand rows RX + r16 (dh2 or dh1), B_j = operand rows b_row[j]; one A and NB B values per step
-    auto mfma_pass = [&](const int (&b_row)[2], int nb, v4f (&acc)[2]) {
-        acc[0] = v4f{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
-        const float* base = rows + (wv * 64 + kq * 16) * RS;
-#pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            const float av = base[st * RS + RX + r16];
-            const float b0 = base[st * RS + b_row[0]];
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[0], 0, 0, 0);
-            if (nb > 1) {
-                const float b1 = base[st * RS + b_row[1]];
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[1], 0, 0, 0);
-            }
-        }
-    };
-    // lane l holds D[4 (l / 16) + i][l % 16], i = 0..3: rows 0..7 live in lanes 0..31.  Block p of the wave -> operand row RX + 8 + m of its pixel 16 p + n
-    auto park_block = [&](const v4f& acc, int p) {
-        if (ln < 32) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) rows[RI(RX + 8 + 4 * kq + i, wv * 64 + 16 * p + r16)] = acc[i];
-        }
-    };
-
     int seen = 0;
     for (int nb = 0; nb < a.N; nb += kChunkN) {
         const int cnt = min(kChunkN, a.N - nb);
@@ -610,11 +573,11 @@ void dyn_bwd2_kernel(DynArgs a, const float* __restrict__ params, const float* _
                 in2[0] = v2f{(a.coors[2 * n] - (float)(cc * a.in_stride + a.in_stride / 2)) / soi,
                              (a.coors[2 * n + 1] - (float)(rr * a.in_stride + a.in_stride / 2)) / soi};
                 if (!valid) in2[0] = v2f{0.f, 0.f};
-                rows[RI(0, tid)] = in2[0].x;          // (read in pass A only: the previous instance's pass A is behind a barrier)
-                rows[RI(1, tid)] = in2[0].y;
+                rows[0 * kRowPad + tid] = in2[0].x;          // (read in pass A only: the previous instance's pass A is behind a barrier)
+                rows[1 * kRowPad + tid] = in2[0].y;
             }
 #pragma unroll
-            for (int k = 0; k < C / 2; ++k) in2[off / 2 + k] = v2f{rows[RI(off + 2 * k, tid)], rows[RI(off + 2 * k + 1, tid)]};
+            for (int k = 0; k < C / 2; ++k) in2[off / 2 + k] = v2f{rows[(off + 2 * k) * kRowPad + tid], rows[(off + 2 * k + 1) * kRowPad + tid]};
             (void)mlp_forward<C, REL>(wts, in2, h1, h2);
             if (!valid) {
 #pragma unroll
@@ -651,8 +614,8 @@ void dyn_bwd2_kernel(DynArgs a, const float* __restrict__ params, const float* _
             // pass B operands: dh2, h1
 #pragma unroll
             for (int i = 0; i < kDC; ++i) {
-                rows[RI(RX + i, tid)] = (i & 1) ? dh2[i / 2].y : dh2[i / 2].x;
-                rows[RI(RX + kDC + i, tid)] = (i & 1) ? h1[i / 2].y : h1[i / 2].x;
+                rows[(RX + i) * kRowPad + tid] = (i & 1) ? dh2[i / 2].y : dh2[i / 2].x;
+                rows[(RX + kDC + i) * kRowPad + tid] = (i & 1) ? h1[i / 2].y : h1[i / 2].x;
             }
 #pragma unroll
             for (int i = 0; i < kDC / 2; ++i) dh1[i] = v2f{0.f, 0.f};
@@ -680,50 +643,6 @@ void dyn_bwd2_kernel(DynArgs a, const float* __restrict__ params, const float* _
 #pragma unroll
             for (int kk = 0; kk < C / 2; ++kk) asm volatile("" : "+v"(dfeat[kk]));
             BXI_SEGMENT();
-#if BXI_DYN_MFMA
-            // ---- pass B on the matrix pipe: dW1 | db1 = dh2 x (h1 | ones): B rows RX + 8 + n, n <= 9 (h1 0..7, ones, pad)
-            v4f accB[2], accA[2];
-            {
-                const int brB[2] = {RX + 8 + min(r16, 9), 0};
-                mfma_pass(brB, 1, accB);
-            }
-            // pass A operands: dh1 over dh2 (this wave's own pixels: its pass-B reads precede these writes in its own LDS order)
-#pragma unroll
-            for (int i = 0; i < kDC; ++i) rows[RI(RX + i, tid)] = (i & 1) ? dh1[i / 2].y : dh1[i / 2].x;
-            {
-                const int brA[2] = {r16, 16 + r16};             // B rows 16 j + n: inputs, ones (row CIN), then nobody's
-                mfma_pass(brA, NBLK_A, accA);
-            }
-            park_block(accB[0], 0);
-#pragma unroll
-            for (int j = 0; j < NBLK_A; ++j) park_block(accA[j], 1 + j);
-            lds_barrier();
-            // one thread per output: the four waves' partials in wave order; and the nine threads that finish dW2 | db2
-            {
-                constexpr int kOutB = kDC * (kDC + 1), kOutA = kDC * (CIN + 1);
-                static_assert(kOutB + kOutA + 9 <= 256, "one output per thread");
-                unsigned t2 = (unsigned)tid;
-                asm volatile("" : "+v"(t2));
-                if (t2 < (unsigned)(kOutB + kOutA)) {
-                    const bool isB = t2 < (unsigned)kOutB;
-                    const unsigned u = isB ? t2 : t2 - kOutB, per = isB ? kDC + 1 : CIN + 1;
-                    const unsigned m = u / per, n = u % per;
-                    const unsigned pblk = isB ? 0u : 1u + n / 16u, col = isB ? n : n % 16u;
-                    const float* src = rows + RI(RX + 8 + m, 16 * pblk + col);
-                    const float sum = ((src[0] + src[64 * RS]) + src[128 * RS]) + src[192 * RS];
-                    const unsigned q = isB ? (n < (unsigned)kDC ? w1 + m * kDC + n : (unsigned)D::B1 + m) : (n < (unsigned)CIN ? m * CIN + n : (unsigned)D::B0 + m);
-                    asm volatile("global_store_dword %0, %1, %2" ::"v"(q * 4u), "v"(sum), "s"(dst) : "memory");
-                } else if (t2 < (unsigned)(kOutB + kOutA + 9)) {
-                    const unsigned i = t2 - (kOutB + kOutA);
-                    float sum = 0.f;
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) sum += red2[u * 12 + i];
-                    const unsigned qq = i < (unsigned)kDC ? w2 + i : (unsigned)D::B2;
-                    asm volatile("global_store_dword %0, %1, %2" ::"v"(qq * 4u), "v"(sum), "s"(dst) : "memory");
-                }
-            }
-            lds_barrier();
-#else
             lds_barrier();
             // ---- pass B: dW1 | db1 (blocks 0..7), and the nine threads that finish dW2 | db2 ------------------------------
             if (blk < NBB) contract(aB, bB, qB, dst);
@@ -739,11 +658,10 @@ void dyn_bwd2_kernel(DynArgs a, const float* __restrict__ params, const float* _
             lds_barrier();
             // pass A operands: dh1 (rel and the features are in their rows already)
 #pragma unroll
-            for (int i = 0; i < kDC; ++i) rows[RI(RX + i, tid)] = (i & 1) ? dh1[i / 2].y : dh1[i / 2].x;
+            for (int i = 0; i < kDC; ++i) rows[(RX + i) * kRowPad + tid] = (i & 1) ? dh1[i / 2].y : dh1[i / 2].x;
             lds_barrier();
             if (blk < NBA) contract(aA, bA, qA, dst);
             lds_barrier();
-#endif
         }
     }
     {
