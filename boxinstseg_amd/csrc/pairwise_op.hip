@@ -6,7 +6,7 @@
 // Roofline: HBM.  Forward moves 4*(1+K) B per pixel (K = size^2-1 output planes, write-bound);
 // backward 4*(1+K+1) B per pixel (g_pairwise read once through L2: every element is used by the
 // pixel itself (channel k) and by one neighbour (channel K-1-k)).  size == 3 runs the tiled kernels
-// further down (12.8 us / 15.4 us at 32x200x256 f32, cold, against 12.7 for a copy of the backward's bytes); the two kernels below serve
+// further down (12.3 us / 14.0 us at 32x200x256 f32, cold, against 12.7 for a linear copy of the backward's bytes); the two kernels below serve
 // the other window sizes.
 #include "common.hpp"
 
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void pairwise3_bwd_kernel(const T* __restrict_
 //             is two multiply-adds and one v_log_f32 against 4 x fewer store instructions;
 //   backward  every UNORDERED pair once (further down).  Rounds 3-5 summed d f/d x_p over all eight taps in the pixel itself: 16 float4
 //             loads per thread, every gradient element fetched twice (tools/micro/pw_bwd_wide_ref.inc keeps that kernel as the
-//             measuring stick: 19.4 us where the pair kernel takes 15.4 and a copy of the bytes 12.7, same box, cold).
+//             measuring stick: 19.4 us where the pair kernel takes 13.8 and a copy of the bytes 12.7, same box, cold).
 // The neighbours' probabilities of the four pixels overlap: 3 rows x (4 + 2d) staged entries are read once per thread.
 // A tile with a logit beyond +-34 (S could underflow) takes a per-pixel log-space path straight from global memory, exactly
 // pairwise.cu:38-58 (block-uniform choice, no extra LDS).
@@ -523,7 +523,10 @@ __global__ __launch_bounds__(256) void pairwise3_fwd_wide_kernel(const float* __
             const float S = qs[1][D + i] * qs[1 + dy][D + i + dx * D] + qm[1][D + i] * qm[1 + dy][D + i + dx * D];
             v[i] = in ? -0.69314718055994531f * __builtin_amdgcn_logf(S) : 0.f;                 // pairwise.cu:43-44: padded pairs are 0
         }
-        *reinterpret_cast<float4*>(ob + (uint32_t)k * plane + pix) = make_float4(v[0], v[1], v[2], v[3]);
+        // (non-temporal: 52 MB nobody in this launch reads -- 12.7 -> 12.3 us cold, same box, interleaved four times)
+        typedef float f4s __attribute__((ext_vector_type(4)));
+        const f4s ov = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(ov, reinterpret_cast<f4s*>(ob + (uint32_t)k * plane + pix));
     }
 }
 
@@ -563,6 +566,7 @@ static __device__ long long* g_pw_trace = nullptr;
 #ifndef BXI_PWP_OCC
 #define BXI_PWP_OCC 5
 #endif
+
 #define BXI_DPP_ROW_SHL1 0x101
 #define BXI_DPP_ROW_SHR1 0x111
 #define BXI_DPP_WAVE_SHL1 0x130
@@ -718,8 +722,12 @@ __global__ __launch_bounds__(256, BXI_PWP_OCC) void pairwise3_bwd_pair_kernel(co
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int dy = j == 0 ? 0 : 1, dx = j == 0 ? 1 : j - 2;
-            own[j] = *(gf4)(pb[4 + j] + (uint32_t)pix);
-            part[j] = *(gf4u)((dy ? pdn[3 - j] : pb[3 - j]) + (uint32_t)pix + dx * D * 4);
+            // non-temporal: every byte of these planes is wanted once by this launch (the few lines a neighbouring tile's edge items ask for again
+            // come from the Infinity Cache); kept out of the L2's way they leave it to the logits and the halo lines.  Same box, cold, us:
+            // plain 15.5 -> output stores nt 14.85 -> + these loads nt 13.77 (the copy: 12.65); nt on the extra rows' dwords +0.3, on the edge items 0,
+            // on the logits +0.35 (profiles/NOTES.md R6-2)
+            own[j] = __builtin_nontemporal_load((gf4)(pb[4 + j] + (uint32_t)pix));
+            part[j] = __builtin_nontemporal_load((gf4u)((dy ? pdn[3 - j] : pb[3 - j]) + (uint32_t)pix + dx * D * 4));
         }
     }
     // (everything below is derived from a thread index the compiler cannot see through: nothing of it is computed -- and kept in registers --
@@ -928,7 +936,8 @@ __global__ __launch_bounds__(256, BXI_PWP_OCC) void pairwise3_bwd_pair_kernel(co
                 const float u = ts[(gr + D) * PC + gc + D + i] * tm[(gr + D) * PC + gc + D + i];
                 o[i] = -u * ((acc[i] + v4[i]) + e4[i]);
             }
-            *reinterpret_cast<float4*>(g_logits + n * P + (int64_t)(r0 + gr) * W + c0 + gc) = make_float4(o[0], o[1], o[2], o[3]);
+            const f4a ov = {o[0], o[1], o[2], o[3]};                     // (non-temporal: nobody in this launch reads the output)
+            __builtin_nontemporal_store(ov, reinterpret_cast<f4a*>(g_logits + n * P + (int64_t)(r0 + gr) * W + c0 + gc));
         }
     }
     if (XR > 0) {
@@ -939,7 +948,7 @@ __global__ __launch_bounds__(256, BXI_PWP_OCC) void pairwise3_bwd_pair_kernel(co
             if (gc < D) e = Es[(0 * TRT + gr) * 4 + gc] + Es[(1 * TRT + gr) * 4 + gc];
             if (gc >= TC - D) e = Es[(2 * TRT + gr) * 4 + gc - (TC - D)];
             const float u = ts[(gr + D) * PC + gc + D] * tm[(gr + D) * PC + gc + D];
-            g_logits[n * P + (int64_t)(r0 + gr) * W + c0 + gc] = -u * ((acc2 + v) + e);
+            __builtin_nontemporal_store(-u * ((acc2 + v) + e), g_logits + n * P + (int64_t)(r0 + gr) * W + c0 + gc);
         }
     }
     PWT(7);

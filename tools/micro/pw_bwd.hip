@@ -95,7 +95,7 @@ int main(int argc, char** argv) {
         const size_t ldw = 2 * sizeof(float) * (size_t)(20 + 2 * D) * bxi::PwGeom<2, 64>::PC;
         hipLaunchKernelGGL((bxi::pairwise3_bwd_wide_kernel<2, 16, 64, 4>), dim3(tiles20), dim3(256), ldw, 0, x[s], g[s], H, W, out, 1);
     };
-    int swz = 1;
+    int swz = 3;
     auto pair = [&](int s, float* out) {
         hipLaunchKernelGGL((bxi::pairwise3_bwd_pair_kernel<2, 4>), dim3(tiles20), dim3(256), (bxi::PwPairGeom<2, 4>::lds_bytes), 0, x[s], g[s], H, W, out, swz);
     };
@@ -133,7 +133,7 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 2; ++rep) { run("wide", wide); run("pair", pair); run("pair16", pair16); run("copy", copy);
 #define GEO(TR, TC, SWZ) run("geo " #TR "x" #TC " swz" #SWZ, [&](int s, float* out) { hipLaunchKernelGGL((copy_geo<TR, TC, SWZ>), dim3(N * ((H + TR - 1) / TR) * (W / TC)), dim3(256), 0, 0, x[s], g[s], out, H, W); })
         for (swz = 0; swz <= 5; ++swz) { char nm[32]; snprintf(nm, 32, "pair swz %d", swz); run(nm, pair); }
-        swz = 1;
+        swz = 3;
         if (rep == 0) { GEO(4, 256, 0); GEO(4, 256, 1); GEO(8, 128, 0); GEO(8, 128, 1); GEO(16, 64, 0); GEO(16, 64, 1); GEO(32, 32, 1); }
         run("copy_t16", [&](int s, float* out) { hipLaunchKernelGGL(copy_tile<0>, dim3(tiles16), dim3(256), 0, 0, x[s], g[s], out, H, W); });
         run("copy_t20", [&](int s, float* out) { hipLaunchKernelGGL(copy_tile<4>, dim3(tiles20), dim3(256), 0, 0, x[s], g[s], out, H, W); }); }
