@@ -69,6 +69,7 @@ constexpr unsigned kFlagSingle = BXI_EVAL_SINGLE_LAUNCH, kFlagTwo = BXI_EVAL_TWO
                    kFlagShared = BXI_EVAL_SHARED_DEVICE, kFlagTargetsReady = BXI_EVAL_TARGETS_READY, kFlagGiveUp = BXI_EVAL_WAITS_GIVE_UP;
 constexpr int kBoxCap = 1024;                   // GT boxes per batch bxi_boxinst_targets_f32 keeps pair counts for
 constexpr int kBoxSplit = 8;                    // count words per box (each in its own 128 bytes): arrivals on one word are performed one after the other
+constexpr int kNtStreamFromMB = 20;             // logit maps of this many MB and more are streamed past the L2 (non-temporal loads)
 constexpr int kLongFrom = 96;                   // single launch, long form (8-row tiles) from this many instances on
 constexpr unsigned int kMaxTag = 0x0fffffffu;   // tags are 28 bits (a predicate word is tag << 4 | bits)
 constexpr int kAcc2Split = 8, kAcc2Stride = 16; // tile arrivals: eight words per instance, each in its own 128 bytes
@@ -439,8 +440,11 @@ __device__ __forceinline__ bool table_complete(const Ws& ws, int N, int spin_lim
 
 // ---- role 2: stream block = 4 waves x 8 rows of one instance map ---------------------------------------------------------
 struct LogitRows {
-    const float* L; int w, vec;
-    __device__ __forceinline__ float4 operator()(int r, int c) const { return load4(L + (int64_t)r * w, c, w, vec); }
+    const float* L; int w, vec, nt;
+    __device__ __forceinline__ float4 operator()(int r, int c) const {
+        if (vec && nt) {      // (non-temporal: launch_fused_eval decides -- maps that outgrow the L2) typedef float f4n __attribute__((ext_vector_type(4))); const f4n t_ = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(L + (int64_t)r * w + c)); return make_float4(t_.x, t_.y, t_.z, t_.w); }
+        return load4(L + (int64_t)r * w, c, w, vec);
+    }
 };
 
 struct NoHook { __device__ __forceinline__ void operator()(Ws&) const {} };
@@ -586,7 +590,14 @@ __device__ __forceinline__ void pool_load(const PoolArgs& pa, int item, int segs
     if (c < w && !BXI_AB(32)) {
         const float* base = pa.imgs + (int64_t)b * 3 * plane + (int64_t)(4 * r + wv) * pa.Wc + 4 * c;
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) v[ch] = *reinterpret_cast<const float4*>(base + pa.dn.src_ch[ch] * plane);
+        for (int ch = 0; ch < 3; ++ch) {
+            // non-temporal: 19.7 MB at 2 x 800 x 1024 that nobody reads twice -- kept out of the L2's way they leave it to the logits, the Lab records
+            // and the predicate words the rest of the launch asks for again: 17.39 -> 16.92 us per evaluation at 32 instances, 22.4 -> 21.9 at 64,
+            // 37.4 -> 36.7 at 128 (same box, interleaved three times; profiles/NOTES.md R6-7)
+            typedef float f4n __attribute__((ext_vector_type(4)));
+            const f4n t_ = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(base + pa.dn.src_ch[ch] * plane));
+            v[ch] = make_float4(t_.x, t_.y, t_.z, t_.w);
+        }
     }
 }
 
@@ -1650,8 +1661,8 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(PoolArgs pa, int n_pool, i
         const int k = blk * kWaves + (int)(threadIdx.x >> 6);
         if (64 * k <= a.N) { ws = with_tag(ws); table_wave(a, pa.meta, dil, R, ws, st, k, true, tl.ready, tl.key); }
     } else if (role == 2) {
-        const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
-        stream_block<false>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);     // (no tagged record in this form)
+        const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec & 1, vec >> 1};
+        stream_block<false>(a, ws, g_logits, vec & 1, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix);     // (no tagged record in this form)
     } else {
         double* lut = reinterpret_cast<double*>(smem);
         double* fch = lut + 256;
@@ -1757,8 +1768,8 @@ __global__ __launch_bounds__(256, (R == 4 ? kOneOcc : BXI_LONG_OCC)) void eval1_
         BXI_TW(0, tix, 0);
         // the table is the first duty of the first stream workgroups' first waves (wave k of the table in workgroup k): a workgroup
         // of its own would be the one workgroup too many for the front half to be resident at once at the headline size
-        const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec};
-        stream_block<true>(a, ws, g_logits, vec, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix, [&](Ws& w_) {
+        const LogitRows rows = {a.logits + (int64_t)(idx / Sn) * a.h * a.w, a.w, vec & 1, vec >> 1};
+        stream_block<true>(a, ws, g_logits, vec & 1, idx, reinterpret_cast<unsigned long long*>(smem), rows, tix, [&](Ws& w_) {
             w_ = with_tag(w_);
             if (!READY && (threadIdx.x >> 6) == 0 && 64 * idx <= N) table_wave(a, pa.meta, D, R, w_, st, idx, false, 0, 0u);
         });
@@ -2148,15 +2159,19 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     Ws ws;
     carve(workspace, batch->B, ws_capacity(batch->B, a.h, a.w, a.N, workspace_bytes), a.h, a.w, &ws);
     ws.ws_n16 = (unsigned int)(workspace_bytes / 16);
-    ws.pred_any = ready ? 1u : 0u;
+    ws.pred_any = (ready ? 1u : 0u);
     LossState st = {};
     if (state) {
         if (reinterpret_cast<uintptr_t>(state) & 255) return BXI_ERR_WORKSPACE;
         carve_state(state, a.N, a.h, a.w, &st);
     }
     st.iter = in->iter_counter;
-    const int vec = ((a.w & 3) == 0 && (reinterpret_cast<uintptr_t>(a.logits) & 15) == 0 &&
-                     (!g_logits || (reinterpret_cast<uintptr_t>(g_logits) & 15) == 0)) ? 1 : 0;
+    // bit 0: 16-byte rows; bit 1: the logit stream is read non-temporally -- where the maps outgrow the L2 anyway (128 instances: 52 MB) the
+    // stream's lines only push the Lab / predicate / table lines out of it: 37.4 -> 34.3 us per evaluation at 128 instances; at 32 (6.5 MB, which
+    // the tile waves find in the L2 again) the hint costs 0.4 us.  profiles/NOTES.md R6-7
+    const int nt_stream = (int64_t)a.N * a.h * a.w * 4 >= ((int64_t)BXI_KNOB("BXI_NT_FROM_MB", kNtStreamFromMB) << 20) ? 2 : 0;
+    const int vec = (((a.w & 3) == 0 && (reinterpret_cast<uintptr_t>(a.logits) & 15) == 0 &&
+                      (!g_logits || (reinterpret_cast<uintptr_t>(g_logits) & 15) == 0)) ? 1 : 0) | nt_stream;
     const int env_rows = BXI_KNOB("BXI_TILE_ROWS", 0);            // developer knobs (-DBXI_DEV builds only)
     const int env_pool_first = BXI_KNOB("BXI_POOL_FIRST", 0);
     const int env_pool_wgs = BXI_KNOB("BXI_POOL_WGS_PER_CU", 5);
@@ -2282,7 +2297,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     if (head && head_C != 8 && head_C != 16) return BXI_ERR_UNSUPPORTED;
     if (head) {
         // the head-fused first launch (factor 2, vector rows): tables, pool blocks, head tiles
-        if (head->factor != 2 || !vec || head->H * 2 != a.h || head->W * 2 != a.w || head->N != a.N || head->B != in->B || !pooled_in_launch)
+        if (head->factor != 2 || !(vec & 1) || head->H * 2 != a.h || head->W * 2 != a.w || head->N != a.N || head->B != in->B || !pooled_in_launch)
             return BXI_ERR_UNSUPPORTED;
         const int tiles = ((head->H + kHeadR - 1) / kHeadR) * ((head->W + kYC - 1) / kYC);
         ws.n_cb = (head->H + kHeadR - 1) / kHeadR;
