@@ -442,7 +442,11 @@ __device__ __forceinline__ bool table_complete(const Ws& ws, int N, int spin_lim
 struct LogitRows {
     const float* L; int w, vec, nt;
     __device__ __forceinline__ float4 operator()(int r, int c) const {
-        if (vec && nt) {      // (non-temporal: launch_fused_eval decides -- maps that outgrow the L2) typedef float f4n __attribute__((ext_vector_type(4))); const f4n t_ = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(L + (int64_t)r * w + c)); return make_float4(t_.x, t_.y, t_.z, t_.w); }
+        if (vec && nt) {      // non-temporal (launch_fused_eval decides: maps that outgrow the L2)
+            typedef float f4n __attribute__((ext_vector_type(4)));
+            const f4n t_ = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(L + (int64_t)r * w + c));
+            return make_float4(t_.x, t_.y, t_.z, t_.w);
+        }
         return load4(L + (int64_t)r * w, c, w, vec);
     }
 };
