@@ -90,10 +90,11 @@ static __device__ unsigned int g_waitlog[16];
 #endif
 constexpr int kOneOcc = BXI_ONE_OCC;           // workgroups per CU of the single-launch form (<= 128 VGPRs: the tile role's budget)
 constexpr unsigned kFaultCounts = 1u, kFaultFinisher = 2u;
-// A wave whose bounded wait ran out says so IN the word the finisher waits for, so that the round that sees every arrival sees
-// every fault: bit 50 of a tile wave's arrival (the sum field stays below 2^46 for every shape the table admits), bit 39 of a
-// predicate workgroup's count arrival -> bit 62 of the published sum W, bit 33 of a leader's dice word.  (Several faults on one
-// word may carry into its arrival count: the finisher then never sees the count it waits for and runs out itself -- as loud.)
+// A wave whose bounded wait ran out says so on the evaluation's fault word (zeroed by the first table wave before the entries every waiter checks),
+// with a returning atomic it waits for BEFORE its arrival: the round in which the finisher sees the last arrival reads the fault word too.  The sum W
+// word and a leader's dice word carry their own fault bit (one writer each); the arrival words of tile waves and predicate workgroups do not any
+// more -- a flag ADDED to an arrival carries into the arrival count from the second (predicate) / fourth (tile) fault on one word on, and the
+// finisher then waits kSpinLimit polls for a count that cannot come (4.5 s per evaluation with foreign targets, where every tile wave is "bad").
 constexpr unsigned long long kArrivalFault = 1ull << 50, kCountFault = 1ull << 39, kSumwFault = 1ull << 62, kDiceFault = 1ull << 33;
 
 #ifdef BXI_TRACE
@@ -1042,6 +1043,7 @@ __device__ __forceinline__ bool pred_words(const Ws& ws, const Tile& t, int h, i
             all = all && (pbyte[i] >> 4) == want;
         }
         if (__all(all)) { ok = true; BXI_WL(4, spins); break; }
+        if (ws.pred_any) break;        // targets ready: the words are an EARLIER launch's -- what is not there now will not come (foreign or overwritten targets: loud at once, not after kSpinLimit polls)
         __builtin_amdgcn_s_sleep(BXI_SLEEP_WORDS);
     }
     return ok;        // false: the caller's arrival says so, and the finisher turns both losses into NaN
@@ -1256,10 +1258,19 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
 // count, ran out (status 2, NaN losses for that evaluation) after kSpinLimit polls = 4.1 s.  Seen five times in 4800 evaluations with the 8-row
 // kernels at four workgroups per CU and 128 instances, where the tile workgroups start just as the stream workgroups' traffic lets the table's
 // drains complete (profiles/NOTES.md R5-7, R6-3: the stall's length follows kSpinLimit, the wait that runs out is the finisher's).
+// A wave whose bounded wait ran out (or that saw a fault word) says so on the evaluation's fault word BEFORE it arrives -- a returning atomic, waited
+// for -- so that the round in which the finisher sees the last arrival sees the fault too.  (Rounds 3-5 added a flag bit to the arrival itself: with
+// six arrivals per word four faults carry into the arrival count, the finisher never sees the count it waits for and the -- already loud -- error path
+// takes kSpinLimit polls: 4.5 s for an evaluation whose targets are somebody else's.)
 __device__ __forceinline__ void tile_wave_arrives(const Ws& ws, int N, int wid, long long fx_sum, bool bad) {
-    if ((threadIdx.x & 63) == 0)
+    if ((threadIdx.x & 63) == 0) {
+        if (bad) {
+            const unsigned int seen = __hip_atomic_fetch_or(ws.fault, kFaultCounts, BXI_RLX, BXI_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(seen) : "memory");
+        }
         __hip_atomic_fetch_add(ws.acc2 + (size_t)(wid % ((N < 64 ? N : 64) * kAcc2Split)) * kAcc2Stride,
-                               (1ull << 52) + (unsigned long long)(fx_sum + (1ll << 24)) + (bad ? kArrivalFault : 0ull), BXI_RLX, BXI_AGENT);
+                               (1ull << 52) + (unsigned long long)(fx_sum + (1ll << 24)), BXI_RLX, BXI_AGENT);
+    }
 }
 
 __device__ __forceinline__ void block_sum4(float (&v)[4], float* red /*[16]*/) {
@@ -1482,12 +1493,16 @@ __device__ __forceinline__ void pred_role(const InstArgs& a, const ValidCells& v
     // an LDS-only barrier: __syncthreads() would also wait for this wave's predicate-word stores to be acknowledged (~1 us) before the
     // count -- which the tile waves' normaliser hangs on -- could leave; the words announce themselves, nobody infers them from the count
     lds_barrier();
-    if (threadIdx.x == 0)    // (segments evaluated, sum W); integer adds commute: run-to-run identical
+    if (threadIdx.x == 0) {  // (segments evaluated, sum W); integer adds commute: run-to-run identical
+        if ((pred_bad[0] | pred_bad[1]) | (pred_bad[2] | pred_bad[3])) {      // loud: on the fault word, ahead of the arrival (a flag bit ADDED to the
+            const unsigned int seen = __hip_atomic_fetch_or(ws.fault, kFaultCounts, BXI_RLX, BXI_AGENT);    // arrival carries into its count from the second fault on)
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(seen) : "memory");
+        }
         __hip_atomic_fetch_add(&ws.acc1[(size_t)(pblk & (kAcc1Words - 1)) * kAcc2Stride],
                                ((unsigned long long)(unsigned int)((pred_seg[0] + pred_seg[1]) + (pred_seg[2] + pred_seg[3])) << 40) |
-                                   (unsigned long long)(unsigned int)((pred_cnt[0] + pred_cnt[1]) + (pred_cnt[2] + pred_cnt[3])) |
-                                   (((pred_bad[0] | pred_bad[1]) | (pred_bad[2] | pred_bad[3])) ? kCountFault : 0ull),      // loud
+                                   (unsigned long long)(unsigned int)((pred_cnt[0] + pred_cnt[1]) + (pred_cnt[2] + pred_cnt[3])),
                                BXI_RLX, BXI_AGENT);
+    }
     BXI_TW(2, pid, 1);
 }
 

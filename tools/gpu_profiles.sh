@@ -33,9 +33,14 @@ for t in pairwise_op dynamic_head head_fused discobox levelset tree_filter; do
   tail -c 300 $R/gpurun_out/${t}_bench.json | tr '\n' ' '; echo
 done
 cd $R
+# op-level pairwise_nlog backward: PMC passes of the stand-alone harness (round-5 kernel, pair kernel, linear copy side by side) + its timings
+if [ -x tools/micro/pw_bwd_nt ]; then
+  (echo "# tools/micro/pw_bwd.hip (wide = the round-5 backward, pair = pairwise3_bwd_pair_kernel, copy / geo = copies of the same bytes), then rocprofv3 --pmc per launch (tools/micro/pmc_pw.sh)"; tools/micro/pw_bwd_nt; tools/micro/pmc_pw.sh tools/micro/pw_bwd_nt 2>&1 | grep -v fillBuffer) > gpurun_out/pairwise_op_pmc.txt 2>&1
+  tail -3 gpurun_out/pairwise_op_pmc.txt | cut -c1-200
+fi
 # the per-wave trace needs the -DBXI_TRACE build of the library (tools/trace_forms.py's docstring); it is not kept in the tree
 if [ -f boxinstseg_amd/lib/libboxinst_hip_trace.so ]; then
-  (python tools/trace_forms.py; IPB=4 python tools/trace_forms.py; IPB=4 BXI_FLAGS=130 python tools/trace_forms.py) 2>&1 | grep -v amdgpu.ids > gpurun_out/block_trace.txt; tail -3 gpurun_out/block_trace.txt | cut -c1-300
+  (python tools/trace_forms.py; IPB=4 python tools/trace_forms.py; IPB=4 BXI_FLAGS=34 python tools/trace_forms.py) 2>&1 | grep -v amdgpu.ids > gpurun_out/block_trace.txt; tail -3 gpurun_out/block_trace.txt | cut -c1-300
 else
   rm -f gpurun_out/block_trace.txt; echo "no trace build: block trace skipped"
 fi

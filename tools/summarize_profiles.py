@@ -27,7 +27,7 @@ for row in ('pairwise_op', 'dynamic_head', 'head_fused', 'discobox', 'levelset',
         shutil.copy(f'{G}/prof_{row}/{rnd}_kernel_stats.csv', f'{P}/{rnd}_{row}_kernel_stats.csv')
     if os.path.exists(f'{G}/{row}_bench.json'):
         shutil.copy(f'{G}/{row}_bench.json', f'{P}/{rnd}_{row}_bench.json')
-for src, dst in (('block_trace.txt', f'{rnd}_block_trace.txt'), ('bench_default.json', f'{rnd}_bench_default.json')):
+for src, dst in (('block_trace.txt', f'{rnd}_block_trace.txt'), ('bench_default.json', f'{rnd}_bench_default.json'), ('pairwise_op_pmc.txt', f'{rnd}_pairwise_op_pmc.txt')):
     if os.path.exists(f'{G}/{src}'):
         shutil.copy(f'{G}/{src}', f'{P}/{dst}')
 stats = {}

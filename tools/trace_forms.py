@@ -3,7 +3,7 @@
 Needs the -DBXI_TRACE build (full stamps; add -DBXI_TRACE_LIGHT for first / last only):
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBXI_TRACE -mllvm -amdgpu-kernarg-preload-count=16 \
         -o boxinstseg_amd/lib/libboxinst_hip_trace.so boxinstseg_amd/csrc/*.hip
-  IPB=4 BXI_FLAGS=9 python tools/trace_forms.py          (flags: include/boxinst_hip.h BXI_EVAL_*; 128 = targets ready)
+  IPB=4 BXI_FLAGS=34 python tools/trace_forms.py         (flags: include/boxinst_hip.h BXI_EVAL_*; 32 = targets ready)
 Phases of a tile wave: 0 start, 1 tile located, 2 logits in + per-pixel done, 3 predicate words + masks, 5 pair loop done, 4 sum W / bands seen,
 6 adds issued, 7 arrived.  Stream / pool waves: 0 start, 1 loads in, 2..4 reductions / barriers, 7 end."""
 import os, sys, ctypes as C
@@ -30,7 +30,7 @@ for seed in range(6):
 st = torch.cuda.current_stream().cuda_stream
 def ev(s):
     batch, inst, losses, grad, state, ws = s[:6]
-    if flags & 128:
+    if flags & _lib.EVAL_TARGETS_READY:
         rc = lib.bxi_boxinst_targets_f32(C.byref(batch.struct), inst.struct.boxes_per_img_host, inst.struct.gt_count_host, 4, 3, 2, 0.3, ws.data_ptr(), ws.numel(), st)
         assert rc == 0, rc
     rc = lib.bxi_boxinst_eval_f32(C.byref(batch.struct), C.byref(inst.struct), 3, 2, 0.3, 1.0, ones.data_ptr(), ones.data_ptr() + 4,
