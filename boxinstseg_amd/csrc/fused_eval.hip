@@ -1445,7 +1445,7 @@ __device__ __forceinline__ bool dice_round(const Ws& ws, int N, int b0, float* d
 // The tile of list position `ti`: the instance whose tile range holds it (table entries: 16 bytes per instance, the same lines
 // for every wave), then the tile's place inside the instance's hull.  e0 = this lane's entry of the first 64 (N < 64: all).
 template <int D, int R, bool ONE>
-__device__ __forceinline__ bool locate_tile(const Ws& ws, const ValidCells& vc, int N, const int4& e0, int ti, int h, int w, int spin_limit, Tile& out) {
+__device__ __forceinline__ bool locate_tile(const Ws& ws, const ValidCells& vc, int N, const int4& e0, const int4& e1, int ti, int h, int w, int spin_limit, Tile& out) {
     const int lane = threadIdx.x & 63;
     int n = 0;
     int4 e = make_int4(0, 0, 0, 0);
@@ -1455,9 +1455,12 @@ __device__ __forceinline__ bool locate_tile(const Ws& ws, const ValidCells& vc, 
         e.x = __builtin_amdgcn_readlane(e0.x, n); e.y = __builtin_amdgcn_readlane(e0.y, n);
         e.z = __builtin_amdgcn_readlane(e0.z, n); e.w = __builtin_amdgcn_readlane(e0.w, n);
     } else {
+        // (entries 0..63 and 64..127 came with the wave's first round trip -- tile_role --: up to 128 instances the search asks memory for nothing.
+        //  Rounds 3-5 loaded chunk after chunk here, two dependent round trips in front of every tile of instances 64.. : the "locate" phase
+        //  of a tile wave, 2.0 us at 128 instances)
         for (int m0 = 0; m0 < N; m0 += 64) {
-            int4 em;
-            if (!tab_entry<ONE>(ws, m0 + lane, m0 + lane < N, spin_limit, em)) return false;
+            int4 em = m0 == 0 ? e0 : e1;
+            if (m0 >= 128 && !tab_entry<ONE>(ws, m0 + lane, m0 + lane < N, spin_limit, em)) return false;
             const unsigned long long mask = __ballot(m0 + lane < N && (em.x & 0xffffff) <= ti);
             const int cntm = __popcll(mask);
             if (cntm == 0) break;
@@ -1622,9 +1625,10 @@ __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& v
     const int wid = tblk * kWaves + wave, nwaves = n_tb * kWaves;
     __builtin_amdgcn_s_setprio(2);                                     // the launch ends on the tile waves, not on the leaders next to them
     BXI_TW(1, wid, 0);
-    int4 e0, eN = make_int4(0, 0, 0, 0);
+    int4 e0, e1 = make_int4(0, 0, 0, 0), eN = make_int4(0, 0, 0, 0);
     bool ok = tab_entry<ONE>(ws, lane, lane <= N, spin_limit, e0);
     if (N >= 64) ok = ok && tab_entry<ONE>(ws, N, true, spin_limit, eN);
+    if (N > 64) ok = ok && tab_entry<ONE>(ws, 64 + lane, 64 + lane < N, spin_limit, e1);      // (with the two above: one round trip in the two-launch form)
     // (a wave whose table wait ran out still arrives, saying so: the finisher then ends at once, loud, instead of running out itself.
     // The table's own zeroing of the arrival words precedes its entries, so without an entry the arrival may be wiped -- then the finisher
     // does run out: as loud)
@@ -1639,7 +1643,7 @@ __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& v
     // instances, 32.1 vs 31.1 at 96, targets ready 30.3 vs 28.7: the early workgroups' waves start their chains first.  profiles/NOTES.md R6-5)
     for (int ti = wid; ti < total && !bad; ti += nwaves) {
         Tile t;
-        if (!locate_tile<D, R, ONE>(ws, vc, N, e0, ti, a.h, a.w, spin_limit, t)) { bad = true; break; }
+        if (!locate_tile<D, R, ONE>(ws, vc, N, e0, e1, ti, a.h, a.w, spin_limit, t)) { bad = true; break; }
         BXI_TW(1, wid, 1);
         math_tile<D, R, ONE>(a, ws, t, upw_warm, n2max, zero_bit, n_items, spin_limit, scale, have_scale, g_logits, gbuf, wid, fx_sum, bad);
     }
