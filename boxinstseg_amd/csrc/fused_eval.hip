@@ -889,6 +889,20 @@ __device__ __forceinline__ float lane_plus_n(float v, int d) {
     for (int s = 0; s < d; ++s) x = __builtin_amdgcn_mov_dpp(x, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
     return __int_as_float(x);
 }
+// Inclusive prefix sum over the 64 lanes on the DPP path: Hillis-Steele inside a row of 16 lanes (row_shr 1, 2, 4, 8; lanes without a source add 0),
+// then the rows' totals by row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3).  Ten VALU instructions, no LDS.
+__device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return v;
+}
+#ifndef BXI_PRED_SCAN
+#define BXI_PRED_SCAN 1
+#endif
 struct ValidCells { int vrow[BXI_MAX_IMAGES], vcol[BXI_MAX_IMAGES]; };   // per image: valid(q) <=> row(q) < vrow && col(q) < vcol (host: :1354-1369,:1405)
 // PER_BOX (bxi_boxinst_targets_f32's second launch; never ONE): the rectangles are the GT BOXES' (ws.boxtab, n_ent of them) instead of the
 // instances', and what a box containing a site adds is kept PER BOX (`boxacc`, LDS of the workgroup, one counter per box) instead of
@@ -905,7 +919,7 @@ __device__ __forceinline__ int pred_item(int h, int w, int n_ent, const ValidCel
     // this row, the row D below, and for the last D lanes their right neighbours (they live in the next segment)
     float4 o0, oD, x0, xD;
     // lane n: instance n's table entry (box cells, image), requested with the Lab
-    int4 rect;
+    int4 rect, rect1 = make_int4(-1, 0, 0, 0);
     if (ONE) {
         // single-launch form: the pool workgroups of THIS launch write these pixels (16-byte records carrying the evaluation's
         // tag, written through); they precede this wave in the grid and wait for nobody
@@ -936,6 +950,9 @@ __device__ __forceinline__ int pred_item(int h, int w, int n_ent, const ValidCel
         if (untagged) ew = *ws.epoch;                                // (a plain load: the word was written by an earlier kernel)
         o0 = L4[(int64_t)r * w + cc]; oD = L4[(int64_t)rD * w + cc]; x0 = L4[(int64_t)r * w + cx]; xD = L4[(int64_t)rD * w + cx];
         rect = lane < n_ent ? (PER_BOX ? ws.boxtab()[lane] : ws.tab[lane]) : make_int4(-1, 0, 0, 0);
+        // (entries 64..127 ride with the same round trip: a load per 64-entry chunk BEHIND the first chunk's arithmetic was a second dependent trip
+        // in every item of an evaluation of more than 64 instances)
+        if (BXI_PRED_SCAN && n_ent > 64) rect1 = 64 + lane < n_ent ? (PER_BOX ? ws.boxtab()[64 + lane] : ws.tab[64 + lane]) : make_int4(-1, 0, 0, 0);
         if (untagged) ws.ep = next_tag((unsigned int)__builtin_amdgcn_readfirstlane((int)ew));
     }
     float nL = lane_plus_n(o0.x, D), nA = lane_plus_n(o0.y, D), nB = lane_plus_n(o0.z, D);
@@ -953,6 +970,38 @@ __device__ __forceinline__ int pred_item(int h, int w, int n_ent, const ValidCel
     // what a box containing the site adds:  (r, c)  (r, c+D)  (r+D, c)  (r+D, c+D)
     const int s00 = (p0 && v0n) + (p2 && vD0) + (p3 && vDn), s0n = (p0 && v00) + (p1 && vD0), sD0 = (p1 && v0n) + (p2 && v00), sDn = (p3 && v00) ? 1 : 0;
     int cnt = 0;
+#if BXI_PRED_SCAN
+    // LANE = RECTANGLE: what rectangle [r0, r1) x [c0, c1) collects from this row segment is a sum of the four site values over a RANGE of lanes
+    //   rows r:      s00 over lanes [c0 - base, c1 - base)  +  s0n over lanes [c0 - D - base, c1 - D - base)        (base = the segment's first column)
+    //   rows r + D:  sD0 over the first range               +  sDn over the second
+    // so ONE prefix sum over the lanes -- the four values packed into the bytes of a word: a segment's sums are <= 192, 128, 128, 64, no byte
+    // carries -- and four crossbar reads per lane serve 64 rectangles at once.  ~60 instructions per 64 rectangles where the loop below walks the
+    // rectangles that reach the row one after the other (~22 instructions each: a handful at 32 instances, 20-30 of an image's 64 at 128 instances,
+    // where the predicate workgroups hold the slots the tile workgroups are waiting for).  The same integers, added in another order.
+    const uint32_t incl = wave_scan_incl_u32((uint32_t)s00 | ((uint32_t)s0n << 8) | ((uint32_t)sD0 << 16) | ((uint32_t)sDn << 24));
+    const int base = seg * 64;
+    for (int m0 = 0; m0 < n_ent; m0 += 64) {
+        if (m0 == 64 && !ONE) rect = rect1;
+        else if (m0) {
+            if (PER_BOX) rect = m0 + lane < n_ent ? ws.boxtab()[m0 + lane] : make_int4(-1, 0, 0, 0);
+            else if (!tab_entry<ONE>(ws, m0 + lane, m0 + lane < n_ent, spin_limit, rect)) { ok = false; return 0; }
+            if (m0 + lane >= n_ent) rect = make_int4(-1, 0, 0, 0);
+        }
+        const int r0 = rect.y & 0xffff, r1 = (int)((unsigned int)rect.y >> 16), c0 = rect.z & 0xffff, c1 = (int)((unsigned int)rect.z >> 16);
+        const bool mine = m0 + lane < n_ent && (int)((unsigned int)rect.x >> 24) == b;
+        const bool rr = mine && r >= r0 && r < r1, rD2 = mine && r + D >= r0 && r + D < r1;
+        if (!__any(rr || rD2)) continue;                       // wave-uniform
+        const int i0 = min(max(c0 - base, 0), 64), i1 = min(max(c1 - base, 0), 64);
+        const int j0 = min(max(c0 - D - base, 0), 64), j1 = min(max(c1 - D - base, 0), 64);
+        // sum over the lanes below i (i in [0, 64]): the inclusive sum of lane i - 1
+        const uint32_t ei0 = (uint32_t)__builtin_amdgcn_ds_bpermute(((i0 - 1) & 63) << 2, (int)incl), ei1 = (uint32_t)__builtin_amdgcn_ds_bpermute(((i1 - 1) & 63) << 2, (int)incl);
+        const uint32_t ej0 = (uint32_t)__builtin_amdgcn_ds_bpermute(((j0 - 1) & 63) << 2, (int)incl), ej1 = (uint32_t)__builtin_amdgcn_ds_bpermute(((j1 - 1) & 63) << 2, (int)incl);
+        const uint32_t X = (i1 > 0 ? ei1 : 0u) - (i0 > 0 ? ei0 : 0u), Y = (j1 > 0 ? ej1 : 0u) - (j0 > 0 ? ej0 : 0u);      // bytewise monotone: no borrows
+        const int add = (rr ? (int)((X & 255u) + ((Y >> 8) & 255u)) : 0) + (rD2 ? (int)(((X >> 16) & 255u) + (Y >> 24)) : 0);
+        if (PER_BOX) { if (add) atomicAdd(&boxacc[m0 + lane], add); }       // LDS; flushed once per workgroup (targets_pred_kernel)
+        else cnt += add;
+    }
+#else
     for (int m0 = 0; m0 < n_ent; m0 += 64) {
         if (m0) {
             if (PER_BOX) rect = m0 + lane < n_ent ? ws.boxtab()[m0 + lane] : make_int4(-1, 0, 0, 0);
@@ -977,6 +1026,7 @@ __device__ __forceinline__ int pred_item(int h, int w, int n_ent, const ValidCel
                 cnt += add;
         }
     }
+#endif
     return cnt;
 }
 
@@ -1049,6 +1099,9 @@ __device__ __forceinline__ bool pred_words(const Ws& ws, const Tile& t, int h, i
     return ok;        // false: the caller's arrival says so, and the finisher turns both losses into NaN
 }
 
+#ifndef BXI_SUMW_EARLY
+#define BXI_SUMW_EARLY 1
+#endif
 template <int D, int R, bool ONE>
 __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float upw_warm, float n2max, int zero_bit, int n_items,
                                           int spin_limit, float& scale, bool& have_scale, float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
@@ -1062,6 +1115,16 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     const bool col_owned = g_logits && lane >= D && lane < 64 - D && c < t.hc1;
     float x[RD];
     load_plane<D, R>(Lg, t, h, w, lane, x);
+    // targets ready: the predicate words are an earlier launch's -- asked for WITH the logits (one round trip instead of two; the per-pixel
+    // arithmetic below runs while they fly), looked at once where the other forms start polling
+    uint32_t pearly[R + D];
+    const bool early = ws.pred_any != 0u && zero_bit == 0;             // wave-uniform
+    if (early) {
+        const unsigned int* pp = ws.pred + (int64_t)t.img * h * w;
+        const uint32_t cc = (uint32_t)min(max(c, 0), w - 1);
+#pragma unroll
+        for (int i = 0; i < R + D; ++i) pearly[i] = __hip_atomic_load(pp + (uint32_t)min(max(t.tile_r0 - D + i, 0), h - 1) * (uint32_t)w + cc, BXI_RLX, BXI_AGENT);
+    }
     float g[R];
     float num = 0.f;
 #pragma unroll
@@ -1100,13 +1163,22 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     }
     const bool slow = zero_bit != 0 || __any(sat);
     bool bad = false;          // a bounded wait of this wave ran out (never expected): its arrival carries the fact to the finisher
+    const int band0 = t.tile_r0 / kSBlk, band1 = (min(t.tile_r0 + R, h) - 1) / kSBlk;
+    const bool look_early = BXI_SUMW_EARLY && !slow && (!have_scale || (ONE && g_logits));       // wave-uniform
+    unsigned long long sw_early = 0ull;
+    unsigned int f0e = 0u, f1e = 0u;
     BXI_TW(1, tix, 2);
     if (!slow) {
         uint32_t pb[4] = {0u, 0u, 0u, 0u};
         {
             uint32_t pbyte[R + D];
             if (BXI_AB(8)) { for (int i = 0; i < R + D; ++i) pbyte[i] = 0xfu; }
-            else bad |= !pred_words<D, R>(ws, t, h, w, c, spin_limit, pbyte);
+            else if (early) {
+                bool all = true;
+#pragma unroll
+                for (int i = 0; i < R + D; ++i) { pbyte[i] = pearly[i]; all = all && (pbyte[i] >> 4) == 0u; }      // (words an earlier launch left carry tag 0)
+                bad |= !__all(all);
+            } else bad |= !pred_words<D, R>(ws, t, h, w, c, spin_limit, pbyte);
 #pragma unroll
             for (int i = 0; i < R + D; ++i)
 #pragma unroll
@@ -1135,6 +1207,15 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
                 dw[dir][q4] = spread4((m[dir].nA >> (4 * q4)) & 15u) + spread4((m[dir].nB >> (4 * q4)) & 15u);
             }
         BXI_TW(1, tix, 3);
+        // the first look at sum W (and, single-launch form, at the band flags of the rows this tile adds onto) goes out BEFORE the pair loop and is
+        // evaluated behind it: the round trip hides under ~2 us of arithmetic; what is not there yet is polled for as before
+        if (look_early) {
+            if (!have_scale) sw_early = __hip_atomic_load(ws.sumw, BXI_RLX, BXI_AGENT);
+            if (ONE && g_logits) {
+                f0e = __hip_atomic_load(&ws.bandflag[(int64_t)n * ws.n_cb + band0], BXI_RLX, BXI_AGENT);
+                f1e = __hip_atomic_load(&ws.bandflag[(int64_t)n * ws.n_cb + band1], BXI_RLX, BXI_AGENT);
+            }
+        }
         // one unordered pair: A = (row ra, this lane) ; B = (row rb of the lane `q` names) ; num collects -log2 S
 #define BXI_PAIR(i, ra, rb, qa, qb, qt, qu, dir, GA, GB)                                                            \
         {                                                                                                           \
@@ -1210,8 +1291,15 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     fx_sum += (long long)(num * kNumScale);                                    // this tile's share of sum W pw, fixed point: integer adds commute
     // single-launch form: the rows this tile adds onto were zero-filled by stream workgroups of THIS launch; their band flags are
     // asked for in the same round as sum W
-    const int band0 = t.tile_r0 / kSBlk, band1 = (min(t.tile_r0 + R, h) - 1) / kSBlk;
     bool bands_ok = !ONE || !g_logits;
+    if (look_early) {
+        if (!have_scale && (sw_early >> 63) != 0ull) {
+            if (sw_early & kSumwFault) bad = true;
+            have_scale = true;
+            scale = upw_warm / fmaxf((float)(double)(sw_early & (kSumwFault - 1ull)), 1.f);
+        }
+        if (ONE && g_logits) bands_ok = f0e == ws.ep && f1e == ws.ep;
+    }
     if (BXI_AB(4)) { bands_ok = true; if (!have_scale) { have_scale = true; scale = 1e-6f; } }
     if (!have_scale || !bands_ok) {           // wave-uniform
         double total_w = 0.0;
@@ -1716,16 +1804,20 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 2 ? 4 : 3) : (D <= 2 ? 3 : 2))
     }
     const Ws ws = with_tag(ws_in);
     const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
+#ifndef BXI_PAIR_TILES_FIRST
+#define BXI_PAIR_TILES_FIRST 0
+#endif
+    const int n_tb = (int)gridDim.x - 2 - N - n_pb;
+    const int lead0 = BXI_PAIR_TILES_FIRST ? n_pb + 1 + n_tb : n_pb + 1, tile0 = BXI_PAIR_TILES_FIRST ? n_pb + 1 : n_pb + 1 + N;
     if (blk == n_pb) {                                          // ---- the reducer
         reducer_role<false>(ws, zero_bit, n_pb > 0 ? n_items : 0, spin_limit);      // (no predicate workgroups here: sum W is in memory already)
-    } else if (blk < n_pb + 1 + N) {                                   // ---- leader of an instance
-        BXI_TW(3, 1 + blk - n_pb - 1, 0);
-        leader_block<false>(a, D, ws, st, blk - n_pb - 1, upp, g_logits, smem, red, spin_limit);
     } else if (blk == (int)gridDim.x - 1) {
-        finisher_role<false>(a, ws, st, upp, upw, resolve_warmup(warmup, st.iter), zero_bit, n_items, spin_limit, R, ((int)gridDim.x - 2 - N - n_pb) * kWaves, losses);
+        finisher_role<false>(a, ws, st, upp, upw, resolve_warmup(warmup, st.iter), zero_bit, n_items, spin_limit, R, n_tb * kWaves, losses);
+    } else if (blk >= lead0 && blk < lead0 + N) {                      // ---- leader of an instance
+        BXI_TW(3, 1 + blk - lead0, 0);
+        leader_block<false>(a, D, ws, st, blk - lead0, upp, g_logits, smem, red, spin_limit);
     } else {
-        tile_role<D, R, false>(a, vc, ws, upw * resolve_warmup(warmup, st.iter), n2max, zero_bit, n_items, spin_limit, g_logits, smem, blk - N - n_pb - 1,
-                               (int)gridDim.x - 2 - N - n_pb);
+        tile_role<D, R, false>(a, vc, ws, upw * resolve_warmup(warmup, st.iter), n2max, zero_bit, n_items, spin_limit, g_logits, smem, blk - tile0, n_tb);
     }
 }
 
@@ -2373,7 +2465,10 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     const int cus2 = stream_cus(s, device_cus());                      // a CU-masked stream has fewer
     const int slots = occ * cus2 > 64 ? occ * cus2 : 64;
     int n_pb = ready ? 0 : (n_items + kWaves - 1) / kWaves;  // (targets ready: the image side is in memory at this kernel's start)
-    if (n_pb > slots / 2) n_pb = slots / 2;
+#ifndef BXI_PB_CAP_8THS
+#define BXI_PB_CAP_8THS 4
+#endif
+    if (n_pb > slots * BXI_PB_CAP_8THS / 8) n_pb = slots * BXI_PB_CAP_8THS / 8;
     // (the predicate workgroups are short-lived: the tile workgroups behind them in the grid take their slots as they leave, so the
     // tile workgroups are sized for the slots, not for what the predicate workgroups leave over -- BXI_PAIR_TB_FULL=0: the round-3 sizing)
     const int env_tb_full = BXI_KNOB("BXI_PAIR_TB_FULL", 1);
