@@ -167,6 +167,14 @@ __device__ __forceinline__ void load16_past_x4(const void* p0, const void* p1, c
                  "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
 }
+// two 8-byte words past the caches, one round trip
+__device__ __forceinline__ void load8_past_x2(const void* p0, const void* p1, unsigned long long& a, unsigned long long& b) {
+    asm volatile("global_load_dwordx2 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(p0), "v"(p1) : "memory");
+}
+__device__ __forceinline__ void load16_past_x3(const void* p0, const void* p1, const void* p2, u4v& a, u4v& b, u4v& c) {
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p0), "v"(p1), "v"(p2) : "memory");
+}
 __device__ __forceinline__ void load16_past_x5(const void* p0, const void* p1, const void* p2, const void* p3, const void* p4, u4v& a, u4v& b, u4v& c, u4v& d,
                                                u4v& e) {
     asm volatile("global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\tglobal_load_dwordx4 %2, %7, off sc1\n\t"
@@ -189,6 +197,52 @@ __device__ __forceinline__ void load16_past_x5_epoch(const void* p0, const void*
                  : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(0), "s"(epoch)
                  : "memory");
 }
+// N words past the caches in ONE round trip: `base` (a scalar register pair) + a 32-bit byte offset per lane and word.  As a sequence of
+// __hip_atomic_load the compiler issues them one at a time, an s_waitcnt vmcnt(0) behind each (atomics are not reordered against each other and
+// each one's consumer is scheduled right behind it): R + D dependent trips to the L2 in front of every tile's pair loop -- six at 4-row tiles,
+// ten at 8-row tiles, the "pred + masks" phase of the per-wave traces (1.4 / 3.3 us).  profiles/NOTES.md R6-11.
+#define BXI_PW_LD(i) "global_load_dword %[v" #i "], %[o" #i "], %[b] sc1\n\t"
+#define BXI_PW_OUT(i) [v##i] "=&v"(v[i])
+#define BXI_PW_IN(i) [o##i] "v"(off[i])
+template <int N>
+__device__ __forceinline__ void load_words_past(const unsigned int* base, const uint32_t (&off)[N], uint32_t (&v)[N]) {
+    static_assert(N >= 5 && N <= 12, "R + D of the tile kernels");
+    if constexpr (N == 5)
+        asm volatile(BXI_PW_LD(0) BXI_PW_LD(1) BXI_PW_LD(2) BXI_PW_LD(3) BXI_PW_LD(4) "s_waitcnt vmcnt(0)"
+                     : BXI_PW_OUT(0), BXI_PW_OUT(1), BXI_PW_OUT(2), BXI_PW_OUT(3), BXI_PW_OUT(4)
+                     : BXI_PW_IN(0), BXI_PW_IN(1), BXI_PW_IN(2), BXI_PW_IN(3), BXI_PW_IN(4), [b] "s"(base) : "memory");
+    else if constexpr (N == 6)
+        asm volatile(BXI_PW_LD(0) BXI_PW_LD(1) BXI_PW_LD(2) BXI_PW_LD(3) BXI_PW_LD(4) BXI_PW_LD(5) "s_waitcnt vmcnt(0)"
+                     : BXI_PW_OUT(0), BXI_PW_OUT(1), BXI_PW_OUT(2), BXI_PW_OUT(3), BXI_PW_OUT(4), BXI_PW_OUT(5)
+                     : BXI_PW_IN(0), BXI_PW_IN(1), BXI_PW_IN(2), BXI_PW_IN(3), BXI_PW_IN(4), BXI_PW_IN(5), [b] "s"(base) : "memory");
+    else if constexpr (N == 7)
+        asm volatile(BXI_PW_LD(0) BXI_PW_LD(1) BXI_PW_LD(2) BXI_PW_LD(3) BXI_PW_LD(4) BXI_PW_LD(5) BXI_PW_LD(6) "s_waitcnt vmcnt(0)"
+                     : BXI_PW_OUT(0), BXI_PW_OUT(1), BXI_PW_OUT(2), BXI_PW_OUT(3), BXI_PW_OUT(4), BXI_PW_OUT(5), BXI_PW_OUT(6)
+                     : BXI_PW_IN(0), BXI_PW_IN(1), BXI_PW_IN(2), BXI_PW_IN(3), BXI_PW_IN(4), BXI_PW_IN(5), BXI_PW_IN(6), [b] "s"(base) : "memory");
+    else if constexpr (N == 8)
+        asm volatile(BXI_PW_LD(0) BXI_PW_LD(1) BXI_PW_LD(2) BXI_PW_LD(3) BXI_PW_LD(4) BXI_PW_LD(5) BXI_PW_LD(6) BXI_PW_LD(7) "s_waitcnt vmcnt(0)"
+                     : BXI_PW_OUT(0), BXI_PW_OUT(1), BXI_PW_OUT(2), BXI_PW_OUT(3), BXI_PW_OUT(4), BXI_PW_OUT(5), BXI_PW_OUT(6), BXI_PW_OUT(7)
+                     : BXI_PW_IN(0), BXI_PW_IN(1), BXI_PW_IN(2), BXI_PW_IN(3), BXI_PW_IN(4), BXI_PW_IN(5), BXI_PW_IN(6), BXI_PW_IN(7), [b] "s"(base) : "memory");
+    else if constexpr (N == 9)
+        asm volatile(BXI_PW_LD(0) BXI_PW_LD(1) BXI_PW_LD(2) BXI_PW_LD(3) BXI_PW_LD(4) BXI_PW_LD(5) BXI_PW_LD(6) BXI_PW_LD(7) BXI_PW_LD(8) "s_waitcnt vmcnt(0)"
+                     : BXI_PW_OUT(0), BXI_PW_OUT(1), BXI_PW_OUT(2), BXI_PW_OUT(3), BXI_PW_OUT(4), BXI_PW_OUT(5), BXI_PW_OUT(6), BXI_PW_OUT(7), BXI_PW_OUT(8)
+                     : BXI_PW_IN(0), BXI_PW_IN(1), BXI_PW_IN(2), BXI_PW_IN(3), BXI_PW_IN(4), BXI_PW_IN(5), BXI_PW_IN(6), BXI_PW_IN(7), BXI_PW_IN(8), [b] "s"(base) : "memory");
+    else if constexpr (N == 10)
+        asm volatile(BXI_PW_LD(0) BXI_PW_LD(1) BXI_PW_LD(2) BXI_PW_LD(3) BXI_PW_LD(4) BXI_PW_LD(5) BXI_PW_LD(6) BXI_PW_LD(7) BXI_PW_LD(8) BXI_PW_LD(9) "s_waitcnt vmcnt(0)"
+                     : BXI_PW_OUT(0), BXI_PW_OUT(1), BXI_PW_OUT(2), BXI_PW_OUT(3), BXI_PW_OUT(4), BXI_PW_OUT(5), BXI_PW_OUT(6), BXI_PW_OUT(7), BXI_PW_OUT(8), BXI_PW_OUT(9)
+                     : BXI_PW_IN(0), BXI_PW_IN(1), BXI_PW_IN(2), BXI_PW_IN(3), BXI_PW_IN(4), BXI_PW_IN(5), BXI_PW_IN(6), BXI_PW_IN(7), BXI_PW_IN(8), BXI_PW_IN(9), [b] "s"(base) : "memory");
+    else if constexpr (N == 11)
+        asm volatile(BXI_PW_LD(0) BXI_PW_LD(1) BXI_PW_LD(2) BXI_PW_LD(3) BXI_PW_LD(4) BXI_PW_LD(5) BXI_PW_LD(6) BXI_PW_LD(7) BXI_PW_LD(8) BXI_PW_LD(9) BXI_PW_LD(10) "s_waitcnt vmcnt(0)"
+                     : BXI_PW_OUT(0), BXI_PW_OUT(1), BXI_PW_OUT(2), BXI_PW_OUT(3), BXI_PW_OUT(4), BXI_PW_OUT(5), BXI_PW_OUT(6), BXI_PW_OUT(7), BXI_PW_OUT(8), BXI_PW_OUT(9), BXI_PW_OUT(10)
+                     : BXI_PW_IN(0), BXI_PW_IN(1), BXI_PW_IN(2), BXI_PW_IN(3), BXI_PW_IN(4), BXI_PW_IN(5), BXI_PW_IN(6), BXI_PW_IN(7), BXI_PW_IN(8), BXI_PW_IN(9), BXI_PW_IN(10), [b] "s"(base) : "memory");
+    else if constexpr (N == 12)
+        asm volatile(BXI_PW_LD(0) BXI_PW_LD(1) BXI_PW_LD(2) BXI_PW_LD(3) BXI_PW_LD(4) BXI_PW_LD(5) BXI_PW_LD(6) BXI_PW_LD(7) BXI_PW_LD(8) BXI_PW_LD(9) BXI_PW_LD(10) BXI_PW_LD(11) "s_waitcnt vmcnt(0)"
+                     : BXI_PW_OUT(0), BXI_PW_OUT(1), BXI_PW_OUT(2), BXI_PW_OUT(3), BXI_PW_OUT(4), BXI_PW_OUT(5), BXI_PW_OUT(6), BXI_PW_OUT(7), BXI_PW_OUT(8), BXI_PW_OUT(9), BXI_PW_OUT(10), BXI_PW_OUT(11)
+                     : BXI_PW_IN(0), BXI_PW_IN(1), BXI_PW_IN(2), BXI_PW_IN(3), BXI_PW_IN(4), BXI_PW_IN(5), BXI_PW_IN(6), BXI_PW_IN(7), BXI_PW_IN(8), BXI_PW_IN(9), BXI_PW_IN(10), BXI_PW_IN(11), [b] "s"(base) : "memory");
+}
+#undef BXI_PW_LD
+#undef BXI_PW_OUT
+#undef BXI_PW_IN
 __device__ __forceinline__ float4 f4_of(const u4v& v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
 
 // ---- workspace ---------------------------------------------------------------------------------------------------------
@@ -797,6 +851,16 @@ __device__ __forceinline__ void dir_masks(const TileFlags& f, const uint32_t (&p
 }
 
 __device__ __forceinline__ uint32_t spread4(uint32_t x4) { return (x4 * 0x00204081u) & 0x01010101u; }   // bits 0..3 -> bytes 0..3
+// the two 16-bit halves of a word times those of another (v_pk_mul_lo_u16 / v_pk_mad_u16: full rate, where a 32-bit multiply is a quarter-rate
+// instruction and the 24-bit one loses the fourth byte)
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_mul_u16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2v)(__builtin_bit_cast(us2v, a) * __builtin_bit_cast(us2v, b))); }
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_bit_cast(uint32_t, (us2v)(__builtin_bit_cast(us2v, a) * __builtin_bit_cast(us2v, b) + __builtin_bit_cast(us2v, c)));
+}
+#ifndef BXI_MASKS_V2
+#define BXI_MASKS_V2 1
+#endif
 
 template <int D>
 __device__ __forceinline__ float lane_plus(float v) {
@@ -1079,19 +1143,31 @@ __device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, cons
 // predicate waves precede the tile waves in the grid and never wait; by the time a tile wave asks they are normally done.
 // A tile wave's own few predicate words (written through by the predicate waves, which precede it in the grid), read past the
 // caches until every one carries this evaluation's tag; usually they are there at once.
+#ifndef BXI_PW_BATCH
+#define BXI_PW_BATCH 1
+#endif
 template <int D, int R>
 __device__ __forceinline__ bool pred_words(const Ws& ws, const Tile& t, int h, int w, int c, int spin_limit, uint32_t (&pbyte)[R + D]) {
-    const unsigned int* pp = ws.pred + (int64_t)t.img * h * w;
+    const unsigned int* pp = ws.pred + (int64_t)t.img * h * w;            // scalar base + 32-bit byte offsets (one plane < 2^31 bytes)
     const uint32_t cc = (uint32_t)min(max(c, 0), w - 1);
     const unsigned int want = ws.pred_any ? 0u : ws.ep;       // words an earlier launch left (bxi_boxinst_targets_f32) carry tag 0: no tag of this evaluation
+    uint32_t off[R + D];
+#pragma unroll
+    for (int i = 0; i < R + D; ++i) off[i] = ((uint32_t)min(max(t.tile_r0 - D + i, 0), h - 1) * (uint32_t)w + cc) * 4u;
     bool ok = false;
     for (int spins = 0; spins <= spin_limit; ++spins) {
         bool all = true;
+#if BXI_PW_BATCH
+        load_words_past<R + D>(pp, off, pbyte);
+#pragma unroll
+        for (int i = 0; i < R + D; ++i) all = all && (pbyte[i] >> 4) == want;
+#else
 #pragma unroll
         for (int i = 0; i < R + D; ++i) {
-            pbyte[i] = __hip_atomic_load(pp + (uint32_t)min(max(t.tile_r0 - D + i, 0), h - 1) * (uint32_t)w + cc, BXI_RLX, BXI_AGENT);
+            pbyte[i] = __hip_atomic_load(pp + off[i] / 4u, BXI_RLX, BXI_AGENT);
             all = all && (pbyte[i] >> 4) == want;
         }
+#endif
         if (__all(all)) { ok = true; BXI_WL(4, spins); break; }
         if (ws.pred_any) break;        // targets ready: the words are an EARLIER launch's -- what is not there now will not come (foreign or overwritten targets: loud at once, not after kSpinLimit polls)
         __builtin_amdgcn_s_sleep(BXI_SLEEP_WORDS);
@@ -1169,24 +1245,14 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     unsigned int f0e = 0u, f1e = 0u;
     BXI_TW(1, tix, 2);
     if (!slow) {
-        uint32_t pb[4] = {0u, 0u, 0u, 0u};
-        {
-            uint32_t pbyte[R + D];
-            if (BXI_AB(8)) { for (int i = 0; i < R + D; ++i) pbyte[i] = 0xfu; }
-            else if (early) {
-                bool all = true;
+        uint32_t pbyte[R + D];
+        if (BXI_AB(8)) { for (int i = 0; i < R + D; ++i) pbyte[i] = 0xfu; }
+        else if (early) {
+            bool all = true;
 #pragma unroll
-                for (int i = 0; i < R + D; ++i) { pbyte[i] = pearly[i]; all = all && (pbyte[i] >> 4) == 0u; }      // (words an earlier launch left carry tag 0)
-                bad |= !__all(all);
-            } else bad |= !pred_words<D, R>(ws, t, h, w, c, spin_limit, pbyte);
-#pragma unroll
-            for (int i = 0; i < R + D; ++i)
-#pragma unroll
-                for (int d = 0; d < 4; ++d) pb[d] |= ((pbyte[i] >> d) & 1u) << i;
-        }
-        const TileFlags f = tile_flags<D, R>(t, h, w, lane);
-        DirMasks m[4];
-        dir_masks<D>(f, pb, m);
+            for (int i = 0; i < R + D; ++i) { pbyte[i] = pearly[i]; all = all && (pbyte[i] >> 4) == 0u; }      // (words an earlier launch left carry tag 0)
+            bad |= !__all(all);
+        } else bad |= !pred_words<D, R>(ws, t, h, w, c, spin_limit, pbyte);
         float gq[PK ? 1 : RD], gR[PK ? 1 : RD];      // gradient of this lane's pixels / of lane + D's
         v2 gq2[PK ? RD / 2 : 1], gR2[PK ? RD / 2 : 1];
         if constexpr (PK) {
@@ -1198,14 +1264,71 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
         }
         // pair weights as bytes, four rows per word: cw = W[k,A] + W[7-k,B] (gradient), dw = the same restricted to
         // pixels this tile owns (loss sum)
-        uint32_t cw[4][(R + D + 3) / 4], dw[4][(R + D + 3) / 4];
+        constexpr int NQ = (R + D + 3) / 4;
+        uint32_t cw[4][NQ], dw[4][NQ];
+#if BXI_MASKS_V2
+        // Every mask of dir_masks is (a 0/1 of the LANE: its column in the box / valid / owned) x (a row range of the TILE: wave-uniform) x (the colour
+        // predicate), so the weights are made in the byte domain at once: the predicate nibbles of four rows packed into a word (bytes = rows), one
+        // shift + AND per direction, an AND with the row range's byte mask (scalar registers, made on the scalar unit) and a packed 16-bit multiply by the
+        // lane's 0 / 1 / 2.  ~160 vector instructions per tile where the bit-mask form (transpose to row bits, AND the flag words, spread nibble by
+        // nibble: tile_flags / dir_masks / spread4, kept below for the record) took ~420 -- next to ~500 of the pair loop itself.  The same bytes.
+        {
+            uint32_t spb[4][NQ];
 #pragma unroll
-        for (int dir = 0; dir < 4; ++dir)
+            for (int q4 = 0; q4 < NQ; ++q4) {
+                uint32_t W = 0u;
 #pragma unroll
-            for (int q4 = 0; q4 < (R + D + 3) / 4; ++q4) {
-                cw[dir][q4] = spread4((m[dir].mA >> (4 * q4)) & 15u) + spread4((m[dir].mB >> (4 * q4)) & 15u);
-                dw[dir][q4] = spread4((m[dir].nA >> (4 * q4)) & 15u) + spread4((m[dir].nB >> (4 * q4)) & 15u);
+                for (int k = 0; k < 4; ++k)
+                    if (4 * q4 + k < R + D) W |= (pbyte[4 * q4 + k] & 15u) << (8 * k);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) spb[d][q4] = (W >> d) & 0x01010101u;
             }
+            const int base = t.tile_r0 - D;
+            const uint32_t rows_box = row_bits(t.r0, t.r1, base, RD), rows_val = row_bits(0, min(h, t.vrow), base, RD);
+            const uint32_t rows_own = row_bits(t.tile_r0, min(t.tile_r0 + R, h), base, RD);
+            const uint32_t X1 = rows_box & rows_val, X2 = (rows_box >> D) & rows_val, X3 = rows_box & (rows_val >> D);
+            const uint32_t X1O = X1 & rows_own, X2OD = X2 & (rows_own >> D), X3O = X3 & rows_own;
+            const int cl = t.tile_c0 - D + lane, cr = cl + D, cv = min(w, t.vcol);
+            const bool inR = lane + D < 64;          // lanes without a right neighbour: every pair weight 0 (they receive some other lane's data)
+            const uint32_t fa = cl >= t.c0 && cl < t.c1, fv = cl >= 0 && cl < cv, fo = lane >= D && lane < 64 - D && cl < t.hc1;
+            const uint32_t faR = inR && cr >= t.c0 && cr < t.c1, fvR = inR && cr >= 0 && cr < cv, foR = inR && lane < 64 - 2 * D && cr < t.hc1;
+            // the lane's multipliers, one per 16-bit half
+            const uint32_t p1 = fa & fvR, q1 = faR & fv, s1 = fa & fv;
+            const uint32_t kp = p1 * 0x10001u, kq = q1 * 0x10001u, ks = s1 * 0x10001u, kpq = kp + kq;
+            const uint32_t kpo = (p1 & fo) * 0x10001u, kqo = (q1 & foR) * 0x10001u, kso = (s1 & fo) * 0x10001u, kpqo = kpo + kqo;
+#pragma unroll
+            for (int q4 = 0; q4 < NQ; ++q4) {
+                const uint32_t b1 = spread4((X1 >> (4 * q4)) & 15u), b2 = spread4((X2 >> (4 * q4)) & 15u), b3 = spread4((X3 >> (4 * q4)) & 15u);
+                const uint32_t b1o = spread4((X1O >> (4 * q4)) & 15u), b2o = spread4((X2OD >> (4 * q4)) & 15u), b3o = spread4((X3O >> (4 * q4)) & 15u);
+                cw[0][q4] = pk_mul_u16(spb[0][q4] & b1, kpq);
+                cw[1][q4] = pk_mad_u16(spb[1][q4] & b2, kp, pk_mul_u16(spb[1][q4] & b3, kq));
+                cw[2][q4] = pk_mul_u16((spb[2][q4] & b3) + (spb[2][q4] & b2), ks);
+                cw[3][q4] = pk_mad_u16(spb[3][q4] & b3, kp, pk_mul_u16(spb[3][q4] & b2, kq));
+                dw[0][q4] = pk_mul_u16(spb[0][q4] & b1o, kpqo);
+                dw[1][q4] = pk_mad_u16(spb[1][q4] & b2o, kpo, pk_mul_u16(spb[1][q4] & b3o, kqo));
+                dw[2][q4] = pk_mul_u16((spb[2][q4] & b3o) + (spb[2][q4] & b2o), kso);
+                dw[3][q4] = pk_mad_u16(spb[3][q4] & b3o, kpo, pk_mul_u16(spb[3][q4] & b2o, kqo));
+            }
+        }
+#else
+        {
+            uint32_t pb[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < R + D; ++i)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) pb[d] |= ((pbyte[i] >> d) & 1u) << i;
+            const TileFlags f = tile_flags<D, R>(t, h, w, lane);
+            DirMasks m[4];
+            dir_masks<D>(f, pb, m);
+#pragma unroll
+            for (int dir = 0; dir < 4; ++dir)
+#pragma unroll
+                for (int q4 = 0; q4 < NQ; ++q4) {
+                    cw[dir][q4] = spread4((m[dir].mA >> (4 * q4)) & 15u) + spread4((m[dir].mB >> (4 * q4)) & 15u);
+                    dw[dir][q4] = spread4((m[dir].nA >> (4 * q4)) & 15u) + spread4((m[dir].nB >> (4 * q4)) & 15u);
+                }
+        }
+#endif
         BXI_TW(1, tix, 3);
         // the first look at sum W (and, single-launch form, at the band flags of the rows this tile adds onto) goes out BEFORE the pair loop and is
         // evaluated behind it: the round trip hides under ~2 us of arithmetic; what is not there yet is polled for as before
@@ -1653,11 +1776,24 @@ __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, c
         mine = 0;
         int arrived = 0;
         bool flt = false;
-        for (int i = threadIdx.x; i < N * kAcc2Split; i += 256) {
-            const unsigned long long x = __hip_atomic_load(ws.acc2 + (size_t)i * kAcc2Stride, BXI_RLX, BXI_AGENT);
-            arrived += (int)(x >> 52);
-            mine += (long long)(x & ((1ull << 52) - 1ull)) - ((long long)(x >> 52) << 24);       // the +1 per tile
-            flt |= (x & (3ull << 50)) != 0ull;                                                   // a tile wave's wait ran out
+        // (the words tile waves arrive on: those of instances 0 .. min(N, 64) - 1 -- tile_wave_arrives --, at most two per thread, asked for in one
+        // round trip.  Rounds 3-6 walked all N x 8 words with one atomic load each: four dependent trips per poll at 128 instances, two of them for
+        // words nobody arrives on.)
+        {
+            const int n_words = (N < 64 ? N : 64) * kAcc2Split;
+            const int i0 = threadIdx.x, i1 = threadIdx.x + 256;
+            unsigned long long x0 = 0ull, x1 = 0ull;
+            if (n_words > 256) load8_past_x2(ws.acc2 + (size_t)(i0 < n_words ? i0 : 0) * kAcc2Stride, ws.acc2 + (size_t)(i1 < n_words ? i1 : 0) * kAcc2Stride, x0, x1);
+            else x0 = __hip_atomic_load(ws.acc2 + (size_t)(i0 < n_words ? i0 : 0) * kAcc2Stride, BXI_RLX, BXI_AGENT);
+            if (i0 >= n_words) x0 = 0ull;
+            if (i1 >= n_words) x1 = 0ull;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const unsigned long long x = k ? x1 : x0;
+                arrived += (int)(x >> 52);
+                mine += (long long)(x & ((1ull << 52) - 1ull)) - ((long long)(x >> 52) << 24);       // the +1 per tile
+                flt |= (x & (3ull << 50)) != 0ull;                                                   // a tile wave's wait ran out
+            }
         }
         // the fault word (waves that gave up WITHOUT arriving set it; the finisher then runs out itself) rides in the same round
         if (threadIdx.x == 0) fault_seen |= __hip_atomic_load(ws.fault, BXI_RLX, BXI_AGENT);
@@ -1714,9 +1850,29 @@ __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& v
     __builtin_amdgcn_s_setprio(2);                                     // the launch ends on the tile waves, not on the leaders next to them
     BXI_TW(1, wid, 0);
     int4 e0, e1 = make_int4(0, 0, 0, 0), eN = make_int4(0, 0, 0, 0);
-    bool ok = tab_entry<ONE>(ws, lane, lane <= N, spin_limit, e0);
-    if (N >= 64) ok = ok && tab_entry<ONE>(ws, N, true, spin_limit, eN);
-    if (N > 64) ok = ok && tab_entry<ONE>(ws, 64 + lane, 64 + lane < N, spin_limit, e1);      // (with the two above: one round trip in the two-launch form)
+    bool ok;
+    if (ONE && N >= 64) {
+        // single-launch form, 64 instances or more: entries 0..63, N and 64..127 polled for in ONE round trip (three tab_entry calls are three
+        // statements with a wait each: three dependent trips in front of every tile of the long form)
+        ok = false;
+        const bool want1 = 64 + lane < N;
+        for (int spins = 0; spins <= spin_limit; ++spins) {
+            u4v v0, vN, v1;
+            load16_past_x3(ws.tab + lane, ws.tab + N, ws.tab + (want1 ? 64 + lane : N), v0, vN, v1);
+            if (__all(v0.w == ws.ep && vN.w == ws.ep && v1.w == ws.ep)) {
+                e0 = make_int4((int)v0.x, (int)v0.y, (int)v0.z, (int)v0.w); eN = make_int4((int)vN.x, (int)vN.y, (int)vN.z, (int)vN.w);
+                if (want1) e1 = make_int4((int)v1.x, (int)v1.y, (int)v1.z, (int)v1.w);
+                ok = true;
+                BXI_WL(1, spins);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(BXI_SLEEP_TAB);
+        }
+    } else {
+        ok = tab_entry<ONE>(ws, lane, lane <= N, spin_limit, e0);
+        if (N >= 64) ok = ok && tab_entry<ONE>(ws, N, true, spin_limit, eN);
+        if (N > 64) ok = ok && tab_entry<ONE>(ws, 64 + lane, 64 + lane < N, spin_limit, e1);      // (with the two above: one round trip in the two-launch form)
+    }
     // (a wave whose table wait ran out still arrives, saying so: the finisher then ends at once, loud, instead of running out itself.
     // The table's own zeroing of the arrival words precedes its entries, so without an entry the arrival may be wiped -- then the finisher
     // does run out: as loud)
@@ -1804,11 +1960,11 @@ __global__ __launch_bounds__(256, (R == 4 ? (D <= 2 ? 4 : 3) : (D <= 2 ? 3 : 2))
     }
     const Ws ws = with_tag(ws_in);
     const float upp = up_prj ? *up_prj : 1.f, upw = up_pw ? *up_pw : 1.f;
-#ifndef BXI_PAIR_TILES_FIRST
-#define BXI_PAIR_TILES_FIRST 0
-#endif
+    // (grid order [predicate][reducer][leaders][tiles][finisher].  Measured and dropped -- profiles/NOTES.md R6-10 --: the tile workgroups AHEAD of the leaders,
+    // so that 128 more of them are resident from the start: 30.7 vs 28.4 us at 96 instances, 35.0 vs 33.0 at 128 -- the leaders then run last and the
+    // finisher waits for their dice words)
     const int n_tb = (int)gridDim.x - 2 - N - n_pb;
-    const int lead0 = BXI_PAIR_TILES_FIRST ? n_pb + 1 + n_tb : n_pb + 1, tile0 = BXI_PAIR_TILES_FIRST ? n_pb + 1 : n_pb + 1 + N;
+    const int lead0 = n_pb + 1, tile0 = n_pb + 1 + N;
     if (blk == n_pb) {                                          // ---- the reducer
         reducer_role<false>(ws, zero_bit, n_pb > 0 ? n_items : 0, spin_limit);      // (no predicate workgroups here: sum W is in memory already)
     } else if (blk == (int)gridDim.x - 1) {
@@ -2465,10 +2621,7 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     const int cus2 = stream_cus(s, device_cus());                      // a CU-masked stream has fewer
     const int slots = occ * cus2 > 64 ? occ * cus2 : 64;
     int n_pb = ready ? 0 : (n_items + kWaves - 1) / kWaves;  // (targets ready: the image side is in memory at this kernel's start)
-#ifndef BXI_PB_CAP_8THS
-#define BXI_PB_CAP_8THS 4
-#endif
-    if (n_pb > slots * BXI_PB_CAP_8THS / 8) n_pb = slots * BXI_PB_CAP_8THS / 8;
+    if (n_pb > slots / 2) n_pb = slots / 2;     // (5 / 8 of the slots -- every item a wave of its own at 2 x 800 x 1024 and three per CU --: no difference, R6-10)
     // (the predicate workgroups are short-lived: the tile workgroups behind them in the grid take their slots as they leave, so the
     // tile workgroups are sized for the slots, not for what the predicate workgroups leave over -- BXI_PAIR_TB_FULL=0: the round-3 sizing)
     const int env_tb_full = BXI_KNOB("BXI_PAIR_TB_FULL", 1);

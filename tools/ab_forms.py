@@ -45,7 +45,7 @@ def main():
              'ready': L.EVAL_TARGETS_READY, 'ready_two': L.EVAL_TARGETS_READY | L.EVAL_TWO_LAUNCHES,
              'ready_two_r4': L.EVAL_TARGETS_READY | L.EVAL_TWO_LAUNCHES | L.EVAL_TILE_ROWS_4, 'targets_only': -1,
              'ready_single': L.EVAL_TARGETS_READY | L.EVAL_SINGLE_LAUNCH, 'ready_single_nostay': L.EVAL_TARGETS_READY | L.EVAL_SINGLE_LAUNCH | L.EVAL_SHARED_DEVICE,
-             'single_any': L.EVAL_SINGLE_LAUNCH,
+             'single_any': L.EVAL_SINGLE_LAUNCH, 'nostay': L.EVAL_SHARED_DEVICE,
              'ready_long': L.EVAL_TARGETS_READY | L.EVAL_SINGLE_LAUNCH | L.EVAL_TILE_ROWS_8}
     if args.forms:
         forms = {k: v for k, v in forms.items() if k in args.forms.split(',')}
