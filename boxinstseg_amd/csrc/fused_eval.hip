@@ -1193,6 +1193,8 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     load_plane<D, R>(Lg, t, h, w, lane, x);
     // targets ready: the predicate words are an earlier launch's -- asked for WITH the logits (one round trip instead of two; the per-pixel
     // arithmetic below runs while they fly), looked at once where the other forms start polling
+    // (Measured and dropped, R6-13: the same early look in the two-launch form, where most tile waves get their slots behind the predicate workgroups --
+    // 31.2 vs 30.6 us at 128 instances, 23.4 vs 22.8 with 4-row tiles at 64: the waves that come too early pay ten wasted loads and poll anyway.)
     uint32_t pearly[R + D];
     const bool early = ws.pred_any != 0u && zero_bit == 0;             // wave-uniform
     if (early) {
@@ -2513,7 +2515,9 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
         // says so (BXI_EVAL_SHARED_DEVICE; boxinstseg_amd/functional.py sets it once a second stream has been
         // seen on the device).  A launch that is being captured into a graph may be replayed next to anything: no staying-on either.
         const int env_merge = BXI_KNOB("BXI_ONE_MERGE", 1);
-        const int merge = env_merge && !long_form && one_fits && !(flags & kFlagShared) && !stream_is_capturing(s) ? 1 : 0;
+        // ... and only while they are at most a QUARTER of the slots: at 64 instances (448 of 1024) the staying-on costs 0.3 us (21.65 vs 21.35 us, their
+        // slots are what the pool workgroups -- three items each then -- are short of); at 32 instances it is worth 0.05 us (R6-12)
+        const int merge = env_merge && !long_form && one_fits && 4 * n_stream <= slots && !(flags & kFlagShared) && !stream_is_capturing(s) ? 1 : 0;
         if (merge) n_tb = n_tb > n_stream ? n_tb - n_stream : 0;
         size_t lds = sizeof(double) * (256 + 3 * 64) + sizeof(int) * 4 * 3 * 64;
         if (lds < 8 * (size_t)kWaves * a.w) lds = 8 * (size_t)kWaves * a.w;
