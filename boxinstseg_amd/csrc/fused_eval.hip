@@ -798,58 +798,17 @@ struct Tile {                                   // wave-uniform (SGPRs)
     int hc1;                                    // end column of the instance's tile hull (= dilated box)
 };
 
-struct TileFlags {   // bit j = data row j (map row tile_r0 - D + j) of this lane's column; R = the lane D to the right
-    uint32_t ib, vd, ow, ibR, vdR, owR;       // in GT box ; valid image pixel ; owned by this tile
-};
-
 __device__ __forceinline__ uint32_t row_bits(int lo, int hi, int base, int n) {   // bits j in [0,n) with lo <= base + j < hi
     const int a = max(lo - base, 0), b = min(hi - base, n);
     if (b <= a) return 0u;
     return ((1u << b) - 1u) & ~((1u << a) - 1u);              // n <= 16
 }
 
-template <int D, int R>
-__device__ __forceinline__ TileFlags tile_flags(const Tile& t, int h, int w, int lane) {
-    constexpr int RD = TG<D, R>::RD;
-    const int base = t.tile_r0 - D;
-    const int cl = t.tile_c0 - D + lane;
-    const uint32_t rows_box = row_bits(t.r0, t.r1, base, RD);
-    const uint32_t rows_val = row_bits(0, min(h, t.vrow), base, RD);
-    const uint32_t rows_own = row_bits(t.tile_r0, min(t.tile_r0 + R, h), base, RD);
-    const int cv = min(w, t.vcol);
-    TileFlags f;
-    {
-        const int c = cl, ln = lane;
-        f.ib = (c >= t.c0 && c < t.c1) ? rows_box : 0u;
-        f.vd = (c >= 0 && c < cv) ? rows_val : 0u;
-        f.ow = (ln >= D && ln < 64 - D && c < t.hc1) ? rows_own : 0u;
-    }
-    {
-        const int c = cl + D, ln = lane + D;
-        const bool in = ln < 64;      // lanes without a right neighbour: every pair weight 0 (they receive some other lane's data)
-        f.ibR = (in && c >= t.c0 && c < t.c1) ? rows_box : 0u;
-        f.vdR = (in && c >= 0 && c < cv) ? rows_val : 0u;
-        f.owR = (in && ln >= D && ln < 64 - D && c < t.hc1) ? rows_own : 0u;
-    }
-    return f;
-}
-
 // The four pair directions of a step i (j = i + D), every one between this lane and the lane D to its right or itself, so
 // that only right-neighbour values are ever fetched:
 //   0: A = (i, l)  B = (i, l + D)   |   1: A = (j, l)  B = (i, l + D)   |   2: A = (i, l)  B = (j, l)   |   3: A = (i, l)  B = (j, l + D)
-// masks, bit i = the pair of step i:  W[k, A] = mA, W[7 - k, B] = mB, and the same restricted to pixels this tile owns;
-// `pb` = the colour predicates of the steps (launch 1's bytes, transposed).
-struct DirMasks { uint32_t mA, mB, nA, nB; };
-template <int D>
-__device__ __forceinline__ void dir_masks(const TileFlags& f, const uint32_t (&pb)[4], DirMasks (&m)[4]) {
-    m[0].mA = f.ib & f.vdR;          m[0].mB = f.ibR & f.vd;          m[0].nA = m[0].mA & f.ow;        m[0].nB = m[0].mB & f.owR;
-    m[1].mA = (f.ib >> D) & f.vdR;   m[1].mB = f.ibR & (f.vd >> D);   m[1].nA = m[1].mA & (f.ow >> D); m[1].nB = m[1].mB & f.owR;
-    m[2].mA = f.ib & (f.vd >> D);    m[2].mB = (f.ib >> D) & f.vd;    m[2].nA = m[2].mA & f.ow;        m[2].nB = m[2].mB & (f.ow >> D);
-    m[3].mA = f.ib & (f.vdR >> D);   m[3].mB = (f.ibR >> D) & f.vd;   m[3].nA = m[3].mA & f.ow;        m[3].nB = m[3].mB & (f.owR >> D);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) { m[d].mA &= pb[d]; m[d].mB &= pb[d]; m[d].nA &= pb[d]; m[d].nB &= pb[d]; }
-}
-
+// Pair weights, per step i:  W[k, A] and W[7 - k, B] -- [A in the GT box][B a valid image pixel][colour predicate of the pair] and the mirror --,
+// and the same restricted to pixels this tile owns (math_tile builds them as bytes).
 __device__ __forceinline__ uint32_t spread4(uint32_t x4) { return (x4 * 0x00204081u) & 0x01010101u; }   // bits 0..3 -> bytes 0..3
 // the two 16-bit halves of a word times those of another (v_pk_mul_lo_u16 / v_pk_mad_u16: full rate, where a 32-bit multiply is a quarter-rate
 // instruction and the 24-bit one loses the fourth byte)
@@ -858,9 +817,6 @@ __device__ __forceinline__ uint32_t pk_mul_u16(uint32_t a, uint32_t b) { return 
 __device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_bit_cast(uint32_t, (us2v)(__builtin_bit_cast(us2v, a) * __builtin_bit_cast(us2v, b) + __builtin_bit_cast(us2v, c)));
 }
-#ifndef BXI_MASKS_V2
-#define BXI_MASKS_V2 1
-#endif
 
 template <int D>
 __device__ __forceinline__ float lane_plus(float v) {
@@ -964,9 +920,6 @@ __device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
     return v;
 }
-#ifndef BXI_PRED_SCAN
-#define BXI_PRED_SCAN 1
-#endif
 struct ValidCells { int vrow[BXI_MAX_IMAGES], vcol[BXI_MAX_IMAGES]; };   // per image: valid(q) <=> row(q) < vrow && col(q) < vcol (host: :1354-1369,:1405)
 // PER_BOX (bxi_boxinst_targets_f32's second launch; never ONE): the rectangles are the GT BOXES' (ws.boxtab, n_ent of them) instead of the
 // instances', and what a box containing a site adds is kept PER BOX (`boxacc`, LDS of the workgroup, one counter per box) instead of
@@ -1016,7 +969,7 @@ __device__ __forceinline__ int pred_item(int h, int w, int n_ent, const ValidCel
         rect = lane < n_ent ? (PER_BOX ? ws.boxtab()[lane] : ws.tab[lane]) : make_int4(-1, 0, 0, 0);
         // (entries 64..127 ride with the same round trip: a load per 64-entry chunk BEHIND the first chunk's arithmetic was a second dependent trip
         // in every item of an evaluation of more than 64 instances)
-        if (BXI_PRED_SCAN && n_ent > 64) rect1 = 64 + lane < n_ent ? (PER_BOX ? ws.boxtab()[64 + lane] : ws.tab[64 + lane]) : make_int4(-1, 0, 0, 0);
+        if (n_ent > 64) rect1 = 64 + lane < n_ent ? (PER_BOX ? ws.boxtab()[64 + lane] : ws.tab[64 + lane]) : make_int4(-1, 0, 0, 0);
         if (untagged) ws.ep = next_tag((unsigned int)__builtin_amdgcn_readfirstlane((int)ew));
     }
     float nL = lane_plus_n(o0.x, D), nA = lane_plus_n(o0.y, D), nB = lane_plus_n(o0.z, D);
@@ -1034,7 +987,6 @@ __device__ __forceinline__ int pred_item(int h, int w, int n_ent, const ValidCel
     // what a box containing the site adds:  (r, c)  (r, c+D)  (r+D, c)  (r+D, c+D)
     const int s00 = (p0 && v0n) + (p2 && vD0) + (p3 && vDn), s0n = (p0 && v00) + (p1 && vD0), sD0 = (p1 && v0n) + (p2 && v00), sDn = (p3 && v00) ? 1 : 0;
     int cnt = 0;
-#if BXI_PRED_SCAN
     // LANE = RECTANGLE: what rectangle [r0, r1) x [c0, c1) collects from this row segment is a sum of the four site values over a RANGE of lanes
     //   rows r:      s00 over lanes [c0 - base, c1 - base)  +  s0n over lanes [c0 - D - base, c1 - D - base)        (base = the segment's first column)
     //   rows r + D:  sD0 over the first range               +  sDn over the second
@@ -1065,32 +1017,6 @@ __device__ __forceinline__ int pred_item(int h, int w, int n_ent, const ValidCel
         if (PER_BOX) { if (add) atomicAdd(&boxacc[m0 + lane], add); }       // LDS; flushed once per workgroup (targets_pred_kernel)
         else cnt += add;
     }
-#else
-    for (int m0 = 0; m0 < n_ent; m0 += 64) {
-        if (m0) {
-            if (PER_BOX) rect = m0 + lane < n_ent ? ws.boxtab()[m0 + lane] : make_int4(-1, 0, 0, 0);
-            else if (!tab_entry<ONE>(ws, m0 + lane, m0 + lane < n_ent, spin_limit, rect)) { ok = false; return 0; }
-            if (m0 + lane >= n_ent) rect = make_int4(-1, 0, 0, 0);
-        }
-        // the instances of this image whose rows reach r or r + D: usually a handful
-        const int q0 = rect.y & 0xffff, q1 = (int)((unsigned int)rect.y >> 16);
-        unsigned long long mask = __ballot(m0 + lane < n_ent && (int)((unsigned int)rect.x >> 24) == b && ((r >= q0 && r < q1) || (r + D >= q0 && r + D < q1)));
-        while (mask) {
-            const int n = __ffsll((long long)mask) - 1;
-            mask &= mask - 1ull;
-            const int ry = __builtin_amdgcn_readlane(rect.y, n), rz = __builtin_amdgcn_readlane(rect.z, n);
-            const int r0 = ry & 0xffff, r1 = (int)((unsigned int)ry >> 16), c0 = rz & 0xffff, c1 = (int)((unsigned int)rz >> 16);
-            const bool rr = r >= r0 && r < r1, rD2 = r + D >= r0 && r + D < r1;
-            const bool c_in = c >= c0 && c < c1, n_in = cn >= c0 && cn < c1;
-            const int add = (rr && c_in ? s00 : 0) + (rr && n_in ? s0n : 0) + (rD2 && c_in ? sD0 : 0) + (rD2 && n_in ? sDn : 0);
-            if (PER_BOX) {
-                const int tot = wave_total_i32(add);
-                if (lane == 0 && tot) atomicAdd(&boxacc[m0 + n], tot);       // LDS; flushed once per workgroup (targets_pred_kernel)
-            } else
-                cnt += add;
-        }
-    }
-#endif
     return cnt;
 }
 
@@ -1143,9 +1069,6 @@ __device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, cons
 // predicate waves precede the tile waves in the grid and never wait; by the time a tile wave asks they are normally done.
 // A tile wave's own few predicate words (written through by the predicate waves, which precede it in the grid), read past the
 // caches until every one carries this evaluation's tag; usually they are there at once.
-#ifndef BXI_PW_BATCH
-#define BXI_PW_BATCH 1
-#endif
 template <int D, int R>
 __device__ __forceinline__ bool pred_words(const Ws& ws, const Tile& t, int h, int w, int c, int spin_limit, uint32_t (&pbyte)[R + D]) {
     const unsigned int* pp = ws.pred + (int64_t)t.img * h * w;            // scalar base + 32-bit byte offsets (one plane < 2^31 bytes)
@@ -1157,17 +1080,9 @@ __device__ __forceinline__ bool pred_words(const Ws& ws, const Tile& t, int h, i
     bool ok = false;
     for (int spins = 0; spins <= spin_limit; ++spins) {
         bool all = true;
-#if BXI_PW_BATCH
         load_words_past<R + D>(pp, off, pbyte);
 #pragma unroll
         for (int i = 0; i < R + D; ++i) all = all && (pbyte[i] >> 4) == want;
-#else
-#pragma unroll
-        for (int i = 0; i < R + D; ++i) {
-            pbyte[i] = __hip_atomic_load(pp + off[i] / 4u, BXI_RLX, BXI_AGENT);
-            all = all && (pbyte[i] >> 4) == want;
-        }
-#endif
         if (__all(all)) { ok = true; BXI_WL(4, spins); break; }
         if (ws.pred_any) break;        // targets ready: the words are an EARLIER launch's -- what is not there now will not come (foreign or overwritten targets: loud at once, not after kSpinLimit polls)
         __builtin_amdgcn_s_sleep(BXI_SLEEP_WORDS);
@@ -1175,9 +1090,6 @@ __device__ __forceinline__ bool pred_words(const Ws& ws, const Tile& t, int h, i
     return ok;        // false: the caller's arrival says so, and the finisher turns both losses into NaN
 }
 
-#ifndef BXI_SUMW_EARLY
-#define BXI_SUMW_EARLY 1
-#endif
 template <int D, int R, bool ONE>
 __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const Tile& t, float upw_warm, float n2max, int zero_bit, int n_items,
                                           int spin_limit, float& scale, bool& have_scale, float* __restrict__ g_logits, float* gbuf /* LDS [R + 1][64] of this wave */,
@@ -1242,7 +1154,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     const bool slow = zero_bit != 0 || __any(sat);
     bool bad = false;          // a bounded wait of this wave ran out (never expected): its arrival carries the fact to the finisher
     const int band0 = t.tile_r0 / kSBlk, band1 = (min(t.tile_r0 + R, h) - 1) / kSBlk;
-    const bool look_early = BXI_SUMW_EARLY && !slow && (!have_scale || (ONE && g_logits));       // wave-uniform
+    const bool look_early = !slow && (!have_scale || (ONE && g_logits));       // wave-uniform
     unsigned long long sw_early = 0ull;
     unsigned int f0e = 0u, f1e = 0u;
     BXI_TW(1, tix, 2);
@@ -1268,12 +1180,11 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
         // pixels this tile owns (loss sum)
         constexpr int NQ = (R + D + 3) / 4;
         uint32_t cw[4][NQ], dw[4][NQ];
-#if BXI_MASKS_V2
         // Every mask of dir_masks is (a 0/1 of the LANE: its column in the box / valid / owned) x (a row range of the TILE: wave-uniform) x (the colour
         // predicate), so the weights are made in the byte domain at once: the predicate nibbles of four rows packed into a word (bytes = rows), one
         // shift + AND per direction, an AND with the row range's byte mask (scalar registers, made on the scalar unit) and a packed 16-bit multiply by the
         // lane's 0 / 1 / 2.  ~160 vector instructions per tile where the bit-mask form (transpose to row bits, AND the flag words, spread nibble by
-        // nibble: tile_flags / dir_masks / spread4, kept below for the record) took ~420 -- next to ~500 of the pair loop itself.  The same bytes.
+        // nibble: rounds 3-6, ~300) stood next to ~500 of the pair loop itself.  The same bytes.  profiles/NOTES.md R6-11
         {
             uint32_t spb[4][NQ];
 #pragma unroll
@@ -1312,25 +1223,6 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
                 dw[3][q4] = pk_mad_u16(spb[3][q4] & b3o, kpo, pk_mul_u16(spb[3][q4] & b2o, kqo));
             }
         }
-#else
-        {
-            uint32_t pb[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int i = 0; i < R + D; ++i)
-#pragma unroll
-                for (int d = 0; d < 4; ++d) pb[d] |= ((pbyte[i] >> d) & 1u) << i;
-            const TileFlags f = tile_flags<D, R>(t, h, w, lane);
-            DirMasks m[4];
-            dir_masks<D>(f, pb, m);
-#pragma unroll
-            for (int dir = 0; dir < 4; ++dir)
-#pragma unroll
-                for (int q4 = 0; q4 < NQ; ++q4) {
-                    cw[dir][q4] = spread4((m[dir].mA >> (4 * q4)) & 15u) + spread4((m[dir].mB >> (4 * q4)) & 15u);
-                    dw[dir][q4] = spread4((m[dir].nA >> (4 * q4)) & 15u) + spread4((m[dir].nB >> (4 * q4)) & 15u);
-                }
-        }
-#endif
         BXI_TW(1, tix, 3);
         // the first look at sum W (and, single-launch form, at the band flags of the rows this tile adds onto) goes out BEFORE the pair loop and is
         // evaluated behind it: the round trip hides under ~2 us of arithmetic; what is not there yet is polled for as before
