@@ -1069,7 +1069,10 @@ __device__ __forceinline__ double total_weight_all_pairs(const InstArgs& a, cons
 // predicate waves precede the tile waves in the grid and never wait; by the time a tile wave asks they are normally done.
 // A tile wave's own few predicate words (written through by the predicate waves, which precede it in the grid), read past the
 // caches until every one carries this evaluation's tag; usually they are there at once.
-template <int D, int R>
+// BATCH: the words in one asm statement (one round trip).  Not in the short single-launch kernels (eval1_kernel<D, 4, *>): there a tile wave is resident
+// before the predicate waves start and polls anyway -- the trips hide in that wait (17.15 us per evaluation either way, R6-11) --, and the statement's
+// twelve early-clobber outputs leave the kernel with a 36-byte private segment that nothing ever touches.
+template <int D, int R, bool BATCH>
 __device__ __forceinline__ bool pred_words(const Ws& ws, const Tile& t, int h, int w, int c, int spin_limit, uint32_t (&pbyte)[R + D]) {
     const unsigned int* pp = ws.pred + (int64_t)t.img * h * w;            // scalar base + 32-bit byte offsets (one plane < 2^31 bytes)
     const uint32_t cc = (uint32_t)min(max(c, 0), w - 1);
@@ -1080,9 +1083,17 @@ __device__ __forceinline__ bool pred_words(const Ws& ws, const Tile& t, int h, i
     bool ok = false;
     for (int spins = 0; spins <= spin_limit; ++spins) {
         bool all = true;
-        load_words_past<R + D>(pp, off, pbyte);
+        if constexpr (BATCH) {
+            load_words_past<R + D>(pp, off, pbyte);
 #pragma unroll
-        for (int i = 0; i < R + D; ++i) all = all && (pbyte[i] >> 4) == want;
+            for (int i = 0; i < R + D; ++i) all = all && (pbyte[i] >> 4) == want;
+        } else {
+#pragma unroll
+            for (int i = 0; i < R + D; ++i) {
+                pbyte[i] = __hip_atomic_load(pp + off[i] / 4u, BXI_RLX, BXI_AGENT);
+                all = all && (pbyte[i] >> 4) == want;
+            }
+        }
         if (__all(all)) { ok = true; BXI_WL(4, spins); break; }
         if (ws.pred_any) break;        // targets ready: the words are an EARLIER launch's -- what is not there now will not come (foreign or overwritten targets: loud at once, not after kSpinLimit polls)
         __builtin_amdgcn_s_sleep(BXI_SLEEP_WORDS);
@@ -1166,7 +1177,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
 #pragma unroll
             for (int i = 0; i < R + D; ++i) { pbyte[i] = pearly[i]; all = all && (pbyte[i] >> 4) == 0u; }      // (words an earlier launch left carry tag 0)
             bad |= !__all(all);
-        } else bad |= !pred_words<D, R>(ws, t, h, w, c, spin_limit, pbyte);
+        } else bad |= !pred_words<D, R, (!ONE || R == 8)>(ws, t, h, w, c, spin_limit, pbyte);
         float gq[PK ? 1 : RD], gR[PK ? 1 : RD];      // gradient of this lane's pixels / of lane + D's
         v2 gq2[PK ? RD / 2 : 1], gR2[PK ? RD / 2 : 1];
         if constexpr (PK) {
@@ -1296,7 +1307,7 @@ __device__ __forceinline__ void math_tile(const InstArgs& a, const Ws& ws, const
     } else {         // wave-uniform; rare
         if (ONE) {   // single-launch form: the tile's predicate words vouch for the Lab pixels the log-space path reads
             uint32_t pbyte[R + D];
-            bad |= !pred_words<D, R>(ws, t, h, w, c, spin_limit, pbyte);
+            bad |= !pred_words<D, R, (!ONE || R == 8)>(ws, t, h, w, c, spin_limit, pbyte);
         }
         slow_tile<D, R, ONE>(Lg, ws.lab4, t, n2max, zero_bit, h, w, lane, gbuf);
         num = gbuf[R * 64 + lane];
@@ -1745,8 +1756,8 @@ __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& v
     BXI_TW(1, wid, 0);
     int4 e0, e1 = make_int4(0, 0, 0, 0), eN = make_int4(0, 0, 0, 0);
     bool ok;
-    if (ONE && N >= 64) {
-        // single-launch form, 64 instances or more: entries 0..63, N and 64..127 polled for in ONE round trip (three tab_entry calls are three
+    if (ONE && R == 8 && N >= 64) {
+        // the long single-launch form (64 instances or more; the short form runs 64..73 instances with the three calls below: see pred_words): entries 0..63, N and 64..127 polled for in ONE round trip (three tab_entry calls are three
         // statements with a wait each: three dependent trips in front of every tile of the long form)
         ok = false;
         const bool want1 = 64 + lane < N;
