@@ -2385,8 +2385,11 @@ int launch_fused_eval(const bxi_image_batch* batch, float color_thresh, const bx
     // 14.85 vs 14.65 at 32 instances, 31.9 vs 31.0 at 128: the tile role is bound by its arithmetic and memory pipeline, not by that hop.)
     // (the long form exists with the targets ready only: with the image side in the launch it measured 36.9 vs 37.1 us for two launches at 128 instances,
     // 32.3 vs 31.6 at 96 -- no gain -- and left the library with ABI 7: BXI_EVAL_SINGLE_LAUNCH | BXI_EVAL_TILE_ROWS_8 without targets runs two launches)
+    // (again in round 6, after the second launch had lost 6 us: the long form with the image side 31.0 vs 30.6 us at 128 instances, 27.8 vs 27.2 at 96 -- R6-14)
     const bool long_form = R == 8 && dil <= 2 && ready && ((flags & kFlagSingle) || (a.N >= BXI_KNOB("BXI_LONG_FROM", kLongFrom) && whole_device && !(flags & kFlagShared)));
-    const bool short_ok = one_fits && !(ready && BXI_KNOB("BXI_READY_TWO", 0));
+    // (targets ready: the short single launch while its stream workgroups are a quarter of the slots -- 14.1 vs 14.4-14.9 us for two launches at 32
+    // instances; at 64 two launches take 18.3 against 18.7 us, and from kLongFrom on the long form 21.6 against 23.9: R6-14)
+    const bool short_ok = one_fits && !(ready && (BXI_KNOB("BXI_READY_TWO", 0) || 4 * (int64_t)a.N * ((a.h + kSBlk - 1) / kSBlk) > one_slots));
     if (env_one && !(flags & kFlagTwo) && (short_ok || env_one == 2 || (flags & kFlagSingle) || long_form) && !head && pooled_in_launch &&
         (R == 4 || long_form) && dil <= 2 && !pr.zero_bit) {
         const int env_one_pool = BXI_KNOB("BXI_ONE_POOL_WGS", 0);

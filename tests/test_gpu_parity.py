@@ -683,6 +683,25 @@ def test_loss_many_instances(dev):
     _check_cfg(d, dev)
 
 
+def test_loss_many_boxes_per_image(dev):
+    """140 GT boxes in two images (70 each), one instance per box: the predicate waves take rectangles 64 at a time with lane = rectangle --
+    chunk 0 with the Lab records, entries 64..127 in the same round trip, 128.. by a load of their own -- for the instances' table (the
+    evaluation that computes its own image side) and for the GT boxes' table (bxi_boxinst_targets_f32: per-box counts by one LDS add per lane).
+    Against the C oracle, and the targets-ahead pair bit for bit against the un-split evaluation, in the default and the two-launch form; the
+    finisher polls 64 x 8 arrival words, two per thread."""
+    from boxinstseg_amd import functional as Fh
+    d = synthetic.make_batch(B=2, H=128, W=256, boxes_per_img=70, inst_per_box=1, seed=812, min_box=16, max_box=90)
+    assert d['N'] == 140 and d['G'] == 140
+    _check_cfg(d, dev)
+    for form in (0, 2):
+        with Fh.eval_flags(form):
+            want = hip_loss(d, dev)
+            got = _loss_with_targets(d, dev)
+        assert Fh.last_eval_status()[0] == 0
+        assert got[0] == want[0] and got[1] == want[1], (form, got[:2], want[:2])
+        assert np.array_equal(got[2], want[2]), form
+
+
 @pytest.mark.parametrize('form', ['single_launch', 'single_launch_shared_device', 'two_launches', 'two_launches_8_row_tiles', 'two_launches_4_row_tiles'])
 def test_loss_every_form_against_the_oracle(dev, form):
     """Each form of the evaluation (the BXI_EVAL_* flags of the call) against the C oracle: the single launch also where the library
