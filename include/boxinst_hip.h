@@ -256,11 +256,11 @@ int bxi_boxinst_targets_f32(const bxi_image_batch* batch_host, const float* cons
 /* `flags` of the two evaluation entry points.  The forms give the same bits (tests run them against each other).
  * What the library runs by itself (flags == 0), at dilation <= 2 on a stride-4 aligned canvas:
  *   - ONE launch (4-row tiles, four workgroups per CU) while its stream workgroups -- instances x ceil(h / 32) -- fill at most half the GPU
- *     (up to 73 instances of 200 x 256 maps);
+ *     (up to 73 instances of 200 x 256 maps); while they fill at most a quarter (36 instances) they stay on as the launch's first tile workgroups;
  *   - beyond that TWO launches (table + logit stream + image pooling | predicates + leaders + tiles + finisher): 4-row tiles up to 95
  *     instances, 8-row tiles from 96 on.  Every in-kernel wait of this form is for a workgroup EARLIER in its grid;
- *   - with BXI_EVAL_TARGETS_READY the same two shapes without the image side, and from 96 instances on ONE launch with 8-row tiles
- *     (three workgroups per CU, nobody waits for a later workgroup).
+ *   - with BXI_EVAL_TARGETS_READY the same two shapes without the image side (the one launch up to a quarter of the GPU: 36 instances), and
+ *     from 96 instances on ONE launch with 8-row tiles (three workgroups per CU, nobody waits for a later workgroup).
  * Other dilations / canvases: two launches (+ the generic pooling launches).  ABI 7 removed the forms that lost their measurements
  * (BXI_EVAL_PRED_IN_PREP, the 8-row single launch with the image side in it) and folded BXI_EVAL_NO_STAY_ON into BXI_EVAL_SHARED_DEVICE. */
 #define BXI_EVAL_SINGLE_LAUNCH   1u   /* the single-launch form wherever it is built, also where the library would not choose it (its stream
