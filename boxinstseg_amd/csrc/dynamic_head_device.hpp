@@ -54,7 +54,11 @@ __device__ __forceinline__ float mlp_forward(const float* __restrict__ wts, cons
     float t[kDC];
 #pragma unroll
     for (int o = 0; o < kDC; ++o) {
-        if (o % 4 == 0) BXI_SEGMENT();
+        // (a fence in front of EVERY output channel: CIN + 1 weights in flight at a time.  With a fence per four channels the 4 x (CIN + 1) = 76 scalar
+        // registers of a segment -- next to the ~40 the instance loop keeps live -- exceeded the file: the compiler parked freshly LOADED weights in VGPR
+        // lanes and read them back, 222 lane moves in dyn_bwd2_kernel's 1883 instructions; 56 in 1742 now, 27.6 -> 25.9 us at 32 instances, 66.5 -> 61.8
+        // at 128.  A fence inside the second layer too makes it worse again: 101-137 lane moves.  profiles/NOTES.md R6-17)
+        BXI_SEGMENT();
         v2f acc = {wts[D::B0 + o], 0.f};
 #pragma unroll
         for (int i = 0; i < D::CIN / 2; ++i) acc = pk_fma(w2_at(wts, o * D::CIN + 2 * i), in2[i], acc);
