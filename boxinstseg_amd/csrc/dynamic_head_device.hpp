@@ -52,17 +52,23 @@ __device__ __forceinline__ float mlp_forward(const float* __restrict__ wts, cons
     using D = Dyn<C, REL>;
     static_assert(D::CIN % 2 == 0, "packed dot products need an even channel count");
     float t[kDC];
+    // First layer: a scheduler fence per PAIR of output channels, the two dot products interleaved.  (i) What may be in flight: with a fence per four
+    // channels the 4 x (CIN + 1) = 76 scalar registers of a segment -- next to the ~40 the instance loop keeps live -- exceeded the file and the compiler
+    // parked freshly LOADED weights in VGPR lanes: 222 lane moves in dyn_bwd2_kernel's 1883 instructions, 56 in 1666 now (27.6 -> 25.3-25.6 us at 32
+    // instances, 66.5 -> 61.2-61.9 at 128; a fence inside the second layer makes it worse again).  (ii) Consecutive v_pk_fma_f32 into ONE accumulator
+    // cost a wait state each (a two-pass instruction): two chains side by side need none; each channel's sum keeps its order -- the same bits.
+    // profiles/NOTES.md R6-17
 #pragma unroll
-    for (int o = 0; o < kDC; ++o) {
-        // (a fence in front of EVERY output channel: CIN + 1 weights in flight at a time.  With a fence per four channels the 4 x (CIN + 1) = 76 scalar
-        // registers of a segment -- next to the ~40 the instance loop keeps live -- exceeded the file: the compiler parked freshly LOADED weights in VGPR
-        // lanes and read them back, 222 lane moves in dyn_bwd2_kernel's 1883 instructions; 56 in 1742 now, 27.6 -> 25.9 us at 32 instances, 66.5 -> 61.8
-        // at 128.  A fence inside the second layer too makes it worse again: 101-137 lane moves.  profiles/NOTES.md R6-17)
+    for (int o = 0; o < kDC; o += 2) {
         BXI_SEGMENT();
-        v2f acc = {wts[D::B0 + o], 0.f};
+        v2f accA = {wts[D::B0 + o], 0.f}, accB = {wts[D::B0 + o + 1], 0.f};
 #pragma unroll
-        for (int i = 0; i < D::CIN / 2; ++i) acc = pk_fma(w2_at(wts, o * D::CIN + 2 * i), in2[i], acc);
-        t[o] = fmaxf(acc.x + acc.y, 0.f);
+        for (int i = 0; i < D::CIN / 2; ++i) {
+            accA = pk_fma(w2_at(wts, o * D::CIN + 2 * i), in2[i], accA);
+            accB = pk_fma(w2_at(wts, (o + 1) * D::CIN + 2 * i), in2[i], accB);
+        }
+        t[o] = fmaxf(accA.x + accA.y, 0.f);
+        t[o + 1] = fmaxf(accB.x + accB.y, 0.f);
     }
 #pragma unroll
     for (int o = 0; o < kDC / 2; ++o) h1[o] = v2f{t[2 * o], t[2 * o + 1]};
