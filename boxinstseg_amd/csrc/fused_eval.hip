@@ -95,7 +95,7 @@ constexpr unsigned kFaultCounts = 1u, kFaultFinisher = 2u;
 // word and a leader's dice word carry their own fault bit (one writer each); the arrival words of tile waves and predicate workgroups do not any
 // more -- a flag ADDED to an arrival carries into the arrival count from the second (predicate) / fourth (tile) fault on one word on, and the
 // finisher then waits kSpinLimit polls for a count that cannot come (4.5 s per evaluation with foreign targets, where every tile wave is "bad").
-constexpr unsigned long long kArrivalFault = 1ull << 50, kCountFault = 1ull << 39, kSumwFault = 1ull << 62, kDiceFault = 1ull << 33;
+constexpr unsigned long long kCountFault = 1ull << 39, kSumwFault = 1ull << 62, kDiceFault = 1ull << 33;      // (bits 50 / 51 of an arrival word: reserved, checked by the finisher, set by nobody since R6-3)
 
 #ifdef BXI_TRACE
 #ifdef BXI_TRACE_LIGHT      // only the first and the last stamp of a wave: two stores per wave instead of eight (the full trace lengthens the launch by half)
