@@ -14,6 +14,8 @@ hb.LIB_PATH = os.path.join(hb.LIB_DIR, os.environ.get('TRACE_LIB', 'libboxinst_h
 from boxinstseg_amd import functional as Fh, synthetic
 lib = _lib.load()
 lib.bxi_debug_set_trace2.argtypes = [C.c_void_p]
+if os.environ.get('BXI_ABLATE_BITS'):      # a -DBXI_TRACE -DBXI_ABLATE build: the trace of the launch with parts switched off (tools/ablate.py's bits)
+    assert lib.bxi_debug_set_ablate(int(os.environ['BXI_ABLATE_BITS'])) == 0
 dev = torch.device('cuda:0')
 ones = torch.ones(2, device=dev)
 flags = int(os.environ.get('BXI_FLAGS', '0'))
