@@ -1752,7 +1752,10 @@ __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& v
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int N = a.N;
     const int wid = tblk * kWaves + wave, nwaves = n_tb * kWaves;
-    __builtin_amdgcn_s_setprio(2);                                     // the launch ends on the tile waves, not on the leaders next to them
+    // (priority 0 like the stream, pool and leader waves.  Rounds 3-6 ran the tile waves at priority 2 -- "the launch ends on the tile waves, not on
+    // the leaders next to them" --, and with the targets ready that starved what they themselves wait for: the stream waves whose band flags gate their
+    // adds.  At 0: targets ready 14.1 -> 13.7 us at 32 instances, 18.2 -> 17.5 at 64, 21.5 -> 20.9 at 96, 26.0 -> 24.8 at 128; the un-split evaluation
+    // 21.5 -> 21.2 at 64, unchanged at 32 / 96 / 128.  Priority 1 loses all of it; the predicate waves' 3 is worth 0.1-0.2 us at 32 instances.  R6-22)
     BXI_TW(1, wid, 0);
     int4 e0, e1 = make_int4(0, 0, 0, 0), eN = make_int4(0, 0, 0, 0);
     bool ok;
