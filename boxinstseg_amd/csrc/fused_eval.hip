@@ -1643,6 +1643,10 @@ __device__ __forceinline__ void finisher_role(const InstArgs& a, const Ws& ws, c
                                               int spin_limit, int R, int n_tile_waves, float* __restrict__ losses) {
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int N = a.N;
+    // the launch ends on this workgroup's polls and its last few instructions: they go ahead of whatever else the CU holds (128 instances, two or
+    // three tile waves on every SIMD: 30.5 -> 29.85 us; 24.9 -> 24.65 with the targets ready; nothing at 32 / 64.  The reducer and the leaders at a
+    // higher priority: nothing.  profiles/NOTES.md R6-23)
+    __builtin_amdgcn_s_setprio(3);
     BXI_TW(3, 0, 0);
     __shared__ double fin_d[kWaves];
     __shared__ int fin_i[kWaves];
