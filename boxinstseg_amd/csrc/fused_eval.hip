@@ -205,8 +205,13 @@ __device__ __forceinline__ void load16_past_x5_epoch(const void* p0, const void*
 #define BXI_PW_OUT(i) [v##i] "=&v"(v[i])
 #define BXI_PW_IN(i) [o##i] "v"(off[i])
 template <int N>
-__device__ __forceinline__ void load_words_past(const unsigned int* base, const uint32_t (&off)[N], uint32_t (&v)[N]) {
+__device__ __forceinline__ void load_words_past(const unsigned int* base_in, const uint32_t (&off)[N], uint32_t (&v)[N]) {
     static_assert(N >= 5 && N <= 12, "R + D of the tile kernels");
+    // the base is wave-uniform by construction (a tile's image); said so explicitly: where the compiler cannot prove it (an ablation build did not)
+    // an "s" operand is handed a VGPR pair and the assembler rejects the statement.  Two v_readfirstlane at most, none when the value is scalar already.
+    const unsigned long long b64 = reinterpret_cast<unsigned long long>(base_in);
+    const unsigned int* base = reinterpret_cast<const unsigned int*>(
+        ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)b64));
     if constexpr (N == 5)
         asm volatile(BXI_PW_LD(0) BXI_PW_LD(1) BXI_PW_LD(2) BXI_PW_LD(3) BXI_PW_LD(4) "s_waitcnt vmcnt(0)"
                      : BXI_PW_OUT(0), BXI_PW_OUT(1), BXI_PW_OUT(2), BXI_PW_OUT(3), BXI_PW_OUT(4)
@@ -1798,6 +1803,7 @@ __device__ __forceinline__ void tile_role(const InstArgs& a, const ValidCells& v
     // Dealt workgroup by workgroup -- three per workgroup, nine per CU instead of twelve or eight -- the launch is SLOWER: 38.4 vs 37.2 us at 128
     // instances, 32.1 vs 31.1 at 96, targets ready 30.3 vs 28.7: the early workgroups' waves start their chains first.  profiles/NOTES.md R6-5)
     for (int ti = wid; ti < total && !bad; ti += nwaves) {
+        if (BXI_AB(256) && (ti & 7) == 7) continue;              // (ablation only: an eighth of the tiles gone -- what fewer tile waves would be worth)
         Tile t;
         if (!locate_tile<D, R, ONE>(ws, vc, N, e0, e1, ti, a.h, a.w, spin_limit, t)) { bad = true; break; }
         BXI_TW(1, wid, 1);

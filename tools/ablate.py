@@ -30,7 +30,7 @@ def ev(s):
                                   losses.data_ptr(), grad.data_ptr(), state.data_ptr(), ws.data_ptr(), ws.numel(), flags, st)
     assert rc == 0, rc
 NAMES = {1: 'no Lab arithmetic', 2: 'no pair loop', 4: 'no wait for sum W / band flags', 8: 'no wait for predicate words', 16: 'no zero-fill',
-         32: 'no image loads', 64: 'no logits stream loads', 128: 'finisher does not wait for arrivals'}
+         32: 'no image loads', 64: 'no logits stream loads', 128: 'finisher does not wait for arrivals', 256: 'an eighth of the tiles skipped'}
 def run(bits, n=3000):
     assert lib.bxi_debug_set_ablate(bits) == 0
     for i in range(200): ev(sets[i % 8])
