@@ -1598,11 +1598,14 @@ __device__ __forceinline__ bool locate_tile(const Ws& ws, const ValidCells& vc, 
 // ---- the roles of the second launch (two-launch form) / of the back half of the single launch ----------------------------------
 // predicate workgroup `pblk` of n_pb: 4 independent waves striding through the pooled row segments
 template <bool ONE>
-__device__ __forceinline__ void pred_role(const InstArgs& a, const ValidCells& vc, Ws ws /* .ep == 0: the first poll fetches the tag */, int D, float n2max, int pblk, int n_pb, int n_items, int spin_limit) {
+__device__ __forceinline__ void pred_role(const InstArgs& a, const ValidCells& vc, Ws ws /* .ep == 0: the first poll fetches the tag */, int D, float n2max, int pblk, int n_pb, int n_items, int spin_limit,
+                                          bool high_prio = true) {
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int segs = (a.w + 63) >> 6, pid = pblk * kWaves + wave;
     BXI_TW(2, pid, 0);
-    __builtin_amdgcn_s_setprio(3);                                 // short, and the tile waves will ask for these words
+    // short, and the tile waves will ask for these words -- except in the single launch WITHOUT the staying-on (37 .. 73 instances), where the predicate
+    // waves mostly wait for Lab records and their priority only takes issue slots from the pool waves they wait for (64 instances: 21.2 -> 21.05 us, R6-27)
+    if (high_prio) __builtin_amdgcn_s_setprio(3);
     int cnt = 0, segments = 0;
     bool ok = true;
     for (int item = pid; item < n_items && ok; item += n_pb * kWaves) { cnt += pred_item<ONE>(a.h, a.w, a.N, vc, ws, D, n2max, item, segs, spin_limit, ok); ++segments; }
@@ -1991,7 +1994,7 @@ __global__ __launch_bounds__(256, (R == 4 ? kOneOcc : BXI_LONG_OCC)) void eval1_
         leader_block<true>(a, D, ws, st, idx, upp, g_logits, smem, red, spin_limit);
         return;
     }
-    if (!READY && role == 3) { pred_role<true>(a, vc, ws, D, n2max, idx, n_pb, n_items, spin_limit); return; }
+    if (!READY && role == 3) { pred_role<true>(a, vc, ws, D, n2max, idx, n_pb, n_items, spin_limit, merge != 0); return; }
     if (role == 6) {
         if (!READY) reducer_role<true>(ws, 0, n_items, spin_limit);
         else if (threadIdx.x < 64) {
