@@ -996,9 +996,10 @@ __device__ __forceinline__ int pred_item(int h, int w, int n_ent, const ValidCel
     //   rows r:      s00 over lanes [c0 - base, c1 - base)  +  s0n over lanes [c0 - D - base, c1 - D - base)        (base = the segment's first column)
     //   rows r + D:  sD0 over the first range               +  sDn over the second
     // so ONE prefix sum over the lanes -- the four values packed into the bytes of a word: a segment's sums are <= 192, 128, 128, 64, no byte
-    // carries -- and four crossbar reads per lane serve 64 rectangles at once.  ~60 instructions per 64 rectangles where the loop below walks the
-    // rectangles that reach the row one after the other (~22 instructions each: a handful at 32 instances, 20-30 of an image's 64 at 128 instances,
-    // where the predicate workgroups hold the slots the tile workgroups are waiting for).  The same integers, added in another order.
+    // carries -- and four crossbar reads per lane serve 64 rectangles at once.  ~60 instructions per 64 rectangles where rounds 2-6 walked the
+    // rectangles that reach the row one after the other (ballot, readlane, four range tests: ~22 instructions each -- a handful at 32 instances, 20-30
+    // of an image's 64 at 128 instances, where the predicate workgroups hold the slots the tile workgroups are waiting for).  The same integers,
+    // added in another order.  profiles/NOTES.md R6-9
     const uint32_t incl = wave_scan_incl_u32((uint32_t)s00 | ((uint32_t)s0n << 8) | ((uint32_t)sD0 << 16) | ((uint32_t)sDn << 24));
     const int base = seg * 64;
     for (int m0 = 0; m0 < n_ent; m0 += 64) {
